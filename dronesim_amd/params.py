@@ -1,0 +1,386 @@
+"""Per-type vehicle constants (host side) and their C-ABI image.
+
+Replaces, for the hot path only, what the reference parses per drone instance:
+``BaseAviary._parseURDFParameters`` (dronesim/envs/BaseAviary.py:2041-2140, the
+``Drone`` dataclass :69-95) and ``INDIControl._parseURDFControlParameters``
+(dronesim/control/INDIControl.py:55-106).  The build keeps ONE constant record
+per vehicle *type*; the fleet indexes it through a ``type_id`` byte.
+
+The shipped vehicle types are built in (values cited to the reference URDFs) so
+the package works where the reference tree is absent (the GPU box);
+:func:`parse_urdf` reads any URDF written in the reference's dialect.
+
+Deviation from the reference, documented: the reference's
+``Gains.att/rate`` are class attributes (dronesim/utils/utils.py:21-24), so in a
+fleet mixing two quad types the last-constructed type's gains leak to all quads.
+Here gains are strictly per type.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import xml.etree.ElementTree as ET
+from dataclasses import dataclass, field
+from typing import Dict, List, Sequence
+
+import numpy as np
+
+MAX_ACT = 6
+KIND_QUAD = 0
+KIND_HEXA6DOF = 1
+
+# Bullet's btMultiBody defaults are float literals (0.04f) held in double
+# precision builds; keeping the exact fp32 value makes fp32 (GPU) and fp64
+# (oracle) use the same constant.
+BULLET_DAMPING = float(np.float32(0.04))
+BULLET_MAX_COORD_VEL = 100.0
+
+
+class TypeParamsC(ctypes.Structure):
+    """ctypes mirror of ``dsim_type_params`` (include/dronesim_amd.h)."""
+
+    _fields_ = [
+        ("kind", ctypes.c_int32),
+        ("n_act", ctypes.c_int32),
+        ("mass", ctypes.c_double),
+        ("inertia", ctypes.c_double * 3),
+        ("kf", ctypes.c_double),
+        ("km", ctypes.c_double),
+        ("pwm2rpm_scale", ctypes.c_double * MAX_ACT),
+        ("pwm2rpm_const", ctypes.c_double * MAX_ACT),
+        ("pwm_min", ctypes.c_double * MAX_ACT),
+        ("pwm_max", ctypes.c_double * MAX_ACT),
+        ("rotor_pos", (ctypes.c_double * 3) * MAX_ACT),
+        ("rotor_axis", (ctypes.c_double * 3) * MAX_ACT),
+        ("rotor_spin", ctypes.c_double * MAX_ACT),
+        ("G1", (ctypes.c_double * MAX_ACT) * MAX_ACT),
+        ("alloc", (ctypes.c_double * MAX_ACT) * MAX_ACT),
+        ("kp_pos", ctypes.c_double),
+        ("kd_pos", ctypes.c_double),
+        ("att_gain", ctypes.c_double * 3),
+        ("rate_gain", ctypes.c_double * 3),
+        ("gravity", ctypes.c_double),
+        ("lin_damping", ctypes.c_double),
+        ("ang_damping", ctypes.c_double),
+        ("max_coord_vel", ctypes.c_double),
+        ("drag_coeff", ctypes.c_double * 3),
+        ("gnd_eff_coeff", ctypes.c_double),
+        ("prop_radius", ctypes.c_double),
+        ("gnd_eff_h_clip", ctypes.c_double),
+        ("dw_coeff", ctypes.c_double * 3),
+    ]
+
+
+@dataclass
+class DroneType:
+    """Constants of one vehicle type (the reference's ``Drone`` dataclass plus the
+    controller constants of ``INDIControl``), fp64."""
+
+    name: str
+    kind: int
+    n_act: int
+    mass: float                      # rigid-body mass used by the integrator
+    inertia: Sequence[float]         # principal moments
+    kf: float
+    km: float
+    pwm2rpm_scale: Sequence[float]
+    pwm2rpm_const: Sequence[float]
+    pwm_min: Sequence[float]
+    pwm_max: Sequence[float]
+    rotor_pos: Sequence[Sequence[float]]
+    rotor_axis: Sequence[Sequence[float]]
+    rotor_spin: Sequence[float]
+    G1: np.ndarray                   # [n_out][n_act]
+    kp_pos: float
+    kd_pos: float
+    att_gain: Sequence[float]
+    rate_gain: Sequence[float]
+    ctrl_mass: float = 0.0           # INDIControl.m = first link's mass (INDIControl.py:66-67)
+    gravity: float = 9.8             # BaseAviary.py:182
+    lin_damping: float = BULLET_DAMPING
+    ang_damping: float = BULLET_DAMPING
+    max_coord_vel: float = BULLET_MAX_COORD_VEL
+    drag_coeff: Sequence[float] = (0.0, 0.0, 0.0)
+    gnd_eff_coeff: float = 0.0
+    prop_radius: float = 0.0
+    gnd_eff_h_clip: float = 0.0
+    dw_coeff: Sequence[float] = (0.0, 0.0, 0.0)
+    reset_thrust: float = 0.0        # INDIControl.reset (INDIControl.py:127); 6DOF 0.3 (:232)
+    reset_cmd: float = 0.0           # INDIControl.py:129; 6DOF 0.5 (:234)
+    alloc: np.ndarray = field(default=None)  # type: ignore[assignment]
+
+    def __post_init__(self):
+        self.G1 = np.asarray(self.G1, dtype=np.float64)
+        if self.alloc is None:
+            self.alloc = self.default_alloc()
+        if self.gnd_eff_h_clip == 0.0 and self.gnd_eff_coeff > 0.0:
+            # BaseAviary.py:235 (commented out in the fork): height below which the
+            # ground-effect boost would exceed the maximum thrust
+            max_rpm = max(s * hi + c for s, hi, c in
+                          zip(self.pwm2rpm_scale, self.pwm_max, self.pwm2rpm_const))
+            max_thrust = self.n_act * self.kf * max_rpm ** 2
+            self.gnd_eff_h_clip = 0.25 * self.prop_radius * math.sqrt(
+                (15 * max_rpm ** 2 * self.kf * self.gnd_eff_coeff) / max_thrust)
+
+    # ---- controller allocation matrix ------------------------------------
+    def default_alloc(self) -> np.ndarray:
+        """quad: ``pinv(G1/0.05)`` exactly as INDIControl.py:459 computes it every
+        call (a per-type constant).  hexa: the first-iteration matrix of
+        ``wls_alloc`` (free set = all actuators): ``p = lstsq(A, d)`` with
+        ``A = [gamma*Wv*B; Wu]`` (wls_alloc.py:190-252) restricted to the ``v``
+        rows, see DESIGN.md."""
+        B = self.G1 / 0.05
+        if self.kind == KIND_QUAD:
+            return np.linalg.pinv(B)
+        Wv = np.array([1000, 1000, 0.1, 10, 10, 100.0])   # INDIControl_6DOF.py:614
+        gam = 100000.0                                     # wls_alloc.py:125 (gamma_sq)
+        A = np.vstack([gam * Wv[:, None] * B, np.eye(self.n_act)])
+        return np.linalg.pinv(A)                           # [n_act][n_v + n_u]; host keeps all 12 cols
+
+    def to_c(self) -> TypeParamsC:
+        c = TypeParamsC()
+        c.kind, c.n_act = self.kind, self.n_act
+        c.mass, c.kf, c.km = self.mass, self.kf, self.km
+        for k in range(3):
+            c.inertia[k] = self.inertia[k]
+            c.att_gain[k] = self.att_gain[k]
+            c.rate_gain[k] = self.rate_gain[k]
+            c.drag_coeff[k] = self.drag_coeff[k]
+            c.dw_coeff[k] = self.dw_coeff[k]
+        for j in range(self.n_act):
+            c.pwm2rpm_scale[j] = self.pwm2rpm_scale[j]
+            c.pwm2rpm_const[j] = self.pwm2rpm_const[j]
+            c.pwm_min[j], c.pwm_max[j] = self.pwm_min[j], self.pwm_max[j]
+            c.rotor_spin[j] = self.rotor_spin[j]
+            for k in range(3):
+                c.rotor_pos[j][k] = self.rotor_pos[j][k]
+                c.rotor_axis[j][k] = self.rotor_axis[j][k]
+        n_out = self.G1.shape[0]
+        for i in range(n_out):
+            for j in range(self.n_act):
+                c.G1[i][j] = self.G1[i, j]
+        a = np.asarray(self.alloc)
+        for j in range(self.n_act):
+            for i in range(min(a.shape[1], MAX_ACT)):
+                c.alloc[j][i] = a[j, i]
+        c.kp_pos, c.kd_pos = self.kp_pos, self.kd_pos
+        c.gravity = self.gravity
+        c.lin_damping, c.ang_damping = self.lin_damping, self.ang_damping
+        c.max_coord_vel = self.max_coord_vel
+        c.gnd_eff_coeff, c.prop_radius = self.gnd_eff_coeff, self.prop_radius
+        c.gnd_eff_h_clip = self.gnd_eff_h_clip
+        return c
+
+    @property
+    def hover_pwm(self) -> float:
+        """PWM at which total thrust equals weight (noise-free)."""
+        rpm = math.sqrt(self.mass * self.gravity / (self.n_act * self.kf))
+        return (rpm - self.pwm2rpm_const[0]) / self.pwm2rpm_scale[0]
+
+
+def types_to_c_array(types: Sequence[DroneType]):
+    arr = (TypeParamsC * len(types))()
+    for i, t in enumerate(types):
+        arr[i] = t.to_c()
+    return arr
+
+
+# ---------------------------------------------------------------------------
+# built-in types (values cited to the reference's URDF assets)
+# ---------------------------------------------------------------------------
+_QUAD_SPIN = (-1.0, 1.0, -1.0, 1.0)          # BaseAviary.py:1527: -t0 + t1 - t2 + t3
+_Z = (0.0, 0.0, 1.0)
+_AERO = dict(                                 # robobee.urdf:31 / tello.urdf:27 (identical)
+    drag_coeff=(9.1785e-7, 9.1785e-7, 10.311e-7),
+    gnd_eff_coeff=11.36859,
+    dw_coeff=(2267.18, 0.16, -0.11),
+)
+
+
+def _robobee() -> DroneType:
+    # dronesim/assets/robobee.urdf: properties :31, control :33-53, base inertial :58-62,
+    # prop link inertial origins :83,102,121,140
+    return DroneType(
+        name="robobee", kind=KIND_QUAD, n_act=4, mass=0.75, ctrl_mass=0.75,
+        inertia=(6.2e-4, 6.2e-4, 1.1e-3), kf=2.0e-8, km=2.74e-10,
+        pwm2rpm_scale=(20000.0,) * 4, pwm2rpm_const=(0.0,) * 4,
+        pwm_min=(0.0,) * 4, pwm_max=(1.0,) * 4,
+        rotor_pos=((0.11, 0.11, 0.0), (-0.11, 0.11, 0.0), (-0.11, -0.11, 0.03), (0.11, -0.11, 0.04)),
+        rotor_axis=(_Z,) * 4, rotor_spin=_QUAD_SPIN,
+        G1=np.array([[50.0, 50.0, -50.0, -50.0], [-50.0, 50.0, 50.0, -50.0],
+                     [-7.0, 7.0, -7.0, 7.0], [1.7, 1.7, 1.7, 1.7]]),
+        kp_pos=1.0, kd_pos=2.2, att_gain=(7.0, 7.0, 5.0), rate_gain=(18.0, 18.0, 10.0),
+        prop_radius=3.31348e-2, **_AERO,
+    )
+
+
+def _tello() -> DroneType:
+    # dronesim/assets/tello.urdf: properties :27, control :29-49, base inertial :54-58,
+    # prop link inertial origins :79,98,117,136
+    a = 0.0475
+    return DroneType(
+        name="tello", kind=KIND_QUAD, n_act=4, mass=0.08, ctrl_mass=0.08,
+        inertia=(4.28e-5, 4.28e-5, 8.36e-5), kf=2.0e-9, km=4.74e-12,
+        pwm2rpm_scale=(20000.0,) * 4, pwm2rpm_const=(0.0,) * 4,
+        pwm_min=(0.0,) * 4, pwm_max=(1.0,) * 4,
+        rotor_pos=((a, a, 0.0), (-a, a, 0.0), (-a, -a, 0.0), (a, -a, 0.0)),
+        rotor_axis=(_Z,) * 4, rotor_spin=_QUAD_SPIN,
+        G1=np.array([[30.0, 30.0, -30.0, -30.0], [-30.0, 30.0, 30.0, -30.0],
+                     [-5.0, 5.0, -5.0, 5.0], [1.7, 1.7, 1.7, 1.7]]),
+        kp_pos=1.7, kd_pos=2.5, att_gain=(10.0, 10.0, 4.0), rate_gain=(12.0, 12.0, 7.0),
+        prop_radius=3.31348e-2, **_AERO,
+    )
+
+
+_BUILTIN_FACTORIES = {"robobee": _robobee, "tello": _tello}
+
+
+def builtin_type(name: str) -> DroneType:
+    """Constants of a shipped vehicle type by the name the reference uses for its
+    URDF (``drone_model=["robobee"]``, examples/fly_INDI.py:33-38)."""
+    try:
+        return _BUILTIN_FACTORIES[name]()
+    except KeyError:
+        raise KeyError(
+            f"unknown drone model {name!r}; built in: {sorted(_BUILTIN_FACTORIES)} "
+            f"(use parse_urdf() for a custom URDF)") from None
+
+
+def register_builtin(name: str, factory) -> None:
+    _BUILTIN_FACTORIES[name] = factory
+
+
+# ---------------------------------------------------------------------------
+# URDF reader (the reference's dialect)
+# ---------------------------------------------------------------------------
+def _floats(s: str) -> List[float]:
+    return [float(t) for t in s.split(" ") if t != ""]
+
+
+def _rpy_matrix(rpy: Sequence[float]) -> np.ndarray:
+    r, p, y = rpy
+    cr, sr, cp, sp, cy, sy = math.cos(r), math.sin(r), math.cos(p), math.sin(p), math.cos(y), math.sin(y)
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def _origin(elem) -> tuple:
+    if elem is None:
+        return np.zeros(3), np.eye(3)
+    xyz = np.array(_floats(elem.attrib.get("xyz", "0 0 0")))
+    rpy = _floats(elem.attrib.get("rpy", "0 0 0"))
+    return xyz, _rpy_matrix(rpy)
+
+
+def parse_urdf(path: str) -> DroneType:
+    """Read a vehicle URDF in the reference's dialect.
+
+    Reads the same attributes as BaseAviary._parseURDFParameters
+    (BaseAviary.py:2041-2140) and INDIControl._parseURDFControlParameters
+    (INDIControl.py:55-106), and additionally walks the link/joint tree (which the
+    reference leaves to PyBullet's loader, BaseAviary.py:681-694) to obtain the
+    points and directions at which the rotor forces act: PyBullet numbers links
+    depth-first in joint order, forces are applied in LINK_FRAME at the link's
+    inertial origin (BaseAviary.py:1528-1536, 1442-1457).
+    """
+    root = ET.parse(path).getroot()
+    name = os.path.splitext(os.path.basename(path))[0]
+    conf = root.find("configuration").attrib["type"]
+    prop = root.find("properties").attrib
+    links = {l.attrib["name"]: l for l in root.findall("link")}
+    joints = root.findall("joint")
+    children: Dict[str, list] = {}
+    child_names = set()
+    for j in joints:
+        children.setdefault(j.find("parent").attrib["link"], []).append(j)
+        child_names.add(j.find("child").attrib["link"])
+    base = next(n for n in links if n not in child_names)
+
+    # depth-first link numbering + transform of each link frame in the base frame
+    order: List[str] = []
+    frames = {base: (np.zeros(3), np.eye(3))}
+
+    def walk(parent):
+        for j in children.get(parent, []):
+            c = j.find("child").attrib["link"]
+            jx, jR = _origin(j.find("origin"))
+            px, pR = frames[parent]
+            frames[c] = (px + pR @ jx, pR @ jR)
+            order.append(c)
+            walk(c)
+
+    walk(base)
+
+    def inertial(lname):
+        ine = links[lname].find("inertial")
+        if ine is None:
+            return 0.0, np.zeros(3), np.eye(3), np.zeros(3)
+        m = float(ine.find("mass").attrib["value"])
+        ox, oR = _origin(ine.find("origin"))
+        I = ine.find("inertia").attrib
+        diag = np.array([float(I["ixx"]), float(I["iyy"]), float(I["izz"])])
+        lx, lR = frames[lname]
+        return m, lx + lR @ ox, lR @ oR, diag
+
+    ctrl = root.find("control")
+    indi = ctrl.find("indi").attrib
+    n_act, n_out = int(indi["actuator_nr"]), int(indi["output_nr"])
+    G1 = np.zeros((n_out, n_act))
+    for i in range(n_out):  # children 1..n_out of <control> (BaseAviary.py:2097-2099)
+        G1[i] = _floats(list(ctrl[i + 1].attrib.values())[0])
+    gg = ctrl.find("indi_guidance_gains/pos").attrib
+    att = ctrl.find("indi_att_gains/att").attrib
+    rate = ctrl.find("indi_att_gains/rate").attrib
+    p2r = list(ctrl.find("pwm/pwm2rpm").attrib.values())
+    lim = list(ctrl.find("pwm/limit").attrib.values())
+
+    is_hexa = "morphing_hexa" in conf
+    if not is_hexa and "quad" not in conf:
+        raise ValueError(f"vehicle configuration {conf!r} is outside the hot path (quad / morphing_hexa only)")
+    rotor_links = [order[i] for i in (range(1, 2 * n_act, 2) if is_hexa else range(n_act))]
+    rotor_pos, rotor_axis = [], []
+    for ln in rotor_links:
+        _, com, R, _ = inertial(ln)
+        rotor_pos.append(tuple(com))
+        rotor_axis.append(tuple(R @ np.array([0.0, 0.0, 1.0])))
+
+    m0, com0, _, diag0 = inertial(base)
+    if is_hexa:
+        # rigid composite of all links (arm joints treated as locked): total mass, COM, inertia
+        ms, coms, Is = [], [], []
+        for ln in [base] + order:
+            m, com, R, d = inertial(ln)
+            if m > 0:
+                ms.append(m); coms.append(com); Is.append(R @ np.diag(d) @ R.T)
+        M = float(sum(ms))
+        C = sum(m * c for m, c in zip(ms, coms)) / M
+        J = np.zeros((3, 3))
+        for m, c, I in zip(ms, coms, Is):
+            r = c - C
+            J += I + m * (r @ r * np.eye(3) - np.outer(r, r))
+        mass, inertia = M, tuple(np.diag(J))
+        rotor_pos = [tuple(np.array(p) - C) for p in rotor_pos]
+        spin = tuple(-1.0 if j % 2 == 0 else 1.0 for j in range(n_act))  # BaseAviary.py:1439-1440
+        kind, rt, rc = KIND_HEXA6DOF, 0.3, 0.5
+    else:
+        mass, inertia = m0, tuple(diag0)
+        spin = _QUAD_SPIN
+        kind, rt, rc = KIND_QUAD, 0.0, 0.0
+
+    return DroneType(
+        name=name, kind=kind, n_act=n_act, mass=mass, ctrl_mass=m0, inertia=inertia,
+        kf=float(prop["kf"]), km=float(prop["km"]),
+        pwm2rpm_scale=_floats(p2r[0]), pwm2rpm_const=_floats(p2r[1]),
+        pwm_min=_floats(lim[0]), pwm_max=_floats(lim[1]),
+        rotor_pos=rotor_pos, rotor_axis=rotor_axis, rotor_spin=spin, G1=G1,
+        kp_pos=float(gg["kp"]), kd_pos=float(gg["kd"]),
+        att_gain=(float(att["p"]), float(att["q"]), float(att["r"])),
+        rate_gain=(float(rate["p"]), float(rate["q"]), float(rate["r"])),
+        drag_coeff=(float(prop["drag_coeff_xy"]), float(prop["drag_coeff_xy"]), float(prop["drag_coeff_z"])),
+        gnd_eff_coeff=float(prop["gnd_eff_coeff"]), prop_radius=float(prop["prop_radius"]),
+        dw_coeff=(float(prop["dw_coeff_1"]), float(prop["dw_coeff_2"]), float(prop["dw_coeff_3"])),
+        reset_thrust=rt, reset_cmd=rc,
+    )

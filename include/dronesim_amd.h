@@ -1,0 +1,187 @@
+/* dronesim_amd.h — C-ABI of the MI355X-native fleet dynamics + INDI control step.
+ *
+ * The reference (enac-drones/dronesim, pure Python) has no FFI: its boundary on
+ * this path is two Python call surfaces,
+ *     gym.Env      reset()/step(action)      dronesim/envs/BaseAviary.py:406-555
+ *     BaseControl  computeControl(...)       dronesim/control/BaseControl.py:107-149
+ *                                            dronesim/control/INDIControl.py:154-227
+ * so the entry points below are what a ctypes binding on the reference side
+ * would bind to replace the per-drone Python loops behind those two surfaces
+ * (INTEGRATION.md shows that binding).  Each entry point cites the reference
+ * code it replaces.
+ *
+ * Conventions (same as the reference): quaternions xyzw (w at index 3,
+ * dronesim/utils/math.py:6,25,47); world frame z-up; angular velocity stored in
+ * WORLD frame (BaseAviary.py:730); PWM commands in [pwm_min, pwm_max].
+ *
+ * Memory: every state / target / action buffer is CALLER-OWNED DEVICE memory
+ * (e.g. a torch-ROCm tensor's data_ptr()).  The library allocates nothing per
+ * call, never frees caller memory and never synchronises the device; work is
+ * stream-ordered on the caller's hipStream_t (passed as void*).  A dsim_ctx owns
+ * only the per-type constant table (device copy).  One ctx per device; a ctx may
+ * be used from one host thread at a time.
+ *
+ * Errors: int return, 0 = OK, negative = library error (DSIM_E_*), positive =
+ * hipError_t.  No exceptions or aborts cross the ABI.  There is NO CPU fallback:
+ * without a HIP device dsim_create fails.
+ */
+#ifndef DRONESIM_AMD_H
+#define DRONESIM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSIM_ABI_VERSION 1
+#define DSIM_MAX_ACT 6     /* actuators per vehicle (quad 4, morphing hexa 6) */
+#define DSIM_MAX_TYPES 8
+
+/* ---- state layout ---------------------------------------------------------
+ * Fleet state is ONE fp32 device array in "blocked SoA":
+ *     addr(field f, drone i) = base + (i / block) * block_stride
+ *                                   + f * field_stride + (i % block)
+ * Plain SoA [F][n_pad] is block = n_pad, field_stride = n_pad; the wave-tiled
+ * form [n_pad/64][F][64] is block = 64, field_stride = 64, block_stride = F*64.
+ * n_pad must be a multiple of 64 (padding lanes are computed and ignored).
+ *
+ * Field order (DSIM_F_*): the 13 rigid-body floats the reference reads back
+ * from Bullet (BaseAviary.py:718-732) followed by the controller memory the
+ * reference keeps on each INDIControl instance (INDIControl.py:109-146).      */
+enum {
+  DSIM_F_POS = 0,        /* 3  world position                                   */
+  DSIM_F_QUAT = 3,       /* 4  xyzw                                            */
+  DSIM_F_VEL = 7,        /* 3  world linear velocity                           */
+  DSIM_F_ANGVEL = 10,    /* 3  world angular velocity                          */
+  DSIM_F_LAST_VEL = 13,  /* 3  INDIControl.last_vel   (INDIControl.py:130,291) */
+  DSIM_F_LAST_RATES = 16,/* 3  INDIControl.last_rates (INDIControl.py:125,442) */
+  DSIM_F_LAST_THRUST = 19,/*1  INDIControl.last_thrust(INDIControl.py:127,455) */
+  DSIM_F_CMD = 20,       /* n_act  INDIControl.cmd == the action fed to step() */
+  DSIM_NF_QUAD = 24,     /* fields for a 4-actuator fleet                      */
+  DSIM_NF_HEXA = 26      /* fields for a 6-actuator (or mixed) fleet           */
+};
+
+/* Per-step targets, same blocked-SoA addressing, 10 fields:
+ * target_pos3, target_vel3, target_acc3, target_yaw (only target_rpy[2] is read
+ * by the reference, INDIControl.py:341; target_rpy_rates is ignored, :404-410) */
+enum { DSIM_T_POS = 0, DSIM_T_VEL = 3, DSIM_T_ACC = 6, DSIM_T_YAW = 9, DSIM_NT = 10 };
+
+typedef struct dsim_view {
+  float*  base;          /* device pointer                                      */
+  int64_t n_pad;         /* padded drone count, multiple of 64                  */
+  int64_t block;         /* drones per block (n_pad for plain SoA, or 64)       */
+  int64_t field_stride;  /* floats between consecutive fields inside a block    */
+  int64_t block_stride;  /* floats between consecutive blocks                   */
+  int32_t n_fields;      /* DSIM_NF_QUAD / DSIM_NF_HEXA / DSIM_NT               */
+  int32_t _pad;
+} dsim_view;
+
+/* ---- per-type constants (host side, fp64; converted to fp32 on upload) -----
+ * Filled by the host from the vehicle URDF exactly as the reference does
+ * (BaseAviary._parseURDFParameters, BaseAviary.py:2041-2140;
+ *  INDIControl._parseURDFControlParameters, INDIControl.py:55-106).            */
+enum { DSIM_KIND_QUAD = 0, DSIM_KIND_HEXA6DOF = 1 };
+
+typedef struct dsim_type_params {
+  int32_t kind;                       /* DSIM_KIND_*                                        */
+  int32_t n_act;                      /* 4 | 6   (indi actuator_nr)                         */
+  double  mass;                       /* total rigid-body mass used by the integrator       */
+  double  inertia[3];                 /* principal moments (URDF ixx,iyy,izz)               */
+  double  kf, km;                     /* thrust / drag-torque coefficients                  */
+  double  pwm2rpm_scale[DSIM_MAX_ACT];
+  double  pwm2rpm_const[DSIM_MAX_ACT];
+  double  pwm_min[DSIM_MAX_ACT], pwm_max[DSIM_MAX_ACT];
+  double  rotor_pos[DSIM_MAX_ACT][3]; /* point of force application, body frame (link inertial origin) */
+  double  rotor_axis[DSIM_MAX_ACT][3];/* thrust direction, body frame ((0,0,1) for quads)   */
+  double  rotor_spin[DSIM_MAX_ACT];   /* sign of km*rpm^2 in the yaw torque (BaseAviary.py:1527: -,+,-,+) */
+  double  G1[DSIM_MAX_ACT][DSIM_MAX_ACT];    /* control effectiveness, [n_out][n_act]       */
+  double  alloc[DSIM_MAX_ACT][DSIM_MAX_ACT]; /* quad: pinv(G1/0.05) [n_act][n_out] (INDIControl.py:459);
+                                                hexa: WLS first-iteration matrix      */
+  double  kp_pos, kd_pos;             /* indi_guidance_gains                                */
+  double  att_gain[3], rate_gain[3];  /* indi_att_gains att / rate                          */
+  double  gravity;                    /* 9.8 (BaseAviary.py:182,673)                        */
+  double  lin_damping, ang_damping;   /* Bullet multibody defaults 0.04f                    */
+  double  max_coord_vel;              /* Bullet multibody default 100                       */
+  double  drag_coeff[3];              /* BaseAviary._drag coefficients (formula P6)         */
+  double  gnd_eff_coeff, prop_radius, gnd_eff_h_clip;   /* formula P7                       */
+  double  dw_coeff[3];                /* formula P8                                         */
+} dsim_type_params;
+
+/* ---- step options ---------------------------------------------------------- */
+enum {
+  DSIM_OPT_DRAG        = 1u << 0,   /* add formula P6 (BaseAviary.py:1705-1732)            */
+  DSIM_OPT_GROUND      = 1u << 1,   /* add formula P7 (BaseAviary.py:1648-1699)            */
+  DSIM_OPT_BCAST_TGT   = 1u << 2    /* targets view holds ONE drone's targets, broadcast   */
+};
+
+typedef struct dsim_step_args {
+  int32_t  phys_substeps;   /* AGGR_PHY_STEPS: Bullet sub-steps per Env.step (BaseAviary.py:510) */
+  float    dt_phys;         /* 1/SIM_FREQ  (BaseAviary.py:675)                                   */
+  float    dt_ctrl;         /* control_timestep handed to computeControl (fly_INDI.py:231)       */
+  uint32_t options;         /* DSIM_OPT_*                                                        */
+  uint64_t noise_seed;      /* 0 = rotor noise off; else counter-based N(0,.01)/N(0,.001) noise  */
+  uint64_t step_index;      /* env-step counter, mixed into the noise counter                    */
+  const float* noise_replay;/* nullable; [phys_substeps][2*n_act][n_pad] recorded normals (tests)*/
+  const uint8_t* type_id;   /* nullable; per-drone index into the ctx type table (mixed fleets)  */
+} dsim_step_args;
+
+typedef struct dsim_ctx dsim_ctx;
+
+/* library / build info */
+int         dsim_abi_version(void);
+const char* dsim_strerror(int code);
+
+/* ctx: uploads the type table to `device`.  Replaces the per-instance parsing in
+ * BaseAviary.__init__ (BaseAviary.py:200-235) + INDIControl.__init__ (:34-52).   */
+int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n_types);
+int dsim_destroy(dsim_ctx* ctx);
+
+/* reset(): BaseAviary._housekeeping (BaseAviary.py:640-714) + INDIControl.reset
+ * (INDIControl.py:109-146).  init_* are device SoA [3][n_pad]; init_vel and
+ * init_cmd nullable (zeros / controller reset value).  Writes every field.       */
+int dsim_reset(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state,
+               const float* init_pos, const float* init_rpy, const float* init_vel,
+               const float* init_cmd, const uint8_t* type_id);
+
+/* One fused Env.step() + computeControl() for every drone:
+ *   physics x phys_substeps with the stored cmd  (BaseAviary.py:510-545, 1477-1543 | 1389-1457,
+ *                                                  p.stepSimulation :542)
+ *   then the INDI law on the fresh state          (INDIControl.py:154-227)
+ * i.e. the body of the example loop (examples/fly_INDI.py:223-239).             */
+int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
+              const dsim_step_args* args);
+
+/* Env.step() only: physics sub-steps with an externally supplied action
+ * (SoA [n_act][n_pad], clipped in-kernel as CtrlAviary._preprocessAction does,
+ * CtrlAviary.py:258-263).  action == NULL uses the stored cmd.  The clipped
+ * action is echoed into the cmd fields (last_clipped_action, BaseAviary.py:545). */
+int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state,
+                 const float* action, const dsim_step_args* args);
+
+/* computeControl() only (INDIControl.py:154-227 / INDIControl_6DOF.py:259-336):
+ * reads the rigid fields, updates the controller-memory fields and cmd.
+ * pos_e_out [3][n_pad] and yaw_e_out [n_pad] nullable.                           */
+int dsim_control(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
+                 const dsim_step_args* args, float* pos_e_out, float* yaw_e_out);
+
+/* _getDroneStateVector (BaseAviary.py:764-790): writes the reference's 20/22-wide
+ * observation rows [pos3 quat4 rpy3 vel3 ang_v3 last_action] as row-major
+ * [n][16+n_act] fp32.                                                            */
+int dsim_observe(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float* obs_out,
+                 int32_t obs_width);
+
+/* error codes */
+enum {
+  DSIM_OK = 0,
+  DSIM_E_ARG = -1,        /* null / inconsistent argument                       */
+  DSIM_E_LAYOUT = -2,     /* view violates the layout contract                  */
+  DSIM_E_NODEVICE = -3,   /* no HIP device / wrong arch                         */
+  DSIM_E_TYPES = -4,      /* bad type table                                     */
+  DSIM_E_UNSUPPORTED = -5
+};
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRONESIM_AMD_H */

@@ -1,0 +1,203 @@
+"""ctypes front-end of the CPU oracle (oracle/dsim_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional, Sequence
+
+import numpy as np
+
+from dronesim_amd.params import DroneType, TypeParamsC, types_to_c_array
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+_D = ctypes.POINTER(ctypes.c_double)
+_U8 = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "dsim_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "dronesim_amd.h")
+    stale = (not os.path.exists(_LIB_PATH)
+             or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        assert _lib.orc_sizeof_params() == ctypes.sizeof(TypeParamsC), "dsim_type_params ABI mismatch"
+    return _lib
+
+
+def _p(a: Optional[np.ndarray], t=_D):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def _c(a, dtype=np.float64):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+# ---- scalar helpers -----------------------------------------------------------
+def quat_inv_comp(q1, q2):
+    out = np.zeros(4)
+    lib().orc_quat_inv_comp(_p(_c(q1)), _p(_c(q2)), _p(out))
+    return out
+
+
+def quat_comp(q1, q2):
+    out = np.zeros(4)
+    lib().orc_quat_comp(_p(_c(q1)), _p(_c(q2)), _p(out))
+    return out
+
+
+def quat_wrap_shortest(q):
+    out = _c(q).copy()
+    lib().orc_quat_wrap_shortest(_p(out))
+    return out
+
+
+def norm_ang(x: float) -> float:
+    f = lib().orc_norm_ang
+    f.restype = ctypes.c_double
+    f.argtypes = [ctypes.c_double]
+    return f(float(x))
+
+
+def euler_from_quat(q):
+    out = np.zeros(3)
+    lib().orc_euler_from_quat(_p(_c(q)), _p(out))
+    return out
+
+
+def quat_from_euler(rpy):
+    out = np.zeros(4)
+    lib().orc_quat_from_euler(_p(_c(rpy)), _p(out))
+    return out
+
+
+def matrix_from_quat(q):
+    out = np.zeros(9)
+    lib().orc_matrix_from_quat(_p(_c(q)), _p(out))
+    return out.reshape(3, 3)
+
+
+def pinv(A, rcond=1e-15):
+    A = _c(A)
+    m, n = A.shape
+    out = np.zeros((n, m))
+    f = lib().orc_pinv
+    f.argtypes = [_D, ctypes.c_int, ctypes.c_int, ctypes.c_double, _D]
+    f(_p(A), m, n, rcond, _p(out))
+    return out
+
+
+def wls_alloc(v, umin, umax, B, Wv=None, Wu=None, up=None, gamma_sq=100000.0, imax=100):
+    v, umin, umax, B = _c(v), _c(umin), _c(umax), _c(B)
+    n_v, n_u = B.shape
+    u = np.zeros(n_u)
+    it = ctypes.c_int(0)
+    f = lib().orc_wls_alloc
+    f.argtypes = [_D, _D, _D, _D, ctypes.c_int, ctypes.c_int, _D, _D, _D, _D, _D, ctypes.c_double,
+                  ctypes.c_int, _D, ctypes.POINTER(ctypes.c_int)]
+    f.restype = ctypes.c_int
+    Wv_ = None if Wv is None else _c(Wv)
+    Wu_ = None if Wu is None else _c(Wu)
+    up_ = None if up is None else _c(up)
+    rc = f(_p(v), _p(umin), _p(umax), _p(B), n_u, n_v, None, None, _p(Wv_), _p(Wu_), _p(up_),
+           gamma_sq, imax, _p(u), ctypes.byref(it))
+    return (u if rc == 0 else None), it.value, rc
+
+
+class CtrlMem(ctypes.Structure):
+    _fields_ = [("last_vel", ctypes.c_double * 3), ("last_rates", ctypes.c_double * 3),
+                ("last_thrust", ctypes.c_double), ("cmd", ctypes.c_double * 6)]
+
+
+def indi_position(t: DroneType, dt, pos, quat, vel, tpos, trpy, tvel, tacc, mem13):
+    """C2 alone: returns (thrust, target_euler, pos_e); mem13 updated in place."""
+    P = t.to_c()
+    m = CtrlMem.from_buffer(mem13)
+    thrust = ctypes.c_double()
+    te, pe = np.zeros(3), np.zeros(3)
+    f = lib().orc_indi_position
+    f.argtypes = [ctypes.POINTER(TypeParamsC), ctypes.c_double] + [_D] * 7 + [
+        ctypes.POINTER(CtrlMem), ctypes.POINTER(ctypes.c_double), _D, _D]
+    f(ctypes.byref(P), dt, _p(_c(pos)), _p(_c(quat)), _p(_c(vel)), _p(_c(tpos)), _p(_c(trpy)),
+      _p(_c(tvel)), _p(_c(tacc)), ctypes.byref(m), ctypes.byref(thrust), _p(te), _p(pe))
+    return thrust.value, te, pe
+
+
+# ---- batch drivers --------------------------------------------------------------
+class Oracle:
+    """Batch fp64 oracle over a type table.  Arrays are AoS:
+    rigid [n,13] = pos3 quat4 vel3 angvel3; mem [n,13] = last_vel3 last_rates3
+    last_thrust cmd6; tgt [n,10] (or [1,10] broadcast) = pos3 vel3 acc3 yaw."""
+
+    def __init__(self, types: Sequence[DroneType]):
+        self.types = list(types)
+        self._c_types = types_to_c_array(self.types)
+        self._L = lib()
+        TP = ctypes.POINTER(TypeParamsC)
+        self._L.orc_control_batch.argtypes = [TP, _U8, ctypes.c_int64, ctypes.c_double, _D, _D, _D,
+                                              ctypes.c_int, _D, _D, ctypes.c_int]
+        self._L.orc_physics_batch.argtypes = [TP, _U8, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                              _D, _D, _D, _D, ctypes.c_uint32, ctypes.c_int]
+        self._L.orc_step_batch.argtypes = [TP, _U8, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                           ctypes.c_double, _D, _D, _D, ctypes.c_int, _D,
+                                           ctypes.c_uint32, ctypes.c_int]
+
+    def reset_mem(self, n: int, type_id: Optional[np.ndarray] = None) -> np.ndarray:
+        mem = np.zeros((n, 13))
+        tid = np.zeros(n, dtype=np.uint8) if type_id is None else type_id
+        for k, t in enumerate(self.types):
+            sel = tid == k
+            mem[sel, 6] = t.reset_thrust
+            mem[sel, 7:7 + t.n_act] = t.reset_cmd
+        return mem
+
+    def control(self, rigid, mem, tgt, dt, type_id=None, nthreads=1):
+        n = rigid.shape[0]
+        pos_e, yaw_e = np.zeros((n, 3)), np.zeros(n)
+        bc = int(tgt.shape[0] == 1 and n != 1)
+        rc = self._L.orc_control_batch(self._c_types, _p(type_id, _U8), n, dt, _p(rigid), _p(mem),
+                                       _p(_c(tgt)), bc, _p(pos_e), _p(yaw_e), nthreads)
+        return rc, pos_e, yaw_e
+
+    def physics(self, rigid, mem, substeps, dt, action=None, noise=None, options=0, type_id=None,
+                nthreads=1):
+        n = rigid.shape[0]
+        act = None if action is None else _c(action)
+        nz = None if noise is None else _c(noise)
+        return self._L.orc_physics_batch(self._c_types, _p(type_id, _U8), n, substeps, dt, _p(rigid),
+                                         _p(act), _p(mem), _p(nz), options, nthreads)
+
+    def step(self, rigid, mem, tgt, substeps, dt_phys, dt_ctrl, noise=None, options=0, type_id=None,
+             nthreads=1):
+        n = rigid.shape[0]
+        bc = int(tgt.shape[0] == 1 and n != 1)
+        nz = None if noise is None else _c(noise)
+        return self._L.orc_step_batch(self._c_types, _p(type_id, _U8), n, substeps, dt_phys, dt_ctrl,
+                                      _p(rigid), _p(mem), _p(_c(tgt)), bc, _p(nz), options, nthreads)
+
+    def noise_normals(self, seed: int, drone: int, sub_counter: int, n_act: int) -> np.ndarray:
+        out = np.zeros(2 * n_act)
+        f = self._L.orc_noise_normals
+        f.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _D]
+        f(seed, drone, sub_counter, n_act, _p(out))
+        return out
+
+    @staticmethod
+    def max_threads() -> int:
+        return lib().orc_max_threads()
