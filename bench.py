@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — drone-steps/s of the fused Env.step()+INDI kernel on synthetic fleets.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one Env.step() (phys_substeps physics sub-steps) + one INDI evaluation for
+every drone of the rank's fleet = ONE launch of k_step_quad.  Inputs are resident in HBM
+before the timed region.  Drones are independent, so ranks shard the fleet with no
+data-path collective (weak scaling: per-GPU fleet fixed).
+
+Workloads:
+  config2x1024 (default)  BASELINE.json configs[1] — 4 096 robobee quads, INDI hover at own start,
+                          initial action 0.4 — as 1 024 vectorised env replicas per GPU
+                          (4 194 304 drones, 0.97 GB of state: exceeds the 256 MB Infinity
+                          Cache, so the HBM fraction means something).  phys_substeps=1.
+  config2                 the single 4 096-drone fleet (launch-latency bound; reported under
+                          "also" in every run)
+  config3                 65 536 robobee, per-drone targets (also under "also")
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+BYTES_PER_DRONE_STEP = 232      # read 13+11+10 floats, write 13+11 floats (quad, per-drone targets)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--workload", default="config2x1024", choices=["config2x1024", "config2", "config3"])
+    p.add_argument("--substeps", type=int, default=1)
+    p.add_argument("--layout", default="soa", choices=["soa", "tile64"])
+    p.add_argument("--noise-seed", type=int, default=1)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-also", action="store_true")
+    return p.parse_args()
+
+
+def grid_fleet(n_fleet, replicas, pitch=1.0, z=0.5):
+    """config-2 set-up: sqrt(n) x sqrt(n) grid, 1 m pitch, z = 0.5, level, at rest; replicated."""
+    side = int(round(n_fleet ** 0.5))
+    ij = np.arange(n_fleet)
+    xyz = np.stack([(ij % side) * pitch, (ij // side) * pitch, np.full(n_fleet, z)], 1)
+    return np.tile(xyz, (replicas, 1))
+
+
+class Fleet:
+    """A resident fleet + per-drone hover targets at the start position."""
+
+    def __init__(self, n_fleet, replicas, device, substeps, layout, noise_seed):
+        import torch
+        from dronesim_amd.envs import CtrlAviary
+        from dronesim_amd.fleet import Targets
+        self.torch = torch
+        xyz = grid_fleet(n_fleet, replicas)
+        self.n = xyz.shape[0]
+        self.env = CtrlAviary(["robobee"], self.n, initial_xyzs=xyz, aggregate_phy_steps=substeps,
+                              device=device, layout=layout, noise_seed=noise_seed, dict_io=False)
+        self.tgt = Targets(self.env.ctx, self.n, layout)
+        self.tgt.set(pos=xyz.T.astype(np.float32), yaw=0.4)
+        # fly_INDI.py:214: the loop starts from action 0.4; afterwards the action is the controller's cmd
+        self.env.step_fused(self.tgt, action=np.full((self.n, 4), 0.4, dtype=np.float32))
+
+    def step(self):
+        self.env.step_fused(self.tgt)
+
+    def timed(self, steps, warmup, barrier=None):
+        torch = self.torch
+        for _ in range(warmup):
+            self.step()
+        if barrier:
+            barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()                      # on torch's current stream == the stream the kernel is launched on
+        for _ in range(steps):
+            self.step()
+        e1.record()
+        if barrier:
+            barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        return wall, e0.elapsed_time(e1) * 1e-3
+
+
+def cpu_baseline(substeps, seconds=8.0):
+    """The fp64 oracle (a scalar C port of the same step) timed on the host cores on a
+    bounded sample of the same workload."""
+    from dronesim_amd.params import builtin_type
+    from oracle import oracle as orc
+    t = builtin_type("robobee")
+    O = orc.Oracle([t])
+    n = 65536
+    xyz = grid_fleet(4096, n // 4096)
+    rigid = np.concatenate([xyz, np.tile([0, 0, 0, 1.0], (n, 1)), np.zeros((n, 6))], 1)
+    mem = O.reset_mem(n); mem[:, 7:11] = 0.4
+    tgt = np.concatenate([xyz, np.zeros((n, 6)), np.full((n, 1), 0.4)], 1)
+    dt = 1.0 / 240.0
+    out = {}
+    for label, nth in (("1", 1), ("all", O.max_threads())):
+        sub_n = 8192 if nth == 1 else n
+        r, m, tg = rigid[:sub_n].copy(), mem[:sub_n].copy(), tgt[:sub_n].copy()
+        t0 = time.perf_counter(); O.step(r, m, tg, substeps, dt, substeps * dt, nthreads=nth)
+        per = time.perf_counter() - t0
+        k = max(1, int(seconds / max(per, 1e-6)))
+        t0 = time.perf_counter()
+        for _ in range(k):
+            O.step(r, m, tg, substeps, dt, substeps * dt, nthreads=nth)
+        el = time.perf_counter() - t0
+        out[label] = (sub_n * k / el, nth, sub_n, k, el)
+    v_all, nth, sub_n, k, el = out["all"]
+    return {
+        "value": v_all, "unit": "drone-steps/s", "cores": nth, "kind": "port",
+        "sample": f"fp64 C oracle (oracle/dsim_oracle.c), {sub_n} robobee x {k} steps, phys_substeps={substeps}, "
+                  f"{el:.1f} s on {nth} OpenMP threads; single thread: {out['1'][0]:.3e} drone-steps/s "
+                  f"({out['1'][2]} drones x {out['1'][3]} steps)",
+        "single_thread_value": out["1"][0],
+        "reference_python_note": "reference INDIControl.computeControl alone: 8.2e3 calls/s/core (SURVEY.md 6, survey "
+                                 "container); PyBullet Env.step not measurable (engine absent)",
+    }
+
+
+def main():
+    a = parse()
+    import torch
+    import __graft_entry__ as graft
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank == 0:
+        graft.build()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.barrier()
+    if rank != 0:
+        graft.build()       # no-op once rank 0 has built
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local)
+    barrier = (lambda: dist.barrier()) if dist else None
+
+    n_fleet, replicas = {"config2x1024": (4096, 1024), "config2": (4096, 1), "config3": (65536, 1)}[a.workload]
+    fl = Fleet(n_fleet, replicas, local, a.substeps, a.layout, a.noise_seed)
+    wall, dev_s = fl.timed(a.steps, a.warmup, barrier)
+    t = torch.tensor([wall, dev_s], dtype=torch.float64, device="cuda")
+    if dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall, dev_s = float(t[0]), float(t[1])
+    n_total = fl.n * world
+    value = n_total * a.steps / wall
+    launch_s = dev_s / a.steps
+    achieved = fl.n * BYTES_PER_DRONE_STEP / launch_s / 1e9
+
+    if rank == 0:
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            tj = json.load(open(tp))
+            if tj.get("workload") == a.workload and tj.get("layout", "soa") == a.layout:
+                traffic = tj.get("hbm_bytes_per_launch")
+        out = {
+            "metric": "drone-steps/sec (num_drones x env steps/s)", "value": value, "unit": "drone-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": {"config2x1024": "configs[1] 4096 robobee INDI hover x 1024 vectorised envs/GPU",
+                                    "config2": "configs[1] 4096 robobee INDI hover (single fleet)",
+                                    "config3": "65536 robobee, per-drone targets"}[a.workload],
+                       "drones_per_gpu": fl.n, "phys_substeps": a.substeps, "layout": a.layout,
+                       "noise_seed": a.noise_seed, "launches_per_step": 1, "parallelism": f"shard{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "k_step_quad", "bytes_per_drone_step": BYTES_PER_DRONE_STEP,
+                         "launch_us": launch_s * 1e6},
+        }
+        if world == 1 and not a.no_also:
+            also = {}
+            # yardstick: achievable copy bandwidth on this device (read + write bytes / time)
+            src = torch.empty(1 << 28, dtype=torch.float32, device="cuda"); dst = torch.empty_like(src)
+            for _ in range(3):
+                dst.copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            e1.record(); torch.cuda.synchronize()
+            also["device_copy_GBps"] = 2 * src.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del src, dst
+            for name, (nf, rep, sub) in {"config2_single_fleet_4096_sub5": (4096, 1, 5),
+                                         "config3_65536_sub2": (65536, 1, 2),
+                                         "config2x1024_sub5": (4096, 1024, 5)}.items():
+                f2 = Fleet(nf, rep, local, sub, a.layout, a.noise_seed)
+                w2, d2 = f2.timed(max(20, a.steps // 2), 10)
+                k2 = max(20, a.steps // 2)
+                also[name] = {"drone_steps_per_s": f2.n * k2 / w2, "launch_us": d2 / k2 * 1e6,
+                              "hbm_frac": f2.n * BYTES_PER_DRONE_STEP / (d2 / k2) / 1e9 / HBM_PEAK_GBPS}
+                f2.env.close(); del f2
+            out["also"] = also
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.substeps)
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+"""ctypes binding of libdronesim_amd.so (the C-ABI in include/dronesim_amd.h).
+
+There is no CPU fallback: if the shared library is missing or does not load the
+import fails loudly, and ``Context`` fails when no HIP device is present.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from .params import TypeParamsC
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdronesim_amd.so")
+
+# every symbol include/dronesim_amd.h declares
+EXPORTS = (
+    "dsim_abi_version", "dsim_strerror", "dsim_create", "dsim_destroy", "dsim_reset", "dsim_step",
+    "dsim_physics", "dsim_control", "dsim_observe",
+)
+
+ABI_VERSION = 1
+NF_QUAD, NF_HEXA, NT = 24, 26, 10
+OPT_DRAG, OPT_GROUND, OPT_BCAST_TGT = 1, 2, 4
+
+
+class View(ctypes.Structure):
+    _fields_ = [
+        ("base", ctypes.c_void_p),
+        ("n_pad", ctypes.c_int64),
+        ("block", ctypes.c_int64),
+        ("field_stride", ctypes.c_int64),
+        ("block_stride", ctypes.c_int64),
+        ("n_fields", ctypes.c_int32),
+        ("_pad", ctypes.c_int32),
+    ]
+
+
+class StepArgs(ctypes.Structure):
+    _fields_ = [
+        ("phys_substeps", ctypes.c_int32),
+        ("dt_phys", ctypes.c_float),
+        ("dt_ctrl", ctypes.c_float),
+        ("options", ctypes.c_uint32),
+        ("noise_seed", ctypes.c_uint64),
+        ("step_index", ctypes.c_uint64),
+        ("noise_replay", ctypes.c_void_p),
+        ("type_id", ctypes.c_void_p),
+        ("action", ctypes.c_void_p),
+    ]
+
+
+class DsimError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP extension; raises if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). dronesim_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    lib.dsim_abi_version.restype = ctypes.c_int
+    lib.dsim_strerror.restype = ctypes.c_char_p
+    lib.dsim_strerror.argtypes = [ctypes.c_int]
+    lib.dsim_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(TypeParamsC), ctypes.c_int]
+    lib.dsim_destroy.argtypes = [vp]
+    lib.dsim_reset.argtypes = [vp, vp, i64, View, vp, vp, vp, vp, vp]
+    lib.dsim_step.argtypes = [vp, vp, i64, View, View, ctypes.POINTER(StepArgs)]
+    lib.dsim_physics.argtypes = [vp, vp, i64, View, vp, ctypes.POINTER(StepArgs)]  # (.., last_action_out, args)
+    lib.dsim_control.argtypes = [vp, vp, i64, View, View, ctypes.POINTER(StepArgs), vp, vp]
+    lib.dsim_observe.argtypes = [vp, vp, i64, View, vp, vp, i32]
+    if lib.dsim_abi_version() != ABI_VERSION:
+        raise ImportError(f"libdronesim_amd.so ABI {lib.dsim_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code != 0:
+        raise DsimError(f"dsim error {code}: {load().dsim_strerror(code).decode()}")

@@ -1,0 +1,129 @@
+"""Batched INDI controller — the reference's ``BaseControl`` / ``INDIControl`` surface
+(dronesim/control/BaseControl.py:13-149, dronesim/control/INDIControl.py:25-227) for a
+whole fleet: same method names, argument meaning and return triple, one HIP launch
+per call instead of one Python object per drone.
+
+The per-drone controller memory (``last_vel``, ``last_rates``, ``last_thrust``,
+``cmd``; INDIControl.py:109-146) lives in the fleet state tensor.  A controller is
+either bound to an env (``INDIControl(env=env)`` — then it reads the env's state in
+place, no copies) or stand-alone (it owns a state block and the caller passes
+positions / quaternions / velocities explicitly, as with the reference).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Union
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from ..fleet import Context, FleetState, Targets
+from ..params import DroneType, builtin_type
+
+
+def _as3(x, n, device) -> torch.Tensor:
+    """-> [3, n] float32 device tensor from (3,), (n,3) or (3,n) input."""
+    t = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x, dtype=torch.float32, device=device)
+    if t.ndim == 1:
+        return t.reshape(3, 1).expand(3, n)
+    if t.shape == (n, 3):
+        return t.T
+    return t.reshape(3, n)
+
+
+class BaseControl:
+    """dronesim/control/BaseControl.py:13-149."""
+
+    def __init__(self, drone_model: Union[str, DroneType] = "tello", g: float = 9.8, *, num_drones: int = 1,
+                 env=None, device: int = 0, layout: str = "soa"):
+        self.DRONE_MODEL = drone_model if isinstance(drone_model, str) else drone_model.name
+        self.type = builtin_type(drone_model) if isinstance(drone_model, str) else drone_model
+        self.GRAVITY = g * self.type.ctrl_mass       # BaseControl.py:36
+        self.KF, self.KM = self.type.kf, self.type.km
+        self.env = env
+        if env is not None:
+            self.ctx, self.state, self.n = env.ctx, env.state, env.NUM_DRONES
+            self._type_id = env._type_id
+        else:
+            self.ctx = Context([self.type], device)
+            self.n = num_drones
+            self.state = FleetState(self.ctx, num_drones, layout)
+            self._type_id = None
+        self._targets = Targets(self.ctx, self.n, self.state.layout)
+        self._pos_e = torch.zeros((3, self.state.n_pad), dtype=torch.float32, device=self.ctx.device)
+        self._yaw_e = torch.zeros((self.state.n_pad,), dtype=torch.float32, device=self.ctx.device)
+        self.reset()
+
+    def reset(self):
+        """BaseControl.reset (BaseControl.py:51-57)."""
+        self.control_counter = 0
+
+    def computeControlFromState(self, control_timestep, state, target_pos, target_vel=np.zeros(3),
+                                target_acc=np.zeros(3), target_rpy=np.zeros(3), target_rpy_rates=np.zeros(3)):
+        """BaseControl.computeControlFromState (BaseControl.py:61-103): slices
+        ``state[0:3], [3:7], [10:13], [13:16]``.  ``state`` is one 20-vector or [N,20];
+        ``None`` with a bound env means "the env's current device state"."""
+        if state is None:
+            if self.env is None:
+                raise ValueError("state=None needs a controller bound to an env")
+            return self.computeControl(control_timestep, None, None, None, None, target_pos, target_vel,
+                                       target_acc, target_rpy, target_rpy_rates)
+        s = torch.as_tensor(np.asarray(state) if not torch.is_tensor(state) else state)
+        single = s.ndim == 1
+        s = s.reshape(-1, s.shape[-1])
+        out = self.computeControl(control_timestep, s[:, 0:3], s[:, 3:7], s[:, 10:13], s[:, 13:16], target_pos,
+                                  target_vel, target_acc, target_rpy, target_rpy_rates)
+        return self._maybe_single(out, single)
+
+    def _maybe_single(self, out, single):
+        if not single:
+            return out
+        cmd, pos_e, yaw_e = out
+        return (cmd[0].double().cpu().numpy(), pos_e[0].double().cpu().numpy(), float(yaw_e[0]))
+
+    def computeControl(self, *a, **k):
+        raise NotImplementedError     # BaseControl.py:107-149
+
+
+class INDIControl(BaseControl):
+    """dronesim/control/INDIControl.py:25-490 for N drones of one quad type."""
+
+    def reset(self):
+        """INDIControl.reset (INDIControl.py:109-146): last_vel = last_rates = 0,
+        last_thrust = 0, cmd = 0 (6DOF: 0.3 / 0.5)."""
+        super().reset()
+        st = self.state
+        st.set_fields(13, torch.zeros((6, st.n), device=self.ctx.device))
+        st.set_fields(19, torch.full((1, st.n), self.type.reset_thrust, device=self.ctx.device))
+        st.set_fields(20, torch.full((st.n_fields - 20, st.n), self.type.reset_cmd, device=self.ctx.device))
+
+    def computeControl(self, control_timestep, cur_pos, cur_quat, cur_vel, cur_ang_vel, target_pos,
+                       target_vel=np.zeros(3), target_acc=np.zeros(3), target_rpy=np.zeros(3),
+                       target_rpy_rates=np.zeros(3)):
+        """INDIControl.computeControl (INDIControl.py:154-227).  Returns
+        ``(cmd [N,4] PWM, pos_e [N,3], yaw_e [N])`` as device tensors.  ``target_rpy_rates``
+        is accepted and ignored, as in the reference (:404-410)."""
+        self.control_counter += 1
+        n, dev, st = self.n, self.ctx.device, self.state
+        if cur_pos is not None:                       # explicit state (stand-alone use)
+            st.set_fields(0, _as3(cur_pos, n, dev))
+            q = torch.as_tensor(np.asarray(cur_quat) if not torch.is_tensor(cur_quat) else cur_quat,
+                                dtype=torch.float32, device=dev)
+            st.set_fields(3, q.reshape(4, 1).expand(4, n) if q.ndim == 1 else (q.T if q.shape == (n, 4) else q))
+            st.set_fields(7, _as3(cur_vel, n, dev))
+            st.set_fields(10, _as3(cur_ang_vel, n, dev))
+        yaw = torch.as_tensor(np.asarray(target_rpy) if not torch.is_tensor(target_rpy) else target_rpy,
+                              dtype=torch.float32, device=dev)
+        yaw = yaw[..., 2].reshape(-1) if yaw.shape[-1] == 3 else yaw.reshape(3, -1)[2]
+        self._targets.set(pos=_as3(target_pos, n, dev), vel=_as3(target_vel, n, dev),
+                          acc=_as3(target_acc, n, dev), yaw=yaw.reshape(1, -1))
+        a = nat.StepArgs()
+        a.phys_substeps, a.dt_phys, a.dt_ctrl = 0, float(control_timestep), float(control_timestep)
+        a.options, a.noise_seed, a.step_index = 0, 0, 0
+        a.noise_replay, a.action = None, None
+        a.type_id = self._type_id.data_ptr() if self._type_id is not None else None
+        nat.check(self.ctx.lib.dsim_control(self.ctx.handle, self.ctx.stream_ptr(), n, st.view(),
+                                            self._targets.view(), ctypes.byref(a), self._pos_e.data_ptr(),
+                                            self._yaw_e.data_ptr()))
+        return st.cmd.T, self._pos_e[:, :n].T, self._yaw_e[:n]

@@ -1,0 +1,436 @@
+// dsim_api.hip — kernels + C-ABI of libdronesim_amd.so (gfx950 only).
+//
+// Execution shape: one drone per lane, 64-drone waves, 256-thread workgroups.
+// State is blocked SoA (include/dronesim_amd.h): consecutive lanes read
+// consecutive floats of one field, so every global access of a wave is one
+// fully-coalesced 256-byte segment.  The fused step kernel reads each state
+// field once and writes it once per Env.step(): 232 B per drone-step for a quad
+// with per-drone targets (192 B with a broadcast target); physics sub-steps and
+// the whole INDI law stay in registers.  The bound is HBM bandwidth.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+
+#include "../../include/dronesim_amd.h"
+#include "dsim_device.h"
+
+struct dsim_ctx {
+  int device;
+  int n_types;
+  DevType* d_types;                       // device copy of the type table
+  dsim_type_params h_types[DSIM_MAX_TYPES];
+};
+
+// ---------------------------------------------------------------------------
+// blocked-SoA addressing
+// ---------------------------------------------------------------------------
+struct KView {
+  float* base;
+  long long field_stride, block_stride;
+  long long mask;   // block - 1 (block is a power of two) ; -1 for plain SoA
+  int shift;        // log2(block) ; 63 for plain SoA
+};
+__device__ __forceinline__ long long kv_off(const KView& v, long long i) {
+  return (i >> v.shift) * v.block_stride + (i & v.mask);
+}
+
+struct StepK {
+  KView st, tg;
+  const DevType* types;
+  const uint8_t* type_id;
+  const float* noise_replay;
+  const float* action;        // SoA [n_act][n_pad] or null (= stored cmd)
+  float* echo;                // physics kernel: clipped action out, or null
+  float* pos_e_out;           // control kernel only
+  float* yaw_e_out;
+  long long n_pad;
+  unsigned long long seed, step_index;
+  int substeps;
+  float dt_phys, dt_ctrl;
+  unsigned options;
+};
+
+template <int NACT>
+__device__ __forceinline__ void load_rigid(const KView& v, long long o, Rigid& s) {
+  const float* p = v.base + o;
+  const long long fs = v.field_stride;
+  s.pos = v3(p[0 * fs], p[1 * fs], p[2 * fs]);
+  s.q = Q4{p[3 * fs], p[4 * fs], p[5 * fs], p[6 * fs]};
+  s.vel = v3(p[7 * fs], p[8 * fs], p[9 * fs]);
+  s.w = v3(p[10 * fs], p[11 * fs], p[12 * fs]);
+}
+__device__ __forceinline__ void store_rigid(const KView& v, long long o, const Rigid& s) {
+  float* p = v.base + o;
+  const long long fs = v.field_stride;
+  p[0 * fs] = s.pos.x; p[1 * fs] = s.pos.y; p[2 * fs] = s.pos.z;
+  p[3 * fs] = s.q.x; p[4 * fs] = s.q.y; p[5 * fs] = s.q.z; p[6 * fs] = s.q.w;
+  p[7 * fs] = s.vel.x; p[8 * fs] = s.vel.y; p[9 * fs] = s.vel.z;
+  p[10 * fs] = s.w.x; p[11 * fs] = s.w.y; p[12 * fs] = s.w.z;
+}
+template <int NACT>
+__device__ __forceinline__ void load_mem(const KView& v, long long o, CtrlMem<NACT>& m) {
+  const float* p = v.base + o;
+  const long long fs = v.field_stride;
+  m.last_vel = v3(p[13 * fs], p[14 * fs], p[15 * fs]);
+  m.last_rates = v3(p[16 * fs], p[17 * fs], p[18 * fs]);
+  m.last_thrust = p[19 * fs];
+#pragma unroll
+  for (int j = 0; j < NACT; ++j) m.cmd[j] = p[(20 + j) * fs];
+}
+template <int NACT>
+__device__ __forceinline__ void store_mem(const KView& v, long long o, const CtrlMem<NACT>& m) {
+  float* p = v.base + o;
+  const long long fs = v.field_stride;
+  p[13 * fs] = m.last_vel.x; p[14 * fs] = m.last_vel.y; p[15 * fs] = m.last_vel.z;
+  p[16 * fs] = m.last_rates.x; p[17 * fs] = m.last_rates.y; p[18 * fs] = m.last_rates.z;
+  p[19 * fs] = m.last_thrust;
+#pragma unroll
+  for (int j = 0; j < NACT; ++j) p[(20 + j) * fs] = m.cmd[j];
+}
+__device__ __forceinline__ void load_target(const KView& v, long long o, bool bcast, Target& t) {
+  // broadcast: the address is wave-uniform -> ten scalar loads
+  const float* p = v.base + (bcast ? 0 : o);
+  const long long fs = v.field_stride;
+  t.pos = v3(p[0 * fs], p[1 * fs], p[2 * fs]);
+  t.vel = v3(p[3 * fs], p[4 * fs], p[5 * fs]);
+  t.acc = v3(p[6 * fs], p[7 * fs], p[8 * fs]);
+  t.yaw = p[9 * fs];
+}
+
+// physics sub-steps of one Env.step for a quad (BaseAviary.py:510-545)
+template <bool NOISE>
+__device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
+                                              const float cmd[4]) {
+  V3 F0, tau0;
+  quad_wrench(T, cmd, nullptr, F0, tau0);   // cmd is constant over the sub-steps
+  for (int k = 0; k < a.substeps; ++k) {
+    V3 F = F0, tau = tau0;
+    if (NOISE) {
+      float nz[8];
+      if (a.noise_replay) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) nz[j] = a.noise_replay[((long long)k * 8 + j) * a.n_pad + i];
+      } else {
+        noise_normals<4>(a.seed, (uint64_t)i, a.step_index * (uint64_t)a.substeps + (uint64_t)k, nz);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { nz[j] *= 0.01f; nz[4 + j] *= 0.001f; }   // BaseAviary.py:1518-1521
+      }
+      quad_wrench(T, cmd, nz, F, tau);
+    }
+    bullet_step(T, a.dt_phys, s, F, tau);
+  }
+}
+
+// ---- fused Env.step + computeControl (the hot path) -----------------------
+template <bool NOISE, bool UNIFORM>
+__global__ __launch_bounds__(256) void k_step_quad(StepK a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_pad) return;
+  const DevType& T = a.types[UNIFORM ? 0 : a.type_id[i]];
+  const long long o = kv_off(a.st, i);
+  Rigid s;
+  CtrlMem<4> m;
+  Target tg;
+  load_rigid<4>(a.st, o, s);
+  load_mem<4>(a.st, o, m);
+  load_target(a.tg, kv_off(a.tg, i), (a.options & DSIM_OPT_BCAST_TGT) != 0, tg);
+  float act[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) act[j] = a.action ? a.action[(long long)j * a.n_pad + i] : m.cmd[j];
+  if (a.action) preprocess_action<4>(T, act, act);   // the stored cmd is already clipped (INDIControl.py:487)
+  quad_substeps<NOISE>(T, a, i, s, act);
+  V3 pos_e;
+  float yaw_e;
+  indi_quad(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  store_rigid(a.st, o, s);
+  store_mem<4>(a.st, o, m);
+}
+
+// ---- Env.step only ---------------------------------------------------------
+template <bool NOISE, bool UNIFORM>
+__global__ __launch_bounds__(256) void k_physics_quad(StepK a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_pad) return;
+  const DevType& T = a.types[UNIFORM ? 0 : a.type_id[i]];
+  const long long o = kv_off(a.st, i);
+  Rigid s;
+  load_rigid<4>(a.st, o, s);
+  float raw[4], cmd[4];
+  const long long fs = a.st.field_stride;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) raw[j] = a.action ? a.action[(long long)j * a.n_pad + i] : a.st.base[o + (20 + j) * fs];
+  preprocess_action<4>(T, raw, cmd);
+  quad_substeps<NOISE>(T, a, i, s, cmd);
+  store_rigid(a.st, o, s);
+  if (a.echo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a.echo[(long long)j * a.n_pad + i] = cmd[j];   // last_clipped_action, BaseAviary.py:545
+  }
+}
+
+// ---- computeControl only ----------------------------------------------------
+template <bool UNIFORM>
+__global__ __launch_bounds__(256) void k_control_quad(StepK a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_pad) return;
+  const DevType& T = a.types[UNIFORM ? 0 : a.type_id[i]];
+  const long long o = kv_off(a.st, i);
+  Rigid s;
+  CtrlMem<4> m;
+  Target tg;
+  load_rigid<4>(a.st, o, s);
+  load_mem<4>(a.st, o, m);
+  load_target(a.tg, kv_off(a.tg, i), (a.options & DSIM_OPT_BCAST_TGT) != 0, tg);
+  V3 pos_e;
+  float yaw_e;
+  indi_quad(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  store_mem<4>(a.st, o, m);
+  if (a.pos_e_out) {
+    a.pos_e_out[i] = pos_e.x; a.pos_e_out[a.n_pad + i] = pos_e.y; a.pos_e_out[2 * a.n_pad + i] = pos_e.z;
+  }
+  if (a.yaw_e_out) a.yaw_e_out[i] = yaw_e;
+}
+
+// ---- reset -------------------------------------------------------------------
+struct ResetK {
+  KView st;
+  const DevType* types;
+  const uint8_t* type_id;
+  const float *pos, *rpy, *vel, *cmd;
+  long long n_pad;
+  int n_fields;
+};
+__global__ __launch_bounds__(256) void k_reset(ResetK a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_pad) return;
+  const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
+  const long long o = kv_off(a.st, i);
+  Rigid s;
+  s.pos = v3(a.pos[i], a.pos[a.n_pad + i], a.pos[2 * a.n_pad + i]);
+  s.q = quat_from_euler(v3(a.rpy[i], a.rpy[a.n_pad + i], a.rpy[2 * a.n_pad + i]));   // BaseAviary.py:687
+  s.vel = a.vel ? v3(a.vel[i], a.vel[a.n_pad + i], a.vel[2 * a.n_pad + i]) : v3(0, 0, 0);  // :695-705
+  s.w = v3(0, 0, 0);
+  store_rigid(a.st, o, s);
+  float* p = a.st.base + o;
+  const long long fs = a.st.field_stride;
+#pragma unroll
+  for (int f = 13; f < 19; ++f) p[f * fs] = 0.0f;            // INDIControl.reset, INDIControl.py:125-130
+  p[19 * fs] = T.reset_thrust;
+  const int nact = a.n_fields - 20;
+  for (int j = 0; j < nact; ++j)
+    p[(20 + j) * fs] = a.cmd ? a.cmd[(long long)j * a.n_pad + i] : (j < T.n_act ? T.reset_cmd : 0.0f);
+}
+
+// ---- observation rows (BaseAviary.py:780-790) --------------------------------
+struct ObsK { KView st; const float* last_action; float* out; long long n, n_pad; int width; };
+__global__ __launch_bounds__(256) void k_observe(ObsK a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const long long o = kv_off(a.st, i);
+  Rigid s;
+  load_rigid<4>(a.st, o, s);
+  const V3 e = euler_from_quat(s.q);
+  float* r = a.out + i * a.width;
+  r[0] = s.pos.x; r[1] = s.pos.y; r[2] = s.pos.z;
+  r[3] = s.q.x; r[4] = s.q.y; r[5] = s.q.z; r[6] = s.q.w;
+  r[7] = e.x; r[8] = e.y; r[9] = e.z;
+  r[10] = s.vel.x; r[11] = s.vel.y; r[12] = s.vel.z;
+  r[13] = s.w.x; r[14] = s.w.y; r[15] = s.w.z;
+  for (int j = 0; j < a.width - 16; ++j)
+    r[16 + j] = a.last_action ? a.last_action[(long long)j * a.n_pad + i] : a.st.base[o + (20 + j) * a.st.field_stride];
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static int make_kview(const dsim_view& v, int need_fields, KView* k, bool bcast = false) {
+  if (!v.base) return DSIM_E_ARG;
+  if (v.n_fields < need_fields) return DSIM_E_LAYOUT;
+  k->base = v.base;
+  k->field_stride = v.field_stride;
+  k->block_stride = v.block_stride;
+  if (bcast) { k->mask = 0; k->shift = 63; return DSIM_OK; }
+  if (v.n_pad <= 0 || (v.n_pad & 63)) return DSIM_E_LAYOUT;
+  if (v.block == v.n_pad) { k->mask = -1; k->shift = 63; return DSIM_OK; }
+  if (v.block < 64 || (v.block & (v.block - 1)) || (v.n_pad % v.block)) return DSIM_E_LAYOUT;
+  k->mask = v.block - 1;
+  int sh = 0;
+  while ((1LL << sh) < v.block) ++sh;
+  k->shift = sh;
+  if (v.field_stride < v.block || v.block_stride < v.field_stride * need_fields) return DSIM_E_LAYOUT;
+  return DSIM_OK;
+}
+
+static void to_dev(const dsim_type_params& p, DevType* d) {
+  memset(d, 0, sizeof(*d));
+  d->kind = p.kind; d->n_act = p.n_act;
+  d->mass = (float)p.mass; d->inv_mass = (float)(1.0 / p.mass);
+  for (int k = 0; k < 3; ++k) {
+    d->J[k] = (float)p.inertia[k]; d->invJ[k] = (float)(1.0 / p.inertia[k]);
+    d->katt[k] = (float)p.att_gain[k]; d->krate[k] = (float)p.rate_gain[k];
+    d->drag[k] = (float)p.drag_coeff[k]; d->dw[k] = (float)p.dw_coeff[k];
+  }
+  d->kf = (float)p.kf; d->km = (float)p.km;
+  for (int j = 0; j < DSIM_MAX_ACT; ++j) {
+    d->scale[j] = (float)p.pwm2rpm_scale[j]; d->cnst[j] = (float)p.pwm2rpm_const[j];
+    d->pmin[j] = (float)p.pwm_min[j]; d->pmax[j] = (float)p.pwm_max[j];
+    d->spin[j] = (float)p.rotor_spin[j];
+    for (int k = 0; k < 3; ++k) { d->rpos[j][k] = (float)p.rotor_pos[j][k]; d->raxis[j][k] = (float)p.rotor_axis[j][k]; }
+    for (int i = 0; i < DSIM_MAX_ACT; ++i) d->alloc[j][i] = (float)p.alloc[j][i];
+  }
+  d->kp = (float)p.kp_pos; d->kd = (float)p.kd_pos;
+  d->g = (float)p.gravity; d->clin = (float)p.lin_damping; d->cang = (float)p.ang_damping;
+  d->maxv = (float)p.max_coord_vel;
+  d->gnd_coeff = (float)p.gnd_eff_coeff; d->prop_radius = (float)p.prop_radius; d->gnd_hclip = (float)p.gnd_eff_h_clip;
+  if (p.kind == DSIM_KIND_HEXA6DOF) { d->reset_thrust = 0.3f; d->reset_cmd = 0.5f; }   // INDIControl_6DOF.py:232-234
+}
+
+extern "C" {
+
+int dsim_abi_version(void) { return DSIM_ABI_VERSION; }
+
+const char* dsim_strerror(int code) {
+  switch (code) {
+    case DSIM_OK: return "ok";
+    case DSIM_E_ARG: return "dsim: null or inconsistent argument";
+    case DSIM_E_LAYOUT: return "dsim: view violates the blocked-SoA layout contract";
+    case DSIM_E_NODEVICE: return "dsim: no HIP device (gfx950 required; there is no CPU fallback)";
+    case DSIM_E_TYPES: return "dsim: bad type table";
+    case DSIM_E_UNSUPPORTED: return "dsim: unsupported configuration";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "dsim: unknown error";
+  }
+}
+
+int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n_types) {
+  if (!out || !types) return DSIM_E_ARG;
+  if (n_types < 1 || n_types > DSIM_MAX_TYPES) return DSIM_E_TYPES;
+  for (int t = 0; t < n_types; ++t) {
+    if (types[t].n_act < 1 || types[t].n_act > DSIM_MAX_ACT || !(types[t].mass > 0)) return DSIM_E_TYPES;
+    for (int k = 0; k < 3; ++k) if (!(types[t].inertia[k] > 0)) return DSIM_E_TYPES;
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0 || device < 0 || device >= count) return DSIM_E_NODEVICE;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return (int)e;
+  dsim_ctx* c = new (std::nothrow) dsim_ctx;
+  if (!c) return DSIM_E_ARG;
+  c->device = device; c->n_types = n_types; c->d_types = nullptr;
+  DevType h[DSIM_MAX_TYPES];
+  for (int t = 0; t < n_types; ++t) { c->h_types[t] = types[t]; to_dev(types[t], &h[t]); }
+  e = hipMalloc((void**)&c->d_types, sizeof(DevType) * n_types);
+  if (e == hipSuccess) e = hipMemcpy(c->d_types, h, sizeof(DevType) * n_types, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { if (c->d_types) (void)hipFree(c->d_types); delete c; return (int)e; }
+  *out = c;
+  return DSIM_OK;
+}
+
+int dsim_destroy(dsim_ctx* ctx) {
+  if (!ctx) return DSIM_E_ARG;
+  hipError_t e = hipFree(ctx->d_types);
+  delete ctx;
+  return (int)e;
+}
+
+static inline unsigned grid_for(long long n) { return (unsigned)((n + 255) / 256); }
+
+static bool all_quad(const dsim_ctx* c) {
+  for (int t = 0; t < c->n_types; ++t) if (c->h_types[t].kind != DSIM_KIND_QUAD) return false;
+  return true;
+}
+
+int dsim_reset(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* init_pos,
+               const float* init_rpy, const float* init_vel, const float* init_cmd, const uint8_t* type_id) {
+  if (!ctx || !init_pos || !init_rpy || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
+  ResetK a;
+  int rc = make_kview(state, DSIM_NF_QUAD, &a.st);
+  if (rc) return rc;
+  a.types = ctx->d_types; a.type_id = type_id;
+  a.pos = init_pos; a.rpy = init_rpy; a.vel = init_vel; a.cmd = init_cmd;
+  a.n_pad = state.n_pad; a.n_fields = state.n_fields;
+  hipLaunchKernelGGL(k_reset, dim3(grid_for(a.n_pad)), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const dsim_view* targets,
+                      const dsim_step_args* args, StepK* a) {
+  if (!ctx || !args || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
+  if (args->phys_substeps < 0 || !(args->dt_phys > 0) || !(args->dt_ctrl > 0)) return DSIM_E_ARG;
+  if (!all_quad(ctx)) return DSIM_E_UNSUPPORTED;
+  if (ctx->n_types > 1 && !args->type_id) return DSIM_E_ARG;
+  int rc = make_kview(state, DSIM_NF_QUAD, &a->st);
+  if (rc) return rc;
+  if (targets) {
+    const bool bc = (args->options & DSIM_OPT_BCAST_TGT) != 0;
+    rc = make_kview(*targets, DSIM_NT, &a->tg, bc);
+    if (rc) return rc;
+    if (!bc && targets->n_pad != state.n_pad) return DSIM_E_LAYOUT;
+  } else {
+    memset(&a->tg, 0, sizeof(a->tg));
+  }
+  a->types = ctx->d_types; a->type_id = args->type_id; a->noise_replay = args->noise_replay;
+  a->action = args->action; a->echo = nullptr; a->pos_e_out = nullptr; a->yaw_e_out = nullptr;
+  a->n_pad = state.n_pad; a->seed = args->noise_seed; a->step_index = args->step_index;
+  a->substeps = args->phys_substeps; a->dt_phys = args->dt_phys; a->dt_ctrl = args->dt_ctrl;
+  a->options = args->options;
+  return DSIM_OK;
+}
+
+#define DSIM_LAUNCH2(KERNEL, NOISE, UNI, a, stream)                                                      \
+  do {                                                                                                   \
+    const dim3 g(grid_for((a).n_pad)), b(256);                                                           \
+    if (NOISE) { if (UNI) hipLaunchKernelGGL((KERNEL<true, true>), g, b, 0, stream, a);                  \
+                 else hipLaunchKernelGGL((KERNEL<true, false>), g, b, 0, stream, a); }                   \
+    else { if (UNI) hipLaunchKernelGGL((KERNEL<false, true>), g, b, 0, stream, a);                       \
+           else hipLaunchKernelGGL((KERNEL<false, false>), g, b, 0, stream, a); }                        \
+  } while (0)
+
+int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
+              const dsim_step_args* args) {
+  StepK a;
+  int rc = fill_stepk(ctx, n, state, &targets, args, &a);
+  if (rc) return rc;
+  const bool noise = args->noise_seed != 0 || args->noise_replay != nullptr;
+  const bool uni = args->type_id == nullptr;
+  DSIM_LAUNCH2(k_step_quad, noise, uni, a, (hipStream_t)stream);
+  return (int)hipGetLastError();
+}
+
+int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float* last_action_out,
+                 const dsim_step_args* args) {
+  StepK a;
+  int rc = fill_stepk(ctx, n, state, nullptr, args, &a);
+  if (rc) return rc;
+  a.echo = last_action_out;
+  const bool noise = args->noise_seed != 0 || args->noise_replay != nullptr;
+  const bool uni = args->type_id == nullptr;
+  DSIM_LAUNCH2(k_physics_quad, noise, uni, a, (hipStream_t)stream);
+  return (int)hipGetLastError();
+}
+
+int dsim_control(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
+                 const dsim_step_args* args, float* pos_e_out, float* yaw_e_out) {
+  StepK a;
+  int rc = fill_stepk(ctx, n, state, &targets, args, &a);
+  if (rc) return rc;
+  a.pos_e_out = pos_e_out; a.yaw_e_out = yaw_e_out;
+  const dim3 g(grid_for(a.n_pad)), b(256);
+  if (args->type_id == nullptr) hipLaunchKernelGGL((k_control_quad<true>), g, b, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((k_control_quad<false>), g, b, 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int dsim_observe(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
+                 float* obs_out, int32_t obs_width) {
+  if (!ctx || !obs_out || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
+  if (obs_width < 16 || obs_width > 16 + DSIM_MAX_ACT || 20 + (obs_width - 16) > state.n_fields) return DSIM_E_ARG;
+  ObsK a;
+  int rc = make_kview(state, DSIM_NF_QUAD, &a.st);
+  if (rc) return rc;
+  a.last_action = last_action; a.out = obs_out; a.n = n; a.n_pad = state.n_pad; a.width = obs_width;
+  hipLaunchKernelGGL(k_observe, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+// dsim_device.h — per-drone device arithmetic (fp32, one drone per lane) for gfx950.
+//
+// Everything here is small-vector arithmetic on registers: no MFMA (there is no
+// dense contraction on this path), no LDS needed for the arithmetic itself.
+// The functions mirror, one for one, the reference functions listed in
+// SURVEY.md 8(a); each cites the reference lines it computes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DSIM_MAX_ACT 6
+
+// fp32 image of dsim_type_params (include/dronesim_amd.h), with the reciprocals
+// the kernel wants.  Lives in device memory; with a homogeneous fleet the address
+// is wave-uniform so every field is fetched by scalar loads into SGPRs.
+struct DevType {
+  int32_t kind, n_act;
+  float mass, inv_mass;
+  float J[3], invJ[3];
+  float kf, km;
+  float scale[DSIM_MAX_ACT], cnst[DSIM_MAX_ACT], pmin[DSIM_MAX_ACT], pmax[DSIM_MAX_ACT];
+  float rpos[DSIM_MAX_ACT][3], raxis[DSIM_MAX_ACT][3], spin[DSIM_MAX_ACT];
+  float alloc[DSIM_MAX_ACT][2 * DSIM_MAX_ACT];
+  float kp, kd, katt[3], krate[3];
+  float g, clin, cang, maxv;
+  float drag[3], gnd_coeff, prop_radius, gnd_hclip, dw[3];
+  float reset_thrust, reset_cmd;
+};
+
+struct V3 { float x, y, z; };
+struct Q4 { float x, y, z, w; };   // xyzw, w last (dronesim/utils/math.py:6,25,47)
+struct M3 { float m[9]; };         // row-major, body -> world
+
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// p.getMatrixFromQuaternion / btMatrix3x3::setRotation (s = 2/|q|^2); C8
+__device__ __forceinline__ M3 matrix_from_quat(Q4 q) {
+  const float d = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+  const float s = 2.0f / d;
+  const float xs = q.x * s, ys = q.y * s, zs = q.z * s;
+  const float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+  const float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
+  const float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+  M3 R;
+  R.m[0] = 1.0f - (yy + zz); R.m[1] = xy - wz;          R.m[2] = xz + wy;
+  R.m[3] = xy + wz;          R.m[4] = 1.0f - (xx + zz); R.m[5] = yz - wx;
+  R.m[6] = xz - wy;          R.m[7] = yz + wx;          R.m[8] = 1.0f - (xx + yy);
+  return R;
+}
+__device__ __forceinline__ V3 mul(const M3& R, V3 a) {   // R a
+  return v3(R.m[0] * a.x + R.m[1] * a.y + R.m[2] * a.z, R.m[3] * a.x + R.m[4] * a.y + R.m[5] * a.z,
+            R.m[6] * a.x + R.m[7] * a.y + R.m[8] * a.z);
+}
+__device__ __forceinline__ V3 mulT(const M3& R, V3 a) {  // R^T a
+  return v3(R.m[0] * a.x + R.m[3] * a.y + R.m[6] * a.z, R.m[1] * a.x + R.m[4] * a.y + R.m[7] * a.z,
+            R.m[2] * a.x + R.m[5] * a.y + R.m[8] * a.z);
+}
+
+// p.getEulerFromQuaternion (ZYX, gimbal clamp at |sarg| >= 0.99999); C8
+__device__ __forceinline__ V3 euler_from_quat(Q4 q) {
+  const float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
+  const float sarg = -2.0f * (q.x * q.z - q.w * q.y);
+  V3 e;
+  if (sarg <= -0.99999f) {
+    e = v3(0.0f, -1.57079632679489662f, 2.0f * atan2f(q.x, -q.y));
+  } else if (sarg >= 0.99999f) {
+    e = v3(0.0f, 1.57079632679489662f, 2.0f * atan2f(-q.x, q.y));
+  } else {
+    e.x = atan2f(2.0f * (q.y * q.z + q.w * q.x), squ - sqx - sqy + sqz);
+    e.y = asinf(sarg);
+    e.z = atan2f(2.0f * (q.x * q.y + q.w * q.z), squ + sqx - sqy - sqz);
+  }
+  return e;
+}
+
+// p.getQuaternionFromEuler (half-angle product, normalised); C8
+__device__ __forceinline__ Q4 quat_from_euler(V3 e) {
+  float sph, cph, sth, cth, sps, cps;
+  sincosf(0.5f * e.x, &sph, &cph);
+  sincosf(0.5f * e.y, &sth, &cth);
+  sincosf(0.5f * e.z, &sps, &cps);
+  Q4 q;
+  q.x = sph * cth * cps - cph * sth * sps;
+  q.y = cph * sth * cps + sph * cth * sps;
+  q.z = cph * cth * sps - sph * sth * cps;
+  q.w = cph * cth * cps + sph * sth * sps;
+  const float inv = rsqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv;
+  return q;
+}
+
+// dronesim/utils/math.py:75-80 norm_ang
+__device__ __forceinline__ float norm_ang(float x) {
+  const float PI = 3.14159265358979323846f;
+  while (x > PI) x -= 2.0f * PI;
+  while (x < -PI) x += 2.0f * PI;
+  return x;
+}
+
+// ---------------------------------------------------------------------------
+// rotor noise: Philox4x32-10 + Box-Muller (definition mirrored by
+// oracle/dsim_oracle.c:orc_noise_normals; the reference's own draws come from
+// the unseeded global numpy RNG, BaseAviary.py:1518-1525, and cannot be replayed)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+  const float u1 = (float)((a >> 8) + 1u) * (1.0f / 16777216.0f);   // (0,1]
+  const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);          // [0,1)
+  const float r = sqrtf(-2.0f * __logf(u1));
+  float s, c;
+  __sincosf(6.28318530717958647692f * u2, &s, &c);
+  n0 = r * c; n1 = r * s;
+}
+// unit normals for (drone, sub-step counter): out[0..n_act) force noise, out[n_act..2 n_act) moment noise
+template <int NACT>
+__device__ __forceinline__ void noise_normals(uint64_t seed, uint64_t drone, uint64_t sub, float* out) {
+  constexpr int NSTREAM = (2 * NACT + 3) / 4;
+#pragma unroll
+  for (int s = 0; s < NSTREAM; ++s) {
+    uint32_t c[4] = {(uint32_t)drone, (uint32_t)(drone >> 32) ^ ((uint32_t)s << 24), (uint32_t)sub,
+                     (uint32_t)(sub >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    float n[4];
+    box_muller(c[0], c[1], n[0], n[1]);
+    box_muller(c[2], c[3], n[2], n[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * s + j < 2 * NACT) out[4 * s + j] = n[j];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// rigid state + controller memory of one drone, in registers
+// ---------------------------------------------------------------------------
+struct Rigid { V3 pos; Q4 q; V3 vel; V3 w; };                 // w: WORLD-frame angular velocity
+template <int NACT> struct CtrlMem { V3 last_vel; V3 last_rates; float last_thrust; float cmd[NACT]; };
+struct Target { V3 pos, vel, acc; float yaw; };
+
+// P1: CtrlAviary._preprocessAction, CtrlAviary.py:258-263
+template <int NACT>
+__device__ __forceinline__ void preprocess_action(const DevType& T, const float* a, float* clipped) {
+#pragma unroll
+  for (int j = 0; j < NACT; ++j) clipped[j] = clampf(a[j], T.pmin[j], T.pmax[j]);
+}
+
+// P2: BaseAviary._quad_copter_physics standard branch, BaseAviary.py:1487-1490, 1514-1543.
+// Body-frame wrench about the COM = what the four link forces (applied at the prop
+// links' inertial origins, LINK_FRAME) and the base torque add up to.
+// nz: 8 scaled normals (f_noise[4] ~ N(0,.01), m_noise[4] ~ N(0,.001)) or nullptr.
+__device__ __forceinline__ void quad_wrench(const DevType& T, const float cmd[4], const float* nz, V3& F, V3& tau) {
+  float f[4], t[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float rpm = T.scale[i] * cmd[i] + T.cnst[i];
+    f[i] = rpm * rpm * T.kf + (nz ? nz[i] : 0.0f);
+    t[i] = rpm * rpm * T.km + (nz ? nz[4 + i] : 0.0f);
+  }
+  const float fx = nz ? nz[0] : 0.0f, fy = nz ? nz[1] : 0.0f;   // x/y reuse noise 0,1 for every rotor (:1532)
+  F = v3(4.0f * fx, 4.0f * fy, (f[0] + f[1]) + (f[2] + f[3]));
+  tau = v3(nz ? nz[4] : 0.0f, nz ? nz[5] : 0.0f, (-t[0] + t[1]) + (-t[2] + t[3]));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const V3 r = v3(T.rpos[i][0], T.rpos[i][1], T.rpos[i][2]);
+    tau = tau + cross(r, v3(fx, fy, f[i]));
+  }
+}
+
+// P4: one Bullet btMultiBody floating-base step [BULLET-INTERNAL, parity unpinned];
+// restated step by step in oracle/dsim_oracle.c:orc_bullet_step.
+__device__ __forceinline__ void bullet_step(const DevType& T, float dt, Rigid& s, V3 F_body, V3 tau_body) {
+  const M3 R = matrix_from_quat(s.q);
+  const V3 wb = mulT(R, s.w);
+  // linear: world-frame form of a_b + w_b x v_b (the m w x v bias cancels), |v_b| = |v|
+  const float vn = sqrtf(dot(s.vel, s.vel));
+  const V3 Fw = mul(R, F_body);
+  const float dl = T.clin + T.clin * vn;
+  V3 vdot = v3(Fw.x * T.inv_mass - dl * s.vel.x, Fw.y * T.inv_mass - dl * s.vel.y,
+               Fw.z * T.inv_mass - T.g - dl * s.vel.z);
+  // angular: alpha_b = J^-1 (tau - w x Jw) - c (1+|w|) w
+  const float wn = sqrtf(dot(wb, wb));
+  const V3 Jw = v3(T.J[0] * wb.x, T.J[1] * wb.y, T.J[2] * wb.z);
+  const V3 gy = cross(wb, Jw);
+  const float da = T.cang + T.cang * wn;
+  const V3 ab = v3((tau_body.x - gy.x) * T.invJ[0] - da * wb.x, (tau_body.y - gy.y) * T.invJ[1] - da * wb.y,
+                   (tau_body.z - gy.z) * T.invJ[2] - da * wb.z);
+  const V3 wdot = mul(R, ab);
+  // applyDeltaVeeMultiDof: += acc*dt, clamp every coordinate to +-maxCoordinateVelocity
+  s.w = v3(clampf(s.w.x + wdot.x * dt, -T.maxv, T.maxv), clampf(s.w.y + wdot.y * dt, -T.maxv, T.maxv),
+           clampf(s.w.z + wdot.z * dt, -T.maxv, T.maxv));
+  s.vel = v3(clampf(s.vel.x + vdot.x * dt, -T.maxv, T.maxv), clampf(s.vel.y + vdot.y * dt, -T.maxv, T.maxv),
+             clampf(s.vel.z + vdot.z * dt, -T.maxv, T.maxv));
+  // stepPositionsMultiDof: semi-implicit position, exponential-map orientation
+  s.pos = s.pos + dt * s.vel;
+  float fAngle = sqrtf(dot(s.w, s.w));
+  if (fAngle * dt > 0.78539816339744831f) fAngle = 0.78539816339744831f / dt;
+  // h = half rotation angle <= pi/8: sin(h)/fAngle = (dt/2) sinc(h); truncation error < 2e-9.
+  // (Bullet's own |w| < 0.001 Taylor branch is the first two terms of the same series.)
+  const float h = 0.5f * fAngle * dt, h2 = h * h;
+  const float sinc = 1.0f + h2 * (-1.0f / 6.0f + h2 * (1.0f / 120.0f + h2 * (-1.0f / 5040.0f)));
+  const float cw = 1.0f + h2 * (-0.5f + h2 * (1.0f / 24.0f + h2 * (-1.0f / 720.0f + h2 * (1.0f / 40320.0f))));
+  const float sc = 0.5f * dt * sinc;
+  const float ax = s.w.x * sc, ay = s.w.y * sc, az = s.w.z * sc;
+  Q4 q = s.q, n;   // n = dq * q
+  n.w = cw * q.w - ax * q.x - ay * q.y - az * q.z;
+  n.x = cw * q.x + ax * q.w + ay * q.z - az * q.y;
+  n.y = cw * q.y + ay * q.w + az * q.x - ax * q.z;
+  n.z = cw * q.z + az * q.w + ax * q.y - ay * q.x;
+  const float inv = rsqrtf(n.x * n.x + n.y * n.y + n.z * n.z + n.w * n.w);
+  s.q = Q4{n.x * inv, n.y * inv, n.z * inv, n.w * inv};
+}
+
+// C2 + C3 + C4: INDIControl.computeControl for a quad, INDIControl.py:154-227.
+// Returns pos_e and yaw_e (the reference's 2nd and 3rd return values).
+__device__ __forceinline__ void indi_quad(const DevType& T, float dt, const Rigid& s, const Target& tg,
+                                          CtrlMem<4>& m, V3& pos_e, float& yaw_e) {
+  // ---- _INDIPositionControl, :278-296
+  pos_e = tg.pos - s.pos;
+  const float inv_dt = 1.0f / dt;
+  V3 a_e;
+  a_e.x = clampf((pos_e.x * T.kp + tg.vel.x - s.vel.x) * T.kd + tg.acc.x - (s.vel.x - m.last_vel.x) * inv_dt, -6.0f, 6.0f);
+  a_e.y = clampf((pos_e.y * T.kp + tg.vel.y - s.vel.y) * T.kd + tg.acc.y - (s.vel.y - m.last_vel.y) * inv_dt, -6.0f, 6.0f);
+  a_e.z = clampf((pos_e.z * T.kp + tg.vel.z - s.vel.z) * T.kd + tg.acc.z - (s.vel.z - m.last_vel.z) * inv_dt, -6.0f, 6.0f);
+  m.last_vel = s.vel;
+  // ---- Euler angles and G, :301-333
+  const V3 rpy = euler_from_quat(s.q);
+  float sph, cph, sth, cth, sps, cps;
+  sincosf(rpy.x, &sph, &cph);
+  sincosf(rpy.y, &sth, &cth);
+  sincosf(rpy.z, &sps, &cps);
+  const float Tg = 9.81f;
+  const float g00 = (cph * sps - sph * cps * sth) * Tg, g01 = (cph * cps * cth) * Tg, g02 = sph * sps + cph * cps * sth;
+  const float g10 = (-sph * sps * sth - cps * cph) * Tg, g11 = (cph * sps * cth) * Tg, g12 = cph * sps * sth - cps * sph;
+  const float g20 = -cth * sph * Tg, g21 = -sth * cph * Tg, g22 = cph * cth;
+  // ---- pinv(G) . accel_e, :336-339.  det(G) = T^2 cos(phi): G is regular except at
+  // roll = +-90 deg, where numpy's pinv (rcond 1e-15) also still inverts; adjugate inverse.
+  const float c00 = g11 * g22 - g12 * g21, c01 = g02 * g21 - g01 * g22, c02 = g01 * g12 - g02 * g11;
+  const float c10 = g12 * g20 - g10 * g22, c11 = g00 * g22 - g02 * g20, c12 = g02 * g10 - g00 * g12;
+  const float c20 = g10 * g21 - g11 * g20, c21 = g01 * g20 - g00 * g21, c22 = g00 * g11 - g01 * g10;
+  float det = g00 * c00 + g01 * c10 + g02 * c20;
+  det = copysignf(fmaxf(fabsf(det), 1e-12f), det);
+  const float idet = 1.0f / det;
+  const float inc0 = (c00 * a_e.x + c01 * a_e.y + c02 * a_e.z) * idet;
+  const float inc1 = (c10 * a_e.x + c11 * a_e.y + c12 * a_e.z) * idet;
+  const float inc2 = (c20 * a_e.x + c21 * a_e.y + c22 * a_e.z) * idet;
+  const float yaw_inc = norm_ang(tg.yaw - rpy.z);                           // :341
+  const V3 target_euler = v3(rpy.x + inc0, rpy.y + inc1, rpy.z + yaw_inc);   // :344-346
+  const float thrust = m.last_thrust + inc2;                                 // :347
+  yaw_e = target_euler.z - rpy.z;                                            // :227
+  // ---- _INDIAttitudeControl, :388-402
+  const Q4 tq = quat_from_euler(target_euler);
+  const Q4 q = s.q;
+  float ew = q.w * tq.w + q.x * tq.x + q.y * tq.y + q.z * tq.z;             // quat_inv_comp, math.py:23-31
+  float ex = q.w * tq.x - q.x * tq.w - q.y * tq.z + q.z * tq.y;
+  float ey = q.w * tq.y + q.x * tq.z - q.y * tq.w - q.z * tq.x;
+  float ez = q.w * tq.z - q.x * tq.y + q.y * tq.x - q.z * tq.w;
+  if (ew < 0.0f) { ex = -ex; ey = -ey; ez = -ez; }                           // quat_wrap_shortest, math.py:46-51
+  const V3 rate_sp = v3(T.katt[0] * ex, T.katt[1] * ey, T.katt[2] * ez);
+  // ---- _INDIRateControl, :428-487
+  const M3 R = matrix_from_quat(q);
+  const V3 wb = mulT(R, s.w);
+  float v[4];
+  v[0] = (rate_sp.x - wb.x) * T.krate[0] - (wb.x - m.last_rates.x) * inv_dt;
+  v[1] = (rate_sp.y - wb.y) * T.krate[1] - (wb.y - m.last_rates.y) * inv_dt;
+  v[2] = (rate_sp.z - wb.z) * T.krate[2] - (wb.z - m.last_rates.z) * inv_dt;
+  v[3] = thrust - m.last_thrust;
+  m.last_rates = wb;
+  m.last_thrust = thrust;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                                              // pinv(G1/0.05) . v ; += ; clip
+    const float du = T.alloc[j][0] * v[0] + T.alloc[j][1] * v[1] + T.alloc[j][2] * v[2] + T.alloc[j][3] * v[3];
+    m.cmd[j] = clampf(m.cmd[j] + du, T.pmin[j], T.pmax[j]);
+  }
+}

@@ -1,0 +1,257 @@
+"""Fleet-sized stand-in for the reference's gym surface.
+
+Mirrors ``BaseAviary`` / ``CtrlAviary`` for the hot path only
+(dronesim/envs/BaseAviary.py:406-555 ``reset``/``step``; dronesim/envs/CtrlAviary.py
+``_preprocessAction`` :258-263, ``_computeObs`` :225-232, dummy reward/done/info
+:267-310): same constructor keywords, same ``reset()`` / ``step(action)`` / ``close()``
+contract, same 20/22-wide state vector — but the whole fleet advances in one HIP
+kernel launch and the state lives in HBM as a blocked-SoA tensor.
+
+Rendering, video, GUI sliders, obstacles and the non-quad airframes are outside
+the hot path ("out of scope") and raise if requested.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from enum import Enum
+from typing import Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from ..fleet import Context, FleetState, Targets
+from ..params import DroneType, builtin_type
+
+
+class Physics(Enum):
+    """dronesim/envs/BaseAviary.py:41-49.  Only PYB works in the reference fork
+    (every other branch is dead code there); the add-on terms are
+    exposed here as their intended formulas."""
+
+    PYB = "pyb"
+    DYN = "dyn"
+    PYB_GND = "pyb_gnd"
+    PYB_DRAG = "pyb_drag"
+    PYB_DW = "pyb_dw"
+    PYB_GND_DRAG_DW = "pyb_gnd_drag_dw"
+
+
+# dict-of-ndarray I/O (the reference's format) is produced up to this many drones;
+# beyond it step()/reset() return device tensors.
+DICT_IO_MAX_DRONES = 64
+
+
+class CtrlAviary:
+    """PWM-action fleet environment (reference: ``CtrlAviary``)."""
+
+    def __init__(
+        self,
+        drone_model: Union[Sequence[str], Sequence[DroneType]] = ("tello",),
+        num_drones: int = 1,
+        neighbourhood_radius: float = np.inf,
+        initial_xyzs=None,
+        initial_vels=None,
+        initial_rpys=None,
+        physics: Physics = Physics.PYB,
+        freq: int = 240,
+        aggregate_phy_steps: int = 1,
+        gui=False,
+        record=False,
+        obstacles=False,
+        user_debug_gui=True,
+        *,
+        device: int = 0,
+        layout: str = "soa",
+        noise_seed: Optional[int] = None,
+        dict_io: Optional[bool] = None,
+    ):
+        if gui or record or obstacles:
+            raise NotImplementedError("gui/record/obstacles are rendering features outside the hot path")
+        if physics not in (Physics.PYB,):
+            raise NotImplementedError(f"physics={physics}: only Physics.PYB is wired (the only live branch "
+                                      "of the reference, BaseAviary.py:523-524)")
+        if isinstance(drone_model, (str, DroneType)):
+            drone_model = [drone_model]
+        models = list(drone_model)
+        if len(models) != 1 and len(models) != num_drones:
+            raise ValueError("drone_model must name one model per drone (or one for all)")
+        # type table: unique models in first-seen order
+        self._type_names, types, tid = [], [], np.zeros(num_drones, dtype=np.uint8)
+        for i, m in enumerate(models):
+            key = m if isinstance(m, str) else m.name
+            if key not in self._type_names:
+                self._type_names.append(key)
+                types.append(builtin_type(m) if isinstance(m, str) else m)
+            tid[i] = self._type_names.index(key)
+        self.drones = [types[k] for k in tid] if num_drones <= DICT_IO_MAX_DRONES else None
+        self.types = types
+        self.G = 9.8                                    # BaseAviary.py:182
+        self.SIM_FREQ = freq
+        self.TIMESTEP = 1.0 / freq
+        self.AGGR_PHY_STEPS = aggregate_phy_steps
+        self.NUM_DRONES = num_drones
+        self.NEIGHBOURHOOD_RADIUS = neighbourhood_radius
+        self.PHYSICS = physics
+        if initial_xyzs is None:
+            # the reference crashes on None in this fork (BaseAviary.py:364-367)
+            raise ValueError("initial_xyzs is required: (NUM_DRONES, 3)")
+        self.INIT_XYZS = np.asarray(initial_xyzs, dtype=np.float64).reshape(num_drones, 3)
+        self.INIT_RPYS = (np.zeros((num_drones, 3)) if initial_rpys is None
+                          else np.asarray(initial_rpys, dtype=np.float64).reshape(num_drones, 3))
+        self.INIT_VELS = None if initial_vels is None else np.asarray(initial_vels, np.float64).reshape(num_drones, 3)
+        # the reference adds unseeded rotor noise every sub-step (BaseAviary.py:1518-1525):
+        # None -> fresh seed per env, 0 -> noise off (parity runs), k -> reproducible
+        self.noise_seed = int.from_bytes(os.urandom(7), "little") | 1 if noise_seed is None else int(noise_seed)
+        self.dict_io = (num_drones <= DICT_IO_MAX_DRONES) if dict_io is None else dict_io
+
+        self.ctx = Context(types, device)
+        self.state = FleetState(self.ctx, num_drones, layout)
+        self._type_id = None
+        if len(types) > 1:
+            t = np.zeros(self.state.n_pad, dtype=np.uint8)
+            t[:num_drones] = tid
+            self._type_id = torch.from_numpy(t).to(self.ctx.device)
+        self.n_act = self.ctx.n_act
+        self._action_buf = torch.zeros((self.n_act, self.state.n_pad), dtype=torch.float32, device=self.ctx.device)
+        # the env's own last_clipped_action (BaseAviary.py:660-663, 545): separate from the
+        # controller's cmd memory, exactly as env and controller are separate objects upstream
+        self._last_action = torch.zeros_like(self._action_buf)
+        self._use_last_action = True
+        self._obs_buf = None      # [N, 16+n_act], allocated on the first observe()
+        self.step_counter = 0
+        self._env_steps = 0
+        self._housekeeping()
+
+    # ------------------------------------------------------------------ helpers
+    def _soa3(self, a: np.ndarray) -> torch.Tensor:
+        t = torch.zeros((3, self.state.n_pad), dtype=torch.float32)
+        t[:, : self.NUM_DRONES] = torch.from_numpy(np.ascontiguousarray(a.T)).float()
+        return t.to(self.ctx.device)
+
+    def step_args(self, dt_ctrl: Optional[float] = None, options: int = 0) -> nat.StepArgs:
+        a = nat.StepArgs()
+        a.phys_substeps = self.AGGR_PHY_STEPS
+        a.dt_phys = self.TIMESTEP
+        a.dt_ctrl = dt_ctrl if dt_ctrl is not None else self.TIMESTEP * self.AGGR_PHY_STEPS
+        a.options = options
+        a.noise_seed = self.noise_seed
+        a.step_index = self._env_steps
+        a.noise_replay = None
+        a.type_id = self._type_id.data_ptr() if self._type_id is not None else None
+        a.action = None
+        return a
+
+    # ------------------------------------------------------------------ gym surface
+    def reset(self):
+        """BaseAviary.reset (BaseAviary.py:406-424): housekeeping, then the initial observation."""
+        self._housekeeping()
+        return self._computeObs()
+
+    def _housekeeping(self):
+        """BaseAviary._housekeeping (BaseAviary.py:640-714): zero counters, place every drone."""
+        self.step_counter = 0
+        self._env_steps = 0
+        pos, rpy = self._soa3(self.INIT_XYZS), self._soa3(self.INIT_RPYS)
+        vel = self._soa3(self.INIT_VELS) if self.INIT_VELS is not None else None
+        self._last_action.zero_()                      # BaseAviary.py:660-663
+        self._use_last_action = True
+        nat.check(self.ctx.lib.dsim_reset(
+            self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, self.state.view(), pos.data_ptr(),
+            rpy.data_ptr(), vel.data_ptr() if vel is not None else None, None,
+            self._type_id.data_ptr() if self._type_id is not None else None))
+        torch.cuda.current_stream(self.ctx.device).synchronize()   # host buffers above go out of scope
+
+    def step(self, action):
+        """BaseAviary.step (BaseAviary.py:428-555) with Physics.PYB."""
+        self._load_action(action)
+        args = self.step_args()
+        args.action = self._action_buf.data_ptr()
+        nat.check(self.ctx.lib.dsim_physics(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
+                                            self.state.view(), self._last_action.data_ptr(), ctypes.byref(args)))
+        self._use_last_action = True
+        self.step_counter += self.AGGR_PHY_STEPS
+        self._env_steps += 1
+        return self._computeObs(), self._computeReward(), self._computeDone(), self._computeInfo()
+
+    def step_fused(self, targets: Targets, control_timestep: Optional[float] = None, action=None):
+        """One launch = ``env.step(action)`` followed by ``computeControl`` for every drone:
+        the body of the reference's example loop (examples/fly_INDI.py:223-239).  ``action``
+        None = the controller's last command (every iteration after the first); the first
+        iteration of the example passes its initial action 0.4 (fly_INDI.py:214)."""
+        args = self.step_args(control_timestep, nat.OPT_BCAST_TGT if targets.broadcast else 0)
+        if action is not None:
+            self._load_action(action)
+            args.action = self._action_buf.data_ptr()
+        self._use_last_action = False   # from here on the applied action IS the controller cmd
+        nat.check(self.ctx.lib.dsim_step(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
+                                         self.state.view(), targets.view(), ctypes.byref(args)))
+        self.step_counter += self.AGGR_PHY_STEPS
+        self._env_steps += 1
+
+    def close(self):
+        self.ctx.close()
+
+    def getPyBulletClient(self):
+        return -1   # there is no PyBullet client; kept so example scripts keep running
+
+    # ------------------------------------------------------------------ pieces
+    def _load_action(self, action) -> None:
+        n = self.NUM_DRONES
+        if isinstance(action, dict):                      # CtrlAviary.py:258-263 format
+            a = np.zeros((self.n_act, n), dtype=np.float32)
+            for k, v in action.items():
+                v = np.asarray(v, dtype=np.float32)
+                a[: v.shape[0], int(k)] = v
+            self._action_buf[:, :n] = torch.from_numpy(a).to(self.ctx.device)
+        else:
+            t = torch.as_tensor(action, dtype=torch.float32, device=self.ctx.device)
+            if t.shape == (n, self.n_act):
+                t = t.T
+            self._action_buf[:, :n] = t
+
+    def observe(self) -> torch.Tensor:
+        """[N, 16+n_act] rows of _getDroneStateVector (BaseAviary.py:780-790), on device."""
+        if self._obs_buf is None:
+            self._obs_buf = torch.zeros((self.NUM_DRONES, 16 + self.n_act), dtype=torch.float32, device=self.ctx.device)
+        la = self._last_action.data_ptr() if self._use_last_action else None
+        nat.check(self.ctx.lib.dsim_observe(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
+                                            self.state.view(), la, self._obs_buf.data_ptr(), 16 + self.n_act))
+        return self._obs_buf
+
+    def _getAdjacencyMatrix(self, pos: np.ndarray) -> np.ndarray:
+        """BaseAviary.py:901-921 — O(N^2), only produced in dict mode (small fleets)."""
+        d = np.linalg.norm(pos[:, None, :] - pos[None, :, :], axis=2)
+        adj = (d < self.NEIGHBOURHOOD_RADIUS).astype(np.float64)
+        np.fill_diagonal(adj, 1.0)
+        return adj
+
+    def _computeObs(self):
+        obs = self.observe()
+        if not self.dict_io:
+            return obs
+        o = obs.double().cpu().numpy()
+        self.pos, self.quat, self.rpy = o[:, 0:3], o[:, 3:7], o[:, 7:10]
+        self.vel, self.ang_v = o[:, 10:13], o[:, 13:16]
+        adj = self._getAdjacencyMatrix(self.pos)
+        out = {}
+        for i in range(self.NUM_DRONES):
+            na = self.drones[i].n_act
+            out[str(i)] = {"state": o[i, : 16 + na].copy(), "neighbors": adj[i, :]}
+        return out
+
+    def _getDroneStateVector(self, nth_drone: int) -> np.ndarray:
+        return self.observe()[nth_drone].double().cpu().numpy()
+
+    @staticmethod
+    def _computeReward():
+        return -1                                   # CtrlAviary.py:267-279
+
+    @staticmethod
+    def _computeDone():
+        return False                                # CtrlAviary.py:283-295
+
+    @staticmethod
+    def _computeInfo():
+        return {"answer": 42}                       # CtrlAviary.py:299-310

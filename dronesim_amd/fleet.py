@@ -1,0 +1,168 @@
+"""Fleet state in HBM + the context that owns the per-type constant table.
+
+Host-side plumbing only (PyTorch-ROCm for device memory and streams); all
+arithmetic happens in the HIP kernels behind the C-ABI.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .params import DroneType, types_to_c_array
+
+# field indices (include/dronesim_amd.h DSIM_F_*)
+F_POS, F_QUAT, F_VEL, F_ANGVEL = 0, 3, 7, 10
+F_LAST_VEL, F_LAST_RATES, F_LAST_THRUST, F_CMD = 13, 16, 19, 20
+
+
+def pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+class Context:
+    """One per device: uploads the type table (dsim_create)."""
+
+    def __init__(self, types: Sequence[DroneType], device: int = 0):
+        self.lib = nat.load()
+        if not torch.cuda.is_available():
+            raise nat.DsimError("dronesim_amd needs a HIP device (MI355X); there is no CPU fallback")
+        self.types = list(types)
+        self.device = torch.device("cuda", device)
+        self._h = ctypes.c_void_p()
+        self._c_types = types_to_c_array(self.types)
+        nat.check(self.lib.dsim_create(ctypes.byref(self._h), device, self._c_types, len(self.types)))
+        self.n_act = max(t.n_act for t in self.types)
+        self.n_fields = nat.NF_QUAD if self.n_act <= 4 else nat.NF_HEXA
+
+    @property
+    def handle(self):
+        return self._h
+
+    def stream_ptr(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def close(self):
+        if self._h:
+            self.lib.dsim_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BlockedSoA:
+    """fp32 device array addressed as the C-ABI's blocked SoA.
+
+    layout "soa":    tensor [F, n_pad]            (block = n_pad)
+    layout "tile64": tensor [n_pad/64, F, 64]     (one 64-drone wave tile per block)
+    """
+
+    def __init__(self, n: int, n_fields: int, device, layout: str = "soa"):
+        self.n, self.n_pad, self.n_fields, self.layout = n, pad64(n), n_fields, layout
+        if layout == "soa":
+            self.data = torch.zeros((n_fields, self.n_pad), dtype=torch.float32, device=device)
+        elif layout == "tile64":
+            self.data = torch.zeros((self.n_pad // 64, n_fields, 64), dtype=torch.float32, device=device)
+        else:
+            raise ValueError(layout)
+
+    def view(self) -> nat.View:
+        v = nat.View()
+        v.base = self.data.data_ptr()
+        v.n_pad = self.n_pad
+        v.n_fields = self.n_fields
+        if self.layout == "soa":
+            v.block, v.field_stride, v.block_stride = self.n_pad, self.n_pad, self.n_pad * self.n_fields
+        else:
+            v.block, v.field_stride, v.block_stride = 64, 64, 64 * self.n_fields
+        return v
+
+    def fields(self, f0: int, nf: int) -> torch.Tensor:
+        """[nf, n] tensor of fields f0..f0+nf (a view for "soa", a gather for "tile64")."""
+        if self.layout == "soa":
+            return self.data[f0:f0 + nf, : self.n]
+        return self.data[:, f0:f0 + nf, :].permute(1, 0, 2).reshape(nf, self.n_pad)[:, : self.n]
+
+    def set_fields(self, f0: int, values: torch.Tensor) -> None:
+        """values: [nf, n]"""
+        nf = values.shape[0]
+        vals = values.to(self.data.device, torch.float32)
+        if self.layout == "soa":
+            self.data[f0:f0 + nf, : self.n] = vals
+        else:
+            full = torch.zeros((nf, self.n_pad), dtype=torch.float32, device=self.data.device)
+            full[:, : self.n] = vals
+            self.data[:, f0:f0 + nf, :] = full.reshape(nf, self.n_pad // 64, 64).permute(1, 0, 2)
+
+
+class FleetState(BlockedSoA):
+    """The 13 rigid-body floats Bullet holds per drone (BaseAviary.py:718-732) plus the
+    controller memory of one INDIControl instance per drone (INDIControl.py:109-146)."""
+
+    def __init__(self, ctx: Context, n: int, layout: str = "soa"):
+        super().__init__(n, ctx.n_fields, ctx.device, layout)
+        self.ctx = ctx
+
+    pos = property(lambda s: s.fields(F_POS, 3))
+    quat = property(lambda s: s.fields(F_QUAT, 4))
+    vel = property(lambda s: s.fields(F_VEL, 3))
+    ang_vel = property(lambda s: s.fields(F_ANGVEL, 3))
+    last_vel = property(lambda s: s.fields(F_LAST_VEL, 3))
+    last_rates = property(lambda s: s.fields(F_LAST_RATES, 3))
+    last_thrust = property(lambda s: s.fields(F_LAST_THRUST, 1))
+    cmd = property(lambda s: s.fields(F_CMD, s.n_fields - F_CMD))
+
+    def rigid_aos(self) -> np.ndarray:
+        """[n,13] fp64 host copy (pos3 quat4 vel3 angvel3) — the oracle's layout."""
+        return self.fields(0, 13).T.double().cpu().numpy().copy()
+
+    def mem_aos(self) -> np.ndarray:
+        """[n,13] fp64 host copy (last_vel3 last_rates3 last_thrust cmd6)."""
+        m = np.zeros((self.n, 13))
+        m[:, : self.n_fields - 13] = self.fields(13, self.n_fields - 13).T.double().cpu().numpy()
+        return m
+
+    def load_aos(self, rigid: np.ndarray, mem: np.ndarray) -> None:
+        self.set_fields(0, torch.from_numpy(np.ascontiguousarray(rigid.T)))
+        self.set_fields(13, torch.from_numpy(np.ascontiguousarray(mem[:, : self.n_fields - 13].T)))
+
+
+class Targets(BlockedSoA):
+    """Per-step targets: pos3 vel3 acc3 yaw (INDIControl.computeControl arguments)."""
+
+    def __init__(self, ctx: Context, n: int, layout: str = "soa", broadcast: bool = False):
+        self.broadcast = broadcast
+        if broadcast:
+            self.n, self.n_pad, self.n_fields, self.layout = 1, 64, nat.NT, "soa"
+            self.data = torch.zeros((nat.NT, 1), dtype=torch.float32, device=ctx.device)
+        else:
+            super().__init__(n, nat.NT, ctx.device, layout)
+
+    def view(self) -> nat.View:
+        if not self.broadcast:
+            return super().view()
+        v = nat.View()
+        v.base = self.data.data_ptr()
+        v.n_pad, v.block, v.field_stride, v.block_stride, v.n_fields = 64, 64, 1, nat.NT, nat.NT
+        return v
+
+    def set(self, pos=None, vel=None, acc=None, yaw=None) -> None:
+        """Each argument [3, n] / [n] (per drone) or length-3 / scalar (same for all)."""
+        dev = self.data.device
+        for f0, val, nf in ((0, pos, 3), (3, vel, 3), (6, acc, 3), (9, yaw, 1)):
+            if val is None:
+                continue
+            t = torch.as_tensor(val, dtype=torch.float32, device=dev).reshape(nf, -1)
+            if self.broadcast:
+                self.data[f0:f0 + nf, :] = t
+            else:
+                if t.shape[1] == 1:
+                    t = t.expand(nf, self.n)
+                self.set_fields(f0, t)

@@ -124,6 +124,10 @@ typedef struct dsim_step_args {
   uint64_t step_index;      /* env-step counter, mixed into the noise counter                    */
   const float* noise_replay;/* nullable; [phys_substeps][2*n_act][n_pad] recorded normals (tests)*/
   const uint8_t* type_id;   /* nullable; per-drone index into the ctx type table (mixed fleets)  */
+  const float* action;      /* nullable; SoA [n_act][n_pad].  dsim_step: action for the physics part
+                               instead of the stored cmd (first iteration of the example loop: the
+                               initial action 0.4, fly_INDI.py:214, while INDIControl.cmd starts at 0).
+                               dsim_physics: the action of Env.step(action); NULL = stored cmd.      */
 } dsim_step_args;
 
 typedef struct dsim_ctx dsim_ctx;
@@ -152,12 +156,14 @@ int dsim_reset(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state,
 int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
               const dsim_step_args* args);
 
-/* Env.step() only: physics sub-steps with an externally supplied action
- * (SoA [n_act][n_pad], clipped in-kernel as CtrlAviary._preprocessAction does,
- * CtrlAviary.py:258-263).  action == NULL uses the stored cmd.  The clipped
- * action is echoed into the cmd fields (last_clipped_action, BaseAviary.py:545). */
+/* Env.step() only: physics sub-steps with args->action (clipped in-kernel as
+ * CtrlAviary._preprocessAction does, CtrlAviary.py:258-263; NULL = stored cmd).
+ * The clipped action is written to last_action_out (SoA [n_act][n_pad], nullable):
+ * the env's last_clipped_action (BaseAviary.py:545).  The controller memory
+ * (state cmd fields) is NOT touched: env and controller are separate objects in
+ * the reference.                                                              */
 int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state,
-                 const float* action, const dsim_step_args* args);
+                 float* last_action_out, const dsim_step_args* args);
 
 /* computeControl() only (INDIControl.py:154-227 / INDIControl_6DOF.py:259-336):
  * reads the rigid fields, updates the controller-memory fields and cmd.
@@ -167,9 +173,10 @@ int dsim_control(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_v
 
 /* _getDroneStateVector (BaseAviary.py:764-790): writes the reference's 20/22-wide
  * observation rows [pos3 quat4 rpy3 vel3 ang_v3 last_action] as row-major
- * [n][16+n_act] fp32.                                                            */
-int dsim_observe(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float* obs_out,
-                 int32_t obs_width);
+ * [n][obs_width] fp32, obs_width = 16 + n_act.  last_action: SoA [n_act][n_pad]
+ * (the env's last_clipped_action); NULL = the stored cmd.                        */
+int dsim_observe(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
+                 float* obs_out, int32_t obs_width);
 
 /* error codes */
 enum {

@@ -164,7 +164,7 @@ static void jacobi_svd(const double* A, int m, int n, double* U, double* s, doub
 /* Moore-Penrose pseudo-inverse, numpy semantics: singular values
  * <= rcond * s_max are treated as zero (np.linalg.pinv default rcond=1e-15). */
 void orc_pinv(const double* A, int m, int n, double rcond, double* Ainv /* n x m */) {
-  double At[144], U[144], V[144], s[12];
+  double At[144] = {0}, U[144], V[144], s[12];
   if (m >= n) {
     jacobi_svd(A, m, n, U, s, V);
     double smax = 0;
@@ -727,21 +727,23 @@ int orc_control_batch(const dsim_type_params* types, const uint8_t* type_id, int
   return fail ? -1 : 0;
 }
 
-/* Env.step physics part: substeps with action (NULL = stored cmd); echoes the
- * clipped action into mem.cmd (last_clipped_action, BaseAviary.py:545).
+/* Env.step physics part: substeps with action [n][6] (NULL = the controller's stored
+ * cmd); the clipped action goes to last_action_out [n][6] (nullable): the env's
+ * last_clipped_action, BaseAviary.py:545.  The controller memory is not modified
+ * (env and controller are separate objects in the reference).
  * noise [n][substeps][12] (f_noise6, m_noise6; quad uses [0:4] of each) or NULL. */
 int orc_physics_batch(const dsim_type_params* types, const uint8_t* type_id, int64_t n, int substeps,
-                      double dt, double* rigid, const double* action, double* mem, const double* noise,
-                      uint32_t options, int nthreads) {
+                      double dt, double* rigid, const double* action, const double* mem, const double* noise,
+                      uint32_t options, double* last_action_out, int nthreads) {
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) {
     const dsim_type_params* P = &types[type_id ? type_id[i] : 0];
-    double* m = mem + i * 13;
+    const double* m = mem + i * 13;
     double clipped[DSIM_MAX_ACT] = {0}, last[DSIM_MAX_ACT];
-    memcpy(last, m + 7, sizeof(last));
+    memcpy(last, last_action_out ? last_action_out + i * 6 : m + 7, sizeof(last));
     orc_preprocess_action(P, action ? action + i * 6 : m + 7, clipped);
     for (int s = 0; s < substeps; ++s) {
       double nz[12];
@@ -753,7 +755,7 @@ int orc_physics_batch(const dsim_type_params* types, const uint8_t* type_id, int
       }
       orc_physics_substep(P, dt, rigid + i * 13, clipped, s == 0 ? last : clipped, np_, options);
     }
-    memcpy(m + 7, clipped, sizeof(clipped));
+    if (last_action_out) memcpy(last_action_out + i * 6, clipped, sizeof(clipped));
   }
   return 0;
 }
@@ -761,8 +763,8 @@ int orc_physics_batch(const dsim_type_params* types, const uint8_t* type_id, int
 /* fused Env.step + computeControl, the example loop body (fly_INDI.py:223-239) */
 int orc_step_batch(const dsim_type_params* types, const uint8_t* type_id, int64_t n, int substeps,
                    double dt_phys, double dt_ctrl, double* rigid, double* mem, const double* tgt,
-                   int bcast_tgt, const double* noise, uint32_t options, int nthreads) {
-  orc_physics_batch(types, type_id, n, substeps, dt_phys, rigid, NULL, mem, noise, options, nthreads);
+                   int bcast_tgt, const double* noise, uint32_t options, const double* action, int nthreads) {
+  orc_physics_batch(types, type_id, n, substeps, dt_phys, rigid, action, mem, noise, options, NULL, nthreads);
   return orc_control_batch(types, type_id, n, dt_ctrl, rigid, mem, tgt, bcast_tgt, NULL, NULL, nthreads);
 }
 

@@ -153,10 +153,10 @@ class Oracle:
         self._L.orc_control_batch.argtypes = [TP, _U8, ctypes.c_int64, ctypes.c_double, _D, _D, _D,
                                               ctypes.c_int, _D, _D, ctypes.c_int]
         self._L.orc_physics_batch.argtypes = [TP, _U8, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
-                                              _D, _D, _D, _D, ctypes.c_uint32, ctypes.c_int]
+                                              _D, _D, _D, _D, ctypes.c_uint32, _D, ctypes.c_int]
         self._L.orc_step_batch.argtypes = [TP, _U8, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
                                            ctypes.c_double, _D, _D, _D, ctypes.c_int, _D,
-                                           ctypes.c_uint32, ctypes.c_int]
+                                           ctypes.c_uint32, _D, ctypes.c_int]
 
     def reset_mem(self, n: int, type_id: Optional[np.ndarray] = None) -> np.ndarray:
         mem = np.zeros((n, 13))
@@ -176,20 +176,22 @@ class Oracle:
         return rc, pos_e, yaw_e
 
     def physics(self, rigid, mem, substeps, dt, action=None, noise=None, options=0, type_id=None,
-                nthreads=1):
+                last_action=None, nthreads=1):
+        """action [n,6] (None = stored cmd); last_action [n,6] in/out (env's last_clipped_action)."""
         n = rigid.shape[0]
         act = None if action is None else _c(action)
         nz = None if noise is None else _c(noise)
         return self._L.orc_physics_batch(self._c_types, _p(type_id, _U8), n, substeps, dt, _p(rigid),
-                                         _p(act), _p(mem), _p(nz), options, nthreads)
+                                         _p(act), _p(mem), _p(nz), options, _p(last_action), nthreads)
 
     def step(self, rigid, mem, tgt, substeps, dt_phys, dt_ctrl, noise=None, options=0, type_id=None,
-             nthreads=1):
+             action=None, nthreads=1):
         n = rigid.shape[0]
         bc = int(tgt.shape[0] == 1 and n != 1)
         nz = None if noise is None else _c(noise)
+        act = None if action is None else _c(action)
         return self._L.orc_step_batch(self._c_types, _p(type_id, _U8), n, substeps, dt_phys, dt_ctrl,
-                                      _p(rigid), _p(mem), _p(_c(tgt)), bc, _p(nz), options, nthreads)
+                                      _p(rigid), _p(mem), _p(_c(tgt)), bc, _p(nz), options, _p(act), nthreads)
 
     def noise_normals(self, seed: int, drone: int, sub_counter: int, n_act: int) -> np.ndarray:
         out = np.zeros(2 * n_act)

@@ -1,0 +1,390 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the fp64 CPU oracle and the
+golden vectors.  Tolerance: BASELINE.json's bar, 1e-4 relative per step (fp32 device
+arithmetic vs the fp64 reference arithmetic), relative error defined in tests/util.py.
+"""
+import ctypes
+import math
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from dronesim_amd import params  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from tests.util import MEM_SCALE, RIGID_SCALE, f32, random_fleet, rel_err  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4          # north_star: per-step state within 1e-4 rel-err
+DT = float(np.float32(1.0 / 240.0))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device; the product has no CPU fallback")
+    from dronesim_amd import _native as nat
+    from dronesim_amd import fleet
+    return nat, fleet
+
+
+def _args(nat, substeps, dt_phys, dt_ctrl, options=0, seed=0, step_index=0, replay=None, type_id=None, action=None):
+    a = nat.StepArgs()
+    a.phys_substeps, a.dt_phys, a.dt_ctrl, a.options = substeps, dt_phys, dt_ctrl, options
+    a.noise_seed, a.step_index = seed, step_index
+    a.noise_replay = replay.data_ptr() if replay is not None else None
+    a.type_id = type_id.data_ptr() if type_id is not None else None
+    a.action = action.data_ptr() if action is not None else None
+    return a
+
+
+def _stream(ctx):
+    return ctx.stream_ptr()
+
+
+def _make(gpu, model, n, layout="soa", seed=0, **kw):
+    nat, fleet = gpu
+    t = params.builtin_type(model)
+    ctx = fleet.Context([t])
+    st = fleet.FleetState(ctx, n, layout)
+    tg = fleet.Targets(ctx, n, layout)
+    rigid, mem, tgt = random_fleet(np.random.default_rng(seed), n, **kw)
+    st.load_aos(rigid, mem)
+    tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
+    return t, ctx, st, tg, rigid, mem, tgt
+
+
+# ---------------------------------------------------------------------------
+# computeControl against the reference's golden vectors
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("model", ["robobee", "tello"])
+@pytest.mark.parametrize("layout", ["soa", "tile64"])
+def test_control_vs_golden(gpu, golden_dir, model, layout):
+    nat, fleet = gpu
+    g = np.load(os.path.join(golden_dir, f"indi_single_{model}.npz"))
+    t = params.builtin_type(model)
+    ctx = fleet.Context([t])
+    n = g["pos"].shape[0]
+    rigid = np.concatenate([g["pos"], g["quat"], g["vel"], g["ang_vel"]], 1)
+    mem = np.zeros((n, 13))
+    mem[:, 0:3], mem[:, 3:6], mem[:, 6], mem[:, 7:11] = g["last_vel"], g["last_rates"], g["last_thrust"], g["cmd"]
+    tgt = np.concatenate([g["target_pos"], g["target_vel"], g["target_acc"], g["target_rpy"][:, 2:3]], 1)
+    worst_gentle = 0.0
+    for dt in np.unique(g["dt"]):
+        sel = np.where(g["dt"] == dt)[0]
+        m = len(sel)
+        st = fleet.FleetState(ctx, m, layout)
+        tg = fleet.Targets(ctx, m, layout)
+        st.load_aos(rigid[sel], mem[sel])
+        tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt[sel].T)))
+        pos_e = torch.zeros((3, st.n_pad), device=ctx.device)
+        yaw_e = torch.zeros((st.n_pad,), device=ctx.device)
+        a = _args(nat, 0, float(dt), float(dt))
+        nat.check(ctx.lib.dsim_control(ctx.handle, _stream(ctx), m, st.view(), tg.view(), ctypes.byref(a),
+                                       pos_e.data_ptr(), yaw_e.data_ptr()))
+        torch.cuda.synchronize()
+        got = st.mem_aos()
+        # conditioning of the G inverse: det(G) = T^2 cos(roll); fp32 input rounding is amplified by 1/|cos(roll)|
+        roll = np.array([orc.euler_from_quat(q)[0] for q in g["quat"][sel]])
+        amp = 1.0 / np.maximum(np.abs(np.cos(roll)), 1e-3)
+        err_cmd = np.abs(got[:, 7:11] - g["cmd_out"][sel]).max(1)
+        assert (err_cmd <= REL_TOL * (1 + amp)).all(), (model, dt, err_cmd.max(), sel[np.argmax(err_cmd)])
+        gentle = sel >= n // 2        # second half of the fixture: near-hover, unsaturated cases
+        worst_gentle = max(worst_gentle, err_cmd[gentle].max())
+        np.testing.assert_allclose(pos_e[:, :m].T.cpu().numpy(), g["pos_e"][sel], rtol=0, atol=2e-6)
+        dy = np.abs(yaw_e[:m].cpu().numpy() - g["yaw_e"][sel])
+        dy = np.minimum(dy, np.abs(dy - 2 * math.pi))   # +-pi wrap may flip under fp32 rounding
+        assert dy.max() < 2e-5, dy.max()
+        np.testing.assert_allclose(got[:, 0:3], f32(g["last_vel_out"][sel]), rtol=0, atol=0)
+        np.testing.assert_allclose(got[:, 3:6], g["last_rates_out"][sel], rtol=0, atol=3e-6)
+        err_thr = np.abs(got[:, 6] - g["last_thrust_out"][sel])
+        assert (err_thr <= REL_TOL * (1 + np.abs(g["last_thrust_out"][sel])) * (1 + amp)).all()
+    assert worst_gentle < 2e-5, worst_gentle   # unsaturated cmd increments pinned to ~fp32 rounding
+    ctx.close()
+
+
+@pytest.mark.parametrize("model", ["robobee", "tello"])
+def test_control_sequence_vs_golden(gpu, golden_dir, model):
+    """Controller memory recursion over 60 calls (reference-generated sequence)."""
+    nat, fleet = gpu
+    g = np.load(os.path.join(golden_dir, f"indi_sequence_{model}.npz"))
+    t = params.builtin_type(model)
+    ctx = fleet.Context([t])
+    S, K = g["pos"].shape[:2]
+    st = fleet.FleetState(ctx, S)
+    tg = fleet.Targets(ctx, S)
+    mem0 = orc.Oracle([t]).reset_mem(S)
+    st.load_aos(np.zeros((S, 13)), mem0)
+    dt = float(g["dt"])
+    for k in range(K):
+        rigid = np.concatenate([g["pos"][:, k], g["quat"][:, k], g["vel"][:, k], g["ang_vel"][:, k]], 1)
+        tgt = np.concatenate([g["target_pos"][:, k], g["target_vel"][:, k], g["target_acc"][:, k],
+                              g["target_rpy"][:, k, 2:3]], 1)
+        st.set_fields(0, torch.from_numpy(np.ascontiguousarray(rigid.T)))
+        tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
+        a = _args(nat, 0, dt, dt)
+        nat.check(ctx.lib.dsim_control(ctx.handle, _stream(ctx), S, st.view(), tg.view(), ctypes.byref(a), None, None))
+        got = st.mem_aos()
+        assert np.abs(got[:, 7:11] - g["cmd_out"][:, k]).max() < 1e-4, k
+        assert np.abs(got[:, 6] - g["last_thrust_out"][:, k]).max() < 1e-4 * (1 + np.abs(g["last_thrust_out"][:, k]).max()), k
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------
+# fused Env.step + computeControl against the oracle
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("model,substeps,layout", [("robobee", 5, "soa"), ("robobee", 1, "tile64"),
+                                                   ("tello", 2, "soa"), ("tello", 5, "tile64")])
+def test_fused_step_vs_oracle(gpu, model, substeps, layout):
+    nat, fleet = gpu
+    n = 4096 + 17                      # ragged: not a multiple of 64
+    t, ctx, st, tg, rigid, mem, tgt = _make(gpu, model, n, layout, seed=3)
+    O = orc.Oracle([t])
+    dtc = float(np.float32(substeps / 240.0))
+    a = _args(nat, substeps, DT, dtc)
+    nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
+    assert O.step(rigid, mem, tgt, substeps, DT, dtc) == 0
+    er = rel_err(st.rigid_aos(), rigid, RIGID_SCALE)
+    em = rel_err(st.mem_aos(), mem, MEM_SCALE)
+    assert er.max() < REL_TOL, (er.max(), np.unravel_index(er.argmax(), er.shape))
+    assert em.max() < REL_TOL, (em.max(), np.unravel_index(em.argmax(), em.shape))
+    ctx.close()
+
+
+def test_fused_step_broadcast_target(gpu):
+    nat, fleet = gpu
+    n = 1000
+    t, ctx, st, tg, rigid, mem, tgt = _make(gpu, "robobee", n, seed=5, spread=3.0)
+    bt = fleet.Targets(ctx, n, broadcast=True)
+    one = f32(np.array([[0.0, 0.0, 0.5, 0.1, 0, 0, 0, 0, 0.05, 0.4]]))
+    bt.set(pos=one[0, 0:3], vel=one[0, 3:6], acc=one[0, 6:9], yaw=one[0, 9])
+    a = _args(nat, 5, DT, float(np.float32(5 / 240)), options=nat.OPT_BCAST_TGT)
+    nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), bt.view(), ctypes.byref(a)))
+    O = orc.Oracle([t])
+    assert O.step(rigid, mem, one, 5, DT, float(np.float32(5 / 240))) == 0
+    assert rel_err(st.rigid_aos(), rigid, RIGID_SCALE).max() < REL_TOL
+    assert rel_err(st.mem_aos(), mem, MEM_SCALE).max() < REL_TOL
+    ctx.close()
+
+
+def test_physics_only_vs_oracle(gpu):
+    """Env.step(action): explicit action clipped in-kernel, echoed to last_action, controller memory untouched."""
+    nat, fleet = gpu
+    n = 2048
+    t, ctx, st, tg, rigid, mem, tgt = _make(gpu, "robobee", n, seed=7)
+    rng = np.random.default_rng(8)
+    act = f32(rng.uniform(-0.2, 1.2, (n, 4)))            # some outside [0,1] -> clipped
+    act_dev = torch.zeros((4, st.n_pad), device=ctx.device)
+    act_dev[:, :n] = torch.from_numpy(act.T).float()
+    echo = torch.full((4, st.n_pad), -7.0, device=ctx.device)
+    a = _args(nat, 5, DT, DT, action=act_dev)
+    nat.check(ctx.lib.dsim_physics(ctx.handle, _stream(ctx), n, st.view(), echo.data_ptr(), ctypes.byref(a)))
+    O = orc.Oracle([t])
+    a6 = np.zeros((n, 6)); a6[:, :4] = act
+    last = np.zeros((n, 6))
+    mem_before = mem.copy()
+    O.physics(rigid, mem, 5, DT, action=a6, last_action=last)
+    assert rel_err(st.rigid_aos(), rigid, RIGID_SCALE).max() < REL_TOL
+    np.testing.assert_array_equal(echo[:, :n].T.cpu().numpy(), np.clip(act, 0, 1).astype(np.float32))
+    np.testing.assert_array_equal(last[:, :4], np.clip(act, 0, 1))
+    np.testing.assert_array_equal(st.mem_aos(), mem_before)          # controller memory untouched
+    ctx.close()
+
+
+def test_hover_trajectory_vs_oracle(gpu):
+    """Config 1 (examples/fly_INDI.py defaults): 1 robobee from (0,1,0.5) to (0,0,0.5), yaw ramp,
+    initial action 0.4, 5 sub-steps per control, 2 s = 96 env steps; trajectory vs the oracle."""
+    nat, fleet = gpu
+    from dronesim_amd.envs import CtrlAviary
+    env = CtrlAviary(["robobee"], 1, initial_xyzs=np.array([[0.0, 1.0, 0.5]]), initial_rpys=np.zeros((1, 3)),
+                     aggregate_phy_steps=5, noise_seed=0)
+    tg = fleet.Targets(env.ctx, 1)
+    t = params.builtin_type("robobee")
+    O = orc.Oracle([t])
+    rigid, mem = env.state.rigid_aos(), env.state.mem_aos()
+    dtc = float(np.float32(5 / 240))
+    worst = 0.0
+    for k in range(96):
+        yaw = float(np.float32(0.4 + k / 200.0))
+        tgt = f32(np.array([[0, 0, 0.5, 0, 0, 0, 0, 0, 0, yaw]]))
+        tg.set(pos=tgt[0, 0:3], yaw=yaw)
+        act = np.full((1, 4), 0.4) if k == 0 else None
+        env.step_fused(tg, control_timestep=dtc, action=act)
+        a6 = None
+        if k == 0:
+            a6 = np.zeros((1, 6)); a6[:, :4] = 0.4
+        assert O.step(rigid, mem, tgt, 5, DT, dtc, action=a6) == 0
+        worst = max(worst, rel_err(env.state.rigid_aos(), rigid, RIGID_SCALE).max())
+    # feedback keeps fp32/fp64 trajectories together; allow 10x the per-step bar over 96 steps
+    assert worst < 1e-3, worst
+    assert np.linalg.norm(rigid[0, 0:2]) < 0.9          # it really flew towards the target
+    env.close()
+
+
+def test_noise_replay_vs_oracle(gpu):
+    nat, fleet = gpu
+    n, sub = 512, 5
+    t, ctx, st, tg, rigid, mem, tgt = _make(gpu, "robobee", n, seed=11)
+    rng = np.random.default_rng(12)
+    fn = f32(rng.normal(0, 0.01, (n, sub, 4)))
+    mn = f32(rng.normal(0, 0.001, (n, sub, 4)))
+    replay = torch.zeros((sub, 8, st.n_pad), device=ctx.device)
+    replay[:, 0:4, :n] = torch.from_numpy(fn.transpose(1, 2, 0)).float()
+    replay[:, 4:8, :n] = torch.from_numpy(mn.transpose(1, 2, 0)).float()
+    a = _args(nat, sub, DT, float(np.float32(sub / 240)), replay=replay)
+    nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
+    nz = np.zeros((n, sub, 12))
+    nz[:, :, 0:4], nz[:, :, 6:10] = fn, mn
+    O = orc.Oracle([t])
+    assert O.step(rigid, mem, tgt, sub, DT, float(np.float32(sub / 240)), noise=nz) == 0
+    assert rel_err(st.rigid_aos(), rigid, RIGID_SCALE).max() < REL_TOL
+    assert rel_err(st.mem_aos(), mem, MEM_SCALE).max() < REL_TOL
+    ctx.close()
+
+
+def test_inkernel_noise_matches_definition(gpu):
+    """In-kernel Philox/Box-Muller noise == the oracle's restatement of the same definition;
+    and it is N(0,.01)/N(0,.001)-distributed."""
+    nat, fleet = gpu
+    n, sub, seed, step_index = 256, 3, 0x1234ABCD5, 7
+    t, ctx, st, tg, rigid, mem, tgt = _make(gpu, "robobee", n, seed=13)
+    a = _args(nat, sub, DT, float(np.float32(sub / 240)), seed=seed, step_index=step_index)
+    nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
+    O = orc.Oracle([t])
+    nz = np.zeros((n, sub, 12))
+    for i in range(n):
+        for s in range(sub):
+            u = O.noise_normals(seed, i, step_index * sub + s, 4)
+            nz[i, s, 0:4] = u[0:4] * 0.01
+            nz[i, s, 6:10] = u[4:8] * 0.001
+    assert abs(nz[:, :, 0:4].std() - 0.01) < 1e-3 and abs(nz[:, :, 0:4].mean()) < 1e-3
+    assert O.step(rigid, mem, tgt, sub, DT, float(np.float32(sub / 240)), noise=nz) == 0
+    assert rel_err(st.rigid_aos(), rigid, RIGID_SCALE).max() < REL_TOL
+    assert rel_err(st.mem_aos(), mem, MEM_SCALE).max() < REL_TOL
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------
+# size-independent properties at BASELINE sizes
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [65536, 1 << 20])
+def test_full_size_properties(gpu, n):
+    nat, fleet = gpu
+    t, ctx, st, tg, rigid, mem, tgt = _make(gpu, "robobee", n, seed=21)
+    st2 = fleet.FleetState(ctx, n, "tile64")
+    tg2 = fleet.Targets(ctx, n, "tile64")
+    st2.load_aos(rigid, mem)
+    tg2.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
+    # permuted copy of the same fleet
+    perm = np.random.default_rng(22).permutation(n)
+    st3 = fleet.FleetState(ctx, n)
+    tg3 = fleet.Targets(ctx, n)
+    st3.load_aos(rigid[perm], mem[perm])
+    tg3.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt[perm].T)))
+    for k in range(4):
+        a = _args(nat, 5, DT, float(np.float32(5 / 240)))
+        for s_, t_ in ((st, tg), (st2, tg2), (st3, tg3)):
+            nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, s_.view(), t_.view(), ctypes.byref(a)))
+    A = st.fields(0, 24).cpu().numpy()
+    B = st2.fields(0, 24).cpu().numpy()
+    C = st3.fields(0, 24).cpu().numpy()
+    assert np.isfinite(A).all()
+    np.testing.assert_array_equal(A, B)                 # layout does not change a single bit
+    np.testing.assert_array_equal(A[:, perm], C)        # drones are independent: permutation-equivariant
+    qn = np.linalg.norm(A[3:7], axis=0)
+    assert np.abs(qn - 1).max() < 1e-6                  # quaternion stays unit
+    assert (A[20:24] >= 0).all() and (A[20:24] <= 1).all()   # PWM clip
+    # spot-check 2048 drones of the big fleet against the oracle over the same 4 steps
+    idx = np.random.default_rng(23).choice(n, 2048, replace=False)
+    r, m, tg_ = rigid[idx].copy(), mem[idx].copy(), tgt[idx].copy()
+    O = orc.Oracle([t])
+    for k in range(4):
+        assert O.step(r, m, tg_, 5, DT, float(np.float32(5 / 240))) == 0
+    assert rel_err(A[:13, idx].T.astype(np.float64), r, RIGID_SCALE).max() < 4 * REL_TOL
+    ctx.close()
+
+
+def test_hover_equilibrium_and_determinism(gpu):
+    nat, fleet = gpu
+    t = params.builtin_type("robobee")
+    ctx = fleet.Context([t])
+    n = 4096
+    st = fleet.FleetState(ctx, n)
+    rigid = np.zeros((n, 13)); rigid[:, 2] = 0.5; rigid[:, 6] = 1.0
+    mem = np.zeros((n, 13)); mem[:, 7:11] = t.hover_pwm
+    st.load_aos(rigid, mem)
+    a = _args(nat, 240, DT, DT)
+    nat.check(ctx.lib.dsim_physics(ctx.handle, _stream(ctx), n, st.view(), None, ctypes.byref(a)))
+    out = st.rigid_aos()
+    assert np.abs(out[:, 0:3] - rigid[:, 0:3]).max() < 1e-4     # thrust == weight: stays put for 1 s
+    assert np.abs(out[:, 7:13]).max() < 1e-4
+    assert (out == out[0]).all()                               # identical drones -> identical bits
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------
+# the reference-shaped Python surfaces
+# ---------------------------------------------------------------------------
+def test_env_and_controller_surfaces(gpu):
+    """Example-style loop (examples/fly_INDI.py:217-239) through CtrlAviary.step + INDIControl.
+    computeControlFromState, against the oracle doing the same calls."""
+    from dronesim_amd.control import INDIControl
+    from dronesim_amd.envs import CtrlAviary
+    n = 3
+    xyz = np.array([[0.0, 1.0, 0.5], [1.0, 0.0, 0.7], [-1.0, 0.5, 1.0]])
+    env = CtrlAviary(["robobee"] * n, n, initial_xyzs=xyz, initial_rpys=np.zeros((n, 3)),
+                     aggregate_phy_steps=5, noise_seed=0)
+    ctrl = INDIControl("robobee", num_drones=n)
+    obs = env.reset()
+    assert set(obs.keys()) == {"0", "1", "2"} and obs["0"]["state"].shape == (20,)
+    assert obs["1"]["neighbors"].shape == (n,)
+    np.testing.assert_allclose(obs["2"]["state"][0:3], xyz[2], atol=1e-6)
+    np.testing.assert_array_equal(obs["0"]["state"][16:20], 0.0)        # last_clipped_action starts at 0
+    t = params.builtin_type("robobee")
+    O = orc.Oracle([t])
+    rigid = np.concatenate([xyz, np.tile([0, 0, 0, 1.0], (n, 1)), np.zeros((n, 6))], 1)
+    mem = O.reset_mem(n)
+    last = np.zeros((n, 6))
+    action = {str(i): np.array([0.4, 0.4, 0.4, 0.4]) for i in range(n)}
+    dtc = float(np.float32(5 / 240))
+    tgt = f32(np.tile([0, 0, 0.5, 0, 0, 0, 0, 0, 0, 0.4], (n, 1)))
+    for k in range(12):
+        obs, reward, done, info = env.step(action)
+        assert reward == -1 and done is False and info == {"answer": 42}
+        states = np.stack([obs[str(i)]["state"] for i in range(n)])
+        cmd, pos_e, yaw_e = ctrl.computeControlFromState(dtc, states, target_pos=np.array([0, 0, 0.5]),
+                                                         target_rpy=np.array([0, 0, 0.4]))
+        action = {str(i): cmd[i].cpu().numpy() for i in range(n)}
+        a6 = np.zeros((n, 6)); a6[:, :4] = 0.4 if k == 0 else mem[:, 7:11]
+        O.physics(rigid, mem, 5, DT, action=a6, last_action=last)
+        np.testing.assert_allclose(states[:, 16:20], last[:, :4], atol=1e-7)
+        # the host loop round-trips the state through the fp32 observation, as the oracle input does here
+        r32 = f32(rigid)
+        rc, pe, ye = O.control(r32, mem, tgt, dtc)
+        assert rc == 0
+        assert np.abs(cmd.cpu().numpy() - mem[:, 7:11]).max() < 2e-4, k
+        np.testing.assert_allclose(pos_e.cpu().numpy(), pe, atol=1e-5)
+    assert rel_err(states[:, [0, 1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, 15]], rigid, RIGID_SCALE).max() < 1e-3
+    # single-drone call returns the reference's shapes
+    c1, pe1, ye1 = ctrl.computeControlFromState(dtc, states[0], target_pos=np.array([0, 0, 0.5]))
+    assert c1.shape == (4,) and pe1.shape == (3,) and isinstance(ye1, float)
+    env.close()
+
+
+def test_abi_argument_errors(gpu):
+    nat, fleet = gpu
+    t = params.builtin_type("robobee")
+    ctx = fleet.Context([t])
+    st = fleet.FleetState(ctx, 64)
+    tg = fleet.Targets(ctx, 64)
+    bad = st.view(); bad.n_pad = 65
+    a = _args(nat, 1, DT, DT)
+    assert ctx.lib.dsim_step(ctx.handle, _stream(ctx), 64, bad, tg.view(), ctypes.byref(a)) == -2   # DSIM_E_LAYOUT
+    assert ctx.lib.dsim_step(ctx.handle, _stream(ctx), 0, st.view(), tg.view(), ctypes.byref(a)) == -1
+    assert ctx.lib.dsim_step(None, _stream(ctx), 64, st.view(), tg.view(), ctypes.byref(a)) == -1
+    a.dt_phys = 0.0
+    assert ctx.lib.dsim_step(ctx.handle, _stream(ctx), 64, st.view(), tg.view(), ctypes.byref(a)) == -1
+    assert b"layout" in ctx.lib.dsim_strerror(-2)
+    ctx.close()
