@@ -96,6 +96,19 @@ class Fleet:
         return wall, e0.elapsed_time(e1) * 1e-3
 
 
+def host_threads():
+    """Threads this process may really use: affinity mask, cgroup CPU quota, and the GPU
+    box's per-GPU CPU share (16) — not the host's raw core count."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(substeps, seconds=8.0):
     """The fp64 oracle (a scalar C port of the same step) timed on the host cores on a
     bounded sample of the same workload."""
@@ -110,15 +123,14 @@ def cpu_baseline(substeps, seconds=8.0):
     tgt = np.concatenate([xyz, np.zeros((n, 6)), np.full((n, 1), 0.4)], 1)
     dt = 1.0 / 240.0
     out = {}
-    for label, nth in (("1", 1), ("all", O.max_threads())):
+    for label, nth in (("1", 1), ("all", host_threads())):
         sub_n = 8192 if nth == 1 else n
         r, m, tg = rigid[:sub_n].copy(), mem[:sub_n].copy(), tgt[:sub_n].copy()
-        t0 = time.perf_counter(); O.step(r, m, tg, substeps, dt, substeps * dt, nthreads=nth)
-        per = time.perf_counter() - t0
-        k = max(1, int(seconds / max(per, 1e-6)))
-        t0 = time.perf_counter()
-        for _ in range(k):
+        O.step(r, m, tg, substeps, dt, substeps * dt, nthreads=nth)      # thread pool start-up, untimed
+        k, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:                        # bounded sample
             O.step(r, m, tg, substeps, dt, substeps * dt, nthreads=nth)
+            k += 1
         el = time.perf_counter() - t0
         out[label] = (sub_n * k / el, nth, sub_n, k, el)
     v_all, nth, sub_n, k, el = out["all"]

@@ -66,6 +66,9 @@ def load() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()'). dronesim_amd has no CPU fallback.")
+    # torch first: its wheel bundles the HIP runtime; loading ours afterwards binds to that same
+    # libamdhip64 instead of pulling a second runtime into the process
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
     lib.dsim_abi_version.restype = ctypes.c_int

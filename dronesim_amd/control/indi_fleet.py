@@ -25,7 +25,7 @@ from ..params import DroneType, builtin_type
 def _as3(x, n, device) -> torch.Tensor:
     """-> [3, n] float32 device tensor from (3,), (n,3) or (3,n) input."""
     t = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x, dtype=torch.float32, device=device)
-    if t.ndim == 1:
+    if t.numel() == 3:
         return t.reshape(3, 1).expand(3, n)
     if t.shape == (n, 3):
         return t.T
@@ -110,7 +110,7 @@ class INDIControl(BaseControl):
             st.set_fields(0, _as3(cur_pos, n, dev))
             q = torch.as_tensor(np.asarray(cur_quat) if not torch.is_tensor(cur_quat) else cur_quat,
                                 dtype=torch.float32, device=dev)
-            st.set_fields(3, q.reshape(4, 1).expand(4, n) if q.ndim == 1 else (q.T if q.shape == (n, 4) else q))
+            st.set_fields(3, q.reshape(4, 1).expand(4, n) if q.numel() == 4 else (q.T if q.shape == (n, 4) else q))
             st.set_fields(7, _as3(cur_vel, n, dev))
             st.set_fields(10, _as3(cur_ang_vel, n, dev))
         yaw = torch.as_tensor(np.asarray(target_rpy) if not torch.is_tensor(target_rpy) else target_rpy,

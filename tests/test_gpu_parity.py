@@ -368,7 +368,8 @@ def test_env_and_controller_surfaces(gpu):
         np.testing.assert_allclose(pos_e.cpu().numpy(), pe, atol=1e-5)
     assert rel_err(states[:, [0, 1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, 15]], rigid, RIGID_SCALE).max() < 1e-3
     # single-drone call returns the reference's shapes
-    c1, pe1, ye1 = ctrl.computeControlFromState(dtc, states[0], target_pos=np.array([0, 0, 0.5]))
+    ctrl1 = INDIControl("robobee")       # one controller per drone, as in the reference (fly_INDI.py:210)
+    c1, pe1, ye1 = ctrl1.computeControlFromState(dtc, states[0], target_pos=np.array([0, 0, 0.5]))
     assert c1.shape == (4,) and pe1.shape == (3,) and isinstance(ye1, float)
     env.close()
 
