@@ -1,0 +1,207 @@
+"""Analytic known-answer tests that pin the oracle's rigid-body half.
+
+The reference delegates integration to PyBullet (absent, unpinned) and has no tests, so the
+physics half of the oracle is "parity unpinned" against the reference itself; what pins it
+are these closed-form checks of the restated Bullet step semantics.  CPU only.
+"""
+import math
+
+import numpy as np
+
+from dronesim_amd import params
+from oracle import oracle as orc
+
+DT = 1.0 / 240.0
+
+
+def _O(model="robobee"):
+    t = params.builtin_type(model)
+    return t, orc.Oracle([t])
+
+
+def _rest(n=1, z=0.5):
+    r = np.zeros((n, 13)); r[:, 2] = z; r[:, 6] = 1.0
+    return r
+
+
+def test_free_fall_one_step_hand_calculation():
+    """(1) zero thrust: v1 = -g dt (no damping at v=0), z1 = z0 + v1 dt (semi-implicit);
+    second step includes the damping c(1+|v|)v with c = 0.04f."""
+    t, O = _O()
+    r, m = _rest(), O.reset_mem(1)          # cmd = 0 -> zero thrust
+    O.physics(r, m, 1, DT)
+    v1 = -9.8 * DT
+    assert r[0, 9] == v1 and r[0, 2] == 0.5 + v1 * DT       # exact: same fp64 operations
+    O.physics(r, m, 1, DT)
+    c = float(np.float32(0.04))
+    v2 = v1 + (-9.8 - c * (1 + abs(v1)) * v1) * DT
+    np.testing.assert_allclose(r[0, 9], v2, rtol=1e-15)
+    np.testing.assert_allclose(r[0, 2], 0.5 + v1 * DT + v2 * DT, rtol=1e-15)
+    np.testing.assert_array_equal(r[0, 3:7], [0, 0, 0, 1])  # no rotation appears
+
+
+def test_terminal_velocity_of_damped_fall():
+    """(1b) long fall converges to g = c(1+v)v  =>  v = (-1 + sqrt(1+4g/c))/2."""
+    t, O = _O()
+    r, m = _rest(z=1e5), O.reset_mem(1)
+    O.physics(r, m, 240 * 60, DT)
+    c = float(np.float32(0.04))
+    vt = (-1 + math.sqrt(1 + 4 * 9.8 / c)) / 2
+    np.testing.assert_allclose(-r[0, 9], vt, rtol=1e-9)
+
+
+def test_hover_equilibrium():
+    """(2) sum F = m g  =>  zero acceleration (robobee rpm ~ 9585, PWM ~ 0.479)."""
+    t, O = _O()
+    assert abs(t.hover_pwm - 0.4793) < 1e-3
+    r, m = _rest(), O.reset_mem(1)
+    m[:, 7:11] = t.hover_pwm
+    O.physics(r, m, 240, DT)
+    assert np.abs(r[0, 7:13]).max() < 1e-12 and abs(r[0, 2] - 0.5) < 1e-12
+
+
+def test_single_rotor_first_step():
+    """(3) one rotor on: dw = J^-1 (r x F + yaw torque) dt from rest, dv = (F/m - g) dt."""
+    t, O = _O()
+    r, m = _rest(), O.reset_mem(1)
+    m[0, 7] = 0.5                       # rotor 0 at (+.11,+.11,0), spin sign -1
+    O.physics(r, m, 1, DT)
+    rpm = 20000 * 0.5
+    F, tq = t.kf * rpm ** 2, t.km * rpm ** 2
+    tau = np.cross(t.rotor_pos[0], [0, 0, F]) + np.array([0, 0, -tq])
+    np.testing.assert_allclose(r[0, 10:13], tau / np.array(t.inertia) * DT, rtol=1e-14)
+    np.testing.assert_allclose(r[0, 9], (F / t.mass - 9.8) * DT, rtol=1e-14)
+
+
+def test_yaw_torque_sign_convention():
+    """(5) z torque = -t0 + t1 - t2 + t3 (BaseAviary.py:1527): speeding rotors 1,3 yaws positive."""
+    t, O = _O("tello")                  # symmetric arms: no roll/pitch torque from equal pairs
+    for hi, sign in (((1, 3), +1), ((0, 2), -1)):
+        r, m = _rest(), O.reset_mem(1)
+        m[0, 7:11] = 0.4
+        for j in hi:
+            m[0, 7 + j] = 0.6
+        O.physics(r, m, 1, DT)
+        assert np.sign(r[0, 12]) == sign and abs(r[0, 10]) < 1e-12 and abs(r[0, 11]) < 1e-12
+
+
+def test_torque_free_spin_about_principal_axis():
+    """(4) spin about z with hover thrust: w decays only by damping, attitude advances by the exact
+    axis-angle of each step: yaw(k) = sum_k w_k dt."""
+    t, O = _O()
+    r, m = _rest(), O.reset_mem(1)
+    m[:, 7:11] = t.hover_pwm
+    w = 3.0
+    r[0, 12] = w
+    c = float(np.float32(0.04))
+    yaw = 0.0
+    for _ in range(100):
+        O.physics(r, m, 1, DT)
+        w = w - c * (1 + abs(w)) * w * DT
+        yaw += w * DT
+        np.testing.assert_allclose(r[0, 12], w, rtol=1e-13)
+        np.testing.assert_allclose(orc.euler_from_quat(r[0, 3:7])[2], yaw, rtol=1e-12)
+    assert abs(r[0, 10]) < 1e-15 and abs(r[0, 11]) < 1e-15
+
+
+def test_gyroscopic_term_conserves_momentum_direction():
+    """Torque-free tumbling of an asymmetric-spin state, damping removed: |L| (world) is conserved
+    to first order by the body-frame gyroscopic term w x Jw."""
+    t = params.builtin_type("robobee")
+    t.lin_damping = t.ang_damping = 0.0
+    O = orc.Oracle([t])
+    r, m = _rest(), O.reset_mem(1)
+    m[:, 7:11] = t.hover_pwm
+    r[0, 10:13] = [2.0, 0.5, 3.0]
+    J = np.array(t.inertia)
+
+    def L(r):
+        R = orc.matrix_from_quat(r[0, 3:7])
+        return R @ (J * (R.T @ r[0, 10:13]))
+
+    L0 = L(r)
+    O.physics(r, m, 480, DT / 8)
+    assert np.linalg.norm(L(r) - L0) / np.linalg.norm(L0) < 2e-2      # explicit Euler drift only
+    t2 = params.builtin_type("robobee"); t2.lin_damping = t2.ang_damping = 0.0
+    t2.inertia = (1e-3, 1e-3, 1e-3)                                   # sphere: no gyroscopic torque at all
+    O2 = orc.Oracle([t2])
+    r2 = _rest(); r2[0, 10:13] = [2.0, 0.5, 3.0]
+    O2.physics(r2, m, 100, DT)
+    np.testing.assert_allclose(r2[0, 10:13], [2.0, 0.5, 3.0], rtol=1e-12)
+
+
+def test_semi_implicit_ordering():
+    """(6) position uses the UPDATED velocity: x1 = x0 + (v0 + a dt) dt."""
+    t, O = _O()
+    r, m = _rest(), O.reset_mem(1)
+    m[:, 7:11] = t.hover_pwm
+    r[0, 7] = 1.0
+    c = float(np.float32(0.04))
+    v1 = 1.0 - c * 2.0 * 1.0 * DT
+    O.physics(r, m, 1, DT)
+    np.testing.assert_allclose(r[0, 7], v1, rtol=1e-15)
+    np.testing.assert_allclose(r[0, 0], v1 * DT, rtol=1e-15)
+
+
+def test_quaternion_stays_unit_and_angle_clamp():
+    """(7) unit norm after 1e5 steps; angular motion per step clamped to pi/4; velocity clamp 100."""
+    t, O = _O()
+    r, m = _rest(z=1e6), O.reset_mem(1)
+    m[0, 7:11] = [0.55, 0.45, 0.5, 0.48]
+    r[0, 10:13] = [0.3, -0.2, 0.5]
+    O.physics(r, m, 100000, DT)
+    assert abs(np.linalg.norm(r[0, 3:7]) - 1) < 1e-14
+    assert np.isfinite(r).all() and np.abs(r[0, 7:13]).max() <= 100.0
+    # |w| dt > pi/4: Bullet clamps the ANGLE used in sin/cos to pi/4 but scales the unclamped
+    # angular velocity by sin(pi/8)/fAngle_clamped, then normalises (btTransformUtil quirk, kept):
+    # rotation = 2 atan2(|w| sin(pi/8)/fA, cos(pi/8)), fA = (pi/4)/dt
+    t2 = params.builtin_type("robobee"); t2.lin_damping = t2.ang_damping = 0.0
+    O2 = orc.Oracle([t2])
+    r2 = _rest(); r2[0, 12] = 90.0                 # 90 rad/s * 1/50 s = 1.8 rad > pi/4
+    m2 = O2.reset_mem(1); m2[:, 7:11] = t2.hover_pwm
+    O2.physics(r2, m2, 1, 1 / 50)
+    fA = (math.pi / 4) / (1 / 50)
+    expect = 2 * math.atan2(90.0 * math.sin(math.pi / 8) / fA, math.cos(math.pi / 8))
+    np.testing.assert_allclose(orc.euler_from_quat(r2[0, 3:7])[2], expect, rtol=1e-12)
+    assert expect < 1.8                            # less than the unclamped 1.8 rad
+    r3 = _rest(); r3[0, 10] = 250.0
+    O2.physics(r3, m2, 1, DT)
+    assert r3[0, 10] == 100.0                      # maxCoordinateVelocity clamp
+
+
+def test_noise_enters_as_the_reference_applies_it():
+    """BaseAviary.py:1518-1543: x/y force noise reuses entries 0,1 for all four rotors (4 fn0, 4 fn1);
+    moment noise 0,1 go to the base x/y torque; z torque uses all four noisy rotor torques."""
+    t, O = _O("tello")
+    r, m = _rest(), O.reset_mem(1)
+    m[:, 7:11] = t.hover_pwm
+    nz = np.zeros((1, 1, 12))
+    nz[0, 0, 0:4] = [0.01, -0.02, 0.003, 0.004]       # f_noise
+    nz[0, 0, 6:10] = [1e-4, -2e-4, 3e-4, 5e-4]        # m_noise
+    O.physics(r, m, 1, DT, noise=nz)
+    np.testing.assert_allclose(r[0, 7], 4 * 0.01 / t.mass * DT, rtol=1e-12)
+    np.testing.assert_allclose(r[0, 8], 4 * -0.02 / t.mass * DT, rtol=1e-12)
+    np.testing.assert_allclose(r[0, 9], (0.01 - 0.02 + 0.003 + 0.004) / t.mass * DT, rtol=1e-9, atol=1e-16)
+    a = 0.0475
+    fz = np.array([0.01, -0.02, 0.003, 0.004])
+    tx = 1e-4 + sum(p[1] * f for p, f in zip(t.rotor_pos, fz))
+    ty = -2e-4 - sum(p[0] * f for p, f in zip(t.rotor_pos, fz))
+    tz = (-1e-4 - 2e-4 - 3e-4 + 5e-4) + sum(p[0] * -0.02 - p[1] * 0.01 for p in t.rotor_pos)
+    np.testing.assert_allclose(r[0, 10:13], np.array([tx, ty, tz]) / np.array(t.inertia) * DT, rtol=1e-9, atol=1e-15)
+
+
+def test_state_vector_layout():
+    """P5 (BaseAviary.py:780-790): [pos3 quat4 rpy3 vel3 ang_v3 last_action]."""
+    import ctypes
+    t, O = _O()
+    rigid = np.arange(13, dtype=np.float64) / 10
+    rigid[3:7] = orc.quat_from_euler([0.1, -0.2, 0.3])
+    out = np.zeros(20)
+    P = t.to_c()
+    D = ctypes.POINTER(ctypes.c_double)
+    la = np.array([0.1, 0.2, 0.3, 0.4])
+    orc.lib().orc_state_vector(ctypes.byref(P), rigid.ctypes.data_as(D), la.ctypes.data_as(D), out.ctypes.data_as(D))
+    np.testing.assert_array_equal(out[0:7], rigid[0:7])
+    np.testing.assert_allclose(out[7:10], [0.1, -0.2, 0.3], atol=1e-15)
+    np.testing.assert_array_equal(out[10:16], rigid[7:13])
+    np.testing.assert_array_equal(out[16:20], la)
