@@ -62,14 +62,15 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("DSIM_LIB", LIB_PATH)     # dev knob: A/B a differently-tuned build of the same ABI
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build the HIP extension first "
+            f"{path} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()'). dronesim_amd has no CPU fallback.")
     # torch first: its wheel bundles the HIP runtime; loading ours afterwards binds to that same
     # libamdhip64 instead of pulling a second runtime into the process
     import torch  # noqa: F401
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
     lib.dsim_abi_version.restype = ctypes.c_int
     lib.dsim_strerror.restype = ctypes.c_char_p

@@ -16,6 +16,12 @@
 #include "../../include/dronesim_amd.h"
 #include "dsim_device.h"
 
+// minimum waves per SIMD the fused kernel is compiled for (2nd __launch_bounds__ argument):
+// bounds the VGPR budget (512 / waves); tuned on MI355X, see DESIGN.md
+#ifndef DSIM_STEP_WAVES
+#define DSIM_STEP_WAVES 4
+#endif
+
 struct dsim_ctx {
   int device;
   int n_types;
@@ -35,6 +41,14 @@ struct KView {
 __device__ __forceinline__ long long kv_off(const KView& v, long long i) {
   return (i >> v.shift) * v.block_stride + (i & v.mask);
 }
+// Workgroups are 256 drones starting at a multiple of 256 and block sizes are powers of two,
+// so kv_off(i0 + t) = kv_off(i0) + kv_lane(t): a wave-uniform 64-bit part (kept in SGPRs and
+// folded into the scalar base of each access) plus a small per-lane 32-bit part (ONE VGPR shared by
+// every field).  Without the split every field costs a 64-bit VGPR address pair.
+__device__ __forceinline__ unsigned kv_lane(const KView& v, unsigned t) {
+  return v.shift >= 8 ? (t & (unsigned)v.mask)   // plain SoA / blocks >= 256: mask keeps t; broadcast view: mask = 0
+                      : (t >> v.shift) * (unsigned)v.block_stride + (t & (unsigned)v.mask);
+}
 
 struct StepK {
   KView st, tg;
@@ -46,70 +60,79 @@ struct StepK {
   float* pos_e_out;           // control kernel only
   float* yaw_e_out;
   long long n_pad;
+  long long first;            // general step kernel: first drone of this launch
   unsigned long long seed, step_index;
   int substeps;
   float dt_phys, dt_ctrl;
   unsigned options;
 };
 
-template <int NACT>
-__device__ __forceinline__ void load_rigid(const KView& v, long long o, Rigid& s) {
-  const float* p = v.base + o;
-  const long long fs = v.field_stride;
-  s.pos = v3(p[0 * fs], p[1 * fs], p[2 * fs]);
-  s.q = Q4{p[3 * fs], p[4 * fs], p[5 * fs], p[6 * fs]};
-  s.vel = v3(p[7 * fs], p[8 * fs], p[9 * fs]);
-  s.w = v3(p[10 * fs], p[11 * fs], p[12 * fs]);
+// Global accesses.  NT = nontemporal (streaming) hint: each state field is read once and written
+// once per step, so for fleets larger than the caches the lines should not linger in L2/MALL
+// (measured on MI355X with this access shape: +12-15 % HBM rate, tools/membench.hip).  Small
+// fleets that fit the Infinity Cache keep the default policy so consecutive steps hit on-die.
+// (uniform base pointer, per-lane BYTE offset): the form that maps onto
+// `global_load_dword v, v_off, s[base:base+1]` (scalar base + 32-bit VGPR offset).
+template <bool NT> __device__ __forceinline__ float ldg(const float* ub, unsigned boff) {
+  const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ub) + boff);
+  return NT ? __builtin_nontemporal_load(p) : *p;
 }
-__device__ __forceinline__ void store_rigid(const KView& v, long long o, const Rigid& s) {
-  float* p = v.base + o;
-  const long long fs = v.field_stride;
-  p[0 * fs] = s.pos.x; p[1 * fs] = s.pos.y; p[2 * fs] = s.pos.z;
-  p[3 * fs] = s.q.x; p[4 * fs] = s.q.y; p[5 * fs] = s.q.z; p[6 * fs] = s.q.w;
-  p[7 * fs] = s.vel.x; p[8 * fs] = s.vel.y; p[9 * fs] = s.vel.z;
-  p[10 * fs] = s.w.x; p[11 * fs] = s.w.y; p[12 * fs] = s.w.z;
+template <bool NT> __device__ __forceinline__ void stg(float* ub, unsigned boff, float v) {
+  float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(ub) + boff);
+  if (NT) __builtin_nontemporal_store(v, p); else *p = v;
 }
-template <int NACT>
-__device__ __forceinline__ void load_mem(const KView& v, long long o, CtrlMem<NACT>& m) {
-  const float* p = v.base + o;
-  const long long fs = v.field_stride;
-  m.last_vel = v3(p[13 * fs], p[14 * fs], p[15 * fs]);
-  m.last_rates = v3(p[16 * fs], p[17 * fs], p[18 * fs]);
-  m.last_thrust = p[19 * fs];
+
+template <bool NT = false>
+__device__ __forceinline__ void load_rigid(const float* ub, long long fs, unsigned lo /* bytes */, Rigid& s) {
+  s.pos = v3(ldg<NT>(ub + 0 * fs, lo), ldg<NT>(ub + 1 * fs, lo), ldg<NT>(ub + 2 * fs, lo));
+  s.q = Q4{ldg<NT>(ub + 3 * fs, lo), ldg<NT>(ub + 4 * fs, lo), ldg<NT>(ub + 5 * fs, lo), ldg<NT>(ub + 6 * fs, lo)};
+  s.vel = v3(ldg<NT>(ub + 7 * fs, lo), ldg<NT>(ub + 8 * fs, lo), ldg<NT>(ub + 9 * fs, lo));
+  s.w = v3(ldg<NT>(ub + 10 * fs, lo), ldg<NT>(ub + 11 * fs, lo), ldg<NT>(ub + 12 * fs, lo));
+}
+template <bool NT = false>
+__device__ __forceinline__ void store_rigid(float* ub, long long fs, unsigned lo /* bytes */, const Rigid& s) {
+  stg<NT>(ub + 0 * fs, lo, s.pos.x); stg<NT>(ub + 1 * fs, lo, s.pos.y); stg<NT>(ub + 2 * fs, lo, s.pos.z);
+  stg<NT>(ub + 3 * fs, lo, s.q.x); stg<NT>(ub + 4 * fs, lo, s.q.y); stg<NT>(ub + 5 * fs, lo, s.q.z); stg<NT>(ub + 6 * fs, lo, s.q.w);
+  stg<NT>(ub + 7 * fs, lo, s.vel.x); stg<NT>(ub + 8 * fs, lo, s.vel.y); stg<NT>(ub + 9 * fs, lo, s.vel.z);
+  stg<NT>(ub + 10 * fs, lo, s.w.x); stg<NT>(ub + 11 * fs, lo, s.w.y); stg<NT>(ub + 12 * fs, lo, s.w.z);
+}
+template <int NACT, bool NT = false>
+__device__ __forceinline__ void load_mem(const float* ub, long long fs, unsigned lo /* bytes */, CtrlMem<NACT>& m) {
+  m.last_vel = v3(ldg<NT>(ub + 13 * fs, lo), ldg<NT>(ub + 14 * fs, lo), ldg<NT>(ub + 15 * fs, lo));
+  m.last_rates = v3(ldg<NT>(ub + 16 * fs, lo), ldg<NT>(ub + 17 * fs, lo), ldg<NT>(ub + 18 * fs, lo));
+  m.last_thrust = ldg<NT>(ub + 19 * fs, lo);
 #pragma unroll
-  for (int j = 0; j < NACT; ++j) m.cmd[j] = p[(20 + j) * fs];
+  for (int j = 0; j < NACT; ++j) m.cmd[j] = ldg<NT>(ub + (20 + j) * fs, lo);
 }
-template <int NACT>
-__device__ __forceinline__ void store_mem(const KView& v, long long o, const CtrlMem<NACT>& m) {
-  float* p = v.base + o;
-  const long long fs = v.field_stride;
-  p[13 * fs] = m.last_vel.x; p[14 * fs] = m.last_vel.y; p[15 * fs] = m.last_vel.z;
-  p[16 * fs] = m.last_rates.x; p[17 * fs] = m.last_rates.y; p[18 * fs] = m.last_rates.z;
-  p[19 * fs] = m.last_thrust;
+template <int NACT, bool NT = false>
+__device__ __forceinline__ void store_mem(float* ub, long long fs, unsigned lo /* bytes */, const CtrlMem<NACT>& m) {
+  stg<NT>(ub + 13 * fs, lo, m.last_vel.x); stg<NT>(ub + 14 * fs, lo, m.last_vel.y); stg<NT>(ub + 15 * fs, lo, m.last_vel.z);
+  stg<NT>(ub + 16 * fs, lo, m.last_rates.x); stg<NT>(ub + 17 * fs, lo, m.last_rates.y); stg<NT>(ub + 18 * fs, lo, m.last_rates.z);
+  stg<NT>(ub + 19 * fs, lo, m.last_thrust);
 #pragma unroll
-  for (int j = 0; j < NACT; ++j) p[(20 + j) * fs] = m.cmd[j];
+  for (int j = 0; j < NACT; ++j) stg<NT>(ub + (20 + j) * fs, lo, m.cmd[j]);
 }
-__device__ __forceinline__ void load_target(const KView& v, long long o, bool bcast, Target& t) {
-  // broadcast: the address is wave-uniform -> ten scalar loads
-  const float* p = v.base + (bcast ? 0 : o);
-  const long long fs = v.field_stride;
-  t.pos = v3(p[0 * fs], p[1 * fs], p[2 * fs]);
-  t.vel = v3(p[3 * fs], p[4 * fs], p[5 * fs]);
-  t.acc = v3(p[6 * fs], p[7 * fs], p[8 * fs]);
-  t.yaw = p[9 * fs];
+// A broadcast target view has mask = 0, so kv_off() is 0 for every lane: all lanes read the same
+// ten floats (one cache line per wave-instruction), no separate code path.
+template <bool NT = false>
+__device__ __forceinline__ void load_target(const float* ub, long long fs, unsigned lo /* bytes */, Target& t) {
+  t.pos = v3(ldg<NT>(ub + 0 * fs, lo), ldg<NT>(ub + 1 * fs, lo), ldg<NT>(ub + 2 * fs, lo));
+  t.vel = v3(ldg<NT>(ub + 3 * fs, lo), ldg<NT>(ub + 4 * fs, lo), ldg<NT>(ub + 5 * fs, lo));
+  t.acc = v3(ldg<NT>(ub + 6 * fs, lo), ldg<NT>(ub + 7 * fs, lo), ldg<NT>(ub + 8 * fs, lo));
+  t.yaw = ldg<NT>(ub + 9 * fs, lo);
 }
 
 // physics sub-steps of one Env.step for a quad (BaseAviary.py:510-545)
-template <bool NOISE>
+// NOISE: 0 = off, 1 = in-kernel counter-based noise, 2 = replay buffer if given else in-kernel
+template <int NOISE>
 __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[4]) {
-  V3 F0, tau0;
-  quad_wrench(T, cmd, nullptr, F0, tau0);   // cmd is constant over the sub-steps
+  V3 F, tau;
+  if (NOISE == 0) quad_wrench(T, cmd, nullptr, F, tau);   // cmd is constant over the sub-steps
   for (int k = 0; k < a.substeps; ++k) {
-    V3 F = F0, tau = tau0;
-    if (NOISE) {
+    if (NOISE != 0) {
       float nz[8];
-      if (a.noise_replay) {
+      if (NOISE == 2 && a.noise_replay) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) nz[j] = a.noise_replay[((long long)k * 8 + j) * a.n_pad + i];
       } else {
@@ -124,28 +147,65 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
 }
 
 // ---- fused Env.step + computeControl (the hot path) -----------------------
+// Fast form: homogeneous fleet, action = the controller's stored cmd, whole 256-drone tiles (the
+// launcher hands ragged tails and every other configuration to the general kernel below).
+// No per-lane branches and no bounds checks, so every access keeps the scalar-base + 32-bit
+// lane-offset form (one VGPR of addressing for all 58 accesses).
+//
+// (Measured and rejected on MI355X, 4.2 M drones: a persistent grid-stride form that prefetches
+// the next tile into registers, 266 vs 176 us, and two tiles per workgroup with both tiles' loads
+// issued up front, 190 vs 163 us — fewer, fatter waves hide HBM latency worse than 4 waves/SIMD of
+// this short kernel; forcing 4 waves/SIMD by spilling also lost, 176 vs 172 us.)
+template <bool NOISE, bool NT>
+__global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_step_fast(StepK a) {
+  const DevType& T = a.types[0];
+  const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
+  const unsigned sl = 4u * kv_lane(a.st, threadIdx.x), tl = 4u * kv_lane(a.tg, threadIdx.x);   // bytes
+  const long long i0 = (long long)blockIdx.x * 256;                   // wave-uniform
+  float* const sb = a.st.base + kv_off(a.st, i0);                     // scalar bases
+  const float* const tb = a.tg.base + kv_off(a.tg, i0);
+  Rigid s;
+  CtrlMem<4> m;
+  Target tg;
+  load_rigid<NT>(sb, sfs, sl, s);
+  load_mem<4, NT>(sb, sfs, sl, m);
+  load_target<NT>(tb, tfs, tl, tg);
+  quad_substeps<NOISE ? 1 : 0>(T, a, i0 + threadIdx.x, s, m.cmd);     // stored cmd is already clipped
+  V3 pos_e;
+  float yaw_e;
+  indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  store_rigid<NT>(sb, sfs, sl, s);
+  store_mem<4, NT>(sb, sfs, sl, m);
+}
+
+// General form: per-drone type ids, explicit action override, noise replay, ragged sizes.
+// a.first = first drone this launch covers.
 template <bool NOISE, bool UNIFORM>
 __global__ __launch_bounds__(256) void k_step_quad(StepK a) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long i = a.first + (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n_pad) return;
   const DevType& T = a.types[UNIFORM ? 0 : a.type_id[i]];
   const long long o = kv_off(a.st, i);
   Rigid s;
   CtrlMem<4> m;
   Target tg;
-  load_rigid<4>(a.st, o, s);
-  load_mem<4>(a.st, o, m);
-  load_target(a.tg, kv_off(a.tg, i), (a.options & DSIM_OPT_BCAST_TGT) != 0, tg);
+  load_rigid(a.st.base + o, a.st.field_stride, 0u, s);
+  load_mem<4>(a.st.base + o, a.st.field_stride, 0u, m);
+  load_target(a.tg.base + kv_off(a.tg, i), a.tg.field_stride, 0u, tg);
   float act[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) act[j] = a.action ? a.action[(long long)j * a.n_pad + i] : m.cmd[j];
-  if (a.action) preprocess_action<4>(T, act, act);   // the stored cmd is already clipped (INDIControl.py:487)
-  quad_substeps<NOISE>(T, a, i, s, act);
+  for (int j = 0; j < 4; ++j) act[j] = m.cmd[j];
+  if (a.action) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) act[j] = a.action[(long long)j * a.n_pad + i];
+    preprocess_action<4>(T, act, act);   // the stored cmd is already clipped (INDIControl.py:487)
+  }
+  quad_substeps<NOISE ? 2 : 0>(T, a, i, s, act);
   V3 pos_e;
   float yaw_e;
-  indi_quad(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  store_rigid(a.st, o, s);
-  store_mem<4>(a.st, o, m);
+  indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  store_rigid(a.st.base + o, a.st.field_stride, 0u, s);
+  store_mem<4>(a.st.base + o, a.st.field_stride, 0u, m);
 }
 
 // ---- Env.step only ---------------------------------------------------------
@@ -156,14 +216,14 @@ __global__ __launch_bounds__(256) void k_physics_quad(StepK a) {
   const DevType& T = a.types[UNIFORM ? 0 : a.type_id[i]];
   const long long o = kv_off(a.st, i);
   Rigid s;
-  load_rigid<4>(a.st, o, s);
+  load_rigid(a.st.base + o, a.st.field_stride, 0u, s);
   float raw[4], cmd[4];
   const long long fs = a.st.field_stride;
 #pragma unroll
   for (int j = 0; j < 4; ++j) raw[j] = a.action ? a.action[(long long)j * a.n_pad + i] : a.st.base[o + (20 + j) * fs];
   preprocess_action<4>(T, raw, cmd);
-  quad_substeps<NOISE>(T, a, i, s, cmd);
-  store_rigid(a.st, o, s);
+  quad_substeps<NOISE ? 2 : 0>(T, a, i, s, cmd);
+  store_rigid(a.st.base + o, a.st.field_stride, 0u, s);
   if (a.echo) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) a.echo[(long long)j * a.n_pad + i] = cmd[j];   // last_clipped_action, BaseAviary.py:545
@@ -180,13 +240,14 @@ __global__ __launch_bounds__(256) void k_control_quad(StepK a) {
   Rigid s;
   CtrlMem<4> m;
   Target tg;
-  load_rigid<4>(a.st, o, s);
-  load_mem<4>(a.st, o, m);
-  load_target(a.tg, kv_off(a.tg, i), (a.options & DSIM_OPT_BCAST_TGT) != 0, tg);
+  load_rigid(a.st.base + o, a.st.field_stride, 0u, s);
+  load_mem<4>(a.st.base + o, a.st.field_stride, 0u, m);
+  load_target(a.tg.base + kv_off(a.tg, i), a.tg.field_stride, 0u, tg);
   V3 pos_e;
   float yaw_e;
-  indi_quad(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  store_mem<4>(a.st, o, m);
+  if (a.yaw_e_out) indi_quad<true>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  else indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  store_mem<4>(a.st.base + o, a.st.field_stride, 0u, m);
   if (a.pos_e_out) {
     a.pos_e_out[i] = pos_e.x; a.pos_e_out[a.n_pad + i] = pos_e.y; a.pos_e_out[2 * a.n_pad + i] = pos_e.z;
   }
@@ -212,7 +273,7 @@ __global__ __launch_bounds__(256) void k_reset(ResetK a) {
   s.q = quat_from_euler(v3(a.rpy[i], a.rpy[a.n_pad + i], a.rpy[2 * a.n_pad + i]));   // BaseAviary.py:687
   s.vel = a.vel ? v3(a.vel[i], a.vel[a.n_pad + i], a.vel[2 * a.n_pad + i]) : v3(0, 0, 0);  // :695-705
   s.w = v3(0, 0, 0);
-  store_rigid(a.st, o, s);
+  store_rigid(a.st.base + o, a.st.field_stride, 0u, s);
   float* p = a.st.base + o;
   const long long fs = a.st.field_stride;
 #pragma unroll
@@ -230,12 +291,12 @@ __global__ __launch_bounds__(256) void k_observe(ObsK a) {
   if (i >= a.n) return;
   const long long o = kv_off(a.st, i);
   Rigid s;
-  load_rigid<4>(a.st, o, s);
-  const V3 e = euler_from_quat(s.q);
+  load_rigid(a.st.base + o, a.st.field_stride, 0u, s);
+  const Euler e = euler_from_quat<true>(s.q);
   float* r = a.out + i * a.width;
   r[0] = s.pos.x; r[1] = s.pos.y; r[2] = s.pos.z;
   r[3] = s.q.x; r[4] = s.q.y; r[5] = s.q.z; r[6] = s.q.w;
-  r[7] = e.x; r[8] = e.y; r[9] = e.z;
+  r[7] = e.roll; r[8] = e.pitch; r[9] = e.yaw;
   r[10] = s.vel.x; r[11] = s.vel.y; r[12] = s.vel.z;
   r[13] = s.w.x; r[14] = s.w.y; r[15] = s.w.z;
   for (int j = 0; j < a.width - 16; ++j)
@@ -371,7 +432,7 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
   }
   a->types = ctx->d_types; a->type_id = args->type_id; a->noise_replay = args->noise_replay;
   a->action = args->action; a->echo = nullptr; a->pos_e_out = nullptr; a->yaw_e_out = nullptr;
-  a->n_pad = state.n_pad; a->seed = args->noise_seed; a->step_index = args->step_index;
+  a->n_pad = state.n_pad; a->first = 0; a->seed = args->noise_seed; a->step_index = args->step_index;
   a->substeps = args->phys_substeps; a->dt_phys = args->dt_phys; a->dt_ctrl = args->dt_ctrl;
   a->options = args->options;
   return DSIM_OK;
@@ -393,7 +454,33 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   if (rc) return rc;
   const bool noise = args->noise_seed != 0 || args->noise_replay != nullptr;
   const bool uni = args->type_id == nullptr;
-  DSIM_LAUNCH2(k_step_quad, noise, uni, a, (hipStream_t)stream);
+  const hipStream_t st_ = (hipStream_t)stream;
+  const dim3 b(256);
+  long long first = 0;
+  if (uni && !args->action && !args->noise_replay) {
+    // fast path over the whole 256-drone tiles.  Streaming (nontemporal) accesses once the fleet's
+    // per-step traffic exceeds what the 256 MB Infinity Cache can keep between consecutive steps
+    // (tuning knob for A/B runs: DSIM_NT = 0|1).
+    static const char* nt_env = getenv("DSIM_NT");
+    const bool nt = nt_env ? atoi(nt_env) != 0 : (double)state.n_pad * 232.0 > 192.0 * 1024 * 1024;
+    const long long tiles = a.n_pad / 256;
+    if (tiles > 0) {
+      const dim3 g((unsigned)tiles);
+      if (noise) { if (nt) hipLaunchKernelGGL((k_step_fast<true, true>), g, b, 0, st_, a);
+                   else hipLaunchKernelGGL((k_step_fast<true, false>), g, b, 0, st_, a); }
+      else { if (nt) hipLaunchKernelGGL((k_step_fast<false, true>), g, b, 0, st_, a);
+             else hipLaunchKernelGGL((k_step_fast<false, false>), g, b, 0, st_, a); }
+      first = tiles * 256;
+    }
+  }
+  if (first < a.n_pad) {   // ragged tail, or everything when the fast path does not apply
+    a.first = first;
+    const dim3 g(grid_for(a.n_pad - first));
+    if (noise) { if (uni) hipLaunchKernelGGL((k_step_quad<true, true>), g, b, 0, st_, a);
+                 else hipLaunchKernelGGL((k_step_quad<true, false>), g, b, 0, st_, a); }
+    else { if (uni) hipLaunchKernelGGL((k_step_quad<false, true>), g, b, 0, st_, a);
+           else hipLaunchKernelGGL((k_step_quad<false, false>), g, b, 0, st_, a); }
+  }
   return (int)hipGetLastError();
 }
 

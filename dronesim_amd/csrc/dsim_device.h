@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dsim_math.h"
+
 #define DSIM_MAX_ACT 6
 
 // fp32 image of dsim_type_params (include/dronesim_amd.h), with the reciprocals
@@ -44,7 +46,7 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fm
 // p.getMatrixFromQuaternion / btMatrix3x3::setRotation (s = 2/|q|^2); C8
 __device__ __forceinline__ M3 matrix_from_quat(Q4 q) {
   const float d = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
-  const float s = 2.0f / d;
+  const float s = 2.0f * DSIM_RCP(d);
   const float xs = q.x * s, ys = q.y * s, zs = q.z * s;
   const float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
   const float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
@@ -64,19 +66,35 @@ __device__ __forceinline__ V3 mulT(const M3& R, V3 a) {  // R^T a
             R.m[2] * a.x + R.m[5] * a.y + R.m[8] * a.z);
 }
 
-// p.getEulerFromQuaternion (ZYX, gimbal clamp at |sarg| >= 0.99999); C8
-__device__ __forceinline__ V3 euler_from_quat(Q4 q) {
+// p.getEulerFromQuaternion (ZYX, gimbal clamp at |sarg| >= 0.99999); C8.
+// Returns the angles the controller adds increments to (roll, pitch; yaw only when WANT_YAW)
+// and the sines/cosines of all three that the G matrix needs (INDIControl.py:301-305).  The
+// sines/cosines come straight from the quaternion products the angles are defined by
+// (sin(atan2(a,b)) = a/hypot(a,b), sin(asin(s)) = s, ...), so no trig call is spent on them.
+struct Euler { float roll, pitch, yaw; float sph, cph, sth, cth, sps, cps; };
+template <bool WANT_YAW>
+__device__ __forceinline__ Euler euler_from_quat(Q4 q) {
   const float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
   const float sarg = -2.0f * (q.x * q.z - q.w * q.y);
-  V3 e;
-  if (sarg <= -0.99999f) {
-    e = v3(0.0f, -1.57079632679489662f, 2.0f * atan2f(q.x, -q.y));
-  } else if (sarg >= 0.99999f) {
-    e = v3(0.0f, 1.57079632679489662f, 2.0f * atan2f(-q.x, q.y));
+  Euler e;
+  if (sarg <= -0.99999f || sarg >= 0.99999f) {
+    const bool up = sarg > 0.0f;
+    const float hs = up ? -q.x : q.x, hc = up ? q.y : -q.y;     // yaw = 2 atan2(hs, hc)
+    const float n2 = hs * hs + hc * hc;
+    const float in2 = n2 > 0.0f ? DSIM_RCP(n2) : 0.0f;
+    e.roll = 0.0f; e.sph = 0.0f; e.cph = 1.0f;
+    e.pitch = up ? DSIM_PI_2 : -DSIM_PI_2; e.sth = up ? 1.0f : -1.0f; e.cth = 0.0f;
+    e.sps = 2.0f * hs * hc * in2;
+    e.cps = n2 > 0.0f ? (hc * hc - hs * hs) * in2 : 1.0f;
+    e.yaw = WANT_YAW ? 2.0f * dsim_atan2(hs, hc) : 0.0f;
   } else {
-    e.x = atan2f(2.0f * (q.y * q.z + q.w * q.x), squ - sqx - sqy + sqz);
-    e.y = asinf(sarg);
-    e.z = atan2f(2.0f * (q.x * q.y + q.w * q.z), squ + sqx - sqy - sqz);
+    const float ra = 2.0f * (q.y * q.z + q.w * q.x), rb = squ - sqx - sqy + sqz;
+    const float ya = 2.0f * (q.x * q.y + q.w * q.z), yb = squ + sqx - sqy - sqz;
+    const float ir = DSIM_RSQ(ra * ra + rb * rb), iy = DSIM_RSQ(ya * ya + yb * yb);
+    e.roll = dsim_atan2(ra, rb); e.sph = ra * ir; e.cph = rb * ir;
+    e.pitch = dsim_asin(sarg); e.sth = sarg; e.cth = DSIM_SQRT(fmaxf(1.0f - sarg * sarg, 0.0f));
+    e.sps = ya * iy; e.cps = yb * iy;
+    e.yaw = WANT_YAW ? dsim_atan2(ya, yb) : 0.0f;
   }
   return e;
 }
@@ -84,24 +102,23 @@ __device__ __forceinline__ V3 euler_from_quat(Q4 q) {
 // p.getQuaternionFromEuler (half-angle product, normalised); C8
 __device__ __forceinline__ Q4 quat_from_euler(V3 e) {
   float sph, cph, sth, cth, sps, cps;
-  sincosf(0.5f * e.x, &sph, &cph);
-  sincosf(0.5f * e.y, &sth, &cth);
-  sincosf(0.5f * e.z, &sps, &cps);
+  dsim_sincos(0.5f * e.x, &sph, &cph);
+  dsim_sincos(0.5f * e.y, &sth, &cth);
+  dsim_sincos(0.5f * e.z, &sps, &cps);
   Q4 q;
   q.x = sph * cth * cps - cph * sth * sps;
   q.y = cph * sth * cps + sph * cth * sps;
   q.z = cph * cth * sps - sph * sth * cps;
   q.w = cph * cth * cps + sph * sth * sps;
-  const float inv = rsqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  const float inv = DSIM_RSQ(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
   q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv;
   return q;
 }
 
 // dronesim/utils/math.py:75-80 norm_ang
 __device__ __forceinline__ float norm_ang(float x) {
-  const float PI = 3.14159265358979323846f;
-  while (x > PI) x -= 2.0f * PI;
-  while (x < -PI) x += 2.0f * PI;
+  while (x > DSIM_PI) x -= 2.0f * DSIM_PI;
+  while (x < -DSIM_PI) x += 2.0f * DSIM_PI;
   return x;
 }
 
@@ -120,29 +137,32 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
 }
-__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
-  const float u1 = (float)((a >> 8) + 1u) * (1.0f / 16777216.0f);   // (0,1]
-  const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);          // [0,1)
-  const float r = sqrtf(-2.0f * __logf(u1));
-  float s, c;
-  __sincosf(6.28318530717958647692f * u2, &s, &c);
-  n0 = r * c; n1 = r * s;
+// One 32-bit Philox word -> two unit normals (Box-Muller): radius from the high 16 bits
+// (u1 = (h+1)/65536 in (0,1], so |n| <= sqrt(2 ln 65536) = 4.71 sigma), angle from the low 16.
+// The hardware transcendentals take the angle in revolutions and log in base 2.
+__device__ __forceinline__ void box_muller16(uint32_t w, float& n0, float& n1) {
+  const float u1 = (float)((w >> 16) + 1u) * (1.0f / 65536.0f);
+  const float u2 = (float)(w & 0xFFFFu) * (1.0f / 65536.0f);
+  const float r = DSIM_SQRT(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));   // -2 ln2 log2(u1)
+  n0 = r * __builtin_amdgcn_cosf(u2);
+  n1 = r * __builtin_amdgcn_sinf(u2);
 }
-// unit normals for (drone, sub-step counter): out[0..n_act) force noise, out[n_act..2 n_act) moment noise
+// unit normals for (drone, sub-step counter): out[0..n_act) force noise, out[n_act..2 n_act) moment
+// noise.  One Philox4x32-10 block yields 8 normals (a quad's whole sub-step), a hexa needs two.
 template <int NACT>
 __device__ __forceinline__ void noise_normals(uint64_t seed, uint64_t drone, uint64_t sub, float* out) {
-  constexpr int NSTREAM = (2 * NACT + 3) / 4;
+  constexpr int NSTREAM = (2 * NACT + 7) / 8;
 #pragma unroll
   for (int s = 0; s < NSTREAM; ++s) {
     uint32_t c[4] = {(uint32_t)drone, (uint32_t)(drone >> 32) ^ ((uint32_t)s << 24), (uint32_t)sub,
                      (uint32_t)(sub >> 32)};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    float n[4];
-    box_muller(c[0], c[1], n[0], n[1]);
-    box_muller(c[2], c[3], n[2], n[3]);
+    float n[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (4 * s + j < 2 * NACT) out[4 * s + j] = n[j];
+    for (int w = 0; w < 4; ++w) box_muller16(c[w], n[2 * w], n[2 * w + 1]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (8 * s + j < 2 * NACT) out[8 * s + j] = n[j];
   }
 }
 
@@ -188,13 +208,13 @@ __device__ __forceinline__ void bullet_step(const DevType& T, float dt, Rigid& s
   const M3 R = matrix_from_quat(s.q);
   const V3 wb = mulT(R, s.w);
   // linear: world-frame form of a_b + w_b x v_b (the m w x v bias cancels), |v_b| = |v|
-  const float vn = sqrtf(dot(s.vel, s.vel));
+  const float vn = DSIM_SQRT(dot(s.vel, s.vel));
   const V3 Fw = mul(R, F_body);
   const float dl = T.clin + T.clin * vn;
   V3 vdot = v3(Fw.x * T.inv_mass - dl * s.vel.x, Fw.y * T.inv_mass - dl * s.vel.y,
                Fw.z * T.inv_mass - T.g - dl * s.vel.z);
   // angular: alpha_b = J^-1 (tau - w x Jw) - c (1+|w|) w
-  const float wn = sqrtf(dot(wb, wb));
+  const float wn = DSIM_SQRT(dot(wb, wb));
   const V3 Jw = v3(T.J[0] * wb.x, T.J[1] * wb.y, T.J[2] * wb.z);
   const V3 gy = cross(wb, Jw);
   const float da = T.cang + T.cang * wn;
@@ -208,8 +228,8 @@ __device__ __forceinline__ void bullet_step(const DevType& T, float dt, Rigid& s
              clampf(s.vel.z + vdot.z * dt, -T.maxv, T.maxv));
   // stepPositionsMultiDof: semi-implicit position, exponential-map orientation
   s.pos = s.pos + dt * s.vel;
-  float fAngle = sqrtf(dot(s.w, s.w));
-  if (fAngle * dt > 0.78539816339744831f) fAngle = 0.78539816339744831f / dt;
+  float fAngle = DSIM_SQRT(dot(s.w, s.w));
+  if (fAngle * dt > DSIM_PI_4) fAngle = DSIM_PI_4 * DSIM_RCP(dt);
   // h = half rotation angle <= pi/8: sin(h)/fAngle = (dt/2) sinc(h); truncation error < 2e-9.
   // (Bullet's own |w| < 0.001 Taylor branch is the first two terms of the same series.)
   const float h = 0.5f * fAngle * dt, h2 = h * h;
@@ -222,28 +242,32 @@ __device__ __forceinline__ void bullet_step(const DevType& T, float dt, Rigid& s
   n.x = cw * q.x + ax * q.w + ay * q.z - az * q.y;
   n.y = cw * q.y + ay * q.w + az * q.x - ax * q.z;
   n.z = cw * q.z + az * q.w + ax * q.y - ay * q.x;
-  const float inv = rsqrtf(n.x * n.x + n.y * n.y + n.z * n.z + n.w * n.w);
+  const float inv = DSIM_RSQ(n.x * n.x + n.y * n.y + n.z * n.z + n.w * n.w);
   s.q = Q4{n.x * inv, n.y * inv, n.z * inv, n.w * inv};
 }
 
 // C2 + C3 + C4: INDIControl.computeControl for a quad, INDIControl.py:154-227.
-// Returns pos_e and yaw_e (the reference's 2nd and 3rd return values).
+// Returns pos_e and (WANT_YAW) yaw_e, the reference's 2nd and 3rd return values.
+//
+// Yaw: the reference builds target_euler.z = psi + norm_ang(psi* - psi) = psi* - 2 pi j.  Only
+// sin/cos of HALF that angle enter the target quaternion, so j flips the sign of the whole
+// quaternion, hence of quat_err, and quat_wrap_shortest (math.py:46-51) removes exactly that
+// sign.  The attitude error therefore depends on psi* alone, and the kernel evaluates
+// sincos(psi*/2) directly; psi itself (one more atan2) is computed only when yaw_e is wanted.
+template <bool WANT_YAW>
 __device__ __forceinline__ void indi_quad(const DevType& T, float dt, const Rigid& s, const Target& tg,
                                           CtrlMem<4>& m, V3& pos_e, float& yaw_e) {
   // ---- _INDIPositionControl, :278-296
   pos_e = tg.pos - s.pos;
-  const float inv_dt = 1.0f / dt;
+  const float inv_dt = DSIM_RCP(dt);
   V3 a_e;
   a_e.x = clampf((pos_e.x * T.kp + tg.vel.x - s.vel.x) * T.kd + tg.acc.x - (s.vel.x - m.last_vel.x) * inv_dt, -6.0f, 6.0f);
   a_e.y = clampf((pos_e.y * T.kp + tg.vel.y - s.vel.y) * T.kd + tg.acc.y - (s.vel.y - m.last_vel.y) * inv_dt, -6.0f, 6.0f);
   a_e.z = clampf((pos_e.z * T.kp + tg.vel.z - s.vel.z) * T.kd + tg.acc.z - (s.vel.z - m.last_vel.z) * inv_dt, -6.0f, 6.0f);
   m.last_vel = s.vel;
   // ---- Euler angles and G, :301-333
-  const V3 rpy = euler_from_quat(s.q);
-  float sph, cph, sth, cth, sps, cps;
-  sincosf(rpy.x, &sph, &cph);
-  sincosf(rpy.y, &sth, &cth);
-  sincosf(rpy.z, &sps, &cps);
+  const Euler e = euler_from_quat<WANT_YAW>(s.q);
+  const float sph = e.sph, cph = e.cph, sth = e.sth, cth = e.cth, sps = e.sps, cps = e.cps;
   const float Tg = 9.81f;
   const float g00 = (cph * sps - sph * cps * sth) * Tg, g01 = (cph * cps * cth) * Tg, g02 = sph * sps + cph * cps * sth;
   const float g10 = (-sph * sps * sth - cps * cph) * Tg, g11 = (cph * sps * cth) * Tg, g12 = cph * sps * sth - cps * sph;
@@ -255,14 +279,18 @@ __device__ __forceinline__ void indi_quad(const DevType& T, float dt, const Rigi
   const float c20 = g10 * g21 - g11 * g20, c21 = g01 * g20 - g00 * g21, c22 = g00 * g11 - g01 * g10;
   float det = g00 * c00 + g01 * c10 + g02 * c20;
   det = copysignf(fmaxf(fabsf(det), 1e-12f), det);
-  const float idet = 1.0f / det;
+  const float idet = DSIM_RCP(det);
   const float inc0 = (c00 * a_e.x + c01 * a_e.y + c02 * a_e.z) * idet;
   const float inc1 = (c10 * a_e.x + c11 * a_e.y + c12 * a_e.z) * idet;
   const float inc2 = (c20 * a_e.x + c21 * a_e.y + c22 * a_e.z) * idet;
-  const float yaw_inc = norm_ang(tg.yaw - rpy.z);                           // :341
-  const V3 target_euler = v3(rpy.x + inc0, rpy.y + inc1, rpy.z + yaw_inc);   // :344-346
   const float thrust = m.last_thrust + inc2;                                 // :347
-  yaw_e = target_euler.z - rpy.z;                                            // :227
+  float target_yaw = tg.yaw;                                                 // == psi + norm_ang(psi* - psi) mod 2 pi
+  if (WANT_YAW) {
+    const float yaw_inc = norm_ang(tg.yaw - e.yaw);                          // :341
+    target_yaw = e.yaw + yaw_inc;                                            // :344-346
+    yaw_e = target_yaw - e.yaw;                                              // :227
+  }
+  const V3 target_euler = v3(e.roll + inc0, e.pitch + inc1, target_yaw);
   // ---- _INDIAttitudeControl, :388-402
   const Q4 tq = quat_from_euler(target_euler);
   const Q4 q = s.q;

@@ -19,8 +19,10 @@ F_POS, F_QUAT, F_VEL, F_ANGVEL = 0, 3, 7, 10
 F_LAST_VEL, F_LAST_RATES, F_LAST_THRUST, F_CMD = 13, 16, 19, 20
 
 
-def pad64(n: int) -> int:
-    return (n + 63) // 64 * 64
+def pad_to(n: int, m: int = 256) -> int:
+    """The C-ABI needs n_pad % 64 == 0; whole 256-drone tiles keep the entire fleet on the
+    fused kernel's fast path (a ragged tail costs one extra small launch)."""
+    return (n + m - 1) // m * m
 
 
 class Context:
@@ -64,8 +66,8 @@ class BlockedSoA:
     layout "tile64": tensor [n_pad/64, F, 64]     (one 64-drone wave tile per block)
     """
 
-    def __init__(self, n: int, n_fields: int, device, layout: str = "soa"):
-        self.n, self.n_pad, self.n_fields, self.layout = n, pad64(n), n_fields, layout
+    def __init__(self, n: int, n_fields: int, device, layout: str = "soa", pad: int = 256):
+        self.n, self.n_pad, self.n_fields, self.layout = n, pad_to(n, pad), n_fields, layout
         if layout == "soa":
             self.data = torch.zeros((n_fields, self.n_pad), dtype=torch.float32, device=device)
         elif layout == "tile64":
@@ -106,8 +108,8 @@ class FleetState(BlockedSoA):
     """The 13 rigid-body floats Bullet holds per drone (BaseAviary.py:718-732) plus the
     controller memory of one INDIControl instance per drone (INDIControl.py:109-146)."""
 
-    def __init__(self, ctx: Context, n: int, layout: str = "soa"):
-        super().__init__(n, ctx.n_fields, ctx.device, layout)
+    def __init__(self, ctx: Context, n: int, layout: str = "soa", pad: int = 256):
+        super().__init__(n, ctx.n_fields, ctx.device, layout, pad)
         self.ctx = ctx
 
     pos = property(lambda s: s.fields(F_POS, 3))
@@ -137,13 +139,13 @@ class FleetState(BlockedSoA):
 class Targets(BlockedSoA):
     """Per-step targets: pos3 vel3 acc3 yaw (INDIControl.computeControl arguments)."""
 
-    def __init__(self, ctx: Context, n: int, layout: str = "soa", broadcast: bool = False):
+    def __init__(self, ctx: Context, n: int, layout: str = "soa", broadcast: bool = False, pad: int = 256):
         self.broadcast = broadcast
         if broadcast:
             self.n, self.n_pad, self.n_fields, self.layout = 1, 64, nat.NT, "soa"
             self.data = torch.zeros((nat.NT, 1), dtype=torch.float32, device=ctx.device)
         else:
-            super().__init__(n, nat.NT, ctx.device, layout)
+            super().__init__(n, nat.NT, ctx.device, layout, pad)
 
     def view(self) -> nat.View:
         if not self.broadcast:

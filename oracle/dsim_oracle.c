@@ -659,8 +659,8 @@ void orc_physics_substep(const dsim_type_params* P, double dt, double rigid[13],
 /* Product noise definition (NOT a reference restatement: the reference draws
  * from the unseeded global numpy RNG, BaseAviary.py:1518-1525, which cannot be
  * reproduced).  Philox4x32-10 keyed by the seed, counter = (drone, substep
- * counter, stream), Box-Muller -> N(0,1).  Mirrors dsim_device.h so that tests
- * can feed the oracle the very normals the kernel draws.                     */
+ * counter, stream), Box-Muller on 16+16-bit halves -> N(0,1) truncated at 4.71 sigma.
+ * Mirrors dsim_device.h so that tests can feed the oracle the very normals the kernel draws.                     */
 /* ======================================================================= */
 static inline void philox_round(uint32_t c[4], const uint32_t k[2]) {
   const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
@@ -675,17 +675,18 @@ void orc_philox4x32(uint32_t c[4], uint64_t seed) {
     k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
   }
 }
-/* unit normals for (drone, substep counter): out[2*n_act] */
+/* unit normals for (drone, substep counter): out[2*n_act].  One Philox block -> 8 normals: each
+ * 32-bit word gives a Box-Muller pair, radius from its high 16 bits (u1 = (h+1)/65536 in (0,1]),
+ * angle from its low 16 bits (u2 = l/65536 turns). */
 void orc_noise_normals(uint64_t seed, uint64_t drone, uint64_t sub_counter, int n_act, double* out) {
   int produced = 0;
   for (uint32_t stream = 0; produced < 2 * n_act; ++stream) {
     uint32_t c[4] = {(uint32_t)drone, (uint32_t)(drone >> 32) ^ (stream << 24), (uint32_t)sub_counter,
                      (uint32_t)(sub_counter >> 32)};
     orc_philox4x32(c, seed);
-    for (int h = 0; h < 2 && produced < 2 * n_act; ++h) {
-      /* u1 in (0,1], u2 in [0,1): 24-bit mantissas, as the fp32 kernel does */
-      const double u1 = ((double)(c[2 * h] >> 8) + 1.0) * (1.0 / 16777216.0);
-      const double u2 = (double)(c[2 * h + 1] >> 8) * (1.0 / 16777216.0);
+    for (int w = 0; w < 4 && produced < 2 * n_act; ++w) {
+      const double u1 = ((double)(c[w] >> 16) + 1.0) * (1.0 / 65536.0);
+      const double u2 = (double)(c[w] & 0xFFFFu) * (1.0 / 65536.0);
       const double r = sqrt(-2.0 * log(u1));
       out[produced++] = r * cos(2 * ORC_PI * u2);
       if (produced < 2 * n_act) out[produced++] = r * sin(2 * ORC_PI * u2);

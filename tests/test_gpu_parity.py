@@ -44,12 +44,12 @@ def _stream(ctx):
     return ctx.stream_ptr()
 
 
-def _make(gpu, model, n, layout="soa", seed=0, **kw):
+def _make(gpu, model, n, layout="soa", seed=0, pad=256, **kw):
     nat, fleet = gpu
     t = params.builtin_type(model)
     ctx = fleet.Context([t])
-    st = fleet.FleetState(ctx, n, layout)
-    tg = fleet.Targets(ctx, n, layout)
+    st = fleet.FleetState(ctx, n, layout, pad)
+    tg = fleet.Targets(ctx, n, layout, pad=pad)
     rigid, mem, tgt = random_fleet(np.random.default_rng(seed), n, **kw)
     st.load_aos(rigid, mem)
     tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
@@ -135,12 +135,14 @@ def test_control_sequence_vs_golden(gpu, golden_dir, model):
 # ---------------------------------------------------------------------------
 # fused Env.step + computeControl against the oracle
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("model,substeps,layout", [("robobee", 5, "soa"), ("robobee", 1, "tile64"),
-                                                   ("tello", 2, "soa"), ("tello", 5, "tile64")])
-def test_fused_step_vs_oracle(gpu, model, substeps, layout):
+@pytest.mark.parametrize("model,substeps,layout,pad", [("robobee", 5, "soa", 256), ("robobee", 1, "tile64", 64),
+                                                       ("tello", 2, "soa", 64), ("tello", 5, "tile64", 256)])
+def test_fused_step_vs_oracle(gpu, model, substeps, layout, pad):
+    """pad=256: whole fleet on the fast kernel; pad=64: n_pad = 4160 = 16 whole tiles on the fast
+    kernel + a 64-drone ragged tail on the general kernel."""
     nat, fleet = gpu
     n = 4096 + 17                      # ragged: not a multiple of 64
-    t, ctx, st, tg, rigid, mem, tgt = _make(gpu, model, n, layout, seed=3)
+    t, ctx, st, tg, rigid, mem, tgt = _make(gpu, model, n, layout, seed=3, pad=pad)
     O = orc.Oracle([t])
     dtc = float(np.float32(substeps / 240.0))
     a = _args(nat, substeps, DT, dtc)
