@@ -167,14 +167,12 @@ def main():
     barrier = (lambda: dist.barrier()) if dist else None
 
     n_fleet, replicas = {"config2x1024": (4096, 1024), "config2": (4096, 1), "config3": (65536, 1)}[a.workload]
-    fl = Fleet(n_fleet, replicas, local, a.substeps, a.layout, a.noise_seed)
+    from dronesim_amd import sharding
+    # weak scaling: every rank owns a same-sized contiguous shard of the N-GPU fleet; no data-path collective
+    fl = Fleet(n_fleet, replicas, local, a.substeps, a.layout, sharding.rank_seed(a.noise_seed, rank))
     wall, dev_s = fl.timed(a.steps, a.warmup, barrier)
-    t = torch.tensor([wall, dev_s], dtype=torch.float64, device="cuda")
-    if dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall, dev_s = float(t[0]), float(t[1])
-    n_total = fl.n * world
-    value = n_total * a.steps / wall
+    wall, dev_s = sharding.reduce_step_times(dist, "cuda", wall, dev_s)     # MAX over ranks
+    value = sharding.aggregate_throughput([fl.n] * world, a.steps, wall)
     launch_s = dev_s / a.steps
     achieved = fl.n * BYTES_PER_DRONE_STEP / launch_s / 1e9
 

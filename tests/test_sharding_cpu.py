@@ -1,0 +1,55 @@
+"""World-size-2 rehearsal (gloo, CPU) of the multi-GPU path's host logic: contiguous shards that
+tile the fleet, per-rank noise keys, and the MAX-over-ranks timing reduction bench.py uses."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dronesim_amd import sharding
+
+
+def test_shard_ranges_tile_the_fleet():
+    for n, w in [(524288, 8), (10, 3), (7, 8), (4194304, 4), (1, 1)]:
+        spans = [sharding.shard_range(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [e - b for b, e in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_range(10, 2, 2)
+    assert sharding.shard_range(524288, 8, 3) == (196608, 262144)      # config 4: 65 536 per GPU
+
+
+def test_rank_seeds_differ_and_zero_stays_off():
+    s = [sharding.rank_seed(1, r) for r in range(8)]
+    assert len(set(s)) == 8 and all(x != 0 for x in s)
+    assert sharding.rank_seed(0, 5) == 0
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, e = sharding.shard_range(1000, world, rank)
+    wall, dev = sharding.reduce_step_times(dist, "cpu", 1.0 + rank, 0.5 + 0.25 * rank)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([e - b]))
+    thr = sharding.aggregate_throughput([int(s) for s in sizes], 10, wall)
+    dist.barrier()
+    out[rank] = (b, e, wall, dev, thr)
+    dist.destroy_process_group()
+
+
+def test_two_rank_timing_reduction_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out[0][:2] == (0, 500) and out[1][:2] == (500, 1000)
+    for r in (0, 1):
+        assert out[r][2] == 2.0 and out[r][3] == 0.75          # MAX over ranks on both
+        assert out[r][4] == 1000 * 10 / 2.0                     # whole-job aggregate
