@@ -59,22 +59,35 @@ def grid_fleet(n_fleet, replicas, pitch=1.0, z=0.5):
 class Fleet:
     """A resident fleet + per-drone hover targets at the start position."""
 
-    def __init__(self, n_fleet, replicas, device, substeps, layout, noise_seed):
+    def __init__(self, n_fleet, replicas, device, substeps, layout, noise_seed, waypoints=False, n_steps=1):
         import torch
         from dronesim_amd.envs import CtrlAviary
-        from dronesim_amd.fleet import Targets
+        from dronesim_amd.fleet import Targets, WaypointTargets
         self.torch = torch
+        self.n_steps = n_steps
         xyz = grid_fleet(n_fleet, replicas)
         self.n = xyz.shape[0]
+        if waypoints:
+            # config 3 (examples/fly_INDI_TrajectoryTrack.py): the reference's own 1200-row waypoint
+            # table (fixture captured from its trajGen), gate 0 + grid offset, phase i*NUM_WP/6
+            g = np.load(os.path.join(ROOT, "tests", "golden", "traj_track_waypoints.npz"))
+            n_wp = g["target_pos"].shape[0]
+            off = xyz.copy(); off[:, 2] = 0.0
+            xyz = g["gates"][0][None, :] + off
+            wp0 = (np.arange(self.n) * n_wp // 6) % n_wp
         self.env = CtrlAviary(["robobee"], self.n, initial_xyzs=xyz, aggregate_phy_steps=substeps,
                               device=device, layout=layout, noise_seed=noise_seed, dict_io=False)
-        self.tgt = Targets(self.env.ctx, self.n, layout)
-        self.tgt.set(pos=xyz.T.astype(np.float32), yaw=0.4)
+        if waypoints:
+            self.tgt = WaypointTargets(self.env.ctx, self.n, g["target_pos"], g["target_vel"], g["target_acc"],
+                                       g["target_yaw"], wp_counters=wp0, offsets=off)
+        else:
+            self.tgt = Targets(self.env.ctx, self.n, layout)
+            self.tgt.set(pos=xyz.T.astype(np.float32), yaw=0.4)
         # fly_INDI.py:214: the loop starts from action 0.4; afterwards the action is the controller's cmd
         self.env.step_fused(self.tgt, action=np.full((self.n, 4), 0.4, dtype=np.float32))
 
     def step(self):
-        self.env.step_fused(self.tgt)
+        self.env.step_fused(self.tgt, n_steps=self.n_steps)
 
     def timed(self, steps, warmup, barrier=None):
         torch = self.torch
@@ -155,10 +168,16 @@ def main():
     if rank == 0:
         graft.build()
     dist = None
+    # rehearsal knob: DSIM_BENCH_BACKEND=gloo lets several ranks share one GPU (RCCL refuses that)
+    backend = os.environ.get("DSIM_BENCH_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
         dist.barrier()
     if rank != 0:
         graft.build()       # no-op once rank 0 has built
@@ -171,7 +190,7 @@ def main():
     # weak scaling: every rank owns a same-sized contiguous shard of the N-GPU fleet; no data-path collective
     fl = Fleet(n_fleet, replicas, local, a.substeps, a.layout, sharding.rank_seed(a.noise_seed, rank))
     wall, dev_s = fl.timed(a.steps, a.warmup, barrier)
-    wall, dev_s = sharding.reduce_step_times(dist, "cuda", wall, dev_s)     # MAX over ranks
+    wall, dev_s = sharding.reduce_step_times(dist, "cuda" if backend == "nccl" else "cpu", wall, dev_s)  # MAX over ranks
     value = sharding.aggregate_throughput([fl.n] * world, a.steps, wall)
     launch_s = dev_s / a.steps
     achieved = fl.n * BYTES_PER_DRONE_STEP / launch_s / 1e9
@@ -194,7 +213,7 @@ def main():
                        "noise_seed": a.noise_seed, "launches_per_step": 1, "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_step_quad", "bytes_per_drone_step": BYTES_PER_DRONE_STEP,
+                         "kernel": "k_step_fast", "bytes_per_drone_step": BYTES_PER_DRONE_STEP,
                          "launch_us": launch_s * 1e6},
         }
         if world == 1 and not a.no_also:
@@ -210,14 +229,20 @@ def main():
             e1.record(); torch.cuda.synchronize()
             also["device_copy_GBps"] = 2 * src.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
             del src, dst
-            for name, (nf, rep, sub) in {"config2_single_fleet_4096_sub5": (4096, 1, 5),
-                                         "config3_65536_sub2": (65536, 1, 2),
-                                         "config2x1024_sub5": (4096, 1024, 5)}.items():
-                f2 = Fleet(nf, rep, local, sub, a.layout, a.noise_seed)
-                w2, d2 = f2.timed(max(20, a.steps // 2), 10)
+            # (fleet, replicas, phys_substeps, waypoint table, Env.steps per launch)
+            for name, (nf, rep, sub, wp, ns) in {
+                    "config2_single_fleet_4096_sub5": (4096, 1, 5, False, 1),
+                    "config2_single_fleet_4096_sub5_32steps_per_launch": (4096, 1, 5, False, 32),
+                    "config3_65536_waypoints_sub2": (65536, 1, 2, True, 1),
+                    "config3_65536_waypoints_sub2_32steps_per_launch": (65536, 1, 2, True, 32),
+                    "config2x1024_sub5": (4096, 1024, 5, False, 1)}.items():
+                f2 = Fleet(nf, rep, local, sub, a.layout, a.noise_seed, waypoints=wp, n_steps=ns)
                 k2 = max(20, a.steps // 2)
-                also[name] = {"drone_steps_per_s": f2.n * k2 / w2, "launch_us": d2 / k2 * 1e6,
-                              "hbm_frac": f2.n * BYTES_PER_DRONE_STEP / (d2 / k2) / 1e9 / HBM_PEAK_GBPS}
+                w2, d2 = f2.timed(k2, 10)
+                also[name] = {"drone_steps_per_s": f2.n * k2 * ns / w2, "launch_us": d2 / k2 * 1e6,
+                              "env_steps_per_launch": ns}
+                if ns == 1:
+                    also[name]["hbm_frac"] = f2.n * BYTES_PER_DRONE_STEP / (d2 / k2) / 1e9 / HBM_PEAK_GBPS
                 f2.env.close(); del f2
             out["also"] = also
         if world == 1 and not a.no_cpu_baseline:

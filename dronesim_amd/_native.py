@@ -19,7 +19,7 @@ EXPORTS = (
     "dsim_physics", "dsim_control", "dsim_observe",
 )
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NF_QUAD, NF_HEXA, NT = 24, 26, 10
 OPT_DRAG, OPT_GROUND, OPT_BCAST_TGT = 1, 2, 4
 
@@ -47,6 +47,11 @@ class StepArgs(ctypes.Structure):
         ("noise_replay", ctypes.c_void_p),
         ("type_id", ctypes.c_void_p),
         ("action", ctypes.c_void_p),
+        ("wp_table", ctypes.c_void_p),
+        ("wp_counter", ctypes.c_void_p),
+        ("wp_offset", ctypes.c_void_p),
+        ("n_wp", ctypes.c_int32),
+        ("n_steps", ctypes.c_int32),
     ]
 
 

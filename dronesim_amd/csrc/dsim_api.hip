@@ -61,6 +61,10 @@ struct StepK {
   float* yaw_e_out;
   long long n_pad;
   long long first;            // general step kernel: first drone of this launch
+  const float* wp_table;      // waypoint mode (null = targets view)
+  int* wp_counter;
+  const float* wp_offset;
+  int n_wp, n_steps;
   unsigned long long seed, step_index;
   int substeps;
   float dt_phys, dt_ctrl;
@@ -122,11 +126,24 @@ __device__ __forceinline__ void load_target(const float* ub, long long fs, unsig
   t.yaw = ldg<NT>(ub + 9 * fs, lo);
 }
 
+// Waypoint-table targets (examples/fly_INDI_TrajectoryTrack.py:242-245): row wp of the table (+ the
+// drone's own position offset).  The 48 KB table is gathered per lane and stays L1/L2-resident.
+__device__ __forceinline__ void waypoint_target(const StepK& a, long long i, int wp, Target& t) {
+  const float* r = a.wp_table + (long long)wp * 10;
+  t.pos = v3(r[0], r[1], r[2]);
+  if (a.wp_offset) t.pos = t.pos + v3(a.wp_offset[i], a.wp_offset[a.n_pad + i], a.wp_offset[2 * a.n_pad + i]);
+  t.vel = v3(r[3], r[4], r[5]);
+  t.acc = v3(r[6], r[7], r[8]);
+  t.yaw = r[9];
+}
+// wp_counters[j] + 1 if < NUM_WP - 1 else 0   (fly_INDI_TrajectoryTrack.py:253-256)
+__device__ __forceinline__ int waypoint_next(int wp, int n_wp) { return wp < n_wp - 1 ? wp + 1 : 0; }
+
 // physics sub-steps of one Env.step for a quad (BaseAviary.py:510-545)
 // NOISE: 0 = off, 1 = in-kernel counter-based noise, 2 = replay buffer if given else in-kernel
 template <int NOISE>
 __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
-                                              const float cmd[4]) {
+                                              const float cmd[4], unsigned long long step_index) {
   V3 F, tau;
   if (NOISE == 0) quad_wrench(T, cmd, nullptr, F, tau);   // cmd is constant over the sub-steps
   for (int k = 0; k < a.substeps; ++k) {
@@ -136,7 +153,7 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
 #pragma unroll
         for (int j = 0; j < 8; ++j) nz[j] = a.noise_replay[((long long)k * 8 + j) * a.n_pad + i];
       } else {
-        noise_normals<4>(a.seed, (uint64_t)i, a.step_index * (uint64_t)a.substeps + (uint64_t)k, nz);
+        noise_normals<4>(a.seed, (uint64_t)i, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { nz[j] *= 0.01f; nz[4 + j] *= 0.001f; }   // BaseAviary.py:1518-1521
       }
@@ -156,8 +173,10 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
 // the next tile into registers, 266 vs 176 us, and two tiles per workgroup with both tiles' loads
 // issued up front, 190 vs 163 us — fewer, fatter waves hide HBM latency worse than 4 waves/SIMD of
 // this short kernel; forcing 4 waves/SIMD by spilling also lost, 176 vs 172 us.)
-template <bool NOISE, bool NT>
-__global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_step_fast(StepK a) {
+// EXT = waypoint-table targets and/or several steps per launch; the plain single-step kernel is
+// compiled without that generality (it would cost the hot kernel registers: 128 + spills vs 121).
+template <bool NOISE, bool NT, bool EXT>
+__global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(StepK a) {
   const DevType& T = a.types[0];
   const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
   const unsigned sl = 4u * kv_lane(a.st, threadIdx.x), tl = 4u * kv_lane(a.tg, threadIdx.x);   // bytes
@@ -169,11 +188,24 @@ __global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_step_fast(StepK a) {
   Target tg;
   load_rigid<NT>(sb, sfs, sl, s);
   load_mem<4, NT>(sb, sfs, sl, m);
-  load_target<NT>(tb, tfs, tl, tg);
-  quad_substeps<NOISE ? 1 : 0>(T, a, i0 + threadIdx.x, s, m.cmd);     // stored cmd is already clipped
+  const long long i = i0 + threadIdx.x;
   V3 pos_e;
   float yaw_e;
-  indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  if (!EXT) {
+    load_target<NT>(tb, tfs, tl, tg);
+    quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index);    // stored cmd is already clipped
+    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  } else {
+    int wp = 0;
+    if (a.wp_table) wp = a.wp_counter[i]; else load_target<NT>(tb, tfs, tl, tg);
+    for (int k = 0; k < a.n_steps; ++k) {
+      if (a.wp_table) waypoint_target(a, i, wp, tg);
+      quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index + k);
+      indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+      wp = waypoint_next(wp, a.n_wp);
+    }
+    if (a.wp_table) a.wp_counter[i] = wp;
+  }
   store_rigid<NT>(sb, sfs, sl, s);
   store_mem<4, NT>(sb, sfs, sl, m);
 }
@@ -191,19 +223,25 @@ __global__ __launch_bounds__(256) void k_step_quad(StepK a) {
   Target tg;
   load_rigid(a.st.base + o, a.st.field_stride, 0u, s);
   load_mem<4>(a.st.base + o, a.st.field_stride, 0u, m);
-  load_target(a.tg.base + kv_off(a.tg, i), a.tg.field_stride, 0u, tg);
-  float act[4];
+  int wp = 0;
+  if (a.wp_table) wp = a.wp_counter[i]; else load_target(a.tg.base + kv_off(a.tg, i), a.tg.field_stride, 0u, tg);
+  for (int k = 0; k < a.n_steps; ++k) {
+    float act[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) act[j] = m.cmd[j];
-  if (a.action) {
+    for (int j = 0; j < 4; ++j) act[j] = m.cmd[j];
+    if (a.action && k == 0) {            // an explicit action applies to the first Env.step only
 #pragma unroll
-    for (int j = 0; j < 4; ++j) act[j] = a.action[(long long)j * a.n_pad + i];
-    preprocess_action<4>(T, act, act);   // the stored cmd is already clipped (INDIControl.py:487)
+      for (int j = 0; j < 4; ++j) act[j] = a.action[(long long)j * a.n_pad + i];
+      preprocess_action<4>(T, act, act);   // the stored cmd is already clipped (INDIControl.py:487)
+    }
+    if (a.wp_table) waypoint_target(a, i, wp, tg);
+    quad_substeps<NOISE ? 2 : 0>(T, a, i, s, act, a.step_index + k);
+    V3 pos_e;
+    float yaw_e;
+    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+    wp = waypoint_next(wp, a.n_wp);
   }
-  quad_substeps<NOISE ? 2 : 0>(T, a, i, s, act);
-  V3 pos_e;
-  float yaw_e;
-  indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  if (a.wp_table) a.wp_counter[i] = wp;
   store_rigid(a.st.base + o, a.st.field_stride, 0u, s);
   store_mem<4>(a.st.base + o, a.st.field_stride, 0u, m);
 }
@@ -222,7 +260,7 @@ __global__ __launch_bounds__(256) void k_physics_quad(StepK a) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) raw[j] = a.action ? a.action[(long long)j * a.n_pad + i] : a.st.base[o + (20 + j) * fs];
   preprocess_action<4>(T, raw, cmd);
-  quad_substeps<NOISE ? 2 : 0>(T, a, i, s, cmd);
+  quad_substeps<NOISE ? 2 : 0>(T, a, i, s, cmd, a.step_index);
   store_rigid(a.st.base + o, a.st.field_stride, 0u, s);
   if (a.echo) {
 #pragma unroll
@@ -422,7 +460,7 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
   if (ctx->n_types > 1 && !args->type_id) return DSIM_E_ARG;
   int rc = make_kview(state, DSIM_NF_QUAD, &a->st);
   if (rc) return rc;
-  if (targets) {
+  if (targets && !args->wp_table) {
     const bool bc = (args->options & DSIM_OPT_BCAST_TGT) != 0;
     rc = make_kview(*targets, DSIM_NT, &a->tg, bc);
     if (rc) return rc;
@@ -432,7 +470,10 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
   }
   a->types = ctx->d_types; a->type_id = args->type_id; a->noise_replay = args->noise_replay;
   a->action = args->action; a->echo = nullptr; a->pos_e_out = nullptr; a->yaw_e_out = nullptr;
-  a->n_pad = state.n_pad; a->first = 0; a->seed = args->noise_seed; a->step_index = args->step_index;
+  a->n_pad = state.n_pad; a->first = 0; a->seed = args->noise_seed;
+  a->wp_table = args->wp_table; a->wp_counter = args->wp_counter; a->wp_offset = args->wp_offset;
+  a->n_wp = args->n_wp; a->n_steps = args->n_steps > 1 ? args->n_steps : 1;
+  if (a->wp_table && (!a->wp_counter || a->n_wp < 1)) return DSIM_E_ARG; a->step_index = args->step_index;
   a->substeps = args->phys_substeps; a->dt_phys = args->dt_phys; a->dt_ctrl = args->dt_ctrl;
   a->options = args->options;
   return DSIM_OK;
@@ -466,10 +507,13 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     const long long tiles = a.n_pad / 256;
     if (tiles > 0) {
       const dim3 g((unsigned)tiles);
-      if (noise) { if (nt) hipLaunchKernelGGL((k_step_fast<true, true>), g, b, 0, st_, a);
-                   else hipLaunchKernelGGL((k_step_fast<true, false>), g, b, 0, st_, a); }
-      else { if (nt) hipLaunchKernelGGL((k_step_fast<false, true>), g, b, 0, st_, a);
-             else hipLaunchKernelGGL((k_step_fast<false, false>), g, b, 0, st_, a); }
+      const bool ext = a.wp_table != nullptr || a.n_steps > 1;
+#define DSIM_FAST_CASE(N_, T_)                                                          \
+  do { if (ext) hipLaunchKernelGGL((k_step_fast<N_, T_, true>), g, b, 0, st_, a);       \
+       else hipLaunchKernelGGL((k_step_fast<N_, T_, false>), g, b, 0, st_, a); } while (0)
+      if (noise) { if (nt) DSIM_FAST_CASE(true, true); else DSIM_FAST_CASE(true, false); }
+      else { if (nt) DSIM_FAST_CASE(false, true); else DSIM_FAST_CASE(false, false); }
+#undef DSIM_FAST_CASE
       first = tiles * 256;
     }
   }

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from .. import _native as nat
-from ..fleet import Context, FleetState, Targets
+from ..fleet import Context, FleetState, Targets, WaypointTargets
 from ..params import DroneType, builtin_type
 
 
@@ -141,6 +141,8 @@ class CtrlAviary:
         a.noise_replay = None
         a.type_id = self._type_id.data_ptr() if self._type_id is not None else None
         a.action = None
+        a.wp_table = a.wp_counter = a.wp_offset = None
+        a.n_wp, a.n_steps = 0, 1
         return a
 
     # ------------------------------------------------------------------ gym surface
@@ -175,20 +177,29 @@ class CtrlAviary:
         self._env_steps += 1
         return self._computeObs(), self._computeReward(), self._computeDone(), self._computeInfo()
 
-    def step_fused(self, targets: Targets, control_timestep: Optional[float] = None, action=None):
+    def step_fused(self, targets, control_timestep: Optional[float] = None, action=None, n_steps: int = 1):
         """One launch = ``env.step(action)`` followed by ``computeControl`` for every drone:
         the body of the reference's example loop (examples/fly_INDI.py:223-239).  ``action``
         None = the controller's last command (every iteration after the first); the first
-        iteration of the example passes its initial action 0.4 (fly_INDI.py:214)."""
+        iteration of the example passes its initial action 0.4 (fly_INDI.py:214).
+        ``targets``: :class:`Targets` (per drone or broadcast) or :class:`WaypointTargets`.
+        ``n_steps`` > 1 runs that many loop iterations inside the one launch."""
+        wp = isinstance(targets, WaypointTargets)
         args = self.step_args(control_timestep, nat.OPT_BCAST_TGT if targets.broadcast else 0)
+        args.n_steps = n_steps
+        if wp:
+            targets.fill(args)
+            tview = nat.View()
+        else:
+            tview = targets.view()
         if action is not None:
             self._load_action(action)
             args.action = self._action_buf.data_ptr()
         self._use_last_action = False   # from here on the applied action IS the controller cmd
         nat.check(self.ctx.lib.dsim_step(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
-                                         self.state.view(), targets.view(), ctypes.byref(args)))
-        self.step_counter += self.AGGR_PHY_STEPS
-        self._env_steps += 1
+                                         self.state.view(), tview, ctypes.byref(args)))
+        self.step_counter += self.AGGR_PHY_STEPS * n_steps
+        self._env_steps += n_steps
 
     def close(self):
         self.ctx.close()

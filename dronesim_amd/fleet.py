@@ -168,3 +168,43 @@ class Targets(BlockedSoA):
                 if t.shape[1] == 1:
                     t = t.expand(nf, self.n)
                 self.set_fields(f0, t)
+
+
+class WaypointTargets:
+    """Targets read from ONE waypoint table shared by the whole fleet, as
+    examples/fly_INDI_TrajectoryTrack.py does per drone (:178-189 tables, :242-245 lookup,
+    :253-256 counter advance with wrap).  The table lives in device memory once
+    (1200 x 10 floats = 48 KB for the example); each drone keeps an int32 row counter and an
+    optional position offset (so a fleet can fly the same figure side by side)."""
+
+    def __init__(self, ctx: Context, n: int, target_pos, target_vel=None, target_acc=None, target_yaw=None,
+                 wp_counters=None, offsets=None, pad: int = 256):
+        dev = ctx.device
+        pos = np.asarray(target_pos, dtype=np.float32)
+        n_wp = pos.shape[0]
+        tab = np.zeros((n_wp, 10), dtype=np.float32)
+        tab[:, 0:3] = pos
+        if target_vel is not None:
+            tab[:, 3:6] = np.asarray(target_vel, dtype=np.float32)
+        if target_acc is not None:
+            tab[:, 6:9] = np.asarray(target_acc, dtype=np.float32)
+        if target_yaw is not None:
+            tab[:, 9] = np.asarray(target_yaw, dtype=np.float32)
+        self.n, self.n_pad, self.n_wp = n, pad_to(n, pad), n_wp
+        self.table = torch.from_numpy(tab).to(dev)
+        c = np.zeros(self.n_pad, dtype=np.int32)
+        if wp_counters is not None:
+            c[:n] = np.asarray(wp_counters, dtype=np.int32)
+        self.counters = torch.from_numpy(c).to(dev)
+        self.offsets = None
+        if offsets is not None:
+            o = np.zeros((3, self.n_pad), dtype=np.float32)
+            o[:, :n] = np.asarray(offsets, dtype=np.float32).T
+            self.offsets = torch.from_numpy(o).to(dev)
+        self.broadcast = False
+
+    def fill(self, args: nat.StepArgs) -> None:
+        args.wp_table = self.table.data_ptr()
+        args.wp_counter = self.counters.data_ptr()
+        args.wp_offset = self.offsets.data_ptr() if self.offsets is not None else None
+        args.n_wp = self.n_wp

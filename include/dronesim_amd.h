@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DSIM_ABI_VERSION 1
+#define DSIM_ABI_VERSION 2
 #define DSIM_MAX_ACT 6     /* actuators per vehicle (quad 4, morphing hexa 6) */
 #define DSIM_MAX_TYPES 8
 
@@ -128,6 +128,20 @@ typedef struct dsim_step_args {
                                instead of the stored cmd (first iteration of the example loop: the
                                initial action 0.4, fly_INDI.py:214, while INDIControl.cmd starts at 0).
                                dsim_physics: the action of Env.step(action); NULL = stored cmd.      */
+  /* -- waypoint-table targets (examples/fly_INDI_TrajectoryTrack.py:178-189, 242-256) ------------
+   * wp_table non-NULL: the targets view is ignored; drone i tracks row wp_counter[i] of the table
+   * (row-major [n_wp][10] = pos3 vel3 acc3 yaw, device memory, read-only; 1200 rows = 48 KB for the
+   * example) plus its own position offset, and after every control evaluation the counter advances
+   * by one and wraps to 0 after n_wp-1, as the example does.                                        */
+  const float* wp_table;
+  int32_t*     wp_counter;  /* [n_pad] device, in-out                                              */
+  const float* wp_offset;   /* nullable; SoA [3][n_pad] added to the table's target position       */
+  int32_t      n_wp;
+  /* -- multi-step launches -------------------------------------------------------------------------
+   * n_steps > 1: dsim_step runs that many consecutive [Env.step + computeControl] iterations in ONE
+   * launch with the state held in registers (step_index, step_index+1, ...); targets stay fixed
+   * unless they come from the waypoint table.  0 is treated as 1.                                   */
+  int32_t      n_steps;
 } dsim_step_args;
 
 typedef struct dsim_ctx dsim_ctx;

@@ -269,6 +269,70 @@ def test_inkernel_noise_matches_definition(gpu):
 
 
 # ---------------------------------------------------------------------------
+# config 3: waypoint-table tracking (examples/fly_INDI_TrajectoryTrack.py) and multi-step launches
+# ---------------------------------------------------------------------------
+def _traj_fleet(gpu, golden_dir, n, noise_seed=0):
+    from dronesim_amd.envs import CtrlAviary
+    from dronesim_amd.fleet import WaypointTargets
+    g = np.load(os.path.join(golden_dir, "traj_track_waypoints.npz"))
+    n_wp = g["target_pos"].shape[0]
+    side = int(math.ceil(math.sqrt(n)))
+    off = np.stack([np.arange(n) % side, np.arange(n) // side, np.zeros(n)], 1).astype(np.float64)
+    xyz = g["gates"][0][None, :] + off                       # each drone starts at gate 0 + its grid offset
+    wp0 = np.array([int((i * n_wp / 6) % n_wp) for i in range(n)])    # fly_INDI_TrajectoryTrack.py:187-189
+    env = CtrlAviary(["robobee"], n, initial_xyzs=xyz, aggregate_phy_steps=2, noise_seed=noise_seed, dict_io=False)
+    wps = WaypointTargets(env.ctx, n, g["target_pos"], g["target_vel"], g["target_acc"], g["target_yaw"],
+                          wp_counters=wp0, offsets=off)
+    return env, wps, g, off, wp0
+
+
+def test_waypoint_tracking_vs_oracle(gpu, golden_dir):
+    """Config 3 semantics: 2 sub-steps per control, control_timestep 2/240 (the reference plays the
+    96 Hz table at 0.8x speed), waypoint row advances by one per control step and wraps."""
+    n = 300
+    env, wps, g, off, wp0 = _traj_fleet(gpu, golden_dir, n)
+    t = params.builtin_type("robobee")
+    O = orc.Oracle([t])
+    rigid, mem = env.state.rigid_aos(), env.state.mem_aos()
+    tab = np.concatenate([g["target_pos"], g["target_vel"], g["target_acc"], g["target_yaw"][:, None]], 1).astype(np.float32).astype(np.float64)
+    dtc = float(np.float32(2 / 240))
+    wp = wp0.copy()
+    n_wp = tab.shape[0]
+    wp[5] = n_wp - 3                                       # forces a wrap inside the run
+    wps.counters[5] = n_wp - 3
+    for k in range(40):
+        env.step_fused(wps, control_timestep=dtc, action=np.full((n, 4), 0.4, dtype=np.float32) if k == 0 else None)
+        tgt = tab[wp].copy()
+        tgt[:, 0:3] = f32(tgt[:, 0:3].astype(np.float32) + off.astype(np.float32))     # fp32 add, as the kernel does
+        a6 = None
+        if k == 0:
+            a6 = np.zeros((n, 6)); a6[:, :4] = 0.4
+        assert O.step(rigid, mem, tgt, 2, DT, dtc, action=a6) == 0
+        wp = np.where(wp < n_wp - 1, wp + 1, 0)
+    np.testing.assert_array_equal(wps.counters[:n].cpu().numpy(), wp)
+    assert rel_err(env.state.rigid_aos(), rigid, RIGID_SCALE).max() < 1e-3     # 40 chained steps
+    assert rel_err(env.state.mem_aos(), mem, MEM_SCALE).max() < 1e-3
+    env.close()
+
+
+@pytest.mark.parametrize("noise_seed", [0, 77])
+def test_multi_step_launch_equals_single_steps(gpu, golden_dir, noise_seed):
+    """n_steps = K in one launch is bit-identical to K single-step launches (state, counters, noise stream)."""
+    n = 1000
+    envA, wpA, *_ = _traj_fleet(gpu, golden_dir, n, noise_seed)
+    envB, wpB, *_ = _traj_fleet(gpu, golden_dir, n, noise_seed)
+    a0 = np.full((n, 4), 0.4, dtype=np.float32)
+    envA.step_fused(wpA, action=a0); envB.step_fused(wpB, action=a0)
+    for _ in range(12):
+        envA.step_fused(wpA)
+    envB.step_fused(wpB, n_steps=5); envB.step_fused(wpB, n_steps=7)
+    np.testing.assert_array_equal(envA.state.fields(0, 24).cpu().numpy(), envB.state.fields(0, 24).cpu().numpy())
+    np.testing.assert_array_equal(wpA.counters.cpu().numpy(), wpB.counters.cpu().numpy())
+    assert envA._env_steps == envB._env_steps == 13
+    envA.close(); envB.close()
+
+
+# ---------------------------------------------------------------------------
 # size-independent properties at BASELINE sizes
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [65536, 1 << 20])
