@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libdronesim_amd.so")
 # every symbol include/dronesim_amd.h declares
 EXPORTS = (
     "dsim_abi_version", "dsim_strerror", "dsim_create", "dsim_destroy", "dsim_reset", "dsim_step",
-    "dsim_physics", "dsim_control", "dsim_observe",
+    "dsim_physics", "dsim_control", "dsim_observe", "dsim_query",
 )
 
 ABI_VERSION = 2
@@ -87,6 +87,7 @@ def load() -> ctypes.CDLL:
     lib.dsim_physics.argtypes = [vp, vp, i64, View, vp, ctypes.POINTER(StepArgs)]  # (.., last_action_out, args)
     lib.dsim_control.argtypes = [vp, vp, i64, View, View, ctypes.POINTER(StepArgs), vp, vp]
     lib.dsim_observe.argtypes = [vp, vp, i64, View, vp, vp, i32]
+    lib.dsim_query.argtypes = [vp, vp, i32, ctypes.POINTER(ctypes.c_int64)]
     if lib.dsim_abi_version() != ABI_VERSION:
         raise ImportError(f"libdronesim_amd.so ABI {lib.dsim_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

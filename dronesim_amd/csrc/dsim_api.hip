@@ -25,7 +25,9 @@
 struct dsim_ctx {
   int device;
   int n_types;
+  int max_act;                            // 4: quads only; 6: the table holds a morphing hexa
   DevType* d_types;                       // device copy of the type table
+  unsigned long long* d_counters;         // [2] diagnostics (dsim_query)
   dsim_type_params h_types[DSIM_MAX_TYPES];
 };
 
@@ -59,6 +61,7 @@ struct StepK {
   float* echo;                // physics kernel: clipped action out, or null
   float* pos_e_out;           // control kernel only
   float* yaw_e_out;
+  unsigned long long* counters;
   long long n_pad;
   long long first;            // general step kernel: first drone of this launch
   const float* wp_table;      // waypoint mode (null = targets view)
@@ -140,8 +143,9 @@ __device__ __forceinline__ void waypoint_target(const StepK& a, long long i, int
 __device__ __forceinline__ int waypoint_next(int wp, int n_wp) { return wp < n_wp - 1 ? wp + 1 : 0; }
 
 // physics sub-steps of one Env.step for a quad (BaseAviary.py:510-545)
-// NOISE: 0 = off, 1 = in-kernel counter-based noise, 2 = replay buffer if given else in-kernel
-template <int NOISE>
+// NOISE: 0 = off, 1 = in-kernel counter-based noise, 2 = replay buffer if given else in-kernel.
+// NROW = rows per sub-step of the replay buffer's force / moment halves (the kernel's NACT).
+template <int NOISE, int NROW = 4>
 __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[4], unsigned long long step_index) {
   V3 F, tau;
@@ -151,7 +155,10 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
       float nz[8];
       if (NOISE == 2 && a.noise_replay) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) nz[j] = a.noise_replay[((long long)k * 8 + j) * a.n_pad + i];
+        for (int j = 0; j < 4; ++j) {
+          nz[j] = a.noise_replay[((long long)k * 2 * NROW + j) * a.n_pad + i];
+          nz[4 + j] = a.noise_replay[((long long)k * 2 * NROW + NROW + j) * a.n_pad + i];
+        }
       } else {
         noise_normals<4>(a.seed, (uint64_t)i, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);
 #pragma unroll
@@ -163,9 +170,32 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
   }
 }
 
+// the same for the morphing hexa (BaseAviary.py:1389-1457); replay rows: f[6], m[6]
+template <bool NOISE>
+__device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
+                                              const float cmd[6], unsigned long long step_index) {
+  V3 F, tau;
+  if (!NOISE) hexa_wrench(T, cmd, nullptr, F, tau);
+  for (int k = 0; k < a.substeps; ++k) {
+    if (NOISE) {
+      float nz[12];
+      if (a.noise_replay) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) nz[j] = a.noise_replay[((long long)k * 12 + j) * a.n_pad + i];
+      } else {
+        noise_normals<6>(a.seed, (uint64_t)i, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { nz[j] *= 0.01f; nz[6 + j] *= 0.001f; }   // BaseAviary.py:1429-1430
+      }
+      hexa_wrench(T, cmd, nz, F, tau);
+    }
+    bullet_step(T, a.dt_phys, s, F, tau);
+  }
+}
+
 // ---- fused Env.step + computeControl (the hot path) -----------------------
-// Fast form: homogeneous fleet, action = the controller's stored cmd, whole 256-drone tiles (the
-// launcher hands ragged tails and every other configuration to the general kernel below).
+// Fast form: homogeneous quad fleet, action = the controller's stored cmd, whole 256-drone tiles
+// (the launcher hands ragged tails and every other configuration to the general kernel below).
 // No per-lane branches and no bounds checks, so every access keeps the scalar-base + 32-bit
 // lane-offset form (one VGPR of addressing for all 58 accesses).
 //
@@ -210,82 +240,102 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
   store_mem<4, NT>(sb, sfs, sl, m);
 }
 
-// General form: per-drone type ids, explicit action override, noise replay, ragged sizes.
-// a.first = first drone this launch covers.
-template <bool NOISE, bool UNIFORM>
-__global__ __launch_bounds__(256) void k_step_quad(StepK a) {
+// General form: per-drone type ids (mixed quad / hexa fleets, NACT = 6), explicit action
+// override, noise replay, ragged sizes.  a.first = first drone this launch covers.
+// In a mixed wave the quad and hexa branches execute one after the other (lane-masked).
+template <bool NOISE, bool UNIFORM, int NACT>
+__global__ __launch_bounds__(256) void k_step_gen(StepK a) {
   const long long i = a.first + (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n_pad) return;
   const DevType& T = a.types[UNIFORM ? 0 : a.type_id[i]];
   const long long o = kv_off(a.st, i);
   Rigid s;
-  CtrlMem<4> m;
+  CtrlMem<NACT> m;
   Target tg;
   load_rigid(a.st.base + o, a.st.field_stride, 0u, s);
-  load_mem<4>(a.st.base + o, a.st.field_stride, 0u, m);
+  load_mem<NACT>(a.st.base + o, a.st.field_stride, 0u, m);
   int wp = 0;
   if (a.wp_table) wp = a.wp_counter[i]; else load_target(a.tg.base + kv_off(a.tg, i), a.tg.field_stride, 0u, tg);
+  const bool hexa = NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA;
   for (int k = 0; k < a.n_steps; ++k) {
-    float act[4];
+    float act[NACT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) act[j] = m.cmd[j];
+    for (int j = 0; j < NACT; ++j) act[j] = m.cmd[j];
     if (a.action && k == 0) {            // an explicit action applies to the first Env.step only
 #pragma unroll
-      for (int j = 0; j < 4; ++j) act[j] = a.action[(long long)j * a.n_pad + i];
-      preprocess_action<4>(T, act, act);   // the stored cmd is already clipped (INDIControl.py:487)
+      for (int j = 0; j < NACT; ++j) act[j] = a.action[(long long)j * a.n_pad + i];
+      preprocess_action<NACT>(T, act, act);   // the stored cmd is already clipped (INDIControl.py:487)
     }
     if (a.wp_table) waypoint_target(a, i, wp, tg);
-    quad_substeps<NOISE ? 2 : 0>(T, a, i, s, act, a.step_index + k);
     V3 pos_e;
     float yaw_e;
-    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+    if (NACT == 6 && hexa) {
+      if constexpr (NACT == 6) {
+        hexa_substeps<NOISE>(T, a, i, s, act, a.step_index + k);
+        indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.counters);
+      }
+    } else {
+      quad_substeps<NOISE ? 2 : 0, NACT>(T, a, i, s, act, a.step_index + k);
+      indi_quad<false, NACT>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+    }
     wp = waypoint_next(wp, a.n_wp);
   }
   if (a.wp_table) a.wp_counter[i] = wp;
   store_rigid(a.st.base + o, a.st.field_stride, 0u, s);
-  store_mem<4>(a.st.base + o, a.st.field_stride, 0u, m);
+  store_mem<NACT>(a.st.base + o, a.st.field_stride, 0u, m);
 }
 
 // ---- Env.step only ---------------------------------------------------------
-template <bool NOISE, bool UNIFORM>
-__global__ __launch_bounds__(256) void k_physics_quad(StepK a) {
+template <bool NOISE, bool UNIFORM, int NACT>
+__global__ __launch_bounds__(256) void k_physics_gen(StepK a) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n_pad) return;
   const DevType& T = a.types[UNIFORM ? 0 : a.type_id[i]];
   const long long o = kv_off(a.st, i);
   Rigid s;
   load_rigid(a.st.base + o, a.st.field_stride, 0u, s);
-  float raw[4], cmd[4];
+  float raw[NACT], cmd[NACT];
   const long long fs = a.st.field_stride;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) raw[j] = a.action ? a.action[(long long)j * a.n_pad + i] : a.st.base[o + (20 + j) * fs];
-  preprocess_action<4>(T, raw, cmd);
-  quad_substeps<NOISE ? 2 : 0>(T, a, i, s, cmd, a.step_index);
+  for (int j = 0; j < NACT; ++j) raw[j] = a.action ? a.action[(long long)j * a.n_pad + i] : a.st.base[o + (20 + j) * fs];
+  preprocess_action<NACT>(T, raw, cmd);
+  if (NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA) {
+    if constexpr (NACT == 6) hexa_substeps<NOISE>(T, a, i, s, cmd, a.step_index);
+  } else {
+    quad_substeps<NOISE ? 2 : 0, NACT>(T, a, i, s, cmd, a.step_index);
+  }
   store_rigid(a.st.base + o, a.st.field_stride, 0u, s);
   if (a.echo) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a.echo[(long long)j * a.n_pad + i] = cmd[j];   // last_clipped_action, BaseAviary.py:545
+    for (int j = 0; j < NACT; ++j) a.echo[(long long)j * a.n_pad + i] = cmd[j];   // last_clipped_action, BaseAviary.py:545
   }
 }
 
 // ---- computeControl only ----------------------------------------------------
-template <bool UNIFORM>
-__global__ __launch_bounds__(256) void k_control_quad(StepK a) {
+template <bool UNIFORM, int NACT>
+__global__ __launch_bounds__(256) void k_control_gen(StepK a) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n_pad) return;
   const DevType& T = a.types[UNIFORM ? 0 : a.type_id[i]];
   const long long o = kv_off(a.st, i);
   Rigid s;
-  CtrlMem<4> m;
+  CtrlMem<NACT> m;
   Target tg;
   load_rigid(a.st.base + o, a.st.field_stride, 0u, s);
-  load_mem<4>(a.st.base + o, a.st.field_stride, 0u, m);
+  load_mem<NACT>(a.st.base + o, a.st.field_stride, 0u, m);
   load_target(a.tg.base + kv_off(a.tg, i), a.tg.field_stride, 0u, tg);
   V3 pos_e;
-  float yaw_e;
-  if (a.yaw_e_out) indi_quad<true>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  else indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  store_mem<4>(a.st.base + o, a.st.field_stride, 0u, m);
+  float yaw_e = 0.0f;
+  if (NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA) {
+    if constexpr (NACT == 6) {
+      if (a.yaw_e_out) indi_hexa<true>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.counters);
+      else indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.counters);
+    }
+  } else {
+    if (a.yaw_e_out) indi_quad<true, NACT>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+    else indi_quad<false, NACT>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  }
+  store_mem<NACT>(a.st.base + o, a.st.field_stride, 0u, m);
   if (a.pos_e_out) {
     a.pos_e_out[i] = pos_e.x; a.pos_e_out[a.n_pad + i] = pos_e.y; a.pos_e_out[2 * a.n_pad + i] = pos_e.z;
   }
@@ -377,7 +427,11 @@ static void to_dev(const dsim_type_params& p, DevType* d) {
     d->pmin[j] = (float)p.pwm_min[j]; d->pmax[j] = (float)p.pwm_max[j];
     d->spin[j] = (float)p.rotor_spin[j];
     for (int k = 0; k < 3; ++k) { d->rpos[j][k] = (float)p.rotor_pos[j][k]; d->raxis[j][k] = (float)p.rotor_axis[j][k]; }
-    for (int i = 0; i < DSIM_MAX_ACT; ++i) d->alloc[j][i] = (float)p.alloc[j][i];
+    for (int i = 0; i < DSIM_MAX_ACT; ++i) {
+      d->alloc[j][i] = (float)p.alloc[j][i];
+      d->alloc2[j][i] = (float)p.alloc2[j][i];
+      d->B[j][i] = (float)(p.G1[j][i] / 0.05);          // INDIControl_6DOF.py:627: self.G1 / 0.05
+    }
   }
   d->kp = (float)p.kp_pos; d->kd = (float)p.kd_pos;
   d->g = (float)p.gravity; d->clin = (float)p.lin_damping; d->cang = (float)p.ang_damping;
@@ -405,8 +459,12 @@ const char* dsim_strerror(int code) {
 int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n_types) {
   if (!out || !types) return DSIM_E_ARG;
   if (n_types < 1 || n_types > DSIM_MAX_TYPES) return DSIM_E_TYPES;
+  int max_act = 4;
   for (int t = 0; t < n_types; ++t) {
-    if (types[t].n_act < 1 || types[t].n_act > DSIM_MAX_ACT || !(types[t].mass > 0)) return DSIM_E_TYPES;
+    if (!(types[t].mass > 0)) return DSIM_E_TYPES;
+    if (types[t].kind == DSIM_KIND_QUAD) { if (types[t].n_act != 4) return DSIM_E_TYPES; }
+    else if (types[t].kind == DSIM_KIND_HEXA6DOF) { if (types[t].n_act != 6) return DSIM_E_TYPES; max_act = 6; }
+    else return DSIM_E_TYPES;
     for (int k = 0; k < 3; ++k) if (!(types[t].inertia[k] > 0)) return DSIM_E_TYPES;
   }
   int count = 0;
@@ -415,12 +473,19 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
   if (e != hipSuccess) return (int)e;
   dsim_ctx* c = new (std::nothrow) dsim_ctx;
   if (!c) return DSIM_E_ARG;
-  c->device = device; c->n_types = n_types; c->d_types = nullptr;
+  c->device = device; c->n_types = n_types; c->max_act = max_act; c->d_types = nullptr; c->d_counters = nullptr;
   DevType h[DSIM_MAX_TYPES];
   for (int t = 0; t < n_types; ++t) { c->h_types[t] = types[t]; to_dev(types[t], &h[t]); }
   e = hipMalloc((void**)&c->d_types, sizeof(DevType) * n_types);
   if (e == hipSuccess) e = hipMemcpy(c->d_types, h, sizeof(DevType) * n_types, hipMemcpyHostToDevice);
-  if (e != hipSuccess) { if (c->d_types) (void)hipFree(c->d_types); delete c; return (int)e; }
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * 2);
+  if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(unsigned long long) * 2);
+  if (e != hipSuccess) {
+    if (c->d_types) (void)hipFree(c->d_types);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    delete c;
+    return (int)e;
+  }
   *out = c;
   return DSIM_OK;
 }
@@ -428,26 +493,33 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
 int dsim_destroy(dsim_ctx* ctx) {
   if (!ctx) return DSIM_E_ARG;
   hipError_t e = hipFree(ctx->d_types);
+  (void)hipFree(ctx->d_counters);
   delete ctx;
   return (int)e;
 }
 
-static inline unsigned grid_for(long long n) { return (unsigned)((n + 255) / 256); }
-
-static bool all_quad(const dsim_ctx* c) {
-  for (int t = 0; t < c->n_types; ++t) if (c->h_types[t].kind != DSIM_KIND_QUAD) return false;
-  return true;
+int dsim_query(dsim_ctx* ctx, void* stream, int32_t what, int64_t* value_out) {
+  if (!ctx || !value_out || what < 0 || what > 1) return DSIM_E_ARG;
+  unsigned long long h[2];
+  hipError_t e = hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  *value_out = (int64_t)h[what];
+  return DSIM_OK;
 }
+
+static inline unsigned grid_for(long long n) { return (unsigned)((n + 255) / 256); }
 
 int dsim_reset(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* init_pos,
                const float* init_rpy, const float* init_vel, const float* init_cmd, const uint8_t* type_id) {
   if (!ctx || !init_pos || !init_rpy || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
+  if (ctx->n_types > 1 && !type_id) return DSIM_E_ARG;
   ResetK a;
-  int rc = make_kview(state, DSIM_NF_QUAD, &a.st);
+  int rc = make_kview(state, 20 + ctx->max_act, &a.st);
   if (rc) return rc;
   a.types = ctx->d_types; a.type_id = type_id;
   a.pos = init_pos; a.rpy = init_rpy; a.vel = init_vel; a.cmd = init_cmd;
-  a.n_pad = state.n_pad; a.n_fields = state.n_fields;
+  a.n_pad = state.n_pad; a.n_fields = 20 + ctx->max_act;
   hipLaunchKernelGGL(k_reset, dim3(grid_for(a.n_pad)), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
@@ -456,9 +528,8 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
                       const dsim_step_args* args, StepK* a) {
   if (!ctx || !args || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
   if (args->phys_substeps < 0 || !(args->dt_phys > 0) || !(args->dt_ctrl > 0)) return DSIM_E_ARG;
-  if (!all_quad(ctx)) return DSIM_E_UNSUPPORTED;
   if (ctx->n_types > 1 && !args->type_id) return DSIM_E_ARG;
-  int rc = make_kview(state, DSIM_NF_QUAD, &a->st);
+  int rc = make_kview(state, 20 + ctx->max_act, &a->st);
   if (rc) return rc;
   if (targets && !args->wp_table) {
     const bool bc = (args->options & DSIM_OPT_BCAST_TGT) != 0;
@@ -470,22 +541,31 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
   }
   a->types = ctx->d_types; a->type_id = args->type_id; a->noise_replay = args->noise_replay;
   a->action = args->action; a->echo = nullptr; a->pos_e_out = nullptr; a->yaw_e_out = nullptr;
+  a->counters = ctx->d_counters;
   a->n_pad = state.n_pad; a->first = 0; a->seed = args->noise_seed;
   a->wp_table = args->wp_table; a->wp_counter = args->wp_counter; a->wp_offset = args->wp_offset;
   a->n_wp = args->n_wp; a->n_steps = args->n_steps > 1 ? args->n_steps : 1;
-  if (a->wp_table && (!a->wp_counter || a->n_wp < 1)) return DSIM_E_ARG; a->step_index = args->step_index;
+  if (a->wp_table && (!a->wp_counter || a->n_wp < 1)) return DSIM_E_ARG;
+  a->step_index = args->step_index;
   a->substeps = args->phys_substeps; a->dt_phys = args->dt_phys; a->dt_ctrl = args->dt_ctrl;
   a->options = args->options;
   return DSIM_OK;
 }
 
-#define DSIM_LAUNCH2(KERNEL, NOISE, UNI, a, stream)                                                      \
-  do {                                                                                                   \
-    const dim3 g(grid_for((a).n_pad)), b(256);                                                           \
-    if (NOISE) { if (UNI) hipLaunchKernelGGL((KERNEL<true, true>), g, b, 0, stream, a);                  \
-                 else hipLaunchKernelGGL((KERNEL<true, false>), g, b, 0, stream, a); }                   \
-    else { if (UNI) hipLaunchKernelGGL((KERNEL<false, true>), g, b, 0, stream, a);                       \
-           else hipLaunchKernelGGL((KERNEL<false, false>), g, b, 0, stream, a); }                        \
+// (noise, uniform) x actuator count dispatch of a general kernel
+#define DSIM_LAUNCH_GEN(KERNEL, NOISE, UNI, SIX, g, a, stream)                                          \
+  do {                                                                                                  \
+    const dim3 b_(256);                                                                                 \
+    switch (((NOISE) ? 4 : 0) | ((UNI) ? 2 : 0) | ((SIX) ? 1 : 0)) {                                    \
+      case 0: hipLaunchKernelGGL((KERNEL<false, false, 4>), g, b_, 0, stream, a); break;                \
+      case 1: hipLaunchKernelGGL((KERNEL<false, false, 6>), g, b_, 0, stream, a); break;                \
+      case 2: hipLaunchKernelGGL((KERNEL<false, true, 4>), g, b_, 0, stream, a); break;                 \
+      case 3: hipLaunchKernelGGL((KERNEL<false, true, 6>), g, b_, 0, stream, a); break;                 \
+      case 4: hipLaunchKernelGGL((KERNEL<true, false, 4>), g, b_, 0, stream, a); break;                 \
+      case 5: hipLaunchKernelGGL((KERNEL<true, false, 6>), g, b_, 0, stream, a); break;                 \
+      case 6: hipLaunchKernelGGL((KERNEL<true, true, 4>), g, b_, 0, stream, a); break;                  \
+      default: hipLaunchKernelGGL((KERNEL<true, true, 6>), g, b_, 0, stream, a); break;                 \
+    }                                                                                                   \
   } while (0)
 
 int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
@@ -495,10 +575,11 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   if (rc) return rc;
   const bool noise = args->noise_seed != 0 || args->noise_replay != nullptr;
   const bool uni = args->type_id == nullptr;
+  const bool six = ctx->max_act == 6;
   const hipStream_t st_ = (hipStream_t)stream;
   const dim3 b(256);
   long long first = 0;
-  if (uni && !args->action && !args->noise_replay) {
+  if (uni && !six && !args->action && !args->noise_replay) {
     // fast path over the whole 256-drone tiles.  Streaming (nontemporal) accesses once the fleet's
     // per-step traffic exceeds what the 256 MB Infinity Cache can keep between consecutive steps
     // (tuning knob for A/B runs: DSIM_NT = 0|1).
@@ -520,10 +601,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   if (first < a.n_pad) {   // ragged tail, or everything when the fast path does not apply
     a.first = first;
     const dim3 g(grid_for(a.n_pad - first));
-    if (noise) { if (uni) hipLaunchKernelGGL((k_step_quad<true, true>), g, b, 0, st_, a);
-                 else hipLaunchKernelGGL((k_step_quad<true, false>), g, b, 0, st_, a); }
-    else { if (uni) hipLaunchKernelGGL((k_step_quad<false, true>), g, b, 0, st_, a);
-           else hipLaunchKernelGGL((k_step_quad<false, false>), g, b, 0, st_, a); }
+    DSIM_LAUNCH_GEN(k_step_gen, noise, uni, six, g, a, st_);
   }
   return (int)hipGetLastError();
 }
@@ -535,20 +613,25 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
   if (rc) return rc;
   a.echo = last_action_out;
   const bool noise = args->noise_seed != 0 || args->noise_replay != nullptr;
-  const bool uni = args->type_id == nullptr;
-  DSIM_LAUNCH2(k_physics_quad, noise, uni, a, (hipStream_t)stream);
+  const dim3 g(grid_for(a.n_pad));
+  DSIM_LAUNCH_GEN(k_physics_gen, noise, args->type_id == nullptr, ctx->max_act == 6, g, a, (hipStream_t)stream);
   return (int)hipGetLastError();
 }
 
 int dsim_control(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
                  const dsim_step_args* args, float* pos_e_out, float* yaw_e_out) {
   StepK a;
+  if (args && args->wp_table) return DSIM_E_UNSUPPORTED;   // computeControl takes explicit targets
   int rc = fill_stepk(ctx, n, state, &targets, args, &a);
   if (rc) return rc;
   a.pos_e_out = pos_e_out; a.yaw_e_out = yaw_e_out;
   const dim3 g(grid_for(a.n_pad)), b(256);
-  if (args->type_id == nullptr) hipLaunchKernelGGL((k_control_quad<true>), g, b, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((k_control_quad<false>), g, b, 0, (hipStream_t)stream, a);
+  const hipStream_t st_ = (hipStream_t)stream;
+  const bool uni = args->type_id == nullptr;
+  if (ctx->max_act == 6) { if (uni) hipLaunchKernelGGL((k_control_gen<true, 6>), g, b, 0, st_, a);
+                           else hipLaunchKernelGGL((k_control_gen<false, 6>), g, b, 0, st_, a); }
+  else { if (uni) hipLaunchKernelGGL((k_control_gen<true, 4>), g, b, 0, st_, a);
+         else hipLaunchKernelGGL((k_control_gen<false, 4>), g, b, 0, st_, a); }
   return (int)hipGetLastError();
 }
 
@@ -557,7 +640,7 @@ int dsim_observe(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const 
   if (!ctx || !obs_out || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
   if (obs_width < 16 || obs_width > 16 + DSIM_MAX_ACT || 20 + (obs_width - 16) > state.n_fields) return DSIM_E_ARG;
   ObsK a;
-  int rc = make_kview(state, DSIM_NF_QUAD, &a.st);
+  int rc = make_kview(state, 20 + ctx->max_act, &a.st);
   if (rc) return rc;
   a.last_action = last_action; a.out = obs_out; a.n = n; a.n_pad = state.n_pad; a.width = obs_width;
   hipLaunchKernelGGL(k_observe, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a);

@@ -11,6 +11,8 @@
 #include "dsim_math.h"
 
 #define DSIM_MAX_ACT 6
+#define DSIM_DEV_KIND_QUAD 0
+#define DSIM_DEV_KIND_HEXA 1
 
 // fp32 image of dsim_type_params (include/dronesim_amd.h), with the reciprocals
 // the kernel wants.  Lives in device memory; with a homogeneous fleet the address
@@ -22,7 +24,9 @@ struct DevType {
   float kf, km;
   float scale[DSIM_MAX_ACT], cnst[DSIM_MAX_ACT], pmin[DSIM_MAX_ACT], pmax[DSIM_MAX_ACT];
   float rpos[DSIM_MAX_ACT][3], raxis[DSIM_MAX_ACT][3], spin[DSIM_MAX_ACT];
-  float alloc[DSIM_MAX_ACT][2 * DSIM_MAX_ACT];
+  float alloc[DSIM_MAX_ACT][DSIM_MAX_ACT];    // quad: pinv(G1/0.05); hexa: M1 (u_opt = M1 v + M4 u0)
+  float alloc2[DSIM_MAX_ACT][DSIM_MAX_ACT];   // hexa: M4
+  float B[DSIM_MAX_ACT][DSIM_MAX_ACT];        // hexa: G1/0.05, for the active-set fallback
   float kp, kd, katt[3], krate[3];
   float g, clin, cang, maxv;
   float drag[3], gnd_coeff, prop_radius, gnd_hclip, dw[3];
@@ -254,9 +258,9 @@ __device__ __forceinline__ void bullet_step(const DevType& T, float dt, Rigid& s
 // quaternion, hence of quat_err, and quat_wrap_shortest (math.py:46-51) removes exactly that
 // sign.  The attitude error therefore depends on psi* alone, and the kernel evaluates
 // sincos(psi*/2) directly; psi itself (one more atan2) is computed only when yaw_e is wanted.
-template <bool WANT_YAW>
+template <bool WANT_YAW, int NACT = 4>
 __device__ __forceinline__ void indi_quad(const DevType& T, float dt, const Rigid& s, const Target& tg,
-                                          CtrlMem<4>& m, V3& pos_e, float& yaw_e) {
+                                          CtrlMem<NACT>& m, V3& pos_e, float& yaw_e) {
   // ---- _INDIPositionControl, :278-296
   pos_e = tg.pos - s.pos;
   const float inv_dt = DSIM_RCP(dt);
@@ -314,5 +318,200 @@ __device__ __forceinline__ void indi_quad(const DevType& T, float dt, const Rigi
   for (int j = 0; j < 4; ++j) {                                              // pinv(G1/0.05) . v ; += ; clip
     const float du = T.alloc[j][0] * v[0] + T.alloc[j][1] * v[1] + T.alloc[j][2] * v[2] + T.alloc[j][3] * v[3];
     m.cmd[j] = clampf(m.cmd[j] + du, T.pmin[j], T.pmax[j]);
+  }
+}
+
+// ===========================================================================
+// morphing hexa: physics P3 and the 6-DOF INDI law C5 with WLS allocation C6
+// ===========================================================================
+
+// P3: BaseAviary._morphing_hexa_physics, BaseAviary.py:1398-1403, 1429-1457: force [0,0,F_j] and
+// torque [0,0,tau_j] in the tilted prop link frames (rigid composite body, see params.py).
+// nz: 12 scaled normals (f_noise[6], m_noise[6]) or nullptr.
+__device__ __forceinline__ void hexa_wrench(const DevType& T, const float cmd[6], const float* nz, V3& F, V3& tau) {
+  F = v3(0, 0, 0); tau = v3(0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float rpm = T.scale[j] * cmd[j] + T.cnst[j];
+    const float f = rpm * rpm * T.kf + (nz ? nz[j] : 0.0f);
+    const float tq = (rpm * rpm * T.km + (nz ? nz[6 + j] : 0.0f)) * T.spin[j];   // :1439-1440
+    const V3 ax = v3(T.raxis[j][0], T.raxis[j][1], T.raxis[j][2]);
+    const V3 fj = f * ax;
+    F = F + fj;
+    tau = tau + cross(v3(T.rpos[j][0], T.rpos[j][1], T.rpos[j][2]), fj) + tq * ax;
+  }
+}
+
+// C6 fallback: the full active-set loop of wls_alloc (dronesim/control/wls_alloc.py:125-350) for
+// the rare drones whose first-iteration solution leaves the +-1.0-slackened box.  fp64: the rows
+// of A are scaled by gamma*Wv up to 1e8.  lstsq by Householder QR (A_free always contains the
+// identity rows, so it has full column rank).  Returns 0 ok, -1 "solution failed" (:350), -2 where
+// the reference would raise.  Kept out of line: it runs on a handful of lanes.
+__device__ __noinline__ int wls_active_set(const DevType& T, const float v[6], const float umin[6],
+                                           const float umax[6], float u_out[6]) {
+  const double gam = 100000.0;
+  const double Wv[6] = {1000, 1000, 0.1, 10, 10, 100};          // INDIControl_6DOF.py:614
+  double A[12][6], Af[12][6], d[12], u[6], u_opt[6], p[6], p_free[6], W[6], Lambda[6];
+  int free_index[6], lookup[6];
+  int n_free = 0, free_chk = -1, iter = 0, n_p_free = 6, id_alpha = 0;
+  bool alpha_set = false;
+  double alpha = 0.0;
+  for (int i = 0; i < 6; ++i) { u[i] = ((double)umax[i] + (double)umin[i]) * 0.5; W[i] = 0.0; p_free[i] = 0.0; }
+  for (int i = 0; i < 6; ++i) { lookup[i] = n_free; free_index[n_free++] = i; }
+  for (int i = 0; i < 6; ++i) {
+    d[i] = gam * Wv[i] * (double)v[i];
+    for (int j = 0; j < 6; ++j) { A[i][j] = gam * Wv[i] * (double)T.B[i][j]; d[i] -= A[i][j] * u[j]; }
+  }
+  for (int i = 6; i < 12; ++i) {
+    for (int j = 0; j < 6; ++j) A[i][j] = (j == i - 6) ? 1.0 : 0.0;   // Wu = 1, up = None -> b = 0
+    d[i] = -u[i - 6];
+  }
+  while (iter < 100) {
+    ++iter;
+    for (int i = 0; i < 6; ++i) { p[i] = 0.0; u_opt[i] = u[i]; }
+    if (free_chk != n_free) {
+      for (int i = 0; i < 12; ++i) for (int j = 0; j < n_free; ++j) Af[i][j] = A[i][free_index[j]];
+      free_chk = n_free;
+    }
+    if (n_free) {   // p_free = lstsq(Af[:, :n_free], d) by Householder QR on copies
+      double Q[12][6], rhs[12];
+      for (int i = 0; i < 12; ++i) { rhs[i] = d[i]; for (int j = 0; j < n_free; ++j) Q[i][j] = Af[i][j]; }
+      for (int k = 0; k < n_free; ++k) {
+        double nrm = 0.0;
+        for (int i = k; i < 12; ++i) nrm += Q[i][k] * Q[i][k];
+        nrm = sqrt(nrm);
+        const double akk = Q[k][k];
+        const double beta = akk >= 0.0 ? -nrm : nrm;
+        const double v0 = akk - beta;                     // reflector v = (v0, Q[k+1..][k]); Q[k][k] <- beta
+        double vtv = v0 * v0;
+        for (int i = k + 1; i < 12; ++i) vtv += Q[i][k] * Q[i][k];
+        if (vtv > 0.0) {
+          for (int j = k + 1; j < n_free; ++j) {
+            double dotv = v0 * Q[k][j];
+            for (int i = k + 1; i < 12; ++i) dotv += Q[i][k] * Q[i][j];
+            const double f = 2.0 * dotv / vtv;
+            Q[k][j] -= f * v0;
+            for (int i = k + 1; i < 12; ++i) Q[i][j] -= f * Q[i][k];
+          }
+          double dotv = v0 * rhs[k];
+          for (int i = k + 1; i < 12; ++i) dotv += Q[i][k] * rhs[i];
+          const double f = 2.0 * dotv / vtv;
+          rhs[k] -= f * v0;
+          for (int i = k + 1; i < 12; ++i) rhs[i] -= f * Q[i][k];
+        }
+        Q[k][k] = beta;
+      }
+      for (int k = n_free - 1; k >= 0; --k) {
+        double acc = rhs[k];
+        for (int j = k + 1; j < n_free; ++j) acc -= Q[k][j] * p_free[j];
+        p_free[k] = acc / Q[k][k];
+      }
+      n_p_free = n_free;
+    }
+    for (int i = 0; i < n_free; ++i) { p[free_index[i]] = p_free[i]; u_opt[free_index[i]] += p_free[i]; }
+    int n_inf = 0;
+    for (int i = 0; i < 6; ++i)
+      if (u_opt[i] >= ((double)umax[i] + 1.0) || u_opt[i] <= ((double)umin[i] - 1.0)) ++n_inf;
+    if (n_inf == 0) {
+      for (int i = 0; i < 6; ++i) { u[i] = u_opt[i]; Lambda[i] = 0.0; }
+      for (int i = 0; i < 12; ++i) {
+        for (int k = 0; k < n_free; ++k) d[i] -= Af[i][k] * p_free[k];
+        for (int k = 0; k < 6; ++k) Lambda[k] += A[i][k] * d[i];
+      }
+      bool brk = true;
+      for (int i = 0; i < 6; ++i) {
+        Lambda[i] *= W[i];
+        if (Lambda[i] < -1.1920929e-07) {
+          brk = false; W[i] = 0.0;
+          if (lookup[i] < 0) { lookup[i] = n_free; free_index[n_free++] = i; }
+        }
+      }
+      if (brk) { for (int i = 0; i < 6; ++i) u_out[i] = (float)u[i]; return 0; }
+    } else {
+      alpha = INFINITY; alpha_set = true; id_alpha = 0;
+    }
+    if (!alpha_set) return -2;
+    for (int i = 0; i < n_free; ++i) {
+      const int id = free_index[i];
+      double at;
+      if (fabs(p[id]) > 1.1920929e-07) at = p[id] < 0 ? ((double)umin[id] - u[id]) / p[id] : ((double)umax[id] - u[id]) / p[id];
+      else at = INFINITY;
+      if (at < alpha) { alpha = at; id_alpha = id; }
+    }
+    for (int i = 0; i < 6; ++i) u[i] += alpha * p[i];
+    const int k_len = n_free < n_p_free ? n_free : n_p_free;
+    for (int i = 0; i < 12; ++i) for (int k = 0; k < k_len; ++k) d[i] -= Af[i][k] * alpha * p_free[k];
+    W[id_alpha] = p[id_alpha] > 0 ? 1.0 : -1.0;
+    --n_free;
+    if (n_free < 0 || lookup[id_alpha] < 0) return -2;
+    free_index[lookup[id_alpha]] = free_index[n_free];
+    lookup[free_index[lookup[id_alpha]]] = lookup[id_alpha];
+    lookup[id_alpha] = -1;
+  }
+  return -1;
+}
+
+// C5: INDIControl_6DOF.computeControl, INDIControl_6DOF.py:259-634.
+// counters: [0] drones x steps that took the active-set fallback, [1] allocations the reference
+// would have failed on (cmd left unchanged).
+template <bool WANT_YAW>
+__device__ __forceinline__ void indi_hexa(const DevType& T, float dt, const Rigid& s, const Target& tg,
+                                          CtrlMem<6>& m, V3& pos_e, float& yaw_e, unsigned long long* counters) {
+  pos_e = tg.pos - s.pos;                                                     // :397
+  const float inv_dt = DSIM_RCP(dt);
+  V3 a_e;                                                                     // :399-413 (no target_acc)
+  a_e.x = clampf((pos_e.x * T.kp + tg.vel.x - s.vel.x) * T.kd - (s.vel.x - m.last_vel.x) * inv_dt, -6.0f, 6.0f);
+  a_e.y = clampf((pos_e.y * T.kp + tg.vel.y - s.vel.y) * T.kd - (s.vel.y - m.last_vel.y) * inv_dt, -6.0f, 6.0f);
+  a_e.z = clampf((pos_e.z * T.kp + tg.vel.z - s.vel.z) * T.kd - (s.vel.z - m.last_vel.z) * inv_dt, -6.0f, 6.0f);
+  m.last_vel = s.vel;
+  const Euler e = euler_from_quat<WANT_YAW>(s.q);                             // :418
+  const float sph = e.sph, cph = e.cph, sth = e.sth, cth = e.cth, sps = e.sps, cps = e.cps;
+  const float Tg = 9.81f;
+  const float g00 = (cph * sps - sph * cps * sth) * Tg, g01 = (cph * cps * cth) * Tg, g02 = sph * sps + cph * cps * sth;
+  const float g10 = (-sph * sps * sth - cps * cph) * Tg, g11 = (cph * sps * cth) * Tg, g12 = cph * sps * sth - cps * sph;
+  const float g20 = -cth * sph * Tg, g21 = -sth * cph * Tg, g22 = cph * cth;
+  // only the thrust increment (third row of inv(G)) survives: target_euler is forced to zero (:495)
+  const float c00 = g11 * g22 - g12 * g21, c10 = g12 * g20 - g10 * g22, c20 = g10 * g21 - g11 * g20;
+  const float c21 = g01 * g20 - g00 * g21, c22 = g00 * g11 - g01 * g10;
+  float det = g00 * c00 + g01 * c10 + g02 * c20;
+  det = copysignf(fmaxf(fabsf(det), 1e-12f), det);
+  const float inc2 = (c20 * a_e.x + c21 * a_e.y + c22 * a_e.z) * DSIM_RCP(det);
+  const float thrust = m.last_thrust + inc2;                                  // :492
+  if (WANT_YAW) yaw_e = 0.0f - e.yaw;                                         // :336, target_euler = 0
+  // attitude: target quaternion = identity -> quat_inv_comp(q, (0,0,0,1)) = (-x,-y,-z,w); no wrap (:543-545)
+  const float ex0 = -s.q.x, ey0 = -s.q.y, ez = -s.q.z;
+  const float ex = cps * ex0 + sps * ey0, ey = -sps * ex0 + cps * ey0;        // inv(R_psi) . att_err.xy, :549-557
+  const M3 R = matrix_from_quat(s.q);                                         // :566
+  const V3 wb = mulT(R, s.w);
+  float v[6];
+  v[0] = (T.katt[0] * ex - wb.x) * T.krate[0] - (wb.x - m.last_rates.x) * inv_dt;   // :560-592
+  v[1] = (T.katt[1] * ey - wb.y) * T.krate[1] - (wb.y - m.last_rates.y) * inv_dt;
+  v[2] = (T.katt[2] * ez - wb.z) * T.krate[2] - (wb.z - m.last_rates.z) * inv_dt;
+  const V3 ab = mulT(R, a_e);                                                 // :589
+  v[3] = ab.x; v[4] = ab.y; v[5] = ab.z;
+  m.last_rates = wb;                                                          // :580
+  m.last_thrust = thrust;                                                     // :598
+  // WLS allocation, :607-628.  First iteration in closed form: u_opt = M1 v + M4 u0.
+  float umin[6], umax[6], du[6];
+  bool feasible = true;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) { umin[j] = T.pmin[j] - m.cmd[j]; umax[j] = T.pmax[j] - m.cmd[j]; }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc += T.alloc[j][i] * v[i] + T.alloc2[j][i] * (0.5f * (umin[i] + umax[i]));
+    du[j] = acc;
+    feasible = feasible && !(acc >= umax[j] + 1.0f || acc <= umin[j] - 1.0f);   // wls_alloc.py:255-259
+  }
+  bool ok = true;
+  if (!feasible) {
+    const int rc = wls_active_set(T, v, umin, umax, du);
+    if (counters) atomicAdd(&counters[0], 1ULL);
+    if (rc != 0) { ok = false; if (counters) atomicAdd(&counters[1], 1ULL); }
+  }
+  if (ok) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) m.cmd[j] = clampf(m.cmd[j] + du[j], T.pmin[j], T.pmax[j]);   // :630-631
   }
 }

@@ -56,6 +56,7 @@ class TypeParamsC(ctypes.Structure):
         ("rotor_spin", ctypes.c_double * MAX_ACT),
         ("G1", (ctypes.c_double * MAX_ACT) * MAX_ACT),
         ("alloc", (ctypes.c_double * MAX_ACT) * MAX_ACT),
+        ("alloc2", (ctypes.c_double * MAX_ACT) * MAX_ACT),
         ("kp_pos", ctypes.c_double),
         ("kd_pos", ctypes.c_double),
         ("att_gain", ctypes.c_double * 3),
@@ -125,18 +126,31 @@ class DroneType:
 
     # ---- controller allocation matrix ------------------------------------
     def default_alloc(self) -> np.ndarray:
-        """quad: ``pinv(G1/0.05)`` exactly as INDIControl.py:459 computes it every
-        call (a per-type constant).  hexa: the first-iteration matrix of
-        ``wls_alloc`` (free set = all actuators): ``p = lstsq(A, d)`` with
-        ``A = [gamma*Wv*B; Wu]`` (wls_alloc.py:190-252) restricted to the ``v``
-        rows, see DESIGN.md."""
+        """quad (or any type flown by the quad law): ``pinv(G1/0.05)`` exactly as
+        INDIControl.py:459 computes it every call (a per-type constant).
+        hexa: M1 of :meth:`wls_first_iteration`."""
         B = self.G1 / 0.05
         if self.kind == KIND_QUAD:
             return np.linalg.pinv(B)
+        return self.wls_first_iteration()[0]
+
+    def wls_first_iteration(self):
+        """First iteration of ``wls_alloc`` as INDIControl_6DOF calls it (free set = all actuators,
+        ``u0 = (umin+umax)/2``, ``up = None``; wls_alloc.py:164-252, INDIControl_6DOF.py:607-628):
+        ``p = lstsq(A, d)`` with ``A = [gamma Wv B; Wu]``, ``d = [gamma Wv (v - B u0); -Wu u0]``, so
+        ``u_opt = u0 + p = M1 v + M4 u0`` with ``M1 = P1 diag(gamma Wv)``, ``M4 = I - M1 B - P2 diag(Wu)``
+        and ``[P1 | P2] = pinv(A)``.  Evaluated in fp64 here so the kernel never forms the 1e8-scaled
+        rows in fp32.  When ``u_opt`` is inside the +-1.0-slackened box (wls_alloc.py:255-259) the
+        reference returns it after this one iteration."""
+        B = self.G1 / 0.05
         Wv = np.array([1000, 1000, 0.1, 10, 10, 100.0])   # INDIControl_6DOF.py:614
+        Wu = np.ones(self.n_act)                           # :615
         gam = 100000.0                                     # wls_alloc.py:125 (gamma_sq)
-        A = np.vstack([gam * Wv[:, None] * B, np.eye(self.n_act)])
-        return np.linalg.pinv(A)                           # [n_act][n_v + n_u]; host keeps all 12 cols
+        A = np.vstack([gam * Wv[:, None] * B, np.diag(Wu)])
+        P = np.linalg.pinv(A)
+        M1 = P[:, :6] * (gam * Wv)[None, :]
+        M4 = np.eye(self.n_act) - M1 @ B - P[:, 6:] * Wu[None, :]
+        return M1, M4
 
     def to_c(self) -> TypeParamsC:
         c = TypeParamsC()
@@ -164,6 +178,11 @@ class DroneType:
         for j in range(self.n_act):
             for i in range(min(a.shape[1], MAX_ACT)):
                 c.alloc[j][i] = a[j, i]
+        if self.kind == KIND_HEXA6DOF:
+            m4 = self.wls_first_iteration()[1]
+            for j in range(self.n_act):
+                for i in range(self.n_act):
+                    c.alloc2[j][i] = m4[j, i]
         c.kp_pos, c.kd_pos = self.kp_pos, self.kd_pos
         c.gravity = self.gravity
         c.lin_damping, c.ang_damping = self.lin_damping, self.ang_damping
@@ -174,8 +193,9 @@ class DroneType:
 
     @property
     def hover_pwm(self) -> float:
-        """PWM at which total thrust equals weight (noise-free)."""
-        rpm = math.sqrt(self.mass * self.gravity / (self.n_act * self.kf))
+        """PWM at which the vertical thrust of a level vehicle equals its weight (noise-free)."""
+        az = sum(self.rotor_axis[j][2] for j in range(self.n_act))
+        rpm = math.sqrt(self.mass * self.gravity / (az * self.kf))
         return (rpm - self.pwm2rpm_const[0]) / self.pwm2rpm_scale[0]
 
 
@@ -233,7 +253,40 @@ def _tello() -> DroneType:
     )
 
 
-_BUILTIN_FACTORIES = {"robobee": _robobee, "tello": _tello}
+def _hexa_6dof() -> DroneType:
+    # dronesim/assets/hexa_6DOF.urdf: properties :27, control :29-53, link inertials :78-81, 94-98,
+    # 238-241, 254-258, joints :382-476.  PyBullet flies it as an articulated body (six revolute arm
+    # joints held by default motors); here it is ONE rigid body: total mass, and inertia / rotor lever
+    # arms about the composite COM, computed by parse_urdf() from those lines (the position state is
+    # the composite COM, 11 mm below the mainbody origin).  Rotor j: thrust along the prop link's z
+    # (tilted +-0.3 rad about the arm), applied at the prop link's inertial origin.
+    return DroneType(
+        name="hexa_6DOF", kind=KIND_HEXA6DOF, n_act=6, mass=0.8600000000000003, ctrl_mass=0.2,
+        inertia=(0.005362949147591898, 0.005381363215733879, 0.009256930068007832),
+        kf=1.9e-8, km=1.9e-9,
+        pwm2rpm_scale=(20000.0,) * 6, pwm2rpm_const=(0.0,) * 6, pwm_min=(0.0,) * 6, pwm_max=(1.0,) * 6,
+        rotor_pos=((0.1128207649635189, -0.06522600911031864, 0.031918173037913264),
+                   (0.0003321933335286087, -0.13000085698891597, 0.031918173037913264),
+                   (-0.11309080300220549, -0.06479695890916311, 0.031918173037913264),
+                   (-0.11309080300220549, 0.0647947362218831, 0.031918173037913264),
+                   (0.0003321933335286087, 0.12999863430163597, 0.031918173037913264),
+                   (0.1128207649635189, 0.06522378642303864, 0.031918173037913264)),
+        rotor_axis=((-0.14760683340635503, -0.2560164355601206, 0.955336489125606),
+                    (0.29552011296128977, 0.00023533063412583874, 0.955336489125606),
+                    (-0.14801439152343665, 0.2557810244078079, 0.955336489125606),
+                    (-0.14801439152343665, -0.2557810244078079, 0.955336489125606),
+                    (0.29552011296128977, -0.00023533063412583874, 0.955336489125606),
+                    (-0.14760683340635503, 0.2560164355601206, 0.955336489125606)),
+        rotor_spin=(-1.0, 1.0, -1.0, 1.0, -1.0, 1.0),     # BaseAviary.py:1439-1440
+        G1=np.array([[-7.5, -15.0, -7.5, 7.5, 15.0, 7.5], [-13.0, 0.0, 13.0, 13.0, 0.0, -13.0],
+                     [-5.0, 5.0, -5.0, 5.0, -5.0, 5.0], [-2.0, 4.0, -2.0, -2.0, 4.0, -2.0],
+                     [-3.0, 0.0, 3.0, -3.0, 0.0, 3.0], [1.5, 1.5, 1.5, 1.5, 1.5, 1.5]]),
+        kp_pos=1.7, kd_pos=2.5, att_gain=(10.0, 10.0, 5.0), rate_gain=(18.0, 18.0, 12.0),
+        prop_radius=6.7e-2, reset_thrust=0.3, reset_cmd=0.5, **_AERO,
+    )
+
+
+_BUILTIN_FACTORIES = {"robobee": _robobee, "tello": _tello, "hexa_6DOF": _hexa_6dof}
 
 
 def builtin_type(name: str) -> DroneType:
@@ -338,6 +391,9 @@ def parse_urdf(path: str) -> DroneType:
     lim = list(ctrl.find("pwm/limit").attrib.values())
 
     is_hexa = "morphing_hexa" in conf
+    if is_hexa and n_out != 6:
+        raise ValueError("morphing_hexa with output_nr != 6 (hexa_6DOF_simple: quad law on six actuators) "
+                         "is not on the hot path")
     if not is_hexa and "quad" not in conf:
         raise ValueError(f"vehicle configuration {conf!r} is outside the hot path (quad / morphing_hexa only)")
     rotor_links = [order[i] for i in (range(1, 2 * n_act, 2) if is_hexa else range(n_act))]

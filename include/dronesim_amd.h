@@ -97,7 +97,8 @@ typedef struct dsim_type_params {
   double  rotor_spin[DSIM_MAX_ACT];   /* sign of km*rpm^2 in the yaw torque (BaseAviary.py:1527: -,+,-,+) */
   double  G1[DSIM_MAX_ACT][DSIM_MAX_ACT];    /* control effectiveness, [n_out][n_act]       */
   double  alloc[DSIM_MAX_ACT][DSIM_MAX_ACT]; /* quad: pinv(G1/0.05) [n_act][n_out] (INDIControl.py:459);
-                                                hexa: WLS first-iteration matrix      */
+                                                hexa: M1 of the WLS first iteration, u_opt = M1 v + M4 u0 */
+  double  alloc2[DSIM_MAX_ACT][DSIM_MAX_ACT];/* hexa: M4 (see DESIGN.md "WLS allocation"); quad: unused  */
   double  kp_pos, kd_pos;             /* indi_guidance_gains                                */
   double  att_gain[3], rate_gain[3];  /* indi_att_gains att / rate                          */
   double  gravity;                    /* 9.8 (BaseAviary.py:182,673)                        */
@@ -191,6 +192,14 @@ int dsim_control(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_v
  * (the env's last_clipped_action); NULL = the stored cmd.                        */
 int dsim_observe(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
                  float* obs_out, int32_t obs_width);
+
+/* Diagnostics counters kept by the ctx (device-side, cumulative; this call synchronises `stream`):
+ *   DSIM_Q_WLS_FALLBACKS  drones x steps whose 6DOF allocation left the first-iteration fast path and
+ *                         ran the full active-set loop of wls_alloc (wls_alloc.py:222-350)
+ *   DSIM_Q_WLS_FAILURES   allocations on which the reference would have failed (wls_alloc returns None
+ *                         -> `self.cmd += None` raises, INDIControl_6DOF.py:626-630); cmd is left unchanged */
+enum { DSIM_Q_WLS_FALLBACKS = 0, DSIM_Q_WLS_FAILURES = 1 };
+int dsim_query(dsim_ctx* ctx, void* stream, int32_t what, int64_t* value_out);
 
 /* error codes */
 enum {

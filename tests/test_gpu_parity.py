@@ -269,6 +269,132 @@ def test_inkernel_noise_matches_definition(gpu):
 
 
 # ---------------------------------------------------------------------------
+# morphing hexa: 6-DOF INDI + WLS allocation + tilted-rotor physics; mixed fleets (config 5)
+# ---------------------------------------------------------------------------
+def _query(nat, ctx, what):
+    v = ctypes.c_int64(0)
+    nat.check(ctx.lib.dsim_query(ctx.handle, _stream(ctx), what, ctypes.byref(v)))
+    return v.value
+
+
+def test_hexa_control_vs_golden(gpu, golden_dir):
+    """INDIControl_6DOF.computeControl against the reference-generated vectors, including the
+    cases whose WLS allocation needs the full active-set loop (fallback path)."""
+    nat, fleet = gpu
+    g = np.load(os.path.join(golden_dir, "indi_single_hexa_6DOF.npz"))
+    t = params.builtin_type("hexa_6DOF")
+    ctx = fleet.Context([t])
+    n = g["pos"].shape[0]
+    rigid = np.concatenate([g["pos"], g["quat"], g["vel"], g["ang_vel"]], 1)
+    mem = np.zeros((n, 13))
+    mem[:, 0:3], mem[:, 3:6], mem[:, 6], mem[:, 7:13] = g["last_vel"], g["last_rates"], g["last_thrust"], g["cmd"]
+    tgt = np.concatenate([g["target_pos"], g["target_vel"], g["target_acc"], g["target_rpy"][:, 2:3]], 1)
+    O = orc.Oracle([t])
+    for dt in np.unique(g["dt"]):
+        sel = np.where(g["dt"] == dt)[0]
+        m = len(sel)
+        st = fleet.FleetState(ctx, m)
+        tg = fleet.Targets(ctx, m)
+        st.load_aos(rigid[sel], mem[sel])
+        tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt[sel].T)))
+        pos_e = torch.zeros((3, st.n_pad), device=ctx.device)
+        yaw_e = torch.zeros((st.n_pad,), device=ctx.device)
+        a = _args(nat, 0, float(dt), float(dt))
+        nat.check(ctx.lib.dsim_control(ctx.handle, _stream(ctx), m, st.view(), tg.view(), ctypes.byref(a),
+                                       pos_e.data_ptr(), yaw_e.data_ptr()))
+        got = st.mem_aos()
+        roll = np.array([orc.euler_from_quat(q)[0] for q in g["quat"][sel]])
+        amp = 1.0 / np.maximum(np.abs(np.cos(roll)), 1e-3)
+        # the oracle on the SAME fp32-rounded inputs separates fp32 input rounding (amplified through
+        # G1^-1 gains ~100 on saturating cases) from arithmetic differences
+        r32, m32, t32 = f32(rigid[sel]), f32(mem[sel]), f32(tgt[sel])
+        rc, _, _ = O.control(r32, m32, t32, float(np.float32(dt)))
+        assert rc == 0
+        err = np.abs(got[:, 7:13] - m32[:, 7:13]).max(1)
+        assert (err <= 2e-4).all(), (dt, err.max(), sel[np.argmax(err)])
+        err_g = np.abs(got[:, 7:13] - g["cmd_out"][sel]).max(1)
+        assert (err_g <= 2e-3 * (1 + amp)).all(), (dt, err_g.max())      # vs the fp64-input golden
+        np.testing.assert_allclose(yaw_e[:m].cpu().numpy(), g["yaw_e"][sel], rtol=0, atol=2e-5)
+        assert np.abs(got[:, 6] - g["last_thrust_out"][sel]).max() < 1e-3 * amp.max()
+    assert _query(nat, ctx, 0) > 0          # the fixture does exercise the active-set fallback
+    assert _query(nat, ctx, 1) == 0         # and none of the reference calls failed
+    ctx.close()
+
+
+@pytest.mark.parametrize("substeps,layout", [(5, "soa"), (1, "tile64")])
+def test_hexa_fused_step_vs_oracle(gpu, substeps, layout):
+    nat, fleet = gpu
+    n = 2000
+    t, ctx, st, tg, rigid, mem, tgt = _make(gpu, "hexa_6DOF", n, layout, seed=31, n_act=6, tilt=0.3, rate=1.0)
+    O = orc.Oracle([t])
+    dtc = float(np.float32(substeps / 240.0))
+    a = _args(nat, substeps, DT, dtc)
+    nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
+    assert O.step(rigid, mem, tgt, substeps, DT, dtc) == 0
+    er = rel_err(st.rigid_aos(), rigid, RIGID_SCALE)
+    em = rel_err(st.mem_aos(), mem, MEM_SCALE)
+    assert er.max() < REL_TOL, (er.max(), np.unravel_index(er.argmax(), er.shape))
+    assert em.max() < 3 * REL_TOL, (em.max(), np.unravel_index(em.argmax(), em.shape))   # G1^-1 gains amplify fp32 rounding of v
+    ctx.close()
+
+
+def test_mixed_fleet_vs_oracle(gpu):
+    """Config 5 layout: even index robobee (quad INDI), odd index hexa_6DOF (6DOF INDI + WLS), one
+    type_id byte per drone; in-kernel noise on."""
+    nat, fleet = gpu
+    n = 3000
+    types = [params.builtin_type("robobee"), params.builtin_type("hexa_6DOF")]
+    ctx = fleet.Context(types)
+    assert ctx.n_fields == 26
+    st = fleet.FleetState(ctx, n)
+    tg = fleet.Targets(ctx, n)
+    rigid, mem, tgt = random_fleet(np.random.default_rng(41), n, n_act=6, tilt=0.3, rate=1.0)
+    tid = (np.arange(n) % 2).astype(np.uint8)
+    mem[tid == 0, 11:13] = 0.0
+    st.load_aos(rigid, mem)
+    tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
+    tid_dev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device)
+    tid_dev[:n] = torch.from_numpy(tid)
+    sub, seed, sidx = 2, 99, 5
+    a = _args(nat, sub, DT, float(np.float32(sub / 240)), seed=seed, step_index=sidx, type_id=tid_dev)
+    nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
+    O = orc.Oracle(types)
+    nz = np.zeros((n, sub, 12))
+    for i in range(n):
+        na = 4 if tid[i] == 0 else 6
+        for s_ in range(sub):
+            u = O.noise_normals(seed, i, sidx * sub + s_, na)
+            nz[i, s_, 0:na] = u[0:na] * 0.01
+            nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
+    assert O.step(rigid, mem, tgt, sub, DT, float(np.float32(sub / 240)), noise=nz, type_id=tid) == 0
+    assert rel_err(st.rigid_aos(), rigid, RIGID_SCALE).max() < REL_TOL
+    assert rel_err(st.mem_aos(), mem, MEM_SCALE).max() < 3 * REL_TOL
+    ctx.close()
+
+
+def test_hexa_hover_physics(gpu):
+    """Level hexa at hover PWM (tilted rotors: vertical thrust = weight, lateral components and all
+    torques cancel) stays put."""
+    nat, fleet = gpu
+    t = params.builtin_type("hexa_6DOF")
+    ctx = fleet.Context([t])
+    n = 256
+    st = fleet.FleetState(ctx, n)
+    rigid = np.zeros((n, 13)); rigid[:, 2] = 1.0; rigid[:, 6] = 1.0
+    mem = np.zeros((n, 13)); mem[:, 7:13] = t.hover_pwm
+    st.load_aos(rigid, mem)
+    a = _args(nat, 240, DT, DT)
+    nat.check(ctx.lib.dsim_physics(ctx.handle, _stream(ctx), n, st.view(), None, ctypes.byref(a)))
+    out = st.rigid_aos()
+    # the URDF's arm yaw angles are rounded (0.523, 1.57, 2.617), so the cancellation is not exact
+    assert np.abs(out[:, 0:3] - rigid[:, 0:3]).max() < 1e-2 and np.abs(out[:, 10:13]).max() < 5e-2
+    O = orc.Oracle([t])
+    O.physics(rigid, mem, 240, DT)
+    assert rel_err(out, rigid, RIGID_SCALE).max() < REL_TOL
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------
 # config 3: waypoint-table tracking (examples/fly_INDI_TrajectoryTrack.py) and multi-step launches
 # ---------------------------------------------------------------------------
 def _traj_fleet(gpu, golden_dir, n, noise_seed=0):
