@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libdronesim_amd.so")
 # every symbol include/dronesim_amd.h declares
 EXPORTS = (
     "dsim_abi_version", "dsim_strerror", "dsim_create", "dsim_destroy", "dsim_reset", "dsim_step",
-    "dsim_physics", "dsim_control", "dsim_observe", "dsim_query",
+    "dsim_physics", "dsim_control", "dsim_observe", "dsim_query", "dsim_downwash", "dsim_downwash_workspace",
 )
 
 ABI_VERSION = 2
@@ -52,6 +52,23 @@ class StepArgs(ctypes.Structure):
         ("wp_offset", ctypes.c_void_p),
         ("n_wp", ctypes.c_int32),
         ("n_steps", ctypes.c_int32),
+        ("ext_force", ctypes.c_void_p),
+    ]
+
+
+class DownwashArgs(ctypes.Structure):
+    _fields_ = [
+        ("pos_all", ctypes.c_void_p),
+        ("m", ctypes.c_int64),
+        ("m_pad", ctypes.c_int64),
+        ("xmin", ctypes.c_float),
+        ("ymin", ctypes.c_float),
+        ("cell", ctypes.c_float),
+        ("nx", ctypes.c_int32),
+        ("ny", ctypes.c_int32),
+        ("workspace", ctypes.c_void_p),
+        ("workspace_len", ctypes.c_int64),
+        ("type_id", ctypes.c_void_p),
     ]
 
 
@@ -88,6 +105,9 @@ def load() -> ctypes.CDLL:
     lib.dsim_control.argtypes = [vp, vp, i64, View, View, ctypes.POINTER(StepArgs), vp, vp]
     lib.dsim_observe.argtypes = [vp, vp, i64, View, vp, vp, i32]
     lib.dsim_query.argtypes = [vp, vp, i32, ctypes.POINTER(ctypes.c_int64)]
+    lib.dsim_downwash_workspace.restype = ctypes.c_int64
+    lib.dsim_downwash_workspace.argtypes = [i64, i32, i32]
+    lib.dsim_downwash.argtypes = [vp, vp, i64, View, ctypes.POINTER(DownwashArgs), vp]
     if lib.dsim_abi_version() != ABI_VERSION:
         raise ImportError(f"libdronesim_amd.so ABI {lib.dsim_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

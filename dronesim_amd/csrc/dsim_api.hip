@@ -67,6 +67,7 @@ struct StepK {
   const float* wp_table;      // waypoint mode (null = targets view)
   int* wp_counter;
   const float* wp_offset;
+  const float* ext_force;     // SoA [3][n_pad] body-frame force at the COM, or null
   int n_wp, n_steps;
   unsigned long long seed, step_index;
   int substeps;
@@ -147,7 +148,8 @@ __device__ __forceinline__ int waypoint_next(int wp, int n_wp) { return wp < n_w
 // NROW = rows per sub-step of the replay buffer's force / moment halves (the kernel's NACT).
 template <int NOISE, int NROW = 4>
 __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
-                                              const float cmd[4], unsigned long long step_index) {
+                                              const float cmd[4], unsigned long long step_index,
+                                              V3 ext = V3{0.0f, 0.0f, 0.0f}) {
   V3 F, tau;
   if (NOISE == 0) quad_wrench(T, cmd, nullptr, F, tau);   // cmd is constant over the sub-steps
   for (int k = 0; k < a.substeps; ++k) {
@@ -166,14 +168,15 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
       }
       quad_wrench(T, cmd, nz, F, tau);
     }
-    bullet_step(T, a.dt_phys, s, F, tau);
+    bullet_step(T, a.dt_phys, s, F + ext, tau);
   }
 }
 
 // the same for the morphing hexa (BaseAviary.py:1389-1457); replay rows: f[6], m[6]
 template <bool NOISE>
 __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
-                                              const float cmd[6], unsigned long long step_index) {
+                                              const float cmd[6], unsigned long long step_index,
+                                              V3 ext = V3{0.0f, 0.0f, 0.0f}) {
   V3 F, tau;
   if (!NOISE) hexa_wrench(T, cmd, nullptr, F, tau);
   for (int k = 0; k < a.substeps; ++k) {
@@ -189,7 +192,7 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
       }
       hexa_wrench(T, cmd, nz, F, tau);
     }
-    bullet_step(T, a.dt_phys, s, F, tau);
+    bullet_step(T, a.dt_phys, s, F + ext, tau);
   }
 }
 
@@ -257,6 +260,8 @@ __global__ __launch_bounds__(256) void k_step_gen(StepK a) {
   int wp = 0;
   if (a.wp_table) wp = a.wp_counter[i]; else load_target(a.tg.base + kv_off(a.tg, i), a.tg.field_stride, 0u, tg);
   const bool hexa = NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA;
+  V3 ext = v3(0, 0, 0);
+  if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
   for (int k = 0; k < a.n_steps; ++k) {
     float act[NACT];
 #pragma unroll
@@ -271,11 +276,11 @@ __global__ __launch_bounds__(256) void k_step_gen(StepK a) {
     float yaw_e;
     if (NACT == 6 && hexa) {
       if constexpr (NACT == 6) {
-        hexa_substeps<NOISE>(T, a, i, s, act, a.step_index + k);
+        hexa_substeps<NOISE>(T, a, i, s, act, a.step_index + k, ext);
         indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.counters);
       }
     } else {
-      quad_substeps<NOISE ? 2 : 0, NACT>(T, a, i, s, act, a.step_index + k);
+      quad_substeps<NOISE ? 2 : 0, NACT>(T, a, i, s, act, a.step_index + k, ext);
       indi_quad<false, NACT>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
     }
     wp = waypoint_next(wp, a.n_wp);
@@ -299,10 +304,12 @@ __global__ __launch_bounds__(256) void k_physics_gen(StepK a) {
 #pragma unroll
   for (int j = 0; j < NACT; ++j) raw[j] = a.action ? a.action[(long long)j * a.n_pad + i] : a.st.base[o + (20 + j) * fs];
   preprocess_action<NACT>(T, raw, cmd);
+  V3 ext = v3(0, 0, 0);
+  if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
   if (NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA) {
-    if constexpr (NACT == 6) hexa_substeps<NOISE>(T, a, i, s, cmd, a.step_index);
+    if constexpr (NACT == 6) hexa_substeps<NOISE>(T, a, i, s, cmd, a.step_index, ext);
   } else {
-    quad_substeps<NOISE ? 2 : 0, NACT>(T, a, i, s, cmd, a.step_index);
+    quad_substeps<NOISE ? 2 : 0, NACT>(T, a, i, s, cmd, a.step_index, ext);
   }
   store_rigid(a.st.base + o, a.st.field_stride, 0u, s);
   if (a.echo) {
@@ -389,6 +396,89 @@ __global__ __launch_bounds__(256) void k_observe(ObsK a) {
   r[13] = s.w.x; r[14] = s.w.y; r[15] = s.w.z;
   for (int j = 0; j < a.width - 16; ++j)
     r[16 + j] = a.last_action ? a.last_action[(long long)j * a.n_pad + i] : a.st.base[o + (20 + j) * a.st.field_stride];
+}
+
+// ---- neighbour downwash (formula P8) ------------------------------------------
+// world positions -> uniform xy grid (counting sort: count, scan, scatter) -> per-drone 3x3 scan
+struct DwK {
+  KView st;
+  const DevType* types;
+  const uint8_t* type_id;
+  const float* pos_all;
+  long long m, m_pad, n, n_pad;
+  float xmin, ymin, inv_cell;
+  int nx, ny;
+  int* count;        // [ncells + 1] -> exclusive prefix after the scan
+  int* cursor;       // [ncells]
+  float4* sorted;    // [m]  (x, y, z, -)
+  float* force_out;  // SoA [3][n_pad]
+};
+__device__ __forceinline__ int dw_cell(const DwK& a, float x, float y, int& cx, int& cy) {
+  cx = min(max((int)floorf((x - a.xmin) * a.inv_cell), 0), a.nx - 1);
+  cy = min(max((int)floorf((y - a.ymin) * a.inv_cell), 0), a.ny - 1);
+  return cy * a.nx + cx;
+}
+__global__ __launch_bounds__(256) void k_dw_count(DwK a) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.m) return;
+  int cx, cy;
+  atomicAdd(&a.count[dw_cell(a, a.pos_all[j], a.pos_all[a.m_pad + j], cx, cy)], 1);
+}
+// exclusive scan of count[0..ncells) by ONE workgroup (ncells is a few thousand); count[ncells] = m
+__global__ __launch_bounds__(1024) void k_dw_scan(DwK a) {
+  __shared__ int part[1024];
+  const int ncells = a.nx * a.ny, t = threadIdx.x;
+  const int per = (ncells + 1023) / 1024, lo = t * per, hi = min(lo + per, ncells);
+  int sum = 0;
+  for (int c = lo; c < hi; ++c) sum += a.count[c];
+  part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - sum;
+  for (int c = lo; c < hi; ++c) { const int k = a.count[c]; a.count[c] = run; a.cursor[c] = run; run += k; }
+  if (t == 1023) a.count[ncells] = part[1023];
+}
+__global__ __launch_bounds__(256) void k_dw_scatter(DwK a) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.m) return;
+  const float x = a.pos_all[j], y = a.pos_all[a.m_pad + j], z = a.pos_all[2 * a.m_pad + j];
+  int cx, cy;
+  const int slot = atomicAdd(&a.cursor[dw_cell(a, x, y, cx, cy)], 1);
+  a.sorted[slot] = make_float4(x, y, z, 0.0f);
+}
+__global__ __launch_bounds__(256) void k_dw_query(DwK a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_pad) return;
+  float fz = 0.0f;
+  if (i < a.n) {
+    const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
+    const long long o = kv_off(a.st, i);
+    const long long fs = a.st.field_stride;
+    const float x = a.st.base[o], y = a.st.base[o + fs], z = a.st.base[o + 2 * fs];
+    int cx, cy;
+    dw_cell(a, x, y, cx, cy);
+    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, a.ny - 1); ++yy) {
+      // the three cells of a row are contiguous in the sorted array
+      const int c0 = yy * a.nx + max(cx - 1, 0), c1 = yy * a.nx + min(cx + 1, a.nx - 1);
+      for (int sIdx = a.count[c0]; sIdx < a.count[c1 + 1]; ++sIdx) {
+        const float4 p = a.sorted[sIdx];
+        const float dz = p.z - z, dx = p.x - x, dy = p.y - y;
+        const float d2 = dx * dx + dy * dy;
+        if (dz > 0.0f && d2 < 100.0f) {                       // BaseAviary.py:1752
+          const float r = T.prop_radius * DSIM_RCP(4.0f * dz);
+          const float alpha = T.dw[0] * r * r;                // :1753
+          const float beta = T.dw[1] * dz + T.dw[2];          // :1754
+          fz -= alpha * __expf(-0.5f * d2 * DSIM_RCP(beta * beta));   // :1755
+        }
+      }
+    }
+  }
+  a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz;
 }
 
 // ---------------------------------------------------------------------------
@@ -545,6 +635,7 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
   a->n_pad = state.n_pad; a->first = 0; a->seed = args->noise_seed;
   a->wp_table = args->wp_table; a->wp_counter = args->wp_counter; a->wp_offset = args->wp_offset;
   a->n_wp = args->n_wp; a->n_steps = args->n_steps > 1 ? args->n_steps : 1;
+  a->ext_force = args->ext_force;
   if (a->wp_table && (!a->wp_counter || a->n_wp < 1)) return DSIM_E_ARG;
   a->step_index = args->step_index;
   a->substeps = args->phys_substeps; a->dt_phys = args->dt_phys; a->dt_ctrl = args->dt_ctrl;
@@ -579,7 +670,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   const hipStream_t st_ = (hipStream_t)stream;
   const dim3 b(256);
   long long first = 0;
-  if (uni && !six && !args->action && !args->noise_replay) {
+  if (uni && !six && !args->action && !args->noise_replay && !args->ext_force) {
     // fast path over the whole 256-drone tiles.  Streaming (nontemporal) accesses once the fleet's
     // per-step traffic exceeds what the 256 MB Infinity Cache can keep between consecutive steps
     // (tuning knob for A/B runs: DSIM_NT = 0|1).
@@ -644,6 +735,39 @@ int dsim_observe(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const 
   if (rc) return rc;
   a.last_action = last_action; a.out = obs_out; a.n = n; a.n_pad = state.n_pad; a.width = obs_width;
   hipLaunchKernelGGL(k_observe, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny) {
+  if (m < 0 || nx < 1 || ny < 1) return -1;
+  return ((int64_t)nx * ny + 1) + (int64_t)nx * ny + 4 + 4 * m;   // count, cursor, 16-B alignment slack, float4[m]
+}
+
+int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_downwash_args* g,
+                  float* force_out) {
+  if (!ctx || !g || !force_out || !g->pos_all || !g->workspace || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
+  if (g->m < 1 || g->m_pad < g->m || g->nx < 1 || g->ny < 1 || !(g->cell >= 10.0f)) return DSIM_E_ARG;
+  if ((long long)g->nx * g->ny > (1 << 24)) return DSIM_E_ARG;
+  if (g->workspace_len < dsim_downwash_workspace(g->m, g->nx, g->ny)) return DSIM_E_ARG;
+  if (ctx->n_types > 1 && !g->type_id) return DSIM_E_ARG;
+  DwK a;
+  int rc = make_kview(state, 20 + ctx->max_act, &a.st);
+  if (rc) return rc;
+  const long long ncells = (long long)g->nx * g->ny;
+  a.types = ctx->d_types; a.type_id = g->type_id; a.pos_all = g->pos_all;
+  a.m = g->m; a.m_pad = g->m_pad; a.n = n; a.n_pad = state.n_pad;
+  a.xmin = g->xmin; a.ymin = g->ymin; a.inv_cell = 1.0f / g->cell; a.nx = g->nx; a.ny = g->ny;
+  a.count = g->workspace; a.cursor = g->workspace + ncells + 1;
+  uintptr_t sp = (uintptr_t)(a.cursor + ncells);
+  a.sorted = (float4*)((sp + 15) & ~(uintptr_t)15);
+  a.force_out = force_out;
+  const hipStream_t st_ = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(a.count, 0, sizeof(int) * (ncells + 1), st_);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(k_dw_count, dim3(grid_for(a.m)), dim3(256), 0, st_, a);
+  hipLaunchKernelGGL(k_dw_scan, dim3(1), dim3(1024), 0, st_, a);
+  hipLaunchKernelGGL(k_dw_scatter, dim3(grid_for(a.m)), dim3(256), 0, st_, a);
+  hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.n_pad)), dim3(256), 0, st_, a);
   return (int)hipGetLastError();
 }
 

@@ -66,12 +66,13 @@ class CtrlAviary:
         layout: str = "soa",
         noise_seed: Optional[int] = None,
         dict_io: Optional[bool] = None,
+        dist=None,
     ):
         if gui or record or obstacles:
             raise NotImplementedError("gui/record/obstacles are rendering features outside the hot path")
-        if physics not in (Physics.PYB,):
-            raise NotImplementedError(f"physics={physics}: only Physics.PYB is wired (the only live branch "
-                                      "of the reference, BaseAviary.py:523-524)")
+        if physics not in (Physics.PYB, Physics.PYB_DW):
+            raise NotImplementedError(f"physics={physics}: Physics.PYB (the only live branch of the reference, "
+                                      "BaseAviary.py:523-524) and Physics.PYB_DW (neighbour downwash) are wired")
         if isinstance(drone_model, (str, DroneType)):
             drone_model = [drone_model]
         models = list(drone_model)
@@ -120,6 +121,12 @@ class CtrlAviary:
         self._last_action = torch.zeros_like(self._action_buf)
         self._use_last_action = True
         self._obs_buf = None      # [N, 16+n_act], allocated on the first observe()
+        # Physics.PYB_DW: neighbour downwash (BaseAviary.py:534-536, 1736-1763); `dist` = an initialised
+        # torch.distributed module when the world's fleet is sharded over several ranks
+        self._downwash = None
+        if physics == Physics.PYB_DW:
+            from ..downwash import Downwash
+            self._downwash = Downwash(self.ctx, self.state, self._type_id, dist)
         self.step_counter = 0
         self._env_steps = 0
         self._housekeeping()
@@ -143,6 +150,7 @@ class CtrlAviary:
         a.action = None
         a.wp_table = a.wp_counter = a.wp_offset = None
         a.n_wp, a.n_steps = 0, 1
+        a.ext_force = self._downwash.compute().data_ptr() if self._downwash is not None else None
         return a
 
     # ------------------------------------------------------------------ gym surface

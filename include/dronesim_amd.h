@@ -143,6 +143,10 @@ typedef struct dsim_step_args {
    * launch with the state held in registers (step_index, step_index+1, ...); targets stay fixed
    * unless they come from the waypoint table.  0 is treated as 1.                                   */
   int32_t      n_steps;
+  /* -- external body-frame force --------------------------------------------------------------------
+   * nullable; SoA [3][n_pad]: extra force applied at the COM in the LINK frame every sub-step, e.g.
+   * the neighbour downwash of dsim_downwash (BaseAviary.py:1755-1762 applies it to link 4 = COM).   */
+  const float* ext_force;
 } dsim_step_args;
 
 typedef struct dsim_ctx dsim_ctx;
@@ -192,6 +196,29 @@ int dsim_control(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_v
  * (the env's last_clipped_action); NULL = the stored cmd.                        */
 int dsim_observe(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
                  float* obs_out, int32_t obs_width);
+
+/* Neighbour downwash, formula P8 (BaseAviary._downwash, BaseAviary.py:1736-1763; dead code in the
+ * fork, intended semantics): for every local drone i and every drone j of the WORLD above it
+ * (dz > 0) within dxy < 10 m,  Fz -= DW1 (PROP_RADIUS/(4 dz))^2 exp(-0.5 (dxy / (DW2 dz + DW3))^2)
+ * with the receiving drone's coefficients, along its body z axis.
+ * pos_all: SoA [3][m_pad] positions of ALL drones of the world (on several GPUs: the all-gather of
+ * every rank's positions); the library bins them into a uniform xy grid (cell >= 10 m; drones outside
+ * the box are clamped to the border cells, which keeps every pair within 10 m in adjacent cells) and
+ * each local drone scans its 3x3 cells: O(n * neighbours) instead of the reference's O(n m).
+ * force_out: SoA [3][n_pad], x and y written as 0 (feed it to dsim_step_args.ext_force).
+ * workspace: caller-owned device int32 buffer of at least dsim_downwash_workspace(m, nx, ny) entries. */
+typedef struct dsim_downwash_args {
+  const float* pos_all;
+  int64_t  m, m_pad;
+  float    xmin, ymin, cell;
+  int32_t  nx, ny;
+  int32_t* workspace;
+  int64_t  workspace_len;
+  const uint8_t* type_id;   /* nullable; types of the LOCAL drones */
+} dsim_downwash_args;
+int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny);
+int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_downwash_args* args,
+                  float* force_out);
 
 /* Diagnostics counters kept by the ctx (device-side, cumulative; this call synchronises `stream`):
  *   DSIM_Q_WLS_FALLBACKS  drones x steps whose 6DOF allocation left the first-iteration fast path and

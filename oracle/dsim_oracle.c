@@ -629,7 +629,8 @@ void orc_bullet_step(const dsim_type_params* P, double dt, double pos[3], double
  * (BaseAviary.py:510-545): wrench from the clipped action, optional add-ons,
  * then the engine step.  noise: [2*n_act] = f_noise then m_noise, or NULL.   */
 void orc_physics_substep(const dsim_type_params* P, double dt, double rigid[13], const double* cmd,
-                         const double* last_cmd, const double* noise, uint32_t options) {
+                         const double* last_cmd, const double* noise, uint32_t options,
+                         const double* ext_force_body /* nullable [3]: extra LINK_FRAME force at the COM */) {
   double F[3], tau[3], rpm[DSIM_MAX_ACT];
   const double* fn = noise;
   const double* mn = noise ? noise + P->n_act : NULL;
@@ -652,6 +653,7 @@ void orc_physics_substep(const dsim_type_params* P, double dt, double rigid[13],
     orc_drag(P, q, v, lrpm, D);
     for (int k = 0; k < 3; ++k) F[k] += D[k];
   }
+  if (ext_force_body) for (int k = 0; k < 3; ++k) F[k] += ext_force_body[k];
   orc_bullet_step(P, dt, pos, q, v, w, F, tau);
 }
 
@@ -735,7 +737,8 @@ int orc_control_batch(const dsim_type_params* types, const uint8_t* type_id, int
  * noise [n][substeps][12] (f_noise6, m_noise6; quad uses [0:4] of each) or NULL. */
 int orc_physics_batch(const dsim_type_params* types, const uint8_t* type_id, int64_t n, int substeps,
                       double dt, double* rigid, const double* action, const double* mem, const double* noise,
-                      uint32_t options, double* last_action_out, int nthreads) {
+                      uint32_t options, double* last_action_out, const double* ext_force_body /* [n][3] nullable */,
+                      int nthreads) {
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
@@ -754,7 +757,8 @@ int orc_physics_batch(const dsim_type_params* types, const uint8_t* type_id, int
         for (int j = 0; j < P->n_act; ++j) { nz[j] = src[j]; nz[P->n_act + j] = src[6 + j]; }
         np_ = nz;
       }
-      orc_physics_substep(P, dt, rigid + i * 13, clipped, s == 0 ? last : clipped, np_, options);
+      orc_physics_substep(P, dt, rigid + i * 13, clipped, s == 0 ? last : clipped, np_, options,
+                          ext_force_body ? ext_force_body + i * 3 : NULL);
     }
     if (last_action_out) memcpy(last_action_out + i * 6, clipped, sizeof(clipped));
   }
@@ -764,9 +768,42 @@ int orc_physics_batch(const dsim_type_params* types, const uint8_t* type_id, int
 /* fused Env.step + computeControl, the example loop body (fly_INDI.py:223-239) */
 int orc_step_batch(const dsim_type_params* types, const uint8_t* type_id, int64_t n, int substeps,
                    double dt_phys, double dt_ctrl, double* rigid, double* mem, const double* tgt,
-                   int bcast_tgt, const double* noise, uint32_t options, const double* action, int nthreads) {
-  orc_physics_batch(types, type_id, n, substeps, dt_phys, rigid, action, mem, noise, options, NULL, nthreads);
+                   int bcast_tgt, const double* noise, uint32_t options, const double* action,
+                   const double* ext_force_body, int nthreads) {
+  orc_physics_batch(types, type_id, n, substeps, dt_phys, rigid, action, mem, noise, options, NULL, ext_force_body, nthreads);
   return orc_control_batch(types, type_id, n, dt_ctrl, rigid, mem, tgt, bcast_tgt, NULL, NULL, nthreads);
+}
+
+/* P8: BaseAviary._downwash, BaseAviary.py:1736-1763 (formula only; dead code in the fork).
+ * For drone i and every drone j of the world above it (dz > 0) within dxy < 10 m:
+ *   alpha = DW1 (PROP_RADIUS / (4 dz))^2 ; beta = DW2 dz + DW3 ; Fz -= alpha exp(-0.5 (dxy/beta)^2)
+ * with the RECEIVING drone's coefficients; applied along the body z axis at the COM (LINK_FRAME,
+ * link 4).  Brute force O(n m).  pos_all [m][3]: every drone of the world; rigid [n][13]: the
+ * receivers (their own entry in pos_all has dz = 0 and drops out).  fz_out [n]. */
+void orc_downwash(const dsim_type_params* types, const uint8_t* type_id, int64_t n, const double* rigid,
+                  const double* pos_all, int64_t m, double* fz_out, int nthreads) {
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    const dsim_type_params* P = &types[type_id ? type_id[i] : 0];
+    const double* p = rigid + i * 13;
+    double fz = 0;
+    for (int64_t j = 0; j < m; ++j) {
+      const double dz = pos_all[j * 3 + 2] - p[2];
+      const double dx = pos_all[j * 3] - p[0], dy = pos_all[j * 3 + 1] - p[1];
+      const double dxy = sqrt(dx * dx + dy * dy);
+      if (dz > 0 && dxy < 10) {
+        const double r = P->prop_radius / (4 * dz);
+        const double alpha = P->dw_coeff[0] * r * r;
+        const double beta = P->dw_coeff[1] * dz + P->dw_coeff[2];
+        const double q = dxy / beta;
+        fz += -alpha * exp(-0.5 * q * q);
+      }
+    }
+    fz_out[i] = fz;
+  }
 }
 
 /* P5: _getDroneStateVector, BaseAviary.py:780-790: [pos quat rpy vel ang_v last_action] */

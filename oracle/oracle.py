@@ -153,10 +153,11 @@ class Oracle:
         self._L.orc_control_batch.argtypes = [TP, _U8, ctypes.c_int64, ctypes.c_double, _D, _D, _D,
                                               ctypes.c_int, _D, _D, ctypes.c_int]
         self._L.orc_physics_batch.argtypes = [TP, _U8, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
-                                              _D, _D, _D, _D, ctypes.c_uint32, _D, ctypes.c_int]
+                                              _D, _D, _D, _D, ctypes.c_uint32, _D, _D, ctypes.c_int]
         self._L.orc_step_batch.argtypes = [TP, _U8, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
                                            ctypes.c_double, _D, _D, _D, ctypes.c_int, _D,
-                                           ctypes.c_uint32, _D, ctypes.c_int]
+                                           ctypes.c_uint32, _D, _D, ctypes.c_int]
+        self._L.orc_downwash.argtypes = [TP, _U8, ctypes.c_int64, _D, _D, ctypes.c_int64, _D, ctypes.c_int]
 
     def reset_mem(self, n: int, type_id: Optional[np.ndarray] = None) -> np.ndarray:
         mem = np.zeros((n, 13))
@@ -176,22 +177,34 @@ class Oracle:
         return rc, pos_e, yaw_e
 
     def physics(self, rigid, mem, substeps, dt, action=None, noise=None, options=0, type_id=None,
-                last_action=None, nthreads=1):
-        """action [n,6] (None = stored cmd); last_action [n,6] in/out (env's last_clipped_action)."""
+                last_action=None, ext_force=None, nthreads=1):
+        """action [n,6] (None = stored cmd); last_action [n,6] in/out (env's last_clipped_action);
+        ext_force [n,3] extra body-frame force at the COM (e.g. downwash)."""
         n = rigid.shape[0]
         act = None if action is None else _c(action)
         nz = None if noise is None else _c(noise)
+        ef = None if ext_force is None else _c(ext_force)
         return self._L.orc_physics_batch(self._c_types, _p(type_id, _U8), n, substeps, dt, _p(rigid),
-                                         _p(act), _p(mem), _p(nz), options, _p(last_action), nthreads)
+                                         _p(act), _p(mem), _p(nz), options, _p(last_action), _p(ef), nthreads)
+
+    def downwash(self, rigid, pos_all, type_id=None, nthreads=1):
+        """Brute-force formula P8: body-z force on each drone of `rigid` from every drone in pos_all [m,3]."""
+        n = rigid.shape[0]
+        pa = _c(pos_all)
+        out = np.zeros(n)
+        self._L.orc_downwash(self._c_types, _p(type_id, _U8), n, _p(rigid), _p(pa), pa.shape[0], _p(out), nthreads)
+        return out
 
     def step(self, rigid, mem, tgt, substeps, dt_phys, dt_ctrl, noise=None, options=0, type_id=None,
-             action=None, nthreads=1):
+             action=None, ext_force=None, nthreads=1):
         n = rigid.shape[0]
         bc = int(tgt.shape[0] == 1 and n != 1)
         nz = None if noise is None else _c(noise)
         act = None if action is None else _c(action)
+        ef = None if ext_force is None else _c(ext_force)
         return self._L.orc_step_batch(self._c_types, _p(type_id, _U8), n, substeps, dt_phys, dt_ctrl,
-                                      _p(rigid), _p(mem), _p(_c(tgt)), bc, _p(nz), options, _p(act), nthreads)
+                                      _p(rigid), _p(mem), _p(_c(tgt)), bc, _p(nz), options, _p(act), _p(ef),
+                                      nthreads)
 
     def noise_normals(self, seed: int, drone: int, sub_counter: int, n_act: int) -> np.ndarray:
         out = np.zeros(2 * n_act)

@@ -20,7 +20,7 @@ def nat():
 def test_header_symbols_exported(nat):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = open(os.path.join(root, "include", "dronesim_amd.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(dsim_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(dsim_\w+)\s*\(", hdr, flags=re.M))
     assert declared == set(nat.EXPORTS), declared ^ set(nat.EXPORTS)
     lib = nat.load()
     for sym in declared:
@@ -34,7 +34,7 @@ def test_struct_sizes_match_c(nat):
     from oracle import oracle as orc
     assert orc.lib().orc_sizeof_params() == ctypes.sizeof(params.TypeParamsC)
     assert ctypes.sizeof(nat.View) == 48
-    assert ctypes.sizeof(nat.StepArgs) == 88
+    assert ctypes.sizeof(nat.StepArgs) == 96
 
 
 def test_no_cpu_fallback(nat):

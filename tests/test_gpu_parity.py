@@ -395,6 +395,68 @@ def test_hexa_hover_physics(gpu):
 
 
 # ---------------------------------------------------------------------------
+# neighbour downwash (formula P8) and the external-force input
+# ---------------------------------------------------------------------------
+def test_downwash_vs_bruteforce_oracle(gpu):
+    nat, fleet = gpu
+    from dronesim_amd.downwash import Downwash
+    n = 4000
+    types = [params.builtin_type("robobee"), params.builtin_type("hexa_6DOF")]
+    ctx = fleet.Context(types)
+    st = fleet.FleetState(ctx, n)
+    rng = np.random.default_rng(51)
+    rigid, mem, _ = random_fleet(rng, n, n_act=6)
+    rigid[:, 0] = f32(rng.uniform(-40, 160, n)); rigid[:, 1] = f32(rng.uniform(-30, 70, n)); rigid[:, 2] = f32(rng.uniform(0.5, 20.5, n))
+    rigid[7, 0:3] = rigid[8, 0:3] + [0.0, 0.0, 0.5]          # one drone right above another: strong term
+    rigid[9, 0:3] = rigid[8, 0:3]                            # coincident pair: dz = 0 drops out
+    st.load_aos(rigid, mem)
+    tid = (np.arange(n) % 2).astype(np.uint8)
+    tid_dev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device); tid_dev[:n] = torch.from_numpy(tid)
+    dw = Downwash(ctx, st, tid_dev)
+    f = dw.compute().cpu().numpy()
+    ref = orc.Oracle(types).downwash(rigid, rigid[:, 0:3], type_id=tid)
+    assert (ref < 0).sum() > n // 2 and ref.min() < -1e-3    # the field is populated
+    np.testing.assert_array_equal(f[0:2], 0.0)
+    err = np.abs(f[2, :n] - ref) / (np.abs(ref) + 1e-3)
+    assert err.max() < 1e-4, (err.max(), err.argmax())
+    # world = local + a remote shard (what another rank would contribute through the all-gather)
+    remote = f32(np.stack([rng.uniform(-40, 160, 1500), rng.uniform(-30, 70, 1500), rng.uniform(0.5, 25, 1500)], 1))
+    world = np.concatenate([rigid[:, 0:3], remote])
+    f2 = dw.compute(torch.from_numpy(np.ascontiguousarray(world.T)).float().to(ctx.device)).cpu().numpy()
+    ref2 = orc.Oracle(types).downwash(rigid, world, type_id=tid)
+    assert (np.abs(f2[2, :n] - ref2) / (np.abs(ref2) + 1e-3)).max() < 1e-4
+    assert np.abs(ref2 - ref).max() > 1e-4                    # the remote shard matters
+    ctx.close()
+
+
+def test_step_with_downwash_env(gpu):
+    """Physics.PYB_DW env: fused step with the downwash force vs the oracle fed the brute-force force."""
+    from dronesim_amd.envs import CtrlAviary, Physics
+    n = 512
+    rng = np.random.default_rng(52)
+    xyz = np.stack([rng.uniform(0, 30, n), rng.uniform(0, 30, n), rng.uniform(0.5, 10, n)], 1)
+    env = CtrlAviary(["robobee"], n, initial_xyzs=xyz, physics=Physics.PYB_DW, aggregate_phy_steps=1,
+                     noise_seed=0, dict_io=False)
+    from dronesim_amd.fleet import Targets
+    tg = Targets(env.ctx, n)
+    tg.set(pos=f32(xyz).T, yaw=0.0)
+    t = params.builtin_type("robobee")
+    O = orc.Oracle([t])
+    rigid, mem = env.state.rigid_aos(), env.state.mem_aos()
+    tgt = np.concatenate([f32(xyz), np.zeros((n, 7))], 1)
+    for k in range(5):
+        fz = O.downwash(rigid, rigid[:, 0:3])
+        ext = np.zeros((n, 3)); ext[:, 2] = f32(fz)
+        a6 = None
+        if k == 0:
+            a6 = np.zeros((n, 6)); a6[:, :4] = 0.45
+        env.step_fused(tg, action=np.full((n, 4), 0.45, dtype=np.float32) if k == 0 else None)
+        assert O.step(rigid, mem, tgt, 1, DT, DT, action=a6, ext_force=ext) == 0
+    assert rel_err(env.state.rigid_aos(), rigid, RIGID_SCALE).max() < 3 * REL_TOL
+    env.close()
+
+
+# ---------------------------------------------------------------------------
 # config 3: waypoint-table tracking (examples/fly_INDI_TrajectoryTrack.py) and multi-step launches
 # ---------------------------------------------------------------------------
 def _traj_fleet(gpu, golden_dir, n, noise_seed=0):

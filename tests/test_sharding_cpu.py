@@ -53,3 +53,28 @@ def test_two_rank_timing_reduction_gloo():
     for r in (0, 1):
         assert out[r][2] == 2.0 and out[r][3] == 0.75          # MAX over ranks on both
         assert out[r][4] == 1000 * 10 / 2.0                     # whole-job aggregate
+
+
+def _gather_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dronesim_amd.downwash import gather_positions
+    n_total = 64
+    b, e = sharding.shard_range(n_total, world, rank)
+    glob = torch.arange(3 * n_total, dtype=torch.float32).reshape(3, n_total)     # "world" positions
+    got = gather_positions(glob[:, b:e].clone(), dist)
+    out[rank] = bool(torch.equal(got, glob))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_position_allgather_restores_global_order_gloo():
+    """The one exchange step of the multi-GPU layout (downwash): all-gather of the shards' positions
+    must give every rank the world array in global drone order."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gather_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out[0] and out[1]
