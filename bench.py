@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
-    p.add_argument("--workload", default="config2x1024", choices=["config2x1024", "config2", "config3"])
+    p.add_argument("--workload", default="config2x1024", choices=["config2x1024", "config2", "config3", "config5"])
     p.add_argument("--substeps", type=int, default=1)
     p.add_argument("--layout", default="tile64", choices=["soa", "tile64"])
     p.add_argument("--noise-seed", type=int, default=1)
@@ -59,14 +59,24 @@ def grid_fleet(n_fleet, replicas, pitch=1.0, z=0.5):
 class Fleet:
     """A resident fleet + per-drone hover targets at the start position."""
 
-    def __init__(self, n_fleet, replicas, device, substeps, layout, noise_seed, waypoints=False, n_steps=1):
+    def __init__(self, n_fleet, replicas, device, substeps, layout, noise_seed, waypoints=False, n_steps=1,
+                 config5=False, dist=None, rank=0):
         import torch
-        from dronesim_amd.envs import CtrlAviary
+        from dronesim_amd.envs import CtrlAviary, Physics
         from dronesim_amd.fleet import Targets, WaypointTargets
         self.torch = torch
         self.n_steps = n_steps
         xyz = grid_fleet(n_fleet, replicas)
         self.n = xyz.shape[0]
+        models, physics = ["robobee"], Physics.PYB
+        if config5:
+            # BASELINE configs[4] (SURVEY.md 8d item 5): even index robobee (quad INDI), odd index
+            # hexa_6DOF (6DOF INDI + WLS); positions uniform in a 1024 x 512 x [0.5, 20.5] m box so that
+            # downwash pairs exist; neighbour downwash on; this rank's shard of the world fleet
+            rng = np.random.default_rng(1234 + rank)
+            xyz = np.stack([rng.uniform(0, 1024, self.n), rng.uniform(0, 512, self.n), rng.uniform(0.5, 20.5, self.n)], 1)
+            models = ["robobee" if i % 2 == 0 else "hexa_6DOF" for i in range(self.n)]
+            physics = Physics.PYB_DW
         if waypoints:
             # config 3 (examples/fly_INDI_TrajectoryTrack.py): the reference's own 1200-row waypoint
             # table (fixture captured from its trajGen), gate 0 + grid offset, phase i*NUM_WP/6
@@ -75,8 +85,8 @@ class Fleet:
             off = xyz.copy(); off[:, 2] = 0.0
             xyz = g["gates"][0][None, :] + off
             wp0 = (np.arange(self.n) * n_wp // 6) % n_wp
-        self.env = CtrlAviary(["robobee"], self.n, initial_xyzs=xyz, aggregate_phy_steps=substeps,
-                              device=device, layout=layout, noise_seed=noise_seed, dict_io=False)
+        self.env = CtrlAviary(models, self.n, initial_xyzs=xyz, aggregate_phy_steps=substeps, physics=physics,
+                              device=device, layout=layout, noise_seed=noise_seed, dict_io=False, dist=dist)
         if waypoints:
             self.tgt = WaypointTargets(self.env.ctx, self.n, g["target_pos"], g["target_vel"], g["target_acc"],
                                        g["target_yaw"], wp_counters=wp0, offsets=off)
@@ -84,7 +94,7 @@ class Fleet:
             self.tgt = Targets(self.env.ctx, self.n, layout)
             self.tgt.set(pos=xyz.T.astype(np.float32), yaw=0.4)
         # fly_INDI.py:214: the loop starts from action 0.4; afterwards the action is the controller's cmd
-        self.env.step_fused(self.tgt, action=np.full((self.n, 4), 0.4, dtype=np.float32))
+        self.env.step_fused(self.tgt, action=np.full((self.n, self.env.n_act), 0.4, dtype=np.float32))
 
     def step(self):
         self.env.step_fused(self.tgt, n_steps=self.n_steps)
@@ -185,10 +195,14 @@ def main():
     torch.cuda.set_device(local)
     barrier = (lambda: dist.barrier()) if dist else None
 
-    n_fleet, replicas = {"config2x1024": (4096, 1024), "config2": (4096, 1), "config3": (65536, 1)}[a.workload]
+    n_fleet, replicas = {"config2x1024": (4096, 1024), "config2": (4096, 1), "config3": (65536, 1),
+                         "config5": (65536, 1)}[a.workload]
     from dronesim_amd import sharding
     # weak scaling: every rank owns a same-sized contiguous shard of the N-GPU fleet; no data-path collective
-    fl = Fleet(n_fleet, replicas, local, a.substeps, a.layout, sharding.rank_seed(a.noise_seed, rank))
+    # (config5 only: one all-gather of positions per step for the neighbour-downwash term)
+    fl = Fleet(n_fleet, replicas, local, a.substeps, a.layout, sharding.rank_seed(a.noise_seed, rank),
+               waypoints=a.workload == "config3", config5=a.workload == "config5",
+               dist=dist if (a.workload == "config5" and backend == "nccl") else None, rank=rank)
     wall, dev_s = fl.timed(a.steps, a.warmup, barrier)
     wall, dev_s = sharding.reduce_step_times(dist, "cuda" if backend == "nccl" else "cpu", wall, dev_s)  # MAX over ranks
     value = sharding.aggregate_throughput([fl.n] * world, a.steps, wall)
@@ -208,7 +222,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": {"config2x1024": "configs[1] 4096 robobee INDI hover x 1024 vectorised envs/GPU",
                                     "config2": "configs[1] 4096 robobee INDI hover (single fleet)",
-                                    "config3": "65536 robobee, per-drone targets"}[a.workload],
+                                    "config3": "65536 robobee, waypoint-table tracking (fly_INDI_TrajectoryTrack)",
+                                    "config5": "65536/GPU shard of 50% robobee + 50% hexa_6DOF, neighbour downwash on"}[a.workload],
                        "drones_per_gpu": fl.n, "phys_substeps": a.substeps, "layout": a.layout,
                        "noise_seed": a.noise_seed, "launches_per_step": 1, "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -235,8 +250,10 @@ def main():
                     "config2_single_fleet_4096_sub5_32steps_per_launch": (4096, 1, 5, False, 32),
                     "config3_65536_waypoints_sub2": (65536, 1, 2, True, 1),
                     "config3_65536_waypoints_sub2_32steps_per_launch": (65536, 1, 2, True, 32),
-                    "config2x1024_sub5": (4096, 1024, 5, False, 1)}.items():
-                f2 = Fleet(nf, rep, local, sub, a.layout, a.noise_seed, waypoints=wp, n_steps=ns)
+                    "config2x1024_sub5": (4096, 1024, 5, False, 1),
+                    "config5_shard_65536_mixed_downwash": (65536, 1, 1, False, 1)}.items():
+                f2 = Fleet(nf, rep, local, sub, a.layout, a.noise_seed, waypoints=wp, n_steps=ns,
+                           config5=name.startswith("config5"))
                 k2 = max(20, a.steps // 2)
                 w2, d2 = f2.timed(k2, 10)
                 also[name] = {"drone_steps_per_s": f2.n * k2 * ns / w2, "launch_us": d2 / k2 * 1e6,
