@@ -21,13 +21,18 @@
 #ifndef DSIM_STEP_WAVES
 #define DSIM_STEP_WAVES 4
 #endif
+#ifndef DSIM_GEN_WAVES
+#define DSIM_GEN_WAVES 2
+#endif
 
 struct dsim_ctx {
   int device;
   int n_types;
   int max_act;                            // 4: quads only; 6: the table holds a morphing hexa
   DevType* d_types;                       // device copy of the type table
-  unsigned long long* d_counters;         // [2] diagnostics (dsim_query)
+  unsigned long long* d_counters;         // [0..1] diagnostics (dsim_query), [2] fallback queue length
+  FbEntry* d_fb;                          // deferred WLS fallback queue, grown to the largest fleet seen
+  long long fb_cap;
   dsim_type_params h_types[DSIM_MAX_TYPES];
 };
 
@@ -61,7 +66,7 @@ struct StepK {
   float* echo;                // physics kernel: clipped action out, or null
   float* pos_e_out;           // control kernel only
   float* yaw_e_out;
-  unsigned long long* counters;
+  FbList fb;                  // deferred WLS fallbacks (hexa)
   long long n_pad;
   long long first;            // general step kernel: first drone of this launch
   const float* wp_table;      // waypoint mode (null = targets view)
@@ -173,7 +178,7 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
 }
 
 // the same for the morphing hexa (BaseAviary.py:1389-1457); replay rows: f[6], m[6]
-template <bool NOISE>
+template <bool NOISE, bool REPLAY = true>
 __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[6], unsigned long long step_index,
                                               V3 ext = V3{0.0f, 0.0f, 0.0f}) {
@@ -182,7 +187,7 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
   for (int k = 0; k < a.substeps; ++k) {
     if (NOISE) {
       float nz[12];
-      if (a.noise_replay) {
+      if (REPLAY && a.noise_replay) {
 #pragma unroll
         for (int j = 0; j < 12; ++j) nz[j] = a.noise_replay[((long long)k * 12 + j) * a.n_pad + i];
       } else {
@@ -243,66 +248,100 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
   store_mem<4, NT>(sb, sfs, sl, m);
 }
 
+// Mixed fleets: every lane carries a type id, but the per-type constants must stay wave-uniform
+// (scalar loads into SGPRs: ~150 floats per type would otherwise sit in VGPRs per lane — 256 VGPRs
+// plus spills).  Waterfall: the wave peels one type per iteration with the lanes of that type active.
+#define DSIM_FOR_MY_TYPE(UNIFORM, a, i, BODY)                                   \
+  do {                                                                          \
+    if (UNIFORM) { const DevType& T = (a).types[0]; BODY; }                     \
+    else {                                                                      \
+      const int my_t_ = (a).type_id[i];                                         \
+      for (;;) {                                                                \
+        const int cur_t_ = __builtin_amdgcn_readfirstlane(my_t_);               \
+        if (my_t_ == cur_t_) { const DevType& T = (a).types[cur_t_]; BODY; break; } \
+      }                                                                         \
+    }                                                                           \
+  } while (0)
+
 // General form: per-drone type ids (mixed quad / hexa fleets, NACT = 6), explicit action
-// override, noise replay, ragged sizes.  a.first = first drone this launch covers.
-// In a mixed wave the quad and hexa branches execute one after the other (lane-masked).
-template <bool NOISE, bool UNIFORM, int NACT>
-__global__ __launch_bounds__(256) void k_step_gen(StepK a) {
-  const long long i = a.first + (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n_pad) return;
-  const DevType& T = a.types[UNIFORM ? 0 : a.type_id[i]];
-  const long long o = kv_off(a.st, i);
+// override, noise replay, external force, ragged sizes.  a.first = first drone this launch covers
+// (a multiple of 256, so the scalar-base + lane-offset addressing of the fast kernel applies).
+struct Addr { float* sb; const float* tb; unsigned sl, tl; long long sfs, tfs; };
+__device__ __forceinline__ Addr make_addr(const StepK& a, long long i0) {
+  Addr r;
+  r.sb = a.st.base + kv_off(a.st, i0);
+  r.tb = a.tg.base ? a.tg.base + kv_off(a.tg, i0) : nullptr;
+  r.sl = 4u * kv_lane(a.st, threadIdx.x);
+  r.tl = 4u * kv_lane(a.tg, threadIdx.x);
+  r.sfs = a.st.field_stride; r.tfs = a.tg.field_stride;
+  return r;
+}
+// FULL = false: the lean form for plain stepping of mixed fleets (stored cmd as the action, no
+// noise replay, no waypoint table, one Env.step per launch) — the options cost registers.
+template <bool NOISE, int NACT, bool FULL>
+__device__ __forceinline__ void step_gen_body(const DevType& T, const StepK& a, long long i, const Addr& ad) {
   Rigid s;
   CtrlMem<NACT> m;
   Target tg;
-  load_rigid(a.st.base + o, a.st.field_stride, 0u, s);
-  load_mem<NACT>(a.st.base + o, a.st.field_stride, 0u, m);
+  load_rigid(ad.sb, ad.sfs, ad.sl, s);
+  load_mem<NACT>(ad.sb, ad.sfs, ad.sl, m);
   int wp = 0;
-  if (a.wp_table) wp = a.wp_counter[i]; else load_target(a.tg.base + kv_off(a.tg, i), a.tg.field_stride, 0u, tg);
-  const bool hexa = NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA;
+  if (FULL && a.wp_table) wp = a.wp_counter[i]; else load_target(ad.tb, ad.tfs, ad.tl, tg);
   V3 ext = v3(0, 0, 0);
   if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
-  for (int k = 0; k < a.n_steps; ++k) {
+  const int n_steps = FULL ? a.n_steps : 1;
+  for (int k = 0; k < n_steps; ++k) {
     float act[NACT];
 #pragma unroll
     for (int j = 0; j < NACT; ++j) act[j] = m.cmd[j];
-    if (a.action && k == 0) {            // an explicit action applies to the first Env.step only
+    if (FULL && a.action && k == 0) {    // an explicit action applies to the first Env.step only
 #pragma unroll
       for (int j = 0; j < NACT; ++j) act[j] = a.action[(long long)j * a.n_pad + i];
       preprocess_action<NACT>(T, act, act);   // the stored cmd is already clipped (INDIControl.py:487)
     }
-    if (a.wp_table) waypoint_target(a, i, wp, tg);
+    if (FULL && a.wp_table) waypoint_target(a, i, wp, tg);
     V3 pos_e;
     float yaw_e;
-    if (NACT == 6 && hexa) {
+    if (NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA) {     // wave-uniform branch
       if constexpr (NACT == 6) {
-        hexa_substeps<NOISE>(T, a, i, s, act, a.step_index + k, ext);
-        indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.counters);
+        hexa_substeps<NOISE, FULL>(T, a, i, s, act, a.step_index + k, ext);
+        indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
       }
     } else {
-      quad_substeps<NOISE ? 2 : 0, NACT>(T, a, i, s, act, a.step_index + k, ext);
+      quad_substeps<NOISE ? (FULL ? 2 : 1) : 0, NACT>(T, a, i, s, act, a.step_index + k, ext);
       indi_quad<false, NACT>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
     }
     wp = waypoint_next(wp, a.n_wp);
   }
-  if (a.wp_table) a.wp_counter[i] = wp;
-  store_rigid(a.st.base + o, a.st.field_stride, 0u, s);
-  store_mem<NACT>(a.st.base + o, a.st.field_stride, 0u, m);
+  if (FULL && a.wp_table) a.wp_counter[i] = wp;
+  store_rigid(ad.sb, ad.sfs, ad.sl, s);
+  store_mem<NACT>(ad.sb, ad.sfs, ad.sl, m);
+}
+template <bool NOISE, bool UNIFORM, int NACT>
+__global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_step_gen(StepK a) {
+  const long long i0 = a.first + (long long)blockIdx.x * 256;
+  const long long i = i0 + threadIdx.x;
+  if (i >= a.n_pad) return;
+  const Addr ad = make_addr(a, i0);
+  DSIM_FOR_MY_TYPE(UNIFORM, a, i, (step_gen_body<NOISE, NACT, true>(T, a, i, ad)));
+}
+template <bool NOISE, bool UNIFORM, int NACT>
+__global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_step_lean(StepK a) {
+  const long long i0 = a.first + (long long)blockIdx.x * 256;
+  const long long i = i0 + threadIdx.x;
+  if (i >= a.n_pad) return;
+  const Addr ad = make_addr(a, i0);
+  DSIM_FOR_MY_TYPE(UNIFORM, a, i, (step_gen_body<NOISE, NACT, false>(T, a, i, ad)));
 }
 
 // ---- Env.step only ---------------------------------------------------------
-template <bool NOISE, bool UNIFORM, int NACT>
-__global__ __launch_bounds__(256) void k_physics_gen(StepK a) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n_pad) return;
-  const DevType& T = a.types[UNIFORM ? 0 : a.type_id[i]];
-  const long long o = kv_off(a.st, i);
+template <bool NOISE, int NACT>
+__device__ __forceinline__ void physics_gen_body(const DevType& T, const StepK& a, long long i, const Addr& ad) {
   Rigid s;
-  load_rigid(a.st.base + o, a.st.field_stride, 0u, s);
+  load_rigid(ad.sb, ad.sfs, ad.sl, s);
   float raw[NACT], cmd[NACT];
-  const long long fs = a.st.field_stride;
 #pragma unroll
-  for (int j = 0; j < NACT; ++j) raw[j] = a.action ? a.action[(long long)j * a.n_pad + i] : a.st.base[o + (20 + j) * fs];
+  for (int j = 0; j < NACT; ++j) raw[j] = a.action ? a.action[(long long)j * a.n_pad + i] : ldg<false>(ad.sb + (20 + j) * ad.sfs, ad.sl);
   preprocess_action<NACT>(T, raw, cmd);
   V3 ext = v3(0, 0, 0);
   if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
@@ -311,42 +350,74 @@ __global__ __launch_bounds__(256) void k_physics_gen(StepK a) {
   } else {
     quad_substeps<NOISE ? 2 : 0, NACT>(T, a, i, s, cmd, a.step_index, ext);
   }
-  store_rigid(a.st.base + o, a.st.field_stride, 0u, s);
+  store_rigid(ad.sb, ad.sfs, ad.sl, s);
   if (a.echo) {
 #pragma unroll
     for (int j = 0; j < NACT; ++j) a.echo[(long long)j * a.n_pad + i] = cmd[j];   // last_clipped_action, BaseAviary.py:545
   }
 }
+template <bool NOISE, bool UNIFORM, int NACT>
+__global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_physics_gen(StepK a) {
+  const long long i0 = (long long)blockIdx.x * 256;
+  const long long i = i0 + threadIdx.x;
+  if (i >= a.n_pad) return;
+  const Addr ad = make_addr(a, i0);
+  DSIM_FOR_MY_TYPE(UNIFORM, a, i, (physics_gen_body<NOISE, NACT>(T, a, i, ad)));
+}
 
 // ---- computeControl only ----------------------------------------------------
-template <bool UNIFORM, int NACT>
-__global__ __launch_bounds__(256) void k_control_gen(StepK a) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n_pad) return;
-  const DevType& T = a.types[UNIFORM ? 0 : a.type_id[i]];
-  const long long o = kv_off(a.st, i);
+template <int NACT>
+__device__ __forceinline__ void control_gen_body(const DevType& T, const StepK& a, long long i, const Addr& ad) {
   Rigid s;
   CtrlMem<NACT> m;
   Target tg;
-  load_rigid(a.st.base + o, a.st.field_stride, 0u, s);
-  load_mem<NACT>(a.st.base + o, a.st.field_stride, 0u, m);
-  load_target(a.tg.base + kv_off(a.tg, i), a.tg.field_stride, 0u, tg);
+  load_rigid(ad.sb, ad.sfs, ad.sl, s);
+  load_mem<NACT>(ad.sb, ad.sfs, ad.sl, m);
+  load_target(ad.tb, ad.tfs, ad.tl, tg);
   V3 pos_e;
   float yaw_e = 0.0f;
   if (NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA) {
     if constexpr (NACT == 6) {
-      if (a.yaw_e_out) indi_hexa<true>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.counters);
-      else indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.counters);
+      if (a.yaw_e_out) indi_hexa<true>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
+      else indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
     }
   } else {
     if (a.yaw_e_out) indi_quad<true, NACT>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
     else indi_quad<false, NACT>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
-  store_mem<NACT>(a.st.base + o, a.st.field_stride, 0u, m);
+  store_mem<NACT>(ad.sb, ad.sfs, ad.sl, m);
   if (a.pos_e_out) {
     a.pos_e_out[i] = pos_e.x; a.pos_e_out[a.n_pad + i] = pos_e.y; a.pos_e_out[2 * a.n_pad + i] = pos_e.z;
   }
   if (a.yaw_e_out) a.yaw_e_out[i] = yaw_e;
+}
+template <bool UNIFORM, int NACT>
+__global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_control_gen(StepK a) {
+  const long long i0 = (long long)blockIdx.x * 256;
+  const long long i = i0 + threadIdx.x;
+  if (i >= a.n_pad) return;
+  const Addr ad = make_addr(a, i0);
+  DSIM_FOR_MY_TYPE(UNIFORM, a, i, (control_gen_body<NACT>(T, a, i, ad)));
+}
+
+// ---- deferred WLS fallbacks (hexa) -----------------------------------------------
+struct FbK { KView st; const DevType* types; const uint8_t* type_id; FbList fb; };
+__global__ __launch_bounds__(64) void k_wls_fallback(FbK a) {
+  const unsigned long long cnt = *a.fb.count;
+  for (unsigned long long e = (unsigned long long)blockIdx.x * 64 + threadIdx.x; e < cnt;
+       e += (unsigned long long)gridDim.x * 64) {
+    const FbEntry en = a.fb.entries[e];
+    const long long i = en.drone;
+    const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
+    float* p = a.st.base + kv_off(a.st, i);
+    const long long fs = a.st.field_stride;
+    float cmd[6], umin[6], umax[6], du[6];
+    for (int j = 0; j < 6; ++j) { cmd[j] = p[(20 + j) * fs]; umin[j] = T.pmin[j] - cmd[j]; umax[j] = T.pmax[j] - cmd[j]; }
+    const int rc = wls_active_set(T, en.v, umin, umax, du);
+    atomicAdd(&a.fb.counters[0], 1ULL);
+    if (rc == 0) { for (int j = 0; j < 6; ++j) p[(20 + j) * fs] = clampf(cmd[j] + du[j], T.pmin[j], T.pmax[j]); }
+    else atomicAdd(&a.fb.counters[1], 1ULL);   // the reference would raise here; cmd is left unchanged
+  }
 }
 
 // ---- reset -------------------------------------------------------------------
@@ -564,12 +635,13 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
   dsim_ctx* c = new (std::nothrow) dsim_ctx;
   if (!c) return DSIM_E_ARG;
   c->device = device; c->n_types = n_types; c->max_act = max_act; c->d_types = nullptr; c->d_counters = nullptr;
+  c->d_fb = nullptr; c->fb_cap = 0;
   DevType h[DSIM_MAX_TYPES];
   for (int t = 0; t < n_types; ++t) { c->h_types[t] = types[t]; to_dev(types[t], &h[t]); }
   e = hipMalloc((void**)&c->d_types, sizeof(DevType) * n_types);
   if (e == hipSuccess) e = hipMemcpy(c->d_types, h, sizeof(DevType) * n_types, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * 2);
-  if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(unsigned long long) * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * 4);
+  if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(unsigned long long) * 4);
   if (e != hipSuccess) {
     if (c->d_types) (void)hipFree(c->d_types);
     if (c->d_counters) (void)hipFree(c->d_counters);
@@ -584,6 +656,7 @@ int dsim_destroy(dsim_ctx* ctx) {
   if (!ctx) return DSIM_E_ARG;
   hipError_t e = hipFree(ctx->d_types);
   (void)hipFree(ctx->d_counters);
+  if (ctx->d_fb) (void)hipFree(ctx->d_fb);
   delete ctx;
   return (int)e;
 }
@@ -631,7 +704,7 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
   }
   a->types = ctx->d_types; a->type_id = args->type_id; a->noise_replay = args->noise_replay;
   a->action = args->action; a->echo = nullptr; a->pos_e_out = nullptr; a->yaw_e_out = nullptr;
-  a->counters = ctx->d_counters;
+  a->fb.entries = ctx->d_fb; a->fb.count = ctx->d_counters + 2; a->fb.counters = ctx->d_counters;
   a->n_pad = state.n_pad; a->first = 0; a->seed = args->noise_seed;
   a->wp_table = args->wp_table; a->wp_counter = args->wp_counter; a->wp_offset = args->wp_offset;
   a->n_wp = args->n_wp; a->n_steps = args->n_steps > 1 ? args->n_steps : 1;
@@ -641,6 +714,29 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
   a->substeps = args->phys_substeps; a->dt_phys = args->dt_phys; a->dt_ctrl = args->dt_ctrl;
   a->options = args->options;
   return DSIM_OK;
+}
+
+// The deferred-fallback queue is the one ctx-owned buffer that depends on the fleet size: it is
+// (re)allocated when a larger hexa fleet is first seen, never per call afterwards.
+static int fb_prepare(dsim_ctx* ctx, long long n_pad, hipStream_t st) {
+  if (ctx->max_act != 6) return DSIM_OK;
+  if (ctx->fb_cap < n_pad) {
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return (int)e;
+    if (ctx->d_fb) (void)hipFree(ctx->d_fb);
+    ctx->d_fb = nullptr; ctx->fb_cap = 0;
+    e = hipMalloc((void**)&ctx->d_fb, sizeof(FbEntry) * n_pad);
+    if (e != hipSuccess) return (int)e;
+    ctx->fb_cap = n_pad;
+  }
+  return (int)hipMemsetAsync(ctx->d_counters + 2, 0, sizeof(unsigned long long), st);
+}
+static void fb_finish(dsim_ctx* ctx, const StepK& a, hipStream_t st) {
+  if (ctx->max_act != 6) return;
+  FbK f;
+  f.st = a.st; f.types = a.types; f.type_id = a.type_id; f.fb = a.fb;
+  f.fb.entries = ctx->d_fb;
+  hipLaunchKernelGGL(k_wls_fallback, dim3(64), dim3(64), 0, st, f);
 }
 
 // (noise, uniform) x actuator count dispatch of a general kernel
@@ -692,7 +788,26 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   if (first < a.n_pad) {   // ragged tail, or everything when the fast path does not apply
     a.first = first;
     const dim3 g(grid_for(a.n_pad - first));
-    DSIM_LAUNCH_GEN(k_step_gen, noise, uni, six, g, a, st_);
+    const bool lean = !args->action && !args->noise_replay && !a.wp_table && a.n_steps == 1;
+    if (!six) {
+      if (lean) DSIM_LAUNCH_GEN(k_step_lean, noise, uni, false, g, a, st_);
+      else DSIM_LAUNCH_GEN(k_step_gen, noise, uni, false, g, a, st_);
+    } else {
+      // hexa fleets: deferred WLS fallbacks must land before the next Env.step reads cmd, so several
+      // steps per call become several launches (each followed by the tiny fallback kernel)
+      const int steps = a.n_steps;
+      a.n_steps = 1;
+      for (int k = 0; k < steps; ++k) {
+        rc = fb_prepare(ctx, a.n_pad, st_);
+        if (rc) return rc;
+        a.fb.entries = ctx->d_fb;
+        if (lean && !a.action) DSIM_LAUNCH_GEN(k_step_lean, noise, uni, true, g, a, st_);
+        else DSIM_LAUNCH_GEN(k_step_gen, noise, uni, true, g, a, st_);
+        fb_finish(ctx, a, st_);
+        a.step_index += 1;
+        a.action = nullptr;             // an explicit action applies to the first Env.step only
+      }
+    }
   }
   return (int)hipGetLastError();
 }
@@ -719,8 +834,14 @@ int dsim_control(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_v
   const dim3 g(grid_for(a.n_pad)), b(256);
   const hipStream_t st_ = (hipStream_t)stream;
   const bool uni = args->type_id == nullptr;
-  if (ctx->max_act == 6) { if (uni) hipLaunchKernelGGL((k_control_gen<true, 6>), g, b, 0, st_, a);
-                           else hipLaunchKernelGGL((k_control_gen<false, 6>), g, b, 0, st_, a); }
+  if (ctx->max_act == 6) {
+    rc = fb_prepare(ctx, a.n_pad, st_);
+    if (rc) return rc;
+    a.fb.entries = ctx->d_fb;
+    if (uni) hipLaunchKernelGGL((k_control_gen<true, 6>), g, b, 0, st_, a);
+    else hipLaunchKernelGGL((k_control_gen<false, 6>), g, b, 0, st_, a);
+    fb_finish(ctx, a, st_);
+  }
   else { if (uni) hipLaunchKernelGGL((k_control_gen<true, 4>), g, b, 0, st_, a);
          else hipLaunchKernelGGL((k_control_gen<false, 4>), g, b, 0, st_, a); }
   return (int)hipGetLastError();

@@ -342,12 +342,18 @@ __device__ __forceinline__ void hexa_wrench(const DevType& T, const float cmd[6]
   }
 }
 
+// Drones whose WLS allocation leaves the closed-form first iteration are queued here and finished by
+// a second, tiny kernel (k_wls_fallback): the fp64 active-set loop needs ~250 registers and 2 KB of
+// scratch, which must not be charged to every lane of the step kernels.
+struct FbEntry { long long drone; float v[6]; };
+struct FbList { FbEntry* entries; unsigned long long* count; unsigned long long* counters; };
+
 // C6 fallback: the full active-set loop of wls_alloc (dronesim/control/wls_alloc.py:125-350) for
 // the rare drones whose first-iteration solution leaves the +-1.0-slackened box.  fp64: the rows
 // of A are scaled by gamma*Wv up to 1e8.  lstsq by Householder QR (A_free always contains the
 // identity rows, so it has full column rank).  Returns 0 ok, -1 "solution failed" (:350), -2 where
 // the reference would raise.  Kept out of line: it runs on a handful of lanes.
-__device__ __noinline__ int wls_active_set(const DevType& T, const float v[6], const float umin[6],
+__device__ __forceinline__ int wls_active_set(const DevType& T, const float v[6], const float umin[6],
                                            const float umax[6], float u_out[6]) {
   const double gam = 100000.0;
   const double Wv[6] = {1000, 1000, 0.1, 10, 10, 100};          // INDIControl_6DOF.py:614
@@ -452,11 +458,10 @@ __device__ __noinline__ int wls_active_set(const DevType& T, const float v[6], c
 }
 
 // C5: INDIControl_6DOF.computeControl, INDIControl_6DOF.py:259-634.
-// counters: [0] drones x steps that took the active-set fallback, [1] allocations the reference
-// would have failed on (cmd left unchanged).
+// Infeasible first iterations are queued in `fb` (see FbList).
 template <bool WANT_YAW>
 __device__ __forceinline__ void indi_hexa(const DevType& T, float dt, const Rigid& s, const Target& tg,
-                                          CtrlMem<6>& m, V3& pos_e, float& yaw_e, unsigned long long* counters) {
+                                          CtrlMem<6>& m, V3& pos_e, float& yaw_e, const FbList& fb, long long drone) {
   pos_e = tg.pos - s.pos;                                                     // :397
   const float inv_dt = DSIM_RCP(dt);
   V3 a_e;                                                                     // :399-413 (no target_acc)
@@ -504,14 +509,15 @@ __device__ __forceinline__ void indi_hexa(const DevType& T, float dt, const Rigi
     du[j] = acc;
     feasible = feasible && !(acc >= umax[j] + 1.0f || acc <= umin[j] - 1.0f);   // wls_alloc.py:255-259
   }
-  bool ok = true;
-  if (!feasible) {
-    const int rc = wls_active_set(T, v, umin, umax, du);
-    if (counters) atomicAdd(&counters[0], 1ULL);
-    if (rc != 0) { ok = false; if (counters) atomicAdd(&counters[1], 1ULL); }
-  }
-  if (ok) {
+  if (feasible) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) m.cmd[j] = clampf(m.cmd[j] + du[j], T.pmin[j], T.pmax[j]);   // :630-631
+  } else {   // cmd stays as it is; k_wls_fallback finishes this drone from (v, cmd)
+    const unsigned long long slot = atomicAdd(fb.count, 1ULL);
+    FbEntry e;
+    e.drone = drone;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) e.v[j] = v[j];
+    fb.entries[slot] = e;
   }
 }
