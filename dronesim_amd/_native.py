@@ -69,6 +69,7 @@ class DownwashArgs(ctypes.Structure):
         ("workspace", ctypes.c_void_p),
         ("workspace_len", ctypes.c_int64),
         ("type_id", ctypes.c_void_p),
+        ("local_offset", ctypes.c_int64),
     ]
 
 

@@ -476,12 +476,12 @@ struct DwK {
   const DevType* types;
   const uint8_t* type_id;
   const float* pos_all;
-  long long m, m_pad, n, n_pad;
+  long long m, m_pad, n, n_pad, local_offset;
   float xmin, ymin, inv_cell;
   int nx, ny;
   int* count;        // [ncells + 1] -> exclusive prefix after the scan
   int* cursor;       // [ncells]
-  float4* sorted;    // [m]  (x, y, z, -)
+  float4* sorted;    // [m]  (x, y, z, world index as int bits)
   float* force_out;  // SoA [3][n_pad]
 };
 __device__ __forceinline__ int dw_cell(const DwK& a, float x, float y, int& cx, int& cy) {
@@ -520,32 +520,35 @@ __global__ __launch_bounds__(256) void k_dw_scatter(DwK a) {
   const float x = a.pos_all[j], y = a.pos_all[a.m_pad + j], z = a.pos_all[2 * a.m_pad + j];
   int cx, cy;
   const int slot = atomicAdd(&a.cursor[dw_cell(a, x, y, cx, cy)], 1);
-  a.sorted[slot] = make_float4(x, y, z, 0.0f);
+  a.sorted[slot] = make_float4(x, y, z, __int_as_float((int)j));
 }
+// One thread per SORTED world entry; the entries that belong to this rank's shard are the
+// receivers.  Lanes of a wave therefore sit in the same or neighbouring cells: their 3x3 scans
+// read the same sorted entries (L1/L2 broadcast) and have similar trip counts.
 __global__ __launch_bounds__(256) void k_dw_query(DwK a) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n_pad) return;
+  const long long sidx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (sidx >= a.m) return;
+  const float4 me = a.sorted[sidx];
+  const long long i = (long long)__float_as_int(me.w) - a.local_offset;
+  if (i < 0 || i >= a.n) return;                               // another rank's drone
+  const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
+  const float x = me.x, y = me.y, z = me.z;
+  const float pr = T.prop_radius, d0 = T.dw[0], d1 = T.dw[1], d2c = T.dw[2];
+  int cx, cy;
+  dw_cell(a, x, y, cx, cy);
   float fz = 0.0f;
-  if (i < a.n) {
-    const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
-    const long long o = kv_off(a.st, i);
-    const long long fs = a.st.field_stride;
-    const float x = a.st.base[o], y = a.st.base[o + fs], z = a.st.base[o + 2 * fs];
-    int cx, cy;
-    dw_cell(a, x, y, cx, cy);
-    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, a.ny - 1); ++yy) {
-      // the three cells of a row are contiguous in the sorted array
-      const int c0 = yy * a.nx + max(cx - 1, 0), c1 = yy * a.nx + min(cx + 1, a.nx - 1);
-      for (int sIdx = a.count[c0]; sIdx < a.count[c1 + 1]; ++sIdx) {
-        const float4 p = a.sorted[sIdx];
-        const float dz = p.z - z, dx = p.x - x, dy = p.y - y;
-        const float d2 = dx * dx + dy * dy;
-        if (dz > 0.0f && d2 < 100.0f) {                       // BaseAviary.py:1752
-          const float r = T.prop_radius * DSIM_RCP(4.0f * dz);
-          const float alpha = T.dw[0] * r * r;                // :1753
-          const float beta = T.dw[1] * dz + T.dw[2];          // :1754
-          fz -= alpha * __expf(-0.5f * d2 * DSIM_RCP(beta * beta));   // :1755
-        }
+  for (int yy = max(cy - 1, 0); yy <= min(cy + 1, a.ny - 1); ++yy) {
+    // the three cells of a row are contiguous in the sorted array
+    const int c0 = yy * a.nx + max(cx - 1, 0), c1 = yy * a.nx + min(cx + 1, a.nx - 1);
+    for (int s2 = a.count[c0]; s2 < a.count[c1 + 1]; ++s2) {
+      const float4 p = a.sorted[s2];
+      const float dz = p.z - z, dx = p.x - x, dy = p.y - y;
+      const float dd = dx * dx + dy * dy;
+      if (dz > 0.0f && dd < 100.0f) {                         // BaseAviary.py:1752
+        const float r = pr * DSIM_RCP(4.0f * dz);
+        const float alpha = d0 * r * r;                       // :1753
+        const float beta = d1 * dz + d2c;                     // :1754
+        fz -= alpha * __expf(-0.5f * dd * DSIM_RCP(beta * beta));   // :1755
       }
     }
   }
@@ -876,7 +879,8 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
   if (rc) return rc;
   const long long ncells = (long long)g->nx * g->ny;
   a.types = ctx->d_types; a.type_id = g->type_id; a.pos_all = g->pos_all;
-  a.m = g->m; a.m_pad = g->m_pad; a.n = n; a.n_pad = state.n_pad;
+  a.m = g->m; a.m_pad = g->m_pad; a.n = n; a.n_pad = state.n_pad; a.local_offset = g->local_offset;
+  if (g->local_offset < 0 || g->local_offset + n > g->m || g->m >= (1LL << 31)) return DSIM_E_ARG;
   a.xmin = g->xmin; a.ymin = g->ymin; a.inv_cell = 1.0f / g->cell; a.nx = g->nx; a.ny = g->ny;
   a.count = g->workspace; a.cursor = g->workspace + ncells + 1;
   uintptr_t sp = (uintptr_t)(a.cursor + ncells);
@@ -888,7 +892,7 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
   hipLaunchKernelGGL(k_dw_count, dim3(grid_for(a.m)), dim3(256), 0, st_, a);
   hipLaunchKernelGGL(k_dw_scan, dim3(1), dim3(1024), 0, st_, a);
   hipLaunchKernelGGL(k_dw_scatter, dim3(grid_for(a.m)), dim3(256), 0, st_, a);
-  hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.n_pad)), dim3(256), 0, st_, a);
+  hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m)), dim3(256), 0, st_, a);
   return (int)hipGetLastError();
 }
 

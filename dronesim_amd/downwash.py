@@ -41,26 +41,43 @@ def gather_positions(local_pos: torch.Tensor, dist=None) -> torch.Tensor:
 class Downwash:
     """Evaluates formula P8 for the drones of one env/state block against world positions."""
 
-    def __init__(self, ctx, state, type_id: Optional[torch.Tensor] = None, dist=None, cell: float = CUTOFF):
+    def __init__(self, ctx, state, type_id: Optional[torch.Tensor] = None, dist=None, cell: float = CUTOFF,
+                 box_refresh: int = 256):
         self.ctx, self.state, self.type_id, self.dist, self.cell = ctx, state, type_id, dist, float(cell)
         self.force = torch.zeros((3, state.n_pad), dtype=torch.float32, device=ctx.device)
         self._ws = None
+        self._box = None                 # (xmin, ymin, nx, ny): a search-efficiency hint, never a correctness input
+        self._box_age, self._box_refresh = 0, box_refresh
 
-    def compute(self, world_pos: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Returns the SoA [3, n_pad] body-frame force (x = y = 0) to pass as ``ext_force``."""
+    def _grid_box(self, wp: torch.Tensor):
+        """Bounding box of the world in xy -> grid.  Drones that later leave the box are clamped to
+        its border cells by the kernels (pairs within 10 m stay in adjacent cells), so a stale box
+        only costs search efficiency; it is re-measured every `box_refresh` calls (one host sync)."""
+        if self._box is None or self._box_age >= self._box_refresh:
+            lo = wp[:2].min(dim=1).values.cpu()
+            hi = wp[:2].max(dim=1).values.cpu()
+            xmin, ymin = float(lo[0]) - self.cell, float(lo[1]) - self.cell
+            nx = max(1, int(math.floor((float(hi[0]) + self.cell - xmin) / self.cell)) + 1)
+            ny = max(1, int(math.floor((float(hi[1]) + self.cell - ymin) / self.cell)) + 1)
+            while nx * ny > (1 << 22):      # a pathological spread: coarsen the grid, the search stays exact
+                self.cell *= 2.0
+                nx, ny = (nx + 1) // 2, (ny + 1) // 2
+            self._box, self._box_age = (xmin, ymin, nx, ny), 0
+        self._box_age += 1
+        return self._box
+
+    def compute(self, world_pos: Optional[torch.Tensor] = None, local_offset: Optional[int] = None) -> torch.Tensor:
+        """Returns the SoA [3, n_pad] body-frame force (x = y = 0) to pass as ``ext_force``.
+        ``world_pos`` [3, m]: positions of every drone of the world with this block's drones at
+        ``local_offset`` (default: gathered from the ranks' states / the block alone)."""
         st = self.state
         if world_pos is None:
             world_pos = gather_positions(st.fields(0, 3), self.dist)
+            rank = self.dist.get_rank() if (self.dist is not None and self.dist.is_initialized()) else 0
+            local_offset = rank * st.n
         wp = world_pos.to(torch.float32).contiguous()
         m = wp.shape[1]
-        lo = wp[:2].min(dim=1).values
-        hi = wp[:2].max(dim=1).values
-        xmin, ymin = float(lo[0]), float(lo[1])
-        nx = max(1, int(math.floor((float(hi[0]) - xmin) / self.cell)) + 1)
-        ny = max(1, int(math.floor((float(hi[1]) - ymin) / self.cell)) + 1)
-        while nx * ny > (1 << 22):          # a pathological spread: coarsen the grid, the search stays exact
-            self.cell *= 2.0
-            nx, ny = (nx + 1) // 2, (ny + 1) // 2
+        xmin, ymin, nx, ny = self._grid_box(wp)
         need = self.ctx.lib.dsim_downwash_workspace(m, nx, ny)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty((need,), dtype=torch.int32, device=self.ctx.device)
@@ -69,6 +86,7 @@ class Downwash:
         a.xmin, a.ymin, a.cell, a.nx, a.ny = xmin, ymin, self.cell, nx, ny
         a.workspace, a.workspace_len = self._ws.data_ptr(), self._ws.numel()
         a.type_id = self.type_id.data_ptr() if self.type_id is not None else None
+        a.local_offset = int(local_offset or 0)
         nat.check(self.ctx.lib.dsim_downwash(self.ctx.handle, self.ctx.stream_ptr(), st.n, st.view(),
                                              ctypes.byref(a), self.force.data_ptr()))
         self._keep = wp                     # the kernels read it asynchronously on the stream

@@ -204,7 +204,9 @@ int dsim_observe(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const 
  * pos_all: SoA [3][m_pad] positions of ALL drones of the world (on several GPUs: the all-gather of
  * every rank's positions); the library bins them into a uniform xy grid (cell >= 10 m; drones outside
  * the box are clamped to the border cells, which keeps every pair within 10 m in adjacent cells) and
- * each local drone scans its 3x3 cells: O(n * neighbours) instead of the reference's O(n m).
+ * each local drone scans its 3x3 cells: O(n * neighbours) instead of the reference's O(n m).  Receivers
+ * are processed in grid order (a wave's lanes sit in the same or neighbouring cells, so their scans
+ * read the same sorted entries).
  * force_out: SoA [3][n_pad], x and y written as 0 (feed it to dsim_step_args.ext_force).
  * workspace: caller-owned device int32 buffer of at least dsim_downwash_workspace(m, nx, ny) entries. */
 typedef struct dsim_downwash_args {
@@ -215,6 +217,8 @@ typedef struct dsim_downwash_args {
   int32_t* workspace;
   int64_t  workspace_len;
   const uint8_t* type_id;   /* nullable; types of the LOCAL drones */
+  int64_t  local_offset;    /* index inside pos_all of local drone 0 (the rank's shard begin); the local
+                               drones' entries of pos_all must equal their state positions               */
 } dsim_downwash_args;
 int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny);
 int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_downwash_args* args,

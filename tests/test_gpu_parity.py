@@ -421,8 +421,8 @@ def test_downwash_vs_bruteforce_oracle(gpu):
     assert err.max() < 1e-4, (err.max(), err.argmax())
     # world = local + a remote shard (what another rank would contribute through the all-gather)
     remote = f32(np.stack([rng.uniform(-40, 160, 1500), rng.uniform(-30, 70, 1500), rng.uniform(0.5, 25, 1500)], 1))
-    world = np.concatenate([rigid[:, 0:3], remote])
-    f2 = dw.compute(torch.from_numpy(np.ascontiguousarray(world.T)).float().to(ctx.device)).cpu().numpy()
+    world = np.concatenate([remote[:700], rigid[:, 0:3], remote[700:]])      # this "rank's" shard sits in the middle
+    f2 = dw.compute(torch.from_numpy(np.ascontiguousarray(world.T)).float().to(ctx.device), local_offset=700).cpu().numpy()
     ref2 = orc.Oracle(types).downwash(rigid, world, type_id=tid)
     assert (np.abs(f2[2, :n] - ref2) / (np.abs(ref2) + 1e-3)).max() < 1e-4
     assert np.abs(ref2 - ref).max() > 1e-4                    # the remote shard matters
