@@ -151,10 +151,12 @@ __device__ __forceinline__ int waypoint_next(int wp, int n_wp) { return wp < n_w
 // physics sub-steps of one Env.step for a quad (BaseAviary.py:510-545)
 // NOISE: 0 = off, 1 = in-kernel counter-based noise, 2 = replay buffer if given else in-kernel.
 // NROW = rows per sub-step of the replay buffer's force / moment halves (the kernel's NACT).
-template <int NOISE, int NROW = 4>
+// OPTS: honour the drag / ground-effect option bits (general kernels only).  prev = the action of the
+// previous Env.step (last_clipped_action) for the drag of sub-step 0, or null = this step's action.
+template <int NOISE, int NROW = 4, bool OPTS = false>
 __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[4], unsigned long long step_index,
-                                              V3 ext = V3{0.0f, 0.0f, 0.0f}) {
+                                              V3 ext = V3{0.0f, 0.0f, 0.0f}, const float* prev = nullptr) {
   V3 F, tau;
   if (NOISE == 0) quad_wrench(T, cmd, nullptr, F, tau);   // cmd is constant over the sub-steps
   for (int k = 0; k < a.substeps; ++k) {
@@ -172,6 +174,13 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
         for (int j = 0; j < 4; ++j) { nz[j] *= 0.01f; nz[4 + j] *= 0.001f; }   // BaseAviary.py:1518-1521
       }
       quad_wrench(T, cmd, nz, F, tau);
+    }
+    if (OPTS && (a.options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND))) {
+      V3 F2 = F + ext, tau2 = tau;
+      if (a.options & DSIM_OPT_GROUND) ground_effect_quad(T, s, cmd, F2, tau2);              // BaseAviary.py:528-529
+      if (a.options & DSIM_OPT_DRAG) F2 = F2 + drag_quad(T, s, (k == 0 && prev) ? prev : cmd);   // :531-532
+      bullet_step(T, a.dt_phys, s, F2, tau2);
+      continue;
     }
     bullet_step(T, a.dt_phys, s, F + ext, tau);
   }
@@ -308,7 +317,7 @@ __device__ __forceinline__ void step_gen_body(const DevType& T, const StepK& a, 
         indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
       }
     } else {
-      quad_substeps<NOISE ? (FULL ? 2 : 1) : 0, NACT>(T, a, i, s, act, a.step_index + k, ext);
+      quad_substeps<NOISE ? (FULL ? 2 : 1) : 0, NACT, FULL>(T, a, i, s, act, a.step_index + k, ext);
       indi_quad<false, NACT>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
     }
     wp = waypoint_next(wp, a.n_wp);
@@ -348,7 +357,12 @@ __device__ __forceinline__ void physics_gen_body(const DevType& T, const StepK& 
   if (NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA) {
     if constexpr (NACT == 6) hexa_substeps<NOISE>(T, a, i, s, cmd, a.step_index, ext);
   } else {
-    quad_substeps<NOISE ? 2 : 0, NACT>(T, a, i, s, cmd, a.step_index, ext);
+    float prev[4];
+    if (a.echo) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) prev[j] = a.echo[(long long)j * a.n_pad + i];   // last_clipped_action of the previous step
+    }
+    quad_substeps<NOISE ? 2 : 0, NACT, true>(T, a, i, s, cmd, a.step_index, ext, a.echo ? prev : nullptr);
   }
   store_rigid(ad.sb, ad.sfs, ad.sl, s);
   if (a.echo) {
@@ -451,7 +465,7 @@ __global__ __launch_bounds__(256) void k_reset(ResetK a) {
 }
 
 // ---- observation rows (BaseAviary.py:780-790) --------------------------------
-struct ObsK { KView st; const float* last_action; float* out; long long n, n_pad; int width; };
+struct ObsK { KView st; const float* last_action; float* out; long long n, n_pad; int width; int soa; };
 __global__ __launch_bounds__(256) void k_observe(ObsK a) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;
@@ -459,14 +473,16 @@ __global__ __launch_bounds__(256) void k_observe(ObsK a) {
   Rigid s;
   load_rigid(a.st.base + o, a.st.field_stride, 0u, s);
   const Euler e = euler_from_quat<true>(s.q);
-  float* r = a.out + i * a.width;
-  r[0] = s.pos.x; r[1] = s.pos.y; r[2] = s.pos.z;
-  r[3] = s.q.x; r[4] = s.q.y; r[5] = s.q.z; r[6] = s.q.w;
-  r[7] = e.roll; r[8] = e.pitch; r[9] = e.yaw;
-  r[10] = s.vel.x; r[11] = s.vel.y; r[12] = s.vel.z;
-  r[13] = s.w.x; r[14] = s.w.y; r[15] = s.w.z;
+  // row-major [n][width] (the reference's per-drone vectors) or field-major [width][n_pad] (log slabs)
+  float* r = a.soa ? a.out + i : a.out + i * a.width;
+  const long long st = a.soa ? a.n_pad : 1;
+  r[0 * st] = s.pos.x; r[1 * st] = s.pos.y; r[2 * st] = s.pos.z;
+  r[3 * st] = s.q.x; r[4 * st] = s.q.y; r[5 * st] = s.q.z; r[6 * st] = s.q.w;
+  r[7 * st] = e.roll; r[8 * st] = e.pitch; r[9 * st] = e.yaw;
+  r[10 * st] = s.vel.x; r[11 * st] = s.vel.y; r[12 * st] = s.vel.z;
+  r[13 * st] = s.w.x; r[14 * st] = s.w.y; r[15 * st] = s.w.z;
   for (int j = 0; j < a.width - 16; ++j)
-    r[16 + j] = a.last_action ? a.last_action[(long long)j * a.n_pad + i] : a.st.base[o + (20 + j) * a.st.field_stride];
+    r[(16 + j) * st] = a.last_action ? a.last_action[(long long)j * a.n_pad + i] : a.st.base[o + (20 + j) * a.st.field_stride];
 }
 
 // ---- neighbour downwash (formula P8) ------------------------------------------
@@ -769,7 +785,9 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   const hipStream_t st_ = (hipStream_t)stream;
   const dim3 b(256);
   long long first = 0;
-  if (uni && !six && !args->action && !args->noise_replay && !args->ext_force) {
+  const bool phys_opts = (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)) != 0;
+  if (phys_opts && six) return DSIM_E_UNSUPPORTED;      // the add-on formulas are written for the four-rotor links
+  if (uni && !six && !args->action && !args->noise_replay && !args->ext_force && !phys_opts) {
     // fast path over the whole 256-drone tiles.  Streaming (nontemporal) accesses once the fleet's
     // per-step traffic exceeds what the 256 MB Infinity Cache can keep between consecutive steps
     // (tuning knob for A/B runs: DSIM_NT = 0|1).
@@ -791,7 +809,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   if (first < a.n_pad) {   // ragged tail, or everything when the fast path does not apply
     a.first = first;
     const dim3 g(grid_for(a.n_pad - first));
-    const bool lean = !args->action && !args->noise_replay && !a.wp_table && a.n_steps == 1;
+    const bool lean = !args->action && !args->noise_replay && !a.wp_table && a.n_steps == 1 && !phys_opts;
     if (!six) {
       if (lean) DSIM_LAUNCH_GEN(k_step_lean, noise, uni, false, g, a, st_);
       else DSIM_LAUNCH_GEN(k_step_gen, noise, uni, false, g, a, st_);
@@ -821,6 +839,7 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
   int rc = fill_stepk(ctx, n, state, nullptr, args, &a);
   if (rc) return rc;
   a.echo = last_action_out;
+  if ((args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)) && ctx->max_act == 6) return DSIM_E_UNSUPPORTED;
   const bool noise = args->noise_seed != 0 || args->noise_replay != nullptr;
   const dim3 g(grid_for(a.n_pad));
   DSIM_LAUNCH_GEN(k_physics_gen, noise, args->type_id == nullptr, ctx->max_act == 6, g, a, (hipStream_t)stream);
@@ -850,14 +869,24 @@ int dsim_control(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_v
   return (int)hipGetLastError();
 }
 
+static int observe_impl(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
+                        float* obs_out, int32_t obs_width, int soa);
 int dsim_observe(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
                  float* obs_out, int32_t obs_width) {
+  return observe_impl(ctx, stream, n, state, last_action, obs_out, obs_width, 0);
+}
+int dsim_observe_soa(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
+                     float* obs_out, int32_t obs_width) {
+  return observe_impl(ctx, stream, n, state, last_action, obs_out, obs_width, 1);
+}
+static int observe_impl(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
+                        float* obs_out, int32_t obs_width, int soa) {
   if (!ctx || !obs_out || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
   if (obs_width < 16 || obs_width > 16 + DSIM_MAX_ACT || 20 + (obs_width - 16) > state.n_fields) return DSIM_E_ARG;
   ObsK a;
   int rc = make_kview(state, 20 + ctx->max_act, &a.st);
   if (rc) return rc;
-  a.last_action = last_action; a.out = obs_out; a.n = n; a.n_pad = state.n_pad; a.width = obs_width;
+  a.last_action = last_action; a.out = obs_out; a.n = n; a.n_pad = state.n_pad; a.width = obs_width; a.soa = soa;
   hipLaunchKernelGGL(k_observe, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }

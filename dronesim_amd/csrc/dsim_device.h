@@ -206,6 +206,37 @@ __device__ __forceinline__ void quad_wrench(const DevType& T, const float cmd[4]
   }
 }
 
+// P7: BaseAviary._groundEffect, BaseAviary.py:1648-1699 (formula; dead code in the fork): per rotor
+// dF_i = kf rpm_i^2 GND_EFF_COEFF (PROP_RADIUS / (4 h_i))^2 along the link z axis at the rotor link,
+// h_i = rotor height clipped below at GND_EFF_H_CLIP, only while |roll|, |pitch| < pi/2.
+__device__ __forceinline__ void ground_effect_quad(const DevType& T, const Rigid& s, const float cmd[4], V3& F, V3& tau) {
+  const Q4 q = s.q;
+  const float sarg = -2.0f * (q.x * q.z - q.w * q.y);
+  const float rb = q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z;      // cos(roll) > 0  <=>  |roll| < pi/2
+  if (!(fabsf(sarg) < 0.99999f && rb > 0.0f)) return;                   // gimbal branch reports |pitch| = pi/2
+  const M3 R = matrix_from_quat(q);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float rpm = T.scale[i] * cmd[i] + T.cnst[i];
+    const V3 r = v3(T.rpos[i][0], T.rpos[i][1], T.rpos[i][2]);
+    const float h = fmaxf(s.pos.z + R.m[6] * r.x + R.m[7] * r.y + R.m[8] * r.z, T.gnd_hclip);
+    const float ratio = T.prop_radius * DSIM_RCP(4.0f * h);
+    const float dF = rpm * rpm * T.kf * T.gnd_coeff * ratio * ratio;
+    F.z += dF;
+    tau = tau + cross(r, v3(0.0f, 0.0f, dF));
+  }
+}
+
+// P6: BaseAviary._drag, BaseAviary.py:1705-1732 (formula; dead code in the fork), restated literally:
+// drag = R . (-DRAG_COEFF * sum(2 pi rpm / 60) * v_world), handed to Bullet as a LINK_FRAME force at the COM.
+__device__ __forceinline__ V3 drag_quad(const DevType& T, const Rigid& s, const float last_cmd[4]) {
+  float w = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w += (T.scale[i] * last_cmd[i] + T.cnst[i]) * (6.28318530717958647692f / 60.0f);
+  const M3 R = matrix_from_quat(s.q);
+  return mul(R, v3(-T.drag[0] * w * s.vel.x, -T.drag[1] * w * s.vel.y, -T.drag[2] * w * s.vel.z));
+}
+
 // P4: one Bullet btMultiBody floating-base step [BULLET-INTERNAL, parity unpinned];
 // restated step by step in oracle/dsim_oracle.c:orc_bullet_step.
 __device__ __forceinline__ void bullet_step(const DevType& T, float dt, Rigid& s, V3 F_body, V3 tau_body) {

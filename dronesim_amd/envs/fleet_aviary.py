@@ -70,9 +70,13 @@ class CtrlAviary:
     ):
         if gui or record or obstacles:
             raise NotImplementedError("gui/record/obstacles are rendering features outside the hot path")
-        if physics not in (Physics.PYB, Physics.PYB_DW):
-            raise NotImplementedError(f"physics={physics}: Physics.PYB (the only live branch of the reference, "
-                                      "BaseAviary.py:523-524) and Physics.PYB_DW (neighbour downwash) are wired")
+        if physics == Physics.DYN:
+            raise NotImplementedError("Physics.DYN (explicit rpy-Euler model, CF2X/CF2P mixers only, dead code in the "
+                                      "reference: BaseAviary.py:1767-1828) is not on the path")
+        # the add-on terms of the PYB_* modes (dead code in the reference fork, intended formulas)
+        self._phys_options = {Physics.PYB: 0, Physics.PYB_DW: 0, Physics.PYB_GND: nat.OPT_GROUND,
+                              Physics.PYB_DRAG: nat.OPT_DRAG,
+                              Physics.PYB_GND_DRAG_DW: nat.OPT_GROUND | nat.OPT_DRAG}[physics]
         if isinstance(drone_model, (str, DroneType)):
             drone_model = [drone_model]
         models = list(drone_model)
@@ -124,7 +128,7 @@ class CtrlAviary:
         # Physics.PYB_DW: neighbour downwash (BaseAviary.py:534-536, 1736-1763); `dist` = an initialised
         # torch.distributed module when the world's fleet is sharded over several ranks
         self._downwash = None
-        if physics == Physics.PYB_DW:
+        if physics in (Physics.PYB_DW, Physics.PYB_GND_DRAG_DW):
             from ..downwash import Downwash
             self._downwash = Downwash(self.ctx, self.state, self._type_id, dist)
         self.step_counter = 0
@@ -142,7 +146,7 @@ class CtrlAviary:
         a.phys_substeps = self.AGGR_PHY_STEPS
         a.dt_phys = self.TIMESTEP
         a.dt_ctrl = dt_ctrl if dt_ctrl is not None else self.TIMESTEP * self.AGGR_PHY_STEPS
-        a.options = options
+        a.options = options | self._phys_options
         a.noise_seed = self.noise_seed
         a.step_index = self._env_steps
         a.noise_replay = None

@@ -197,6 +197,11 @@ int dsim_control(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_v
 int dsim_observe(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
                  float* obs_out, int32_t obs_width);
 
+/* The same rows as dsim_observe, written field-major: SoA [obs_width][n_pad] (coalesced), the slab a
+ * device-side Logger appends per step (dronesim/utils/Logger.py:117-139 stores exactly this vector). */
+int dsim_observe_soa(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
+                     float* obs_out, int32_t obs_width);
+
 /* Neighbour downwash, formula P8 (BaseAviary._downwash, BaseAviary.py:1736-1763; dead code in the
  * fork, intended semantics): for every local drone i and every drone j of the WORLD above it
  * (dz > 0) within dxy < 10 m,  Fz -= DW1 (PROP_RADIUS/(4 dz))^2 exp(-0.5 (dxy / (DW2 dz + DW3))^2)

@@ -747,8 +747,10 @@ int orc_physics_batch(const dsim_type_params* types, const uint8_t* type_id, int
     const dsim_type_params* P = &types[type_id ? type_id[i] : 0];
     const double* m = mem + i * 13;
     double clipped[DSIM_MAX_ACT] = {0}, last[DSIM_MAX_ACT];
-    memcpy(last, last_action_out ? last_action_out + i * 6 : m + 7, sizeof(last));
     orc_preprocess_action(P, action ? action + i * 6 : m + 7, clipped);
+    /* drag uses the PREVIOUS step's action on sub-step 0 (BaseAviary.py:532, 545); without an env-side
+       last_clipped_action buffer (fused stepping) the current action stands in */
+    memcpy(last, last_action_out ? last_action_out + i * 6 : clipped, sizeof(last));
     for (int s = 0; s < substeps; ++s) {
       double nz[12];
       const double* np_ = NULL;

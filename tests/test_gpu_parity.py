@@ -429,6 +429,41 @@ def test_downwash_vs_bruteforce_oracle(gpu):
     ctx.close()
 
 
+@pytest.mark.parametrize("opts", [1, 2, 3])          # DSIM_OPT_DRAG, DSIM_OPT_GROUND, both
+def test_drag_and_ground_effect_vs_oracle(gpu, opts):
+    """Formulas P6/P7 (dead code in the reference fork) as switchable physics terms: Env.step with an
+    explicit action + last_clipped_action (drag uses the previous step's rpm), then a fused step."""
+    nat, fleet = gpu
+    n = 1500
+    t, ctx, st, tg, rigid, mem, tgt = _make(gpu, "robobee", n, seed=61, tilt=0.6)
+    rigid[:, 2] = f32(np.random.default_rng(62).uniform(0.02, 0.6, n))      # near the ground: P7 matters
+    rigid[:40, 3:7] = f32(np.tile(orc.quat_from_euler([2.0, 0.1, 0.3]), (40, 1)))   # |roll| > pi/2: no ground effect
+    st.load_aos(rigid, mem)
+    rng = np.random.default_rng(63)
+    act = f32(rng.uniform(0.2, 0.9, (n, 4)))
+    prev = f32(rng.uniform(0.2, 0.9, (n, 4)))
+    act_dev = torch.zeros((4, st.n_pad), device=ctx.device); act_dev[:, :n] = torch.from_numpy(act.T).float()
+    echo = torch.zeros((4, st.n_pad), device=ctx.device); echo[:, :n] = torch.from_numpy(prev.T).float()
+    a = _args(nat, 3, DT, DT, options=opts, action=act_dev)
+    nat.check(ctx.lib.dsim_physics(ctx.handle, _stream(ctx), n, st.view(), echo.data_ptr(), ctypes.byref(a)))
+    O = orc.Oracle([t])
+    a6 = np.zeros((n, 6)); a6[:, :4] = act
+    last = np.zeros((n, 6)); last[:, :4] = prev
+    before = rigid.copy()
+    O.physics(rigid, mem, 3, DT, action=a6, options=opts, last_action=last)
+    assert rel_err(st.rigid_aos(), rigid, RIGID_SCALE).max() < REL_TOL
+    plain = before.copy()
+    O.physics(plain, mem, 3, DT, action=a6)
+    assert np.abs(plain - rigid).max() > 1e-5                         # the option really changes the step
+    # fused step with the same options (general kernel; drag falls back to the current action's rpm)
+    a2 = _args(nat, 2, DT, float(np.float32(2 / 240)), options=opts)
+    nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a2)))
+    assert O.step(rigid, mem, tgt, 2, DT, float(np.float32(2 / 240)), options=opts) == 0
+    assert rel_err(st.rigid_aos(), rigid, RIGID_SCALE).max() < 2 * REL_TOL
+    assert rel_err(st.mem_aos(), mem, MEM_SCALE).max() < 2 * REL_TOL
+    ctx.close()
+
+
 def test_step_with_downwash_env(gpu):
     """Physics.PYB_DW env: fused step with the downwash force vs the oracle fed the brute-force force."""
     from dronesim_amd.envs import CtrlAviary, Physics
@@ -625,6 +660,33 @@ def test_env_and_controller_surfaces(gpu):
     ctrl1 = INDIControl("robobee")       # one controller per drone, as in the reference (fly_INDI.py:210)
     c1, pe1, ye1 = ctrl1.computeControlFromState(dtc, states[0], target_pos=np.array([0, 0, 0.5]))
     assert c1.shape == (4,) and pe1.shape == (3,) and isinstance(ye1, float)
+    env.close()
+
+
+def test_device_logger_matches_reference_layout(gpu, tmp_path):
+    """Logger: states[N,20,T] / controls[N,12,T] / timestamps[N,T] and the np.savez keys of the
+    reference (Logger.py:53-86, 134-139, 152-157); rows equal the per-step observation vectors."""
+    from dronesim_amd.envs import CtrlAviary
+    from dronesim_amd.utils import Logger
+    n = 5
+    xyz = np.array([[i, 0.0, 1.0 + 0.1 * i] for i in range(n)])
+    env = CtrlAviary(["robobee"] * n, n, initial_xyzs=xyz, aggregate_phy_steps=5, noise_seed=0)
+    log = Logger(logging_freq_hz=48, env=env, duration_sec=1)
+    rows = []
+    action = {str(i): np.array([0.5, 0.5, 0.5, 0.5]) for i in range(n)}
+    for k in range(10):
+        obs, *_ = env.step(action)
+        ctrl = np.zeros((12, n)); ctrl[0:3] = xyz.T; ctrl[5] = 0.4
+        log.log(timestamp=k * 5 / 240, control=ctrl)
+        rows.append(np.stack([obs[str(i)]["state"] for i in range(n)]))
+    ts, st, ct = log.arrays()
+    assert ts.shape == (n, 10) and st.shape == (n, 20, 10) and ct.shape == (n, 12, 10)
+    np.testing.assert_allclose(st, np.stack(rows, 2), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(ts[3], np.arange(10) * 5 / 240)
+    np.testing.assert_allclose(ct[2, 0:3, 4], xyz[2], atol=1e-6)
+    path = log.save(str(tmp_path) + "/", "flight", drones=slice(1, 3))
+    z = np.load(path)
+    assert set(z.files) == {"timestamps", "states", "controls"} and z["states"].shape == (2, 20, 10)
     env.close()
 
 
