@@ -414,6 +414,48 @@ __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_control_gen(StepK a) {
   DSIM_FOR_MY_TYPE(UNIFORM, a, i, (control_gen_body<NACT>(T, a, i, ad)));
 }
 
+// ---- Env.step of the alternate action adaptors (VelocityAviary / RPYTAviary) --------------
+// control (inside _preprocessAction) on the CURRENT state, then the physics with the new command
+template <int MODE, bool NOISE>
+__device__ __forceinline__ void adaptor_body(const DevType& T, const StepK& a, long long i, const Addr& ad) {
+  Rigid s;
+  CtrlMem<4> m;
+  load_rigid(ad.sb, ad.sfs, ad.sl, s);
+  load_mem<4>(ad.sb, ad.sfs, ad.sl, m);
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = a.action[(long long)j * a.n_pad + i];
+  if (MODE == DSIM_ADAPT_VELOCITY) {                       // VelocityAviary.py:241-262
+    const float nrm = DSIM_SQRT(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float sc = nrm != 0.0f ? T.speed_limit * fabsf(v[3]) * DSIM_RCP(nrm) : 0.0f;
+    Target tg;
+    tg.pos = s.pos;                                        // "same as the current position"
+    tg.vel = v3(sc * v[0], sc * v[1], sc * v[2]);
+    tg.acc = v3(0, 0, 0);
+    tg.yaw = euler_from_quat<true>(s.q).yaw;               // "keep current yaw" (state[9])
+    V3 pos_e;
+    float yaw_e;
+    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  } else {                                                 // RPYTAviary.py:184-191
+    indi_rate<4>(T, DSIM_RCP(a.dt_ctrl), s, v3(v[0], v[1], v[2]), v[3], m);
+  }
+  quad_substeps<NOISE ? 1 : 0, 4>(T, a, i, s, m.cmd, a.step_index);
+  store_rigid(ad.sb, ad.sfs, ad.sl, s);
+  store_mem<4>(ad.sb, ad.sfs, ad.sl, m);
+  if (a.echo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a.echo[(long long)j * a.n_pad + i] = m.cmd[j];
+  }
+}
+template <int MODE, bool NOISE, bool UNIFORM>
+__global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_adaptor(StepK a) {
+  const long long i0 = (long long)blockIdx.x * 256;
+  const long long i = i0 + threadIdx.x;
+  if (i >= a.n_pad) return;
+  const Addr ad = make_addr(a, i0);
+  DSIM_FOR_MY_TYPE(UNIFORM, a, i, (adaptor_body<MODE, NOISE>(T, a, i, ad)));
+}
+
 // ---- deferred WLS fallbacks (hexa) -----------------------------------------------
 struct FbK { KView st; const DevType* types; const uint8_t* type_id; FbList fb; };
 __global__ __launch_bounds__(64) void k_wls_fallback(FbK a) {
@@ -618,6 +660,7 @@ static void to_dev(const dsim_type_params& p, DevType* d) {
   d->maxv = (float)p.max_coord_vel;
   d->gnd_coeff = (float)p.gnd_eff_coeff; d->prop_radius = (float)p.prop_radius; d->gnd_hclip = (float)p.gnd_eff_h_clip;
   if (p.kind == DSIM_KIND_HEXA6DOF) { d->reset_thrust = 0.3f; d->reset_cmd = 0.5f; }   // INDIControl_6DOF.py:232-234
+  d->speed_limit = (float)(p.max_speed_kmh * (1000.0 / 3600.0));
 }
 
 extern "C" {
@@ -843,6 +886,28 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
   const bool noise = args->noise_seed != 0 || args->noise_replay != nullptr;
   const dim3 g(grid_for(a.n_pad));
   DSIM_LAUNCH_GEN(k_physics_gen, noise, args->type_id == nullptr, ctx->max_act == 6, g, a, (hipStream_t)stream);
+  return (int)hipGetLastError();
+}
+
+int dsim_step_adaptor(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* action,
+                      int32_t mode, float* last_action_out, const dsim_step_args* args) {
+  StepK a;
+  if (!action || (mode != DSIM_ADAPT_VELOCITY && mode != DSIM_ADAPT_RPYT)) return DSIM_E_ARG;
+  if (ctx && ctx->max_act == 6) return DSIM_E_UNSUPPORTED;
+  if (args && (args->noise_replay || args->wp_table)) return DSIM_E_UNSUPPORTED;
+  int rc = fill_stepk(ctx, n, state, nullptr, args, &a);
+  if (rc) return rc;
+  a.action = action; a.echo = last_action_out;
+  const bool noise = args->noise_seed != 0, uni = args->type_id == nullptr;
+  const dim3 g(grid_for(a.n_pad)), b(256);
+  const hipStream_t st_ = (hipStream_t)stream;
+#define DSIM_ADAPT_CASE(M_)                                                                         \
+  do { if (noise) { if (uni) hipLaunchKernelGGL((k_adaptor<M_, true, true>), g, b, 0, st_, a);      \
+                    else hipLaunchKernelGGL((k_adaptor<M_, true, false>), g, b, 0, st_, a); }       \
+       else { if (uni) hipLaunchKernelGGL((k_adaptor<M_, false, true>), g, b, 0, st_, a);           \
+              else hipLaunchKernelGGL((k_adaptor<M_, false, false>), g, b, 0, st_, a); } } while (0)
+  if (mode == DSIM_ADAPT_VELOCITY) DSIM_ADAPT_CASE(DSIM_ADAPT_VELOCITY); else DSIM_ADAPT_CASE(DSIM_ADAPT_RPYT);
+#undef DSIM_ADAPT_CASE
   return (int)hipGetLastError();
 }
 

@@ -31,6 +31,7 @@ struct DevType {
   float g, clin, cang, maxv;
   float drag[3], gnd_coeff, prop_radius, gnd_hclip, dw[3];
   float reset_thrust, reset_cmd;
+  float speed_limit;                          // MAX_SPEED_KMH * 1000/3600 (VelocityAviary.py:92-94)
 };
 
 struct V3 { float x, y, z; };
@@ -281,6 +282,28 @@ __device__ __forceinline__ void bullet_step(const DevType& T, float dt, Rigid& s
   s.q = Q4{n.x * inv, n.y * inv, n.z * inv, n.w * inv};
 }
 
+// C4: INDIControl._INDIRateControl, INDIControl.py:413-490 (also the whole of RPYTAviary's action
+// adaptor, RPYTAviary.py:181-193): body rates, finite-difference angular acceleration, the virtual
+// control v, du = pinv(G1/0.05) v, cmd += du, clip.
+template <int NACT = 4>
+__device__ __forceinline__ void indi_rate(const DevType& T, float inv_dt, const Rigid& s, V3 rate_sp, float thrust,
+                                          CtrlMem<NACT>& m) {
+  const M3 R = matrix_from_quat(s.q);                                          // :428
+  const V3 wb = mulT(R, s.w);                                                  // :430
+  float v[4];
+  v[0] = (rate_sp.x - wb.x) * T.krate[0] - (wb.x - m.last_rates.x) * inv_dt;   // :433-453
+  v[1] = (rate_sp.y - wb.y) * T.krate[1] - (wb.y - m.last_rates.y) * inv_dt;
+  v[2] = (rate_sp.z - wb.z) * T.krate[2] - (wb.z - m.last_rates.z) * inv_dt;
+  v[3] = thrust - m.last_thrust;                                               // :454
+  m.last_rates = wb;                                                           // :442
+  m.last_thrust = thrust;                                                      // :455
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                                                // :459, 486-487
+    const float du = T.alloc[j][0] * v[0] + T.alloc[j][1] * v[1] + T.alloc[j][2] * v[2] + T.alloc[j][3] * v[3];
+    m.cmd[j] = clampf(m.cmd[j] + du, T.pmin[j], T.pmax[j]);
+  }
+}
+
 // C2 + C3 + C4: INDIControl.computeControl for a quad, INDIControl.py:154-227.
 // Returns pos_e and (WANT_YAW) yaw_e, the reference's 2nd and 3rd return values.
 //
@@ -335,21 +358,7 @@ __device__ __forceinline__ void indi_quad(const DevType& T, float dt, const Rigi
   float ez = q.w * tq.z - q.x * tq.y + q.y * tq.x - q.z * tq.w;
   if (ew < 0.0f) { ex = -ex; ey = -ey; ez = -ez; }                           // quat_wrap_shortest, math.py:46-51
   const V3 rate_sp = v3(T.katt[0] * ex, T.katt[1] * ey, T.katt[2] * ez);
-  // ---- _INDIRateControl, :428-487
-  const M3 R = matrix_from_quat(q);
-  const V3 wb = mulT(R, s.w);
-  float v[4];
-  v[0] = (rate_sp.x - wb.x) * T.krate[0] - (wb.x - m.last_rates.x) * inv_dt;
-  v[1] = (rate_sp.y - wb.y) * T.krate[1] - (wb.y - m.last_rates.y) * inv_dt;
-  v[2] = (rate_sp.z - wb.z) * T.krate[2] - (wb.z - m.last_rates.z) * inv_dt;
-  v[3] = thrust - m.last_thrust;
-  m.last_rates = wb;
-  m.last_thrust = thrust;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {                                              // pinv(G1/0.05) . v ; += ; clip
-    const float du = T.alloc[j][0] * v[0] + T.alloc[j][1] * v[1] + T.alloc[j][2] * v[2] + T.alloc[j][3] * v[3];
-    m.cmd[j] = clampf(m.cmd[j] + du, T.pmin[j], T.pmax[j]);
-  }
+  indi_rate<NACT>(T, inv_dt, s, rate_sp, thrust, m);
 }
 
 // ===========================================================================

@@ -278,3 +278,41 @@ class CtrlAviary:
     @staticmethod
     def _computeInfo():
         return {"answer": 42}                       # CtrlAviary.py:299-310
+
+
+class _AdaptorAviary(CtrlAviary):
+    """Shared body of the two alternate action adaptors: the action is turned into a PWM command by
+    (part of) the INDI law INSIDE step() — on the current state — and the physics follows."""
+
+    _MODE = -1
+
+    def step(self, action):
+        self._load_action(action)
+        args = self.step_args(self.AGGR_PHY_STEPS * self.TIMESTEP)
+        nat.check(self.ctx.lib.dsim_step_adaptor(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
+                                                 self.state.view(), self._action_buf.data_ptr(), self._MODE,
+                                                 self._last_action.data_ptr(), ctypes.byref(args)))
+        self._use_last_action = True
+        self.step_counter += self.AGGR_PHY_STEPS
+        self._env_steps += 1
+        return self._computeObs(), self._computeReward(), self._computeDone(), self._computeInfo()
+
+
+class VelocityAviary(_AdaptorAviary):
+    """dronesim/envs/VelocityAviary.py: action = (vx, vy, vz, speed fraction) per drone; the env runs
+    the full INDI law with target_pos = current position, target yaw = current yaw and
+    target_vel = SPEED_LIMIT |a3| unit(a0..2) (VelocityAviary.py:241-262), SPEED_LIMIT =
+    MAX_SPEED_KMH / 3.6 (:92-94)."""
+
+    _MODE = nat.ADAPT_VELOCITY
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.SPEED_LIMIT = [t.max_speed_kmh * (1000 / 3600) for t in (self.drones or self.types)]
+
+
+class RPYTAviary(_AdaptorAviary):
+    """dronesim/envs/RPYTAviary.py: action = (p, q, r body-rate set-points, thrust) per drone, fed to
+    INDIControl._INDIRateControl only (RPYTAviary.py:181-193)."""
+
+    _MODE = nat.ADAPT_RPYT

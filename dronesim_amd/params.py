@@ -70,6 +70,7 @@ class TypeParamsC(ctypes.Structure):
         ("prop_radius", ctypes.c_double),
         ("gnd_eff_h_clip", ctypes.c_double),
         ("dw_coeff", ctypes.c_double * 3),
+        ("max_speed_kmh", ctypes.c_double),
     ]
 
 
@@ -107,6 +108,7 @@ class DroneType:
     prop_radius: float = 0.0
     gnd_eff_h_clip: float = 0.0
     dw_coeff: Sequence[float] = (0.0, 0.0, 0.0)
+    max_speed_kmh: float = 30.0      # URDF properties max_speed_kmh (all shipped types: 30)
     reset_thrust: float = 0.0        # INDIControl.reset (INDIControl.py:127); 6DOF 0.3 (:232)
     reset_cmd: float = 0.0           # INDIControl.py:129; 6DOF 0.5 (:234)
     alloc: np.ndarray = field(default=None)  # type: ignore[assignment]
@@ -189,6 +191,7 @@ class DroneType:
         c.max_coord_vel = self.max_coord_vel
         c.gnd_eff_coeff, c.prop_radius = self.gnd_eff_coeff, self.prop_radius
         c.gnd_eff_h_clip = self.gnd_eff_h_clip
+        c.max_speed_kmh = self.max_speed_kmh
         return c
 
     @property
@@ -438,5 +441,6 @@ def parse_urdf(path: str) -> DroneType:
         drag_coeff=(float(prop["drag_coeff_xy"]), float(prop["drag_coeff_xy"]), float(prop["drag_coeff_z"])),
         gnd_eff_coeff=float(prop["gnd_eff_coeff"]), prop_radius=float(prop["prop_radius"]),
         dw_coeff=(float(prop["dw_coeff_1"]), float(prop["dw_coeff_2"]), float(prop["dw_coeff_3"])),
+        max_speed_kmh=float(prop["max_speed_kmh"]),
         reset_thrust=rt, reset_cmd=rc,
     )

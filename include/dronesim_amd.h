@@ -107,6 +107,7 @@ typedef struct dsim_type_params {
   double  drag_coeff[3];              /* BaseAviary._drag coefficients (formula P6)         */
   double  gnd_eff_coeff, prop_radius, gnd_eff_h_clip;   /* formula P7                       */
   double  dw_coeff[3];                /* formula P8                                         */
+  double  max_speed_kmh;              /* URDF max_speed_kmh (VelocityAviary speed limit)    */
 } dsim_type_params;
 
 /* ---- step options ---------------------------------------------------------- */
@@ -183,6 +184,20 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
  * the reference.                                                              */
 int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state,
                  float* last_action_out, const dsim_step_args* args);
+
+/* Env.step() of the reference's two alternate action adaptors, which run (part of) the INDI law
+ * INSIDE _preprocessAction and then the physics:  control on the current state first, then
+ * phys_substeps with the new command.  action: SoA [4][n_pad].
+ *   DSIM_ADAPT_VELOCITY  VelocityAviary._preprocessAction (VelocityAviary.py:221-264): action =
+ *       (vx, vy, vz, speed fraction); full INDI with target_pos = current position, target yaw =
+ *       current yaw, target_vel = SPEED_LIMIT |a3| unit(a0..2)
+ *   DSIM_ADAPT_RPYT      RPYTAviary._preprocessAction (RPYTAviary.py:181-193): action = (p, q, r
+ *       body-rate set-points, thrust) fed to _INDIRateControl only
+ * dt_ctrl of args is the control_timestep (AGGR_PHY_STEPS * TIMESTEP).  Quad types only.
+ * last_action_out (nullable, SoA [4][n_pad]) receives the applied command (last_clipped_action). */
+enum { DSIM_ADAPT_VELOCITY = 0, DSIM_ADAPT_RPYT = 1 };
+int dsim_step_adaptor(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* action,
+                      int32_t mode, float* last_action_out, const dsim_step_args* args);
 
 /* computeControl() only (INDIControl.py:154-227 / INDIControl_6DOF.py:259-336):
  * reads the rigid fields, updates the controller-memory fields and cmd.

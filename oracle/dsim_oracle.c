@@ -808,6 +808,42 @@ void orc_downwash(const dsim_type_params* types, const uint8_t* type_id, int64_t
   }
 }
 
+/* Env.step of the alternate action adaptors: _preprocessAction runs (part of) the INDI law on the
+ * CURRENT state, then BaseAviary.step's physics loop runs with that command.
+ *   mode 0: VelocityAviary._preprocessAction, VelocityAviary.py:221-264
+ *   mode 1: RPYTAviary._preprocessAction, RPYTAviary.py:181-193
+ * action [n][4]. */
+int orc_adaptor_step_batch(const dsim_type_params* types, const uint8_t* type_id, int64_t n, int mode,
+                           int substeps, double dt_phys, double dt_ctrl, double* rigid, double* mem,
+                           const double* action, int nthreads) {
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    const dsim_type_params* P = &types[type_id ? type_id[i] : 0];
+    double* r = rigid + i * 13;
+    const double* v = action + i * 4;
+    orc_ctrl_mem c;
+    mem_load(mem + i * 13, &c);
+    if (mode == 0) {
+      double rpy[3], tvel[3] = {0, 0, 0}, pe[3], ye;
+      orc_euler_from_quat(r + 3, rpy);                                   /* state[9] */
+      const double nrm = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);  /* :243-246 */
+      const double speed_limit = P->max_speed_kmh * (1000.0 / 3600.0);   /* :92-94 */
+      if (nrm != 0) for (int k = 0; k < 3; ++k) tvel[k] = speed_limit * fabs(v[3]) * (v[k] / nrm);   /* :256-258 */
+      const double tacc[3] = {0, 0, 0}, trpy[3] = {0, 0, rpy[2]};        /* :255 */
+      orc_indi_compute_control(P, dt_ctrl, r, r + 3, r + 7, r + 10, r /* target_pos = cur pos */, tvel, tacc,
+                               trpy, &c, pe, &ye);
+    } else {
+      orc_indi_rate(P, dt_ctrl, v[3], r + 3, r + 10, v, &c);             /* RPYTAviary.py:185-190 */
+    }
+    mem_store(&c, mem + i * 13);
+    for (int s = 0; s < substeps; ++s) orc_physics_substep(P, dt_phys, r, c.cmd, c.cmd, NULL, 0, NULL);
+  }
+  return 0;
+}
+
 /* P5: _getDroneStateVector, BaseAviary.py:780-790: [pos quat rpy vel ang_v last_action] */
 void orc_state_vector(const dsim_type_params* P, const double rigid[13], const double* last_action, double* out) {
   memcpy(out, rigid, sizeof(double) * 7);

@@ -158,6 +158,8 @@ class Oracle:
                                            ctypes.c_double, _D, _D, _D, ctypes.c_int, _D,
                                            ctypes.c_uint32, _D, _D, ctypes.c_int]
         self._L.orc_downwash.argtypes = [TP, _U8, ctypes.c_int64, _D, _D, ctypes.c_int64, _D, ctypes.c_int]
+        self._L.orc_adaptor_step_batch.argtypes = [TP, _U8, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_double, ctypes.c_double, _D, _D, _D, ctypes.c_int]
 
     def reset_mem(self, n: int, type_id: Optional[np.ndarray] = None) -> np.ndarray:
         mem = np.zeros((n, 13))
@@ -186,6 +188,11 @@ class Oracle:
         ef = None if ext_force is None else _c(ext_force)
         return self._L.orc_physics_batch(self._c_types, _p(type_id, _U8), n, substeps, dt, _p(rigid),
                                          _p(act), _p(mem), _p(nz), options, _p(last_action), _p(ef), nthreads)
+
+    def adaptor_step(self, mode, rigid, mem, action, substeps, dt_phys, dt_ctrl, type_id=None, nthreads=1):
+        """Env.step of VelocityAviary (mode 0) / RPYTAviary (mode 1); action [n,4]."""
+        return self._L.orc_adaptor_step_batch(self._c_types, _p(type_id, _U8), rigid.shape[0], mode, substeps,
+                                              dt_phys, dt_ctrl, _p(rigid), _p(mem), _p(_c(action)), nthreads)
 
     def downwash(self, rigid, pos_all, type_id=None, nthreads=1):
         """Brute-force formula P8: body-z force on each drone of `rigid` from every drone in pos_all [m,3]."""

@@ -663,6 +663,35 @@ def test_env_and_controller_surfaces(gpu):
     env.close()
 
 
+@pytest.mark.parametrize("mode", ["velocity", "rpyt"])
+def test_action_adaptor_envs_vs_oracle(gpu, mode):
+    """VelocityAviary / RPYTAviary: control inside step() on the current state, then the physics."""
+    from dronesim_amd.envs import RPYTAviary, VelocityAviary
+    n = 700
+    rng = np.random.default_rng(71)
+    xyz = np.stack([rng.uniform(-5, 5, n), rng.uniform(-5, 5, n), rng.uniform(1, 5, n)], 1)
+    rpy = np.stack([rng.uniform(-0.2, 0.2, n), rng.uniform(-0.2, 0.2, n), rng.uniform(-3, 3, n)], 1)
+    cls = VelocityAviary if mode == "velocity" else RPYTAviary
+    env = cls(["robobee"], n, initial_xyzs=xyz, initial_rpys=rpy, aggregate_phy_steps=5, noise_seed=0, dict_io=False)
+    t = params.builtin_type("robobee")
+    O = orc.Oracle([t])
+    rigid, mem = env.state.rigid_aos(), env.state.mem_aos()
+    dtc = float(np.float32(5 * (1.0 / 240)))
+    for k in range(6):
+        if mode == "velocity":
+            act = np.concatenate([rng.uniform(-1, 1, (n, 3)), rng.uniform(0, 0.3, (n, 1))], 1)
+            act[0, 0:3] = 0.0                                  # zero vector: unit vector := 0 (VelocityAviary.py:243-246)
+        else:
+            act = np.concatenate([rng.uniform(-0.5, 0.5, (n, 3)), rng.uniform(0.3, 0.6, (n, 1))], 1)
+        act = f32(act)
+        obs, reward, done, info = env.step(torch.from_numpy(act.astype(np.float32)))
+        assert O.adaptor_step(0 if mode == "velocity" else 1, rigid, mem, act, 5, DT, dtc) == 0
+    assert rel_err(env.state.rigid_aos(), rigid, RIGID_SCALE).max() < 5 * REL_TOL     # 6 chained steps
+    assert rel_err(env.state.mem_aos(), mem, MEM_SCALE).max() < 5 * REL_TOL
+    np.testing.assert_allclose(obs[:, 16:20].cpu().numpy(), mem[:, 7:11], atol=5e-4)  # echoed command
+    env.close()
+
+
 def test_device_logger_matches_reference_layout(gpu, tmp_path):
     """Logger: states[N,20,T] / controls[N,12,T] / timestamps[N,T] and the np.savez keys of the
     reference (Logger.py:53-86, 134-139, 152-157); rows equal the per-step observation vectors."""
