@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libdronesim_amd.so")
 # every symbol include/dronesim_amd.h declares
 EXPORTS = (
     "dsim_abi_version", "dsim_strerror", "dsim_create", "dsim_destroy", "dsim_reset", "dsim_step",
-    "dsim_physics", "dsim_control", "dsim_step_adaptor", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash", "dsim_downwash_workspace",
+    "dsim_physics", "dsim_control", "dsim_step_adaptor", "dsim_traj_sample", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash", "dsim_downwash_workspace",
 )
 
 ABI_VERSION = 2
@@ -106,6 +106,7 @@ def load() -> ctypes.CDLL:
     lib.dsim_physics.argtypes = [vp, vp, i64, View, vp, ctypes.POINTER(StepArgs)]  # (.., last_action_out, args)
     lib.dsim_control.argtypes = [vp, vp, i64, View, View, ctypes.POINTER(StepArgs), vp, vp]
     lib.dsim_step_adaptor.argtypes = [vp, vp, i64, View, vp, i32, vp, ctypes.POINTER(StepArgs)]
+    lib.dsim_traj_sample.argtypes = [vp, vp, i64, vp, vp, i32, vp, ctypes.c_double, vp, vp, View]
     lib.dsim_observe.argtypes = [vp, vp, i64, View, vp, vp, i32]
     lib.dsim_observe_soa.argtypes = [vp, vp, i64, View, vp, vp, i32]
     lib.dsim_query.argtypes = [vp, vp, i32, ctypes.POINTER(ctypes.c_int64)]

@@ -527,6 +527,69 @@ __global__ __launch_bounds__(256) void k_observe(ObsK a) {
     r[(16 + j) * st] = a.last_action ? a.last_action[(long long)j * a.n_pad + i] : a.st.base[o + (20 + j) * a.st.field_stride];
 }
 
+// ---- trajectory sampler (trajGen.get_des_state + get_yaw) ------------------------------
+struct TrajK {
+  KView tg;
+  const double* coeffs;   // [n_seg*10][3]
+  const double* ts;       // [n_seg+1]
+  double* t;              // [n_pad]
+  double* yaw_state;      // SoA [3][n_pad]
+  const float* offset;    // SoA [3][n_pad] or null
+  long long n, n_pad;
+  int n_seg;
+  double dt_advance;
+};
+__global__ __launch_bounds__(256) void k_traj_sample(TrajK a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  double t = a.t[i];
+  const double t_end = a.ts[a.n_seg];
+  if (t > t_end) t = t_end - 0.001;                                   // trajGen.py:110-111
+  int seg = 0;
+  for (int k = 0; k <= a.n_seg; ++k) if (t >= a.ts[k]) seg = k;       // :113
+  if (seg >= a.n_seg) seg = a.n_seg - 1;
+  t -= a.ts[seg];                                                      // :115
+  double pw[10];
+  pw[0] = 1.0;
+#pragma unroll
+  for (int j = 1; j < 10; ++j) pw[j] = pw[j - 1] * t;
+  double out[9];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    double p = 0.0, v = 0.0, ac = 0.0;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {                                     // coeff @ polyder(t, k), :118-120
+      const double c = a.coeffs[(seg * 10 + j) * 3 + d];
+      p += c * pw[j];
+      if (j >= 1) v += c * (double)j * pw[j - 1];
+      if (j >= 2) ac += c * (double)(j * (j - 1)) * pw[j - 2];
+    }
+    out[d] = p; out[3 + d] = v; out[6 + d] = ac;
+  }
+  // get_yaw(vel[:2]), :128-143 — per-drone memory (yaw, heading)
+  double yaw = a.yaw_state[i];
+  const double hx = a.yaw_state[a.n_pad + i], hy = a.yaw_state[2 * a.n_pad + i];
+  const double nv = sqrt(out[3] * out[3] + out[4] * out[4]);
+  const double cx = out[3] / nv, cy = out[4] / nv;
+  const double cosine = fmax(-1.0, fmin(hx * cx + hy * cy, 1.0));
+  const double dyaw = acos(cosine);
+  const double cr = hx * cy - hy * cx;
+  yaw += (cr > 0.0 ? 1.0 : (cr < 0.0 ? -1.0 : 0.0)) * dyaw;
+  if (yaw > 3.14159265358979323846) yaw -= 2.0 * 3.14159265358979323846;
+  if (yaw < -3.14159265358979323846) yaw += 2.0 * 3.14159265358979323846;
+  a.yaw_state[i] = yaw; a.yaw_state[a.n_pad + i] = cx; a.yaw_state[2 * a.n_pad + i] = cy;
+  a.t[i] += a.dt_advance;
+  float* q = a.tg.base + kv_off(a.tg, i);
+  const long long fs = a.tg.field_stride;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    q[d * fs] = (float)out[d] + (a.offset ? a.offset[d * a.n_pad + i] : 0.0f);
+    q[(3 + d) * fs] = (float)out[3 + d];
+    q[(6 + d) * fs] = (float)out[6 + d];
+  }
+  q[9 * fs] = (float)yaw;
+}
+
 // ---- neighbour downwash (formula P8) ------------------------------------------
 // world positions -> uniform xy grid (counting sort: count, scan, scatter) -> per-drone 3x3 scan
 struct DwK {
@@ -953,6 +1016,19 @@ static int observe_impl(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state,
   if (rc) return rc;
   a.last_action = last_action; a.out = obs_out; a.n = n; a.n_pad = state.n_pad; a.width = obs_width; a.soa = soa;
   hipLaunchKernelGGL(k_observe, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int dsim_traj_sample(dsim_ctx* ctx, void* stream, int64_t n, const double* coeffs, const double* ts,
+                     int32_t n_seg, double* t, double dt_advance, double* yaw_state, const float* offset,
+                     dsim_view targets_out) {
+  if (!ctx || !coeffs || !ts || !t || !yaw_state || n <= 0 || n > targets_out.n_pad || n_seg < 1) return DSIM_E_ARG;
+  TrajK a;
+  int rc = make_kview(targets_out, DSIM_NT, &a.tg);
+  if (rc) return rc;
+  a.coeffs = coeffs; a.ts = ts; a.t = t; a.yaw_state = yaw_state; a.offset = offset;
+  a.n = n; a.n_pad = targets_out.n_pad; a.n_seg = n_seg; a.dt_advance = dt_advance;
+  hipLaunchKernelGGL(k_traj_sample, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

@@ -208,3 +208,36 @@ class WaypointTargets:
         args.wp_counter = self.counters.data_ptr()
         args.wp_offset = self.offsets.data_ptr() if self.offsets is not None else None
         args.n_wp = self.n_wp
+
+
+class TrajectoryTargets(Targets):
+    """Targets sampled ON DEVICE from a min-snap trajectory (the reference pre-samples
+    ``trajGenerator.get_des_state`` on the host into waypoint tables,
+    examples/fly_INDI_TrajectoryTrack.py:133-160).  ``coeffs`` [n_seg*10, 3] and ``TS`` [n_seg+1]
+    are ``trajGenerator.coeffs`` / ``.TS``; every drone has its own trajectory time ``t`` and its own
+    yaw/heading memory (the reference's ``get_yaw`` is stateful, trajGen.py:128-143).  Call
+    :meth:`sample` once per control step, then pass the object as ``targets``."""
+
+    def __init__(self, ctx: Context, n: int, coeffs, TS, t0=None, offsets=None, layout: str = "soa", pad: int = 256):
+        super().__init__(ctx, n, layout, pad=pad)
+        self.ctx = ctx
+        dev = ctx.device
+        self.coeffs = torch.as_tensor(np.ascontiguousarray(coeffs), dtype=torch.float64).to(dev)
+        self.TS = torch.as_tensor(np.ascontiguousarray(TS), dtype=torch.float64).to(dev)
+        self.n_seg = int(self.TS.numel() - 1)
+        self.t = torch.zeros((self.n_pad,), dtype=torch.float64, device=dev)
+        if t0 is not None:
+            self.t[:n] = torch.as_tensor(np.asarray(t0), dtype=torch.float64).to(dev)
+        self.yaw_state = torch.zeros((3, self.n_pad), dtype=torch.float64, device=dev)
+        self.offsets = None
+        if offsets is not None:
+            o = np.zeros((3, self.n_pad), dtype=np.float32)
+            o[:, :n] = np.asarray(offsets, dtype=np.float32).T
+            self.offsets = torch.from_numpy(o).to(dev)
+
+    def sample(self, dt_advance: float) -> None:
+        """targets <- get_des_state(t) per drone; t += dt_advance."""
+        nat.check(self.ctx.lib.dsim_traj_sample(
+            self.ctx.handle, self.ctx.stream_ptr(), self.n, self.coeffs.data_ptr(), self.TS.data_ptr(), self.n_seg,
+            self.t.data_ptr(), float(dt_advance), self.yaw_state.data_ptr(),
+            self.offsets.data_ptr() if self.offsets is not None else None, self.view()))

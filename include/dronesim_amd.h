@@ -212,6 +212,19 @@ int dsim_control(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_v
 int dsim_observe(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
                  float* obs_out, int32_t obs_width);
 
+/* Trajectory sampler on device: trajGenerator.get_des_state(t) (dronesim/utils/trajGen.py:108-126,
+ * polyder trajutils.py:13-21) per drone, including the stateful yaw-from-velocity rule
+ * (trajGen.py:128-143), written into a targets view that dsim_step / dsim_control then consume.
+ * coeffs: device, row-major [n_seg*10][3] fp64 (trajGenerator.coeffs); ts: device [n_seg+1] fp64.
+ * t: device [n_pad] fp64 in-out, each drone's own trajectory time; advanced by dt_advance after
+ * sampling (the example samples at 1/control_freq).  yaw_state: device SoA [3][n_pad] fp64 in-out
+ * (yaw, heading_x, heading_y), zero-initialised like trajGenerator; fp64 because the rule integrates
+ * acos() of nearly parallel unit headings, whose error is sqrt(eps) per step.  offset: nullable fp32
+ * SoA [3][n_pad] added to the sampled position.  Polynomials (degree 9, t up to ~7 s) in fp64. */
+int dsim_traj_sample(dsim_ctx* ctx, void* stream, int64_t n, const double* coeffs, const double* ts,
+                     int32_t n_seg, double* t, double dt_advance, double* yaw_state, const float* offset,
+                     dsim_view targets_out);
+
 /* The same rows as dsim_observe, written field-major: SoA [obs_width][n_pad] (coalesced), the slab a
  * device-side Logger appends per step (dronesim/utils/Logger.py:117-139 stores exactly this vector). */
 int dsim_observe_soa(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,

@@ -808,6 +808,43 @@ void orc_downwash(const dsim_type_params* types, const uint8_t* type_id, int64_t
   }
 }
 
+/* trajGenerator.get_des_state + get_yaw, dronesim/utils/trajGen.py:108-143 (polyder: trajutils.py:13-21).
+ * coeffs [n_seg*10][3] (row-major, as trajGenerator.coeffs), TS [n_seg+1].  yaw_state = (yaw, heading_x,
+ * heading_y) is the sampler's memory (trajGen.py:128-143: yaw integrates the signed angle between
+ * consecutive velocity headings), updated in place.  out10 = pos3 vel3 acc3 yaw. */
+void orc_traj_sample(const double* coeffs, const double* TS, int n_seg, double t, double yaw_state[3], double out10[10]) {
+  if (t > TS[n_seg]) t = TS[n_seg] - 0.001;                       /* :110-111 */
+  int seg = 0;
+  for (int k = 0; k <= n_seg; ++k) if (t >= TS[k]) seg = k;       /* :113 np.where(t >= TS)[0][-1] */
+  if (seg >= n_seg) seg = n_seg - 1;                              /* t == TS[-1] cannot happen after the clamp above */
+  t -= TS[seg];
+  double pw[10];
+  pw[0] = 1.0;
+  for (int j = 1; j < 10; ++j) pw[j] = pw[j - 1] * t;
+  for (int d = 0; d < 3; ++d) {
+    double p = 0, v = 0, a = 0;
+    for (int j = 0; j < 10; ++j) {
+      const double c = coeffs[(seg * 10 + j) * 3 + d];
+      p += c * pw[j];
+      if (j >= 1) v += c * j * pw[j - 1];
+      if (j >= 2) a += c * j * (j - 1) * pw[j - 2];
+    }
+    out10[d] = p; out10[3 + d] = v; out10[6 + d] = a;
+  }
+  /* get_yaw(vel[:2]) :128-143 */
+  const double nv = sqrt(out10[3] * out10[3] + out10[4] * out10[4]);
+  const double cx = out10[3] / nv, cy = out10[4] / nv;
+  double cosine = yaw_state[1] * cx + yaw_state[2] * cy;
+  cosine = fmax(-1.0, fmin(cosine, 1.0));
+  const double dyaw = acos(cosine);
+  const double cr = yaw_state[1] * cy - yaw_state[2] * cx;        /* np.cross of 2-vectors */
+  yaw_state[0] += (cr > 0 ? 1.0 : (cr < 0 ? -1.0 : 0.0)) * dyaw;
+  if (yaw_state[0] > ORC_PI) yaw_state[0] -= 2 * ORC_PI;
+  if (yaw_state[0] < -ORC_PI) yaw_state[0] += 2 * ORC_PI;
+  yaw_state[1] = cx; yaw_state[2] = cy;
+  out10[9] = yaw_state[0];
+}
+
 /* Env.step of the alternate action adaptors: _preprocessAction runs (part of) the INDI law on the
  * CURRENT state, then BaseAviary.step's physics loop runs with that command.
  *   mode 0: VelocityAviary._preprocessAction, VelocityAviary.py:221-264

@@ -120,6 +120,16 @@ def wls_alloc(v, umin, umax, B, Wv=None, Wu=None, up=None, gamma_sq=100000.0, im
     return (u if rc == 0 else None), it.value, rc
 
 
+def traj_sample(coeffs, TS, t, yaw_state):
+    """trajGenerator.get_des_state(t) incl. the stateful yaw rule; yaw_state (3,) updated in place."""
+    cf, ts = _c(coeffs), _c(TS)
+    out = np.zeros(10)
+    f = lib().orc_traj_sample
+    f.argtypes = [_D, _D, ctypes.c_int, ctypes.c_double, _D, _D]
+    f(_p(cf), _p(ts), len(ts) - 1, float(t), _p(yaw_state), _p(out))
+    return out
+
+
 class CtrlMem(ctypes.Structure):
     _fields_ = [("last_vel", ctypes.c_double * 3), ("last_rates", ctypes.c_double * 3),
                 ("last_thrust", ctypes.c_double), ("cmd", ctypes.c_double * 6)]

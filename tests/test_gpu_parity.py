@@ -538,6 +538,44 @@ def test_waypoint_tracking_vs_oracle(gpu, golden_dir):
     env.close()
 
 
+def test_device_trajectory_sampler_vs_reference_table(gpu, golden_dir):
+    """dsim_traj_sample == the reference trajGenerator's own samples (golden table), per drone with its
+    own start time and yaw memory; then the fused step consumes the sampled targets."""
+    nat, fleet = gpu
+    g = np.load(os.path.join(golden_dir, "traj_track_waypoints.npz"))
+    t = params.builtin_type("robobee")
+    ctx = fleet.Context([t])
+    n = 3
+    starts = [0, 100, 400]                       # drone j starts at table row starts[j]
+    tr = fleet.TrajectoryTargets(ctx, n, g["coeffs"], g["TS"], t0=[g["t"][s_] for s_ in starts],
+                                 offsets=[[0, 0, 0], [10, 0, 0], [0, 5, 1]])
+    # yaw memory of a sampler that starts mid-trajectory: the reference's state after sampling rows < start
+    for j, s_ in enumerate(starts):
+        ys = np.zeros(3)
+        for k in range(s_):
+            orc.traj_sample(g["coeffs"], g["TS"], g["t"][k], ys)
+        tr.yaw_state[:, j] = torch.from_numpy(ys)
+    off = np.array([[0, 0, 0], [10, 0, 0], [0, 5, 1.0]])
+    for k in range(300):
+        tr.sample(1.0 / 96)
+        T = tr.fields(0, 10).T.double().cpu().numpy()
+        for j, s_ in enumerate(starts):
+            row = s_ + k
+            np.testing.assert_allclose(T[j, 0:3], g["target_pos"][row] + off[j], rtol=0, atol=2e-6)   # fp32 output rounding
+            np.testing.assert_allclose(T[j, 3:6], g["target_vel"][row], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(T[j, 6:9], g["target_acc"][row], rtol=0, atol=1e-6)
+            assert abs(T[j, 9] - g["target_yaw"][row]) < 2e-5, (j, k)
+    st = fleet.FleetState(ctx, n)
+    rigid, mem, _ = random_fleet(np.random.default_rng(81), n)
+    st.load_aos(rigid, mem)
+    a = _args(nat, 2, DT, float(np.float32(2 / 240)))
+    nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tr.view(), ctypes.byref(a)))
+    tgt = tr.fields(0, 10).T.double().cpu().numpy()
+    assert orc.Oracle([t]).step(rigid, mem, tgt, 2, DT, float(np.float32(2 / 240))) == 0
+    assert rel_err(st.rigid_aos(), rigid, RIGID_SCALE).max() < REL_TOL
+    ctx.close()
+
+
 @pytest.mark.parametrize("noise_seed", [0, 77])
 def test_multi_step_launch_equals_single_steps(gpu, golden_dir, noise_seed):
     """n_steps = K in one launch is bit-identical to K single-step launches (state, counters, noise stream)."""

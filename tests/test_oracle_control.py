@@ -163,3 +163,16 @@ def test_indi_6dof_single_call(golden_dir):
         np.testing.assert_allclose(m[:, 7:13], g["cmd_out"][sel], rtol=0, atol=1e-7)
         np.testing.assert_allclose(yaw_e, g["yaw_e"][sel], rtol=0, atol=1e-12)
         np.testing.assert_allclose(m[:, 6], g["last_thrust_out"][sel], rtol=0, atol=1e-8)
+
+
+def test_trajectory_sampler_matches_reference_table(golden_dir):
+    """orc_traj_sample (trajGen.get_des_state + stateful get_yaw) against the 1200-row table the
+    reference's own trajGenerator produced for the fly_INDI_TrajectoryTrack gates."""
+    g = _load(golden_dir, "traj_track_waypoints.npz")
+    ys = np.zeros(3)
+    for k, t in enumerate(g["t"]):
+        o = orc.traj_sample(g["coeffs"], g["TS"], t, ys)
+        np.testing.assert_allclose(o[0:3], g["target_pos"][k], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(o[3:6], g["target_vel"][k], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(o[6:9], g["target_acc"][k], rtol=0, atol=1e-9)
+        assert abs(o[9] - g["target_yaw"][k]) < 1e-5, k   # yaw integrates acos() of nearly parallel headings (ill-conditioned)
