@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libdronesim_amd.so")
 # every symbol include/dronesim_amd.h declares
 EXPORTS = (
     "dsim_abi_version", "dsim_strerror", "dsim_create", "dsim_destroy", "dsim_reset", "dsim_step",
-    "dsim_physics", "dsim_control", "dsim_step_adaptor", "dsim_traj_sample", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash", "dsim_downwash_workspace",
+    "dsim_physics", "dsim_control", "dsim_step_adaptor", "dsim_traj_sample", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash", "dsim_downwash_workspace", "dsim_adjacency",
 )
 
 ABI_VERSION = 2
@@ -113,6 +113,7 @@ def load() -> ctypes.CDLL:
     lib.dsim_downwash_workspace.restype = ctypes.c_int64
     lib.dsim_downwash_workspace.argtypes = [i64, i32, i32]
     lib.dsim_downwash.argtypes = [vp, vp, i64, View, ctypes.POINTER(DownwashArgs), vp]
+    lib.dsim_adjacency.argtypes = [vp, vp, i64, View, ctypes.POINTER(DownwashArgs), ctypes.c_float, vp, vp, i32]
     if lib.dsim_abi_version() != ABI_VERSION:
         raise ImportError(f"libdronesim_amd.so ABI {lib.dsim_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

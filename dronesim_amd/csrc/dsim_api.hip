@@ -604,6 +604,10 @@ struct DwK {
   int* cursor;       // [ncells]
   float4* sorted;    // [m]  (x, y, z, world index as int bits)
   float* force_out;  // SoA [3][n_pad]
+  float radius2;     // adjacency
+  int* adj_count;    // [n_pad]
+  int* adj_list;     // [max_k][n_pad] or null
+  int max_k;
 };
 __device__ __forceinline__ int dw_cell(const DwK& a, float x, float y, int& cx, int& cy) {
   cx = min(max((int)floorf((x - a.xmin) * a.inv_cell), 0), a.nx - 1);
@@ -674,6 +678,32 @@ __global__ __launch_bounds__(256) void k_dw_query(DwK a) {
     }
   }
   a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz;
+}
+
+// adjacency (BaseAviary.py:913-921): neighbours within `radius` in 3-D, same grid, receivers in grid order
+__global__ __launch_bounds__(256) void k_adj_query(DwK a) {
+  const long long sidx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (sidx >= a.m) return;
+  const float4 me = a.sorted[sidx];
+  const int jme = __float_as_int(me.w);
+  const long long i = (long long)jme - a.local_offset;
+  if (i < 0 || i >= a.n) return;
+  int cx, cy, cnt = 0;
+  dw_cell(a, me.x, me.y, cx, cy);
+  for (int yy = max(cy - 1, 0); yy <= min(cy + 1, a.ny - 1); ++yy) {
+    const int c0 = yy * a.nx + max(cx - 1, 0), c1 = yy * a.nx + min(cx + 1, a.nx - 1);
+    for (int s2 = a.count[c0]; s2 < a.count[c1 + 1]; ++s2) {
+      const float4 p = a.sorted[s2];
+      const float dx = p.x - me.x, dy = p.y - me.y, dz = p.z - me.z;
+      const int j = __float_as_int(p.w);
+      if (j != jme && dx * dx + dy * dy + dz * dz < a.radius2) {
+        if (a.adj_list && cnt < a.max_k) a.adj_list[(long long)cnt * a.n_pad + i] = j;
+        ++cnt;
+      }
+    }
+  }
+  a.adj_count[i] = cnt;
+  if (a.adj_list) for (int k = cnt; k < a.max_k; ++k) a.adj_list[(long long)k * a.n_pad + i] = -1;
 }
 
 // ---------------------------------------------------------------------------
@@ -1037,14 +1067,44 @@ int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny) {
   return ((int64_t)nx * ny + 1) + (int64_t)nx * ny + 4 + 4 * m;   // count, cursor, 16-B alignment slack, float4[m]
 }
 
+static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view& state,
+                      const dsim_downwash_args* g, float min_cell, DwK* out);
+
 int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_downwash_args* g,
                   float* force_out) {
-  if (!ctx || !g || !force_out || !g->pos_all || !g->workspace || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
-  if (g->m < 1 || g->m_pad < g->m || g->nx < 1 || g->ny < 1 || !(g->cell >= 10.0f)) return DSIM_E_ARG;
+  if (!force_out) return DSIM_E_ARG;
+  if (ctx && g && ctx->n_types > 1 && !g->type_id) return DSIM_E_ARG;
+  DwK a;
+  const hipStream_t st_ = (hipStream_t)stream;
+  int rc = grid_build(ctx, st_, n, state, g, 10.0f, &a);
+  if (rc) return rc;
+  a.force_out = force_out;
+  hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m)), dim3(256), 0, st_, a);
+  return (int)hipGetLastError();
+}
+
+int dsim_adjacency(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_downwash_args* g,
+                   float radius, int32_t* count_out, int32_t* list_out, int32_t max_k) {
+  if (!count_out || !(radius > 0) || (list_out && max_k < 1)) return DSIM_E_ARG;
+  DwK a;
+  const hipStream_t st_ = (hipStream_t)stream;
+  int rc = grid_build(ctx, st_, n, state, g, radius, &a);
+  if (rc) return rc;
+  a.radius2 = radius * radius; a.adj_count = count_out; a.adj_list = list_out; a.max_k = list_out ? max_k : 0;
+  hipLaunchKernelGGL(k_adj_query, dim3(grid_for(a.m)), dim3(256), 0, st_, a);
+  return (int)hipGetLastError();
+}
+
+// counting sort of the world's positions into the xy grid (count, scan, scatter)
+static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view& state,
+                      const dsim_downwash_args* g, float min_cell, DwK* out) {
+  DwK& a_ = *out;
+  if (!ctx || !g || !g->pos_all || !g->workspace || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
+  if (g->m < 1 || g->m_pad < g->m || g->nx < 1 || g->ny < 1 || !(g->cell >= min_cell)) return DSIM_E_ARG;
   if ((long long)g->nx * g->ny > (1 << 24)) return DSIM_E_ARG;
   if (g->workspace_len < dsim_downwash_workspace(g->m, g->nx, g->ny)) return DSIM_E_ARG;
-  if (ctx->n_types > 1 && !g->type_id) return DSIM_E_ARG;
   DwK a;
+  memset(&a, 0, sizeof(a));
   int rc = make_kview(state, 20 + ctx->max_act, &a.st);
   if (rc) return rc;
   const long long ncells = (long long)g->nx * g->ny;
@@ -1055,15 +1115,13 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
   a.count = g->workspace; a.cursor = g->workspace + ncells + 1;
   uintptr_t sp = (uintptr_t)(a.cursor + ncells);
   a.sorted = (float4*)((sp + 15) & ~(uintptr_t)15);
-  a.force_out = force_out;
-  const hipStream_t st_ = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(a.count, 0, sizeof(int) * (ncells + 1), st_);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(k_dw_count, dim3(grid_for(a.m)), dim3(256), 0, st_, a);
   hipLaunchKernelGGL(k_dw_scan, dim3(1), dim3(1024), 0, st_, a);
   hipLaunchKernelGGL(k_dw_scatter, dim3(grid_for(a.m)), dim3(256), 0, st_, a);
-  hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m)), dim3(256), 0, st_, a);
-  return (int)hipGetLastError();
+  a_ = a;
+  return DSIM_OK;
 }
 
 }  // extern "C"

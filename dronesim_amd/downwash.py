@@ -66,10 +66,7 @@ class Downwash:
         self._box_age += 1
         return self._box
 
-    def compute(self, world_pos: Optional[torch.Tensor] = None, local_offset: Optional[int] = None) -> torch.Tensor:
-        """Returns the SoA [3, n_pad] body-frame force (x = y = 0) to pass as ``ext_force``.
-        ``world_pos`` [3, m]: positions of every drone of the world with this block's drones at
-        ``local_offset`` (default: gathered from the ranks' states / the block alone)."""
+    def _grid_args(self, world_pos, local_offset) -> nat.DownwashArgs:
         st = self.state
         if world_pos is None:
             world_pos = gather_positions(st.fields(0, 3), self.dist)
@@ -87,7 +84,31 @@ class Downwash:
         a.workspace, a.workspace_len = self._ws.data_ptr(), self._ws.numel()
         a.type_id = self.type_id.data_ptr() if self.type_id is not None else None
         a.local_offset = int(local_offset or 0)
-        nat.check(self.ctx.lib.dsim_downwash(self.ctx.handle, self.ctx.stream_ptr(), st.n, st.view(),
-                                             ctypes.byref(a), self.force.data_ptr()))
         self._keep = wp                     # the kernels read it asynchronously on the stream
+        return a
+
+    def compute(self, world_pos: Optional[torch.Tensor] = None, local_offset: Optional[int] = None) -> torch.Tensor:
+        """Returns the SoA [3, n_pad] body-frame force (x = y = 0) to pass as ``ext_force``.
+        ``world_pos`` [3, m]: positions of every drone of the world with this block's drones at
+        ``local_offset`` (default: gathered from the ranks' states / the block alone)."""
+        a = self._grid_args(world_pos, local_offset)
+        nat.check(self.ctx.lib.dsim_downwash(self.ctx.handle, self.ctx.stream_ptr(), self.state.n, self.state.view(),
+                                             ctypes.byref(a), self.force.data_ptr()))
         return self.force
+
+    def adjacency(self, radius: float, max_k: int = 0, world_pos: Optional[torch.Tensor] = None,
+                  local_offset: Optional[int] = None):
+        """Fleet-scale form of BaseAviary._getAdjacencyMatrix (BaseAviary.py:901-921): per local drone
+        the number of drones within ``radius`` and, if ``max_k`` > 0, up to max_k of their world
+        indices ([max_k, n], -1 padded).  The dense O(N^2) matrix of the reference is produced only by
+        the dict-mode observations of small fleets."""
+        self.cell = max(self.cell, float(radius))
+        self._box = None if self._box is not None and self.cell > CUTOFF else self._box
+        a = self._grid_args(world_pos, local_offset)
+        st = self.state
+        count = torch.zeros((st.n_pad,), dtype=torch.int32, device=self.ctx.device)
+        lst = torch.full((max_k, st.n_pad), -1, dtype=torch.int32, device=self.ctx.device) if max_k > 0 else None
+        nat.check(self.ctx.lib.dsim_adjacency(self.ctx.handle, self.ctx.stream_ptr(), st.n, st.view(), ctypes.byref(a),
+                                              float(radius), count.data_ptr(), lst.data_ptr() if lst is not None else None,
+                                              max_k))
+        return count[: st.n], (lst[:, : st.n] if lst is not None else None)

@@ -257,6 +257,15 @@ int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny);
 int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_downwash_args* args,
                   float* force_out);
 
+/* Neighbourhood adjacency at fleet scale (BaseAviary._getAdjacencyMatrix, BaseAviary.py:901-921: drones
+ * i != j are neighbours when |pos_i - pos_j| < neighbourhood_radius).  The reference returns the dense
+ * O(N^2) matrix row in every observation; here the same uniform grid as the downwash gives, per local
+ * drone, the neighbour count and (optionally) up to max_k neighbour indices into pos_all in ascending
+ * grid order (count_out [n_pad]; list_out [max_k][n_pad] nullable, unused slots -1).  args->cell must be
+ * >= radius; pos_all / workspace / local_offset as for dsim_downwash (type_id is ignored). */
+int dsim_adjacency(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_downwash_args* args,
+                   float radius, int32_t* count_out, int32_t* list_out, int32_t max_k);
+
 /* Diagnostics counters kept by the ctx (device-side, cumulative; this call synchronises `stream`):
  *   DSIM_Q_WLS_FALLBACKS  drones x steps whose 6DOF allocation left the first-iteration fast path and
  *                         ran the full active-set loop of wls_alloc (wls_alloc.py:222-350)

@@ -464,6 +464,30 @@ def test_drag_and_ground_effect_vs_oracle(gpu, opts):
     ctx.close()
 
 
+def test_adjacency_vs_bruteforce(gpu):
+    """Fleet-scale neighbourhood query == the reference's O(N^2) rule (BaseAviary.py:913-921)."""
+    nat, fleet = gpu
+    from dronesim_amd.downwash import Downwash
+    n, radius = 3000, 7.5
+    t = params.builtin_type("robobee")
+    ctx = fleet.Context([t])
+    st = fleet.FleetState(ctx, n)
+    rng = np.random.default_rng(91)
+    rigid, mem, _ = random_fleet(rng, n)
+    rigid[:, 0:3] = f32(np.stack([rng.uniform(0, 120, n), rng.uniform(0, 80, n), rng.uniform(0, 15, n)], 1))
+    st.load_aos(rigid, mem)
+    cnt, lst = Downwash(ctx, st).adjacency(radius, max_k=64)
+    p = rigid[:, 0:3].astype(np.float32)
+    d2 = ((p[:, None, :] - p[None, :, :]) ** 2).sum(-1)
+    adj = (d2 < np.float32(radius) ** 2) & ~np.eye(n, dtype=bool)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), adj.sum(1))
+    L = lst.cpu().numpy()
+    for i in rng.choice(n, 200, replace=False):
+        got = set(int(x) for x in L[:, i] if x >= 0)
+        assert got == set(np.nonzero(adj[i])[0].tolist()) or (adj[i].sum() > 64 and len(got) == 64)
+    ctx.close()
+
+
 def test_step_with_downwash_env(gpu):
     """Physics.PYB_DW env: fused step with the downwash force vs the oracle fed the brute-force force."""
     from dronesim_amd.envs import CtrlAviary, Physics
