@@ -60,7 +60,7 @@ class Fleet:
     """A resident fleet + per-drone hover targets at the start position."""
 
     def __init__(self, n_fleet, replicas, device, substeps, layout, noise_seed, waypoints=False, n_steps=1,
-                 config5=False, dist=None, rank=0):
+                 config5=False, dist=None, rank=0, chained=False):
         import torch
         from dronesim_amd.envs import CtrlAviary, Physics
         from dronesim_amd.fleet import Targets, WaypointTargets
@@ -86,7 +86,8 @@ class Fleet:
             xyz = g["gates"][0][None, :] + off
             wp0 = (np.arange(self.n) * n_wp // 6) % n_wp
         self.env = CtrlAviary(models, self.n, initial_xyzs=xyz, aggregate_phy_steps=substeps, physics=physics,
-                              device=device, layout=layout, noise_seed=noise_seed, dict_io=False, dist=dist)
+                              device=device, layout=layout, noise_seed=noise_seed, dict_io=False, dist=dist,
+                              chained=chained)
         if waypoints:
             self.tgt = WaypointTargets(self.env.ctx, self.n, g["target_pos"], g["target_vel"], g["target_acc"],
                                        g["target_yaw"], wp_counters=wp0, offsets=off)
@@ -251,15 +252,20 @@ def main():
                     "config3_65536_waypoints_sub2": (65536, 1, 2, True, 1),
                     "config3_65536_waypoints_sub2_32steps_per_launch": (65536, 1, 2, True, 32),
                     "config2x1024_sub5": (4096, 1024, 5, False, 1),
-                    "config5_shard_65536_mixed_downwash": (65536, 1, 1, False, 1)}.items():
+                    "config5_shard_65536_mixed_downwash": (65536, 1, 1, False, 1),
+                    # DSIM_OPT_CHAINED: the six controller-memory fields that are functions of the stored
+                    # rigid state are neither read nor written: 184 B of real traffic per drone-step
+                    "config2x1024_chained_184B": (4096, 1024, 1, False, 1)}.items():
                 f2 = Fleet(nf, rep, local, sub, a.layout, a.noise_seed, waypoints=wp, n_steps=ns,
-                           config5=name.startswith("config5"))
+                           config5=name.startswith("config5"), chained="chained" in name)
                 k2 = max(20, a.steps // 2)
                 w2, d2 = f2.timed(k2, 10)
                 also[name] = {"drone_steps_per_s": f2.n * k2 * ns / w2, "launch_us": d2 / k2 * 1e6,
                               "env_steps_per_launch": ns}
                 if ns == 1:
-                    also[name]["hbm_frac"] = f2.n * BYTES_PER_DRONE_STEP / (d2 / k2) / 1e9 / HBM_PEAK_GBPS
+                    bts = 184 if "chained" in name else BYTES_PER_DRONE_STEP
+                    also[name]["hbm_frac"] = f2.n * bts / (d2 / k2) / 1e9 / HBM_PEAK_GBPS
+                    also[name]["bytes_per_drone_step"] = bts
                 f2.env.close(); del f2
             out["also"] = also
         if world == 1 and not a.no_cpu_baseline:

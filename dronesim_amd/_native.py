@@ -16,12 +16,12 @@ LIB_PATH = os.path.join(_HERE, "libdronesim_amd.so")
 # every symbol include/dronesim_amd.h declares
 EXPORTS = (
     "dsim_abi_version", "dsim_strerror", "dsim_create", "dsim_destroy", "dsim_reset", "dsim_step",
-    "dsim_physics", "dsim_control", "dsim_step_adaptor", "dsim_traj_sample", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash", "dsim_downwash_workspace", "dsim_adjacency",
+    "dsim_physics", "dsim_control", "dsim_step_adaptor", "dsim_traj_sample", "dsim_materialize", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash", "dsim_downwash_workspace", "dsim_adjacency",
 )
 
 ABI_VERSION = 2
 NF_QUAD, NF_HEXA, NT = 24, 26, 10
-OPT_DRAG, OPT_GROUND, OPT_BCAST_TGT = 1, 2, 4
+OPT_DRAG, OPT_GROUND, OPT_BCAST_TGT, OPT_CHAINED = 1, 2, 4, 8
 ADAPT_VELOCITY, ADAPT_RPYT = 0, 1
 
 
@@ -107,6 +107,7 @@ def load() -> ctypes.CDLL:
     lib.dsim_control.argtypes = [vp, vp, i64, View, View, ctypes.POINTER(StepArgs), vp, vp]
     lib.dsim_step_adaptor.argtypes = [vp, vp, i64, View, vp, i32, vp, ctypes.POINTER(StepArgs)]
     lib.dsim_traj_sample.argtypes = [vp, vp, i64, vp, vp, i32, vp, ctypes.c_double, vp, vp, View]
+    lib.dsim_materialize.argtypes = [vp, vp, i64, View]
     lib.dsim_observe.argtypes = [vp, vp, i64, View, vp, vp, i32]
     lib.dsim_observe_soa.argtypes = [vp, vp, i64, View, vp, vp, i32]
     lib.dsim_query.argtypes = [vp, vp, i32, ctypes.POINTER(ctypes.c_int64)]

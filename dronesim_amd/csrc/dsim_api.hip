@@ -109,18 +109,23 @@ __device__ __forceinline__ void store_rigid(float* ub, long long fs, unsigned lo
   stg<NT>(ub + 7 * fs, lo, s.vel.x); stg<NT>(ub + 8 * fs, lo, s.vel.y); stg<NT>(ub + 9 * fs, lo, s.vel.z);
   stg<NT>(ub + 10 * fs, lo, s.w.x); stg<NT>(ub + 11 * fs, lo, s.w.y); stg<NT>(ub + 12 * fs, lo, s.w.z);
 }
-template <int NACT, bool NT = false>
+// CH (chained): last_vel / last_rates are neither read nor written (DSIM_OPT_CHAINED)
+template <int NACT, bool NT = false, bool CH = false>
 __device__ __forceinline__ void load_mem(const float* ub, long long fs, unsigned lo /* bytes */, CtrlMem<NACT>& m) {
-  m.last_vel = v3(ldg<NT>(ub + 13 * fs, lo), ldg<NT>(ub + 14 * fs, lo), ldg<NT>(ub + 15 * fs, lo));
-  m.last_rates = v3(ldg<NT>(ub + 16 * fs, lo), ldg<NT>(ub + 17 * fs, lo), ldg<NT>(ub + 18 * fs, lo));
+  if (!CH) {
+    m.last_vel = v3(ldg<NT>(ub + 13 * fs, lo), ldg<NT>(ub + 14 * fs, lo), ldg<NT>(ub + 15 * fs, lo));
+    m.last_rates = v3(ldg<NT>(ub + 16 * fs, lo), ldg<NT>(ub + 17 * fs, lo), ldg<NT>(ub + 18 * fs, lo));
+  }
   m.last_thrust = ldg<NT>(ub + 19 * fs, lo);
 #pragma unroll
   for (int j = 0; j < NACT; ++j) m.cmd[j] = ldg<NT>(ub + (20 + j) * fs, lo);
 }
-template <int NACT, bool NT = false>
+template <int NACT, bool NT = false, bool CH = false>
 __device__ __forceinline__ void store_mem(float* ub, long long fs, unsigned lo /* bytes */, const CtrlMem<NACT>& m) {
-  stg<NT>(ub + 13 * fs, lo, m.last_vel.x); stg<NT>(ub + 14 * fs, lo, m.last_vel.y); stg<NT>(ub + 15 * fs, lo, m.last_vel.z);
-  stg<NT>(ub + 16 * fs, lo, m.last_rates.x); stg<NT>(ub + 17 * fs, lo, m.last_rates.y); stg<NT>(ub + 18 * fs, lo, m.last_rates.z);
+  if (!CH) {
+    stg<NT>(ub + 13 * fs, lo, m.last_vel.x); stg<NT>(ub + 14 * fs, lo, m.last_vel.y); stg<NT>(ub + 15 * fs, lo, m.last_vel.z);
+    stg<NT>(ub + 16 * fs, lo, m.last_rates.x); stg<NT>(ub + 17 * fs, lo, m.last_rates.y); stg<NT>(ub + 18 * fs, lo, m.last_rates.z);
+  }
   stg<NT>(ub + 19 * fs, lo, m.last_thrust);
 #pragma unroll
   for (int j = 0; j < NACT; ++j) stg<NT>(ub + (20 + j) * fs, lo, m.cmd[j]);
@@ -222,7 +227,9 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
 // this short kernel; forcing 4 waves/SIMD by spilling also lost, 176 vs 172 us.)
 // EXT = waypoint-table targets and/or several steps per launch; the plain single-step kernel is
 // compiled without that generality (it would cost the hot kernel registers: 128 + spills vs 121).
-template <bool NOISE, bool NT, bool EXT>
+// CH = DSIM_OPT_CHAINED: last_vel / last_rates are recomputed from the rigid state the previous step
+// stored (they are functions of it) instead of being read, and are not written: 184 B/drone-step.
+template <bool NOISE, bool NT, bool EXT, bool CH = false>
 __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(StepK a) {
   const DevType& T = a.types[0];
   const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
@@ -234,7 +241,8 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
   CtrlMem<4> m;
   Target tg;
   load_rigid<NT>(sb, sfs, sl, s);
-  load_mem<4, NT>(sb, sfs, sl, m);
+  load_mem<4, NT, CH>(sb, sfs, sl, m);
+  if (CH) { m.last_vel = s.vel; m.last_rates = mulT(matrix_from_quat(s.q), s.w); }
   const long long i = i0 + threadIdx.x;
   V3 pos_e;
   float yaw_e;
@@ -254,7 +262,21 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
     if (a.wp_table) a.wp_counter[i] = wp;
   }
   store_rigid<NT>(sb, sfs, sl, s);
-  store_mem<4, NT>(sb, sfs, sl, m);
+  store_mem<4, NT, CH>(sb, sfs, sl, m);
+}
+
+// ends a chained sequence: last_vel / last_rates back into the state block
+struct MatK { KView st; long long n_pad; };
+__global__ __launch_bounds__(256) void k_materialize(MatK a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_pad) return;
+  float* p = a.st.base + kv_off(a.st, i);
+  const long long fs = a.st.field_stride;
+  Rigid s;
+  load_rigid(p, fs, 0u, s);
+  const V3 wb = mulT(matrix_from_quat(s.q), s.w);
+  p[13 * fs] = s.vel.x; p[14 * fs] = s.vel.y; p[15 * fs] = s.vel.z;
+  p[16 * fs] = wb.x; p[17 * fs] = wb.y; p[18 * fs] = wb.z;
 }
 
 // Mixed fleets: every lane carries a type id, but the per-type constants must stay wave-uniform
@@ -923,6 +945,9 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   long long first = 0;
   const bool phys_opts = (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)) != 0;
   if (phys_opts && six) return DSIM_E_UNSUPPORTED;      // the add-on formulas are written for the four-rotor links
+  if ((args->options & DSIM_OPT_CHAINED) && (!uni || six || args->action || args->noise_replay || args->ext_force ||
+                                             phys_opts || (state.n_pad % 256)))
+    return DSIM_E_UNSUPPORTED;                          // chained stepping is a fast-path-only mode
   if (uni && !six && !args->action && !args->noise_replay && !args->ext_force && !phys_opts) {
     // fast path over the whole 256-drone tiles.  Streaming (nontemporal) accesses once the fleet's
     // per-step traffic exceeds what the 256 MB Infinity Cache can keep between consecutive steps
@@ -933,9 +958,12 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     if (tiles > 0) {
       const dim3 g((unsigned)tiles);
       const bool ext = a.wp_table != nullptr || a.n_steps > 1;
-#define DSIM_FAST_CASE(N_, T_)                                                          \
-  do { if (ext) hipLaunchKernelGGL((k_step_fast<N_, T_, true>), g, b, 0, st_, a);       \
-       else hipLaunchKernelGGL((k_step_fast<N_, T_, false>), g, b, 0, st_, a); } while (0)
+      const bool ch = (args->options & DSIM_OPT_CHAINED) != 0;
+#define DSIM_FAST_CASE(N_, T_)                                                                      \
+  do { if (ext) { if (ch) hipLaunchKernelGGL((k_step_fast<N_, T_, true, true>), g, b, 0, st_, a);   \
+                  else hipLaunchKernelGGL((k_step_fast<N_, T_, true, false>), g, b, 0, st_, a); }   \
+       else { if (ch) hipLaunchKernelGGL((k_step_fast<N_, T_, false, true>), g, b, 0, st_, a);      \
+              else hipLaunchKernelGGL((k_step_fast<N_, T_, false, false>), g, b, 0, st_, a); } } while (0)
       if (noise) { if (nt) DSIM_FAST_CASE(true, true); else DSIM_FAST_CASE(true, false); }
       else { if (nt) DSIM_FAST_CASE(false, true); else DSIM_FAST_CASE(false, false); }
 #undef DSIM_FAST_CASE
@@ -966,6 +994,16 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
       }
     }
   }
+  return (int)hipGetLastError();
+}
+
+int dsim_materialize(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state) {
+  if (!ctx || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
+  MatK a;
+  int rc = make_kview(state, 20 + ctx->max_act, &a.st);
+  if (rc) return rc;
+  a.n_pad = state.n_pad;
+  hipLaunchKernelGGL(k_materialize, dim3(grid_for(a.n_pad)), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

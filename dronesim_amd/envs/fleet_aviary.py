@@ -67,6 +67,7 @@ class CtrlAviary:
         noise_seed: Optional[int] = None,
         dict_io: Optional[bool] = None,
         dist=None,
+        chained: bool = False,
     ):
         if gui or record or obstacles:
             raise NotImplementedError("gui/record/obstacles are rendering features outside the hot path")
@@ -125,6 +126,12 @@ class CtrlAviary:
         self._last_action = torch.zeros_like(self._action_buf)
         self._use_last_action = True
         self._obs_buf = None      # [N, 16+n_act], allocated on the first observe()
+        # chained fused stepping (DSIM_OPT_CHAINED): consecutive step_fused() calls skip the six
+        # controller-memory fields that are functions of the stored rigid state (184 instead of 232
+        # bytes per drone-step); anything else first calls materialize()
+        self._chained_enabled = chained
+        self._chain_live = False          # last_vel / last_rates in HBM are stale
+        self._chain_ok = False            # the previous operation was a fused step (memory consistent with the state)
         # Physics.PYB_DW: neighbour downwash (BaseAviary.py:534-536, 1736-1763); `dist` = an initialised
         # torch.distributed module when the world's fleet is sharded over several ranks
         self._downwash = None
@@ -163,8 +170,16 @@ class CtrlAviary:
         self._housekeeping()
         return self._computeObs()
 
+    def materialize(self):
+        """Ends a chained sequence: last_vel / last_rates are written back into the state block."""
+        if self._chain_live:
+            nat.check(self.ctx.lib.dsim_materialize(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
+                                                    self.state.view()))
+            self._chain_live = False
+
     def _housekeeping(self):
         """BaseAviary._housekeeping (BaseAviary.py:640-714): zero counters, place every drone."""
+        self._chain_live = self._chain_ok = False
         self.step_counter = 0
         self._env_steps = 0
         pos, rpy = self._soa3(self.INIT_XYZS), self._soa3(self.INIT_RPYS)
@@ -179,6 +194,8 @@ class CtrlAviary:
 
     def step(self, action):
         """BaseAviary.step (BaseAviary.py:428-555) with Physics.PYB."""
+        self.materialize()
+        self._chain_ok = False
         self._load_action(action)
         args = self.step_args()
         args.action = self._action_buf.data_ptr()
@@ -208,8 +225,16 @@ class CtrlAviary:
             self._load_action(action)
             args.action = self._action_buf.data_ptr()
         self._use_last_action = False   # from here on the applied action IS the controller cmd
+        chain = (self._chained_enabled and self._chain_ok and action is None and self._type_id is None
+                 and self.n_act == 4 and args.ext_force is None and self._phys_options == 0)
+        if chain:
+            args.options |= nat.OPT_CHAINED
+            self._chain_live = True
+        else:
+            self.materialize()
         nat.check(self.ctx.lib.dsim_step(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
                                          self.state.view(), tview, ctypes.byref(args)))
+        self._chain_ok = True
         self.step_counter += self.AGGR_PHY_STEPS * n_steps
         self._env_steps += n_steps
 
@@ -287,6 +312,8 @@ class _AdaptorAviary(CtrlAviary):
     _MODE = -1
 
     def step(self, action):
+        self.materialize()
+        self._chain_ok = False
         self._load_action(action)
         args = self.step_args(self.AGGR_PHY_STEPS * self.TIMESTEP)
         nat.check(self.ctx.lib.dsim_step_adaptor(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,

@@ -114,7 +114,13 @@ typedef struct dsim_type_params {
 enum {
   DSIM_OPT_DRAG        = 1u << 0,   /* add formula P6 (BaseAviary.py:1705-1732)            */
   DSIM_OPT_GROUND      = 1u << 1,   /* add formula P7 (BaseAviary.py:1648-1699)            */
-  DSIM_OPT_BCAST_TGT   = 1u << 2    /* targets view holds ONE drone's targets, broadcast   */
+  DSIM_OPT_BCAST_TGT   = 1u << 2,   /* targets view holds ONE drone's targets, broadcast   */
+  DSIM_OPT_CHAINED     = 1u << 3    /* dsim_step only.  The caller asserts that the stored controller memory is
+                                       the one the previous dsim_step / dsim_control left on the SAME rigid state,
+                                       i.e. last_vel == vel and last_rates == R(quat)^T ang_vel.  Both are then
+                                       recomputed from the rigid state instead of being read, and are NOT written
+                                       back (6 of the 24 fields: 184 instead of 232 bytes of traffic per
+                                       drone-step).  The six fields are stale until dsim_materialize is called. */
 };
 
 typedef struct dsim_step_args {
@@ -175,6 +181,9 @@ int dsim_reset(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state,
  * i.e. the body of the example loop (examples/fly_INDI.py:223-239).             */
 int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
               const dsim_step_args* args);
+
+/* Rewrites last_vel / last_rates from the rigid state (ends a DSIM_OPT_CHAINED sequence). */
+int dsim_materialize(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state);
 
 /* Env.step() only: physics sub-steps with args->action (clipped in-kernel as
  * CtrlAviary._preprocessAction does, CtrlAviary.py:258-263; NULL = stored cmd).

@@ -657,6 +657,42 @@ def test_full_size_properties(gpu, n):
     ctx.close()
 
 
+def test_chained_stepping(gpu):
+    """DSIM_OPT_CHAINED: last_vel / last_rates recomputed from the stored rigid state instead of being read,
+    and not written; materialize() restores them.  Same trajectory as the plain mode and as the oracle."""
+    from dronesim_amd.envs import CtrlAviary
+    from dronesim_amd.fleet import Targets
+    n = 2048
+    rng = np.random.default_rng(95)
+    xyz = np.stack([rng.uniform(-20, 20, n), rng.uniform(-20, 20, n), rng.uniform(1, 5, n)], 1)
+    rpy = np.stack([rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n), rng.uniform(-3, 3, n)], 1)
+    envs = [CtrlAviary(["robobee"], n, initial_xyzs=xyz, initial_rpys=rpy, aggregate_phy_steps=2, noise_seed=5,
+                       dict_io=False, chained=c) for c in (False, True)]
+    tgts = []
+    for e in envs:
+        tg = Targets(e.ctx, n); tg.set(pos=f32(xyz + 0.3).T, yaw=0.5); tgts.append(tg)
+    a0 = np.full((n, 4), 0.4, dtype=np.float32)
+    for e, tg in zip(envs, tgts):
+        e.step_fused(tg, action=a0)              # first step: explicit action -> not chained
+        for _ in range(15):
+            e.step_fused(tg)
+    assert envs[1]._chain_live and not envs[0]._chain_live
+    A, B = envs[0].state.fields(0, 24).cpu().numpy(), envs[1].state.fields(0, 24).cpu().numpy()
+    live = [f for f in range(24) if not 13 <= f < 19]
+    assert np.abs(A[live] - B[live]).max() < 2e-5           # same trajectory (recomputed R^T w may differ by an ulp)
+    assert np.abs(A[13:19] - B[13:19]).max() > 1e-3         # the six fields ARE stale in chained mode...
+    envs[1].materialize()
+    B2 = envs[1].state.fields(0, 24).cpu().numpy()
+    assert np.abs(A[13:19] - B2[13:19]).max() < 2e-5        # ...until materialized
+    # and a non-chained operation after a chained run sees consistent memory: one more plain step agrees
+    for e, tg in zip(envs, tgts):
+        e._chained_enabled = False
+        e.step_fused(tg)
+    assert np.abs(envs[0].state.fields(0, 24).cpu().numpy() - envs[1].state.fields(0, 24).cpu().numpy()).max() < 5e-5
+    for e in envs:
+        e.close()
+
+
 def test_hover_equilibrium_and_determinism(gpu):
     nat, fleet = gpu
     t = params.builtin_type("robobee")
