@@ -817,6 +817,45 @@ def test_device_logger_matches_reference_layout(gpu, tmp_path):
     env.close()
 
 
+def test_c_caller_without_python_or_torch(gpu, tmp_path):
+    """The boundary is a C-ABI: a plain C program (tests/c_abi_smoke.c) links the library, flies a
+    fleet for 5 s and checks it reached the hover target."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_smoke")
+    lib_dir = os.path.join(root, "dronesim_amd")
+    subprocess.check_call(["gcc", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(root, "tests", "c_abi_smoke.c"), "-o", exe, "-L" + lib_dir, "-ldronesim_amd",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "c_abi_smoke" in out.stdout
+
+
+def test_two_quad_types_keep_their_own_gains(gpu):
+    """robobee + tello in one fleet (type_id): each drone is flown with ITS type's constants and gains
+    (the reference's class-attribute Gains would leak the last-constructed type's gains to all quads;
+    documented deviation)."""
+    nat, fleet = gpu
+    n = 1500
+    types = [params.builtin_type("robobee"), params.builtin_type("tello")]
+    ctx = fleet.Context(types)
+    assert ctx.n_fields == 24
+    st = fleet.FleetState(ctx, n, "tile64")
+    tg = fleet.Targets(ctx, n, "tile64")
+    rigid, mem, tgt = random_fleet(np.random.default_rng(97), n)
+    tid = (np.random.default_rng(98).uniform(size=n) < 0.4).astype(np.uint8)
+    st.load_aos(rigid, mem)
+    tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
+    tid_dev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device); tid_dev[:n] = torch.from_numpy(tid)
+    a = _args(nat, 5, DT, float(np.float32(5 / 240)), type_id=tid_dev)
+    nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
+    assert orc.Oracle(types).step(rigid, mem, tgt, 5, DT, float(np.float32(5 / 240)), type_id=tid) == 0
+    assert rel_err(st.rigid_aos(), rigid, RIGID_SCALE).max() < REL_TOL
+    assert rel_err(st.mem_aos(), mem, MEM_SCALE).max() < REL_TOL
+    ctx.close()
+
+
 def test_abi_argument_errors(gpu):
     nat, fleet = gpu
     t = params.builtin_type("robobee")
