@@ -132,6 +132,7 @@ class CtrlAviary:
         self._chained_enabled = chained
         self._chain_live = False          # last_vel / last_rates in HBM are stale
         self._chain_ok = False            # the previous operation was a fused step (memory consistent with the state)
+        self._fused_plan = None           # cached argument block of the repeated step_fused() call
         # Physics.PYB_DW: neighbour downwash (BaseAviary.py:534-536, 1736-1763); `dist` = an initialised
         # torch.distributed module when the world's fleet is sharded over several ranks
         self._downwash = None
@@ -172,6 +173,7 @@ class CtrlAviary:
 
     def materialize(self):
         """Ends a chained sequence: last_vel / last_rates are written back into the state block."""
+        self._fused_plan = None
         if self._chain_live:
             nat.check(self.ctx.lib.dsim_materialize(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
                                                     self.state.view()))
@@ -180,6 +182,7 @@ class CtrlAviary:
     def _housekeeping(self):
         """BaseAviary._housekeeping (BaseAviary.py:640-714): zero counters, place every drone."""
         self._chain_live = self._chain_ok = False
+        self._fused_plan = None
         self.step_counter = 0
         self._env_steps = 0
         pos, rpy = self._soa3(self.INIT_XYZS), self._soa3(self.INIT_RPYS)
@@ -213,6 +216,19 @@ class CtrlAviary:
         iteration of the example passes its initial action 0.4 (fly_INDI.py:214).
         ``targets``: :class:`Targets` (per drone or broadcast) or :class:`WaypointTargets`.
         ``n_steps`` > 1 runs that many loop iterations inside the one launch."""
+        # hot loop: the same targets object, no explicit action, no downwash -> reuse the prepared
+        # argument block (the Python side of a launch drops from ~9 us to ~3 us, which is what bounds
+        # small fleets)
+        key = (id(targets), control_timestep, n_steps, self._chained_enabled)
+        plan = self._fused_plan
+        if (action is None and plan is not None and plan[0] == key and self._downwash is None and self._chain_ok
+                and (self._chain_live or not self._chained_enabled)):
+            _, args, sview, tview, ref = plan
+            args.step_index = self._env_steps
+            nat.check(self.ctx.lib.dsim_step(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, sview, tview, ref))
+            self.step_counter += self.AGGR_PHY_STEPS * n_steps
+            self._env_steps += n_steps
+            return
         wp = isinstance(targets, WaypointTargets)
         args = self.step_args(control_timestep, nat.OPT_BCAST_TGT if targets.broadcast else 0)
         args.n_steps = n_steps
@@ -232,11 +248,20 @@ class CtrlAviary:
             self._chain_live = True
         else:
             self.materialize()
+        sview = self.state.view()
         nat.check(self.ctx.lib.dsim_step(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
-                                         self.state.view(), tview, ctypes.byref(args)))
+                                         sview, tview, ctypes.byref(args)))
         self._chain_ok = True
         self.step_counter += self.AGGR_PHY_STEPS * n_steps
         self._env_steps += n_steps
+        # what the NEXT identical call would pass (a chained env switches to the chained form after this call)
+        self._fused_plan = None
+        if action is None and self._downwash is None:
+            nxt = nat.StepArgs.from_buffer_copy(args)
+            if self._chained_enabled and chain:
+                nxt.options |= nat.OPT_CHAINED
+            if not self._chained_enabled or chain:
+                self._fused_plan = (key, nxt, sview, tview, ctypes.byref(nxt))
 
     def close(self):
         self.ctx.close()
