@@ -33,6 +33,9 @@ struct dsim_ctx {
   unsigned long long* d_counters;         // [0..1] diagnostics (dsim_query), [2] fallback queue length
   FbEntry* d_fb;                          // deferred WLS fallback queue, grown to the largest fleet seen
   long long fb_cap;
+  const int32_t* dw_ws;                   // downwash grid: workspace / shape / count-buffer parity of the last call
+  long long dw_cells;
+  int dw_parity;
   dsim_type_params h_types[DSIM_MAX_TYPES];
 };
 
@@ -496,6 +499,16 @@ __global__ __launch_bounds__(64) void k_wls_fallback(FbK a) {
     if (rc == 0) { for (int j = 0; j < 6; ++j) p[(20 + j) * fs] = clampf(cmd[j] + du[j], T.pmin[j], T.pmax[j]); }
     else atomicAdd(&a.fb.counters[1], 1ULL);   // the reference would raise here; cmd is left unchanged
   }
+  // the last workgroup to finish empties the queue for the next step (no per-step memset on the stream)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&a.fb.counters[3], 1ULL) == (unsigned long long)gridDim.x - 1) {
+      *a.fb.count = 0ULL;
+      a.fb.counters[3] = 0ULL;
+      __threadfence();
+    }
+  }
 }
 
 // ---- reset -------------------------------------------------------------------
@@ -623,6 +636,7 @@ struct DwK {
   float xmin, ymin, inv_cell;
   int nx, ny;
   int* count;        // [ncells + 1] -> exclusive prefix after the scan
+  int* count_next;   // the other buffer: zeroed by this call's query kernel for the next call
   int* cursor;       // [ncells]
   float4* sorted;    // [m]  (x, y, z, world index as int bits)
   float* force_out;  // SoA [3][n_pad]
@@ -638,6 +652,8 @@ __device__ __forceinline__ int dw_cell(const DwK& a, float x, float y, int& cx, 
 }
 __global__ __launch_bounds__(256) void k_dw_count(DwK a) {
   const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  // also zeroes the count buffer the NEXT grid build will use (double-buffered: no memset per step)
+  if (j <= (long long)a.nx * a.ny) a.count_next[j] = 0;
   if (j >= a.m) return;
   int cx, cy;
   atomicAdd(&a.count[dw_cell(a, a.pos_all[j], a.pos_all[a.m_pad + j], cx, cy)], 1);
@@ -669,39 +685,54 @@ __global__ __launch_bounds__(256) void k_dw_scatter(DwK a) {
   const int slot = atomicAdd(&a.cursor[dw_cell(a, x, y, cx, cy)], 1);
   a.sorted[slot] = make_float4(x, y, z, __int_as_float((int)j));
 }
-// One thread per SORTED world entry; the entries that belong to this rank's shard are the
-// receivers.  Lanes of a wave therefore sit in the same or neighbouring cells: their 3x3 scans
-// read the same sorted entries (L1/L2 broadcast) and have similar trip counts.
+// DW_LPR lanes per SORTED world entry; the entries that belong to this rank's shard are the
+// receivers.  The lanes of a wave sit in the same or neighbouring cells, so their 3x3 scans read the
+// same sorted entries; the DW_LPR lanes of one receiver stride its candidate list together (each
+// wave-instruction reads DW_LPR consecutive 16-byte entries per receiver) and reduce by shuffles.
+// A 65 536-drone shard alone is only 1 024 waves: without the split every SIMD holds a single wave
+// that walks a chain of dependent L2 reads (53 us; 8 lanes/receiver + the split scan: see profiles).
+#define DW_LPR 8
 __global__ __launch_bounds__(256) void k_dw_query(DwK a) {
-  const long long sidx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (sidx >= a.m) return;
+  const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long sidx = gt / DW_LPR;
+  const int sub = (int)(gt % DW_LPR);
+  if (sidx >= a.m) return;                                      // whole receiver groups leave together
   const float4 me = a.sorted[sidx];
   const long long i = (long long)__float_as_int(me.w) - a.local_offset;
-  if (i < 0 || i >= a.n) return;                               // another rank's drone
+  if (i < 0 || i >= a.n) return;                                // another rank's drone
   const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
   const float x = me.x, y = me.y, z = me.z;
   const float pr = T.prop_radius, d0 = T.dw[0], d1 = T.dw[1], d2c = T.dw[2];
+  const float4* __restrict__ cand = a.sorted;
   int cx, cy;
   dw_cell(a, x, y, cx, cy);
   float fz = 0.0f;
   for (int yy = max(cy - 1, 0); yy <= min(cy + 1, a.ny - 1); ++yy) {
     // the three cells of a row are contiguous in the sorted array
     const int c0 = yy * a.nx + max(cx - 1, 0), c1 = yy * a.nx + min(cx + 1, a.nx - 1);
-    for (int s2 = a.count[c0]; s2 < a.count[c1 + 1]; ++s2) {
-      const float4 p = a.sorted[s2];
-      const float dz = p.z - z, dx = p.x - x, dy = p.y - y;
-      const float dd = dx * dx + dy * dy;
-      if (dz > 0.0f && dd < 100.0f) {                         // BaseAviary.py:1752
-        const float r = pr * DSIM_RCP(4.0f * dz);
-        const float alpha = d0 * r * r;                       // :1753
-        const float beta = d1 * dz + d2c;                     // :1754
-        fz -= alpha * __expf(-0.5f * dd * DSIM_RCP(beta * beta));   // :1755
+    const int s_end = a.count[c1 + 1];
+    for (int s2 = a.count[c0] + sub; s2 < s_end; s2 += 2 * DW_LPR) {    // two candidates in flight per lane
+      const float4 p0 = cand[s2];
+      const float4 p1 = cand[min(s2 + DW_LPR, s_end - 1)];
+      const bool v1 = s2 + DW_LPR < s_end;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float4 p = u ? p1 : p0;
+        const float dz = p.z - z, dx = p.x - x, dy = p.y - y;
+        const float dd = dx * dx + dy * dy;
+        if ((u == 0 || v1) && dz > 0.0f && dd < 100.0f) {       // BaseAviary.py:1752
+          const float r = pr * DSIM_RCP(4.0f * dz);
+          const float alpha = d0 * r * r;                       // :1753
+          const float beta = d1 * dz + d2c;                     // :1754
+          fz -= alpha * __expf(-0.5f * dd * DSIM_RCP(beta * beta));   // :1755
+        }
       }
     }
   }
-  a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz;
+#pragma unroll
+  for (int off = DW_LPR / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
+  if (sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz; }
 }
-
 // adjacency (BaseAviary.py:913-921): neighbours within `radius` in 3-D, same grid, receivers in grid order
 __global__ __launch_bounds__(256) void k_adj_query(DwK a) {
   const long long sidx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -812,7 +843,7 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
   dsim_ctx* c = new (std::nothrow) dsim_ctx;
   if (!c) return DSIM_E_ARG;
   c->device = device; c->n_types = n_types; c->max_act = max_act; c->d_types = nullptr; c->d_counters = nullptr;
-  c->d_fb = nullptr; c->fb_cap = 0;
+  c->d_fb = nullptr; c->fb_cap = 0; c->dw_ws = nullptr; c->dw_cells = 0; c->dw_parity = 0;
   DevType h[DSIM_MAX_TYPES];
   for (int t = 0; t < n_types; ++t) { c->h_types[t] = types[t]; to_dev(types[t], &h[t]); }
   e = hipMalloc((void**)&c->d_types, sizeof(DevType) * n_types);
@@ -906,14 +937,14 @@ static int fb_prepare(dsim_ctx* ctx, long long n_pad, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     ctx->fb_cap = n_pad;
   }
-  return (int)hipMemsetAsync(ctx->d_counters + 2, 0, sizeof(unsigned long long), st);
+  return DSIM_OK;   // the queue length is reset by k_wls_fallback itself
 }
 static void fb_finish(dsim_ctx* ctx, const StepK& a, hipStream_t st) {
   if (ctx->max_act != 6) return;
   FbK f;
   f.st = a.st; f.types = a.types; f.type_id = a.type_id; f.fb = a.fb;
   f.fb.entries = ctx->d_fb;
-  hipLaunchKernelGGL(k_wls_fallback, dim3(64), dim3(64), 0, st, f);
+  hipLaunchKernelGGL(k_wls_fallback, dim3(32), dim3(64), 0, st, f);
 }
 
 // (noise, uniform) x actuator count dispatch of a general kernel
@@ -1102,7 +1133,7 @@ int dsim_traj_sample(dsim_ctx* ctx, void* stream, int64_t n, const double* coeff
 
 int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny) {
   if (m < 0 || nx < 1 || ny < 1) return -1;
-  return ((int64_t)nx * ny + 1) + (int64_t)nx * ny + 4 + 4 * m;   // count, cursor, 16-B alignment slack, float4[m]
+  return 2 * ((int64_t)nx * ny + 1) + (int64_t)nx * ny + 4 + 4 * m;   // count x2, cursor, 16-B alignment slack, float4[m]
 }
 
 static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view& state,
@@ -1117,7 +1148,7 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
   int rc = grid_build(ctx, st_, n, state, g, 10.0f, &a);
   if (rc) return rc;
   a.force_out = force_out;
-  hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m)), dim3(256), 0, st_, a);
+  hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m * DW_LPR)), dim3(256), 0, st_, a);
   return (int)hipGetLastError();
 }
 
@@ -1150,12 +1181,21 @@ static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view
   a.m = g->m; a.m_pad = g->m_pad; a.n = n; a.n_pad = state.n_pad; a.local_offset = g->local_offset;
   if (g->local_offset < 0 || g->local_offset + n > g->m || g->m >= (1LL << 31)) return DSIM_E_ARG;
   a.xmin = g->xmin; a.ymin = g->ymin; a.inv_cell = 1.0f / g->cell; a.nx = g->nx; a.ny = g->ny;
-  a.count = g->workspace; a.cursor = g->workspace + ncells + 1;
+  // two count buffers alternate between calls; the one for the next call is zeroed by k_dw_zero_next
+  const bool same = ctx->dw_ws == g->workspace && ctx->dw_cells == ncells;
+  const int cur = same ? ctx->dw_parity : 0;
+  a.count = g->workspace + (long long)cur * (ncells + 1);
+  a.count_next = g->workspace + (long long)(1 - cur) * (ncells + 1);
+  a.cursor = g->workspace + 2 * (ncells + 1);
   uintptr_t sp = (uintptr_t)(a.cursor + ncells);
   a.sorted = (float4*)((sp + 15) & ~(uintptr_t)15);
-  hipError_t e = hipMemsetAsync(a.count, 0, sizeof(int) * (ncells + 1), st_);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(k_dw_count, dim3(grid_for(a.m)), dim3(256), 0, st_, a);
+  if (!same) {   // first use of this workspace / grid shape
+    hipError_t e = hipMemsetAsync(g->workspace, 0, sizeof(int) * 2 * (ncells + 1), st_);
+    if (e != hipSuccess) return (int)e;
+    ctx->dw_ws = g->workspace; ctx->dw_cells = ncells;
+  }
+  ctx->dw_parity = 1 - cur;
+  hipLaunchKernelGGL(k_dw_count, dim3(grid_for(a.m > ncells + 1 ? a.m : ncells + 1)), dim3(256), 0, st_, a);
   hipLaunchKernelGGL(k_dw_scan, dim3(1), dim3(1024), 0, st_, a);
   hipLaunchKernelGGL(k_dw_scatter, dim3(grid_for(a.m)), dim3(256), 0, st_, a);
   a_ = a;
