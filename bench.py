@@ -60,7 +60,7 @@ class Fleet:
     """A resident fleet + per-drone hover targets at the start position."""
 
     def __init__(self, n_fleet, replicas, device, substeps, layout, noise_seed, waypoints=False, n_steps=1,
-                 config5=False, dist=None, rank=0, chained=False):
+                 config5=False, dist=None, rank=0, chained=False, hexa=False):
         import torch
         from dronesim_amd.envs import CtrlAviary, Physics
         from dronesim_amd.fleet import Targets, WaypointTargets
@@ -69,6 +69,8 @@ class Fleet:
         xyz = grid_fleet(n_fleet, replicas)
         self.n = xyz.shape[0]
         models, physics = ["robobee"], Physics.PYB
+        if hexa:
+            models = ["hexa_6DOF"]
         if config5:
             # BASELINE configs[4]: even index robobee (quad INDI), odd index
             # hexa_6DOF (6DOF INDI + WLS); positions uniform in a 1024 x 512 x [0.5, 20.5] m box so that
@@ -255,15 +257,18 @@ def main():
                     "config5_shard_65536_mixed_downwash": (65536, 1, 1, False, 1),
                     # DSIM_OPT_CHAINED: the six controller-memory fields that are functions of the stored
                     # rigid state are neither read nor written: 184 B of real traffic per drone-step
-                    "config2x1024_chained_184B": (4096, 1024, 1, False, 1)}.items():
+                    "config2x1024_chained_184B": (4096, 1024, 1, False, 1),
+                    # homogeneous morphing-hexa fleet: 6-DOF INDI + WLS allocation, 248 B/drone-step
+                    "hexa_6DOF_1048576_indi6dof_wls": (4096, 256, 1, False, 1)}.items():
                 f2 = Fleet(nf, rep, local, sub, a.layout, a.noise_seed, waypoints=wp, n_steps=ns,
-                           config5=name.startswith("config5"), chained="chained" in name)
+                           config5=name.startswith("config5"), chained="chained" in name,
+                           hexa=name.startswith("hexa"))
                 k2 = max(20, a.steps // 2)
                 w2, d2 = f2.timed(k2, 10)
                 also[name] = {"drone_steps_per_s": f2.n * k2 * ns / w2, "launch_us": d2 / k2 * 1e6,
                               "env_steps_per_launch": ns}
                 if ns == 1:
-                    bts = 184 if "chained" in name else BYTES_PER_DRONE_STEP
+                    bts = 184 if "chained" in name else (248 if name.startswith("hexa") else BYTES_PER_DRONE_STEP)
                     also[name]["hbm_frac"] = f2.n * bts / (d2 / k2) / 1e9 / HBM_PEAK_GBPS
                     also[name]["bytes_per_drone_step"] = bts
                 f2.env.close(); del f2

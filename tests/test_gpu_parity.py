@@ -657,6 +657,45 @@ def test_full_size_properties(gpu, n):
     ctx.close()
 
 
+def test_bench_size_fleet_properties(gpu):
+    """BASELINE bench size (4 194 304 drones, 0.97 GB of state): checked on the device — both layouts
+    agree bit for bit after 3 noisy steps, quaternions stay unit, PWM stays clipped, everything is
+    finite — plus an oracle check of a 1 024-drone sample (noise replayed through the oracle's
+    restatement of the same counter-based generator)."""
+    nat, fleet = gpu
+    n = 4194304
+    t = params.builtin_type("robobee")
+    ctx = fleet.Context([t])
+    rigid, mem, tgt = random_fleet(np.random.default_rng(101), n)
+    states, targets = [], []
+    for layout in ("soa", "tile64"):
+        st = fleet.FleetState(ctx, n, layout); tg = fleet.Targets(ctx, n, layout)
+        st.load_aos(rigid, mem); tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
+        states.append(st); targets.append(tg)
+    seed = 4242
+    for k in range(3):
+        a = _args(nat, 1, DT, DT, seed=seed, step_index=k)
+        for st, tg in zip(states, targets):
+            nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
+    A, B = states[0].fields(0, 24), states[1].fields(0, 24)
+    assert bool(torch.equal(A, B))
+    assert bool(torch.isfinite(A).all())
+    assert float((A[3:7].square().sum(0).sqrt() - 1).abs().max()) < 1e-6
+    assert float(A[20:24].min()) >= 0.0 and float(A[20:24].max()) <= 1.0
+    idx = np.sort(np.random.default_rng(102).choice(n, 1024, replace=False))
+    O = orc.Oracle([t])
+    r, m, tg_ = rigid[idx].copy(), mem[idx].copy(), tgt[idx].copy()
+    for k in range(3):
+        nz = np.zeros((len(idx), 1, 12))
+        for q, i in enumerate(idx):
+            u = O.noise_normals(seed, int(i), k, 4)
+            nz[q, 0, 0:4], nz[q, 0, 6:10] = u[0:4] * 0.01, u[4:8] * 0.001
+        assert O.step(r, m, tg_, 1, DT, DT, noise=nz) == 0
+    got = A[:, torch.from_numpy(idx).to(A.device)].T.double().cpu().numpy()
+    assert rel_err(got[:, :13], r, RIGID_SCALE).max() < 3 * REL_TOL
+    ctx.close()
+
+
 def test_chained_stepping(gpu):
     """DSIM_OPT_CHAINED: last_vel / last_rates recomputed from the stored rigid state instead of being read,
     and not written; materialize() restores them.  Same trajectory as the plain mode and as the oracle."""
