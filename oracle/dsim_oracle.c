@@ -808,6 +808,34 @@ void orc_downwash(const dsim_type_params* types, const uint8_t* type_id, int64_t
   }
 }
 
+/* BaseAviary._dynamics, BaseAviary.py:1767-1828: the reference's OWN explicit rigid-body model
+ * (Physics.DYN; dead code in the fork, CF2X mixer).  Not the parity target — Physics.PYB is — but an
+ * independent formulation inside the reference against which the wrench -> acceleration mapping of
+ * P2 + P4 (signs, lever arms, yaw-torque convention, semi-implicit order) can be cross-checked.
+ * state: pos3, rpy3, vel3, rpy_rates3.  L_over_sqrt2 = arm * cos(45 deg) of the X layout. */
+void orc_dynamics_step(const dsim_type_params* P, double dt, double L_over_sqrt2, const double rpm[4],
+                       double pos[3], double rpy[3], double vel[3], double rpy_rates[3]) {
+  double q[4], R[9], forces[4], zt[4];
+  orc_quat_from_euler(rpy, q);
+  orc_matrix_from_quat(q, R);                                             /* :1785 */
+  double thrust = 0;
+  for (int i = 0; i < 4; ++i) { forces[i] = rpm[i] * rpm[i] * P->kf; zt[i] = rpm[i] * rpm[i] * P->km; thrust += forces[i]; }
+  const double fw[3] = {R[2] * thrust, R[5] * thrust, R[8] * thrust - P->gravity * P->mass};   /* :1788-1791 */
+  const double z_torque = -zt[0] + zt[1] - zt[2] + zt[3];                  /* :1793 */
+  const double x_torque = (forces[0] + forces[1] - forces[2] - forces[3]) * L_over_sqrt2;       /* :1795-1797 */
+  const double y_torque = (-forces[0] + forces[1] + forces[2] - forces[3]) * L_over_sqrt2;      /* :1798-1800 */
+  double tq[3] = {x_torque, y_torque, z_torque}, Jw[3], gy[3];
+  for (int k = 0; k < 3; ++k) Jw[k] = P->inertia[k] * rpy_rates[k];
+  cross3(rpy_rates, Jw, gy);
+  for (int k = 0; k < 3; ++k) tq[k] -= gy[k];                              /* :1805 */
+  for (int k = 0; k < 3; ++k) {
+    vel[k] += dt * fw[k] / P->mass;                                        /* :1809 */
+    rpy_rates[k] += dt * tq[k] / P->inertia[k];                            /* :1810 */
+    pos[k] += dt * vel[k];                                                 /* :1811 */
+    rpy[k] += dt * rpy_rates[k];                                           /* :1812 */
+  }
+}
+
 /* trajGenerator.get_des_state + get_yaw, dronesim/utils/trajGen.py:108-143 (polyder: trajutils.py:13-21).
  * coeffs [n_seg*10][3] (row-major, as trajGenerator.coeffs), TS [n_seg+1].  yaw_state = (yaw, heading_x,
  * heading_y) is the sampler's memory (trajGen.py:128-143: yaw integrates the signed angle between
