@@ -41,7 +41,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--workload", default="config2x1024", choices=["config2x1024", "config2", "config3", "config5"])
     p.add_argument("--substeps", type=int, default=1)
-    p.add_argument("--layout", default="tile64", choices=["soa", "tile64"])
+    p.add_argument("--layout", default="tile64", choices=["soa", "tile64", "tile256", "tile1024", "tile4096"])
     p.add_argument("--noise-seed", type=int, default=1)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-also", action="store_true")

@@ -63,15 +63,20 @@ class BlockedSoA:
     """fp32 device array addressed as the C-ABI's blocked SoA.
 
     layout "soa":    tensor [F, n_pad]            (block = n_pad)
-    layout "tile64": tensor [n_pad/64, F, 64]     (one 64-drone wave tile per block)
+    layout "tileB":  tensor [n_pad/B, F, B]       (B = 64, 256, 1024, 4096: B-drone blocks, each field a
+                                                   contiguous 4B-byte row; n_pad is rounded up to a multiple of B)
     """
 
     def __init__(self, n: int, n_fields: int, device, layout: str = "soa", pad: int = 256):
-        self.n, self.n_pad, self.n_fields, self.layout = n, pad_to(n, pad), n_fields, layout
+        self.n, self.n_fields, self.layout = n, n_fields, layout
         if layout == "soa":
+            self.block = 0
+            self.n_pad = pad_to(n, pad)
             self.data = torch.zeros((n_fields, self.n_pad), dtype=torch.float32, device=device)
-        elif layout == "tile64":
-            self.data = torch.zeros((self.n_pad // 64, n_fields, 64), dtype=torch.float32, device=device)
+        elif layout.startswith("tile") and layout[4:].isdigit() and int(layout[4:]) in (64, 256, 1024, 4096):
+            self.block = B = int(layout[4:])
+            self.n_pad = pad_to(n, max(pad, B))
+            self.data = torch.zeros((self.n_pad // B, n_fields, B), dtype=torch.float32, device=device)
         else:
             raise ValueError(layout)
 
@@ -83,11 +88,11 @@ class BlockedSoA:
         if self.layout == "soa":
             v.block, v.field_stride, v.block_stride = self.n_pad, self.n_pad, self.n_pad * self.n_fields
         else:
-            v.block, v.field_stride, v.block_stride = 64, 64, 64 * self.n_fields
+            v.block, v.field_stride, v.block_stride = self.block, self.block, self.block * self.n_fields
         return v
 
     def fields(self, f0: int, nf: int) -> torch.Tensor:
-        """[nf, n] tensor of fields f0..f0+nf (a view for "soa", a gather for "tile64")."""
+        """[nf, n] tensor of fields f0..f0+nf (a view for "soa", a gather for the tiled layouts)."""
         if self.layout == "soa":
             return self.data[f0:f0 + nf, : self.n]
         return self.data[:, f0:f0 + nf, :].permute(1, 0, 2).reshape(nf, self.n_pad)[:, : self.n]
@@ -101,7 +106,7 @@ class BlockedSoA:
         else:
             full = torch.zeros((nf, self.n_pad), dtype=torch.float32, device=self.data.device)
             full[:, : self.n] = vals
-            self.data[:, f0:f0 + nf, :] = full.reshape(nf, self.n_pad // 64, 64).permute(1, 0, 2)
+            self.data[:, f0:f0 + nf, :] = full.reshape(nf, self.n_pad // self.block, self.block).permute(1, 0, 2)
 
 
 class FleetState(BlockedSoA):
