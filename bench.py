@@ -66,6 +66,7 @@ class Fleet:
         from dronesim_amd.fleet import Targets, WaypointTargets
         self.torch = torch
         self.n_steps = n_steps
+        self.graph = None
         xyz = grid_fleet(n_fleet, replicas)
         self.n = xyz.shape[0]
         models, physics = ["robobee"], Physics.PYB
@@ -100,7 +101,15 @@ class Fleet:
         self.env.step_fused(self.tgt, action=np.full((self.n, self.env.n_act), 0.4, dtype=np.float32))
 
     def step(self):
-        self.env.step_fused(self.tgt, n_steps=self.n_steps)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.env.step_fused(self.tgt, n_steps=self.n_steps)
+
+    def use_graph(self, steps):
+        """Replay `steps` fused launches per step() call from one captured hipGraph."""
+        self.graph = self.env.capture_fused(self.tgt, steps)
+        self.n_steps = steps
 
     def timed(self, steps, warmup, barrier=None):
         torch = self.torch
@@ -251,7 +260,9 @@ def main():
             for name, (nf, rep, sub, wp, ns) in {
                     "config2_single_fleet_4096_sub5": (4096, 1, 5, False, 1),
                     "config2_single_fleet_4096_sub5_32steps_per_launch": (4096, 1, 5, False, 32),
+                    "config2_single_fleet_4096_sub5_hipgraph_of_32_launches": (4096, 1, 5, False, 32),
                     "config3_65536_waypoints_sub2": (65536, 1, 2, True, 1),
+                    "config3_65536_waypoints_sub2_hipgraph_of_32_launches": (65536, 1, 2, True, 32),
                     "config3_65536_waypoints_sub2_32steps_per_launch": (65536, 1, 2, True, 32),
                     "config2x1024_sub5": (4096, 1024, 5, False, 1),
                     "config5_shard_65536_mixed_downwash": (65536, 1, 1, False, 1),
@@ -263,6 +274,9 @@ def main():
                 f2 = Fleet(nf, rep, local, sub, a.layout, a.noise_seed, waypoints=wp, n_steps=ns,
                            config5=name.startswith("config5"), chained="chained" in name,
                            hexa=name.startswith("hexa"))
+                if "hipgraph" in name:
+                    f2.n_steps = 1
+                    f2.use_graph(ns)
                 k2 = max(20, a.steps // 2)
                 w2, d2 = f2.timed(k2, 10)
                 also[name] = {"drone_steps_per_s": f2.n * k2 * ns / w2, "launch_us": d2 / k2 * 1e6,

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libdronesim_amd.so")
 # every symbol include/dronesim_amd.h declares
 EXPORTS = (
     "dsim_abi_version", "dsim_strerror", "dsim_create", "dsim_destroy", "dsim_reset", "dsim_step",
-    "dsim_physics", "dsim_control", "dsim_step_adaptor", "dsim_traj_sample", "dsim_materialize", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash", "dsim_downwash_workspace", "dsim_adjacency",
+    "dsim_physics", "dsim_control", "dsim_step_adaptor", "dsim_traj_sample", "dsim_materialize", "dsim_counter_add", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash", "dsim_downwash_workspace", "dsim_adjacency",
 )
 
 ABI_VERSION = 2
@@ -54,6 +54,7 @@ class StepArgs(ctypes.Structure):
         ("n_wp", ctypes.c_int32),
         ("n_steps", ctypes.c_int32),
         ("ext_force", ctypes.c_void_p),
+        ("step_index_dev", ctypes.c_void_p),
     ]
 
 
@@ -108,6 +109,7 @@ def load() -> ctypes.CDLL:
     lib.dsim_step_adaptor.argtypes = [vp, vp, i64, View, vp, i32, vp, ctypes.POINTER(StepArgs)]
     lib.dsim_traj_sample.argtypes = [vp, vp, i64, vp, vp, i32, vp, ctypes.c_double, vp, vp, View]
     lib.dsim_materialize.argtypes = [vp, vp, i64, View]
+    lib.dsim_counter_add.argtypes = [vp, vp, vp, ctypes.c_uint64]
     lib.dsim_observe.argtypes = [vp, vp, i64, View, vp, vp, i32]
     lib.dsim_observe_soa.argtypes = [vp, vp, i64, View, vp, vp, i32]
     lib.dsim_query.argtypes = [vp, vp, i32, ctypes.POINTER(ctypes.c_int64)]

@@ -76,6 +76,7 @@ struct StepK {
   int* wp_counter;
   const float* wp_offset;
   const float* ext_force;     // SoA [3][n_pad] body-frame force at the COM, or null
+  const unsigned long long* step_index_dev;   // added to step_index (graph replay), or null
   int n_wp, n_steps;
   unsigned long long seed, step_index;
   int substeps;
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
   load_mem<4, NT, CH>(sb, sfs, sl, m);
   if (CH) { m.last_vel = s.vel; m.last_rates = mulT(matrix_from_quat(s.q), s.w); }
   const long long i = i0 + threadIdx.x;
+  if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;    // wave-uniform scalar load
   V3 pos_e;
   float yaw_e;
   if (!EXT) {
@@ -267,6 +269,8 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
   store_rigid<NT>(sb, sfs, sl, s);
   store_mem<4, NT, CH>(sb, sfs, sl, m);
 }
+
+__global__ void k_counter_add(unsigned long long* c, unsigned long long inc) { *c += inc; }
 
 // ends a chained sequence: last_vel / last_rates back into the state block
 struct MatK { KView st; long long n_pad; };
@@ -356,6 +360,7 @@ __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_step_gen(StepK a) {
   const long long i0 = a.first + (long long)blockIdx.x * 256;
   const long long i = i0 + threadIdx.x;
   if (i >= a.n_pad) return;
+  if (a.step_index_dev) a.step_index += *a.step_index_dev;
   const Addr ad = make_addr(a, i0);
   DSIM_FOR_MY_TYPE(UNIFORM, a, i, (step_gen_body<NOISE, NACT, true>(T, a, i, ad)));
 }
@@ -364,6 +369,7 @@ __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_step_lean(StepK a) {
   const long long i0 = a.first + (long long)blockIdx.x * 256;
   const long long i = i0 + threadIdx.x;
   if (i >= a.n_pad) return;
+  if (a.step_index_dev) a.step_index += *a.step_index_dev;
   const Addr ad = make_addr(a, i0);
   DSIM_FOR_MY_TYPE(UNIFORM, a, i, (step_gen_body<NOISE, NACT, false>(T, a, i, ad)));
 }
@@ -916,7 +922,7 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
   a->n_pad = state.n_pad; a->first = 0; a->seed = args->noise_seed;
   a->wp_table = args->wp_table; a->wp_counter = args->wp_counter; a->wp_offset = args->wp_offset;
   a->n_wp = args->n_wp; a->n_steps = args->n_steps > 1 ? args->n_steps : 1;
-  a->ext_force = args->ext_force;
+  a->ext_force = args->ext_force; a->step_index_dev = (const unsigned long long*)args->step_index_dev;
   if (a->wp_table && (!a->wp_counter || a->n_wp < 1)) return DSIM_E_ARG;
   a->step_index = args->step_index;
   a->substeps = args->phys_substeps; a->dt_phys = args->dt_phys; a->dt_ctrl = args->dt_ctrl;
@@ -1025,6 +1031,13 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
       }
     }
   }
+  return (int)hipGetLastError();
+}
+
+int dsim_counter_add(dsim_ctx* ctx, void* stream, uint64_t* counter, uint64_t inc) {
+  if (!ctx || !counter) return DSIM_E_ARG;
+  hipLaunchKernelGGL(k_counter_add, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)counter,
+                     (unsigned long long)inc);
   return (int)hipGetLastError();
 }
 

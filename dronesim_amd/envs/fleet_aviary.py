@@ -263,6 +263,17 @@ class CtrlAviary:
             if not self._chained_enabled or chain:
                 self._fused_plan = (key, nxt, sview, tview, ctypes.byref(nxt))
 
+    def capture_fused(self, targets, steps: int, control_timestep: Optional[float] = None):
+        """Captures ``steps`` consecutive :meth:`step_fused` launches into ONE hipGraph and returns a
+        ``FusedGraph`` whose ``replay()`` runs them with a single host call.  For small fleets the loop is
+        launch-latency bound (a few us per launch from Python; 10-16 us per graph replay whatever its
+        length), which is what a graph removes.  Kernel arguments are frozen at capture time, so the
+        env-step counter that seeds the rotor noise lives in device memory and is advanced by a
+        one-thread kernel after every step (``step_index_dev``).  Quad fleets, plain/waypoint targets."""
+        if self.n_act != 4 or self._downwash is not None:
+            raise NotImplementedError("graph capture: quad fleets without the downwash exchange")
+        return FusedGraph(self, targets, steps, control_timestep)
+
     def close(self):
         self.ctx.close()
 
@@ -328,6 +339,55 @@ class CtrlAviary:
     @staticmethod
     def _computeInfo():
         return {"answer": 42}                       # CtrlAviary.py:299-310
+
+
+class FusedGraph:
+    """A captured sequence of fused steps (see :meth:`CtrlAviary.capture_fused`)."""
+
+    def __init__(self, env: CtrlAviary, targets, steps: int, control_timestep):
+        self.env, self.steps = env, steps
+        env.materialize()
+        dev = env.ctx.device
+        self._counter = torch.zeros((1,), dtype=torch.int64, device=dev)
+        wp = isinstance(targets, WaypointTargets)
+        self._args = env.step_args(control_timestep, nat.OPT_BCAST_TGT if targets.broadcast else 0)
+        self._args.step_index = 0
+        self._args.step_index_dev = self._counter.data_ptr()
+        if wp:
+            targets.fill(self._args)
+            self._tview = nat.View()
+        else:
+            self._tview = targets.view()
+        self._sview = env.state.view()
+        self._targets = targets
+        lib, h, n = env.ctx.lib, env.ctx.handle, env.NUM_DRONES
+        self._graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            # one untimed eager pass on the side stream (lazy module loading must not happen under capture)
+            nat.check(lib.dsim_counter_add(h, side.cuda_stream, self._counter.data_ptr(), 0))
+            with torch.cuda.graph(self._graph, stream=side):
+                sp = torch.cuda.current_stream(dev).cuda_stream
+                for i in range(steps):
+                    self._args.step_index = i          # frozen offset; the base is read from the device counter
+                    nat.check(lib.dsim_step(h, sp, n, self._sview, self._tview, ctypes.byref(self._args)))
+                nat.check(lib.dsim_counter_add(h, sp, self._counter.data_ptr(), steps))
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self._counter_host = 0
+
+    def replay(self) -> None:
+        env = self.env
+        env.materialize()
+        if self._counter_host != env._env_steps:  # eager steps in between: realign the noise stream
+            self._counter.fill_(env._env_steps)
+        self._graph.replay()
+        self._counter_host = env._env_steps + self.steps
+        env._use_last_action = False
+        env._chain_ok = True
+        env._fused_plan = None
+        env.step_counter += env.AGGR_PHY_STEPS * self.steps
+        env._env_steps += self.steps
 
 
 class _AdaptorAviary(CtrlAviary):

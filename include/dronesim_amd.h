@@ -154,6 +154,11 @@ typedef struct dsim_step_args {
    * nullable; SoA [3][n_pad]: extra force applied at the COM in the LINK frame every sub-step, e.g.
    * the neighbour downwash of dsim_downwash (BaseAviary.py:1755-1762 applies it to link 4 = COM).   */
   const float* ext_force;
+  /* -- graph replay -----------------------------------------------------------------------------------
+   * nullable device pointer; the effective env-step counter is step_index + *step_index_dev.  Lets a
+   * captured hipGraph of [dsim_step, dsim_counter_add] pairs be replayed without repeating the noise
+   * stream (kernel arguments are frozen at capture time, device memory is not).                        */
+  const uint64_t* step_index_dev;
 } dsim_step_args;
 
 typedef struct dsim_ctx dsim_ctx;
@@ -181,6 +186,9 @@ int dsim_reset(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state,
  * i.e. the body of the example loop (examples/fly_INDI.py:223-239).             */
 int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
               const dsim_step_args* args);
+
+/* *counter += inc on the stream (a one-thread kernel; the companion of step_index_dev). */
+int dsim_counter_add(dsim_ctx* ctx, void* stream, uint64_t* counter, uint64_t inc);
 
 /* Rewrites last_vel / last_rates from the rigid state (ends a DSIM_OPT_CHAINED sequence). */
 int dsim_materialize(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state);

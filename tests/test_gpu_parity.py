@@ -696,6 +696,28 @@ def test_bench_size_fleet_properties(gpu):
     ctx.close()
 
 
+def test_graph_replay_equals_eager_steps(gpu, golden_dir):
+    """hipGraph of 8 fused steps, replayed 3 times == 24 eager steps, bit for bit, rotor noise on (the
+    env-step counter that seeds it is read from device memory inside the captured kernels)."""
+    n = 4096
+    envA, wpA, *_ = _traj_fleet(gpu, golden_dir, n, noise_seed=1234)
+    envB, wpB, *_ = _traj_fleet(gpu, golden_dir, n, noise_seed=1234)
+    a0 = np.full((n, 4), 0.4, dtype=np.float32)
+    envA.step_fused(wpA, action=a0); envB.step_fused(wpB, action=a0)
+    for _ in range(24):
+        envA.step_fused(wpA)
+    g = envB.capture_fused(wpB, steps=8)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(envA.state.fields(0, 24).cpu().numpy(), envB.state.fields(0, 24).cpu().numpy())
+    np.testing.assert_array_equal(wpA.counters.cpu().numpy(), wpB.counters.cpu().numpy())
+    assert envA._env_steps == envB._env_steps == 25
+    envB.step_fused(wpB); envA.step_fused(wpA)               # eager stepping continues seamlessly after a replay
+    np.testing.assert_array_equal(envA.state.fields(0, 24).cpu().numpy(), envB.state.fields(0, 24).cpu().numpy())
+    envA.close(); envB.close()
+
+
 def test_chained_stepping(gpu):
     """DSIM_OPT_CHAINED: last_vel / last_rates recomputed from the stored rigid state instead of being read,
     and not written; materialize() restores them.  Same trajectory as the plain mode and as the oracle."""
