@@ -13,7 +13,11 @@
  *     reference's own INDIControl / INDIControl_6DOF / wls_alloc / utils.math
  *     code (tests/golden/make_goldens.py; the three pybullet closed-form math
  *     helpers are a stand-in there, see that file's header).
- *   physics half (P2..P4): "PARITY UNPINNED".  The reference delegates rigid-body
+ *   env-side half (P0..P3 force map, P6..P8 aero terms, action adaptors): PINNED by
+ *     recordings of what the reference's own BaseAviary._physics/_drag/_groundEffect/
+ *     _downwash/_preprocessAction hand to the engine (tests/golden/env_side.npz,
+ *     tests/test_oracle_env_side.py).
+ *   integrator (P4): "PARITY UNPINNED".  The reference delegates rigid-body
  *     integration to the third-party engine PyBullet (`pybullet`, version
  *     unpinned in setup.py:14, not vendored, not installed, no network).  P4 below
  *     restates Bullet 3.x's published btMultiBody floating-base step

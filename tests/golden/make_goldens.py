@@ -270,8 +270,187 @@ def run_sequence(ctrl_cls, model, rng, n_seq, n_steps, dt):
     return S
 
 
+# ----------------------------------------------------------------------------
+# Env-side pieces of the path: the reference's OWN force-map / aero / action-adaptor
+# code run against recording stand-ins for the Bullet calls it makes
+# ----------------------------------------------------------------------------
+def capture_env_side():
+    """BaseAviary._physics (P2/P3), _drag (P6), _groundEffect (P7), _downwash (P8),
+    CtrlAviary/VelocityAviary/RPYTAviary._preprocessAction (P1, adaptors) are plain methods that
+    read a few attributes of `self` and talk to Bullet only through p.applyExternalForce /
+    p.applyExternalTorque / p.getLinkStates.  They are called here UNBOUND on a namespace object
+    carrying those attributes, with recorders in place of the three Bullet calls: what is stored
+    is every (link, vector, frame flag) the reference hands to the engine.  The Drone records come
+    from the reference's own URDF parser (BaseAviary._parseURDFParameters)."""
+    import pybullet as p                                  # the in-memory stand-in module
+    from types import SimpleNamespace as NS
+    from dronesim.envs.BaseAviary import BaseAviary, Drone
+    from dronesim.envs.CtrlAviary import CtrlAviary
+    from dronesim.envs.VelocityAviary import VelocityAviary
+    from dronesim.envs.RPYTAviary import RPYTAviary
+    from dronesim.control.INDIControl import INDIControl
+
+    calls = []
+    p.LINK_FRAME, p.WORLD_FRAME = 1, 2                   # Bullet's enum values
+    p.applyExternalForce = lambda body, link, forceObj, posObj, flags, physicsClientId=0: calls.append(
+        (0, link, [float(x) for x in forceObj], [float(x) for x in posObj], flags))
+    p.applyExternalTorque = lambda body, link, torqueObj, flags, physicsClientId=0: calls.append(
+        (1, link, [float(x) for x in torqueObj], [0.0, 0.0, 0.0], flags))
+
+    def drone_of(model):
+        return Drone(*BaseAviary._parseURDFParameters(None, model + ".urdf"))
+
+    out = {}
+    # ---- P0: every scalar the reference's URDF parser yields ------------------
+    for model in ("robobee", "tello", "hexa_6DOF"):
+        d = drone_of(model)
+        for k in ("M", "L", "KF", "KM", "MAX_SPEED_KMH", "GND_EFF_COEFF", "PROP_RADIUS", "DW_COEFF_1",
+                  "DW_COEFF_2", "DW_COEFF_3", "INDI_ACTUATOR_NR", "INDI_OUTPUT_NR"):
+            out[f"{model}_{k}"] = np.array(getattr(d, k))
+        for k in ("J", "DRAG_COEFF", "PWM2RPM_SCALE", "PWM2RPM_CONST", "G1", "MIN_PWM", "MAX_PWM"):
+            out[f"{model}_{k}"] = np.array(getattr(d, k), dtype=np.float64)
+        out[f"{model}_TYPE"] = np.array(d.TYPE)
+
+    # ---- P2 / P3: rotor force map incl. the noise draws -----------------------
+    rng = np.random.default_rng(31)
+    for model in ("robobee", "tello", "hexa_6DOF"):
+        d = drone_of(model)
+        # _physics dispatches to self._quad_copter_physics / self._morphing_hexa_physics: bind the reference's own
+        Fake = type("Fake", (), {"_quad_copter_physics": BaseAviary._quad_copter_physics,
+                                 "_morphing_hexa_physics": BaseAviary._morphing_hexa_physics})
+        fake = Fake()
+        fake.drones, fake.DRONE_IDS, fake.CLIENT = [d], [7], 0
+        n_act, K = d.INDI_ACTUATOR_NR, 24
+        cmds = rng.uniform(np.array(d.MIN_PWM), np.array(d.MAX_PWM), (K, n_act))
+        cmds[0] = 0.4
+        cmds[1] = np.array(d.MAX_PWM)
+        cmds[2] = np.array(d.MIN_PWM)
+        seeds = 5000 + np.arange(K)
+        rec_kind, rec_link, rec_vec, rec_pos, rec_flag, fn, mn = [], [], [], [], [], [], []
+        for i in range(K):
+            np.random.seed(int(seeds[i]))                 # the reference draws from the global numpy RNG
+            calls.clear()
+            BaseAviary._physics(fake, cmds[i].copy(), 0)
+            rec_kind.append([c[0] for c in calls]); rec_link.append([c[1] for c in calls])
+            rec_vec.append([c[2] for c in calls]); rec_pos.append([c[3] for c in calls])
+            rec_flag.append([c[4] for c in calls])
+            np.random.seed(int(seeds[i]))                 # the same stream again, as plain inputs for the oracle:
+            fn.append(np.random.normal(0, 0.01, n_act))   # f_noise first, m_noise second (BaseAviary.py:1518-1521, 1429-1430)
+            mn.append(np.random.normal(0, 0.001, n_act))
+        out.update({f"{model}_fm_cmd": cmds, f"{model}_fm_seed": seeds, f"{model}_fm_kind": np.array(rec_kind),
+                    f"{model}_fm_link": np.array(rec_link), f"{model}_fm_vec": np.array(rec_vec),
+                    f"{model}_fm_pos": np.array(rec_pos), f"{model}_fm_flag": np.array(rec_flag),
+                    f"{model}_fm_f_noise": np.array(fn), f"{model}_fm_m_noise": np.array(mn)})
+
+    # ---- P6 / P7 / P8: aero add-ons (dead code in the fork: they read self.KF etc., which the fork
+    #      moved into self.drones[i]; the attributes are supplied from the parsed Drone) ----------
+    d = drone_of("robobee")
+    K = 32
+    rpy = np.stack([rng.uniform(-1.9, 1.9, K), rng.uniform(-1.4, 1.4, K), rng.uniform(-3.1, 3.1, K)], 1)
+    rpy[0] = 0.0
+    quat = np.stack([quat_from_euler(*e) for e in rpy])
+    # what getEulerFromQuaternion hands back for that quaternion (what BaseAviary stores in self.rpy)
+    rpy_store = np.stack([_getEulerFromQuaternion(q) for q in quat])
+    vel = rng.uniform(-3, 3, (K, 3))
+    rpm = rng.uniform(2000, 19000, (K, 4))
+    pos = np.stack([rng.uniform(-2, 2, K), rng.uniform(-2, 2, K), rng.uniform(0.02, 1.0, K)], 1)
+    h_clip = 0.05                                          # GND_EFF_H_CLIP: its definition is commented out (BaseAviary.py:235)
+    prop_h = rng.uniform(0.01, 0.6, (K, 4))                 # rotor heights getLinkStates would report (inputs)
+    drag_vec, gnd_vec, gnd_n = [], [], []
+    for i in range(K):
+        fake = NS(DRONE_IDS=[7], CLIENT=0, quat=quat[i:i + 1], vel=vel[i:i + 1], rpy=rpy_store[i:i + 1],
+                  DRAG_COEFF=d.DRAG_COEFF, KF=d.KF, GND_EFF_COEFF=d.GND_EFF_COEFF, PROP_RADIUS=d.PROP_RADIUS,
+                  GND_EFF_H_CLIP=h_clip)
+        calls.clear()
+        BaseAviary._drag(fake, rpm[i].copy(), 0)
+        assert len(calls) == 1 and calls[0][1] == 4 and calls[0][4] == p.LINK_FRAME
+        drag_vec.append(calls[0][2])
+        # Bullet returns ragged per-link tuples (pos3, orn4, ...), which numpy >= 1.24 refuses to pack the way
+        # the reference's np.array(...) expects; the stand-in pads every field to 4 so that the reference's
+        # `link_states[j, 0][2]` reads the same number: the rotor height, an INPUT of this case
+        p.getLinkStates = lambda body, linkIndices, computeLinkVelocity, computeForwardKinematics, physicsClientId, _i=i: [
+            [(0.0, 0.0, float(prop_h[_i, j]) if j < 4 else float(pos[_i, 2]), 0.0)] + [(0.0, 0.0, 0.0, 1.0)] * 7
+            for j in linkIndices]
+        calls.clear()
+        try:
+            BaseAviary._groundEffect(fake, rpm[i].copy(), 0)
+            g = np.zeros(4)
+            for c in calls:
+                assert c[0] == 0 and c[4] == p.LINK_FRAME and c[2][0] == 0 and c[2][1] == 0
+                g[c[1]] = c[2][2]
+            gnd_vec.append(g); gnd_n.append(len(calls))
+        except Exception as e:                              # numpy's ragged-array refusal on newer versions
+            raise RuntimeError(f"_groundEffect did not run: {e}")
+    out.update(aero_quat=quat, aero_rpy=rpy_store, aero_vel=vel, aero_rpm=rpm, aero_pos=pos, aero_prop_h=prop_h,
+               aero_h_clip=np.array(h_clip), aero_drag=np.array(drag_vec), aero_gnd=np.array(gnd_vec),
+               aero_gnd_calls=np.array(gnd_n))
+    # downwash: a small world, force on every drone
+    M = 48
+    wpos = np.stack([rng.uniform(0, 14, M), rng.uniform(0, 14, M), rng.uniform(0.5, 6, M)], 1)
+    wpos[1] = wpos[0] + [0.0, 0.0, 0.5]                      # directly above
+    wpos[3] = wpos[2] + [9.99, 0.0, 1.0]                     # just inside / just outside the 10 m cut
+    wpos[5] = wpos[4] + [10.01, 0.0, 1.0]
+    fake = NS(DRONE_IDS=list(range(M)), CLIENT=0, NUM_DRONES=M, pos=wpos, DW_COEFF_1=d.DW_COEFF_1,
+              DW_COEFF_2=d.DW_COEFF_2, DW_COEFF_3=d.DW_COEFF_3, PROP_RADIUS=d.PROP_RADIUS)
+    dw = np.zeros(M)
+    for i in range(M):
+        calls.clear()
+        BaseAviary._downwash(fake, i)
+        for c in calls:
+            assert c[0] == 0 and c[1] == 4 and c[4] == p.LINK_FRAME and c[2][0] == 0 and c[2][1] == 0
+            dw[i] += c[2][2]
+    out.update(dw_pos=wpos, dw_fz=dw)
+
+    # ---- P1 + the two alternate action adaptors -------------------------------
+    d = drone_of("robobee")
+    a = rng.uniform(-0.5, 1.5, (16, 4))
+    clipped = CtrlAviary._preprocessAction(NS(drones=[d]), {"0": a[0]})
+    out["clip_in"] = a
+    out["clip_out"] = np.stack([CtrlAviary._preprocessAction(NS(drones=[d]), {"0": v})["0"] for v in a])
+    K = 48
+    for model in ("robobee", "tello"):
+        d = drone_of(model)
+        ctrl = INDIControl(drone_model=model)
+        rpy = np.stack([rng.uniform(-0.6, 0.6, K), rng.uniform(-0.6, 0.6, K), rng.uniform(-3.1, 3.1, K)], 1)
+        st = np.zeros((K, 20))
+        st[:, 0:3] = rng.uniform(-2, 2, (K, 3))
+        st[:, 3:7] = np.stack([quat_from_euler(*e) for e in rpy])
+        st[:, 7:10] = np.stack([_getEulerFromQuaternion(q) for q in st[:, 3:7]])
+        st[:, 10:13] = rng.uniform(-1, 1, (K, 3))
+        st[:, 13:16] = rng.uniform(-1, 1, (K, 3))
+        mem = {"last_vel": st[:, 10:13] + rng.normal(0, 0.02, (K, 3)), "last_rates": rng.uniform(-1, 1, (K, 3)),
+               "last_thrust": rng.uniform(-1, 1, K), "cmd": rng.uniform(0.2, 0.8, (K, 4))}
+        act_v = np.concatenate([rng.normal(0, 1, (K, 3)), rng.uniform(-1, 1, (K, 1))], 1)
+        act_v[0, :3] = 0.0                                   # zero direction: v_unit_vector = 0 branch
+        act_r = np.concatenate([rng.uniform(-2, 2, (K, 3)), rng.uniform(-1, 1, (K, 1))], 1)
+        res = {}
+        for name, cls, acts in (("vel", VelocityAviary, act_v), ("rpyt", RPYTAviary, act_r)):
+            o_cmd, o_lv, o_lr, o_lt = [], [], [], []
+            for i in range(K):
+                ctrl.reset()
+                ctrl.last_vel, ctrl.last_rates = mem["last_vel"][i].copy(), mem["last_rates"][i].copy()
+                ctrl.last_thrust, ctrl.cmd = float(mem["last_thrust"][i]), mem["cmd"][i].copy()
+                fake = NS(ctrl=[ctrl], AGGR_PHY_STEPS=5, TIMESTEP=1 / 240, SPEED_LIMIT=[d.MAX_SPEED_KMH * (1000 / 3600)],
+                          _getDroneStateVector=lambda k, _i=i: st[_i].copy())
+                r = cls._preprocessAction(fake, {"0": acts[i].copy()})["0"]
+                o_cmd.append(np.array(r)); o_lv.append(ctrl.last_vel.copy()); o_lr.append(np.array(ctrl.last_rates).copy())
+                o_lt.append(ctrl.last_thrust)
+            res[name] = (np.array(o_cmd), np.array(o_lv), np.array(o_lr), np.array(o_lt))
+        out.update({f"{model}_ad_state": st, f"{model}_ad_last_vel": mem["last_vel"], f"{model}_ad_last_rates": mem["last_rates"],
+                    f"{model}_ad_last_thrust": mem["last_thrust"], f"{model}_ad_cmd": mem["cmd"],
+                    f"{model}_ad_vel_action": act_v, f"{model}_ad_rpyt_action": act_r})
+        for name in ("vel", "rpyt"):
+            out.update({f"{model}_ad_{name}_cmd_out": res[name][0], f"{model}_ad_{name}_last_vel_out": res[name][1],
+                        f"{model}_ad_{name}_last_rates_out": res[name][2], f"{model}_ad_{name}_last_thrust_out": res[name][3]})
+    np.savez(os.path.join(OUT, "env_side.npz"), **out)
+    print("env-side goldens written")
+
+
 def main():
     install_standins()
+    if len(sys.argv) > 1 and sys.argv[1] == "env":        # only the env-side file
+        capture_env_side()
+        return
     from dronesim.control.INDIControl import INDIControl
     from dronesim.control.INDIControl_6DOF import INDIControl as INDIControl_6DOF  # same class name in both modules
     from dronesim.control.wls_alloc import wls_alloc
@@ -366,6 +545,7 @@ def main():
     np.savez(os.path.join(OUT, "traj_track_waypoints.npz"), TS=traj.TS, coeffs=traj.coeffs,
              t=ts, target_pos=np.array(P), target_vel=np.array(V), target_acc=np.array(Ac),
              target_yaw=np.array(Y), gates=gates)
+    capture_env_side()
     print("goldens written to", OUT)
 
 

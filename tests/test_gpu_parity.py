@@ -246,6 +246,46 @@ def test_noise_replay_vs_oracle(gpu):
     ctx.close()
 
 
+@pytest.mark.parametrize("model", ["robobee", "tello", "hexa_6DOF"])
+def test_force_map_vs_reference_recorded_calls(gpu, golden_dir, model):
+    """The wrench the kernel applies == the sum of the applyExternalForce/applyExternalTorque calls the
+    reference's own _physics made for the same command and noise draws (tests/golden/env_side.npz):
+    from level rest one sub-step gives v = (F/m - g z) dt and w = J^-1 tau dt (no damping, no gyro term)."""
+    nat, fleet = gpu
+    G = np.load(os.path.join(golden_dir, "env_side.npz"))
+    t = params.builtin_type(model)
+    na = t.n_act
+    cmd, fn, mn, vec = (G[f"{model}_fm_{k}"] for k in ("cmd", "f_noise", "m_noise", "vec"))
+    n = cmd.shape[0]
+    r, ax = np.asarray(t.rotor_pos)[:na], np.asarray(t.rotor_axis)[:na]
+    if na == 4:
+        F = vec[:, :4].sum(1)
+        tau = np.cross(r[None], vec[:, :4]).sum(1) + vec[:, 4]
+    else:
+        f = ax[None] * vec[:, 0::2, 2:3]
+        F = f.sum(1)
+        tau = np.cross(r[None], f).sum(1) + (ax[None] * vec[:, 1::2, 2:3]).sum(1)
+    ctx = fleet.Context([t])
+    st = fleet.FleetState(ctx, n)
+    rigid = np.zeros((n, 13)); rigid[:, 2] = 1.0; rigid[:, 6] = 1.0
+    st.load_aos(rigid, np.zeros((n, 13)))
+    act = torch.zeros((na, st.n_pad), device=ctx.device)
+    act[:, :n] = torch.from_numpy(np.ascontiguousarray(cmd.T)).float()
+    replay = torch.zeros((1, 2 * na, st.n_pad), device=ctx.device)
+    replay[0, 0:na, :n] = torch.from_numpy(np.ascontiguousarray(fn.T)).float()
+    replay[0, na:2 * na, :n] = torch.from_numpy(np.ascontiguousarray(mn.T)).float()
+    last = torch.zeros((na, st.n_pad), device=ctx.device)
+    a = _args(nat, 1, DT, DT, replay=replay, action=act)
+    nat.check(ctx.lib.dsim_physics(ctx.handle, _stream(ctx), n, st.view(), last.data_ptr(), ctypes.byref(a)))
+    torch.cuda.synchronize()
+    got = st.rigid_aos()
+    v = (F / t.mass + np.array([0, 0, -t.gravity])) * DT
+    w = tau / np.asarray(t.inertia)[None] * DT
+    np.testing.assert_allclose(got[:, 7:10], v, rtol=REL_TOL, atol=REL_TOL * np.abs(v).max())
+    np.testing.assert_allclose(got[:, 10:13], w, rtol=REL_TOL, atol=REL_TOL * np.abs(w).max())
+    ctx.close()
+
+
 def test_inkernel_noise_matches_definition(gpu):
     """In-kernel Philox/Box-Muller noise == the oracle's restatement of the same definition;
     and it is N(0,.01)/N(0,.001)-distributed."""
@@ -849,6 +889,43 @@ def test_action_adaptor_envs_vs_oracle(gpu, mode):
     assert rel_err(env.state.mem_aos(), mem, MEM_SCALE).max() < 5 * REL_TOL
     np.testing.assert_allclose(obs[:, 16:20].cpu().numpy(), mem[:, 7:11], atol=5e-4)  # echoed command
     env.close()
+
+
+@pytest.mark.parametrize("model", ["robobee", "tello"])
+@pytest.mark.parametrize("mode", ["vel", "rpyt"])
+def test_action_adaptors_vs_reference_golden(gpu, golden_dir, model, mode):
+    """dsim_step_adaptor against what the reference's own VelocityAviary / RPYTAviary._preprocessAction
+    returned on the same states (tests/golden/env_side.npz): command and controller memory."""
+    nat, fleet = gpu
+    G = np.load(os.path.join(golden_dir, "env_side.npz"))
+    g = lambda k: G[f"{model}_ad_{k}"]
+    t = params.builtin_type(model)
+    ctx = fleet.Context([t])
+    sv = g("state")
+    n = sv.shape[0]
+    rigid = np.concatenate([sv[:, 0:7], sv[:, 10:16]], 1)
+    mem = np.zeros((n, 13))
+    mem[:, 0:3], mem[:, 3:6], mem[:, 6], mem[:, 7:11] = g("last_vel"), g("last_rates"), g("last_thrust"), g("cmd")
+    st = fleet.FleetState(ctx, n)
+    st.load_aos(rigid, mem)
+    act = torch.zeros((4, st.n_pad), device=ctx.device)
+    act[:, :n] = torch.from_numpy(np.ascontiguousarray(g(f"{mode}_action").T)).float()
+    last = torch.zeros((6, st.n_pad), device=ctx.device)
+    a = _args(nat, 5, DT, float(np.float32(5 / 240)))
+    nat.check(ctx.lib.dsim_step_adaptor(ctx.handle, _stream(ctx), n, st.view(), act.data_ptr(),
+                                        nat.ADAPT_VELOCITY if mode == "vel" else nat.ADAPT_RPYT, last.data_ptr(),
+                                        ctypes.byref(a)))
+    torch.cuda.synchronize()
+    got = st.mem_aos()
+    roll = np.array([orc.euler_from_quat(q)[0] for q in sv[:, 3:7]])
+    amp = 1.0 / np.maximum(np.abs(np.cos(roll)), 1e-3) if mode == "vel" else np.ones(n)
+    err = np.abs(got[:, 7:11] - g(f"{mode}_cmd_out")).max(1)
+    assert (err <= REL_TOL * (1 + amp)).all(), (err.max(), int(np.argmax(err)))
+    np.testing.assert_allclose(got[:, 3:6], g(f"{mode}_last_rates_out"), rtol=0, atol=3e-6)
+    lt = g(f"{mode}_last_thrust_out")
+    assert (np.abs(got[:, 6] - lt) <= REL_TOL * (1 + np.abs(lt)) * (1 + amp)).all()
+    np.testing.assert_allclose(last[:4, :n].T.cpu().numpy(), got[:, 7:11], rtol=0, atol=0)   # echoed into the env's action buffer
+    ctx.close()
 
 
 def test_device_logger_matches_reference_layout(gpu, tmp_path):
