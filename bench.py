@@ -76,8 +76,12 @@ class Fleet:
             # BASELINE configs[4]: even index robobee (quad INDI), odd index
             # hexa_6DOF (6DOF INDI + WLS); positions uniform in a 1024 x 512 x [0.5, 20.5] m box so that
             # downwash pairs exist; neighbour downwash on; this rank's shard of the world fleet
+            # sharded runs: slab decomposition along x (rank r owns x in [r, r+1) * 1024/world), positions exchanged
+            # between neighbouring slabs only (downwash.HaloExchange: grouped RCCL send/recv)
             rng = np.random.default_rng(1234 + rank)
-            xyz = np.stack([rng.uniform(0, 1024, self.n), rng.uniform(0, 512, self.n), rng.uniform(0.5, 20.5, self.n)], 1)
+            world = dist.get_world_size() if dist is not None else 1
+            xyz = np.stack([rng.uniform(rank * 1024 / world, (rank + 1) * 1024 / world, self.n),
+                            rng.uniform(0, 512, self.n), rng.uniform(0.5, 20.5, self.n)], 1)
             models = ["robobee" if i % 2 == 0 else "hexa_6DOF" for i in range(self.n)]
             physics = Physics.PYB_DW
         if waypoints:
@@ -90,7 +94,7 @@ class Fleet:
             wp0 = (np.arange(self.n) * n_wp // 6) % n_wp
         self.env = CtrlAviary(models, self.n, initial_xyzs=xyz, aggregate_phy_steps=substeps, physics=physics,
                               device=device, layout=layout, noise_seed=noise_seed, dict_io=False, dist=dist,
-                              chained=chained)
+                              chained=chained, downwash_exchange=os.environ.get("DSIM_DW_EXCHANGE", "halo"))
         if waypoints:
             self.tgt = WaypointTargets(self.env.ctx, self.n, g["target_pos"], g["target_vel"], g["target_acc"],
                                        g["target_yaw"], wp_counters=wp0, offsets=off)
@@ -211,15 +215,19 @@ def main():
                          "config5": (65536, 1)}[a.workload]
     from dronesim_amd import sharding
     # weak scaling: every rank owns a same-sized contiguous shard of the N-GPU fleet; no data-path collective
-    # (config5 only: one all-gather of positions per step for the neighbour-downwash term)
+    # (config5 only: one halo exchange of positions per step for the neighbour-downwash term)
     fl = Fleet(n_fleet, replicas, local, a.substeps, a.layout, sharding.rank_seed(a.noise_seed, rank),
                waypoints=a.workload == "config3", config5=a.workload == "config5",
-               dist=dist if (a.workload == "config5" and backend == "nccl") else None, rank=rank)
+               dist=dist if a.workload == "config5" else None, rank=rank)
     wall, dev_s = fl.timed(a.steps, a.warmup, barrier)
     wall, dev_s = sharding.reduce_step_times(dist, "cuda" if backend == "nccl" else "cpu", wall, dev_s)  # MAX over ranks
     value = sharding.aggregate_throughput([fl.n] * world, a.steps, wall)
     launch_s = dev_s / a.steps
-    achieved = fl.n * BYTES_PER_DRONE_STEP / launch_s / 1e9
+    # config 5: half quads (232 B) half hexas (248 B) + 1 B type id + the 12 B downwash force the step kernel reads;
+    # its step is a chain of kernels (grid build, neighbour query, step, WLS fallback), timed as a whole
+    bytes_per = {"config5": 253}.get(a.workload, BYTES_PER_DRONE_STEP)
+    kernel = {"config5": "k_dw_count+scan+scatter+query, k_step_lean, k_wls_fallback"}.get(a.workload, "k_step_fast")
+    achieved = fl.n * bytes_per / launch_s / 1e9
 
     if rank == 0:
         traffic = None
@@ -235,12 +243,13 @@ def main():
             "config": {"workload": {"config2x1024": "configs[1] 4096 robobee INDI hover x 1024 vectorised envs/GPU",
                                     "config2": "configs[1] 4096 robobee INDI hover (single fleet)",
                                     "config3": "65536 robobee, waypoint-table tracking (fly_INDI_TrajectoryTrack)",
-                                    "config5": "65536/GPU shard of 50% robobee + 50% hexa_6DOF, neighbour downwash on"}[a.workload],
+                                    "config5": "65536/GPU slab shard of 50% robobee + 50% hexa_6DOF, neighbour downwash on, "
+                                               "halo exchange of positions between neighbouring slabs"}[a.workload],
                        "drones_per_gpu": fl.n, "phys_substeps": a.substeps, "layout": a.layout,
                        "noise_seed": a.noise_seed, "launches_per_step": 1, "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_step_fast", "bytes_per_drone_step": BYTES_PER_DRONE_STEP,
+                         "kernel": kernel, "bytes_per_drone_step": bytes_per,
                          "launch_us": launch_s * 1e6},
         }
         if world == 1 and not a.no_also:

@@ -2,10 +2,11 @@
 fleet that may be sharded over several GPUs.
 
 This is the ONLY inter-drone term on the path and therefore the only exchange step of the
-multi-GPU layout: every rank contributes the positions of its shard (12 B/drone), one all-gather
-(RCCL over xGMI; 6.3 MB in total for 524 288 drones) gives every rank the world's positions, and
-each rank evaluates the force on its OWN drones against that array with a uniform-grid neighbour
-search (dsim_downwash).  Nothing else of the state ever leaves its GPU.
+multi-GPU layout.  Two forms: an all-gather of every shard's positions (12 B/drone; RCCL over xGMI;
+6.3 MB in total for 524 288 drones; works for any index sharding), or — for a spatially sharded fleet —
+a halo exchange between neighbouring slabs (HaloExchange: grouped send/recv of the boundary drones
+only).  Either way each rank then evaluates the force on its OWN drones against the positions it holds
+with a uniform-grid neighbour search (dsim_downwash).  Nothing else of the state ever leaves its GPU.
 
 The reference's loop is O(N^2) over the whole world, per drone, per sub-step, and is dead code in
 the fork; the intended semantics are kept: receivers use their own type's coefficients, the force
@@ -32,18 +33,103 @@ def gather_positions(local_pos: torch.Tensor, dist=None) -> torch.Tensor:
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local_pos.contiguous()
     world = dist.get_world_size()
-    loc = local_pos.contiguous()
+    dev = local_pos.device
+    loc = local_pos.contiguous().to(_wire_device(dist, dev))
     out = torch.empty((world * 3, loc.shape[1]), dtype=loc.dtype, device=loc.device)   # ranks stacked on dim 0
     dist.all_gather_into_tensor(out, loc)
-    return out.reshape(world, 3, loc.shape[1]).permute(1, 0, 2).reshape(3, world * loc.shape[1]).contiguous()
+    return out.reshape(world, 3, loc.shape[1]).permute(1, 0, 2).reshape(3, world * loc.shape[1]).contiguous().to(dev)
+
+
+def _wire_device(dist, dev):
+    """RCCL moves device memory directly; the gloo backend (CPU tests, and several rehearsal ranks sharing
+    one GPU) has no device-memory point-to-point, so there the payload is staged through the host."""
+    return torch.device("cpu") if dist.get_backend() == "gloo" else dev
+
+
+class HaloExchange:
+    """Halo exchange of positions between the ranks of a SPATIALLY sharded fleet (BASELINE config 5: slab
+    decomposition, RCCL send/recv between neighbouring slabs only) — the alternative to the all-gather.
+
+    Every `refresh` Env.steps the ranks all-gather their xy bounding boxes (4 floats each, one host sync)
+    and each rank fixes, per peer, the index list of its own drones that can come within the 10 m cut-off
+    of ANY drone of that peer before the next refresh: those inside the peer's box grown by
+    `cutoff + 2 * margin`, where `margin = v_axis_max * dt_env * refresh` bounds how far a drone moves
+    along one axis in that time (Bullet clamps every coordinate velocity to `max_coord_vel`, P4) — once for
+    the sender's own motion, once for the growth of the peer's box.  Between refreshes the message sizes
+    are therefore known on the host, and one step's exchange is: gather the listed positions, one grouped
+    batch of isend/irecv (ncclGroupStart/End over xGMI point-to-point links), concatenate.  Nothing is
+    approximated: a drone that is not in the list cannot reach the cut-off, and the force kernel re-tests
+    every candidate pair with the current positions.  Ranks whose boxes are far apart exchange nothing."""
+
+    def __init__(self, dist, v_axis_max: float, dt_env: float, cutoff: float = CUTOFF, refresh: int = 16):
+        self.dist, self.cutoff, self.refresh = dist, float(cutoff), int(refresh)
+        self.margin = float(v_axis_max) * float(dt_env) * self.refresh
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self._age = None
+        self._send_idx, self._recv_buf = {}, {}
+        self.sent_per_step = 0            # drones this rank sends per step (diagnostic)
+
+    def _refresh(self, pos: torch.Tensor) -> None:
+        dist = self.dist
+        box = torch.cat([pos[:2].min(dim=1).values, pos[:2].max(dim=1).values]).to(torch.float32)
+        wire = _wire_device(dist, pos.device)
+        boxes = torch.empty((self.world, 4), dtype=torch.float32, device=wire)
+        dist.all_gather_into_tensor(boxes, box.reshape(1, 4).contiguous().to(wire))
+        boxes = boxes.cpu()
+        reach = self.cutoff + 2.0 * self.margin
+        mine = boxes[self.rank]
+        self._send_idx = {}
+        counts = torch.zeros((self.world,), dtype=torch.int64)
+        for p in range(self.world):
+            if p == self.rank:
+                continue
+            lo, hi = boxes[p, :2] - reach, boxes[p, 2:] + reach
+            if bool((mine[2:] < lo).any() or (mine[:2] > hi).any()):      # my whole box is out of that peer's reach
+                continue
+            m = (pos[0] >= lo[0]) & (pos[0] <= hi[0]) & (pos[1] >= lo[1]) & (pos[1] <= hi[1])
+            idx = torch.nonzero(m).squeeze(1)
+            if idx.numel():
+                self._send_idx[p] = idx
+                counts[p] = idx.numel()
+        table = torch.empty((self.world, self.world), dtype=torch.int64, device=wire)
+        dist.all_gather_into_tensor(table, counts.reshape(1, -1).to(wire))
+        table = table.cpu()
+        self._recv_buf = {p: torch.empty((3, int(table[p, self.rank])), dtype=pos.dtype, device=wire)
+                          for p in range(self.world) if p != self.rank and int(table[p, self.rank]) > 0}
+        self.sent_per_step = int(counts.sum())
+        self._age = 0
+
+    def exchange(self, local_pos: torch.Tensor) -> torch.Tensor:
+        """local_pos [3, n] -> [3, n + halo]: this rank's drones first (local_offset = 0), then the halo
+        drones received from the peers."""
+        pos = local_pos.contiguous()
+        if self._age is None or self._age >= self.refresh:
+            self._refresh(pos)
+        self._age += 1
+        dist = self.dist
+        ops, keep = [], []
+        for p, idx in self._send_idx.items():
+            buf = pos.index_select(1, idx).contiguous().to(self._recv_wire(pos))
+            keep.append(buf)
+            ops.append(dist.P2POp(dist.isend, buf, p))
+        for p, buf in self._recv_buf.items():
+            ops.append(dist.P2POp(dist.irecv, buf, p))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        return torch.cat([pos] + [self._recv_buf[p].to(pos.device) for p in sorted(self._recv_buf)], dim=1)
+
+    def _recv_wire(self, pos):
+        return _wire_device(self.dist, pos.device)
 
 
 class Downwash:
     """Evaluates formula P8 for the drones of one env/state block against world positions."""
 
     def __init__(self, ctx, state, type_id: Optional[torch.Tensor] = None, dist=None, cell: float = CUTOFF,
-                 box_refresh: int = 256):
+                 box_refresh: int = 256, halo: Optional[HaloExchange] = None):
         self.ctx, self.state, self.type_id, self.dist, self.cell = ctx, state, type_id, dist, float(cell)
+        self.halo = halo                 # None: all-gather of the world's positions (any index sharding)
         self.force = torch.zeros((3, state.n_pad), dtype=torch.float32, device=ctx.device)
         self._ws = None
         self._box = None                 # (xmin, ymin, nx, ny): a search-efficiency hint, never a correctness input
@@ -68,7 +154,9 @@ class Downwash:
 
     def _grid_args(self, world_pos, local_offset) -> nat.DownwashArgs:
         st = self.state
-        if world_pos is None:
+        if world_pos is None and self.halo is not None:
+            world_pos, local_offset = self.halo.exchange(st.fields(0, 3)[:, : st.n]), 0
+        elif world_pos is None:
             world_pos = gather_positions(st.fields(0, 3), self.dist)
             rank = self.dist.get_rank() if (self.dist is not None and self.dist.is_initialized()) else 0
             local_offset = rank * st.n

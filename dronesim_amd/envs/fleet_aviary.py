@@ -68,6 +68,7 @@ class CtrlAviary:
         dict_io: Optional[bool] = None,
         dist=None,
         chained: bool = False,
+        downwash_exchange: str = "allgather",
     ):
         if gui or record or obstacles:
             raise NotImplementedError("gui/record/obstacles are rendering features outside the hot path")
@@ -137,8 +138,14 @@ class CtrlAviary:
         # torch.distributed module when the world's fleet is sharded over several ranks
         self._downwash = None
         if physics in (Physics.PYB_DW, Physics.PYB_GND_DRAG_DW):
-            from ..downwash import Downwash
-            self._downwash = Downwash(self.ctx, self.state, self._type_id, dist)
+            from ..downwash import Downwash, HaloExchange
+            halo = None
+            if downwash_exchange == "halo" and dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+                # spatially sharded fleet: positions travel between neighbouring slabs only
+                halo = HaloExchange(dist, max(t.max_coord_vel for t in self.types), self.AGGR_PHY_STEPS * self.TIMESTEP)
+            elif downwash_exchange not in ("allgather", "halo"):
+                raise ValueError(downwash_exchange)
+            self._downwash = Downwash(self.ctx, self.state, self._type_id, dist, halo=halo)
         self.step_counter = 0
         self._env_steps = 0
         self._housekeeping()

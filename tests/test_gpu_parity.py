@@ -555,6 +555,65 @@ def test_step_with_downwash_env(gpu):
     env.close()
 
 
+def _sharded_dw_worker(rank, world, port, mode, out):
+    """One rank of a 2-rank fleet sharing the single GPU (gloo stands in for RCCL, which wants one device
+    per rank): mixed quad/hexa slab shard with neighbour downwash, against a whole-world run."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dronesim_amd.envs import CtrlAviary, Physics
+    from dronesim_amd.fleet import Targets
+    n, slab = 1536, 60.0
+    xyzs, models = [], []
+    for r in range(world):
+        rng = np.random.default_rng(900 + r)
+        xyzs.append(np.stack([rng.uniform(r * slab, (r + 1) * slab, n), rng.uniform(0, 40, n), rng.uniform(0.5, 12, n)], 1))
+        models += ["robobee" if i % 2 == 0 else "hexa_6DOF" for i in range(n)]
+    xyz_w = np.concatenate(xyzs)
+
+    def fly(env, xyz, steps=12):
+        tg = Targets(env.ctx, xyz.shape[0])
+        tg.set(pos=f32(xyz).T + np.array([[0.5], [0.0], [0.2]], dtype=np.float32), yaw=0.3)
+        for _ in range(steps):
+            env.step_fused(tg)
+        torch.cuda.synchronize()
+        return env.state.rigid_aos(), env.state.mem_aos()
+
+    mine = CtrlAviary(models[rank * n:(rank + 1) * n], n, initial_xyzs=xyzs[rank], physics=Physics.PYB_DW,
+                      noise_seed=0, dict_io=False, dist=dist, downwash_exchange=mode)
+    r_s, m_s = fly(mine, xyzs[rank])
+    halo = mine._downwash.halo
+    sent = halo.sent_per_step if halo is not None else None
+    whole = CtrlAviary(models, world * n, initial_xyzs=xyz_w, physics=Physics.PYB_DW, noise_seed=0, dict_io=False)
+    r_w, m_w = fly(whole, xyz_w)
+    sl = slice(rank * n, (rank + 1) * n)
+    moved = float(np.abs(r_w[sl, 0:3] - xyzs[rank]).max())
+    out[rank] = (float(rel_err(r_s, r_w[sl], RIGID_SCALE).max()), float(np.abs(m_s - m_w[sl]).max()), sent, moved)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["allgather", "halo"])
+def test_two_rank_sharded_downwash_equals_whole_fleet(gpu, mode):
+    """The multi-GPU exchange step end to end on the kernels: each of two ranks flies its slab shard of a
+    mixed fleet with neighbour downwash on, positions exchanged by all-gather or by halo send/recv; the
+    shard's trajectory equals the same drones' trajectory in a single whole-fleet run."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sharded_dw_worker, args=(2, port, mode, out), nprocs=2, join=True)
+    for r in (0, 1):
+        err_r, err_m, sent, moved = out[r]
+        assert err_r < 1e-5 and err_m < 1e-4, (r, out[r])
+        assert moved > 1e-3
+        if mode == "halo":
+            assert 0 < sent < 1536          # only the boundary strip travels
+
+
 # ---------------------------------------------------------------------------
 # config 3: waypoint-table tracking (examples/fly_INDI_TrajectoryTrack.py) and multi-step launches
 # ---------------------------------------------------------------------------

@@ -78,3 +78,54 @@ def test_position_allgather_restores_global_order_gloo():
     out = mgr.dict()
     mp.spawn(_gather_worker, args=(2, port, out), nprocs=2, join=True)
     assert out[0] and out[1]
+
+
+def _halo_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from dronesim_amd import params
+    from dronesim_amd.downwash import HaloExchange, gather_positions
+    from oracle import oracle as orc
+    n, slab, vmax, dt, refresh = 300, 40.0, 100.0, 1.0 / 240.0, 8
+    rng = np.random.default_rng(100 + rank)
+    # slab decomposition along x: rank r owns x in [r*slab, (r+1)*slab)
+    pos = np.stack([rng.uniform(rank * slab, (rank + 1) * slab, n), rng.uniform(0, 30, n), rng.uniform(0.5, 8, n)])
+    O = orc.Oracle([params.builtin_type("robobee")])
+    halo = HaloExchange(dist, vmax, dt, refresh=refresh)
+    ok, sizes, sent = True, [], []
+    for step in range(2 * refresh + 3):                  # crosses two refreshes
+        loc = torch.from_numpy(pos.astype(np.float32))
+        got = halo.exchange(loc)                          # [3, n + halo]
+        world_pos = gather_positions(loc, dist)           # the all-gather mode, for comparison
+        rigid = np.zeros((n, 13)); rigid[:, 0:3] = loc.numpy().T; rigid[:, 6] = 1.0
+        f_halo = O.downwash(rigid, got.numpy().T.astype(np.float64))
+        f_all = O.downwash(rigid, world_pos.numpy().T.astype(np.float64))
+        ok = ok and bool(torch.equal(got[:, :n], loc)) and np.allclose(f_halo, f_all, rtol=1e-12, atol=0) \
+            and (f_all != 0).sum() > n // 4
+        sizes.append(got.shape[1]); sent.append(halo.sent_per_step)
+        # worst-case motion the margin must absorb: every drone moves at the velocity clamp along x,
+        # the slabs rushing towards each other
+        pos[0] += (1.0 if rank % 2 == 0 else -1.0) * vmax * dt
+        pos[1] += rng.uniform(-1, 1, n) * vmax * dt
+    out[rank] = (ok, max(sizes), sorted(halo._send_idx.keys()), max(sent))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_halo_exchange_equals_allgather_gloo():
+    """Config 5's exchange step in its halo form, 3 ranks in a row of slabs: the force on every local drone
+    computed from own + halo positions equals the one computed from the all-gathered world, at every step
+    between and across refreshes, with all drones moving at the velocity clamp; the outer ranks exchange
+    nothing with each other, and a rank receives far fewer positions than the world holds."""
+    world = 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_halo_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        assert out[r][0], r
+    assert out[0][2] == [1] and out[2][2] == [1] and out[1][2] == [0, 2]     # neighbours only
+    assert out[0][1] < 300 + 300 and out[0][3] < 300                           # a strict subset travels
