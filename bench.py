@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
-    p.add_argument("--workload", default="config2x1024", choices=["config2x1024", "config2", "config3", "config5"])
+    p.add_argument("--workload", default="config2x1024", choices=["config2x1024", "config2", "config3", "config5", "hexa"])
     p.add_argument("--substeps", type=int, default=1)
     p.add_argument("--layout", default="tile64", choices=["soa", "tile64", "tile256", "tile1024", "tile4096"])
     p.add_argument("--noise-seed", type=int, default=1)
@@ -212,21 +212,22 @@ def main():
     barrier = (lambda: dist.barrier()) if dist else None
 
     n_fleet, replicas = {"config2x1024": (4096, 1024), "config2": (4096, 1), "config3": (65536, 1),
-                         "config5": (65536, 1)}[a.workload]
+                         "config5": (65536, 1), "hexa": (4096, 1024)}[a.workload]
     from dronesim_amd import sharding
     # weak scaling: every rank owns a same-sized contiguous shard of the N-GPU fleet; no data-path collective
     # (config5 only: one halo exchange of positions per step for the neighbour-downwash term)
     fl = Fleet(n_fleet, replicas, local, a.substeps, a.layout, sharding.rank_seed(a.noise_seed, rank),
                waypoints=a.workload == "config3", config5=a.workload == "config5",
-               dist=dist if a.workload == "config5" else None, rank=rank)
+               dist=dist if a.workload == "config5" else None, rank=rank, hexa=a.workload == "hexa")
     wall, dev_s = fl.timed(a.steps, a.warmup, barrier)
     wall, dev_s = sharding.reduce_step_times(dist, "cuda" if backend == "nccl" else "cpu", wall, dev_s)  # MAX over ranks
     value = sharding.aggregate_throughput([fl.n] * world, a.steps, wall)
     launch_s = dev_s / a.steps
     # config 5: half quads (232 B) half hexas (248 B) + 1 B type id + the 12 B downwash force the step kernel reads;
     # its step is a chain of kernels (grid build, neighbour query, step, WLS fallback), timed as a whole
-    bytes_per = {"config5": 253}.get(a.workload, BYTES_PER_DRONE_STEP)
-    kernel = {"config5": "k_dw_count+scan+scatter+query, k_step_lean, k_wls_fallback"}.get(a.workload, "k_step_fast")
+    bytes_per = {"config5": 253, "hexa": 248}.get(a.workload, BYTES_PER_DRONE_STEP)
+    kernel = {"config5": "k_dw_count+scan+scatter+query, k_step_lean, k_wls_fallback",
+              "hexa": "k_step_hexa (+ k_wls_fallback)"}.get(a.workload, "k_step_fast")
     achieved = fl.n * bytes_per / launch_s / 1e9
 
     if rank == 0:
@@ -243,6 +244,7 @@ def main():
             "config": {"workload": {"config2x1024": "configs[1] 4096 robobee INDI hover x 1024 vectorised envs/GPU",
                                     "config2": "configs[1] 4096 robobee INDI hover (single fleet)",
                                     "config3": "65536 robobee, waypoint-table tracking (fly_INDI_TrajectoryTrack)",
+                                    "hexa": "4096 hexa_6DOF (6-DOF INDI + WLS) hover x 1024 vectorised envs/GPU",
                                     "config5": "65536/GPU slab shard of 50% robobee + 50% hexa_6DOF, neighbour downwash on, "
                                                "halo exchange of positions between neighbouring slabs"}[a.workload],
                        "drones_per_gpu": fl.n, "phys_substeps": a.substeps, "layout": a.layout,
@@ -279,7 +281,7 @@ def main():
                     # rigid state are neither read nor written: 184 B of real traffic per drone-step
                     "config2x1024_chained_184B": (4096, 1024, 1, False, 1),
                     # homogeneous morphing-hexa fleet: 6-DOF INDI + WLS allocation, 248 B/drone-step
-                    "hexa_6DOF_1048576_indi6dof_wls": (4096, 256, 1, False, 1)}.items():
+                    "hexa_6DOF_4194304_indi6dof_wls": (4096, 1024, 1, False, 1)}.items():
                 f2 = Fleet(nf, rep, local, sub, a.layout, a.noise_seed, waypoints=wp, n_steps=ns,
                            config5=name.startswith("config5"), chained="chained" in name,
                            hexa=name.startswith("hexa"))

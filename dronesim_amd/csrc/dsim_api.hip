@@ -272,6 +272,37 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
 
 __global__ void k_counter_add(unsigned long long* c, unsigned long long inc) { *c += inc; }
 
+// The same fast form for a homogeneous morphing-hexa fleet (6-DOF INDI, first WLS iteration in closed form,
+// infeasible drones queued for k_wls_fallback): whole tiles, stored cmd as the action, one Env.step per
+// launch.  Compiled apart from the mixed-fleet kernel, whose quad branch and per-lane options cost it
+// registers (177-252 VGPRs, 2 waves/SIMD).
+#ifndef DSIM_HEXA_WAVES
+#define DSIM_HEXA_WAVES 3
+#endif
+template <bool NOISE, bool NT>
+__global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
+  const DevType& T = a.types[0];
+  const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
+  const unsigned sl = 4u * kv_lane(a.st, threadIdx.x), tl = 4u * kv_lane(a.tg, threadIdx.x);
+  const long long i0 = (long long)blockIdx.x * 256;
+  float* const sb = a.st.base + kv_off(a.st, i0);
+  const float* const tb = a.tg.base + kv_off(a.tg, i0);
+  Rigid s;
+  CtrlMem<6> m;
+  Target tg;
+  load_rigid<NT>(sb, sfs, sl, s);
+  load_mem<6, NT>(sb, sfs, sl, m);
+  load_target<NT>(tb, tfs, tl, tg);
+  const long long i = i0 + threadIdx.x;
+  if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
+  V3 pos_e;
+  float yaw_e;
+  hexa_substeps<NOISE, false>(T, a, i, s, m.cmd, a.step_index);
+  indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
+  store_rigid<NT>(sb, sfs, sl, s);
+  store_mem<6, NT>(sb, sfs, sl, m);
+}
+
 // ends a chained sequence: last_vel / last_rates back into the state block
 struct MatK { KView st; long long n_pad; };
 __global__ __launch_bounds__(256) void k_materialize(MatK a) {
@@ -1007,6 +1038,24 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
       first = tiles * 256;
     }
   }
+  bool fb_open = false;
+  if (uni && six && ctx->h_types[0].kind == DSIM_KIND_HEXA6DOF && !args->action && !args->noise_replay && !args->ext_force &&
+      !a.wp_table && a.n_steps == 1 && a.n_pad >= 256) {
+    const long long tiles = a.n_pad / 256;
+    static const char* nt_env = getenv("DSIM_NT");
+    const bool nt = nt_env ? atoi(nt_env) != 0 : (double)state.n_pad * 248.0 > 192.0 * 1024 * 1024;
+    rc = fb_prepare(ctx, a.n_pad, st_);
+    if (rc) return rc;
+    a.fb.entries = ctx->d_fb;
+    fb_open = true;
+    const dim3 g((unsigned)tiles);
+    if (noise) { if (nt) hipLaunchKernelGGL((k_step_hexa<true, true>), g, b, 0, st_, a);
+                 else hipLaunchKernelGGL((k_step_hexa<true, false>), g, b, 0, st_, a); }
+    else { if (nt) hipLaunchKernelGGL((k_step_hexa<false, true>), g, b, 0, st_, a);
+           else hipLaunchKernelGGL((k_step_hexa<false, false>), g, b, 0, st_, a); }
+    first = tiles * 256;
+    if (first >= a.n_pad) fb_finish(ctx, a, st_);
+  }
   if (first < a.n_pad) {   // ragged tail, or everything when the fast path does not apply
     a.first = first;
     const dim3 g(grid_for(a.n_pad - first));
@@ -1020,9 +1069,12 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
       const int steps = a.n_steps;
       a.n_steps = 1;
       for (int k = 0; k < steps; ++k) {
-        rc = fb_prepare(ctx, a.n_pad, st_);
-        if (rc) return rc;
-        a.fb.entries = ctx->d_fb;
+        if (!fb_open) {                 // (open already when the tiles went through k_step_hexa: one queue, one fallback pass)
+          rc = fb_prepare(ctx, a.n_pad, st_);
+          if (rc) return rc;
+          a.fb.entries = ctx->d_fb;
+        }
+        fb_open = false;
         if (lean && !a.action) DSIM_LAUNCH_GEN(k_step_lean, noise, uni, true, g, a, st_);
         else DSIM_LAUNCH_GEN(k_step_gen, noise, uni, true, g, a, st_);
         fb_finish(ctx, a, st_);
