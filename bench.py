@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
-    p.add_argument("--workload", default="config2x1024", choices=["config2x1024", "config2", "config3", "config5", "hexa"])
+    p.add_argument("--workload", default="config2x1024", choices=["config2x1024", "config2", "config3", "config5", "hexa", "mixed"])
     p.add_argument("--substeps", type=int, default=1)
     p.add_argument("--layout", default="tile64", choices=["soa", "tile64", "tile256", "tile1024", "tile4096"])
     p.add_argument("--noise-seed", type=int, default=1)
@@ -60,7 +60,7 @@ class Fleet:
     """A resident fleet + per-drone hover targets at the start position."""
 
     def __init__(self, n_fleet, replicas, device, substeps, layout, noise_seed, waypoints=False, n_steps=1,
-                 config5=False, dist=None, rank=0, chained=False, hexa=False):
+                 config5=False, dist=None, rank=0, chained=False, hexa=False, mixed=False):
         import torch
         from dronesim_amd.envs import CtrlAviary, Physics
         from dronesim_amd.fleet import Targets, WaypointTargets
@@ -69,9 +69,13 @@ class Fleet:
         self.graph = None
         xyz = grid_fleet(n_fleet, replicas)
         self.n = xyz.shape[0]
-        models, physics = ["robobee"], Physics.PYB
+        models, physics, type_ids = ["robobee"], Physics.PYB, None
         if hexa:
             models = ["hexa_6DOF"]
+        if mixed:       # config 5's fleet composition (even index quad, odd index hexa) without the downwash term
+            models, type_ids = ["robobee", "hexa_6DOF"], (np.arange(self.n) % 2).astype(np.uint8)
+            if mixed == "type_major":                  # the same fleet stored type-major (fleet.type_major_order)
+                type_ids = np.sort(type_ids)
         if config5:
             # BASELINE configs[4]: even index robobee (quad INDI), odd index
             # hexa_6DOF (6DOF INDI + WLS); positions uniform in a 1024 x 512 x [0.5, 20.5] m box so that
@@ -82,7 +86,7 @@ class Fleet:
             world = dist.get_world_size() if dist is not None else 1
             xyz = np.stack([rng.uniform(rank * 1024 / world, (rank + 1) * 1024 / world, self.n),
                             rng.uniform(0, 512, self.n), rng.uniform(0.5, 20.5, self.n)], 1)
-            models = ["robobee" if i % 2 == 0 else "hexa_6DOF" for i in range(self.n)]
+            models, type_ids = ["robobee", "hexa_6DOF"], (np.arange(self.n) % 2).astype(np.uint8)
             physics = Physics.PYB_DW
         if waypoints:
             # config 3 (examples/fly_INDI_TrajectoryTrack.py): the reference's own 1200-row waypoint
@@ -94,7 +98,8 @@ class Fleet:
             wp0 = (np.arange(self.n) * n_wp // 6) % n_wp
         self.env = CtrlAviary(models, self.n, initial_xyzs=xyz, aggregate_phy_steps=substeps, physics=physics,
                               device=device, layout=layout, noise_seed=noise_seed, dict_io=False, dist=dist,
-                              chained=chained, downwash_exchange=os.environ.get("DSIM_DW_EXCHANGE", "halo"))
+                              chained=chained, downwash_exchange=os.environ.get("DSIM_DW_EXCHANGE", "halo"),
+                              type_ids=type_ids)
         if waypoints:
             self.tgt = WaypointTargets(self.env.ctx, self.n, g["target_pos"], g["target_vel"], g["target_acc"],
                                        g["target_yaw"], wp_counters=wp0, offsets=off)
@@ -212,22 +217,23 @@ def main():
     barrier = (lambda: dist.barrier()) if dist else None
 
     n_fleet, replicas = {"config2x1024": (4096, 1024), "config2": (4096, 1), "config3": (65536, 1),
-                         "config5": (65536, 1), "hexa": (4096, 1024)}[a.workload]
+                         "config5": (65536, 1), "hexa": (4096, 1024), "mixed": (4096, 1024)}[a.workload]
     from dronesim_amd import sharding
     # weak scaling: every rank owns a same-sized contiguous shard of the N-GPU fleet; no data-path collective
     # (config5 only: one halo exchange of positions per step for the neighbour-downwash term)
     fl = Fleet(n_fleet, replicas, local, a.substeps, a.layout, sharding.rank_seed(a.noise_seed, rank),
                waypoints=a.workload == "config3", config5=a.workload == "config5",
-               dist=dist if a.workload == "config5" else None, rank=rank, hexa=a.workload == "hexa")
+               dist=dist if a.workload == "config5" else None, rank=rank, hexa=a.workload == "hexa", mixed=a.workload == "mixed")
     wall, dev_s = fl.timed(a.steps, a.warmup, barrier)
     wall, dev_s = sharding.reduce_step_times(dist, "cuda" if backend == "nccl" else "cpu", wall, dev_s)  # MAX over ranks
     value = sharding.aggregate_throughput([fl.n] * world, a.steps, wall)
     launch_s = dev_s / a.steps
     # config 5: half quads (232 B) half hexas (248 B) + 1 B type id + the 12 B downwash force the step kernel reads;
     # its step is a chain of kernels (grid build, neighbour query, step, WLS fallback), timed as a whole
-    bytes_per = {"config5": 253, "hexa": 248}.get(a.workload, BYTES_PER_DRONE_STEP)
+    bytes_per = {"config5": 253, "hexa": 248, "mixed": 241}.get(a.workload, BYTES_PER_DRONE_STEP)
     kernel = {"config5": "k_dw_count+scan+scatter+query, k_step_lean, k_wls_fallback",
-              "hexa": "k_step_hexa (+ k_wls_fallback)"}.get(a.workload, "k_step_fast")
+              "hexa": "k_step_hexa (+ k_wls_fallback)",
+              "mixed": "k_step_typed per type (+ k_wls_fallback)"}.get(a.workload, "k_step_fast")
     achieved = fl.n * bytes_per / launch_s / 1e9
 
     if rank == 0:
@@ -244,6 +250,7 @@ def main():
             "config": {"workload": {"config2x1024": "configs[1] 4096 robobee INDI hover x 1024 vectorised envs/GPU",
                                     "config2": "configs[1] 4096 robobee INDI hover (single fleet)",
                                     "config3": "65536 robobee, waypoint-table tracking (fly_INDI_TrajectoryTrack)",
+                                    "mixed": "even index robobee, odd index hexa_6DOF, 4096 x 1024 envs/GPU, no downwash",
                                     "hexa": "4096 hexa_6DOF (6-DOF INDI + WLS) hover x 1024 vectorised envs/GPU",
                                     "config5": "65536/GPU slab shard of 50% robobee + 50% hexa_6DOF, neighbour downwash on, "
                                                "halo exchange of positions between neighbouring slabs"}[a.workload],
@@ -281,10 +288,15 @@ def main():
                     # rigid state are neither read nor written: 184 B of real traffic per drone-step
                     "config2x1024_chained_184B": (4096, 1024, 1, False, 1),
                     # homogeneous morphing-hexa fleet: 6-DOF INDI + WLS allocation, 248 B/drone-step
-                    "hexa_6DOF_4194304_indi6dof_wls": (4096, 1024, 1, False, 1)}.items():
+                    "hexa_6DOF_4194304_indi6dof_wls": (4096, 1024, 1, False, 1),
+                    # config 5's composition at roofline size, no downwash: 240 B average + 1 B type id
+                    "mixed_quad_hexa_4194304": (4096, 1024, 1, False, 1),
+                    # the same fleet in type-major storage: one single-type launch per type
+                    "mixed_quad_hexa_4194304_type_major": (4096, 1024, 1, False, 1)}.items():
                 f2 = Fleet(nf, rep, local, sub, a.layout, a.noise_seed, waypoints=wp, n_steps=ns,
                            config5=name.startswith("config5"), chained="chained" in name,
-                           hexa=name.startswith("hexa"))
+                           hexa=name.startswith("hexa"),
+                           mixed=("type_major" if "type_major" in name else name.startswith("mixed")))
                 if "hipgraph" in name:
                     f2.n_steps = 1
                     f2.use_graph(ns)
@@ -293,7 +305,8 @@ def main():
                 also[name] = {"drone_steps_per_s": f2.n * k2 * ns / w2, "launch_us": d2 / k2 * 1e6,
                               "env_steps_per_launch": ns}
                 if ns == 1:
-                    bts = 184 if "chained" in name else (248 if name.startswith("hexa") else BYTES_PER_DRONE_STEP)
+                    bts = 184 if "chained" in name else (248 if name.startswith("hexa") else
+                                                         (241 if name.startswith("mixed") else BYTES_PER_DRONE_STEP))
                     also[name]["hbm_frac"] = f2.n * bts / (d2 / k2) / 1e9 / HBM_PEAK_GBPS
                     also[name]["bytes_per_drone_step"] = bts
                 f2.env.close(); del f2

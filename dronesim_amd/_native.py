@@ -19,7 +19,7 @@ EXPORTS = (
     "dsim_physics", "dsim_control", "dsim_step_adaptor", "dsim_traj_sample", "dsim_materialize", "dsim_counter_add", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash", "dsim_downwash_workspace", "dsim_adjacency",
 )
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NF_QUAD, NF_HEXA, NT = 24, 26, 10
 OPT_DRAG, OPT_GROUND, OPT_BCAST_TGT, OPT_CHAINED = 1, 2, 4, 8
 ADAPT_VELOCITY, ADAPT_RPYT = 0, 1
@@ -55,7 +55,14 @@ class StepArgs(ctypes.Structure):
         ("n_steps", ctypes.c_int32),
         ("ext_force", ctypes.c_void_p),
         ("step_index_dev", ctypes.c_void_p),
+        ("runs", ctypes.c_void_p),
+        ("n_runs", ctypes.c_int32),
+        ("_pad_runs", ctypes.c_int32),
     ]
+
+
+class TypeRun(ctypes.Structure):
+    _fields_ = [("first", ctypes.c_int64), ("count", ctypes.c_int64), ("type", ctypes.c_int32), ("_pad", ctypes.c_int32)]
 
 
 class DownwashArgs(ctypes.Structure):

@@ -82,6 +82,9 @@ struct StepK {
   int substeps;
   float dt_phys, dt_ctrl;
   unsigned options;
+  long long last;             // run kernels: one past the last drone of the run
+  int run_type;               // run kernels: the run's type
+  unsigned hexa_types;        // bit t set: type t of the table is a morphing hexa (26 state fields in use)
 };
 
 // Global accesses.  NT = nontemporal (streaming) hint: each state field is read once and written
@@ -332,16 +335,64 @@ __global__ __launch_bounds__(256) void k_materialize(MatK a) {
     }                                                                           \
   } while (0)
 
+// Before the waterfall, a mixed tile is PARTITIONED by type: the 256 lanes of the workgroup re-assign the
+// tile's 256 drones among themselves so that drones of one type sit in consecutive lanes (a stable counting
+// sort on the type id: per-wave ballots + popcounts, per-wave/per-type counts and the slot -> drone table in
+// LDS).  Waves become type-homogeneous except where one type's run ends inside a wave (at most n_types - 1
+// waves per tile), so the waterfall runs once instead of once per type present — in config 5 (even index
+// quad, odd index hexa) every wave would otherwise execute BOTH laws at half occupancy of its lanes.  Lanes
+// then gather their drone's fields from within the same 256-drone tile (same cache lines, HBM traffic
+// unchanged).  Everything keyed by the drone index (noise stream, per-drone buffers) is unaffected.
+// slot (lane of the workgroup) that processes this lane's natural drone: a stable counting sort of the tile on
+// the type id `my` (0..DSIM_MAX_TYPES, the last value = no drone, sorted last).  One barrier.
+template <int WAVES>
+__device__ __forceinline__ unsigned tile_dest(int my) {
+  __shared__ unsigned short cnt[WAVES][DSIM_MAX_TYPES + 1];
+  const unsigned t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const unsigned long long lt = (1ULL << lane) - 1ULL;
+  unsigned rank = 0, c_mine = 0;
+#pragma unroll
+  for (int ty = 0; ty <= DSIM_MAX_TYPES; ++ty) {
+    const unsigned long long mask = __ballot(my == ty);
+    if (my == ty) rank = (unsigned)__popcll(mask & lt);
+    if ((int)lane == ty) c_mine = (unsigned)__popcll(mask);
+  }
+  if (lane <= DSIM_MAX_TYPES) cnt[w][lane] = (unsigned short)c_mine;
+  __syncthreads();
+  unsigned dest = rank;
+  for (int ty = 0; ty <= DSIM_MAX_TYPES; ++ty) {
+#pragma unroll
+    for (unsigned ww = 0; ww < WAVES; ++ww) {
+      const unsigned c = cnt[ww][ty];
+      dest += (ty < my || (ty == my && ww < w)) ? c : 0u;
+    }
+  }
+  return dest;
+}
+__device__ __forceinline__ unsigned tile_partition(const uint8_t* type_id, long long i0, long long n_pad) {
+  __shared__ unsigned char slot2drone[256];
+  const unsigned t = threadIdx.x;
+  const int my = (i0 + t < n_pad) ? min((int)type_id[i0 + t], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;   // out of range: sorted last
+  slot2drone[tile_dest<4>(my)] = (unsigned char)t;
+  __syncthreads();
+  return slot2drone[t];
+}
+template <bool UNIFORM>
+__device__ __forceinline__ unsigned tile_slot(const uint8_t* type_id, long long i0, long long n_pad) {
+  if (UNIFORM) return threadIdx.x;
+  return tile_partition(type_id, i0, n_pad);
+}
+
 // General form: per-drone type ids (mixed quad / hexa fleets, NACT = 6), explicit action
 // override, noise replay, external force, ragged sizes.  a.first = first drone this launch covers
 // (a multiple of 256, so the scalar-base + lane-offset addressing of the fast kernel applies).
 struct Addr { float* sb; const float* tb; unsigned sl, tl; long long sfs, tfs; };
-__device__ __forceinline__ Addr make_addr(const StepK& a, long long i0) {
+__device__ __forceinline__ Addr make_addr(const StepK& a, long long i0, unsigned p /* drone within the tile */) {
   Addr r;
   r.sb = a.st.base + kv_off(a.st, i0);
   r.tb = a.tg.base ? a.tg.base + kv_off(a.tg, i0) : nullptr;
-  r.sl = 4u * kv_lane(a.st, threadIdx.x);
-  r.tl = 4u * kv_lane(a.tg, threadIdx.x);
+  r.sl = 4u * kv_lane(a.st, p);
+  r.tl = 4u * kv_lane(a.tg, p);
   r.sfs = a.st.field_stride; r.tfs = a.tg.field_stride;
   return r;
 }
@@ -389,20 +440,160 @@ __device__ __forceinline__ void step_gen_body(const DevType& T, const StepK& a, 
 template <bool NOISE, bool UNIFORM, int NACT>
 __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_step_gen(StepK a) {
   const long long i0 = a.first + (long long)blockIdx.x * 256;
-  const long long i = i0 + threadIdx.x;
+  const unsigned p = tile_slot<UNIFORM>(a.type_id, i0, a.n_pad);
+  const long long i = i0 + p;
   if (i >= a.n_pad) return;
   if (a.step_index_dev) a.step_index += *a.step_index_dev;
-  const Addr ad = make_addr(a, i0);
+  const Addr ad = make_addr(a, i0, p);
   DSIM_FOR_MY_TYPE(UNIFORM, a, i, (step_gen_body<NOISE, NACT, true>(T, a, i, ad)));
 }
 template <bool NOISE, bool UNIFORM, int NACT>
 __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_step_lean(StepK a) {
   const long long i0 = a.first + (long long)blockIdx.x * 256;
-  const long long i = i0 + threadIdx.x;
+  const unsigned p = tile_slot<UNIFORM>(a.type_id, i0, a.n_pad);
+  const long long i = i0 + p;
   if (i >= a.n_pad) return;
   if (a.step_index_dev) a.step_index += *a.step_index_dev;
-  const Addr ad = make_addr(a, i0);
+  const Addr ad = make_addr(a, i0, p);
   DSIM_FOR_MY_TYPE(UNIFORM, a, i, (step_gen_body<NOISE, NACT, false>(T, a, i, ad)));
+}
+
+// Mixed fleets, plain stepping (stored cmd as the action, one Env.step per launch).  The tile is partitioned
+// by type (above) and STAGED THROUGH LDS: every lane loads the fields of its natural drone (whole cache
+// lines per wave, streaming) and writes them to the LDS column of the slot that will process that drone;
+// after the barrier each wave reads its columns and runs the complete law of ITS type's kind — compiled as
+// two separate bodies, quads of a 6-actuator table touch 24 fields, not 26 — writes the results back to its
+// columns, and after a second barrier the natural lanes store them, coalesced again.  36 KB of LDS per
+// 256-drone tile; every line of the state crosses HBM once per direction.
+// (Measured and rejected on MI355X, 4.2 M drones, even index quad / odd index hexa: gathering the permuted
+// drones straight from global memory — the half-used lines are evicted between the two waves that share
+// them, 322 us, no better than no partition at all, 414 us with nontemporal loads; one launch per type with
+// the other types' waves retiring at once, 490 us: every line is pulled once per launch.)
+#define DSIM_STAGE_FIELDS 36
+#ifndef DSIM_MIXED_WAVES
+#define DSIM_MIXED_WAVES 3
+#endif
+template <bool HEXA, bool NOISE, int TILE>
+__device__ __forceinline__ void staged_body(const DevType& T, const StepK& a, long long i,
+                                            float (*stage)[TILE], unsigned t) {
+  constexpr int NA = HEXA ? 6 : 4;
+  Rigid s;
+  CtrlMem<NA> m;
+  Target tg;
+  s.pos = v3(stage[0][t], stage[1][t], stage[2][t]);
+  s.q = Q4{stage[3][t], stage[4][t], stage[5][t], stage[6][t]};
+  s.vel = v3(stage[7][t], stage[8][t], stage[9][t]);
+  s.w = v3(stage[10][t], stage[11][t], stage[12][t]);
+  m.last_vel = v3(stage[13][t], stage[14][t], stage[15][t]);
+  m.last_rates = v3(stage[16][t], stage[17][t], stage[18][t]);
+  m.last_thrust = stage[19][t];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) m.cmd[j] = stage[20 + j][t];
+  tg.pos = v3(stage[26][t], stage[27][t], stage[28][t]);
+  tg.vel = v3(stage[29][t], stage[30][t], stage[31][t]);
+  tg.acc = v3(stage[32][t], stage[33][t], stage[34][t]);
+  tg.yaw = stage[35][t];
+  V3 ext = v3(0, 0, 0);
+  if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
+  V3 pos_e;
+  float yaw_e;
+  if constexpr (HEXA) {
+    hexa_substeps<NOISE, false>(T, a, i, s, m.cmd, a.step_index, ext);
+    indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
+  } else {
+    quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
+    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  }
+  stage[0][t] = s.pos.x; stage[1][t] = s.pos.y; stage[2][t] = s.pos.z;
+  stage[3][t] = s.q.x; stage[4][t] = s.q.y; stage[5][t] = s.q.z; stage[6][t] = s.q.w;
+  stage[7][t] = s.vel.x; stage[8][t] = s.vel.y; stage[9][t] = s.vel.z;
+  stage[10][t] = s.w.x; stage[11][t] = s.w.y; stage[12][t] = s.w.z;
+  stage[13][t] = m.last_vel.x; stage[14][t] = m.last_vel.y; stage[15][t] = m.last_vel.z;
+  stage[16][t] = m.last_rates.x; stage[17][t] = m.last_rates.y; stage[18][t] = m.last_rates.z;
+  stage[19][t] = m.last_thrust;
+#pragma unroll
+  for (int j = 0; j < NA; ++j) stage[20 + j][t] = m.cmd[j];
+}
+template <bool NOISE, bool NT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, DSIM_MIXED_WAVES) void k_step_mixed(StepK a) {
+  constexpr int TILE = 64 * WAVES;
+  __shared__ float stage[DSIM_STAGE_FIELDS][TILE];
+  __shared__ unsigned char slot_drone[TILE], slot_type[TILE];
+  const long long i0 = a.first + (long long)blockIdx.x * TILE;
+  const unsigned t = threadIdx.x;
+  const int nat_t = (i0 + t < a.n_pad) ? min((int)a.type_id[i0 + t], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
+  const unsigned dest = tile_dest<WAVES>(nat_t);
+  const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
+  const unsigned sl = 4u * kv_lane(a.st, t), tl = 4u * kv_lane(a.tg, t);
+  float* const sb = a.st.base + kv_off(a.st, i0);
+  const float* const tb = a.tg.base + kv_off(a.tg, i0);
+  const bool nat_ok = nat_t < DSIM_MAX_TYPES;
+  const bool nat_hexa = nat_ok && ((a.hexa_types >> nat_t) & 1u);
+  slot_drone[dest] = (unsigned char)t;
+  slot_type[dest] = (unsigned char)nat_t;
+  if (nat_ok) {
+#pragma unroll
+    for (int f = 0; f < 24; ++f) stage[f][dest] = ldg<NT>(sb + f * sfs, sl);
+    if (nat_hexa) { stage[24][dest] = ldg<NT>(sb + 24 * sfs, sl); stage[25][dest] = ldg<NT>(sb + 25 * sfs, sl); }
+#pragma unroll
+    for (int f = 0; f < 10; ++f) stage[26 + f][dest] = ldg<NT>(tb + f * tfs, tl);
+  }
+  __syncthreads();
+  const int my_t = slot_type[t];
+  if (my_t < DSIM_MAX_TYPES) {
+    const long long i = i0 + slot_drone[t];
+    if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
+    for (;;) {
+      const int cur_t = __builtin_amdgcn_readfirstlane(my_t);
+      if (my_t == cur_t) {
+        const DevType& T = a.types[cur_t];
+        if (T.kind == DSIM_DEV_KIND_HEXA) staged_body<true, NOISE, TILE>(T, a, i, stage, t);
+        else staged_body<false, NOISE, TILE>(T, a, i, stage, t);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  if (nat_ok) {
+#pragma unroll
+    for (int f = 0; f < 24; ++f) stg<NT>(sb + f * sfs, sl, stage[f][dest]);
+    if (nat_hexa) { stg<NT>(sb + 24 * sfs, sl, stage[24][dest]); stg<NT>(sb + 25 * sfs, sl, stage[25][dest]); }
+  }
+}
+
+// Type-major storage (dsim_step_args.runs): a run of one type is stepped by the single-type law of its kind,
+// the fast form (no partition, no waterfall, per-type constants in SGPRs); ext = optional downwash force.
+template <bool HEXA, bool NOISE, bool NT>
+__global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void k_step_run(StepK a) {
+  const long long i0 = a.first + (long long)blockIdx.x * 256;
+  const long long i = i0 + threadIdx.x;
+  if (i >= a.last) return;
+  const DevType& T = a.types[a.run_type];
+  const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
+  const unsigned sl = 4u * kv_lane(a.st, threadIdx.x), tl = 4u * kv_lane(a.tg, threadIdx.x);
+  float* const sb = a.st.base + kv_off(a.st, i0);
+  const float* const tb = a.tg.base + kv_off(a.tg, i0);
+  constexpr int NA = HEXA ? 6 : 4;
+  Rigid s;
+  CtrlMem<NA> m;
+  Target tg;
+  load_rigid<NT>(sb, sfs, sl, s);
+  load_mem<NA, NT>(sb, sfs, sl, m);
+  load_target<NT>(tb, tfs, tl, tg);
+  V3 ext = v3(0, 0, 0);
+  if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
+  if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
+  V3 pos_e;
+  float yaw_e;
+  if constexpr (HEXA) {
+    hexa_substeps<NOISE, false>(T, a, i, s, m.cmd, a.step_index, ext);
+    indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
+  } else {
+    quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
+    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  }
+  store_rigid<NT>(sb, sfs, sl, s);
+  store_mem<NA, NT>(sb, sfs, sl, m);
 }
 
 // ---- Env.step only ---------------------------------------------------------
@@ -435,9 +626,10 @@ __device__ __forceinline__ void physics_gen_body(const DevType& T, const StepK& 
 template <bool NOISE, bool UNIFORM, int NACT>
 __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_physics_gen(StepK a) {
   const long long i0 = (long long)blockIdx.x * 256;
-  const long long i = i0 + threadIdx.x;
+  const unsigned p = tile_slot<UNIFORM>(a.type_id, i0, a.n_pad);
+  const long long i = i0 + p;
   if (i >= a.n_pad) return;
-  const Addr ad = make_addr(a, i0);
+  const Addr ad = make_addr(a, i0, p);
   DSIM_FOR_MY_TYPE(UNIFORM, a, i, (physics_gen_body<NOISE, NACT>(T, a, i, ad)));
 }
 
@@ -470,9 +662,10 @@ __device__ __forceinline__ void control_gen_body(const DevType& T, const StepK& 
 template <bool UNIFORM, int NACT>
 __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_control_gen(StepK a) {
   const long long i0 = (long long)blockIdx.x * 256;
-  const long long i = i0 + threadIdx.x;
+  const unsigned p = tile_slot<UNIFORM>(a.type_id, i0, a.n_pad);
+  const long long i = i0 + p;
   if (i >= a.n_pad) return;
-  const Addr ad = make_addr(a, i0);
+  const Addr ad = make_addr(a, i0, p);
   DSIM_FOR_MY_TYPE(UNIFORM, a, i, (control_gen_body<NACT>(T, a, i, ad)));
 }
 
@@ -512,9 +705,10 @@ __device__ __forceinline__ void adaptor_body(const DevType& T, const StepK& a, l
 template <int MODE, bool NOISE, bool UNIFORM>
 __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_adaptor(StepK a) {
   const long long i0 = (long long)blockIdx.x * 256;
-  const long long i = i0 + threadIdx.x;
+  const unsigned p = tile_slot<UNIFORM>(a.type_id, i0, a.n_pad);
+  const long long i = i0 + p;
   if (i >= a.n_pad) return;
-  const Addr ad = make_addr(a, i0);
+  const Addr ad = make_addr(a, i0, p);
   DSIM_FOR_MY_TYPE(UNIFORM, a, i, (adaptor_body<MODE, NOISE>(T, a, i, ad)));
 }
 
@@ -947,6 +1141,8 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
   } else {
     memset(&a->tg, 0, sizeof(a->tg));
   }
+  a->hexa_types = 0;
+  for (int t = 0; t < ctx->n_types; ++t) a->hexa_types |= (ctx->h_types[t].kind == DSIM_KIND_HEXA6DOF ? 1u : 0u) << t;
   a->types = ctx->d_types; a->type_id = args->type_id; a->noise_replay = args->noise_replay;
   a->action = args->action; a->echo = nullptr; a->pos_e_out = nullptr; a->yaw_e_out = nullptr;
   a->fb.entries = ctx->d_fb; a->fb.count = ctx->d_counters + 2; a->fb.counters = ctx->d_counters;
@@ -1016,6 +1212,40 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   if ((args->options & DSIM_OPT_CHAINED) && (!uni || six || args->action || args->noise_replay || args->ext_force ||
                                              phys_opts || (state.n_pad % 256)))
     return DSIM_E_UNSUPPORTED;                          // chained stepping is a fast-path-only mode
+  if (args->runs && args->n_runs > 0 && !args->action && !args->noise_replay && !a.wp_table && a.n_steps == 1 &&
+      !phys_opts && a.tg.base && !(args->options & DSIM_OPT_CHAINED)) {
+    // type-major storage: one single-type launch per run
+    static const char* nt_env = getenv("DSIM_NT");
+    const bool nt = nt_env ? atoi(nt_env) != 0 : (double)state.n_pad * 240.0 > 192.0 * 1024 * 1024;
+    bool any_hexa = false;
+    for (int r = 0; r < args->n_runs; ++r) {
+      const dsim_type_run& run = args->runs[r];
+      if (run.first < 0 || run.count < 0 || (run.first % 256) || run.first + run.count > a.n_pad || run.type < 0 ||
+          run.type >= ctx->n_types)
+        return DSIM_E_ARG;
+      any_hexa |= ctx->h_types[run.type].kind == DSIM_KIND_HEXA6DOF;
+    }
+    if (any_hexa) {
+      rc = fb_prepare(ctx, a.n_pad, st_);
+      if (rc) return rc;
+      a.fb.entries = ctx->d_fb;
+    }
+#define DSIM_RUN_CASE(H_)                                                                         \
+  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_run<H_, true, true>), g, b, 0, st_, a);    \
+                    else hipLaunchKernelGGL((k_step_run<H_, true, false>), g, b, 0, st_, a); }    \
+       else { if (nt) hipLaunchKernelGGL((k_step_run<H_, false, true>), g, b, 0, st_, a);         \
+              else hipLaunchKernelGGL((k_step_run<H_, false, false>), g, b, 0, st_, a); } } while (0)
+    for (int r = 0; r < args->n_runs; ++r) {
+      const dsim_type_run& run = args->runs[r];
+      if (run.count == 0) continue;
+      a.first = run.first; a.last = run.first + run.count; a.run_type = run.type;
+      const dim3 g(grid_for(run.count));
+      if (ctx->h_types[run.type].kind == DSIM_KIND_HEXA6DOF) DSIM_RUN_CASE(true); else DSIM_RUN_CASE(false);
+    }
+#undef DSIM_RUN_CASE
+    if (any_hexa) fb_finish(ctx, a, st_);
+    return (int)hipGetLastError();
+  }
   if (uni && !six && !args->action && !args->noise_replay && !args->ext_force && !phys_opts) {
     // fast path over the whole 256-drone tiles.  Streaming (nontemporal) accesses once the fleet's
     // per-step traffic exceeds what the 256 MB Infinity Cache can keep between consecutive steps
@@ -1060,7 +1290,29 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     a.first = first;
     const dim3 g(grid_for(a.n_pad - first));
     const bool lean = !args->action && !args->noise_replay && !a.wp_table && a.n_steps == 1 && !phys_opts;
-    if (!six) {
+    static const char* typed_env = getenv("DSIM_TYPED");      // A/B knob: 0 = the general mixed-law kernel
+    if (lean && !uni && a.tg.base && !(typed_env && atoi(typed_env) == 0)) {
+      static const char* nt_env = getenv("DSIM_NT");
+      const bool nt = nt_env ? atoi(nt_env) != 0 : (double)state.n_pad * 240.0 > 192.0 * 1024 * 1024;
+      bool any_hexa = false;
+      for (int t = 0; t < ctx->n_types; ++t) any_hexa |= ctx->h_types[t].kind == DSIM_KIND_HEXA6DOF;
+      if (any_hexa && !fb_open) {
+        rc = fb_prepare(ctx, a.n_pad, st_);
+        if (rc) return rc;
+        a.fb.entries = ctx->d_fb;
+      }
+      static const char* mw_env = getenv("DSIM_MIXED_TILE");   // A/B knob: drones per workgroup (128 | 256)
+      const int mw = mw_env ? atoi(mw_env) : 128;                // measured: 293 vs 303 us at 4.2 M drones
+#define DSIM_MIXED_CASE(W_)                                                                                       \
+  do { const dim3 gm((unsigned)((a.n_pad - first + 64 * W_ - 1) / (64 * W_))), bm(64 * W_);                      \
+       if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed<true, true, W_>), gm, bm, 0, st_, a);                \
+                    else hipLaunchKernelGGL((k_step_mixed<true, false, W_>), gm, bm, 0, st_, a); }                \
+       else { if (nt) hipLaunchKernelGGL((k_step_mixed<false, true, W_>), gm, bm, 0, st_, a);                     \
+              else hipLaunchKernelGGL((k_step_mixed<false, false, W_>), gm, bm, 0, st_, a); } } while (0)
+      if (mw == 128) DSIM_MIXED_CASE(2); else DSIM_MIXED_CASE(4);
+#undef DSIM_MIXED_CASE
+      if (any_hexa) fb_finish(ctx, a, st_);
+    } else if (!six) {
       if (lean) DSIM_LAUNCH_GEN(k_step_lean, noise, uni, false, g, a, st_);
       else DSIM_LAUNCH_GEN(k_step_gen, noise, uni, false, g, a, st_);
     } else {

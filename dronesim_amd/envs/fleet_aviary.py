@@ -69,6 +69,7 @@ class CtrlAviary:
         dist=None,
         chained: bool = False,
         downwash_exchange: str = "allgather",
+        type_ids=None,
     ):
         if gui or record or obstacles:
             raise NotImplementedError("gui/record/obstacles are rendering features outside the hot path")
@@ -82,16 +83,24 @@ class CtrlAviary:
         if isinstance(drone_model, (str, DroneType)):
             drone_model = [drone_model]
         models = list(drone_model)
-        if len(models) != 1 and len(models) != num_drones:
-            raise ValueError("drone_model must name one model per drone (or one for all)")
-        # type table: unique models in first-seen order
         self._type_names, types, tid = [], [], np.zeros(num_drones, dtype=np.uint8)
-        for i, m in enumerate(models):
-            key = m if isinstance(m, str) else m.name
-            if key not in self._type_names:
-                self._type_names.append(key)
-                types.append(builtin_type(m) if isinstance(m, str) else m)
-            tid[i] = self._type_names.index(key)
+        if type_ids is not None:
+            # large mixed fleets: drone_model is the table of distinct models, type_ids[i] indexes it
+            tid = np.asarray(type_ids, dtype=np.uint8).reshape(num_drones)
+            if int(tid.max(initial=0)) >= len(models):
+                raise ValueError("type_ids index past drone_model")
+            types = [builtin_type(m) if isinstance(m, str) else m for m in models]
+            self._type_names = [t.name for t in types]
+        else:
+            if len(models) != 1 and len(models) != num_drones:
+                raise ValueError("drone_model must name one model per drone (or one for all)")
+            # type table: unique models in first-seen order
+            for i, m in enumerate(models):
+                key = m if isinstance(m, str) else m.name
+                if key not in self._type_names:
+                    self._type_names.append(key)
+                    types.append(builtin_type(m) if isinstance(m, str) else m)
+                tid[i] = self._type_names.index(key)
         self.drones = [types[k] for k in tid] if num_drones <= DICT_IO_MAX_DRONES else None
         self.types = types
         self.G = 9.8                                    # BaseAviary.py:182
@@ -120,6 +129,17 @@ class CtrlAviary:
             t = np.zeros(self.state.n_pad, dtype=np.uint8)
             t[:num_drones] = tid
             self._type_id = torch.from_numpy(t).to(self.ctx.device)
+        # type-major storage: when the fleet is laid out as runs of one type starting at multiples of 256, each
+        # run is stepped by the single-type kernel of its kind (fleet.type_major_order() builds such an order)
+        self._runs = None
+        if len(types) > 1:
+            from ..fleet import type_runs
+            runs = type_runs(tid)
+            if all(f % 256 == 0 for f, _, _ in runs) and len(runs) <= 64:
+                arr = (nat.TypeRun * len(runs))()
+                for k, (f, c, ty) in enumerate(runs):
+                    arr[k].first, arr[k].count, arr[k].type = f, c, ty
+                self._runs = arr
         self.n_act = self.ctx.n_act
         self._action_buf = torch.zeros((self.n_act, self.state.n_pad), dtype=torch.float32, device=self.ctx.device)
         # the env's own last_clipped_action (BaseAviary.py:660-663, 545): separate from the
@@ -170,6 +190,8 @@ class CtrlAviary:
         a.wp_table = a.wp_counter = a.wp_offset = None
         a.n_wp, a.n_steps = 0, 1
         a.ext_force = self._downwash.compute().data_ptr() if self._downwash is not None else None
+        if self._runs is not None:
+            a.runs, a.n_runs = ctypes.addressof(self._runs), len(self._runs)
         return a
 
     # ------------------------------------------------------------------ gym surface

@@ -59,6 +59,35 @@ class Context:
             pass
 
 
+def type_runs(type_ids) -> list:
+    """[(first, count, type), ...]: maximal runs of equal consecutive type ids."""
+    t = np.asarray(type_ids).astype(np.int64).ravel()
+    if t.size == 0:
+        return []
+    cut = np.flatnonzero(np.diff(t)) + 1
+    first = np.concatenate([[0], cut])
+    count = np.diff(np.concatenate([first, [t.size]]))
+    return [(int(f), int(c), int(t[f])) for f, c in zip(first, count)]
+
+
+def type_major_order(type_ids, align: int = 256):
+    """Storage order for a heterogeneous fleet: drones grouped by type, each group starting at a multiple of
+    `align` (the gaps are padding slots).  Returns (slot_of_drone [n] int64, n_slots, slot_types [n_slots] uint8):
+    drone i of the caller's numbering lives in storage slot slot_of_drone[i]; padding slots carry the type of
+    the group they follow.  A fleet built in this order (CtrlAviary(type_ids=slot_types, ...)) is stepped by one
+    single-type kernel per group instead of the mixed-fleet kernel."""
+    t = np.asarray(type_ids).astype(np.int64).ravel()
+    slot = np.zeros(t.size, dtype=np.int64)
+    slot_types, base = [], 0
+    for ty in np.unique(t):
+        idx = np.flatnonzero(t == ty)
+        slot[idx] = base + np.arange(idx.size)
+        size = -(-idx.size // align) * align
+        slot_types.append(np.full(size, ty, dtype=np.uint8))
+        base += size
+    return slot, base, np.concatenate(slot_types) if slot_types else np.zeros(0, np.uint8)
+
+
 class BlockedSoA:
     """fp32 device array addressed as the C-ABI's blocked SoA.
 

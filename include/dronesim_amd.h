@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DSIM_ABI_VERSION 2
+#define DSIM_ABI_VERSION 3
 #define DSIM_MAX_ACT 6     /* actuators per vehicle (quad 4, morphing hexa 6) */
 #define DSIM_MAX_TYPES 8
 
@@ -123,6 +123,14 @@ enum {
                                        drone-step).  The six fields are stale until dsim_materialize is called. */
 };
 
+/* A run of consecutive drones of one type (type-major storage of a heterogeneous fleet). */
+typedef struct dsim_type_run {
+  int64_t first;            /* first drone of the run; a multiple of 256                                */
+  int64_t count;            /* drones in the run                                                        */
+  int32_t type;             /* index into the ctx type table                                            */
+  int32_t _pad;
+} dsim_type_run;
+
 typedef struct dsim_step_args {
   int32_t  phys_substeps;   /* AGGR_PHY_STEPS: Bullet sub-steps per Env.step (BaseAviary.py:510) */
   float    dt_phys;         /* 1/SIM_FREQ  (BaseAviary.py:675)                                   */
@@ -159,6 +167,14 @@ typedef struct dsim_step_args {
    * captured hipGraph of [dsim_step, dsim_counter_add] pairs be replayed without repeating the noise
    * stream (kernel arguments are frozen at capture time, device memory is not).                        */
   const uint64_t* step_index_dev;
+  /* -- type-major storage ------------------------------------------------------------------------------
+   * nullable HOST array: the fleet is stored as n_runs runs of one type each (type_id[], still required by
+   * the other entry points, must agree).  dsim_step then launches the single-type kernel of each run's kind
+   * over that run — the mixed-fleet kernel, which has to hold every law and re-sort each tile by type, is
+   * not needed.  Drones outside every run are not stepped.                                              */
+  const dsim_type_run* runs;
+  int32_t n_runs;
+  int32_t _pad_runs;
 } dsim_step_args;
 
 typedef struct dsim_ctx dsim_ctx;

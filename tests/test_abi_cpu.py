@@ -34,7 +34,7 @@ def test_struct_sizes_match_c(nat):
     from oracle import oracle as orc
     assert orc.lib().orc_sizeof_params() == ctypes.sizeof(params.TypeParamsC)
     assert ctypes.sizeof(nat.View) == 48
-    assert ctypes.sizeof(nat.StepArgs) == 104
+    assert ctypes.sizeof(nat.StepArgs) == 120
 
 
 def test_no_cpu_fallback(nat):

@@ -412,6 +412,67 @@ def test_mixed_fleet_vs_oracle(gpu):
     ctx.close()
 
 
+def test_type_major_runs_equal_mixed_kernel_and_oracle(gpu):
+    """Type-major storage (dsim_step_args.runs): three types grouped in runs that start at multiples of 256
+    (fleet.type_major_order), each run stepped by the single-type kernel of its kind — same result as the
+    mixed-fleet kernel on the same storage (bitwise: same arithmetic, drone-keyed noise) and as the oracle."""
+    nat, fleet = gpu
+    types = [params.builtin_type("robobee"), params.builtin_type("hexa_6DOF"), params.builtin_type("tello")]
+    rng = np.random.default_rng(43)
+    n = 1500
+    caller_tid = rng.integers(0, 3, n).astype(np.uint8)               # the caller's (interleaved) numbering
+    slot, n_slots, slot_types = fleet.type_major_order(caller_tid)
+    assert n_slots % 256 == 0 and (slot_types[slot] == caller_tid).all() and len(set(slot)) == n
+    runs = fleet.type_runs(slot_types)
+    assert [r[2] for r in runs] == [0, 1, 2] and all(r[0] % 256 == 0 for r in runs)
+    rigid, mem, tgt = random_fleet(rng, n_slots, n_act=6, tilt=0.3, rate=1.0)
+    mem[slot_types != 1, 11:13] = 0.0
+    sub, seed, sidx = 2, 77, 3
+    results = []
+    for use_runs in (True, False):
+        ctx = fleet.Context(types)
+        st, tg = fleet.FleetState(ctx, n_slots), fleet.Targets(ctx, n_slots)
+        st.load_aos(rigid, mem)
+        tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
+        tid_dev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device)
+        tid_dev[:n_slots] = torch.from_numpy(slot_types)
+        a = _args(nat, sub, DT, float(np.float32(sub / 240)), seed=seed, step_index=sidx, type_id=tid_dev)
+        arr = (nat.TypeRun * len(runs))()
+        for k, (f, c, ty) in enumerate(runs):
+            arr[k].first, arr[k].count, arr[k].type = f, c, ty
+        if use_runs:
+            a.runs, a.n_runs = ctypes.addressof(arr), len(runs)
+        for k in range(3):
+            a.step_index = sidx + k
+            nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n_slots, st.view(), tg.view(), ctypes.byref(a)))
+        torch.cuda.synchronize()
+        results.append((st.rigid_aos(), st.mem_aos()))
+        ctx.close()
+    np.testing.assert_array_equal(results[0][0], results[1][0])
+    np.testing.assert_array_equal(results[0][1], results[1][1])
+    O = orc.Oracle(types)
+    for k in range(3):
+        nz = np.zeros((n_slots, sub, 12))
+        for i in range(n_slots):
+            na = 6 if slot_types[i] == 1 else 4
+            for s_ in range(sub):
+                u = O.noise_normals(seed, i, (sidx + k) * sub + s_, na)
+                nz[i, s_, 0:na] = u[0:na] * 0.01
+                nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
+        assert O.step(rigid, mem, tgt, sub, DT, float(np.float32(sub / 240)), noise=nz, type_id=slot_types) == 0
+    assert rel_err(results[0][0], rigid, RIGID_SCALE).max() < 3 * REL_TOL
+    assert rel_err(results[0][1], mem, MEM_SCALE).max() < 6 * REL_TOL
+    # a misaligned run is refused
+    ctx = fleet.Context(types)
+    st, tg = fleet.FleetState(ctx, n_slots), fleet.Targets(ctx, n_slots)
+    tid_dev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device)
+    a = _args(nat, 1, DT, DT, type_id=tid_dev)
+    bad = (nat.TypeRun * 1)(); bad[0].first, bad[0].count, bad[0].type = 100, 50, 0
+    a.runs, a.n_runs = ctypes.addressof(bad), 1
+    assert ctx.lib.dsim_step(ctx.handle, _stream(ctx), n_slots, st.view(), tg.view(), ctypes.byref(a)) == -1   # DSIM_E_ARG
+    ctx.close()
+
+
 def test_hexa_hover_physics(gpu):
     """Level hexa at hover PWM (tilted rotors: vertical thrust = weight, lateral components and all
     torques cancel) stays put."""
