@@ -310,6 +310,25 @@ def main():
                     also[name]["hbm_frac"] = f2.n * bts / (d2 / k2) / 1e9 / HBM_PEAK_GBPS
                     also[name]["bytes_per_drone_step"] = bts
                 f2.env.close(); del f2
+            # the reference-shaped loop at the same size: obs = env.step(cmd); cmd = ctrl.computeControlFromState(...)
+            # (three kernels + the [N,20] observation instead of the fused one: 480+ B per drone-step)
+            from dronesim_amd.control import INDIControl
+            from dronesim_amd.envs import CtrlAviary
+            xyz = grid_fleet(4096, 1024)
+            env = CtrlAviary(["robobee"], xyz.shape[0], initial_xyzs=xyz, aggregate_phy_steps=1, noise_seed=a.noise_seed,
+                             dict_io=False, layout=a.layout, device=local)
+            ctrl = INDIControl("robobee", env=env)
+            tp = torch.from_numpy(np.ascontiguousarray(xyz.T.astype(np.float32))).to(env.ctx.device)
+            cmd = torch.full((xyz.shape[0], 4), 0.4, device=env.ctx.device)
+            for timed_pass in (False, True):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(20):
+                    obs, _, _, _ = env.step(cmd)
+                    cmd, _, _ = ctrl.computeControlFromState(1 / 240, None, target_pos=tp, target_rpy=np.array([0, 0, 0.4]))
+                torch.cuda.synchronize(); el = time.perf_counter() - t0
+            also["config2x1024_env_step_then_computeControl"] = {"drone_steps_per_s": xyz.shape[0] * 20 / el,
+                                                                 "loop_us": el / 20 * 1e6}
+            env.close(); del env, ctrl
             out["also"] = also
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.substeps)

@@ -132,6 +132,8 @@ class BlockedSoA:
         vals = values.to(self.data.device, torch.float32)
         if self.layout == "soa":
             self.data[f0:f0 + nf, : self.n] = vals
+        elif self.n == self.n_pad:          # whole tiles: one strided copy, no staging buffer
+            self.data[:, f0:f0 + nf, :] = vals.reshape(nf, self.n_pad // self.block, self.block).permute(1, 0, 2)
         else:
             full = torch.zeros((nf, self.n_pad), dtype=torch.float32, device=self.data.device)
             full[:, : self.n] = vals
