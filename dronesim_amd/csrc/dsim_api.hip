@@ -102,6 +102,15 @@ template <bool NT> __device__ __forceinline__ void stg(float* ub, unsigned boff,
   if (NT) __builtin_nontemporal_store(v, p); else *p = v;
 }
 
+// The stores sit in a later basic block than the loads; instruction selection works per block and would no
+// longer see that the lane offset is a zero-extended 32-bit value, so every store would get a 64-bit VGPR
+// address (one v_lshl_add_u64 + two VGPRs per field).  Re-materialising the offset in the store's block keeps
+// the scalar-base + 32-bit-lane-offset form there too.
+__device__ __forceinline__ unsigned pin_lane_offset(unsigned off) {
+  asm volatile("" : "+v"(off));
+  return off;
+}
+
 template <bool NT = false>
 __device__ __forceinline__ void load_rigid(const float* ub, long long fs, unsigned lo /* bytes */, Rigid& s) {
   s.pos = v3(ldg<NT>(ub + 0 * fs, lo), ldg<NT>(ub + 1 * fs, lo), ldg<NT>(ub + 2 * fs, lo));
@@ -269,8 +278,9 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
     }
     if (a.wp_table) a.wp_counter[i] = wp;
   }
-  store_rigid<NT>(sb, sfs, sl, s);
-  store_mem<4, NT, CH>(sb, sfs, sl, m);
+  const unsigned so = pin_lane_offset(sl);
+  store_rigid<NT>(sb, sfs, so, s);
+  store_mem<4, NT, CH>(sb, sfs, so, m);
 }
 
 __global__ void k_counter_add(unsigned long long* c, unsigned long long inc) { *c += inc; }
@@ -302,8 +312,9 @@ __global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
   float yaw_e;
   hexa_substeps<NOISE, false>(T, a, i, s, m.cmd, a.step_index);
   indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
-  store_rigid<NT>(sb, sfs, sl, s);
-  store_mem<6, NT>(sb, sfs, sl, m);
+  const unsigned so = pin_lane_offset(sl);
+  store_rigid<NT>(sb, sfs, so, s);
+  store_mem<6, NT>(sb, sfs, so, m);
 }
 
 // ends a chained sequence: last_vel / last_rates back into the state block
@@ -592,8 +603,9 @@ __global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void
     quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
-  store_rigid<NT>(sb, sfs, sl, s);
-  store_mem<NA, NT>(sb, sfs, sl, m);
+  const unsigned so = pin_lane_offset(sl);
+  store_rigid<NT>(sb, sfs, so, s);
+  store_mem<NA, NT>(sb, sfs, so, m);
 }
 
 // ---- Env.step only ---------------------------------------------------------
