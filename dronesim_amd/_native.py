@@ -23,6 +23,7 @@ ABI_VERSION = 3
 NF_QUAD, NF_HEXA, NT = 24, 26, 10
 OPT_DRAG, OPT_GROUND, OPT_BCAST_TGT, OPT_CHAINED = 1, 2, 4, 8
 ADAPT_VELOCITY, ADAPT_RPYT = 0, 1
+QUERY_WLS_FALLBACKS, QUERY_WLS_FAILURES = 0, 1
 
 
 class View(ctypes.Structure):

@@ -47,6 +47,13 @@ class Context:
     def stream_ptr(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def query(self, what: int) -> int:
+        """dsim_query (synchronises the stream): nat.QUERY_WLS_FALLBACKS = drones that took the full active-set
+        WLS loop so far, nat.QUERY_WLS_FAILURES = those where it did not converge (the reference would raise)."""
+        v = ctypes.c_int64(0)
+        nat.check(self.lib.dsim_query(self._h, self.stream_ptr(), int(what), ctypes.byref(v)))
+        return int(v.value)
+
     def close(self):
         if self._h:
             self.lib.dsim_destroy(self._h)
