@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_step_lean(StepK a) {
 #endif
 template <bool HEXA, bool NOISE, int TILE>
 __device__ __forceinline__ void staged_body(const DevType& T, const StepK& a, long long i,
-                                            float (*stage)[TILE], unsigned t) {
+                                            float (*stage)[TILE], unsigned t, bool active) {
   constexpr int NA = HEXA ? 6 : 4;
   Rigid s;
   CtrlMem<NA> m;
@@ -510,11 +510,12 @@ __device__ __forceinline__ void staged_body(const DevType& T, const StepK& a, lo
   float yaw_e;
   if constexpr (HEXA) {
     hexa_substeps<NOISE, false>(T, a, i, s, m.cmd, a.step_index, ext);
-    indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
+    indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, active ? i : -1LL);
   } else {
     quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
+  if (!active) return;
   stage[0][t] = s.pos.x; stage[1][t] = s.pos.y; stage[2][t] = s.pos.z;
   stage[3][t] = s.q.x; stage[4][t] = s.q.y; stage[5][t] = s.q.z; stage[6][t] = s.q.w;
   stage[7][t] = s.vel.x; stage[8][t] = s.vel.y; stage[9][t] = s.vel.z;
@@ -525,24 +526,52 @@ __device__ __forceinline__ void staged_body(const DevType& T, const StepK& a, lo
 #pragma unroll
   for (int j = 0; j < NA; ++j) stage[20 + j][t] = m.cmd[j];
 }
-template <bool NOISE, bool NT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, DSIM_MIXED_WAVES) void k_step_mixed(StepK a) {
-  constexpr int TILE = 64 * WAVES;
-  __shared__ float stage[DSIM_STAGE_FIELDS][TILE];
-  __shared__ unsigned char slot_drone[TILE], slot_type[TILE];
+// WT = waves per workgroup = 2 natural waves (the tile is 128 drones) + one spare wave per additional type of the
+// table: every type's drones start at a wave boundary of the slot space, so EVERY wave holds one type and runs
+// one law in uniform control flow with no loop around it (a wave whose type's run ends inside it idles the rest
+// of its lanes; spare waves without drones retire at once).  With the two laws inside a per-wave loop over the
+// types present (or under a per-lane branch) the compiler needs 168 VGPRs + 100-300 B of spills at 3 waves/SIMD —
+// loop-invariant code motion stretches live ranges over both laws; in straight-line form it needs 133.
+template <bool NOISE, bool NT, int WT>
+__global__ __launch_bounds__(64 * WT, DSIM_MIXED_WAVES) void k_step_mixed(StepK a) {
+  constexpr int TILE = 128, SLOTS = 64 * WT;
+  __shared__ float stage[DSIM_STAGE_FIELDS][SLOTS];
+  __shared__ unsigned char slot_drone[SLOTS];
+  __shared__ unsigned short cnt[2][DSIM_MAX_TYPES];
   const long long i0 = a.first + (long long)blockIdx.x * TILE;
-  const unsigned t = threadIdx.x;
-  const int nat_t = (i0 + t < a.n_pad) ? min((int)a.type_id[i0 + t], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
-  const unsigned dest = tile_dest<WAVES>(nat_t);
+  const unsigned t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const bool nat_ok = t < TILE && i0 + t < a.n_pad;
+  const int nat_t = nat_ok ? min((int)a.type_id[i0 + t], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
+  unsigned rank = 0, c_mine = 0;
+  if (w < 2) {                                   // wave-uniform
+    const unsigned long long lt = (1ULL << lane) - 1ULL;
+#pragma unroll
+    for (int ty = 0; ty < DSIM_MAX_TYPES; ++ty) {
+      const unsigned long long mask = __ballot(nat_t == ty);
+      if (nat_t == ty) rank = (unsigned)__popcll(mask & lt);
+      if ((int)lane == ty) c_mine = (unsigned)__popcll(mask);
+    }
+    if (lane < DSIM_MAX_TYPES) cnt[w][lane] = (unsigned short)c_mine;
+  }
+  slot_drone[t] = 255;
+  __syncthreads();
+  // slot space: type ty owns ceil(count/64) whole waves, types in ascending order
+  unsigned dest = 0, acc_w = 0;
+  int wave_t = -1;
+#pragma unroll
+  for (int ty = 0; ty < DSIM_MAX_TYPES; ++ty) {
+    const unsigned c0 = cnt[0][ty], tot = c0 + cnt[1][ty], nw = (tot + 63) >> 6;
+    if (nat_t == ty) dest = acc_w * 64 + (w == 1 ? c0 : 0u) + rank;
+    if (w >= acc_w && w < acc_w + nw) wave_t = ty;
+    acc_w += nw;
+  }
   const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
   const unsigned sl = 4u * kv_lane(a.st, t), tl = 4u * kv_lane(a.tg, t);
   float* const sb = a.st.base + kv_off(a.st, i0);
   const float* const tb = a.tg.base + kv_off(a.tg, i0);
-  const bool nat_ok = nat_t < DSIM_MAX_TYPES;
   const bool nat_hexa = nat_ok && ((a.hexa_types >> nat_t) & 1u);
-  slot_drone[dest] = (unsigned char)t;
-  slot_type[dest] = (unsigned char)nat_t;
   if (nat_ok) {
+    slot_drone[dest] = (unsigned char)t;
 #pragma unroll
     for (int f = 0; f < 24; ++f) stage[f][dest] = ldg<NT>(sb + f * sfs, sl);
     if (nat_hexa) { stage[24][dest] = ldg<NT>(sb + 24 * sfs, sl); stage[25][dest] = ldg<NT>(sb + 25 * sfs, sl); }
@@ -550,25 +579,22 @@ __global__ __launch_bounds__(64 * WAVES, DSIM_MIXED_WAVES) void k_step_mixed(Ste
     for (int f = 0; f < 10; ++f) stage[26 + f][dest] = ldg<NT>(tb + f * tfs, tl);
   }
   __syncthreads();
-  const int my_t = slot_type[t];
-  if (my_t < DSIM_MAX_TYPES) {
-    const long long i = i0 + slot_drone[t];
+  wave_t = __builtin_amdgcn_readfirstlane(wave_t);
+  if (wave_t >= 0) {
+    const unsigned d = slot_drone[t];
+    const bool active = d != 255;                // idle lanes behind the end of the type's run: same law, nothing kept
+    const long long i = i0 + (active ? d : 0u);
     if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
-    for (;;) {
-      const int cur_t = __builtin_amdgcn_readfirstlane(my_t);
-      if (my_t == cur_t) {
-        const DevType& T = a.types[cur_t];
-        if (T.kind == DSIM_DEV_KIND_HEXA) staged_body<true, NOISE, TILE>(T, a, i, stage, t);
-        else staged_body<false, NOISE, TILE>(T, a, i, stage, t);
-        break;
-      }
-    }
+    const DevType& T = a.types[wave_t];
+    if (T.kind == DSIM_DEV_KIND_HEXA) staged_body<true, NOISE, SLOTS>(T, a, i, stage, t, active);
+    else staged_body<false, NOISE, SLOTS>(T, a, i, stage, t, active);
   }
   __syncthreads();
   if (nat_ok) {
+    const unsigned so = pin_lane_offset(sl);
 #pragma unroll
-    for (int f = 0; f < 24; ++f) stg<NT>(sb + f * sfs, sl, stage[f][dest]);
-    if (nat_hexa) { stg<NT>(sb + 24 * sfs, sl, stage[24][dest]); stg<NT>(sb + 25 * sfs, sl, stage[25][dest]); }
+    for (int f = 0; f < 24; ++f) stg<NT>(sb + f * sfs, so, stage[f][dest]);
+    if (nat_hexa) { stg<NT>(sb + 24 * sfs, so, stage[24][dest]); stg<NT>(sb + 25 * sfs, so, stage[25][dest]); }
   }
 }
 
@@ -1327,7 +1353,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     const dim3 g(grid_for(a.n_pad - first));
     const bool lean = !args->action && !args->noise_replay && !a.wp_table && a.n_steps == 1 && !phys_opts;
     static const char* typed_env = getenv("DSIM_TYPED");      // A/B knob: 0 = the general mixed-law kernel
-    if (lean && !uni && a.tg.base && !(typed_env && atoi(typed_env) == 0)) {
+    if (lean && !uni && a.tg.base && ctx->n_types <= 4 && !(typed_env && atoi(typed_env) == 0)) {
       static const char* nt_env = getenv("DSIM_NT");
       const bool nt = nt_env ? atoi(nt_env) != 0 : (double)state.n_pad * 240.0 > 192.0 * 1024 * 1024;
       bool any_hexa = false;
@@ -1337,15 +1363,13 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
         if (rc) return rc;
         a.fb.entries = ctx->d_fb;
       }
-      static const char* mw_env = getenv("DSIM_MIXED_TILE");   // A/B knob: drones per workgroup (128 | 256)
-      const int mw = mw_env ? atoi(mw_env) : 128;                // measured: 293 vs 303 us at 4.2 M drones
 #define DSIM_MIXED_CASE(W_)                                                                                       \
-  do { const dim3 gm((unsigned)((a.n_pad - first + 64 * W_ - 1) / (64 * W_))), bm(64 * W_);                      \
+  do { const dim3 gm((unsigned)((a.n_pad - first + 127) / 128)), bm(64 * W_);                                    \
        if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed<true, true, W_>), gm, bm, 0, st_, a);                \
                     else hipLaunchKernelGGL((k_step_mixed<true, false, W_>), gm, bm, 0, st_, a); }                \
        else { if (nt) hipLaunchKernelGGL((k_step_mixed<false, true, W_>), gm, bm, 0, st_, a);                     \
               else hipLaunchKernelGGL((k_step_mixed<false, false, W_>), gm, bm, 0, st_, a); } } while (0)
-      if (mw == 128) DSIM_MIXED_CASE(2); else DSIM_MIXED_CASE(4);
+      if (ctx->n_types == 2) DSIM_MIXED_CASE(3); else if (ctx->n_types == 3) DSIM_MIXED_CASE(4); else DSIM_MIXED_CASE(5);
 #undef DSIM_MIXED_CASE
       if (any_hexa) fb_finish(ctx, a, st_);
     } else if (!six) {

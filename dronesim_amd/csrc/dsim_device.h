@@ -552,7 +552,8 @@ __device__ __forceinline__ void indi_hexa(const DevType& T, float dt, const Rigi
   if (feasible) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) m.cmd[j] = clampf(m.cmd[j] + du[j], T.pmin[j], T.pmax[j]);   // :630-631
-  } else {   // cmd stays as it is; k_wls_fallback finishes this drone from (v, cmd)
+  } else if (drone >= 0) {   // cmd stays as it is; k_wls_fallback finishes this drone from (v, cmd)
+    // (drone < 0: a lane that only keeps a mixed wave's control flow uniform, see k_step_mixed)
     const unsigned long long slot = atomicAdd(fb.count, 1ULL);
     FbEntry e;
     e.drone = drone;
