@@ -212,13 +212,14 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
 }
 
 // the same for the morphing hexa (BaseAviary.py:1389-1457); replay rows: f[6], m[6]
-template <bool NOISE, bool REPLAY = true>
+template <bool NOISE, bool REPLAY = true, bool ONE = false>
 __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[6], unsigned long long step_index,
                                               V3 ext = V3{0.0f, 0.0f, 0.0f}) {
   V3 F, tau;
   if (!NOISE) hexa_wrench(T, cmd, nullptr, F, tau);
-  for (int k = 0; k < a.substeps; ++k) {
+  const int n_sub = ONE ? 1 : a.substeps;
+  for (int k = 0; k < n_sub; ++k) {
     if (NOISE) {
       float nz[12];
       if (REPLAY && a.noise_replay) {
@@ -296,7 +297,7 @@ __global__ void k_counter_add(unsigned long long* c, unsigned long long inc) { *
 #ifndef DSIM_HEXA_WAVES
 #define DSIM_HEXA_WAVES 3
 #endif
-template <bool NOISE, bool NT>
+template <bool NOISE, bool NT, bool S1>
 __global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
   const DevType& T = a.types[0];
   const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
   if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
   V3 pos_e;
   float yaw_e;
-  hexa_substeps<NOISE, false>(T, a, i, s, m.cmd, a.step_index);
+  hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index);
   indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
   const unsigned so = pin_lane_offset(sl);
   store_rigid<NT>(sb, sfs, so, s);
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_step_lean(StepK a) {
 #ifndef DSIM_MIXED_WAVES
 #define DSIM_MIXED_WAVES 3
 #endif
-template <bool HEXA, bool NOISE, int TILE>
+template <bool HEXA, bool NOISE, int TILE, bool S1>
 __device__ __forceinline__ void staged_body(const DevType& T, const StepK& a, long long i,
                                             float (*stage)[TILE], unsigned t, bool active) {
   constexpr int NA = HEXA ? 6 : 4;
@@ -513,10 +514,10 @@ __device__ __forceinline__ void staged_body(const DevType& T, const StepK& a, lo
   V3 pos_e;
   float yaw_e;
   if constexpr (HEXA) {
-    hexa_substeps<NOISE, false>(T, a, i, s, m.cmd, a.step_index, ext);
+    hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
     indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, active ? i : -1LL);
   } else {
-    quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
+    quad_substeps<NOISE ? 1 : 0, 4, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   if (!active) return;
@@ -536,7 +537,7 @@ __device__ __forceinline__ void staged_body(const DevType& T, const StepK& a, lo
 // of its lanes; spare waves without drones retire at once).  With the two laws inside a per-wave loop over the
 // types present (or under a per-lane branch) the compiler needs 168 VGPRs + 100-300 B of spills at 3 waves/SIMD —
 // loop-invariant code motion stretches live ranges over both laws; in straight-line form it needs 133.
-template <bool NOISE, bool NT, int WT>
+template <bool NOISE, bool NT, int WT, bool S1>
 __global__ __launch_bounds__(64 * WT, DSIM_MIXED_WAVES) void k_step_mixed(StepK a) {
   constexpr int TILE = 128, SLOTS = 64 * WT;
   __shared__ float stage[DSIM_STAGE_FIELDS][SLOTS];
@@ -590,8 +591,8 @@ __global__ __launch_bounds__(64 * WT, DSIM_MIXED_WAVES) void k_step_mixed(StepK 
     const long long i = i0 + (active ? d : 0u);
     if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
     const DevType& T = a.types[wave_t];
-    if (T.kind == DSIM_DEV_KIND_HEXA) staged_body<true, NOISE, SLOTS>(T, a, i, stage, t, active);
-    else staged_body<false, NOISE, SLOTS>(T, a, i, stage, t, active);
+    if (T.kind == DSIM_DEV_KIND_HEXA) staged_body<true, NOISE, SLOTS, S1>(T, a, i, stage, t, active);
+    else staged_body<false, NOISE, SLOTS, S1>(T, a, i, stage, t, active);
   }
   __syncthreads();
   if (nat_ok) {
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(64 * WT, DSIM_MIXED_WAVES) void k_step_mixed(StepK 
 
 // Type-major storage (dsim_step_args.runs): a run of one type is stepped by the single-type law of its kind,
 // the fast form (no partition, no waterfall, per-type constants in SGPRs); ext = optional downwash force.
-template <bool HEXA, bool NOISE, bool NT>
+template <bool HEXA, bool NOISE, bool NT, bool S1>
 __global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void k_step_run(StepK a) {
   const long long i0 = a.first + (long long)blockIdx.x * 256;
   const long long i = i0 + threadIdx.x;
@@ -627,10 +628,10 @@ __global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void
   V3 pos_e;
   float yaw_e;
   if constexpr (HEXA) {
-    hexa_substeps<NOISE, false>(T, a, i, s, m.cmd, a.step_index, ext);
+    hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
     indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
   } else {
-    quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
+    quad_substeps<NOISE ? 1 : 0, 4, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   const unsigned so = pin_lane_offset(sl);
@@ -1296,11 +1297,12 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
       if (rc) return rc;
       a.fb.entries = ctx->d_fb;
     }
-#define DSIM_RUN_CASE(H_)                                                                         \
-  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_run<H_, true, true>), g, b, 0, st_, a);    \
-                    else hipLaunchKernelGGL((k_step_run<H_, true, false>), g, b, 0, st_, a); }    \
-       else { if (nt) hipLaunchKernelGGL((k_step_run<H_, false, true>), g, b, 0, st_, a);         \
-              else hipLaunchKernelGGL((k_step_run<H_, false, false>), g, b, 0, st_, a); } } while (0)
+#define DSIM_RUN_CASE2(H_, S_)                                                                        \
+  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_run<H_, true, true, S_>), g, b, 0, st_, a);    \
+                    else hipLaunchKernelGGL((k_step_run<H_, true, false, S_>), g, b, 0, st_, a); }    \
+       else { if (nt) hipLaunchKernelGGL((k_step_run<H_, false, true, S_>), g, b, 0, st_, a);         \
+              else hipLaunchKernelGGL((k_step_run<H_, false, false, S_>), g, b, 0, st_, a); } } while (0)
+#define DSIM_RUN_CASE(H_) do { if (a.substeps == 1) DSIM_RUN_CASE2(H_, true); else DSIM_RUN_CASE2(H_, false); } while (0)
     for (int r = 0; r < args->n_runs; ++r) {
       const dsim_type_run& run = args->runs[r];
       if (run.count == 0) continue;
@@ -1309,6 +1311,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
       if (ctx->h_types[run.type].kind == DSIM_KIND_HEXA6DOF) DSIM_RUN_CASE(true); else DSIM_RUN_CASE(false);
     }
 #undef DSIM_RUN_CASE
+#undef DSIM_RUN_CASE2
     if (any_hexa) fb_finish(ctx, a, st_);
     return (int)hipGetLastError();
   }
@@ -1346,10 +1349,13 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     a.fb.entries = ctx->d_fb;
     fb_open = true;
     const dim3 g((unsigned)tiles);
-    if (noise) { if (nt) hipLaunchKernelGGL((k_step_hexa<true, true>), g, b, 0, st_, a);
-                 else hipLaunchKernelGGL((k_step_hexa<true, false>), g, b, 0, st_, a); }
-    else { if (nt) hipLaunchKernelGGL((k_step_hexa<false, true>), g, b, 0, st_, a);
-           else hipLaunchKernelGGL((k_step_hexa<false, false>), g, b, 0, st_, a); }
+#define DSIM_HEXA_CASE(S_)                                                                          \
+  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_hexa<true, true, S_>), g, b, 0, st_, a);      \
+                    else hipLaunchKernelGGL((k_step_hexa<true, false, S_>), g, b, 0, st_, a); }      \
+       else { if (nt) hipLaunchKernelGGL((k_step_hexa<false, true, S_>), g, b, 0, st_, a);           \
+              else hipLaunchKernelGGL((k_step_hexa<false, false, S_>), g, b, 0, st_, a); } } while (0)
+    if (a.substeps == 1) DSIM_HEXA_CASE(true); else DSIM_HEXA_CASE(false);
+#undef DSIM_HEXA_CASE
     first = tiles * 256;
     if (first >= a.n_pad) fb_finish(ctx, a, st_);
   }
@@ -1368,14 +1374,16 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
         if (rc) return rc;
         a.fb.entries = ctx->d_fb;
       }
-#define DSIM_MIXED_CASE(W_)                                                                                       \
+#define DSIM_MIXED_CASE2(W_, S_)                                                                                  \
   do { const dim3 gm((unsigned)((a.n_pad - first + 127) / 128)), bm(64 * W_);                                    \
-       if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed<true, true, W_>), gm, bm, 0, st_, a);                \
-                    else hipLaunchKernelGGL((k_step_mixed<true, false, W_>), gm, bm, 0, st_, a); }                \
-       else { if (nt) hipLaunchKernelGGL((k_step_mixed<false, true, W_>), gm, bm, 0, st_, a);                     \
-              else hipLaunchKernelGGL((k_step_mixed<false, false, W_>), gm, bm, 0, st_, a); } } while (0)
+       if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed<true, true, W_, S_>), gm, bm, 0, st_, a);            \
+                    else hipLaunchKernelGGL((k_step_mixed<true, false, W_, S_>), gm, bm, 0, st_, a); }            \
+       else { if (nt) hipLaunchKernelGGL((k_step_mixed<false, true, W_, S_>), gm, bm, 0, st_, a);                 \
+              else hipLaunchKernelGGL((k_step_mixed<false, false, W_, S_>), gm, bm, 0, st_, a); } } while (0)
+#define DSIM_MIXED_CASE(W_) do { if (a.substeps == 1) DSIM_MIXED_CASE2(W_, true); else DSIM_MIXED_CASE2(W_, false); } while (0)
       if (ctx->n_types == 2) DSIM_MIXED_CASE(3); else if (ctx->n_types == 3) DSIM_MIXED_CASE(4); else DSIM_MIXED_CASE(5);
 #undef DSIM_MIXED_CASE
+#undef DSIM_MIXED_CASE2
       if (any_hexa) fb_finish(ctx, a, st_);
     } else if (!six) {
       if (lean) DSIM_LAUNCH_GEN(k_step_lean, noise, uni, false, g, a, st_);
