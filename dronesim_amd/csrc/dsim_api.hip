@@ -174,16 +174,17 @@ __device__ __forceinline__ int waypoint_next(int wp, int n_wp) { return wp < n_w
 // NROW = rows per sub-step of the replay buffer's force / moment halves (the kernel's NACT).
 // OPTS: honour the drag / ground-effect option bits (general kernels only).  prev = the action of the
 // previous Env.step (last_clipped_action) for the drag of sub-step 0, or null = this step's action.
-// ONE: the launch runs exactly one sub-step (BASELINE's metric definition): straight-line code — without the
-// loop the compiler keeps the headline kernel in 91 instead of 110 VGPRs (5 waves/SIMD) and 836 instead of 887
-// vector instructions.
-template <int NOISE, int NROW = 4, bool OPTS = false, bool ONE = false>
+// NSUB > 0: the number of sub-steps is a compile-time constant and the code is straight-line.  Used for 1 (BASELINE's
+// metric definition): without the loop the compiler keeps the headline kernel in 91 instead of 110 VGPRs
+// (5 waves/SIMD) and 836 instead of 887 vector instructions.  (Measured and rejected: 2 — no change, 198 us
+// either way; 5 — the unrolled body spills, 533 vs 310 us.)
+template <int NOISE, int NROW = 4, bool OPTS = false, int NSUB = 0>
 __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[4], unsigned long long step_index,
                                               V3 ext = V3{0.0f, 0.0f, 0.0f}, const float* prev = nullptr) {
   V3 F, tau;
   if (NOISE == 0) quad_wrench(T, cmd, nullptr, F, tau);   // cmd is constant over the sub-steps
-  const int n_sub = ONE ? 1 : a.substeps;
+  const int n_sub = NSUB > 0 ? NSUB : a.substeps;
   for (int k = 0; k < n_sub; ++k) {
     if (NOISE != 0) {
       float nz[8];
@@ -250,7 +251,7 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
 // compiled without that generality (it would cost the hot kernel registers: 128 + spills vs 121).
 // CH = DSIM_OPT_CHAINED: last_vel / last_rates are recomputed from the rigid state the previous step
 // stored (they are functions of it) instead of being read, and are not written: 184 B/drone-step.
-template <bool NOISE, bool NT, bool EXT, bool CH = false, bool S1 = false>
+template <bool NOISE, bool NT, bool EXT, bool CH = false, int SUB = 0>
 __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(StepK a) {
   const DevType& T = a.types[0];
   const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
   float yaw_e;
   if (!EXT) {
     load_target<NT>(tb, tfs, tl, tg);
-    quad_substeps<NOISE ? 1 : 0, 4, false, S1>(T, a, i, s, m.cmd, a.step_index);    // stored cmd is already clipped
+    quad_substeps<NOISE ? 1 : 0, 4, false, SUB>(T, a, i, s, m.cmd, a.step_index);    // stored cmd is already clipped
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   } else {
     int wp = 0;
@@ -517,7 +518,7 @@ __device__ __forceinline__ void staged_body(const DevType& T, const StepK& a, lo
     hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
     indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, active ? i : -1LL);
   } else {
-    quad_substeps<NOISE ? 1 : 0, 4, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
+    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   if (!active) return;
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void
     hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
     indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
   } else {
-    quad_substeps<NOISE ? 1 : 0, 4, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
+    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   const unsigned so = pin_lane_offset(sl);
@@ -1330,7 +1331,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   do { if (ext) { if (ch) hipLaunchKernelGGL((k_step_fast<N_, T_, true, true>), g, b, 0, st_, a);   \
                   else hipLaunchKernelGGL((k_step_fast<N_, T_, true, false>), g, b, 0, st_, a); }   \
        else { if (ch) hipLaunchKernelGGL((k_step_fast<N_, T_, false, true>), g, b, 0, st_, a);      \
-              else if (a.substeps == 1) hipLaunchKernelGGL((k_step_fast<N_, T_, false, false, true>), g, b, 0, st_, a); \
+              else if (a.substeps == 1) hipLaunchKernelGGL((k_step_fast<N_, T_, false, false, 1>), g, b, 0, st_, a); \
               else hipLaunchKernelGGL((k_step_fast<N_, T_, false, false>), g, b, 0, st_, a); } } while (0)
       if (noise) { if (nt) DSIM_FAST_CASE(true, true); else DSIM_FAST_CASE(true, false); }
       else { if (nt) DSIM_FAST_CASE(false, true); else DSIM_FAST_CASE(false, false); }
