@@ -225,6 +225,40 @@ def test_hover_trajectory_vs_oracle(gpu):
     env.close()
 
 
+def test_full_flight_config1_vs_oracle(gpu):
+    """The whole 15 s flight of examples/fly_INDI.py (720 control steps x 5 sub-steps, yaw target ramping through
+    the +-pi wrap), three airframe starts side by side: the fp32 kernel's closed-loop trajectory stays on the fp64
+    oracle's for the entire flight, and ends hovering on the target."""
+    nat, fleet = gpu
+    from dronesim_amd.envs import CtrlAviary
+    starts = np.array([[0.0, 1.0, 0.5], [1.0, -1.0, 0.8], [-0.5, 0.5, 1.5]])
+    n = len(starts)
+    env = CtrlAviary(["robobee"], n, initial_xyzs=starts, initial_rpys=np.zeros((n, 3)), aggregate_phy_steps=5,
+                     noise_seed=0, dict_io=False)
+    tg = fleet.Targets(env.ctx, n)
+    O = orc.Oracle([params.builtin_type("robobee")])
+    rigid, mem = env.state.rigid_aos(), env.state.mem_aos()
+    dtc = float(np.float32(5 / 240))
+    worst, worst_k = 0.0, -1
+    for k in range(720):
+        yaw = float(np.float32(0.4 + k / 200.0))                         # fly_INDI.py:165-167 (reaches 4.0 rad)
+        tgt = f32(np.tile(np.array([[0, 0, 0.5, 0, 0, 0, 0, 0, 0, yaw]]), (n, 1)))
+        tg.set(pos=np.ascontiguousarray(tgt[:, 0:3].T), yaw=yaw)
+        env.step_fused(tg, control_timestep=dtc, action=np.full((n, 4), 0.4, dtype=np.float32) if k == 0 else None)
+        a6 = None
+        if k == 0:
+            a6 = np.zeros((n, 6)); a6[:, :4] = 0.4
+        assert O.step(rigid, mem, tgt, 5, DT, dtc, action=a6) == 0
+        if k % 8 == 7 or k == 719:
+            e = rel_err(env.state.rigid_aos(), rigid, RIGID_SCALE).max()
+            if e > worst:
+                worst, worst_k = e, k
+    assert worst < 2e-3, (worst, worst_k)
+    final = env.state.rigid_aos()
+    assert np.abs(final[:, 0:3] - np.array([0, 0, 0.5])).max() < 0.02 and np.abs(final[:, 7:10]).max() < 0.05
+    env.close()
+
+
 def test_noise_replay_vs_oracle(gpu):
     nat, fleet = gpu
     n, sub = 512, 5
