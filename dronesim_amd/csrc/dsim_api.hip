@@ -30,7 +30,7 @@ struct dsim_ctx {
   int n_types;
   int max_act;                            // 4: quads only; 6: the table holds a morphing hexa
   DevType* d_types;                       // device copy of the type table
-  unsigned long long* d_counters;         // [0..1] diagnostics (dsim_query), [2] fallback queue length
+  unsigned long long* d_counters;         // [0..1] diagnostics (dsim_query), [2] fallback queue length, [3] its ticket
   FbEntry* d_fb;                          // deferred WLS fallback queue, grown to the largest fleet seen
   long long fb_cap;
   const int32_t* dw_ws;                   // downwash grid: workspace / shape / count-buffer parity of the last call
@@ -944,6 +944,11 @@ struct DwK {
   int* adj_list;     // [max_k][n_pad] or null
   int max_k;
 };
+// position component c of world entry j: from the gathered array, or (single-rank fleets, pos_all = null)
+// straight from the state block
+__device__ __forceinline__ float dw_pos(const DwK& a, long long j, int c) {
+  return a.pos_all ? a.pos_all[(long long)c * a.m_pad + j] : a.st.base[kv_off(a.st, j) + c * a.st.field_stride];
+}
 __device__ __forceinline__ int dw_cell(const DwK& a, float x, float y, int& cx, int& cy) {
   cx = min(max((int)floorf((x - a.xmin) * a.inv_cell), 0), a.nx - 1);
   cy = min(max((int)floorf((y - a.ymin) * a.inv_cell), 0), a.ny - 1);
@@ -953,9 +958,10 @@ __global__ __launch_bounds__(256) void k_dw_count(DwK a) {
   const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
   // also zeroes the count buffer the NEXT grid build will use (double-buffered: no memset per step)
   if (j <= (long long)a.nx * a.ny) a.count_next[j] = 0;
-  if (j >= a.m) return;
-  int cx, cy;
-  atomicAdd(&a.count[dw_cell(a, a.pos_all[j], a.pos_all[a.m_pad + j], cx, cy)], 1);
+  if (j < a.m) {
+    int cx, cy;
+    atomicAdd(&a.count[dw_cell(a, dw_pos(a, j, 0), dw_pos(a, j, 1), cx, cy)], 1);
+  }
 }
 // exclusive scan of count[0..ncells) by ONE workgroup (ncells is a few thousand); count[ncells] = m
 __global__ __launch_bounds__(1024) void k_dw_scan(DwK a) {
@@ -979,7 +985,7 @@ __global__ __launch_bounds__(1024) void k_dw_scan(DwK a) {
 __global__ __launch_bounds__(256) void k_dw_scatter(DwK a) {
   const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
   if (j >= a.m) return;
-  const float x = a.pos_all[j], y = a.pos_all[a.m_pad + j], z = a.pos_all[2 * a.m_pad + j];
+  const float x = dw_pos(a, j, 0), y = dw_pos(a, j, 1), z = dw_pos(a, j, 2);
   int cx, cy;
   const int slot = atomicAdd(&a.cursor[dw_cell(a, x, y, cx, cy)], 1);
   a.sorted[slot] = make_float4(x, y, z, __int_as_float((int)j));
@@ -1147,8 +1153,8 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
   for (int t = 0; t < n_types; ++t) { c->h_types[t] = types[t]; to_dev(types[t], &h[t]); }
   e = hipMalloc((void**)&c->d_types, sizeof(DevType) * n_types);
   if (e == hipSuccess) e = hipMemcpy(c->d_types, h, sizeof(DevType) * n_types, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * 4);
-  if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(unsigned long long) * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * 8);
+  if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(unsigned long long) * 8);
   if (e != hipSuccess) {
     if (c->d_types) (void)hipFree(c->d_types);
     if (c->d_counters) (void)hipFree(c->d_counters);
@@ -1560,8 +1566,10 @@ int dsim_adjacency(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, cons
 static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view& state,
                       const dsim_downwash_args* g, float min_cell, DwK* out) {
   DwK& a_ = *out;
-  if (!ctx || !g || !g->pos_all || !g->workspace || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
-  if (g->m < 1 || g->m_pad < g->m || g->nx < 1 || g->ny < 1 || !(g->cell >= min_cell)) return DSIM_E_ARG;
+  if (!ctx || !g || !g->workspace || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
+  // pos_all = NULL: the world is this fleet (m = n, local_offset = 0) and positions are read from the state block
+  if (!g->pos_all && (g->m != n || g->local_offset != 0)) return DSIM_E_ARG;
+  if (g->m < 1 || (g->pos_all && g->m_pad < g->m) || g->nx < 1 || g->ny < 1 || !(g->cell >= min_cell)) return DSIM_E_ARG;
   if ((long long)g->nx * g->ny > (1 << 24)) return DSIM_E_ARG;
   if (g->workspace_len < dsim_downwash_workspace(g->m, g->nx, g->ny)) return DSIM_E_ARG;
   DwK a;
@@ -1588,6 +1596,8 @@ static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view
   }
   ctx->dw_parity = 1 - cur;
   hipLaunchKernelGGL(k_dw_count, dim3(grid_for(a.m > ncells + 1 ? a.m : ncells + 1)), dim3(256), 0, st_, a);
+  // (measured and rejected: letting the last count workgroup do the scan — the fences and the one-workgroup scan
+  // behind them cost 28 us against 7 + 6.5 us for the two launches)
   hipLaunchKernelGGL(k_dw_scan, dim3(1), dim3(1024), 0, st_, a);
   hipLaunchKernelGGL(k_dw_scatter, dim3(grid_for(a.m)), dim3(256), 0, st_, a);
   a_ = a;

@@ -140,6 +140,7 @@ class Downwash:
         its border cells by the kernels (pairs within 10 m stay in adjacent cells), so a stale box
         only costs search efficiency; it is re-measured every `box_refresh` calls (one host sync)."""
         if self._box is None or self._box_age >= self._box_refresh:
+            assert wp is not None
             lo = wp[:2].min(dim=1).values.cpu()
             hi = wp[:2].max(dim=1).values.cpu()
             xmin, ymin = float(lo[0]) - self.cell, float(lo[1]) - self.cell
@@ -154,20 +155,29 @@ class Downwash:
 
     def _grid_args(self, world_pos, local_offset) -> nat.DownwashArgs:
         st = self.state
-        if world_pos is None and self.halo is not None:
+        single = (world_pos is None and self.halo is None
+                  and (self.dist is None or not self.dist.is_initialized() or self.dist.get_world_size() == 1))
+        if single:
+            # the world is this fleet: the kernels read positions straight from the state block (no gathered copy)
+            wp, m = None, st.n
+            local_offset = 0
+            box_src = st.fields(0, 2) if (self._box is None or self._box_age >= self._box_refresh) else None
+        elif world_pos is None and self.halo is not None:
             world_pos, local_offset = self.halo.exchange(st.fields(0, 3)[:, : st.n]), 0
         elif world_pos is None:
             world_pos = gather_positions(st.fields(0, 3), self.dist)
             rank = self.dist.get_rank() if (self.dist is not None and self.dist.is_initialized()) else 0
             local_offset = rank * st.n
-        wp = world_pos.to(torch.float32).contiguous()
-        m = wp.shape[1]
-        xmin, ymin, nx, ny = self._grid_box(wp)
+        if not single:
+            wp = world_pos.to(torch.float32).contiguous()
+            m = wp.shape[1]
+            box_src = wp
+        xmin, ymin, nx, ny = self._grid_box(box_src)
         need = self.ctx.lib.dsim_downwash_workspace(m, nx, ny)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty((need,), dtype=torch.int32, device=self.ctx.device)
         a = nat.DownwashArgs()
-        a.pos_all, a.m, a.m_pad = wp.data_ptr(), m, m
+        a.pos_all, a.m, a.m_pad = (wp.data_ptr() if wp is not None else None), m, m
         a.xmin, a.ymin, a.cell, a.nx, a.ny = xmin, ymin, self.cell, nx, ny
         a.workspace, a.workspace_len = self._ws.data_ptr(), self._ws.numel()
         a.type_id = self.type_id.data_ptr() if self.type_id is not None else None

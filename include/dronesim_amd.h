@@ -276,7 +276,8 @@ int dsim_observe_soa(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, co
  * force_out: SoA [3][n_pad], x and y written as 0 (feed it to dsim_step_args.ext_force).
  * workspace: caller-owned device int32 buffer of at least dsim_downwash_workspace(m, nx, ny) entries. */
 typedef struct dsim_downwash_args {
-  const float* pos_all;
+  const float* pos_all;     /* SoA [3][m_pad] positions of every drone of the world, or NULL: the world is this
+                               fleet alone (m = n, local_offset = 0) and positions are read from the state block */
   int64_t  m, m_pad;
   float    xmin, ymin, cell;
   int32_t  nx, ny;
