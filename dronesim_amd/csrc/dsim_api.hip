@@ -1146,7 +1146,7 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) return (int)e;
   dsim_ctx* c = new (std::nothrow) dsim_ctx;
-  if (!c) return DSIM_E_ARG;
+  if (!c) return (int)hipErrorOutOfMemory;
   c->device = device; c->n_types = n_types; c->max_act = max_act; c->d_types = nullptr; c->d_counters = nullptr;
   c->d_fb = nullptr; c->fb_cap = 0; c->dw_ws = nullptr; c->dw_cells = 0; c->dw_parity = 0;
   DevType h[DSIM_MAX_TYPES];

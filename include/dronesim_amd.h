@@ -18,8 +18,11 @@
  * (e.g. a torch-ROCm tensor's data_ptr()).  The library allocates nothing per
  * call, never frees caller memory and never synchronises the device; work is
  * stream-ordered on the caller's hipStream_t (passed as void*).  A dsim_ctx owns
- * only the per-type constant table (device copy).  One ctx per device; a ctx may
- * be used from one host thread at a time.
+ * only the per-type constant table (device copy), a few diagnostic counters and, for
+ * fleets with the morphing hexa, the queue of deferred WLS fallbacks (grown when a
+ * larger fleet is first seen).  One ctx per device; a ctx may be used from one host
+ * thread at a time; the calling thread's current HIP device must be the ctx's device
+ * (dsim_create makes it so) and the stream must belong to it.
  *
  * Errors: int return, 0 = OK, negative = library error (DSIM_E_*), positive =
  * hipError_t.  No exceptions or aborts cross the ABI.  There is NO CPU fallback:
