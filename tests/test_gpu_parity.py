@@ -891,6 +891,40 @@ def test_bench_size_fleet_properties(gpu):
     ctx.close()
 
 
+def test_fleet_beyond_4GiB_of_state(gpu):
+    """Maximum sizes: 50 331 648 drones = 4.8 GB of state in one block (offsets past 2^32 bytes), both layouts.
+    Every drone starts identical (noise off, one broadcast target), so after three steps every drone of the
+    fleet — first tile to last — must hold bit-identical values, equal to those of a 256-drone fleet."""
+    nat, fleet = gpu
+    n = 50331648
+    ctx = fleet.Context([params.builtin_type("robobee")])
+
+    def fly(n_, layout):
+        st = fleet.FleetState(ctx, n_, layout)
+        d = st.data if layout == "soa" else st.data.permute(1, 0, 2)          # [F, ...] view, filled on the device
+        d[2] = 0.5; d[6] = 1.0; d[7] = 0.3; d[11] = 0.2; d[20:24] = 0.45
+        tg = fleet.Targets(ctx, n_, layout, broadcast=True)
+        tg.set(pos=np.array([0.4, -0.2, 0.9], dtype=np.float32), yaw=0.3)
+        a = _args(nat, 2, DT, float(np.float32(2 / 240)), options=nat.OPT_BCAST_TGT)
+        for k in range(3):
+            nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n_, st.view(), tg.view(), ctypes.byref(a)))
+        torch.cuda.synchronize()
+        return st
+
+    ref = fly(256, "soa").data[:, 0].clone()                                  # [24] one drone's fields
+    assert abs(float(ref[2]) - 0.5) > 1e-6                                    # it moved
+    for layout in ("soa", "tile64"):
+        st = fly(n, layout)
+        assert st.data.numel() * 4 > (1 << 32)
+        d = st.data if layout == "soa" else st.data.permute(1, 0, 2).reshape(24, -1)
+        for f in range(24):
+            lo, hi = float(d[f].min()), float(d[f].max())
+            assert lo == hi == float(ref[f]), (layout, f, lo, hi, float(ref[f]))
+        del st, d
+        torch.cuda.empty_cache()
+    ctx.close()
+
+
 def test_graph_replay_equals_eager_steps(gpu, golden_dir):
     """hipGraph of 8 fused steps, replayed 3 times == 24 eager steps, bit for bit, rotor noise on (the
     env-step counter that seeds it is read from device memory inside the captured kernels)."""
