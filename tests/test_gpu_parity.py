@@ -228,7 +228,8 @@ def test_hover_trajectory_vs_oracle(gpu):
 def test_full_flight_config1_vs_oracle(gpu):
     """The whole 15 s flight of examples/fly_INDI.py (720 control steps x 5 sub-steps, yaw target ramping through
     the +-pi wrap), three airframe starts side by side: the fp32 kernel's closed-loop trajectory stays on the fp64
-    oracle's for the entire flight, and ends hovering on the target."""
+    oracle's for the entire flight, and ends hovering on the target.  (Kernel and oracle share the no-ground
+    model: the first start dips below z = 0 where PyBullet's plane would catch it)"""
     nat, fleet = gpu
     from dronesim_amd.envs import CtrlAviary
     starts = np.array([[0.0, 1.0, 0.5], [1.0, -1.0, 0.8], [-0.5, 0.5, 1.5]])
