@@ -309,6 +309,9 @@ def main():
                                                          (241 if name.startswith("mixed") else BYTES_PER_DRONE_STEP))
                     also[name]["hbm_frac"] = f2.n * bts / (d2 / k2) / 1e9 / HBM_PEAK_GBPS
                     also[name]["bytes_per_drone_step"] = bts
+                    if name.startswith("hexa"):
+                        also[name]["note"] = ("248 B is the budgeted figure (SURVEY 8d); the 6-DOF law never reads the target "
+                                              "acceleration and yaw, measured HBM traffic is 232 B per drone-step")
                 f2.env.close(); del f2
             # the reference-shaped loop at the same size: obs = env.step(cmd); cmd = ctrl.computeControlFromState(...)
             # (three kernels + the [N,20] observation instead of the fused one: 480+ B per drone-step)

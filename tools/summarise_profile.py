@@ -7,7 +7,8 @@ separate --pmc passes; on gfx950 FETCH_SIZE reports exactly half the bytes of a 
 streaming read, so hbm_read = 2 * FETCH_SIZE * 1024.  Calibration on a known byte count in this
 code's own access pattern (one dword per lane, SoA): k_reset reads exactly 24 B/drone
 (init_pos + init_rpy), and its corrected FETCH_SIZE is checked against that below.
-usage: python tools/summarise_profile.py <tag> <workload> <layout> <drones_per_launch>"""
+usage: python tools/summarise_profile.py <tag> <workload> <layout> <drones_per_launch> [bytes_per_drone_step=232]
+(traffic.json, which bench.py reads, is only rewritten for the default workload config2x1024)"""
 import collections
 import csv
 import glob
@@ -17,6 +18,7 @@ import shutil
 import sys
 
 tag, workload, layout, n = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+BPD = int(sys.argv[5]) if len(sys.argv) > 5 else 232
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
@@ -49,21 +51,22 @@ for k, r in stats.items():
         e["WRITE_SIZE_KiB_avg"] = write[k]
         e["hbm_write_bytes"] = write[k] * 1024
     out["kernels"][k] = e
-step = next((k for k in out["kernels"] if "k_step" in k), None)
+step = max((k for k in out["kernels"] if "k_step" in k), key=lambda k: out["kernels"][k]["calls"], default=None)
 if step:
     e = out["kernels"][step]
     tot = e.get("hbm_read_bytes", 0) + e.get("hbm_write_bytes", 0)
     out["dominant_kernel"] = step
     out["hbm_bytes_per_launch"] = tot
-    out["algorithmic_bytes_per_launch"] = 232 * n
-    out["traffic_over_algorithmic"] = tot / (232 * n)
-    out["achieved_GBps_profiled"] = 232 * n / (e["avg_us"] * 1e-6) / 1e9
+    out["algorithmic_bytes_per_launch"] = BPD * n
+    out["traffic_over_algorithmic"] = tot / (BPD * n)
+    out["achieved_GBps_profiled"] = BPD * n / (e["avg_us"] * 1e-6) / 1e9
 rs = out["kernels"].get("k_reset(ResetK)")
 if rs and "hbm_read_bytes" in rs:
     out["calibration"] = {"kernel": "k_reset", "known_read_bytes": 24 * n,
                           "corrected_FETCH_bytes": rs["hbm_read_bytes"],
                           "ratio": rs["hbm_read_bytes"] / (24 * n)}
 json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
-json.dump({"workload": workload, "layout": layout, "hbm_bytes_per_launch": out.get("hbm_bytes_per_launch"),
-           "source": f"profiles/{tag}_summary.json"}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+if workload == "config2x1024":
+    json.dump({"workload": workload, "layout": layout, "hbm_bytes_per_launch": out.get("hbm_bytes_per_launch"),
+               "source": f"profiles/{tag}_summary.json"}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
