@@ -1,6 +1,7 @@
 """Oracle (oracle/dsim_oracle.c, fp64) against the golden vectors produced by the
 reference's own controller code (tests/golden/make_goldens.py).  CPU only."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -176,3 +177,40 @@ def test_trajectory_sampler_matches_reference_table(golden_dir):
         np.testing.assert_allclose(o[3:6], g["target_vel"][k], rtol=0, atol=1e-9)
         np.testing.assert_allclose(o[6:9], g["target_acc"][k], rtol=0, atol=1e-9)
         assert abs(o[9] - g["target_yaw"][k]) < 1e-5, k   # yaw integrates acos() of nearly parallel headings (ill-conditioned)
+
+
+def test_golden_fixtures_regenerate_bit_identically(tmp_path):
+    """The committed fixtures are exactly what tests/golden/make_goldens.py produces from the reference tree
+    (runs only where /root/reference is mounted: the build container, not the GPU box)."""
+    import glob
+    import importlib.util
+    import os
+    if not os.path.isdir("/root/reference/dronesim"):
+        pytest.skip("reference tree not present")
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_goldens", os.path.join(here, "make_goldens.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    mg.OUT = str(tmp_path)
+    saved = {k: sys.modules.get(k) for k in ("pybullet", "pybullet_data", "gym", "gym.spaces")}
+    argv = sys.argv
+    import warnings
+    try:
+        sys.argv = ["make_goldens.py"]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")             # the reference's own numpy deprecations
+            mg.main()
+    finally:
+        sys.argv = argv
+        for k, v in saved.items():                      # the generator's stand-in modules must not leak into other tests
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    files = sorted(glob.glob(os.path.join(here, "*.npz")))
+    assert len(files) == 13
+    for f in files:
+        a, b = np.load(f, allow_pickle=True), np.load(os.path.join(str(tmp_path), os.path.basename(f)), allow_pickle=True)
+        assert set(a.files) == set(b.files), f
+        for k in a.files:
+            assert np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), (f, k)
