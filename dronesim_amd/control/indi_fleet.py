@@ -113,11 +113,17 @@ class INDIControl(BaseControl):
             st.set_fields(3, q.reshape(4, 1).expand(4, n) if q.numel() == 4 else (q.T if q.shape == (n, 4) else q))
             st.set_fields(7, _as3(cur_vel, n, dev))
             st.set_fields(10, _as3(cur_ang_vel, n, dev))
-        yaw = torch.as_tensor(np.asarray(target_rpy) if not torch.is_tensor(target_rpy) else target_rpy,
-                              dtype=torch.float32, device=dev)
-        yaw = yaw[..., 2].reshape(-1) if yaw.shape[-1] == 3 else yaw.reshape(3, -1)[2]
-        self._targets.set(pos=_as3(target_pos, n, dev), vel=_as3(target_vel, n, dev),
-                          acc=_as3(target_acc, n, dev), yaw=yaw.reshape(1, -1))
+        if torch.is_tensor(target_rpy):
+            yaw = target_rpy.to(dev, torch.float32)
+            yaw = (yaw[..., 2].reshape(-1) if yaw.shape[-1] == 3 else yaw.reshape(3, -1)[2]).reshape(1, -1)
+        else:                                             # only target_rpy[2] is read (INDIControl.py:341)
+            r = np.asarray(target_rpy, dtype=np.float32)
+            yaw = float(r.reshape(-1)[2]) if r.size == 3 else np.ascontiguousarray(
+                r[..., 2] if r.shape[-1] == 3 else r.reshape(3, -1)[2]).reshape(1, -1)
+
+        def as_target(x):      # a bare 3-vector stays one: Targets.set skips a constant it already holds
+            return x if (not torch.is_tensor(x) and np.size(x) == 3) else _as3(x, n, dev)
+        self._targets.set(pos=as_target(target_pos), vel=as_target(target_vel), acc=as_target(target_acc), yaw=yaw)
         a = nat.StepArgs()
         a.phys_substeps, a.dt_phys, a.dt_ctrl = 0, float(control_timestep), float(control_timestep)
         a.options, a.noise_seed, a.step_index = 0, 0, 0

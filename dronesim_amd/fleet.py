@@ -201,16 +201,30 @@ class Targets(BlockedSoA):
     def set(self, pos=None, vel=None, acc=None, yaw=None) -> None:
         """Each argument [3, n] / [n] (per drone) or length-3 / scalar (same for all)."""
         dev = self.data.device
+        if not hasattr(self, "_const"):
+            self._const = {}                  # field group -> the constant it was last filled with (None: per-drone data)
         for f0, val, nf in ((0, pos, 3), (3, vel, 3), (6, acc, 3), (9, yaw, 1)):
             if val is None:
                 continue
+            # the same broadcast constant as last time (e.g. the zero target_vel / target_acc of every
+            # computeControl call): the fields already hold it, skip the fleet-sized fill
+            key = None
+            if not torch.is_tensor(val) and np.size(val) == nf:
+                key = tuple(float(x) for x in np.asarray(val, dtype=np.float32).ravel())
+                if self._const.get(f0) == key:
+                    continue
             t = torch.as_tensor(val, dtype=torch.float32, device=dev).reshape(nf, -1)
             if self.broadcast:
                 self.data[f0:f0 + nf, :] = t
             else:
                 if t.shape[1] == 1:
                     t = t.expand(nf, self.n)
-                self.set_fields(f0, t)
+                BlockedSoA.set_fields(self, f0, t)
+            self._const[f0] = key
+
+    def set_fields(self, f0: int, values: torch.Tensor) -> None:
+        self._const = {}                      # written behind set()'s back: nothing is known to be constant any more
+        super().set_fields(f0, values)
 
 
 class WaypointTargets:
