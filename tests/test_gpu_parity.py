@@ -321,11 +321,12 @@ def test_force_map_vs_reference_recorded_calls(gpu, golden_dir, model):
     ctx.close()
 
 
-def test_inkernel_noise_matches_definition(gpu):
+@pytest.mark.parametrize("sub", [1, 3])        # 1: straight-line single-sub-step kernel, 3: the looped one
+def test_inkernel_noise_matches_definition(gpu, sub):
     """In-kernel Philox/Box-Muller noise == the oracle's restatement of the same definition;
     and it is N(0,.01)/N(0,.001)-distributed."""
     nat, fleet = gpu
-    n, sub, seed, step_index = 256, 3, 0x1234ABCD5, 7
+    n, seed, step_index = 256, 0x1234ABCD5, 7
     t, ctx, st, tg, rigid, mem, tgt = _make(gpu, "robobee", n, seed=13)
     a = _args(nat, sub, DT, float(np.float32(sub / 240)), seed=seed, step_index=step_index)
     nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
@@ -413,7 +414,8 @@ def test_hexa_fused_step_vs_oracle(gpu, substeps, layout):
     ctx.close()
 
 
-def test_mixed_fleet_vs_oracle(gpu):
+@pytest.mark.parametrize("sub", [1, 2])
+def test_mixed_fleet_vs_oracle(gpu, sub):
     """Config 5 layout: even index robobee (quad INDI), odd index hexa_6DOF (6DOF INDI + WLS), one
     type_id byte per drone; in-kernel noise on."""
     nat, fleet = gpu
@@ -430,7 +432,7 @@ def test_mixed_fleet_vs_oracle(gpu):
     tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
     tid_dev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device)
     tid_dev[:n] = torch.from_numpy(tid)
-    sub, seed, sidx = 2, 99, 5
+    seed, sidx = 99, 5
     a = _args(nat, sub, DT, float(np.float32(sub / 240)), seed=seed, step_index=sidx, type_id=tid_dev)
     nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
     O = orc.Oracle(types)
@@ -447,7 +449,8 @@ def test_mixed_fleet_vs_oracle(gpu):
     ctx.close()
 
 
-def test_type_major_runs_equal_mixed_kernel_and_oracle(gpu):
+@pytest.mark.parametrize("sub", [1, 2])
+def test_type_major_runs_equal_mixed_kernel_and_oracle(gpu, sub):
     """Type-major storage (dsim_step_args.runs): three types grouped in runs that start at multiples of 256
     (fleet.type_major_order), each run stepped by the single-type kernel of its kind — same result as the
     mixed-fleet kernel on the same storage (same law, drone-keyed noise) and as the oracle."""
@@ -462,7 +465,7 @@ def test_type_major_runs_equal_mixed_kernel_and_oracle(gpu):
     assert [r[2] for r in runs] == [0, 1, 2] and all(r[0] % 256 == 0 for r in runs)
     rigid, mem, tgt = random_fleet(rng, n_slots, n_act=6, tilt=0.3, rate=1.0)
     mem[slot_types != 1, 11:13] = 0.0
-    sub, seed, sidx = 2, 77, 3
+    seed, sidx = 77, 3
     results = []
     for use_runs in (True, False):
         ctx = fleet.Context(types)
@@ -948,7 +951,8 @@ def test_graph_replay_equals_eager_steps(gpu, golden_dir):
     envA.close(); envB.close()
 
 
-def test_chained_stepping(gpu):
+@pytest.mark.parametrize("sub", [1, 2])        # 1: the straight-line single-sub-step kernels, 2: the looped ones
+def test_chained_stepping(gpu, sub):
     """DSIM_OPT_CHAINED: last_vel / last_rates recomputed from the stored rigid state instead of being read,
     and not written; materialize() restores them.  Same trajectory as the plain mode and as the oracle."""
     from dronesim_amd.envs import CtrlAviary
@@ -957,7 +961,7 @@ def test_chained_stepping(gpu):
     rng = np.random.default_rng(95)
     xyz = np.stack([rng.uniform(-20, 20, n), rng.uniform(-20, 20, n), rng.uniform(1, 5, n)], 1)
     rpy = np.stack([rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n), rng.uniform(-3, 3, n)], 1)
-    envs = [CtrlAviary(["robobee"], n, initial_xyzs=xyz, initial_rpys=rpy, aggregate_phy_steps=2, noise_seed=5,
+    envs = [CtrlAviary(["robobee"], n, initial_xyzs=xyz, initial_rpys=rpy, aggregate_phy_steps=sub, noise_seed=5,
                        dict_io=False, chained=c) for c in (False, True)]
     tgts = []
     for e in envs:
