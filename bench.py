@@ -233,7 +233,7 @@ def main():
     bytes_per = {"config5": 253, "hexa": 248, "mixed": 241}.get(a.workload, BYTES_PER_DRONE_STEP)
     kernel = {"config5": "k_dw_count+scan+scatter+query, k_step_lean, k_wls_fallback",
               "hexa": "k_step_hexa (+ k_wls_fallback)",
-              "mixed": "k_step_typed per type (+ k_wls_fallback)"}.get(a.workload, "k_step_fast")
+              "mixed": "k_step_mixed (+ k_wls_fallback)"}.get(a.workload, "k_step_fast")
     achieved = fl.n * bytes_per / launch_s / 1e9
 
     if rank == 0:
