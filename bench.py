@@ -153,37 +153,40 @@ def host_threads():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(substeps, seconds=8.0):
-    """The fp64 oracle (a scalar C port of the same step) timed on the host cores on a
-    bounded sample of the same workload."""
+def cpu_baseline(substeps, seconds=4.0):
+    """The fp64 oracle (a scalar C port of the same step) timed on the host cores on bounded samples of the same
+    workload: fleets of 4 096 and 65 536 drones, one thread and all usable threads each."""
     from dronesim_amd.params import builtin_type
     from oracle import oracle as orc
     t = builtin_type("robobee")
     O = orc.Oracle([t])
-    n = 65536
-    xyz = grid_fleet(4096, n // 4096)
-    rigid = np.concatenate([xyz, np.tile([0, 0, 0, 1.0], (n, 1)), np.zeros((n, 6))], 1)
-    mem = O.reset_mem(n); mem[:, 7:11] = 0.4
-    tgt = np.concatenate([xyz, np.zeros((n, 6)), np.full((n, 1), 0.4)], 1)
     dt = 1.0 / 240.0
-    out = {}
-    for label, nth in (("1", 1), ("all", host_threads())):
-        sub_n = 8192 if nth == 1 else n
-        r, m, tg = rigid[:sub_n].copy(), mem[:sub_n].copy(), tgt[:sub_n].copy()
-        O.step(r, m, tg, substeps, dt, substeps * dt, nthreads=nth)      # thread pool start-up, untimed
-        k, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < seconds:                        # bounded sample
-            O.step(r, m, tg, substeps, dt, substeps * dt, nthreads=nth)
-            k += 1
-        el = time.perf_counter() - t0
-        out[label] = (sub_n * k / el, nth, sub_n, k, el)
-    v_all, nth, sub_n, k, el = out["all"]
+    runs, fleets = {}, {}
+    for n in (4096, 65536):
+        xyz = grid_fleet(4096, n // 4096)
+        rigid = np.concatenate([xyz, np.tile([0, 0, 0, 1.0], (n, 1)), np.zeros((n, 6))], 1)
+        mem = O.reset_mem(n); mem[:, 7:11] = 0.4
+        fleets[n] = (rigid, mem, np.concatenate([xyz, np.zeros((n, 6)), np.full((n, 1), 0.4)], 1))
+    for nth in (1, host_threads()):                # one switch of the OpenMP team size, not one per sample
+        for n in (4096, 65536):
+            r, m, tg = (x.copy() for x in fleets[n])
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.5:                            # thread team start-up, untimed
+                O.step(r, m, tg, substeps, dt, substeps * dt, nthreads=nth)
+            k, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < seconds:                        # bounded sample
+                O.step(r, m, tg, substeps, dt, substeps * dt, nthreads=nth)
+                k += 1
+            el = time.perf_counter() - t0
+            runs[(n, nth)] = (n * k / el, k, el)
+    nth = host_threads()
+    v_all, k, el = runs[(65536, nth)]
     return {
         "value": v_all, "unit": "drone-steps/s", "cores": nth, "kind": "port",
-        "sample": f"fp64 C oracle (oracle/dsim_oracle.c), {sub_n} robobee x {k} steps, phys_substeps={substeps}, "
-                  f"{el:.1f} s on {nth} OpenMP threads; single thread: {out['1'][0]:.3e} drone-steps/s "
-                  f"({out['1'][2]} drones x {out['1'][3]} steps)",
-        "single_thread_value": out["1"][0],
+        "sample": f"fp64 C oracle (oracle/dsim_oracle.c), 65536 robobee x {k} steps, phys_substeps={substeps}, "
+                  f"{el:.1f} s on {nth} OpenMP threads",
+        "single_thread_value": runs[(65536, 1)][0],
+        "by_fleet_and_threads": {f"{n}_drones_{th}_threads": round(v[0]) for (n, th), v in runs.items()},
         "reference_python_note": "reference INDIControl.computeControl alone: 8.2e3 calls/s/core (SURVEY.md 6, survey "
                                  "container); PyBullet Env.step not measurable (engine absent)",
     }
