@@ -297,8 +297,9 @@ class CtrlAviary:
         ``FusedGraph`` whose ``replay()`` runs them with a single host call.  For small fleets the loop is
         launch-latency bound (a few us per launch from Python; 10-16 us per graph replay whatever its
         length), which is what a graph removes.  Kernel arguments are frozen at capture time, so the
-        env-step counter that seeds the rotor noise lives in device memory and is advanced by a
-        one-thread kernel after every step (``step_index_dev``).  Quad fleets, plain/waypoint targets."""
+        env-step counter that seeds the rotor noise is read from device memory (``step_index_dev``: captured step
+        i uses counter + i) and advanced by ``steps`` by a one-thread node at the end of the graph.  Quad fleets
+        (hexa steps may grow the fallback queue, an allocation), plain/waypoint targets."""
         if self.n_act != 4 or self._downwash is not None:
             raise NotImplementedError("graph capture: quad fleets without the downwash exchange")
         return FusedGraph(self, targets, steps, control_timestep)
