@@ -1100,6 +1100,10 @@ static void to_dev(const dsim_type_params& p, DevType* d) {
     d->pmin[j] = (float)p.pwm_min[j]; d->pmax[j] = (float)p.pwm_max[j];
     d->spin[j] = (float)p.rotor_spin[j];
     for (int k = 0; k < 3; ++k) { d->rpos[j][k] = (float)p.rotor_pos[j][k]; d->raxis[j][k] = (float)p.rotor_axis[j][k]; }
+    const double* r = p.rotor_pos[j]; const double* ax = p.rotor_axis[j];
+    d->rxa[j][0] = (float)(r[1] * ax[2] - r[2] * ax[1]);
+    d->rxa[j][1] = (float)(r[2] * ax[0] - r[0] * ax[2]);
+    d->rxa[j][2] = (float)(r[0] * ax[1] - r[1] * ax[0]);
     for (int i = 0; i < DSIM_MAX_ACT; ++i) {
       d->alloc[j][i] = (float)p.alloc[j][i];
       d->alloc2[j][i] = (float)p.alloc2[j][i];

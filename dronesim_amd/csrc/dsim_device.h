@@ -24,6 +24,7 @@ struct DevType {
   float kf, km;
   float scale[DSIM_MAX_ACT], cnst[DSIM_MAX_ACT], pmin[DSIM_MAX_ACT], pmax[DSIM_MAX_ACT];
   float rpos[DSIM_MAX_ACT][3], raxis[DSIM_MAX_ACT][3], spin[DSIM_MAX_ACT];
+  float rxa[DSIM_MAX_ACT][3];                 // rpos x raxis: torque about the COM per unit thrust of rotor j
   float alloc[DSIM_MAX_ACT][DSIM_MAX_ACT];    // quad: pinv(G1/0.05); hexa: M1 (u_opt = M1 v + M4 u0)
   float alloc2[DSIM_MAX_ACT][DSIM_MAX_ACT];   // hexa: M4
   float B[DSIM_MAX_ACT][DSIM_MAX_ACT];        // hexa: G1/0.05, for the active-set fallback
@@ -369,16 +370,16 @@ __device__ __forceinline__ void indi_quad(const DevType& T, float dt, const Rigi
 // torque [0,0,tau_j] in the tilted prop link frames (rigid composite body, see params.py).
 // nz: 12 scaled normals (f_noise[6], m_noise[6]) or nullptr.
 __device__ __forceinline__ void hexa_wrench(const DevType& T, const float cmd[6], const float* nz, V3& F, V3& tau) {
+  // F = sum_j f_j a_j ;  tau = sum_j f_j (r_j x a_j) + tq_j a_j   (a_j: rotor axis, r_j: lever arm; r_j x a_j is a
+  // per-type constant, so the wrench is three 3x6 matrix-vector products instead of six cross products)
   F = v3(0, 0, 0); tau = v3(0, 0, 0);
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     const float rpm = T.scale[j] * cmd[j] + T.cnst[j];
     const float f = rpm * rpm * T.kf + (nz ? nz[j] : 0.0f);
     const float tq = (rpm * rpm * T.km + (nz ? nz[6 + j] : 0.0f)) * T.spin[j];   // :1439-1440
-    const V3 ax = v3(T.raxis[j][0], T.raxis[j][1], T.raxis[j][2]);
-    const V3 fj = f * ax;
-    F = F + fj;
-    tau = tau + cross(v3(T.rpos[j][0], T.rpos[j][1], T.rpos[j][2]), fj) + tq * ax;
+    F = F + f * v3(T.raxis[j][0], T.raxis[j][1], T.raxis[j][2]);
+    tau = tau + f * v3(T.rxa[j][0], T.rxa[j][1], T.rxa[j][2]) + tq * v3(T.raxis[j][0], T.raxis[j][1], T.raxis[j][2]);
   }
 }
 
