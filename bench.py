@@ -17,6 +17,10 @@ Workloads:
   config2                 the single 4 096-drone fleet (launch-latency bound; reported under
                           "also" in every run)
   config3                 65 536 robobee, per-drone targets (also under "also")
+  config4                 configs[3]: 65 536 robobee per GPU (x8 = 524 288), hover, no coupling
+  config5                 configs[4]: 65 536 per GPU, even index robobee / odd index hexa_6DOF, neighbour downwash,
+                          slab shards with halo exchange of positions
+  hexa, mixed             4 194 304 hexa_6DOF / interleaved quad+hexa drones (roofline-size variants)
 """
 import argparse
 import json
@@ -39,7 +43,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
-    p.add_argument("--workload", default="config2x1024", choices=["config2x1024", "config2", "config3", "config5", "hexa", "mixed"])
+    p.add_argument("--workload", default="config2x1024", choices=["config2x1024", "config2", "config3", "config4", "config5", "hexa", "mixed"])
     p.add_argument("--substeps", type=int, default=1)
     p.add_argument("--layout", default="tile64", choices=["soa", "tile64", "tile256", "tile1024", "tile4096"])
     p.add_argument("--noise-seed", type=int, default=1)
@@ -219,7 +223,7 @@ def main():
     torch.cuda.set_device(local)
     barrier = (lambda: dist.barrier()) if dist else None
 
-    n_fleet, replicas = {"config2x1024": (4096, 1024), "config2": (4096, 1), "config3": (65536, 1),
+    n_fleet, replicas = {"config2x1024": (4096, 1024), "config2": (4096, 1), "config3": (65536, 1), "config4": (4096, 16),
                          "config5": (65536, 1), "hexa": (4096, 1024), "mixed": (4096, 1024)}[a.workload]
     from dronesim_amd import sharding
     # weak scaling: every rank owns a same-sized contiguous shard of the N-GPU fleet; no data-path collective
@@ -253,6 +257,7 @@ def main():
             "config": {"workload": {"config2x1024": "configs[1] 4096 robobee INDI hover x 1024 vectorised envs/GPU",
                                     "config2": "configs[1] 4096 robobee INDI hover (single fleet)",
                                     "config3": "65536 robobee, waypoint-table tracking (fly_INDI_TrajectoryTrack)",
+                                    "config4": "configs[3] shard: 65536 robobee INDI hover per GPU (524288 over 8 GPUs), no coupling",
                                     "mixed": "even index robobee, odd index hexa_6DOF, 4096 x 1024 envs/GPU, no downwash",
                                     "hexa": "4096 hexa_6DOF (6-DOF INDI + WLS) hover x 1024 vectorised envs/GPU",
                                     "config5": "65536/GPU slab shard of 50% robobee + 50% hexa_6DOF, neighbour downwash on, "
@@ -285,6 +290,8 @@ def main():
                     "config3_65536_waypoints_sub2": (65536, 1, 2, True, 1),
                     "config3_65536_waypoints_sub2_hipgraph_of_32_launches": (65536, 1, 2, True, 32),
                     "config3_65536_waypoints_sub2_32steps_per_launch": (65536, 1, 2, True, 32),
+                    # configs[3]: one GPU's 65 536-drone shard of the 524 288-drone fleet (no coupling between shards)
+                    "config4_shard_65536_hover_sub1": (4096, 16, 1, False, 1),
                     "config2x1024_sub5": (4096, 1024, 5, False, 1),
                     "config5_shard_65536_mixed_downwash": (65536, 1, 1, False, 1),
                     # DSIM_OPT_CHAINED: the six controller-memory fields that are functions of the stored
