@@ -214,3 +214,20 @@ def test_golden_fixtures_regenerate_bit_identically(tmp_path):
         assert set(a.files) == set(b.files), f
         for k in a.files:
             assert np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), (f, k)
+
+
+def test_euler_and_matrix_conventions_match_scipy():
+    """Row C8: the three PyBullet math helpers are restated (nothing of Bullet is available here).  Their
+    convention — quaternion xyzw, roll-pitch-yaw = rotations about the FIXED x, y, z axes in that order
+    (URDF / Bullet 'rpy') — is cross-checked against an independent implementation, scipy's Rotation."""
+    from scipy.spatial.transform import Rotation as R
+    rng = np.random.default_rng(7)
+    rpy = np.stack([rng.uniform(-np.pi, np.pi, 500), rng.uniform(-1.5, 1.5, 500), rng.uniform(-np.pi, np.pi, 500)], 1)
+    for e in rpy:
+        q = orc.quat_from_euler(e)
+        qs = R.from_euler("xyz", e).as_quat()                       # extrinsic xyz, scalar-last
+        assert min(np.abs(q - qs).max(), np.abs(q + qs).max()) < 1e-14
+        np.testing.assert_allclose(orc.matrix_from_quat(q), R.from_quat(q).as_matrix(), rtol=0, atol=1e-14)
+        back = orc.euler_from_quat(q)
+        np.testing.assert_allclose(back, R.from_quat(q).as_euler("xyz"), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(back, e, rtol=0, atol=1e-9)
