@@ -243,3 +243,52 @@ def test_wrench_mapping_agrees_with_the_reference_dynamics_formula():
         r, pos, rpy, vel, rr = run(DT / div, 24 * div)                # 0.1 s manoeuvre
         errs.append(np.abs(r[0:3] - pos).max() + np.abs(orc.euler_from_quat(r[3:7]) - rpy).max())
     assert errs[0] < 2e-3 and errs[2] < errs[0]                       # small, and not growing with refinement
+
+
+def test_step_is_a_consistent_discretisation_of_the_damped_newton_euler_equations():
+    """Independent formulation: integrate m v' = R F_b + m g - m c (1+|v|) v,  J w_b' = tau_b - w_b x J w_b -
+    c (1+|w|) J w_b,  q' = 1/2 q (0, w_b) with scipy's adaptive Runge-Kutta (rtol 1e-11) under a constant body
+    wrench that excites translation, all three rotation axes and the gyroscopic coupling; the restated
+    semi-implicit step must converge to it at first order in dt (error halves when dt halves)."""
+    from scipy.integrate import solve_ivp
+    t = params.builtin_type("robobee")
+    O = orc.Oracle([t])
+    m_, J, c, g = t.mass, np.asarray(t.inertia, dtype=float), float(np.float32(0.04)), t.gravity
+    cmd = np.array([0.500, 0.494, 0.497, 0.503])
+    P = t.to_c()
+    import ctypes
+    D = ctypes.POINTER(ctypes.c_double)
+    F, tau, rpm = np.zeros(3), np.zeros(3), np.zeros(4)
+    f = orc.lib().orc_quad_wrench
+    f.argtypes = [ctypes.POINTER(type(P)), D, D, D, D, D, D]
+    f(ctypes.byref(P), cmd.ctypes.data_as(D), None, None, F.ctypes.data_as(D), tau.ctypes.data_as(D), rpm.ctypes.data_as(D))
+    w0 = np.array([0.8, -0.5, 1.2])                       # body rates at t = 0 (level start: world = body)
+
+    def rhs(_, y):
+        pos, q, v, wb = y[0:3], y[3:7], y[7:10], y[10:13]
+        q = q / np.linalg.norm(q)
+        R = orc.matrix_from_quat(q)
+        a = R @ F / m_ + np.array([0, 0, -g]) - c * (1 + np.linalg.norm(v)) * v
+        dw = (tau - np.cross(wb, J * wb) - c * (1 + np.linalg.norm(wb)) * J * wb) / J
+        x, y_, z, w = q
+        dq = 0.5 * np.array([w * wb[0] + y_ * wb[2] - z * wb[1], w * wb[1] + z * wb[0] - x * wb[2],
+                             w * wb[2] + x * wb[1] - y_ * wb[0], -x * wb[0] - y_ * wb[1] - z * wb[2]])
+        return np.concatenate([v, dq, a, dw])
+
+    T_end = 0.5
+    y0 = np.concatenate([[0, 0, 1.0], [0, 0, 0, 1.0], [0.3, -0.2, 0.1], w0])
+    ref = solve_ivp(rhs, (0, T_end), y0, rtol=1e-11, atol=1e-13).y[:, -1]
+    R_end = orc.matrix_from_quat(ref[3:7] / np.linalg.norm(ref[3:7]))
+    errs = []
+    for div in (1, 2, 4):
+        dt = (1.0 / 240.0) / div
+        r = np.zeros((1, 13)); r[0, 0:3] = y0[0:3]; r[0, 6] = 1.0; r[0, 7:10] = y0[7:10]; r[0, 10:13] = w0
+        mem = O.reset_mem(1); mem[0, 7:11] = cmd
+        O.physics(r, mem, int(round(T_end / dt)), dt)
+        e_pos = np.abs(r[0, 0:3] - ref[0:3]).max()
+        e_vel = np.abs(r[0, 7:10] - ref[7:10]).max()
+        e_w = np.abs(r[0, 10:13] - R_end @ ref[10:13]).max()             # the state holds WORLD-frame rates
+        q = r[0, 3:7]
+        e_q = min(np.abs(q - ref[3:7] / np.linalg.norm(ref[3:7])).max(), np.abs(q + ref[3:7] / np.linalg.norm(ref[3:7])).max())
+        errs.append(max(e_pos, e_vel, e_w, e_q))
+    assert errs[0] < 5e-2 and 1.7 < errs[0] / errs[1] < 2.3 and 1.7 < errs[1] / errs[2] < 2.3, errs
