@@ -63,7 +63,7 @@ class CtrlAviary:
         user_debug_gui=True,
         *,
         device: int = 0,
-        layout: str = "soa",
+        layout: Optional[str] = None,
         noise_seed: Optional[int] = None,
         dict_io: Optional[bool] = None,
         dist=None,
@@ -123,6 +123,10 @@ class CtrlAviary:
         self.dict_io = (num_drones <= DICT_IO_MAX_DRONES) if dict_io is None else dict_io
 
         self.ctx = Context(types, device)
+        if layout is None:
+            # plain SoA [F][n_pad] is the simplest view for small fleets; from a few hundred thousand drones on the
+            # wave-tiled form [n/64][F][64] is 3-8 % faster (power-of-two field strides alias HBM channels)
+            layout = "tile64" if num_drones >= 262144 else "soa"
         self.state = FleetState(self.ctx, num_drones, layout)
         self._type_id = None
         if len(types) > 1:
