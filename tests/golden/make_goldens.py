@@ -446,10 +446,43 @@ def capture_env_side():
     print("env-side goldens written")
 
 
+def capture_roll_sweep():
+    """INDIControl.computeControl with the roll angle swept through +-90 deg, where det(G) = T^2 cos(roll) of the
+    position law's 3x3 system (INDIControl.py:314-339) goes through zero and np.linalg.pinv changes regime."""
+    from dronesim.control.INDIControl import INDIControl
+    ctrl = INDIControl(drone_model="robobee")
+    deltas = np.array([1e-1, 3e-2, 1e-2, 1e-3, 1e-4, 1e-6, 1e-9, 0.0])
+    rolls = np.concatenate([s * (math.pi / 2 - d * t) for s in (1.0, -1.0) for t in (1.0, -1.0) for d in [deltas]])
+    rng = np.random.default_rng(77)
+    n = len(rolls)
+    pitch, yaw = rng.uniform(-0.4, 0.4, n), rng.uniform(-3, 3, n)
+    c = {"roll": rolls, "quat": np.stack([quat_from_euler(r, p_, y) for r, p_, y in zip(rolls, pitch, yaw)]),
+         "pos": rng.uniform(-1, 1, (n, 3)), "vel": rng.uniform(-0.5, 0.5, (n, 3)), "ang_vel": rng.uniform(-0.5, 0.5, (n, 3)),
+         "target_pos": rng.uniform(-1, 1, (n, 3)), "target_yaw": rng.uniform(-3, 3, n),
+         "last_vel": rng.uniform(-0.5, 0.5, (n, 3)), "last_rates": rng.uniform(-0.5, 0.5, (n, 3)),
+         "last_thrust": rng.uniform(-0.5, 0.5, n), "cmd": rng.uniform(0.3, 0.7, (n, 4)), "dt": np.array(5 / 240)}
+    out = {"cmd_out": np.zeros((n, 4)), "last_thrust_out": np.zeros(n), "last_rates_out": np.zeros((n, 3))}
+    for i in range(n):
+        ctrl.reset()
+        ctrl.last_vel, ctrl.last_rates = c["last_vel"][i].copy(), c["last_rates"][i].copy()
+        ctrl.last_thrust, ctrl.cmd = float(c["last_thrust"][i]), c["cmd"][i].copy()
+        cmd, _, _ = ctrl.computeControl(control_timestep=float(c["dt"]), cur_pos=c["pos"][i].copy(), cur_quat=c["quat"][i].copy(),
+                                        cur_vel=c["vel"][i].copy(), cur_ang_vel=c["ang_vel"][i].copy(),
+                                        target_pos=c["target_pos"][i].copy(),
+                                        target_rpy=np.array([0.0, 0.0, c["target_yaw"][i]]))
+        out["cmd_out"][i], out["last_thrust_out"][i], out["last_rates_out"][i] = cmd, ctrl.last_thrust, ctrl.last_rates
+    c.update(out)
+    np.savez(os.path.join(OUT, "indi_roll_sweep.npz"), **c)
+    print("roll-sweep goldens written")
+
+
 def main():
     install_standins()
     if len(sys.argv) > 1 and sys.argv[1] == "env":        # only the env-side file
         capture_env_side()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "roll":       # only the roll-sweep file
+        capture_roll_sweep()
         return
     from dronesim.control.INDIControl import INDIControl
     from dronesim.control.INDIControl_6DOF import INDIControl as INDIControl_6DOF  # same class name in both modules
@@ -546,6 +579,7 @@ def main():
              t=ts, target_pos=np.array(P), target_vel=np.array(V), target_acc=np.array(Ac),
              target_yaw=np.array(Y), gates=gates)
     capture_env_side()
+    capture_roll_sweep()
     print("goldens written to", OUT)
 
 

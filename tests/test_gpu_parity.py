@@ -105,6 +105,39 @@ def test_control_vs_golden(gpu, golden_dir, model, layout):
     ctx.close()
 
 
+def test_roll_sweep_through_the_pinv_singularity(gpu, golden_dir):
+    """The kernel's closed-form inverse of G (orthogonal columns: scaled transpose; only the pitch row carries
+    1 / cos^2(roll)) against the reference's np.linalg.pinv swept through roll = +-90 deg: equal within the fp32
+    conditioning (error ~ 1e-4 / |cos roll|) while |cos roll| >= 1e-2; finite, PWM-clipped commands all the way to
+    cos(roll) = 0; and the thrust state exact everywhere except AT the singular point, where numpy's pinv switches
+    to the minimum-norm solution (the reference itself jumps there: -8.6 at 1e-9 rad from it, -7.3 on it)."""
+    nat, fleet = gpu
+    g = np.load(os.path.join(golden_dir, "indi_roll_sweep.npz"))
+    ctx = fleet.Context([params.builtin_type("robobee")])
+    n = len(g["roll"])
+    rigid = np.concatenate([g["pos"], g["quat"], g["vel"], g["ang_vel"]], 1)
+    mem = np.zeros((n, 13))
+    mem[:, 0:3], mem[:, 3:6], mem[:, 6], mem[:, 7:11] = g["last_vel"], g["last_rates"], g["last_thrust"], g["cmd"]
+    st, tg = fleet.FleetState(ctx, n), fleet.Targets(ctx, n)
+    st.load_aos(rigid, mem)
+    tg.set(pos=np.ascontiguousarray(g["target_pos"].T), yaw=g["target_yaw"][None, :])
+    a = _args(nat, 0, float(g["dt"]), float(g["dt"]))
+    pos_e = torch.zeros((3, st.n_pad), device=ctx.device); yaw_e = torch.zeros((st.n_pad,), device=ctx.device)
+    nat.check(ctx.lib.dsim_control(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a),
+                                   pos_e.data_ptr(), yaw_e.data_ptr()))
+    torch.cuda.synchronize()
+    got = st.mem_aos()
+    assert np.isfinite(got).all() and got[:, 7:11].min() >= 0.0 and got[:, 7:11].max() <= 1.0
+    c = np.abs(np.cos(g["roll"]))
+    err = np.abs(got[:, 7:11] - g["cmd_out"]).max(1)
+    ok = c >= 1e-2
+    assert ok.sum() >= 8 and (err[ok] <= 3 * REL_TOL / c[ok]).all(), (err[ok] * c[ok]).max()
+    # the thrust increment is the well-conditioned row of inv(G): exact right up to the singular point
+    off = np.abs(np.abs(g["roll"]) - np.pi / 2) > 0
+    assert np.abs(got[off, 6] - g["last_thrust_out"][off]).max() < 2e-5 * (1 + np.abs(g["last_thrust_out"]).max())
+    ctx.close()
+
+
 @pytest.mark.parametrize("model", ["robobee", "tello"])
 def test_control_sequence_vs_golden(gpu, golden_dir, model):
     """Controller memory recursion over 60 calls (reference-generated sequence)."""

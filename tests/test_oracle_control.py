@@ -208,7 +208,7 @@ def test_golden_fixtures_regenerate_bit_identically(tmp_path):
             else:
                 sys.modules[k] = v
     files = sorted(glob.glob(os.path.join(here, "*.npz")))
-    assert len(files) == 13
+    assert len(files) == 14
     for f in files:
         a, b = np.load(f, allow_pickle=True), np.load(os.path.join(str(tmp_path), os.path.basename(f)), allow_pickle=True)
         assert set(a.files) == set(b.files), f
@@ -231,3 +231,23 @@ def test_euler_and_matrix_conventions_match_scipy():
         back = orc.euler_from_quat(q)
         np.testing.assert_allclose(back, R.from_quat(q).as_euler("xyz"), rtol=0, atol=1e-9)
         np.testing.assert_allclose(back, e, rtol=0, atol=1e-9)
+
+
+def test_roll_sweep_through_the_pinv_singularity_vs_reference(golden_dir):
+    """det G = T^2 cos(roll): the reference's np.linalg.pinv (INDIControl.py:336) is swept through roll = +-90 deg
+    (tests/golden/indi_roll_sweep.npz, |roll| - 90 deg from 1e-1 rad down to 0).  The oracle's SVD pinv follows the
+    reference to rounding down to 1e-4 rad and stays with it (ill-conditioned, but the same regime) below."""
+    g = _load(golden_dir, "indi_roll_sweep.npz")
+    O = orc.Oracle([params.builtin_type("robobee")])
+    n = len(g["roll"])
+    rigid = np.concatenate([g["pos"], g["quat"], g["vel"], g["ang_vel"]], 1)
+    mem = np.zeros((n, 13))
+    mem[:, 0:3], mem[:, 3:6], mem[:, 6], mem[:, 7:11] = g["last_vel"], g["last_rates"], g["last_thrust"], g["cmd"]
+    tgt = np.concatenate([g["target_pos"], np.zeros((n, 6)), g["target_yaw"][:, None]], 1)
+    rc, _, _ = O.control(rigid, mem, tgt, float(g["dt"]))
+    assert rc == 0 and np.isfinite(mem).all()
+    d = np.abs(np.abs(g["roll"]) - np.pi / 2)
+    err = np.abs(mem[:, 7:11] - g["cmd_out"]).max(1)
+    assert err[d >= 1e-4].max() < 1e-10 and err[d < 1e-4].max() < 5e-3
+    np.testing.assert_allclose(mem[:, 6], g["last_thrust_out"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(mem[:, 3:6], g["last_rates_out"], rtol=0, atol=1e-13)
