@@ -5,7 +5,7 @@
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
 One "step" = one Env.step() (phys_substeps physics sub-steps) + one INDI evaluation for
-every drone of the rank's fleet = ONE launch of k_step_quad.  Inputs are resident in HBM
+every drone of the rank's fleet = ONE launch of k_step_fast.  Inputs are resident in HBM
 before the timed region.  Drones are independent, so ranks shard the fleet with no
 data-path collective (weak scaling: per-GPU fleet fixed).
 

@@ -1,5 +1,5 @@
 // membench.hip — dev micro-benchmark (not part of the product): what HBM rate can THIS traffic
-// shape reach on MI355X?  Shape of k_step_quad: per drone read 34 floats (24 state + 10 target),
+// shape reach on MI355X?  Shape of k_step_fast: per drone read 34 floats (24 state + 10 target),
 // write 24 floats, one drone per lane.  Variants differ only in layout / access width.
 //   hipcc -O3 --offload-arch=gfx950 -o membench tools/membench.hip && ./membench
 #include <hip/hip_runtime.h>
