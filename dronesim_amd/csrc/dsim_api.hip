@@ -36,6 +36,7 @@ struct dsim_ctx {
   const int32_t* dw_ws;                   // downwash grid: workspace / shape / count-buffer parity of the last call
   long long dw_cells;
   int dw_parity;
+  int dw_mode;                            // 0: counting sort, 1: cell buckets (which layout the count buffers hold)
   dsim_type_params h_types[DSIM_MAX_TYPES];
 };
 
@@ -940,6 +941,8 @@ struct DwK {
   int* count_next;   // the other buffer: zeroed by this call's query kernel for the next call
   int* cursor;       // [ncells]
   float4* sorted;    // [m]  (x, y, z, world index as int bits)
+  float4* buckets;   // bucket form: [ncells][DW_CAP] entries per cell; count[ncells] = overflow length
+  float4* overflow;  // bucket form: [m] entries that found their cell full
   float* force_out;  // SoA [3][n_pad]
   float radius2;     // adjacency
   int* adj_count;    // [n_pad]
@@ -992,6 +995,60 @@ __global__ __launch_bounds__(256) void k_dw_scatter(DwK a) {
   const int slot = atomicAdd(&a.cursor[dw_cell(a, x, y, cx, cy)], 1);
   a.sorted[slot] = make_float4(x, y, z, __int_as_float((int)j));
 }
+// ---- bucket form of the grid (small worlds: a shard of tens of thousands of drones) ------------------------------
+// One Env.step of such a shard is a chain of launch-bound kernels; count + scan + scatter are replaced by ONE
+// binning kernel that appends every entry to its cell's fixed-capacity bucket, entries that find the bucket full go
+// to a shared overflow list which every receiver scans as well (normally empty), so the result never depends on
+// the capacity.  The host picks this form when the mean cell occupancy is at most DW_CAP / 2.
+#define DW_CAP 32
+__global__ __launch_bounds__(256) void k_dw_bin(DwK a) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int ncells = a.nx * a.ny;
+  if (j <= (long long)ncells + 1) a.count_next[j] = 0;          // the buffer the NEXT grid build will use
+  if (j >= a.m) return;
+  const float x = dw_pos(a, j, 0), y = dw_pos(a, j, 1), z = dw_pos(a, j, 2);
+  int cx, cy;
+  const int c = dw_cell(a, x, y, cx, cy);
+  const float4 e = make_float4(x, y, z, __int_as_float((int)j));
+  const int slot = atomicAdd(&a.count[c], 1);
+  if (slot < DW_CAP) a.buckets[(long long)c * DW_CAP + slot] = e;
+  else a.overflow[atomicAdd(&a.count[ncells], 1)] = e;
+}
+__device__ __forceinline__ float dw_pair(float4 p, float x, float y, float z, float pr, float d0, float d1, float d2c) {
+  const float dz = p.z - z, dx = p.x - x, dy = p.y - y;
+  const float dd = dx * dx + dy * dy;
+  if (!(dz > 0.0f && dd < 100.0f)) return 0.0f;                 // BaseAviary.py:1752
+  const float r = pr * DSIM_RCP(4.0f * dz);
+  const float beta = d1 * dz + d2c;                             // :1754
+  return -(d0 * r * r) * __expf(-0.5f * dd * DSIM_RCP(beta * beta));   // :1753, 1755
+}
+// DW_LPR lanes per LOCAL drone stride through the nine buckets around it and the overflow list
+__global__ __launch_bounds__(256) void k_dw_query_b(DwK a) {
+  const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long i = gt / 8;
+  const int sub = (int)(gt % 8);
+  if (i >= a.n) return;
+  const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
+  const float* sp = a.st.base + kv_off(a.st, i);
+  const float x = sp[0], y = sp[a.st.field_stride], z = sp[2 * a.st.field_stride];
+  const float pr = T.prop_radius, d0 = T.dw[0], d1 = T.dw[1], d2c = T.dw[2];
+  int cx, cy;
+  dw_cell(a, x, y, cx, cy);
+  float fz = 0.0f;
+  for (int yy = max(cy - 1, 0); yy <= min(cy + 1, a.ny - 1); ++yy)
+    for (int xx = max(cx - 1, 0); xx <= min(cx + 1, a.nx - 1); ++xx) {
+      const int c = yy * a.nx + xx;
+      const int cnt = min(a.count[c], DW_CAP);
+      const float4* __restrict__ b = a.buckets + (long long)c * DW_CAP;
+      for (int e = sub; e < cnt; e += 8) fz += dw_pair(b[e], x, y, z, pr, d0, d1, d2c);
+    }
+  const int n_ovf = a.count[a.nx * a.ny];
+  for (int e = sub; e < n_ovf; e += 8) fz += dw_pair(a.overflow[e], x, y, z, pr, d0, d1, d2c);
+#pragma unroll
+  for (int off = 4; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
+  if (sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz; }
+}
+
 // DW_LPR lanes per SORTED world entry; the entries that belong to this rank's shard are the
 // receivers.  The lanes of a wave sit in the same or neighbouring cells, so their 3x3 scans read the
 // same sorted entries; the DW_LPR lanes of one receiver stride its candidate list together (each
@@ -1154,7 +1211,7 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
   dsim_ctx* c = new (std::nothrow) dsim_ctx;
   if (!c) return (int)hipErrorOutOfMemory;
   c->device = device; c->n_types = n_types; c->max_act = max_act; c->d_types = nullptr; c->d_counters = nullptr;
-  c->d_fb = nullptr; c->fb_cap = 0; c->dw_ws = nullptr; c->dw_cells = 0; c->dw_parity = 0;
+  c->d_fb = nullptr; c->fb_cap = 0; c->dw_ws = nullptr; c->dw_cells = 0; c->dw_parity = 0; c->dw_mode = 0;
   DevType h[DSIM_MAX_TYPES];
   for (int t = 0; t < n_types; ++t) { c->h_types[t] = types[t]; to_dev(types[t], &h[t]); }
   e = hipMalloc((void**)&c->d_types, sizeof(DevType) * n_types);
@@ -1535,13 +1592,19 @@ int dsim_traj_sample(dsim_ctx* ctx, void* stream, int64_t n, const double* coeff
   return (int)hipGetLastError();
 }
 
+// bucket form: small grids with at most DW_CAP / 2 entries per cell on average
+static inline bool dw_use_buckets(int64_t m, int64_t ncells) { return ncells <= 65536 && m <= ncells * (DW_CAP / 2); }
+
 int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny) {
   if (m < 0 || nx < 1 || ny < 1) return -1;
-  return 2 * ((int64_t)nx * ny + 1) + (int64_t)nx * ny + 4 + 4 * m;   // count x2, cursor, 16-B alignment slack, float4[m]
+  const int64_t ncells = (int64_t)nx * ny;
+  const int64_t sort_form = 2 * (ncells + 1) + ncells + 4 + 4 * m;   // count x2, cursor, 16-B alignment slack, float4[m]
+  const int64_t bucket_form = 2 * (ncells + 2) + 4 + 4 * ncells * DW_CAP + 4 * m;   // count x2, slack, buckets, overflow
+  return dw_use_buckets(m, ncells) && bucket_form > sort_form ? bucket_form : sort_form;
 }
 
 static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view& state,
-                      const dsim_downwash_args* g, float min_cell, DwK* out);
+                      const dsim_downwash_args* g, float min_cell, DwK* out, bool allow_buckets = false);
 
 int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_downwash_args* g,
                   float* force_out) {
@@ -1549,10 +1612,11 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
   if (ctx && g && ctx->n_types > 1 && !g->type_id) return DSIM_E_ARG;
   DwK a;
   const hipStream_t st_ = (hipStream_t)stream;
-  int rc = grid_build(ctx, st_, n, state, g, 10.0f, &a);
+  int rc = grid_build(ctx, st_, n, state, g, 10.0f, &a, true);
   if (rc) return rc;
   a.force_out = force_out;
-  hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m * DW_LPR)), dim3(256), 0, st_, a);
+  if (a.buckets) hipLaunchKernelGGL(k_dw_query_b, dim3(grid_for(a.n * 8)), dim3(256), 0, st_, a);
+  else hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m * DW_LPR)), dim3(256), 0, st_, a);
   return (int)hipGetLastError();
 }
 
@@ -1570,7 +1634,7 @@ int dsim_adjacency(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, cons
 
 // counting sort of the world's positions into the xy grid (count, scan, scatter)
 static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view& state,
-                      const dsim_downwash_args* g, float min_cell, DwK* out) {
+                      const dsim_downwash_args* g, float min_cell, DwK* out, bool allow_buckets) {
   DwK& a_ = *out;
   if (!ctx || !g || !g->workspace || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
   // pos_all = NULL: the world is this fleet (m = n, local_offset = 0) and positions are read from the state block
@@ -1587,20 +1651,30 @@ static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view
   a.m = g->m; a.m_pad = g->m_pad; a.n = n; a.n_pad = state.n_pad; a.local_offset = g->local_offset;
   if (g->local_offset < 0 || g->local_offset + n > g->m || g->m >= (1LL << 31)) return DSIM_E_ARG;
   a.xmin = g->xmin; a.ymin = g->ymin; a.inv_cell = 1.0f / g->cell; a.nx = g->nx; a.ny = g->ny;
-  // two count buffers alternate between calls; the one for the next call is zeroed by k_dw_zero_next
-  const bool same = ctx->dw_ws == g->workspace && ctx->dw_cells == ncells;
+  const bool buckets = allow_buckets && dw_use_buckets(g->m, ncells);
+  const long long cstride = ncells + (buckets ? 2 : 1);      // the bucket form keeps the overflow length behind the cells
+  // two count buffers alternate between calls; the one for the next call is zeroed by this call's first kernel
+  const bool same = ctx->dw_ws == g->workspace && ctx->dw_cells == ncells && ctx->dw_mode == (buckets ? 1 : 0);
   const int cur = same ? ctx->dw_parity : 0;
-  a.count = g->workspace + (long long)cur * (ncells + 1);
-  a.count_next = g->workspace + (long long)(1 - cur) * (ncells + 1);
+  a.count = g->workspace + (long long)cur * cstride;
+  a.count_next = g->workspace + (long long)(1 - cur) * cstride;
+  if (!same) {   // first use of this workspace / grid shape / form
+    hipError_t e = hipMemsetAsync(g->workspace, 0, sizeof(int) * 2 * cstride, st_);
+    if (e != hipSuccess) return (int)e;
+    ctx->dw_ws = g->workspace; ctx->dw_cells = ncells; ctx->dw_mode = buckets ? 1 : 0;
+  }
+  ctx->dw_parity = 1 - cur;
+  if (buckets) {
+    uintptr_t sp = (uintptr_t)(g->workspace + 2 * cstride);
+    a.buckets = (float4*)((sp + 15) & ~(uintptr_t)15);
+    a.overflow = a.buckets + ncells * DW_CAP;
+    hipLaunchKernelGGL(k_dw_bin, dim3(grid_for(a.m > ncells + 2 ? a.m : ncells + 2)), dim3(256), 0, st_, a);
+    a_ = a;
+    return DSIM_OK;
+  }
   a.cursor = g->workspace + 2 * (ncells + 1);
   uintptr_t sp = (uintptr_t)(a.cursor + ncells);
   a.sorted = (float4*)((sp + 15) & ~(uintptr_t)15);
-  if (!same) {   // first use of this workspace / grid shape
-    hipError_t e = hipMemsetAsync(g->workspace, 0, sizeof(int) * 2 * (ncells + 1), st_);
-    if (e != hipSuccess) return (int)e;
-    ctx->dw_ws = g->workspace; ctx->dw_cells = ncells;
-  }
-  ctx->dw_parity = 1 - cur;
   hipLaunchKernelGGL(k_dw_count, dim3(grid_for(a.m > ncells + 1 ? a.m : ncells + 1)), dim3(256), 0, st_, a);
   // (measured and rejected: letting the last count workgroup do the scan — the fences and the one-workgroup scan
   // behind them cost 28 us against 7 + 6.5 us for the two launches)

@@ -602,6 +602,32 @@ def test_downwash_vs_bruteforce_oracle(gpu):
     ctx.close()
 
 
+def test_downwash_bucket_grid_with_overflowing_cells(gpu):
+    """The bucket form of the neighbour grid (small worlds: one binning kernel instead of count + scan + scatter):
+    a swarm of 700 drones packed into one 10 m cell overflows its 32-entry bucket many times over; the overflow list
+    keeps the result equal to the brute-force sum."""
+    nat, fleet = gpu
+    from dronesim_amd.downwash import Downwash
+    n = 2500
+    ctx = fleet.Context([params.builtin_type("robobee")])
+    st = fleet.FleetState(ctx, n)
+    rng = np.random.default_rng(58)
+    rigid, mem, _ = random_fleet(rng, n)
+    rigid[:, 0] = f32(rng.uniform(0, 300, n)); rigid[:, 1] = f32(rng.uniform(0, 300, n)); rigid[:, 2] = f32(rng.uniform(0.5, 20, n))
+    rigid[:700, 0] = f32(rng.uniform(101, 108, 700)); rigid[:700, 1] = f32(rng.uniform(201, 208, 700))   # the swarm
+    st.load_aos(rigid, mem)
+    dw = Downwash(ctx, st)
+    f = dw.compute().cpu().numpy()
+    assert ctx.lib.dsim_downwash_workspace(n, 33, 33) > 4 * 33 * 33 * 32        # this shape takes the bucket form
+    ref = orc.Oracle([params.builtin_type("robobee")]).downwash(rigid, rigid[:, 0:3])
+    assert (ref[:700] < 0).sum() > 600
+    err = np.abs(f[2, :n] - ref) / (np.abs(ref) + 1e-3)
+    assert err.max() < 1e-4, (err.max(), err.argmax())
+    f_again = dw.compute().cpu().numpy()                        # second build: the double-buffered counts were re-zeroed
+    assert (np.abs(f_again[2, :n] - ref) / (np.abs(ref) + 1e-3)).max() < 1e-4
+    ctx.close()
+
+
 @pytest.mark.parametrize("opts", [1, 2, 3])          # DSIM_OPT_DRAG, DSIM_OPT_GROUND, both
 def test_drag_and_ground_effect_vs_oracle(gpu, opts):
     """Formulas P6/P7 (dead code in the reference fork) as switchable physics terms: Env.step with an
