@@ -1022,11 +1022,14 @@ __device__ __forceinline__ float dw_pair(float4 p, float x, float y, float z, fl
   const float beta = d1 * dz + d2c;                             // :1754
   return -(d0 * r * r) * __expf(-0.5f * dd * DSIM_RCP(beta * beta));   // :1753, 1755
 }
-// DW_LPR lanes per LOCAL drone stride through the nine buckets around it and the overflow list
+// DW_LPB lanes per LOCAL drone stride through the nine buckets around it and the overflow list
+#ifndef DW_LPB
+#define DW_LPB 8
+#endif
 __global__ __launch_bounds__(256) void k_dw_query_b(DwK a) {
   const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long i = gt / 8;
-  const int sub = (int)(gt % 8);
+  const long long i = gt / DW_LPB;
+  const int sub = (int)(gt % DW_LPB);
   if (i >= a.n) return;
   const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
   const float* sp = a.st.base + kv_off(a.st, i);
@@ -1040,12 +1043,12 @@ __global__ __launch_bounds__(256) void k_dw_query_b(DwK a) {
       const int c = yy * a.nx + xx;
       const int cnt = min(a.count[c], DW_CAP);
       const float4* __restrict__ b = a.buckets + (long long)c * DW_CAP;
-      for (int e = sub; e < cnt; e += 8) fz += dw_pair(b[e], x, y, z, pr, d0, d1, d2c);
+      for (int e = sub; e < cnt; e += DW_LPB) fz += dw_pair(b[e], x, y, z, pr, d0, d1, d2c);
     }
   const int n_ovf = a.count[a.nx * a.ny];
-  for (int e = sub; e < n_ovf; e += 8) fz += dw_pair(a.overflow[e], x, y, z, pr, d0, d1, d2c);
+  for (int e = sub; e < n_ovf; e += DW_LPB) fz += dw_pair(a.overflow[e], x, y, z, pr, d0, d1, d2c);
 #pragma unroll
-  for (int off = 4; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
+  for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
   if (sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz; }
 }
 
@@ -1615,7 +1618,7 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
   int rc = grid_build(ctx, st_, n, state, g, 10.0f, &a, true);
   if (rc) return rc;
   a.force_out = force_out;
-  if (a.buckets) hipLaunchKernelGGL(k_dw_query_b, dim3(grid_for(a.n * 8)), dim3(256), 0, st_, a);
+  if (a.buckets) hipLaunchKernelGGL(k_dw_query_b, dim3(grid_for(a.n * DW_LPB)), dim3(256), 0, st_, a);
   else hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m * DW_LPR)), dim3(256), 0, st_, a);
   return (int)hipGetLastError();
 }
