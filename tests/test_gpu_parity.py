@@ -1309,6 +1309,67 @@ def test_two_quad_types_keep_their_own_gains(gpu):
     ctx.close()
 
 
+@pytest.mark.parametrize("n_types", [3, 4, 8])      # 3, 4: the LDS-staged mixed kernel (4 resp. 5 waves per tile); 8: the general one
+def test_randomised_airframes_vs_oracle(gpu, n_types):
+    """Nothing of robobee/tello is baked into the kernels: six made-up quad types and two made-up hexa types (random
+    mass, inertia, kf/km, pwm map and limits, rotor geometry, G1, gains, damping, gravity) in one interleaved fleet,
+    fused step with in-kernel noise, against the oracle built from the same type table."""
+    import dataclasses
+    nat, fleet = gpu
+    rng = np.random.default_rng(2024)
+    types = []
+    for k in range(8):
+        hexa = k in (2, 5)
+        t = dataclasses.replace(params.builtin_type("hexa_6DOF" if hexa else "robobee"), name=f"random{k}")
+        na = t.n_act
+        t.mass = float(rng.uniform(0.05, 2.0)); t.ctrl_mass = t.mass
+        t.inertia = tuple(float(x) for x in rng.uniform(2e-5, 3e-3, 3))
+        t.kf = float(rng.uniform(1e-9, 4e-8)); t.km = float(t.kf * rng.uniform(0.005, 0.1))
+        sc = np.zeros(6); sc[:na] = rng.uniform(8000, 25000, na); t.pwm2rpm_scale = sc
+        cn = np.zeros(6); cn[:na] = rng.uniform(0, 1500, na); t.pwm2rpm_const = cn
+        lo = np.zeros(6); lo[:na] = rng.uniform(0.0, 0.15, na); t.pwm_min = lo
+        hi = np.zeros(6); hi[:na] = rng.uniform(0.8, 1.0, na); t.pwm_max = hi
+        rp = np.asarray(t.rotor_pos, dtype=float).copy(); rp[:na] *= rng.uniform(0.5, 2.0); rp[:na] += rng.normal(0, 0.005, (na, 3)); t.rotor_pos = rp
+        G1 = np.asarray(t.G1, dtype=float).copy(); G1[:, :na] *= rng.uniform(0.6, 1.6, (G1.shape[0], 1)); t.G1 = G1
+        t.kp_pos, t.kd_pos = float(rng.uniform(0.8, 2.0)), float(rng.uniform(1.5, 3.0))
+        t.att_gain = tuple(float(x) for x in rng.uniform(4, 12, 3)); t.rate_gain = tuple(float(x) for x in rng.uniform(6, 20, 3))
+        t.gravity = float(rng.uniform(3.0, 12.0))
+        t.lin_damping, t.ang_damping = float(rng.uniform(0.0, 0.1)), float(rng.uniform(0.0, 0.1))
+        t.alloc = None; t.__post_init__()                      # allocation matrices follow the new G1
+        types.append(t)
+    types = types[:n_types]
+    n = 4000
+    ctx = fleet.Context(types)
+    st, tg = fleet.FleetState(ctx, n), fleet.Targets(ctx, n)
+    rigid, mem, tgt = random_fleet(rng, n, n_act=6, tilt=0.3, rate=1.0)
+    tid = rng.integers(0, n_types, n).astype(np.uint8)
+    is_hexa = np.isin(tid, (2, 5))
+    mem[~is_hexa, 11:13] = 0.0
+    lo_all = np.stack([np.asarray(t.pwm_min)[:6] for t in types])[tid]; hi_all = np.stack([np.asarray(t.pwm_max)[:6] for t in types])[tid]
+    mem[:, 7:13] = np.clip(mem[:, 7:13], lo_all, np.maximum(hi_all, lo_all))
+    mem[~is_hexa, 11:13] = 0.0
+    st.load_aos(rigid, mem)
+    tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
+    tid_dev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device); tid_dev[:n] = torch.from_numpy(tid)
+    O = orc.Oracle(types)
+    for sub in (1, 3):                  # both sub-step forms
+        seed, sidx = 31 + sub, 2
+        a = _args(nat, sub, DT, float(np.float32(sub / 240)), seed=seed, step_index=sidx, type_id=tid_dev)
+        nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
+        nz = np.zeros((n, sub, 12))
+        for i in range(n):
+            na = 6 if is_hexa[i] else 4
+            for s_ in range(sub):
+                u = O.noise_normals(seed, i, sidx * sub + s_, na)
+                nz[i, s_, 0:na] = u[0:na] * 0.01
+                nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
+        assert O.step(rigid, mem, tgt, sub, DT, float(np.float32(sub / 240)), noise=nz, type_id=tid) == 0
+        assert rel_err(st.rigid_aos(), rigid, RIGID_SCALE).max() < 2 * REL_TOL
+        assert rel_err(st.mem_aos(), mem, MEM_SCALE).max() < 6 * REL_TOL
+        st.load_aos(rigid, mem)         # continue from the oracle's state
+    ctx.close()
+
+
 def test_abi_argument_errors(gpu):
     nat, fleet = gpu
     t = params.builtin_type("robobee")
