@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libdronesim_amd.so")
 # every symbol include/dronesim_amd.h declares
 EXPORTS = (
     "dsim_abi_version", "dsim_strerror", "dsim_create", "dsim_destroy", "dsim_reset", "dsim_step",
-    "dsim_physics", "dsim_control", "dsim_step_adaptor", "dsim_traj_sample", "dsim_materialize", "dsim_counter_add", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash", "dsim_downwash_workspace", "dsim_adjacency",
+    "dsim_physics", "dsim_control", "dsim_step_adaptor", "dsim_traj_sample", "dsim_materialize", "dsim_counter_add", "dsim_reserve", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash", "dsim_downwash_workspace", "dsim_adjacency",
 )
 
 ABI_VERSION = 3
@@ -118,6 +118,7 @@ def load() -> ctypes.CDLL:
     lib.dsim_traj_sample.argtypes = [vp, vp, i64, vp, vp, i32, vp, ctypes.c_double, vp, vp, View]
     lib.dsim_materialize.argtypes = [vp, vp, i64, View]
     lib.dsim_counter_add.argtypes = [vp, vp, vp, ctypes.c_uint64]
+    lib.dsim_reserve.argtypes = [vp, vp, i64]
     lib.dsim_observe.argtypes = [vp, vp, i64, View, vp, vp, i32]
     lib.dsim_observe_soa.argtypes = [vp, vp, i64, View, vp, vp, i32]
     lib.dsim_query.argtypes = [vp, vp, i32, ctypes.POINTER(ctypes.c_int64)]

@@ -1485,6 +1485,11 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   return (int)hipGetLastError();
 }
 
+int dsim_reserve(dsim_ctx* ctx, void* stream, int64_t n_pad) {
+  if (!ctx || n_pad <= 0) return DSIM_E_ARG;
+  return fb_prepare(ctx, n_pad, (hipStream_t)stream);
+}
+
 int dsim_counter_add(dsim_ctx* ctx, void* stream, uint64_t* counter, uint64_t inc) {
   if (!ctx || !counter) return DSIM_E_ARG;
   hipLaunchKernelGGL(k_counter_add, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)counter,

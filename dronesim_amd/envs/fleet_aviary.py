@@ -302,10 +302,12 @@ class CtrlAviary:
         launch-latency bound (a few us per launch from Python; 10-16 us per graph replay whatever its
         length), which is what a graph removes.  Kernel arguments are frozen at capture time, so the
         env-step counter that seeds the rotor noise is read from device memory (``step_index_dev``: captured step
-        i uses counter + i) and advanced by ``steps`` by a one-thread node at the end of the graph.  Quad fleets
-        (hexa steps may grow the fallback queue, an allocation), plain/waypoint targets."""
-        if self.n_act != 4 or self._downwash is not None:
-            raise NotImplementedError("graph capture: quad fleets without the downwash exchange")
+        i uses counter + i) and advanced by ``steps`` by a one-thread node at the end of the graph.  Any fleet
+        composition, plain or waypoint targets; not with the neighbour-downwash exchange."""
+        if self._downwash is not None:
+            raise NotImplementedError("graph capture: fleets without the downwash exchange (it sizes buffers on the host)")
+        # nothing may allocate under capture: the fallback queue of hexa fleets is reserved up front
+        nat.check(self.ctx.lib.dsim_reserve(self.ctx.handle, self.ctx.stream_ptr(), self.state.n_pad))
         return FusedGraph(self, targets, steps, control_timestep)
 
     def close(self):

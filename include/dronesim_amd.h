@@ -206,6 +206,11 @@ int dsim_reset(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state,
 int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
               const dsim_step_args* args);
 
+/* Pre-allocates what the ctx owns for fleets of up to n_pad drones (today: the deferred-WLS-fallback queue of
+ * tables that hold a morphing hexa; a no-op otherwise), so that no later call allocates or synchronises — which
+ * hipGraph capture of dsim_step requires. */
+int dsim_reserve(dsim_ctx* ctx, void* stream, int64_t n_pad);
+
 /* *counter += inc on the stream (a one-thread kernel; the companion of step_index_dev). */
 int dsim_counter_add(dsim_ctx* ctx, void* stream, uint64_t* counter, uint64_t inc);
 

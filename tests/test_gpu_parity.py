@@ -1042,6 +1042,33 @@ def test_graph_replay_equals_eager_steps(gpu, golden_dir):
     envA.close(); envB.close()
 
 
+def test_graph_replay_hexa_fleet(gpu):
+    """hipGraph capture also covers fleets with the morphing hexa (the deferred-WLS-fallback queue is reserved
+    beforehand through dsim_reserve): replay == eager stepping, rotor noise on, mixed interleaved fleet."""
+    from dronesim_amd.envs import CtrlAviary
+    from dronesim_amd.fleet import Targets
+    n = 3000
+    rng = np.random.default_rng(123)
+    xyz = np.stack([rng.uniform(0, 50, n), rng.uniform(0, 50, n), rng.uniform(1, 5, n)], 1)
+    tid = (np.arange(n) % 2).astype(np.uint8)
+    envs, tgts = [], []
+    for _ in range(2):
+        e = CtrlAviary(["robobee", "hexa_6DOF"], n, initial_xyzs=xyz, aggregate_phy_steps=1, noise_seed=99, dict_io=False,
+                       type_ids=tid)
+        t = Targets(e.ctx, n); t.set(pos=f32(xyz + 0.2).T, yaw=0.2)
+        envs.append(e); tgts.append(t)
+    for _ in range(12):
+        envs[0].step_fused(tgts[0])
+    g = envs[1].capture_fused(tgts[1], steps=4)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(envs[0].state.fields(0, 26).cpu().numpy(), envs[1].state.fields(0, 26).cpu().numpy())
+    assert envs[0]._env_steps == envs[1]._env_steps == 12
+    for e in envs:
+        e.close()
+
+
 @pytest.mark.parametrize("sub", [1, 2])        # 1: the straight-line single-sub-step kernels, 2: the looped ones
 def test_chained_stepping(gpu, sub):
     """DSIM_OPT_CHAINED: last_vel / last_rates recomputed from the stored rigid state instead of being read,
