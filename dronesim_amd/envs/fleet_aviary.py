@@ -172,6 +172,8 @@ class CtrlAviary:
             self._downwash = Downwash(self.ctx, self.state, self._type_id, dist, halo=halo)
         self.step_counter = 0
         self._env_steps = 0
+        # what the ctx owns for this fleet size is allocated now, not inside the first step
+        nat.check(self.ctx.lib.dsim_reserve(self.ctx.handle, self.ctx.stream_ptr(), self.state.n_pad))
         self._housekeeping()
 
     # ------------------------------------------------------------------ helpers
