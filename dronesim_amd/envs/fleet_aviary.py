@@ -254,6 +254,9 @@ class CtrlAviary:
         # hot loop: the same targets object, no explicit action, no downwash -> reuse the prepared
         # argument block (the Python side of a launch drops from ~9 us to ~3 us, which is what bounds
         # small fleets)
+        if n_steps > 1 and self._downwash is not None:
+            raise ValueError("n_steps > 1 with the neighbour-downwash term: the force (and the position exchange behind "
+                             "it) is evaluated once per Env.step")
         key = (id(targets), control_timestep, n_steps, self._chained_enabled)
         plan = self._fused_plan
         if (action is None and plan is not None and plan[0] == key and self._downwash is None and self._chain_ok
