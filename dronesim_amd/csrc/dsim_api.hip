@@ -1022,7 +1022,9 @@ __device__ __forceinline__ float dw_pair(float4 p, float x, float y, float z, fl
   const float beta = d1 * dz + d2c;                             // :1754
   return -(d0 * r * r) * __expf(-0.5f * dd * DSIM_RCP(beta * beta));   // :1753, 1755
 }
-// DW_LPB lanes per LOCAL drone stride through the nine buckets around it and the overflow list
+// DW_LPB lanes per LOCAL drone stride through the nine buckets around it and the overflow list.
+// (Measured and rejected: taking the receivers in bucket order — one group per bucket slot — so that the groups of
+// a wave read the same buckets: 41.5 vs 36 us per config-5 step; two thirds of the groups find an empty slot.)
 #ifndef DW_LPB
 #define DW_LPB 8
 #endif
