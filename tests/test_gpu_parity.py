@@ -1397,6 +1397,79 @@ def test_randomised_airframes_vs_oracle(gpu, n_types):
     ctx.close()
 
 
+@pytest.mark.parametrize("layout", ["soa", "tile64"])
+@pytest.mark.parametrize("fleet_kind", ["quad", "hexa", "mixed"])
+def test_kernels_stay_inside_their_views(gpu, layout, fleet_kind):
+    """Every entry point writes only inside the views it was handed: state, targets, action/echo, observation and
+    force buffers are carved out of larger allocations whose guard bands (before and after) must keep their
+    sentinel pattern after reset, fused / physics / control steps (ragged fleet: fast kernel + tail kernel),
+    observation and downwash."""
+    nat, fleet = gpu
+    names = {"quad": ["robobee"], "hexa": ["hexa_6DOF"], "mixed": ["robobee", "hexa_6DOF"]}[fleet_kind]
+    types = [params.builtin_type(m) for m in names]
+    ctx = fleet.Context(types)
+    n, n_pad, G = 1000, 1024, 8192
+    F = ctx.n_fields
+    dev = ctx.device
+    SENT = 12345.678
+
+    def carve(numel):
+        buf = torch.full((numel + 2 * G,), SENT, dtype=torch.float32, device=dev)
+        return buf, buf[G:G + numel]
+
+    def mk_view(t, nf):
+        v = nat.View(); v.base = t.data_ptr(); v.n_pad = n_pad; v.n_fields = nf
+        if layout == "soa":
+            v.block, v.field_stride, v.block_stride = n_pad, n_pad, n_pad * nf
+        else:
+            v.block, v.field_stride, v.block_stride = 64, 64, 64 * nf
+        return v
+
+    bufs = {}
+    for name, numel in (("state", F * n_pad), ("targets", 10 * n_pad), ("action", 6 * n_pad), ("echo", 6 * n_pad),
+                        ("obs", n * (16 + ctx.n_act)), ("force", 3 * n_pad), ("pos_e", 3 * n_pad), ("yaw_e", n_pad),
+                        ("init", 3 * n_pad)):
+        bufs[name] = carve(numel)
+    for k in ("targets", "action", "init"):
+        bufs[k][1].zero_()
+    bufs["action"][1].fill_(0.45)
+    bufs["init"][1].copy_(torch.rand(3 * n_pad, device=dev) * 20 + 1)
+    sv, tv = mk_view(bufs["state"][1], F), mk_view(bufs["targets"][1], 10)
+    tid = None
+    if fleet_kind == "mixed":
+        tid = torch.zeros(n_pad, dtype=torch.uint8, device=dev); tid[:n] = torch.from_numpy((np.arange(n) % 2).astype(np.uint8))
+    tp = tid.data_ptr() if tid is not None else None
+    s = _stream(ctx)
+    zeros = torch.zeros(3 * n_pad, device=dev)
+    nat.check(ctx.lib.dsim_reset(ctx.handle, s, n, sv, bufs["init"][1].data_ptr(), zeros.data_ptr(), None, None, tp))
+    a = _args(nat, 2, DT, float(np.float32(2 / 240)), seed=5, type_id=tid)
+    for k in range(3):
+        a.step_index = k
+        nat.check(ctx.lib.dsim_step(ctx.handle, s, n, sv, tv, ctypes.byref(a)))
+    a1 = _args(nat, 1, DT, DT, seed=5, type_id=tid)
+    nat.check(ctx.lib.dsim_step(ctx.handle, s, n, sv, tv, ctypes.byref(a1)))                   # single-sub-step kernels
+    a.action = bufs["action"][1].data_ptr()
+    nat.check(ctx.lib.dsim_step(ctx.handle, s, n, sv, tv, ctypes.byref(a)))                    # explicit action: general kernel
+    nat.check(ctx.lib.dsim_physics(ctx.handle, s, n, sv, bufs["echo"][1].data_ptr(), ctypes.byref(a)))
+    a.action = None
+    nat.check(ctx.lib.dsim_control(ctx.handle, s, n, sv, tv, ctypes.byref(a), bufs["pos_e"][1].data_ptr(),
+                                   bufs["yaw_e"][1].data_ptr()))
+    nat.check(ctx.lib.dsim_observe(ctx.handle, s, n, sv, None, bufs["obs"][1].data_ptr(), 16 + ctx.n_act))
+    g = nat.DownwashArgs()
+    nx = ny = 4
+    ws = torch.empty((ctx.lib.dsim_downwash_workspace(n, nx, ny),), dtype=torch.int32, device=dev)
+    g.pos_all, g.m, g.m_pad = None, n, n
+    g.xmin, g.ymin, g.cell, g.nx, g.ny = 0.0, 0.0, 10.0, nx, ny
+    g.workspace, g.workspace_len, g.type_id, g.local_offset = ws.data_ptr(), ws.numel(), tp, 0
+    nat.check(ctx.lib.dsim_downwash(ctx.handle, s, n, sv, ctypes.byref(g), bufs["force"][1].data_ptr()))
+    torch.cuda.synchronize()
+    for name, (buf, inner) in bufs.items():
+        assert bool((buf[:G] == SENT).all()) and bool((buf[-G:] == SENT).all()), name
+    st_inner = bufs["state"][1]
+    assert bool(torch.isfinite(st_inner.reshape(-1)[: 13 * 64] if layout == "tile64" else st_inner[:n]).all())
+    ctx.close()
+
+
 def test_abi_argument_errors(gpu):
     nat, fleet = gpu
     t = params.builtin_type("robobee")
