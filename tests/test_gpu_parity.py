@@ -1462,7 +1462,37 @@ def test_kernels_stay_inside_their_views(gpu, layout, fleet_kind):
     g.xmin, g.ymin, g.cell, g.nx, g.ny = 0.0, 0.0, 10.0, nx, ny
     g.workspace, g.workspace_len, g.type_id, g.local_offset = ws.data_ptr(), ws.numel(), tp, 0
     nat.check(ctx.lib.dsim_downwash(ctx.handle, s, n, sv, ctypes.byref(g), bufs["force"][1].data_ptr()))
+    # the remaining entry points: field-major observation, adjacency, and (quads) adaptor / chained / trajectory sampler
+    extra = {}
+    for name, numel in (("obs_soa", (16 + ctx.n_act) * n_pad), ("adj_list", 4 * n_pad)):
+        extra[name] = carve(numel)
+    nat.check(ctx.lib.dsim_observe_soa(ctx.handle, s, n, sv, None, extra["obs_soa"][1].data_ptr(), 16 + ctx.n_act))
+    cnt_buf = torch.full((n_pad + 2 * G,), -7, dtype=torch.int32, device=dev)
+    lst_buf = torch.full((4 * n_pad + 2 * G,), -7, dtype=torch.int32, device=dev)
+    nat.check(ctx.lib.dsim_adjacency(ctx.handle, s, n, sv, ctypes.byref(g), 5.0, cnt_buf[G:].data_ptr(), lst_buf[G:].data_ptr(), 4))
+    if fleet_kind == "quad":
+        a.action = bufs["action"][1].data_ptr()
+        for mode in (nat.ADAPT_VELOCITY, nat.ADAPT_RPYT):
+            nat.check(ctx.lib.dsim_step_adaptor(ctx.handle, s, n, sv, bufs["action"][1].data_ptr(), mode,
+                                                bufs["echo"][1].data_ptr(), ctypes.byref(a)))
+        a.action = None
+        a1.options = nat.OPT_CHAINED
+        nat.check(ctx.lib.dsim_step(ctx.handle, s, n, sv, tv, ctypes.byref(a1)))
+        nat.check(ctx.lib.dsim_materialize(ctx.handle, s, n, sv))
+        gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traj_track_waypoints.npz"))
+        co = torch.from_numpy(np.ascontiguousarray(gold["coeffs"])).double().to(dev)
+        ts = torch.from_numpy(gold["TS"]).double().to(dev)
+        tt = torch.full((n_pad + 2 * G,), -3.0, dtype=torch.float64, device=dev); tt[G:G + n_pad] = 0.5
+        ys = torch.full((3 * n_pad + 2 * G,), -3.0, dtype=torch.float64, device=dev); ys[G:G + 3 * n_pad] = 0.0; ys[G + n_pad:G + 2 * n_pad] = 1.0
+        nat.check(ctx.lib.dsim_traj_sample(ctx.handle, s, n, co.data_ptr(), ts.data_ptr(), len(gold["TS"]) - 1,
+                                           tt[G:].data_ptr(), 1 / 48, ys[G:].data_ptr(), None, tv))
+        torch.cuda.synchronize()
+        assert bool((tt[:G] == -3.0).all()) and bool((tt[-G:] == -3.0).all())
+        assert bool((ys[:G] == -3.0).all()) and bool((ys[-G:] == -3.0).all())
     torch.cuda.synchronize()
+    assert bool((cnt_buf[:G] == -7).all()) and bool((cnt_buf[-G:] == -7).all())
+    assert bool((lst_buf[:G] == -7).all()) and bool((lst_buf[-G:] == -7).all())
+    bufs.update(extra)
     for name, (buf, inner) in bufs.items():
         assert bool((buf[:G] == SENT).all()) and bool((buf[-G:] == SENT).all()), name
     st_inner = bufs["state"][1]
