@@ -921,6 +921,18 @@ void orc_state_vector(const dsim_type_params* P, const double rigid[13], const d
   memcpy(out + 16, last_action, sizeof(double) * P->n_act);
 }
 
+/* the same for a fleet: rigid [n][13], last_action [n][6], out [n][width] (width = 16 + max n_act of the table;
+ * rows of types with fewer actuators are zero-filled behind their own n_act, as the device rows are) */
+void orc_state_vector_batch(const dsim_type_params* types, const uint8_t* type_id, int64_t n, const double* rigid,
+                            const double* last_action, int width, double* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    const dsim_type_params* P = &types[type_id ? type_id[i] : 0];
+    double* o = out + i * width;
+    for (int j = 16; j < width; ++j) o[j] = 0.0;
+    orc_state_vector(P, rigid + i * 13, last_action + i * 6, o);
+  }
+}
+
 int orc_sizeof_params(void) { return (int)sizeof(dsim_type_params); }
 int orc_max_threads(void) {
 #ifdef _OPENMP

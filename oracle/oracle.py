@@ -223,6 +223,18 @@ class Oracle:
                                       _p(rigid), _p(mem), _p(_c(tgt)), bc, _p(nz), options, _p(act), _p(ef),
                                       nthreads)
 
+    def state_vector(self, rigid, last_action, type_id=None) -> np.ndarray:
+        """_getDroneStateVector rows (BaseAviary.py:780-790): [n, 16 + max n_act] = pos3 quat4 rpy3 vel3 ang_v3
+        last_action; last_action [n,6]."""
+        n = rigid.shape[0]
+        width = 16 + max(t.n_act for t in self.types)
+        out = np.zeros((n, width))
+        f = self._L.orc_state_vector_batch
+        f.argtypes = [ctypes.POINTER(TypeParamsC), _U8, ctypes.c_int64, _D, _D, ctypes.c_int, _D]
+        f.restype = None
+        f(self._c_types, _p(type_id, _U8), n, _p(_c(rigid)), _p(_c(last_action)), width, _p(out))
+        return out
+
     def noise_normals(self, seed: int, drone: int, sub_counter: int, n_act: int) -> np.ndarray:
         out = np.zeros(2 * n_act)
         f = self._L.orc_noise_normals

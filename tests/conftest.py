@@ -17,3 +17,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Worst pass margin of every increment-parity check (tests/util.py): ratio 1.0 = at the bar."""
+    try:
+        from tests.util import WORST
+    except Exception:
+        return
+    if WORST:
+        terminalreporter.write_line("increment-parity margins (|d_gpu - d_oracle| / (1e-4 |d_oracle| + k ulp32(M)); <= 1 passes):")
+        for k, v in sorted(WORST.items()):
+            terminalreporter.write_line(f"  {k:<60s} {v:.3f}")
+        out = os.environ.get("DSIM_MARGINS_OUT")
+        if out:
+            import json
+            with open(out, "w") as fh:
+                json.dump({k: round(v, 4) for k, v in sorted(WORST.items())}, fh, indent=1)
