@@ -2,29 +2,37 @@
 """bench.py — drone-steps/s of the fused Env.step()+INDI kernel on synthetic fleets.
 
     python bench.py --gpus N --steps K --warmup W [--workload NAME]
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1: when the process was not started by a launcher (WORLD_SIZE unset) bench.py starts N ranks itself —
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py ...`` as a CHILD
+process, before anything in this process touches the GPU — one rank per device, RCCL (backend "nccl") over xGMI.
+Started by such a launcher (RANK / LOCAL_RANK / WORLD_SIZE in the environment) it is one of the ranks.
 
 One "step" = one Env.step() (phys_substeps physics sub-steps) + one INDI evaluation for
 every drone of the rank's fleet = ONE launch of k_step_fast.  Inputs are resident in HBM
 before the timed region.  Drones are independent, so ranks shard the fleet with no
-data-path collective (weak scaling: per-GPU fleet fixed).
+data-path collective (weak scaling: per-GPU fleet fixed; N = 1 is exactly the BENCH workload).
 
 Workloads:
   config2x1024 (default)  BASELINE.json configs[1] — 4 096 robobee quads, INDI hover at own start,
                           initial action 0.4 — as 1 024 vectorised env replicas per GPU
                           (4 194 304 drones, 0.97 GB of state: exceeds the 256 MB Infinity
                           Cache, so the HBM fraction means something).  phys_substeps=1.
-  config2                 the single 4 096-drone fleet (launch-latency bound; reported under
-                          "also" in every run)
-  config3                 65 536 robobee, per-drone targets (also under "also")
+  config2                 the single 4 096-drone fleet (launch-latency bound)
+  config3                 65 536 robobee, waypoint-table tracking
   config4                 configs[3]: 65 536 robobee per GPU (x8 = 524 288), hover, no coupling
-  config5                 configs[4]: 65 536 per GPU, even index robobee / odd index hexa_6DOF, neighbour downwash,
-                          slab shards with halo exchange of positions
+  config5                 configs[4]: 65 536 per GPU, even index robobee / odd index hexa_6DOF, neighbour downwash at the
+                          config's density (524 288 drones in 1024 m x 512 m = one per m^2: every rank owns a
+                          128 m x 512 m slab), halo exchange of positions between neighbouring slabs
   hexa, mixed             4 194 304 hexa_6DOF / interleaved quad+hexa drones (roofline-size variants)
+The N = 1 line also carries the literal BASELINE configs 1-3 at their own sizes ("baseline_configs") and further
+variants ("also").
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,20 +44,43 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 BYTES_PER_DRONE_STEP = 232      # read 13+11+10 floats, write 13+11 floats (quad, per-drone targets)
+MIN_TIMED_S = 0.05              # the timed region is repeated (whole K-step regions) until it covers this much
+WORKLOADS = ["config2x1024", "config2", "config3", "config4", "config5", "hexa", "mixed"]
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
-    p.add_argument("--workload", default="config2x1024", choices=["config2x1024", "config2", "config3", "config4", "config5", "hexa", "mixed"])
+    p.add_argument("--workload", default="config2x1024", choices=WORKLOADS)
     p.add_argument("--substeps", type=int, default=1)
     p.add_argument("--layout", default="tile64", choices=["soa", "tile64", "tile256", "tile1024", "tile4096"])
     p.add_argument("--noise-seed", type=int, default=1)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-also", action="store_true")
-    return p.parse_args()
+    p.add_argument("--stream", choices=["auto", "on", "off"], default="auto",
+                   help="nontemporal state accesses: DSIM_OPT_STREAM_ON/_OFF (A/B knob; default: the library's size rule)")
+    p.add_argument("--generic-mixed", action="store_true", help="mixed fleets: DSIM_OPT_GENERIC_MIXED (A/B knob)")
+    p.add_argument("--lib", default=None, help="a differently-tuned build of libdronesim_amd.so (A/B runs)")
+    p.add_argument("--dry-run", action="store_true",
+                   help="host logic only (launcher, rendezvous, reductions, the JSON line); no device work — CPU tests")
+    return p.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# launcher: N ranks as child processes, started before this process touches the GPU
+# ----------------------------------------------------------------------------------------------------------------
+def launch_ranks(a, argv):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this stack
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def grid_fleet(n_fleet, replicas, pitch=1.0, z=0.5):
@@ -64,7 +95,7 @@ class Fleet:
     """A resident fleet + per-drone hover targets at the start position."""
 
     def __init__(self, n_fleet, replicas, device, substeps, layout, noise_seed, waypoints=False, n_steps=1,
-                 config5=False, dist=None, rank=0, chained=False, hexa=False, mixed=False):
+                 config5=False, dist=None, rank=0, chained=False, hexa=False, mixed=False, options=0, slab_m=128.0):
         import torch
         from dronesim_amd.envs import CtrlAviary, Physics
         from dronesim_amd.fleet import Targets, WaypointTargets
@@ -81,14 +112,14 @@ class Fleet:
             if mixed == "type_major":                  # the same fleet stored type-major (fleet.type_major_order)
                 type_ids = np.sort(type_ids)
         if config5:
-            # BASELINE configs[4]: even index robobee (quad INDI), odd index
-            # hexa_6DOF (6DOF INDI + WLS); positions uniform in a 1024 x 512 x [0.5, 20.5] m box so that
-            # downwash pairs exist; neighbour downwash on; this rank's shard of the world fleet
-            # sharded runs: slab decomposition along x (rank r owns x in [r, r+1) * 1024/world), positions exchanged
-            # between neighbouring slabs only (downwash.HaloExchange: grouped RCCL send/recv)
+            # BASELINE configs[4]: even index robobee (quad INDI), odd index hexa_6DOF (6DOF INDI +
+            # WLS); 524 288 drones uniform in a 1024 x 512 x [0.5, 20.5] m box = one drone per m^2 of ground, neighbour
+            # downwash on.  Slab decomposition along x: every rank owns slab_m = 1024/8 = 128 m of it with its 65 536
+            # drones, whatever the number of ranks in this run (weak scaling at the config's own density: per-GPU work —
+            # about 900 candidate pairs per drone — does not change with N); positions are exchanged between
+            # neighbouring slabs only (downwash.HaloExchange: grouped RCCL send/recv)
             rng = np.random.default_rng(1234 + rank)
-            world = dist.get_world_size() if dist is not None else 1
-            xyz = np.stack([rng.uniform(rank * 1024 / world, (rank + 1) * 1024 / world, self.n),
+            xyz = np.stack([rng.uniform(rank * slab_m, (rank + 1) * slab_m, self.n),
                             rng.uniform(0, 512, self.n), rng.uniform(0.5, 20.5, self.n)], 1)
             models, type_ids = ["robobee", "hexa_6DOF"], (np.arange(self.n) % 2).astype(np.uint8)
             physics = Physics.PYB_DW
@@ -103,7 +134,7 @@ class Fleet:
         self.env = CtrlAviary(models, self.n, initial_xyzs=xyz, aggregate_phy_steps=substeps, physics=physics,
                               device=device, layout=layout, noise_seed=noise_seed, dict_io=False, dist=dist,
                               chained=chained, downwash_exchange=os.environ.get("DSIM_DW_EXCHANGE", "halo"),
-                              type_ids=type_ids)
+                              type_ids=type_ids, options=options)
         if waypoints:
             self.tgt = WaypointTargets(self.env.ctx, self.n, g["target_pos"], g["target_vel"], g["target_acc"],
                                        g["target_yaw"], wp_counters=wp0, offsets=off)
@@ -124,24 +155,36 @@ class Fleet:
         self.graph = self.env.capture_fused(self.tgt, steps)
         self.n_steps = steps
 
-    def timed(self, steps, warmup, barrier=None):
+    def timed(self, steps, warmup, barrier=None, min_s=0.0, repeat_rule=None):
+        """W untimed warm-up steps, then regions of EXACTLY `steps` steps each, bracketed by barrier + device
+        synchronisation on both sides, repeated until they cover `min_s` seconds.  Returns (wall seconds, device
+        seconds, regions): sums over the regions; the device seconds come from events on the launch stream.
+        repeat_rule(region_wall_s) -> total number of regions (so that every rank runs the same number)."""
         torch = self.torch
         for _ in range(warmup):
             self.step()
-        if barrier:
-            barrier()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record()                      # on torch's current stream == the stream the kernel is launched on
-        for _ in range(steps):
-            self.step()
-        e1.record()
-        if barrier:
-            barrier()
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-        return wall, e0.elapsed_time(e1) * 1e-3
+        wall_sum = dev_sum = 0.0
+        regions, want = 0, 1
+        while regions < want:
+            if barrier:
+                barrier()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()                      # on torch's current stream == the stream the kernel is launched on
+            for _ in range(steps):
+                self.step()
+            e1.record()
+            if barrier:
+                barrier()
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            wall_sum += wall
+            dev_sum += e0.elapsed_time(e1) * 1e-3
+            regions += 1
+            if regions == 1 and min_s > 0.0:
+                want = repeat_rule(wall) if repeat_rule else max(1, int(np.ceil(min_s / max(wall, 1e-9))))
+        return wall_sum, dev_sum, regions
 
 
 def host_threads():
@@ -196,18 +239,68 @@ def cpu_baseline(substeps, seconds=4.0):
     }
 
 
-def main():
-    a = parse()
-    import torch
-    import __graft_entry__ as graft
+WORKLOAD_TEXT = {
+    "config2x1024": "configs[1] 4096 robobee INDI hover x 1024 vectorised envs/GPU",
+    "config2": "configs[1] 4096 robobee INDI hover (single fleet)",
+    "config3": "configs[2] 65536 robobee, waypoint-table tracking (fly_INDI_TrajectoryTrack)",
+    "config4": "configs[3] shard: 65536 robobee INDI hover per GPU (524288 over 8 GPUs), no coupling",
+    "mixed": "even index robobee, odd index hexa_6DOF, 4096 x 1024 envs/GPU, no downwash",
+    "hexa": "4096 hexa_6DOF (6-DOF INDI + WLS) hover x 1024 vectorised envs/GPU",
+    "config5": "configs[4] shard: 65536/GPU, 50% robobee + 50% hexa_6DOF interleaved, neighbour downwash at the config's "
+               "density (one drone per m^2: a 128 m x 512 m slab per GPU), halo exchange between neighbouring slabs",
+}
+
+
+def measure_variant(torch, local, layout, seed, steps, name, nf, rep, sub, wp, ns, options=0):
+    """One entry of "baseline_configs" / "also": a fresh fleet, one warm region, then timed regions of k steps until
+    they cover MIN_TIMED_S (sums reported, nothing picked)."""
+    f2 = Fleet(nf, rep, local, sub, layout, seed, waypoints=wp, n_steps=ns,
+               config5=name.startswith("config5"), chained="chained" in name, hexa=name.startswith("hexa"),
+               mixed=("type_major" if "type_major" in name else name.startswith("mixed")), options=options,
+               slab_m=(1024.0 if "lowdensity" in name else 128.0))
+    if "hipgraph" in name:
+        f2.n_steps = 1
+        f2.use_graph(ns)
+    k2 = max(20, steps // 2)
+    w2, d2, reg = f2.timed(k2, 10, min_s=MIN_TIMED_S)
+    e = {"drone_steps_per_s": f2.n * k2 * reg * ns / w2, "launch_us": d2 / (k2 * reg) * 1e6, "env_steps_per_launch": ns,
+         "drones": f2.n, "phys_substeps": sub, "steps_timed": k2 * reg}
+    if ns == 1:
+        bts = 184 if "chained" in name else (248 if name.startswith("hexa") else
+                                             (253 if name.startswith("config5") else
+                                              (241 if name.startswith("mixed") else BYTES_PER_DRONE_STEP)))
+        e["hbm_frac"] = f2.n * bts / (d2 / (k2 * reg)) / 1e9 / HBM_PEAK_GBPS
+        e["bytes_per_drone_step"] = bts
+    f2.env.close()
+    del f2
+    return e
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not started by a launcher: start the ranks as children — nothing in THIS process has touched the GPU
+        sys.exit(launch_ranks(a, argv))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; the two must agree", file=sys.stderr)
+        sys.exit(2)
+    # rehearsal knob: DSIM_BENCH_BACKEND=gloo lets several ranks share one GPU (RCCL wants one device per rank)
+    backend = os.environ.get("DSIM_BENCH_BACKEND", "nccl")
+    import torch
+    dist = None
+    dist_info = {"world_size": 1, "backend": None}
+    if a.dry_run:
+        return dry_run(a, rank, world, backend)
+    import __graft_entry__ as graft
+    if a.lib:
+        from dronesim_amd import _native as nat0
+        nat0.load(a.lib)            # an A/B build of the same ABI: loaded first, so that everything below binds to it
     if rank == 0:
         graft.build()
-    dist = None
-    # rehearsal knob: DSIM_BENCH_BACKEND=gloo lets several ranks share one GPU (RCCL refuses that)
-    backend = os.environ.get("DSIM_BENCH_BACKEND", "nccl")
     local = local % max(1, torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
@@ -217,11 +310,18 @@ def main():
         else:
             dist.init_process_group(backend)
         dist.barrier()
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                     "devices_visible": torch.cuda.device_count()}
     if rank != 0:
         graft.build()       # no-op once rank 0 has built
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local)
+    from dronesim_amd import _native as nat
+    nat.load(a.lib)
+    options = {"auto": 0, "on": nat.OPT_STREAM_ON, "off": nat.OPT_STREAM_OFF}[a.stream]
+    options |= nat.OPT_GENERIC_MIXED if a.generic_mixed else 0
     barrier = (lambda: dist.barrier()) if dist else None
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     n_fleet, replicas = {"config2x1024": (4096, 1024), "config2": (4096, 1), "config3": (65536, 1), "config4": (4096, 16),
                          "config5": (65536, 1), "hexa": (4096, 1024), "mixed": (4096, 1024)}[a.workload]
@@ -230,46 +330,64 @@ def main():
     # (config5 only: one halo exchange of positions per step for the neighbour-downwash term)
     fl = Fleet(n_fleet, replicas, local, a.substeps, a.layout, sharding.rank_seed(a.noise_seed, rank),
                waypoints=a.workload == "config3", config5=a.workload == "config5",
-               dist=dist if a.workload == "config5" else None, rank=rank, hexa=a.workload == "hexa", mixed=a.workload == "mixed")
-    wall, dev_s = fl.timed(a.steps, a.warmup, barrier)
-    wall, dev_s = sharding.reduce_step_times(dist, "cuda" if backend == "nccl" else "cpu", wall, dev_s)  # MAX over ranks
-    value = sharding.aggregate_throughput([fl.n] * world, a.steps, wall)
-    launch_s = dev_s / a.steps
+               dist=dist if a.workload == "config5" else None, rank=rank, hexa=a.workload == "hexa",
+               mixed=a.workload == "mixed", options=options)
+
+    def repeat_rule(first_wall):
+        # the slowest rank's first region decides how many regions every rank runs
+        w, _ = sharding.reduce_step_times(dist, red_dev, first_wall, 0.0)
+        return max(1, int(np.ceil(MIN_TIMED_S / max(w, 1e-9))))
+
+    wall, dev_s, regions = fl.timed(a.steps, a.warmup, barrier, min_s=MIN_TIMED_S, repeat_rule=repeat_rule)
+    wall, dev_s = sharding.reduce_step_times(dist, red_dev, wall, dev_s)  # MAX over ranks
+    steps_timed = a.steps * regions
+    value = sharding.aggregate_throughput([fl.n] * world, steps_timed, wall)
+    launch_s = dev_s / steps_timed
     # config 5: half quads (232 B) half hexas (248 B) + 1 B type id + the 12 B downwash force the step kernel reads;
-    # its step is a chain of kernels (grid build, neighbour query, step, WLS fallback), timed as a whole
+    # its step is a chain of kernels (neighbour query, step + grid binning, WLS fallback), timed as a whole
     bytes_per = {"config5": 253, "hexa": 248, "mixed": 241}.get(a.workload, BYTES_PER_DRONE_STEP)
-    kernel = {"config5": "k_dw_count+scan+scatter+query, k_step_lean, k_wls_fallback",
+    kernel = {"config5": "k_dw_query_cell, k_step_mixed (+ fused k_dw_bin), k_wls_fallback",
               "hexa": "k_step_hexa (+ k_wls_fallback)",
               "mixed": "k_step_mixed (+ k_wls_fallback)"}.get(a.workload, "k_step_fast")
     achieved = fl.n * bytes_per / launch_s / 1e9
 
     if rank == 0:
-        traffic = None
+        traffic, traffic_source = None, None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             tj = json.load(open(tp))
             if tj.get("workload") == a.workload and tj.get("layout", "soa") == a.layout:
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = (f"{tj.get('source')}: FETCH_SIZE x2 + WRITE_SIZE of this kernel from SEPARATE rocprofv3 --pmc "
+                                  "passes of this command (tools/profile_gpu.sh), not measured in this run")
         out = {
             "metric": "drone-steps/sec (num_drones x env steps/s)", "value": value, "unit": "drone-steps/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall / steps_timed * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"config2x1024": "configs[1] 4096 robobee INDI hover x 1024 vectorised envs/GPU",
-                                    "config2": "configs[1] 4096 robobee INDI hover (single fleet)",
-                                    "config3": "65536 robobee, waypoint-table tracking (fly_INDI_TrajectoryTrack)",
-                                    "config4": "configs[3] shard: 65536 robobee INDI hover per GPU (524288 over 8 GPUs), no coupling",
-                                    "mixed": "even index robobee, odd index hexa_6DOF, 4096 x 1024 envs/GPU, no downwash",
-                                    "hexa": "4096 hexa_6DOF (6-DOF INDI + WLS) hover x 1024 vectorised envs/GPU",
-                                    "config5": "65536/GPU slab shard of 50% robobee + 50% hexa_6DOF, neighbour downwash on, "
-                                               "halo exchange of positions between neighbouring slabs"}[a.workload],
+            "steps_timed": steps_timed, "timed_regions": regions,
+            "timing_note": f"regions of exactly --steps steps, each bracketed by barrier + device synchronisation, repeated "
+                           f"until they cover {MIN_TIMED_S * 1e3:.0f} ms; value and ms_per_step are sums over all of them",
+            "config": {"workload": WORKLOAD_TEXT[a.workload],
                        "drones_per_gpu": fl.n, "phys_substeps": a.substeps, "layout": a.layout,
                        "noise_seed": a.noise_seed, "launches_per_step": 1, "parallelism": f"shard{world}"},
+            "dist": dist_info,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel, "bytes_per_drone_step": bytes_per,
                          "launch_us": launch_s * 1e6},
         }
         if world == 1 and not a.no_also:
+            # ---- BASELINE.json configs 1-3 at their LITERAL sizes and example settings --------------------------------
+            # (fleet, replicas, phys_substeps, waypoint table, Env.steps per launch)
+            base = {}
+            for name, spec in {
+                    "configs[1]_4096_robobee_hover_sub5": (4096, 1, 5, False, 1),
+                    "configs[1]_4096_robobee_hover_sub5_32_env_steps_per_launch": (4096, 1, 5, False, 32),
+                    "configs[2]_65536_robobee_waypoints_sub2": (65536, 1, 2, True, 1),
+                    "configs[2]_65536_robobee_waypoints_sub2_32_env_steps_per_launch": (65536, 1, 2, True, 32),
+                    "configs[3]_shard_65536_robobee_hover_sub1": (4096, 16, 1, False, 1)}.items():
+                base[name] = measure_variant(torch, local, a.layout, a.noise_seed, a.steps, name, *spec, options=options)
+            out["baseline_configs"] = base
             also = {}
             # yardstick: achievable copy bandwidth on this device (read + write bytes / time)
             src = torch.empty(1 << 28, dtype=torch.float32, device="cuda"); dst = torch.empty_like(src)
@@ -282,18 +400,14 @@ def main():
             e1.record(); torch.cuda.synchronize()
             also["device_copy_GBps"] = 2 * src.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
             del src, dst
-            # (fleet, replicas, phys_substeps, waypoint table, Env.steps per launch)
-            for name, (nf, rep, sub, wp, ns) in {
-                    "config2_single_fleet_4096_sub5": (4096, 1, 5, False, 1),
-                    "config2_single_fleet_4096_sub5_32steps_per_launch": (4096, 1, 5, False, 32),
+            for name, spec in {
                     "config2_single_fleet_4096_sub5_hipgraph_of_32_launches": (4096, 1, 5, False, 32),
-                    "config3_65536_waypoints_sub2": (65536, 1, 2, True, 1),
                     "config3_65536_waypoints_sub2_hipgraph_of_32_launches": (65536, 1, 2, True, 32),
-                    "config3_65536_waypoints_sub2_32steps_per_launch": (65536, 1, 2, True, 32),
-                    # configs[3]: one GPU's 65 536-drone shard of the 524 288-drone fleet (no coupling between shards)
-                    "config4_shard_65536_hover_sub1": (4096, 16, 1, False, 1),
                     "config2x1024_sub5": (4096, 1024, 5, False, 1),
+                    # configs[4] shard at the config's density (128 m slab), and the round-1 definition of the same
+                    # line (the 65 536 drones spread over the whole 1024 m box: an eighth of the density)
                     "config5_shard_65536_mixed_downwash": (65536, 1, 1, False, 1),
+                    "config5_lowdensity_r01_definition": (65536, 1, 1, False, 1),
                     # DSIM_OPT_CHAINED: the six controller-memory fields that are functions of the stored
                     # rigid state are neither read nor written: 184 B of real traffic per drone-step
                     "config2x1024_chained_184B": (4096, 1024, 1, False, 1),
@@ -303,49 +417,66 @@ def main():
                     "mixed_quad_hexa_4194304": (4096, 1024, 1, False, 1),
                     # the same fleet in type-major storage: one single-type launch per type
                     "mixed_quad_hexa_4194304_type_major": (4096, 1024, 1, False, 1)}.items():
-                f2 = Fleet(nf, rep, local, sub, a.layout, a.noise_seed, waypoints=wp, n_steps=ns,
-                           config5=name.startswith("config5"), chained="chained" in name,
-                           hexa=name.startswith("hexa"),
-                           mixed=("type_major" if "type_major" in name else name.startswith("mixed")))
-                if "hipgraph" in name:
-                    f2.n_steps = 1
-                    f2.use_graph(ns)
-                k2 = max(20, a.steps // 2)
-                w2, d2 = min(f2.timed(k2, 10), f2.timed(k2, 0))       # these timed regions are ~10 ms: best of two
-                also[name] = {"drone_steps_per_s": f2.n * k2 * ns / w2, "launch_us": d2 / k2 * 1e6,
-                              "env_steps_per_launch": ns}
-                if ns == 1:
-                    bts = 184 if "chained" in name else (248 if name.startswith("hexa") else
-                                                         (241 if name.startswith("mixed") else BYTES_PER_DRONE_STEP))
-                    also[name]["hbm_frac"] = f2.n * bts / (d2 / k2) / 1e9 / HBM_PEAK_GBPS
-                    also[name]["bytes_per_drone_step"] = bts
-                    if name.startswith("hexa"):
-                        also[name]["note"] = ("248 B is the budgeted figure (SURVEY 8d); the 6-DOF law never reads the target "
-                                              "acceleration and yaw, measured HBM traffic is 232 B per drone-step")
-                f2.env.close(); del f2
+                also[name] = measure_variant(torch, local, a.layout, a.noise_seed, a.steps, name, *spec, options=options)
+                if name.startswith("hexa"):
+                    also[name]["note"] = ("248 B is the budgeted figure (SURVEY 8d); the 6-DOF law never reads the target "
+                                          "acceleration and yaw, measured HBM traffic is 232 B per drone-step")
             # the reference-shaped loop at the same size: obs = env.step(cmd); cmd = ctrl.computeControlFromState(...)
-            # (three kernels + the [N,20] observation instead of the fused one: 480+ B per drone-step)
+            # (two launches: physics with the observation rows fused, control with the command handed back in place)
             from dronesim_amd.control import INDIControl
             from dronesim_amd.envs import CtrlAviary
             xyz = grid_fleet(4096, 1024)
             env = CtrlAviary(["robobee"], xyz.shape[0], initial_xyzs=xyz, aggregate_phy_steps=1, noise_seed=a.noise_seed,
-                             dict_io=False, layout=a.layout, device=local)
+                             dict_io=False, layout=a.layout, device=local, options=options)
             ctrl = INDIControl("robobee", env=env)
-            tp = torch.from_numpy(np.ascontiguousarray(xyz.T.astype(np.float32))).to(env.ctx.device)
+            tpos = torch.from_numpy(np.ascontiguousarray(xyz.T.astype(np.float32))).to(env.ctx.device)
             cmd = torch.full((xyz.shape[0], 4), 0.4, device=env.ctx.device)
-            for timed_pass in (False, True):
+            iters, el = 0, 0.0
+            for timed_pass in (False, True, True):
                 torch.cuda.synchronize(); t0 = time.perf_counter()
-                for _ in range(20):
+                for _ in range(50):
                     obs, _, _, _ = env.step(cmd)
-                    cmd, _, _ = ctrl.computeControlFromState(1 / 240, None, target_pos=tp, target_rpy=np.array([0, 0, 0.4]))
-                torch.cuda.synchronize(); el = time.perf_counter() - t0
-            also["config2x1024_env_step_then_computeControl"] = {"drone_steps_per_s": xyz.shape[0] * 20 / el,
-                                                                 "loop_us": el / 20 * 1e6}
+                    cmd, _, _ = ctrl.computeControlFromState(1 / 240, None, target_pos=tpos, target_rpy=np.array([0, 0, 0.4]))
+                torch.cuda.synchronize()
+                if timed_pass:
+                    el += time.perf_counter() - t0
+                    iters += 50
+            also["config2x1024_env_step_then_computeControl"] = {
+                "drone_steps_per_s": xyz.shape[0] * iters / el, "loop_us": el / iters * 1e6, "steps_timed": iters,
+                "bytes_per_drone_step": 428, "hbm_frac": xyz.shape[0] * 428 / (el / iters) / 1e9 / HBM_PEAK_GBPS,
+                "note": "physics 68 r + 148 w (13 rigid, 4 action | 13 rigid, 4 echo, 20-wide observation row); "
+                        "control 136 r + 76 w (13 + 11 + 10 | 11 memory, 4 cmd, 3 pos_e, yaw_e)"}
             env.close(); del env, ctrl
             out["also"] = also
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.substeps)
         print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def dry_run(a, rank, world, backend):
+    """The host logic of a run without a device: rendezvous (gloo), barriers, the timing reduction and the JSON line —
+    so that the launcher and the N-rank plumbing are testable where there is no GPU.  No kernel runs and no value is
+    reported (value = null, "dry_run": true); it is never a benchmark result."""
+    dist = None
+    dist_info = {"world_size": 1, "backend": None}
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        dist.barrier()
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend()}
+    from dronesim_amd import sharding
+    if dist:
+        dist.barrier()
+    wall = 1e-3 * (rank + 1)                 # synthetic and distinct per rank: the MAX reduction is observable
+    wall_max, _ = sharding.reduce_step_times(dist, "cpu", wall, 0.0)
+    if rank == 0:
+        print(json.dumps({"metric": "drone-steps/sec (num_drones x env steps/s)", "value": None, "unit": "drone-steps/s",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "dry_run": True, "scaling": "weak",
+                          "config": {"workload": WORKLOAD_TEXT[a.workload], "parallelism": f"shard{world}"},
+                          "dist": dist_info, "wall_max_over_ranks_s": wall_max, "rank0_wall_s": wall}))
     if dist:
         dist.barrier()
         dist.destroy_process_group()

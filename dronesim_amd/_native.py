@@ -16,12 +16,15 @@ LIB_PATH = os.path.join(_HERE, "libdronesim_amd.so")
 # every symbol include/dronesim_amd.h declares
 EXPORTS = (
     "dsim_abi_version", "dsim_strerror", "dsim_create", "dsim_destroy", "dsim_reset", "dsim_step",
-    "dsim_physics", "dsim_control", "dsim_step_adaptor", "dsim_traj_sample", "dsim_materialize", "dsim_counter_add", "dsim_reserve", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash", "dsim_downwash_workspace", "dsim_adjacency",
+    "dsim_physics", "dsim_control", "dsim_control2", "dsim_step_adaptor", "dsim_traj_sample", "dsim_materialize",
+    "dsim_counter_add", "dsim_reserve", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash",
+    "dsim_downwash_workspace", "dsim_downwash_prebin_ok", "dsim_adjacency",
 )
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NF_QUAD, NF_HEXA, NT = 24, 26, 10
 OPT_DRAG, OPT_GROUND, OPT_BCAST_TGT, OPT_CHAINED = 1, 2, 4, 8
+OPT_STREAM_ON, OPT_STREAM_OFF, OPT_GENERIC_MIXED = 16, 32, 64      # tuning knobs (results do not depend on them)
 ADAPT_VELOCITY, ADAPT_RPYT = 0, 1
 QUERY_WLS_FALLBACKS, QUERY_WLS_FAILURES = 0, 1
 
@@ -58,7 +61,9 @@ class StepArgs(ctypes.Structure):
         ("step_index_dev", ctypes.c_void_p),
         ("runs", ctypes.c_void_p),
         ("n_runs", ctypes.c_int32),
-        ("_pad_runs", ctypes.c_int32),
+        ("obs_width", ctypes.c_int32),
+        ("obs_out", ctypes.c_void_p),
+        ("bin_next", ctypes.c_void_p),
     ]
 
 
@@ -80,6 +85,8 @@ class DownwashArgs(ctypes.Structure):
         ("workspace_len", ctypes.c_int64),
         ("type_id", ctypes.c_void_p),
         ("local_offset", ctypes.c_int64),
+        ("prebinned", ctypes.c_int32),
+        ("_pad", ctypes.c_int32),
     ]
 
 
@@ -90,12 +97,13 @@ class DsimError(RuntimeError):
 _lib = None
 
 
-def load() -> ctypes.CDLL:
-    """Load the HIP extension; raises if it has not been built (``__graft_entry__.build()``)."""
+def load(path: str = None) -> ctypes.CDLL:
+    """Load the HIP extension; raises if it has not been built (``__graft_entry__.build()``).  ``path``: a
+    differently-tuned build of the same ABI (A/B runs); must be given on the first call."""
     global _lib
     if _lib is not None:
         return _lib
-    path = os.environ.get("DSIM_LIB", LIB_PATH)     # dev knob: A/B a differently-tuned build of the same ABI
+    path = path or LIB_PATH
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build the HIP extension first "
@@ -114,6 +122,8 @@ def load() -> ctypes.CDLL:
     lib.dsim_step.argtypes = [vp, vp, i64, View, View, ctypes.POINTER(StepArgs)]
     lib.dsim_physics.argtypes = [vp, vp, i64, View, vp, ctypes.POINTER(StepArgs)]  # (.., last_action_out, args)
     lib.dsim_control.argtypes = [vp, vp, i64, View, View, ctypes.POINTER(StepArgs), vp, vp]
+    lib.dsim_control2.argtypes = [vp, vp, i64, View, View, ctypes.POINTER(StepArgs), vp, vp, vp]
+    lib.dsim_downwash_prebin_ok.argtypes = [i64, i32, i32]
     lib.dsim_step_adaptor.argtypes = [vp, vp, i64, View, vp, i32, vp, ctypes.POINTER(StepArgs)]
     lib.dsim_traj_sample.argtypes = [vp, vp, i64, vp, vp, i32, vp, ctypes.c_double, vp, vp, View]
     lib.dsim_materialize.argtypes = [vp, vp, i64, View]

@@ -53,6 +53,9 @@ class BaseControl:
         self._targets = Targets(self.ctx, self.n, self.state.layout)
         self._pos_e = torch.zeros((3, self.state.n_pad), dtype=torch.float32, device=self.ctx.device)
         self._yaw_e = torch.zeros((self.state.n_pad,), dtype=torch.float32, device=self.ctx.device)
+        # the command as a plain SoA [n_act][n_pad] array, written by the control launch: its transposed view is what
+        # computeControl returns, and Env.step takes it back as the action without a copy
+        self._cmd = torch.zeros((self.ctx.n_act, self.state.n_pad), dtype=torch.float32, device=self.ctx.device)
         self.reset()
 
     def reset(self):
@@ -106,6 +109,11 @@ class INDIControl(BaseControl):
         is accepted and ignored, as in the reference (:404-410)."""
         self.control_counter += 1
         n, dev, st = self.n, self.ctx.device, self.state
+        if self.env is not None:
+            # the controller memory it is about to differentiate against must be the stored one: a chained
+            # step_fused() sequence leaves last_vel / last_rates stale until materialized
+            self.env.materialize()
+            self.env._chain_ok = False
         if cur_pos is not None:                       # explicit state (stand-alone use)
             st.set_fields(0, _as3(cur_pos, n, dev))
             q = torch.as_tensor(np.asarray(cur_quat) if not torch.is_tensor(cur_quat) else cur_quat,
@@ -129,7 +137,8 @@ class INDIControl(BaseControl):
         a.options, a.noise_seed, a.step_index = 0, 0, 0
         a.noise_replay, a.action = None, None
         a.type_id = self._type_id.data_ptr() if self._type_id is not None else None
-        nat.check(self.ctx.lib.dsim_control(self.ctx.handle, self.ctx.stream_ptr(), n, st.view(),
-                                            self._targets.view(), ctypes.byref(a), self._pos_e.data_ptr(),
-                                            self._yaw_e.data_ptr()))
-        return st.cmd.T, self._pos_e[:, :n].T, self._yaw_e[:n]
+        a.options = getattr(self.env, "_tuning", 0)
+        nat.check(self.ctx.lib.dsim_control2(self.ctx.handle, self.ctx.stream_ptr(), n, st.view(),
+                                             self._targets.view(), ctypes.byref(a), self._pos_e.data_ptr(),
+                                             self._yaw_e.data_ptr(), self._cmd.data_ptr()))
+        return self._cmd[:, :n].T, self._pos_e[:, :n].T, self._yaw_e[:n]

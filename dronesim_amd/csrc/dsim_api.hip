@@ -37,6 +37,10 @@ struct dsim_ctx {
   long long dw_cells;
   int dw_parity;
   int dw_mode;                            // 0: counting sort, 1: cell buckets (which layout the count buffers hold)
+  int n_cu;                               // compute units of the device
+  bool dw_prebin;                         // the count buffer dw_parity holds the local drones, binned by the last dsim_step
+  long long dw_prebin_n, dw_prebin_off;
+  float dw_prebin_geo[3];
   dsim_type_params h_types[DSIM_MAX_TYPES];
 };
 
@@ -61,6 +65,45 @@ __device__ __forceinline__ unsigned kv_lane(const KView& v, unsigned t) {
                       : (t >> v.shift) * (unsigned)v.block_stride + (t & (unsigned)v.mask);
 }
 
+// ---- neighbour grid, bucket form (downwash P8 / adjacency) ---------------------------------------------------------
+// Uniform xy grid of cells >= the 10 m cut-off; every cell owns a bucket of DW_CAP entries (x, y, z, world index),
+// entries that find their bucket full go to one shared overflow list that every receiver scans too, so results never
+// depend on the capacity.  The step kernels can fill the grid for the NEXT Env.step themselves (BinK in StepK): the
+// new position is in registers when the state is stored, which removes the binning launch from the step chain.
+#define DW_CAP 192
+struct BinK {
+  int* count;          // [ncells + 2]: entries per cell; count[ncells] = overflow length.  null = no binning
+  float4* buckets;     // [ncells][DW_CAP]
+  float4* overflow;    // [m]
+  float xmin, ymin, inv_cell;
+  int nx, ny;
+  long long local_offset;   // world index of local drone 0
+};
+__device__ __forceinline__ int bin_cell(const BinK& b, float x, float y) {
+  const int cx = min(max((int)floorf((x - b.xmin) * b.inv_cell), 0), b.nx - 1);
+  const int cy = min(max((int)floorf((y - b.ymin) * b.inv_cell), 0), b.ny - 1);
+  return cy * b.nx + cx;
+}
+__device__ __forceinline__ void bin_entry(const BinK& b, float x, float y, float z, long long world_index) {
+  const int c = bin_cell(b, x, y);
+  const float4 e = make_float4(x, y, z, __int_as_float((int)world_index));
+  const int slot = atomicAdd(&b.count[c], 1);
+  if (slot < DW_CAP) b.buckets[(long long)c * DW_CAP + slot] = e;
+  else b.overflow[atomicAdd(&b.count[b.nx * b.ny], 1)] = e;
+}
+
+// bucket form: grids of up to 16 384 cells with at most 2/3 DW_CAP = 128 entries per cell on average (BASELINE config 5:
+// one drone per m^2 = 100 per cell); the buckets take ncells * DW_CAP * 16 bytes of the workspace
+static inline bool dw_use_buckets(int64_t m, int64_t ncells) { return ncells <= 16384 && m <= ncells * (DW_CAP * 2 / 3); }
+// where the bucket form keeps things inside the workspace (ints): count x2 | 16-byte aligned buckets | overflow
+static inline void bucket_layout(int32_t* ws, long long ncells, int parity, BinK* b) {
+  const long long cstride = ncells + 2;
+  b->count = ws + (long long)parity * cstride;
+  uintptr_t sp = (uintptr_t)(ws + 2 * cstride);
+  b->buckets = (float4*)((sp + 15) & ~(uintptr_t)15);
+  b->overflow = b->buckets + ncells * DW_CAP;
+}
+
 struct StepK {
   KView st, tg;
   const DevType* types;
@@ -70,6 +113,9 @@ struct StepK {
   float* echo;                // physics kernel: clipped action out, or null
   float* pos_e_out;           // control kernel only
   float* yaw_e_out;
+  float* cmd_out;             // control kernel only: SoA [n_act][n_pad] copy of the new command, or null
+  float* obs_out;             // physics kernel: fused observation rows [n][obs_width], or null
+  long long n;                // drones (rows of obs_out)
   FbList fb;                  // deferred WLS fallbacks (hexa)
   long long n_pad;
   long long first;            // general step kernel: first drone of this launch
@@ -86,6 +132,7 @@ struct StepK {
   long long last;             // run kernels: one past the last drone of the run
   int run_type;               // run kernels: the run's type
   unsigned hexa_types;        // bit t set: type t of the table is a morphing hexa (26 state fields in use)
+  BinK bin;                   // grid of the next Env.step's downwash (k_step_mixed / k_step_run), count = null: none
 };
 
 // Global accesses.  NT = nontemporal (streaming) hint: each state field is read once and written
@@ -205,7 +252,12 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
     if (OPTS && (a.options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND))) {
       V3 F2 = F + ext, tau2 = tau;
       if (a.options & DSIM_OPT_GROUND) ground_effect_quad(T, s, cmd, F2, tau2);              // BaseAviary.py:528-529
-      if (a.options & DSIM_OPT_DRAG) F2 = F2 + drag_quad(T, s, (k == 0 && prev) ? prev : cmd);   // :531-532
+      if (a.options & DSIM_OPT_DRAG) {                                                        // :531-532
+        float lc[4];     // rotor speeds of the PREVIOUS action on sub-step 0 (values selected, not pointers: a pointer
+#pragma unroll           // select between two register arrays sends both to scratch)
+        for (int j = 0; j < 4; ++j) lc[j] = (k == 0 && prev) ? prev[j] : cmd[j];
+        F2 = F2 + drag_quad(T, s, lc);
+      }
       bullet_step(T, a.dt_phys, s, F2, tau2);
       continue;
     }
@@ -252,7 +304,10 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
 // compiled without that generality (it would cost the hot kernel registers: 128 + spills vs 121).
 // CH = DSIM_OPT_CHAINED: last_vel / last_rates are recomputed from the rigid state the previous step
 // stored (they are functions of it) instead of being read, and are not written: 184 B/drone-step.
-template <bool NOISE, bool NT, bool EXT, bool CH = false, int SUB = 0>
+// ACT = an explicit action for the physics part (dsim_step_args.action: the first iteration of the example loop,
+// or a caller that overrides the controller): four more loads, clipped as CtrlAviary._preprocessAction does; the
+// controller memory keeps its own cmd.  A template flag so that the plain form does not even test the pointer.
+template <bool NOISE, bool NT, bool EXT, bool CH = false, int SUB = 0, bool ACT = false>
 __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(StepK a) {
   const DevType& T = a.types[0];
   const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
@@ -272,7 +327,14 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
   float yaw_e;
   if (!EXT) {
     load_target<NT>(tb, tfs, tl, tg);
-    quad_substeps<NOISE ? 1 : 0, 4, false, SUB>(T, a, i, s, m.cmd, a.step_index);    // stored cmd is already clipped
+    if (ACT) {
+      float act[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) act[j] = clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]);   // CtrlAviary.py:258-263
+      quad_substeps<NOISE ? 1 : 0, 4, false, SUB>(T, a, i, s, act, a.step_index);
+    } else {
+      quad_substeps<NOISE ? 1 : 0, 4, false, SUB>(T, a, i, s, m.cmd, a.step_index);    // stored cmd is already clipped
+    }
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   } else {
     int wp = 0;
@@ -299,7 +361,7 @@ __global__ void k_counter_add(unsigned long long* c, unsigned long long inc) { *
 #ifndef DSIM_HEXA_WAVES
 #define DSIM_HEXA_WAVES 3
 #endif
-template <bool NOISE, bool NT, bool S1>
+template <bool NOISE, bool NT, bool S1, bool ACT = false>
 __global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
   const DevType& T = a.types[0];
   const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
@@ -317,7 +379,14 @@ __global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
   if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
   V3 pos_e;
   float yaw_e;
-  hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index);
+  if (ACT) {
+    float act[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) act[j] = clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]);
+    hexa_substeps<NOISE, false, S1>(T, a, i, s, act, a.step_index);
+  } else {
+    hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index);
+  }
   indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
   const unsigned so = pin_lane_offset(sl);
   store_rigid<NT>(sb, sfs, so, s);
@@ -455,8 +524,11 @@ __device__ __forceinline__ void step_gen_body(const DevType& T, const StepK& a, 
   store_rigid(ad.sb, ad.sfs, ad.sl, s);
   store_mem<NACT>(ad.sb, ad.sfs, ad.sl, m);
 }
+// The full-option body with the in-kernel noise holds both laws, the replay and waypoint paths and the add-on terms:
+// compiled for 2 waves/SIMD (256 VGPRs) it spills 200-380 B of scratch per lane, and the scratch traffic (2.8 x the
+// state's bytes) costs more than the lost occupancy; those instances take the whole register file instead.
 template <bool NOISE, bool UNIFORM, int NACT>
-__global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_step_gen(StepK a) {
+__global__ __launch_bounds__(256, NOISE ? 1 : DSIM_GEN_WAVES) void k_step_gen(StepK a) {
   const long long i0 = a.first + (long long)blockIdx.x * 256;
   const unsigned p = tile_slot<UNIFORM>(a.type_id, i0, a.n_pad);
   const long long i = i0 + p;
@@ -604,6 +676,8 @@ __global__ __launch_bounds__(64 * WT, DSIM_MIXED_WAVES) void k_step_mixed(StepK 
 #pragma unroll
     for (int f = 0; f < 24; ++f) stg<NT>(sb + f * sfs, so, stage[f][dest]);
     if (nat_hexa) { stg<NT>(sb + 24 * sfs, so, stage[24][dest]); stg<NT>(sb + 25 * sfs, so, stage[25][dest]); }
+    if (a.bin.count && i0 + t < a.n)                                          // the next step's neighbour grid
+      bin_entry(a.bin, stage[0][dest], stage[1][dest], stage[2][dest], a.bin.local_offset + i0 + t);
   }
 }
 
@@ -641,6 +715,7 @@ __global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void
   const unsigned so = pin_lane_offset(sl);
   store_rigid<NT>(sb, sfs, so, s);
   store_mem<NA, NT>(sb, sfs, so, m);
+  if (a.bin.count && i < a.n) bin_entry(a.bin, s.pos.x, s.pos.y, s.pos.z, a.bin.local_offset + i);   // next step's grid
 }
 
 // ---- Env.step only ---------------------------------------------------------
@@ -657,12 +732,10 @@ __device__ __forceinline__ void physics_gen_body(const DevType& T, const StepK& 
   if (NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA) {
     if constexpr (NACT == 6) hexa_substeps<NOISE>(T, a, i, s, cmd, a.step_index, ext);
   } else {
-    float prev[4];
-    if (a.echo) {
+    float prev[4];       // last_clipped_action of the previous step (drag of sub-step 0); this step's action without it
 #pragma unroll
-      for (int j = 0; j < 4; ++j) prev[j] = a.echo[(long long)j * a.n_pad + i];   // last_clipped_action of the previous step
-    }
-    quad_substeps<NOISE ? 2 : 0, NACT, true>(T, a, i, s, cmd, a.step_index, ext, a.echo ? prev : nullptr);
+    for (int j = 0; j < 4; ++j) prev[j] = a.echo ? a.echo[(long long)j * a.n_pad + i] : cmd[j];
+    quad_substeps<NOISE ? 2 : 0, NACT, true>(T, a, i, s, cmd, a.step_index, ext, prev);
   }
   store_rigid(ad.sb, ad.sfs, ad.sl, s);
   if (a.echo) {
@@ -705,6 +778,10 @@ __device__ __forceinline__ void control_gen_body(const DevType& T, const StepK& 
     a.pos_e_out[i] = pos_e.x; a.pos_e_out[a.n_pad + i] = pos_e.y; a.pos_e_out[2 * a.n_pad + i] = pos_e.z;
   }
   if (a.yaw_e_out) a.yaw_e_out[i] = yaw_e;
+  if (a.cmd_out) {
+#pragma unroll
+    for (int j = 0; j < NACT; ++j) a.cmd_out[(long long)j * a.n_pad + i] = m.cmd[j];
+  }
 }
 template <bool UNIFORM, int NACT>
 __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_control_gen(StepK a) {
@@ -714,6 +791,94 @@ __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_control_gen(StepK a) {
   if (i >= a.n_pad) return;
   const Addr ad = make_addr(a, i0, p);
   DSIM_FOR_MY_TYPE(UNIFORM, a, i, (control_gen_body<NACT>(T, a, i, ad)));
+}
+
+// ---- the reference-shaped two-call loop, fast forms ------------------------------------------------------------------
+// obs = env.step(action); action = ctrl.computeControlFromState(obs)  (examples/fly_INDI.py:223-239) is two entry
+// points here, dsim_physics and dsim_control.  For a homogeneous quad fleet in whole 256-drone tiles both have a fast
+// form with the fused kernel's addressing (scalar base + one lane offset, streaming accesses, no per-lane branches):
+//   k_physics_fast  reads 13 rigid + 4 action floats, writes 13 rigid + 4 echoed action floats and, fused (OBS), the
+//                   20-wide observation row of the NEW state (Env.step's return value, BaseAviary.py:547-555) —
+//                   transposed through LDS so that the row-major [n][20] block of the tile is written linearly;
+//   k_control_fast  reads 13 + 11 + 10, writes the 11 controller-memory floats (+ pos_e, yaw_e, and the command as a
+//                   plain SoA array that the next dsim_physics takes as its action without a copy).
+// 216 + 212 bytes per drone and iteration instead of the 480+ of physics_gen + observe + control_gen + copies.
+template <bool NOISE, bool NT, bool OBS>
+__global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_physics_fast(StepK a) {
+  constexpr int W = 20;
+  __shared__ float rows[OBS ? 256 * (W + 1) : 1];        // rows padded to W + 1 floats (bank spread)
+  const DevType& T = a.types[0];
+  const long long sfs = a.st.field_stride;
+  const unsigned sl = 4u * kv_lane(a.st, threadIdx.x);
+  const long long i0 = (long long)blockIdx.x * 256;
+  float* const sb = a.st.base + kv_off(a.st, i0);
+  const long long i = i0 + threadIdx.x;
+  Rigid s;
+  load_rigid<NT>(sb, sfs, sl, s);
+  float cmd[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float raw = a.action ? ldg<NT>(a.action + (long long)j * a.n_pad + i0, 4u * threadIdx.x) : ldg<NT>(sb + (20 + j) * sfs, sl);
+    cmd[j] = clampf(raw, T.pmin[j], T.pmax[j]);                                       // CtrlAviary.py:258-263
+  }
+  if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
+  quad_substeps<NOISE ? 1 : 0>(T, a, i, s, cmd, a.step_index);
+  const unsigned so = pin_lane_offset(sl);
+  store_rigid<NT>(sb, sfs, so, s);
+  if (a.echo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stg<NT>(a.echo + (long long)j * a.n_pad + i0, 4u * threadIdx.x, cmd[j]);   // BaseAviary.py:545
+  }
+  if (OBS) {
+    const Euler e = euler_from_quat<true>(s.q);                                        // BaseAviary.py:729
+    float* r = rows + threadIdx.x * (W + 1);
+    r[0] = s.pos.x; r[1] = s.pos.y; r[2] = s.pos.z;
+    r[3] = s.q.x; r[4] = s.q.y; r[5] = s.q.z; r[6] = s.q.w;
+    r[7] = e.roll; r[8] = e.pitch; r[9] = e.yaw;
+    r[10] = s.vel.x; r[11] = s.vel.y; r[12] = s.vel.z;
+    r[13] = s.w.x; r[14] = s.w.y; r[15] = s.w.z;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[16 + j] = cmd[j];
+    __syncthreads();
+    const long long left = a.n - i0;                       // rows of this tile that exist (the last tile may be ragged)
+    const int total = (int)(left < 256 ? left : 256) * W;
+    float* dst = a.obs_out + i0 * W;
+    for (int k = threadIdx.x; k < total; k += 256) {
+      const int rr = k / W, f = k - rr * W;
+      stg<NT>(dst, 4u * (unsigned)k, rows[rr * (W + 1) + f]);
+    }
+  }
+}
+
+template <bool NT, bool WANT_YAW>
+__global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_control_fast(StepK a) {
+  const DevType& T = a.types[0];
+  const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
+  const unsigned sl = 4u * kv_lane(a.st, threadIdx.x), tl = 4u * kv_lane(a.tg, threadIdx.x);
+  const long long i0 = (long long)blockIdx.x * 256;
+  float* const sb = a.st.base + kv_off(a.st, i0);
+  const float* const tb = a.tg.base + kv_off(a.tg, i0);
+  Rigid s;
+  CtrlMem<4> m;
+  Target tg;
+  load_rigid<NT>(sb, sfs, sl, s);
+  load_mem<4, NT>(sb, sfs, sl, m);
+  load_target<NT>(tb, tfs, tl, tg);
+  V3 pos_e;
+  float yaw_e = 0.0f;
+  indi_quad<WANT_YAW>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  const unsigned so = pin_lane_offset(sl);
+  store_mem<4, NT>(sb, sfs, so, m);
+  const unsigned lo = 4u * threadIdx.x;
+  if (a.cmd_out) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stg<NT>(a.cmd_out + (long long)j * a.n_pad + i0, lo, m.cmd[j]);
+  }
+  if (a.pos_e_out) {
+    stg<NT>(a.pos_e_out + i0, lo, pos_e.x); stg<NT>(a.pos_e_out + a.n_pad + i0, lo, pos_e.y);
+    stg<NT>(a.pos_e_out + 2 * a.n_pad + i0, lo, pos_e.z);
+  }
+  if (WANT_YAW) stg<NT>(a.yaw_e_out + i0, lo, yaw_e);
 }
 
 // ---- Env.step of the alternate action adaptors (VelocityAviary / RPYTAviary) --------------
@@ -760,11 +925,19 @@ __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_adaptor(StepK a) {
 }
 
 // ---- deferred WLS fallbacks (hexa) -----------------------------------------------
+// Launched behind every step of a fleet that holds a morphing hexa.  The queue is normally EMPTY: every workgroup
+// then leaves after one scalar load (no fence, no ticket — 1.5-2 us of kernel boundary instead of the 4.7 us the
+// unconditional fence-and-ticket epilogue of round 1 cost).  Otherwise the grid (sized for the chip by the host:
+// up to one 64-lane workgroup per CU, 144 KB of LDS each) strides over the queue, and the last workgroup to finish
+// empties it for the next step.
 struct FbK { KView st; const DevType* types; const uint8_t* type_id; FbList fb; };
-__global__ __launch_bounds__(64) void k_wls_fallback(FbK a) {
+#define DSIM_FB_LANES 64
+__global__ __launch_bounds__(DSIM_FB_LANES) void k_wls_fallback(FbK a) {
   const unsigned long long cnt = *a.fb.count;
-  for (unsigned long long e = (unsigned long long)blockIdx.x * 64 + threadIdx.x; e < cnt;
-       e += (unsigned long long)gridDim.x * 64) {
+  if (cnt == 0) return;                                   // wave-uniform: the queue length is final (previous kernel)
+  __shared__ WlsWork work[DSIM_FB_LANES];
+  for (unsigned long long e = (unsigned long long)blockIdx.x * DSIM_FB_LANES + threadIdx.x; e < cnt;
+       e += (unsigned long long)gridDim.x * DSIM_FB_LANES) {
     const FbEntry en = a.fb.entries[e];
     const long long i = en.drone;
     const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
@@ -772,7 +945,7 @@ __global__ __launch_bounds__(64) void k_wls_fallback(FbK a) {
     const long long fs = a.st.field_stride;
     float cmd[6], umin[6], umax[6], du[6];
     for (int j = 0; j < 6; ++j) { cmd[j] = p[(20 + j) * fs]; umin[j] = T.pmin[j] - cmd[j]; umax[j] = T.pmax[j] - cmd[j]; }
-    const int rc = wls_active_set(T, en.v, umin, umax, du);
+    const int rc = wls_active_set(T, en.v, umin, umax, du, work[threadIdx.x]);
     atomicAdd(&a.fb.counters[0], 1ULL);
     if (rc == 0) { for (int j = 0; j < 6; ++j) p[(20 + j) * fs] = clampf(cmd[j] + du[j], T.pmin[j], T.pmax[j]); }
     else atomicAdd(&a.fb.counters[1], 1ULL);   // the reference would raise here; cmd is left unchanged
@@ -995,24 +1168,15 @@ __global__ __launch_bounds__(256) void k_dw_scatter(DwK a) {
   const int slot = atomicAdd(&a.cursor[dw_cell(a, x, y, cx, cy)], 1);
   a.sorted[slot] = make_float4(x, y, z, __int_as_float((int)j));
 }
-// ---- bucket form of the grid (small worlds: a shard of tens of thousands of drones) ------------------------------
-// One Env.step of such a shard is a chain of launch-bound kernels; count + scan + scatter are replaced by ONE
-// binning kernel that appends every entry to its cell's fixed-capacity bucket, entries that find the bucket full go
-// to a shared overflow list which every receiver scans as well (normally empty), so the result never depends on
-// the capacity.  The host picks this form when the mean cell occupancy is at most DW_CAP / 2.
-#define DW_CAP 32
-__global__ __launch_bounds__(256) void k_dw_bin(DwK a) {
-  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int ncells = a.nx * a.ny;
-  if (j <= (long long)ncells + 1) a.count_next[j] = 0;          // the buffer the NEXT grid build will use
-  if (j >= a.m) return;
-  const float x = dw_pos(a, j, 0), y = dw_pos(a, j, 1), z = dw_pos(a, j, 2);
-  int cx, cy;
-  const int c = dw_cell(a, x, y, cx, cy);
-  const float4 e = make_float4(x, y, z, __int_as_float((int)j));
-  const int slot = atomicAdd(&a.count[c], 1);
-  if (slot < DW_CAP) a.buckets[(long long)c * DW_CAP + slot] = e;
-  else a.overflow[atomicAdd(&a.count[ncells], 1)] = e;
+// ---- bucket form of the grid: binning pass + cell-centred query ---------------------------------------------------
+// k_dw_bin appends the world entries [j0, j1) except [skip0, skip1) (the local drones, when the previous step kernel
+// has already binned them: BinK) to their cells' buckets.
+struct BinRange { long long j0, j1, skip0, skip1; };
+__global__ __launch_bounds__(256) void k_dw_bin(DwK a, BinK b, BinRange r) {
+  long long j = r.j0 + (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= r.skip0) j += r.skip1 - r.skip0;
+  if (j >= r.j1) return;
+  bin_entry(b, dw_pos(a, j, 0), dw_pos(a, j, 1), dw_pos(a, j, 2), j);
 }
 __device__ __forceinline__ float dw_pair(float4 p, float x, float y, float z, float pr, float d0, float d1, float d2c) {
   const float dz = p.z - z, dx = p.x - x, dy = p.y - y;
@@ -1022,36 +1186,94 @@ __device__ __forceinline__ float dw_pair(float4 p, float x, float y, float z, fl
   const float beta = d1 * dz + d2c;                             // :1754
   return -(d0 * r * r) * __expf(-0.5f * dd * DSIM_RCP(beta * beta));   // :1753, 1755
 }
-// DW_LPB lanes per LOCAL drone stride through the nine buckets around it and the overflow list.
-// (Measured and rejected: taking the receivers in bucket order — one group per bucket slot — so that the groups of
-// a wave read the same buckets: 41.5 vs 36 us per config-5 step; two thirds of the groups find an empty slot.)
-#ifndef DW_LPB
+// Cell-centred query.  One workgroup per (cell, chunk of 32 receivers of that cell): the nine buckets around the cell
+// are copied to LDS once (coalesced 16-byte rows), then DW_LPB lanes per receiver stride the LDS copy together — every
+// wave-instruction reads DW_LPB consecutive entries that its 8 receivers share (LDS broadcast, conflict-free) — and
+// reduce by shuffles.  At BASELINE config 5's density (one drone per m^2: ~100 per cell, ~900 candidates per receiver)
+// the candidates of a cell are read from L2 once per chunk instead of once per receiver.  Receivers that sit in the
+// overflow list are handled by the last DW_OVF_GROUPS workgroups straight from global memory.  The kernel also zeroes
+// the count buffer of the NEXT grid build (double-buffered: no memset on the stream).
 #define DW_LPB 8
-#endif
-__global__ __launch_bounds__(256) void k_dw_query_b(DwK a) {
-  const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long i = gt / DW_LPB;
-  const int sub = (int)(gt % DW_LPB);
-  if (i >= a.n) return;
-  const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
-  const float* sp = a.st.base + kv_off(a.st, i);
-  const float x = sp[0], y = sp[a.st.field_stride], z = sp[2 * a.st.field_stride];
-  const float pr = T.prop_radius, d0 = T.dw[0], d1 = T.dw[1], d2c = T.dw[2];
-  int cx, cy;
-  dw_cell(a, x, y, cx, cy);
-  float fz = 0.0f;
-  for (int yy = max(cy - 1, 0); yy <= min(cy + 1, a.ny - 1); ++yy)
-    for (int xx = max(cx - 1, 0); xx <= min(cx + 1, a.nx - 1); ++xx) {
-      const int c = yy * a.nx + xx;
-      const int cnt = min(a.count[c], DW_CAP);
-      const float4* __restrict__ b = a.buckets + (long long)c * DW_CAP;
-      for (int e = sub; e < cnt; e += DW_LPB) fz += dw_pair(b[e], x, y, z, pr, d0, d1, d2c);
+#define DW_RPB 32                      // receivers per workgroup
+#define DW_CHUNKS (DW_CAP / DW_RPB)
+#define DW_OVF_GROUPS 16
+__global__ __launch_bounds__(256) void k_dw_query_cell(DwK a, BinK b) {
+  __shared__ float4 tile[9 * DW_CAP];
+  const int ncells = b.nx * b.ny;
+  const unsigned t = threadIdx.x;
+  {
+    const long long gid = (long long)blockIdx.x * 256 + t;
+    if (gid < (long long)ncells + 2) a.count_next[gid] = 0;
+  }
+  const int sub = (int)(t % DW_LPB), r_in = (int)(t / DW_LPB);
+  const int n_ovf = b.count[ncells];
+  float4 me;
+  bool have = false;
+  int total = 0;
+  int cx = 0, cy = 0;
+  if ((int)blockIdx.x < ncells * DW_CHUNKS) {
+    const int c = (int)blockIdx.x / DW_CHUNKS, ch = (int)blockIdx.x % DW_CHUNKS;      // workgroup-uniform
+    const int cnt_c = min(b.count[c], DW_CAP);
+    if (ch * DW_RPB >= cnt_c) return;                                                  // no receivers in this chunk
+    cx = c % b.nx; cy = c / b.nx;
+    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, b.ny - 1); ++yy)
+      for (int xx = max(cx - 1, 0); xx <= min(cx + 1, b.nx - 1); ++xx) {
+        const int cc = yy * b.nx + xx;
+        const int cnt = min(b.count[cc], DW_CAP);                                      // scalar load
+        const float4* __restrict__ src = b.buckets + (long long)cc * DW_CAP;
+        for (int e = (int)t; e < cnt; e += 256) tile[total + e] = src[e];
+        total += cnt;
+      }
+    __syncthreads();
+    const int r = ch * DW_RPB + r_in;
+    if (r < cnt_c) { me = b.buckets[(long long)c * DW_CAP + r]; have = true; }
+  } else {
+    // receivers that overflowed their bucket: grid-stride over the overflow list, candidates from global memory
+    const int g = (int)blockIdx.x - ncells * DW_CHUNKS;
+    for (int r = g * DW_RPB + r_in; r < n_ovf; r += DW_OVF_GROUPS * DW_RPB) {
+      const float4 m2 = b.overflow[r];
+      const long long i = (long long)__float_as_int(m2.w) - a.local_offset;
+      if (i < 0 || i >= a.n) continue;
+      const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
+      const float pr = T.prop_radius, d0 = T.dw[0], d1 = T.dw[1], d2c = T.dw[2];
+      int ox, oy;
+      dw_cell(a, m2.x, m2.y, ox, oy);
+      float fz = 0.0f;
+      for (int yy = max(oy - 1, 0); yy <= min(oy + 1, b.ny - 1); ++yy)
+        for (int xx = max(ox - 1, 0); xx <= min(ox + 1, b.nx - 1); ++xx) {
+          const int cc = yy * b.nx + xx;
+          const int cnt = min(b.count[cc], DW_CAP);
+          const float4* __restrict__ src = b.buckets + (long long)cc * DW_CAP;
+          for (int e = sub; e < cnt; e += DW_LPB) fz += dw_pair(src[e], m2.x, m2.y, m2.z, pr, d0, d1, d2c);
+        }
+      for (int e = sub; e < n_ovf; e += DW_LPB) fz += dw_pair(b.overflow[e], m2.x, m2.y, m2.z, pr, d0, d1, d2c);
+#pragma unroll
+      for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
+      if (sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz; }
     }
-  const int n_ovf = a.count[a.nx * a.ny];
-  for (int e = sub; e < n_ovf; e += DW_LPB) fz += dw_pair(a.overflow[e], x, y, z, pr, d0, d1, d2c);
+    return;
+  }
+  long long i = -1;
+  if (have) {
+    i = (long long)__float_as_int(me.w) - a.local_offset;
+    if (i < 0 || i >= a.n) have = false;                                               // another rank's drone: a candidate only
+  }
+  float fz = 0.0f;
+  if (have) {
+    const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
+    const float pr = T.prop_radius, d0 = T.dw[0], d1 = T.dw[1], d2c = T.dw[2];
+    int e = sub;
+    for (; e + DW_LPB < total; e += 2 * DW_LPB) {                                      // two candidates in flight per lane
+      const float4 p0 = tile[e], p1 = tile[e + DW_LPB];
+      fz += dw_pair(p0, me.x, me.y, me.z, pr, d0, d1, d2c);
+      fz += dw_pair(p1, me.x, me.y, me.z, pr, d0, d1, d2c);
+    }
+    if (e < total) fz += dw_pair(tile[e], me.x, me.y, me.z, pr, d0, d1, d2c);
+    for (int k = sub; k < n_ovf; k += DW_LPB) fz += dw_pair(b.overflow[k], me.x, me.y, me.z, pr, d0, d1, d2c);
+  }
 #pragma unroll
   for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
-  if (sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz; }
+  if (have && sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz; }
 }
 
 // DW_LPR lanes per SORTED world entry; the entries that belong to this rank's shard are the
@@ -1217,6 +1439,9 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
   if (!c) return (int)hipErrorOutOfMemory;
   c->device = device; c->n_types = n_types; c->max_act = max_act; c->d_types = nullptr; c->d_counters = nullptr;
   c->d_fb = nullptr; c->fb_cap = 0; c->dw_ws = nullptr; c->dw_cells = 0; c->dw_parity = 0; c->dw_mode = 0;
+  c->n_cu = 256; c->dw_prebin = false; c->dw_prebin_n = 0; c->dw_prebin_off = 0;
+  c->dw_prebin_geo[0] = c->dw_prebin_geo[1] = c->dw_prebin_geo[2] = 0.0f;
+  { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->n_cu = v; }
   DevType h[DSIM_MAX_TYPES];
   for (int t = 0; t < n_types; ++t) { c->h_types[t] = types[t]; to_dev(types[t], &h[t]); }
   e = hipMalloc((void**)&c->d_types, sizeof(DevType) * n_types);
@@ -1253,6 +1478,16 @@ int dsim_query(dsim_ctx* ctx, void* stream, int32_t what, int64_t* value_out) {
 }
 
 static inline unsigned grid_for(long long n) { return (unsigned)((n + 255) / 256); }
+static int observe_impl(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
+                        float* obs_out, int32_t obs_width, int soa);
+
+// Streaming (nontemporal) accesses once one step's traffic exceeds what the 256 MB Infinity Cache can keep between
+// consecutive steps; DSIM_OPT_STREAM_ON / _OFF override (the library reads no environment variables).
+static inline bool stream_policy(const dsim_step_args* a, long long n_pad, double bytes_per_drone) {
+  if (a->options & DSIM_OPT_STREAM_ON) return true;
+  if (a->options & DSIM_OPT_STREAM_OFF) return false;
+  return (double)n_pad * bytes_per_drone > 192.0 * 1024 * 1024;
+}
 
 int dsim_reset(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* init_pos,
                const float* init_rpy, const float* init_vel, const float* init_cmd, const uint8_t* type_id) {
@@ -1287,6 +1522,7 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
   for (int t = 0; t < ctx->n_types; ++t) a->hexa_types |= (ctx->h_types[t].kind == DSIM_KIND_HEXA6DOF ? 1u : 0u) << t;
   a->types = ctx->d_types; a->type_id = args->type_id; a->noise_replay = args->noise_replay;
   a->action = args->action; a->echo = nullptr; a->pos_e_out = nullptr; a->yaw_e_out = nullptr;
+  a->cmd_out = nullptr; a->obs_out = nullptr; a->n = n;
   a->fb.entries = ctx->d_fb; a->fb.count = ctx->d_counters + 2; a->fb.counters = ctx->d_counters;
   a->n_pad = state.n_pad; a->first = 0; a->seed = args->noise_seed;
   a->wp_table = args->wp_table; a->wp_counter = args->wp_counter; a->wp_offset = args->wp_offset;
@@ -1296,7 +1532,29 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
   a->step_index = args->step_index;
   a->substeps = args->phys_substeps; a->dt_phys = args->dt_phys; a->dt_ctrl = args->dt_ctrl;
   a->options = args->options;
+  memset(&a->bin, 0, sizeof(a->bin));
+  a->last = a->n_pad; a->run_type = 0;
   return DSIM_OK;
+}
+
+// dsim_step_args.bin_next: the step kernel fills the bucket grid of the next dsim_downwash call.  Only when that grid
+// is the one the last dsim_downwash used (its spare count buffer is then known to be zero) and takes the bucket form.
+static void bin_next_prepare(dsim_ctx* ctx, int64_t n, const dsim_step_args* args, StepK* a) {
+  const dsim_downwash_args* g = args->bin_next;
+  if (!g || !g->workspace || g->nx < 1 || g->ny < 1 || !(g->cell > 0)) return;
+  const long long ncells = (long long)g->nx * g->ny;
+  if (!dw_use_buckets(g->m, ncells) || ctx->dw_ws != g->workspace || ctx->dw_cells != ncells || ctx->dw_mode != 1 ||
+      ctx->dw_prebin || g->local_offset < 0 || g->local_offset + n > g->m)
+    return;
+  bucket_layout(g->workspace, ncells, ctx->dw_parity, &a->bin);
+  a->bin.xmin = g->xmin; a->bin.ymin = g->ymin; a->bin.inv_cell = 1.0f / g->cell; a->bin.nx = g->nx; a->bin.ny = g->ny;
+  a->bin.local_offset = g->local_offset;
+}
+static void bin_next_commit(dsim_ctx* ctx, int64_t n, const dsim_step_args* args, const StepK& a) {
+  if (!a.bin.count) return;
+  ctx->dw_prebin = true; ctx->dw_prebin_n = n; ctx->dw_prebin_off = args->bin_next->local_offset;
+  ctx->dw_prebin_geo[0] = args->bin_next->xmin; ctx->dw_prebin_geo[1] = args->bin_next->ymin;
+  ctx->dw_prebin_geo[2] = args->bin_next->cell;
 }
 
 // The deferred-fallback queue is the one ctx-owned buffer that depends on the fleet size: it is
@@ -1319,7 +1577,10 @@ static void fb_finish(dsim_ctx* ctx, const StepK& a, hipStream_t st) {
   FbK f;
   f.st = a.st; f.types = a.types; f.type_id = a.type_id; f.fb = a.fb;
   f.fb.entries = ctx->d_fb;
-  hipLaunchKernelGGL(k_wls_fallback, dim3(32), dim3(64), 0, st, f);
+  // one workgroup per 64 possible entries, at most one per CU (each holds 144 KB of LDS): a start-up transient that
+  // queues a large part of a big fleet is worked off by the whole chip, an empty queue costs one scalar load per group
+  const long long groups = (a.n_pad + DSIM_FB_LANES - 1) / DSIM_FB_LANES;
+  hipLaunchKernelGGL(k_wls_fallback, dim3((unsigned)(groups < ctx->n_cu ? groups : ctx->n_cu)), dim3(DSIM_FB_LANES), 0, st, f);
 }
 
 // (noise, uniform) x actuator count dispatch of a general kernel
@@ -1354,14 +1615,24 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   if ((args->options & DSIM_OPT_CHAINED) && (!uni || six || args->action || args->noise_replay || args->ext_force ||
                                              phys_opts || (state.n_pad % 256)))
     return DSIM_E_UNSUPPORTED;                          // chained stepping is a fast-path-only mode
-  if (args->runs && args->n_runs > 0 && !args->action && !args->noise_replay && !a.wp_table && a.n_steps == 1 &&
-      !phys_opts && a.tg.base && !(args->options & DSIM_OPT_CHAINED)) {
+  const bool plain = !args->action && !args->noise_replay && !a.wp_table && a.n_steps == 1 && !phys_opts && a.tg.base &&
+                     !(args->options & DSIM_OPT_CHAINED);
+  const dsim_type_run* runs = args->runs;
+  int n_runs = args->n_runs;
+  dsim_type_run whole;
+  if (!(runs && n_runs > 0) && uni && plain && args->ext_force) {
+    // a homogeneous fleet with an external (downwash) force: ONE run of its only type — the single-type kernel with
+    // the force input and the fused neighbour-grid binning, instead of the general kernel
+    whole.first = 0; whole.count = a.n_pad; whole.type = 0; whole._pad = 0;
+    runs = &whole; n_runs = 1;
+  }
+  if (runs && n_runs > 0 && plain) {
     // type-major storage: one single-type launch per run
-    static const char* nt_env = getenv("DSIM_NT");
-    const bool nt = nt_env ? atoi(nt_env) != 0 : (double)state.n_pad * 240.0 > 192.0 * 1024 * 1024;
+    const bool nt = stream_policy(args, state.n_pad, 240.0);
     bool any_hexa = false;
-    for (int r = 0; r < args->n_runs; ++r) {
-      const dsim_type_run& run = args->runs[r];
+    bin_next_prepare(ctx, n, args, &a);
+    for (int r = 0; r < n_runs; ++r) {
+      const dsim_type_run& run = runs[r];
       if (run.first < 0 || run.count < 0 || (run.first % 256) || run.first + run.count > a.n_pad || run.type < 0 ||
           run.type >= ctx->n_types)
         return DSIM_E_ARG;
@@ -1378,8 +1649,8 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
        else { if (nt) hipLaunchKernelGGL((k_step_run<H_, false, true, S_>), g, b, 0, st_, a);         \
               else hipLaunchKernelGGL((k_step_run<H_, false, false, S_>), g, b, 0, st_, a); } } while (0)
 #define DSIM_RUN_CASE(H_) do { if (a.substeps == 1) DSIM_RUN_CASE2(H_, true); else DSIM_RUN_CASE2(H_, false); } while (0)
-    for (int r = 0; r < args->n_runs; ++r) {
-      const dsim_type_run& run = args->runs[r];
+    for (int r = 0; r < n_runs; ++r) {
+      const dsim_type_run& run = runs[r];
       if (run.count == 0) continue;
       a.first = run.first; a.last = run.first + run.count; a.run_type = run.type;
       const dim3 g(grid_for(run.count));
@@ -1388,23 +1659,24 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
 #undef DSIM_RUN_CASE
 #undef DSIM_RUN_CASE2
     if (any_hexa) fb_finish(ctx, a, st_);
+    bin_next_commit(ctx, n, args, a);
     return (int)hipGetLastError();
   }
-  if (uni && !six && !args->action && !args->noise_replay && !args->ext_force && !phys_opts) {
-    // fast path over the whole 256-drone tiles.  Streaming (nontemporal) accesses once the fleet's
-    // per-step traffic exceeds what the 256 MB Infinity Cache can keep between consecutive steps
-    // (tuning knob for A/B runs: DSIM_NT = 0|1).
-    static const char* nt_env = getenv("DSIM_NT");
-    const bool nt = nt_env ? atoi(nt_env) != 0 : (double)state.n_pad * 232.0 > 192.0 * 1024 * 1024;
+  const bool multi = a.wp_table != nullptr || a.n_steps > 1;
+  if (uni && !six && !(args->action && multi) && !args->noise_replay && !args->ext_force && !phys_opts) {
+    // fast path over the whole 256-drone tiles (an explicit action: the ACT instances of the plain form)
+    const bool nt = stream_policy(args, state.n_pad, 232.0);
     const long long tiles = a.n_pad / 256;
     if (tiles > 0) {
       const dim3 g((unsigned)tiles);
-      const bool ext = a.wp_table != nullptr || a.n_steps > 1;
+      const bool ext = multi;
       const bool ch = (args->options & DSIM_OPT_CHAINED) != 0;
 #define DSIM_FAST_CASE(N_, T_)                                                                      \
   do { if (ext) { if (ch) hipLaunchKernelGGL((k_step_fast<N_, T_, true, true>), g, b, 0, st_, a);   \
                   else hipLaunchKernelGGL((k_step_fast<N_, T_, true, false>), g, b, 0, st_, a); }   \
-       else { if (ch && a.substeps == 1) hipLaunchKernelGGL((k_step_fast<N_, T_, false, true, 1>), g, b, 0, st_, a); \
+       else { if (args->action) { if (a.substeps == 1) hipLaunchKernelGGL((k_step_fast<N_, T_, false, false, 1, true>), g, b, 0, st_, a); \
+                                  else hipLaunchKernelGGL((k_step_fast<N_, T_, false, false, 0, true>), g, b, 0, st_, a); } \
+              else if (ch && a.substeps == 1) hipLaunchKernelGGL((k_step_fast<N_, T_, false, true, 1>), g, b, 0, st_, a); \
               else if (ch) hipLaunchKernelGGL((k_step_fast<N_, T_, false, true>), g, b, 0, st_, a); \
               else if (a.substeps == 1) hipLaunchKernelGGL((k_step_fast<N_, T_, false, false, 1>), g, b, 0, st_, a); \
               else hipLaunchKernelGGL((k_step_fast<N_, T_, false, false>), g, b, 0, st_, a); } } while (0)
@@ -1415,23 +1687,24 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     }
   }
   bool fb_open = false;
-  if (uni && six && ctx->h_types[0].kind == DSIM_KIND_HEXA6DOF && !args->action && !args->noise_replay && !args->ext_force &&
+  if (uni && six && ctx->h_types[0].kind == DSIM_KIND_HEXA6DOF && !args->noise_replay && !args->ext_force &&
       !a.wp_table && a.n_steps == 1 && a.n_pad >= 256) {
     const long long tiles = a.n_pad / 256;
-    static const char* nt_env = getenv("DSIM_NT");
-    const bool nt = nt_env ? atoi(nt_env) != 0 : (double)state.n_pad * 248.0 > 192.0 * 1024 * 1024;
+    const bool nt = stream_policy(args, state.n_pad, 248.0);
     rc = fb_prepare(ctx, a.n_pad, st_);
     if (rc) return rc;
     a.fb.entries = ctx->d_fb;
     fb_open = true;
     const dim3 g((unsigned)tiles);
-#define DSIM_HEXA_CASE(S_)                                                                          \
-  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_hexa<true, true, S_>), g, b, 0, st_, a);      \
-                    else hipLaunchKernelGGL((k_step_hexa<true, false, S_>), g, b, 0, st_, a); }      \
-       else { if (nt) hipLaunchKernelGGL((k_step_hexa<false, true, S_>), g, b, 0, st_, a);           \
-              else hipLaunchKernelGGL((k_step_hexa<false, false, S_>), g, b, 0, st_, a); } } while (0)
+#define DSIM_HEXA_CASE2(S_, A_)                                                                     \
+  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_hexa<true, true, S_, A_>), g, b, 0, st_, a);  \
+                    else hipLaunchKernelGGL((k_step_hexa<true, false, S_, A_>), g, b, 0, st_, a); }  \
+       else { if (nt) hipLaunchKernelGGL((k_step_hexa<false, true, S_, A_>), g, b, 0, st_, a);       \
+              else hipLaunchKernelGGL((k_step_hexa<false, false, S_, A_>), g, b, 0, st_, a); } } while (0)
+#define DSIM_HEXA_CASE(S_) do { if (args->action) DSIM_HEXA_CASE2(S_, true); else DSIM_HEXA_CASE2(S_, false); } while (0)
     if (a.substeps == 1) DSIM_HEXA_CASE(true); else DSIM_HEXA_CASE(false);
 #undef DSIM_HEXA_CASE
+#undef DSIM_HEXA_CASE2
     first = tiles * 256;
     if (first >= a.n_pad) fb_finish(ctx, a, st_);
   }
@@ -1439,10 +1712,8 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     a.first = first;
     const dim3 g(grid_for(a.n_pad - first));
     const bool lean = !args->action && !args->noise_replay && !a.wp_table && a.n_steps == 1 && !phys_opts;
-    static const char* typed_env = getenv("DSIM_TYPED");      // A/B knob: 0 = the general mixed-law kernel
-    if (lean && !uni && a.tg.base && ctx->n_types <= 4 && !(typed_env && atoi(typed_env) == 0)) {
-      static const char* nt_env = getenv("DSIM_NT");
-      const bool nt = nt_env ? atoi(nt_env) != 0 : (double)state.n_pad * 240.0 > 192.0 * 1024 * 1024;
+    if (lean && !uni && a.tg.base && ctx->n_types <= 4 && !(args->options & DSIM_OPT_GENERIC_MIXED)) {
+      const bool nt = stream_policy(args, state.n_pad, 240.0);
       bool any_hexa = false;
       for (int t = 0; t < ctx->n_types; ++t) any_hexa |= ctx->h_types[t].kind == DSIM_KIND_HEXA6DOF;
       if (any_hexa && !fb_open) {
@@ -1450,6 +1721,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
         if (rc) return rc;
         a.fb.entries = ctx->d_fb;
       }
+      if (first == 0) bin_next_prepare(ctx, n, args, &a);      // (the whole fleet goes through this kernel)
 #define DSIM_MIXED_CASE2(W_, S_)                                                                                  \
   do { const dim3 gm((unsigned)((a.n_pad - first + 127) / 128)), bm(64 * W_);                                    \
        if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed<true, true, W_, S_>), gm, bm, 0, st_, a);            \
@@ -1461,6 +1733,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
 #undef DSIM_MIXED_CASE
 #undef DSIM_MIXED_CASE2
       if (any_hexa) fb_finish(ctx, a, st_);
+      bin_next_commit(ctx, n, args, a);
     } else if (!six) {
       if (lean) DSIM_LAUNCH_GEN(k_step_lean, noise, uni, false, g, a, st_);
       else DSIM_LAUNCH_GEN(k_step_gen, noise, uni, false, g, a, st_);
@@ -1515,10 +1788,29 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
   int rc = fill_stepk(ctx, n, state, nullptr, args, &a);
   if (rc) return rc;
   a.echo = last_action_out;
-  if ((args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)) && ctx->max_act == 6) return DSIM_E_UNSUPPORTED;
+  const bool phys_opts = (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)) != 0;
+  if (phys_opts && ctx->max_act == 6) return DSIM_E_UNSUPPORTED;
+  const int obs_w = 16 + ctx->max_act;
+  if (args->obs_out && args->obs_width != obs_w) return DSIM_E_ARG;
   const bool noise = args->noise_seed != 0 || args->noise_replay != nullptr;
+  const hipStream_t st_ = (hipStream_t)stream;
+  if (args->type_id == nullptr && ctx->max_act == 4 && !args->noise_replay && !args->ext_force && !phys_opts &&
+      (a.n_pad % 256) == 0) {
+    // homogeneous quad fleet in whole tiles: the fast form, observation fused
+    a.obs_out = args->obs_out;
+    const bool nt = stream_policy(args, state.n_pad, args->obs_out ? 216.0 : 136.0);
+    const dim3 g((unsigned)(a.n_pad / 256)), b(256);
+#define DSIM_PHYS_CASE(N_, T_) do { if (a.obs_out) hipLaunchKernelGGL((k_physics_fast<N_, T_, true>), g, b, 0, st_, a);   \
+                                    else hipLaunchKernelGGL((k_physics_fast<N_, T_, false>), g, b, 0, st_, a); } while (0)
+    if (noise) { if (nt) DSIM_PHYS_CASE(true, true); else DSIM_PHYS_CASE(true, false); }
+    else { if (nt) DSIM_PHYS_CASE(false, true); else DSIM_PHYS_CASE(false, false); }
+#undef DSIM_PHYS_CASE
+    return (int)hipGetLastError();
+  }
   const dim3 g(grid_for(a.n_pad));
-  DSIM_LAUNCH_GEN(k_physics_gen, noise, args->type_id == nullptr, ctx->max_act == 6, g, a, (hipStream_t)stream);
+  DSIM_LAUNCH_GEN(k_physics_gen, noise, args->type_id == nullptr, ctx->max_act == 6, g, a, st_);
+  if (args->obs_out)       // general fleets: the same rows by the observation kernel, behind the step on the stream
+    return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, obs_w, 0);
   return (int)hipGetLastError();
 }
 
@@ -1546,14 +1838,28 @@ int dsim_step_adaptor(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, c
 
 int dsim_control(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
                  const dsim_step_args* args, float* pos_e_out, float* yaw_e_out) {
+  return dsim_control2(ctx, stream, n, state, targets, args, pos_e_out, yaw_e_out, nullptr);
+}
+
+int dsim_control2(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
+                  const dsim_step_args* args, float* pos_e_out, float* yaw_e_out, float* cmd_out) {
   StepK a;
   if (args && args->wp_table) return DSIM_E_UNSUPPORTED;   // computeControl takes explicit targets
   int rc = fill_stepk(ctx, n, state, &targets, args, &a);
   if (rc) return rc;
-  a.pos_e_out = pos_e_out; a.yaw_e_out = yaw_e_out;
+  a.pos_e_out = pos_e_out; a.yaw_e_out = yaw_e_out; a.cmd_out = cmd_out;
   const dim3 g(grid_for(a.n_pad)), b(256);
   const hipStream_t st_ = (hipStream_t)stream;
   const bool uni = args->type_id == nullptr;
+  if (uni && ctx->max_act == 4 && (a.n_pad % 256) == 0 && a.tg.base) {
+    const bool nt = stream_policy(args, state.n_pad, 212.0);
+    const dim3 gt((unsigned)(a.n_pad / 256));
+    if (yaw_e_out) { if (nt) hipLaunchKernelGGL((k_control_fast<true, true>), gt, b, 0, st_, a);
+                     else hipLaunchKernelGGL((k_control_fast<false, true>), gt, b, 0, st_, a); }
+    else { if (nt) hipLaunchKernelGGL((k_control_fast<true, false>), gt, b, 0, st_, a);
+           else hipLaunchKernelGGL((k_control_fast<false, false>), gt, b, 0, st_, a); }
+    return (int)hipGetLastError();
+  }
   if (ctx->max_act == 6) {
     rc = fb_prepare(ctx, a.n_pad, st_);
     if (rc) return rc;
@@ -1567,8 +1873,6 @@ int dsim_control(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_v
   return (int)hipGetLastError();
 }
 
-static int observe_impl(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
-                        float* obs_out, int32_t obs_width, int soa);
 int dsim_observe(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
                  float* obs_out, int32_t obs_width) {
   return observe_impl(ctx, stream, n, state, last_action, obs_out, obs_width, 0);
@@ -1602,8 +1906,9 @@ int dsim_traj_sample(dsim_ctx* ctx, void* stream, int64_t n, const double* coeff
   return (int)hipGetLastError();
 }
 
-// bucket form: small grids with at most DW_CAP / 2 entries per cell on average
-static inline bool dw_use_buckets(int64_t m, int64_t ncells) { return ncells <= 65536 && m <= ncells * (DW_CAP / 2); }
+int dsim_downwash_prebin_ok(int64_t m, int32_t nx, int32_t ny) {
+  return (m > 0 && nx > 0 && ny > 0 && dw_use_buckets(m, (int64_t)nx * ny)) ? 1 : 0;
+}
 
 int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny) {
   if (m < 0 || nx < 1 || ny < 1) return -1;
@@ -1625,7 +1930,14 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
   int rc = grid_build(ctx, st_, n, state, g, 10.0f, &a, true);
   if (rc) return rc;
   a.force_out = force_out;
-  if (a.buckets) hipLaunchKernelGGL(k_dw_query_b, dim3(grid_for(a.n * DW_LPB)), dim3(256), 0, st_, a);
+  if (a.buckets) {
+    BinK b;
+    memset(&b, 0, sizeof(b));
+    b.count = a.count; b.buckets = a.buckets; b.overflow = a.overflow;
+    b.xmin = a.xmin; b.ymin = a.ymin; b.inv_cell = a.inv_cell; b.nx = a.nx; b.ny = a.ny; b.local_offset = a.local_offset;
+    const long long ncells = (long long)a.nx * a.ny;
+    hipLaunchKernelGGL(k_dw_query_cell, dim3((unsigned)(ncells * DW_CHUNKS + DW_OVF_GROUPS)), dim3(256), 0, st_, a, b);
+  }
   else hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m * DW_LPR)), dim3(256), 0, st_, a);
   return (int)hipGetLastError();
 }
@@ -1674,11 +1986,26 @@ static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view
     ctx->dw_ws = g->workspace; ctx->dw_cells = ncells; ctx->dw_mode = buckets ? 1 : 0;
   }
   ctx->dw_parity = 1 - cur;
+  // local entries already binned by the previous dsim_step (dsim_step_args.bin_next) into THIS count buffer?
+  const bool pre_live = same && buckets && ctx->dw_prebin;
+  const bool pre = pre_live && g->prebinned && ctx->dw_prebin_n == n && ctx->dw_prebin_off == g->local_offset &&
+                   ctx->dw_prebin_geo[0] == g->xmin && ctx->dw_prebin_geo[1] == g->ymin && ctx->dw_prebin_geo[2] == g->cell;
+  ctx->dw_prebin = false;
   if (buckets) {
-    uintptr_t sp = (uintptr_t)(g->workspace + 2 * cstride);
-    a.buckets = (float4*)((sp + 15) & ~(uintptr_t)15);
-    a.overflow = a.buckets + ncells * DW_CAP;
-    hipLaunchKernelGGL(k_dw_bin, dim3(grid_for(a.m > ncells + 2 ? a.m : ncells + 2)), dim3(256), 0, st_, a);
+    BinK b;
+    memset(&b, 0, sizeof(b));
+    bucket_layout(g->workspace, ncells, cur, &b);
+    b.xmin = a.xmin; b.ymin = a.ymin; b.inv_cell = a.inv_cell; b.nx = a.nx; b.ny = a.ny; b.local_offset = a.local_offset;
+    a.buckets = b.buckets; a.overflow = b.overflow;
+    if (pre_live && !pre) {          // a step binned into this buffer but the caller does not vouch for it: start over
+      hipError_t e = hipMemsetAsync(a.count, 0, sizeof(int) * cstride, st_);
+      if (e != hipSuccess) return (int)e;
+    }
+    BinRange r;
+    r.j0 = 0; r.j1 = a.m; r.skip0 = r.skip1 = a.m;
+    long long todo = a.m;
+    if (pre) { r.skip0 = a.local_offset; r.skip1 = a.local_offset + n; todo = a.m - n; }
+    if (todo > 0) hipLaunchKernelGGL(k_dw_bin, dim3(grid_for(todo)), dim3(256), 0, st_, a, b, r);
     a_ = a;
     return DSIM_OK;
   }

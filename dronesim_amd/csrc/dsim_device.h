@@ -129,21 +129,40 @@ __device__ __forceinline__ float norm_ang(float x) {
 }
 
 // ---------------------------------------------------------------------------
-// rotor noise: Philox4x32-10 + Box-Muller (definition mirrored by
+// rotor noise: Threefry4x32-12 + Box-Muller (definition mirrored by
 // oracle/dsim_oracle.c:orc_noise_normals; the reference's own draws come from
 // the unseeded global numpy RNG, BaseAviary.py:1518-1525, and cannot be replayed)
+//
+// Counter-based: block = Threefry4x32-12(key = seed, counter = (drone, sub-step)).  Threefry (Salmon et al.,
+// "Parallel random numbers: as easy as 1, 2, 3", SC'11; 12 rounds = the Crush-resistant form with margin) is
+// add / rotate / xor only — ~85 full-rate vector instructions per block.  The round-1 generator, Philox4x32-10,
+// needs 40 32-bit multiplies (v_mul_hi_u32 / v_mul_lo_u32, quarter rate on CDNA) and made the 5-sub-step kernel
+// VALU-bound on the noise alone.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return __builtin_rotateleft32(x, (uint32_t)r); }
+__device__ __forceinline__ void threefry4x32_12(uint32_t x[4], uint32_t k0, uint32_t k1) {
+  // key words 2, 3 are zero; ks[4] = parity constant ^ all key words
+  const uint32_t ks[5] = {k0, k1, 0u, 0u, 0x1BD11BDAu ^ k0 ^ k1};
+  x[0] += ks[0]; x[1] += ks[1]; x[2] += ks[2]; x[3] += ks[3];
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
-    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  for (int r = 0; r < 12; ++r) {
+    // rotation constants R_32x4 of Threefry4x32, period 8
+    constexpr int R0[8] = {10, 11, 13, 23, 6, 17, 25, 18};
+    constexpr int R1[8] = {26, 21, 27, 5, 20, 11, 10, 20};
+    if ((r & 1) == 0) {
+      x[0] += x[1]; x[1] = rotl32(x[1], R0[r & 7]) ^ x[0];
+      x[2] += x[3]; x[3] = rotl32(x[3], R1[r & 7]) ^ x[2];
+    } else {
+      x[0] += x[3]; x[3] = rotl32(x[3], R0[r & 7]) ^ x[0];
+      x[2] += x[1]; x[1] = rotl32(x[1], R1[r & 7]) ^ x[2];
+    }
+    if ((r & 3) == 3) {                       // key injection after every 4th round
+      const int s = r / 4 + 1;
+      x[0] += ks[s % 5]; x[1] += ks[(s + 1) % 5]; x[2] += ks[(s + 2) % 5]; x[3] += ks[(s + 3) % 5] + (uint32_t)s;
+    }
   }
 }
-// One 32-bit Philox word -> two unit normals (Box-Muller): radius from the high 16 bits
+// One 32-bit word -> two unit normals (Box-Muller): radius from the high 16 bits
 // (u1 = (h+1)/65536 in (0,1], so |n| <= sqrt(2 ln 65536) = 4.71 sigma), angle from the low 16.
 // The hardware transcendentals take the angle in revolutions and log in base 2.
 __device__ __forceinline__ void box_muller16(uint32_t w, float& n0, float& n1) {
@@ -154,7 +173,7 @@ __device__ __forceinline__ void box_muller16(uint32_t w, float& n0, float& n1) {
   n1 = r * __builtin_amdgcn_sinf(u2);
 }
 // unit normals for (drone, sub-step counter): out[0..n_act) force noise, out[n_act..2 n_act) moment
-// noise.  One Philox4x32-10 block yields 8 normals (a quad's whole sub-step), a hexa needs two.
+// noise.  One Threefry4x32-12 block yields 8 normals (a quad's whole sub-step), a hexa needs two.
 template <int NACT>
 __device__ __forceinline__ void noise_normals(uint64_t seed, uint64_t drone, uint64_t sub, float* out) {
   constexpr int NSTREAM = (2 * NACT + 7) / 8;
@@ -162,7 +181,7 @@ __device__ __forceinline__ void noise_normals(uint64_t seed, uint64_t drone, uin
   for (int s = 0; s < NSTREAM; ++s) {
     uint32_t c[4] = {(uint32_t)drone, (uint32_t)(drone >> 32) ^ ((uint32_t)s << 24), (uint32_t)sub,
                      (uint32_t)(sub >> 32)};
-    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    threefry4x32_12(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     float n[8];
 #pragma unroll
     for (int w = 0; w < 4; ++w) box_muller16(c[w], n[2 * w], n[2 * w + 1]);
@@ -392,13 +411,20 @@ struct FbList { FbEntry* entries; unsigned long long* count; unsigned long long*
 // the rare drones whose first-iteration solution leaves the +-1.0-slackened box.  fp64: the rows
 // of A are scaled by gamma*Wv up to 1e8.  lstsq by Householder QR (A_free always contains the
 // identity rows, so it has full column rank).  Returns 0 ok, -1 "solution failed" (:350), -2 where
-// the reference would raise.  Kept out of line: it runs on a handful of lanes.
+// the reference would raise.  The loop indexes its matrices and index sets dynamically (free set, pivots), so the
+// working set lives in LDS (WlsWork, one per lane of k_wls_fallback) — in registers it would be 2 KB of scratch.
+struct WlsWork {
+  double A[12][6], Af[12][6], Q[12][6], d[12], rhs[12], u[6], u_opt[6], p[6], p_free[6], W[6], Lambda[6];
+  int free_index[6], lookup[6];
+};
 __device__ __forceinline__ int wls_active_set(const DevType& T, const float v[6], const float umin[6],
-                                           const float umax[6], float u_out[6]) {
+                                           const float umax[6], float u_out[6], WlsWork& ws) {
   const double gam = 100000.0;
   const double Wv[6] = {1000, 1000, 0.1, 10, 10, 100};          // INDIControl_6DOF.py:614
-  double A[12][6], Af[12][6], d[12], u[6], u_opt[6], p[6], p_free[6], W[6], Lambda[6];
-  int free_index[6], lookup[6];
+  double (&A)[12][6] = ws.A, (&Af)[12][6] = ws.Af, (&Q)[12][6] = ws.Q;
+  double (&d)[12] = ws.d, (&rhs)[12] = ws.rhs;
+  double (&u)[6] = ws.u, (&u_opt)[6] = ws.u_opt, (&p)[6] = ws.p, (&p_free)[6] = ws.p_free, (&W)[6] = ws.W, (&Lambda)[6] = ws.Lambda;
+  int (&free_index)[6] = ws.free_index, (&lookup)[6] = ws.lookup;
   int n_free = 0, free_chk = -1, iter = 0, n_p_free = 6, id_alpha = 0;
   bool alpha_set = false;
   double alpha = 0.0;
@@ -420,7 +446,6 @@ __device__ __forceinline__ int wls_active_set(const DevType& T, const float v[6]
       free_chk = n_free;
     }
     if (n_free) {   // p_free = lstsq(Af[:, :n_free], d) by Householder QR on copies
-      double Q[12][6], rhs[12];
       for (int i = 0; i < 12; ++i) { rhs[i] = d[i]; for (int j = 0; j < n_free; ++j) Q[i][j] = Af[i][j]; }
       for (int k = 0; k < n_free; ++k) {
         double nrm = 0.0;

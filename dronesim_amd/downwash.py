@@ -27,17 +27,38 @@ from . import _native as nat
 CUTOFF = 10.0     # BaseAviary.py:1752: "Ignore drones more than 10 meters away"
 
 
-def gather_positions(local_pos: torch.Tensor, dist=None) -> torch.Tensor:
-    """local_pos [3, n_local] (same n_local on every rank) -> world positions [3, world * n_local] in
-    global drone order (rank-major, i.e. the contiguous shards of sharding.shard_range)."""
+def shard_counts(n_local: int, dist=None):
+    """Drones per rank, [world] python ints (one small all-gather; sharding.shard_range hands out shards whose sizes
+    differ by one when the fleet does not divide evenly)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [int(n_local)]
+    world = dist.get_world_size()
+    wire = torch.device("cpu") if dist.get_backend() == "gloo" else torch.device("cuda", torch.cuda.current_device())
+    mine = torch.tensor([int(n_local)], dtype=torch.int64, device=wire)
+    out = torch.empty((world,), dtype=torch.int64, device=wire)
+    dist.all_gather_into_tensor(out, mine)
+    return [int(x) for x in out.cpu()]
+
+
+def gather_positions(local_pos: torch.Tensor, dist=None, counts=None) -> torch.Tensor:
+    """local_pos [3, n_local] -> world positions [3, sum(counts)] in global drone order (rank-major, i.e. the
+    contiguous shards of sharding.shard_range).  ``counts`` = drones per rank (shard_counts); None = every rank
+    holds n_local.  Unequal shards are padded to the largest for the collective and compacted afterwards."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local_pos.contiguous()
     world = dist.get_world_size()
     dev = local_pos.device
-    loc = local_pos.contiguous().to(_wire_device(dist, dev))
-    out = torch.empty((world * 3, loc.shape[1]), dtype=loc.dtype, device=loc.device)   # ranks stacked on dim 0
+    n_max = local_pos.shape[1] if counts is None else max(counts)
+    loc = local_pos.contiguous()
+    if loc.shape[1] < n_max:
+        loc = torch.cat([loc, loc.new_zeros((3, n_max - loc.shape[1]))], dim=1)
+    loc = loc.to(_wire_device(dist, dev))
+    out = torch.empty((world * 3, n_max), dtype=loc.dtype, device=loc.device)   # ranks stacked on dim 0
     dist.all_gather_into_tensor(out, loc)
-    return out.reshape(world, 3, loc.shape[1]).permute(1, 0, 2).reshape(3, world * loc.shape[1]).contiguous().to(dev)
+    out = out.reshape(world, 3, n_max).permute(1, 0, 2)                          # [3, world, n_max]
+    if counts is None or all(c == n_max for c in counts):
+        return out.reshape(3, world * n_max).contiguous().to(dev)
+    return torch.cat([out[:, r, :c] for r, c in enumerate(counts)], dim=1).contiguous().to(dev)
 
 
 def _wire_device(dist, dev):
@@ -131,6 +152,9 @@ class Downwash:
         self.ctx, self.state, self.type_id, self.dist, self.cell = ctx, state, type_id, dist, float(cell)
         self.halo = halo                 # None: all-gather of the world's positions (any index sharding)
         self.force = torch.zeros((3, state.n_pad), dtype=torch.float32, device=ctx.device)
+        self._counts = None              # drones per rank (all-gather form; fetched once)
+        self._last = None                # DownwashArgs of the last compute(): the grid a step kernel may fill for the next
+        self._prebin_version = None      # state.version at the time a step kernel was handed that grid
         self._ws = None
         self._box = None                 # (xmin, ymin, nx, ny): a search-efficiency hint, never a correctness input
         self._box_age, self._box_refresh = 0, box_refresh
@@ -165,9 +189,11 @@ class Downwash:
         elif world_pos is None and self.halo is not None:
             world_pos, local_offset = self.halo.exchange(st.fields(0, 3)[:, : st.n]), 0
         elif world_pos is None:
-            world_pos = gather_positions(st.fields(0, 3), self.dist)
+            if self._counts is None:
+                self._counts = shard_counts(st.n, self.dist)
+            world_pos = gather_positions(st.fields(0, 3), self.dist, self._counts)
             rank = self.dist.get_rank() if (self.dist is not None and self.dist.is_initialized()) else 0
-            local_offset = rank * st.n
+            local_offset = sum(self._counts[:rank])
         if not single:
             wp = world_pos.to(torch.float32).contiguous()
             m = wp.shape[1]
@@ -182,16 +208,35 @@ class Downwash:
         a.workspace, a.workspace_len = self._ws.data_ptr(), self._ws.numel()
         a.type_id = self.type_id.data_ptr() if self.type_id is not None else None
         a.local_offset = int(local_offset or 0)
+        a.prebinned = 0
         self._keep = wp                     # the kernels read it asynchronously on the stream
         return a
+
+    # ---- the step kernel fills the next step's grid (dsim_step_args.bin_next) ------------------------------------
+    def bin_next_ptr(self):
+        """Pointer to the grid description of the NEXT compute() for ``dsim_step_args.bin_next``, or None when that
+        grid cannot be filled ahead (no compute() yet, or a shape that takes the counting-sort form).  The library
+        re-checks everything; a grid that changes after all (box refresh, halo resize) just means a full binning pass."""
+        a = self._last
+        if a is None or not self.ctx.lib.dsim_downwash_prebin_ok(a.m, a.nx, a.ny):
+            return None
+        self._prebin_version = self.state.version
+        return ctypes.addressof(a)
+
+    def invalidate_prebin(self) -> None:
+        """The state was changed by something other than the fused step that pre-binned it."""
+        self._prebin_version = None
 
     def compute(self, world_pos: Optional[torch.Tensor] = None, local_offset: Optional[int] = None) -> torch.Tensor:
         """Returns the SoA [3, n_pad] body-frame force (x = y = 0) to pass as ``ext_force``.
         ``world_pos`` [3, m]: positions of every drone of the world with this block's drones at
         ``local_offset`` (default: gathered from the ranks' states / the block alone)."""
         a = self._grid_args(world_pos, local_offset)
+        a.prebinned = int(self._prebin_version is not None and self._prebin_version == self.state.version)
+        self._prebin_version = None
         nat.check(self.ctx.lib.dsim_downwash(self.ctx.handle, self.ctx.stream_ptr(), self.state.n, self.state.view(),
                                              ctypes.byref(a), self.force.data_ptr()))
+        self._last = a
         return self.force
 
     def adjacency(self, radius: float, max_k: int = 0, world_pos: Optional[torch.Tensor] = None,
@@ -202,6 +247,7 @@ class Downwash:
         the dict-mode observations of small fleets."""
         self.cell = max(self.cell, float(radius))
         self._box = None if self._box is not None and self.cell > CUTOFF else self._box
+        self._prebin_version = None
         a = self._grid_args(world_pos, local_offset)
         st = self.state
         count = torch.zeros((st.n_pad,), dtype=torch.int32, device=self.ctx.device)

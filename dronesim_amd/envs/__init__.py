@@ -1,1 +1,1 @@
-from .fleet_aviary import CtrlAviary, Physics, RPYTAviary, VelocityAviary  # noqa: F401
+from .fleet_aviary import CtrlAviary, FleetObs, Physics, RPYTAviary, VelocityAviary  # noqa: F401

@@ -15,7 +15,7 @@ from __future__ import annotations
 import ctypes
 import os
 from enum import Enum
-from typing import Optional, Sequence, Union
+from typing import NamedTuple, Optional, Sequence, Union
 
 import numpy as np
 import torch
@@ -41,6 +41,18 @@ class Physics(Enum):
 # dict-of-ndarray I/O (the reference's format) is produced up to this many drones;
 # beyond it step()/reset() return device tensors.
 DICT_IO_MAX_DRONES = 64
+
+
+class FleetObs(NamedTuple):
+    """Observation of a fleet in tensor mode when neighbour lists are requested (``neighbors_k`` > 0): what the
+    reference returns per drone as ``{"state": ..., "neighbors": ...}`` (CtrlAviary.py:225-232), for the whole fleet
+    on the device.  ``neighbor_count[i]`` = drones within NEIGHBOURHOOD_RADIUS of drone i (the row sum of the
+    reference's adjacency matrix minus the diagonal), ``neighbor_list[:, i]`` = up to ``neighbors_k`` of their indices
+    (-1 padded): the sparse form of the reference's dense O(N^2) row."""
+
+    state: torch.Tensor            # [N, 16 + n_act]
+    neighbor_count: torch.Tensor   # [N] int32
+    neighbor_list: torch.Tensor    # [neighbors_k, N] int32
 
 
 class CtrlAviary:
@@ -70,6 +82,8 @@ class CtrlAviary:
         chained: bool = False,
         downwash_exchange: str = "allgather",
         type_ids=None,
+        neighbors_k: int = 0,
+        options: int = 0,
     ):
         if gui or record or obstacles:
             raise NotImplementedError("gui/record/obstacles are rendering features outside the hot path")
@@ -80,6 +94,9 @@ class CtrlAviary:
         self._phys_options = {Physics.PYB: 0, Physics.PYB_DW: 0, Physics.PYB_GND: nat.OPT_GROUND,
                               Physics.PYB_DRAG: nat.OPT_DRAG,
                               Physics.PYB_GND_DRAG_DW: nat.OPT_GROUND | nat.OPT_DRAG}[physics]
+        # tuning bits handed to every call (nat.OPT_STREAM_ON/_OFF, nat.OPT_GENERIC_MIXED); results do not depend on them
+        self._tuning = int(options) & (nat.OPT_STREAM_ON | nat.OPT_STREAM_OFF | nat.OPT_GENERIC_MIXED)
+        self.neighbors_k = int(neighbors_k)
         if isinstance(drone_model, (str, DroneType)):
             drone_model = [drone_model]
         models = list(drone_model)
@@ -151,6 +168,8 @@ class CtrlAviary:
         self._last_action = torch.zeros_like(self._action_buf)
         self._use_last_action = True
         self._obs_buf = None      # [N, 16+n_act], allocated on the first observe()
+        self._adjacency = None    # grid for neighbors(), built on first use
+        self._action_keep = None  # keeps a zero-copy action tensor alive while the launch that reads it is queued
         # chained fused stepping (DSIM_OPT_CHAINED): consecutive step_fused() calls skip the six
         # controller-memory fields that are functions of the stored rigid state (184 instead of 232
         # bytes per drone-step); anything else first calls materialize()
@@ -187,7 +206,7 @@ class CtrlAviary:
         a.phys_substeps = self.AGGR_PHY_STEPS
         a.dt_phys = self.TIMESTEP
         a.dt_ctrl = dt_ctrl if dt_ctrl is not None else self.TIMESTEP * self.AGGR_PHY_STEPS
-        a.options = options | self._phys_options
+        a.options = options | self._phys_options | self._tuning
         a.noise_seed = self.noise_seed
         a.step_index = self._env_steps
         a.noise_replay = None
@@ -198,6 +217,7 @@ class CtrlAviary:
         a.ext_force = self._downwash.compute().data_ptr() if self._downwash is not None else None
         if self._runs is not None:
             a.runs, a.n_runs = ctypes.addressof(self._runs), len(self._runs)
+        a.obs_out, a.obs_width, a.bin_next = None, 0, None
         return a
 
     # ------------------------------------------------------------------ gym surface
@@ -220,6 +240,8 @@ class CtrlAviary:
         self._fused_plan = None
         self.step_counter = 0
         self._env_steps = 0
+        if getattr(self, "_downwash", None) is not None:
+            self._downwash.invalidate_prebin()
         pos, rpy = self._soa3(self.INIT_XYZS), self._soa3(self.INIT_RPYS)
         vel = self._soa3(self.INIT_VELS) if self.INIT_VELS is not None else None
         self._last_action.zero_()                      # BaseAviary.py:660-663
@@ -234,15 +256,19 @@ class CtrlAviary:
         """BaseAviary.step (BaseAviary.py:428-555) with Physics.PYB."""
         self.materialize()
         self._chain_ok = False
-        self._load_action(action)
+        if self._downwash is not None:
+            self._downwash.invalidate_prebin()
         args = self.step_args()
-        args.action = self._action_buf.data_ptr()
+        args.action = self._action_ptr(action)
+        # the observation rows are written by the physics launch itself (BaseAviary.py:547-555 returns them from step)
+        obs = self._obs_tensor()
+        args.obs_out, args.obs_width = obs.data_ptr(), 16 + self.n_act
         nat.check(self.ctx.lib.dsim_physics(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
                                             self.state.view(), self._last_action.data_ptr(), ctypes.byref(args)))
         self._use_last_action = True
         self.step_counter += self.AGGR_PHY_STEPS
         self._env_steps += 1
-        return self._computeObs(), self._computeReward(), self._computeDone(), self._computeInfo()
+        return self._computeObs(obs), self._computeReward(), self._computeDone(), self._computeInfo()
 
     def step_fused(self, targets, control_timestep: Optional[float] = None, action=None, n_steps: int = 1):
         """One launch = ``env.step(action)`` followed by ``computeControl`` for every drone:
@@ -257,11 +283,15 @@ class CtrlAviary:
         if n_steps > 1 and self._downwash is not None:
             raise ValueError("n_steps > 1 with the neighbour-downwash term: the force (and the position exchange behind "
                              "it) is evaluated once per Env.step")
-        key = (id(targets), control_timestep, n_steps, self._chained_enabled)
+        # (the plan holds the targets object itself: compared by identity while it is alive, so a new object that
+        # happens to reuse the address of a dropped one can never match; and the device pointers it was built from
+        # are re-checked, so a Targets whose tensor was swapped does not either)
+        key = (control_timestep, n_steps, self._chained_enabled)
         plan = self._fused_plan
-        if (action is None and plan is not None and plan[0] == key and self._downwash is None and self._chain_ok
-                and (self._chain_live or not self._chained_enabled)):
-            _, args, sview, tview, ref = plan
+        if (action is None and plan is not None and plan[5] is targets and plan[0] == key and self._downwash is None
+                and self._chain_ok and (self._chain_live or not self._chained_enabled)
+                and plan[6] == self._targets_ptrs(targets)):
+            _, args, sview, tview, ref = plan[:5]
             args.step_index = self._env_steps
             nat.check(self.ctx.lib.dsim_step(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, sview, tview, ref))
             self.step_counter += self.AGGR_PHY_STEPS * n_steps
@@ -276,8 +306,9 @@ class CtrlAviary:
         else:
             tview = targets.view()
         if action is not None:
-            self._load_action(action)
-            args.action = self._action_buf.data_ptr()
+            args.action = self._action_ptr(action)
+        if self._downwash is not None:
+            args.bin_next = self._downwash.bin_next_ptr()      # the step kernel fills the next step's neighbour grid
         self._use_last_action = False   # from here on the applied action IS the controller cmd
         chain = (self._chained_enabled and self._chain_ok and action is None and self._type_id is None
                  and self.n_act == 4 and args.ext_force is None and self._phys_options == 0)
@@ -299,7 +330,7 @@ class CtrlAviary:
             if self._chained_enabled and chain:
                 nxt.options |= nat.OPT_CHAINED
             if not self._chained_enabled or chain:
-                self._fused_plan = (key, nxt, sview, tview, ctypes.byref(nxt))
+                self._fused_plan = (key, nxt, sview, tview, ctypes.byref(nxt), targets, self._targets_ptrs(targets))
 
     def capture_fused(self, targets, steps: int, control_timestep: Optional[float] = None):
         """Captures ``steps`` consecutive :meth:`step_fused` launches into ONE hipGraph and returns a
@@ -322,6 +353,30 @@ class CtrlAviary:
         return -1   # there is no PyBullet client; kept so example scripts keep running
 
     # ------------------------------------------------------------------ pieces
+    @staticmethod
+    def _targets_ptrs(targets):
+        if isinstance(targets, WaypointTargets):
+            return (targets.table.data_ptr(), targets.counters.data_ptr(),
+                    targets.offsets.data_ptr() if targets.offsets is not None else 0, targets.n_wp)
+        return (targets.data.data_ptr(), tuple(targets.data.shape))
+
+    def _action_ptr(self, action) -> int:
+        """Device pointer of the action as SoA [n_act][n_pad].  A tensor that already IS such an array (the command
+        a bound ``INDIControl`` returns is the transposed view of one) is passed through without a copy."""
+        if torch.is_tensor(action) and action.is_cuda and action.dtype == torch.float32:
+            base = action.T if (action.ndim == 2 and action.shape[1] == self.n_act and action.shape[0] != self.n_act) else action
+            if (base.ndim == 2 and base.shape[0] == self.n_act and base.stride() == (self.state.n_pad, 1)
+                    and base.shape[1] <= self.state.n_pad and base.shape[1] >= self.NUM_DRONES):
+                self._action_keep = action
+                return base.data_ptr()
+        self._load_action(action)
+        return self._action_buf.data_ptr()
+
+    def _obs_tensor(self) -> torch.Tensor:
+        if self._obs_buf is None:
+            self._obs_buf = torch.zeros((self.NUM_DRONES, 16 + self.n_act), dtype=torch.float32, device=self.ctx.device)
+        return self._obs_buf
+
     def _load_action(self, action) -> None:
         n = self.NUM_DRONES
         if isinstance(action, dict):                      # CtrlAviary.py:258-263 format
@@ -338,12 +393,26 @@ class CtrlAviary:
 
     def observe(self) -> torch.Tensor:
         """[N, 16+n_act] rows of _getDroneStateVector (BaseAviary.py:780-790), on device."""
-        if self._obs_buf is None:
-            self._obs_buf = torch.zeros((self.NUM_DRONES, 16 + self.n_act), dtype=torch.float32, device=self.ctx.device)
+        self._obs_tensor()
         la = self._last_action.data_ptr() if self._use_last_action else None
         nat.check(self.ctx.lib.dsim_observe(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
                                             self.state.view(), la, self._obs_buf.data_ptr(), 16 + self.n_act))
         return self._obs_buf
+
+    def neighbors(self, max_k: Optional[int] = None):
+        """Fleet-scale form of the observation's ``neighbors`` entry (BaseAviary._getAdjacencyMatrix,
+        BaseAviary.py:901-921; CtrlAviary.py:225-231): (count [N] int32, list [max_k, N] int32, -1 padded) of the drones
+        within NEIGHBOURHOOD_RADIUS of each drone, by the uniform-grid query of dsim_adjacency."""
+        from ..downwash import Downwash
+        if not np.isfinite(self.NEIGHBOURHOOD_RADIUS):
+            raise ValueError("neighbourhood_radius is infinite: every drone neighbours every other (the reference's "
+                             "default); pass a finite radius for neighbour lists")
+        if self._adjacency is None:
+            self._adjacency = Downwash(self.ctx, self.state, self._type_id, None)
+        if self._downwash is not None:
+            self._downwash.invalidate_prebin()            # the adjacency pass re-uses the ctx's grid bookkeeping
+        k = self.neighbors_k if max_k is None else int(max_k)
+        return self._adjacency.adjacency(float(self.NEIGHBOURHOOD_RADIUS), max_k=k)
 
     def _getAdjacencyMatrix(self, pos: np.ndarray) -> np.ndarray:
         """BaseAviary.py:901-921 — O(N^2), only produced in dict mode (small fleets)."""
@@ -352,9 +421,12 @@ class CtrlAviary:
         np.fill_diagonal(adj, 1.0)
         return adj
 
-    def _computeObs(self):
-        obs = self.observe()
+    def _computeObs(self, obs=None):
+        obs = self.observe() if obs is None else obs
         if not self.dict_io:
+            if self.neighbors_k > 0:
+                cnt, lst = self.neighbors()
+                return FleetObs(obs, cnt, lst)
             return obs
         o = obs.double().cpu().numpy()
         self.pos, self.quat, self.rpy = o[:, 0:3], o[:, 3:7], o[:, 7:10]
@@ -436,6 +508,14 @@ class _AdaptorAviary(CtrlAviary):
     (part of) the INDI law INSIDE step() — on the current state — and the physics follows."""
 
     _MODE = -1
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        if self.PHYSICS != Physics.PYB:
+            # dsim_step_adaptor flies plain PYB (no drag / ground effect / downwash inputs): refuse instead of
+            # silently ignoring the mode the caller asked for
+            raise NotImplementedError(f"{type(self).__name__}: physics={self.PHYSICS} — the action-adaptor envs "
+                                      "support Physics.PYB only")
 
     def step(self, action):
         self.materialize()

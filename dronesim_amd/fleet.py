@@ -105,6 +105,7 @@ class BlockedSoA:
 
     def __init__(self, n: int, n_fields: int, device, layout: str = "soa", pad: int = 256):
         self.n, self.n_fields, self.layout = n, n_fields, layout
+        self.version = 0            # bumped by every host-side write (set_fields): caches keyed on the contents check it
         if layout == "soa":
             self.block = 0
             self.n_pad = pad_to(n, pad)
@@ -135,6 +136,7 @@ class BlockedSoA:
 
     def set_fields(self, f0: int, values: torch.Tensor) -> None:
         """values: [nf, n]"""
+        self.version += 1
         nf = values.shape[0]
         vals = values.to(self.data.device, torch.float32)
         if self.layout == "soa":

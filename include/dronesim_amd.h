@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DSIM_ABI_VERSION 3
+#define DSIM_ABI_VERSION 4
 #define DSIM_MAX_ACT 6     /* actuators per vehicle (quad 4, morphing hexa 6) */
 #define DSIM_MAX_TYPES 8
 
@@ -118,12 +118,18 @@ enum {
   DSIM_OPT_DRAG        = 1u << 0,   /* add formula P6 (BaseAviary.py:1705-1732)            */
   DSIM_OPT_GROUND      = 1u << 1,   /* add formula P7 (BaseAviary.py:1648-1699)            */
   DSIM_OPT_BCAST_TGT   = 1u << 2,   /* targets view holds ONE drone's targets, broadcast   */
-  DSIM_OPT_CHAINED     = 1u << 3    /* dsim_step only.  The caller asserts that the stored controller memory is
+  DSIM_OPT_CHAINED     = 1u << 3,   /* dsim_step only.  The caller asserts that the stored controller memory is
                                        the one the previous dsim_step / dsim_control left on the SAME rigid state,
                                        i.e. last_vel == vel and last_rates == R(quat)^T ang_vel.  Both are then
                                        recomputed from the rigid state instead of being read, and are NOT written
                                        back (6 of the 24 fields: 184 instead of 232 bytes of traffic per
                                        drone-step).  The six fields are stale until dsim_materialize is called. */
+  /* -- tuning knobs (results do not depend on them; the library reads no environment variables) --------------- */
+  DSIM_OPT_STREAM_ON   = 1u << 4,   /* force nontemporal (streaming) loads/stores of the state; default: on when one
+                                       step's traffic exceeds what the 256 MB Infinity Cache keeps between steps   */
+  DSIM_OPT_STREAM_OFF  = 1u << 5,   /* force the default cache policy                                              */
+  DSIM_OPT_GENERIC_MIXED = 1u << 6  /* mixed fleets: use the general per-lane-type kernel instead of the LDS-staged
+                                       one (A/B knob)                                                              */
 };
 
 /* A run of consecutive drones of one type (type-major storage of a heterogeneous fleet). */
@@ -177,7 +183,18 @@ typedef struct dsim_step_args {
    * not needed.  Drones outside every run are not stepped.                                              */
   const dsim_type_run* runs;
   int32_t n_runs;
-  int32_t _pad_runs;
+  /* -- fused observation (dsim_physics only) -----------------------------------------------------------------------
+   * obs_out nullable: the rows of dsim_observe (BaseAviary._getDroneStateVector, BaseAviary.py:764-790) of the state
+   * AFTER the step with the applied (clipped) action echoed, written by the same launch: what Env.step() returns
+   * (BaseAviary.py:547-555).  Row-major [n][obs_width], obs_width = 16 + n_act of the ctx.                           */
+  int32_t obs_width;
+  float*  obs_out;
+  /* -- neighbour grid for the NEXT Env.step (dsim_step only) --------------------------------------------------------
+   * nullable: the grid description of the next dsim_downwash call.  The step kernel then appends the NEW position of
+   * every local drone to its cell's bucket while the position is still in registers, and that dsim_downwash call
+   * (same workspace and shape, args->prebinned = 1) skips the binning launch for the local drones.  Honoured on the
+   * bucket form of the grid only (dsim_downwash_prebin_ok() != 0); otherwise ignored.                                */
+  const struct dsim_downwash_args* bin_next;
 } dsim_step_args;
 
 typedef struct dsim_ctx dsim_ctx;
@@ -245,6 +262,11 @@ int dsim_step_adaptor(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, c
  * pos_e_out [3][n_pad] and yaw_e_out [n_pad] nullable.                           */
 int dsim_control(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
                  const dsim_step_args* args, float* pos_e_out, float* yaw_e_out);
+/* The same, and the new command is also written to cmd_out (nullable, SoA [n_act][n_pad]): the first return value of
+ * computeControl as a plain array, in the layout Env.step's action (dsim_step_args.action) takes — the command goes
+ * from the controller to the next Env.step without a copy. */
+int dsim_control2(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
+                  const dsim_step_args* args, float* pos_e_out, float* yaw_e_out, float* cmd_out);
 
 /* _getDroneStateVector (BaseAviary.py:764-790): writes the reference's 20/22-wide
  * observation rows [pos3 quat4 rpy3 vel3 ang_v3 last_action] as row-major
@@ -294,8 +316,16 @@ typedef struct dsim_downwash_args {
   const uint8_t* type_id;   /* nullable; types of the LOCAL drones */
   int64_t  local_offset;    /* index inside pos_all of local drone 0 (the rank's shard begin); the local
                                drones' entries of pos_all must equal their state positions               */
+  int32_t  prebinned;       /* 1: the previous dsim_step was given this grid as bin_next and has already binned the
+                               local drones (see dsim_step_args.bin_next); only the other entries of pos_all are
+                               binned by this call.  The library falls back to a full binning pass when its own
+                               record of the last prebinning does not match.                              */
+  int32_t  _pad;
 } dsim_downwash_args;
 int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny);
+/* != 0 when a grid of this shape takes the bucket form (one binning pass, cell-centred LDS-tiled query), which is
+ * the form dsim_step_args.bin_next can fill. */
+int dsim_downwash_prebin_ok(int64_t m, int32_t nx, int32_t ny);
 int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_downwash_args* args,
                   float* force_out);
 

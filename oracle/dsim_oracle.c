@@ -664,32 +664,43 @@ void orc_physics_substep(const dsim_type_params* P, double dt, double rigid[13],
 /* ======================================================================= */
 /* Product noise definition (NOT a reference restatement: the reference draws
  * from the unseeded global numpy RNG, BaseAviary.py:1518-1525, which cannot be
- * reproduced).  Philox4x32-10 keyed by the seed, counter = (drone, substep
+ * reproduced).  Threefry4x32-12 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
+ * SC'11 — the Random123 generator; add/rotate/xor only) keyed by the seed, counter = (drone, substep
  * counter, stream), Box-Muller on 16+16-bit halves -> N(0,1) truncated at 4.71 sigma.
- * Mirrors dsim_device.h so that tests can feed the oracle the very normals the kernel draws.                     */
+ * Mirrors dsim_device.h so that tests can feed the oracle the very normals the kernel draws.
+ * orc_threefry4x32 takes the round count so that the published known-answer vectors (13 and 20 rounds,
+ * Random123 kat_vectors) pin the round function, rotation constants and key schedule
+ * (tests/test_oracle_physics.py).                                                                               */
 /* ======================================================================= */
-static inline void philox_round(uint32_t c[4], const uint32_t k[2]) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)p1;
-  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
-  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-void orc_philox4x32(uint32_t c[4], uint64_t seed) {
-  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-  for (int r = 0; r < 10; ++r) {
-    philox_round(c, k);
-    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+static inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+void orc_threefry4x32(uint32_t x[4], const uint32_t key[4], int rounds) {
+  static const int R0[8] = {10, 11, 13, 23, 6, 17, 25, 18}, R1[8] = {26, 21, 27, 5, 20, 11, 10, 20};
+  const uint32_t ks[5] = {key[0], key[1], key[2], key[3], 0x1BD11BDAu ^ key[0] ^ key[1] ^ key[2] ^ key[3]};
+  for (int i = 0; i < 4; ++i) x[i] += ks[i];
+  for (int r = 0; r < rounds; ++r) {
+    if ((r & 1) == 0) {
+      x[0] += x[1]; x[1] = rotl32(x[1], R0[r & 7]) ^ x[0];
+      x[2] += x[3]; x[3] = rotl32(x[3], R1[r & 7]) ^ x[2];
+    } else {
+      x[0] += x[3]; x[3] = rotl32(x[3], R0[r & 7]) ^ x[0];
+      x[2] += x[1]; x[1] = rotl32(x[1], R1[r & 7]) ^ x[2];
+    }
+    if ((r & 3) == 3) {
+      const int s = r / 4 + 1;
+      x[0] += ks[s % 5]; x[1] += ks[(s + 1) % 5]; x[2] += ks[(s + 2) % 5]; x[3] += ks[(s + 3) % 5] + (uint32_t)s;
+    }
   }
 }
-/* unit normals for (drone, substep counter): out[2*n_act].  One Philox block -> 8 normals: each
+/* unit normals for (drone, substep counter): out[2*n_act].  One block -> 8 normals: each
  * 32-bit word gives a Box-Muller pair, radius from its high 16 bits (u1 = (h+1)/65536 in (0,1]),
  * angle from its low 16 bits (u2 = l/65536 turns). */
 void orc_noise_normals(uint64_t seed, uint64_t drone, uint64_t sub_counter, int n_act, double* out) {
   int produced = 0;
+  const uint32_t key[4] = {(uint32_t)seed, (uint32_t)(seed >> 32), 0u, 0u};
   for (uint32_t stream = 0; produced < 2 * n_act; ++stream) {
     uint32_t c[4] = {(uint32_t)drone, (uint32_t)(drone >> 32) ^ (stream << 24), (uint32_t)sub_counter,
                      (uint32_t)(sub_counter >> 32)};
-    orc_philox4x32(c, seed);
+    orc_threefry4x32(c, key, 12);
     for (int w = 0; w < 4 && produced < 2 * n_act; ++w) {
       const double u1 = ((double)(c[w] >> 16) + 1.0) * (1.0 / 65536.0);
       const double u2 = (double)(c[w] & 0xFFFFu) * (1.0 / 65536.0);

@@ -30,11 +30,30 @@ def test_header_symbols_exported(nat):
     assert b"no HIP device" in lib.dsim_strerror(-3)
 
 
-def test_struct_sizes_match_c(nat):
+def test_struct_sizes_match_c(nat, tmp_path):
+    """Every struct of the header: the ctypes mirror has the C compiler's size and field offsets (a plain-C
+    translation unit that includes include/dronesim_amd.h, compiled here with gcc)."""
+    import subprocess
     from oracle import oracle as orc
     assert orc.lib().orc_sizeof_params() == ctypes.sizeof(params.TypeParamsC)
-    assert ctypes.sizeof(nat.View) == 48
-    assert ctypes.sizeof(nat.StepArgs) == 120
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mirrors = {"dsim_view": nat.View, "dsim_step_args": nat.StepArgs, "dsim_type_run": nat.TypeRun,
+               "dsim_downwash_args": nat.DownwashArgs, "dsim_type_params": params.TypeParamsC}
+    lines = []
+    for cname, cls in mirrors.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dronesim_amd.h"\nint main(void) {\n'
+                   + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I", os.path.join(root, "include"), "-o", str(exe), str(src)])
+    got = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in mirrors.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
 
 
 def test_no_cpu_fallback(nat):

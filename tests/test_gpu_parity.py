@@ -1722,8 +1722,24 @@ def test_kernels_stay_inside_their_views(gpu, layout, fleet_kind):
     nat.check(ctx.lib.dsim_downwash(ctx.handle, s, n, sv, ctypes.byref(g), bufs["force"][1].data_ptr()))
     # the remaining entry points: field-major observation, adjacency, and (quads) adaptor / chained / trajectory sampler
     extra = {}
-    for name, numel in (("obs_soa", (16 + ctx.n_act) * n_pad), ("adj_list", 4 * n_pad)):
+    for name, numel in (("obs_soa", (16 + ctx.n_act) * n_pad), ("adj_list", 4 * n_pad), ("cmd_out", ctx.n_act * n_pad),
+                        ("obs2", n * (16 + ctx.n_act))):
         extra[name] = carve(numel)
+    # fused step that also fills the next neighbour grid, then the downwash call that relies on it
+    a2 = _args(nat, 1, DT, DT, seed=5, type_id=tid)
+    a2.ext_force = bufs["force"][1].data_ptr()
+    a2.bin_next = ctypes.addressof(g)
+    nat.check(ctx.lib.dsim_step(ctx.handle, s, n, sv, tv, ctypes.byref(a2)))
+    g.prebinned = 1
+    nat.check(ctx.lib.dsim_downwash(ctx.handle, s, n, sv, ctypes.byref(g), bufs["force"][1].data_ptr()))
+    g.prebinned = 0
+    # Env.step with the observation rows fused, computeControl with the command handed out as a plain array
+    a3 = _args(nat, 2, DT, float(np.float32(2 / 240)), seed=5, type_id=tid, action=bufs["action"][1])
+    a3.obs_out, a3.obs_width = extra["obs2"][1].data_ptr(), 16 + ctx.n_act
+    nat.check(ctx.lib.dsim_physics(ctx.handle, s, n, sv, bufs["echo"][1].data_ptr(), ctypes.byref(a3)))
+    a3.action, a3.obs_out, a3.obs_width = None, None, 0
+    nat.check(ctx.lib.dsim_control2(ctx.handle, s, n, sv, tv, ctypes.byref(a3), bufs["pos_e"][1].data_ptr(),
+                                    bufs["yaw_e"][1].data_ptr(), extra["cmd_out"][1].data_ptr()))
     nat.check(ctx.lib.dsim_observe_soa(ctx.handle, s, n, sv, None, extra["obs_soa"][1].data_ptr(), 16 + ctx.n_act))
     cnt_buf = torch.full((n_pad + 2 * G,), -7, dtype=torch.int32, device=dev)
     lst_buf = torch.full((4 * n_pad + 2 * G,), -7, dtype=torch.int32, device=dev)
@@ -1773,3 +1789,220 @@ def test_abi_argument_errors(gpu):
     assert ctx.lib.dsim_step(ctx.handle, _stream(ctx), 64, st.view(), tg.view(), ctypes.byref(a)) == -1
     assert b"layout" in ctx.lib.dsim_strerror(-2)
     ctx.close()
+
+
+# ---------------------------------------------------------------------------
+# round 2: the two-call loop's fast forms, neighbour lists in the observation, prebinned neighbour grid
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", ["soa", "tile64"])
+@pytest.mark.parametrize("noise", [0, 9])
+def test_env_step_fused_observation_and_zero_copy_command(gpu, layout, noise):
+    """The reference-shaped loop on a fleet in tensor mode: env.step(cmd) is ONE launch (k_physics_fast) that also
+    writes the [N,20] observation rows, computeControlFromState(None) one launch (k_control_fast) whose command
+    array goes back into env.step without a copy.  Every step against the oracle from the device's previous state;
+    observation rows (all 20 columns) against orc_state_vector; and the same flight through the general kernels
+    (ragged fleet) gives the same rows."""
+    from dronesim_amd.control import INDIControl
+    from dronesim_amd.envs import CtrlAviary
+    nat, fleet = gpu
+    n = 2048
+    rng = np.random.default_rng(17)
+    xyz = np.stack([rng.uniform(-30, 30, n), rng.uniform(-30, 30, n), rng.uniform(1, 6, n)], 1)
+    rpy = np.stack([rng.uniform(-0.4, 0.4, n), rng.uniform(-0.4, 0.4, n), rng.uniform(-3, 3, n)], 1)
+    env = CtrlAviary(["robobee"], n, initial_xyzs=xyz, initial_rpys=rpy, aggregate_phy_steps=2, noise_seed=noise,
+                     dict_io=False, layout=layout)
+    ctrl = INDIControl("robobee", env=env)
+    t = params.builtin_type("robobee")
+    O = orc.Oracle([t])
+    dtc = float(np.float32(2 / 240))
+    tpos = f32(xyz + rng.uniform(-0.5, 0.5, (n, 3)))
+    tgt = np.concatenate([tpos, np.zeros((n, 6)), np.full((n, 1), float(np.float32(0.3)))], 1)
+    cmd = torch.full((n, 4), 0.45, device=env.ctx.device)
+    for k in range(6):
+        r0 = env.state.rigid_aos()
+        act = f32(cmd.double().cpu().numpy())
+        obs, reward, done, info = env.step(cmd)
+        assert obs.shape == (n, 20) and reward == -1 and done is False
+        if k > 0:
+            assert env._action_keep is cmd                    # the controller's array went in by pointer, no copy
+        a6 = np.zeros((n, 6)); a6[:, :4] = act
+        nz = None
+        if noise:
+            nz = np.zeros((n, 2, 12))
+            for i in range(n):
+                for s_ in range(2):
+                    u = O.noise_normals(noise, i, k * 2 + s_, 4)
+                    nz[i, s_, 0:4], nz[i, s_, 6:10] = u[0:4] * 0.01, u[4:8] * 0.001
+        r1, last = r0.copy(), np.zeros((n, 6))
+        O.physics(r1, env.state.mem_aos(), 2, DT, action=a6, noise=nz, last_action=last)
+        assert_step_parity(f"two_call_loop physics[{layout},{noise}]", [t], None, r0, env.state.mem_aos(), tgt,
+                           env.state.rigid_aos(), None, r1, None, DT, dtc, 2, control=False, action=act)
+        rows = obs.double().cpu().numpy()
+        _check_obs_rows(f"two_call_loop obs[{layout}]", O, rows, env.state.rigid_aos(), last, None, [t])
+        np.testing.assert_array_equal(rows, env.observe().double().cpu().numpy())     # == the stand-alone kernel
+        m0 = env.state.mem_aos()
+        cmd, pos_e, yaw_e = ctrl.computeControlFromState(dtc, None, target_pos=torch.from_numpy(tpos.T.copy()).float().to(env.ctx.device),
+                                                         target_rpy=np.array([0, 0, 0.3]))
+        m1 = m0.copy()
+        rc, pe, ye = O.control(env.state.rigid_aos(), m1, tgt, dtc)
+        assert rc == 0
+        assert_control_parity(f"two_call_loop control[{layout}]", [t], None, env.state.rigid_aos(), m0, tgt,
+                              env.state.mem_aos(), m1, dtc)
+        np.testing.assert_array_equal(cmd.cpu().numpy(), env.state.mem_aos()[:, 7:11].astype(np.float32))
+    env.close()
+
+
+def test_fused_observation_general_kernels_agree(gpu):
+    """dsim_physics with obs_out on fleets that take the general kernel (ragged size, mixed types): the rows equal
+    dsim_observe's."""
+    from dronesim_amd.envs import CtrlAviary
+    n = 333
+    rng = np.random.default_rng(19)
+    xyz = np.stack([rng.uniform(-5, 5, n), rng.uniform(-5, 5, n), rng.uniform(1, 3, n)], 1)
+    tid = (np.arange(n) % 2).astype(np.uint8)
+    env = CtrlAviary(["robobee", "hexa_6DOF"], n, initial_xyzs=xyz, aggregate_phy_steps=3, noise_seed=0, dict_io=False,
+                     type_ids=tid)
+    act = torch.from_numpy(rng.uniform(0.3, 0.6, (n, 6)).astype(np.float32)).to(env.ctx.device)
+    for _ in range(3):
+        obs, *_ = env.step(act)
+        np.testing.assert_array_equal(obs.cpu().numpy(), env.observe().cpu().numpy())
+    O = orc.Oracle(env.types)
+    last = np.zeros((n, 6)); last[:, :] = act.double().cpu().numpy(); last[tid == 0, 4:6] = 0.0
+    _check_obs_rows("fused_obs_general", O, obs.double().cpu().numpy(), env.state.rigid_aos(), last, tid, env.types)
+    env.close()
+
+
+def test_neighbor_lists_in_the_fleet_observation(gpu):
+    """CtrlAviary(..., neighbors_k=K) in tensor mode: the observation carries, per drone, the count and the indices
+    of the drones within NEIGHBOURHOOD_RADIUS — the sparse form of the reference's adjacency row
+    (CtrlAviary.py:225-231, BaseAviary.py:901-921), from the device-side grid query; checked against the O(N^2) rule."""
+    from dronesim_amd.envs import CtrlAviary, FleetObs
+    n, radius, K = 2500, 4.0, 48
+    rng = np.random.default_rng(23)
+    xyz = np.stack([rng.uniform(0, 60, n), rng.uniform(0, 60, n), rng.uniform(0.5, 8, n)], 1)
+    env = CtrlAviary(["robobee"], n, neighbourhood_radius=radius, initial_xyzs=xyz, noise_seed=0, dict_io=False, neighbors_k=K)
+    obs = env.reset()
+    assert isinstance(obs, FleetObs) and obs.state.shape == (n, 20) and obs.neighbor_list.shape == (K, n)
+    obs, *_ = env.step(torch.full((n, 4), 0.5, device=env.ctx.device))
+    p = obs.state[:, 0:3].cpu().numpy()
+    d2 = ((p[:, None, :] - p[None, :, :]) ** 2).sum(-1)
+    adj = (d2 < np.float32(radius) ** 2) & ~np.eye(n, dtype=bool)
+    np.testing.assert_array_equal(obs.neighbor_count.cpu().numpy(), adj.sum(1))
+    L = obs.neighbor_list.cpu().numpy()
+    for i in rng.choice(n, 150, replace=False):
+        got = set(int(x) for x in L[:, i] if x >= 0)
+        assert got == set(np.nonzero(adj[i])[0].tolist()) or (adj[i].sum() > K and len(got) == K)
+    env.close()
+
+
+def test_action_adaptor_envs_refuse_physics_modes_they_do_not_fly(gpu):
+    from dronesim_amd.envs import Physics, RPYTAviary, VelocityAviary
+    for cls in (VelocityAviary, RPYTAviary):
+        for ph in (Physics.PYB_DRAG, Physics.PYB_GND, Physics.PYB_DW, Physics.PYB_GND_DRAG_DW):
+            with pytest.raises(NotImplementedError):
+                cls(["robobee"], 4, initial_xyzs=np.zeros((4, 3)) + 1.0, physics=ph)
+
+
+def test_prebinned_neighbour_grid_is_dropped_when_the_state_changes_behind_it(gpu):
+    """step_fused() lets the step kernel fill the next step's neighbour grid; a physics-only step, a reset or a host
+    write to the state in between must not leave stale cells behind: the next downwash force is the brute-force one
+    on the CURRENT positions."""
+    from dronesim_amd.envs import CtrlAviary, Physics
+    from dronesim_amd.fleet import Targets
+    n = 768
+    rng = np.random.default_rng(29)
+    xyz = np.stack([rng.uniform(0, 25, n), rng.uniform(0, 25, n), rng.uniform(0.5, 9, n)], 1)
+    tid = (np.arange(n) % 2).astype(np.uint8)
+    env = CtrlAviary(["robobee", "hexa_6DOF"], n, initial_xyzs=xyz, physics=Physics.PYB_DW, noise_seed=0, dict_io=False,
+                     type_ids=tid)
+    tg = Targets(env.ctx, n); tg.set(pos=f32(xyz).T, yaw=0.0)
+    O = orc.Oracle(env.types)
+
+    def force_ok():
+        f = env._downwash.compute().cpu().numpy()[2, :n]
+        r = env.state.rigid_aos()
+        ref = O.downwash(r, r[:, 0:3], type_id=tid)
+        assert (np.abs(f - ref) / (np.abs(ref) + 1e-3)).max() < 1e-4
+        return ref
+
+    for _ in range(3):
+        env.step_fused(tg)                                   # prebins for the next compute()
+    assert env._downwash._prebin_version is not None
+    ref0 = force_ok()                                        # consumes the prebinned grid
+    env.step_fused(tg)
+    env.step(torch.full((n, 6), 0.47, device=env.ctx.device))      # Env.step moves the drones behind the prebinned grid
+    force_ok()
+    env.step_fused(tg)
+    moved = env.state.fields(0, 3).clone(); moved[0] += 3.0; moved[2] = moved[2].flip(0)
+    env.state.set_fields(0, moved)                                 # host write behind it
+    ref1 = force_ok()
+    assert np.abs(ref1 - ref0).max() > 1e-3
+    env.step_fused(tg)
+    env.reset()
+    force_ok()
+    env.close()
+
+
+def test_wls_fallback_queue_of_a_large_fleet(gpu):
+    """A saturating target step on a large hexa fleet sends a large share of it through the active-set loop at once
+    (k_wls_fallback: chip-sized grid, LDS work area): counted, finite, within the PWM box, and equal to the oracle's
+    full wls_alloc on a sample."""
+    nat, fleet = gpu
+    n = 131072
+    t = params.builtin_type("hexa_6DOF")
+    ctx = fleet.Context([t])
+    rng = np.random.default_rng(37)
+    rigid, mem, tgt = random_fleet(rng, n, n_act=6, tilt=0.3, rate=1.0)
+    mem[:, 7:13] = f32(rng.uniform(0.0, 1.0, (n, 6)))            # commands anywhere in the box: bounds bind
+    tgt[:, 0:3] = f32(rigid[:, 0:3] + rng.uniform(-40, 40, (n, 3)))
+    rigid[:, 10:13] = f32(rng.uniform(-25, 25, (n, 3)))          # violent rates: the first WLS iteration leaves the box
+    st, tg = fleet.FleetState(ctx, n), fleet.Targets(ctx, n)
+    st.load_aos(rigid, mem)
+    tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
+    a = _args(nat, 0, DT, DT)
+    torch.cuda.synchronize()
+    import time as _t
+    t0 = _t.perf_counter()
+    nat.check(ctx.lib.dsim_control(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a), None, None))
+    torch.cuda.synchronize()
+    el = _t.perf_counter() - t0
+    fb = _query(nat, ctx, 0)
+    assert fb > n // 20, fb                                      # a real queue, tens of thousands long
+    assert _query(nat, ctx, 1) == 0
+    assert el < 2.0, el                                          # worked off by the whole chip, not by 32 workgroups
+    got = st.mem_aos()
+    assert np.isfinite(got).all() and got[:, 7:13].min() >= 0.0 and got[:, 7:13].max() <= 1.0
+    idx = rng.choice(n, 3000, replace=False)
+    o = mem[idx].copy()
+    assert orc.Oracle([t]).control(rigid[idx], o, tgt[idx], DT)[0] == 0
+    # the active-set iterations solve lstsq problems whose rows are scaled by gamma Wv (up to 1e8): the fp32 inputs nu
+    # enter with that conditioning, so the increments are compared where the allocation is well inside the box and
+    # the clip decides the rest identically
+    both_clipped = ((got[idx, 7:13] <= 0) | (got[idx, 7:13] >= 1)) & ((o[:, 7:13] <= 0) | (o[:, 7:13] >= 1))
+    err = np.abs(got[idx, 7:13] - o[:, 7:13])
+    assert np.median(err) < 1e-5 and (err[both_clipped] == 0).all() and np.quantile(err, 0.99) < 2e-3
+    # a second call finds the queue emptied by the first
+    nat.check(ctx.lib.dsim_control(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a), None, None))
+    assert np.isfinite(st.mem_aos()).all()
+    ctx.close()
+
+
+def test_bench_launches_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` (no launcher around it) starts two ranks itself, before the parent touches the GPU;
+    with DSIM_BENCH_BACKEND=gloo both may share this box's one device.  One JSON line, n_gpus = 2, whole-job value."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSIM_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+                        "--workload", "config4"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dist"]["world_size"] == 2 and d["dist"]["backend"] == "gloo"
+    assert d["config"]["drones_per_gpu"] == 65536 and d["value"] > 1e8 and d["steps_timed"] >= 10
+    assert d["scaling"] == "weak" and "also" not in d

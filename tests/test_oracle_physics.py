@@ -292,3 +292,37 @@ def test_step_is_a_consistent_discretisation_of_the_damped_newton_euler_equation
         e_q = min(np.abs(q - ref[3:7] / np.linalg.norm(ref[3:7])).max(), np.abs(q + ref[3:7] / np.linalg.norm(ref[3:7])).max())
         errs.append(max(e_pos, e_vel, e_w, e_q))
     assert errs[0] < 5e-2 and 1.7 < errs[0] / errs[1] < 2.3 and 1.7 < errs[1] / errs[2] < 2.3, errs
+
+
+def test_threefry_known_answers_and_noise_moments():
+    """The rotor-noise generator (product-defined: the reference's draws are unseeded): Threefry4x32 against the
+    published known-answer vectors of Random123 (13 and 20 rounds — same round function, rotation constants and key
+    schedule as the 12-round form the product uses), and the N(0,1) moments of the Box-Muller normals built on it."""
+    import ctypes
+    L = orc.lib()
+    U4 = ctypes.c_uint32 * 4
+    f = L.orc_threefry4x32
+    f.argtypes = [U4, U4, ctypes.c_int]
+    f.restype = None
+    kat = [
+        (13, [0] * 4, [0] * 4, [0x531c7e4f, 0x39491ee5, 0x2c855a92, 0x3d6abf9a]),
+        (20, [0] * 4, [0] * 4, [0x9c6ca96a, 0xe17eae66, 0xfc10ecd4, 0x5256a7d8]),
+        (20, [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0, 0x082efa98, 0xec4e6c89],
+         [0x59cd1dbb, 0xb8879579, 0x86b5d00c, 0xac8b6d84]),
+    ]
+    for rounds, ctr, key, want in kat:
+        x = U4(*ctr)
+        f(x, U4(*key), rounds)
+        assert list(x) == want, (rounds, [hex(v) for v in x])
+    O = orc.Oracle([params.builtin_type("robobee")])
+    z = np.array([O.noise_normals(0x1234ABCD5, i, s, 4) for i in range(4000) for s in range(5)])   # 160 000 normals
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01
+    assert abs((z ** 3).mean()) < 0.03 and abs((z ** 4).mean() - 3.0) < 0.08          # skewness, kurtosis
+    assert np.abs(z).max() <= math.sqrt(2 * math.log(65536.0)) + 1e-9                  # 16-bit radius: 4.71 sigma
+    c = np.corrcoef(z.T)                                                               # the 8 normals of a block
+    assert np.abs(c - np.eye(8)).max() < 0.035          # 20 000 blocks: sampling sigma 0.007, 28 pairs
+    lag = np.corrcoef(z[:-1, 0], z[1:, 0])[0, 1]                                       # consecutive counters
+    assert abs(lag) < 0.035
+    # a hexa draws a second block (stream 1) for normals 8..11
+    h = O.noise_normals(77, 3, 9, 6)
+    assert h.shape == (12,) and len(set(np.round(h, 12))) == 12
