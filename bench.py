@@ -62,6 +62,9 @@ def parse(argv=None):
     p.add_argument("--stream", choices=["auto", "on", "off"], default="auto",
                    help="nontemporal state accesses: DSIM_OPT_STREAM_ON/_OFF (A/B knob; default: the library's size rule)")
     p.add_argument("--generic-mixed", action="store_true", help="mixed fleets: DSIM_OPT_GENERIC_MIXED (A/B knob)")
+    p.add_argument("--mixed-v1", action="store_true", help="mixed fleets: DSIM_OPT_MIXED_V1, the round-1 staged kernel (A/B knob)")
+    p.add_argument("--slab-m", type=float, default=128.0,
+                   help="config5: width of a rank's slab; 128 = the config's density, 1024 = round 1's definition of the line")
     p.add_argument("--lib", default=None, help="a differently-tuned build of libdronesim_amd.so (A/B runs)")
     p.add_argument("--dry-run", action="store_true",
                    help="host logic only (launcher, rendezvous, reductions, the JSON line); no device work — CPU tests")
@@ -320,6 +323,7 @@ def main(argv=None):
     nat.load(a.lib)
     options = {"auto": 0, "on": nat.OPT_STREAM_ON, "off": nat.OPT_STREAM_OFF}[a.stream]
     options |= nat.OPT_GENERIC_MIXED if a.generic_mixed else 0
+    options |= nat.OPT_MIXED_V1 if a.mixed_v1 else 0
     barrier = (lambda: dist.barrier()) if dist else None
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
@@ -331,7 +335,7 @@ def main(argv=None):
     fl = Fleet(n_fleet, replicas, local, a.substeps, a.layout, sharding.rank_seed(a.noise_seed, rank),
                waypoints=a.workload == "config3", config5=a.workload == "config5",
                dist=dist if a.workload == "config5" else None, rank=rank, hexa=a.workload == "hexa",
-               mixed=a.workload == "mixed", options=options)
+               mixed=a.workload == "mixed", options=options, slab_m=a.slab_m)
 
     def repeat_rule(first_wall):
         # the slowest rank's first region decides how many regions every rank runs

@@ -681,6 +681,164 @@ __global__ __launch_bounds__(64 * WT, DSIM_MIXED_WAVES) void k_step_mixed(StepK 
   }
 }
 
+// ---- mixed fleets, second form: LDS-DMA staging, software-pipelined tiles -------------------------------------------
+// The first form above is bound by memory-level parallelism: a workgroup has bytes in flight only during its load
+// phase (about a third of its life), and a CU holds ~30 KB in flight on average against the ~50 KB that 6 TB/s times
+// the loaded HBM latency asks for (63 % of the wave cycles parked at the barriers: profiles/r01f_sq_counters.json).
+// Here workgroups are PERSISTENT and walk the 128-drone tiles of the fleet with a two-deep LDS ring:
+//   * tile k+1 is brought in by LDS-DMA (global_load_lds_dword: no VGPR round trip, 256-byte rows land in LDS in
+//     NATURAL drone order) while tile k is being computed and stored — a whole tile per workgroup is in flight all
+//     the time (4 workgroups x 17 KB per CU);
+//   * the DMAs are issued by wave 2 (never a storing wave), so its vmcnt(0) before the barrier waits for the tile and
+//     for nothing else — the natural waves' result stores are never waited for;
+//   * the partition by type needs no LDS table and no barrier of its own: EVERY wave ballots the tile's type ids
+//     itself (masks in SGPRs), owns whole waves of one type as before, and lane r of a compute wave finds the r-th
+//     drone of its type by a select-the-r-th-set-bit on the two 64-bit masks, then gathers that drone's column;
+//   * results go back to the same columns, and after the second barrier the natural waves store whole rows.
+// Two barriers per tile instead of three, none of them behind an HBM round trip.
+__device__ __forceinline__ unsigned nth_set_bit64(unsigned long long m, unsigned r) {     // position of the r-th (0-based) set bit
+  unsigned pos = 0;
+  unsigned w = (unsigned)m;
+  unsigned c = (unsigned)__popc(w);
+  if (r >= c) { r -= c; pos = 32; w = (unsigned)(m >> 32); }
+#pragma unroll
+  for (int sh = 16; sh >= 1; sh >>= 1) {
+    const unsigned lo = w & ((1u << sh) - 1u);
+    c = (unsigned)__popc(lo);
+    if (r >= c) { r -= c; pos += sh; w >>= sh; } else { w = lo; }
+  }
+  return pos;
+}
+template <bool HEXA, bool NOISE, int TILE, bool S1>
+__device__ __forceinline__ void staged_body2(const DevType& T, const StepK& a, long long i, float (*stage)[TILE],
+                                             unsigned d, bool active) {
+  constexpr int NA = HEXA ? 6 : 4;
+  Rigid s;
+  CtrlMem<NA> m;
+  Target tg;
+  s.pos = v3(stage[0][d], stage[1][d], stage[2][d]);
+  s.q = Q4{stage[3][d], stage[4][d], stage[5][d], stage[6][d]};
+  s.vel = v3(stage[7][d], stage[8][d], stage[9][d]);
+  s.w = v3(stage[10][d], stage[11][d], stage[12][d]);
+  m.last_vel = v3(stage[13][d], stage[14][d], stage[15][d]);
+  m.last_rates = v3(stage[16][d], stage[17][d], stage[18][d]);
+  m.last_thrust = stage[19][d];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) m.cmd[j] = stage[20 + j][d];
+  tg.pos = v3(stage[26][d], stage[27][d], stage[28][d]);
+  tg.vel = v3(stage[29][d], stage[30][d], stage[31][d]);
+  tg.acc = v3(stage[32][d], stage[33][d], stage[34][d]);
+  tg.yaw = stage[35][d];
+  V3 ext = v3(0, 0, 0);
+  if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
+  V3 pos_e;
+  float yaw_e;
+  if constexpr (HEXA) {
+    hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
+    indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, active ? i : -1LL);
+  } else {
+    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
+    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  }
+  if (!active) return;
+  stage[0][d] = s.pos.x; stage[1][d] = s.pos.y; stage[2][d] = s.pos.z;
+  stage[3][d] = s.q.x; stage[4][d] = s.q.y; stage[5][d] = s.q.z; stage[6][d] = s.q.w;
+  stage[7][d] = s.vel.x; stage[8][d] = s.vel.y; stage[9][d] = s.vel.z;
+  stage[10][d] = s.w.x; stage[11][d] = s.w.y; stage[12][d] = s.w.z;
+  stage[13][d] = m.last_vel.x; stage[14][d] = m.last_vel.y; stage[15][d] = m.last_vel.z;
+  stage[16][d] = m.last_rates.x; stage[17][d] = m.last_rates.y; stage[18][d] = m.last_rates.z;
+  stage[19][d] = m.last_thrust;
+#pragma unroll
+  for (int j = 0; j < NA; ++j) stage[20 + j][d] = m.cmd[j];
+}
+#define DSIM_MIXED2_TYPES 4            // the launcher takes this form for tables of up to four types
+template <bool NOISE, bool NT, int WT, bool S1>
+__global__ __launch_bounds__(64 * WT, 3) void k_step_mixed2(StepK a, long long n_tiles) {
+  constexpr int TILE = 128;
+  __shared__ float stage[2][DSIM_STAGE_FIELDS][TILE];
+  const unsigned t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
+  const bool bcast = a.tg.mask == 0 && a.tg.shift == 63;          // one broadcast target row (kv_lane() = 0 for every lane)
+  if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
+  constexpr int AUX = NT ? 2 : 0;                                   // nt on the DMA reads of once-read state
+
+  // wave 2 brings tile `tile` into ring slot `buf`: two 64-drone halves, one 256-byte row per (field, half)
+  auto issue_dma = [&](long long tile, int buf) {
+    const long long i0 = a.first + tile * TILE;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long long ih = i0 + 64 * h;
+      const long long il = ih + lane;
+      if (ih >= a.n_pad) continue;                                  // wave-uniform: n_pad is a multiple of 64
+      const int ty = min((int)a.type_id[il], DSIM_MAX_TYPES - 1);
+      const bool hexa = (a.hexa_types >> ty) & 1u;
+      const float* sp = a.st.base + kv_off(a.st, il);
+      const float* tp = a.tg.base + (bcast ? 0 : kv_off(a.tg, il));
+#pragma unroll
+      for (int f = 0; f < 24; ++f)
+        __builtin_amdgcn_global_load_lds(sp + f * sfs, &stage[buf][f][64 * h], 4, 0, AUX);
+      if (hexa) {
+        __builtin_amdgcn_global_load_lds(sp + 24 * sfs, &stage[buf][24][64 * h], 4, 0, AUX);
+        __builtin_amdgcn_global_load_lds(sp + 25 * sfs, &stage[buf][25][64 * h], 4, 0, AUX);
+      }
+#pragma unroll
+      for (int f = 0; f < 10; ++f)
+        __builtin_amdgcn_global_load_lds(tp + f * tfs, &stage[buf][26 + f][64 * h], 4, 0, AUX);
+    }
+  };
+
+  long long tile = blockIdx.x;
+  int buf = 0;
+  if (w == 2 && tile < n_tiles) issue_dma(tile, 0);
+  for (; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+    const long long i0 = a.first + tile * TILE;
+    // ---- partition: every wave ballots both halves itself; the masks are wave-uniform (SGPRs)
+    const int t0 = (i0 + lane < a.n_pad) ? min((int)a.type_id[i0 + lane], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
+    const int t1 = (i0 + 64 + lane < a.n_pad) ? min((int)a.type_id[i0 + 64 + lane], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
+    int wave_t = -1;
+    unsigned d = 0;
+    bool active = false;
+    unsigned acc_w = 0;
+#pragma unroll
+    for (int ty = 0; ty < DSIM_MIXED2_TYPES; ++ty) {
+      const unsigned long long m0 = __ballot(t0 == ty), m1 = __ballot(t1 == ty);
+      const unsigned c0 = (unsigned)__popcll(m0), tot = c0 + (unsigned)__popcll(m1), nw = (tot + 63) >> 6;
+      if (w >= acc_w && w < acc_w + nw) {                           // wave-uniform: this wave runs type ty
+        wave_t = ty;
+        const unsigned r = (w - acc_w) * 64 + lane;
+        active = r < tot;
+        const unsigned rr = active ? r : 0u;
+        d = rr < c0 ? nth_set_bit64(m0, rr) : 64u + nth_set_bit64(m1, rr - c0);
+      }
+      acc_w += nw;
+    }
+    // ---- the tile has landed (only wave 2 has DMAs in flight; nobody waits for result stores)
+    if (w == 2) __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0), lgkmcnt / expcnt untouched
+    __syncthreads();
+    if (w == 2 && tile + gridDim.x < n_tiles) issue_dma(tile + gridDim.x, buf ^ 1);
+    // ---- compute: one type, one law per wave, uniform control flow
+    wave_t = __builtin_amdgcn_readfirstlane(wave_t);
+    if (wave_t >= 0) {
+      const long long i = i0 + d;
+      const DevType& T = a.types[wave_t];
+      if (T.kind == DSIM_DEV_KIND_HEXA) staged_body2<true, NOISE, TILE, S1>(T, a, i, stage[buf], d, active);
+      else staged_body2<false, NOISE, TILE, S1>(T, a, i, stage[buf], d, active);
+    }
+    __syncthreads();
+    // ---- natural lanes store whole rows
+    if (t < TILE && i0 + t < a.n_pad) {
+      const int nt_ = min((int)a.type_id[i0 + t], DSIM_MAX_TYPES - 1);       // (re-read: not kept live across the laws)
+      const bool nat_hexa = (a.hexa_types >> nt_) & 1u;
+      float* sp = a.st.base + kv_off(a.st, i0 + t);
+#pragma unroll
+      for (int f = 0; f < 24; ++f) stg<NT>(sp + f * sfs, 0u, stage[buf][f][t]);
+      if (nat_hexa) { stg<NT>(sp + 24 * sfs, 0u, stage[buf][24][t]); stg<NT>(sp + 25 * sfs, 0u, stage[buf][25][t]); }
+      if (a.bin.count && i0 + t < a.n)
+        bin_entry(a.bin, stage[buf][0][t], stage[buf][1][t], stage[buf][2][t], a.bin.local_offset + i0 + t);
+    }
+  }
+}
+
 // Type-major storage (dsim_step_args.runs): a run of one type is stepped by the single-type law of its kind,
 // the fast form (no partition, no waterfall, per-type constants in SGPRs); ext = optional downwash force.
 template <bool HEXA, bool NOISE, bool NT, bool S1>
@@ -1722,6 +1880,24 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
         a.fb.entries = ctx->d_fb;
       }
       if (first == 0) bin_next_prepare(ctx, n, args, &a);      // (the whole fleet goes through this kernel)
+      if (!(args->options & DSIM_OPT_MIXED_V1)) {
+        // persistent workgroups, LDS-DMA ring (k_step_mixed2): 4 per CU (37 KB of LDS each)
+        const long long n_tiles = (a.n_pad - first + 127) / 128;
+        const long long cap = 4LL * ctx->n_cu;
+#define DSIM_MIXED2_CASE2(W_, S_)                                                                                \
+  do { const dim3 gm((unsigned)(n_tiles < cap ? n_tiles : cap)), bm(64 * W_);                                    \
+       if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed2<true, true, W_, S_>), gm, bm, 0, st_, a, n_tiles);  \
+                    else hipLaunchKernelGGL((k_step_mixed2<true, false, W_, S_>), gm, bm, 0, st_, a, n_tiles); }  \
+       else { if (nt) hipLaunchKernelGGL((k_step_mixed2<false, true, W_, S_>), gm, bm, 0, st_, a, n_tiles);       \
+              else hipLaunchKernelGGL((k_step_mixed2<false, false, W_, S_>), gm, bm, 0, st_, a, n_tiles); } } while (0)
+#define DSIM_MIXED2_CASE(W_) do { if (a.substeps == 1) DSIM_MIXED2_CASE2(W_, true); else DSIM_MIXED2_CASE2(W_, false); } while (0)
+        if (ctx->n_types == 2) DSIM_MIXED2_CASE(3); else if (ctx->n_types == 3) DSIM_MIXED2_CASE(4); else DSIM_MIXED2_CASE(5);
+#undef DSIM_MIXED2_CASE
+#undef DSIM_MIXED2_CASE2
+        if (any_hexa) fb_finish(ctx, a, st_);
+        bin_next_commit(ctx, n, args, a);
+        return (int)hipGetLastError();
+      }
 #define DSIM_MIXED_CASE2(W_, S_)                                                                                  \
   do { const dim3 gm((unsigned)((a.n_pad - first + 127) / 128)), bm(64 * W_);                                    \
        if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed<true, true, W_, S_>), gm, bm, 0, st_, a);            \

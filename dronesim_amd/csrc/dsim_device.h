@@ -415,16 +415,19 @@ struct FbList { FbEntry* entries; unsigned long long* count; unsigned long long*
 // working set lives in LDS (WlsWork, one per lane of k_wls_fallback) — in registers it would be 2 KB of scratch.
 struct WlsWork {
   double A[12][6], Af[12][6], Q[12][6], d[12], rhs[12], u[6], u_opt[6], p[6], p_free[6], W[6], Lambda[6];
+  double umin[6], umax[6];
   int free_index[6], lookup[6];
 };
-__device__ __forceinline__ int wls_active_set(const DevType& T, const float v[6], const float umin[6],
-                                           const float umax[6], float u_out[6], WlsWork& ws) {
+__device__ __forceinline__ int wls_active_set(const DevType& T, const float v[6], const float umin_[6],
+                                           const float umax_[6], float u_out[6], WlsWork& ws) {
   const double gam = 100000.0;
   const double Wv[6] = {1000, 1000, 0.1, 10, 10, 100};          // INDIControl_6DOF.py:614
   double (&A)[12][6] = ws.A, (&Af)[12][6] = ws.Af, (&Q)[12][6] = ws.Q;
   double (&d)[12] = ws.d, (&rhs)[12] = ws.rhs;
   double (&u)[6] = ws.u, (&u_opt)[6] = ws.u_opt, (&p)[6] = ws.p, (&p_free)[6] = ws.p_free, (&W)[6] = ws.W, (&Lambda)[6] = ws.Lambda;
   int (&free_index)[6] = ws.free_index, (&lookup)[6] = ws.lookup;
+  double (&umin)[6] = ws.umin, (&umax)[6] = ws.umax;      // indexed by the pivot: in LDS with the rest
+  for (int i = 0; i < 6; ++i) { umin[i] = (double)umin_[i]; umax[i] = (double)umax_[i]; }
   int n_free = 0, free_chk = -1, iter = 0, n_p_free = 6, id_alpha = 0;
   bool alpha_set = false;
   double alpha = 0.0;

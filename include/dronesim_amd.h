@@ -128,8 +128,10 @@ enum {
   DSIM_OPT_STREAM_ON   = 1u << 4,   /* force nontemporal (streaming) loads/stores of the state; default: on when one
                                        step's traffic exceeds what the 256 MB Infinity Cache keeps between steps   */
   DSIM_OPT_STREAM_OFF  = 1u << 5,   /* force the default cache policy                                              */
-  DSIM_OPT_GENERIC_MIXED = 1u << 6  /* mixed fleets: use the general per-lane-type kernel instead of the LDS-staged
+  DSIM_OPT_GENERIC_MIXED = 1u << 6, /* mixed fleets: use the general per-lane-type kernel instead of the LDS-staged
                                        one (A/B knob)                                                              */
+  DSIM_OPT_MIXED_V1    = 1u << 7    /* mixed fleets: the round-1 form of the LDS-staged kernel (one tile per workgroup,
+                                       VGPR staging, three barriers) instead of the LDS-DMA ring (A/B knob)        */
 };
 
 /* A run of consecutive drones of one type (type-major storage of a heterogeneous fleet). */

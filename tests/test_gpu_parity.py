@@ -1509,11 +1509,13 @@ def test_device_logger_matches_reference_layout(gpu, tmp_path):
     assert ts.shape == (n, 10) and st.shape == (n, 20, 10) and ct.shape == (n, 12, 10)
     want = np.stack(want_rows, 2)
     assert np.abs(want[:, 7:10, -1]).min() > 1e-3                      # every Euler angle is live in this flight
-    # the log == the oracle's rows: copies exact, rpy within the per-row bound already asserted on the same values
-    np.testing.assert_array_equal(st, np.stack(obs_rows, 2))
+    # the log == the oracle's rows: copies exact (also == what env.step returned), rpy within the per-row bound
     cp = [0, 1, 2, 3, 4, 5, 6, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19]
+    np.testing.assert_array_equal(st[:, cp, :], np.stack(obs_rows, 2)[:, cp, :])
     np.testing.assert_array_equal(st[:, cp, :], want[:, cp, :])
-    assert np.abs(st[:, 7:10, :] - want[:, 7:10, :]).max() < 1e-5
+    for k in range(10):
+        tol = _obs_rpy_tol(want[:, 3:7, k])
+        assert (np.abs(st[:, 7:10, k] - want[:, 7:10, k]) <= tol).all(), k
     np.testing.assert_allclose(ts[3], np.arange(10) * 5 / 240)
     np.testing.assert_allclose(ct[2, 0:3, 4], xyz[2], atol=1e-6)
     path = log.save(str(tmp_path) + "/", "flight", drones=slice(1, 3))
@@ -1839,7 +1841,12 @@ def test_env_step_fused_observation_and_zero_copy_command(gpu, layout, noise):
                            env.state.rigid_aos(), None, r1, None, DT, dtc, 2, control=False, action=act)
         rows = obs.double().cpu().numpy()
         _check_obs_rows(f"two_call_loop obs[{layout}]", O, rows, env.state.rigid_aos(), last, None, [t])
-        np.testing.assert_array_equal(rows, env.observe().double().cpu().numpy())     # == the stand-alone kernel
+        # == the stand-alone observation kernel: copies bit for bit, the Euler angles to the last place or two (two
+        # compilations of the same polynomial atan2 / asin; each is held to _obs_rpy_tol against the oracle)
+        alone = env.observe().double().cpu().numpy()
+        cp = [c for c in range(20) if not 7 <= c < 10]
+        np.testing.assert_array_equal(rows[:, cp], alone[:, cp])
+        _check_obs_rows(f"two_call_loop obs[{layout}]", O, alone, env.state.rigid_aos(), last, None, [t])
         m0 = env.state.mem_aos()
         cmd, pos_e, yaw_e = ctrl.computeControlFromState(dtc, None, target_pos=torch.from_numpy(tpos.T.copy()).float().to(env.ctx.device),
                                                          target_rpy=np.array([0, 0, 0.3]))
@@ -1865,7 +1872,7 @@ def test_fused_observation_general_kernels_agree(gpu):
     act = torch.from_numpy(rng.uniform(0.3, 0.6, (n, 6)).astype(np.float32)).to(env.ctx.device)
     for _ in range(3):
         obs, *_ = env.step(act)
-        np.testing.assert_array_equal(obs.cpu().numpy(), env.observe().cpu().numpy())
+        np.testing.assert_array_equal(obs.cpu().numpy(), env.observe().cpu().numpy())     # both from k_observe here
     O = orc.Oracle(env.types)
     last = np.zeros((n, 6)); last[:, :] = act.double().cpu().numpy(); last[tid == 0, 4:6] = 0.0
     _check_obs_rows("fused_obs_general", O, obs.double().cpu().numpy(), env.state.rigid_aos(), last, tid, env.types)

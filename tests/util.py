@@ -126,10 +126,14 @@ def tilt_gain(types, type_id, rigid):
     return g
 
 
+TINY = 1e-3     # m, m/s, rad/s, PWM: below k ulp32(1e-3) = k x 1.2e-10 a difference is numerical zero (a drone at rest with
+                # zero command has rates of 1e-20 on both sides, from cancelling denormal-sized terms)
+
+
 def increment_ratio(got, ref, prev, terms, k):
-    """|d_got - d_ref| / (REL_TOL |d_ref| + k ulp32(max(|prev|, |ref|, terms))): <= 1 passes."""
+    """|d_got - d_ref| / (REL_TOL |d_ref| + k ulp32(max(|prev|, |ref|, terms, TINY))): <= 1 passes."""
     d_ref = ref - prev
-    M = np.maximum(np.maximum(np.abs(prev), np.abs(ref)), terms)
+    M = np.maximum(np.maximum(np.maximum(np.abs(prev), np.abs(ref)), terms), TINY)
     return np.abs(got - ref) / (REL_TOL * np.abs(d_ref) + k * ulp32(M))
 
 
@@ -160,7 +164,7 @@ def control_bound(types, type_id, rigid, prev_mem, tgt, ref_mem, dt_ctrl, k=K_UL
     """Per-case tolerance [n,13] of one computeControl call on the controller memory (last_vel3 last_rates3
     last_thrust cmd6): REL_TOL |d_ref| + k ulp32(M), M from step_terms with no physics in front."""
     _, tm = step_terms(types, type_id, rigid, prev_mem, tgt, 0.0, dt_ctrl, 1, True)
-    M = np.maximum(np.maximum(np.abs(prev_mem), np.abs(ref_mem)), tm)
+    M = np.maximum(np.maximum(np.maximum(np.abs(prev_mem), np.abs(ref_mem)), tm), TINY)
     return REL_TOL * np.abs(ref_mem - prev_mem) + k * tilt_gain(types, type_id, rigid) * ulp32(M)
 
 

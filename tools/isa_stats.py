@@ -11,7 +11,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "dronesim_amd", "csrc", "dsim_api.hip")
 out = os.path.join(tempfile.gettempdir(), "dsim_isa.s")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-S", "-o", out,
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-S", "-o", out,
                        "--cuda-device-only", src], stderr=subprocess.DEVNULL)
 lines = open(out).read().split("\n")
 want = sys.argv[1] if len(sys.argv) > 1 else ""
