@@ -66,11 +66,14 @@ __device__ __forceinline__ unsigned kv_lane(const KView& v, unsigned t) {
 }
 
 // ---- neighbour grid, bucket form (downwash P8 / adjacency) ---------------------------------------------------------
-// Uniform xy grid of cells >= the 10 m cut-off; every cell owns a bucket of DW_CAP entries (x, y, z, world index),
-// entries that find their bucket full go to one shared overflow list that every receiver scans too, so results never
-// depend on the capacity.  The step kernels can fill the grid for the NEXT Env.step themselves (BinK in StepK): the
-// new position is in registers when the state is stored, which removes the binning launch from the step chain.
-#define DW_CAP 192
+// Uniform xy grid of cells of HALF the 10 m cut-off or more (a receiver scans the 5 x 5 cells around its own: 625 m^2
+// for 5 m cells against the 900 m^2 of 3 x 3 cells of 10 m — 30 % fewer candidate pairs, and four times fewer drones
+// per cell counter); every cell owns a bucket of DW_CAP entries (x, y, z, world index), entries that find their bucket
+// full go to one shared overflow list that every receiver scans too, so results never depend on the capacity.  The
+// step kernels can fill the grid for the NEXT Env.step themselves (BinK in StepK): the new position is in registers
+// when the state is stored, which removes the binning launch from the step chain.
+#define DW_CAP 64
+#define DW_CUTOFF 10.0f
 struct BinK {
   int* count;          // [ncells + 2]: entries per cell; count[ncells] = overflow length.  null = no binning
   float4* buckets;     // [ncells][DW_CAP]
@@ -92,9 +95,9 @@ __device__ __forceinline__ void bin_entry(const BinK& b, float x, float y, float
   else b.overflow[atomicAdd(&b.count[b.nx * b.ny], 1)] = e;
 }
 
-// bucket form: grids of up to 16 384 cells with at most 2/3 DW_CAP = 128 entries per cell on average (BASELINE config 5:
-// one drone per m^2 = 100 per cell); the buckets take ncells * DW_CAP * 16 bytes of the workspace
-static inline bool dw_use_buckets(int64_t m, int64_t ncells) { return ncells <= 16384 && m <= ncells * (DW_CAP * 2 / 3); }
+// bucket form: grids of up to 65 536 cells with at most 5/8 DW_CAP = 40 entries per cell on average (BASELINE config 5:
+// one drone per m^2 = 25 per 5 m cell); the buckets take ncells * DW_CAP * 16 bytes of the workspace (67 MB at most)
+static inline bool dw_use_buckets(int64_t m, int64_t ncells) { return ncells <= 65536 && m <= ncells * (DW_CAP * 5 / 8); }
 // where the bucket form keeps things inside the workspace (ints): count x2 | 16-byte aligned buckets | overflow
 static inline void bucket_layout(int32_t* ws, long long ncells, int parity, BinK* b) {
   const long long cstride = ncells + 2;
@@ -709,26 +712,32 @@ __device__ __forceinline__ unsigned nth_set_bit64(unsigned long long m, unsigned
   }
   return pos;
 }
-template <bool HEXA, bool NOISE, int TILE, bool S1>
-__device__ __forceinline__ void staged_body2(const DevType& T, const StepK& a, long long i, float (*stage)[TILE],
-                                             unsigned d, bool active) {
+// LDS image of one 64-drone block: the block's rows as they lie in the wave-tiled state / target arrays
+// ([F][64] floats, field rows contiguous), so that a 16-byte-per-lane DMA moves four rows at once.
+struct Stage64 { float st[DSIM_NF_HEXA][64]; float tg[DSIM_NT][64]; };       // 26 + 10 rows = 9 KB
+template <bool HEXA, bool NOISE, bool S1>
+__device__ __forceinline__ void staged_body2(const DevType& T, const StepK& a, long long i, Stage64* tile, unsigned d,
+                                             bool active) {
   constexpr int NA = HEXA ? 6 : 4;
+  float (*st)[64] = tile[d >> 6].st;
+  float (*tt)[64] = tile[d >> 6].tg;
+  const unsigned c = d & 63u;
   Rigid s;
   CtrlMem<NA> m;
   Target tg;
-  s.pos = v3(stage[0][d], stage[1][d], stage[2][d]);
-  s.q = Q4{stage[3][d], stage[4][d], stage[5][d], stage[6][d]};
-  s.vel = v3(stage[7][d], stage[8][d], stage[9][d]);
-  s.w = v3(stage[10][d], stage[11][d], stage[12][d]);
-  m.last_vel = v3(stage[13][d], stage[14][d], stage[15][d]);
-  m.last_rates = v3(stage[16][d], stage[17][d], stage[18][d]);
-  m.last_thrust = stage[19][d];
+  s.pos = v3(st[0][c], st[1][c], st[2][c]);
+  s.q = Q4{st[3][c], st[4][c], st[5][c], st[6][c]};
+  s.vel = v3(st[7][c], st[8][c], st[9][c]);
+  s.w = v3(st[10][c], st[11][c], st[12][c]);
+  m.last_vel = v3(st[13][c], st[14][c], st[15][c]);
+  m.last_rates = v3(st[16][c], st[17][c], st[18][c]);
+  m.last_thrust = st[19][c];
 #pragma unroll
-  for (int j = 0; j < NA; ++j) m.cmd[j] = stage[20 + j][d];
-  tg.pos = v3(stage[26][d], stage[27][d], stage[28][d]);
-  tg.vel = v3(stage[29][d], stage[30][d], stage[31][d]);
-  tg.acc = v3(stage[32][d], stage[33][d], stage[34][d]);
-  tg.yaw = stage[35][d];
+  for (int j = 0; j < NA; ++j) m.cmd[j] = st[20 + j][c];
+  tg.pos = v3(tt[0][c], tt[1][c], tt[2][c]);
+  tg.vel = v3(tt[3][c], tt[4][c], tt[5][c]);
+  tg.acc = v3(tt[6][c], tt[7][c], tt[8][c]);
+  tg.yaw = tt[9][c];
   V3 ext = v3(0, 0, 0);
   if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
   V3 pos_e;
@@ -741,49 +750,45 @@ __device__ __forceinline__ void staged_body2(const DevType& T, const StepK& a, l
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   if (!active) return;
-  stage[0][d] = s.pos.x; stage[1][d] = s.pos.y; stage[2][d] = s.pos.z;
-  stage[3][d] = s.q.x; stage[4][d] = s.q.y; stage[5][d] = s.q.z; stage[6][d] = s.q.w;
-  stage[7][d] = s.vel.x; stage[8][d] = s.vel.y; stage[9][d] = s.vel.z;
-  stage[10][d] = s.w.x; stage[11][d] = s.w.y; stage[12][d] = s.w.z;
-  stage[13][d] = m.last_vel.x; stage[14][d] = m.last_vel.y; stage[15][d] = m.last_vel.z;
-  stage[16][d] = m.last_rates.x; stage[17][d] = m.last_rates.y; stage[18][d] = m.last_rates.z;
-  stage[19][d] = m.last_thrust;
+  st[0][c] = s.pos.x; st[1][c] = s.pos.y; st[2][c] = s.pos.z;
+  st[3][c] = s.q.x; st[4][c] = s.q.y; st[5][c] = s.q.z; st[6][c] = s.q.w;
+  st[7][c] = s.vel.x; st[8][c] = s.vel.y; st[9][c] = s.vel.z;
+  st[10][c] = s.w.x; st[11][c] = s.w.y; st[12][c] = s.w.z;
+  st[13][c] = m.last_vel.x; st[14][c] = m.last_vel.y; st[15][c] = m.last_vel.z;
+  st[16][c] = m.last_rates.x; st[17][c] = m.last_rates.y; st[18][c] = m.last_rates.z;
+  st[19][c] = m.last_thrust;
 #pragma unroll
-  for (int j = 0; j < NA; ++j) stage[20 + j][d] = m.cmd[j];
+  for (int j = 0; j < NA; ++j) st[20 + j][c] = m.cmd[j];
 }
 #define DSIM_MIXED2_TYPES 4            // the launcher takes this form for tables of up to four types
+// Requires the wave-tiled layout for state and targets (block = 64, field_stride = 64: the rows of a block are
+// contiguous) and a 26-field state; the launcher falls back to the first form otherwise.
 template <bool NOISE, bool NT, int WT, bool S1>
 __global__ __launch_bounds__(64 * WT, 3) void k_step_mixed2(StepK a, long long n_tiles) {
   constexpr int TILE = 128;
-  __shared__ float stage[2][DSIM_STAGE_FIELDS][TILE];
+  __shared__ __attribute__((aligned(16))) Stage64 ring[2][2];                // [slot][half]: 2 x 18 KB
   const unsigned t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
-  const bool bcast = a.tg.mask == 0 && a.tg.shift == 63;          // one broadcast target row (kv_lane() = 0 for every lane)
   if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
-  constexpr int AUX = NT ? 2 : 0;                                   // nt on the DMA reads of once-read state
+  constexpr int AUX = NT ? 2 : 0;                                           // nt on the DMA reads of once-read state
 
-  // wave 2 brings tile `tile` into ring slot `buf`: two 64-drone halves, one 256-byte row per (field, half)
+  // wave 2 brings tile `tile` into ring slot `buf`: per 64-drone half, 7 DMAs of 1 KB for the 26 state rows (6.5 KB,
+  // the last one half-masked) and 3 for the 10 target rows
   auto issue_dma = [&](long long tile, int buf) {
     const long long i0 = a.first + tile * TILE;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const long long ih = i0 + 64 * h;
-      const long long il = ih + lane;
-      if (ih >= a.n_pad) continue;                                  // wave-uniform: n_pad is a multiple of 64
-      const int ty = min((int)a.type_id[il], DSIM_MAX_TYPES - 1);
-      const bool hexa = (a.hexa_types >> ty) & 1u;
-      const float* sp = a.st.base + kv_off(a.st, il);
-      const float* tp = a.tg.base + (bcast ? 0 : kv_off(a.tg, il));
+      if (ih >= a.n_pad) continue;                                          // wave-uniform: n_pad is a multiple of 64
+      const float* sp = a.st.base + (ih >> 6) * a.st.block_stride + 4 * lane;       // 16 bytes per lane
+      const float* tp = a.tg.base + (ih >> 6) * a.tg.block_stride + 4 * lane;
+      float* ls = &ring[buf][h].st[0][0];
+      float* lt = &ring[buf][h].tg[0][0];
 #pragma unroll
-      for (int f = 0; f < 24; ++f)
-        __builtin_amdgcn_global_load_lds(sp + f * sfs, &stage[buf][f][64 * h], 4, 0, AUX);
-      if (hexa) {
-        __builtin_amdgcn_global_load_lds(sp + 24 * sfs, &stage[buf][24][64 * h], 4, 0, AUX);
-        __builtin_amdgcn_global_load_lds(sp + 25 * sfs, &stage[buf][25][64 * h], 4, 0, AUX);
-      }
-#pragma unroll
-      for (int f = 0; f < 10; ++f)
-        __builtin_amdgcn_global_load_lds(tp + f * tfs, &stage[buf][26 + f][64 * h], 4, 0, AUX);
+      for (int q = 0; q < 6; ++q) __builtin_amdgcn_global_load_lds(sp + 256 * q, ls + 256 * q, 16, 0, AUX);
+      if (lane < 32) __builtin_amdgcn_global_load_lds(sp + 256 * 6, ls + 256 * 6, 16, 0, AUX);       // rows 24, 25
+      __builtin_amdgcn_global_load_lds(tp, lt, 16, 0, AUX);
+      __builtin_amdgcn_global_load_lds(tp + 256, lt + 256, 16, 0, AUX);
+      if (lane < 32) __builtin_amdgcn_global_load_lds(tp + 512, lt + 512, 16, 0, AUX);               // rows 8, 9
     }
   };
 
@@ -821,20 +826,21 @@ __global__ __launch_bounds__(64 * WT, 3) void k_step_mixed2(StepK a, long long n
     if (wave_t >= 0) {
       const long long i = i0 + d;
       const DevType& T = a.types[wave_t];
-      if (T.kind == DSIM_DEV_KIND_HEXA) staged_body2<true, NOISE, TILE, S1>(T, a, i, stage[buf], d, active);
-      else staged_body2<false, NOISE, TILE, S1>(T, a, i, stage[buf], d, active);
+      if (T.kind == DSIM_DEV_KIND_HEXA) staged_body2<true, NOISE, S1>(T, a, i, ring[buf], d, active);
+      else staged_body2<false, NOISE, S1>(T, a, i, ring[buf], d, active);
     }
     __syncthreads();
     // ---- natural lanes store whole rows
     if (t < TILE && i0 + t < a.n_pad) {
       const int nt_ = min((int)a.type_id[i0 + t], DSIM_MAX_TYPES - 1);       // (re-read: not kept live across the laws)
       const bool nat_hexa = (a.hexa_types >> nt_) & 1u;
-      float* sp = a.st.base + kv_off(a.st, i0 + t);
+      float* sp = a.st.base + ((i0 + t) >> 6) * a.st.block_stride + lane;
+      float (*rows)[64] = ring[buf][w].st;
 #pragma unroll
-      for (int f = 0; f < 24; ++f) stg<NT>(sp + f * sfs, 0u, stage[buf][f][t]);
-      if (nat_hexa) { stg<NT>(sp + 24 * sfs, 0u, stage[buf][24][t]); stg<NT>(sp + 25 * sfs, 0u, stage[buf][25][t]); }
+      for (int f = 0; f < 24; ++f) stg<NT>(sp + f * 64, 0u, rows[f][lane]);
+      if (nat_hexa) { stg<NT>(sp + 24 * 64, 0u, rows[24][lane]); stg<NT>(sp + 25 * 64, 0u, rows[25][lane]); }
       if (a.bin.count && i0 + t < a.n)
-        bin_entry(a.bin, stage[buf][0][t], stage[buf][1][t], stage[buf][2][t], a.bin.local_offset + i0 + t);
+        bin_entry(a.bin, rows[0][lane], rows[1][lane], rows[2][lane], a.bin.local_offset + i0 + t);
     }
   }
 }
@@ -1336,27 +1342,33 @@ __global__ __launch_bounds__(256) void k_dw_bin(DwK a, BinK b, BinRange r) {
   if (j >= r.j1) return;
   bin_entry(b, dw_pos(a, j, 0), dw_pos(a, j, 1), dw_pos(a, j, 2), j);
 }
+// one candidate's term of formula P8, branch-free (a wave almost always holds a lane that passes the test, so a branch
+// only adds its own overhead): the result is selected, never skipped
 __device__ __forceinline__ float dw_pair(float4 p, float x, float y, float z, float pr, float d0, float d1, float d2c) {
   const float dz = p.z - z, dx = p.x - x, dy = p.y - y;
   const float dd = dx * dx + dy * dy;
-  if (!(dz > 0.0f && dd < 100.0f)) return 0.0f;                 // BaseAviary.py:1752
-  const float r = pr * DSIM_RCP(4.0f * dz);
-  const float beta = d1 * dz + d2c;                             // :1754
-  return -(d0 * r * r) * __expf(-0.5f * dd * DSIM_RCP(beta * beta));   // :1753, 1755
+  const bool hit = dz > 0.0f && dd < DW_CUTOFF * DW_CUTOFF;     // BaseAviary.py:1752
+  const float dzs = hit ? dz : 1.0f;                            // keeps the rejected lanes' arithmetic finite
+  const float r = pr * DSIM_RCP(4.0f * dzs);
+  const float beta = d1 * dzs + d2c;                            // :1754
+  const float term = -(d0 * r * r) * __expf(-0.5f * dd * DSIM_RCP(beta * beta));   // :1753, 1755
+  return hit ? term : 0.0f;
 }
-// Cell-centred query.  One workgroup per (cell, chunk of 32 receivers of that cell): the nine buckets around the cell
-// are copied to LDS once (coalesced 16-byte rows), then DW_LPB lanes per receiver stride the LDS copy together — every
-// wave-instruction reads DW_LPB consecutive entries that its 8 receivers share (LDS broadcast, conflict-free) — and
-// reduce by shuffles.  At BASELINE config 5's density (one drone per m^2: ~100 per cell, ~900 candidates per receiver)
-// the candidates of a cell are read from L2 once per chunk instead of once per receiver.  Receivers that sit in the
-// overflow list are handled by the last DW_OVF_GROUPS workgroups straight from global memory.  The kernel also zeroes
-// the count buffer of the NEXT grid build (double-buffered: no memset on the stream).
+// Cell-centred query.  One workgroup per cell: the buckets of the (2 rings + 1)^2 cells around it are copied to LDS
+// once — all counts first, then one flattened pass, so every global load of the fill is in flight together — and the
+// cell's receivers are taken 32 at a time, DW_LPB lanes each: every wave-instruction reads DW_LPB consecutive LDS
+// entries that its 8 receivers share (16-byte broadcast reads, conflict-free), partial sums are reduced by shuffles.
+// At BASELINE config 5's density (one drone per m^2: 25 per 5 m cell, 625 candidates per receiver) the candidates
+// come from L2 once per cell instead of once per receiver.  Receivers that sit in the overflow list are handled by
+// the last DW_OVF_GROUPS workgroups straight from global memory.  The kernel also zeroes the count buffer of the NEXT
+// grid build (double-buffered: no memset on the stream).
 #define DW_LPB 8
-#define DW_RPB 32                      // receivers per workgroup
-#define DW_CHUNKS (DW_CAP / DW_RPB)
+#define DW_RPB 32                      // receivers per pass
+#define DW_NBR 25                      // (2 * 2 + 1)^2 cells at most
 #define DW_OVF_GROUPS 16
-__global__ __launch_bounds__(256) void k_dw_query_cell(DwK a, BinK b) {
-  __shared__ float4 tile[9 * DW_CAP];
+__global__ __launch_bounds__(256) void k_dw_query_cell(DwK a, BinK b, int rings) {
+  __shared__ float4 tile[DW_NBR * DW_CAP];
+  __shared__ int nb_cell[DW_NBR], nb_cnt[DW_NBR];
   const int ncells = b.nx * b.ny;
   const unsigned t = threadIdx.x;
   {
@@ -1365,29 +1377,9 @@ __global__ __launch_bounds__(256) void k_dw_query_cell(DwK a, BinK b) {
   }
   const int sub = (int)(t % DW_LPB), r_in = (int)(t / DW_LPB);
   const int n_ovf = b.count[ncells];
-  float4 me;
-  bool have = false;
-  int total = 0;
-  int cx = 0, cy = 0;
-  if ((int)blockIdx.x < ncells * DW_CHUNKS) {
-    const int c = (int)blockIdx.x / DW_CHUNKS, ch = (int)blockIdx.x % DW_CHUNKS;      // workgroup-uniform
-    const int cnt_c = min(b.count[c], DW_CAP);
-    if (ch * DW_RPB >= cnt_c) return;                                                  // no receivers in this chunk
-    cx = c % b.nx; cy = c / b.nx;
-    for (int yy = max(cy - 1, 0); yy <= min(cy + 1, b.ny - 1); ++yy)
-      for (int xx = max(cx - 1, 0); xx <= min(cx + 1, b.nx - 1); ++xx) {
-        const int cc = yy * b.nx + xx;
-        const int cnt = min(b.count[cc], DW_CAP);                                      // scalar load
-        const float4* __restrict__ src = b.buckets + (long long)cc * DW_CAP;
-        for (int e = (int)t; e < cnt; e += 256) tile[total + e] = src[e];
-        total += cnt;
-      }
-    __syncthreads();
-    const int r = ch * DW_RPB + r_in;
-    if (r < cnt_c) { me = b.buckets[(long long)c * DW_CAP + r]; have = true; }
-  } else {
+  if ((int)blockIdx.x >= ncells) {
     // receivers that overflowed their bucket: grid-stride over the overflow list, candidates from global memory
-    const int g = (int)blockIdx.x - ncells * DW_CHUNKS;
+    const int g = (int)blockIdx.x - ncells;
     for (int r = g * DW_RPB + r_in; r < n_ovf; r += DW_OVF_GROUPS * DW_RPB) {
       const float4 m2 = b.overflow[r];
       const long long i = (long long)__float_as_int(m2.w) - a.local_offset;
@@ -1397,8 +1389,8 @@ __global__ __launch_bounds__(256) void k_dw_query_cell(DwK a, BinK b) {
       int ox, oy;
       dw_cell(a, m2.x, m2.y, ox, oy);
       float fz = 0.0f;
-      for (int yy = max(oy - 1, 0); yy <= min(oy + 1, b.ny - 1); ++yy)
-        for (int xx = max(ox - 1, 0); xx <= min(ox + 1, b.nx - 1); ++xx) {
+      for (int yy = max(oy - rings, 0); yy <= min(oy + rings, b.ny - 1); ++yy)
+        for (int xx = max(ox - rings, 0); xx <= min(ox + rings, b.nx - 1); ++xx) {
           const int cc = yy * b.nx + xx;
           const int cnt = min(b.count[cc], DW_CAP);
           const float4* __restrict__ src = b.buckets + (long long)cc * DW_CAP;
@@ -1411,27 +1403,54 @@ __global__ __launch_bounds__(256) void k_dw_query_cell(DwK a, BinK b) {
     }
     return;
   }
-  long long i = -1;
-  if (have) {
-    i = (long long)__float_as_int(me.w) - a.local_offset;
-    if (i < 0 || i >= a.n) have = false;                                               // another rank's drone: a candidate only
+  const int c = (int)blockIdx.x;                                                       // this workgroup's cell
+  const int cnt_c = min(b.count[c], DW_CAP);
+  if (cnt_c == 0) return;                                                              // nobody to serve here
+  const int cx = c % b.nx, cy = c / b.nx;
+  const int side = 2 * rings + 1;
+  if ((int)t < side * side) {                                                          // all neighbour counts at once
+    const int xx = cx - rings + (int)t % side, yy = cy - rings + (int)t / side;
+    const bool in = xx >= 0 && xx < b.nx && yy >= 0 && yy < b.ny;
+    const int cc = in ? yy * b.nx + xx : 0;
+    nb_cell[t] = cc;
+    nb_cnt[t] = in ? min(b.count[cc], DW_CAP) : 0;
   }
-  float fz = 0.0f;
-  if (have) {
-    const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
-    const float pr = T.prop_radius, d0 = T.dw[0], d1 = T.dw[1], d2c = T.dw[2];
-    int e = sub;
-    for (; e + DW_LPB < total; e += 2 * DW_LPB) {                                      // two candidates in flight per lane
-      const float4 p0 = tile[e], p1 = tile[e + DW_LPB];
-      fz += dw_pair(p0, me.x, me.y, me.z, pr, d0, d1, d2c);
-      fz += dw_pair(p1, me.x, me.y, me.z, pr, d0, d1, d2c);
+  __syncthreads();
+  int total = 0;
+  for (int k = 0; k < side * side; ++k) total += nb_cnt[k];
+  for (int e = (int)t; e < total; e += 256) {                                          // flattened fill: loads back to back
+    int k = 0, base = 0;
+    while (e >= base + nb_cnt[k]) { base += nb_cnt[k]; ++k; }
+    tile[e] = b.buckets[(long long)nb_cell[k] * DW_CAP + (e - base)];
+  }
+  __syncthreads();
+  for (int r0 = 0; r0 < cnt_c; r0 += DW_RPB) {
+    const int r = r0 + r_in;
+    bool have = r < cnt_c;
+    float4 me = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    long long i = -1;
+    if (have) {
+      me = b.buckets[(long long)c * DW_CAP + r];
+      i = (long long)__float_as_int(me.w) - a.local_offset;
+      if (i < 0 || i >= a.n) have = false;                                             // another rank's drone: a candidate only
     }
-    if (e < total) fz += dw_pair(tile[e], me.x, me.y, me.z, pr, d0, d1, d2c);
-    for (int k = sub; k < n_ovf; k += DW_LPB) fz += dw_pair(b.overflow[k], me.x, me.y, me.z, pr, d0, d1, d2c);
-  }
+    float fz = 0.0f;
+    if (have) {
+      const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
+      const float pr = T.prop_radius, d0 = T.dw[0], d1 = T.dw[1], d2c = T.dw[2];
+      int e = sub;
+      for (; e + DW_LPB < total; e += 2 * DW_LPB) {                                    // two candidates in flight per lane
+        const float4 p0 = tile[e], p1 = tile[e + DW_LPB];
+        fz += dw_pair(p0, me.x, me.y, me.z, pr, d0, d1, d2c);
+        fz += dw_pair(p1, me.x, me.y, me.z, pr, d0, d1, d2c);
+      }
+      if (e < total) fz += dw_pair(tile[e], me.x, me.y, me.z, pr, d0, d1, d2c);
+      for (int k = sub; k < n_ovf; k += DW_LPB) fz += dw_pair(b.overflow[k], me.x, me.y, me.z, pr, d0, d1, d2c);
+    }
 #pragma unroll
-  for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
-  if (have && sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz; }
+    for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
+    if (have && sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz; }
+  }
 }
 
 // DW_LPR lanes per SORTED world entry; the entries that belong to this rank's shard are the
@@ -1880,7 +1899,11 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
         a.fb.entries = ctx->d_fb;
       }
       if (first == 0) bin_next_prepare(ctx, n, args, &a);      // (the whole fleet goes through this kernel)
-      if (!(args->options & DSIM_OPT_MIXED_V1)) {
+      // the LDS-DMA ring moves whole 1 KB row groups: it needs the wave-tiled layout [n/64][F][64] for the state
+      // (26 fields: a table with a morphing hexa) and for per-drone targets
+      const bool tiled = state.block == 64 && state.field_stride == 64 && ctx->max_act == 6 &&
+                         !(args->options & DSIM_OPT_BCAST_TGT) && targets.block == 64 && targets.field_stride == 64;
+      if (tiled && !(args->options & DSIM_OPT_MIXED_V1)) {
         // persistent workgroups, LDS-DMA ring (k_step_mixed2): 4 per CU (37 KB of LDS each)
         const long long n_tiles = (a.n_pad - first + 127) / 128;
         const long long cap = 4LL * ctx->n_cu;
@@ -2103,7 +2126,10 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
   if (ctx && g && ctx->n_types > 1 && !g->type_id) return DSIM_E_ARG;
   DwK a;
   const hipStream_t st_ = (hipStream_t)stream;
-  int rc = grid_build(ctx, st_, n, state, g, 10.0f, &a, true);
+  // bucket form: cells of half the cut-off or more (two rings of neighbours below 10 m); counting-sort form: >= 10 m
+  if (!g) return DSIM_E_ARG;
+  const bool bucket_form = g->nx > 0 && g->ny > 0 && dw_use_buckets(g->m, (int64_t)g->nx * g->ny);
+  int rc = grid_build(ctx, st_, n, state, g, bucket_form ? 0.5f * DW_CUTOFF : DW_CUTOFF, &a, true);
   if (rc) return rc;
   a.force_out = force_out;
   if (a.buckets) {
@@ -2112,7 +2138,8 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
     b.count = a.count; b.buckets = a.buckets; b.overflow = a.overflow;
     b.xmin = a.xmin; b.ymin = a.ymin; b.inv_cell = a.inv_cell; b.nx = a.nx; b.ny = a.ny; b.local_offset = a.local_offset;
     const long long ncells = (long long)a.nx * a.ny;
-    hipLaunchKernelGGL(k_dw_query_cell, dim3((unsigned)(ncells * DW_CHUNKS + DW_OVF_GROUPS)), dim3(256), 0, st_, a, b);
+    hipLaunchKernelGGL(k_dw_query_cell, dim3((unsigned)(ncells + DW_OVF_GROUPS)), dim3(256), 0, st_, a, b,
+                       g->cell >= DW_CUTOFF ? 1 : 2);
   }
   else hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m * DW_LPR)), dim3(256), 0, st_, a);
   return (int)hipGetLastError();

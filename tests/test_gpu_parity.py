@@ -526,17 +526,19 @@ def test_hexa_fused_step_vs_oracle(gpu, substeps, layout):
     ctx.close()
 
 
+@pytest.mark.parametrize("layout,v1", [("soa", False), ("tile64", False), ("tile64", True)])
 @pytest.mark.parametrize("sub", [1, 2])
-def test_mixed_fleet_vs_oracle(gpu, sub):
+def test_mixed_fleet_vs_oracle(gpu, sub, layout, v1):
     """Config 5 layout: even index robobee (quad INDI), odd index hexa_6DOF (6DOF INDI + WLS), one
-    type_id byte per drone; in-kernel noise on."""
+    type_id byte per drone; in-kernel noise on.  Wave-tiled storage takes the LDS-DMA ring (k_step_mixed2), plain SoA
+    (or DSIM_OPT_MIXED_V1) the one-tile-per-workgroup form."""
     nat, fleet = gpu
     n = 3000
     types = [params.builtin_type("robobee"), params.builtin_type("hexa_6DOF")]
     ctx = fleet.Context(types)
     assert ctx.n_fields == 26
-    st = fleet.FleetState(ctx, n)
-    tg = fleet.Targets(ctx, n)
+    st = fleet.FleetState(ctx, n, layout)
+    tg = fleet.Targets(ctx, n, layout)
     rigid, mem, tgt = random_fleet(np.random.default_rng(41), n, n_act=6, tilt=0.3, rate=1.0)
     tid = (np.arange(n) % 2).astype(np.uint8)
     mem[tid == 0, 11:13] = 0.0
@@ -545,7 +547,8 @@ def test_mixed_fleet_vs_oracle(gpu, sub):
     tid_dev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device)
     tid_dev[:n] = torch.from_numpy(tid)
     seed, sidx = 99, 5
-    a = _args(nat, sub, DT, float(np.float32(sub / 240)), seed=seed, step_index=sidx, type_id=tid_dev)
+    a = _args(nat, sub, DT, float(np.float32(sub / 240)), seed=seed, step_index=sidx, type_id=tid_dev,
+              options=nat.OPT_MIXED_V1 if v1 else 0)
     nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
     O = orc.Oracle(types)
     nz = np.zeros((n, sub, 12))
@@ -557,7 +560,7 @@ def test_mixed_fleet_vs_oracle(gpu, sub):
             nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
     r0, m0 = rigid.copy(), mem.copy()
     assert O.step(rigid, mem, tgt, sub, DT, float(np.float32(sub / 240)), noise=nz, type_id=tid) == 0
-    assert_step_parity(f"mixed_fleet[{sub}]", types, tid, r0, m0, tgt, st.rigid_aos(), st.mem_aos(), rigid, mem, DT,
+    assert_step_parity(f"mixed_fleet[{sub},{layout},v1={v1}]", types, tid, r0, m0, tgt, st.rigid_aos(), st.mem_aos(), rigid, mem, DT,
                        float(np.float32(sub / 240)), sub)
     ctx.close()
 
@@ -686,9 +689,9 @@ def test_downwash_vs_bruteforce_oracle(gpu):
 
 
 def test_downwash_bucket_grid_with_overflowing_cells(gpu):
-    """The bucket form of the neighbour grid (small worlds: one binning kernel instead of count + scan + scatter):
-    a swarm of 700 drones packed into one 10 m cell overflows its 32-entry bucket many times over; the overflow list
-    keeps the result equal to the brute-force sum."""
+    """The bucket form of the neighbour grid (one binning pass, cell-centred LDS-tiled query): a swarm of 700 drones
+    packed into a 7 m square overflows the 64-entry buckets of its 5 m cells many times over; the overflow list keeps
+    the result equal to the brute-force sum."""
     nat, fleet = gpu
     from dronesim_amd.downwash import Downwash
     n = 2500
@@ -701,7 +704,8 @@ def test_downwash_bucket_grid_with_overflowing_cells(gpu):
     st.load_aos(rigid, mem)
     dw = Downwash(ctx, st)
     f = dw.compute().cpu().numpy()
-    assert ctx.lib.dsim_downwash_workspace(n, 33, 33) > 4 * 33 * 33 * 32        # this shape takes the bucket form
+    g = dw._last
+    assert g.cell == 5.0 and ctx.lib.dsim_downwash_prebin_ok(g.m, g.nx, g.ny) == 1      # this shape takes the bucket form
     ref = orc.Oracle([params.builtin_type("robobee")]).downwash(rigid, rigid[:, 0:3])
     assert (ref[:700] < 0).sum() > 600
     err = np.abs(f[2, :n] - ref) / (np.abs(ref) + 1e-3)
@@ -1172,7 +1176,7 @@ def test_graph_replay_hexa_fleet(gpu):
     envs, tgts = [], []
     for _ in range(2):
         e = CtrlAviary(["robobee", "hexa_6DOF"], n, initial_xyzs=xyz, aggregate_phy_steps=1, noise_seed=99, dict_io=False,
-                       type_ids=tid)
+                       type_ids=tid, layout="tile64")          # wave-tiled: the persistent LDS-DMA ring kernel under capture
         t = Targets(e.ctx, n); t.set(pos=f32(xyz + 0.2).T, yaw=0.2)
         envs.append(e); tgts.append(t)
     for _ in range(12):
@@ -1420,16 +1424,22 @@ def test_action_adaptor_envs_vs_oracle(gpu, mode):
         act = f32(act)
         r0, m0 = env.state.rigid_aos(), env.state.mem_aos()    # every step from the device's previous state
         obs, reward, done, info = env.step(torch.from_numpy(act.astype(np.float32)))
-        rigid, mem = r0.copy(), m0.copy()
-        assert O.adaptor_step(0 if mode == "velocity" else 1, rigid, mem, act, 5, DT, dtc) == 0
-        # the adaptor's targets: velocity mode tracks (own position, commanded velocity); rate mode has none
-        tgt = np.concatenate([r0[:, 0:3], np.zeros((n, 7))], 1)
+        got_r, got_m = env.state.rigid_aos(), env.state.mem_aos()
+        # (a) the law inside _preprocessAction, on the state BEFORE the physics: the oracle's adaptor step with no
+        # sub-steps is exactly that control call
+        rc0, mem = r0.copy(), m0.copy()
+        assert O.adaptor_step(0 if mode == "velocity" else 1, rc0, mem, act, 0, DT, dtc) == 0
+        tgt = np.concatenate([r0[:, 0:3], np.zeros((n, 7))], 1)       # velocity mode tracks (own position, commanded velocity)
         if mode == "velocity":
             nrm = np.linalg.norm(act[:, 0:3], axis=1, keepdims=True)
             tgt[:, 3:6] = t.max_speed_kmh / 3.6 * np.abs(act[:, 3:4]) * np.divide(act[:, 0:3], nrm, out=np.zeros((n, 3)), where=nrm > 0)
-        # control runs first here, so the wrench terms follow the NEW command
-        assert_step_parity(f"adaptor_env[{mode}]", [t], None, r0, m0, tgt, env.state.rigid_aos(), env.state.mem_aos(),
-                           rigid, mem, DT, dtc, 5, action=mem[:, 7:11])
+        assert_control_parity(f"adaptor_env[{mode}] control", [t], None, r0, m0, tgt, got_m, mem, dtc)
+        # (b) the physics with the command the DEVICE computed (its fp32 rounding is judged in (a), not again here)
+        rigid = r0.copy()
+        a6 = np.zeros((n, 6)); a6[:, :4] = got_m[:, 7:11]
+        O.physics(rigid, got_m.copy(), 5, DT, action=a6)
+        assert_step_parity(f"adaptor_env[{mode}] physics", [t], None, r0, got_m, tgt, got_r, None, rigid, None, DT, dtc, 5,
+                           control=False, action=got_m[:, 7:11])
         np.testing.assert_array_equal(obs[:, 16:20].cpu().numpy(), env.state.mem_aos()[:, 7:11].astype(np.float32))  # echoed command
     env.close()
 
@@ -1625,7 +1635,8 @@ def test_randomised_airframes_vs_oracle(gpu, n_types):
     types = types[:n_types]
     n = 4000
     ctx = fleet.Context(types)
-    st, tg = fleet.FleetState(ctx, n), fleet.Targets(ctx, n)
+    layout = "tile64" if n_types == 4 else "soa"        # 4 types, wave-tiled: the LDS-DMA ring with 5 waves per tile
+    st, tg = fleet.FleetState(ctx, n, layout), fleet.Targets(ctx, n, layout)
     rigid, mem, tgt = random_fleet(rng, n, n_act=6, tilt=0.3, rate=1.0)
     tid = rng.integers(0, n_types, n).astype(np.uint8)
     is_hexa = np.isin(tid, (2, 5))
@@ -1716,10 +1727,11 @@ def test_kernels_stay_inside_their_views(gpu, layout, fleet_kind):
                                    bufs["yaw_e"][1].data_ptr()))
     nat.check(ctx.lib.dsim_observe(ctx.handle, s, n, sv, None, bufs["obs"][1].data_ptr(), 16 + ctx.n_act))
     g = nat.DownwashArgs()
-    nx = ny = 4
+    nx = ny = 8
+    assert ctx.lib.dsim_downwash_prebin_ok(n, nx, ny) == 1          # bucket form: the step kernel can fill it ahead
     ws = torch.empty((ctx.lib.dsim_downwash_workspace(n, nx, ny),), dtype=torch.int32, device=dev)
     g.pos_all, g.m, g.m_pad = None, n, n
-    g.xmin, g.ymin, g.cell, g.nx, g.ny = 0.0, 0.0, 10.0, nx, ny
+    g.xmin, g.ymin, g.cell, g.nx, g.ny = 0.0, 0.0, 5.0, nx, ny
     g.workspace, g.workspace_len, g.type_id, g.local_offset = ws.data_ptr(), ws.numel(), tp, 0
     nat.check(ctx.lib.dsim_downwash(ctx.handle, s, n, sv, ctypes.byref(g), bufs["force"][1].data_ptr()))
     # the remaining entry points: field-major observation, adjacency, and (quads) adaptor / chained / trajectory sampler
