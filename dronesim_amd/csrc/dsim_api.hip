@@ -845,6 +845,96 @@ __global__ __launch_bounds__(64 * WT, 3) void k_step_mixed2(StepK a, long long n
   }
 }
 
+// ---- mixed fleets, third form: one tile per workgroup, LDS-DMA staging, partition by ballots ---------------------------
+// The ring above keeps a tile per workgroup in flight at all times, but its 37 KB of LDS leave a CU only 12 waves, and
+// with two barriers per tile three waves per SIMD cannot keep the vector pipe busy: it measured SLOWER (227 us) than the
+// first form (211 us) at 4 194 304 drones.  What the first form lacks is waves, not prefetch depth: this form keeps its
+// one-tile-per-workgroup shape (the hardware overlaps workgroups) and removes what limits their number and speed —
+//   * staging in NATURAL drone order by LDS-DMA (no VGPR round trip, no staging ds_writes): 18 KB instead of 27.6 KB
+//     per workgroup, so a CU holds 8 of them instead of 5;
+//   * the partition by type needs no LDS table and no barrier (every wave ballots the tile's type ids itself and finds
+//     its drones by select-the-r-th-set-bit, as in the ring): two barriers per tile instead of three.
+// TILED: wave-tiled layout (rows of a block contiguous) -> 10 DMAs of 1 KB per half; otherwise 36 row DMAs of 256 B.
+template <bool NOISE, bool NT, int WT, bool S1, bool TILED>
+__global__ __launch_bounds__(64 * WT, 4) void k_step_mixed3(StepK a) {
+  constexpr int TILE = 128;
+  __shared__ __attribute__((aligned(16))) Stage64 tile[2];                  // [half]: 18 KB
+  const unsigned t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const long long i0 = a.first + (long long)blockIdx.x * TILE;
+  if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
+  constexpr int AUX = NT ? 2 : 0;
+  const long long ih = i0 + 64 * (long long)w;
+  if (w < 2 && ih < a.n_pad) {                                              // each natural wave brings its own half in
+    if (TILED) {
+      const float* sp = a.st.base + (ih >> 6) * a.st.block_stride + 4 * lane;       // 16 bytes per lane
+      const float* tp = a.tg.base + (ih >> 6) * a.tg.block_stride + 4 * lane;
+      float* ls = &tile[w].st[0][0];
+      float* lt = &tile[w].tg[0][0];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) __builtin_amdgcn_global_load_lds(sp + 256 * q, ls + 256 * q, 16, 0, AUX);
+      if (lane < 32) __builtin_amdgcn_global_load_lds(sp + 256 * 6, ls + 256 * 6, 16, 0, AUX);       // rows 24, 25
+      __builtin_amdgcn_global_load_lds(tp, lt, 16, 0, AUX);
+      __builtin_amdgcn_global_load_lds(tp + 256, lt + 256, 16, 0, AUX);
+      if (lane < 32) __builtin_amdgcn_global_load_lds(tp + 512, lt + 512, 16, 0, AUX);               // rows 8, 9
+    } else {
+      const long long il = ih + lane;
+      const float* sp = a.st.base + kv_off(a.st, il);
+      const float* tp = a.tg.base + kv_off(a.tg, il);                       // (a broadcast row: kv_off = 0 for every lane)
+      const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
+      const bool hexa = (a.hexa_types >> min((int)a.type_id[il], DSIM_MAX_TYPES - 1)) & 1u;
+#pragma unroll
+      for (int f = 0; f < 24; ++f) __builtin_amdgcn_global_load_lds(sp + f * sfs, &tile[w].st[f][0], 4, 0, AUX);
+      if (hexa) {
+        __builtin_amdgcn_global_load_lds(sp + 24 * sfs, &tile[w].st[24][0], 4, 0, AUX);
+        __builtin_amdgcn_global_load_lds(sp + 25 * sfs, &tile[w].st[25][0], 4, 0, AUX);
+      }
+#pragma unroll
+      for (int f = 0; f < 10; ++f) __builtin_amdgcn_global_load_lds(tp + f * tfs, &tile[w].tg[f][0], 4, 0, AUX);
+    }
+  }
+  // ---- partition (overlaps the DMAs): every wave ballots both halves itself; the masks are wave-uniform (SGPRs)
+  const int t0 = (i0 + lane < a.n_pad) ? min((int)a.type_id[i0 + lane], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
+  const int t1 = (i0 + 64 + lane < a.n_pad) ? min((int)a.type_id[i0 + 64 + lane], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
+  int wave_t = -1;
+  unsigned d = 0;
+  bool active = false;
+  unsigned acc_w = 0;
+#pragma unroll
+  for (int ty = 0; ty < DSIM_MIXED2_TYPES; ++ty) {
+    const unsigned long long m0 = __ballot(t0 == ty), m1 = __ballot(t1 == ty);
+    const unsigned c0 = (unsigned)__popcll(m0), tot = c0 + (unsigned)__popcll(m1), nw = (tot + 63) >> 6;
+    if (w >= acc_w && w < acc_w + nw) {                             // wave-uniform: this wave runs type ty
+      wave_t = ty;
+      const unsigned r = (w - acc_w) * 64 + lane;
+      active = r < tot;
+      const unsigned rr = active ? r : 0u;
+      d = rr < c0 ? nth_set_bit64(m0, rr) : 64u + nth_set_bit64(m1, rr - c0);
+    }
+    acc_w += nw;
+  }
+  wave_t = __builtin_amdgcn_readfirstlane(wave_t);
+  __builtin_amdgcn_s_waitcnt(0x0f70);                               // vmcnt(0): this wave's DMAs have landed
+  __syncthreads();
+  if (wave_t >= 0) {
+    const long long i = i0 + d;
+    const DevType& T = a.types[wave_t];
+    if (T.kind == DSIM_DEV_KIND_HEXA) staged_body2<true, NOISE, S1>(T, a, i, tile, d, active);
+    else staged_body2<false, NOISE, S1>(T, a, i, tile, d, active);
+  }
+  __syncthreads();
+  if (t < TILE && i0 + t < a.n_pad) {
+    const bool nat_hexa = (a.hexa_types >> (w == 0 ? t0 : t1)) & 1u;
+    float* sp = a.st.base + kv_off(a.st, i0 + t);
+    const long long sfs = a.st.field_stride;
+    float (*rows)[64] = tile[w].st;
+#pragma unroll
+    for (int f = 0; f < 24; ++f) stg<NT>(sp + f * sfs, 0u, rows[f][lane]);
+    if (nat_hexa) { stg<NT>(sp + 24 * sfs, 0u, rows[24][lane]); stg<NT>(sp + 25 * sfs, 0u, rows[25][lane]); }
+    if (a.bin.count && i0 + t < a.n)
+      bin_entry(a.bin, rows[0][lane], rows[1][lane], rows[2][lane], a.bin.local_offset + i0 + t);
+  }
+}
+
 // Type-major storage (dsim_step_args.runs): a run of one type is stepped by the single-type law of its kind,
 // the fast form (no partition, no waterfall, per-type constants in SGPRs); ext = optional downwash force.
 template <bool HEXA, bool NOISE, bool NT, bool S1>
@@ -1356,31 +1446,35 @@ __device__ __forceinline__ float dw_pair(float4 p, float x, float y, float z, fl
 }
 // Cell-centred query.  One workgroup per cell: the buckets of the (2 rings + 1)^2 cells around it are copied to LDS
 // once — all counts first, then one flattened pass, so every global load of the fill is in flight together — and the
-// cell's receivers are taken 32 at a time, DW_LPB lanes each: every wave-instruction reads DW_LPB consecutive LDS
-// entries that its 8 receivers share (16-byte broadcast reads, conflict-free), partial sums are reduced by shuffles.
-// At BASELINE config 5's density (one drone per m^2: 25 per 5 m cell, 625 candidates per receiver) the candidates
-// come from L2 once per cell instead of once per receiver.  Receivers that sit in the overflow list are handled by
-// the last DW_OVF_GROUPS workgroups straight from global memory.  The kernel also zeroes the count buffer of the NEXT
-// grid build (double-buffered: no memset on the stream).
+// cell's receivers (read back from that LDS copy) are taken TPB / 8 at a time, DW_LPB lanes each: every
+// wave-instruction reads DW_LPB consecutive LDS entries that its 8 receivers share (16-byte broadcast reads,
+// conflict-free), partial sums are reduced by shuffles.  At BASELINE config 5's density (one drone per m^2: 25 per
+// 5 m cell, 625 candidates per receiver) the candidates come from L2 once per cell instead of once per receiver.
+// The workgroup size and the LDS tile are chosen by the host from the mean occupancy (sparse worlds: one wave and 8 KB
+// per cell, so that a CU holds 20 cells at once and their latency chains overlap; dense ones: four waves, 16 KB); a
+// neighbourhood that does not fit the tile is processed in several fills.  Receivers that sit in the overflow list are
+// handled by the last DW_OVF_GROUPS workgroups straight from global memory.  The kernel also zeroes the count buffer
+// of the NEXT grid build (double-buffered: no memset on the stream).
 #define DW_LPB 8
-#define DW_RPB 32                      // receivers per pass
 #define DW_NBR 25                      // (2 * 2 + 1)^2 cells at most
 #define DW_OVF_GROUPS 16
-__global__ __launch_bounds__(256) void k_dw_query_cell(DwK a, BinK b, int rings) {
-  __shared__ float4 tile[DW_NBR * DW_CAP];
+template <int TPB>
+__global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings, int tile_cap) {
+  extern __shared__ float4 tile[];                                                     // tile_cap entries
   __shared__ int nb_cell[DW_NBR], nb_cnt[DW_NBR];
+  constexpr int RPB = TPB / DW_LPB;                                                    // receivers per pass
   const int ncells = b.nx * b.ny;
   const unsigned t = threadIdx.x;
   {
-    const long long gid = (long long)blockIdx.x * 256 + t;
-    if (gid < (long long)ncells + 2) a.count_next[gid] = 0;
+    const long long gid = (long long)blockIdx.x * TPB + t;
+    for (long long z = gid; z < (long long)ncells + 2; z += (long long)gridDim.x * TPB) a.count_next[z] = 0;
   }
   const int sub = (int)(t % DW_LPB), r_in = (int)(t / DW_LPB);
-  const int n_ovf = b.count[ncells];
   if ((int)blockIdx.x >= ncells) {
     // receivers that overflowed their bucket: grid-stride over the overflow list, candidates from global memory
+    const int n_ovf = b.count[ncells];
     const int g = (int)blockIdx.x - ncells;
-    for (int r = g * DW_RPB + r_in; r < n_ovf; r += DW_OVF_GROUPS * DW_RPB) {
+    for (int r = g * RPB + r_in; r < n_ovf; r += DW_OVF_GROUPS * RPB) {
       const float4 m2 = b.overflow[r];
       const long long i = (long long)__float_as_int(m2.w) - a.local_offset;
       if (i < 0 || i >= a.n) continue;
@@ -1404,49 +1498,68 @@ __global__ __launch_bounds__(256) void k_dw_query_cell(DwK a, BinK b, int rings)
     return;
   }
   const int c = (int)blockIdx.x;                                                       // this workgroup's cell
-  const int cnt_c = min(b.count[c], DW_CAP);
-  if (cnt_c == 0) return;                                                              // nobody to serve here
   const int cx = c % b.nx, cy = c / b.nx;
-  const int side = 2 * rings + 1;
-  if ((int)t < side * side) {                                                          // all neighbour counts at once
+  const int side = 2 * rings + 1, n_nb = side * side, centre = rings * side + rings;
+  int n_ovf = 0;
+  if ((int)t < n_nb) {                                                                 // all neighbour counts at once
     const int xx = cx - rings + (int)t % side, yy = cy - rings + (int)t / side;
     const bool in = xx >= 0 && xx < b.nx && yy >= 0 && yy < b.ny;
     const int cc = in ? yy * b.nx + xx : 0;
     nb_cell[t] = cc;
     nb_cnt[t] = in ? min(b.count[cc], DW_CAP) : 0;
   }
+  n_ovf = b.count[ncells];                                                             // (scalar load, same round trip)
   __syncthreads();
-  int total = 0;
-  for (int k = 0; k < side * side; ++k) total += nb_cnt[k];
-  for (int e = (int)t; e < total; e += 256) {                                          // flattened fill: loads back to back
-    int k = 0, base = 0;
-    while (e >= base + nb_cnt[k]) { base += nb_cnt[k]; ++k; }
-    tile[e] = b.buckets[(long long)nb_cell[k] * DW_CAP + (e - base)];
-  }
-  __syncthreads();
-  for (int r0 = 0; r0 < cnt_c; r0 += DW_RPB) {
+  const int cnt_c = nb_cnt[centre];
+  if (cnt_c == 0) return;                                                              // nobody to serve here (uniform)
+  int total = 0, centre_base = 0;
+  for (int k = 0; k < n_nb; ++k) { if (k == centre) centre_base = total; total += nb_cnt[k]; }
+  // the tile holds the whole neighbourhood in the normal case: one fill, every receiver pass reads it
+  const bool whole = total <= tile_cap;
+  for (int r0 = 0; r0 < cnt_c; r0 += RPB) {
     const int r = r0 + r_in;
     bool have = r < cnt_c;
     float4 me = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     long long i = -1;
-    if (have) {
-      me = b.buckets[(long long)c * DW_CAP + r];
-      i = (long long)__float_as_int(me.w) - a.local_offset;
-      if (i < 0 || i >= a.n) have = false;                                             // another rank's drone: a candidate only
-    }
+    float pr = 0.0f, d0 = 0.0f, d1 = 0.0f, d2c = 0.0f;
     float fz = 0.0f;
-    if (have) {
-      const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
-      const float pr = T.prop_radius, d0 = T.dw[0], d1 = T.dw[1], d2c = T.dw[2];
-      int e = sub;
-      for (; e + DW_LPB < total; e += 2 * DW_LPB) {                                    // two candidates in flight per lane
-        const float4 p0 = tile[e], p1 = tile[e + DW_LPB];
-        fz += dw_pair(p0, me.x, me.y, me.z, pr, d0, d1, d2c);
-        fz += dw_pair(p1, me.x, me.y, me.z, pr, d0, d1, d2c);
+    for (int base = 0; base < total; base += tile_cap) {
+      if (!whole || r0 == 0) {
+        if (base > 0 || r0 > 0) __syncthreads();                                       // the previous tile is done with
+        const int lim = min(tile_cap, total - base);
+        for (int e = (int)t; e < lim; e += TPB) {                                      // flattened fill: loads back to back
+          int k = 0, acc = 0;
+          const int g = base + e;
+          while (g >= acc + nb_cnt[k]) { acc += nb_cnt[k]; ++k; }
+          tile[e] = b.buckets[(long long)nb_cell[k] * DW_CAP + (g - acc)];
+        }
+        __syncthreads();
       }
-      if (e < total) fz += dw_pair(tile[e], me.x, me.y, me.z, pr, d0, d1, d2c);
-      for (int k = sub; k < n_ovf; k += DW_LPB) fz += dw_pair(b.overflow[k], me.x, me.y, me.z, pr, d0, d1, d2c);
+      if (base == 0) {
+        if (have) {
+          // the receiver itself: from the tile when its entry is in this fill, else from its bucket
+          me = (centre_base + r < tile_cap) ? tile[centre_base + r] : b.buckets[(long long)c * DW_CAP + r];
+          i = (long long)__float_as_int(me.w) - a.local_offset;
+          if (i < 0 || i >= a.n) have = false;                                         // another rank's drone: a candidate only
+        }
+        if (have) {
+          const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
+          pr = T.prop_radius; d0 = T.dw[0]; d1 = T.dw[1]; d2c = T.dw[2];
+        }
+      }
+      if (have) {
+        const int lim = min(tile_cap, total - base);
+        int e = sub;
+        for (; e + DW_LPB < lim; e += 2 * DW_LPB) {                                    // two candidates in flight per lane
+          const float4 p0 = tile[e], p1 = tile[e + DW_LPB];
+          fz += dw_pair(p0, me.x, me.y, me.z, pr, d0, d1, d2c);
+          fz += dw_pair(p1, me.x, me.y, me.z, pr, d0, d1, d2c);
+        }
+        if (e < lim) fz += dw_pair(tile[e], me.x, me.y, me.z, pr, d0, d1, d2c);
+      }
     }
+    if (have)
+      for (int k = sub; k < n_ovf; k += DW_LPB) fz += dw_pair(b.overflow[k], me.x, me.y, me.z, pr, d0, d1, d2c);
 #pragma unroll
     for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
     if (have && sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz; }
@@ -1903,7 +2016,26 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
       // (26 fields: a table with a morphing hexa) and for per-drone targets
       const bool tiled = state.block == 64 && state.field_stride == 64 && ctx->max_act == 6 &&
                          !(args->options & DSIM_OPT_BCAST_TGT) && targets.block == 64 && targets.field_stride == 64;
-      if (tiled && !(args->options & DSIM_OPT_MIXED_V1)) {
+      if (!(args->options & (DSIM_OPT_MIXED_V1 | DSIM_OPT_MIXED_RING)) && ctx->max_act == 6) {
+        // third form: one tile per workgroup, LDS-DMA staging in natural order, ballot partition
+        const dim3 gm((unsigned)((a.n_pad - first + 127) / 128));
+#define DSIM_MIXED3_CASE3(W_, S_, T_)                                                                             \
+  do { const dim3 bm(64 * W_);                                                                                    \
+       if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed3<true, true, W_, S_, T_>), gm, bm, 0, st_, a);        \
+                    else hipLaunchKernelGGL((k_step_mixed3<true, false, W_, S_, T_>), gm, bm, 0, st_, a); }        \
+       else { if (nt) hipLaunchKernelGGL((k_step_mixed3<false, true, W_, S_, T_>), gm, bm, 0, st_, a);             \
+              else hipLaunchKernelGGL((k_step_mixed3<false, false, W_, S_, T_>), gm, bm, 0, st_, a); } } while (0)
+#define DSIM_MIXED3_CASE2(W_, S_) do { if (tiled) DSIM_MIXED3_CASE3(W_, S_, true); else DSIM_MIXED3_CASE3(W_, S_, false); } while (0)
+#define DSIM_MIXED3_CASE(W_) do { if (a.substeps == 1) DSIM_MIXED3_CASE2(W_, true); else DSIM_MIXED3_CASE2(W_, false); } while (0)
+        if (ctx->n_types == 2) DSIM_MIXED3_CASE(3); else if (ctx->n_types == 3) DSIM_MIXED3_CASE(4); else DSIM_MIXED3_CASE(5);
+#undef DSIM_MIXED3_CASE
+#undef DSIM_MIXED3_CASE2
+#undef DSIM_MIXED3_CASE3
+        if (any_hexa) fb_finish(ctx, a, st_);
+        bin_next_commit(ctx, n, args, a);
+        return (int)hipGetLastError();
+      }
+      if (tiled && (args->options & DSIM_OPT_MIXED_RING)) {
         // persistent workgroups, LDS-DMA ring (k_step_mixed2): 4 per CU (37 KB of LDS each)
         const long long n_tiles = (a.n_pad - first + 127) / 128;
         const long long cap = 4LL * ctx->n_cu;
@@ -2138,8 +2270,13 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
     b.count = a.count; b.buckets = a.buckets; b.overflow = a.overflow;
     b.xmin = a.xmin; b.ymin = a.ymin; b.inv_cell = a.inv_cell; b.nx = a.nx; b.ny = a.ny; b.local_offset = a.local_offset;
     const long long ncells = (long long)a.nx * a.ny;
-    hipLaunchKernelGGL(k_dw_query_cell, dim3((unsigned)(ncells + DW_OVF_GROUPS)), dim3(256), 0, st_, a, b,
-                       g->cell >= DW_CUTOFF ? 1 : 2);
+    // sparse worlds (mean occupancy of a neighbourhood <= 128 entries): one wave per cell and an 8 KB tile, so that a
+    // CU holds ~20 cells at once; dense ones: four waves and 16 KB (BASELINE config 5: 625 entries per neighbourhood)
+    const int rings = g->cell >= DW_CUTOFF ? 1 : 2;
+    const double nb_mean = (double)a.m / (double)ncells * (2 * rings + 1) * (2 * rings + 1);
+    const dim3 gq((unsigned)(ncells + DW_OVF_GROUPS));
+    if (nb_mean <= 128.0) hipLaunchKernelGGL((k_dw_query_cell<64>), gq, dim3(64), 512 * sizeof(float4), st_, a, b, rings, 512);
+    else hipLaunchKernelGGL((k_dw_query_cell<256>), gq, dim3(256), 1024 * sizeof(float4), st_, a, b, rings, 1024);
   }
   else hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m * DW_LPR)), dim3(256), 0, st_, a);
   return (int)hipGetLastError();

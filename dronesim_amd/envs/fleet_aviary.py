@@ -95,7 +95,7 @@ class CtrlAviary:
                               Physics.PYB_DRAG: nat.OPT_DRAG,
                               Physics.PYB_GND_DRAG_DW: nat.OPT_GROUND | nat.OPT_DRAG}[physics]
         # tuning bits handed to every call (nat.OPT_STREAM_ON/_OFF, nat.OPT_GENERIC_MIXED); results do not depend on them
-        self._tuning = int(options) & (nat.OPT_STREAM_ON | nat.OPT_STREAM_OFF | nat.OPT_GENERIC_MIXED | nat.OPT_MIXED_V1)
+        self._tuning = int(options) & nat.TUNING_MASK
         self.neighbors_k = int(neighbors_k)
         if isinstance(drone_model, (str, DroneType)):
             drone_model = [drone_model]

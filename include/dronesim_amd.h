@@ -130,8 +130,10 @@ enum {
   DSIM_OPT_STREAM_OFF  = 1u << 5,   /* force the default cache policy                                              */
   DSIM_OPT_GENERIC_MIXED = 1u << 6, /* mixed fleets: use the general per-lane-type kernel instead of the LDS-staged
                                        one (A/B knob)                                                              */
-  DSIM_OPT_MIXED_V1    = 1u << 7    /* mixed fleets: the round-1 form of the LDS-staged kernel (one tile per workgroup,
-                                       VGPR staging, three barriers) instead of the LDS-DMA ring (A/B knob)        */
+  DSIM_OPT_MIXED_V1    = 1u << 7,   /* mixed fleets: the round-1 form of the LDS-staged kernel (one tile per workgroup,
+                                       VGPR staging, three barriers) (A/B knob)                                    */
+  DSIM_OPT_MIXED_RING  = 1u << 8    /* mixed fleets, wave-tiled layout: persistent workgroups with a two-deep LDS-DMA
+                                       ring (A/B knob; measured slower than the default form)                      */
 };
 
 /* A run of consecutive drones of one type (type-major storage of a heterogeneous fleet). */

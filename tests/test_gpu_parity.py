@@ -526,12 +526,14 @@ def test_hexa_fused_step_vs_oracle(gpu, substeps, layout):
     ctx.close()
 
 
-@pytest.mark.parametrize("layout,v1", [("soa", False), ("tile64", False), ("tile64", True)])
+@pytest.mark.parametrize("layout,form", [("soa", "default"), ("tile64", "default"), ("tile64", "v1"), ("soa", "v1"),
+                                         ("tile64", "ring")])
 @pytest.mark.parametrize("sub", [1, 2])
-def test_mixed_fleet_vs_oracle(gpu, sub, layout, v1):
+def test_mixed_fleet_vs_oracle(gpu, sub, layout, form):
     """Config 5 layout: even index robobee (quad INDI), odd index hexa_6DOF (6DOF INDI + WLS), one
-    type_id byte per drone; in-kernel noise on.  Wave-tiled storage takes the LDS-DMA ring (k_step_mixed2), plain SoA
-    (or DSIM_OPT_MIXED_V1) the one-tile-per-workgroup form."""
+    type_id byte per drone; in-kernel noise on.  Every form of the mixed-fleet kernel: the default (LDS-DMA staging in
+    natural order, partition by ballots; 1 KB DMAs on the wave-tiled layout, row DMAs otherwise), round 1's staged
+    kernel (DSIM_OPT_MIXED_V1) and the persistent LDS-DMA ring (DSIM_OPT_MIXED_RING)."""
     nat, fleet = gpu
     n = 3000
     types = [params.builtin_type("robobee"), params.builtin_type("hexa_6DOF")]
@@ -548,7 +550,7 @@ def test_mixed_fleet_vs_oracle(gpu, sub, layout, v1):
     tid_dev[:n] = torch.from_numpy(tid)
     seed, sidx = 99, 5
     a = _args(nat, sub, DT, float(np.float32(sub / 240)), seed=seed, step_index=sidx, type_id=tid_dev,
-              options=nat.OPT_MIXED_V1 if v1 else 0)
+              options={"default": 0, "v1": nat.OPT_MIXED_V1, "ring": nat.OPT_MIXED_RING}[form])
     nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
     O = orc.Oracle(types)
     nz = np.zeros((n, sub, 12))
@@ -560,7 +562,7 @@ def test_mixed_fleet_vs_oracle(gpu, sub, layout, v1):
             nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
     r0, m0 = rigid.copy(), mem.copy()
     assert O.step(rigid, mem, tgt, sub, DT, float(np.float32(sub / 240)), noise=nz, type_id=tid) == 0
-    assert_step_parity(f"mixed_fleet[{sub},{layout},v1={v1}]", types, tid, r0, m0, tgt, st.rigid_aos(), st.mem_aos(), rigid, mem, DT,
+    assert_step_parity(f"mixed_fleet[{sub},{layout},{form}]", types, tid, r0, m0, tgt, st.rigid_aos(), st.mem_aos(), rigid, mem, DT,
                        float(np.float32(sub / 240)), sub)
     ctx.close()
 
