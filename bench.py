@@ -377,6 +377,9 @@ def main(argv=None):
                        "drones_per_gpu": fl.n, "phys_substeps": a.substeps, "layout": a.layout,
                        "noise_seed": a.noise_seed, "launches_per_step": 1, "parallelism": f"shard{world}"},
             "dist": dist_info,
+            # drone-steps of the whole run (set-up, warm-up and timed regions) whose collision cylinder reached the ground
+            # plane, which this library does not model: 0 = every step of the workload lies in the modelled domain
+            "ground_contacts": fl.env.ground_contacts(),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel, "bytes_per_drone_step": bytes_per,

@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
     } else {
       quad_substeps<NOISE ? 1 : 0, 4, false, SUB>(T, a, i, s, m.cmd, a.step_index);    // stored cmd is already clipped
     }
+    ground_watch(T, s, a.fb.counters, i < a.n);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   } else {
     int wp = 0;
@@ -345,6 +346,7 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
     for (int k = 0; k < a.n_steps; ++k) {
       if (a.wp_table) waypoint_target(a, i, wp, tg);
       quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index + k);
+      ground_watch(T, s, a.fb.counters, i < a.n);
       indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
       wp = waypoint_next(wp, a.n_wp);
     }
@@ -390,6 +392,7 @@ __global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
   } else {
     hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index);
   }
+  ground_watch(T, s, a.fb.counters, i < a.n);
   indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
   const unsigned so = pin_lane_offset(sl);
   store_rigid<NT>(sb, sfs, so, s);
@@ -515,10 +518,12 @@ __device__ __forceinline__ void step_gen_body(const DevType& T, const StepK& a, 
     if (NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA) {     // wave-uniform branch
       if constexpr (NACT == 6) {
         hexa_substeps<NOISE, FULL>(T, a, i, s, act, a.step_index + k, ext);
+        ground_watch(T, s, a.fb.counters, i < a.n);
         indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
       }
     } else {
       quad_substeps<NOISE ? (FULL ? 2 : 1) : 0, NACT, FULL>(T, a, i, s, act, a.step_index + k, ext);
+      ground_watch(T, s, a.fb.counters, i < a.n);
       indi_quad<false, NACT>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
     }
     wp = waypoint_next(wp, a.n_wp);
@@ -594,9 +599,11 @@ __device__ __forceinline__ void staged_body(const DevType& T, const StepK& a, lo
   float yaw_e;
   if constexpr (HEXA) {
     hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
+    ground_watch(T, s, a.fb.counters, active && i < a.n);
     indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, active ? i : -1LL);
   } else {
     quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
+    ground_watch(T, s, a.fb.counters, active && i < a.n);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   if (!active) return;
@@ -713,8 +720,28 @@ __device__ __forceinline__ unsigned nth_set_bit64(unsigned long long m, unsigned
   return pos;
 }
 // LDS image of one 64-drone block: the block's rows as they lie in the wave-tiled state / target arrays
-// ([F][64] floats, field rows contiguous), so that a 16-byte-per-lane DMA moves four rows at once.
-struct Stage64 { float st[DSIM_NF_HEXA][64]; float tg[DSIM_NT][64]; };       // 26 + 10 rows = 9 KB
+// ([F][64] floats, field rows contiguous), so that a 16-byte-per-lane DMA moves four rows at once.  Both row groups
+// are padded to a multiple of four rows: the last DMA of each group (rows 24-25 / 8-9) runs with ALL lanes active, its
+// upper half re-reading the same two rows into the padding.  (An exec-masked DMA under `if (lane < 32)` is a hazard:
+// the LDS destination of an LDS-DMA is wave-uniform (M0), and the compiler's tail merging of the two sides of such a
+// branch produced ONE instruction with a per-lane "uniform" destination resolved by v_readfirstlane — half the wave's
+// rows landed in the wrong place.  No DMA in this file sits under a per-lane branch.)
+struct Stage64 { float st[DSIM_NF_HEXA + 2][64]; float tg[DSIM_NT + 2][64]; };       // 28 + 12 rows = 10 KB
+// the 7 + 3 DMAs of 1 KB that bring one 64-drone block (26 state rows, 10 target rows) into a Stage64
+template <int AUX>
+__device__ __forceinline__ void dma_block64(const float* state_block, const float* target_block, Stage64& dst, unsigned lane) {
+  const float* sp = state_block + 4 * lane;            // 16 bytes per lane
+  const float* tp = target_block + 4 * lane;
+  const unsigned fold = 4 * (lane & 31u);              // last DMA of a group: lanes 32..63 re-read what lanes 0..31 read
+  float* ls = &dst.st[0][0];
+  float* lt = &dst.tg[0][0];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) __builtin_amdgcn_global_load_lds(sp + 256 * q, ls + 256 * q, 16, 0, AUX);
+  __builtin_amdgcn_global_load_lds(state_block + 256 * 6 + fold, ls + 256 * 6, 16, 0, AUX);        // rows 24, 25 (+ padding)
+  __builtin_amdgcn_global_load_lds(tp, lt, 16, 0, AUX);
+  __builtin_amdgcn_global_load_lds(tp + 256, lt + 256, 16, 0, AUX);
+  __builtin_amdgcn_global_load_lds(target_block + 512 + fold, lt + 512, 16, 0, AUX);                // rows 8, 9 (+ padding)
+}
 template <bool HEXA, bool NOISE, bool S1>
 __device__ __forceinline__ void staged_body2(const DevType& T, const StepK& a, long long i, Stage64* tile, unsigned d,
                                              bool active) {
@@ -744,9 +771,11 @@ __device__ __forceinline__ void staged_body2(const DevType& T, const StepK& a, l
   float yaw_e;
   if constexpr (HEXA) {
     hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
+    ground_watch(T, s, a.fb.counters, active && i < a.n);
     indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, active ? i : -1LL);
   } else {
     quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
+    ground_watch(T, s, a.fb.counters, active && i < a.n);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   if (!active) return;
@@ -766,7 +795,7 @@ __device__ __forceinline__ void staged_body2(const DevType& T, const StepK& a, l
 template <bool NOISE, bool NT, int WT, bool S1>
 __global__ __launch_bounds__(64 * WT, 3) void k_step_mixed2(StepK a, long long n_tiles) {
   constexpr int TILE = 128;
-  __shared__ __attribute__((aligned(16))) Stage64 ring[2][2];                // [slot][half]: 2 x 18 KB
+  __shared__ __attribute__((aligned(16))) Stage64 ring[2][2];                // [slot][half]: 2 x 20 KB
   const unsigned t = threadIdx.x, w = t >> 6, lane = t & 63;
   if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
   constexpr int AUX = NT ? 2 : 0;                                           // nt on the DMA reads of once-read state
@@ -779,16 +808,8 @@ __global__ __launch_bounds__(64 * WT, 3) void k_step_mixed2(StepK a, long long n
     for (int h = 0; h < 2; ++h) {
       const long long ih = i0 + 64 * h;
       if (ih >= a.n_pad) continue;                                          // wave-uniform: n_pad is a multiple of 64
-      const float* sp = a.st.base + (ih >> 6) * a.st.block_stride + 4 * lane;       // 16 bytes per lane
-      const float* tp = a.tg.base + (ih >> 6) * a.tg.block_stride + 4 * lane;
-      float* ls = &ring[buf][h].st[0][0];
-      float* lt = &ring[buf][h].tg[0][0];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) __builtin_amdgcn_global_load_lds(sp + 256 * q, ls + 256 * q, 16, 0, AUX);
-      if (lane < 32) __builtin_amdgcn_global_load_lds(sp + 256 * 6, ls + 256 * 6, 16, 0, AUX);       // rows 24, 25
-      __builtin_amdgcn_global_load_lds(tp, lt, 16, 0, AUX);
-      __builtin_amdgcn_global_load_lds(tp + 256, lt + 256, 16, 0, AUX);
-      if (lane < 32) __builtin_amdgcn_global_load_lds(tp + 512, lt + 512, 16, 0, AUX);               // rows 8, 9
+      dma_block64<AUX>(a.st.base + (ih >> 6) * a.st.block_stride, a.tg.base + (ih >> 6) * a.tg.block_stride,
+                       ring[buf][h], lane);
     }
   };
 
@@ -858,7 +879,7 @@ __global__ __launch_bounds__(64 * WT, 3) void k_step_mixed2(StepK a, long long n
 template <bool NOISE, bool NT, int WT, bool S1, bool TILED>
 __global__ __launch_bounds__(64 * WT, 4) void k_step_mixed3(StepK a) {
   constexpr int TILE = 128;
-  __shared__ __attribute__((aligned(16))) Stage64 tile[2];                  // [half]: 18 KB
+  __shared__ __attribute__((aligned(16))) Stage64 tile[2];                  // [half]: 20 KB
   const unsigned t = threadIdx.x, w = t >> 6, lane = t & 63;
   const long long i0 = a.first + (long long)blockIdx.x * TILE;
   if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
@@ -866,28 +887,16 @@ __global__ __launch_bounds__(64 * WT, 4) void k_step_mixed3(StepK a) {
   const long long ih = i0 + 64 * (long long)w;
   if (w < 2 && ih < a.n_pad) {                                              // each natural wave brings its own half in
     if (TILED) {
-      const float* sp = a.st.base + (ih >> 6) * a.st.block_stride + 4 * lane;       // 16 bytes per lane
-      const float* tp = a.tg.base + (ih >> 6) * a.tg.block_stride + 4 * lane;
-      float* ls = &tile[w].st[0][0];
-      float* lt = &tile[w].tg[0][0];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) __builtin_amdgcn_global_load_lds(sp + 256 * q, ls + 256 * q, 16, 0, AUX);
-      if (lane < 32) __builtin_amdgcn_global_load_lds(sp + 256 * 6, ls + 256 * 6, 16, 0, AUX);       // rows 24, 25
-      __builtin_amdgcn_global_load_lds(tp, lt, 16, 0, AUX);
-      __builtin_amdgcn_global_load_lds(tp + 256, lt + 256, 16, 0, AUX);
-      if (lane < 32) __builtin_amdgcn_global_load_lds(tp + 512, lt + 512, 16, 0, AUX);               // rows 8, 9
+      dma_block64<AUX>(a.st.base + (ih >> 6) * a.st.block_stride, a.tg.base + (ih >> 6) * a.tg.block_stride, tile[w], lane);
     } else {
       const long long il = ih + lane;
       const float* sp = a.st.base + kv_off(a.st, il);
       const float* tp = a.tg.base + kv_off(a.tg, il);                       // (a broadcast row: kv_off = 0 for every lane)
       const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
-      const bool hexa = (a.hexa_types >> min((int)a.type_id[il], DSIM_MAX_TYPES - 1)) & 1u;
+      // (all 26 rows for every lane — quads' rows 24, 25 are unused words of the 26-field state: no DMA under a
+      // per-lane branch, see Stage64)
 #pragma unroll
-      for (int f = 0; f < 24; ++f) __builtin_amdgcn_global_load_lds(sp + f * sfs, &tile[w].st[f][0], 4, 0, AUX);
-      if (hexa) {
-        __builtin_amdgcn_global_load_lds(sp + 24 * sfs, &tile[w].st[24][0], 4, 0, AUX);
-        __builtin_amdgcn_global_load_lds(sp + 25 * sfs, &tile[w].st[25][0], 4, 0, AUX);
-      }
+      for (int f = 0; f < 26; ++f) __builtin_amdgcn_global_load_lds(sp + f * sfs, &tile[w].st[f][0], 4, 0, AUX);
 #pragma unroll
       for (int f = 0; f < 10; ++f) __builtin_amdgcn_global_load_lds(tp + f * tfs, &tile[w].tg[f][0], 4, 0, AUX);
     }
@@ -961,9 +970,11 @@ __global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void
   float yaw_e;
   if constexpr (HEXA) {
     hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
+    ground_watch(T, s, a.fb.counters, i < a.n);
     indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
   } else {
     quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
+    ground_watch(T, s, a.fb.counters, i < a.n);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   const unsigned so = pin_lane_offset(sl);
@@ -991,6 +1002,7 @@ __device__ __forceinline__ void physics_gen_body(const DevType& T, const StepK& 
     for (int j = 0; j < 4; ++j) prev[j] = a.echo ? a.echo[(long long)j * a.n_pad + i] : cmd[j];
     quad_substeps<NOISE ? 2 : 0, NACT, true>(T, a, i, s, cmd, a.step_index, ext, prev);
   }
+  ground_watch(T, s, a.fb.counters, i < a.n);
   store_rigid(ad.sb, ad.sfs, ad.sl, s);
   if (a.echo) {
 #pragma unroll
@@ -1077,6 +1089,7 @@ __global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_physics_fast(StepK a) 
   }
   if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
   quad_substeps<NOISE ? 1 : 0>(T, a, i, s, cmd, a.step_index);
+  ground_watch(T, s, a.fb.counters, i < a.n);
   const unsigned so = pin_lane_offset(sl);
   store_rigid<NT>(sb, sfs, so, s);
   if (a.echo) {
@@ -1161,6 +1174,7 @@ __device__ __forceinline__ void adaptor_body(const DevType& T, const StepK& a, l
     indi_rate<4>(T, DSIM_RCP(a.dt_ctrl), s, v3(v[0], v[1], v[2]), v[3], m);
   }
   quad_substeps<NOISE ? 1 : 0, 4>(T, a, i, s, m.cmd, a.step_index);
+  ground_watch(T, s, a.fb.counters, i < a.n);
   store_rigid(ad.sb, ad.sfs, ad.sl, s);
   store_mem<4>(ad.sb, ad.sfs, ad.sl, m);
   if (a.echo) {
@@ -1692,6 +1706,7 @@ static void to_dev(const dsim_type_params& p, DevType* d) {
   d->gnd_coeff = (float)p.gnd_eff_coeff; d->prop_radius = (float)p.prop_radius; d->gnd_hclip = (float)p.gnd_eff_h_clip;
   if (p.kind == DSIM_KIND_HEXA6DOF) { d->reset_thrust = 0.3f; d->reset_cmd = 0.5f; }   // INDIControl_6DOF.py:232-234
   d->speed_limit = (float)(p.max_speed_kmh * (1000.0 / 3600.0));
+  d->coll_r = (float)p.collision_radius; d->coll_below = (float)p.collision_below;
 }
 
 extern "C" {
@@ -1736,8 +1751,8 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
   for (int t = 0; t < n_types; ++t) { c->h_types[t] = types[t]; to_dev(types[t], &h[t]); }
   e = hipMalloc((void**)&c->d_types, sizeof(DevType) * n_types);
   if (e == hipSuccess) e = hipMemcpy(c->d_types, h, sizeof(DevType) * n_types, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * 8);
-  if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(unsigned long long) * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * (8 + DSIM_GROUND_SHARDS));
+  if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(unsigned long long) * (8 + DSIM_GROUND_SHARDS));
   if (e != hipSuccess) {
     if (c->d_types) (void)hipFree(c->d_types);
     if (c->d_counters) (void)hipFree(c->d_counters);
@@ -1758,12 +1773,18 @@ int dsim_destroy(dsim_ctx* ctx) {
 }
 
 int dsim_query(dsim_ctx* ctx, void* stream, int32_t what, int64_t* value_out) {
-  if (!ctx || !value_out || what < 0 || what > 1) return DSIM_E_ARG;
-  unsigned long long h[2];
+  if (!ctx || !value_out || what < 0 || what > 2) return DSIM_E_ARG;
+  unsigned long long h[8 + DSIM_GROUND_SHARDS];
   hipError_t e = hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream);
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
-  *value_out = (int64_t)h[what];
+  if (what == DSIM_Q_GROUND_CONTACTS) {
+    unsigned long long sum = 0;
+    for (int k = 0; k < DSIM_GROUND_SHARDS; ++k) sum += h[8 + k];
+    *value_out = (int64_t)sum;
+  } else {
+    *value_out = (int64_t)h[what];
+  }
   return DSIM_OK;
 }
 

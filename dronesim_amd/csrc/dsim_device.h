@@ -33,6 +33,7 @@ struct DevType {
   float drag[3], gnd_coeff, prop_radius, gnd_hclip, dw[3];
   float reset_thrust, reset_cmd;
   float speed_limit;                          // MAX_SPEED_KMH * 1000/3600 (VelocityAviary.py:92-94)
+  float coll_r, coll_below;                   // bounding cylinder of the collision shapes (ground-plane watch)
 };
 
 struct V3 { float x, y, z; };
@@ -197,6 +198,19 @@ __device__ __forceinline__ void noise_normals(uint64_t seed, uint64_t drone, uin
 struct Rigid { V3 pos; Q4 q; V3 vel; V3 w; };                 // w: WORLD-frame angular velocity
 template <int NACT> struct CtrlMem { V3 last_vel; V3 last_rates; float last_thrust; float cmd[NACT]; };
 struct Target { V3 pos, vel, acc; float yaw; };
+
+// Ground-plane watch.  The reference loads plane.urdf with collisions on (BaseAviary.py:680); plane contact is not
+// modelled here, so an Env.step that ends with the vehicle's collision cylinder at or below z = 0 is
+// COUNTED: one atomic per wave that holds such a drone, on one of 64 counter shards (dsim_query sums them).
+#define DSIM_GROUND_SHARDS 64
+__device__ __forceinline__ void ground_watch(const DevType& T, const Rigid& s, unsigned long long* counters, bool live = true) {
+  const float r22 = 1.0f - 2.0f * (s.q.x * s.q.x + s.q.y * s.q.y);                     // body z . world z (unit q)
+  const float reach = T.coll_below * fabsf(r22) + T.coll_r * DSIM_SQRT(fmaxf(1.0f - r22 * r22, 0.0f));
+  const bool hit = live && T.coll_r > 0.0f && s.pos.z <= reach;
+  const unsigned long long m = __ballot(hit);
+  if (m != 0ULL && (int)(threadIdx.x & 63u) == __builtin_ctzll(m))
+    atomicAdd(&counters[8 + (blockIdx.x & (DSIM_GROUND_SHARDS - 1))], (unsigned long long)__popcll(m));
+}
 
 // P1: CtrlAviary._preprocessAction, CtrlAviary.py:258-263
 template <int NACT>

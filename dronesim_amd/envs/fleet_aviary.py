@@ -346,6 +346,13 @@ class CtrlAviary:
         nat.check(self.ctx.lib.dsim_reserve(self.ctx.handle, self.ctx.stream_ptr(), self.state.n_pad))
         return FusedGraph(self, targets, steps, control_timestep)
 
+    def ground_contacts(self) -> int:
+        """Drone x Env.steps so far that ended with the vehicle's collision cylinder at or below z = 0 (cumulative over
+        this env's context; synchronises the stream).  The reference's PyBullet world has a ground plane with
+        collisions on (BaseAviary.py:680); contact is not modelled here, so a non-zero count means part of the
+        flight lies outside the domain in which trajectories are comparable with the reference."""
+        return self.ctx.query(nat.QUERY_GROUND_CONTACTS)
+
     def close(self):
         self.ctx.close()
 

@@ -71,6 +71,8 @@ class TypeParamsC(ctypes.Structure):
         ("gnd_eff_h_clip", ctypes.c_double),
         ("dw_coeff", ctypes.c_double * 3),
         ("max_speed_kmh", ctypes.c_double),
+        ("collision_radius", ctypes.c_double),
+        ("collision_below", ctypes.c_double),
     ]
 
 
@@ -109,6 +111,8 @@ class DroneType:
     gnd_eff_h_clip: float = 0.0
     dw_coeff: Sequence[float] = (0.0, 0.0, 0.0)
     max_speed_kmh: float = 30.0      # URDF properties max_speed_kmh (all shipped types: 30)
+    collision_radius: float = 0.0    # bounding cylinder of the <collision> shapes about body z: radius ...
+    collision_below: float = 0.0     # ... and extent below the COM (ground-plane watch; 0 = none)
     reset_thrust: float = 0.0        # INDIControl.reset (INDIControl.py:127); 6DOF 0.3 (:232)
     reset_cmd: float = 0.0           # INDIControl.py:129; 6DOF 0.5 (:234)
     alloc: np.ndarray = field(default=None)  # type: ignore[assignment]
@@ -192,6 +196,7 @@ class DroneType:
         c.gnd_eff_coeff, c.prop_radius = self.gnd_eff_coeff, self.prop_radius
         c.gnd_eff_h_clip = self.gnd_eff_h_clip
         c.max_speed_kmh = self.max_speed_kmh
+        c.collision_radius, c.collision_below = self.collision_radius, self.collision_below
         return c
 
     @property
@@ -234,7 +239,7 @@ def _robobee() -> DroneType:
         G1=np.array([[50.0, 50.0, -50.0, -50.0], [-50.0, 50.0, 50.0, -50.0],
                      [-7.0, 7.0, -7.0, 7.0], [1.7, 1.7, 1.7, 1.7]]),
         kp_pos=1.0, kd_pos=2.2, att_gain=(7.0, 7.0, 5.0), rate_gain=(18.0, 18.0, 10.0),
-        prop_radius=3.31348e-2, **_AERO,
+        prop_radius=3.31348e-2, collision_radius=0.15, collision_below=0.05, **_AERO,      # robobee.urdf:72-77
     )
 
 
@@ -252,7 +257,7 @@ def _tello() -> DroneType:
         G1=np.array([[30.0, 30.0, -30.0, -30.0], [-30.0, 30.0, 30.0, -30.0],
                      [-5.0, 5.0, -5.0, 5.0], [1.7, 1.7, 1.7, 1.7]]),
         kp_pos=1.7, kd_pos=2.5, att_gain=(10.0, 10.0, 4.0), rate_gain=(12.0, 12.0, 7.0),
-        prop_radius=3.31348e-2, **_AERO,
+        prop_radius=3.31348e-2, collision_radius=0.0475, collision_below=0.0205, **_AERO,   # tello.urdf:68-73
     )
 
 
@@ -285,7 +290,9 @@ def _hexa_6dof() -> DroneType:
                      [-5.0, 5.0, -5.0, 5.0, -5.0, 5.0], [-2.0, 4.0, -2.0, -2.0, 4.0, -2.0],
                      [-3.0, 0.0, 3.0, -3.0, 0.0, 3.0], [1.5, 1.5, 1.5, 1.5, 1.5, 1.5]]),
         kp_pos=1.7, kd_pos=2.5, att_gain=(10.0, 10.0, 5.0), rate_gain=(18.0, 18.0, 12.0),
-        prop_radius=6.7e-2, reset_thrust=0.3, reset_cmd=0.5, **_AERO,
+        prop_radius=6.7e-2, reset_thrust=0.3, reset_cmd=0.5,
+        collision_radius=0.18986507827381124, collision_below=0.06903716345121234,   # all links' <collision> shapes
+        **_AERO,
     )
 
 
@@ -429,6 +436,30 @@ def parse_urdf(path: str) -> DroneType:
         spin = _QUAD_SPIN
         kind, rt, rc = KIND_QUAD, 0.0, 0.0
 
+    # bounding cylinder (about the body z axis through the COM) of every <collision> shape of every link, with the
+    # links in their URDF rest pose: radius and extent below the COM
+    com_ref = C if is_hexa else com0
+    coll_r = coll_below = 0.0
+    for ln in [base] + order:
+        for col in links[ln].findall("collision"):
+            geo = col.find("geometry")
+            ox, oR = _origin(col.find("origin"))
+            lx, lR = frames[ln]
+            ctr, Rs = lx + lR @ ox - com_ref, lR @ oR
+            if geo.find("cylinder") is not None:
+                r, h = float(geo.find("cylinder").attrib["radius"]), 0.5 * float(geo.find("cylinder").attrib["length"])
+                az = abs(Rs[2, 2])
+                down, out = h * az + r * math.sqrt(max(0.0, 1 - az * az)), r * az + h * math.sqrt(max(0.0, 1 - az * az))
+            elif geo.find("sphere") is not None:
+                down = out = float(geo.find("sphere").attrib["radius"])
+            elif geo.find("box") is not None:
+                half = 0.5 * np.array(_floats(geo.find("box").attrib["size"]))
+                down, out = float(np.abs(Rs[2]) @ half), float(np.linalg.norm((np.abs(Rs[:2]) @ half)))
+            else:
+                continue        # meshes: not used by the shipped vehicles' collision shapes
+            coll_below = max(coll_below, down - ctr[2])
+            coll_r = max(coll_r, float(np.linalg.norm(ctr[:2])) + out)
+
     return DroneType(
         name=name, kind=kind, n_act=n_act, mass=mass, ctrl_mass=m0, inertia=inertia,
         kf=float(prop["kf"]), km=float(prop["km"]),
@@ -443,4 +474,5 @@ def parse_urdf(path: str) -> DroneType:
         dw_coeff=(float(prop["dw_coeff_1"]), float(prop["dw_coeff_2"]), float(prop["dw_coeff_3"])),
         max_speed_kmh=float(prop["max_speed_kmh"]),
         reset_thrust=rt, reset_cmd=rc,
+        collision_radius=coll_r, collision_below=coll_below,
     )

@@ -111,6 +111,12 @@ typedef struct dsim_type_params {
   double  gnd_eff_coeff, prop_radius, gnd_eff_h_clip;   /* formula P7                       */
   double  dw_coeff[3];                /* formula P8                                         */
   double  max_speed_kmh;              /* URDF max_speed_kmh (VelocityAviary speed limit)    */
+  /* bounding cylinder of the vehicle's collision shapes about its body z axis (URDF <collision>; robobee: the
+   * 0.15 m x 0.1 m cylinder, robobee.urdf:72-77): radius, and extent below the centre of mass.  The reference loads
+   * plane.urdf with collisions on (BaseAviary.py:680); plane contact is NOT modelled by this library — every
+   * drone-step that ends with this cylinder reaching z <= 0 is counted instead (DSIM_Q_GROUND_CONTACTS), so that a
+   * caller knows when a flight has left the domain in which results are comparable.  0 = no watch for this type.  */
+  double  collision_radius, collision_below;
 } dsim_type_params;
 
 /* ---- step options ---------------------------------------------------------- */
@@ -346,8 +352,10 @@ int dsim_adjacency(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, cons
  *   DSIM_Q_WLS_FALLBACKS  drones x steps whose 6DOF allocation left the first-iteration fast path and
  *                         ran the full active-set loop of wls_alloc (wls_alloc.py:222-350)
  *   DSIM_Q_WLS_FAILURES   allocations on which the reference would have failed (wls_alloc returns None
- *                         -> `self.cmd += None` raises, INDIControl_6DOF.py:626-630); cmd is left unchanged */
-enum { DSIM_Q_WLS_FALLBACKS = 0, DSIM_Q_WLS_FAILURES = 1 };
+ *                         -> `self.cmd += None` raises, INDIControl_6DOF.py:626-630); cmd is left unchanged
+ *   DSIM_Q_GROUND_CONTACTS  drone x Env.steps that ended with the vehicle's collision cylinder at or below z = 0, where
+ *                         PyBullet's ground plane would have acted (see dsim_type_params.collision_radius)      */
+enum { DSIM_Q_WLS_FALLBACKS = 0, DSIM_Q_WLS_FAILURES = 1, DSIM_Q_GROUND_CONTACTS = 2 };
 int dsim_query(dsim_ctx* ctx, void* stream, int32_t what, int64_t* value_out);
 
 /* error codes */

@@ -85,7 +85,8 @@ def test_builtin_types_match_reference_urdf(model):
     if not os.path.exists(urdf):
         pytest.skip("reference tree not present (GPU box)")
     a, b = params.builtin_type(model), params.parse_urdf(urdf)
-    for f in ("kind", "n_act", "mass", "kf", "km", "kp_pos", "kd_pos", "prop_radius", "gnd_eff_coeff"):
+    for f in ("kind", "n_act", "mass", "kf", "km", "kp_pos", "kd_pos", "prop_radius", "gnd_eff_coeff", "collision_radius",
+              "collision_below"):
         assert getattr(a, f) == getattr(b, f), f
     import numpy as np
     for f in ("inertia", "pwm2rpm_scale", "pwm2rpm_const", "pwm_min", "pwm_max", "rotor_pos", "rotor_axis",

@@ -2027,3 +2027,53 @@ def test_bench_launches_its_own_ranks(gpu):
     assert d["n_gpus"] == 2 and d["dist"]["world_size"] == 2 and d["dist"]["backend"] == "gloo"
     assert d["config"]["drones_per_gpu"] == 65536 and d["value"] > 1e8 and d["steps_timed"] >= 10
     assert d["scaling"] == "weak" and "also" not in d
+
+
+def test_ground_plane_watch_counts_what_pybullet_would_have_caught(gpu):
+    """Plane contact is not modelled; the library counts instead every drone-step that ends with the
+    vehicle's collision cylinder (robobee.urdf:72-77: radius 0.15 m, 0.1 m long) at or below z = 0: exact against the
+    device's own trajectory for falling and tumbling drones, zero for a hovering fleet, through the fused step, the
+    physics-only step and the mixed-fleet kernel."""
+    from dronesim_amd.envs import CtrlAviary
+    from dronesim_amd.fleet import Targets
+    nat, fleet = gpu
+    t = params.builtin_type("robobee")
+
+    def expected(rigid_f32):
+        q, z = rigid_f32[:, 3:7].astype(np.float32), rigid_f32[:, 2].astype(np.float32)
+        r22 = np.float32(1) - np.float32(2) * (q[:, 0] * q[:, 0] + q[:, 1] * q[:, 1])
+        reach = np.float32(t.collision_below) * np.abs(r22) + np.float32(t.collision_radius) * np.sqrt(np.maximum(np.float32(1) - r22 * r22, np.float32(0)))
+        return z <= reach
+
+    # (a) free fall from staggered heights, some tilted (the rim reaches the plane before the centre would): Env.step only
+    n = 320
+    xyz = np.stack([np.arange(n) * 1.0, np.zeros(n), np.linspace(0.06, 0.9, n)], 1)
+    rpy = np.zeros((n, 3)); rpy[::3, 0] = 0.7; rpy[1::3, 1] = -1.2
+    env = CtrlAviary(["robobee"], n, initial_xyzs=xyz, initial_rpys=rpy, aggregate_phy_steps=2, noise_seed=0, dict_io=False)
+    assert env.ground_contacts() == 0
+    want = 0
+    zero = torch.zeros((n, 4), device=env.ctx.device)
+    for k in range(30):
+        env.step(zero)
+        hit = expected(env.state.rigid_aos())
+        want += int(hit.sum())
+    assert 0 < want < 30 * n and env.ground_contacts() == want
+    # (b) the fused step (fast kernel) on the same env keeps counting
+    tg = Targets(env.ctx, n); tg.set(pos=f32(xyz).T, yaw=0.0)
+    for k in range(5):
+        env.step_fused(tg)
+        want += int(expected(env.state.rigid_aos()).sum())
+    assert env.ground_contacts() == want
+    env.close()
+    # (c) a fleet hovering on its targets one metre up never touches it; mixed fleet, LDS-staged kernel
+    n = 4096
+    xyz = np.stack([np.arange(n) % 64, np.arange(n) // 64, np.full(n, 1.0)], 1).astype(np.float64)
+    tid = (np.arange(n) % 2).astype(np.uint8)
+    env = CtrlAviary(["robobee", "hexa_6DOF"], n, initial_xyzs=xyz, noise_seed=3, dict_io=False, type_ids=tid, layout="tile64")
+    tg = Targets(env.ctx, n, "tile64"); tg.set(pos=f32(xyz).T, yaw=0.2)
+    hover = np.where(tid[:, None] == 0, t.hover_pwm, params.builtin_type("hexa_6DOF").hover_pwm) * np.ones((n, 6))
+    env.step_fused(tg, action=hover.astype(np.float32))
+    for _ in range(200):
+        env.step_fused(tg)
+    assert env.ground_contacts() == 0 and float(env.state.fields(2, 1).min()) > 0.9
+    env.close()
