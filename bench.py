@@ -45,7 +45,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 BYTES_PER_DRONE_STEP = 232      # read 13+11+10 floats, write 13+11 floats (quad, per-drone targets)
 MIN_TIMED_S = 0.05              # the timed region is repeated (whole K-step regions) until it covers this much
-WORKLOADS = ["config2x1024", "config2", "config3", "config4", "config5", "hexa", "mixed"]
+WORKLOADS = ["config2x1024", "config2", "config3", "config4", "config5", "hexa", "mixed", "mixed_type_major", "two_call_loop"]
 
 
 def parse(argv=None):
@@ -106,6 +106,7 @@ class Fleet:
         self.torch = torch
         self.n_steps = n_steps
         self.graph = None
+        self.loop = None
         xyz = grid_fleet(n_fleet, replicas)
         self.n = xyz.shape[0]
         models, physics, type_ids = ["robobee"], Physics.PYB, None
@@ -149,10 +150,28 @@ class Fleet:
         self.env.step_fused(self.tgt, action=np.full((self.n, self.env.n_act), 0.4, dtype=np.float32))
 
     def step(self):
-        if self.graph is not None:
+        if self.loop is not None:
+            self.loop()
+        elif self.graph is not None:
             self.graph.replay()
         else:
             self.env.step_fused(self.tgt, n_steps=self.n_steps)
+
+    def make_two_call_loop(self):
+        """step() = one iteration of the reference's example loop (examples/fly_INDI.py:223-239) through the two
+        reference-shaped surfaces: Env.step(action) -> obs, then computeControlFromState -> action."""
+        from dronesim_amd.control import INDIControl
+        torch = self.torch
+        ctrl = INDIControl("robobee", env=self.env)
+        tpos = self.tgt.fields(0, 3).contiguous()
+        state = {"cmd": torch.full((self.n, 4), 0.4, device=self.env.ctx.device)}
+        yaw = np.array([0, 0, 0.4])
+
+        def one():
+            obs, _, _, _ = self.env.step(state["cmd"])
+            state["cmd"], _, _ = ctrl.computeControlFromState(self.env.TIMESTEP * self.env.AGGR_PHY_STEPS, None, target_pos=tpos,
+                                                               target_rpy=yaw)
+        self.loop = one
 
     def use_graph(self, steps):
         """Replay `steps` fused launches per step() call from one captured hipGraph."""
@@ -249,6 +268,9 @@ WORKLOAD_TEXT = {
     "config3": "configs[2] 65536 robobee, waypoint-table tracking (fly_INDI_TrajectoryTrack)",
     "config4": "configs[3] shard: 65536 robobee INDI hover per GPU (524288 over 8 GPUs), no coupling",
     "mixed": "even index robobee, odd index hexa_6DOF, 4096 x 1024 envs/GPU, no downwash",
+    "mixed_type_major": "the same 50/50 robobee + hexa_6DOF fleet stored type-major (one run per type)",
+    "two_call_loop": "configs[1] x 1024 envs/GPU through the reference-shaped loop: obs = env.step(cmd); "
+                     "cmd = ctrl.computeControlFromState(obs)",
     "hexa": "4096 hexa_6DOF (6-DOF INDI + WLS) hover x 1024 vectorised envs/GPU",
     "config5": "configs[4] shard: 65536/GPU, 50% robobee + 50% hexa_6DOF interleaved, neighbour downwash at the config's "
                "density (one drone per m^2: a 128 m x 512 m slab per GPU), halo exchange between neighbouring slabs",
@@ -330,14 +352,18 @@ def main(argv=None):
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
     n_fleet, replicas = {"config2x1024": (4096, 1024), "config2": (4096, 1), "config3": (65536, 1), "config4": (4096, 16),
-                         "config5": (65536, 1), "hexa": (4096, 1024), "mixed": (4096, 1024)}[a.workload]
+                         "config5": (65536, 1), "hexa": (4096, 1024), "mixed": (4096, 1024),
+                         "mixed_type_major": (4096, 1024), "two_call_loop": (4096, 1024)}[a.workload]
     from dronesim_amd import sharding
     # weak scaling: every rank owns a same-sized contiguous shard of the N-GPU fleet; no data-path collective
     # (config5 only: one halo exchange of positions per step for the neighbour-downwash term)
     fl = Fleet(n_fleet, replicas, local, a.substeps, a.layout, sharding.rank_seed(a.noise_seed, rank),
                waypoints=a.workload == "config3", config5=a.workload == "config5",
                dist=dist if a.workload == "config5" else None, rank=rank, hexa=a.workload == "hexa",
-               mixed=a.workload == "mixed", options=options, slab_m=a.slab_m)
+               mixed=("type_major" if a.workload == "mixed_type_major" else a.workload == "mixed"), options=options,
+               slab_m=a.slab_m)
+    if a.workload == "two_call_loop":
+        fl.make_two_call_loop()
 
     def repeat_rule(first_wall):
         # the slowest rank's first region decides how many regions every rank runs
@@ -351,10 +377,13 @@ def main(argv=None):
     launch_s = dev_s / steps_timed
     # config 5: half quads (232 B) half hexas (248 B) + 1 B type id + the 12 B downwash force the step kernel reads;
     # its step is a chain of kernels (neighbour query, step + grid binning, WLS fallback), timed as a whole
-    bytes_per = {"config5": 253, "hexa": 248, "mixed": 241}.get(a.workload, BYTES_PER_DRONE_STEP)
-    kernel = {"config5": "k_dw_query_cell, k_step_mixed (+ fused k_dw_bin), k_wls_fallback",
+    bytes_per = {"config5": 253, "hexa": 248, "mixed": 241, "mixed_type_major": 241,
+                 "two_call_loop": 428}.get(a.workload, BYTES_PER_DRONE_STEP)
+    kernel = {"config5": "k_dw_query_cell, k_step_mixed3 (+ fused grid binning), k_wls_fallback",
               "hexa": "k_step_hexa (+ k_wls_fallback)",
-              "mixed": "k_step_mixed (+ k_wls_fallback)"}.get(a.workload, "k_step_fast")
+              "mixed": "k_step_mixed3 (+ k_wls_fallback)",
+              "mixed_type_major": "k_step_run x2 (+ k_wls_fallback)",
+              "two_call_loop": "k_physics_fast (observation fused) + k_control_fast"}.get(a.workload, "k_step_fast")
     achieved = fl.n * bytes_per / launch_s / 1e9
 
     if rank == 0:
