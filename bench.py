@@ -64,6 +64,7 @@ def parse(argv=None):
     p.add_argument("--generic-mixed", action="store_true", help="mixed fleets: DSIM_OPT_GENERIC_MIXED (A/B knob)")
     p.add_argument("--mixed-v1", action="store_true", help="mixed fleets: DSIM_OPT_MIXED_V1, the round-1 staged kernel (A/B knob)")
     p.add_argument("--mixed-ring", action="store_true", help="mixed fleets: DSIM_OPT_MIXED_RING, the persistent LDS-DMA ring (A/B knob)")
+    p.add_argument("--mixed-v3", action="store_true", help="mixed fleets: DSIM_OPT_MIXED_V3, the three-wave LDS-DMA-staged form (A/B knob)")
     p.add_argument("--slab-m", type=float, default=128.0,
                    help="config5: width of a rank's slab; 128 = the config's density, 1024 = round 1's definition of the line")
     p.add_argument("--lib", default=None, help="a differently-tuned build of libdronesim_amd.so (A/B runs)")
@@ -348,6 +349,7 @@ def main(argv=None):
     options |= nat.OPT_GENERIC_MIXED if a.generic_mixed else 0
     options |= nat.OPT_MIXED_V1 if a.mixed_v1 else 0
     options |= nat.OPT_MIXED_RING if a.mixed_ring else 0
+    options |= nat.OPT_MIXED_V3 if a.mixed_v3 else 0
     barrier = (lambda: dist.barrier()) if dist else None
     red_dev = "cuda" if backend == "nccl" else "cpu"
 

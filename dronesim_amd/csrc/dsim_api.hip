@@ -932,13 +932,142 @@ __global__ __launch_bounds__(64 * WT, 4) void k_step_mixed3(StepK a) {
   }
   __syncthreads();
   if (t < TILE && i0 + t < a.n_pad) {
-    const bool nat_hexa = (a.hexa_types >> (w == 0 ? t0 : t1)) & 1u;
+    const bool nat_hexa = (a.hexa_types >> min((int)a.type_id[i0 + t], DSIM_MAX_TYPES - 1)) & 1u;   // (re-read: not kept live)
     float* sp = a.st.base + kv_off(a.st, i0 + t);
     const long long sfs = a.st.field_stride;
     float (*rows)[64] = tile[w].st;
 #pragma unroll
     for (int f = 0; f < 24; ++f) stg<NT>(sp + f * sfs, 0u, rows[f][lane]);
     if (nat_hexa) { stg<NT>(sp + 24 * sfs, 0u, rows[24][lane]); stg<NT>(sp + 25 * sfs, 0u, rows[25][lane]); }
+    if (a.bin.count && i0 + t < a.n)
+      bin_entry(a.bin, rows[0][lane], rows[1][lane], rows[2][lane], a.bin.local_offset + i0 + t);
+  }
+}
+
+// ---- mixed fleets, fourth form: TWO waves per 128-drone tile ------------------------------------------------------------
+// Counters of the third form at 4 194 304 drones (profiles/r02_mixed_summary.json): waves parked 70 % of their cycles,
+// vector ALU 16 % — a latency-bound kernel, and what bounds it is the number of drones a CU has in flight: 5 workgroups
+// x 128 drones against the 28 waves x 64 drones of the single-type kernels.  A third of the form's waves are the
+// SPARE waves, which exist so that every type can start at a wave boundary and which, in a 64 / 64 tile, do nothing but
+// hold a wave slot and its registers for the workgroup's lifetime.  Here a workgroup is the two natural waves only; the
+// slot groups (whole waves of one type, as before) are dealt to them round-robin, so a tile that needs a third group
+// (65 + 63, or three types) costs one of its waves a second pass instead of costing EVERY tile a third wave.  With
+// the unpadded LDS image (18.4 KB) a CU holds 8 workgroups = 1 024 drones.
+struct Stage64u { float st[DSIM_NF_HEXA][64]; float tg[DSIM_NT][64]; };      // 26 + 10 rows, no padding: 9 KB
+template <int AUX>
+__device__ __forceinline__ void dma_block64u(const float* state_block, const float* target_block, Stage64u& dst, unsigned lane) {
+  const float* sp = state_block + 4 * lane;            // 16 bytes per lane: four rows per DMA
+  const float* tp = target_block + 4 * lane;
+  float* ls = &dst.st[0][0];
+  float* lt = &dst.tg[0][0];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) __builtin_amdgcn_global_load_lds(sp + 256 * q, ls + 256 * q, 16, 0, AUX);
+  __builtin_amdgcn_global_load_lds(state_block + 24 * 64 + lane, ls + 24 * 64, 4, 0, AUX);          // rows 24, 25: one row each
+  __builtin_amdgcn_global_load_lds(state_block + 25 * 64 + lane, ls + 25 * 64, 4, 0, AUX);
+  __builtin_amdgcn_global_load_lds(tp, lt, 16, 0, AUX);
+  __builtin_amdgcn_global_load_lds(tp + 256, lt + 256, 16, 0, AUX);
+  __builtin_amdgcn_global_load_lds(target_block + 8 * 64 + lane, lt + 8 * 64, 4, 0, AUX);           // rows 8, 9
+  __builtin_amdgcn_global_load_lds(target_block + 9 * 64 + lane, lt + 9 * 64, 4, 0, AUX);
+}
+template <bool HEXA, bool NOISE, bool S1>
+__device__ __forceinline__ void staged_body4(const DevType& T, const StepK& a, long long i, Stage64u* tile, unsigned d,
+                                             bool active) {
+  constexpr int NA = HEXA ? 6 : 4;
+  float (*st)[64] = tile[d >> 6].st;
+  float (*tt)[64] = tile[d >> 6].tg;
+  const unsigned c = d & 63u;
+  Rigid s;
+  CtrlMem<NA> m;
+  Target tg;
+  s.pos = v3(st[0][c], st[1][c], st[2][c]);
+  s.q = Q4{st[3][c], st[4][c], st[5][c], st[6][c]};
+  s.vel = v3(st[7][c], st[8][c], st[9][c]);
+  s.w = v3(st[10][c], st[11][c], st[12][c]);
+  m.last_vel = v3(st[13][c], st[14][c], st[15][c]);
+  m.last_rates = v3(st[16][c], st[17][c], st[18][c]);
+  m.last_thrust = st[19][c];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) m.cmd[j] = st[20 + j][c];
+  tg.pos = v3(tt[0][c], tt[1][c], tt[2][c]);
+  tg.vel = v3(tt[3][c], tt[4][c], tt[5][c]);
+  tg.acc = v3(tt[6][c], tt[7][c], tt[8][c]);
+  tg.yaw = tt[9][c];
+  V3 ext = v3(0, 0, 0);
+  if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
+  V3 pos_e;
+  float yaw_e;
+  if constexpr (HEXA) {
+    hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
+    ground_watch(T, s, a.fb.counters, active && i < a.n);
+    indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, active ? i : -1LL);
+  } else {
+    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
+    ground_watch(T, s, a.fb.counters, active && i < a.n);
+    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  }
+  if (!active) return;
+  st[0][c] = s.pos.x; st[1][c] = s.pos.y; st[2][c] = s.pos.z;
+  st[3][c] = s.q.x; st[4][c] = s.q.y; st[5][c] = s.q.z; st[6][c] = s.q.w;
+  st[7][c] = s.vel.x; st[8][c] = s.vel.y; st[9][c] = s.vel.z;
+  st[10][c] = s.w.x; st[11][c] = s.w.y; st[12][c] = s.w.z;
+  st[13][c] = m.last_vel.x; st[14][c] = m.last_vel.y; st[15][c] = m.last_vel.z;
+  st[16][c] = m.last_rates.x; st[17][c] = m.last_rates.y; st[18][c] = m.last_rates.z;
+  st[19][c] = m.last_thrust;
+#pragma unroll
+  for (int j = 0; j < NA; ++j) st[20 + j][c] = m.cmd[j];
+}
+// wave-tiled layout only (state of 26 fields and per-drone targets, as for the ring); up to DSIM_MIXED2_TYPES types
+template <bool NOISE, bool NT, bool S1>
+__global__ __launch_bounds__(128, S1 ? 4 : 3) void k_step_mixed4(StepK a) {
+  constexpr int TILE = 128;
+  __shared__ __attribute__((aligned(16))) Stage64u tile[2];                 // [half]: 18.4 KB
+  const unsigned t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const long long i0 = a.first + (long long)blockIdx.x * TILE;
+  if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
+  constexpr int AUX = NT ? 2 : 0;
+  const long long ih = i0 + 64 * (long long)w;
+  if (ih < a.n_pad)                                                         // each wave brings its own half in
+    dma_block64u<AUX>(a.st.base + (ih >> 6) * a.st.block_stride, a.tg.base + (ih >> 6) * a.tg.block_stride, tile[w], lane);
+  // ---- partition (overlaps the DMAs): both waves ballot both halves; masks and counts are wave-uniform (SGPRs)
+  const int t0 = (i0 + lane < a.n_pad) ? min((int)a.type_id[i0 + lane], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
+  const int t1 = (i0 + 64 + lane < a.n_pad) ? min((int)a.type_id[i0 + 64 + lane], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
+  unsigned long long m0[DSIM_MIXED2_TYPES], m1[DSIM_MIXED2_TYPES];
+  unsigned g0[DSIM_MIXED2_TYPES + 1];                                       // first slot group of each type
+  g0[0] = 0;
+#pragma unroll
+  for (int ty = 0; ty < DSIM_MIXED2_TYPES; ++ty) {
+    m0[ty] = __ballot(t0 == ty); m1[ty] = __ballot(t1 == ty);
+    g0[ty + 1] = g0[ty] + (((unsigned)__popcll(m0[ty]) + (unsigned)__popcll(m1[ty]) + 63u) >> 6);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);                               // vmcnt(0): this wave's DMAs have landed
+  __syncthreads();
+  // ---- the slot groups, dealt round-robin to the two waves: group g of type ty = its drones of rank 64 (g - g0[ty]) ...
+  for (unsigned g = w; g < g0[DSIM_MIXED2_TYPES]; g += 2) {
+    int ty = 0;
+#pragma unroll
+    for (int k = 1; k < DSIM_MIXED2_TYPES; ++k) ty += (g >= g0[k]) ? 1 : 0;
+    ty = __builtin_amdgcn_readfirstlane(ty);
+    unsigned long long ma = 0, mb = 0;
+#pragma unroll
+    for (int k = 0; k < DSIM_MIXED2_TYPES; ++k) if (k == ty) { ma = m0[k]; mb = m1[k]; }
+    const unsigned c0 = (unsigned)__popcll(ma), tot = c0 + (unsigned)__popcll(mb);
+    const unsigned r = (g - g0[ty]) * 64 + lane;
+    const bool active = r < tot;
+    const unsigned rr = active ? r : 0u;
+    const unsigned d = rr < c0 ? nth_set_bit64(ma, rr) : 64u + nth_set_bit64(mb, rr - c0);
+    const long long i = i0 + d;
+    const DevType& T = a.types[ty];
+    if (T.kind == DSIM_DEV_KIND_HEXA) staged_body4<true, NOISE, S1>(T, a, i, tile, d, active);
+    else staged_body4<false, NOISE, S1>(T, a, i, tile, d, active);
+  }
+  __syncthreads();
+  if (i0 + t < a.n_pad) {
+    const bool nat_hexa = (a.hexa_types >> min((int)a.type_id[i0 + t], DSIM_MAX_TYPES - 1)) & 1u;   // (re-read: not kept live)
+    float* sp = a.st.base + ((i0 + t) >> 6) * a.st.block_stride + lane;
+    float (*rows)[64] = tile[w].st;
+#pragma unroll
+    for (int f = 0; f < 24; ++f) stg<NT>(sp + f * 64, 0u, rows[f][lane]);
+    if (nat_hexa) { stg<NT>(sp + 24 * 64, 0u, rows[24][lane]); stg<NT>(sp + 25 * 64, 0u, rows[25][lane]); }
     if (a.bin.count && i0 + t < a.n)
       bin_entry(a.bin, rows[0][lane], rows[1][lane], rows[2][lane], a.bin.local_offset + i0 + t);
   }
@@ -1447,15 +1576,20 @@ __global__ __launch_bounds__(256) void k_dw_bin(DwK a, BinK b, BinRange r) {
   bin_entry(b, dw_pos(a, j, 0), dw_pos(a, j, 1), dw_pos(a, j, 2), j);
 }
 // one candidate's term of formula P8, branch-free (a wave almost always holds a lane that passes the test, so a branch
-// only adds its own overhead): the result is selected, never skipped
-__device__ __forceinline__ float dw_pair(float4 p, float x, float y, float z, float pr, float d0, float d1, float d2c) {
+// only adds its own overhead): the result is selected, never skipped.  K = DW1 (PROP_RADIUS / 4)^2 of the receiver.
+//   alpha = K / dz^2,  beta = DW2 dz + DW3,  term = -alpha exp(-dxy^2 / (2 beta^2))        (BaseAviary.py:1752-1755)
+// ONE reciprocal serves both quotients (1 / (dz^2 beta^2); transcendental instructions issue at a quarter of the FMA
+// rate and were a third of this loop); beta^2 is floored at 1e-12 so that the product cannot underflow — the term is
+// exp(-huge) = 0 there either way.
+__device__ __forceinline__ float dw_pair(float4 p, float x, float y, float z, float K, float d1, float d2c) {
   const float dz = p.z - z, dx = p.x - x, dy = p.y - y;
   const float dd = dx * dx + dy * dy;
-  const bool hit = dz > 0.0f && dd < DW_CUTOFF * DW_CUTOFF;     // BaseAviary.py:1752
+  const bool hit = dz > 0.0f && dd < DW_CUTOFF * DW_CUTOFF;     // :1752
   const float dzs = hit ? dz : 1.0f;                            // keeps the rejected lanes' arithmetic finite
-  const float r = pr * DSIM_RCP(4.0f * dzs);
   const float beta = d1 * dzs + d2c;                            // :1754
-  const float term = -(d0 * r * r) * __expf(-0.5f * dd * DSIM_RCP(beta * beta));   // :1753, 1755
+  const float dz2 = dzs * dzs, b2 = fmaxf(beta * beta, 1e-12f);
+  const float inv = DSIM_RCP(dz2 * b2);
+  const float term = -(K * (inv * b2)) * __expf(-0.5f * dd * (inv * dz2));   // :1753, 1755
   return hit ? term : 0.0f;
 }
 // Cell-centred query.  One workgroup per cell: the buckets of the (2 rings + 1)^2 cells around it are copied to LDS
@@ -1493,7 +1627,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
       const long long i = (long long)__float_as_int(m2.w) - a.local_offset;
       if (i < 0 || i >= a.n) continue;
       const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
-      const float pr = T.prop_radius, d0 = T.dw[0], d1 = T.dw[1], d2c = T.dw[2];
+      const float K = T.dw[0] * (0.25f * T.prop_radius) * (0.25f * T.prop_radius), d1 = T.dw[1], d2c = T.dw[2];
       int ox, oy;
       dw_cell(a, m2.x, m2.y, ox, oy);
       float fz = 0.0f;
@@ -1502,9 +1636,9 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
           const int cc = yy * b.nx + xx;
           const int cnt = min(b.count[cc], DW_CAP);
           const float4* __restrict__ src = b.buckets + (long long)cc * DW_CAP;
-          for (int e = sub; e < cnt; e += DW_LPB) fz += dw_pair(src[e], m2.x, m2.y, m2.z, pr, d0, d1, d2c);
+          for (int e = sub; e < cnt; e += DW_LPB) fz += dw_pair(src[e], m2.x, m2.y, m2.z, K, d1, d2c);
         }
-      for (int e = sub; e < n_ovf; e += DW_LPB) fz += dw_pair(b.overflow[e], m2.x, m2.y, m2.z, pr, d0, d1, d2c);
+      for (int e = sub; e < n_ovf; e += DW_LPB) fz += dw_pair(b.overflow[e], m2.x, m2.y, m2.z, K, d1, d2c);
 #pragma unroll
       for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
       if (sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz; }
@@ -1535,7 +1669,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
     bool have = r < cnt_c;
     float4 me = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     long long i = -1;
-    float pr = 0.0f, d0 = 0.0f, d1 = 0.0f, d2c = 0.0f;
+    float K = 0.0f, d1 = 0.0f, d2c = 0.0f;
     float fz = 0.0f;
     for (int base = 0; base < total; base += tile_cap) {
       if (!whole || r0 == 0) {
@@ -1558,7 +1692,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
         }
         if (have) {
           const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
-          pr = T.prop_radius; d0 = T.dw[0]; d1 = T.dw[1]; d2c = T.dw[2];
+          K = T.dw[0] * (0.25f * T.prop_radius) * (0.25f * T.prop_radius); d1 = T.dw[1]; d2c = T.dw[2];
         }
       }
       if (have) {
@@ -1566,14 +1700,14 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
         int e = sub;
         for (; e + DW_LPB < lim; e += 2 * DW_LPB) {                                    // two candidates in flight per lane
           const float4 p0 = tile[e], p1 = tile[e + DW_LPB];
-          fz += dw_pair(p0, me.x, me.y, me.z, pr, d0, d1, d2c);
-          fz += dw_pair(p1, me.x, me.y, me.z, pr, d0, d1, d2c);
+          fz += dw_pair(p0, me.x, me.y, me.z, K, d1, d2c);
+          fz += dw_pair(p1, me.x, me.y, me.z, K, d1, d2c);
         }
-        if (e < lim) fz += dw_pair(tile[e], me.x, me.y, me.z, pr, d0, d1, d2c);
+        if (e < lim) fz += dw_pair(tile[e], me.x, me.y, me.z, K, d1, d2c);
       }
     }
     if (have)
-      for (int k = sub; k < n_ovf; k += DW_LPB) fz += dw_pair(b.overflow[k], me.x, me.y, me.z, pr, d0, d1, d2c);
+      for (int k = sub; k < n_ovf; k += DW_LPB) fz += dw_pair(b.overflow[k], me.x, me.y, me.z, K, d1, d2c);
 #pragma unroll
     for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
     if (have && sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz; }
@@ -2037,6 +2171,20 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
       // (26 fields: a table with a morphing hexa) and for per-drone targets
       const bool tiled = state.block == 64 && state.field_stride == 64 && ctx->max_act == 6 &&
                          !(args->options & DSIM_OPT_BCAST_TGT) && targets.block == 64 && targets.field_stride == 64;
+      if (tiled && !(args->options & (DSIM_OPT_MIXED_V1 | DSIM_OPT_MIXED_RING | DSIM_OPT_MIXED_V3))) {
+        // fourth form: two waves per tile, slot groups dealt round-robin (wave-tiled layout)
+        const dim3 gm((unsigned)((a.n_pad - first + 127) / 128)), bm(128);
+#define DSIM_MIXED4_CASE(S_)                                                                                      \
+  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed4<true, true, S_>), gm, bm, 0, st_, a);                \
+                    else hipLaunchKernelGGL((k_step_mixed4<true, false, S_>), gm, bm, 0, st_, a); }                \
+       else { if (nt) hipLaunchKernelGGL((k_step_mixed4<false, true, S_>), gm, bm, 0, st_, a);                     \
+              else hipLaunchKernelGGL((k_step_mixed4<false, false, S_>), gm, bm, 0, st_, a); } } while (0)
+        if (a.substeps == 1) DSIM_MIXED4_CASE(true); else DSIM_MIXED4_CASE(false);
+#undef DSIM_MIXED4_CASE
+        if (any_hexa) fb_finish(ctx, a, st_);
+        bin_next_commit(ctx, n, args, a);
+        return (int)hipGetLastError();
+      }
       if (!(args->options & (DSIM_OPT_MIXED_V1 | DSIM_OPT_MIXED_RING)) && ctx->max_act == 6) {
         // third form: one tile per workgroup, LDS-DMA staging in natural order, ballot partition
         const dim3 gm((unsigned)((a.n_pad - first + 127) / 128));

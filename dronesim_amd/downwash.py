@@ -203,8 +203,9 @@ class Downwash:
             m = wp.shape[1]
             box_src = wp
         xmin, ymin, nx, ny = self._grid_box(box_src)
-        if self._auto_cell and self.cell < CUTOFF and not self.ctx.lib.dsim_downwash_prebin_ok(m, nx, ny):
-            # too many cells or too dense for the bucket form: the counting-sort form wants cells of the full cut-off
+        if self._auto_cell and self.cell < CUTOFF and (m < 4 * nx * ny or not self.ctx.lib.dsim_downwash_prebin_ok(m, nx, ny)):
+            # sparse world (fewer than 4 drones per 5 m cell: four times fewer, fuller cells serve it better), or too
+            # many cells / too dense for the bucket form (the counting-sort form wants cells of the full cut-off)
             self.cell, self._box = CUTOFF, None
             if box_src is None:
                 box_src = st.fields(0, 2) if single else wp

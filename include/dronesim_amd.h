@@ -138,8 +138,10 @@ enum {
                                        one (A/B knob)                                                              */
   DSIM_OPT_MIXED_V1    = 1u << 7,   /* mixed fleets: the round-1 form of the LDS-staged kernel (one tile per workgroup,
                                        VGPR staging, three barriers) (A/B knob)                                    */
-  DSIM_OPT_MIXED_RING  = 1u << 8    /* mixed fleets, wave-tiled layout: persistent workgroups with a two-deep LDS-DMA
+  DSIM_OPT_MIXED_RING  = 1u << 8,   /* mixed fleets, wave-tiled layout: persistent workgroups with a two-deep LDS-DMA
                                        ring (A/B knob; measured slower than the default form)                      */
+  DSIM_OPT_MIXED_V3    = 1u << 9    /* mixed fleets, wave-tiled layout: the three-wave form of the LDS-DMA-staged kernel
+                                       (what other layouts get) instead of the two-wave one (A/B knob)             */
 };
 
 /* A run of consecutive drones of one type (type-major storage of a heterogeneous fleet). */

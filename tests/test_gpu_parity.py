@@ -527,13 +527,14 @@ def test_hexa_fused_step_vs_oracle(gpu, substeps, layout):
 
 
 @pytest.mark.parametrize("layout,form", [("soa", "default"), ("tile64", "default"), ("tile64", "v1"), ("soa", "v1"),
-                                         ("tile64", "ring")])
+                                         ("tile64", "ring"), ("tile64", "v3")])
 @pytest.mark.parametrize("sub", [1, 2])
 def test_mixed_fleet_vs_oracle(gpu, sub, layout, form):
     """Config 5 layout: even index robobee (quad INDI), odd index hexa_6DOF (6DOF INDI + WLS), one
     type_id byte per drone; in-kernel noise on.  Every form of the mixed-fleet kernel: the default (LDS-DMA staging in
-    natural order, partition by ballots; 1 KB DMAs on the wave-tiled layout, row DMAs otherwise), round 1's staged
-    kernel (DSIM_OPT_MIXED_V1) and the persistent LDS-DMA ring (DSIM_OPT_MIXED_RING)."""
+    natural order, partition by ballots: two waves per tile with 1 KB DMAs on the wave-tiled layout, three waves with
+    row DMAs otherwise or under DSIM_OPT_MIXED_V3), round 1's staged kernel (DSIM_OPT_MIXED_V1) and the persistent
+    LDS-DMA ring (DSIM_OPT_MIXED_RING)."""
     nat, fleet = gpu
     n = 3000
     types = [params.builtin_type("robobee"), params.builtin_type("hexa_6DOF")]
@@ -550,7 +551,7 @@ def test_mixed_fleet_vs_oracle(gpu, sub, layout, form):
     tid_dev[:n] = torch.from_numpy(tid)
     seed, sidx = 99, 5
     a = _args(nat, sub, DT, float(np.float32(sub / 240)), seed=seed, step_index=sidx, type_id=tid_dev,
-              options={"default": 0, "v1": nat.OPT_MIXED_V1, "ring": nat.OPT_MIXED_RING}[form])
+              options={"default": 0, "v1": nat.OPT_MIXED_V1, "ring": nat.OPT_MIXED_RING, "v3": nat.OPT_MIXED_V3}[form])
     nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
     O = orc.Oracle(types)
     nz = np.zeros((n, sub, 12))

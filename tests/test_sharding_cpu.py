@@ -129,3 +129,33 @@ def test_halo_exchange_equals_allgather_gloo():
         assert out[r][0], r
     assert out[0][2] == [1] and out[2][2] == [1] and out[1][2] == [0, 2]     # neighbours only
     assert out[0][1] < 300 + 300 and out[0][3] < 300                           # a strict subset travels
+
+
+def _uneven_gather_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dronesim_amd.downwash import gather_positions, shard_counts
+    n_total = 65                                                 # 65 drones over 3 ranks: shards of 22, 22, 21
+    b, e = sharding.shard_range(n_total, world, rank)
+    glob = torch.arange(3 * n_total, dtype=torch.float32).reshape(3, n_total)
+    counts = shard_counts(e - b, dist)
+    got = gather_positions(glob[:, b:e].clone(), dist, counts)
+    out[rank] = (counts, bool(torch.equal(got, glob)), sum(counts[:rank]) == b)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_position_allgather_with_uneven_shards_gloo():
+    """sharding.shard_range hands out shards that differ by one drone when the fleet does not divide evenly; the
+    all-gather form of the position exchange pads to the largest shard for the collective and compacts afterwards, and
+    a rank's offset into the world array is the sum of the counts before it (not rank x its own count)."""
+    world = 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_uneven_gather_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        counts, same, offset_ok = out[r]
+        assert counts == [22, 22, 21] and same and offset_ok, (r, out[r])
