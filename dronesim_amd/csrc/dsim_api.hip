@@ -1017,7 +1017,8 @@ __device__ __forceinline__ void staged_body4(const DevType& T, const StepK& a, l
   for (int j = 0; j < NA; ++j) st[20 + j][c] = m.cmd[j];
 }
 // wave-tiled layout only (state of 26 fields and per-drone targets, as for the ring); up to DSIM_MIXED2_TYPES types
-template <bool NOISE, bool NT, bool S1>
+// NTY = number of types in the table (2..4): the ballot loop and the group bookkeeping are sized for it
+template <bool NOISE, bool NT, bool S1, int NTY>
 __global__ __launch_bounds__(128, S1 ? 4 : 3) void k_step_mixed4(StepK a) {
   constexpr int TILE = 128;
   __shared__ __attribute__((aligned(16))) Stage64u tile[2];                 // [half]: 18.4 KB
@@ -1031,25 +1032,25 @@ __global__ __launch_bounds__(128, S1 ? 4 : 3) void k_step_mixed4(StepK a) {
   // ---- partition (overlaps the DMAs): both waves ballot both halves; masks and counts are wave-uniform (SGPRs)
   const int t0 = (i0 + lane < a.n_pad) ? min((int)a.type_id[i0 + lane], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
   const int t1 = (i0 + 64 + lane < a.n_pad) ? min((int)a.type_id[i0 + 64 + lane], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
-  unsigned long long m0[DSIM_MIXED2_TYPES], m1[DSIM_MIXED2_TYPES];
-  unsigned g0[DSIM_MIXED2_TYPES + 1];                                       // first slot group of each type
+  unsigned long long m0[NTY], m1[NTY];
+  unsigned g0[NTY + 1];                                       // first slot group of each type
   g0[0] = 0;
 #pragma unroll
-  for (int ty = 0; ty < DSIM_MIXED2_TYPES; ++ty) {
+  for (int ty = 0; ty < NTY; ++ty) {
     m0[ty] = __ballot(t0 == ty); m1[ty] = __ballot(t1 == ty);
     g0[ty + 1] = g0[ty] + (((unsigned)__popcll(m0[ty]) + (unsigned)__popcll(m1[ty]) + 63u) >> 6);
   }
   __builtin_amdgcn_s_waitcnt(0x0f70);                               // vmcnt(0): this wave's DMAs have landed
   __syncthreads();
   // ---- the slot groups, dealt round-robin to the two waves: group g of type ty = its drones of rank 64 (g - g0[ty]) ...
-  for (unsigned g = w; g < g0[DSIM_MIXED2_TYPES]; g += 2) {
+  for (unsigned g = w; g < g0[NTY]; g += 2) {
     int ty = 0;
 #pragma unroll
-    for (int k = 1; k < DSIM_MIXED2_TYPES; ++k) ty += (g >= g0[k]) ? 1 : 0;
+    for (int k = 1; k < NTY; ++k) ty += (g >= g0[k]) ? 1 : 0;
     ty = __builtin_amdgcn_readfirstlane(ty);
     unsigned long long ma = 0, mb = 0;
 #pragma unroll
-    for (int k = 0; k < DSIM_MIXED2_TYPES; ++k) if (k == ty) { ma = m0[k]; mb = m1[k]; }
+    for (int k = 0; k < NTY; ++k) if (k == ty) { ma = m0[k]; mb = m1[k]; }
     const unsigned c0 = (unsigned)__popcll(ma), tot = c0 + (unsigned)__popcll(mb);
     const unsigned r = (g - g0[ty]) * 64 + lane;
     const bool active = r < tot;
@@ -1660,8 +1661,8 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
   __syncthreads();
   const int cnt_c = nb_cnt[centre];
   if (cnt_c == 0) return;                                                              // nobody to serve here (uniform)
-  int total = 0, centre_base = 0;
-  for (int k = 0; k < n_nb; ++k) { if (k == centre) centre_base = total; total += nb_cnt[k]; }
+  int total = 0;
+  for (int k = 0; k < n_nb; ++k) total += nb_cnt[k];
   // the tile holds the whole neighbourhood in the normal case: one fill, every receiver pass reads it
   const bool whole = total <= tile_cap;
   for (int r0 = 0; r0 < cnt_c; r0 += RPB) {
@@ -1671,6 +1672,15 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
     long long i = -1;
     float K = 0.0f, d1 = 0.0f, d2c = 0.0f;
     float fz = 0.0f;
+    if (have) {          // the receiver and its type's coefficients, straight from its bucket: in flight beside the fill
+      me = b.buckets[(long long)c * DW_CAP + r];
+      i = (long long)__float_as_int(me.w) - a.local_offset;
+      if (i < 0 || i >= a.n) have = false;                                             // another rank's drone: a candidate only
+    }
+    if (have) {
+      const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
+      K = T.dw[0] * (0.25f * T.prop_radius) * (0.25f * T.prop_radius); d1 = T.dw[1]; d2c = T.dw[2];
+    }
     for (int base = 0; base < total; base += tile_cap) {
       if (!whole || r0 == 0) {
         if (base > 0 || r0 > 0) __syncthreads();                                       // the previous tile is done with
@@ -1683,18 +1693,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
         }
         __syncthreads();
       }
-      if (base == 0) {
-        if (have) {
-          // the receiver itself: from the tile when its entry is in this fill, else from its bucket
-          me = (centre_base + r < tile_cap) ? tile[centre_base + r] : b.buckets[(long long)c * DW_CAP + r];
-          i = (long long)__float_as_int(me.w) - a.local_offset;
-          if (i < 0 || i >= a.n) have = false;                                         // another rank's drone: a candidate only
-        }
-        if (have) {
-          const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
-          K = T.dw[0] * (0.25f * T.prop_radius) * (0.25f * T.prop_radius); d1 = T.dw[1]; d2c = T.dw[2];
-        }
-      }
+
       if (have) {
         const int lim = min(tile_cap, total - base);
         int e = sub;
@@ -2174,13 +2173,16 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
       if (tiled && !(args->options & (DSIM_OPT_MIXED_V1 | DSIM_OPT_MIXED_RING | DSIM_OPT_MIXED_V3))) {
         // fourth form: two waves per tile, slot groups dealt round-robin (wave-tiled layout)
         const dim3 gm((unsigned)((a.n_pad - first + 127) / 128)), bm(128);
-#define DSIM_MIXED4_CASE(S_)                                                                                      \
-  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed4<true, true, S_>), gm, bm, 0, st_, a);                \
-                    else hipLaunchKernelGGL((k_step_mixed4<true, false, S_>), gm, bm, 0, st_, a); }                \
-       else { if (nt) hipLaunchKernelGGL((k_step_mixed4<false, true, S_>), gm, bm, 0, st_, a);                     \
-              else hipLaunchKernelGGL((k_step_mixed4<false, false, S_>), gm, bm, 0, st_, a); } } while (0)
+#define DSIM_MIXED4_CASE2(S_, Y_)                                                                                 \
+  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed4<true, true, S_, Y_>), gm, bm, 0, st_, a);            \
+                    else hipLaunchKernelGGL((k_step_mixed4<true, false, S_, Y_>), gm, bm, 0, st_, a); }            \
+       else { if (nt) hipLaunchKernelGGL((k_step_mixed4<false, true, S_, Y_>), gm, bm, 0, st_, a);                 \
+              else hipLaunchKernelGGL((k_step_mixed4<false, false, S_, Y_>), gm, bm, 0, st_, a); } } while (0)
+#define DSIM_MIXED4_CASE(S_) do { if (ctx->n_types == 2) DSIM_MIXED4_CASE2(S_, 2); else if (ctx->n_types == 3) DSIM_MIXED4_CASE2(S_, 3); \
+                                  else DSIM_MIXED4_CASE2(S_, 4); } while (0)
         if (a.substeps == 1) DSIM_MIXED4_CASE(true); else DSIM_MIXED4_CASE(false);
 #undef DSIM_MIXED4_CASE
+#undef DSIM_MIXED4_CASE2
         if (any_hexa) fb_finish(ctx, a, st_);
         bin_next_commit(ctx, n, args, a);
         return (int)hipGetLastError();
@@ -2440,12 +2442,14 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
     b.xmin = a.xmin; b.ymin = a.ymin; b.inv_cell = a.inv_cell; b.nx = a.nx; b.ny = a.ny; b.local_offset = a.local_offset;
     const long long ncells = (long long)a.nx * a.ny;
     // sparse worlds (mean occupancy of a neighbourhood <= 128 entries): one wave per cell and an 8 KB tile, so that a
-    // CU holds ~20 cells at once; dense ones: four waves and 16 KB (BASELINE config 5: 625 entries per neighbourhood)
+    // CU holds ~20 cells at once; dense ones (BASELINE config 5: 625 entries per neighbourhood): two waves and 12 KB —
+    // 11 cells per CU, so that the ~2 800 cells of a 65 536-drone shard are all resident in ONE round (four-wave
+    // workgroups needed 1.4 rounds of 8 per CU, and the thin second round cost 40 % of the kernel's time)
     const int rings = g->cell >= DW_CUTOFF ? 1 : 2;
     const double nb_mean = (double)a.m / (double)ncells * (2 * rings + 1) * (2 * rings + 1);
     const dim3 gq((unsigned)(ncells + DW_OVF_GROUPS));
     if (nb_mean <= 128.0) hipLaunchKernelGGL((k_dw_query_cell<64>), gq, dim3(64), 512 * sizeof(float4), st_, a, b, rings, 512);
-    else hipLaunchKernelGGL((k_dw_query_cell<256>), gq, dim3(256), 1024 * sizeof(float4), st_, a, b, rings, 1024);
+    else hipLaunchKernelGGL((k_dw_query_cell<128>), gq, dim3(128), 768 * sizeof(float4), st_, a, b, rings, 768);
   }
   else hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m * DW_LPR)), dim3(256), 0, st_, a);
   return (int)hipGetLastError();

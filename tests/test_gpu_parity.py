@@ -693,8 +693,8 @@ def test_downwash_vs_bruteforce_oracle(gpu):
 
 def test_downwash_bucket_grid_with_overflowing_cells(gpu):
     """The bucket form of the neighbour grid (one binning pass, cell-centred LDS-tiled query): a swarm of 700 drones
-    packed into a 7 m square overflows the 64-entry buckets of its 5 m cells many times over; the overflow list keeps
-    the result equal to the brute-force sum."""
+    packed into a 7 m square overflows the 64-entry buckets of the cells it sits in many times over; the overflow list
+    keeps the result equal to the brute-force sum.  (Also: a dense world, 5 m cells and the two-wave query.)"""
     nat, fleet = gpu
     from dronesim_amd.downwash import Downwash
     n = 2500
@@ -708,13 +708,29 @@ def test_downwash_bucket_grid_with_overflowing_cells(gpu):
     dw = Downwash(ctx, st)
     f = dw.compute().cpu().numpy()
     g = dw._last
-    assert g.cell == 5.0 and ctx.lib.dsim_downwash_prebin_ok(g.m, g.nx, g.ny) == 1      # this shape takes the bucket form
+    assert ctx.lib.dsim_downwash_prebin_ok(g.m, g.nx, g.ny) == 1      # this shape takes the bucket form (10 m cells: sparse world)
     ref = orc.Oracle([params.builtin_type("robobee")]).downwash(rigid, rigid[:, 0:3])
     assert (ref[:700] < 0).sum() > 600
     err = np.abs(f[2, :n] - ref) / (np.abs(ref) + 1e-3)
     assert err.max() < 1e-4, (err.max(), err.argmax())
     f_again = dw.compute().cpu().numpy()                        # second build: the double-buffered counts were re-zeroed
     assert (np.abs(f_again[2, :n] - ref) / (np.abs(ref) + 1e-3)).max() < 1e-4
+    ctx.close()
+    # a dense world: 0.8 drones per m^2 -> 5 m cells, 5 x 5 neighbourhoods of ~500 entries (two-wave query, 12 KB tile),
+    # plus a knot of 400 drones in one cell whose neighbourhood does not fit the tile (several fills)
+    n = 6000
+    ctx = fleet.Context([params.builtin_type("robobee")])
+    st = fleet.FleetState(ctx, n)
+    rigid, mem, _ = random_fleet(rng, n)
+    rigid[:, 0] = f32(rng.uniform(0, 85, n)); rigid[:, 1] = f32(rng.uniform(0, 85, n)); rigid[:, 2] = f32(rng.uniform(0.5, 20, n))
+    rigid[:400, 0] = f32(rng.uniform(41, 44, 400)); rigid[:400, 1] = f32(rng.uniform(41, 44, 400))
+    st.load_aos(rigid, mem)
+    dw = Downwash(ctx, st)
+    f = dw.compute().cpu().numpy()
+    assert dw._last.cell == 5.0
+    ref = orc.Oracle([params.builtin_type("robobee")]).downwash(rigid, rigid[:, 0:3])
+    err = np.abs(f[2, :n] - ref) / (np.abs(ref) + 1e-3)
+    assert err.max() < 1e-4, (err.max(), err.argmax())
     ctx.close()
 
 
