@@ -1593,33 +1593,12 @@ __device__ __forceinline__ float dw_pair(float4 p, float x, float y, float z, fl
   const float term = -(K * (inv * b2)) * __expf(-0.5f * dd * (inv * dz2));   // :1753, 1755
   return hit ? term : 0.0f;
 }
-// TWO candidates at once in packed fp32 (v_pk_add/mul/fma_f32: one instruction, both halves).  Measured on this kernel
-// and on the 5-sub-step fused kernel (profiles/r02_c5_summary.json, r02_sub5_summary.json): a wave64 fp32 instruction
-// occupies its SIMD's vector pipe for ~4 cycles, so a VALU-bound loop runs at half the chip's quoted fp32 rate unless
-// its arithmetic is packed; the compiler's own SLP packing loses that again in operand shuffles (it is switched off
-// for this library), but here the LDS image is laid out for it — x, y and z of the candidates in separate arrays, so
-// that one 8-byte LDS read delivers (x_e, x_e+1) as the register pair a packed instruction wants.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f dw_pair2(v2f X, v2f Y, v2f Z, float x, float y, float z, float K, float d1, float d2c) {
-  const v2f dz = Z - z, dx = X - x, dy = Y - y;
-  const v2f dd = dx * dx + dy * dy;
-  const bool h0 = dz.x > 0.0f && dd.x < DW_CUTOFF * DW_CUTOFF, h1 = dz.y > 0.0f && dd.y < DW_CUTOFF * DW_CUTOFF;   // :1752
-  v2f dzs;
-  dzs.x = h0 ? dz.x : 1.0f; dzs.y = h1 ? dz.y : 1.0f;
-  const v2f beta = dzs * d1 + d2c;                              // :1754
-  const v2f dz2 = dzs * dzs;
-  v2f b2 = beta * beta;
-  b2.x = fmaxf(b2.x, 1e-12f); b2.y = fmaxf(b2.y, 1e-12f);
-  const v2f prod = dz2 * b2;
-  v2f inv;
-  inv.x = DSIM_RCP(prod.x); inv.y = DSIM_RCP(prod.y);
-  const v2f arg = dd * (inv * dz2) * (-0.5f * 1.44269504088896340736f);      // exp(a) = exp2(a log2 e)
-  v2f ex;
-  ex.x = __builtin_amdgcn_exp2f(arg.x); ex.y = __builtin_amdgcn_exp2f(arg.y);
-  v2f term = (inv * b2) * ex * (-K);                            // :1753, 1755
-  term.x = h0 ? term.x : 0.0f; term.y = h1 ? term.y : 0.0f;
-  return term;
-}
+// (Measured and rejected: the same loop in PACKED fp32 — two candidates per v_pk_add/mul/fma_f32 on an x | y | z LDS
+// image read 8 bytes at a time, 16 packed instructions per candidate pair instead of ~50 scalar ones: 135 us instead of
+// 50 us at BASELINE config 5's density.  On gfx950 a v_pk_*_f32 costs far more issue time than the two scalar
+// instructions it replaces (MI355X_MICROARCH.md prices one v_pk_fma_f32 at +22 cycles over two v_fma_f32), which is
+// also why the compiler's SLP vectoriser is switched off for this library.  The loop is bound by the vector pipe at
+// ~4.6 cycles per wave64 instruction: 22.1 M instructions per launch, profiles/r02_c5_summary.json.)
 // Cell-centred query.  One workgroup per cell: the buckets of the (2 rings + 1)^2 cells around it are copied to LDS
 // once — all counts first, then one flattened pass, so every global load of the fill is in flight together — and the
 // cell's receivers (read back from that LDS copy) are taken TPB / 8 at a time, DW_LPB lanes each: every
@@ -1636,10 +1615,7 @@ __device__ __forceinline__ v2f dw_pair2(v2f X, v2f Y, v2f Z, float x, float y, f
 #define DW_OVF_GROUPS 16
 template <int TPB>
 __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings, int tile_cap) {
-  extern __shared__ float tile_f[];                               // x[cap + 2] | y[cap + 2] | z[cap + 2] of the candidates
-  float* const tx = tile_f;
-  float* const ty = tile_f + (tile_cap + 2);
-  float* const tz = tile_f + 2 * (tile_cap + 2);
+  extern __shared__ float4 tile[];                                                     // tile_cap entries
   __shared__ int nb_cell[DW_NBR], nb_cnt[DW_NBR];
   constexpr int RPB = TPB / DW_LPB;                                                    // receivers per pass
   const int ncells = b.nx * b.ny;
@@ -1719,22 +1695,20 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
           int k = 0, acc = 0;
           const int g = base + e;
           while (g >= acc + nb_cnt[k]) { acc += nb_cnt[k]; ++k; }
-          const float4 p = b.buckets[(long long)nb_cell[k] * DW_CAP + (g - acc)];
-          tx[e] = p.x; ty[e] = p.y; tz[e] = p.z;
+          tile[e] = b.buckets[(long long)nb_cell[k] * DW_CAP + (g - acc)];
         }
-        if (t == 0) { tx[lim] = 0.0f; ty[lim] = 0.0f; tz[lim] = -3.0e38f; }            // pads an odd count: below everybody
         __syncthreads();
       }
 
       if (have) {
         const int lim = min(tile_cap, total - base);
-        v2f acc2 = {0.0f, 0.0f};
-        for (int e = 2 * sub; e < lim; e += 2 * DW_LPB) {                              // candidates e, e + 1: packed
-          const v2f X = *reinterpret_cast<const v2f*>(tx + e), Y = *reinterpret_cast<const v2f*>(ty + e),
-                    Z = *reinterpret_cast<const v2f*>(tz + e);
-          acc2 += dw_pair2(X, Y, Z, me.x, me.y, me.z, K, d1, d2c);
+        int e = sub;
+        for (; e + DW_LPB < lim; e += 2 * DW_LPB) {                                    // two candidates in flight per lane
+          const float4 p0 = tile[e], p1 = tile[e + DW_LPB];
+          fz += dw_pair(p0, me.x, me.y, me.z, K, d1, d2c);
+          fz += dw_pair(p1, me.x, me.y, me.z, K, d1, d2c);
         }
-        fz += acc2.x + acc2.y;
+        if (e < lim) fz += dw_pair(tile[e], me.x, me.y, me.z, K, d1, d2c);
       }
     }
     if (have)
@@ -2480,8 +2454,8 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
     const int rings = g->cell >= DW_CUTOFF ? 1 : 2;
     const double nb_mean = (double)a.m / (double)ncells * (2 * rings + 1) * (2 * rings + 1);
     const dim3 gq((unsigned)(ncells + DW_OVF_GROUPS));
-    if (nb_mean <= 128.0) hipLaunchKernelGGL((k_dw_query_cell<64>), gq, dim3(64), 3 * (512 + 2) * sizeof(float), st_, a, b, rings, 512);
-    else hipLaunchKernelGGL((k_dw_query_cell<128>), gq, dim3(128), 3 * (768 + 2) * sizeof(float), st_, a, b, rings, 768);
+    if (nb_mean <= 128.0) hipLaunchKernelGGL((k_dw_query_cell<64>), gq, dim3(64), 512 * sizeof(float4), st_, a, b, rings, 512);
+    else hipLaunchKernelGGL((k_dw_query_cell<128>), gq, dim3(128), 768 * sizeof(float4), st_, a, b, rings, 768);
   }
   else hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m * DW_LPR)), dim3(256), 0, st_, a);
   return (int)hipGetLastError();

@@ -16,7 +16,11 @@ one() {  # label, args...
     python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$label', round(d['value']/1e9,3), 'Gds/s', round(d['roofline']['launch_us'],1), 'us frac', round(d['roofline']['frac'],3))" | tee -a $OUT/ab.txt
 }
 for round in 1 2; do
-  one "mixed (default)" --workload mixed
+  one "mixed v4(default: two waves per tile)" --workload mixed
+  one "mixed v3 (three waves)" --workload mixed --mixed-v3
+  one "mixed v3 soa layout" --workload mixed --layout soa
+  one "mixed type-major" --workload mixed_type_major
+  one "two-call loop" --workload two_call_loop
   one "config5 slab128" --workload config5
   one "config5 slab1024(r01 def)" --workload config5 --slab-m 1024
 done
