@@ -392,11 +392,11 @@ __global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
   } else {
     hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index);
   }
-  ground_watch(T, s, a.fb.counters, i < a.n);
   indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
   const unsigned so = pin_lane_offset(sl);
   store_rigid<NT>(sb, sfs, so, s);
   store_mem<6, NT>(sb, sfs, so, m);
+  ground_watch(T, s, a.fb.counters, i < a.n);       // (at the very end: between the physics and the law it cost 44 VGPRs)
 }
 
 // ends a chained sequence: last_vel / last_rates back into the state block
@@ -771,13 +771,12 @@ __device__ __forceinline__ void staged_body2(const DevType& T, const StepK& a, l
   float yaw_e;
   if constexpr (HEXA) {
     hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
-    ground_watch(T, s, a.fb.counters, active && i < a.n);
     indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, active ? i : -1LL);
   } else {
     quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
-    ground_watch(T, s, a.fb.counters, active && i < a.n);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
+  ground_watch(T, s, a.fb.counters, active && i < a.n);      // (behind the law: in front of it it costs registers)
   if (!active) return;
   st[0][c] = s.pos.x; st[1][c] = s.pos.y; st[2][c] = s.pos.z;
   st[3][c] = s.q.x; st[4][c] = s.q.y; st[5][c] = s.q.z; st[6][c] = s.q.w;
@@ -877,7 +876,7 @@ __global__ __launch_bounds__(64 * WT, 3) void k_step_mixed2(StepK a, long long n
 //     its drones by select-the-r-th-set-bit, as in the ring): two barriers per tile instead of three.
 // TILED: wave-tiled layout (rows of a block contiguous) -> 10 DMAs of 1 KB per half; otherwise 36 row DMAs of 256 B.
 template <bool NOISE, bool NT, int WT, bool S1, bool TILED>
-__global__ __launch_bounds__(64 * WT, 4) void k_step_mixed3(StepK a) {
+__global__ __launch_bounds__(64 * WT, S1 ? 4 : 3) void k_step_mixed3(StepK a) {
   constexpr int TILE = 128;
   __shared__ __attribute__((aligned(16))) Stage64 tile[2];                  // [half]: 20 KB
   const unsigned t = threadIdx.x, w = t >> 6, lane = t & 63;
@@ -998,13 +997,12 @@ __device__ __forceinline__ void staged_body4(const DevType& T, const StepK& a, l
   float yaw_e;
   if constexpr (HEXA) {
     hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
-    ground_watch(T, s, a.fb.counters, active && i < a.n);
     indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, active ? i : -1LL);
   } else {
     quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
-    ground_watch(T, s, a.fb.counters, active && i < a.n);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
+  ground_watch(T, s, a.fb.counters, active && i < a.n);      // (behind the law: in front of it it costs registers)
   if (!active) return;
   st[0][c] = s.pos.x; st[1][c] = s.pos.y; st[2][c] = s.pos.z;
   st[3][c] = s.q.x; st[4][c] = s.q.y; st[5][c] = s.q.z; st[6][c] = s.q.w;
@@ -1100,16 +1098,15 @@ __global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void
   float yaw_e;
   if constexpr (HEXA) {
     hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
-    ground_watch(T, s, a.fb.counters, i < a.n);
     indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
   } else {
     quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
-    ground_watch(T, s, a.fb.counters, i < a.n);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   const unsigned so = pin_lane_offset(sl);
   store_rigid<NT>(sb, sfs, so, s);
   store_mem<NA, NT>(sb, sfs, so, m);
+  ground_watch(T, s, a.fb.counters, i < a.n);
   if (a.bin.count && i < a.n) bin_entry(a.bin, s.pos.x, s.pos.y, s.pos.z, a.bin.local_offset + i);   // next step's grid
 }
 
