@@ -26,6 +26,7 @@ NF_QUAD, NF_HEXA, NT = 24, 26, 10
 OPT_DRAG, OPT_GROUND, OPT_BCAST_TGT, OPT_CHAINED = 1, 2, 4, 8
 OPT_STREAM_ON, OPT_STREAM_OFF, OPT_GENERIC_MIXED, OPT_MIXED_V1, OPT_MIXED_RING, OPT_MIXED_V3 = 16, 32, 64, 128, 256, 512   # tuning knobs
 TUNING_MASK = OPT_STREAM_ON | OPT_STREAM_OFF | OPT_GENERIC_MIXED | OPT_MIXED_V1 | OPT_MIXED_RING | OPT_MIXED_V3   # (results do not depend on them)
+OPT_PLANE = 1 << 10        # ground-plane contact (product-defined model, oracle/dsim_oracle.c:orc_plane_contact)
 ADAPT_VELOCITY, ADAPT_RPYT = 0, 1
 QUERY_WLS_FALLBACKS, QUERY_WLS_FAILURES, QUERY_GROUND_CONTACTS = 0, 1, 2
 

@@ -229,7 +229,7 @@ __device__ __forceinline__ int waypoint_next(int wp, int n_wp) { return wp < n_w
 // metric definition): without the loop the compiler keeps the headline kernel in 91 instead of 110 VGPRs
 // (5 waves/SIMD) and 836 instead of 887 vector instructions.  (Measured and rejected: 2 — no change, 198 us
 // either way; 5 — the unrolled body spills, 533 vs 310 us.)
-template <int NOISE, int NROW = 4, bool OPTS = false, int NSUB = 0>
+template <int NOISE, int NROW = 4, bool OPTS = false, int NSUB = 0, bool PLANE = false>
 __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[4], unsigned long long step_index,
                                               V3 ext = V3{0.0f, 0.0f, 0.0f}, const float* prev = nullptr) {
@@ -252,7 +252,7 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
       }
       quad_wrench(T, cmd, nz, F, tau);
     }
-    if (OPTS && (a.options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND))) {
+    if (OPTS && (PLANE || (a.options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)))) {
       V3 F2 = F + ext, tau2 = tau;
       if (a.options & DSIM_OPT_GROUND) ground_effect_quad(T, s, cmd, F2, tau2);              // BaseAviary.py:528-529
       if (a.options & DSIM_OPT_DRAG) {                                                        // :531-532
@@ -261,7 +261,7 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
         for (int j = 0; j < 4; ++j) lc[j] = (k == 0 && prev) ? prev[j] : cmd[j];
         F2 = F2 + drag_quad(T, s, lc);
       }
-      bullet_step(T, a.dt_phys, s, F2, tau2);
+      bullet_step<PLANE>(T, a.dt_phys, s, F2, tau2);
       continue;
     }
     bullet_step(T, a.dt_phys, s, F + ext, tau);
@@ -269,7 +269,7 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
 }
 
 // the same for the morphing hexa (BaseAviary.py:1389-1457); replay rows: f[6], m[6]
-template <bool NOISE, bool REPLAY = true, bool ONE = false>
+template <bool NOISE, bool REPLAY = true, bool ONE = false, bool PLANE = false>
 __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[6], unsigned long long step_index,
                                               V3 ext = V3{0.0f, 0.0f, 0.0f}) {
@@ -289,7 +289,7 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
       }
       hexa_wrench(T, cmd, nz, F, tau);
     }
-    bullet_step(T, a.dt_phys, s, F + ext, tau);
+    bullet_step<PLANE>(T, a.dt_phys, s, F + ext, tau);
   }
 }
 
@@ -491,7 +491,7 @@ __device__ __forceinline__ Addr make_addr(const StepK& a, long long i0, unsigned
 }
 // FULL = false: the lean form for plain stepping of mixed fleets (stored cmd as the action, no
 // noise replay, no waypoint table, one Env.step per launch) — the options cost registers.
-template <bool NOISE, int NACT, bool FULL>
+template <bool NOISE, int NACT, bool FULL, bool PLANE = false>
 __device__ __forceinline__ void step_gen_body(const DevType& T, const StepK& a, long long i, const Addr& ad) {
   Rigid s;
   CtrlMem<NACT> m;
@@ -517,12 +517,12 @@ __device__ __forceinline__ void step_gen_body(const DevType& T, const StepK& a, 
     float yaw_e;
     if (NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA) {     // wave-uniform branch
       if constexpr (NACT == 6) {
-        hexa_substeps<NOISE, FULL>(T, a, i, s, act, a.step_index + k, ext);
+        hexa_substeps<NOISE, FULL, false, PLANE>(T, a, i, s, act, a.step_index + k, ext);
         ground_watch(T, s, a.fb.counters, i < a.n);
         indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
       }
     } else {
-      quad_substeps<NOISE ? (FULL ? 2 : 1) : 0, NACT, FULL>(T, a, i, s, act, a.step_index + k, ext);
+      quad_substeps<NOISE ? (FULL ? 2 : 1) : 0, NACT, FULL, 0, PLANE>(T, a, i, s, act, a.step_index + k, ext);
       ground_watch(T, s, a.fb.counters, i < a.n);
       indi_quad<false, NACT>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
     }
@@ -544,6 +544,19 @@ __global__ __launch_bounds__(256, NOISE ? 1 : DSIM_GEN_WAVES) void k_step_gen(St
   if (a.step_index_dev) a.step_index += *a.step_index_dev;
   const Addr ad = make_addr(a, i0, p);
   DSIM_FOR_MY_TYPE(UNIFORM, a, i, (step_gen_body<NOISE, NACT, true>(T, a, i, ad)));
+}
+// DSIM_OPT_PLANE: the full-option body with the ground-plane contact solve between the velocity and the position
+// update of every sub-step (dsim_device.h:plane_contact).  A landing / take-off configuration, not a flight one:
+// these instances take the whole register file rather than spill.
+template <bool NOISE, bool UNIFORM, int NACT>
+__global__ __launch_bounds__(256, 1) void k_step_plane(StepK a) {
+  const long long i0 = a.first + (long long)blockIdx.x * 256;
+  const unsigned p = tile_slot<UNIFORM>(a.type_id, i0, a.n_pad);
+  const long long i = i0 + p;
+  if (i >= a.n_pad) return;
+  if (a.step_index_dev) a.step_index += *a.step_index_dev;
+  const Addr ad = make_addr(a, i0, p);
+  DSIM_FOR_MY_TYPE(UNIFORM, a, i, (step_gen_body<NOISE, NACT, true, true>(T, a, i, ad)));
 }
 template <bool NOISE, bool UNIFORM, int NACT>
 __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_step_lean(StepK a) {
@@ -1111,7 +1124,7 @@ __global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void
 }
 
 // ---- Env.step only ---------------------------------------------------------
-template <bool NOISE, int NACT>
+template <bool NOISE, int NACT, bool PLANE = false>
 __device__ __forceinline__ void physics_gen_body(const DevType& T, const StepK& a, long long i, const Addr& ad) {
   Rigid s;
   load_rigid(ad.sb, ad.sfs, ad.sl, s);
@@ -1122,12 +1135,12 @@ __device__ __forceinline__ void physics_gen_body(const DevType& T, const StepK& 
   V3 ext = v3(0, 0, 0);
   if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
   if (NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA) {
-    if constexpr (NACT == 6) hexa_substeps<NOISE>(T, a, i, s, cmd, a.step_index, ext);
+    if constexpr (NACT == 6) hexa_substeps<NOISE, true, false, PLANE>(T, a, i, s, cmd, a.step_index, ext);
   } else {
     float prev[4];       // last_clipped_action of the previous step (drag of sub-step 0); this step's action without it
 #pragma unroll
     for (int j = 0; j < 4; ++j) prev[j] = a.echo ? a.echo[(long long)j * a.n_pad + i] : cmd[j];
-    quad_substeps<NOISE ? 2 : 0, NACT, true>(T, a, i, s, cmd, a.step_index, ext, prev);
+    quad_substeps<NOISE ? 2 : 0, NACT, true, 0, PLANE>(T, a, i, s, cmd, a.step_index, ext, prev);
   }
   ground_watch(T, s, a.fb.counters, i < a.n);
   store_rigid(ad.sb, ad.sfs, ad.sl, s);
@@ -1144,6 +1157,15 @@ __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_physics_gen(StepK a) {
   if (i >= a.n_pad) return;
   const Addr ad = make_addr(a, i0, p);
   DSIM_FOR_MY_TYPE(UNIFORM, a, i, (physics_gen_body<NOISE, NACT>(T, a, i, ad)));
+}
+template <bool NOISE, bool UNIFORM, int NACT>
+__global__ __launch_bounds__(256, 1) void k_physics_plane(StepK a) {     // DSIM_OPT_PLANE (see k_step_plane)
+  const long long i0 = (long long)blockIdx.x * 256;
+  const unsigned p = tile_slot<UNIFORM>(a.type_id, i0, a.n_pad);
+  const long long i = i0 + p;
+  if (i >= a.n_pad) return;
+  const Addr ad = make_addr(a, i0, p);
+  DSIM_FOR_MY_TYPE(UNIFORM, a, i, (physics_gen_body<NOISE, NACT, true>(T, a, i, ad)));
 }
 
 // ---- computeControl only ----------------------------------------------------
@@ -1277,7 +1299,7 @@ __global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_control_fast(StepK a) 
 
 // ---- Env.step of the alternate action adaptors (VelocityAviary / RPYTAviary) --------------
 // control (inside _preprocessAction) on the CURRENT state, then the physics with the new command
-template <int MODE, bool NOISE>
+template <int MODE, bool NOISE, bool PLANE>
 __device__ __forceinline__ void adaptor_body(const DevType& T, const StepK& a, long long i, const Addr& ad) {
   Rigid s;
   CtrlMem<4> m;
@@ -1300,7 +1322,7 @@ __device__ __forceinline__ void adaptor_body(const DevType& T, const StepK& a, l
   } else {                                                 // RPYTAviary.py:184-191
     indi_rate<4>(T, DSIM_RCP(a.dt_ctrl), s, v3(v[0], v[1], v[2]), v[3], m);
   }
-  quad_substeps<NOISE ? 1 : 0, 4>(T, a, i, s, m.cmd, a.step_index);
+  quad_substeps<NOISE ? 1 : 0, 4, PLANE, 0, PLANE>(T, a, i, s, m.cmd, a.step_index);
   ground_watch(T, s, a.fb.counters, i < a.n);
   store_rigid(ad.sb, ad.sfs, ad.sl, s);
   store_mem<4>(ad.sb, ad.sfs, ad.sl, m);
@@ -1309,14 +1331,14 @@ __device__ __forceinline__ void adaptor_body(const DevType& T, const StepK& a, l
     for (int j = 0; j < 4; ++j) a.echo[(long long)j * a.n_pad + i] = m.cmd[j];
   }
 }
-template <int MODE, bool NOISE, bool UNIFORM>
-__global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_adaptor(StepK a) {
+template <int MODE, bool NOISE, bool UNIFORM, bool PLANE = false>
+__global__ __launch_bounds__(256, PLANE ? 1 : DSIM_GEN_WAVES) void k_adaptor(StepK a) {
   const long long i0 = (long long)blockIdx.x * 256;
   const unsigned p = tile_slot<UNIFORM>(a.type_id, i0, a.n_pad);
   const long long i = i0 + p;
   if (i >= a.n_pad) return;
   const Addr ad = make_addr(a, i0, p);
-  DSIM_FOR_MY_TYPE(UNIFORM, a, i, (adaptor_body<MODE, NOISE>(T, a, i, ad)));
+  DSIM_FOR_MY_TYPE(UNIFORM, a, i, (adaptor_body<MODE, NOISE, PLANE>(T, a, i, ad)));
 }
 
 // ---- deferred WLS fallbacks (hexa) -----------------------------------------------
@@ -1843,6 +1865,7 @@ static void to_dev(const dsim_type_params& p, DevType* d) {
   if (p.kind == DSIM_KIND_HEXA6DOF) { d->reset_thrust = 0.3f; d->reset_cmd = 0.5f; }   // INDIControl_6DOF.py:232-234
   d->speed_limit = (float)(p.max_speed_kmh * (1000.0 / 3600.0));
   d->coll_r = (float)p.collision_radius; d->coll_below = (float)p.collision_below;
+  d->mu_plane = (float)p.contact_friction;
 }
 
 extern "C" {
@@ -2057,8 +2080,10 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   const hipStream_t st_ = (hipStream_t)stream;
   const dim3 b(256);
   long long first = 0;
-  const bool phys_opts = (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)) != 0;
-  if (phys_opts && six) return DSIM_E_UNSUPPORTED;      // the add-on formulas are written for the four-rotor links
+  const bool phys_opts = (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND | DSIM_OPT_PLANE)) != 0;
+  const bool plane = (args->options & DSIM_OPT_PLANE) != 0;
+  if ((args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)) && six)
+    return DSIM_E_UNSUPPORTED;                          // the add-on formulas are written for the four-rotor links
   if ((args->options & DSIM_OPT_CHAINED) && (!uni || six || args->action || args->noise_replay || args->ext_force ||
                                              phys_opts || (state.n_pad % 256)))
     return DSIM_E_UNSUPPORTED;                          // chained stepping is a fast-path-only mode
@@ -2135,7 +2160,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   }
   bool fb_open = false;
   if (uni && six && ctx->h_types[0].kind == DSIM_KIND_HEXA6DOF && !args->noise_replay && !args->ext_force &&
-      !a.wp_table && a.n_steps == 1 && a.n_pad >= 256) {
+      !a.wp_table && a.n_steps == 1 && a.n_pad >= 256 && !phys_opts) {
     const long long tiles = a.n_pad / 256;
     const bool nt = stream_policy(args, state.n_pad, 248.0);
     rc = fb_prepare(ctx, a.n_pad, st_);
@@ -2241,6 +2266,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
       bin_next_commit(ctx, n, args, a);
     } else if (!six) {
       if (lean) DSIM_LAUNCH_GEN(k_step_lean, noise, uni, false, g, a, st_);
+      else if (plane) DSIM_LAUNCH_GEN(k_step_plane, noise, uni, false, g, a, st_);
       else DSIM_LAUNCH_GEN(k_step_gen, noise, uni, false, g, a, st_);
     } else {
       // hexa fleets: deferred WLS fallbacks must land before the next Env.step reads cmd, so several
@@ -2255,6 +2281,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
         }
         fb_open = false;
         if (lean && !a.action) DSIM_LAUNCH_GEN(k_step_lean, noise, uni, true, g, a, st_);
+        else if (plane) DSIM_LAUNCH_GEN(k_step_plane, noise, uni, true, g, a, st_);
         else DSIM_LAUNCH_GEN(k_step_gen, noise, uni, true, g, a, st_);
         fb_finish(ctx, a, st_);
         a.step_index += 1;
@@ -2293,8 +2320,8 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
   int rc = fill_stepk(ctx, n, state, nullptr, args, &a);
   if (rc) return rc;
   a.echo = last_action_out;
-  const bool phys_opts = (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)) != 0;
-  if (phys_opts && ctx->max_act == 6) return DSIM_E_UNSUPPORTED;
+  const bool phys_opts = (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND | DSIM_OPT_PLANE)) != 0;
+  if ((args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)) && ctx->max_act == 6) return DSIM_E_UNSUPPORTED;
   const int obs_w = 16 + ctx->max_act;
   if (args->obs_out && args->obs_width != obs_w) return DSIM_E_ARG;
   const bool noise = args->noise_seed != 0 || args->noise_replay != nullptr;
@@ -2313,7 +2340,8 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
     return (int)hipGetLastError();
   }
   const dim3 g(grid_for(a.n_pad));
-  DSIM_LAUNCH_GEN(k_physics_gen, noise, args->type_id == nullptr, ctx->max_act == 6, g, a, st_);
+  if (args->options & DSIM_OPT_PLANE) DSIM_LAUNCH_GEN(k_physics_plane, noise, args->type_id == nullptr, ctx->max_act == 6, g, a, st_);
+  else DSIM_LAUNCH_GEN(k_physics_gen, noise, args->type_id == nullptr, ctx->max_act == 6, g, a, st_);
   if (args->obs_out)       // general fleets: the same rows by the observation kernel, behind the step on the stream
     return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, obs_w, 0);
   return (int)hipGetLastError();
@@ -2324,20 +2352,24 @@ int dsim_step_adaptor(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, c
   StepK a;
   if (!action || (mode != DSIM_ADAPT_VELOCITY && mode != DSIM_ADAPT_RPYT)) return DSIM_E_ARG;
   if (ctx && ctx->max_act == 6) return DSIM_E_UNSUPPORTED;
-  if (args && (args->noise_replay || args->wp_table)) return DSIM_E_UNSUPPORTED;
+  if (args && (args->noise_replay || args->wp_table || args->ext_force ||
+               (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND))))
+    return DSIM_E_UNSUPPORTED;        // plain PYB physics (+ the plane): refuse what the adaptor kernels would silently drop
   int rc = fill_stepk(ctx, n, state, nullptr, args, &a);
   if (rc) return rc;
   a.action = action; a.echo = last_action_out;
   const bool noise = args->noise_seed != 0, uni = args->type_id == nullptr;
   const dim3 g(grid_for(a.n_pad)), b(256);
   const hipStream_t st_ = (hipStream_t)stream;
-#define DSIM_ADAPT_CASE(M_)                                                                         \
-  do { if (noise) { if (uni) hipLaunchKernelGGL((k_adaptor<M_, true, true>), g, b, 0, st_, a);      \
-                    else hipLaunchKernelGGL((k_adaptor<M_, true, false>), g, b, 0, st_, a); }       \
-       else { if (uni) hipLaunchKernelGGL((k_adaptor<M_, false, true>), g, b, 0, st_, a);           \
-              else hipLaunchKernelGGL((k_adaptor<M_, false, false>), g, b, 0, st_, a); } } while (0)
+#define DSIM_ADAPT_CASE2(M_, P_)                                                                       \
+  do { if (noise) { if (uni) hipLaunchKernelGGL((k_adaptor<M_, true, true, P_>), g, b, 0, st_, a);      \
+                    else hipLaunchKernelGGL((k_adaptor<M_, true, false, P_>), g, b, 0, st_, a); }       \
+       else { if (uni) hipLaunchKernelGGL((k_adaptor<M_, false, true, P_>), g, b, 0, st_, a);           \
+              else hipLaunchKernelGGL((k_adaptor<M_, false, false, P_>), g, b, 0, st_, a); } } while (0)
+#define DSIM_ADAPT_CASE(M_) do { if (args->options & DSIM_OPT_PLANE) DSIM_ADAPT_CASE2(M_, true); else DSIM_ADAPT_CASE2(M_, false); } while (0)
   if (mode == DSIM_ADAPT_VELOCITY) DSIM_ADAPT_CASE(DSIM_ADAPT_VELOCITY); else DSIM_ADAPT_CASE(DSIM_ADAPT_RPYT);
 #undef DSIM_ADAPT_CASE
+#undef DSIM_ADAPT_CASE2
   return (int)hipGetLastError();
 }
 

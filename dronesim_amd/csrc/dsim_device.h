@@ -34,6 +34,7 @@ struct DevType {
   float reset_thrust, reset_cmd;
   float speed_limit;                          // MAX_SPEED_KMH * 1000/3600 (VelocityAviary.py:92-94)
   float coll_r, coll_below;                   // bounding cylinder of the collision shapes (ground-plane watch)
+  float mu_plane;                             // DSIM_OPT_PLANE: Coulomb coefficient against the plane
 };
 
 struct V3 { float x, y, z; };
@@ -272,8 +273,77 @@ __device__ __forceinline__ V3 drag_quad(const DevType& T, const Rigid& s, const 
   return mul(R, v3(-T.drag[0] * w * s.vel.x, -T.drag[1] * w * s.vel.y, -T.drag[2] * w * s.vel.z));
 }
 
+// DSIM_OPT_PLANE: contact with the ground plane z = 0 — the product-defined model documented at
+// oracle/dsim_oracle.c:orc_plane_contact (four rim points of the collision cylinder's lower face, the first at the
+// rim's lowest point; penetrating points driven to erp depth / dt, separated ones limited to gap / dt inside the 0.02 m
+// margin; Coulomb pyramid on the world tangents; DSIM_PLANE_ITERS projected Gauss-Seidel sweeps on (v, w)).  Kept out
+// of the flight kernels: only the k_step_plane / k_physics_plane instances compile it (launched when the option bit is
+// set), and only waves that hold a drone within the margin run the sweeps.
+#define DSIM_PLANE_ITERS 24
+__device__ __forceinline__ V3 inv_inertia_world(const DevType& T, const M3& R, V3 x) {
+  const V3 b = mulT(R, x);
+  return mul(R, v3(b.x * T.invJ[0], b.y * T.invJ[1], b.z * T.invJ[2]));
+}
+__device__ __forceinline__ void plane_contact(const DevType& T, float dt, const V3 pos, const Q4 q, V3& v, V3& w) {
+  if (!(T.coll_r > 0.0f)) return;
+  const M3 R = matrix_from_quat(q);
+  const V3 a = v3(R.m[2], R.m[5], R.m[8]);                          // body z axis in the world
+  const float sgn = a.z >= 0.0f ? 1.0f : -1.0f;                     // which face is the lower one
+  const V3 c = (-sgn * T.coll_below) * a;                           // its centre, relative to the COM
+  V3 d = v3(a.z * a.x, a.z * a.y, a.z * a.z - 1.0f);                // steepest descent inside the face plane
+  float dn = DSIM_SQRT(dot(d, d));
+  if (dn < 1e-6f) { d = v3(R.m[0], R.m[3], R.m[6]); dn = 1.0f; }    // level: body x
+  d = DSIM_RCP(dn) * d;
+  const V3 e = cross(a, d);
+  V3 r[4];
+  float gap[4], lam[4][3], K[4][3];
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float cj = (j == 0) ? 1.0f : (j == 2 ? -1.0f : 0.0f), sj = (j == 1) ? 1.0f : (j == 3 ? -1.0f : 0.0f);
+    r[j] = c + T.coll_r * (cj * d + sj * e);
+    gap[j] = pos.z + r[j].z;
+    any = any || gap[j] < 0.02f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const V3 ax = v3(k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f);
+      const V3 u = cross(inv_inertia_world(T, R, cross(r[j], ax)), r[j]);
+      K[j][k] = T.inv_mass + (k == 0 ? u.x : (k == 1 ? u.y : u.z));
+      lam[j][k] = 0.0f;
+    }
+  }
+  if (!any) return;
+  const float inv_dt = DSIM_RCP(dt);
+  for (int it = 0; it < DSIM_PLANE_ITERS; ++it) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!(gap[j] < 0.02f)) continue;
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass) {
+        const int k = pass == 0 ? 2 : pass - 1;                     // normal (z) first, then the tangents x, y
+        const V3 wr = cross(w, r[j]);
+        const float u = (k == 0 ? v.x + wr.x : (k == 1 ? v.y + wr.y : v.z + wr.z));
+        float dl;
+        if (k == 2) {
+          const float target = gap[j] < 0.0f ? 0.2f * (-gap[j]) * inv_dt : -gap[j] * inv_dt;
+          const float nl = fmaxf(0.0f, lam[j][2] + (target - u) / K[j][2]);
+          dl = nl - lam[j][2]; lam[j][2] = nl;
+        } else {
+          const float lim = T.mu_plane * lam[j][2];
+          const float nl = clampf(lam[j][k] - u / K[j][k], -lim, lim);
+          dl = nl - lam[j][k]; lam[j][k] = nl;
+        }
+        const V3 imp = v3(k == 0 ? dl : 0.0f, k == 1 ? dl : 0.0f, k == 2 ? dl : 0.0f);
+        v = v + T.inv_mass * imp;
+        w = w + inv_inertia_world(T, R, cross(r[j], imp));
+      }
+    }
+  }
+}
+
 // P4: one Bullet btMultiBody floating-base step [BULLET-INTERNAL, parity unpinned];
-// restated step by step in oracle/dsim_oracle.c:orc_bullet_step.
+// restated step by step in oracle/dsim_oracle.c:orc_bullet_step.  PLANE: with the contact solve (DSIM_OPT_PLANE).
+template <bool PLANE = false>
 __device__ __forceinline__ void bullet_step(const DevType& T, float dt, Rigid& s, V3 F_body, V3 tau_body) {
   const M3 R = matrix_from_quat(s.q);
   const V3 wb = mulT(R, s.w);
@@ -296,6 +366,7 @@ __device__ __forceinline__ void bullet_step(const DevType& T, float dt, Rigid& s
            clampf(s.w.z + wdot.z * dt, -T.maxv, T.maxv));
   s.vel = v3(clampf(s.vel.x + vdot.x * dt, -T.maxv, T.maxv), clampf(s.vel.y + vdot.y * dt, -T.maxv, T.maxv),
              clampf(s.vel.z + vdot.z * dt, -T.maxv, T.maxv));
+  if (PLANE) plane_contact(T, dt, s.pos, s.q, s.vel, s.w);      // velocity-level contact solve, then the positions
   // stepPositionsMultiDof: semi-implicit position, exponential-map orientation
   s.pos = s.pos + dt * s.vel;
   float fAngle = DSIM_SQRT(dot(s.w, s.w));

@@ -84,6 +84,7 @@ class CtrlAviary:
         type_ids=None,
         neighbors_k: int = 0,
         options: int = 0,
+        ground_plane: Optional[bool] = None,
     ):
         if gui or record or obstacles:
             raise NotImplementedError("gui/record/obstacles are rendering features outside the hot path")
@@ -94,6 +95,15 @@ class CtrlAviary:
         self._phys_options = {Physics.PYB: 0, Physics.PYB_DW: 0, Physics.PYB_GND: nat.OPT_GROUND,
                               Physics.PYB_DRAG: nat.OPT_DRAG,
                               Physics.PYB_GND_DRAG_DW: nat.OPT_GROUND | nat.OPT_DRAG}[physics]
+        # The reference always loads plane.urdf (BaseAviary.py:660).  ground_plane=True enforces z = 0 by the contact
+        # model of oracle/dsim_oracle.c:orc_plane_contact (DSIM_OPT_PLANE, the general kernels); None = on for the
+        # reference-sized fleets that get dict observations, off for the large in-flight fleets of the fast kernels,
+        # where ground_contacts() reports how many drone-steps would have touched it.
+        if ground_plane is None:
+            ground_plane = num_drones <= DICT_IO_MAX_DRONES and (dict_io is None or dict_io)
+        self.ground_plane = bool(ground_plane)
+        if self.ground_plane:
+            self._phys_options |= nat.OPT_PLANE
         # tuning bits handed to every call (nat.OPT_STREAM_ON/_OFF, nat.OPT_GENERIC_MIXED); results do not depend on them
         self._tuning = int(options) & nat.TUNING_MASK
         self.neighbors_k = int(neighbors_k)

@@ -73,6 +73,7 @@ class TypeParamsC(ctypes.Structure):
         ("max_speed_kmh", ctypes.c_double),
         ("collision_radius", ctypes.c_double),
         ("collision_below", ctypes.c_double),
+        ("contact_friction", ctypes.c_double),
     ]
 
 
@@ -113,6 +114,7 @@ class DroneType:
     max_speed_kmh: float = 30.0      # URDF properties max_speed_kmh (all shipped types: 30)
     collision_radius: float = 0.0    # bounding cylinder of the <collision> shapes about body z: radius ...
     collision_below: float = 0.0     # ... and extent below the COM (ground-plane watch; 0 = none)
+    contact_friction: float = 0.5    # DSIM_OPT_PLANE: plane.urdf lateral_friction 1.0 x PyBullet's default 0.5 for the vehicle
     reset_thrust: float = 0.0        # INDIControl.reset (INDIControl.py:127); 6DOF 0.3 (:232)
     reset_cmd: float = 0.0           # INDIControl.py:129; 6DOF 0.5 (:234)
     alloc: np.ndarray = field(default=None)  # type: ignore[assignment]
@@ -197,6 +199,7 @@ class DroneType:
         c.gnd_eff_h_clip = self.gnd_eff_h_clip
         c.max_speed_kmh = self.max_speed_kmh
         c.collision_radius, c.collision_below = self.collision_radius, self.collision_below
+        c.contact_friction = self.contact_friction
         return c
 
     @property

@@ -117,6 +117,8 @@ typedef struct dsim_type_params {
    * drone-step that ends with this cylinder reaching z <= 0 is counted instead (DSIM_Q_GROUND_CONTACTS), so that a
    * caller knows when a flight has left the domain in which results are comparable.  0 = no watch for this type.  */
   double  collision_radius, collision_below;
+  double  contact_friction;           /* DSIM_OPT_PLANE: Coulomb coefficient against the plane (PyBullet combines by product:
+                                         plane.urdf's lateral_friction 1.0 x the vehicle's default 0.5)                 */
 } dsim_type_params;
 
 /* ---- step options ---------------------------------------------------------- */
@@ -140,8 +142,14 @@ enum {
                                        VGPR staging, three barriers) (A/B knob)                                    */
   DSIM_OPT_MIXED_RING  = 1u << 8,   /* mixed fleets, wave-tiled layout: persistent workgroups with a two-deep LDS-DMA
                                        ring (A/B knob; measured slower than the default form)                      */
-  DSIM_OPT_MIXED_V3    = 1u << 9    /* mixed fleets, wave-tiled layout: the three-wave form of the LDS-DMA-staged kernel
+  DSIM_OPT_MIXED_V3    = 1u << 9,   /* mixed fleets, wave-tiled layout: the three-wave form of the LDS-DMA-staged kernel
                                        (what other layouts get) instead of the two-wave one (A/B knob)             */
+  /* -- physics (changes results) ------------------------------------------------------------------------------------ */
+  DSIM_OPT_PLANE       = 1u << 10   /* ground plane z = 0 with contact and friction, as the reference's world has
+                                       (BaseAviary.py:680 loads plane.urdf, collisions on).  A PRODUCT-DEFINED contact
+                                       model (four rim points of the vehicle's collision cylinder, sequential impulses,
+                                       ERP 0.2, restitution 0, Coulomb friction): Bullet's own contact pipeline cannot be
+                                       restated or pinned here.  General kernels only.          */
 };
 
 /* A run of consecutive drones of one type (type-major storage of a heterogeneous fleet). */

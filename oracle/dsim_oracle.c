@@ -580,10 +580,103 @@ void orc_ground_effect(const dsim_type_params* P, const double pos[3], const dou
  *        q <- dq(w_new, dt) * q with the exponential map of btTransformUtil:
  *        angle clamp ANGULAR_MOTION_THRESHOLD = pi/4, Taylor branch for |w|<0.001; normalise
  *  External forces are cleared after the step (BaseAviary re-applies them each sub-step).
- *  Ground contact is not modelled (flight only).                              */
+ *  Ground contact: orc_plane_contact below (optional, DSIM_OPT_PLANE), between (3) and (4).  */
 /* ======================================================================= */
+
+/* Plane contact (DSIM_OPT_PLANE) — a PRODUCT-DEFINED model, "parity unpinned" like P4 and more so: the reference loads
+ * pybullet_data's plane.urdf with collisions on (BaseAviary.py:680, 710-712) and leaves contact to Bullet's
+ * btMultiBodyConstraintSolver (GJK/EPA manifold of the base link's collision cylinder, robobee.urdf:72-77, against the
+ * plane's box; sequential impulses, 50 iterations, contact ERP 0.2, restitution 0, friction = product of the two
+ * lateral-friction coefficients, 1.0 x 0.5).  Neither the engine nor any recording of it is available, so this is NOT a
+ * restatement of Bullet's manifold generation; it keeps the documented ingredients of that solver on a fixed manifold:
+ *   - the vehicle's collision shape is its bounding cylinder (radius collision_radius, half-height collision_below,
+ *     centred on the COM, axis = body z); the manifold is four points on the rim of its lower face, the first at
+ *     the rim's lowest point (steepest descent of the face), the others at 90 degree steps — an edge landing touches
+ *     with the first, a flat one with all four;
+ *   - a point closer than the contact breaking threshold (0.02 m) is a constraint: penetrating, its normal velocity
+ *     is driven to erp depth / dt (erp = 0.2, restitution 0); separated, it may close no faster than gap / dt;
+ *   - Coulomb friction mu = contact_friction on the two world tangents, each clamped to +-mu lambda_n (pyramid);
+ *   - projected Gauss-Seidel, ORC_PLANE_ITERS sweeps, impulses applied to (v, w) through 1/m and the world inertia;
+ * solved between the velocity update and the position update of the step, as a velocity-level solver does.
+ * The plane is infinite (pybullet's is a 30 m x 30 m box).  Pinned only by analytic tests (rest, drop, slide, tip). */
+#define ORC_PLANE_ITERS 24
+#define ORC_PLANE_ERP 0.2
+#define ORC_PLANE_MARGIN 0.02
+static void inv_inertia_world(const dsim_type_params* P, const double R[9], const double x[3], double y[3]) {
+  double b[3];
+  for (int k = 0; k < 3; ++k) b[k] = (R[0 * 3 + k] * x[0] + R[1 * 3 + k] * x[1] + R[2 * 3 + k] * x[2]) / P->inertia[k];
+  for (int k = 0; k < 3; ++k) y[k] = R[k * 3] * b[0] + R[k * 3 + 1] * b[1] + R[k * 3 + 2] * b[2];
+}
+void orc_plane_contact(const dsim_type_params* P, double dt, const double pos[3], const double q[4], double v[3], double w[3]) {
+  if (!(P->collision_radius > 0)) return;
+  double R[9];
+  orc_matrix_from_quat(q, R);
+  const double a[3] = {R[2], R[5], R[8]};                 /* body z axis in the world */
+  const double sgn = a[2] >= 0 ? 1.0 : -1.0;              /* which face is the lower one */
+  double c[3], d[3], e[3];
+  for (int k = 0; k < 3; ++k) c[k] = -sgn * P->collision_below * a[k];      /* lower face centre, relative to the COM */
+  /* steepest descent inside the face plane: -e_z + (e_z . a) a */
+  d[0] = a[2] * a[0]; d[1] = a[2] * a[1]; d[2] = a[2] * a[2] - 1.0;
+  double dn = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (dn < 1e-6) { d[0] = R[0]; d[1] = R[3]; d[2] = R[6]; dn = 1.0; }       /* level: body x */
+  for (int k = 0; k < 3; ++k) d[k] /= dn;
+  cross3(a, d, e);
+  double r[4][3], gap[4], lam[4][3], K[4][3];
+  int active[4], any = 0;
+  for (int j = 0; j < 4; ++j) {
+    const double cj = (j == 0) - (j == 2), sj = (j == 1) - (j == 3);
+    for (int k = 0; k < 3; ++k) r[j][k] = c[k] + P->collision_radius * (cj * d[k] + sj * e[k]);
+    gap[j] = pos[2] + r[j][2];
+    active[j] = gap[j] < ORC_PLANE_MARGIN;
+    any |= active[j];
+    for (int k = 0; k < 3; ++k) {
+      lam[j][k] = 0.0;
+      double ax[3] = {k == 0, k == 1, k == 2}, rxn[3], t[3], u[3];
+      cross3(r[j], ax, rxn);
+      inv_inertia_world(P, R, rxn, t);
+      cross3(t, r[j], u);
+      K[j][k] = 1.0 / P->mass + u[k];
+    }
+  }
+  if (!any) return;
+  const double mu = P->contact_friction;
+  for (int it = 0; it < ORC_PLANE_ITERS; ++it)
+    for (int j = 0; j < 4; ++j) {
+      if (!active[j]) continue;
+      for (int pass = 0; pass < 3; ++pass) {
+        const int k = pass == 0 ? 2 : pass - 1;            /* normal (z) first, then the tangents x, y */
+        double wr[3];
+        cross3(w, r[j], wr);
+        const double u = v[k] + wr[k];
+        double dl;
+        if (k == 2) {
+          const double target = gap[j] < 0 ? ORC_PLANE_ERP * (-gap[j]) / dt : -gap[j] / dt;
+          const double nl = fmax(0.0, lam[j][2] + (target - u) / K[j][2]);
+          dl = nl - lam[j][2]; lam[j][2] = nl;
+        } else {
+          const double lim = mu * lam[j][2];
+          double nl = lam[j][k] - u / K[j][k];
+          nl = nl < -lim ? -lim : (nl > lim ? lim : nl);
+          dl = nl - lam[j][k]; lam[j][k] = nl;
+        }
+        double imp[3] = {0, 0, 0}, rxi[3], dw[3];
+        imp[k] = dl;
+        v[k] += dl / P->mass;
+        cross3(r[j], imp, rxi);
+        inv_inertia_world(P, R, rxi, dw);
+        for (int m = 0; m < 3; ++m) w[m] += dw[m];
+      }
+    }
+}
+
+void orc_bullet_step_ex(const dsim_type_params* P, double dt, double pos[3], double q[4], double v[3],
+                        double w[3], const double F_body[3], const double tau_body[3], int plane);
 void orc_bullet_step(const dsim_type_params* P, double dt, double pos[3], double q[4], double v[3],
                      double w[3], const double F_body[3], const double tau_body[3]) {
+  orc_bullet_step_ex(P, dt, pos, q, v, w, F_body, tau_body, 0);
+}
+void orc_bullet_step_ex(const dsim_type_params* P, double dt, double pos[3], double q[4], double v[3],
+                        double w[3], const double F_body[3], const double tau_body[3], int plane) {
   double R[9], wb[3], vb[3], Jw[3], gyro[3], alpha_b[3], a_b[3];
   orc_matrix_from_quat(q, R); /* body -> world */
   for (int k = 0; k < 3; ++k) {
@@ -612,6 +705,7 @@ void orc_bullet_step(const dsim_type_params* P, double dt, double pos[3], double
     w[k] = w[k] < -mx ? -mx : (w[k] > mx ? mx : w[k]);
     v[k] = v[k] < -mx ? -mx : (v[k] > mx ? mx : v[k]);
   }
+  if (plane) orc_plane_contact(P, dt, pos, q, v, w);       /* velocity-level contact solve, then the positions */
   for (int k = 0; k < 3; ++k) pos[k] += dt * v[k];
   double fAngle = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
   if (fAngle * dt > 0.5 * (ORC_PI * 0.5)) fAngle = 0.5 * (ORC_PI * 0.5) / dt;
@@ -658,7 +752,7 @@ void orc_physics_substep(const dsim_type_params* P, double dt, double rigid[13],
     for (int k = 0; k < 3; ++k) F[k] += D[k];
   }
   if (ext_force_body) for (int k = 0; k < 3; ++k) F[k] += ext_force_body[k];
-  orc_bullet_step(P, dt, pos, q, v, w, F, tau);
+  orc_bullet_step_ex(P, dt, pos, q, v, w, F, tau, (options & DSIM_OPT_PLANE) != 0);
 }
 
 /* ======================================================================= */

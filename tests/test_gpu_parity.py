@@ -2094,3 +2094,202 @@ def test_ground_plane_watch_counts_what_pybullet_would_have_caught(gpu):
         env.step_fused(tg)
     assert env.ground_contacts() == 0 and float(env.state.fields(2, 1).min()) > 0.5      # (start-up dip of ~0.1 m)
     env.close()
+
+
+# ---------------------------------------------------------------------------
+# DSIM_OPT_PLANE: the ground plane of the reference's world (BaseAviary.py:660) — the product-defined contact model of
+# oracle/dsim_oracle.c:orc_plane_contact on the device (dsim_device.h:plane_contact), against the oracle
+# ---------------------------------------------------------------------------
+PLANE_SWEEPS = 24       # DSIM_PLANE_ITERS: every sweep updates (v, w) twelve times; one ulp of the contact terms per sweep
+
+
+def _near_ground_fleet(t, n, seed, n_act=4):
+    """Seeded fleet around the plane: a third resting on it, a third arriving (tilted, descending, spinning), a third
+    flying clear of the 0.02 m margin."""
+    rng = np.random.default_rng(seed)
+    rigid, mem, tgt = random_fleet(rng, n, n_act=n_act, tilt=0.6, speed=1.5, rate=2.0, spread=20.0)
+    h = t.collision_below
+    kind = np.arange(n) % 3
+    rest = kind == 0
+    rigid[rest, 2] = h + rng.uniform(-2e-3, 2e-3, rest.sum())                 # within the penetration / margin band
+    rigid[rest, 3:7] = np.stack([orc.quat_from_euler([0.0, 0.0, y]) for y in rng.uniform(-3, 3, rest.sum())])
+    rigid[rest, 7:10] = rng.uniform(-0.3, 0.3, (rest.sum(), 3)) * np.array([1.0, 1.0, 0.2])    # sliding
+    rigid[rest, 10:13] = rng.uniform(-0.2, 0.2, (rest.sum(), 3))
+    arrive = kind == 1
+    rigid[arrive, 2] = h + rng.uniform(-0.01, 0.12, arrive.sum())             # tilted rims reach the plane at different heights
+    rigid[arrive, 9] = -np.abs(rigid[arrive, 9])
+    rigid[kind == 2, 2] = rng.uniform(0.5, 3.0, (kind == 2).sum())
+    return f32(rigid), mem, tgt, kind
+
+
+@pytest.mark.parametrize("model,sub", [("robobee", 1), ("robobee", 5), ("tello", 2), ("hexa_6DOF", 1), ("hexa_6DOF", 4)])
+def test_plane_contact_vs_oracle(gpu, model, sub):
+    """Env.step (explicit action) and the fused step with DSIM_OPT_PLANE from the same near-ground state, per drone
+    and field on the increments.  Tolerance: the step's own bar (tests/util.py) with the contact terms added to the
+    magnitudes (plane_terms) and PLANE_SWEEPS more roundings per sub-step — stated here, checked per case."""
+    from tests.util import plane_terms
+    nat, fleet = gpu
+    t = params.builtin_type(model)
+    na = t.n_act
+    n = 1800
+    ctx = fleet.Context([t])
+    st = fleet.FleetState(ctx, n, "soa", 256)
+    tg = fleet.Targets(ctx, n, "soa", pad=256)
+    rigid, mem, tgt, kind = _near_ground_fleet(t, n, 131 + sub, na)
+    st.load_aos(rigid, mem)
+    tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
+    O = orc.Oracle([t])
+    dtc = float(np.float32(sub / 240.0))
+    k_contact = K_ULP * sub * (1 + PLANE_SWEEPS)
+    # (a) Env.step with an explicit action: idle, hover and full thrust
+    rng = np.random.default_rng(5)
+    act = f32(t.hover_pwm * rng.choice([0.0, 1.0, 1.6], (n, 1)) * np.ones((1, na)))
+    act_dev = torch.zeros((na, st.n_pad), device=ctx.device); act_dev[:, :n] = torch.from_numpy(act.T).float()
+    echo = torch.zeros((na, st.n_pad), device=ctx.device)
+    a = _args(nat, sub, DT, dtc, options=nat.OPT_PLANE, action=act_dev)
+    nat.check(ctx.lib.dsim_physics(ctx.handle, _stream(ctx), n, st.view(), echo.data_ptr(), ctypes.byref(a)))
+    a6 = np.zeros((n, 6)); a6[:, :na] = act
+    ref = rigid.copy()
+    O.physics(ref, mem, sub, DT, action=a6, options=nat.OPT_PLANE)
+    free = rigid.copy()
+    O.physics(free, mem, sub, DT, action=a6)
+    touched = np.abs(free - ref).max(1) > 1e-6
+    assert touched[kind == 0].mean() > 0.3 and not touched[kind == 2].any() and 0.15 < touched[kind == 1].mean() < 0.95
+    got = st.rigid_aos()
+    assert_step_parity(f"plane_physics[{model},{sub}]", [t], None, rigid, mem, tgt, got, None, ref, None, DT, dtc, sub,
+                       control=False, k=k_contact, action=act, extra_terms=plane_terms([t], None, rigid, dtc))
+    # drones clear of the margin take the same arithmetic as without the option: the plain bar holds for them
+    fly = kind == 2
+    assert_step_parity(f"plane_physics[{model},{sub}] clear of the plane", [t], None, rigid[fly], mem[fly], tgt[fly], got[fly],
+                       None, ref[fly], None, DT, dtc, sub, control=False, action=act[fly])
+    # nothing ends the step deeper in the plane than it started, beyond the solver's residual
+    def lowest(r):
+        r22 = 1.0 - 2.0 * (r[:, 3] ** 2 + r[:, 4] ** 2)
+        return r[:, 2] - (t.collision_below * np.abs(r22) + t.collision_radius * np.sqrt(np.maximum(1.0 - r22 * r22, 0.0)))
+    assert (lowest(got) >= np.minimum(lowest(rigid), 0.0) - 2e-3).all()
+    # (b) the fused step (physics + INDI law) from the device's state
+    r0, m0 = st.rigid_aos(), st.mem_aos()
+    a2 = _args(nat, sub, DT, dtc, options=nat.OPT_PLANE)
+    nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a2)))
+    r1, m1 = r0.copy(), m0.copy()
+    assert O.step(r1, m1, tgt, sub, DT, dtc, options=nat.OPT_PLANE) == 0
+    assert_step_parity(f"plane_fused[{model},{sub}]", [t], None, r0, m0, tgt, st.rigid_aos(), st.mem_aos(), r1, m1, DT, dtc,
+                       sub, k=k_contact, extra_terms=plane_terms([t], None, r0, dtc))
+    ctx.close()
+
+
+def test_plane_touchdown_flight_config1(gpu):
+    """BASELINE configs[0]'s flight with the plane the reference's world has: a robobee starting 0.1 m up under the
+    INDI law sinks onto the plane while the thrust state winds up, rests ON it (instead of passing through z = 0 to
+    -0.14 m), lifts off and reaches its target.  CtrlAviary switches the plane on by itself for
+    such a fleet; every step is also judged against the oracle from the device's own previous state."""
+    from dronesim_amd.control import INDIControl
+    from dronesim_amd.envs import CtrlAviary
+    from tests.util import plane_terms
+    nat, fleet = gpu
+    t = params.builtin_type("robobee")
+    env = CtrlAviary(["robobee"], 1, initial_xyzs=np.array([[0.0, 0.0, 0.1]]), aggregate_phy_steps=5, noise_seed=0)
+    assert env.ground_plane
+    ctrl = INDIControl("robobee")
+    O = orc.Oracle([t])
+    dtc = float(np.float32(5 / 240.0))
+    target = np.array([0.0, 0.0, 1.0])
+    obs, _, _, _ = env.step({"0": np.zeros(4)})
+    zs = []
+    for k in range(48 * 6):
+        cmd, _, _ = ctrl.computeControlFromState(control_timestep=dtc, state=obs["0"]["state"], target_pos=target,
+                                                 target_rpy=np.zeros(3))
+        r0 = env.state.rigid_aos()
+        obs, _, _, _ = env.step({"0": cmd})
+        ref = r0.copy()
+        a6 = np.zeros((1, 6)); a6[0, :4] = f32(cmd)
+        O.physics(ref, np.zeros((1, 13)), 5, DT, action=a6, options=nat.OPT_PLANE)
+        assert_step_parity("plane_touchdown_flight", [t], None, r0, np.zeros((1, 13)), np.zeros((1, 10)), env.state.rigid_aos(),
+                           None, ref, None, DT, dtc, 5, control=False, k=K_ULP * 5 * (1 + PLANE_SWEEPS), action=f32(cmd)[None, :],
+                           extra_terms=plane_terms([t], None, r0, dtc))
+        zs.append(float(obs["0"]["state"][2]))
+    zs = np.array(zs)
+    assert t.collision_below - 2e-3 < zs.min() < t.collision_below + 0.01         # rests on the plane, not below it
+    on_ground = (zs < t.collision_below + 5e-3).sum() * dtc
+    assert 0.03 < on_ground < 1.5
+    assert abs(zs[-1] - 1.0) < 0.05 and env.ground_contacts() > 0
+    env.close()
+    # the same flight without the plane goes through the floor (what the watch counter reports)
+    env = CtrlAviary(["robobee"], 1, initial_xyzs=np.array([[0.0, 0.0, 0.1]]), aggregate_phy_steps=5, noise_seed=0, ground_plane=False)
+    ctrl = INDIControl("robobee")
+    obs, _, _, _ = env.step({"0": np.zeros(4)})
+    zmin = 1.0
+    for k in range(48 * 2):
+        cmd, _, _ = ctrl.computeControlFromState(control_timestep=dtc, state=obs["0"]["state"], target_pos=target, target_rpy=np.zeros(3))
+        obs, _, _, _ = env.step({"0": cmd})
+        zmin = min(zmin, float(obs["0"]["state"][2]))
+    assert zmin < -0.05
+    env.close()
+
+
+@pytest.mark.parametrize("mode", ["velocity", "rpyt"])
+def test_plane_action_adaptor_envs(gpu, mode):
+    """VelocityAviary / RPYTAviary over the plane: the law on the current state, then the physics with the contact
+    solve — a fleet parked on the ground and commanded down / idle stays on it, and the step matches the oracle."""
+    from dronesim_amd.envs import RPYTAviary, VelocityAviary
+    from tests.util import plane_terms
+    nat, fleet = gpu
+    t = params.builtin_type("tello")
+    n = 48
+    rng = np.random.default_rng(17)
+    xyz = np.stack([np.arange(n) * 1.0, np.zeros(n), np.where(np.arange(n) % 2 == 0, t.collision_below, 0.5)], 1)
+    cls = VelocityAviary if mode == "velocity" else RPYTAviary
+    env = cls(["tello"], n, initial_xyzs=xyz, aggregate_phy_steps=2, noise_seed=0, ground_plane=True)
+    O = orc.Oracle([t])
+    dtc = float(np.float32(2 / 240.0))
+    for k in range(25):
+        if mode == "velocity":
+            act = np.concatenate([rng.uniform(-1, 1, (n, 2)), -np.ones((n, 1)), np.full((n, 1), 0.2)], 1)   # descend
+        else:
+            act = np.concatenate([np.zeros((n, 3)), np.full((n, 1), 0.2)], 1)                                # low thrust, level
+        act = f32(act)
+        r0, m0 = env.state.rigid_aos(), env.state.mem_aos()
+        env.step({str(i): act[i] for i in range(n)})
+        got_r, got_m = env.state.rigid_aos(), env.state.mem_aos()
+        ref = r0.copy()
+        a6 = np.zeros((n, 6)); a6[:, :4] = got_m[:, 7:11]
+        O.physics(ref, got_m.copy(), 2, DT, action=a6, options=nat.OPT_PLANE)
+        assert_step_parity(f"plane_adaptor_env[{mode}]", [t], None, r0, got_m, np.zeros((n, 10)), got_r, None, ref, None, DT, dtc, 2,
+                           control=False, k=K_ULP * 2 * (1 + PLANE_SWEEPS), action=got_m[:, 7:11],
+                           extra_terms=plane_terms([t], None, r0, dtc))
+    z = env.state.rigid_aos()[:, 2]
+    assert (z[::2] > t.collision_below - 2e-3).all() and (z[::2] < t.collision_below + 5e-3).all()    # parked: still on the plane
+    assert (z > t.collision_below - 2e-3).all()                                                       # nobody below it
+    env.close()
+
+
+def test_plane_option_routing_and_refusals(gpu):
+    """The plane works for every airframe kind and storage (general kernels); the add-on formulas that are written for
+    four-rotor links still refuse the hexa, with or without it."""
+    nat, fleet = gpu
+    t4, t6 = params.builtin_type("robobee"), params.builtin_type("hexa_6DOF")
+    ctx = fleet.Context([t4, t6])
+    n = 700
+    tid = (np.arange(n) % 2).astype(np.uint8)
+    for layout in ("soa", "tile64"):
+        st = fleet.FleetState(ctx, n, layout, 256)
+        tg = fleet.Targets(ctx, n, layout, pad=256)
+        rigid, mem, tgt = random_fleet(np.random.default_rng(3), n, n_act=6, tilt=0.4)
+        rigid[:, 2] = f32(np.where(tid == 0, t4.collision_below, t6.collision_below) + np.random.default_rng(4).uniform(-1e-3, 0.05, n))
+        rigid[:, 9] = -np.abs(rigid[:, 9])
+        mem[tid == 0, 11:13] = 0.0
+        st.load_aos(rigid, mem)
+        tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
+        type_dev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device); type_dev[:n] = torch.from_numpy(tid)
+        a = _args(nat, 2, DT, float(np.float32(2 / 240)), options=nat.OPT_PLANE, type_id=type_dev, seed=0)
+        nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
+        O = orc.Oracle([t4, t6])
+        r1, m1 = rigid.copy(), mem.copy()
+        assert O.step(r1, m1, tgt, 2, DT, float(np.float32(2 / 240)), options=nat.OPT_PLANE, type_id=tid) == 0
+        from tests.util import plane_terms
+        assert_step_parity(f"plane_mixed_fleet[{layout}]", [t4, t6], tid, rigid, mem, tgt, st.rigid_aos(), st.mem_aos(), r1, m1,
+                           DT, float(np.float32(2 / 240)), 2, k=K_ULP * 2 * (1 + PLANE_SWEEPS),
+                           extra_terms=plane_terms([t4, t6], tid, rigid, float(np.float32(2 / 240))))
+        a.options = nat.OPT_PLANE | nat.OPT_DRAG
+        assert ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)) == -5     # DSIM_E_UNSUPPORTED
+    ctx.close()

@@ -326,3 +326,101 @@ def test_threefry_known_answers_and_noise_moments():
     # a hexa draws a second block (stream 1) for normals 8..11
     h = O.noise_normals(77, 3, 9, 6)
     assert h.shape == (12,) and len(set(np.round(h, 12))) == 12
+
+
+# ---------------------------------------------------------------------------
+# DSIM_OPT_PLANE: the ground plane of the reference's world (BaseAviary.py:680) as a product-defined contact model
+# (oracle/dsim_oracle.c: orc_plane_contact) — analytic behaviour checks; there is nothing of Bullet to pin it against
+# ---------------------------------------------------------------------------
+PLANE = 1 << 10
+
+
+def test_plane_rest_drop_and_liftoff():
+    t, O = _O()
+    h = t.collision_below
+    # resting on the plane with no thrust: stays put
+    r, m = _rest(z=h), O.reset_mem(1)
+    O.physics(r, m, 240, DT, options=PLANE)
+    assert abs(r[0, 2] - h) < 5e-4 and np.abs(r[0, 7:13]).max() < 2e-3 and abs(r[0, 6] - 1) < 1e-6   # (24 Gauss-Seidel sweeps: sub-mm, mrad/s residuals)
+    # dropped from half a metre: comes to rest on the plane, never sinks into it by more than a millimetre or so
+    r = _rest(z=0.5)
+    zmin = 1.0
+    for _ in range(360):
+        O.physics(r, m, 1, DT, options=PLANE)
+        zmin = min(zmin, r[0, 2])
+    assert zmin > h - 2e-3 and abs(r[0, 2] - h) < 1e-3 and np.abs(r[0, 7:10]).max() < 5e-3
+    # without the option it falls through
+    r2 = _rest(z=0.5)
+    O.physics(r2, m, 360, DT)
+    assert r2[0, 2] < -1.0
+    # thrust above weight lifts it off again (contact only pushes)
+    m[0, 7:11] = 0.6
+    O.physics(r, m, 120, DT, options=PLANE)
+    assert r[0, 2] > h + 0.3 and r[0, 9] > 0.5
+
+
+def test_plane_friction_stops_a_slide_over_the_coulomb_distance():
+    t, O = _O()
+    h, mu, g = t.collision_below, t.contact_friction, t.gravity
+    r, m = _rest(z=h), O.reset_mem(1)
+    v0 = 1.0
+    r[0, 7] = v0
+    x_stop = None
+    for k in range(480):
+        O.physics(r, m, 1, DT, options=PLANE)
+        if x_stop is None and abs(r[0, 7]) < 1e-3:
+            x_stop = r[0, 0]
+    assert x_stop is not None
+    d = v0 * v0 / (2 * mu * g)                                 # 0.102 m; Bullet's velocity damping shortens it a little
+    assert 0.85 * d < x_stop < 1.02 * d, (x_stop, d)
+    assert abs(r[0, 2] - h) < 1e-3 and np.abs(r[0, 3:6]).max() < 2e-2     # stays on the plane, does not tumble
+    # a frictionless plane lets it glide (only the 4 % / s air damping acts)
+    import dataclasses
+    t0 = dataclasses.replace(t, contact_friction=0.0)
+    O0 = orc.Oracle([t0])
+    r = _rest(z=h); r[0, 7] = v0
+    O0.physics(r, m, 240, DT, options=PLANE)
+    assert r[0, 7] > 0.9 * v0
+
+
+def test_plane_edge_landing_levels_the_vehicle():
+    """Dropped tilted by 0.5 rad: the low rim touches first, the contact torque rotates it flat, it ends level at rest."""
+    t, O = _O()
+    r, m = _rest(z=0.4), O.reset_mem(1)
+    r[0, 3:7] = orc.quat_from_euler([0.5, 0.0, 0.3])
+    first_touch_z = None
+    for k in range(600):
+        O.physics(r, m, 1, DT, options=PLANE)
+        if first_touch_z is None and abs(r[0, 10:13]).max() > 1e-3:
+            first_touch_z = r[0, 2]
+    roll, pitch, _ = orc.euler_from_quat(r[0, 3:7])
+    # first contact when the low rim reaches the plane: z = h cos(tilt) + r sin(tilt), well above the level rest height
+    assert first_touch_z is not None and first_touch_z > t.collision_below + 0.03
+    assert abs(roll) < 0.02 and abs(pitch) < 0.02 and abs(r[0, 2] - t.collision_below) < 2e-3
+    assert np.abs(r[0, 7:13]).max() < 2e-2
+
+
+def test_plane_config1_default_flight_touches_down_and_takes_off():
+    """examples/fly_INDI.py defaults (start at z = 0.5, initial action 0.4 < hover, controller thrust from 0): with
+    the plane on the drone sinks onto it, sits there while the INDI thrust state winds up, lifts off and reaches the
+    target — instead of passing through z = 0 to -0.14 m as the plane-less model does."""
+    t, O = _O()
+    dtc = 5 * DT
+    zs = {}
+    for opt in (0, PLANE):
+        r = _rest(z=0.5); r[0, 1] = 1.0
+        m = O.reset_mem(1)
+        z = []
+        for k in range(720):
+            tgt = np.array([[0, 0, 0.5, 0, 0, 0, 0, 0, 0, 0.4 + k / 200.0]])
+            a6 = None
+            if k == 0:
+                a6 = np.zeros((1, 6)); a6[0, :4] = 0.4
+            assert O.step(r, m, tgt, 5, DT, dtc, action=a6, options=opt) == 0
+            z.append(r[0, 2])
+        zs[opt] = np.array(z)
+        assert np.abs(r[0, 0:3] - [0, 0, 0.5]).max() < 0.03                 # both end hovering on the target
+    assert zs[0].min() < -0.1                                               # no plane: through the floor
+    assert t.collision_below - 2e-3 < zs[PLANE].min() < t.collision_below + 0.01    # plane: rests on it
+    on_ground = (zs[PLANE] < t.collision_below + 5e-3).sum() * dtc
+    assert 0.03 < on_ground < 1.5                                           # for a few control periods, then lifts off

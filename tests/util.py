@@ -140,13 +140,42 @@ def increment_ratio(got, ref, prev, terms, k):
 WORST = {}     # test label -> worst ratio seen (printed by conftest at the end of the session)
 
 
+def plane_terms(types, type_id, rigid, dt_ctrl):
+    """DSIM_OPT_PLANE: what the contact solve adds to the magnitudes of step_terms, per drone ([n,13], [n,13]).  A contact
+    point moves at u = v + w x r, |u| <= |v| + |w| R (R: COM to the rim of the collision cylinder); an impulse that
+    changes u by du changes v by at most du and w by at most du / (2 rho) (rho = sqrt(J_min / m): the maximum of
+    (l / J) / (1 / m + l^2 / J) over the lever arm l).  The controller differentiates the new velocity and rates."""
+    n = rigid.shape[0]
+    tr = np.zeros((n, 13))
+    tm = np.zeros((n, 13))
+    tid = np.zeros(n, dtype=np.int64) if type_id is None else np.asarray(type_id).astype(np.int64)
+    for k, t in enumerate(types):
+        s = np.flatnonzero(tid == k)
+        R = math.hypot(t.collision_radius, t.collision_below)
+        u = np.linalg.norm(rigid[s, 7:10], axis=1) + np.linalg.norm(rigid[s, 10:13], axis=1) * R
+        rho = math.sqrt(min(t.inertia) / t.mass)
+        tr[s, 7:10] = u[:, None]
+        tr[s, 10:13] = (u / (2 * rho))[:, None]
+        tm[s, 0:3] = tr[s, 7:10]
+        tm[s, 3:6] = tr[s, 10:13]
+        tm[s, 6] = u / dt_ctrl
+        A = np.abs(np.asarray(t.alloc, dtype=np.float64))
+        na = t.n_act
+        rate = np.max(t.rate_gain) * u / (2 * rho) + u / (2 * rho) / dt_ctrl
+        nu = np.stack([rate] * 3 + [u / dt_ctrl] * (na - 3), 1)
+        tm[s, 7:7 + na] = nu @ A[:na, :na].T
+    return tr, tm
+
+
 def assert_step_parity(label, types, type_id, prev_rigid, prev_mem, tgt, got_rigid, got_mem, ref_rigid, ref_mem,
-                       dt_phys, dt_ctrl, substeps, control=True, k=None, action=None):
+                       dt_phys, dt_ctrl, substeps, control=True, k=None, action=None, extra_terms=None):
     """One step of the HIP path against one step of the oracle from the same (fp32-representable) state,
     judged on the increments (module docstring).  got_mem / ref_mem may be None (physics only); action [n, n_act] =
     the explicit action of this step where it is not the stored cmd."""
     k = K_ULP * max(1, substeps) if k is None else k
     tr, tm = step_terms(types, type_id, prev_rigid, prev_mem, tgt, dt_phys, dt_ctrl, max(1, substeps), control, action)
+    if extra_terms is not None:
+        tr, tm = tr + extra_terms[0], tm + extra_terms[1]
     rr = increment_ratio(got_rigid, ref_rigid, prev_rigid, tr, k)
     worst = float(rr.max())
     where = ("rigid",) + tuple(int(x) for x in np.unravel_index(rr.argmax(), rr.shape))
