@@ -274,15 +274,18 @@ __device__ __forceinline__ V3 drag_quad(const DevType& T, const Rigid& s, const 
 }
 
 // DSIM_OPT_PLANE: contact with the ground plane z = 0 — the product-defined model documented at
-// oracle/dsim_oracle.c:orc_plane_contact (four rim points of the collision cylinder's lower face, the first at the
-// rim's lowest point; penetrating points driven to erp depth / dt, separated ones limited to gap / dt inside the 0.02 m
-// margin; Coulomb pyramid on the world tangents; DSIM_PLANE_ITERS projected Gauss-Seidel sweeps on (v, w)).  Kept out
-// of the flight kernels: only the k_step_plane / k_physics_plane instances compile it (launched when the option bit is
-// set), and only waves that hold a drone within the margin run the sweeps.
+// oracle/dsim_oracle.c:orc_plane_contact (DSIM_PLANE_POINTS body-fixed points on the rim of the collision cylinder's
+// lower face, 45 degrees apart from body x; penetrating points driven to erp depth / dt, separated ones limited to
+// gap / dt inside the 0.02 m margin; Coulomb pyramid on the world tangents; DSIM_PLANE_ITERS projected Gauss-Seidel
+// sweeps on (v, w)).  Kept out of the flight kernels: only the k_step_plane / k_physics_plane / k_adaptor<.., true>
+// instances compile it (launched when the option bit is set), and only lanes that hold a drone within the margin run
+// the sweeps.  Registers: the impulses and 1 / K of the 24 rows stay live (48), the points are rebuilt from the face
+// centre and the two scaled body axes.
 #define DSIM_PLANE_ITERS 24
-__device__ __forceinline__ V3 inv_inertia_world(const DevType& T, const M3& R, V3 x) {
-  const V3 b = mulT(R, x);
-  return mul(R, v3(b.x * T.invJ[0], b.y * T.invJ[1], b.z * T.invJ[2]));
+#define DSIM_PLANE_POINTS 8
+struct SymM3 { float xx, xy, xz, yy, yz, zz; };
+__device__ __forceinline__ V3 mul(const SymM3& A, V3 b) {
+  return v3(A.xx * b.x + A.xy * b.y + A.xz * b.z, A.xy * b.x + A.yy * b.y + A.yz * b.z, A.xz * b.x + A.yz * b.y + A.zz * b.z);
 }
 __device__ __forceinline__ void plane_contact(const DevType& T, float dt, const V3 pos, const Q4 q, V3& v, V3& w) {
   if (!(T.coll_r > 0.0f)) return;
@@ -290,25 +293,33 @@ __device__ __forceinline__ void plane_contact(const DevType& T, float dt, const 
   const V3 a = v3(R.m[2], R.m[5], R.m[8]);                          // body z axis in the world
   const float sgn = a.z >= 0.0f ? 1.0f : -1.0f;                     // which face is the lower one
   const V3 c = (-sgn * T.coll_below) * a;                           // its centre, relative to the COM
-  V3 d = v3(a.z * a.x, a.z * a.y, a.z * a.z - 1.0f);                // steepest descent inside the face plane
-  float dn = DSIM_SQRT(dot(d, d));
-  if (dn < 1e-6f) { d = v3(R.m[0], R.m[3], R.m[6]); dn = 1.0f; }    // level: body x
-  d = DSIM_RCP(dn) * d;
-  const V3 e = cross(a, d);
-  V3 r[4];
-  float gap[4], lam[4][3], K[4][3];
+  const V3 ex = T.coll_r * v3(R.m[0], R.m[3], R.m[6]), ey = T.coll_r * v3(R.m[1], R.m[4], R.m[7]);   // body x, y, scaled
+  // world inverse inertia R diag(1 / J) R^T
+  SymM3 Ji;
+  {
+    const float i0 = T.invJ[0], i1 = T.invJ[1], i2 = T.invJ[2];
+    Ji.xx = R.m[0] * R.m[0] * i0 + R.m[1] * R.m[1] * i1 + R.m[2] * R.m[2] * i2;
+    Ji.xy = R.m[0] * R.m[3] * i0 + R.m[1] * R.m[4] * i1 + R.m[2] * R.m[5] * i2;
+    Ji.xz = R.m[0] * R.m[6] * i0 + R.m[1] * R.m[7] * i1 + R.m[2] * R.m[8] * i2;
+    Ji.yy = R.m[3] * R.m[3] * i0 + R.m[4] * R.m[4] * i1 + R.m[5] * R.m[5] * i2;
+    Ji.yz = R.m[3] * R.m[6] * i0 + R.m[4] * R.m[7] * i1 + R.m[5] * R.m[8] * i2;
+    Ji.zz = R.m[6] * R.m[6] * i0 + R.m[7] * R.m[7] * i1 + R.m[8] * R.m[8] * i2;
+  }
+  constexpr float H = 0.70710678118654752440f;
+  constexpr float CB[8] = {1.0f, H, 0.0f, -H, -1.0f, -H, 0.0f, H};
+  constexpr float SB[8] = {0.0f, H, 1.0f, H, 0.0f, -H, -1.0f, -H};
+  float gap[DSIM_PLANE_POINTS], lam[DSIM_PLANE_POINTS][3], iK[DSIM_PLANE_POINTS][3];
   bool any = false;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float cj = (j == 0) ? 1.0f : (j == 2 ? -1.0f : 0.0f), sj = (j == 1) ? 1.0f : (j == 3 ? -1.0f : 0.0f);
-    r[j] = c + T.coll_r * (cj * d + sj * e);
-    gap[j] = pos.z + r[j].z;
+  for (int j = 0; j < DSIM_PLANE_POINTS; ++j) {
+    const V3 r = c + (CB[j] * ex + SB[j] * ey);
+    gap[j] = pos.z + r.z;
     any = any || gap[j] < 0.02f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const V3 ax = v3(k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f);
-      const V3 u = cross(inv_inertia_world(T, R, cross(r[j], ax)), r[j]);
-      K[j][k] = T.inv_mass + (k == 0 ? u.x : (k == 1 ? u.y : u.z));
+      const V3 u = cross(mul(Ji, cross(r, ax)), r);
+      iK[j][k] = DSIM_RCP(T.inv_mass + (k == 0 ? u.x : (k == 1 ? u.y : u.z)));
       lam[j][k] = 0.0f;
     }
   }
@@ -316,26 +327,27 @@ __device__ __forceinline__ void plane_contact(const DevType& T, float dt, const 
   const float inv_dt = DSIM_RCP(dt);
   for (int it = 0; it < DSIM_PLANE_ITERS; ++it) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < DSIM_PLANE_POINTS; ++j) {
       if (!(gap[j] < 0.02f)) continue;
+      const V3 r = c + (CB[j] * ex + SB[j] * ey);
 #pragma unroll
       for (int pass = 0; pass < 3; ++pass) {
         const int k = pass == 0 ? 2 : pass - 1;                     // normal (z) first, then the tangents x, y
-        const V3 wr = cross(w, r[j]);
+        const V3 wr = cross(w, r);
         const float u = (k == 0 ? v.x + wr.x : (k == 1 ? v.y + wr.y : v.z + wr.z));
         float dl;
         if (k == 2) {
           const float target = gap[j] < 0.0f ? 0.2f * (-gap[j]) * inv_dt : -gap[j] * inv_dt;
-          const float nl = fmaxf(0.0f, lam[j][2] + (target - u) / K[j][2]);
+          const float nl = fmaxf(0.0f, lam[j][2] + (target - u) * iK[j][2]);
           dl = nl - lam[j][2]; lam[j][2] = nl;
         } else {
           const float lim = T.mu_plane * lam[j][2];
-          const float nl = clampf(lam[j][k] - u / K[j][k], -lim, lim);
+          const float nl = clampf(lam[j][k] - u * iK[j][k], -lim, lim);
           dl = nl - lam[j][k]; lam[j][k] = nl;
         }
         const V3 imp = v3(k == 0 ? dl : 0.0f, k == 1 ? dl : 0.0f, k == 2 ? dl : 0.0f);
         v = v + T.inv_mass * imp;
-        w = w + inv_inertia_world(T, R, cross(r[j], imp));
+        w = w + mul(Ji, cross(r, imp));
       }
     }
   }

@@ -113,9 +113,10 @@ typedef struct dsim_type_params {
   double  max_speed_kmh;              /* URDF max_speed_kmh (VelocityAviary speed limit)    */
   /* bounding cylinder of the vehicle's collision shapes about its body z axis (URDF <collision>; robobee: the
    * 0.15 m x 0.1 m cylinder, robobee.urdf:72-77): radius, and extent below the centre of mass.  The reference loads
-   * plane.urdf with collisions on (BaseAviary.py:680); plane contact is NOT modelled by this library — every
-   * drone-step that ends with this cylinder reaching z <= 0 is counted instead (DSIM_Q_GROUND_CONTACTS), so that a
-   * caller knows when a flight has left the domain in which results are comparable.  0 = no watch for this type.  */
+   * plane.urdf with collisions on (BaseAviary.py:680).  DSIM_OPT_PLANE enforces that plane on this cylinder (general
+   * kernels); without the option the flight kernels do not model it, and every drone-step that ends with this
+   * cylinder reaching z <= 0 is counted instead (DSIM_Q_GROUND_CONTACTS), so that a caller knows when a flight has
+   * left the domain in which results are comparable.  0 = no watch and no contact for this type.  */
   double  collision_radius, collision_below;
   double  contact_friction;           /* DSIM_OPT_PLANE: Coulomb coefficient against the plane (PyBullet combines by product:
                                          plane.urdf's lateral_friction 1.0 x the vehicle's default 0.5)                 */
@@ -147,9 +148,11 @@ enum {
   /* -- physics (changes results) ------------------------------------------------------------------------------------ */
   DSIM_OPT_PLANE       = 1u << 10   /* ground plane z = 0 with contact and friction, as the reference's world has
                                        (BaseAviary.py:680 loads plane.urdf, collisions on).  A PRODUCT-DEFINED contact
-                                       model (four rim points of the vehicle's collision cylinder, sequential impulses,
-                                       ERP 0.2, restitution 0, Coulomb friction): Bullet's own contact pipeline cannot be
-                                       restated or pinned here.  General kernels only.          */
+                                       model (eight body-fixed rim points of the vehicle's collision cylinder, 24
+                                       sequential-impulse sweeps, ERP 0.2, restitution 0, Coulomb friction): Bullet's own
+                                       contact pipeline cannot be restated or pinned here.  Served
+                                       by the k_step_plane / k_physics_plane / k_adaptor kernels; every airframe kind;
+                                       not combined with DSIM_OPT_CHAINED.                                            */
 };
 
 /* A run of consecutive drones of one type (type-major storage of a heterogeneous fleet). */

@@ -590,9 +590,12 @@ void orc_ground_effect(const dsim_type_params* P, const double pos[3], const dou
  * lateral-friction coefficients, 1.0 x 0.5).  Neither the engine nor any recording of it is available, so this is NOT a
  * restatement of Bullet's manifold generation; it keeps the documented ingredients of that solver on a fixed manifold:
  *   - the vehicle's collision shape is its bounding cylinder (radius collision_radius, half-height collision_below,
- *     centred on the COM, axis = body z); the manifold is four points on the rim of its lower face, the first at
- *     the rim's lowest point (steepest descent of the face), the others at 90 degree steps — an edge landing touches
- *     with the first, a flat one with all four;
+ *     centred on the COM, axis = body z); the manifold is ORC_PLANE_POINTS = 8 BODY-FIXED points on the rim of its lower
+ *     face, at 45 degree steps from body x.  (A manifold that follows the rim's lowest point was tried first and
+ *     dropped: the azimuth of a nearly level vehicle's tilt is noise, so the support polygon turned with the rounding
+ *     of the state and a vehicle rocking through level under rotor torque came out 5 % different in fp32 and fp64.
+ *     With fixed points an edge landing is seen at most r sin(tilt) (1 - cos 22.5 deg) = 0.076 r sin(tilt) late.)
+ *     The lower face is the one the body z axis points away from; a vehicle lying exactly on its side switches faces.
  *   - a point closer than the contact breaking threshold (0.02 m) is a constraint: penetrating, its normal velocity
  *     is driven to erp depth / dt (erp = 0.2, restitution 0); separated, it may close no faster than gap / dt;
  *   - Coulomb friction mu = contact_friction on the two world tangents, each clamped to +-mu lambda_n (pyramid);
@@ -600,6 +603,7 @@ void orc_ground_effect(const dsim_type_params* P, const double pos[3], const dou
  * solved between the velocity update and the position update of the step, as a velocity-level solver does.
  * The plane is infinite (pybullet's is a 30 m x 30 m box).  Pinned only by analytic tests (rest, drop, slide, tip). */
 #define ORC_PLANE_ITERS 24
+#define ORC_PLANE_POINTS 8
 #define ORC_PLANE_ERP 0.2
 #define ORC_PLANE_MARGIN 0.02
 static void inv_inertia_world(const dsim_type_params* P, const double R[9], const double x[3], double y[3]) {
@@ -612,20 +616,16 @@ void orc_plane_contact(const dsim_type_params* P, double dt, const double pos[3]
   double R[9];
   orc_matrix_from_quat(q, R);
   const double a[3] = {R[2], R[5], R[8]};                 /* body z axis in the world */
+  const double ex[3] = {R[0], R[3], R[6]}, ey[3] = {R[1], R[4], R[7]};      /* body x, y */
   const double sgn = a[2] >= 0 ? 1.0 : -1.0;              /* which face is the lower one */
-  double c[3], d[3], e[3];
+  double c[3];
   for (int k = 0; k < 3; ++k) c[k] = -sgn * P->collision_below * a[k];      /* lower face centre, relative to the COM */
-  /* steepest descent inside the face plane: -e_z + (e_z . a) a */
-  d[0] = a[2] * a[0]; d[1] = a[2] * a[1]; d[2] = a[2] * a[2] - 1.0;
-  double dn = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-  if (dn < 1e-6) { d[0] = R[0]; d[1] = R[3]; d[2] = R[6]; dn = 1.0; }       /* level: body x */
-  for (int k = 0; k < 3; ++k) d[k] /= dn;
-  cross3(a, d, e);
-  double r[4][3], gap[4], lam[4][3], K[4][3];
-  int active[4], any = 0;
-  for (int j = 0; j < 4; ++j) {
-    const double cj = (j == 0) - (j == 2), sj = (j == 1) - (j == 3);
-    for (int k = 0; k < 3; ++k) r[j][k] = c[k] + P->collision_radius * (cj * d[k] + sj * e[k]);
+  double r[ORC_PLANE_POINTS][3], gap[ORC_PLANE_POINTS], lam[ORC_PLANE_POINTS][3], K[ORC_PLANE_POINTS][3];
+  int active[ORC_PLANE_POINTS], any = 0;
+  for (int j = 0; j < ORC_PLANE_POINTS; ++j) {
+    static const double cb[8] = {1, 0.70710678118654752440, 0, -0.70710678118654752440, -1, -0.70710678118654752440, 0, 0.70710678118654752440};
+    static const double sb[8] = {0, 0.70710678118654752440, 1, 0.70710678118654752440, 0, -0.70710678118654752440, -1, -0.70710678118654752440};
+    for (int k = 0; k < 3; ++k) r[j][k] = c[k] + P->collision_radius * (cb[j] * ex[k] + sb[j] * ey[k]);
     gap[j] = pos[2] + r[j][2];
     active[j] = gap[j] < ORC_PLANE_MARGIN;
     any |= active[j];
@@ -641,7 +641,7 @@ void orc_plane_contact(const dsim_type_params* P, double dt, const double pos[3]
   if (!any) return;
   const double mu = P->contact_friction;
   for (int it = 0; it < ORC_PLANE_ITERS; ++it)
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < ORC_PLANE_POINTS; ++j) {
       if (!active[j]) continue;
       for (int pass = 0; pass < 3; ++pass) {
         const int k = pass == 0 ? 2 : pass - 1;            /* normal (z) first, then the tangents x, y */

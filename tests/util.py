@@ -140,11 +140,18 @@ def increment_ratio(got, ref, prev, terms, k):
 WORST = {}     # test label -> worst ratio seen (printed by conftest at the end of the session)
 
 
-def plane_terms(types, type_id, rigid, dt_ctrl):
-    """DSIM_OPT_PLANE: what the contact solve adds to the magnitudes of step_terms, per drone ([n,13], [n,13]).  A contact
-    point moves at u = v + w x r, |u| <= |v| + |w| R (R: COM to the rim of the collision cylinder); an impulse that
-    changes u by du changes v by at most du and w by at most du / (2 rho) (rho = sqrt(J_min / m): the maximum of
-    (l / J) / (1 / m + l^2 / J) over the lever arm l).  The controller differentiates the new velocity and rates."""
+PLANE_SWEEPS = 24       # DSIM_PLANE_ITERS / ORC_PLANE_ITERS
+
+
+def plane_terms(types, type_id, rigid, dt_ctrl, dt_phys=1.0 / 240.0):
+    """DSIM_OPT_PLANE: what the contact solve adds to the magnitudes of step_terms, per drone ([n,13], [n,13]); to be
+    used with k = K_ULP x sub-steps x (1 + PLANE_SWEEPS) — one more rounding of the contact terms per sweep.
+      - a contact point moves at u = v + w x r, |u| <= |v| + |w| R (R: COM to the rim of the collision cylinder); an
+        impulse that changes u by du changes v by at most du and w by at most du / (2 rho) (rho = sqrt(J_min / m): the
+        maximum of (l / J) / (1 / m + l^2 / J) over the lever arm l);
+      - the target velocity of a point is its gap over dt, gap = z + r_z: operands |z| / dt and R / dt, entering once
+        per sub-step, not once per sweep (hence the division: k ulp(M) then charges them K_ULP ulps per sub-step);
+      - the controller differentiates the new velocity and rates."""
     n = rigid.shape[0]
     tr = np.zeros((n, 13))
     tm = np.zeros((n, 13))
@@ -153,9 +160,11 @@ def plane_terms(types, type_id, rigid, dt_ctrl):
         s = np.flatnonzero(tid == k)
         R = math.hypot(t.collision_radius, t.collision_below)
         u = np.linalg.norm(rigid[s, 7:10], axis=1) + np.linalg.norm(rigid[s, 10:13], axis=1) * R
+        u = u + (np.abs(rigid[s, 2]) + R) / dt_phys / (1 + PLANE_SWEEPS)
         rho = math.sqrt(min(t.inertia) / t.mass)
         tr[s, 7:10] = u[:, None]
         tr[s, 10:13] = (u / (2 * rho))[:, None]
+        tr[s, 0:3] = tr[s, 7:10] * dt_phys
         tm[s, 0:3] = tr[s, 7:10]
         tm[s, 3:6] = tr[s, 10:13]
         tm[s, 6] = u / dt_ctrl
