@@ -1774,14 +1774,23 @@ def test_kernels_stay_inside_their_views(gpu, layout, fleet_kind):
     nat.check(ctx.lib.dsim_control2(ctx.handle, s, n, sv, tv, ctypes.byref(a3), bufs["pos_e"][1].data_ptr(),
                                     bufs["yaw_e"][1].data_ptr(), extra["cmd_out"][1].data_ptr()))
     nat.check(ctx.lib.dsim_observe_soa(ctx.handle, s, n, sv, None, extra["obs_soa"][1].data_ptr(), 16 + ctx.n_act))
+    # the ground-plane instances of the general kernels (fused, Env.step with observation rows, and the adaptors below)
+    ap = _args(nat, 2, DT, float(np.float32(2 / 240)), seed=5, type_id=tid, options=nat.OPT_PLANE)
+    nat.check(ctx.lib.dsim_step(ctx.handle, s, n, sv, tv, ctypes.byref(ap)))
+    ap.action = bufs["action"][1].data_ptr()
+    ap.obs_out, ap.obs_width = extra["obs2"][1].data_ptr(), 16 + ctx.n_act
+    nat.check(ctx.lib.dsim_physics(ctx.handle, s, n, sv, bufs["echo"][1].data_ptr(), ctypes.byref(ap)))
     cnt_buf = torch.full((n_pad + 2 * G,), -7, dtype=torch.int32, device=dev)
     lst_buf = torch.full((4 * n_pad + 2 * G,), -7, dtype=torch.int32, device=dev)
     nat.check(ctx.lib.dsim_adjacency(ctx.handle, s, n, sv, ctypes.byref(g), 5.0, cnt_buf[G:].data_ptr(), lst_buf[G:].data_ptr(), 4))
     if fleet_kind == "quad":
         a.action = bufs["action"][1].data_ptr()
         for mode in (nat.ADAPT_VELOCITY, nat.ADAPT_RPYT):
-            nat.check(ctx.lib.dsim_step_adaptor(ctx.handle, s, n, sv, bufs["action"][1].data_ptr(), mode,
-                                                bufs["echo"][1].data_ptr(), ctypes.byref(a)))
+            for opt in (0, nat.OPT_PLANE):
+                a.options = opt
+                nat.check(ctx.lib.dsim_step_adaptor(ctx.handle, s, n, sv, bufs["action"][1].data_ptr(), mode,
+                                                    bufs["echo"][1].data_ptr(), ctypes.byref(a)))
+        a.options = 0
         a.action = None
         a1.options = nat.OPT_CHAINED
         nat.check(ctx.lib.dsim_step(ctx.handle, s, n, sv, tv, ctypes.byref(a1)))
