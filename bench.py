@@ -381,9 +381,11 @@ def main(argv=None):
     # its step is a chain of kernels (neighbour query, step + grid binning, WLS fallback), timed as a whole
     bytes_per = {"config5": 253, "hexa": 248, "mixed": 241, "mixed_type_major": 241,
                  "two_call_loop": 428}.get(a.workload, BYTES_PER_DRONE_STEP)
-    kernel = {"config5": "k_dw_query_cell, k_step_mixed3 (+ fused grid binning), k_wls_fallback",
+    mixed_k = ("k_step_lean" if a.generic_mixed else "k_step_mixed" if a.mixed_v1 else "k_step_mixed2" if a.mixed_ring
+               else "k_step_mixed3" if (a.mixed_v3 or a.layout != "tile64") else "k_step_mixed4")
+    kernel = {"config5": f"k_dw_query_cell, {mixed_k} (+ fused grid binning), k_wls_fallback",
               "hexa": "k_step_hexa (+ k_wls_fallback)",
-              "mixed": "k_step_mixed3 (+ k_wls_fallback)",
+              "mixed": f"{mixed_k} (+ k_wls_fallback)",
               "mixed_type_major": "k_step_run x2 (+ k_wls_fallback)",
               "two_call_loop": "k_physics_fast (observation fused) + k_control_fast"}.get(a.workload, "k_step_fast")
     achieved = fl.n * bytes_per / launch_s / 1e9

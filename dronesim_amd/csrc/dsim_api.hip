@@ -965,6 +965,13 @@ __global__ __launch_bounds__(64 * WT, S1 ? 4 : 3) void k_step_mixed3(StepK a) {
 // slot groups (whole waves of one type, as before) are dealt to them round-robin, so a tile that needs a third group
 // (65 + 63, or three types) costs one of its waves a second pass instead of costing EVERY tile a third wave.  With
 // the unpadded LDS image (18.4 KB) a CU holds 8 workgroups = 1 024 drones.
+// (Measured and rejected, round 2: NO staging — the slot permutation applied to the lane offset of the single-type
+// kernels' addressing, so that no LDS image bounds the drones in flight and no barrier sits in a workgroup's lifetime.
+// A slot group's lanes then use every other dword of four 128-byte lines per instruction, and every line is requested
+// by both waves of the tile: 421 us with streaming accesses (partial-line writes), 278 us with the default policy,
+// against 199 us for this form — the staging buys whole-line traffic, which is worth more than the occupancy.  Its
+// other lesson is kept: two inlined laws behind one branch need ~113 VGPRs where each alone needs 72-75, and a loop
+// around them makes the compiler hoist all 36 field addresses into SGPR pairs until the scalar file spills.)
 struct Stage64u { float st[DSIM_NF_HEXA][64]; float tg[DSIM_NT][64]; };      // 26 + 10 rows, no padding: 9 KB
 template <int AUX>
 __device__ __forceinline__ void dma_block64u(const float* state_block, const float* target_block, Stage64u& dst, unsigned lane) {
@@ -1033,7 +1040,7 @@ template <bool NOISE, bool NT, bool S1, int NTY>
 __global__ __launch_bounds__(128, S1 ? 4 : 3) void k_step_mixed4(StepK a) {
   constexpr int TILE = 128;
   __shared__ __attribute__((aligned(16))) Stage64u tile[2];                 // [half]: 18.4 KB
-  const unsigned t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const unsigned t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;     // (w: an SGPR, so is the group loop)
   const long long i0 = a.first + (long long)blockIdx.x * TILE;
   if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
   constexpr int AUX = NT ? 2 : 0;
@@ -1045,11 +1052,13 @@ __global__ __launch_bounds__(128, S1 ? 4 : 3) void k_step_mixed4(StepK a) {
   const int t1 = (i0 + 64 + lane < a.n_pad) ? min((int)a.type_id[i0 + 64 + lane], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
   unsigned long long m0[NTY], m1[NTY];
   unsigned g0[NTY + 1];                                       // first slot group of each type
+  unsigned long long hexa_mine = 0;                           // the hexas of this wave's own half (for the store phase)
   g0[0] = 0;
 #pragma unroll
   for (int ty = 0; ty < NTY; ++ty) {
     m0[ty] = __ballot(t0 == ty); m1[ty] = __ballot(t1 == ty);
     g0[ty + 1] = g0[ty] + (((unsigned)__popcll(m0[ty]) + (unsigned)__popcll(m1[ty]) + 63u) >> 6);
+    if ((a.hexa_types >> ty) & 1u) hexa_mine |= w ? m1[ty] : m0[ty];
   }
   __builtin_amdgcn_s_waitcnt(0x0f70);                               // vmcnt(0): this wave's DMAs have landed
   __syncthreads();
@@ -1074,7 +1083,7 @@ __global__ __launch_bounds__(128, S1 ? 4 : 3) void k_step_mixed4(StepK a) {
   }
   __syncthreads();
   if (i0 + t < a.n_pad) {
-    const bool nat_hexa = (a.hexa_types >> min((int)a.type_id[i0 + t], DSIM_MAX_TYPES - 1)) & 1u;   // (re-read: not kept live)
+    const bool nat_hexa = (hexa_mine >> lane) & 1ull;           // (from the ballots: no second read of type_id in front of the stores)
     float* sp = a.st.base + ((i0 + t) >> 6) * a.st.block_stride + lane;
     float (*rows)[64] = tile[w].st;
 #pragma unroll
