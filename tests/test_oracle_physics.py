@@ -7,6 +7,7 @@ are these closed-form checks of the restated Bullet step semantics.  CPU only.
 import math
 
 import numpy as np
+import pytest
 
 from dronesim_amd import params
 from oracle import oracle as orc
@@ -424,3 +425,26 @@ def test_plane_config1_default_flight_touches_down_and_takes_off():
     assert t.collision_below - 2e-3 < zs[PLANE].min() < t.collision_below + 0.01    # plane: rests on it
     on_ground = (zs[PLANE] < t.collision_below + 5e-3).sum() * dtc
     assert 0.03 < on_ground < 1.5                                           # for a few control periods, then lifts off
+
+
+@pytest.mark.parametrize("model", ["robobee", "tello", "hexa_6DOF"])
+def test_plane_every_airframe_rests_tips_back_and_lifts_off(model):
+    """Each shipped airframe: at rest on its collision cylinder with idle rotors it stays put; put down tilted by
+    0.3 rad with a spin it settles level on the plane; above hover thrust it leaves the ground (contact only pushes)."""
+    t, O = _O(model)
+    h = t.collision_below
+    na = t.n_act
+    r, m = _rest(z=h), O.reset_mem(1)
+    m[0, 7:7 + na] = 0.0
+    O.physics(r, m, 240, DT, options=PLANE)
+    assert abs(r[0, 2] - h) < 5e-4 and np.abs(r[0, 7:13]).max() < 5e-3
+    r = _rest(z=h + t.collision_radius * math.sin(0.3) + 0.01)
+    r[0, 3:7] = orc.quat_from_euler([0.3, 0.0, -1.0])
+    r[0, 12] = 2.0                                                 # spinning about the vertical: friction stops it
+    for _ in range(720):
+        O.physics(r, m, 1, DT, options=PLANE)
+    roll, pitch, _ = orc.euler_from_quat(r[0, 3:7])
+    assert abs(roll) < 0.02 and abs(pitch) < 0.02 and abs(r[0, 2] - h) < 2e-3 and np.abs(r[0, 7:13]).max() < 2e-2
+    m[0, 7:7 + na] = min(1.0, 1.3 * t.hover_pwm)
+    O.physics(r, m, 120, DT, options=PLANE)
+    assert r[0, 2] > h + 0.1 and r[0, 9] > 0.2
