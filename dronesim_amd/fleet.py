@@ -215,6 +215,15 @@ class Targets(BlockedSoA):
                 key = tuple(float(x) for x in np.asarray(val, dtype=np.float32).ravel())
                 if self._const.get(f0) == key:
                     continue
+            elif torch.is_tensor(val) and val.device == dev:
+                # the same per-drone device tensor as last time, not written since (torch counts in-place writes, also
+                # through views): the fields already hold it — the reference-shaped loop hands computeControl the same
+                # target_pos every call, and a fleet-sized copy per call is 7 % of that loop
+                key = ("tensor", val, val._version, val.data_ptr(), tuple(val.shape), tuple(val.stride()))
+                old = self._const.get(f0)
+                # (the held reference keeps that storage alive, so an equal address is the same memory)
+                if isinstance(old, tuple) and len(old) == 6 and old[0] == "tensor" and old[2:] == key[2:]:
+                    continue
             t = torch.as_tensor(val, dtype=torch.float32, device=dev).reshape(nf, -1)
             if self.broadcast:
                 self.data[f0:f0 + nf, :] = t

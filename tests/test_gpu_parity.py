@@ -1896,6 +1896,20 @@ def test_env_step_fused_observation_and_zero_copy_command(gpu, layout, noise):
         assert_control_parity(f"two_call_loop control[{layout}]", [t], None, env.state.rigid_aos(), m0, tgt,
                               env.state.mem_aos(), m1, dtc)
         np.testing.assert_array_equal(cmd.cpu().numpy(), env.state.mem_aos()[:, 7:11].astype(np.float32))
+    # a per-drone target tensor handed in again unchanged is not copied again (the loop of examples/fly_INDI.py passes
+    # the same target every call); written in place — also through a view — it is picked up
+    tp = torch.from_numpy(tpos.T.copy()).float().to(env.ctx.device)
+    held = ctrl._targets
+    ctrl.computeControlFromState(dtc, None, target_pos=tp, target_rpy=np.array([0, 0, 0.3]))
+    key0 = held._const[0]
+    ctrl.computeControlFromState(dtc, None, target_pos=tp, target_rpy=np.array([0, 0, 0.3]))
+    assert held._const[0][2:] == key0[2:]
+    np.testing.assert_array_equal(held.fields(0, 3)[:, :n].cpu().numpy(), tp.cpu().numpy())
+    tp[1, 5:9] += 2.0                                             # in place, through a view
+    _, pos_e, _ = ctrl.computeControlFromState(dtc, None, target_pos=tp, target_rpy=np.array([0, 0, 0.3]))
+    np.testing.assert_array_equal(held.fields(0, 3)[:, :n].cpu().numpy(), tp.cpu().numpy())
+    want = tp.cpu().numpy().T - env.state.rigid_aos()[:, 0:3].astype(np.float32)
+    np.testing.assert_allclose(pos_e.cpu().numpy(), want, rtol=0, atol=1e-5)
     env.close()
 
 
