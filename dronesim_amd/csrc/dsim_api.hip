@@ -1547,6 +1547,7 @@ struct DwK {
   int* adj_count;    // [n_pad]
   int* adj_list;     // [max_k][n_pad] or null
   int max_k;
+  int n_types;       // length of types[]
 };
 // position component c of world entry j: from the gathered array, or (single-rank fleets, pos_all = null)
 // straight from the state block
@@ -1610,6 +1611,9 @@ __global__ __launch_bounds__(256) void k_dw_bin(DwK a, BinK b, BinRange r) {
 // ONE reciprocal serves both quotients (1 / (dz^2 beta^2); transcendental instructions issue at a quarter of the FMA
 // rate and were a third of this loop); beta^2 is floored at 1e-12 so that the product cannot underflow — the term is
 // exp(-huge) = 0 there either way.
+#define DSIM_EXP2(x) __builtin_amdgcn_exp2f(x)     // v_exp_f32
+// The receiver's K multiplies the SUM (callers pass K = 1 inside their loops and scale once at the end), and the
+// exponent's -1/2 is folded with log2(e) into one constant in front of v_exp_f32: 24 vector instructions per candidate.
 __device__ __forceinline__ float dw_pair(float4 p, float x, float y, float z, float K, float d1, float d2c) {
   const float dz = p.z - z, dx = p.x - x, dy = p.y - y;
   const float dd = dx * dx + dy * dy;
@@ -1618,7 +1622,7 @@ __device__ __forceinline__ float dw_pair(float4 p, float x, float y, float z, fl
   const float beta = d1 * dzs + d2c;                            // :1754
   const float dz2 = dzs * dzs, b2 = fmaxf(beta * beta, 1e-12f);
   const float inv = DSIM_RCP(dz2 * b2);
-  const float term = -(K * (inv * b2)) * __expf(-0.5f * dd * (inv * dz2));   // :1753, 1755
+  const float term = -(K * (inv * b2)) * DSIM_EXP2((-0.5f * 1.44269504088896341f) * dd * (inv * dz2));   // :1753, 1755
   return hit ? term : 0.0f;
 }
 // (Measured and rejected: the same loop in PACKED fp32 — two candidates per v_pk_add/mul/fma_f32 on an x | y | z LDS
@@ -1645,6 +1649,7 @@ template <int TPB>
 __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings, int tile_cap) {
   extern __shared__ float4 tile[];                                                     // tile_cap entries
   __shared__ int nb_cell[DW_NBR], nb_cnt[DW_NBR];
+  __shared__ float coef[DSIM_MAX_TYPES][4];                                            // (K, DW2, DW3) of every type
   constexpr int RPB = TPB / DW_LPB;                                                    // receivers per pass
   const int ncells = b.nx * b.ny;
   const unsigned t = threadIdx.x;
@@ -1671,25 +1676,39 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
           const int cc = yy * b.nx + xx;
           const int cnt = min(b.count[cc], DW_CAP);
           const float4* __restrict__ src = b.buckets + (long long)cc * DW_CAP;
-          for (int e = sub; e < cnt; e += DW_LPB) fz += dw_pair(src[e], m2.x, m2.y, m2.z, K, d1, d2c);
+          for (int e = sub; e < cnt; e += DW_LPB) fz += dw_pair(src[e], m2.x, m2.y, m2.z, 1.0f, d1, d2c);
         }
-      for (int e = sub; e < n_ovf; e += DW_LPB) fz += dw_pair(b.overflow[e], m2.x, m2.y, m2.z, K, d1, d2c);
+      for (int e = sub; e < n_ovf; e += DW_LPB) fz += dw_pair(b.overflow[e], m2.x, m2.y, m2.z, 1.0f, d1, d2c);
 #pragma unroll
       for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
-      if (sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz; }
+      if (sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = K * fz; }
     }
     return;
   }
+  // The workgroup's life is a chain of dependent global round trips, and the buckets were written by other XCDs (no
+  // shared L2: every trip goes to the fabric, 1.5-2 us each) — it was four trips long (counts; the receivers' entries;
+  // their type ids; their types' coefficients) and is two: the first trip brings the counts, the first pass's
+  // receiver entries (speculatively: slot r of the bucket exists whether or not it is filled) and the coefficient
+  // table of ALL types (to LDS); the second the tile and the receivers' type ids.
   const int c = (int)blockIdx.x;                                                       // this workgroup's cell
   const int cx = c % b.nx, cy = c / b.nx;
   const int side = 2 * rings + 1, n_nb = side * side, centre = rings * side + rings;
   int n_ovf = 0;
+  const float4 me_first = b.buckets[(long long)c * DW_CAP + r_in];                     // (r_in < RPB <= DW_CAP)
+  // (unconditional loads from clamped addresses, so that all of them are issued before anything waits)
+  const int nxx = cx - rings + (int)t % side, nyy = cy - rings + (int)t / side;
+  const bool nin = (int)t < n_nb && nxx >= 0 && nxx < b.nx && nyy >= 0 && nyy < b.ny;
+  const int ncc = nin ? nyy * b.nx + nxx : c;
+  const int ncount = b.count[ncc];
+  const int cty = min(TPB - 1 - (int)t, a.n_types - 1);                                // the LAST lanes hold the types
+  const DevType& CT = a.types[cty];
+  const float c_dw0 = CT.dw[0], c_dw1 = CT.dw[1], c_dw2 = CT.dw[2], c_pr = CT.prop_radius;
   if ((int)t < n_nb) {                                                                 // all neighbour counts at once
-    const int xx = cx - rings + (int)t % side, yy = cy - rings + (int)t / side;
-    const bool in = xx >= 0 && xx < b.nx && yy >= 0 && yy < b.ny;
-    const int cc = in ? yy * b.nx + xx : 0;
-    nb_cell[t] = cc;
-    nb_cnt[t] = in ? min(b.count[cc], DW_CAP) : 0;
+    nb_cell[t] = nin ? ncc : 0;
+    nb_cnt[t] = nin ? min(ncount, DW_CAP) : 0;
+  }
+  if ((int)t >= TPB - a.n_types) {
+    coef[cty][0] = c_dw0 * (0.25f * c_pr) * (0.25f * c_pr); coef[cty][1] = c_dw1; coef[cty][2] = c_dw2;
   }
   n_ovf = b.count[ncells];                                                             // (scalar load, same round trip)
   __syncthreads();
@@ -1706,15 +1725,13 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
     long long i = -1;
     float K = 0.0f, d1 = 0.0f, d2c = 0.0f;
     float fz = 0.0f;
-    if (have) {          // the receiver and its type's coefficients, straight from its bucket: in flight beside the fill
-      me = b.buckets[(long long)c * DW_CAP + r];
+    int ty = 0;
+    if (have) {          // the receiver, straight from its bucket, and its type id: in flight beside the fill
+      me = r0 == 0 ? me_first : b.buckets[(long long)c * DW_CAP + r];
       i = (long long)__float_as_int(me.w) - a.local_offset;
       if (i < 0 || i >= a.n) have = false;                                             // another rank's drone: a candidate only
     }
-    if (have) {
-      const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
-      K = T.dw[0] * (0.25f * T.prop_radius) * (0.25f * T.prop_radius); d1 = T.dw[1]; d2c = T.dw[2];
-    }
+    if (have && a.type_id) ty = a.type_id[i];
     for (int base = 0; base < total; base += tile_cap) {
       if (!whole || r0 == 0) {
         if (base > 0 || r0 > 0) __syncthreads();                                       // the previous tile is done with
@@ -1729,21 +1746,22 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
       }
 
       if (have) {
+        K = coef[ty][0]; d1 = coef[ty][1]; d2c = coef[ty][2];                          // (LDS: written before the first barrier)
         const int lim = min(tile_cap, total - base);
         int e = sub;
         for (; e + DW_LPB < lim; e += 2 * DW_LPB) {                                    // two candidates in flight per lane
           const float4 p0 = tile[e], p1 = tile[e + DW_LPB];
-          fz += dw_pair(p0, me.x, me.y, me.z, K, d1, d2c);
-          fz += dw_pair(p1, me.x, me.y, me.z, K, d1, d2c);
+          fz += dw_pair(p0, me.x, me.y, me.z, 1.0f, d1, d2c);
+          fz += dw_pair(p1, me.x, me.y, me.z, 1.0f, d1, d2c);
         }
-        if (e < lim) fz += dw_pair(tile[e], me.x, me.y, me.z, K, d1, d2c);
+        if (e < lim) fz += dw_pair(tile[e], me.x, me.y, me.z, 1.0f, d1, d2c);
       }
     }
     if (have)
-      for (int k = sub; k < n_ovf; k += DW_LPB) fz += dw_pair(b.overflow[k], me.x, me.y, me.z, K, d1, d2c);
+      for (int k = sub; k < n_ovf; k += DW_LPB) fz += dw_pair(b.overflow[k], me.x, me.y, me.z, 1.0f, d1, d2c);
 #pragma unroll
     for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
-    if (have && sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz; }
+    if (have && sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = K * fz; }
   }
 }
 
@@ -2492,7 +2510,7 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
     const int rings = g->cell >= DW_CUTOFF ? 1 : 2;
     const double nb_mean = (double)a.m / (double)ncells * (2 * rings + 1) * (2 * rings + 1);
     const dim3 gq((unsigned)(ncells + DW_OVF_GROUPS));
-    if (nb_mean <= 128.0) hipLaunchKernelGGL((k_dw_query_cell<64>), gq, dim3(64), 512 * sizeof(float4), st_, a, b, rings, 512);
+    if (nb_mean <= 128.0) hipLaunchKernelGGL((k_dw_query_cell<64>), gq, dim3(64), 256 * sizeof(float4), st_, a, b, rings, 256);
     else hipLaunchKernelGGL((k_dw_query_cell<128>), gq, dim3(128), 768 * sizeof(float4), st_, a, b, rings, 768);
   }
   else hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m * DW_LPR)), dim3(256), 0, st_, a);
@@ -2526,7 +2544,7 @@ static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view
   int rc = make_kview(state, 20 + ctx->max_act, &a.st);
   if (rc) return rc;
   const long long ncells = (long long)g->nx * g->ny;
-  a.types = ctx->d_types; a.type_id = g->type_id; a.pos_all = g->pos_all;
+  a.types = ctx->d_types; a.type_id = g->type_id; a.pos_all = g->pos_all; a.n_types = ctx->n_types;
   a.m = g->m; a.m_pad = g->m_pad; a.n = n; a.n_pad = state.n_pad; a.local_offset = g->local_offset;
   if (g->local_offset < 0 || g->local_offset + n > g->m || g->m >= (1LL << 31)) return DSIM_E_ARG;
   a.xmin = g->xmin; a.ymin = g->ymin; a.inv_cell = 1.0f / g->cell; a.nx = g->nx; a.ny = g->ny;
