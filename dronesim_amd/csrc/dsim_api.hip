@@ -1645,11 +1645,25 @@ __device__ __forceinline__ float dw_pair(float4 p, float x, float y, float z, fl
 #define DW_LPB 8
 #define DW_NBR 25                      // (2 * 2 + 1)^2 cells at most
 #define DW_OVF_GROUPS 16
-template <int TPB>
+// BAND (dense worlds): the term needs the candidate ABOVE the receiver, so half of all pairs are rejected on dz alone.
+// The cell's receivers are sorted by height (one wave, a bitonic network on shuffles) and taken in groups of
+// DW_RPG = 8; a candidate's band is the number of groups whose lowest receiver is below it, the tile is laid out by
+// band, highest first (counted and placed with LDS atomics while the entries wait in registers), and group g reads
+// only the prefix that holds bands > g: the lowest group scans everything, the highest almost nothing.  The groups
+// are dealt to the waves in snake order so that both waves get the same work.  ~48 % fewer pair evaluations at
+// BASELINE config 5's density (25 receivers = 4 groups per cell).
+#define DW_RPG 8
+#define DW_MAXG (DW_CAP / DW_RPG)
+#define DW_ENT_PER_THREAD 6            // ceil(768 / 128): the tile of the dense form, per thread
+template <int TPB, bool BAND>
 __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings, int tile_cap) {
   extern __shared__ float4 tile[];                                                     // tile_cap entries
   __shared__ int nb_cell[DW_NBR], nb_cnt[DW_NBR];
   __shared__ float coef[DSIM_MAX_TYPES][4];                                            // (K, DW2, DW3) of every type
+  __shared__ float4 recv[BAND ? DW_CAP : 1];                                           // receivers, sorted by height
+  __shared__ int rty[BAND ? DW_CAP : 1];                                               // their types (-1: not mine to serve)
+  __shared__ float zlo[BAND ? DW_MAXG : 1];                                            // lowest receiver of every group
+  __shared__ int bcnt[BAND ? DW_MAXG + 1 : 1], bcur[BAND ? DW_MAXG + 1 : 1];           // entries per band; placement cursors
   constexpr int RPB = TPB / DW_LPB;                                                    // receivers per pass
   const int ncells = b.nx * b.ny;
   const unsigned t = threadIdx.x;
@@ -1695,6 +1709,8 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
   const int side = 2 * rings + 1, n_nb = side * side, centre = rings * side + rings;
   int n_ovf = 0;
   const float4 me_first = b.buckets[(long long)c * DW_CAP + r_in];                     // (r_in < RPB <= DW_CAP)
+  float4 mine = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                   // BAND: the whole bucket, one entry per lane
+  if (BAND && t < 64) mine = b.buckets[(long long)c * DW_CAP + t];
   // (unconditional loads from clamped addresses, so that all of them are issued before anything waits)
   const int nxx = cx - rings + (int)t % side, nyy = cy - rings + (int)t / side;
   const bool nin = (int)t < n_nb && nxx >= 0 && nxx < b.nx && nyy >= 0 && nyy < b.ny;
@@ -1718,6 +1734,111 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
   for (int k = 0; k < n_nb; ++k) total += nb_cnt[k];
   // the tile holds the whole neighbourhood in the normal case: one fill, every receiver pass reads it
   const bool whole = total <= tile_cap;
+  if constexpr (BAND) {
+    const int G = (cnt_c + DW_RPG - 1) / DW_RPG;
+    if (whole && G >= 2 && total <= DW_ENT_PER_THREAD * TPB) {
+      const unsigned lane = t & 63u;
+      const int w = __builtin_amdgcn_readfirstlane((int)(t >> 6));
+      int my_ty = -1;
+      if (w == 0) {
+        // ---- sort the receivers by height: bitonic network over the wave, key (z, slot) ----
+        float key = (int)lane < cnt_c ? mine.z : __builtin_inff();
+        int idx = (int)lane;
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+          for (int j = k >> 1; j > 0; j >>= 1) {
+            const float ok = __shfl_xor(key, j);
+            const int oi = __shfl_xor(idx, j);
+            const bool want_min = (((int)lane & j) == 0) == (((int)lane & k) == 0);
+            const bool lt = key < ok || (key == ok && idx < oi);
+            if (want_min != lt) { key = ok; idx = oi; }
+          }
+        }
+        const float4 srt = make_float4(__shfl(mine.x, idx), __shfl(mine.y, idx), __shfl(mine.z, idx), __shfl(mine.w, idx));
+        recv[lane] = srt;
+        if ((lane & (DW_RPG - 1)) == 0) zlo[lane / DW_RPG] = key;
+        if (lane <= DW_MAXG) { bcnt[lane] = 0; bcur[lane] = 0; }
+        const long long i = (long long)__float_as_int(srt.w) - a.local_offset;
+        if ((int)lane < cnt_c && i >= 0 && i < a.n) my_ty = a.type_id ? (int)a.type_id[i] : 0;   // (lands during the fill)
+      }
+      __syncthreads();
+      // ---- fill by band: the entries wait in registers while their bands are counted ----
+      float4 ent[DW_ENT_PER_THREAD];
+      unsigned bands = 0;                                                              // 4 bits per entry
+#pragma unroll
+      for (int q = 0; q < DW_ENT_PER_THREAD; ++q) {
+        const int e = (int)t + q * TPB;
+        ent[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (e < total) {
+          int k = 0, acc = 0;
+          while (e >= acc + nb_cnt[k]) { acc += nb_cnt[k]; ++k; }
+          ent[q] = b.buckets[(long long)nb_cell[k] * DW_CAP + (e - acc)];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < DW_ENT_PER_THREAD; ++q) {
+        const int e = (int)t + q * TPB;
+        int band = 0;
+        if (e < total) {
+          for (int g = 0; g < G; ++g) band += zlo[g] < ent[q].z ? 1 : 0;
+          if (band > 0) atomicAdd(&bcnt[band], 1);
+        }
+        bands |= (unsigned)band << (4 * q);
+      }
+      if (w == 0) rty[lane] = my_ty;
+      __syncthreads();
+      int cb[DW_MAXG + 1];                                                             // entries per band (0 beyond G)
+#pragma unroll
+      for (int k = 1; k <= DW_MAXG; ++k) cb[k] = k <= G ? bcnt[k] : 0;
+#pragma unroll
+      for (int q = 0; q < DW_ENT_PER_THREAD; ++q) {
+        const int band = (int)((bands >> (4 * q)) & 15u);
+        if (band > 0) {
+          int start = 0;                                                               // bands above this one come first
+#pragma unroll
+          for (int k = 1; k <= DW_MAXG; ++k) start += k > band ? cb[k] : 0;
+          tile[start + atomicAdd(&bcur[band], 1)] = ent[q];
+        }
+      }
+      __syncthreads();
+      // ---- the groups, dealt to the waves in snake order ----
+      constexpr int NW = TPB / 64;
+      const int sub8 = (int)(lane % DW_LPB), rg = (int)(lane / DW_LPB);
+      for (int rd = 0; rd * NW < G; ++rd) {
+        const int g = rd * NW + ((rd & 1) ? NW - 1 - w : w);
+        if (g >= G) continue;
+        int lim = 0;                                                                   // end of band g + 1
+#pragma unroll
+        for (int k = 1; k <= DW_MAXG; ++k) lim += k > g ? cb[k] : 0;
+        const int r = g * DW_RPG + rg;
+        const float4 me = recv[r];
+        const int ty = rty[r];
+        const bool have = ty >= 0;
+        float fz = 0.0f;
+        float K = 0.0f;
+        if (have) {
+          K = coef[ty][0];
+          const float d1 = coef[ty][1], d2c = coef[ty][2];
+          int e = sub8;
+          for (; e + DW_LPB < lim; e += 2 * DW_LPB) {
+            const float4 p0 = tile[e], p1 = tile[e + DW_LPB];
+            fz += dw_pair(p0, me.x, me.y, me.z, 1.0f, d1, d2c);
+            fz += dw_pair(p1, me.x, me.y, me.z, 1.0f, d1, d2c);
+          }
+          if (e < lim) fz += dw_pair(tile[e], me.x, me.y, me.z, 1.0f, d1, d2c);
+          for (int k = sub8; k < n_ovf; k += DW_LPB) fz += dw_pair(b.overflow[k], me.x, me.y, me.z, 1.0f, d1, d2c);
+        }
+#pragma unroll
+        for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
+        if (have && sub8 == 0) {
+          const long long i = (long long)__float_as_int(me.w) - a.local_offset;
+          a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = K * fz;
+        }
+      }
+      return;
+    }
+  }
   for (int r0 = 0; r0 < cnt_c; r0 += RPB) {
     const int r = r0 + r_in;
     bool have = r < cnt_c;
@@ -2510,8 +2631,8 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
     const int rings = g->cell >= DW_CUTOFF ? 1 : 2;
     const double nb_mean = (double)a.m / (double)ncells * (2 * rings + 1) * (2 * rings + 1);
     const dim3 gq((unsigned)(ncells + DW_OVF_GROUPS));
-    if (nb_mean <= 128.0) hipLaunchKernelGGL((k_dw_query_cell<64>), gq, dim3(64), 256 * sizeof(float4), st_, a, b, rings, 256);
-    else hipLaunchKernelGGL((k_dw_query_cell<128>), gq, dim3(128), 768 * sizeof(float4), st_, a, b, rings, 768);
+    if (nb_mean <= 128.0) hipLaunchKernelGGL((k_dw_query_cell<64, false>), gq, dim3(64), 256 * sizeof(float4), st_, a, b, rings, 256);
+    else hipLaunchKernelGGL((k_dw_query_cell<128, true>), gq, dim3(128), 768 * sizeof(float4), st_, a, b, rings, 768);
   }
   else hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m * DW_LPR)), dim3(256), 0, st_, a);
   return (int)hipGetLastError();

@@ -734,6 +734,46 @@ def test_downwash_bucket_grid_with_overflowing_cells(gpu):
     ctx.close()
 
 
+@pytest.mark.parametrize("heights", ["uniform", "flat", "two_layers", "ties"])
+def test_downwash_dense_world_height_bands(gpu, heights):
+    """The dense form of the query sorts a cell's receivers by height and lays its tile out in height bands (a group of
+    receivers reads only the candidates above its lowest member): against the brute-force sum on worlds that stress the
+    banding — uniform heights, a FLAT fleet (every candidate at or below every receiver: all bands empty, zero force), two
+    thin layers, many exactly equal heights — with two types, and with another rank's drones among the candidates."""
+    nat, fleet = gpu
+    from dronesim_amd.downwash import Downwash
+    n = 5200
+    types = [params.builtin_type("robobee"), params.builtin_type("hexa_6DOF")]
+    ctx = fleet.Context(types)
+    st = fleet.FleetState(ctx, n)
+    rng = np.random.default_rng({"uniform": 1, "flat": 2, "two_layers": 3, "ties": 4}[heights])
+    rigid, mem, _ = random_fleet(rng, n, n_act=6)
+    rigid[:, 0] = f32(rng.uniform(0, 80, n)); rigid[:, 1] = f32(rng.uniform(0, 80, n))          # 0.8 drones per m^2
+    z = {"uniform": rng.uniform(0.5, 20.5, n), "flat": np.full(n, 3.0),
+         "two_layers": np.where(rng.random(n) < 0.5, 2.0, 2.5) + rng.uniform(0, 1e-3, n),
+         "ties": np.round(rng.uniform(0.5, 6.5, n) * 2) / 2}[heights]                           # 13 distinct heights
+    rigid[:, 2] = f32(z)
+    st.load_aos(rigid, mem)
+    tid = (rng.random(n) < 0.5).astype(np.uint8)
+    tid_dev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device); tid_dev[:n] = torch.from_numpy(tid)
+    dw = Downwash(ctx, st, tid_dev)
+    remote = f32(np.stack([rng.uniform(0, 80, 1300), rng.uniform(0, 80, 1300), rng.uniform(0.5, 22, 1300)], 1))
+    world = np.concatenate([remote[:500], rigid[:, 0:3], remote[500:]])
+    f = dw.compute(torch.from_numpy(np.ascontiguousarray(world.T)).float().to(ctx.device), local_offset=500).cpu().numpy()
+    assert dw._last.cell == 5.0                                                                # the dense form
+    ref = orc.Oracle(types).downwash(rigid, world, type_id=tid)
+    err = np.abs(f[2, :n] - ref) / (np.abs(ref) + 1e-3)
+    assert err.max() < 1e-4, (err.max(), err.argmax())
+    own = orc.Oracle(types).downwash(rigid, rigid[:, 0:3], type_id=tid)
+    if heights == "flat":
+        assert np.abs(own).max() == 0.0 and (ref < 0).sum() > 100        # only the remote drones above push down
+    else:
+        assert (own < 0).sum() > n // 3
+    f_own = dw.compute().cpu().numpy()                                   # the fleet alone
+    assert (np.abs(f_own[2, :n] - own) / (np.abs(own) + 1e-3)).max() < 1e-4
+    ctx.close()
+
+
 @pytest.mark.parametrize("opts", [1, 2, 3])          # DSIM_OPT_DRAG, DSIM_OPT_GROUND, both
 def test_drag_and_ground_effect_vs_oracle(gpu, opts):
     """Formulas P6/P7 (dead code in the reference fork) as switchable physics terms: Env.step with an
