@@ -290,8 +290,11 @@ def measure_variant(torch, local, layout, seed, steps, name, nf, rep, sub, wp, n
         f2.use_graph(ns)
     k2 = max(20, steps // 2)
     w2, d2, reg = f2.timed(k2, 10, min_s=MIN_TIMED_S)
+    # drone_steps_per_s: from the host's clock around the regions; launch_us (and device_drone_steps_per_s): from the
+    # events on the launch stream — they differ when the host, not the device, paces the loop (or hiccups)
     e = {"drone_steps_per_s": f2.n * k2 * reg * ns / w2, "launch_us": d2 / (k2 * reg) * 1e6, "env_steps_per_launch": ns,
-         "drones": f2.n, "phys_substeps": sub, "steps_timed": k2 * reg}
+         "drones": f2.n, "phys_substeps": sub, "steps_timed": k2 * reg,
+         "device_drone_steps_per_s": f2.n * k2 * reg * ns / d2}
     if ns == 1:
         bts = 184 if "chained" in name else (248 if name.startswith("hexa") else
                                              (253 if name.startswith("config5") else
@@ -473,18 +476,23 @@ def main(argv=None):
             ctrl = INDIControl("robobee", env=env)
             tpos = torch.from_numpy(np.ascontiguousarray(xyz.T.astype(np.float32))).to(env.ctx.device)
             cmd = torch.full((xyz.shape[0], 4), 0.4, device=env.ctx.device)
-            iters, el = 0, 0.0
-            for timed_pass in (False, True, True):
+            iters, el, el_dev = 0, 0.0, 0.0
+            for timed_pass in (False, True, True, True):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 torch.cuda.synchronize(); t0 = time.perf_counter()
-                for _ in range(50):
+                e0.record()
+                for _ in range(100):
                     obs, _, _, _ = env.step(cmd)
                     cmd, _, _ = ctrl.computeControlFromState(1 / 240, None, target_pos=tpos, target_rpy=np.array([0, 0, 0.4]))
+                e1.record()
                 torch.cuda.synchronize()
                 if timed_pass:
                     el += time.perf_counter() - t0
-                    iters += 50
+                    el_dev += e0.elapsed_time(e1) * 1e-3
+                    iters += 100
             also["config2x1024_env_step_then_computeControl"] = {
                 "drone_steps_per_s": xyz.shape[0] * iters / el, "loop_us": el / iters * 1e6, "steps_timed": iters,
+                "loop_us_device": el_dev / iters * 1e6,
                 "bytes_per_drone_step": 428, "hbm_frac": xyz.shape[0] * 428 / (el / iters) / 1e9 / HBM_PEAK_GBPS,
                 "note": "physics 68 r + 148 w (13 rigid, 4 action | 13 rigid, 4 echo, 20-wide observation row); "
                         "control 136 r + 76 w (13 + 11 + 10 | 11 memory, 4 cmd, 3 pos_e, yaw_e)"}
