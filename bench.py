@@ -29,6 +29,7 @@ The N = 1 line also carries the literal BASELINE configs 1-3 at their own sizes 
 variants ("also").
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -187,6 +188,12 @@ class Fleet:
         torch = self.torch
         for _ in range(warmup):
             self.step()
+        # the collector stays off inside the timed regions (as timeit does): a collection that frees another variant's
+        # graphs or fleet in the middle of a region stalls the host for tens of milliseconds (seen: 3x wall vs device)
+        gc.collect()
+        torch.cuda.synchronize()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         wall_sum = dev_sum = 0.0
         regions, want = 0, 1
         while regions < want:
@@ -208,6 +215,8 @@ class Fleet:
             regions += 1
             if regions == 1 and min_s > 0.0:
                 want = repeat_rule(wall) if repeat_rule else max(1, int(np.ceil(min_s / max(wall, 1e-9))))
+        if gc_was_on:
+            gc.enable()
         return wall_sum, dev_sum, regions
 
 
@@ -477,6 +486,8 @@ def main(argv=None):
             tpos = torch.from_numpy(np.ascontiguousarray(xyz.T.astype(np.float32))).to(env.ctx.device)
             cmd = torch.full((xyz.shape[0], 4), 0.4, device=env.ctx.device)
             iters, el, el_dev = 0, 0.0, 0.0
+            gc.collect()
+            gc.disable()
             for timed_pass in (False, True, True, True):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -490,6 +501,7 @@ def main(argv=None):
                     el += time.perf_counter() - t0
                     el_dev += e0.elapsed_time(e1) * 1e-3
                     iters += 100
+            gc.enable()
             also["config2x1024_env_step_then_computeControl"] = {
                 "drone_steps_per_s": xyz.shape[0] * iters / el, "loop_us": el / iters * 1e6, "steps_timed": iters,
                 "loop_us_device": el_dev / iters * 1e6,
