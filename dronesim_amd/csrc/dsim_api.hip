@@ -275,6 +275,13 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
                                               V3 ext = V3{0.0f, 0.0f, 0.0f}) {
   V3 F, tau;
   if (!NOISE) hexa_wrench(T, cmd, nullptr, F, tau);
+  // The state holds what PyBullet reports — the BASE link's centre of mass (dsim_type_params.base_offset); the composite
+  // body is integrated about its own: p = p_b - R d, v = v_b - w x (R d) in front of the sub-steps, and back behind them.
+  const V3 bo = v3(T.base_off[0], T.base_off[1], T.base_off[2]);
+  {
+    const V3 o = mul(matrix_from_quat(s.q), bo);
+    s.pos = s.pos - o; s.vel = s.vel - cross(s.w, o);
+  }
   const int n_sub = ONE ? 1 : a.substeps;
   for (int k = 0; k < n_sub; ++k) {
     if (NOISE) {
@@ -290,6 +297,10 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
       hexa_wrench(T, cmd, nz, F, tau);
     }
     bullet_step<PLANE>(T, a.dt_phys, s, F + ext, tau);
+  }
+  {
+    const V3 o = mul(matrix_from_quat(s.q), bo);
+    s.pos = s.pos + o; s.vel = s.vel + cross(s.w, o);
   }
 }
 
@@ -2014,6 +2025,8 @@ static void to_dev(const dsim_type_params& p, DevType* d) {
   d->speed_limit = (float)(p.max_speed_kmh * (1000.0 / 3600.0));
   d->coll_r = (float)p.collision_radius; d->coll_below = (float)p.collision_below;
   d->mu_plane = (float)p.contact_friction;
+  for (int k = 0; k < 3; ++k) d->base_off[k] = (float)p.base_offset[k];
+  d->watch_below = (float)(p.collision_below + p.base_offset[2]);    // (the offset of the shipped hexa is along body z)
 }
 
 extern "C" {

@@ -35,6 +35,8 @@ struct DevType {
   float speed_limit;                          // MAX_SPEED_KMH * 1000/3600 (VelocityAviary.py:92-94)
   float coll_r, coll_below;                   // bounding cylinder of the collision shapes (ground-plane watch)
   float mu_plane;                             // DSIM_OPT_PLANE: Coulomb coefficient against the plane
+  float base_off[3];                          // integrated COM -> the reported point (base link COM), body frame
+  float watch_below;                          // coll_below seen from the reported point (ground-plane watch)
 };
 
 struct V3 { float x, y, z; };
@@ -206,7 +208,7 @@ struct Target { V3 pos, vel, acc; float yaw; };
 #define DSIM_GROUND_SHARDS 64
 __device__ __forceinline__ void ground_watch(const DevType& T, const Rigid& s, unsigned long long* counters, bool live = true) {
   const float r22 = 1.0f - 2.0f * (s.q.x * s.q.x + s.q.y * s.q.y);                     // body z . world z (unit q)
-  const float reach = T.coll_below * fabsf(r22) + T.coll_r * DSIM_SQRT(fmaxf(1.0f - r22 * r22, 0.0f));
+  const float reach = T.watch_below * fabsf(r22) + T.coll_r * DSIM_SQRT(fmaxf(1.0f - r22 * r22, 0.0f));
   const bool hit = live && T.coll_r > 0.0f && s.pos.z <= reach;
   const unsigned long long m = __ballot(hit);
   if (m != 0ULL && (int)(threadIdx.x & 63u) == __builtin_ctzll(m))

@@ -74,6 +74,7 @@ class TypeParamsC(ctypes.Structure):
         ("collision_radius", ctypes.c_double),
         ("collision_below", ctypes.c_double),
         ("contact_friction", ctypes.c_double),
+        ("base_offset", ctypes.c_double * 3),
     ]
 
 
@@ -115,6 +116,7 @@ class DroneType:
     collision_radius: float = 0.0    # bounding cylinder of the <collision> shapes about body z: radius ...
     collision_below: float = 0.0     # ... and extent below the COM (ground-plane watch; 0 = none)
     contact_friction: float = 0.5    # DSIM_OPT_PLANE: plane.urdf lateral_friction 1.0 x PyBullet's default 0.5 for the vehicle
+    base_offset: Sequence[float] = (0.0, 0.0, 0.0)   # integrated COM -> the point PyBullet reports (base link COM), body frame
     reset_thrust: float = 0.0        # INDIControl.reset (INDIControl.py:127); 6DOF 0.3 (:232)
     reset_cmd: float = 0.0           # INDIControl.py:129; 6DOF 0.5 (:234)
     alloc: np.ndarray = field(default=None)  # type: ignore[assignment]
@@ -160,6 +162,11 @@ class DroneType:
         M4 = np.eye(self.n_act) - M1 @ B - P[:, 6:] * Wu[None, :]
         return M1, M4
 
+    @property
+    def rest_height(self) -> float:
+        """z of the reported point (base link COM) when the vehicle stands level on the ground plane."""
+        return float(self.collision_below) + float(self.base_offset[2])
+
     def to_c(self) -> TypeParamsC:
         c = TypeParamsC()
         c.kind, c.n_act = self.kind, self.n_act
@@ -200,6 +207,8 @@ class DroneType:
         c.max_speed_kmh = self.max_speed_kmh
         c.collision_radius, c.collision_below = self.collision_radius, self.collision_below
         c.contact_friction = self.contact_friction
+        for j in range(3):
+            c.base_offset[j] = float(self.base_offset[j])
         return c
 
     @property
@@ -268,8 +277,8 @@ def _hexa_6dof() -> DroneType:
     # dronesim/assets/hexa_6DOF.urdf: properties :27, control :29-53, link inertials :78-81, 94-98,
     # 238-241, 254-258, joints :382-476.  PyBullet flies it as an articulated body (six revolute arm
     # joints held by default motors); here it is ONE rigid body: total mass, and inertia / rotor lever
-    # arms about the composite COM, computed by parse_urdf() from those lines (the position state is
-    # the composite COM, 11 mm below the mainbody origin).  Rotor j: thrust along the prop link's z
+    # arms about the composite COM, computed by parse_urdf() from those lines (the state block holds
+    # the base link's COM as PyBullet reports it; the composite COM, base_offset away, is what is integrated).  Rotor j: thrust along the prop link's z
     # (tilted +-0.3 rad about the arm), applied at the prop link's inertial origin.
     return DroneType(
         name="hexa_6DOF", kind=KIND_HEXA6DOF, n_act=6, mass=0.8600000000000003, ctrl_mass=0.2,
@@ -295,6 +304,7 @@ def _hexa_6dof() -> DroneType:
         kp_pos=1.7, kd_pos=2.5, att_gain=(10.0, 10.0, 5.0), rate_gain=(18.0, 18.0, 12.0),
         prop_radius=6.7e-2, reset_thrust=0.3, reset_cmd=0.5,
         collision_radius=0.18986507827381124, collision_below=0.06903716345121234,   # all links' <collision> shapes
+        base_offset=(-1.1106382076676865e-05, -1.111343640005967e-06, 0.010962836548787658),   # mainbody COM - composite COM
         **_AERO,
     )
 
@@ -478,4 +488,5 @@ def parse_urdf(path: str) -> DroneType:
         max_speed_kmh=float(prop["max_speed_kmh"]),
         reset_thrust=rt, reset_cmd=rc,
         collision_radius=coll_r, collision_below=coll_below,
+        base_offset=tuple(float(x) for x in (com0 - C)) if is_hexa else (0.0, 0.0, 0.0),
     )

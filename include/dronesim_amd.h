@@ -120,6 +120,12 @@ typedef struct dsim_type_params {
   double  collision_radius, collision_below;
   double  contact_friction;           /* DSIM_OPT_PLANE: Coulomb coefficient against the plane (PyBullet combines by product:
                                          plane.urdf's lateral_friction 1.0 x the vehicle's default 0.5)                 */
+  /* Body-frame vector from the centre of mass the physics integrates to the point whose position and velocity the state
+   * block holds — what p.getBasePositionAndOrientation / getBaseVelocity report (BaseAviary.py:726-732): the BASE
+   * link's centre of mass.  Zero for the single-body quads; the morphing hexa is flown as the rigid composite of its 19
+   * links, whose centre of mass lies 11 mm below the base link's (hexa_6DOF.urdf).  mass, inertia, rotor_pos and the
+   * collision cylinder are about the integrated centre of mass. */
+  double  base_offset[3];
 } dsim_type_params;
 
 /* ---- step options ---------------------------------------------------------- */

@@ -733,6 +733,17 @@ void orc_physics_substep(const dsim_type_params* P, double dt, double rigid[13],
   const double* fn = noise;
   const double* mn = noise ? noise + P->n_act : NULL;
   double* pos = rigid; double* q = rigid + 3; double* v = rigid + 7; double* w = rigid + 10;
+  /* The state holds what p.getBasePositionAndOrientation / getBaseVelocity report (BaseAviary.py:726-732): the BASE link's
+   * centre of mass.  A vehicle flown as the rigid composite of several links (the morphing hexa) is integrated about the
+   * composite's centre of mass, base_offset away: p = p_b - R d, v = v_b - w x (R d) in front of the step, and back. */
+  const int shifted = P->base_offset[0] != 0.0 || P->base_offset[1] != 0.0 || P->base_offset[2] != 0.0;
+  if (shifted) {
+    double R[9], o[3], wo[3];
+    orc_matrix_from_quat(q, R);
+    for (int k = 0; k < 3; ++k) o[k] = R[3 * k] * P->base_offset[0] + R[3 * k + 1] * P->base_offset[1] + R[3 * k + 2] * P->base_offset[2];
+    cross3(w, o, wo);
+    for (int k = 0; k < 3; ++k) { pos[k] -= o[k]; v[k] -= wo[k]; }
+  }
   if (P->kind == DSIM_KIND_HEXA6DOF) orc_hexa_wrench(P, cmd, fn, mn, F, tau, rpm);
   else orc_quad_wrench(P, cmd, fn, mn, F, tau, rpm);
   if (options & DSIM_OPT_GROUND) { /* BaseAviary.py:528-529: extra thrust per rotor link */
@@ -753,6 +764,13 @@ void orc_physics_substep(const dsim_type_params* P, double dt, double rigid[13],
   }
   if (ext_force_body) for (int k = 0; k < 3; ++k) F[k] += ext_force_body[k];
   orc_bullet_step_ex(P, dt, pos, q, v, w, F, tau, (options & DSIM_OPT_PLANE) != 0);
+  if (shifted) {
+    double R[9], o[3], wo[3];
+    orc_matrix_from_quat(q, R);
+    for (int k = 0; k < 3; ++k) o[k] = R[3 * k] * P->base_offset[0] + R[3 * k + 1] * P->base_offset[1] + R[3 * k + 2] * P->base_offset[2];
+    cross3(w, o, wo);
+    for (int k = 0; k < 3; ++k) { pos[k] += o[k]; v[k] += wo[k]; }
+  }
 }
 
 /* ======================================================================= */

@@ -418,6 +418,13 @@ def test_force_map_vs_reference_recorded_calls(gpu, golden_dir, model):
     got = st.rigid_aos()
     v = (F / t.mass + np.array([0, 0, -t.gravity])) * DT
     w = tau / np.asarray(t.inertia)[None] * DT
+    # the state holds the velocity of the point PyBullet reports (the base link's COM: base_offset from the integrated
+    # one; zero for the quads) — v_b = v + w x (R d), R the attitude after the sub-step
+    qx, qy, qz, qw = (got[:, 3 + k] for k in range(4))
+    R = np.stack([np.stack([1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)], 1),
+                  np.stack([2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx)], 1),
+                  np.stack([2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)], 1)], 1)
+    v = v + np.cross(w, R @ np.asarray(t.base_offset))
     np.testing.assert_allclose(got[:, 7:10], v, rtol=REL_TOL, atol=REL_TOL * np.abs(v).max())
     np.testing.assert_allclose(got[:, 10:13], w, rtol=REL_TOL, atol=REL_TOL * np.abs(w).max())
     ctx.close()
@@ -2171,7 +2178,7 @@ def _near_ground_fleet(t, n, seed, n_act=4):
     flying clear of the 0.02 m margin."""
     rng = np.random.default_rng(seed)
     rigid, mem, tgt = random_fleet(rng, n, n_act=n_act, tilt=0.6, speed=1.5, rate=2.0, spread=20.0)
-    h = t.collision_below
+    h = t.rest_height
     kind = np.arange(n) % 3
     rest = kind == 0
     rigid[rest, 2] = h + rng.uniform(-2e-3, 2e-3, rest.sum())                 # within the penetration / margin band
@@ -2228,7 +2235,7 @@ def test_plane_contact_vs_oracle(gpu, model, sub):
     # nothing ends the step deeper in the plane than it started, beyond the solver's residual
     def lowest(r):
         r22 = 1.0 - 2.0 * (r[:, 3] ** 2 + r[:, 4] ** 2)
-        return r[:, 2] - (t.collision_below * np.abs(r22) + t.collision_radius * np.sqrt(np.maximum(1.0 - r22 * r22, 0.0)))
+        return r[:, 2] - (t.rest_height * np.abs(r22) + t.collision_radius * np.sqrt(np.maximum(1.0 - r22 * r22, 0.0)))
     # (the eight body-fixed rim points see an edge at most r sin(tilt) (1 - cos 22.5 deg) late)
     r22 = 1.0 - 2.0 * (got[:, 3] ** 2 + got[:, 4] ** 2)
     late = 0.0762 * t.collision_radius * np.sqrt(np.maximum(1.0 - r22 * r22, 0.0))
@@ -2341,7 +2348,7 @@ def test_plane_option_routing_and_refusals(gpu):
         st = fleet.FleetState(ctx, n, layout, 256)
         tg = fleet.Targets(ctx, n, layout, pad=256)
         rigid, mem, tgt = random_fleet(np.random.default_rng(3), n, n_act=6, tilt=0.4)
-        rigid[:, 2] = f32(np.where(tid == 0, t4.collision_below, t6.collision_below) + np.random.default_rng(4).uniform(-1e-3, 0.05, n))
+        rigid[:, 2] = f32(np.where(tid == 0, t4.rest_height, t6.rest_height) + np.random.default_rng(4).uniform(-1e-3, 0.05, n))
         rigid[:, 9] = -np.abs(rigid[:, 9])
         mem[tid == 0, 11:13] = 0.0
         st.load_aos(rigid, mem)

@@ -432,7 +432,7 @@ def test_plane_every_airframe_rests_tips_back_and_lifts_off(model):
     """Each shipped airframe: at rest on its collision cylinder with idle rotors it stays put; put down tilted by
     0.3 rad with a spin it settles level on the plane; above hover thrust it leaves the ground (contact only pushes)."""
     t, O = _O(model)
-    h = t.collision_below
+    h = t.rest_height                                              # (hexa: the base link's COM is 11 mm above the composite's)
     na = t.n_act
     r, m = _rest(z=h), O.reset_mem(1)
     m[0, 7:7 + na] = 0.0
@@ -448,3 +448,31 @@ def test_plane_every_airframe_rests_tips_back_and_lifts_off(model):
     m[0, 7:7 + na] = min(1.0, 1.3 * t.hover_pwm)
     O.physics(r, m, 120, DT, options=PLANE)
     assert r[0, 2] > h + 0.1 and r[0, 9] > 0.2
+
+
+def test_hexa_state_is_the_base_link_the_composite_com_is_what_flies():
+    """p.getBasePositionAndOrientation reports the BASE link's centre of mass (BaseAviary.py:726-732); the morphing hexa
+    is integrated as the rigid composite of its links, whose centre of mass is 11 mm lower (dsim_type_params.base_offset).
+    Torque-free, force-free, undamped: the composite COM reconstructed from the state moves in a straight line while the
+    reported point circles it, and the reported velocity is v_com + w x (R d)."""
+    import dataclasses
+    t0 = params.builtin_type("hexa_6DOF")
+    d = np.asarray(t0.base_offset)
+    assert abs(d[2] - 0.011) < 1e-3 and np.abs(d[:2]).max() < 1e-4
+    t = dataclasses.replace(t0, gravity=0.0, lin_damping=0.0, ang_damping=0.0, kf=0.0, km=0.0)
+    O = orc.Oracle([t])
+    r, m = _rest(z=1.0), O.reset_mem(1)
+    w0 = np.array([3.0, 0.0, 0.0])                                   # about a principal axis: stays constant
+    vcom = np.array([0.1, -0.2, 0.05])
+    r[0, 10:13] = w0
+    r[0, 7:10] = vcom + np.cross(w0, d)                              # level: R = I
+    com0 = r[0, 0:3] - d
+    for k in range(1, 241):
+        O.physics(r, m, 1, DT)
+        R = np.array(orc.matrix_from_quat(r[0, 3:7])).reshape(3, 3)
+        np.testing.assert_allclose(r[0, 0:3] - R @ d, com0 + vcom * k * DT, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(r[0, 7:10], vcom + np.cross(r[0, 10:13], R @ d), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(r[0, 10:13], w0, rtol=0, atol=1e-12)
+    assert abs(np.linalg.norm(r[0, 0:3] - (com0 + vcom * 240 * DT)) - np.linalg.norm(d)) < 1e-12
+    # a quad's reported point IS its centre of mass
+    assert tuple(params.builtin_type("robobee").base_offset) == (0.0, 0.0, 0.0)
