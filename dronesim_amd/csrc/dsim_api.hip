@@ -277,9 +277,8 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
   if (!NOISE) hexa_wrench(T, cmd, nullptr, F, tau);
   // The state holds what PyBullet reports — the BASE link's centre of mass (dsim_type_params.base_offset); the composite
   // body is integrated about its own: p = p_b - R d, v = v_b - w x (R d) in front of the sub-steps, and back behind them.
-  const V3 bo = v3(T.base_off[0], T.base_off[1], T.base_off[2]);
   {
-    const V3 o = mul(matrix_from_quat(s.q), bo);
+    const V3 o = mul(matrix_from_quat(s.q), v3(T.base_off[0], T.base_off[1], T.base_off[2]));
     s.pos = s.pos - o; s.vel = s.vel - cross(s.w, o);
   }
   const int n_sub = ONE ? 1 : a.substeps;
@@ -299,7 +298,7 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
     bullet_step<PLANE>(T, a.dt_phys, s, F + ext, tau);
   }
   {
-    const V3 o = mul(matrix_from_quat(s.q), bo);
+    const V3 o = mul(matrix_from_quat(s.q), v3(T.base_off[0], T.base_off[1], T.base_off[2]));
     s.pos = s.pos + o; s.vel = s.vel + cross(s.w, o);
   }
 }
@@ -1005,7 +1004,7 @@ __device__ __forceinline__ void staged_body4(const DevType& T, const StepK& a, l
   constexpr int NA = HEXA ? 6 : 4;
   float (*st)[64] = tile[d >> 6].st;
   float (*tt)[64] = tile[d >> 6].tg;
-  const unsigned c = d & 63u;
+  unsigned c = d & 63u;
   Rigid s;
   CtrlMem<NA> m;
   Target tg;
@@ -1013,26 +1012,26 @@ __device__ __forceinline__ void staged_body4(const DevType& T, const StepK& a, l
   s.q = Q4{st[3][c], st[4][c], st[5][c], st[6][c]};
   s.vel = v3(st[7][c], st[8][c], st[9][c]);
   s.w = v3(st[10][c], st[11][c], st[12][c]);
-  m.last_vel = v3(st[13][c], st[14][c], st[15][c]);
-  m.last_rates = v3(st[16][c], st[17][c], st[18][c]);
-  m.last_thrust = st[19][c];
 #pragma unroll
   for (int j = 0; j < NA; ++j) m.cmd[j] = st[20 + j][c];
-  tg.pos = v3(tt[0][c], tt[1][c], tt[2][c]);
-  tg.vel = v3(tt[3][c], tt[4][c], tt[5][c]);
-  tg.acc = v3(tt[6][c], tt[7][c], tt[8][c]);
-  tg.yaw = tt[9][c];
   V3 ext = v3(0, 0, 0);
   if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
   V3 pos_e;
   float yaw_e;
-  if constexpr (HEXA) {
-    hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
-    indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, active ? i : -1LL);
-  } else {
-    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
-    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  }
+  if constexpr (HEXA) hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
+  else quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
+  // what only the law reads — the rest of the controller memory and the targets — comes out of LDS BEHIND the sub-steps
+  // (tied to their result): read in front of them it is 17 registers held through the physics
+  asm volatile("" : "+v"(c) : "v"(s.pos.z));
+  m.last_vel = v3(st[13][c], st[14][c], st[15][c]);
+  m.last_rates = v3(st[16][c], st[17][c], st[18][c]);
+  m.last_thrust = st[19][c];
+  tg.pos = v3(tt[0][c], tt[1][c], tt[2][c]);
+  tg.vel = v3(tt[3][c], tt[4][c], tt[5][c]);
+  tg.acc = v3(tt[6][c], tt[7][c], tt[8][c]);
+  tg.yaw = tt[9][c];
+  if constexpr (HEXA) indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, active ? i : -1LL);
+  else indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   ground_watch(T, s, a.fb.counters, active && i < a.n);      // (behind the law: in front of it it costs registers)
   if (!active) return;
   st[0][c] = s.pos.x; st[1][c] = s.pos.y; st[2][c] = s.pos.z;
