@@ -87,6 +87,17 @@ __device__ __forceinline__ int bin_cell(const BinK& b, float x, float y) {
   const int cy = min(max((int)floorf((y - b.ymin) * b.inv_cell), 0), b.ny - 1);
   return cy * b.nx + cx;
 }
+// the two halves of bin_entry: the slot's reservation is an atomic round trip to another XCD's L2 (~2 us); issued as soon
+// as the new position exists it is hidden behind the control law instead of standing at the end of the workgroup
+__device__ __forceinline__ int bin_reserve(const BinK& b, float x, float y, int& cell) {
+  cell = bin_cell(b, x, y);
+  return atomicAdd(&b.count[cell], 1);
+}
+__device__ __forceinline__ void bin_commit(const BinK& b, int cell, int slot, float x, float y, float z, long long world_index) {
+  const float4 e = make_float4(x, y, z, __int_as_float((int)world_index));
+  if (slot < DW_CAP) b.buckets[(long long)cell * DW_CAP + slot] = e;
+  else b.overflow[atomicAdd(&b.count[b.nx * b.ny], 1)] = e;
+}
 __device__ __forceinline__ void bin_entry(const BinK& b, float x, float y, float z, long long world_index) {
   const int c = bin_cell(b, x, y);
   const float4 e = make_float4(x, y, z, __int_as_float((int)world_index));
@@ -998,7 +1009,7 @@ __device__ __forceinline__ void dma_block64u(const float* state_block, const flo
   __builtin_amdgcn_global_load_lds(target_block + 8 * 64 + lane, lt + 8 * 64, 4, 0, AUX);           // rows 8, 9
   __builtin_amdgcn_global_load_lds(target_block + 9 * 64 + lane, lt + 9 * 64, 4, 0, AUX);
 }
-template <bool HEXA, bool NOISE, bool S1>
+template <bool HEXA, bool NOISE, bool S1, bool BIN>
 __device__ __forceinline__ void staged_body4(const DevType& T, const StepK& a, long long i, Stage64u* tile, unsigned d,
                                              bool active) {
   constexpr int NA = HEXA ? 6 : 4;
@@ -1023,6 +1034,9 @@ __device__ __forceinline__ void staged_body4(const DevType& T, const StepK& a, l
   // what only the law reads — the rest of the controller memory and the targets — comes out of LDS BEHIND the sub-steps
   // (tied to their result): read in front of them it is 17 registers held through the physics
   asm volatile("" : "+v"(c) : "v"(s.pos.z));
+  int bcell = 0, bslot = -1;                                  // next step's neighbour grid: reserve the slot now
+  const bool binning = BIN && active && i < a.n;              // (BIN instances are launched when a.bin.count is set)
+  if (binning) bslot = bin_reserve(a.bin, s.pos.x, s.pos.y, bcell);
   m.last_vel = v3(st[13][c], st[14][c], st[15][c]);
   m.last_rates = v3(st[16][c], st[17][c], st[18][c]);
   m.last_thrust = st[19][c];
@@ -1043,10 +1057,11 @@ __device__ __forceinline__ void staged_body4(const DevType& T, const StepK& a, l
   st[19][c] = m.last_thrust;
 #pragma unroll
   for (int j = 0; j < NA; ++j) st[20 + j][c] = m.cmd[j];
+  if (binning) bin_commit(a.bin, bcell, bslot, s.pos.x, s.pos.y, s.pos.z, a.bin.local_offset + i);
 }
 // wave-tiled layout only (state of 26 fields and per-drone targets, as for the ring); up to DSIM_MIXED2_TYPES types
 // NTY = number of types in the table (2..4): the ballot loop and the group bookkeeping are sized for it
-template <bool NOISE, bool NT, bool S1, int NTY>
+template <bool NOISE, bool NT, bool S1, int NTY, bool BIN>
 __global__ __launch_bounds__(128, S1 ? 4 : 3) void k_step_mixed4(StepK a) {
   constexpr int TILE = 128;
   __shared__ __attribute__((aligned(16))) Stage64u tile[2];                 // [half]: 18.4 KB
@@ -1088,8 +1103,8 @@ __global__ __launch_bounds__(128, S1 ? 4 : 3) void k_step_mixed4(StepK a) {
     const unsigned d = rr < c0 ? nth_set_bit64(ma, rr) : 64u + nth_set_bit64(mb, rr - c0);
     const long long i = i0 + d;
     const DevType& T = a.types[ty];
-    if (T.kind == DSIM_DEV_KIND_HEXA) staged_body4<true, NOISE, S1>(T, a, i, tile, d, active);
-    else staged_body4<false, NOISE, S1>(T, a, i, tile, d, active);
+    if (T.kind == DSIM_DEV_KIND_HEXA) staged_body4<true, NOISE, S1, BIN>(T, a, i, tile, d, active);
+    else staged_body4<false, NOISE, S1, BIN>(T, a, i, tile, d, active);
   }
   __syncthreads();
   if (i0 + t < a.n_pad) {
@@ -1099,8 +1114,6 @@ __global__ __launch_bounds__(128, S1 ? 4 : 3) void k_step_mixed4(StepK a) {
 #pragma unroll
     for (int f = 0; f < 24; ++f) stg<NT>(sp + f * 64, 0u, rows[f][lane]);
     if (nat_hexa) { stg<NT>(sp + 24 * 64, 0u, rows[24][lane]); stg<NT>(sp + 25 * 64, 0u, rows[25][lane]); }
-    if (a.bin.count && i0 + t < a.n)
-      bin_entry(a.bin, rows[0][lane], rows[1][lane], rows[2][lane], a.bin.local_offset + i0 + t);
   }
 }
 
@@ -2361,16 +2374,18 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
       if (tiled && !(args->options & (DSIM_OPT_MIXED_V1 | DSIM_OPT_MIXED_RING | DSIM_OPT_MIXED_V3))) {
         // fourth form: two waves per tile, slot groups dealt round-robin (wave-tiled layout)
         const dim3 gm((unsigned)((a.n_pad - first + 127) / 128)), bm(128);
-#define DSIM_MIXED4_CASE2(S_, Y_)                                                                                 \
-  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed4<true, true, S_, Y_>), gm, bm, 0, st_, a);            \
-                    else hipLaunchKernelGGL((k_step_mixed4<true, false, S_, Y_>), gm, bm, 0, st_, a); }            \
-       else { if (nt) hipLaunchKernelGGL((k_step_mixed4<false, true, S_, Y_>), gm, bm, 0, st_, a);                 \
-              else hipLaunchKernelGGL((k_step_mixed4<false, false, S_, Y_>), gm, bm, 0, st_, a); } } while (0)
+#define DSIM_MIXED4_CASE3(S_, Y_, B_)                                                                             \
+  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed4<true, true, S_, Y_, B_>), gm, bm, 0, st_, a);            \
+                    else hipLaunchKernelGGL((k_step_mixed4<true, false, S_, Y_, B_>), gm, bm, 0, st_, a); }            \
+       else { if (nt) hipLaunchKernelGGL((k_step_mixed4<false, true, S_, Y_, B_>), gm, bm, 0, st_, a);                 \
+              else hipLaunchKernelGGL((k_step_mixed4<false, false, S_, Y_, B_>), gm, bm, 0, st_, a); } } while (0)
+#define DSIM_MIXED4_CASE2(S_, Y_) do { if (a.bin.count) DSIM_MIXED4_CASE3(S_, Y_, true); else DSIM_MIXED4_CASE3(S_, Y_, false); } while (0)
 #define DSIM_MIXED4_CASE(S_) do { if (ctx->n_types == 2) DSIM_MIXED4_CASE2(S_, 2); else if (ctx->n_types == 3) DSIM_MIXED4_CASE2(S_, 3); \
                                   else DSIM_MIXED4_CASE2(S_, 4); } while (0)
         if (a.substeps == 1) DSIM_MIXED4_CASE(true); else DSIM_MIXED4_CASE(false);
 #undef DSIM_MIXED4_CASE
 #undef DSIM_MIXED4_CASE2
+#undef DSIM_MIXED4_CASE3
         if (any_hexa) fb_finish(ctx, a, st_);
         bin_next_commit(ctx, n, args, a);
         return (int)hipGetLastError();
