@@ -1789,14 +1789,16 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
       // ---- fill by band: the entries wait in registers while their bands are counted ----
       float4 ent[DW_ENT_PER_THREAD];
       unsigned bands = 0;                                                              // 4 bits per entry
-#pragma unroll
-      for (int q = 0; q < DW_ENT_PER_THREAD; ++q) {
-        const int e = (int)t + q * TPB;
-        ent[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (e < total) {
-          int k = 0, acc = 0;
-          while (e >= acc + nb_cnt[k]) { acc += nb_cnt[k]; ++k; }
-          ent[q] = b.buckets[(long long)nb_cell[k] * DW_CAP + (e - acc)];
+      {
+        int k = 0, acc = 0;                                                            // (the thread's entries ascend: the walk
+#pragma unroll                                                                         //  over the neighbour counts resumes)
+        for (int q = 0; q < DW_ENT_PER_THREAD; ++q) {
+          const int e = (int)t + q * TPB;
+          ent[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (e < total) {
+            while (e >= acc + nb_cnt[k]) { acc += nb_cnt[k]; ++k; }
+            ent[q] = b.buckets[(long long)nb_cell[k] * DW_CAP + (e - acc)];
+          }
         }
       }
 #pragma unroll
@@ -1811,16 +1813,12 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
       }
       if (w == 0) rty[lane] = my_ty;
       __syncthreads();
-      int cb[DW_MAXG + 1];                                                             // entries per band (0 beyond G)
-#pragma unroll
-      for (int k = 1; k <= DW_MAXG; ++k) cb[k] = k <= G ? bcnt[k] : 0;
 #pragma unroll
       for (int q = 0; q < DW_ENT_PER_THREAD; ++q) {
         const int band = (int)((bands >> (4 * q)) & 15u);
         if (band > 0) {
           int start = 0;                                                               // bands above this one come first
-#pragma unroll
-          for (int k = 1; k <= DW_MAXG; ++k) start += k > band ? cb[k] : 0;
+          for (int k = band + 1; k <= G; ++k) start += bcnt[k];
           tile[start + atomicAdd(&bcur[band], 1)] = ent[q];
         }
       }
@@ -1832,8 +1830,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
         const int g = rd * NW + ((rd & 1) ? NW - 1 - w : w);
         if (g >= G) continue;
         int lim = 0;                                                                   // end of band g + 1
-#pragma unroll
-        for (int k = 1; k <= DW_MAXG; ++k) lim += k > g ? cb[k] : 0;
+        for (int k = g + 1; k <= G; ++k) lim += bcnt[k];
         const int r = g * DW_RPG + rg;
         const float4 me = recv[r];
         const int ty = rty[r];
