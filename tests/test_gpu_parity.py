@@ -741,6 +741,37 @@ def test_downwash_bucket_grid_with_overflowing_cells(gpu):
     ctx.close()
 
 
+@pytest.mark.parametrize("density", ["sparse", "dense"])
+def test_downwash_receiver_coefficients_of_many_types(gpu, density):
+    """The receiver's three downwash coefficients come from a table of ALL types that the query kernel keeps in LDS:
+    five airframes whose DW1, DW2, DW3 and propeller radius all differ (the shipped ones share DW2 and DW3), in both
+    forms of the query."""
+    import dataclasses
+    nat, fleet = gpu
+    from dronesim_amd.downwash import Downwash
+    base = params.builtin_type("robobee")
+    types = [dataclasses.replace(base, name=f"rb{k}", dw_coeff=(2267.18 * (1 + 0.3 * k), 0.16 + 0.02 * k, -0.11 + 0.015 * k),
+                                 prop_radius=base.prop_radius * (1 + 0.2 * k)) for k in range(5)]
+    n = 4000
+    side = 220.0 if density == "sparse" else 70.0
+    ctx = fleet.Context(types)
+    st = fleet.FleetState(ctx, n)
+    rng = np.random.default_rng(77)
+    rigid, mem, _ = random_fleet(rng, n)
+    rigid[:, 0] = f32(rng.uniform(0, side, n)); rigid[:, 1] = f32(rng.uniform(0, side, n)); rigid[:, 2] = f32(rng.uniform(0.5, 12, n))
+    st.load_aos(rigid, mem)
+    tid = rng.integers(0, 5, n).astype(np.uint8)
+    tid_dev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device); tid_dev[:n] = torch.from_numpy(tid)
+    dw = Downwash(ctx, st, tid_dev)
+    f = dw.compute().cpu().numpy()
+    assert dw._last.cell == (10.0 if density == "sparse" else 5.0)
+    ref = orc.Oracle(types).downwash(rigid, rigid[:, 0:3], type_id=tid)
+    assert (np.abs(f[2, :n] - ref) / (np.abs(ref) + 1e-3)).max() < 1e-4
+    wrong = orc.Oracle(types).downwash(rigid, rigid[:, 0:3], type_id=(tid + 1) % 5)
+    assert (np.abs(wrong - ref) / (np.abs(ref) + 1e-3)).max() > 1e-2          # the coefficients do matter
+    ctx.close()
+
+
 @pytest.mark.parametrize("heights", ["uniform", "flat", "two_layers", "ties"])
 def test_downwash_dense_world_height_bands(gpu, heights):
     """The dense form of the query sorts a cell's receivers by height and lays its tile out in height bands (a group of
