@@ -2397,3 +2397,46 @@ def test_plane_option_routing_and_refusals(gpu):
         a.options = nat.OPT_PLANE | nat.OPT_DRAG
         assert ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)) == -5     # DSIM_E_UNSUPPORTED
     ctx.close()
+
+
+def test_plane_with_waypoints_multi_step_launches_and_fused_rows(gpu, golden_dir):
+    """The plane instances of the general kernels carry every option of the general path: a fleet that starts ON the
+    ground and tracks the waypoint table with n_steps = K per launch ends bit-identical to K single-step launches
+    (state, waypoint counters, contact counter), noise on; and Env.step's fused observation rows over the plane equal
+    the stand-alone observation kernel's."""
+    from dronesim_amd.envs import CtrlAviary
+    from dronesim_amd.fleet import WaypointTargets
+    nat, fleet = gpu
+    g = np.load(os.path.join(golden_dir, "traj_track_waypoints.npz"))
+    t = params.builtin_type("robobee")
+    n = 700                                                  # ragged: general kernels with or without the plane
+    off = np.stack([np.arange(n) % 30 * 1.5, np.arange(n) // 30 * 1.5, np.zeros(n)], 1)
+    xyz = off + np.array([0.0, 0.0, t.rest_height])          # parked on the plane
+    wp0 = np.arange(n) % g["target_pos"].shape[0]
+    envs, wps = [], []
+    for _ in range(2):
+        env = CtrlAviary(["robobee"], n, initial_xyzs=xyz, aggregate_phy_steps=2, noise_seed=11, dict_io=False, ground_plane=True)
+        envs.append(env)
+        wps.append(WaypointTargets(env.ctx, n, g["target_pos"], g["target_vel"], g["target_acc"], g["target_yaw"],
+                                   wp_counters=wp0, offsets=off))
+    a0 = np.full((n, 4), 0.1, dtype=np.float32)
+    for env, wp in zip(envs, wps):
+        env.step_fused(wp, action=a0)
+    for _ in range(12):
+        envs[0].step_fused(wps[0])
+    envs[1].step_fused(wps[1], n_steps=5); envs[1].step_fused(wps[1], n_steps=7)
+    np.testing.assert_array_equal(envs[0].state.fields(0, 24).cpu().numpy(), envs[1].state.fields(0, 24).cpu().numpy())
+    np.testing.assert_array_equal(wps[0].counters.cpu().numpy(), wps[1].counters.cpu().numpy())
+    assert envs[0].ground_contacts() == envs[1].ground_contacts() > 0
+    z = envs[0].state.rigid_aos()[:, 2]
+    assert (z > t.rest_height - 3e-3).all()                  # nobody went through the floor on the way up
+    # Env.step with the observation rows fused (general kernel + observation kernel behind it) over the plane
+    env = envs[0]
+    act = torch.full((n, 4), 0.2, device=env.ctx.device)
+    obs, _, _, _ = env.step(act)
+    alone = env.observe()
+    cp = [c for c in range(20) if not 7 <= c < 10]
+    np.testing.assert_array_equal(obs.cpu().numpy()[:, cp], alone.cpu().numpy()[:, cp])
+    np.testing.assert_allclose(obs.cpu().numpy()[:, 7:10], alone.cpu().numpy()[:, 7:10], rtol=0, atol=1e-6)
+    for e in envs:
+        e.close()
