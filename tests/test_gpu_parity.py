@@ -741,6 +741,43 @@ def test_downwash_bucket_grid_with_overflowing_cells(gpu):
     ctx.close()
 
 
+@pytest.mark.parametrize("world", ["crowd", "vast"])
+def test_downwash_counting_sort_form(gpu, world):
+    """Worlds the bucket form does not take — more than 40 drones per cell on average (a crowd: 2.4 per m^2), or more
+    than 65 536 cells (3 km x 3 km) — go through the counting-sort grid (count, scan, scatter, sorted query): against
+    the brute-force sum, two types, and with another rank's drones among the candidates."""
+    nat, fleet = gpu
+    from dronesim_amd.downwash import Downwash
+    types = [params.builtin_type("robobee"), params.builtin_type("hexa_6DOF")]
+    n = 6000
+    side = 50.0 if world == "crowd" else 3000.0
+    ctx = fleet.Context(types)
+    st = fleet.FleetState(ctx, n)
+    rng = np.random.default_rng(91)
+    rigid, mem, _ = random_fleet(rng, n, n_act=6)
+    rigid[:, 0] = f32(rng.uniform(0, side, n)); rigid[:, 1] = f32(rng.uniform(0, side, n)); rigid[:, 2] = f32(rng.uniform(0.5, 20.5, n))
+    if world == "vast":                                      # clusters, so that pairs exist at all
+        c = rng.integers(0, 40, n)
+        ctr = rng.uniform(100, side - 100, (40, 2))
+        rigid[:, 0:2] = f32(ctr[c] + rng.uniform(-15, 15, (n, 2)))
+    st.load_aos(rigid, mem)
+    tid = (np.arange(n) % 2).astype(np.uint8)
+    tid_dev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device); tid_dev[:n] = torch.from_numpy(tid)
+    dw = Downwash(ctx, st, tid_dev)
+    f = dw.compute().cpu().numpy()
+    g = dw._last
+    assert ctx.lib.dsim_downwash_prebin_ok(g.m, g.nx, g.ny) == 0 and g.cell == 10.0       # not the bucket form
+    ref = orc.Oracle(types).downwash(rigid, rigid[:, 0:3], type_id=tid)
+    assert (ref < 0).sum() > n // 4
+    assert (np.abs(f[2, :n] - ref) / (np.abs(ref) + 1e-3)).max() < 1e-4
+    remote = f32(np.concatenate([rigid[:800, 0:2] + rng.uniform(-3, 3, (800, 2)), rng.uniform(0.5, 25, (800, 1))], 1))
+    world_pos = np.concatenate([remote[:300], rigid[:, 0:3], remote[300:]])
+    f2 = dw.compute(torch.from_numpy(np.ascontiguousarray(world_pos.T)).float().to(ctx.device), local_offset=300).cpu().numpy()
+    ref2 = orc.Oracle(types).downwash(rigid, world_pos, type_id=tid)
+    assert (np.abs(f2[2, :n] - ref2) / (np.abs(ref2) + 1e-3)).max() < 1e-4
+    ctx.close()
+
+
 @pytest.mark.parametrize("density", ["sparse", "dense"])
 def test_downwash_receiver_coefficients_of_many_types(gpu, density):
     """The receiver's three downwash coefficients come from a table of ALL types that the query kernel keeps in LDS:
