@@ -2477,3 +2477,40 @@ def test_plane_with_waypoints_multi_step_launches_and_fused_rows(gpu, golden_dir
     np.testing.assert_allclose(obs.cpu().numpy()[:, 7:10], alone.cpu().numpy()[:, 7:10], rtol=0, atol=1e-6)
     for e in envs:
         e.close()
+
+
+@pytest.mark.parametrize("fleet_kind", ["quad", "hexa", "mixed"])
+def test_tuning_options_do_not_change_results(gpu, fleet_kind):
+    """DSIM_OPT_STREAM_ON / _OFF select the streaming or the default cache policy of the same kernel: bit-identical
+    states.  DSIM_OPT_GENERIC_MIXED steps a mixed fleet with the general kernel instead of the staged one: the same
+    step within the step's bar."""
+    nat, fleet = gpu
+    names = {"quad": ["robobee"], "hexa": ["hexa_6DOF"], "mixed": ["robobee", "hexa_6DOF"]}[fleet_kind]
+    types = [params.builtin_type(m) for m in names]
+    n = 2048
+    na = max(t.n_act for t in types)
+    rigid, mem, tgt = random_fleet(np.random.default_rng(5), n, n_act=na, tilt=0.3, rate=1.0)
+    tid = (np.arange(n) % 2).astype(np.uint8) if fleet_kind == "mixed" else None
+    if tid is not None:
+        mem[tid == 0, 11:13] = 0.0
+    out = {}
+    for name, opt in (("on", nat.OPT_STREAM_ON), ("off", nat.OPT_STREAM_OFF), ("generic", nat.OPT_GENERIC_MIXED)):
+        if name == "generic" and fleet_kind != "mixed":
+            continue
+        ctx = fleet.Context(types)
+        st = fleet.FleetState(ctx, n, "tile64")
+        tg = fleet.Targets(ctx, n, "tile64")
+        st.load_aos(rigid, mem)
+        tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
+        tdev = None
+        if tid is not None:
+            tdev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device); tdev[:n] = torch.from_numpy(tid)
+        a = _args(nat, 2, DT, float(np.float32(2 / 240)), options=opt, seed=21, step_index=3, type_id=tdev)
+        nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
+        out[name] = (st.rigid_aos(), st.mem_aos())
+        ctx.close()
+    np.testing.assert_array_equal(out["on"][0], out["off"][0])
+    np.testing.assert_array_equal(out["on"][1], out["off"][1])
+    if "generic" in out:
+        assert_step_parity("generic_mixed_vs_staged", types, tid, rigid, mem, tgt, out["generic"][0], out["generic"][1],
+                           out["on"][0], out["on"][1], DT, float(np.float32(2 / 240)), 2)
