@@ -2514,3 +2514,120 @@ def test_tuning_options_do_not_change_results(gpu, fleet_kind):
     if "generic" in out:
         assert_step_parity("generic_mixed_vs_staged", types, tid, rigid, mem, tgt, out["generic"][0], out["generic"][1],
                            out["on"][0], out["on"][1], DT, float(np.float32(2 / 240)), 2)
+
+
+# ---------------------------------------------------------------------------
+# every template instance of the step kernels: each combination the launcher can dispatch is run once —
+# streaming and default cache policy give the same bits, and the result meets the oracle at the step's bar
+# ---------------------------------------------------------------------------
+def _noise_block(O, types, tid, n, seed, step_index, sub):
+    nz = np.zeros((n, sub, 12))
+    for i in range(n):
+        na = types[0 if tid is None else int(tid[i])].n_act
+        for s_ in range(sub):
+            u = O.noise_normals(seed, i, step_index * sub + s_, na)
+            nz[i, s_, 0:na] = u[0:na] * 0.01
+            nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
+    return nz
+
+
+def _sweep_case(gpu, label, types, tid, n, sub, seed, options, action=None, n_steps=1, runs=None, layout="tile64"):
+    nat, fleet = gpu
+    na = max(t.n_act for t in types)
+    rigid, mem, tgt = random_fleet(np.random.default_rng(n + sub + seed), n, n_act=na, tilt=0.3, rate=1.0)
+    if tid is not None:
+        for k, t in enumerate(types):
+            mem[tid == k, 7 + t.n_act:13] = 0.0
+    elif na == 4:
+        mem[:, 11:13] = 0.0
+    if options & nat.OPT_CHAINED:
+        # the chained form does not READ last_vel / last_rates: it takes them to be what a previous step left — the
+        # velocity and the body rates of the stored state (computeControl stores them at the end of every call)
+        mem[:, 0:3] = rigid[:, 7:10]
+        for i in range(n):
+            R = np.array(orc.matrix_from_quat(rigid[i, 3:7])).reshape(3, 3)
+            mem[i, 3:6] = f32(R.T @ rigid[i, 10:13])
+        mem = f32(mem)
+    dtc = float(np.float32(sub / 240))
+    sidx = 4
+    got = {}
+    for pol in (nat.OPT_STREAM_ON, nat.OPT_STREAM_OFF):
+        ctx = fleet.Context(types)
+        st, tg = fleet.FleetState(ctx, n, layout), fleet.Targets(ctx, n, layout)
+        st.load_aos(rigid, mem)
+        tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
+        tdev = None
+        if tid is not None:
+            tdev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device); tdev[:n] = torch.from_numpy(tid)
+        adev = None
+        if action is not None:
+            adev = torch.zeros((na, st.n_pad), device=ctx.device); adev[:, :n] = torch.from_numpy(np.ascontiguousarray(action.T)).float()
+        a = _args(nat, sub, DT, dtc, options=options | pol, seed=seed, step_index=sidx, type_id=tdev, action=adev)
+        a.n_steps = n_steps
+        arr = None
+        if runs is not None:
+            arr = (nat.TypeRun * len(runs))()
+            for k, (f, c, ty) in enumerate(runs):
+                arr[k].first, arr[k].count, arr[k].type = f, c, ty
+            a.runs, a.n_runs = ctypes.addressof(arr), len(runs)
+        nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
+        if options & nat.OPT_CHAINED:
+            nat.check(ctx.lib.dsim_materialize(ctx.handle, _stream(ctx), n, st.view()))
+        got[pol] = (st.rigid_aos(), st.mem_aos())
+        ctx.close()
+    np.testing.assert_array_equal(got[nat.OPT_STREAM_ON][0], got[nat.OPT_STREAM_OFF][0], err_msg=label)
+    np.testing.assert_array_equal(got[nat.OPT_STREAM_ON][1], got[nat.OPT_STREAM_OFF][1], err_msg=label)
+    O = orc.Oracle(types)
+    r, m = rigid.copy(), mem.copy()
+    for k in range(n_steps):
+        r0, m0 = r.copy(), m.copy()
+        nz = _noise_block(O, types, tid, n, seed, sidx + k, sub) if seed else None
+        a6 = None
+        if action is not None and k == 0:
+            a6 = np.zeros((n, 6)); a6[:, :na] = action
+        assert O.step(r, m, tgt, sub, DT, dtc, noise=nz, type_id=tid, action=a6) == 0
+    if n_steps == 1:
+        assert_step_parity(label, types, tid, rigid, mem, tgt, got[nat.OPT_STREAM_OFF][0], got[nat.OPT_STREAM_OFF][1], r, m,
+                           DT, dtc, sub, action=action)
+    else:      # several Env.steps in one launch: the bar of the LAST step from the oracle's previous state, widened by the count
+        assert_step_parity(label, types, tid, r0, m0, tgt, got[nat.OPT_STREAM_OFF][0], got[nat.OPT_STREAM_OFF][1], r, m,
+                           DT, dtc, sub, k=K_ULP * sub * 4 * n_steps)
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+@pytest.mark.parametrize("sub", [1, 2])
+def test_every_instance_of_the_single_type_step_kernels(gpu, sub, seed):
+    nat, fleet = gpu
+    rb, hx = params.builtin_type("robobee"), params.builtin_type("hexa_6DOF")
+    n = 512
+    act4 = f32(np.random.default_rng(1).uniform(0.3, 0.7, (n, 4)))
+    act6 = f32(np.random.default_rng(2).uniform(0.3, 0.7, (n, 6)))
+    # k_step_fast<NOISE, NT, EXT, CH, SUB, ACT>: plain, explicit action, chained, several steps per launch (+ chained)
+    _sweep_case(gpu, f"sweep fast plain[{sub},{seed}]", [rb], None, n, sub, seed, 0)
+    _sweep_case(gpu, f"sweep fast action[{sub},{seed}]", [rb], None, n, sub, seed, 0, action=act4)
+    _sweep_case(gpu, f"sweep fast chained[{sub},{seed}]", [rb], None, n, sub, seed, nat.OPT_CHAINED)
+    _sweep_case(gpu, f"sweep fast 3 steps[{sub},{seed}]", [rb], None, n, sub, seed, 0, n_steps=3)
+    _sweep_case(gpu, f"sweep fast 3 steps chained[{sub},{seed}]", [rb], None, n, sub, seed, nat.OPT_CHAINED, n_steps=3)
+    # k_step_hexa<NOISE, NT, S1, ACT>
+    _sweep_case(gpu, f"sweep hexa plain[{sub},{seed}]", [hx], None, n, sub, seed, 0)
+    _sweep_case(gpu, f"sweep hexa action[{sub},{seed}]", [hx], None, n, sub, seed, 0, action=act6)
+    # k_step_run<HEXA, NOISE, NT, S1>: type-major runs
+    tid = np.repeat(np.array([0, 1], dtype=np.uint8), 256)
+    _sweep_case(gpu, f"sweep runs[{sub},{seed}]", [rb, hx], tid, n, sub, seed, 0, runs=[(0, 256, 0), (256, 256, 1)])
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+@pytest.mark.parametrize("sub", [1, 2])
+@pytest.mark.parametrize("n_types", [2, 3, 4])
+def test_every_instance_of_the_mixed_fleet_kernels(gpu, n_types, sub, seed):
+    """k_step_mixed4 / mixed3 / mixed / mixed2 <NOISE, NT, waves | types, S1, ...>: every form, 2-4 types, on the layouts
+    that select them."""
+    import dataclasses
+    nat, fleet = gpu
+    rb, hx, te = params.builtin_type("robobee"), params.builtin_type("hexa_6DOF"), params.builtin_type("tello")
+    types = [rb, hx, te, dataclasses.replace(rb, name="rb2", kp_pos=1.3, mass=0.8)][:n_types]
+    n = 640
+    tid = np.random.default_rng(n_types).integers(0, n_types, n).astype(np.uint8)
+    for form, opt, layout in (("v4", 0, "tile64"), ("v3", nat.OPT_MIXED_V3, "tile64"), ("v3 soa", 0, "soa"),
+                              ("v1", nat.OPT_MIXED_V1, "tile64"), ("v1 soa", nat.OPT_MIXED_V1, "soa"), ("ring", nat.OPT_MIXED_RING, "tile64")):
+        _sweep_case(gpu, f"sweep mixed {form}[{n_types},{sub},{seed}]", types, tid, n, sub, seed, opt, layout=layout)
