@@ -2631,3 +2631,220 @@ def test_every_instance_of_the_mixed_fleet_kernels(gpu, n_types, sub, seed):
     for form, opt, layout in (("v4", 0, "tile64"), ("v3", nat.OPT_MIXED_V3, "tile64"), ("v3 soa", 0, "soa"),
                               ("v1", nat.OPT_MIXED_V1, "tile64"), ("v1 soa", nat.OPT_MIXED_V1, "soa"), ("ring", nat.OPT_MIXED_RING, "tile64")):
         _sweep_case(gpu, f"sweep mixed {form}[{n_types},{sub},{seed}]", types, tid, n, sub, seed, opt, layout=layout)
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+@pytest.mark.parametrize("sub", [1, 2])
+@pytest.mark.parametrize("n_types", [2, 3, 4])
+def test_every_binning_instance_of_the_mixed_kernel(gpu, n_types, sub, seed):
+    """k_step_mixed4<.., BIN = true>: the step kernel that also fills the NEXT neighbour grid (dsim_step_args.bin_next).
+    Same step as the oracle's, streaming on or off, and the downwash evaluated from the pre-binned grid equals the
+    brute-force sum over the NEW positions."""
+    import dataclasses
+    nat, fleet = gpu
+    rb, hx, te = params.builtin_type("robobee"), params.builtin_type("hexa_6DOF"), params.builtin_type("tello")
+    types = [rb, hx, te, dataclasses.replace(rb, name="rb2", kp_pos=1.3, mass=0.8)][:n_types]
+    n = 1024
+    rng = np.random.default_rng(10 * n_types + sub)
+    tid = rng.integers(0, n_types, n).astype(np.uint8)
+    rigid, mem, tgt = random_fleet(rng, n, n_act=6, tilt=0.3, rate=1.0)
+    rigid[:, 0] = f32(rng.uniform(1, 79, n)); rigid[:, 1] = f32(rng.uniform(1, 59, n)); rigid[:, 2] = f32(rng.uniform(1, 15, n))
+    for k, t in enumerate(types):
+        mem[tid == k, 7 + t.n_act:13] = 0.0
+    dtc = float(np.float32(sub / 240))
+    O = orc.Oracle(types)
+    got = {}
+    for pol in (nat.OPT_STREAM_ON, nat.OPT_STREAM_OFF):
+        ctx = fleet.Context(types)
+        st, tg = fleet.FleetState(ctx, n, "tile64"), fleet.Targets(ctx, n, "tile64")
+        st.load_aos(rigid, mem)
+        tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
+        tdev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device); tdev[:n] = torch.from_numpy(tid)
+        g = nat.DownwashArgs()
+        nx, ny = 16, 12
+        assert ctx.lib.dsim_downwash_prebin_ok(n, nx, ny) == 1
+        ws = torch.empty((ctx.lib.dsim_downwash_workspace(n, nx, ny),), dtype=torch.int32, device=ctx.device)
+        g.pos_all, g.m, g.m_pad = None, n, n
+        g.xmin, g.ymin, g.cell, g.nx, g.ny = 0.0, 0.0, 5.0, nx, ny
+        g.workspace, g.workspace_len, g.type_id, g.local_offset = ws.data_ptr(), ws.numel(), tdev.data_ptr(), 0
+        force = torch.zeros((3, st.n_pad), device=ctx.device)
+        s_ = _stream(ctx)
+        nat.check(ctx.lib.dsim_downwash(ctx.handle, s_, n, st.view(), ctypes.byref(g), force.data_ptr()))   # builds grid 0, zeroes grid 1
+        f0 = force.cpu().numpy()[2, :n].astype(np.float64)
+        a = _args(nat, sub, DT, dtc, options=pol, seed=seed, step_index=2, type_id=tdev)
+        a.ext_force, a.bin_next = force.data_ptr(), ctypes.addressof(g)
+        nat.check(ctx.lib.dsim_step(ctx.handle, s_, n, st.view(), tg.view(), ctypes.byref(a)))
+        g.prebinned = 1
+        force2 = torch.zeros((3, st.n_pad), device=ctx.device)
+        nat.check(ctx.lib.dsim_downwash(ctx.handle, s_, n, st.view(), ctypes.byref(g), force2.data_ptr()))
+        got[pol] = (st.rigid_aos(), st.mem_aos(), force2.cpu().numpy()[2, :n].astype(np.float64))
+        ctx.close()
+    on, off = got[nat.OPT_STREAM_ON], got[nat.OPT_STREAM_OFF]
+    # (not bitwise here: the bucket order, hence the summation order of the force that enters the step, follows an atomic scatter)
+    np.testing.assert_allclose(on[0], off[0], rtol=2e-6, atol=1e-7); np.testing.assert_allclose(on[1], off[1], rtol=2e-5, atol=2e-6)
+    # the step itself, with the downwash force of the old positions held over the sub-steps
+    ref0 = O.downwash(rigid, rigid[:, 0:3], type_id=tid)
+    assert (np.abs(f0 - ref0) / (np.abs(ref0) + 1e-3)).max() < 1e-4
+    r, m = rigid.copy(), mem.copy()
+    nz = _noise_block(O, types, tid, n, seed, 2, sub) if seed else None
+    ext = np.zeros((n, 3)); ext[:, 2] = f32(f0)
+    assert O.step(r, m, tgt, sub, DT, dtc, noise=nz, type_id=tid, ext_force=ext) == 0
+    assert_step_parity(f"sweep mixed v4 binning[{n_types},{sub},{seed}]", types, tid, rigid, mem, tgt, off[0], off[1], r, m, DT, dtc, sub)
+    # the grid the step kernel filled: the force from it == brute force over the device's new positions
+    ref1 = O.downwash(off[0], off[0][:, 0:3], type_id=tid)
+    assert (np.abs(off[2] - ref1) / (np.abs(ref1) + 1e-3)).max() < 1e-4
+    assert (ref1 < 0).sum() > n // 4
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+def test_every_instance_of_the_two_call_adaptor_and_general_kernels(gpu, seed):
+    """What the sweeps above leave: the streaming instances of k_physics_fast / k_control_fast, and the general and
+    adaptor kernels on a fleet of TWO QUAD types (per-lane types with four actuators: <.., UNIFORM = false, 4>), with
+    and without the plane.  Streaming on/off bitwise; each against the oracle."""
+    import dataclasses
+    nat, fleet = gpu
+    rb = params.builtin_type("robobee")
+    rb2 = dataclasses.replace(rb, name="rb2", kp_pos=1.3, mass=0.8)
+    te = params.builtin_type("tello")
+    dtc = float(np.float32(2 / 240))
+
+    def run(types, tid, n, fn, layout="tile64", near_ground=False):
+        rigid, mem, tgt = random_fleet(np.random.default_rng(n + seed), n, n_act=4, tilt=0.3, rate=1.0)
+        if near_ground:
+            rigid[:, 2] = f32(np.array([types[0 if tid is None else int(k)].rest_height for k in (tid if tid is not None else np.zeros(n))])
+                              + np.random.default_rng(3).uniform(-1e-3, 0.04, n))
+            rigid[:, 9] = -np.abs(rigid[:, 9])
+        mem[:, 11:13] = 0.0
+        out = {}
+        for pol in (nat.OPT_STREAM_ON, nat.OPT_STREAM_OFF):
+            ctx = fleet.Context(types)
+            st, tg = fleet.FleetState(ctx, n, layout), fleet.Targets(ctx, n, layout)
+            st.load_aos(rigid, mem)
+            tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
+            tdev = None
+            if tid is not None:
+                tdev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device); tdev[:n] = torch.from_numpy(tid)
+            out[pol] = fn(ctx, st, tg, tdev, pol)
+            ctx.close()
+        for x, y in zip(out[nat.OPT_STREAM_ON], out[nat.OPT_STREAM_OFF]):
+            np.testing.assert_array_equal(x, y)
+        return rigid, mem, tgt, out[nat.OPT_STREAM_OFF]
+
+    O1 = orc.Oracle([rb])
+    n = 512
+    act = f32(np.random.default_rng(9).uniform(0.3, 0.7, (n, 4)))
+
+    # ---- k_physics_fast<NOISE, NT, OBS> and k_control_fast<NT, WANT_YAW> (homogeneous quads, whole tiles)
+    for with_obs in (False, True):
+        def phys(ctx, st, tg, tdev, pol):
+            adev = torch.zeros((4, st.n_pad), device=ctx.device); adev[:, :n] = torch.from_numpy(np.ascontiguousarray(act.T)).float()
+            echo = torch.zeros((4, st.n_pad), device=ctx.device)
+            obs = torch.zeros((n, 20), device=ctx.device)
+            a = _args(nat, 2, DT, dtc, options=pol, seed=seed, step_index=1, action=adev)
+            if with_obs:
+                a.obs_out, a.obs_width = obs.data_ptr(), 20
+            nat.check(ctx.lib.dsim_physics(ctx.handle, _stream(ctx), n, st.view(), echo.data_ptr(), ctypes.byref(a)))
+            return st.rigid_aos(), echo.cpu().numpy(), obs.cpu().numpy()
+        rigid, mem, tgt, (gr, ge, go) = run([rb], None, n, phys)
+        r = rigid.copy()
+        a6 = np.zeros((n, 6)); a6[:, :4] = act
+        O1.physics(r, mem, 2, DT, action=a6, noise=_noise_block(O1, [rb], None, n, seed, 1, 2) if seed else None)
+        assert_step_parity(f"sweep physics_fast[{with_obs},{seed}]", [rb], None, rigid, mem, tgt, gr, None, r, None, DT, dtc, 2,
+                           control=False, action=act)
+        np.testing.assert_array_equal(ge[:, :n].T, act)
+        if with_obs:
+            np.testing.assert_array_equal(go[:, 0:7], gr[:, 0:7].astype(np.float32))
+    for want_yaw in (False, True):
+        def ctrl(ctx, st, tg, tdev, pol):
+            pe = torch.zeros((3, st.n_pad), device=ctx.device); ye = torch.zeros((st.n_pad,), device=ctx.device)
+            cmd = torch.zeros((4, st.n_pad), device=ctx.device)
+            a = _args(nat, 0, dtc, dtc, options=pol)
+            nat.check(ctx.lib.dsim_control2(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a), pe.data_ptr(),
+                                            ye.data_ptr() if want_yaw else None, cmd.data_ptr()))
+            return st.mem_aos(), pe.cpu().numpy(), cmd.cpu().numpy()
+        rigid, mem, tgt, (gm, gpe, gcmd) = run([rb], None, n, ctrl)
+        m = mem.copy()
+        rc, pe, ye = O1.control(rigid, m, tgt, dtc)
+        assert rc == 0
+        assert_control_parity(f"sweep control_fast[{want_yaw}]", [rb], None, rigid, mem, tgt, gm, m, dtc)
+        np.testing.assert_array_equal(gcmd[:, :n].T, gm[:, 7:11].astype(np.float32))
+
+    # ---- two quad types, per-lane: general step (explicit action), lean step (DSIM_OPT_GENERIC_MIXED), Env.step, control,
+    # the adaptors — and the same over the plane
+    types = [rb, te]
+    n2 = 600
+    tid = (np.arange(n2) % 2).astype(np.uint8)
+    O2 = orc.Oracle(types)
+    act2 = f32(np.random.default_rng(8).uniform(0.3, 0.7, (n2, 4)))
+    from tests.util import plane_terms
+    for plane in (0, nat.OPT_PLANE):
+        kw = {}
+        if plane:
+            kw = dict(near_ground=True)
+        k_bar = K_ULP * 2 * (1 + PLANE_SWEEPS) if plane else None
+
+        def step_action(ctx, st, tg, tdev, pol):
+            adev = torch.zeros((4, st.n_pad), device=ctx.device); adev[:, :n2] = torch.from_numpy(np.ascontiguousarray(act2.T)).float()
+            a = _args(nat, 2, DT, dtc, options=pol | plane, seed=seed, step_index=1, type_id=tdev, action=adev)
+            nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n2, st.view(), tg.view(), ctypes.byref(a)))
+            return st.rigid_aos(), st.mem_aos()
+        rigid, mem, tgt, (gr, gm) = run(types, tid, n2, step_action, **kw)
+        r, m = rigid.copy(), mem.copy()
+        a6 = np.zeros((n2, 6)); a6[:, :4] = act2
+        nz = _noise_block(O2, types, tid, n2, seed, 1, 2) if seed else None
+        assert O2.step(r, m, tgt, 2, DT, dtc, noise=nz, type_id=tid, action=a6, options=plane) == 0
+        assert_step_parity(f"sweep gen two quads[{plane},{seed}]", types, tid, rigid, mem, tgt, gr, gm, r, m, DT, dtc, 2, action=act2,
+                           k=k_bar, extra_terms=plane_terms(types, tid, rigid, dtc) if plane else None)
+
+        def phys2(ctx, st, tg, tdev, pol):
+            adev = torch.zeros((4, st.n_pad), device=ctx.device); adev[:, :n2] = torch.from_numpy(np.ascontiguousarray(act2.T)).float()
+            echo = torch.zeros((4, st.n_pad), device=ctx.device)
+            a = _args(nat, 2, DT, dtc, options=pol | plane, seed=seed, step_index=1, type_id=tdev, action=adev)
+            nat.check(ctx.lib.dsim_physics(ctx.handle, _stream(ctx), n2, st.view(), echo.data_ptr(), ctypes.byref(a)))
+            return (st.rigid_aos(),)
+        rigid, mem, tgt, (gr,) = run(types, tid, n2, phys2, **kw)
+        r = rigid.copy()
+        O2.physics(r, mem, 2, DT, action=a6, noise=nz, type_id=tid, options=plane)
+        assert_step_parity(f"sweep physics two quads[{plane},{seed}]", types, tid, rigid, mem, tgt, gr, None, r, None, DT, dtc, 2,
+                           control=False, action=act2, k=k_bar, extra_terms=plane_terms(types, tid, rigid, dtc) if plane else None)
+
+        for mode, mname in ((nat.ADAPT_VELOCITY, "velocity"), (nat.ADAPT_RPYT, "rpyt")):
+            av = f32(np.concatenate([np.random.default_rng(6).uniform(-1, 1, (n2, 3)), np.full((n2, 1), 0.25)], 1))
+
+            def adapt(ctx, st, tg, tdev, pol):
+                adev = torch.zeros((4, st.n_pad), device=ctx.device); adev[:, :n2] = torch.from_numpy(np.ascontiguousarray(av.T)).float()
+                echo = torch.zeros((4, st.n_pad), device=ctx.device)
+                a = _args(nat, 2, DT, dtc, options=pol | plane, seed=seed, step_index=1, type_id=tdev)
+                nat.check(ctx.lib.dsim_step_adaptor(ctx.handle, _stream(ctx), n2, st.view(), adev.data_ptr(), mode, echo.data_ptr(),
+                                                    ctypes.byref(a)))
+                return st.rigid_aos(), st.mem_aos()
+            rigid, mem, tgt, (gr, gm) = run(types, tid, n2, adapt, **kw)
+            # the law (on the state before the physics), then the physics with the command the DEVICE computed
+            rc0, m = rigid.copy(), mem.copy()
+            assert O2.adaptor_step(0 if mode == nat.ADAPT_VELOCITY else 1, rc0, m, av, 0, DT, dtc, type_id=tid) == 0
+            r = rigid.copy()
+            c6 = np.zeros((n2, 6)); c6[:, :4] = gm[:, 7:11]
+            O2.physics(r, gm.copy(), 2, DT, action=c6, noise=nz, type_id=tid, options=plane)
+            assert_step_parity(f"sweep adaptor two quads[{mname},{plane},{seed}]", types, tid, rigid, gm, tgt, gr, None, r, None, DT, dtc, 2,
+                               control=False, action=gm[:, 7:11], k=k_bar,
+                               extra_terms=plane_terms(types, tid, rigid, dtc) if plane else None)
+            assert np.abs(gm[:, 7:11] - m[:, 7:11]).max() < 1e-3
+
+    def lean(ctx, st, tg, tdev, pol):
+        a = _args(nat, 2, DT, dtc, options=pol | nat.OPT_GENERIC_MIXED, seed=seed, step_index=1, type_id=tdev)
+        nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n2, st.view(), tg.view(), ctypes.byref(a)))
+        return st.rigid_aos(), st.mem_aos()
+    rigid, mem, tgt, (gr, gm) = run(types, tid, n2, lean)
+    r, m = rigid.copy(), mem.copy()
+    assert O2.step(r, m, tgt, 2, DT, dtc, noise=_noise_block(O2, types, tid, n2, seed, 1, 2) if seed else None, type_id=tid) == 0
+    assert_step_parity(f"sweep lean two quads[{seed}]", types, tid, rigid, mem, tgt, gr, gm, r, m, DT, dtc, 2)
+
+    def ctrl2(ctx, st, tg, tdev, pol):
+        pe = torch.zeros((3, st.n_pad), device=ctx.device); ye = torch.zeros((st.n_pad,), device=ctx.device)
+        a = _args(nat, 0, dtc, dtc, options=pol, type_id=tdev)
+        nat.check(ctx.lib.dsim_control(ctx.handle, _stream(ctx), n2, st.view(), tg.view(), ctypes.byref(a), pe.data_ptr(), ye.data_ptr()))
+        return (st.mem_aos(),)
+    rigid, mem, tgt, (gm,) = run(types, tid, n2, ctrl2)
+    m = mem.copy()
+    assert O2.control(rigid, m, tgt, dtc, type_id=tid)[0] == 0
+    assert_control_parity("sweep control two quads", types, tid, rigid, mem, tgt, gm, m, dtc)
