@@ -2531,7 +2531,7 @@ def _noise_block(O, types, tid, n, seed, step_index, sub):
     return nz
 
 
-def _sweep_case(gpu, label, types, tid, n, sub, seed, options, action=None, n_steps=1, runs=None, layout="tile64"):
+def _sweep_case(gpu, label, types, tid, n, sub, seed, options, action=None, n_steps=1, runs=None, layout="tile64", pad=256):
     nat, fleet = gpu
     na = max(t.n_act for t in types)
     rigid, mem, tgt = random_fleet(np.random.default_rng(n + sub + seed), n, n_act=na, tilt=0.3, rate=1.0)
@@ -2553,7 +2553,7 @@ def _sweep_case(gpu, label, types, tid, n, sub, seed, options, action=None, n_st
     got = {}
     for pol in (nat.OPT_STREAM_ON, nat.OPT_STREAM_OFF):
         ctx = fleet.Context(types)
-        st, tg = fleet.FleetState(ctx, n, layout), fleet.Targets(ctx, n, layout)
+        st, tg = fleet.FleetState(ctx, n, layout, pad), fleet.Targets(ctx, n, layout, pad=pad)
         st.load_aos(rigid, mem)
         tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
         tdev = None
@@ -2848,3 +2848,57 @@ def test_every_instance_of_the_two_call_adaptor_and_general_kernels(gpu, seed):
     m = mem.copy()
     assert O2.control(rigid, m, tgt, dtc, type_id=tid)[0] == 0
     assert_control_parity("sweep control two quads", types, tid, rigid, mem, tgt, gm, m, dtc)
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+def test_every_instance_of_the_tail_kernels(gpu, seed):
+    """Ragged fleets (n_pad not a multiple of 256: the general kernels serve the tail, or everything below one tile) of
+    one type and of quads + hexas, plain and with an explicit action, and computeControl on them."""
+    nat, fleet = gpu
+    rb, hx = params.builtin_type("robobee"), params.builtin_type("hexa_6DOF")
+    n = 300                                                       # n_pad = 320: one whole tile + a 64-drone tail
+    act4 = f32(np.random.default_rng(1).uniform(0.3, 0.7, (n, 4)))
+    act6 = f32(np.random.default_rng(2).uniform(0.3, 0.7, (n, 6)))
+    tid = (np.arange(n) % 2).astype(np.uint8)
+    for layout in ("soa", "tile64"):
+        _sweep_case(gpu, f"sweep tail quad[{seed}]", [rb], None, n, 2, seed, 0, layout=layout, pad=64)
+        _sweep_case(gpu, f"sweep tail quad action[{seed}]", [rb], None, n, 2, seed, 0, action=act4, n_steps=2, layout=layout, pad=64)
+        _sweep_case(gpu, f"sweep tail hexa[{seed}]", [hx], None, n, 2, seed, 0, layout=layout, pad=64)
+        _sweep_case(gpu, f"sweep tail hexa action[{seed}]", [hx], None, n, 2, seed, 0, action=act6, layout=layout, pad=64)
+        _sweep_case(gpu, f"sweep generic mixed[{seed}]", [rb, hx], tid, n, 2, seed, nat.OPT_GENERIC_MIXED, layout=layout, pad=64)
+        _sweep_case(gpu, f"sweep mixed action[{seed}]", [rb, hx], tid, n, 2, seed, 0, action=act6, layout=layout, pad=64)
+    if seed:
+        return
+    # Env.step over the plane on the mixed fleet, no noise; computeControl on the ragged quad fleet
+    from tests.util import plane_terms
+    types = [rb, hx]
+    rigid, mem, tgt = random_fleet(np.random.default_rng(4), n, n_act=6, tilt=0.3)
+    rigid[:, 2] = f32(np.where(tid == 0, rb.rest_height, hx.rest_height) + np.random.default_rng(5).uniform(-1e-3, 0.04, n))
+    mem[tid == 0, 11:13] = 0.0
+    dtc = float(np.float32(2 / 240))
+    ctx = fleet.Context(types)
+    st = fleet.FleetState(ctx, n, "soa", 64)
+    st.load_aos(rigid, mem)
+    tdev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device); tdev[:n] = torch.from_numpy(tid)
+    adev = torch.zeros((6, st.n_pad), device=ctx.device); adev[:, :n] = torch.from_numpy(np.ascontiguousarray(act6.T)).float()
+    echo = torch.zeros((6, st.n_pad), device=ctx.device)
+    a = _args(nat, 2, DT, dtc, options=nat.OPT_PLANE, type_id=tdev, action=adev)
+    nat.check(ctx.lib.dsim_physics(ctx.handle, _stream(ctx), n, st.view(), echo.data_ptr(), ctypes.byref(a)))
+    r = rigid.copy()
+    a6 = act6.astype(np.float64).copy(); a6[tid == 0, 4:] = 0.0
+    orc.Oracle(types).physics(r, mem, 2, DT, action=a6, type_id=tid, options=nat.OPT_PLANE)
+    assert_step_parity("sweep physics plane mixed", types, tid, rigid, mem, tgt, st.rigid_aos(), None, r, None, DT, dtc, 2, control=False,
+                       action=a6, k=K_ULP * 2 * (1 + PLANE_SWEEPS), extra_terms=plane_terms(types, tid, rigid, dtc))
+    ctx.close()
+    rigid, mem, tgt = random_fleet(np.random.default_rng(6), n, tilt=0.4)
+    ctx = fleet.Context([rb])
+    st, tg = fleet.FleetState(ctx, n, "soa", 64), fleet.Targets(ctx, n, "soa", pad=64)
+    st.load_aos(rigid, mem)
+    tg.set_fields(0, torch.from_numpy(np.ascontiguousarray(tgt.T)))
+    pe = torch.zeros((3, st.n_pad), device=ctx.device); ye = torch.zeros((st.n_pad,), device=ctx.device)
+    a = _args(nat, 0, dtc, dtc)
+    nat.check(ctx.lib.dsim_control(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a), pe.data_ptr(), ye.data_ptr()))
+    m = mem.copy()
+    assert orc.Oracle([rb]).control(rigid, m, tgt, dtc)[0] == 0
+    assert_control_parity("sweep control ragged quad", [rb], None, rigid, mem, tgt, st.mem_aos(), m, dtc)
+    ctx.close()
