@@ -1859,8 +1859,15 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
       return;
     }
   }
-  for (int r0 = 0; r0 < cnt_c; r0 += RPB) {
-    const int r = r0 + r_in;
+  // A pass serves TPB / 8 receivers with 8 lanes each; when fewer are left (a cell's last pass is half empty on
+  // average) the lane groups are widened — 16, 32 or 64 lanes per receiver — so that the candidates are split over all
+  // lanes instead of over those of the receivers that exist.
+  for (int r0 = 0; r0 < cnt_c;) {
+    const int rem = cnt_c - r0;
+    int sh = 0;
+    while (sh < 3 && (RPB >> (sh + 1)) >= rem) ++sh;
+    const int lpb = DW_LPB << sh;
+    const int sub_p = (int)t & (lpb - 1), r = r0 + ((int)t >> (3 + sh));
     bool have = r < cnt_c;
     float4 me = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     long long i = -1;
@@ -1868,7 +1875,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
     float fz = 0.0f;
     int ty = 0;
     if (have) {          // the receiver, straight from its bucket, and its type id: in flight beside the fill
-      me = r0 == 0 ? me_first : b.buckets[(long long)c * DW_CAP + r];
+      me = (r0 == 0 && sh == 0) ? me_first : b.buckets[(long long)c * DW_CAP + r];
       i = (long long)__float_as_int(me.w) - a.local_offset;
       if (i < 0 || i >= a.n) have = false;                                             // another rank's drone: a candidate only
     }
@@ -1889,9 +1896,9 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
       if (have) {
         K = coef[ty][0]; d1 = coef[ty][1]; d2c = coef[ty][2];                          // (LDS: written before the first barrier)
         const int lim = min(tile_cap, total - base);
-        int e = sub;
-        for (; e + DW_LPB < lim; e += 2 * DW_LPB) {                                    // two candidates in flight per lane
-          const float4 p0 = tile[e], p1 = tile[e + DW_LPB];
+        int e = sub_p;
+        for (; e + lpb < lim; e += 2 * lpb) {                                          // two candidates in flight per lane
+          const float4 p0 = tile[e], p1 = tile[e + lpb];
           fz += dw_pair(p0, me.x, me.y, me.z, 1.0f, d1, d2c);
           fz += dw_pair(p1, me.x, me.y, me.z, 1.0f, d1, d2c);
         }
@@ -1899,10 +1906,10 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
       }
     }
     if (have)
-      for (int k = sub; k < n_ovf; k += DW_LPB) fz += dw_pair(b.overflow[k], me.x, me.y, me.z, 1.0f, d1, d2c);
-#pragma unroll
-    for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
-    if (have && sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = K * fz; }
+      for (int k = sub_p; k < n_ovf; k += lpb) fz += dw_pair(b.overflow[k], me.x, me.y, me.z, 1.0f, d1, d2c);
+    for (int off = lpb / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
+    if (have && sub_p == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = K * fz; }
+    r0 += RPB >> sh;
   }
 }
 
