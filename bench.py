@@ -472,6 +472,10 @@ def main(argv=None):
                     # the same fleet in type-major storage: one single-type launch per type
                     "mixed_quad_hexa_4194304_type_major": (4096, 1024, 1, False, 1)}.items():
                 also[name] = measure_variant(torch, local, a.layout, a.noise_seed, a.steps, name, *spec, options=options)
+                if name.startswith("config5"):
+                    also[name]["note"] = ("a chain of three dependent launches on a 65 536-drone shard (neighbour query, step + grid "
+                                          "binning, WLS fallback): bound by the vector pipe of the query (profiles/r02_c5*_summary.json) "
+                                          "and by launch latency, not by HBM — hbm_frac is reported for completeness")
                 if name.startswith("hexa"):
                     also[name]["note"] = ("248 B is the budgeted figure (SURVEY 8d); the 6-DOF law never reads the target "
                                           "acceleration and yaw, measured HBM traffic is 232 B per drone-step")
