@@ -122,7 +122,8 @@ def test_plane_contact_model_against_the_recorded_touchdown():
         O.physics(rigid, mem, int(g["aggr"]), DT, action=a6, options=PLANE)
         tgt = np.array([[0, 0, 0.5, 0, 0, 0, 0, 0, 0, g["target_yaw"][k]]])
         assert O.control(rigid, mem, tgt, dtc)[0] == 0
-        zs.append(rigid[0, 2]); touching.append(rigid[0, 2] < t.rest_height + 5e-3)
+        # (getContactPoints lists points inside Bullet's contact breaking threshold, 0.02 m, not only touching ones)
+        zs.append(rigid[0, 2]); touching.append(rigid[0, 2] < t.rest_height + 0.02)
     zs, touching = np.array(zs), np.array(touching)
     assert abs(zs.min() - rest_rec) < 5e-3
     if touching.any() and leave_rec < n_rec:
