@@ -257,9 +257,7 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
           nz[4 + j] = a.noise_replay[((long long)k * 2 * NROW + NROW + j) * a.n_pad + i];
         }
       } else {
-        noise_normals<4>(a.seed, (uint64_t)i, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { nz[j] *= 0.01f; nz[4 + j] *= 0.001f; }   // BaseAviary.py:1518-1521
+        noise_normals<4>(a.seed, (uint64_t)i, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);   // N(0,.01) | N(0,.001)
       }
       quad_wrench(T, cmd, nz, F, tau);
     }
@@ -300,9 +298,7 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
 #pragma unroll
         for (int j = 0; j < 12; ++j) nz[j] = a.noise_replay[((long long)k * 12 + j) * a.n_pad + i];
       } else {
-        noise_normals<6>(a.seed, (uint64_t)i, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) { nz[j] *= 0.01f; nz[6 + j] *= 0.001f; }   // BaseAviary.py:1429-1430
+        noise_normals<6>(a.seed, (uint64_t)i, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);   // N(0,.01) | N(0,.001)
       }
       hexa_wrench(T, cmd, nz, F, tau);
     }

@@ -166,18 +166,24 @@ __device__ __forceinline__ void threefry4x32_12(uint32_t x[4], uint32_t k0, uint
     }
   }
 }
-// One 32-bit word -> two unit normals (Box-Muller): radius from the high 16 bits
+// One 32-bit word -> two normals of standard deviation SIGMA (Box-Muller): radius from the high 16 bits
 // (u1 = (h+1)/65536 in (0,1], so |n| <= sqrt(2 ln 65536) = 4.71 sigma), angle from the low 16.
-// The hardware transcendentals take the angle in revolutions and log in base 2.
+// The hardware transcendentals take the angle in revolutions and log in base 2; the deviation is folded into the
+// radius: sigma sqrt(-2 ln u1) = sqrt(-sigma^2 2 ln2 log2(u1)) — no multiplication of the normals afterwards (8
+// instructions per sub-step less than scaling unit normals).  (u1 keeps its own 1/65536: folded in as
+// 16 - log2(h + 1) the subtraction costs the small normals a decimal digit, measured at 1.8 x the step's bar.)
+template <int SIGMA_E3>      // the deviation in thousandths: 10 = rotor force noise, 1 = rotor moment noise, 1000 = unit
 __device__ __forceinline__ void box_muller16(uint32_t w, float& n0, float& n1) {
+  constexpr float S2 = (SIGMA_E3 * 1e-3f) * (SIGMA_E3 * 1e-3f) * 1.38629436111989061883f;     // sigma^2 2 ln2
   const float u1 = (float)((w >> 16) + 1u) * (1.0f / 65536.0f);
   const float u2 = (float)(w & 0xFFFFu) * (1.0f / 65536.0f);
-  const float r = DSIM_SQRT(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));   // -2 ln2 log2(u1)
+  const float r = DSIM_SQRT(-S2 * __builtin_amdgcn_logf(u1));
   n0 = r * __builtin_amdgcn_cosf(u2);
   n1 = r * __builtin_amdgcn_sinf(u2);
 }
 // unit normals for (drone, sub-step counter): out[0..n_act) force noise, out[n_act..2 n_act) moment
 // noise.  One Threefry4x32-12 block yields 8 normals (a quad's whole sub-step), a hexa needs two.
+// out[0 .. NACT): force noise ~ N(0, 0.01), out[NACT .. 2 NACT): moment noise ~ N(0, 0.001)   (BaseAviary.py:1518-1521, 1429-1430)
 template <int NACT>
 __device__ __forceinline__ void noise_normals(uint64_t seed, uint64_t drone, uint64_t sub, float* out) {
   constexpr int NSTREAM = (2 * NACT + 7) / 8;
@@ -188,7 +194,10 @@ __device__ __forceinline__ void noise_normals(uint64_t seed, uint64_t drone, uin
     threefry4x32_12(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     float n[8];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) box_muller16(c[w], n[2 * w], n[2 * w + 1]);
+    for (int w = 0; w < 4; ++w) {            // (NACT is even: a pair never straddles the force / moment boundary)
+      if (8 * s + 2 * w < NACT) box_muller16<10>(c[w], n[2 * w], n[2 * w + 1]);
+      else box_muller16<1>(c[w], n[2 * w], n[2 * w + 1]);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (8 * s + j < 2 * NACT) out[8 * s + j] = n[j];
@@ -202,9 +211,9 @@ struct Rigid { V3 pos; Q4 q; V3 vel; V3 w; };                 // w: WORLD-frame 
 template <int NACT> struct CtrlMem { V3 last_vel; V3 last_rates; float last_thrust; float cmd[NACT]; };
 struct Target { V3 pos, vel, acc; float yaw; };
 
-// Ground-plane watch.  The reference loads plane.urdf with collisions on (BaseAviary.py:680); plane contact is not
-// modelled here, so an Env.step that ends with the vehicle's collision cylinder at or below z = 0 is
-// COUNTED: one atomic per wave that holds such a drone, on one of 64 counter shards (dsim_query sums them).
+// Ground-plane watch.  The reference loads plane.urdf with collisions on (BaseAviary.py:680); the flight kernels do not
+// model the plane (DSIM_OPT_PLANE does, in its own kernel instances), so an Env.step that ends with the vehicle's
+// collision cylinder at or below z = 0 is COUNTED: one atomic per wave that holds such a drone, on one of 64 counter shards (dsim_query sums them).
 #define DSIM_GROUND_SHARDS 64
 __device__ __forceinline__ void ground_watch(const DevType& T, const Rigid& s, unsigned long long* counters, bool live = true) {
   const float r22 = 1.0f - 2.0f * (s.q.x * s.q.x + s.q.y * s.q.y);                     // body z . world z (unit q)
