@@ -43,7 +43,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBPS = 6290.0    # MI355X_MICROARCH.md: the float4-copy rate that guide measured (what a kernel can reach)
 BYTES_PER_DRONE_STEP = 232      # read 13+11+10 floats, write 13+11 floats (quad, per-drone targets)
 MIN_TIMED_S = 0.05              # the timed region is repeated (whole K-step regions) until it covers this much
 WORKLOADS = ["config2x1024", "config2", "config3", "config4", "config5", "hexa", "mixed", "mixed_type_major", "two_call_loop"]
@@ -141,7 +142,8 @@ class Fleet:
         self.env = CtrlAviary(models, self.n, initial_xyzs=xyz, aggregate_phy_steps=substeps, physics=physics,
                               device=device, layout=layout, noise_seed=noise_seed, dict_io=False, dist=dist,
                               chained=chained, downwash_exchange=os.environ.get("DSIM_DW_EXCHANGE", "halo"),
-                              type_ids=type_ids, options=options)
+                              type_ids=type_ids, options=options, storage=os.environ.get("DSIM_STORAGE", "auto"),
+                              downwash_split=os.environ.get("DSIM_DW_SPLIT", "1") != "0")
         if waypoints:
             self.tgt = WaypointTargets(self.env.ctx, self.n, g["target_pos"], g["target_vel"], g["target_acc"],
                                        g["target_yaw"], wp_counters=wp0, offsets=off)
@@ -163,9 +165,10 @@ class Fleet:
         """step() = one iteration of the reference's example loop (examples/fly_INDI.py:223-239) through the two
         reference-shaped surfaces: Env.step(action) -> obs, then computeControlFromState -> action."""
         from dronesim_amd.control import INDIControl
+        from dronesim_amd.fleet import frozen
         torch = self.torch
         ctrl = INDIControl("robobee", env=self.env)
-        tpos = self.tgt.fields(0, 3).contiguous()
+        tpos = frozen(self.tgt.fields(0, 3).contiguous())      # the same hover target every iteration: copied once
         state = {"cmd": torch.full((self.n, 4), 0.4, device=self.env.ctx.device)}
         yaw = np.array([0, 0, 0.4])
 
@@ -196,27 +199,29 @@ class Fleet:
         gc.disable()
         wall_sum = dev_sum = 0.0
         regions, want = 0, 1
-        while regions < want:
-            if barrier:
-                barrier()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t0 = time.perf_counter()
-            e0.record()                      # on torch's current stream == the stream the kernel is launched on
-            for _ in range(steps):
-                self.step()
-            e1.record()
-            if barrier:
-                barrier()
-            torch.cuda.synchronize()
-            wall = time.perf_counter() - t0
-            wall_sum += wall
-            dev_sum += e0.elapsed_time(e1) * 1e-3
-            regions += 1
-            if regions == 1 and min_s > 0.0:
-                want = repeat_rule(wall) if repeat_rule else max(1, int(np.ceil(min_s / max(wall, 1e-9))))
-        if gc_was_on:
-            gc.enable()
+        try:
+            while regions < want:
+                if barrier:
+                    barrier()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                e0.record()                      # on torch's current stream == the stream the kernel is launched on
+                for _ in range(steps):
+                    self.step()
+                e1.record()
+                if barrier:
+                    barrier()
+                torch.cuda.synchronize()
+                wall = time.perf_counter() - t0
+                wall_sum += wall
+                dev_sum += e0.elapsed_time(e1) * 1e-3
+                regions += 1
+                if regions == 1 and min_s > 0.0:
+                    want = repeat_rule(wall) if repeat_rule else max(1, int(np.ceil(min_s / max(wall, 1e-9))))
+        finally:
+            if gc_was_on:
+                gc.enable()
         return wall_sum, dev_sum, regions
 
 
@@ -270,6 +275,59 @@ def cpu_baseline(substeps, seconds=4.0):
         "reference_python_note": "reference INDIControl.computeControl alone: 8.2e3 calls/s/core (SURVEY.md 6, survey "
                                  "container); PyBullet Env.step not measurable (engine absent)",
     }
+
+
+def memory_yardstick(n_drones):
+    """tools/membench --json as a child process (built by __graft_entry__.build()): {} when it cannot run."""
+    exe = os.path.join(ROOT, "tools", "membench")
+    try:
+        out = subprocess.run([exe, "--json", str(int(n_drones))], capture_output=True, text=True, timeout=120)
+        d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        return {"device_copy_GBps": d["float4_copy_GBps"], "access_shape_floor_us": d["access_shape_floor_us"],
+                "access_shape_GBps": d["access_shape_GBps"], "yardstick_source": "tools/membench.hip (float4 copy; the "
+                "headline kernel's 58 dword accesses per lane, wave-tiled layout, streaming, no arithmetic)"}
+    except Exception as e:      # a missing probe must not cost the headline
+        return {"device_copy_GBps": None, "yardstick_error": repr(e)[:200]}
+
+
+def gather_ranks(dist, red_dev, values):
+    """[world][len(values)] of every rank's numbers (a small all-gather; world 1: the values themselves)."""
+    import torch
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=red_dev)
+    if dist is None:
+        return [t.tolist()]
+    out = torch.zeros((dist.get_world_size(), len(values)), dtype=torch.float64, device=red_dev)
+    dist.all_gather_into_tensor(out, t.reshape(1, -1))
+    return out.tolist()
+
+
+def exchange_report(fl, dist, red_dev, steps=20):
+    """config 5 on several ranks: what one step's exchange moves, and how long its side-stream part (select + pack,
+    send/recv, halo binning) takes — timed with events on the side stream over `steps` extra steps after the timed regions."""
+    import torch
+    dwn = fl.env._downwash
+    hp = dwn.halo if dwn is not None else None
+    if hp is None:
+        n_world = fl.n * (dist.get_world_size() if dist else 1)
+        return {"form": "allgather", "bytes_per_step_max": 12 * n_world, "sent_per_step_max": fl.n}
+    hp.timing = []
+    for _ in range(steps):
+        fl.step()
+    torch.cuda.synchronize()
+    us = [a.elapsed_time(b) * 1e3 for a, b in hp.timing]
+    hp.timing = None
+    msg_bytes = sum(4 * (8 + 3 * hp.send_cap[p]) for p in hp.messages())
+    rows = gather_ranks(dist, red_dev, [hp.sent_per_step, hp.recv_per_step, float(np.mean(us)) if us else 0.0,
+                                        hp.overflow(), msg_bytes, len(hp.messages())])
+    sent = [int(r[0]) for r in rows]
+    return {"form": "halo", "split_phase_query": bool(dwn.split), "resize_every_steps": hp.resize_every,
+            "selection_margin_m": hp.step_reach - hp.cutoff,
+            "sent_per_step_max": max(sent), "sent_per_step_min": min(sent), "bytes_per_step_max": 12 * max(sent),
+            "message_bytes_per_step_max": int(max(r[4] for r in rows)), "peers_max": int(max(r[5] for r in rows)),
+            "recv_per_step_max": int(max(r[1] for r in rows)),
+            "side_stream_us_max": max(r[2] for r in rows), "side_stream_us_min": min(r[2] for r in rows),
+            "side_stream_note": "select + pack, grouped send/recv, halo binning on the side stream, beside the local pass of the query",
+            "overflow": int(sum(r[3] for r in rows))}
 
 
 WORKLOAD_TEXT = {
@@ -384,8 +442,8 @@ def main(argv=None):
         w, _ = sharding.reduce_step_times(dist, red_dev, first_wall, 0.0)
         return max(1, int(np.ceil(MIN_TIMED_S / max(w, 1e-9))))
 
-    wall, dev_s, regions = fl.timed(a.steps, a.warmup, barrier, min_s=MIN_TIMED_S, repeat_rule=repeat_rule)
-    wall, dev_s = sharding.reduce_step_times(dist, red_dev, wall, dev_s)  # MAX over ranks
+    wall_local, dev_s_local, regions = fl.timed(a.steps, a.warmup, barrier, min_s=MIN_TIMED_S, repeat_rule=repeat_rule)
+    wall, dev_s = sharding.reduce_step_times(dist, red_dev, wall_local, dev_s_local)  # MAX over ranks
     steps_timed = a.steps * regions
     value = sharding.aggregate_throughput([fl.n] * world, steps_timed, wall)
     launch_s = dev_s / steps_timed
@@ -395,12 +453,18 @@ def main(argv=None):
                  "two_call_loop": 428}.get(a.workload, BYTES_PER_DRONE_STEP)
     mixed_k = ("k_step_lean" if a.generic_mixed else "k_step_mixed" if a.mixed_v1 else "k_step_mixed2" if a.mixed_ring
                else "k_step_mixed3" if (a.mixed_v3 or a.layout != "tile64") else "k_step_mixed4")
+    if fl.env.order is not None:
+        # the interleaved fleet is STORED type-major behind the caller's numbering (fleet.StorageOrder): one single-type
+        # launch per type; + 4 B per drone-step for the caller's index that keys the noise stream
+        mixed_k = "k_step_run x2 (type-major storage behind the caller's interleaved order)"
     kernel = {"config5": f"k_dw_query_cell, {mixed_k} (+ fused grid binning), k_wls_fallback",
               "hexa": "k_step_hexa (+ k_wls_fallback)",
               "mixed": f"{mixed_k} (+ k_wls_fallback)",
               "mixed_type_major": "k_step_run x2 (+ k_wls_fallback)",
               "two_call_loop": "k_physics_fast (observation fused) + k_control_fast"}.get(a.workload, "k_step_fast")
     achieved = fl.n * bytes_per / launch_s / 1e9
+    rank_rows = gather_ranks(dist, red_dev, [dev_s_local / steps_timed * 1e6, wall_local / steps_timed * 1e6])
+    exchange = exchange_report(fl, dist, red_dev) if (a.workload == "config5" and world > 1) else None
 
     if rank == 0:
         traffic, traffic_source = None, None
@@ -422,14 +486,20 @@ def main(argv=None):
                        "drones_per_gpu": fl.n, "phys_substeps": a.substeps, "layout": a.layout,
                        "noise_seed": a.noise_seed, "launches_per_step": 1, "parallelism": f"shard{world}"},
             "dist": dist_info,
+            "ranks": {"launch_us_min": min(r[0] for r in rank_rows), "launch_us_max": max(r[0] for r in rank_rows),
+                      "host_us_per_step_min": min(r[1] for r in rank_rows), "host_us_per_step_max": max(r[1] for r in rank_rows)},
             # drone-steps of the whole run (set-up, warm-up and timed regions) whose collision cylinder reached the ground
-            # plane, which this library does not model: 0 = every step of the workload lies in the modelled domain
+            # plane, which the flight kernels of large fleets do not model (DSIM_OPT_PLANE does, for landing-sized fleets):
+            # 0 = every step of the workload lies in the domain the flight kernels cover
             "ground_contacts": fl.env.ground_contacts(),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": achieved / HBM_PEAK_GBPS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBPS,
+                         "achievable": HBM_ACHIEVABLE_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel, "bytes_per_drone_step": bytes_per,
                          "launch_us": launch_s * 1e6},
         }
+        if exchange is not None:
+            out["exchange"] = exchange
         if world == 1 and not a.no_also:
             # ---- BASELINE.json configs 1-3 at their LITERAL sizes and example settings --------------------------------
             # (fleet, replicas, phys_substeps, waypoint table, Env.steps per launch)
@@ -443,17 +513,10 @@ def main(argv=None):
                 base[name] = measure_variant(torch, local, a.layout, a.noise_seed, a.steps, name, *spec, options=options)
             out["baseline_configs"] = base
             also = {}
-            # yardstick: achievable copy bandwidth on this device (read + write bytes / time)
-            src = torch.empty(1 << 28, dtype=torch.float32, device="cuda"); dst = torch.empty_like(src)
-            for _ in range(3):
-                dst.copy_(src)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                dst.copy_(src)
-            e1.record(); torch.cuda.synchronize()
-            also["device_copy_GBps"] = 2 * src.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-            del src, dst
+            # yardsticks of THIS device, from the repo's own probe (tools/membench.hip, a child process): the float4-copy
+            # rate, and the floor of the headline kernel's access shape — its 58 streaming dword accesses per lane on the
+            # wave-tiled layout with no arithmetic behind them
+            also.update(memory_yardstick(fl.n))
             for name, spec in {
                     "config2_single_fleet_4096_sub5_hipgraph_of_32_launches": (4096, 1, 5, False, 32),
                     "config3_65536_waypoints_sub2_hipgraph_of_32_launches": (65536, 1, 2, True, 32),
@@ -489,27 +552,31 @@ def main(argv=None):
             ctrl = INDIControl("robobee", env=env)
             tpos = torch.from_numpy(np.ascontiguousarray(xyz.T.astype(np.float32))).to(env.ctx.device)
             cmd = torch.full((xyz.shape[0], 4), 0.4, device=env.ctx.device)
+            from dronesim_amd.fleet import frozen
+            tpos = frozen(tpos)                                      # the same hover target every iteration: copied once
             iters, el, el_dev = 0, 0.0, 0.0
             gc.collect()
             gc.disable()
-            for timed_pass in (False, True, True, True):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-                e0.record()
-                for _ in range(100):
-                    obs, _, _, _ = env.step(cmd)
-                    cmd, _, _ = ctrl.computeControlFromState(1 / 240, None, target_pos=tpos, target_rpy=np.array([0, 0, 0.4]))
-                e1.record()
-                torch.cuda.synchronize()
-                if timed_pass:
-                    el += time.perf_counter() - t0
-                    el_dev += e0.elapsed_time(e1) * 1e-3
-                    iters += 100
-            gc.enable()
+            try:
+                for timed_pass in (False, True, True, True):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    e0.record()
+                    for _ in range(100):
+                        obs, _, _, _ = env.step(cmd)
+                        cmd, _, _ = ctrl.computeControlFromState(1 / 240, None, target_pos=tpos, target_rpy=np.array([0, 0, 0.4]))
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if timed_pass:
+                        el += time.perf_counter() - t0
+                        el_dev += e0.elapsed_time(e1) * 1e-3
+                        iters += 100
+            finally:
+                gc.enable()
             also["config2x1024_env_step_then_computeControl"] = {
                 "drone_steps_per_s": xyz.shape[0] * iters / el, "loop_us": el / iters * 1e6, "steps_timed": iters,
                 "loop_us_device": el_dev / iters * 1e6,
-                "bytes_per_drone_step": 428, "hbm_frac": xyz.shape[0] * 428 / (el / iters) / 1e9 / HBM_PEAK_GBPS,
+                "bytes_per_drone_step": 428, "hbm_frac": xyz.shape[0] * 428 / (el_dev / iters) / 1e9 / HBM_PEAK_GBPS,
                 "note": "physics 68 r + 148 w (13 rigid, 4 action | 13 rigid, 4 echo, 20-wide observation row); "
                         "control 136 r + 76 w (13 + 11 + 10 | 11 memory, 4 cmd, 3 pos_e, yaw_e)"}
             env.close(); del env, ctrl

@@ -18,17 +18,22 @@ EXPORTS = (
     "dsim_abi_version", "dsim_strerror", "dsim_create", "dsim_destroy", "dsim_reset", "dsim_step",
     "dsim_physics", "dsim_control", "dsim_control2", "dsim_step_adaptor", "dsim_traj_sample", "dsim_materialize",
     "dsim_counter_add", "dsim_reserve", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash",
-    "dsim_downwash_workspace", "dsim_downwash_prebin_ok", "dsim_adjacency",
+    "dsim_downwash_workspace", "dsim_downwash_prebin_ok", "dsim_adjacency", "dsim_wls_fallback", "dsim_fleet_bounds",
+    "dsim_halo_pack", "dsim_downwash_workspace_halo",
 )
 
-ABI_VERSION = 4
+ABI_VERSION = 5
+MAX_PEERS = 8
+HALO_HDR = 8           # header floats of a halo message (DSIM_HALO_HDR)
+DW_ALL, DW_LOCAL, DW_HALO_BIN, DW_HALO_QUERY = 0, 1, 2, 3
 NF_QUAD, NF_HEXA, NT = 24, 26, 10
 OPT_DRAG, OPT_GROUND, OPT_BCAST_TGT, OPT_CHAINED = 1, 2, 4, 8
 OPT_STREAM_ON, OPT_STREAM_OFF, OPT_GENERIC_MIXED, OPT_MIXED_V1, OPT_MIXED_RING, OPT_MIXED_V3 = 16, 32, 64, 128, 256, 512   # tuning knobs
 TUNING_MASK = OPT_STREAM_ON | OPT_STREAM_OFF | OPT_GENERIC_MIXED | OPT_MIXED_V1 | OPT_MIXED_RING | OPT_MIXED_V3   # (results do not depend on them)
 OPT_PLANE = 1 << 10        # ground-plane contact (product-defined model, oracle/dsim_oracle.c:orc_plane_contact)
+OPT_DEFER_FALLBACK = 1 << 11   # the caller launches dsim_wls_fallback itself (scheduling only)
 ADAPT_VELOCITY, ADAPT_RPYT = 0, 1
-QUERY_WLS_FALLBACKS, QUERY_WLS_FAILURES, QUERY_GROUND_CONTACTS = 0, 1, 2
+QUERY_WLS_FALLBACKS, QUERY_WLS_FAILURES, QUERY_GROUND_CONTACTS, QUERY_HALO_OVERFLOW = 0, 1, 2, 3
 
 
 class View(ctypes.Structure):
@@ -66,6 +71,7 @@ class StepArgs(ctypes.Structure):
         ("obs_width", ctypes.c_int32),
         ("obs_out", ctypes.c_void_p),
         ("bin_next", ctypes.c_void_p),
+        ("drone_id", ctypes.c_void_p),
     ]
 
 
@@ -88,7 +94,22 @@ class DownwashArgs(ctypes.Structure):
         ("type_id", ctypes.c_void_p),
         ("local_offset", ctypes.c_int64),
         ("prebinned", ctypes.c_int32),
-        ("_pad", ctypes.c_int32),
+        ("phase", ctypes.c_int32),
+        ("halo", ctypes.c_void_p),
+    ]
+
+
+class HaloPlan(ctypes.Structure):
+    _fields_ = [
+        ("world", ctypes.c_int32),
+        ("rank", ctypes.c_int32),
+        ("cap", ctypes.c_int64),
+        ("send", ctypes.c_void_p),
+        ("recv", ctypes.c_void_p),
+        ("scratch", ctypes.c_void_p),
+        ("send_cap", ctypes.c_int32 * MAX_PEERS),
+        ("recv_cap", ctypes.c_int32 * MAX_PEERS),
+        ("reach", ctypes.c_float * MAX_PEERS),
     ]
 
 
@@ -138,6 +159,11 @@ def load(path: str = None) -> ctypes.CDLL:
     lib.dsim_downwash_workspace.argtypes = [i64, i32, i32]
     lib.dsim_downwash.argtypes = [vp, vp, i64, View, ctypes.POINTER(DownwashArgs), vp]
     lib.dsim_adjacency.argtypes = [vp, vp, i64, View, ctypes.POINTER(DownwashArgs), ctypes.c_float, vp, vp, i32]
+    lib.dsim_wls_fallback.argtypes = [vp, vp, i64, View, vp, vp]
+    lib.dsim_fleet_bounds.argtypes = [vp, vp, i64, View, vp]
+    lib.dsim_halo_pack.argtypes = [vp, vp, i64, View, ctypes.POINTER(HaloPlan)]
+    lib.dsim_downwash_workspace_halo.restype = ctypes.c_int64
+    lib.dsim_downwash_workspace_halo.argtypes = [i64, i64, i32, i32]
     if lib.dsim_abi_version() != ABI_VERSION:
         raise ImportError(f"libdronesim_amd.so ABI {lib.dsim_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

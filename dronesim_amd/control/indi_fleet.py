@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from .. import _native as nat
-from ..fleet import Context, FleetState, Targets
+from ..fleet import Context, FleetState, Frozen, Targets
 from ..params import DroneType, builtin_type
 
 
@@ -129,7 +129,9 @@ class INDIControl(BaseControl):
             yaw = float(r.reshape(-1)[2]) if r.size == 3 else np.ascontiguousarray(
                 r[..., 2] if r.shape[-1] == 3 else r.reshape(3, -1)[2]).reshape(1, -1)
 
-        def as_target(x):      # a bare 3-vector stays one: Targets.set skips a constant it already holds
+        def as_target(x):      # a bare 3-vector stays one: Targets.set skips a constant it already holds, and a Frozen
+            if isinstance(x, Frozen):      # tensor it has already copied (fleet.frozen)
+                return x
             return x if (not torch.is_tensor(x) and np.size(x) == 3) else _as3(x, n, dev)
         self._targets.set(pos=as_target(target_pos), vel=as_target(target_vel), acc=as_target(target_acc), yaw=yaw)
         a = nat.StepArgs()
@@ -141,4 +143,12 @@ class INDIControl(BaseControl):
         nat.check(self.ctx.lib.dsim_control2(self.ctx.handle, self.ctx.stream_ptr(), n, st.view(),
                                              self._targets.view(), ctypes.byref(a), self._pos_e.data_ptr(),
                                              self._yaw_e.data_ptr(), self._cmd.data_ptr()))
-        return self._cmd[:, :n].T, self._pos_e[:, :n].T, self._yaw_e[:n]
+        order = st.order
+        if order is None:
+            return self._cmd[:, :n].T, self._pos_e[:, :n].T, self._yaw_e[:n]
+        # a fleet stored in another order than the caller's: the triple goes back in the caller's numbering; the env
+        # recognises the command tensor when it comes back as the next action and takes the storage-order array as is
+        cmd = order.to_caller(self._cmd[:, :n], 1).T
+        if self.env is not None:
+            self.env._cmd_token = (cmd, cmd._version, self._cmd)
+        return cmd, order.to_caller(self._pos_e[:, :n], 1).T, order.to_caller(self._yaw_e[:n], 0)

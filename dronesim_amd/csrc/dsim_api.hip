@@ -39,8 +39,15 @@ struct dsim_ctx {
   int dw_mode;                            // 0: counting sort, 1: cell buckets (which layout the count buffers hold)
   int n_cu;                               // compute units of the device
   bool dw_prebin;                         // the count buffer dw_parity holds the local drones, binned by the last dsim_step
+  bool dw_prebin_valid;                   // ... and no call has moved the positions since without re-binning them
   long long dw_prebin_n, dw_prebin_off;
   float dw_prebin_geo[3];
+  int dw_prebin_nx, dw_prebin_ny;
+  long long dw_local_m;                   // overflow capacity of the local grid in the workspace (layout of what follows it)
+  int dwh_parity;                         // halo grid (split-phase downwash): count-buffer parity
+  const int32_t* dwh_ws;                  // ... and the workspace / shape it was zeroed for
+  long long dwh_cells;
+  unsigned* d_bounds;                     // dsim_fleet_bounds: 5 order-preserving keys + a ticket
   dsim_type_params h_types[DSIM_MAX_TYPES];
 };
 
@@ -143,8 +150,9 @@ struct StepK {
   int substeps;
   float dt_phys, dt_ctrl;
   unsigned options;
-  long long last;             // run kernels: one past the last drone of the run
+  long long lo, last;         // run kernels: first drone of the run (the launch starts at the tile that holds it), one past its last
   int run_type;               // run kernels: the run's type
+  const int* drone_id;        // the caller's index of storage slot i (keys the noise counter), or null = i
   unsigned hexa_types;        // bit t set: type t of the table is a morphing hexa (26 state fields in use)
   BinK bin;                   // grid of the next Env.step's downwash (k_step_mixed / k_step_run), count = null: none
 };
@@ -243,7 +251,10 @@ __device__ __forceinline__ int waypoint_next(int wp, int n_wp) { return wp < n_w
 template <int NOISE, int NROW = 4, bool OPTS = false, int NSUB = 0, bool PLANE = false>
 __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[4], unsigned long long step_index,
-                                              V3 ext = V3{0.0f, 0.0f, 0.0f}, const float* prev = nullptr) {
+                                              V3 ext = V3{0.0f, 0.0f, 0.0f}, const float* prev = nullptr, long long nid = -1) {
+  // nid: the drone's index in the caller's numbering when the fleet is stored in another order (StepK.drone_id): the
+  // key of its noise stream.  -1 (a constant at the call sites of the single-order kernels) = i.
+  const uint64_t noise_key = (uint64_t)(nid >= 0 ? nid : i);
   V3 F, tau;
   if (NOISE == 0) quad_wrench(T, cmd, nullptr, F, tau);   // cmd is constant over the sub-steps
   const int n_sub = NSUB > 0 ? NSUB : a.substeps;
@@ -257,7 +268,7 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
           nz[4 + j] = a.noise_replay[((long long)k * 2 * NROW + NROW + j) * a.n_pad + i];
         }
       } else {
-        noise_normals<4>(a.seed, (uint64_t)i, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);   // N(0,.01) | N(0,.001)
+        noise_normals<4>(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);   // N(0,.01) | N(0,.001)
       }
       quad_wrench(T, cmd, nz, F, tau);
     }
@@ -281,7 +292,8 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
 template <bool NOISE, bool REPLAY = true, bool ONE = false, bool PLANE = false>
 __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[6], unsigned long long step_index,
-                                              V3 ext = V3{0.0f, 0.0f, 0.0f}) {
+                                              V3 ext = V3{0.0f, 0.0f, 0.0f}, long long nid = -1) {
+  const uint64_t noise_key = (uint64_t)(nid >= 0 ? nid : i);
   V3 F, tau;
   if (!NOISE) hexa_wrench(T, cmd, nullptr, F, tau);
   // The state holds what PyBullet reports — the BASE link's centre of mass (dsim_type_params.base_offset); the composite
@@ -298,7 +310,7 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
 #pragma unroll
         for (int j = 0; j < 12; ++j) nz[j] = a.noise_replay[((long long)k * 12 + j) * a.n_pad + i];
       } else {
-        noise_normals<6>(a.seed, (uint64_t)i, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);   // N(0,.01) | N(0,.001)
+        noise_normals<6>(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);   // N(0,.01) | N(0,.001)
       }
       hexa_wrench(T, cmd, nz, F, tau);
     }
@@ -309,6 +321,8 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
     s.pos = s.pos + o; s.vel = s.vel + cross(s.w, o);
   }
 }
+
+__device__ __forceinline__ long long noise_id(const StepK& a, long long i) { return a.drone_id ? (long long)a.drone_id[i] : -1LL; }
 
 // ---- fused Env.step + computeControl (the hot path) -----------------------
 // Fast form: homogeneous quad fleet, action = the controller's stored cmd, whole 256-drone tiles
@@ -534,12 +548,13 @@ __device__ __forceinline__ void step_gen_body(const DevType& T, const StepK& a, 
     float yaw_e;
     if (NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA) {     // wave-uniform branch
       if constexpr (NACT == 6) {
-        hexa_substeps<NOISE, FULL, false, PLANE>(T, a, i, s, act, a.step_index + k, ext);
+        hexa_substeps<NOISE, FULL, false, PLANE>(T, a, i, s, act, a.step_index + k, ext, NOISE ? noise_id(a, i) : -1LL);
         ground_watch(T, s, a.fb.counters, i < a.n);
         indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
       }
     } else {
-      quad_substeps<NOISE ? (FULL ? 2 : 1) : 0, NACT, FULL, 0, PLANE>(T, a, i, s, act, a.step_index + k, ext);
+      quad_substeps<NOISE ? (FULL ? 2 : 1) : 0, NACT, FULL, 0, PLANE>(T, a, i, s, act, a.step_index + k, ext, nullptr,
+                                                                      NOISE ? noise_id(a, i) : -1LL);
       ground_watch(T, s, a.fb.counters, i < a.n);
       indi_quad<false, NACT>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
     }
@@ -1119,7 +1134,7 @@ template <bool HEXA, bool NOISE, bool NT, bool S1>
 __global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void k_step_run(StepK a) {
   const long long i0 = a.first + (long long)blockIdx.x * 256;
   const long long i = i0 + threadIdx.x;
-  if (i >= a.last) return;
+  if (i >= a.last || i < a.lo) return;      // (a run may begin and end inside a tile: the neighbouring run's launch takes the rest)
   const DevType& T = a.types[a.run_type];
   const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
   const unsigned sl = 4u * kv_lane(a.st, threadIdx.x), tl = 4u * kv_lane(a.tg, threadIdx.x);
@@ -1137,11 +1152,12 @@ __global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void
   if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
   V3 pos_e;
   float yaw_e;
+  const long long nid = NOISE ? noise_id(a, i) : -1LL;
   if constexpr (HEXA) {
-    hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
+    hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext, nid);
     indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
   } else {
-    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
+    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext, nullptr, nid);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   const unsigned so = pin_lane_offset(sl);
@@ -1163,12 +1179,12 @@ __device__ __forceinline__ void physics_gen_body(const DevType& T, const StepK& 
   V3 ext = v3(0, 0, 0);
   if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
   if (NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA) {
-    if constexpr (NACT == 6) hexa_substeps<NOISE, true, false, PLANE>(T, a, i, s, cmd, a.step_index, ext);
+    if constexpr (NACT == 6) hexa_substeps<NOISE, true, false, PLANE>(T, a, i, s, cmd, a.step_index, ext, NOISE ? noise_id(a, i) : -1LL);
   } else {
     float prev[4];       // last_clipped_action of the previous step (drag of sub-step 0); this step's action without it
 #pragma unroll
     for (int j = 0; j < 4; ++j) prev[j] = a.echo ? a.echo[(long long)j * a.n_pad + i] : cmd[j];
-    quad_substeps<NOISE ? 2 : 0, NACT, true, 0, PLANE>(T, a, i, s, cmd, a.step_index, ext, prev);
+    quad_substeps<NOISE ? 2 : 0, NACT, true, 0, PLANE>(T, a, i, s, cmd, a.step_index, ext, prev, NOISE ? noise_id(a, i) : -1LL);
   }
   ground_watch(T, s, a.fb.counters, i < a.n);
   store_rigid(ad.sb, ad.sfs, ad.sl, s);
@@ -1249,7 +1265,13 @@ __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_control_gen(StepK a) {
 template <bool NOISE, bool NT, bool OBS>
 __global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_physics_fast(StepK a) {
   constexpr int W = 20;
-  __shared__ float rows[OBS ? 256 * (W + 1) : 1];        // rows padded to W + 1 floats (bank spread)
+  // Observation rows: each wave owns 64 consecutive rows = 5 120 contiguous bytes of the row-major [n][20] output.  Lane r
+  // writes ITS row to the wave's private LDS block as five 16-byte pieces (row stride 80 B: eight lanes cover the 32
+  // banks exactly once), and the block goes out as five 16-byte stores per lane over consecutive addresses.  No
+  // workgroup barrier — the block is the wave's own — and no index arithmetic per element (round 2: a __syncthreads,
+  // twenty dword stores per lane and a division by W each; SQ_WAIT_ANY 0.36).
+  typedef float vf4 __attribute__((ext_vector_type(4)));       // (a native vector: what the nontemporal builtin takes)
+  __shared__ __attribute__((aligned(16))) vf4 rows[OBS ? 4 * 64 * (W / 4) : 1];
   const DevType& T = a.types[0];
   const long long sfs = a.st.field_stride;
   const unsigned sl = 4u * kv_lane(a.st, threadIdx.x);
@@ -1275,21 +1297,27 @@ __global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_physics_fast(StepK a) 
   }
   if (OBS) {
     const Euler e = euler_from_quat<true>(s.q);                                        // BaseAviary.py:729
-    float* r = rows + threadIdx.x * (W + 1);
-    r[0] = s.pos.x; r[1] = s.pos.y; r[2] = s.pos.z;
-    r[3] = s.q.x; r[4] = s.q.y; r[5] = s.q.z; r[6] = s.q.w;
-    r[7] = e.roll; r[8] = e.pitch; r[9] = e.yaw;
-    r[10] = s.vel.x; r[11] = s.vel.y; r[12] = s.vel.z;
-    r[13] = s.w.x; r[14] = s.w.y; r[15] = s.w.z;
+    const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    vf4* blk = rows + w * (64 * (W / 4));                    // the wave's 64 rows x 5 pieces
+    vf4* r = blk + lane * (W / 4);
+    r[0] = vf4{s.pos.x, s.pos.y, s.pos.z, s.q.x};
+    r[1] = vf4{s.q.y, s.q.z, s.q.w, e.roll};
+    r[2] = vf4{e.pitch, e.yaw, s.vel.x, s.vel.y};
+    r[3] = vf4{s.vel.z, s.w.x, s.w.y, s.w.z};
+    r[4] = vf4{cmd[0], cmd[1], cmd[2], cmd[3]};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's own LDS writes, then its own reads: in order
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const long long w0 = i0 + 64 * (long long)w;             // first row of this wave
+    const long long left = a.n - w0;                         // rows of this wave that exist (the last tile may be ragged)
+    vf4* dst = reinterpret_cast<vf4*>(a.obs_out + w0 * W);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r[16 + j] = cmd[j];
-    __syncthreads();
-    const long long left = a.n - i0;                       // rows of this tile that exist (the last tile may be ragged)
-    const int total = (int)(left < 256 ? left : 256) * W;
-    float* dst = a.obs_out + i0 * W;
-    for (int k = threadIdx.x; k < total; k += 256) {
-      const int rr = k / W, f = k - rr * W;
-      stg<NT>(dst, 4u * (unsigned)k, rows[rr * (W + 1) + f]);
+    for (int k = 0; k < W / 4; ++k) {
+      const unsigned p = (unsigned)k * 64u + lane;           // piece p of the block belongs to row p / 5
+      const vf4 v = blk[p];
+      if ((long long)(p / (W / 4)) < left) {
+        if (NT) __builtin_nontemporal_store(v, dst + p); else dst[p] = v;
+      }
     }
   }
 }
@@ -1350,7 +1378,8 @@ __device__ __forceinline__ void adaptor_body(const DevType& T, const StepK& a, l
   } else {                                                 // RPYTAviary.py:184-191
     indi_rate<4>(T, DSIM_RCP(a.dt_ctrl), s, v3(v[0], v[1], v[2]), v[3], m);
   }
-  quad_substeps<NOISE ? 1 : 0, 4, PLANE, 0, PLANE>(T, a, i, s, m.cmd, a.step_index);
+  quad_substeps<NOISE ? 1 : 0, 4, PLANE, 0, PLANE>(T, a, i, s, m.cmd, a.step_index, V3{0.0f, 0.0f, 0.0f}, nullptr,
+                                                   NOISE ? noise_id(a, i) : -1LL);
   ground_watch(T, s, a.fb.counters, i < a.n);
   store_rigid(ad.sb, ad.sfs, ad.sl, s);
   store_mem<4>(ad.sb, ad.sfs, ad.sl, m);
@@ -1375,7 +1404,7 @@ __global__ __launch_bounds__(256, PLANE ? 1 : DSIM_GEN_WAVES) void k_adaptor(Ste
 // unconditional fence-and-ticket epilogue of round 1 cost).  Otherwise the grid (sized for the chip by the host:
 // up to one 64-lane workgroup per CU, 144 KB of LDS each) strides over the queue, and the last workgroup to finish
 // empties it for the next step.
-struct FbK { KView st; const DevType* types; const uint8_t* type_id; FbList fb; };
+struct FbK { KView st; const DevType* types; const uint8_t* type_id; FbList fb; float* cmd_out; long long n_pad; };
 #define DSIM_FB_LANES 64
 __global__ __launch_bounds__(DSIM_FB_LANES) void k_wls_fallback(FbK a) {
   const unsigned long long cnt = *a.fb.count;
@@ -1392,7 +1421,13 @@ __global__ __launch_bounds__(DSIM_FB_LANES) void k_wls_fallback(FbK a) {
     for (int j = 0; j < 6; ++j) { cmd[j] = p[(20 + j) * fs]; umin[j] = T.pmin[j] - cmd[j]; umax[j] = T.pmax[j] - cmd[j]; }
     const int rc = wls_active_set(T, en.v, umin, umax, du, work[threadIdx.x]);
     atomicAdd(&a.fb.counters[0], 1ULL);
-    if (rc == 0) { for (int j = 0; j < 6; ++j) p[(20 + j) * fs] = clampf(cmd[j] + du[j], T.pmin[j], T.pmax[j]); }
+    if (rc == 0) {
+      for (int j = 0; j < 6; ++j) {
+        const float c = clampf(cmd[j] + du[j], T.pmin[j], T.pmax[j]);
+        p[(20 + j) * fs] = c;
+        if (a.cmd_out) a.cmd_out[(long long)j * a.n_pad + i] = c;   // computeControl's first return value (dsim_control2)
+      }
+    }
     else atomicAdd(&a.fb.counters[1], 1ULL);   // the reference would raise here; cmd is left unchanged
   }
   // the last workgroup to finish empties the queue for the next step (no per-step memset on the stream)
@@ -1674,8 +1709,16 @@ __device__ __forceinline__ float dw_pair(float4 p, float x, float y, float z, fl
 #define DW_RPG 8
 #define DW_MAXG (DW_CAP / DW_RPG)
 #define DW_ENT_PER_THREAD 6            // ceil(768 / 128): the tile of the dense form, per thread
+// Two grids: the RECEIVERS are the entries of grid b, the CANDIDATES those of grid cnd — the same grid in the one-pass
+// form; in the split form of a sharded fleet (DSIM_DW_LOCAL / DSIM_DW_HALO_QUERY) the local pass runs while the
+// neighbouring ranks' positions are still on the wire, and the second pass (accumulate: force += ) takes the local
+// receivers against the halo grid, where only the cells within the cut-off of a slab edge find anything.
+__device__ __forceinline__ void dw_write(const DwK& a, long long i, float fz, int accumulate) {
+  if (accumulate) { a.force_out[2 * a.n_pad + i] += fz; return; }
+  a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz;
+}
 template <int TPB, bool BAND>
-__global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings, int tile_cap) {
+__global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, int rings, int tile_cap, int accumulate) {
   extern __shared__ float4 tile[];                                                     // tile_cap entries
   __shared__ int nb_cell[DW_NBR], nb_cnt[DW_NBR];
   __shared__ float coef[DSIM_MAX_TYPES][4];                                            // (K, DW2, DW3) of every type
@@ -1693,7 +1736,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
   const int sub = (int)(t % DW_LPB), r_in = (int)(t / DW_LPB);
   if ((int)blockIdx.x >= ncells) {
     // receivers that overflowed their bucket: grid-stride over the overflow list, candidates from global memory
-    const int n_ovf = b.count[ncells];
+    const int n_ovf = b.count[ncells], n_ovf_c = cnd.count[ncells];
     const int g = (int)blockIdx.x - ncells;
     for (int r = g * RPB + r_in; r < n_ovf; r += DW_OVF_GROUPS * RPB) {
       const float4 m2 = b.overflow[r];
@@ -1707,14 +1750,14 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
       for (int yy = max(oy - rings, 0); yy <= min(oy + rings, b.ny - 1); ++yy)
         for (int xx = max(ox - rings, 0); xx <= min(ox + rings, b.nx - 1); ++xx) {
           const int cc = yy * b.nx + xx;
-          const int cnt = min(b.count[cc], DW_CAP);
-          const float4* __restrict__ src = b.buckets + (long long)cc * DW_CAP;
+          const int cnt = min(cnd.count[cc], DW_CAP);
+          const float4* __restrict__ src = cnd.buckets + (long long)cc * DW_CAP;
           for (int e = sub; e < cnt; e += DW_LPB) fz += dw_pair(src[e], m2.x, m2.y, m2.z, 1.0f, d1, d2c);
         }
-      for (int e = sub; e < n_ovf; e += DW_LPB) fz += dw_pair(b.overflow[e], m2.x, m2.y, m2.z, 1.0f, d1, d2c);
+      for (int e = sub; e < n_ovf_c; e += DW_LPB) fz += dw_pair(cnd.overflow[e], m2.x, m2.y, m2.z, 1.0f, d1, d2c);
 #pragma unroll
       for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
-      if (sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = K * fz; }
+      if (sub == 0) dw_write(a, i, K * fz, accumulate);
     }
     return;
   }
@@ -1734,7 +1777,8 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
   const int nxx = cx - rings + (int)t % side, nyy = cy - rings + (int)t / side;
   const bool nin = (int)t < n_nb && nxx >= 0 && nxx < b.nx && nyy >= 0 && nyy < b.ny;
   const int ncc = nin ? nyy * b.nx + nxx : c;
-  const int ncount = b.count[ncc];
+  const int ncount = cnd.count[ncc];
+  const int rcount = b.count[c];                                                       // receivers of this cell (scalar load)
   const int cty = min(TPB - 1 - (int)t, a.n_types - 1);                                // the LAST lanes hold the types
   const DevType& CT = a.types[cty];
   const float c_dw0 = CT.dw[0], c_dw1 = CT.dw[1], c_dw2 = CT.dw[2], c_pr = CT.prop_radius;
@@ -1745,12 +1789,13 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
   if ((int)t >= TPB - a.n_types) {
     coef[cty][0] = c_dw0 * (0.25f * c_pr) * (0.25f * c_pr); coef[cty][1] = c_dw1; coef[cty][2] = c_dw2;
   }
-  n_ovf = b.count[ncells];                                                             // (scalar load, same round trip)
+  n_ovf = cnd.count[ncells];                                                           // (scalar load, same round trip)
   __syncthreads();
-  const int cnt_c = nb_cnt[centre];
+  const int cnt_c = min(rcount, DW_CAP);
   if (cnt_c == 0) return;                                                              // nobody to serve here (uniform)
   int total = 0;
   for (int k = 0; k < n_nb; ++k) total += nb_cnt[k];
+  if (accumulate && total == 0 && n_ovf == 0) return;                                  // second pass: nothing of the halo near this cell
   // the tile holds the whole neighbourhood in the normal case: one fill, every receiver pass reads it
   const bool whole = total <= tile_cap;
   if constexpr (BAND) {
@@ -1793,7 +1838,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
           ent[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
           if (e < total) {
             while (e >= acc + nb_cnt[k]) { acc += nb_cnt[k]; ++k; }
-            ent[q] = b.buckets[(long long)nb_cell[k] * DW_CAP + (e - acc)];
+            ent[q] = cnd.buckets[(long long)nb_cell[k] * DW_CAP + (e - acc)];
           }
         }
       }
@@ -1843,14 +1888,11 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
             fz += dw_pair(p1, me.x, me.y, me.z, 1.0f, d1, d2c);
           }
           if (e < lim) fz += dw_pair(tile[e], me.x, me.y, me.z, 1.0f, d1, d2c);
-          for (int k = sub8; k < n_ovf; k += DW_LPB) fz += dw_pair(b.overflow[k], me.x, me.y, me.z, 1.0f, d1, d2c);
+          for (int k = sub8; k < n_ovf; k += DW_LPB) fz += dw_pair(cnd.overflow[k], me.x, me.y, me.z, 1.0f, d1, d2c);
         }
 #pragma unroll
         for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
-        if (have && sub8 == 0) {
-          const long long i = (long long)__float_as_int(me.w) - a.local_offset;
-          a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = K * fz;
-        }
+        if (have && sub8 == 0) dw_write(a, (long long)__float_as_int(me.w) - a.local_offset, K * fz, accumulate);
       }
       return;
     }
@@ -1884,7 +1926,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
           int k = 0, acc = 0;
           const int g = base + e;
           while (g >= acc + nb_cnt[k]) { acc += nb_cnt[k]; ++k; }
-          tile[e] = b.buckets[(long long)nb_cell[k] * DW_CAP + (g - acc)];
+          tile[e] = cnd.buckets[(long long)nb_cell[k] * DW_CAP + (g - acc)];
         }
         __syncthreads();
       }
@@ -1902,11 +1944,170 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, int rings,
       }
     }
     if (have)
-      for (int k = sub_p; k < n_ovf; k += lpb) fz += dw_pair(b.overflow[k], me.x, me.y, me.z, 1.0f, d1, d2c);
+      for (int k = sub_p; k < n_ovf; k += lpb) fz += dw_pair(cnd.overflow[k], me.x, me.y, me.z, 1.0f, d1, d2c);
     for (int off = lpb / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
-    if (have && sub_p == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = K * fz; }
+    if (have && sub_p == 0) dw_write(a, i, K * fz, accumulate);
     r0 += RPB >> sh;
   }
+}
+
+// ---- halo exchange of a spatially sharded fleet: bounds, per-peer lists, packing, binning what arrived ----------------
+// (include/dronesim_amd.h: dsim_halo_plan).  All of it is HBM/latency work on a few thousand boundary drones per step.
+__device__ __forceinline__ unsigned fkey(float f) {            // order-preserving key of a float (atomicMin / atomicMax on unsigned)
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
+struct BoundsK { KView st; long long n; unsigned* keys; float* out; };
+__global__ __launch_bounds__(256) void k_fleet_bounds(BoundsK a) {
+  float xmin = __builtin_inff(), ymin = __builtin_inff(), xmax = -__builtin_inff(), ymax = -__builtin_inff(), vmax = 0.0f;
+  const long long fs = a.st.field_stride;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+    const float* p = a.st.base + kv_off(a.st, i);
+    const float x = p[0], y = p[fs];
+    xmin = fminf(xmin, x); xmax = fmaxf(xmax, x); ymin = fminf(ymin, y); ymax = fmaxf(ymax, y);
+    vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(p[7 * fs]), fabsf(p[8 * fs])), fabsf(p[9 * fs])));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    xmin = fminf(xmin, __shfl_xor(xmin, off)); ymin = fminf(ymin, __shfl_xor(ymin, off));
+    xmax = fmaxf(xmax, __shfl_xor(xmax, off)); ymax = fmaxf(ymax, __shfl_xor(ymax, off));
+    vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+  }
+  if ((threadIdx.x & 63u) == 0) {      // (atomics only from the waves that improve on what is already there)
+    if (fkey(xmin) < __atomic_load_n(&a.keys[0], __ATOMIC_RELAXED)) atomicMin(&a.keys[0], fkey(xmin));
+    if (fkey(ymin) < __atomic_load_n(&a.keys[1], __ATOMIC_RELAXED)) atomicMin(&a.keys[1], fkey(ymin));
+    if (fkey(xmax) > __atomic_load_n(&a.keys[2], __ATOMIC_RELAXED)) atomicMax(&a.keys[2], fkey(xmax));
+    if (fkey(ymax) > __atomic_load_n(&a.keys[3], __ATOMIC_RELAXED)) atomicMax(&a.keys[3], fkey(ymax));
+    if (fkey(vmax) > __atomic_load_n(&a.keys[4], __ATOMIC_RELAXED)) atomicMax(&a.keys[4], fkey(vmax));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&a.keys[5], 1u) == gridDim.x - 1) {          // the last workgroup decodes, and resets the keys for the next call
+      __threadfence();
+      a.out[0] = fkey_inv(atomicExch(&a.keys[0], 0xFFFFFFFFu)); a.out[1] = fkey_inv(atomicExch(&a.keys[1], 0xFFFFFFFFu));
+      a.out[2] = fkey_inv(atomicExch(&a.keys[2], 0u)); a.out[3] = fkey_inv(atomicExch(&a.keys[3], 0u));
+      a.out[4] = fkey_inv(atomicExch(&a.keys[4], 0u));
+      a.keys[5] = 0u;
+      __threadfence();
+    }
+  }
+}
+// The wire format of one peer's buffer: DSIM_HALO_HDR header floats, then xyz triples (include/dronesim_amd.h).
+struct HaloK {
+  KView st; long long n;
+  float* send; const float* recv; long long stride;      // floats per peer buffer = DSIM_HALO_HDR + 3 cap
+  int world, rank;
+  int send_cap[DSIM_MAX_PEERS], recv_cap[DSIM_MAX_PEERS];
+  float reach[DSIM_MAX_PEERS];
+  int* scratch;                                          // [0..7] counts, [8] ticket, [9..13] bound keys (as unsigned)
+  unsigned long long* counters;
+  int off[DSIM_MAX_PEERS + 1];                           // HALO_BIN: prefix of recv_cap (off[q] = the total for q >= world)
+  long long index0;
+};
+// Select + pack, one launch.  For every peer p whose last known box (the header of p's last message, device memory)
+// grown by reach[p] holds this drone, the drone's position is appended to send[p] (one atomic per wave and peer); the
+// workgroups also reduce this rank's own box, and the last one to finish writes the headers (count SELECTED, own box)
+// and resets the scratch for the next call.  ~8 vector instructions per drone and peer: noise beside the query.
+__global__ __launch_bounds__(256) void k_halo_pack(HaloK a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < a.n;
+  float x = 0.0f, y = 0.0f, z = 0.0f, vm = 0.0f;
+  if (live) {
+    const float* q = a.st.base + kv_off(a.st, i);
+    const long long fs = a.st.field_stride;
+    x = q[0]; y = q[fs]; z = q[2 * fs];
+    vm = fmaxf(fmaxf(fabsf(q[7 * fs]), fabsf(q[8 * fs])), fabsf(q[9 * fs]));
+  }
+  const unsigned lane = threadIdx.x & 63u;
+#pragma unroll
+  for (int p = 0; p < DSIM_MAX_PEERS; ++p) {
+    if (p >= a.world || p == a.rank || a.send_cap[p] == 0) continue;           // uniform
+    const float* hdr = a.recv + (long long)p * a.stride;                        // scalar loads
+    const float r = a.reach[p];
+    const bool in = live && x >= hdr[1] - r && x <= hdr[3] + r && y >= hdr[2] - r && y <= hdr[4] + r;
+    const unsigned long long m = __ballot(in);
+    if (m == 0ULL) continue;
+    const int lead = __builtin_ctzll(m);
+    int base = 0;
+    if ((int)lane == lead) base = atomicAdd(&a.scratch[p], (int)__popcll(m));
+    base = __shfl(base, lead);
+    if (in) {
+      const int slot = base + (int)__popcll(m & ((1ULL << lane) - 1ULL));
+      if (slot < a.send_cap[p]) {
+        float* d = a.send + (long long)p * a.stride + DSIM_HALO_HDR + 3LL * slot;
+        d[0] = x; d[1] = y; d[2] = z;
+      }
+    }
+  }
+  // own box: wave reduce, then atomics only from the waves that improve on what is already there
+  float xmin = live ? x : __builtin_inff(), xmax = live ? x : -__builtin_inff();
+  float ymin = live ? y : __builtin_inff(), ymax = live ? y : -__builtin_inff();
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    xmin = fminf(xmin, __shfl_xor(xmin, off)); ymin = fminf(ymin, __shfl_xor(ymin, off));
+    xmax = fmaxf(xmax, __shfl_xor(xmax, off)); ymax = fmaxf(ymax, __shfl_xor(ymax, off));
+    vm = fmaxf(vm, __shfl_xor(vm, off));
+  }
+  // (the minima are kept as the maxima of the inverted keys, so that a zero-initialised scratch is the neutral element)
+  unsigned* keys = reinterpret_cast<unsigned*>(a.scratch + 9);
+  if (lane == 0) {
+    const unsigned k0 = ~fkey(xmin), k1 = ~fkey(ymin), k2 = fkey(xmax), k3 = fkey(ymax), k4 = fkey(vm);
+    if (k0 > __atomic_load_n(&keys[0], __ATOMIC_RELAXED)) atomicMax(&keys[0], k0);
+    if (k1 > __atomic_load_n(&keys[1], __ATOMIC_RELAXED)) atomicMax(&keys[1], k1);
+    if (k2 > __atomic_load_n(&keys[2], __ATOMIC_RELAXED)) atomicMax(&keys[2], k2);
+    if (k3 > __atomic_load_n(&keys[3], __ATOMIC_RELAXED)) atomicMax(&keys[3], k3);
+    if (k4 > __atomic_load_n(&keys[4], __ATOMIC_RELAXED)) atomicMax(&keys[4], k4);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&a.scratch[8], 1) == (int)gridDim.x - 1) {
+      __threadfence();
+      const float bx0 = fkey_inv(~atomicExch(&keys[0], 0u)), by0 = fkey_inv(~atomicExch(&keys[1], 0u));
+      const float bx1 = fkey_inv(atomicExch(&keys[2], 0u)), by1 = fkey_inv(atomicExch(&keys[3], 0u));
+      const float bv = fkey_inv(atomicExch(&keys[4], 0u));
+      unsigned long long lost = 0;
+#pragma unroll
+      for (int p = 0; p < DSIM_MAX_PEERS; ++p) {
+        if (p >= a.world) continue;
+        const int c = atomicExch(&a.scratch[p], 0);
+        if (p == a.rank || a.send_cap[p] == 0) continue;
+        float* hdr = a.send + (long long)p * a.stride;
+        hdr[0] = __int_as_float(c); hdr[1] = bx0; hdr[2] = by0; hdr[3] = bx1; hdr[4] = by1; hdr[5] = bv; hdr[6] = 0.0f; hdr[7] = 0.0f;
+        if (c > a.send_cap[p]) lost += (unsigned long long)(c - a.send_cap[p]);
+      }
+      if (lost) atomicAdd(&a.counters[4], lost);                       // DSIM_Q_HALO_OVERFLOW
+      a.scratch[8] = 0;
+      __threadfence();
+    }
+  }
+}
+// flat entry e over the messages' capacities -> (peer, slot): constant-index walk over the prefix (a dynamically
+// indexed argument array would go to scratch)
+__device__ __forceinline__ void halo_locate(const HaloK& h, int e, int& p, int& k) {
+  p = 0; k = e;
+#pragma unroll
+  for (int q = 1; q < DSIM_MAX_PEERS; ++q)
+    if (e >= h.off[q]) { p = q; k = e - h.off[q]; }
+}
+// what the peers sent -> a bucket grid (world index index0 + running number: anything outside the local range); how
+// many positions a message really holds is in its header
+__global__ __launch_bounds__(256) void k_dw_bin_halo(BinK b, HaloK h) {
+  const int e = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (e >= h.off[DSIM_MAX_PEERS]) return;
+  int p, k;
+  halo_locate(h, e, p, k);
+  const float* msg = h.recv + (long long)p * h.stride;
+  int cap = 0;
+#pragma unroll
+  for (int q = 0; q < DSIM_MAX_PEERS; ++q) if (q == p) cap = h.recv_cap[q];
+  const int cnt = __float_as_int(msg[0]);
+  if (k == 0 && cnt > cap) atomicAdd(&h.counters[4], (unsigned long long)(cnt - cap));     // the sender counted it too
+  if (k >= min(cnt, cap)) return;
+  const float* t = msg + DSIM_HALO_HDR + 3LL * k;
+  bin_entry(b, t[0], t[1], t[2], h.index0 + e);
 }
 
 // DW_LPR lanes per SORTED world entry; the entries that belong to this rank's shard are the
@@ -2076,8 +2277,10 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
   if (!c) return (int)hipErrorOutOfMemory;
   c->device = device; c->n_types = n_types; c->max_act = max_act; c->d_types = nullptr; c->d_counters = nullptr;
   c->d_fb = nullptr; c->fb_cap = 0; c->dw_ws = nullptr; c->dw_cells = 0; c->dw_parity = 0; c->dw_mode = 0;
-  c->n_cu = 256; c->dw_prebin = false; c->dw_prebin_n = 0; c->dw_prebin_off = 0;
+  c->n_cu = 256; c->dw_prebin = false; c->dw_prebin_valid = false; c->dw_prebin_n = 0; c->dw_prebin_off = 0;
   c->dw_prebin_geo[0] = c->dw_prebin_geo[1] = c->dw_prebin_geo[2] = 0.0f;
+  c->dw_prebin_nx = c->dw_prebin_ny = 0; c->dw_local_m = 0; c->dwh_parity = 0; c->dwh_ws = nullptr; c->dwh_cells = 0;
+  c->d_bounds = nullptr;
   { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->n_cu = v; }
   DevType h[DSIM_MAX_TYPES];
   for (int t = 0; t < n_types; ++t) { c->h_types[t] = types[t]; to_dev(types[t], &h[t]); }
@@ -2085,9 +2288,15 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
   if (e == hipSuccess) e = hipMemcpy(c->d_types, h, sizeof(DevType) * n_types, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * (8 + DSIM_GROUND_SHARDS));
   if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(unsigned long long) * (8 + DSIM_GROUND_SHARDS));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_bounds, sizeof(unsigned) * 8);
+  if (e == hipSuccess) {
+    const unsigned init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u};     // min keys, max keys, ticket
+    e = hipMemcpy(c->d_bounds, init, sizeof(init), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     if (c->d_types) (void)hipFree(c->d_types);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_bounds) (void)hipFree(c->d_bounds);
     delete c;
     return (int)e;
   }
@@ -2099,13 +2308,14 @@ int dsim_destroy(dsim_ctx* ctx) {
   if (!ctx) return DSIM_E_ARG;
   hipError_t e = hipFree(ctx->d_types);
   (void)hipFree(ctx->d_counters);
+  (void)hipFree(ctx->d_bounds);
   if (ctx->d_fb) (void)hipFree(ctx->d_fb);
   delete ctx;
   return (int)e;
 }
 
 int dsim_query(dsim_ctx* ctx, void* stream, int32_t what, int64_t* value_out) {
-  if (!ctx || !value_out || what < 0 || what > 2) return DSIM_E_ARG;
+  if (!ctx || !value_out || what < 0 || what > 3) return DSIM_E_ARG;
   unsigned long long h[8 + DSIM_GROUND_SHARDS];
   hipError_t e = hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream);
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
@@ -2114,6 +2324,8 @@ int dsim_query(dsim_ctx* ctx, void* stream, int32_t what, int64_t* value_out) {
     unsigned long long sum = 0;
     for (int k = 0; k < DSIM_GROUND_SHARDS; ++k) sum += h[8 + k];
     *value_out = (int64_t)sum;
+  } else if (what == DSIM_Q_HALO_OVERFLOW) {
+    *value_out = (int64_t)h[4];
   } else {
     *value_out = (int64_t)h[what];
   }
@@ -2139,6 +2351,7 @@ int dsim_reset(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const fl
   ResetK a;
   int rc = make_kview(state, 20 + ctx->max_act, &a.st);
   if (rc) return rc;
+  ctx->dw_prebin_valid = false;
   a.types = ctx->d_types; a.type_id = type_id;
   a.pos = init_pos; a.rpy = init_rpy; a.vel = init_vel; a.cmd = init_cmd;
   a.n_pad = state.n_pad; a.n_fields = 20 + ctx->max_act;
@@ -2176,26 +2389,34 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
   a->substeps = args->phys_substeps; a->dt_phys = args->dt_phys; a->dt_ctrl = args->dt_ctrl;
   a->options = args->options;
   memset(&a->bin, 0, sizeof(a->bin));
-  a->last = a->n_pad; a->run_type = 0;
+  a->lo = 0; a->last = a->n_pad; a->run_type = 0;
+  a->drone_id = args->drone_id;
   return DSIM_OK;
 }
 
 // dsim_step_args.bin_next: the step kernel fills the bucket grid of the next dsim_downwash call.  Only when that grid
 // is the one the last dsim_downwash used (its spare count buffer is then known to be zero) and takes the bucket form.
-static void bin_next_prepare(dsim_ctx* ctx, int64_t n, const dsim_step_args* args, StepK* a) {
+static void bin_next_prepare(dsim_ctx* ctx, int64_t n, const dsim_step_args* args, StepK* a, hipStream_t st) {
   const dsim_downwash_args* g = args->bin_next;
   if (!g || !g->workspace || g->nx < 1 || g->ny < 1 || !(g->cell > 0)) return;
   const long long ncells = (long long)g->nx * g->ny;
   if (!dw_use_buckets(g->m, ncells) || ctx->dw_ws != g->workspace || ctx->dw_cells != ncells || ctx->dw_mode != 1 ||
-      ctx->dw_prebin || g->local_offset < 0 || g->local_offset + n > g->m)
+      g->local_offset < 0 || g->local_offset + n > g->m)
     return;
   bucket_layout(g->workspace, ncells, ctx->dw_parity, &a->bin);
+  if (ctx->dw_prebin) {
+    // an earlier step already filled this buffer and no dsim_downwash has consumed it (two steps in a row): start over,
+    // so that the buffer never holds two generations of positions
+    (void)hipMemsetAsync(a->bin.count, 0, sizeof(int) * (size_t)(ncells + 2), st);
+    ctx->dw_prebin = false;
+  }
   a->bin.xmin = g->xmin; a->bin.ymin = g->ymin; a->bin.inv_cell = 1.0f / g->cell; a->bin.nx = g->nx; a->bin.ny = g->ny;
   a->bin.local_offset = g->local_offset;
 }
 static void bin_next_commit(dsim_ctx* ctx, int64_t n, const dsim_step_args* args, const StepK& a) {
   if (!a.bin.count) return;
-  ctx->dw_prebin = true; ctx->dw_prebin_n = n; ctx->dw_prebin_off = args->bin_next->local_offset;
+  ctx->dw_prebin = true; ctx->dw_prebin_valid = true; ctx->dw_prebin_n = n; ctx->dw_prebin_off = args->bin_next->local_offset;
+  ctx->dw_prebin_nx = args->bin_next->nx; ctx->dw_prebin_ny = args->bin_next->ny;
   ctx->dw_prebin_geo[0] = args->bin_next->xmin; ctx->dw_prebin_geo[1] = args->bin_next->ymin;
   ctx->dw_prebin_geo[2] = args->bin_next->cell;
 }
@@ -2217,8 +2438,10 @@ static int fb_prepare(dsim_ctx* ctx, long long n_pad, hipStream_t st) {
 }
 static void fb_finish(dsim_ctx* ctx, const StepK& a, hipStream_t st) {
   if (ctx->max_act != 6) return;
+  if (a.options & DSIM_OPT_DEFER_FALLBACK) return;          // the caller launches dsim_wls_fallback itself
   FbK f;
   f.st = a.st; f.types = a.types; f.type_id = a.type_id; f.fb = a.fb;
+  f.cmd_out = a.cmd_out; f.n_pad = a.n_pad;
   f.fb.entries = ctx->d_fb;
   // one workgroup per 64 possible entries, at most one per CU (each holds 144 KB of LDS): a start-up transient that
   // queues a large part of a big fleet is worked off by the whole chip, an empty queue costs one scalar load per group
@@ -2247,6 +2470,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   StepK a;
   int rc = fill_stepk(ctx, n, state, &targets, args, &a);
   if (rc) return rc;
+  ctx->dw_prebin_valid = false;      // the positions move: a grid binned before this call is stale (bin_next_commit re-validates)
   const bool noise = args->noise_seed != 0 || args->noise_replay != nullptr;
   const bool uni = args->type_id == nullptr;
   const bool six = ctx->max_act == 6;
@@ -2275,11 +2499,10 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     // type-major storage: one single-type launch per run
     const bool nt = stream_policy(args, state.n_pad, 240.0);
     bool any_hexa = false;
-    bin_next_prepare(ctx, n, args, &a);
+    bin_next_prepare(ctx, n, args, &a, st_);
     for (int r = 0; r < n_runs; ++r) {
       const dsim_type_run& run = runs[r];
-      if (run.first < 0 || run.count < 0 || (run.first % 256) || run.first + run.count > a.n_pad || run.type < 0 ||
-          run.type >= ctx->n_types)
+      if (run.first < 0 || run.count < 0 || run.first + run.count > a.n_pad || run.type < 0 || run.type >= ctx->n_types)
         return DSIM_E_ARG;
       any_hexa |= ctx->h_types[run.type].kind == DSIM_KIND_HEXA6DOF;
     }
@@ -2297,8 +2520,10 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     for (int r = 0; r < n_runs; ++r) {
       const dsim_type_run& run = runs[r];
       if (run.count == 0) continue;
-      a.first = run.first; a.last = run.first + run.count; a.run_type = run.type;
-      const dim3 g(grid_for(run.count));
+      // the launch covers whole 256-drone tiles from the one that holds the run's first drone; lanes outside
+      // [lo, last) retire, so two runs may share a tile (each launch takes its own lanes of it)
+      a.first = run.first & ~255LL; a.lo = run.first; a.last = run.first + run.count; a.run_type = run.type;
+      const dim3 g(grid_for(a.last - a.first));
       if (ctx->h_types[run.type].kind == DSIM_KIND_HEXA6DOF) DSIM_RUN_CASE(true); else DSIM_RUN_CASE(false);
     }
 #undef DSIM_RUN_CASE
@@ -2366,7 +2591,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
         if (rc) return rc;
         a.fb.entries = ctx->d_fb;
       }
-      if (first == 0) bin_next_prepare(ctx, n, args, &a);      // (the whole fleet goes through this kernel)
+      if (first == 0) bin_next_prepare(ctx, n, args, &a, st_);      // (the whole fleet goes through this kernel)
       // the LDS-DMA ring moves whole 1 KB row groups: it needs the wave-tiled layout [n/64][F][64] for the state
       // (26 fields: a table with a morphing hexa) and for per-drone targets
       const bool tiled = state.block == 64 && state.field_stride == 64 && ctx->max_act == 6 &&
@@ -2472,6 +2697,22 @@ int dsim_reserve(dsim_ctx* ctx, void* stream, int64_t n_pad) {
   return fb_prepare(ctx, n_pad, (hipStream_t)stream);
 }
 
+int dsim_wls_fallback(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const uint8_t* type_id, float* cmd_out) {
+  if (!ctx || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
+  if (ctx->max_act != 6) return DSIM_OK;                     // no morphing hexa in the table: nothing is ever queued
+  if (ctx->n_types > 1 && !type_id) return DSIM_E_ARG;
+  StepK a;
+  memset(&a, 0, sizeof(a));
+  int rc = make_kview(state, 20 + ctx->max_act, &a.st);
+  if (rc) return rc;
+  rc = fb_prepare(ctx, state.n_pad, (hipStream_t)stream);
+  if (rc) return rc;
+  a.types = ctx->d_types; a.type_id = type_id; a.n_pad = state.n_pad; a.cmd_out = cmd_out;
+  a.fb.entries = ctx->d_fb; a.fb.count = ctx->d_counters + 2; a.fb.counters = ctx->d_counters;
+  fb_finish(ctx, a, (hipStream_t)stream);
+  return (int)hipGetLastError();
+}
+
 int dsim_counter_add(dsim_ctx* ctx, void* stream, uint64_t* counter, uint64_t inc) {
   if (!ctx || !counter) return DSIM_E_ARG;
   hipLaunchKernelGGL(k_counter_add, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)counter,
@@ -2494,6 +2735,7 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
   StepK a;
   int rc = fill_stepk(ctx, n, state, nullptr, args, &a);
   if (rc) return rc;
+  ctx->dw_prebin_valid = false;
   a.echo = last_action_out;
   const bool phys_opts = (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND | DSIM_OPT_PLANE)) != 0;
   if ((args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)) && ctx->max_act == 6) return DSIM_E_UNSUPPORTED;
@@ -2503,8 +2745,10 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
   const hipStream_t st_ = (hipStream_t)stream;
   if (args->type_id == nullptr && ctx->max_act == 4 && !args->noise_replay && !args->ext_force && !phys_opts &&
       (a.n_pad % 256) == 0) {
-    // homogeneous quad fleet in whole tiles: the fast form, observation fused
-    a.obs_out = args->obs_out;
+    // homogeneous quad fleet in whole tiles: the fast form, observation fused (16-byte stores: any torch allocation is
+    // aligned far beyond that; a misaligned caller buffer gets the rows from the observation kernel behind the step)
+    const bool obs_fused = args->obs_out && ((uintptr_t)args->obs_out & 15u) == 0;
+    a.obs_out = obs_fused ? args->obs_out : nullptr;
     const bool nt = stream_policy(args, state.n_pad, args->obs_out ? 216.0 : 136.0);
     const dim3 g((unsigned)(a.n_pad / 256)), b(256);
 #define DSIM_PHYS_CASE(N_, T_) do { if (a.obs_out) hipLaunchKernelGGL((k_physics_fast<N_, T_, true>), g, b, 0, st_, a);   \
@@ -2512,6 +2756,7 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
     if (noise) { if (nt) DSIM_PHYS_CASE(true, true); else DSIM_PHYS_CASE(true, false); }
     else { if (nt) DSIM_PHYS_CASE(false, true); else DSIM_PHYS_CASE(false, false); }
 #undef DSIM_PHYS_CASE
+    if (args->obs_out && !obs_fused) return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, obs_w, 0);
     return (int)hipGetLastError();
   }
   const dim3 g(grid_for(a.n_pad));
@@ -2532,6 +2777,7 @@ int dsim_step_adaptor(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, c
     return DSIM_E_UNSUPPORTED;        // plain PYB physics (+ the plane): refuse what the adaptor kernels would silently drop
   int rc = fill_stepk(ctx, n, state, nullptr, args, &a);
   if (rc) return rc;
+  ctx->dw_prebin_valid = false;
   a.action = action; a.echo = last_action_out;
   const bool noise = args->noise_seed != 0, uni = args->type_id == nullptr;
   const dim3 g(grid_for(a.n_pad)), b(256);
@@ -2633,15 +2879,140 @@ int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny) {
 static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view& state,
                       const dsim_downwash_args* g, float min_cell, DwK* out, bool allow_buckets = false);
 
+// the halo grid of the split-phase downwash sits behind the local grid (whose overflow list holds n_local entries)
+static inline void halo_layout(int32_t* ws, long long ncells, long long n_local, int parity, BinK* b) {
+  BinK loc;
+  bucket_layout(ws, ncells, 0, &loc);
+  const long long cstride = ncells + 2;
+  uintptr_t sp = (uintptr_t)(loc.overflow + n_local);
+  int* base = (int*)((sp + 15) & ~(uintptr_t)15);
+  b->count = base + (long long)parity * cstride;
+  sp = (uintptr_t)(base + 2 * cstride);
+  b->buckets = (float4*)((sp + 15) & ~(uintptr_t)15);
+  b->overflow = b->buckets + ncells * DW_CAP;
+}
+int64_t dsim_downwash_workspace_halo(int64_t n, int64_t h, int32_t nx, int32_t ny) {
+  if (n < 1 || h < 0 || nx < 1 || ny < 1) return -1;
+  const int64_t ncells = (int64_t)nx * ny;
+  if (!dw_use_buckets(n + h, ncells)) return -1;
+  const int64_t local = 2 * (ncells + 2) + 4 + 4 * ncells * DW_CAP + 4 * n;
+  const int64_t split = local + 4 + 2 * (ncells + 2) + 4 + 4 * ncells * DW_CAP + 4 * h;
+  const int64_t one = dsim_downwash_workspace(n + h, nx, ny);      // DSIM_DW_ALL on the same buffer
+  return split > one ? split : one;
+}
+static long long halo_total(const dsim_halo_plan* h, int* off /* [DSIM_MAX_PEERS + 1] */) {     // capacities of the messages received
+  long long tot = 0;
+  for (int q = 0; q <= DSIM_MAX_PEERS; ++q) {
+    off[q] = (int)tot;
+    if (q < h->world && q != h->rank) tot += h->recv_cap[q];
+  }
+  off[DSIM_MAX_PEERS] = (int)tot;
+  return tot;
+}
+static int halo_check(const dsim_halo_plan* h) {
+  if (!h || h->world < 1 || h->world > DSIM_MAX_PEERS || h->rank < 0 || h->rank >= h->world || h->cap < 1) return DSIM_E_ARG;
+  for (int q = 0; q < h->world; ++q)
+    if (h->send_cap[q] < 0 || h->send_cap[q] > h->cap || h->recv_cap[q] < 0 || h->recv_cap[q] > h->cap || !(h->reach[q] >= 0.0f))
+      return DSIM_E_ARG;
+  return DSIM_OK;
+}
+static void halo_fill(const dsim_halo_plan* h, HaloK* k) {
+  k->send = h->send; k->recv = h->recv; k->stride = DSIM_HALO_HDR + 3 * h->cap; k->world = h->world; k->rank = h->rank;
+  k->scratch = h->scratch;
+  for (int q = 0; q < DSIM_MAX_PEERS; ++q) {
+    const bool live = q < h->world && q != h->rank;
+    k->send_cap[q] = live ? h->send_cap[q] : 0; k->recv_cap[q] = live ? h->recv_cap[q] : 0; k->reach[q] = live ? h->reach[q] : 0.0f;
+  }
+}
+
+// the cell-centred query over (receiver grid b, candidate grid cnd)
+static void launch_query_cell(dsim_ctx* ctx, hipStream_t st_, const DwK& a, const BinK& b, const BinK& cnd, float cell,
+                              long long m_candidates, int accumulate) {
+  const long long ncells = (long long)a.nx * a.ny;
+  // sparse worlds (mean occupancy of a neighbourhood <= 128 entries): one wave per cell and an 8 KB tile, so that a
+  // CU holds ~20 cells at once; dense ones (BASELINE config 5: 625 entries per neighbourhood): two waves and 12 KB —
+  // 11 cells per CU, so that the ~2 800 cells of a 65 536-drone shard are all resident in ONE round (four-wave
+  // workgroups needed 1.4 rounds of 8 per CU, and the thin second round cost 40 % of the kernel's time)
+  const int rings = cell >= DW_CUTOFF ? 1 : 2;
+  const double nb_mean = (double)m_candidates / (double)ncells * (2 * rings + 1) * (2 * rings + 1);
+  const dim3 gq((unsigned)(ncells + DW_OVF_GROUPS));
+  if (nb_mean <= 128.0) hipLaunchKernelGGL((k_dw_query_cell<64, false>), gq, dim3(64), 256 * sizeof(float4), st_, a, b, cnd, rings, 256, accumulate);
+  else hipLaunchKernelGGL((k_dw_query_cell<128, true>), gq, dim3(128), 768 * sizeof(float4), st_, a, b, cnd, rings, 768, accumulate);
+}
+
 int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_downwash_args* g,
                   float* force_out) {
-  if (!force_out) return DSIM_E_ARG;
-  if (ctx && g && ctx->n_types > 1 && !g->type_id) return DSIM_E_ARG;
+  if (!g) return DSIM_E_ARG;
+  if (!force_out && g->phase != DSIM_DW_HALO_BIN) return DSIM_E_ARG;
+  if (ctx && ctx->n_types > 1 && !g->type_id && g->phase != DSIM_DW_HALO_BIN) return DSIM_E_ARG;
+  if (g->phase < DSIM_DW_ALL || g->phase > DSIM_DW_HALO_QUERY || (g->phase != DSIM_DW_ALL && !g->halo)) return DSIM_E_ARG;
   DwK a;
   const hipStream_t st_ = (hipStream_t)stream;
+  const long long ncells = (long long)g->nx * g->ny;
+  int h_off[DSIM_MAX_PEERS + 1];
+  long long h_tot = 0;
+  if (g->halo) {
+    int rc = halo_check(g->halo);
+    if (rc) return rc;
+    h_tot = halo_total(g->halo, h_off);
+    // the halo plan stands for the rest of the world: positions of the local drones come from the state block
+    if (!ctx || g->pos_all || g->local_offset != 0 || g->m != n + h_tot || g->nx < 1 || g->ny < 1 || !g->workspace) return DSIM_E_ARG;
+    if (h_tot > 0 && !g->halo->recv) return DSIM_E_ARG;
+    if (!dw_use_buckets(g->m, ncells)) return DSIM_E_UNSUPPORTED;      // the bucket form only (the caller gathers pos_all otherwise)
+    if (g->phase != DSIM_DW_ALL && g->workspace_len < dsim_downwash_workspace_halo(n, h_tot, g->nx, g->ny)) return DSIM_E_ARG;
+  }
+  HaloK hk;
+  memset(&hk, 0, sizeof(hk));
+  if (g->halo) {
+    halo_fill(g->halo, &hk);
+    hk.index0 = n; hk.counters = ctx->d_counters;
+    for (int q = 0; q <= DSIM_MAX_PEERS; ++q) hk.off[q] = h_off[q];
+  }
+  if (g->phase == DSIM_DW_HALO_BIN || g->phase == DSIM_DW_HALO_QUERY) {
+    // the halo grid: two count buffers alternate between steps; HALO_BIN fills the current one, HALO_QUERY reads it,
+    // zeroes the other for the next step and flips
+    if (n <= 0 || n > state.n_pad || !(g->cell >= 0.5f * DW_CUTOFF)) return DSIM_E_ARG;
+    BinK hb;
+    memset(&hb, 0, sizeof(hb));
+    const bool fresh = ctx->dwh_ws != g->workspace || ctx->dwh_cells != ncells || ctx->dw_local_m != n;
+    if (fresh) {
+      if (g->phase == DSIM_DW_HALO_QUERY) return DSIM_E_ARG;          // HALO_BIN of this step comes first
+      halo_layout(g->workspace, ncells, n, 0, &hb);
+      hipError_t e = hipMemsetAsync(hb.count, 0, sizeof(int) * 2 * (size_t)(ncells + 2), st_);
+      if (e != hipSuccess) return (int)e;
+      ctx->dwh_ws = g->workspace; ctx->dwh_cells = ncells; ctx->dw_local_m = n; ctx->dwh_parity = 0;
+    }
+    halo_layout(g->workspace, ncells, n, ctx->dwh_parity, &hb);
+    hb.xmin = g->xmin; hb.ymin = g->ymin; hb.inv_cell = 1.0f / g->cell; hb.nx = g->nx; hb.ny = g->ny; hb.local_offset = 0;
+    if (g->phase == DSIM_DW_HALO_BIN) {
+      if (h_tot > 0) hipLaunchKernelGGL(k_dw_bin_halo, dim3(grid_for(h_tot)), dim3(256), 0, st_, hb, hk);
+      return (int)hipGetLastError();
+    }
+    // HALO_QUERY: receivers = the local grid DSIM_DW_LOCAL of this step built (the buffer before the flip)
+    if (ctx->dw_ws != g->workspace || ctx->dw_cells != ncells || ctx->dw_mode != 1) return DSIM_E_ARG;
+    memset(&a, 0, sizeof(a));
+    int rc = make_kview(state, 20 + ctx->max_act, &a.st);
+    if (rc) return rc;
+    BinK lb;
+    memset(&lb, 0, sizeof(lb));
+    bucket_layout(g->workspace, ncells, 1 - ctx->dw_parity, &lb);
+    lb.xmin = g->xmin; lb.ymin = g->ymin; lb.inv_cell = hb.inv_cell; lb.nx = g->nx; lb.ny = g->ny; lb.local_offset = 0;
+    a.types = ctx->d_types; a.type_id = g->type_id; a.n_types = ctx->n_types;
+    a.m = g->m; a.n = n; a.n_pad = state.n_pad; a.local_offset = 0;
+    a.xmin = g->xmin; a.ymin = g->ymin; a.inv_cell = hb.inv_cell; a.nx = g->nx; a.ny = g->ny;
+    a.force_out = force_out;
+    BinK nxt;
+    halo_layout(g->workspace, ncells, n, 1 - ctx->dwh_parity, &nxt);
+    a.count_next = nxt.count;
+    ctx->dwh_parity = 1 - ctx->dwh_parity;
+    if (h_tot == 0) return DSIM_OK;                                   // nothing arrived, nothing was binned: nothing to add or clear
+    // tile shape as for the local pass of this grid (the candidates of a neighbourhood are the halo's, never more)
+    launch_query_cell(ctx, st_, a, lb, hb, g->cell, n, 1);
+    return (int)hipGetLastError();
+  }
   // bucket form: cells of half the cut-off or more (two rings of neighbours below 10 m); counting-sort form: >= 10 m
-  if (!g) return DSIM_E_ARG;
   const bool bucket_form = g->nx > 0 && g->ny > 0 && dw_use_buckets(g->m, (int64_t)g->nx * g->ny);
+  if (g->halo && g->phase == DSIM_DW_ALL && ctx) ctx->dwh_ws = nullptr;   // (the one-grid form's overflow list may run over the halo grid's place)
   int rc = grid_build(ctx, st_, n, state, g, bucket_form ? 0.5f * DW_CUTOFF : DW_CUTOFF, &a, true);
   if (rc) return rc;
   a.force_out = force_out;
@@ -2650,18 +3021,38 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
     memset(&b, 0, sizeof(b));
     b.count = a.count; b.buckets = a.buckets; b.overflow = a.overflow;
     b.xmin = a.xmin; b.ymin = a.ymin; b.inv_cell = a.inv_cell; b.nx = a.nx; b.ny = a.ny; b.local_offset = a.local_offset;
-    const long long ncells = (long long)a.nx * a.ny;
-    // sparse worlds (mean occupancy of a neighbourhood <= 128 entries): one wave per cell and an 8 KB tile, so that a
-    // CU holds ~20 cells at once; dense ones (BASELINE config 5: 625 entries per neighbourhood): two waves and 12 KB —
-    // 11 cells per CU, so that the ~2 800 cells of a 65 536-drone shard are all resident in ONE round (four-wave
-    // workgroups needed 1.4 rounds of 8 per CU, and the thin second round cost 40 % of the kernel's time)
-    const int rings = g->cell >= DW_CUTOFF ? 1 : 2;
-    const double nb_mean = (double)a.m / (double)ncells * (2 * rings + 1) * (2 * rings + 1);
-    const dim3 gq((unsigned)(ncells + DW_OVF_GROUPS));
-    if (nb_mean <= 128.0) hipLaunchKernelGGL((k_dw_query_cell<64, false>), gq, dim3(64), 256 * sizeof(float4), st_, a, b, rings, 256);
-    else hipLaunchKernelGGL((k_dw_query_cell<128, true>), gq, dim3(128), 768 * sizeof(float4), st_, a, b, rings, 768);
+    if (g->halo && g->phase == DSIM_DW_ALL && h_tot > 0)              // one grid: what the peers sent goes in beside the local drones
+      hipLaunchKernelGGL(k_dw_bin_halo, dim3(grid_for(h_tot)), dim3(256), 0, st_, b, hk);
+    launch_query_cell(ctx, st_, a, b, b, g->cell, g->phase == DSIM_DW_LOCAL ? n : a.m, 0);
   }
   else hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m * DW_LPR)), dim3(256), 0, st_, a);
+  return (int)hipGetLastError();
+}
+
+int dsim_fleet_bounds(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float* out5) {
+  if (!ctx || !out5 || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
+  BoundsK a;
+  int rc = make_kview(state, 20 + ctx->max_act, &a.st);
+  if (rc) return rc;
+  a.n = n; a.keys = ctx->d_bounds; a.out = out5;
+  const long long groups = (n + 255) / 256;
+  hipLaunchKernelGGL(k_fleet_bounds, dim3((unsigned)(groups < 4LL * ctx->n_cu ? groups : 4LL * ctx->n_cu)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int dsim_halo_pack(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_halo_plan* plan) {
+  if (!ctx || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
+  int rc = halo_check(plan);
+  if (rc) return rc;
+  if (!plan->send || !plan->recv || !plan->scratch) return DSIM_E_ARG;
+  HaloK h;
+  memset(&h, 0, sizeof(h));
+  rc = make_kview(state, 20 + ctx->max_act, &h.st);
+  if (rc) return rc;
+  halo_fill(plan, &h);
+  h.n = n; h.counters = ctx->d_counters;
+  hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, h);
   return (int)hipGetLastError();
 }
 
@@ -2682,8 +3073,9 @@ static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view
                       const dsim_downwash_args* g, float min_cell, DwK* out, bool allow_buckets) {
   DwK& a_ = *out;
   if (!ctx || !g || !g->workspace || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
-  // pos_all = NULL: the world is this fleet (m = n, local_offset = 0) and positions are read from the state block
-  if (!g->pos_all && (g->m != n || g->local_offset != 0)) return DSIM_E_ARG;
+  // pos_all = NULL: the world is this fleet (m = n, local_offset = 0) and positions are read from the state block — or,
+  // with a halo plan, this fleet plus what the plan's peers sent (checked by dsim_downwash)
+  if (!g->pos_all && !g->halo && (g->m != n || g->local_offset != 0)) return DSIM_E_ARG;
   if (g->m < 1 || (g->pos_all && g->m_pad < g->m) || g->nx < 1 || g->ny < 1 || !(g->cell >= min_cell)) return DSIM_E_ARG;
   if ((long long)g->nx * g->ny > (1 << 24)) return DSIM_E_ARG;
   if (g->workspace_len < dsim_downwash_workspace(g->m, g->nx, g->ny)) return DSIM_E_ARG;
@@ -2711,8 +3103,10 @@ static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view
   ctx->dw_parity = 1 - cur;
   // local entries already binned by the previous dsim_step (dsim_step_args.bin_next) into THIS count buffer?
   const bool pre_live = same && buckets && ctx->dw_prebin;
-  const bool pre = pre_live && g->prebinned && ctx->dw_prebin_n == n && ctx->dw_prebin_off == g->local_offset &&
-                   ctx->dw_prebin_geo[0] == g->xmin && ctx->dw_prebin_geo[1] == g->ymin && ctx->dw_prebin_geo[2] == g->cell;
+  const bool pre = pre_live && ctx->dw_prebin_valid && g->prebinned && ctx->dw_prebin_n == n &&
+                   ctx->dw_prebin_off == g->local_offset && ctx->dw_prebin_geo[0] == g->xmin &&
+                   ctx->dw_prebin_geo[1] == g->ymin && ctx->dw_prebin_geo[2] == g->cell && ctx->dw_prebin_nx == g->nx &&
+                   ctx->dw_prebin_ny == g->ny;
   ctx->dw_prebin = false;
   if (buckets) {
     BinK b;
@@ -2724,10 +3118,11 @@ static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view
       hipError_t e = hipMemsetAsync(a.count, 0, sizeof(int) * cstride, st_);
       if (e != hipSuccess) return (int)e;
     }
+    const long long m_here = g->halo ? n : a.m;         // entries this pass reads through dw_pos (the halo has its own kernel)
     BinRange r;
-    r.j0 = 0; r.j1 = a.m; r.skip0 = r.skip1 = a.m;
-    long long todo = a.m;
-    if (pre) { r.skip0 = a.local_offset; r.skip1 = a.local_offset + n; todo = a.m - n; }
+    r.j0 = 0; r.j1 = m_here; r.skip0 = r.skip1 = m_here;
+    long long todo = m_here;
+    if (pre) { r.skip0 = a.local_offset; r.skip1 = a.local_offset + n; todo = m_here - n; }
     if (todo > 0) hipLaunchKernelGGL(k_dw_bin, dim3(grid_for(todo)), dim3(256), 0, st_, a, b, r);
     a_ = a;
     return DSIM_OK;

@@ -67,94 +67,254 @@ def _wire_device(dist, dev):
     return torch.device("cpu") if dist.get_backend() == "gloo" else dev
 
 
-class HaloExchange:
-    """Halo exchange of positions between the ranks of a SPATIALLY sharded fleet (BASELINE config 5: slab
-    decomposition, RCCL send/recv between neighbouring slabs only) — the alternative to the all-gather.
+class HaloWire:
+    """Host logic of the halo exchange of a SPATIALLY sharded fleet (BASELINE config 5: slabs along x, one rank per GPU),
+    on whatever device its buffers live.  The device operations are hooks — HaloPlan implements them with the library's
+    kernels; the CPU rehearsal of tests/test_sharding_cpu.py with torch on the host.
 
-    Every `refresh` Env.steps the ranks all-gather their xy bounding boxes (4 floats each, one host sync)
-    and each rank fixes, per peer, the index list of its own drones that can come within the 10 m cut-off
-    of ANY drone of that peer before the next refresh: those inside the peer's box grown by
-    `cutoff + 2 * margin`, where `margin = v_axis_max * dt_env * refresh` bounds how far a drone moves
-    along one axis in that time (Bullet clamps every coordinate velocity to `max_coord_vel`, P4) — once for
-    the sender's own motion, once for the growth of the peer's box.  Between refreshes the message sizes
-    are therefore known on the host, and one step's exchange is: gather the listed positions, one grouped
-    batch of isend/irecv (ncclGroupStart/End over xGMI point-to-point links), concatenate.  Nothing is
-    approximated: a drone that is not in the list cannot reach the cut-off, and the force kernel re-tests
-    every candidate pair with the current positions.  Ranks whose boxes are far apart exchange nothing."""
+    A message to a peer is a HEADER (nat.HALO_HDR floats: how many positions follow, and the sender's xy box at the time
+    of sending) + xyz triples, in a persistent per-peer buffer.  Every Env.step `_pack` selects, per peer, the own drones
+    inside that peer's box — as its LAST message reported it — grown by reach = cut-off + v_clamp x dt_env: the box is one
+    step old, and no coordinate can move further than that in one step (Bullet clamps every coordinate velocity to
+    max_coord_vel, P4), so the selection is exact for ANY motion — no measured-speed assumption (BASELINE config 5's
+    random world holds near-vertical pairs whose P8 term is singular: drones leave at tens of m/s).  Then ONE grouped
+    batch of isend / irecv moves the buffers.  Message sizes are fixed on the host (capacities with headroom); the
+    count travels in the header.  Only `resize` synchronises the host, every `resize_every` steps: it all-gathers the
+    boxes (seeding the headers), lets `_pack` count what would travel, all-gathers the counts and re-makes the capacities;
+    a pair of ranks whose boxes are further apart than cut-off + v_clamp x dt_env x resize_every cannot meet before the
+    next resize and exchanges nothing.  A selection that outgrows its capacity in between is dropped AND counted
+    (`_overflow`): 0 certifies that nothing was missed; a non-zero count raises at the next resize."""
 
-    def __init__(self, dist, v_axis_max: float, dt_env: float, cutoff: float = CUTOFF, refresh: int = 16):
-        self.dist, self.cutoff, self.refresh = dist, float(cutoff), int(refresh)
-        self.margin = float(v_axis_max) * float(dt_env) * self.refresh
+    def __init__(self, dist, device, cap: int, dt_env: float, v_clamp: float, cutoff: float = CUTOFF, resize_every: int = 128,
+                 headroom: float = 1.25, slack: int = 512):
+        self.dist = dist
+        self.cutoff, self.resize_every, self.dt_env, self.v_clamp = float(cutoff), int(resize_every), float(dt_env), float(v_clamp)
+        self.headroom, self.slack = float(headroom), int(slack)
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        if self.world > nat.MAX_PEERS:
+            raise ValueError(f"halo plan: at most {nat.MAX_PEERS} ranks (one node)")
+        dev = torch.device(device)
+        self.device, self.cap = dev, int(cap)
+        self.stride = nat.HALO_HDR + 3 * self.cap
+        self.gloo = dist.get_backend() == "gloo"
+        self.send = torch.zeros((self.world, self.stride), dtype=torch.float32, device=dev)
+        self.recv = torch.zeros((self.world, self.stride), dtype=torch.float32, device=dev)
+        self.bounds_dev = torch.zeros((5,), dtype=torch.float32, device=dev)
+        self.bounds_all = torch.zeros((self.world, 5), dtype=torch.float32, device=dev)
+        self.count_dev = torch.zeros((self.world,), dtype=torch.int32, device=dev)
+        self.table_dev = torch.zeros((self.world, self.world), dtype=torch.int32, device=dev)
+        self.send_cap = [0] * nat.MAX_PEERS
+        self.recv_cap = [0] * nat.MAX_PEERS
+        self.reach = [0.0] * nat.MAX_PEERS
+        self.step_reach = self.cutoff + self.v_clamp * self.dt_env
         self._age = None
-        self._send_idx, self._recv_buf = {}, {}
-        self.sent_per_step = 0            # drones this rank sends per step (diagnostic)
+        self._ops = []
+        self.bounds_host = None                   # [world, 5] of the last resize
+        self.sent_per_step = self.recv_per_step = 0          # positions selected at the last resize (what a step ships, +- the flux)
+        self._overflow_seen = 0
+        self._staged = self.gloo and dev.type == "cuda"      # gloo has no device-memory point-to-point: through pinned host memory
+        if self._staged:
+            self._h_send = torch.zeros((self.world, self.stride), dtype=torch.float32).pin_memory()
+            self._h_recv = torch.zeros((self.world, self.stride), dtype=torch.float32).pin_memory()
 
-    def _refresh(self, pos: torch.Tensor) -> None:
-        dist = self.dist
-        box = torch.cat([pos[:2].min(dim=1).values, pos[:2].max(dim=1).values]).to(torch.float32)
-        wire = _wire_device(dist, pos.device)
-        boxes = torch.empty((self.world, 4), dtype=torch.float32, device=wire)
-        dist.all_gather_into_tensor(boxes, box.reshape(1, 4).contiguous().to(wire))
-        boxes = boxes.cpu()
-        reach = self.cutoff + 2.0 * self.margin
-        mine = boxes[self.rank]
-        self._send_idx = {}
-        counts = torch.zeros((self.world,), dtype=torch.int64)
+    # ---- the device operations ----
+    def _bounds(self) -> None:
+        raise NotImplementedError                 # -> self.bounds_dev: xmin, ymin, xmax, ymax, max |coordinate velocity|
+
+    def _pack(self) -> None:
+        raise NotImplementedError                 # self.send[p] = header + positions, for every p with send_cap[p] > 0
+
+    def _overflow(self) -> int:
+        return 0                                  # positions dropped for lack of capacity so far
+
+    def _sync(self) -> None:
+        pass
+
+    def _caps_changed(self) -> None:
+        pass
+
+    # ---- collectives on small tensors (gloo with device tensors: through the host) ----
+    def _all_gather(self, out: torch.Tensor, mine: torch.Tensor) -> None:
+        if self.gloo and out.device.type == "cuda":
+            o = torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(o, mine.cpu().reshape(1, -1).contiguous())
+            out.copy_(o)
+        else:
+            self.dist.all_gather_into_tensor(out, mine.reshape(1, -1).contiguous())
+
+    def halo_total(self) -> int:
+        """Capacity of what the peers send (the upper bound of the halo's size that the grid is laid out for)."""
+        return int(sum(self.recv_cap[p] for p in range(self.world) if p != self.rank))
+
+    def messages(self):
+        return [p for p in range(self.world) if self.send_cap[p] > 0]
+
+    def resize(self) -> None:
+        """Re-makes which pairs of ranks talk and how large their messages are (class docstring): two small collectives,
+        one dry pack, ONE read-back."""
+        ov = self._overflow()
+        if ov != self._overflow_seen:
+            self._overflow_seen = ov
+            raise RuntimeError("halo plan: a selection outgrew its message since the last resize; the force of those steps may "
+                               "have missed pairs inside the cut-off (raise headroom / slack or resize more often)")
+        self._bounds()
+        self._all_gather(self.bounds_all, self.bounds_dev)
+        b = self.bounds_all.cpu().numpy()
+        self.bounds_host = b
+        far = self.cutoff + self.v_clamp * self.dt_env * self.resize_every
+        talk = [False] * nat.MAX_PEERS
         for p in range(self.world):
-            if p == self.rank:
-                continue
-            lo, hi = boxes[p, :2] - reach, boxes[p, 2:] + reach
-            if bool((mine[2:] < lo).any() or (mine[:2] > hi).any()):      # my whole box is out of that peer's reach
-                continue
-            m = (pos[0] >= lo[0]) & (pos[0] <= hi[0]) & (pos[1] >= lo[1]) & (pos[1] <= hi[1])
-            idx = torch.nonzero(m).squeeze(1)
-            if idx.numel():
-                self._send_idx[p] = idx
-                counts[p] = idx.numel()
-        table = torch.empty((self.world, self.world), dtype=torch.int64, device=wire)
-        dist.all_gather_into_tensor(table, counts.reshape(1, -1).to(wire))
-        table = table.cpu()
-        self._recv_buf = {p: torch.empty((3, int(table[p, self.rank])), dtype=pos.dtype, device=wire)
-                          for p in range(self.world) if p != self.rank and int(table[p, self.rank]) > 0}
-        self.sent_per_step = int(counts.sum())
+            if p != self.rank:
+                gap = max(b[p, 0] - b[self.rank, 2], b[self.rank, 0] - b[p, 2], b[p, 1] - b[self.rank, 3], b[self.rank, 1] - b[p, 3], 0.0)
+                talk[p] = bool(gap <= far)
+        # the peers' boxes as of now go where their messages' headers will keep them fresh
+        self.recv[:, 1:5] = self.bounds_all[:, 0:4]
+        for p in range(nat.MAX_PEERS):
+            self.send_cap[p] = self.cap if talk[p] else 0          # a dry pack counts what each talking peer would get
+            self.reach[p] = self.step_reach
+        self._caps_changed()
+        self._pack()
+        self._sync()
+        self.count_dev.copy_(self.send[:, 0].view(torch.int32))
+        self._all_gather(self.table_dev, self.count_dev)
+        table = self.table_dev.cpu()                                   # the read-back of the window
+
+        def capacity(count):
+            return int(min(self.cap, -(-int(count * self.headroom + self.slack) // 256) * 256))
+        for p in range(nat.MAX_PEERS):
+            self.send_cap[p] = capacity(table[self.rank, p]) if talk[p] else 0
+            self.recv_cap[p] = capacity(table[p, self.rank]) if talk[p] else 0
+        self.sent_per_step = int(sum(int(table[self.rank, p]) for p in range(self.world) if talk[p]))
+        self.recv_per_step = int(sum(int(table[p, self.rank]) for p in range(self.world) if talk[p]))
+        self._caps_changed()
+        # the grouped batch of the window: persistent buffers, fixed sizes
+        src, dst = (self._h_send, self._h_recv) if self._staged else (self.send, self.recv)
+        n_s = lambda p: nat.HALO_HDR + 3 * self.send_cap[p]
+        n_r = lambda p: nat.HALO_HDR + 3 * self.recv_cap[p]
+        self._ops = [self.dist.P2POp(self.dist.isend, src[p, : n_s(p)], p) for p in range(self.world) if self.send_cap[p]]
+        self._ops += [self.dist.P2POp(self.dist.irecv, dst[p, : n_r(p)], p) for p in range(self.world) if self.recv_cap[p]]
         self._age = 0
 
-    def exchange(self, local_pos: torch.Tensor) -> torch.Tensor:
-        """local_pos [3, n] -> [3, n + halo]: this rank's drones first (local_offset = 0), then the halo
-        drones received from the peers."""
-        pos = local_pos.contiguous()
-        if self._age is None or self._age >= self.refresh:
-            self._refresh(pos)
-        self._age += 1
-        dist = self.dist
-        ops, keep = [], []
-        for p, idx in self._send_idx.items():
-            buf = pos.index_select(1, idx).contiguous().to(self._recv_wire(pos))
-            keep.append(buf)
-            ops.append(dist.P2POp(dist.isend, buf, p))
-        for p, buf in self._recv_buf.items():
-            ops.append(dist.P2POp(dist.irecv, buf, p))
-        if ops:
-            for r in dist.batch_isend_irecv(ops):
-                r.wait()
-        return torch.cat([pos] + [self._recv_buf[p].to(pos.device) for p in sorted(self._recv_buf)], dim=1)
+    def due(self) -> bool:
+        return self._age is None or self._age >= self.resize_every
 
-    def _recv_wire(self, pos):
-        return _wire_device(self.dist, pos.device)
+    def _wire(self, sync=None) -> None:
+        """The packed buffers travel: one grouped batch (ncclGroupStart/End over xGMI point-to-point on RCCL)."""
+        if not self._ops:
+            return
+        if self._staged:
+            for p in range(self.world):
+                if self.send_cap[p]:
+                    k = nat.HALO_HDR + 3 * self.send_cap[p]
+                    self._h_send[p, :k].copy_(self.send[p, :k], non_blocking=True)
+            sync()                                                     # the rehearsal path synchronises the host here
+        for w in self.dist.batch_isend_irecv(self._ops):
+            w.wait()                                                   # RCCL: a stream-level wait, the host runs on
+        if self._staged:
+            for p in range(self.world):
+                if self.recv_cap[p]:
+                    k = nat.HALO_HDR + 3 * self.recv_cap[p]
+                    self.recv[p, :k].copy_(self._h_recv[p, :k], non_blocking=True)
+
+    def exchange(self) -> None:
+        if self.due():
+            self.resize()
+        self._age += 1
+        self._pack()
+        self._wire()
+
+    def received_positions(self) -> torch.Tensor:
+        """[3, halo] of what the peers sent last (host-synchronous: reads the headers' counts; tests and the rare
+        counting-sort form of the grid)."""
+        parts = []
+        for p in range(self.world):
+            if self.recv_cap[p]:
+                k = min(int(self.recv[p, 0:1].view(torch.int32)[0]), self.recv_cap[p])
+                parts.append(self.recv[p, nat.HALO_HDR: nat.HALO_HDR + 3 * k].reshape(k, 3))
+        if not parts:
+            return torch.zeros((3, 0), dtype=torch.float32, device=self.device)
+        return torch.cat(parts, dim=0).T.contiguous()
+
+
+class HaloPlan(HaloWire):
+    """HaloWire on the device, device-paced.  Everything per-step is preallocated and enqueued, nothing synchronises
+    the host:
+
+        side stream:  dsim_halo_pack (selection against the peers' boxes + packing + headers, one launch) -> ONE grouped
+                      batch of isend/irecv on persistent per-peer buffers -> dsim_downwash(DSIM_DW_HALO_BIN)
+        main stream:  dsim_downwash(DSIM_DW_LOCAL) — the local part of the query runs while the positions are on the
+                      wire — wait(side) -> dsim_downwash(DSIM_DW_HALO_QUERY) -> dsim_step
+
+    DSIM_Q_HALO_OVERFLOW counts what a message could not hold.  The gloo backend (rehearsal ranks sharing one GPU) stages
+    the packed buffers through pinned host memory, which synchronises the host: a rehearsal of the logic, not of the
+    pacing."""
+
+    def __init__(self, ctx, state, dist, dt_env: float, v_clamp: float, cutoff: float = CUTOFF, resize_every: int = 128,
+                 headroom: float = 1.25, slack: int = 512):
+        super().__init__(dist, ctx.device, state.n_pad, dt_env, v_clamp, cutoff, resize_every, headroom, slack)
+        self.ctx, self.state = ctx, state
+        self.scratch = torch.zeros((32,), dtype=torch.int32, device=ctx.device)
+        self.plan = nat.HaloPlan()
+        self.plan.world, self.plan.rank, self.plan.cap = self.world, self.rank, self.cap
+        self.plan.send, self.plan.recv, self.plan.scratch = self.send.data_ptr(), self.recv.data_ptr(), self.scratch.data_ptr()
+        self.side = torch.cuda.Stream(device=ctx.device)
+        self.ev_ready = torch.cuda.Event()        # main -> side: the positions of this step are final
+        self.ev_halo = torch.cuda.Event()         # side -> main: the halo grid is filled
+        self.timing = None                        # a list: every step appends (start, end) events of its side-stream part
+
+    def _bounds(self) -> None:
+        st = self.state
+        nat.check(self.ctx.lib.dsim_fleet_bounds(self.ctx.handle, self.ctx.stream_ptr(), st.n, st.view(), self.bounds_dev.data_ptr()))
+
+    def _pack(self) -> None:
+        st = self.state
+        nat.check(self.ctx.lib.dsim_halo_pack(self.ctx.handle, self.ctx.stream_ptr(), st.n, st.view(), ctypes.byref(self.plan)))
+
+    def _sync(self) -> None:
+        torch.cuda.current_stream(self.ctx.device).synchronize()
+
+    def _overflow(self) -> int:
+        return self.overflow()
+
+    def _caps_changed(self) -> None:
+        for p in range(nat.MAX_PEERS):
+            self.plan.send_cap[p], self.plan.recv_cap[p], self.plan.reach[p] = self.send_cap[p], self.recv_cap[p], self.reach[p]
+
+    def overflow(self) -> int:
+        """Positions that a message could not hold so far (synchronises the stream); 0 = nothing was ever missed."""
+        return self.ctx.query(nat.QUERY_HALO_OVERFLOW)
+
+    def exchange(self) -> None:
+        """Select + pack, send/recv — enqueued on the side stream behind `ev_ready`; the caller bins what arrived
+        (DSIM_DW_HALO_BIN) on the same stream and records `ev_halo`."""
+        if self.due():
+            self.resize()                              # (main stream, host-synchronous, every resize_every steps)
+        main = torch.cuda.current_stream(self.ctx.device)
+        self.ev_ready.record(main)
+        self.side.wait_event(self.ev_ready)
+        self._age += 1
+        if self.timing is not None:
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record(self.side)
+        if not self._ops:
+            return
+        with torch.cuda.stream(self.side):
+            self._pack()
+            self._wire(self.side.synchronize)
 
 
 class Downwash:
     """Evaluates formula P8 for the drones of one env/state block against world positions."""
 
     def __init__(self, ctx, state, type_id: Optional[torch.Tensor] = None, dist=None, cell: Optional[float] = None,
-                 box_refresh: int = 256, halo: Optional[HaloExchange] = None):
+                 box_refresh: int = 256, halo: Optional[HaloPlan] = None, split: bool = True):
         # cell = None: 5 m cells (half the cut-off, 5 x 5 cells scanned per drone: 30 % fewer candidate pairs than
         # 3 x 3 cells of 10 m) whenever the world's shape takes the bucket form of the grid, 10 m cells otherwise
         self.ctx, self.state, self.type_id, self.dist = ctx, state, type_id, dist
         self._auto_cell = cell is None
         self.cell = 0.5 * CUTOFF if cell is None else float(cell)
         self.halo = halo                 # None: all-gather of the world's positions (any index sharding)
+        self.split = bool(split)         # halo form: local pass beside the exchange, then a halo pass (False: one grid, one pass)
         self.force = torch.zeros((3, state.n_pad), dtype=torch.float32, device=ctx.device)
         self._counts = None              # drones per rank (all-gather form; fetched once)
         self._last = None                # DownwashArgs of the last compute(): the grid a step kernel may fill for the next
@@ -162,15 +322,20 @@ class Downwash:
         self._ws = None
         self._box = None                 # (xmin, ymin, nx, ny): a search-efficiency hint, never a correctness input
         self._box_age, self._box_refresh = 0, box_refresh
+        self._gather_out = None          # all-gather form: the preallocated [world * 3, n_max] receive buffer
 
-    def _grid_box(self, wp: torch.Tensor):
+    def _grid_box(self, wp, lo_hi=None):
         """Bounding box of the world in xy -> grid.  Drones that later leave the box are clamped to
         its border cells by the kernels (pairs within 10 m stay in adjacent cells), so a stale box
-        only costs search efficiency; it is re-measured every `box_refresh` calls (one host sync)."""
-        if self._box is None or self._box_age >= self._box_refresh:
-            assert wp is not None
-            lo = wp[:2].min(dim=1).values.cpu()
-            hi = wp[:2].max(dim=1).values.cpu()
+        only costs search efficiency; it is re-measured every `box_refresh` calls (one host sync), or, with a halo
+        plan, taken from the bounds its refresh has already read back (lo_hi)."""
+        if self._box is None or self._box_age >= self._box_refresh or lo_hi is not None:
+            if lo_hi is not None:
+                lo, hi = lo_hi
+            else:
+                assert wp is not None
+                lo = wp[:2].min(dim=1).values.cpu()
+                hi = wp[:2].max(dim=1).values.cpu()
             xmin, ymin = float(lo[0]) - self.cell, float(lo[1]) - self.cell
             nx = max(1, int(math.floor((float(hi[0]) + self.cell - xmin) / self.cell)) + 1)
             ny = max(1, int(math.floor((float(hi[1]) + self.cell - ymin) / self.cell)) + 1)
@@ -181,6 +346,21 @@ class Downwash:
         self._box_age += 1
         return self._box
 
+    def _fill(self, wp, m, local_offset, box) -> nat.DownwashArgs:
+        xmin, ymin, nx, ny = box
+        a = nat.DownwashArgs()
+        a.pos_all, a.m, a.m_pad = (wp.data_ptr() if wp is not None else None), m, m
+        a.xmin, a.ymin, a.cell, a.nx, a.ny = xmin, ymin, self.cell, nx, ny
+        a.type_id = self.type_id.data_ptr() if self.type_id is not None else None
+        a.local_offset = int(local_offset or 0)
+        a.prebinned, a.phase, a.halo = 0, nat.DW_ALL, None
+        return a
+
+    def _workspace(self, a, need) -> None:
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((int(need),), dtype=torch.int32, device=self.ctx.device)
+        a.workspace, a.workspace_len = self._ws.data_ptr(), self._ws.numel()
+
     def _grid_args(self, world_pos, local_offset) -> nat.DownwashArgs:
         st = self.state
         single = (world_pos is None and self.halo is None
@@ -189,39 +369,43 @@ class Downwash:
             # the world is this fleet: the kernels read positions straight from the state block (no gathered copy)
             wp, m = None, st.n
             local_offset = 0
-            box_src = st.fields(0, 2) if (self._box is None or self._box_age >= self._box_refresh) else None
-        elif world_pos is None and self.halo is not None:
-            world_pos, local_offset = self.halo.exchange(st.fields(0, 3)[:, : st.n]), 0
+            box_src = st.raw_fields(0, 2) if (self._box is None or self._box_age >= self._box_refresh) else None
         elif world_pos is None:
             if self._counts is None:
                 self._counts = shard_counts(st.n, self.dist)
-            world_pos = gather_positions(st.fields(0, 3), self.dist, self._counts)
+            world_pos = self._gather(st.raw_fields(0, 3))
             rank = self.dist.get_rank() if (self.dist is not None and self.dist.is_initialized()) else 0
             local_offset = sum(self._counts[:rank])
         if not single:
             wp = world_pos.to(torch.float32).contiguous()
             m = wp.shape[1]
             box_src = wp
-        xmin, ymin, nx, ny = self._grid_box(box_src)
-        if self._auto_cell and self.cell < CUTOFF and (m < 4 * nx * ny or not self.ctx.lib.dsim_downwash_prebin_ok(m, nx, ny)):
+        box = self._grid_box(box_src)
+        if self._auto_cell and self.cell < CUTOFF and (m < 4 * box[2] * box[3] or not self.ctx.lib.dsim_downwash_prebin_ok(m, box[2], box[3])):
             # sparse world (fewer than 4 drones per 5 m cell: four times fewer, fuller cells serve it better), or too
             # many cells / too dense for the bucket form (the counting-sort form wants cells of the full cut-off)
             self.cell, self._box = CUTOFF, None
             if box_src is None:
-                box_src = st.fields(0, 2) if single else wp
-            xmin, ymin, nx, ny = self._grid_box(box_src)
-        need = self.ctx.lib.dsim_downwash_workspace(m, nx, ny)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty((need,), dtype=torch.int32, device=self.ctx.device)
-        a = nat.DownwashArgs()
-        a.pos_all, a.m, a.m_pad = (wp.data_ptr() if wp is not None else None), m, m
-        a.xmin, a.ymin, a.cell, a.nx, a.ny = xmin, ymin, self.cell, nx, ny
-        a.workspace, a.workspace_len = self._ws.data_ptr(), self._ws.numel()
-        a.type_id = self.type_id.data_ptr() if self.type_id is not None else None
-        a.local_offset = int(local_offset or 0)
-        a.prebinned = 0
+                box_src = st.raw_fields(0, 2) if single else wp
+            box = self._grid_box(box_src)
+        a = self._fill(wp, m, local_offset, box)
+        self._workspace(a, self.ctx.lib.dsim_downwash_workspace(m, box[2], box[3]))
         self._keep = wp                     # the kernels read it asynchronously on the stream
         return a
+
+    def _gather(self, local_pos: torch.Tensor) -> torch.Tensor:
+        """All-gather form with equal shards on RCCL: one collective into a preallocated buffer, one strided copy into
+        global drone order; anything else (unequal shards, gloo) goes through gather_positions."""
+        dist, counts = self.dist, self._counts
+        if dist.get_backend() == "gloo" or any(c != counts[0] for c in counts) or local_pos.shape[1] != counts[0]:
+            return gather_positions(local_pos, dist, counts)
+        world, nmax = len(counts), counts[0]
+        if self._gather_out is None or self._gather_out.shape != (world * 3, nmax):
+            self._gather_out = torch.empty((world * 3, nmax), dtype=torch.float32, device=local_pos.device)
+            self._gather_wp = torch.empty((3, world * nmax), dtype=torch.float32, device=local_pos.device)
+        dist.all_gather_into_tensor(self._gather_out, local_pos.contiguous())
+        self._gather_wp.view(3, world, nmax).copy_(self._gather_out.view(world, 3, nmax).permute(1, 0, 2))
+        return self._gather_wp
 
     # ---- the step kernel fills the next step's grid (dsim_step_args.bin_next) ------------------------------------
     def bin_next_ptr(self):
@@ -242,11 +426,70 @@ class Downwash:
         """Returns the SoA [3, n_pad] body-frame force (x = y = 0) to pass as ``ext_force``.
         ``world_pos`` [3, m]: positions of every drone of the world with this block's drones at
         ``local_offset`` (default: gathered from the ranks' states / the block alone)."""
+        if self.halo is not None and world_pos is None:
+            return self._compute_halo()
         a = self._grid_args(world_pos, local_offset)
         a.prebinned = int(self._prebin_version is not None and self._prebin_version == self.state.version)
         self._prebin_version = None
         nat.check(self.ctx.lib.dsim_downwash(self.ctx.handle, self.ctx.stream_ptr(), self.state.n, self.state.view(),
                                              ctypes.byref(a), self.force.data_ptr()))
+        self._last = a
+        return self.force
+
+    def _compute_halo(self) -> torch.Tensor:
+        """Spatially sharded fleet: the rest of the world is what the halo plan's peers send (class HaloPlan)."""
+        lib, h, st, hp = self.ctx.lib, self.ctx.handle, self.state, self.halo
+        resized = hp.due()
+        hp.exchange()                                    # (resize when due: host-synchronous, rare) side stream: pack, send / recv
+        if resized:
+            # the grid covers this rank's box grown by what can happen before the next resize on every side (what lies
+            # beyond is clamped to the border cells: exact, see _grid_box); re-made from bounds that are on the host anyway
+            b = hp.bounds_host[hp.rank]
+            grow = hp.cutoff + min(hp.v_clamp * hp.dt_env * hp.resize_every, 2.0 * hp.cutoff)
+            self._halo_box = self._grid_box(None, ((b[0] - grow, b[1] - grow), (b[2] + grow, b[3] + grow)))
+            m = st.n + hp.halo_total()
+            if self._auto_cell and self.cell < CUTOFF and m < 4 * self._halo_box[2] * self._halo_box[3]:
+                self.cell = CUTOFF
+                self._halo_box = self._grid_box(None, ((b[0] - grow, b[1] - grow), (b[2] + grow, b[3] + grow)))
+        box = self._halo_box
+        m = st.n + hp.halo_total()
+        if not lib.dsim_downwash_prebin_ok(m, box[2], box[3]):
+            # a world too dense or too vast for the bucket form: one array, the counting-sort form (no overlap)
+            torch.cuda.current_stream(self.ctx.device).wait_stream(hp.side)
+            wp = torch.cat([st.raw_fields(0, 3), hp.received_positions()], dim=1).contiguous()
+            m = wp.shape[1]
+            a = self._fill(wp, m, 0, box)
+            self._workspace(a, lib.dsim_downwash_workspace(m, box[2], box[3]))
+            self._keep = wp
+            self._prebin_version = None
+            nat.check(lib.dsim_downwash(h, self.ctx.stream_ptr(), st.n, st.view(), ctypes.byref(a), self.force.data_ptr()))
+            self._last = None
+            return self.force
+        a = self._fill(None, m, 0, box)
+        a.halo = ctypes.addressof(hp.plan)
+        self._workspace(a, lib.dsim_downwash_workspace_halo(st.n, hp.halo_total(), box[2], box[3]))
+        a.prebinned = int(self._prebin_version is not None and self._prebin_version == self.state.version)
+        self._prebin_version = None
+        main = torch.cuda.current_stream(self.ctx.device)
+        if not self.split:
+            main.wait_stream(hp.side)
+            a.phase = nat.DW_ALL
+            nat.check(lib.dsim_downwash(h, main.cuda_stream, st.n, st.view(), ctypes.byref(a), self.force.data_ptr()))
+            self._last = a
+            return self.force
+        a.phase = nat.DW_HALO_BIN                        # side stream, behind the receives
+        nat.check(lib.dsim_downwash(h, hp.side.cuda_stream, st.n, st.view(), ctypes.byref(a), None))
+        hp.ev_halo.record(hp.side)
+        if hp.timing is not None:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record(hp.side)
+            hp.timing.append((hp._t0, t1))
+        a.phase = nat.DW_LOCAL                           # main stream: overlaps the exchange
+        nat.check(lib.dsim_downwash(h, main.cuda_stream, st.n, st.view(), ctypes.byref(a), self.force.data_ptr()))
+        main.wait_event(hp.ev_halo)
+        a.phase, a.prebinned = nat.DW_HALO_QUERY, 0
+        nat.check(lib.dsim_downwash(h, main.cuda_stream, st.n, st.view(), ctypes.byref(a), self.force.data_ptr()))
+        a.phase = nat.DW_LOCAL                           # what a step kernel that bins ahead is told about the next grid
         self._last = a
         return self.force
 

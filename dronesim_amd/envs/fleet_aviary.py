@@ -85,6 +85,8 @@ class CtrlAviary:
         neighbors_k: int = 0,
         options: int = 0,
         ground_plane: Optional[bool] = None,
+        storage: str = "auto",
+        downwash_split: bool = True,
     ):
         if gui or record or obstacles:
             raise NotImplementedError("gui/record/obstacles are rendering features outside the hot path")
@@ -150,6 +152,20 @@ class CtrlAviary:
         self.dict_io = (num_drones <= DICT_IO_MAX_DRONES) if dict_io is None else dict_io
 
         self.ctx = Context(types, device)
+        # Storage order.  Drones are independent on the path, so a heterogeneous fleet in ARBITRARY order (BASELINE
+        # config 5: even index quad, odd index hexa) is stored type-major — a stable sort by type, no padding slots — and
+        # every type becomes one run for the single-type kernel of its kind (dsim_step_args.runs).  Everything the caller
+        # passes or reads keeps its own numbering: fleet.StorageOrder translates in the accessors.  storage="caller"
+        # keeps the caller's order in HBM (the mixed-fleet kernel then partitions every tile by type).
+        if storage not in ("auto", "caller"):
+            raise ValueError(storage)
+        self.order = None
+        if len(types) > 1 and storage == "auto":
+            from ..fleet import StorageOrder, type_runs as _tr
+            if len(_tr(tid)) > len(types):             # not grouped by type already
+                self.order = StorageOrder(tid, self.ctx.device)
+                self.ctx.order = self.order
+                tid = self.order.types_storage
         if layout is None:
             # plain SoA [F][n_pad] is the simplest view for small fleets; from a few hundred thousand drones on the
             # wave-tiled form [n/64][F][64] is 3-8 % faster (power-of-two field strides alias HBM channels)
@@ -166,7 +182,7 @@ class CtrlAviary:
         if len(types) > 1:
             from ..fleet import type_runs
             runs = type_runs(tid)
-            if all(f % 256 == 0 for f, _, _ in runs) and len(runs) <= 64:
+            if len(runs) <= 64:                        # (a run may start anywhere: the launch begins at the tile that holds it)
                 arr = (nat.TypeRun * len(runs))()
                 for k, (f, c, ty) in enumerate(runs):
                     arr[k].first, arr[k].count, arr[k].type = f, c, ty
@@ -190,15 +206,25 @@ class CtrlAviary:
         # Physics.PYB_DW: neighbour downwash (BaseAviary.py:534-536, 1736-1763); `dist` = an initialised
         # torch.distributed module when the world's fleet is sharded over several ranks
         self._downwash = None
+        self._fb_event = None             # a deferred WLS fallback pass is in flight on the side stream
+        self._fb_stream = None
         if physics in (Physics.PYB_DW, Physics.PYB_GND_DRAG_DW):
-            from ..downwash import Downwash, HaloExchange
+            from ..downwash import Downwash, HaloPlan
             halo = None
             if downwash_exchange == "halo" and dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
                 # spatially sharded fleet: positions travel between neighbouring slabs only
-                halo = HaloExchange(dist, max(t.max_coord_vel for t in self.types), self.AGGR_PHY_STEPS * self.TIMESTEP)
+                halo = HaloPlan(self.ctx, self.state, dist, self.AGGR_PHY_STEPS * self.TIMESTEP,
+                                max(t.max_coord_vel for t in self.types))
             elif downwash_exchange not in ("allgather", "halo"):
                 raise ValueError(downwash_exchange)
-            self._downwash = Downwash(self.ctx, self.state, self._type_id, dist, halo=halo)
+            self._downwash = Downwash(self.ctx, self.state, self._type_id, dist, halo=halo, split=downwash_split)
+            if self.n_act == 6:
+                # the WLS fallback pass of a step (normally an empty queue) runs on a side stream beside the NEXT step's
+                # neighbour query instead of between the two on one stream (DSIM_OPT_DEFER_FALLBACK); everything that
+                # reads the commands joins it first (_join_fallback)
+                self._fb_stream = torch.cuda.Stream(device=self.ctx.device)
+                self._fb_done, self._fb_go = torch.cuda.Event(), torch.cuda.Event()
+                self.state.pre_access = self._join_fallback
         self.step_counter = 0
         self._env_steps = 0
         # what the ctx owns for this fleet size is allocated now, not inside the first step
@@ -208,8 +234,27 @@ class CtrlAviary:
     # ------------------------------------------------------------------ helpers
     def _soa3(self, a: np.ndarray) -> torch.Tensor:
         t = torch.zeros((3, self.state.n_pad), dtype=torch.float32)
+        if self.order is not None:
+            a = self.order.to_storage_np(a)
         t[:, : self.NUM_DRONES] = torch.from_numpy(np.ascontiguousarray(a.T)).float()
         return t.to(self.ctx.device)
+
+    def _join_fallback(self) -> None:
+        """Orders the current stream behind a deferred WLS fallback pass (see __init__)."""
+        if self._fb_event is not None:
+            torch.cuda.current_stream(self.ctx.device).wait_event(self._fb_event)
+            self._fb_event = None
+
+    def _defer_fallback(self) -> None:
+        """Launches the fallback pass of the step just enqueued on the side stream."""
+        main = torch.cuda.current_stream(self.ctx.device)
+        self._fb_go.record(main)
+        self._fb_stream.wait_event(self._fb_go)
+        nat.check(self.ctx.lib.dsim_wls_fallback(self.ctx.handle, self._fb_stream.cuda_stream, self.NUM_DRONES,
+                                                 self.state.view(), self._type_id.data_ptr() if self._type_id is not None else None,
+                                                 None))
+        self._fb_done.record(self._fb_stream)
+        self._fb_event = self._fb_done
 
     def step_args(self, dt_ctrl: Optional[float] = None, options: int = 0) -> nat.StepArgs:
         a = nat.StepArgs()
@@ -225,9 +270,11 @@ class CtrlAviary:
         a.wp_table = a.wp_counter = a.wp_offset = None
         a.n_wp, a.n_steps = 0, 1
         a.ext_force = self._downwash.compute().data_ptr() if self._downwash is not None else None
+        self._join_fallback()          # (behind the neighbour query, which does not read the commands)
         if self._runs is not None:
             a.runs, a.n_runs = ctypes.addressof(self._runs), len(self._runs)
         a.obs_out, a.obs_width, a.bin_next = None, 0, None
+        a.drone_id = self.order.drone_id(self.state.n_pad).data_ptr() if self.order is not None else None
         return a
 
     # ------------------------------------------------------------------ gym surface
@@ -238,6 +285,7 @@ class CtrlAviary:
 
     def materialize(self):
         """Ends a chained sequence: last_vel / last_rates are written back into the state block."""
+        self._join_fallback()
         self._fused_plan = None
         if self._chain_live:
             nat.check(self.ctx.lib.dsim_materialize(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
@@ -278,7 +326,7 @@ class CtrlAviary:
         self._use_last_action = True
         self.step_counter += self.AGGR_PHY_STEPS
         self._env_steps += 1
-        return self._computeObs(obs), self._computeReward(), self._computeDone(), self._computeInfo()
+        return self._computeObs(self._rows_to_caller(obs)), self._computeReward(), self._computeDone(), self._computeInfo()
 
     def step_fused(self, targets, control_timestep: Optional[float] = None, action=None, n_steps: int = 1):
         """One launch = ``env.step(action)`` followed by ``computeControl`` for every drone:
@@ -317,8 +365,12 @@ class CtrlAviary:
             tview = targets.view()
         if action is not None:
             args.action = self._action_ptr(action)
+        defer = False
         if self._downwash is not None:
             args.bin_next = self._downwash.bin_next_ptr()      # the step kernel fills the next step's neighbour grid
+            if self._fb_stream is not None:
+                args.options |= nat.OPT_DEFER_FALLBACK
+                defer = True
         self._use_last_action = False   # from here on the applied action IS the controller cmd
         chain = (self._chained_enabled and self._chain_ok and action is None and self._type_id is None
                  and self.n_act == 4 and args.ext_force is None and self._phys_options == 0)
@@ -330,6 +382,8 @@ class CtrlAviary:
         sview = self.state.view()
         nat.check(self.ctx.lib.dsim_step(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
                                          sview, tview, ctypes.byref(args)))
+        if defer:
+            self._defer_fallback()
         self._chain_ok = True
         self.step_counter += self.AGGR_PHY_STEPS * n_steps
         self._env_steps += n_steps
@@ -359,8 +413,10 @@ class CtrlAviary:
     def ground_contacts(self) -> int:
         """Drone x Env.steps so far that ended with the vehicle's collision cylinder at or below z = 0 (cumulative over
         this env's context; synchronises the stream).  The reference's PyBullet world has a ground plane with
-        collisions on (BaseAviary.py:680); contact is not modelled here, so a non-zero count means part of the
-        flight lies outside the domain in which trajectories are comparable with the reference."""
+        collisions on (BaseAviary.py:680).  With ``ground_plane=False`` (the default for large fleets: the flight
+        kernels) contact is not modelled, and a non-zero count means part of the flight lies outside the domain in
+        which trajectories are comparable with the reference; with ``ground_plane=True`` (the default for
+        reference-sized fleets) the product-defined contact model of DSIM_OPT_PLANE acts there instead."""
         return self.ctx.query(nat.QUERY_GROUND_CONTACTS)
 
     def close(self):
@@ -380,7 +436,10 @@ class CtrlAviary:
     def _action_ptr(self, action) -> int:
         """Device pointer of the action as SoA [n_act][n_pad].  A tensor that already IS such an array (the command
         a bound ``INDIControl`` returns is the transposed view of one) is passed through without a copy."""
-        if torch.is_tensor(action) and action.is_cuda and action.dtype == torch.float32:
+        tok = getattr(self, "_cmd_token", None)
+        if tok is not None and action is tok[0] and action._version == tok[1]:
+            return tok[2].data_ptr()     # the command a bound controller just returned: its storage-order array, no copy
+        if self.order is None and torch.is_tensor(action) and action.is_cuda and action.dtype == torch.float32:
             base = action.T if (action.ndim == 2 and action.shape[1] == self.n_act and action.shape[0] != self.n_act) else action
             if (base.ndim == 2 and base.shape[0] == self.n_act and base.stride() == (self.state.n_pad, 1)
                     and base.shape[1] <= self.state.n_pad and base.shape[1] >= self.NUM_DRONES):
@@ -401,20 +460,25 @@ class CtrlAviary:
             for k, v in action.items():
                 v = np.asarray(v, dtype=np.float32)
                 a[: v.shape[0], int(k)] = v
-            self._action_buf[:, :n] = torch.from_numpy(a).to(self.ctx.device)
+            t = torch.from_numpy(a).to(self.ctx.device)
         else:
             t = torch.as_tensor(action, dtype=torch.float32, device=self.ctx.device)
             if t.shape == (n, self.n_act):
                 t = t.T
-            self._action_buf[:, :n] = t
+        self._action_buf[:, :n] = t if self.order is None else self.order.to_storage(t, 1)
+
+    def _rows_to_caller(self, rows: torch.Tensor) -> torch.Tensor:
+        """Observation rows as the kernels write them (one per storage slot) -> the caller's numbering."""
+        return rows if self.order is None else self.order.to_caller(rows, 0)
 
     def observe(self) -> torch.Tensor:
         """[N, 16+n_act] rows of _getDroneStateVector (BaseAviary.py:780-790), on device."""
         self._obs_tensor()
+        self._join_fallback()
         la = self._last_action.data_ptr() if self._use_last_action else None
         nat.check(self.ctx.lib.dsim_observe(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
                                             self.state.view(), la, self._obs_buf.data_ptr(), 16 + self.n_act))
-        return self._obs_buf
+        return self._rows_to_caller(self._obs_buf)
 
     def neighbors(self, max_k: Optional[int] = None):
         """Fleet-scale form of the observation's ``neighbors`` entry (BaseAviary._getAdjacencyMatrix,
@@ -429,7 +493,13 @@ class CtrlAviary:
         if self._downwash is not None:
             self._downwash.invalidate_prebin()            # the adjacency pass re-uses the ctx's grid bookkeeping
         k = self.neighbors_k if max_k is None else int(max_k)
-        return self._adjacency.adjacency(float(self.NEIGHBOURHOOD_RADIUS), max_k=k)
+        cnt, lst = self._adjacency.adjacency(float(self.NEIGHBOURHOOD_RADIUS), max_k=k)
+        if self.order is not None:              # per-slot results of slot indices -> per-drone results of drone indices
+            cnt = self.order.to_caller(cnt, 0)
+            if lst is not None:
+                lst = self.order.to_caller(lst, 1).long()
+                lst = torch.where(lst >= 0, self.order.drone[lst.clamp(min=0)], lst).to(torch.int32)
+        return cnt, lst
 
     def _getAdjacencyMatrix(self, pos: np.ndarray) -> np.ndarray:
         """BaseAviary.py:901-921 — O(N^2), only produced in dict mode (small fleets)."""

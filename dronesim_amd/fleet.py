@@ -39,6 +39,10 @@ class Context:
         nat.check(self.lib.dsim_create(ctypes.byref(self._h), device, self._c_types, len(self.types)))
         self.n_act = max(t.n_act for t in self.types)
         self.n_fields = nat.NF_QUAD if self.n_act <= 4 else nat.NF_HEXA
+        # StorageOrder of the fleet this context serves, or None: set by an env that stores an interleaved heterogeneous
+        # fleet type-major; every per-drone block built on this context for that fleet (state, targets, waypoint
+        # counters) then translates between the caller's numbering and the storage slots
+        self.order = None
 
     @property
     def handle(self):
@@ -77,6 +81,60 @@ def type_runs(type_ids) -> list:
     return [(int(f), int(c), int(t[f])) for f, c in zip(first, count)]
 
 
+class StorageOrder:
+    """Drones are independent on the path, so the order in which a fleet is STORED is free.  A
+    heterogeneous fleet in arbitrary order (BASELINE config 5: even index quad, odd index hexa) is stored type-major —
+    a stable sort by type id, a pure permutation of [0, n) with no padding slots — so that every type is one run that
+    the single-type kernel of its kind steps (dsim_step_args.runs: 0.78 of HBM instead of the mixed-fleet kernel's 0.64),
+    while everything the caller sees (initial positions, targets, actions, observations, state accessors) keeps the
+    caller's numbering.  slot[d] = storage slot of drone d; drone[s] = drone stored in slot s."""
+
+    def __init__(self, type_ids, device):
+        t = np.asarray(type_ids).astype(np.int64).ravel()
+        self.n = int(t.size)
+        self.drone_np = np.argsort(t, kind="stable")
+        self.slot_np = np.empty_like(self.drone_np)
+        self.slot_np[self.drone_np] = np.arange(self.n)
+        self.types_storage = t[self.drone_np].astype(np.uint8)
+        self.slot = torch.from_numpy(self.slot_np).to(device)            # int64: index_select indices
+        self.drone = torch.from_numpy(self.drone_np).to(device)
+        self._drone_id = {}
+
+    def drone_id(self, n_pad: int) -> torch.Tensor:
+        """int32 [n_pad] for dsim_step_args.drone_id (padding slots map to themselves)."""
+        if n_pad not in self._drone_id:
+            d = np.arange(n_pad, dtype=np.int32)
+            d[: self.n] = self.drone_np
+            self._drone_id[n_pad] = torch.from_numpy(d).to(self.slot.device)
+        return self._drone_id[n_pad]
+
+    def to_storage(self, values: torch.Tensor, dim: int = -1) -> torch.Tensor:
+        """values indexed by drone along `dim` -> indexed by slot."""
+        return values.index_select(dim, self.drone.to(values.device))
+
+    def to_caller(self, values: torch.Tensor, dim: int = -1) -> torch.Tensor:
+        return values.index_select(dim, self.slot.to(values.device))
+
+    def to_storage_np(self, a: np.ndarray, axis: int = 0) -> np.ndarray:
+        return np.take(a, self.drone_np, axis=axis)
+
+
+class Frozen:
+    """A per-drone device tensor the caller promises not to write while it keeps passing it (``frozen(t)``):
+    ``Targets.set`` copies it into the target block the first time and skips the fleet-sized copy on every later
+    call with the SAME object (the reference-shaped loop hands computeControl the same target_pos every iteration,
+    examples/fly_INDI.py:229-239).  A plain tensor is always copied: torch's write counter does not see what this
+    library's own kernels write through raw pointers (the state block, observation rows, a sampled trajectory), so an
+    unchanged counter proves nothing."""
+
+    def __init__(self, tensor: torch.Tensor):
+        self.tensor = tensor
+
+
+def frozen(tensor: torch.Tensor) -> Frozen:
+    return Frozen(tensor)
+
+
 def type_major_order(type_ids, align: int = 256):
     """Storage order for a heterogeneous fleet: drones grouped by type, each group starting at a multiple of
     `align` (the gaps are padding slots).  Returns (slot_of_drone [n] int64, n_slots, slot_types [n_slots] uint8):
@@ -103,9 +161,11 @@ class BlockedSoA:
                                                    contiguous 4B-byte row; n_pad is rounded up to a multiple of B)
     """
 
-    def __init__(self, n: int, n_fields: int, device, layout: str = "soa", pad: int = 256):
+    def __init__(self, n: int, n_fields: int, device, layout: str = "soa", pad: int = 256, order=None):
         self.n, self.n_fields, self.layout = n, n_fields, layout
         self.version = 0            # bumped by every host-side write (set_fields): caches keyed on the contents check it
+        self.order = order if (order is not None and order.n == n) else None    # StorageOrder: caller numbering <-> slots
+        self.pre_access = None      # optional callable run before the block is read or written from the host side
         if layout == "soa":
             self.block = 0
             self.n_pad = pad_to(n, pad)
@@ -128,17 +188,28 @@ class BlockedSoA:
             v.block, v.field_stride, v.block_stride = self.block, self.block, self.block * self.n_fields
         return v
 
-    def fields(self, f0: int, nf: int) -> torch.Tensor:
-        """[nf, n] tensor of fields f0..f0+nf (a view for "soa", a gather for the tiled layouts)."""
+    def raw_fields(self, f0: int, nf: int) -> torch.Tensor:
+        """[nf, n] tensor of fields f0..f0+nf in STORAGE order (a view for "soa", a gather for the tiled layouts)."""
+        if self.pre_access is not None:
+            self.pre_access()
         if self.layout == "soa":
             return self.data[f0:f0 + nf, : self.n]
         return self.data[:, f0:f0 + nf, :].permute(1, 0, 2).reshape(nf, self.n_pad)[:, : self.n]
 
+    def fields(self, f0: int, nf: int) -> torch.Tensor:
+        """[nf, n] tensor of fields f0..f0+nf in the caller's numbering (with a storage order: a gathered copy)."""
+        raw = self.raw_fields(f0, nf)
+        return raw if self.order is None else self.order.to_caller(raw, 1)
+
     def set_fields(self, f0: int, values: torch.Tensor) -> None:
-        """values: [nf, n]"""
+        """values: [nf, n] in the caller's numbering"""
+        if self.pre_access is not None:
+            self.pre_access()
         self.version += 1
         nf = values.shape[0]
         vals = values.to(self.data.device, torch.float32)
+        if self.order is not None:
+            vals = self.order.to_storage(vals, 1)
         if self.layout == "soa":
             self.data[f0:f0 + nf, : self.n] = vals
         elif self.n == self.n_pad:          # whole tiles: one strided copy, no staging buffer
@@ -154,7 +225,7 @@ class FleetState(BlockedSoA):
     controller memory of one INDIControl instance per drone (INDIControl.py:109-146)."""
 
     def __init__(self, ctx: Context, n: int, layout: str = "soa", pad: int = 256):
-        super().__init__(n, ctx.n_fields, ctx.device, layout, pad)
+        super().__init__(n, ctx.n_fields, ctx.device, layout, pad, order=ctx.order)
         self.ctx = ctx
 
     pos = property(lambda s: s.fields(F_POS, 3))
@@ -189,8 +260,9 @@ class Targets(BlockedSoA):
         if broadcast:
             self.n, self.n_pad, self.n_fields, self.layout = 1, 64, nat.NT, "soa"
             self.data = torch.zeros((nat.NT, 1), dtype=torch.float32, device=ctx.device)
+            self.order, self.pre_access, self.version = None, None, 0
         else:
-            super().__init__(n, nat.NT, ctx.device, layout, pad)
+            super().__init__(n, nat.NT, ctx.device, layout, pad, order=ctx.order)
 
     def view(self) -> nat.View:
         if not self.broadcast:
@@ -211,18 +283,20 @@ class Targets(BlockedSoA):
             # the same broadcast constant as last time (e.g. the zero target_vel / target_acc of every
             # computeControl call): the fields already hold it, skip the fleet-sized fill
             key = None
-            if not torch.is_tensor(val) and np.size(val) == nf:
+            if isinstance(val, Frozen):
+                # the caller's promise (see Frozen): the same OBJECT as last time means the fields already hold it — a
+                # fleet-sized copy per computeControl call is 7 % of the reference-shaped loop.  The object is held, so
+                # the identity cannot be recycled.
+                old = self._const.get(f0)
+                if isinstance(old, tuple) and len(old) == 2 and old[0] == "frozen" and old[1] is val:
+                    continue
+                key = ("frozen", val)
+                val = val.tensor
+                if val.ndim == 2 and val.shape[0] != nf and val.shape[1] == nf:
+                    val = val.T
+            elif not torch.is_tensor(val) and np.size(val) == nf:
                 key = tuple(float(x) for x in np.asarray(val, dtype=np.float32).ravel())
                 if self._const.get(f0) == key:
-                    continue
-            elif torch.is_tensor(val) and val.device == dev:
-                # the same per-drone device tensor as last time, not written since (torch counts in-place writes, also
-                # through views): the fields already hold it — the reference-shaped loop hands computeControl the same
-                # target_pos every call, and a fleet-sized copy per call is 7 % of that loop
-                key = ("tensor", val, val._version, val.data_ptr(), tuple(val.shape), tuple(val.stride()))
-                old = self._const.get(f0)
-                # (the held reference keeps that storage alive, so an equal address is the same memory)
-                if isinstance(old, tuple) and len(old) == 6 and old[0] == "tensor" and old[2:] == key[2:]:
                     continue
             t = torch.as_tensor(val, dtype=torch.float32, device=dev).reshape(nf, -1)
             if self.broadcast:
@@ -260,14 +334,17 @@ class WaypointTargets:
             tab[:, 9] = np.asarray(target_yaw, dtype=np.float32)
         self.n, self.n_pad, self.n_wp = n, pad_to(n, pad), n_wp
         self.table = torch.from_numpy(tab).to(dev)
+        order = ctx.order if (ctx.order is not None and ctx.order.n == n) else None    # per-drone arrays live in storage order
         c = np.zeros(self.n_pad, dtype=np.int32)
         if wp_counters is not None:
-            c[:n] = np.asarray(wp_counters, dtype=np.int32)
+            w = np.asarray(wp_counters, dtype=np.int32)
+            c[:n] = w if order is None else order.to_storage_np(w)
         self.counters = torch.from_numpy(c).to(dev)
         self.offsets = None
         if offsets is not None:
             o = np.zeros((3, self.n_pad), dtype=np.float32)
-            o[:, :n] = np.asarray(offsets, dtype=np.float32).T
+            off = np.asarray(offsets, dtype=np.float32)
+            o[:, :n] = (off if order is None else order.to_storage_np(off)).T
             self.offsets = torch.from_numpy(o).to(dev)
         self.broadcast = False
 
@@ -293,14 +370,16 @@ class TrajectoryTargets(Targets):
         self.coeffs = torch.as_tensor(np.ascontiguousarray(coeffs), dtype=torch.float64).to(dev)
         self.TS = torch.as_tensor(np.ascontiguousarray(TS), dtype=torch.float64).to(dev)
         self.n_seg = int(self.TS.numel() - 1)
-        self.t = torch.zeros((self.n_pad,), dtype=torch.float64, device=dev)
+        self.t = torch.zeros((self.n_pad,), dtype=torch.float64, device=dev)      # (per-drone arrays: storage order)
         if t0 is not None:
-            self.t[:n] = torch.as_tensor(np.asarray(t0), dtype=torch.float64).to(dev)
+            t0 = np.asarray(t0, dtype=np.float64)
+            self.t[:n] = torch.from_numpy(t0 if self.order is None else self.order.to_storage_np(t0)).to(dev)
         self.yaw_state = torch.zeros((3, self.n_pad), dtype=torch.float64, device=dev)
         self.offsets = None
         if offsets is not None:
             o = np.zeros((3, self.n_pad), dtype=np.float32)
-            o[:, :n] = np.asarray(offsets, dtype=np.float32).T
+            off = np.asarray(offsets, dtype=np.float32)
+            o[:, :n] = (off if self.order is None else self.order.to_storage_np(off)).T
             self.offsets = torch.from_numpy(o).to(dev)
 
     def sample(self, dt_advance: float) -> None:

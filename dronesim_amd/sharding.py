@@ -21,7 +21,7 @@ def shard_range(n_total: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 def rank_seed(noise_seed: int, rank: int) -> int:
-    """Per-rank Philox key: every rank numbers its drones from 0, so the key separates the streams.
+    """Per-rank Threefry key: every rank numbers its drones from 0, so the key separates the streams.
     0 (noise off) stays 0."""
     if noise_seed == 0:
         return 0

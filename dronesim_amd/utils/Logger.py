@@ -44,7 +44,10 @@ class Logger:
                                                self.state_length))
         if control is not None:
             c = torch.as_tensor(control, dtype=torch.float32, device=self._controls.device)
-            self._controls[k, :, : self.NUM_DRONES] = c.reshape(self.control_length, -1)
+            c = c.reshape(self.control_length, -1)
+            if getattr(env, "order", None) is not None:
+                c = env.order.to_storage(c, 1)
+            self._controls[k, :, : self.NUM_DRONES] = c
         self._times[k] = timestamp
         self.count += 1
 
@@ -58,6 +61,8 @@ class Logger:
         as numpy arrays in the reference's shapes."""
         idx = self._order()
         sel = torch.arange(self.NUM_DRONES)[drones]
+        if getattr(self.env, "order", None) is not None:      # the slabs are written per storage slot
+            sel = self.env.order.slot.cpu()[sel]
         st = self._states[idx][:, :, sel].permute(2, 1, 0).double().cpu().numpy()
         ct = self._controls[idx][:, :, sel].permute(2, 1, 0).double().cpu().numpy()
         ts = np.tile(self._times[idx], (st.shape[0], 1))

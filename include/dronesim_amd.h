@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DSIM_ABI_VERSION 4
+#define DSIM_ABI_VERSION 5
 #define DSIM_MAX_ACT 6     /* actuators per vehicle (quad 4, morphing hexa 6) */
 #define DSIM_MAX_TYPES 8
 
@@ -152,18 +152,25 @@ enum {
   DSIM_OPT_MIXED_V3    = 1u << 9,   /* mixed fleets, wave-tiled layout: the three-wave form of the LDS-DMA-staged kernel
                                        (what other layouts get) instead of the two-wave one (A/B knob)             */
   /* -- physics (changes results) ------------------------------------------------------------------------------------ */
-  DSIM_OPT_PLANE       = 1u << 10   /* ground plane z = 0 with contact and friction, as the reference's world has
+  DSIM_OPT_PLANE       = 1u << 10,  /* ground plane z = 0 with contact and friction, as the reference's world has
                                        (BaseAviary.py:680 loads plane.urdf, collisions on).  A PRODUCT-DEFINED contact
                                        model (eight body-fixed rim points of the vehicle's collision cylinder, 24
                                        sequential-impulse sweeps, ERP 0.2, restitution 0, Coulomb friction): Bullet's own
                                        contact pipeline cannot be restated or pinned here.  Served
                                        by the k_step_plane / k_physics_plane / k_adaptor kernels; every airframe kind;
                                        not combined with DSIM_OPT_CHAINED.                                            */
+  /* -- scheduling (results do not depend on it) ---------------------------------------------------------------------- */
+  DSIM_OPT_DEFER_FALLBACK = 1u << 11 /* dsim_step / dsim_control2 of a table with a morphing hexa do NOT launch the deferred
+                                       WLS fallback pass behind the step; the caller launches dsim_wls_fallback itself —
+                                       on any stream ordered behind this call — before the commands are next read
+                                       (INDIControl_6DOF.py:600-631 finishes the allocation inside computeControl; here its
+                                       rare active-set tail may overlap the next Env.step's neighbour query).            */
 };
 
 /* A run of consecutive drones of one type (type-major storage of a heterogeneous fleet). */
 typedef struct dsim_type_run {
-  int64_t first;            /* first drone of the run; a multiple of 256                                */
+  int64_t first;            /* first drone of the run (any index: the launch starts at the 256-drone tile that
+                               holds it and the lanes in front of `first` retire)                        */
   int64_t count;            /* drones in the run                                                        */
   int32_t type;             /* index into the ctx type table                                            */
   int32_t _pad;
@@ -224,6 +231,11 @@ typedef struct dsim_step_args {
    * (same workspace and shape, args->prebinned = 1) skips the binning launch for the local drones.  Honoured on the
    * bucket form of the grid only (dsim_downwash_prebin_ok() != 0); otherwise ignored.                                */
   const struct dsim_downwash_args* bin_next;
+  /* -- storage order --------------------------------------------------------------------------------------------------
+   * nullable device array [n_pad]: the index of storage slot i in the CALLER's numbering.  Drones are independent, so a
+   * host class may store a heterogeneous fleet type-major (runs) whatever order its caller uses; the rotor-noise
+   * counter is then keyed by drone_id[i] instead of i, so that a drone draws the same noise wherever it is stored.   */
+  const int32_t* drone_id;
 } dsim_step_args;
 
 typedef struct dsim_ctx dsim_ctx;
@@ -334,6 +346,7 @@ int dsim_observe_soa(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, co
  * read the same sorted entries).
  * force_out: SoA [3][n_pad], x and y written as 0 (feed it to dsim_step_args.ext_force).
  * workspace: caller-owned device int32 buffer of at least dsim_downwash_workspace(m, nx, ny) entries. */
+struct dsim_halo_plan;
 typedef struct dsim_downwash_args {
   const float* pos_all;     /* SoA [3][m_pad] positions of every drone of the world, or NULL: the world is this
                                fleet alone (m = n, local_offset = 0) and positions are read from the state block */
@@ -348,10 +361,63 @@ typedef struct dsim_downwash_args {
   int32_t  prebinned;       /* 1: the previous dsim_step was given this grid as bin_next and has already binned the
                                local drones (see dsim_step_args.bin_next); only the other entries of pos_all are
                                binned by this call.  The library falls back to a full binning pass when its own
-                               record of the last prebinning does not match.                              */
-  int32_t  _pad;
+                               record of the last prebinning does not match (another grid, or the positions were
+                               moved since by a call that did not re-bin them).                              */
+  int32_t  phase;           /* DSIM_DW_*: with a halo plan the call can be split so that the exchange overlaps the local
+                               part of the query (see dsim_halo_plan)                                        */
+  const struct dsim_halo_plan* halo;   /* nullable: the rest of the world is what the neighbouring ranks sent (pos_all must
+                               be NULL, local_offset 0, m = n + the sum of the plan's recv_cap); bucket form only */
 } dsim_downwash_args;
 int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny);
+
+/* ---- halo exchange of a spatially sharded fleet (BASELINE config 5: slabs along x, one rank per GPU) -----------------
+ * The reference's downwash loop runs over the whole world (BaseAviary.py:1736-1763); a sharded fleet needs, per rank,
+ * the positions of the other ranks' drones that can be within the 10 m cut-off of one of its own.  The library does the
+ * device side of that exchange — selecting and packing the boundary drones, binning what arrived — and the caller moves
+ * the packed buffers between ranks (RCCL send/recv; the library itself has no communicator).  Per Env.step, with no
+ * host synchronisation anywhere:
+ *     stream B:  dsim_halo_pack -> [send/recv of the caller] -> dsim_downwash(phase = DSIM_DW_HALO_BIN)
+ *     stream A:  dsim_downwash(DSIM_DW_LOCAL)  ........ wait(B) -> dsim_downwash(DSIM_DW_HALO_QUERY) -> dsim_step(bin_next)
+ * A message is a HEADER (DSIM_HALO_HDR floats: the number of positions that follow, and the sender's xy bounding box at
+ * the time of sending) followed by xyz triples.  dsim_halo_pack selects, for every peer, the local drones inside that
+ * peer's box — read from the header of the LAST message that peer sent, in device memory — grown by reach[p]; with a
+ * message every step the box is one Env.step old, so reach = cut-off + (max coordinate velocity) x dt_env is exact for ANY
+ * motion the integrator allows (Bullet clamps every coordinate velocity to 100 m/s, P4).  Message sizes are fixed on
+ * the host (send_cap / recv_cap, re-made rarely from counts read back); the count travels in the header, and a
+ * selection that does not fit is dropped AND counted (DSIM_Q_HALO_OVERFLOW: 0 certifies that nothing was missed).      */
+#define DSIM_MAX_PEERS 8
+#define DSIM_HALO_HDR 8      /* floats: [0] count (int32 bits)  [1..4] xmin ymin xmax ymax of the sender  [5] max |coordinate
+                                velocity| of the sender (diagnostic)  [6..7] reserved                                    */
+enum {
+  DSIM_DW_ALL = 0,          /* one grid, one query: local drones and whatever pos_all / the halo plan hold               */
+  DSIM_DW_LOCAL = 1,        /* bin (unless pre-binned) and query the LOCAL drones only; force_out is written              */
+  DSIM_DW_HALO_BIN = 2,     /* bin the plan's received positions into the halo grid (touches nothing else: may run on
+                               another stream beside DSIM_DW_LOCAL of the same step)                                      */
+  DSIM_DW_HALO_QUERY = 3    /* local receivers against the halo grid; force_out += (after LOCAL and HALO_BIN)             */
+};
+typedef struct dsim_halo_plan {
+  int32_t world, rank;
+  int64_t cap;              /* positions a peer's buffer can hold; buffer p begins at float (DSIM_HALO_HDR + 3 cap) p      */
+  float*  send;             /* device [world][DSIM_HALO_HDR + 3 cap]: dsim_halo_pack writes header + triples for peer p    */
+  const float* recv;        /* device, same shape: the last message of peer p (its header is read by the NEXT pack)       */
+  int32_t* scratch;         /* device int32[32], zero-initialised by the caller once, owned by the plan's pack calls       */
+  int32_t send_cap[DSIM_MAX_PEERS];   /* host: positions in the message to peer p (0: no message to p)                    */
+  int32_t recv_cap[DSIM_MAX_PEERS];   /* host: positions in the message from peer p                                       */
+  float   reach[DSIM_MAX_PEERS];      /* host: selection margin around peer p's last known box, >= the cut-off             */
+} dsim_halo_plan;
+/* out5 (device float[5]): xmin, ymin, xmax, ymax of the n local drones and their largest |coordinate velocity|. */
+int dsim_fleet_bounds(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float* out5);
+/* One launch: for every peer p != rank, send[p] = header + the positions of the local drones inside p's last known box
+ * grown by reach[p] (at most send_cap[p] of them; the header carries the number SELECTED, so the receiver sees an
+ * overflow too), and this rank's own box in every header. */
+int dsim_halo_pack(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_halo_plan* plan);
+/* workspace (int32 entries) of a split-phase downwash: the local grid of n drones + the halo grid of up to h drones */
+int64_t dsim_downwash_workspace_halo(int64_t n, int64_t h, int32_t nx, int32_t ny);
+
+/* The deferred WLS fallback pass of a table with a morphing hexa (wls_alloc.py:222-350 for the drones whose first
+ * iteration left the box), as its own call: what dsim_step / dsim_control2 launch behind themselves unless
+ * DSIM_OPT_DEFER_FALLBACK is set.  cmd_out nullable (SoA [n_act][n_pad], as dsim_control2). */
+int dsim_wls_fallback(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const uint8_t* type_id, float* cmd_out);
 /* != 0 when a grid of this shape takes the bucket form (one binning pass, cell-centred LDS-tiled query), which is
  * the form dsim_step_args.bin_next can fill. */
 int dsim_downwash_prebin_ok(int64_t m, int32_t nx, int32_t ny);
@@ -373,8 +439,10 @@ int dsim_adjacency(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, cons
  *   DSIM_Q_WLS_FAILURES   allocations on which the reference would have failed (wls_alloc returns None
  *                         -> `self.cmd += None` raises, INDIControl_6DOF.py:626-630); cmd is left unchanged
  *   DSIM_Q_GROUND_CONTACTS  drone x Env.steps that ended with the vehicle's collision cylinder at or below z = 0, where
- *                         PyBullet's ground plane would have acted (see dsim_type_params.collision_radius)      */
-enum { DSIM_Q_WLS_FALLBACKS = 0, DSIM_Q_WLS_FAILURES = 1, DSIM_Q_GROUND_CONTACTS = 2 };
+ *                         PyBullet's ground plane would have acted (see dsim_type_params.collision_radius)
+ *   DSIM_Q_HALO_OVERFLOW  positions dsim_halo_pack selected but could not ship (send_cap too small), or received
+ *                         headers that announced more than recv_cap: the force of that step may have missed pairs   */
+enum { DSIM_Q_WLS_FALLBACKS = 0, DSIM_Q_WLS_FAILURES = 1, DSIM_Q_GROUND_CONTACTS = 2, DSIM_Q_HALO_OVERFLOW = 3 };
 int dsim_query(dsim_ctx* ctx, void* stream, int32_t what, int64_t* value_out);
 
 /* error codes */

@@ -80,44 +80,100 @@ def test_position_allgather_restores_global_order_gloo():
     assert out[0] and out[1]
 
 
+def _cpu_halo_class():
+    """HaloWire with its device operations done by torch on the host (test infrastructure: the product's HaloPlan does them
+    with dsim_fleet_bounds / dsim_halo_pack, which tests/test_gpu_round3.py checks against this same rule) — everything
+    else (resize protocol, who talks to whom, capacities, the grouped batch on persistent buffers) is the product's code."""
+    from dronesim_amd import _native as nat
+    from dronesim_amd.downwash import HaloWire
+
+    class CpuHalo(HaloWire):
+        def __init__(self, dist, n, **kw):
+            super().__init__(dist, "cpu", n, **kw)
+            self.pos = torch.zeros((3, n))
+            self.vel = torch.zeros((3, n))
+            self.lost = 0
+
+        def _bounds(self):
+            self.bounds_dev[0:2] = self.pos[:2].min(dim=1).values
+            self.bounds_dev[2:4] = self.pos[:2].max(dim=1).values
+            self.bounds_dev[4] = self.vel.abs().max()
+
+        def _pack(self):
+            self._bounds()
+            for p in range(self.world):
+                if p == self.rank or self.send_cap[p] == 0:
+                    continue
+                box, r = self.recv[p, 1:5], self.reach[p]
+                m = ((self.pos[0] >= box[0] - r) & (self.pos[0] <= box[2] + r) & (self.pos[1] >= box[1] - r) & (self.pos[1] <= box[3] + r))
+                idx = torch.nonzero(m).squeeze(1)
+                k = min(int(idx.numel()), self.send_cap[p])
+                self.lost += int(idx.numel()) - k
+                self.send[p, 0:1].view(torch.int32)[0] = int(idx.numel())
+                self.send[p, 1:5] = self.bounds_dev[0:4]
+                self.send[p, nat.HALO_HDR: nat.HALO_HDR + 3 * k] = self.pos[:, idx[:k]].T.reshape(-1)
+
+        def _overflow(self):
+            return self.lost
+
+    return CpuHalo
+
+
 def _halo_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import numpy as np
     from dronesim_amd import params
-    from dronesim_amd.downwash import HaloExchange, gather_positions
+    from dronesim_amd.downwash import gather_positions
     from oracle import oracle as orc
-    n, slab, vmax, dt, refresh = 300, 40.0, 100.0, 1.0 / 240.0, 8
+    n, slab, vmax, dt, every = 300, 40.0, 100.0, 1.0 / 240.0, 8
     rng = np.random.default_rng(100 + rank)
     # slab decomposition along x: rank r owns x in [r*slab, (r+1)*slab)
     pos = np.stack([rng.uniform(rank * slab, (rank + 1) * slab, n), rng.uniform(0, 30, n), rng.uniform(0.5, 8, n)])
     O = orc.Oracle([params.builtin_type("robobee")])
-    halo = HaloExchange(dist, vmax, dt, refresh=refresh)
+    halo = _cpu_halo_class()(dist, n, dt_env=dt, v_clamp=vmax, resize_every=every, slack=64)
     ok, sizes, sent = True, [], []
-    for step in range(2 * refresh + 3):                  # crosses two refreshes
+    for step in range(2 * every + 3):                    # crosses two resizes
         loc = torch.from_numpy(pos.astype(np.float32))
-        got = halo.exchange(loc)                          # [3, n + halo]
+        halo.pos, halo.vel = loc, torch.full((3, n), float(vmax))
+        halo.exchange()
+        got = torch.cat([loc, halo.received_positions()], dim=1)            # [3, n + halo]
         world_pos = gather_positions(loc, dist)           # the all-gather mode, for comparison
         rigid = np.zeros((n, 13)); rigid[:, 0:3] = loc.numpy().T; rigid[:, 6] = 1.0
         f_halo = O.downwash(rigid, got.numpy().T.astype(np.float64))
         f_all = O.downwash(rigid, world_pos.numpy().T.astype(np.float64))
-        ok = ok and bool(torch.equal(got[:, :n], loc)) and np.allclose(f_halo, f_all, rtol=1e-12, atol=0) \
-            and (f_all != 0).sum() > n // 4
+        ok = ok and np.allclose(f_halo, f_all, rtol=1e-12, atol=0) and (f_all != 0).sum() > n // 4
         sizes.append(got.shape[1]); sent.append(halo.sent_per_step)
-        # worst-case motion the margin must absorb: every drone moves at the velocity clamp along x,
-        # the slabs rushing towards each other
+        if step == 0:
+            peers = halo.messages()                      # (slabs 1 and 2 fly apart later and stop talking)
+        # worst-case motion the one-step margin must absorb: every drone moves at the velocity CLAMP along x, the
+        # slabs rushing towards each other
         pos[0] += (1.0 if rank % 2 == 0 else -1.0) * vmax * dt
         pos[1] += rng.uniform(-1, 1, n) * vmax * dt
-    out[rank] = (ok, max(sizes), sorted(halo._send_idx.keys()), max(sent))
+    margin = halo.step_reach - halo.cutoff
+    lost_before = halo.lost
+    # a selection that outgrows its message is dropped and counted (_pack above does both; here the counter is moved by
+    # hand so that every rank sees it, whatever its neighbours are doing by now), and reported at the next resize —
+    # before that resize's first collective
+    halo.lost += 5
+    raised = False
+    halo._age = every
+    try:
+        halo.exchange()
+    except RuntimeError:
+        raised = True
+    out[rank] = (ok, max(sizes), peers, max(sent), margin, raised, lost_before)
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_halo_exchange_equals_allgather_gloo():
-    """Config 5's exchange step in its halo form, 3 ranks in a row of slabs: the force on every local drone
-    computed from own + halo positions equals the one computed from the all-gathered world, at every step
-    between and across refreshes, with all drones moving at the velocity clamp; the outer ranks exchange
-    nothing with each other, and a rank receives far fewer positions than the world holds."""
+    """Config 5's exchange step in its halo form, 3 ranks in a row of slabs, the product's HaloWire over gloo (resize
+    protocol, who talks to whom, message capacities, grouped isend/irecv on persistent buffers, boxes travelling in the
+    headers): the force on every local drone computed from own + halo positions equals the one computed from the
+    all-gathered world at every step between and across resizes, with all drones moving at the velocity CLAMP, the slabs
+    rushing towards each other (the one-step margin cut-off + v_clamp dt assumes nothing else); the outer ranks exchange
+    nothing with each other, a rank ships a strict subset of its drones, and an outgrown message raises at the next resize."""
     world = 3
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -127,6 +183,8 @@ def test_halo_exchange_equals_allgather_gloo():
     mp.spawn(_halo_worker, args=(world, port, out), nprocs=world, join=True)
     for r in range(world):
         assert out[r][0], r
+        assert out[r][5] and out[r][6] == 0, out[r]                          # nothing lost in flight; the forced overflow raised
+        assert abs(out[r][4] - 100.0 / 240.0) < 1e-6                         # margin = ONE step at the clamp, not sixteen
     assert out[0][2] == [1] and out[2][2] == [1] and out[1][2] == [0, 2]     # neighbours only
     assert out[0][1] < 300 + 300 and out[0][3] < 300                           # a strict subset travels
 

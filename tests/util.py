@@ -274,3 +274,53 @@ def attitude_zoo(rng, n_random=2000):
     sarg = -2.0 * (q[:, 0] * q[:, 2] - q[:, 3] * q[:, 1])
     keep = np.abs(np.abs(sarg) - 0.99999) > 1e-6                      # off the discontinuity
     return q[keep]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# neighbour downwash (formula P8): tolerance per receiver
+# ---------------------------------------------------------------------------------------------------------------------
+FLT_MIN = 1.17549435e-38     # smallest normal fp32: v_exp_f32 flushes what lies below it to zero
+
+
+def p8_terms(types, type_id, recv_pos, world_pos, cutoff=10.0, chunk=256):
+    """Per receiver of formula P8 (BaseAviary.py:1736-1763; oracle/dsim_oracle.c:orc_downwash), in fp64 numpy:
+    (n_pairs, largest |term|, straddle, flush) — the number of contributing pairs, the largest single term, the summed
+    magnitude of the terms of pairs that sit within 2e-5 m of the cut-off circle or of dz = 0, where the fp32 and the
+    fp64 evaluation of `dz > 0 and dxy < 10` may legitimately disagree, and sum(alpha) x FLT_MIN: a term is alpha x
+    exp(..), and an exponential below the smallest normal fp32 is flushed to zero by the hardware while fp64 keeps it
+    (forces of 1e-30 N: "no force" either way)."""
+    recv_pos, world_pos = np.asarray(recv_pos, np.float64), np.asarray(world_pos, np.float64)
+    n = recv_pos.shape[0]
+    tid = np.zeros(n, dtype=np.int64) if type_id is None else np.asarray(type_id).astype(np.int64)
+    d0 = np.array([t.dw_coeff[0] for t in types])[tid]; d1 = np.array([t.dw_coeff[1] for t in types])[tid]
+    d2 = np.array([t.dw_coeff[2] for t in types])[tid]; pr = np.array([t.prop_radius for t in types])[tid]
+    n_pairs, t_max, straddle, flush = np.zeros(n, dtype=np.int64), np.zeros(n), np.zeros(n), np.zeros(n)
+    chunk = max(1, min(chunk, (1 << 23) // max(1, world_pos.shape[0])))          # <= 8 M pairs (64 MB per temporary) at a time
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        dz = world_pos[None, :, 2] - recv_pos[s:e, None, 2]
+        dxy = np.hypot(world_pos[None, :, 0] - recv_pos[s:e, None, 0], world_pos[None, :, 1] - recv_pos[s:e, None, 1])
+        near = (dz > -2e-5) & (dxy < cutoff + 2e-5)
+        dzs = np.where(dz > 1e-12, dz, 1.0)
+        alpha = d0[s:e, None] * (pr[s:e, None] / (4 * dzs)) ** 2
+        term = alpha * np.exp(-0.5 * (dxy / (d1[s:e, None] * dzs + d2[s:e, None])) ** 2)
+        hit = (dz > 0) & (dxy < cutoff)
+        flush[s:e] = np.where(hit, alpha, 0.0).sum(1) * FLT_MIN
+        edge = near & ((np.abs(dxy - cutoff) < 2e-5) | (np.abs(dz) < 2e-5))
+        n_pairs[s:e] = hit.sum(1)
+        t_max[s:e] = np.where(hit, term, 0.0).max(1)
+        straddle[s:e] = np.where(edge & (dz > 1e-12), term, 0.0).sum(1)
+    return n_pairs, t_max, straddle, flush
+
+
+def assert_downwash(label, got, ref, types, type_id, recv_pos, world_pos):
+    """|got - ref| <= 1e-4 |ref| + n_pairs ulp32(largest term) (+ what straddles the cut-off, + the flushed exponentials),
+    per receiver.  The terms of one receiver all have the same sign, so |ref| is the sum of their magnitudes: the bar
+    is relative to what was summed, with no absolute floor that would hide the weak far-field terms."""
+    n_pairs, t_max, straddle, flush = p8_terms(types, type_id, recv_pos, world_pos)
+    tol = REL_TOL * np.abs(ref) + n_pairs * ulp32(np.maximum(t_max, 1e-300)) * (t_max > 0) + straddle + flush + 1e-300
+    ratio = np.abs(np.asarray(got, np.float64) - ref) / tol
+    worst = float(ratio.max())
+    WORST[label] = max(WORST.get(label, 0.0), worst)
+    assert worst <= 1.0, (label, worst, int(ratio.argmax()), float(got[ratio.argmax()]), float(ref[ratio.argmax()]))
+    return worst

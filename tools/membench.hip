@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 #include <algorithm>
 
@@ -128,7 +129,26 @@ float time_it(F f, int iters) {
 }
 
 int main(int argc, char** argv) {
-  const long long n = argc > 1 ? atoll(argv[1]) : (1LL << 22);
+  bool json = false;
+  long long n = 1LL << 22;
+  for (int k = 1; k < argc; ++k) { if (!strcmp(argv[k], "--json")) json = true; else n = atoll(argv[k]); }
+  if (json) {
+    // the two yardsticks bench.py prints beside the headline: the float4 copy rate of this device, and the floor of the
+    // headline kernel's ACCESS SHAPE (58 dword accesses per lane on the wave-tiled layout, streaming, no arithmetic)
+    float *st, *tg;
+    CK(hipMalloc(&st, sizeof(float) * FS * n));
+    CK(hipMalloc(&tg, sizeof(float) * FT * n));
+    CK(hipMemset(st, 0, sizeof(float) * FS * n));
+    CK(hipMemset(tg, 0, sizeof(float) * FT * n));
+    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    const float shape_ms = time_it([&] { hipLaunchKernelGGL(k_tile<true>, g, b, 0, 0, st, tg, n); }, 20);
+    const long long n4 = FS * n / 4;
+    float4* dst; CK(hipMalloc(&dst, sizeof(float4) * n4));
+    const float copy_ms = time_it([&] { hipLaunchKernelGGL(k_copy4, dim3((unsigned)((n4 + 255) / 256)), b, 0, 0, (const float4*)st, dst, n4); }, 20);
+    printf("{\"drones\": %lld, \"access_shape_floor_us\": %.2f, \"access_shape_GBps\": %.1f, \"float4_copy_GBps\": %.1f}\n", n,
+           shape_ms * 1e3, 232.0 * n / (shape_ms * 1e-3) / 1e9, 2.0 * 16 * n4 / (copy_ms * 1e-3) / 1e9);
+    return 0;
+  }
   float *st, *tg;
   CK(hipMalloc(&st, sizeof(float) * FS * n));
   CK(hipMalloc(&tg, sizeof(float) * FT * n));
