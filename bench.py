@@ -70,6 +70,9 @@ def parse(argv=None):
     p.add_argument("--slab-m", type=float, default=128.0,
                    help="config5: width of a rank's slab; 128 = the config's density, 1024 = round 1's definition of the line")
     p.add_argument("--lib", default=None, help="a differently-tuned build of libdronesim_amd.so (A/B runs)")
+    p.add_argument("--runs", choices=["auto", "one", "separate"], default="auto",
+                   help="type-major storage: DSIM_OPT_RUNS_ONE_LAUNCH / _SEPARATE (A/B knob)")
+    p.add_argument("--replicas", type=int, default=0, help="override the number of vectorised env replicas (A/B runs)")
     p.add_argument("--dry-run", action="store_true",
                    help="host logic only (launcher, rendezvous, reductions, the JSON line); no device work — CPU tests")
     return p.parse_args(argv)
@@ -102,7 +105,7 @@ class Fleet:
     """A resident fleet + per-drone hover targets at the start position."""
 
     def __init__(self, n_fleet, replicas, device, substeps, layout, noise_seed, waypoints=False, n_steps=1,
-                 config5=False, dist=None, rank=0, chained=False, hexa=False, mixed=False, options=0, slab_m=128.0):
+                 config5=False, dist=None, rank=0, chained=False, hexa=False, mixed=False, options=0, slab_m=128.0, storage=None):
         import torch
         from dronesim_amd.envs import CtrlAviary, Physics
         from dronesim_amd.fleet import Targets, WaypointTargets
@@ -142,8 +145,9 @@ class Fleet:
         self.env = CtrlAviary(models, self.n, initial_xyzs=xyz, aggregate_phy_steps=substeps, physics=physics,
                               device=device, layout=layout, noise_seed=noise_seed, dict_io=False, dist=dist,
                               chained=chained, downwash_exchange=os.environ.get("DSIM_DW_EXCHANGE", "halo"),
-                              type_ids=type_ids, options=options, storage=os.environ.get("DSIM_STORAGE", "auto"),
-                              downwash_split=os.environ.get("DSIM_DW_SPLIT", "1") != "0")
+                              type_ids=type_ids, options=options, storage=storage or os.environ.get("DSIM_STORAGE", "auto"),
+                              downwash_split=os.environ.get("DSIM_DW_SPLIT", "1") != "0",
+                              defer_fallback=os.environ.get("DSIM_DEFER_FB", "0") != "0")
         if waypoints:
             self.tgt = WaypointTargets(self.env.ctx, self.n, g["target_pos"], g["target_vel"], g["target_acc"],
                                        g["target_yaw"], wp_counters=wp0, offsets=off)
@@ -330,6 +334,61 @@ def exchange_report(fl, dist, red_dev, steps=20):
             "overflow": int(sum(r[3] for r in rows))}
 
 
+def config5_all_ranks(a, local, rank, world, dist, red_dev, barrier, options):
+    """N > 1, default workload: BASELINE configs[4] — the one workload with an exchange step — measured on the ranks of
+    THIS run as well (65 536 mixed drones per rank in 128 m slabs, halo exchange over the run's backend), so that a
+    multi-GPU run of the default line also says what the RCCL path does.  Every rank takes part (the exchange is
+    collective); rank 0 gets the entry."""
+    from dronesim_amd import sharding
+    fl5 = Fleet(65536, 1, local, 1, a.layout, sharding.rank_seed(a.noise_seed, rank), config5=True, dist=dist, rank=rank,
+                options=options)
+    steps = max(20, a.steps // 2)
+
+    def rule(first_wall):
+        w, _ = sharding.reduce_step_times(dist, red_dev, first_wall, 0.0)
+        return max(1, int(np.ceil(MIN_TIMED_S / max(w, 1e-9))))
+    wall_l, dev_l, regions = fl5.timed(steps, 10, barrier, min_s=MIN_TIMED_S, repeat_rule=rule)
+    wall, dev = sharding.reduce_step_times(dist, red_dev, wall_l, dev_l)
+    k = steps * regions
+    rows = gather_ranks(dist, red_dev, [dev_l / k * 1e6, wall_l / k * 1e6, fl5.env.ground_contacts()])
+    ex = exchange_report(fl5, dist, red_dev)
+    e = {"workload": WORKLOAD_TEXT["config5"], "drones_per_gpu": fl5.n, "n_gpus": world,
+         "drone_steps_per_s": sharding.aggregate_throughput([fl5.n] * world, k, wall), "ms_per_step": wall / k * 1e3,
+         "steps_timed": k, "step_chain_us_min": min(r[0] for r in rows), "step_chain_us_max": max(r[0] for r in rows),
+         "host_us_per_step_max": max(r[1] for r in rows), "ground_contacts": int(sum(r[2] for r in rows)), "exchange": ex,
+         "kernel": "dsim_halo_pack + send/recv + halo binning (side stream) | k_dw_query_cell local pass, halo pass, "
+                   "k_step_runs + fused grid binning, k_wls_fallback"}
+    fl5.env.close()
+    return e
+
+
+class Watchdog:
+    """A section that every rank must finish together (a collective workload behind the headline): if it does not within
+    `seconds`, rank 0 prints the line it already has — the headline measurement must not be lost to a hang in an extra —
+    and every rank leaves with exit code 0."""
+
+    def __init__(self, seconds, rank, line):
+        import threading
+        self.rank, self.line = rank, line
+        self.t = threading.Timer(seconds, self.fire)
+        self.t.daemon = True
+        self.seconds = seconds
+
+    def fire(self):
+        if self.rank == 0:
+            self.line["config5_all_ranks"] = {"error": f"did not finish within {self.seconds} s; abandoned"}
+            print(json.dumps(self.line), flush=True)
+        os._exit(0)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
 WORKLOAD_TEXT = {
     "config2x1024": "configs[1] 4096 robobee INDI hover x 1024 vectorised envs/GPU",
     "config2": "configs[1] 4096 robobee INDI hover (single fleet)",
@@ -351,7 +410,7 @@ def measure_variant(torch, local, layout, seed, steps, name, nf, rep, sub, wp, n
     f2 = Fleet(nf, rep, local, sub, layout, seed, waypoints=wp, n_steps=ns,
                config5=name.startswith("config5"), chained="chained" in name, hexa=name.startswith("hexa"),
                mixed=("type_major" if "type_major" in name else name.startswith("mixed")), options=options,
-               slab_m=(1024.0 if "lowdensity" in name else 128.0))
+               slab_m=(1024.0 if "lowdensity" in name else 128.0), storage=("caller" if "caller_order" in name else None))
     if "hipgraph" in name:
         f2.n_steps = 1
         f2.use_graph(ns)
@@ -420,12 +479,15 @@ def main(argv=None):
     options |= nat.OPT_MIXED_V1 if a.mixed_v1 else 0
     options |= nat.OPT_MIXED_RING if a.mixed_ring else 0
     options |= nat.OPT_MIXED_V3 if a.mixed_v3 else 0
+    options |= {"auto": 0, "one": nat.OPT_RUNS_ONE_LAUNCH, "separate": nat.OPT_RUNS_SEPARATE}[a.runs]
     barrier = (lambda: dist.barrier()) if dist else None
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
     n_fleet, replicas = {"config2x1024": (4096, 1024), "config2": (4096, 1), "config3": (65536, 1), "config4": (4096, 16),
                          "config5": (65536, 1), "hexa": (4096, 1024), "mixed": (4096, 1024),
                          "mixed_type_major": (4096, 1024), "two_call_loop": (4096, 1024)}[a.workload]
+    if a.replicas > 0:
+        replicas = a.replicas
     from dronesim_amd import sharding
     # weak scaling: every rank owns a same-sized contiguous shard of the N-GPU fleet; no data-path collective
     # (config5 only: one halo exchange of positions per step for the neighbour-downwash term)
@@ -500,6 +562,17 @@ def main(argv=None):
         }
         if exchange is not None:
             out["exchange"] = exchange
+    else:
+        out = {}
+    if world > 1 and a.workload == "config2x1024" and not a.no_also:
+        with Watchdog(240, rank, out):
+            try:
+                e5 = config5_all_ranks(a, local, rank, world, dist, red_dev, barrier, options)
+            except Exception as e:                # (a rank-local failure; a hang of the others ends in the watchdog)
+                e5 = {"error": repr(e)[:300]}
+            if rank == 0:
+                out["config5_all_ranks"] = e5
+    if rank == 0:
         if world == 1 and not a.no_also:
             # ---- BASELINE.json configs 1-3 at their LITERAL sizes and example settings --------------------------------
             # (fleet, replicas, phys_substeps, waypoint table, Env.steps per launch)
@@ -530,8 +603,11 @@ def main(argv=None):
                     "config2x1024_chained_184B": (4096, 1024, 1, False, 1),
                     # homogeneous morphing-hexa fleet: 6-DOF INDI + WLS allocation, 248 B/drone-step
                     "hexa_6DOF_4194304_indi6dof_wls": (4096, 1024, 1, False, 1),
-                    # config 5's composition at roofline size, no downwash: 240 B average + 1 B type id
+                    # config 5's composition at roofline size, no downwash: 240 B average + 1 B type id.  The caller hands the
+                    # fleet over interleaved (even index quad, odd index hexa); the env stores it type-major behind that
+                    # numbering (fleet.StorageOrder) — and, for comparison, in the caller's own order (k_step_mixed4)
                     "mixed_quad_hexa_4194304": (4096, 1024, 1, False, 1),
+                    "mixed_quad_hexa_4194304_caller_order_storage": (4096, 1024, 1, False, 1),
                     # the same fleet in type-major storage: one single-type launch per type
                     "mixed_quad_hexa_4194304_type_major": (4096, 1024, 1, False, 1)}.items():
                 also[name] = measure_variant(torch, local, a.layout, a.noise_seed, a.steps, name, *spec, options=options)
@@ -605,11 +681,14 @@ def dry_run(a, rank, world, backend):
         dist.barrier()
     wall = 1e-3 * (rank + 1)                 # synthetic and distinct per rank: the MAX reduction is observable
     wall_max, _ = sharding.reduce_step_times(dist, "cpu", wall, 0.0)
+    rows = gather_ranks(dist, "cpu", [wall * 1e6, float(rank)])          # the per-rank rows of the real line
     if rank == 0:
         print(json.dumps({"metric": "drone-steps/sec (num_drones x env steps/s)", "value": None, "unit": "drone-steps/s",
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "dry_run": True, "scaling": "weak",
                           "config": {"workload": WORKLOAD_TEXT[a.workload], "parallelism": f"shard{world}"},
-                          "dist": dist_info, "wall_max_over_ranks_s": wall_max, "rank0_wall_s": wall}))
+                          "dist": dist_info, "wall_max_over_ranks_s": wall_max, "rank0_wall_s": wall,
+                          "ranks": {"launch_us_min": min(r[0] for r in rows), "launch_us_max": max(r[0] for r in rows),
+                                    "seen": sorted(int(r[1]) for r in rows)}}))
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -29,9 +29,11 @@ DW_ALL, DW_LOCAL, DW_HALO_BIN, DW_HALO_QUERY = 0, 1, 2, 3
 NF_QUAD, NF_HEXA, NT = 24, 26, 10
 OPT_DRAG, OPT_GROUND, OPT_BCAST_TGT, OPT_CHAINED = 1, 2, 4, 8
 OPT_STREAM_ON, OPT_STREAM_OFF, OPT_GENERIC_MIXED, OPT_MIXED_V1, OPT_MIXED_RING, OPT_MIXED_V3 = 16, 32, 64, 128, 256, 512   # tuning knobs
-TUNING_MASK = OPT_STREAM_ON | OPT_STREAM_OFF | OPT_GENERIC_MIXED | OPT_MIXED_V1 | OPT_MIXED_RING | OPT_MIXED_V3   # (results do not depend on them)
+TUNING_MASK = (OPT_STREAM_ON | OPT_STREAM_OFF | OPT_GENERIC_MIXED | OPT_MIXED_V1 | OPT_MIXED_RING | OPT_MIXED_V3
+               | (1 << 12) | (1 << 13))   # (results do not depend on them)
 OPT_PLANE = 1 << 10        # ground-plane contact (product-defined model, oracle/dsim_oracle.c:orc_plane_contact)
 OPT_DEFER_FALLBACK = 1 << 11   # the caller launches dsim_wls_fallback itself (scheduling only)
+OPT_RUNS_ONE_LAUNCH, OPT_RUNS_SEPARATE = 1 << 12, 1 << 13     # tuning knobs of type-major storage
 ADAPT_VELOCITY, ADAPT_RPYT = 0, 1
 QUERY_WLS_FALLBACKS, QUERY_WLS_FAILURES, QUERY_GROUND_CONTACTS, QUERY_HALO_OVERFLOW = 0, 1, 2, 3
 

@@ -1131,11 +1131,10 @@ __global__ __launch_bounds__(128, S1 ? 4 : 3) void k_step_mixed4(StepK a) {
 // Type-major storage (dsim_step_args.runs): a run of one type is stepped by the single-type law of its kind,
 // the fast form (no partition, no waterfall, per-type constants in SGPRs); ext = optional downwash force.
 template <bool HEXA, bool NOISE, bool NT, bool S1>
-__global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void k_step_run(StepK a) {
-  const long long i0 = a.first + (long long)blockIdx.x * 256;
+__device__ __forceinline__ void run_body(const StepK& a, long long i0, long long lo, long long last, int run_type) {
   const long long i = i0 + threadIdx.x;
-  if (i >= a.last || i < a.lo) return;      // (a run may begin and end inside a tile: the neighbouring run's launch takes the rest)
-  const DevType& T = a.types[a.run_type];
+  if (i >= last || i < lo) return;          // (a run may begin and end inside a tile: the neighbouring run's lanes take the rest)
+  const DevType& T = a.types[run_type];
   const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
   const unsigned sl = 4u * kv_lane(a.st, threadIdx.x), tl = 4u * kv_lane(a.tg, threadIdx.x);
   float* const sb = a.st.base + kv_off(a.st, i0);
@@ -1149,15 +1148,16 @@ __global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void
   load_target<NT>(tb, tfs, tl, tg);
   V3 ext = v3(0, 0, 0);
   if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
-  if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
+  unsigned long long step_index = a.step_index;
+  if (NOISE && a.step_index_dev) step_index += *a.step_index_dev;
   V3 pos_e;
   float yaw_e;
   const long long nid = NOISE ? noise_id(a, i) : -1LL;
   if constexpr (HEXA) {
-    hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext, nid);
+    hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, step_index, ext, nid);
     indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
   } else {
-    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext, nullptr, nid);
+    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, step_index, ext, nullptr, nid);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   const unsigned so = pin_lane_offset(sl);
@@ -1165,6 +1165,35 @@ __global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void
   store_mem<NA, NT>(sb, sfs, so, m);
   ground_watch(T, s, a.fb.counters, i < a.n);
   if (a.bin.count && i < a.n) bin_entry(a.bin, s.pos.x, s.pos.y, s.pos.z, a.bin.local_offset + i);   // next step's grid
+}
+template <bool HEXA, bool NOISE, bool NT, bool S1>
+__global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void k_step_run(StepK a) {
+  run_body<HEXA, NOISE, NT, S1>(a, a.first + (long long)blockIdx.x * 256, a.lo, a.last, a.run_type);
+}
+// All the runs of a type-major fleet in ONE launch: a workgroup finds its run by its index (constant-index walk over the
+// table, everything wave-uniform) and runs that run's law.  A 65 536-drone shard of BASELINE config 5 is two runs of 128
+// workgroups: 9.5 + 9.0 us as two dependent launches, 12.0 us as one; at 4 194 304 drones 160.1 against 165.2 us.  One
+// launch per run (k_step_run) stays as DSIM_OPT_RUNS_SEPARATE and for fleets with a single run.
+struct RunTab {
+  int blk0[DSIM_MAX_TYPES + 1];            // first workgroup of run q (blk0[q] = the total for q >= n_runs)
+  long long first[DSIM_MAX_TYPES], lo[DSIM_MAX_TYPES], last[DSIM_MAX_TYPES];
+  int type[DSIM_MAX_TYPES];
+  unsigned hexa_mask;
+};
+template <bool NOISE, bool NT, bool S1>
+__global__ __launch_bounds__(256, 3) void k_step_runs(StepK a, RunTab rt) {
+  int r = 0;
+#pragma unroll
+  for (int q = 1; q < DSIM_MAX_TYPES; ++q) if ((int)blockIdx.x >= rt.blk0[q]) r = q;
+  r = __builtin_amdgcn_readfirstlane(r);
+  long long first = rt.first[0], lo = rt.lo[0], last = rt.last[0];
+  int type = rt.type[0], b0 = rt.blk0[0];
+#pragma unroll
+  for (int q = 1; q < DSIM_MAX_TYPES; ++q)
+    if (q == r) { first = rt.first[q]; lo = rt.lo[q]; last = rt.last[q]; type = rt.type[q]; b0 = rt.blk0[q]; }
+  const long long i0 = first + (long long)((int)blockIdx.x - b0) * 256;
+  if ((rt.hexa_mask >> r) & 1u) run_body<true, NOISE, NT, S1>(a, i0, lo, last, type);
+  else run_body<false, NOISE, NT, S1>(a, i0, lo, last, type);
 }
 
 // ---- Env.step only ---------------------------------------------------------
@@ -2510,6 +2539,38 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
       rc = fb_prepare(ctx, a.n_pad, st_);
       if (rc) return rc;
       a.fb.entries = ctx->d_fb;
+    }
+    // (measured on MI355X, 50 % quads + 50 % hexas: 65 536 drones 12.0 us against 9.5 + 9.0 us for two dependent launches;
+    // 4 194 304 drones 160.1 against 165.2 us — the launch boundary between the runs costs more than the registers the
+    // second law adds (83 VGPRs, 5 waves per SIMD, against 74 and 6): one launch is the default at every size)
+    const bool one_launch = !(args->options & DSIM_OPT_RUNS_SEPARATE);
+    if (n_runs >= 2 && n_runs <= DSIM_MAX_TYPES && one_launch) {
+      // small fleet, several runs: one launch for all of them (k_step_runs)
+      RunTab rt;
+      memset(&rt, 0, sizeof(rt));
+      int blocks = 0;
+      for (int r = 0; r < DSIM_MAX_TYPES; ++r) {
+        rt.blk0[r] = blocks;
+        if (r >= n_runs) continue;
+        const dsim_type_run& run = runs[r];
+        rt.first[r] = run.first & ~255LL; rt.lo[r] = run.first; rt.last[r] = run.first + run.count; rt.type[r] = run.type;
+        if (ctx->h_types[run.type].kind == DSIM_KIND_HEXA6DOF) rt.hexa_mask |= 1u << r;
+        blocks += run.count > 0 ? (int)grid_for(rt.last[r] - rt.first[r]) : 0;
+      }
+      rt.blk0[DSIM_MAX_TYPES] = blocks;
+      if (blocks > 0) {
+        const dim3 g((unsigned)blocks);
+#define DSIM_RUNS_CASE(S_)                                                                              \
+  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_runs<true, true, S_>), g, b, 0, st_, a, rt);     \
+                    else hipLaunchKernelGGL((k_step_runs<true, false, S_>), g, b, 0, st_, a, rt); }     \
+       else { if (nt) hipLaunchKernelGGL((k_step_runs<false, true, S_>), g, b, 0, st_, a, rt);          \
+              else hipLaunchKernelGGL((k_step_runs<false, false, S_>), g, b, 0, st_, a, rt); } } while (0)
+        if (a.substeps == 1) DSIM_RUNS_CASE(true); else DSIM_RUNS_CASE(false);
+#undef DSIM_RUNS_CASE
+      }
+      if (any_hexa) fb_finish(ctx, a, st_);
+      bin_next_commit(ctx, n, args, a);
+      return (int)hipGetLastError();
     }
 #define DSIM_RUN_CASE2(H_, S_)                                                                        \
   do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_run<H_, true, true, S_>), g, b, 0, st_, a);    \

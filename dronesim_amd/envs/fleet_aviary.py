@@ -87,6 +87,7 @@ class CtrlAviary:
         ground_plane: Optional[bool] = None,
         storage: str = "auto",
         downwash_split: bool = True,
+        defer_fallback: bool = False,
     ):
         if gui or record or obstacles:
             raise NotImplementedError("gui/record/obstacles are rendering features outside the hot path")
@@ -218,10 +219,12 @@ class CtrlAviary:
             elif downwash_exchange not in ("allgather", "halo"):
                 raise ValueError(downwash_exchange)
             self._downwash = Downwash(self.ctx, self.state, self._type_id, dist, halo=halo, split=downwash_split)
-            if self.n_act == 6:
-                # the WLS fallback pass of a step (normally an empty queue) runs on a side stream beside the NEXT step's
-                # neighbour query instead of between the two on one stream (DSIM_OPT_DEFER_FALLBACK); everything that
-                # reads the commands joins it first (_join_fallback)
+            if self.n_act == 6 and defer_fallback:
+                # option (off by default): the WLS fallback pass of a step (normally an empty queue) runs on a side stream
+                # beside the NEXT step's neighbour query instead of between the two on one stream
+                # (DSIM_OPT_DEFER_FALLBACK); everything that reads the commands joins it first (_join_fallback).
+                # Measured on one MI355X at BASELINE config 5's shard size: 56.6 us per step against 50.3 us with the pass
+                # inline — the two cross-stream events cost more than the ~2 us launch they take off the chain.
                 self._fb_stream = torch.cuda.Stream(device=self.ctx.device)
                 self._fb_done, self._fb_go = torch.cuda.Event(), torch.cuda.Event()
                 self.state.pre_access = self._join_fallback

@@ -151,6 +151,9 @@ enum {
                                        ring (A/B knob; measured slower than the default form)                      */
   DSIM_OPT_MIXED_V3    = 1u << 9,   /* mixed fleets, wave-tiled layout: the three-wave form of the LDS-DMA-staged kernel
                                        (what other layouts get) instead of the two-wave one (A/B knob)             */
+  DSIM_OPT_RUNS_ONE_LAUNCH = 1u << 12, /* type-major storage (runs): all runs in ONE launch holding every law (the default;
+                                       the bit is kept for symmetry) (A/B knob)                                           */
+  DSIM_OPT_RUNS_SEPARATE = 1u << 13, /* ... one single-law launch per run (A/B knob)                                      */
   /* -- physics (changes results) ------------------------------------------------------------------------------------ */
   DSIM_OPT_PLANE       = 1u << 10,  /* ground plane z = 0 with contact and friction, as the reference's world has
                                        (BaseAviary.py:680 loads plane.urdf, collisions on).  A PRODUCT-DEFINED contact

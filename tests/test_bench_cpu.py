@@ -43,3 +43,31 @@ def test_single_rank_needs_no_launcher():
 def test_gpus_must_agree_with_the_launcher():
     r = _run(["--gpus", "2", "--dry-run"], env={"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2 and "must agree" in r.stderr
+
+
+def test_eight_ranks_dry_run_config5():
+    """The N = 8 launch of the driver's scaling run, host logic only: eight gloo ranks rendezvous, every rank's row
+    reaches rank 0, one line comes out."""
+    r = _run(["--gpus", "8", "--steps", "3", "--warmup", "1", "--dry-run", "--workload", "config5"], timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 8 and d["dist"]["world_size"] == 8 and "configs[4]" in d["config"]["workload"]
+    assert d["ranks"]["seen"] == list(range(8))
+    assert d["ranks"]["launch_us_min"] == 1e3 and d["ranks"]["launch_us_max"] == 8e3 and d["wall_max_over_ranks_s"] == 8e-3
+
+
+def test_watchdog_saves_the_headline_when_an_extra_section_hangs():
+    """bench.py measures config 5 on all ranks BEHIND the headline of a multi-GPU run; if that collective section hangs,
+    rank 0 still prints the line it has and every rank leaves with exit code 0."""
+    code = ("import sys, time, json; sys.path.insert(0, %r); import bench\n"
+            "line = {'metric': 'm', 'value': 1.5}\n"
+            "with bench.Watchdog(0.5, 0, line):\n"
+            "    time.sleep(30)\n"
+            "print('not reached')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "not reached" not in r.stdout
+    d = _json_line(r.stdout)
+    assert d["value"] == 1.5 and "abandoned" in d["config5_all_ranks"]["error"]
+    code2 = code.replace("bench.Watchdog(0.5, 0, line)", "bench.Watchdog(0.5, 3, line)")
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip() == ""           # the other ranks leave quietly

@@ -110,6 +110,21 @@ __global__ __launch_bounds__(256) void k_copy4(const float4* a, float4* b, long 
   if (i < n4) b[i] = a[i];
 }
 
+// K4 / K5: one-directional yardsticks.  HBM3E on MI355X does not serve reads and writes at the same rate, so a kernel's
+// floor depends on its read : write mix (bench.py prints both and the floor of the headline mix).
+__global__ __launch_bounds__(256) void k_read4(const f4* a, float* sink, long long n4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  f4 v = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4) v = __builtin_nontemporal_load(a + i);
+  const float s = v.x + v.y + v.z + v.w;
+  if (s == 12345.678f) sink[0] = s;            // never true: keeps the load alive without a store
+}
+__global__ __launch_bounds__(256) void k_write4(f4* b, long long n4, float x) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const f4 v = {x, x + 1.f, x + 2.f, x + 3.f};
+  if (i < n4) __builtin_nontemporal_store(v, b + i);
+}
+
 template <typename F>
 float time_it(F f, int iters) {
   hipEvent_t e0, e1;
@@ -145,8 +160,12 @@ int main(int argc, char** argv) {
     const long long n4 = FS * n / 4;
     float4* dst; CK(hipMalloc(&dst, sizeof(float4) * n4));
     const float copy_ms = time_it([&] { hipLaunchKernelGGL(k_copy4, dim3((unsigned)((n4 + 255) / 256)), b, 0, 0, (const float4*)st, dst, n4); }, 20);
-    printf("{\"drones\": %lld, \"access_shape_floor_us\": %.2f, \"access_shape_GBps\": %.1f, \"float4_copy_GBps\": %.1f}\n", n,
-           shape_ms * 1e3, 232.0 * n / (shape_ms * 1e-3) / 1e9, 2.0 * 16 * n4 / (copy_ms * 1e-3) / 1e9);
+    const float read_ms = time_it([&] { hipLaunchKernelGGL(k_read4, dim3((unsigned)((n4 + 255) / 256)), b, 0, 0, (const f4*)st, tg, n4); }, 20);
+    const float write_ms = time_it([&] { hipLaunchKernelGGL(k_write4, dim3((unsigned)((n4 + 255) / 256)), b, 0, 0, (f4*)dst, n4, 1.0f); }, 20);
+    printf("{\"drones\": %lld, \"access_shape_floor_us\": %.2f, \"access_shape_GBps\": %.1f, \"float4_copy_GBps\": %.1f, "
+           "\"float4_read_GBps\": %.1f, \"float4_write_GBps\": %.1f}\n", n,
+           shape_ms * 1e3, 232.0 * n / (shape_ms * 1e-3) / 1e9, 2.0 * 16 * n4 / (copy_ms * 1e-3) / 1e9,
+           16.0 * n4 / (read_ms * 1e-3) / 1e9, 16.0 * n4 / (write_ms * 1e-3) / 1e9);
     return 0;
   }
   float *st, *tg;
