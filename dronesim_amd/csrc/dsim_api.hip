@@ -81,8 +81,12 @@ __device__ __forceinline__ unsigned kv_lane(const KView& v, unsigned t) {
 // when the state is stored, which removes the binning launch from the step chain.
 #define DW_CAP 64
 #define DW_CUTOFF 10.0f
+// ints behind the per-cell counts of a bucket grid's count buffer: [0] overflow length; [1..4] the cell range that holds
+// entries, as maxima so that an all-zero buffer is the neutral element: nx-1-cx_min, cx_max, ny-1-cy_min, cy_max (kept by
+// the halo binning only: the halo pass of the query leaves at once where no halo entry can be in reach); [5] spare
+#define DW_CNT_EXTRA 6
 struct BinK {
-  int* count;          // [ncells + 2]: entries per cell; count[ncells] = overflow length.  null = no binning
+  int* count;          // [ncells + DW_CNT_EXTRA]: entries per cell, then the extras above.  null = no binning
   float4* buckets;     // [ncells][DW_CAP]
   float4* overflow;    // [m]
   float xmin, ymin, inv_cell;
@@ -118,7 +122,7 @@ __device__ __forceinline__ void bin_entry(const BinK& b, float x, float y, float
 static inline bool dw_use_buckets(int64_t m, int64_t ncells) { return ncells <= 65536 && m <= ncells * (DW_CAP * 5 / 8); }
 // where the bucket form keeps things inside the workspace (ints): count x2 | 16-byte aligned buckets | overflow
 static inline void bucket_layout(int32_t* ws, long long ncells, int parity, BinK* b) {
-  const long long cstride = ncells + 2;
+  const long long cstride = ncells + DW_CNT_EXTRA;
   b->count = ws + (long long)parity * cstride;
   uintptr_t sp = (uintptr_t)(ws + 2 * cstride);
   b->buckets = (float4*)((sp + 15) & ~(uintptr_t)15);
@@ -1291,8 +1295,15 @@ __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_control_gen(StepK a) {
 //   k_control_fast  reads 13 + 11 + 10, writes the 11 controller-memory floats (+ pos_e, yaw_e, and the command as a
 //                   plain SoA array that the next dsim_physics takes as its action without a copy).
 // 216 + 212 bytes per drone and iteration instead of the 480+ of physics_gen + observe + control_gen + copies.
+#ifndef DSIM_PHYS_WAVES
+#define DSIM_PHYS_WAVES DSIM_STEP_WAVES   // (79 VGPRs, 6 waves per SIMD.  Measured and rejected: 8 waves per SIMD — 64 VGPRs and
+                                          // 12 B of scratch per lane, 320 against 327 us for the two-call loop, inside that box's run-to-run spread)
+#endif
+#ifndef DSIM_OBS_STREAM
+#define DSIM_OBS_STREAM 1      // observation rows leave with the streaming hint when the state does (A/B knob of the build)
+#endif
 template <bool NOISE, bool NT, bool OBS>
-__global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_physics_fast(StepK a) {
+__global__ __launch_bounds__(256, DSIM_PHYS_WAVES) void k_physics_fast(StepK a) {
   constexpr int W = 20;
   // Observation rows: each wave owns 64 consecutive rows = 5 120 contiguous bytes of the row-major [n][20] output.  Lane r
   // writes ITS row to the wave's private LDS block as five 16-byte pieces (row stride 80 B: eight lanes cover the 32
@@ -1345,7 +1356,7 @@ __global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_physics_fast(StepK a) 
       const unsigned p = (unsigned)k * 64u + lane;           // piece p of the block belongs to row p / 5
       const vf4 v = blk[p];
       if ((long long)(p / (W / 4)) < left) {
-        if (NT) __builtin_nontemporal_store(v, dst + p); else dst[p] = v;
+        if (NT && DSIM_OBS_STREAM) __builtin_nontemporal_store(v, dst + p); else dst[p] = v;
       }
     }
   }
@@ -1760,7 +1771,16 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
   const unsigned t = threadIdx.x;
   {
     const long long gid = (long long)blockIdx.x * TPB + t;
-    for (long long z = gid; z < (long long)ncells + 2; z += (long long)gridDim.x * TPB) a.count_next[z] = 0;
+    for (long long z = gid; z < (long long)ncells + DW_CNT_EXTRA; z += (long long)gridDim.x * TPB) a.count_next[z] = 0;
+  }
+  if (accumulate && (int)blockIdx.x < ncells) {
+    // halo pass: the cells that hold halo entries span [lo, hi] in each direction (kept by k_dw_bin_halo); a cell further
+    // than the neighbourhood's reach from that range has nothing to add — most of a slab's cells: two scalar loads and out
+    const int cx_ = (int)blockIdx.x % b.nx, cy_ = (int)blockIdx.x / b.nx;
+    const int rg = rings;
+    const int xlo = b.nx - 1 - cnd.count[ncells + 1], xhi = cnd.count[ncells + 2];
+    const int ylo = b.ny - 1 - cnd.count[ncells + 3], yhi = cnd.count[ncells + 4];
+    if (cx_ + rg < xlo || cx_ - rg > xhi || cy_ + rg < ylo || cy_ - rg > yhi) return;
   }
   const int sub = (int)(t % DW_LPB), r_in = (int)(t / DW_LPB);
   if ((int)blockIdx.x >= ncells) {
@@ -1829,6 +1849,8 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
   const bool whole = total <= tile_cap;
   if constexpr (BAND) {
     const int G = (cnt_c + DW_RPG - 1) / DW_RPG;
+    // (measured and rejected: sending the halo pass — few candidates — down the plain path below: 65.5 against 62.1 us for
+    // the three phases; the bands save more pairs than their set-up costs even there)
     if (whole && G >= 2 && total <= DW_ENT_PER_THREAD * TPB) {
       const unsigned lane = t & 63u;
       const int w = __builtin_amdgcn_readfirstlane((int)(t >> 6));
@@ -1871,13 +1893,25 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
           }
         }
       }
+      // A candidate further than the cut-off from every point of THIS cell is useless to all of its receivers: the
+      // 5 x 5 cells around a 5 m cell cover 625 m^2, the cell grown by 10 m 539 m^2 (the corner cells lose two thirds of
+      // their area) — 14 % fewer pair evaluations for one distance test per candidate.  (Border cells also hold the
+      // drones that lie outside the grid, clamped: their box is open on that side.  The 1 mm of slack covers the rounding
+      // of the cell assignment; every pair is still tested against the cut-off itself.)
+      const float cs = DSIM_RCP(b.inv_cell);
+      const float bx0 = cx == 0 ? -__builtin_inff() : b.xmin + (float)cx * cs, bx1 = cx == b.nx - 1 ? __builtin_inff() : b.xmin + (float)(cx + 1) * cs;
+      const float by0 = cy == 0 ? -__builtin_inff() : b.ymin + (float)cy * cs, by1 = cy == b.ny - 1 ? __builtin_inff() : b.ymin + (float)(cy + 1) * cs;
+      constexpr float REACH2 = (DW_CUTOFF + 1e-3f) * (DW_CUTOFF + 1e-3f);
 #pragma unroll
       for (int q = 0; q < DW_ENT_PER_THREAD; ++q) {
         const int e = (int)t + q * TPB;
         int band = 0;
         if (e < total) {
-          for (int g = 0; g < G; ++g) band += zlo[g] < ent[q].z ? 1 : 0;
-          if (band > 0) atomicAdd(&bcnt[band], 1);
+          const float ox = fmaxf(fmaxf(bx0 - ent[q].x, ent[q].x - bx1), 0.0f), oy = fmaxf(fmaxf(by0 - ent[q].y, ent[q].y - by1), 0.0f);
+          if (ox * ox + oy * oy < REACH2) {
+            for (int g = 0; g < G; ++g) band += zlo[g] < ent[q].z ? 1 : 0;
+            if (band > 0) atomicAdd(&bcnt[band], 1);
+          }
         }
         bands |= (unsigned)band << (4 * q);
       }
@@ -2036,11 +2070,17 @@ struct HaloK {
   long long index0;
 };
 // Select + pack, one launch.  For every peer p whose last known box (the header of p's last message, device memory)
-// grown by reach[p] holds this drone, the drone's position is appended to send[p] (one atomic per wave and peer); the
-// workgroups also reduce this rank's own box, and the last one to finish writes the headers (count SELECTED, own box)
-// and resets the scratch for the next call.  ~8 vector instructions per drone and peer: noise beside the query.
-__global__ __launch_bounds__(256) void k_halo_pack(HaloK a) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+// grown by reach[p] holds this drone, the drone's position is appended to send[p]; the workgroups also reduce this rank's
+// own box, and the last one to finish writes the headers (count SELECTED, own box) and resets the scratch for the next
+// call.  Workgroups of 1 024 drones with ONE reservation per workgroup and peer: the slots are reserved by atomics on one
+// counter per peer, which the memory system serialises — reserved per wave (1 024 waves of a 65 536-drone shard, each
+// holding a few drones of the strip) the kernel took ~70 us; 64 reservations take ~3.
+#define DSIM_PACK_TPB 1024
+__global__ __launch_bounds__(DSIM_PACK_TPB) void k_halo_pack(HaloK a) {
+  constexpr int NW = DSIM_PACK_TPB / 64;
+  __shared__ int wsum[DSIM_MAX_PEERS][NW];                 // per peer: selected per wave, then each wave's first slot
+  __shared__ float wred[5][NW];
+  const long long i = (long long)blockIdx.x * DSIM_PACK_TPB + threadIdx.x;
   const bool live = i < a.n;
   float x = 0.0f, y = 0.0f, z = 0.0f, vm = 0.0f;
   if (live) {
@@ -2049,28 +2089,19 @@ __global__ __launch_bounds__(256) void k_halo_pack(HaloK a) {
     x = q[0]; y = q[fs]; z = q[2 * fs];
     vm = fmaxf(fmaxf(fabsf(q[7 * fs]), fabsf(q[8 * fs])), fabsf(q[9 * fs]));
   }
-  const unsigned lane = threadIdx.x & 63u;
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  unsigned long long sel[DSIM_MAX_PEERS];                  // (constant indices only: wave-uniform masks in SGPRs)
 #pragma unroll
   for (int p = 0; p < DSIM_MAX_PEERS; ++p) {
-    if (p >= a.world || p == a.rank || a.send_cap[p] == 0) continue;           // uniform
+    sel[p] = 0ULL;
+    if (p >= a.world || p == a.rank || a.send_cap[p] == 0) { if (lane == 0) wsum[p][wave] = 0; continue; }   // uniform
     const float* hdr = a.recv + (long long)p * a.stride;                        // scalar loads
     const float r = a.reach[p];
     const bool in = live && x >= hdr[1] - r && x <= hdr[3] + r && y >= hdr[2] - r && y <= hdr[4] + r;
-    const unsigned long long m = __ballot(in);
-    if (m == 0ULL) continue;
-    const int lead = __builtin_ctzll(m);
-    int base = 0;
-    if ((int)lane == lead) base = atomicAdd(&a.scratch[p], (int)__popcll(m));
-    base = __shfl(base, lead);
-    if (in) {
-      const int slot = base + (int)__popcll(m & ((1ULL << lane) - 1ULL));
-      if (slot < a.send_cap[p]) {
-        float* d = a.send + (long long)p * a.stride + DSIM_HALO_HDR + 3LL * slot;
-        d[0] = x; d[1] = y; d[2] = z;
-      }
-    }
+    sel[p] = __ballot(in);
+    if (lane == 0) wsum[p][wave] = (int)__popcll(sel[p]);
   }
-  // own box: wave reduce, then atomics only from the waves that improve on what is already there
+  // own box: wave reduce here, workgroup and grid below
   float xmin = live ? x : __builtin_inff(), xmax = live ? x : -__builtin_inff();
   float ymin = live ? y : __builtin_inff(), ymax = live ? y : -__builtin_inff();
 #pragma unroll
@@ -2079,10 +2110,24 @@ __global__ __launch_bounds__(256) void k_halo_pack(HaloK a) {
     xmax = fmaxf(xmax, __shfl_xor(xmax, off)); ymax = fmaxf(ymax, __shfl_xor(ymax, off));
     vm = fmaxf(vm, __shfl_xor(vm, off));
   }
-  // (the minima are kept as the maxima of the inverted keys, so that a zero-initialised scratch is the neutral element)
-  unsigned* keys = reinterpret_cast<unsigned*>(a.scratch + 9);
-  if (lane == 0) {
-    const unsigned k0 = ~fkey(xmin), k1 = ~fkey(ymin), k2 = fkey(xmax), k3 = fkey(ymax), k4 = fkey(vm);
+  if (lane == 0) { wred[0][wave] = xmin; wred[1][wave] = ymin; wred[2][wave] = xmax; wred[3][wave] = ymax; wred[4][wave] = vm; }
+  __syncthreads();
+  if (threadIdx.x < DSIM_MAX_PEERS) {                       // thread p: the workgroup's reservation for peer p
+    const int p = (int)threadIdx.x;
+    int run = 0;
+    for (int w = 0; w < NW; ++w) { const int c = wsum[p][w]; wsum[p][w] = run; run += c; }
+    const int base = run ? atomicAdd(&a.scratch[p], run) : 0;
+    for (int w = 0; w < NW; ++w) wsum[p][w] += base;
+  } else if (threadIdx.x == 64) {                           // (another wave: the workgroup's box, then the grid's)
+    float b0 = wred[0][0], b1 = wred[1][0], b2 = wred[2][0], b3 = wred[3][0], b4 = wred[4][0];
+    for (int w = 1; w < NW; ++w) {
+      b0 = fminf(b0, wred[0][w]); b1 = fminf(b1, wred[1][w]); b2 = fmaxf(b2, wred[2][w]); b3 = fmaxf(b3, wred[3][w]);
+      b4 = fmaxf(b4, wred[4][w]);
+    }
+    // (the minima are kept as the maxima of the inverted keys, so that a zero-initialised scratch is the neutral element;
+    // atomics only where the workgroup improves on what is already there)
+    unsigned* keys = reinterpret_cast<unsigned*>(a.scratch + 9);
+    const unsigned k0 = ~fkey(b0), k1 = ~fkey(b1), k2 = fkey(b2), k3 = fkey(b3), k4 = fkey(b4);
     if (k0 > __atomic_load_n(&keys[0], __ATOMIC_RELAXED)) atomicMax(&keys[0], k0);
     if (k1 > __atomic_load_n(&keys[1], __ATOMIC_RELAXED)) atomicMax(&keys[1], k1);
     if (k2 > __atomic_load_n(&keys[2], __ATOMIC_RELAXED)) atomicMax(&keys[2], k2);
@@ -2090,10 +2135,23 @@ __global__ __launch_bounds__(256) void k_halo_pack(HaloK a) {
     if (k4 > __atomic_load_n(&keys[4], __ATOMIC_RELAXED)) atomicMax(&keys[4], k4);
   }
   __syncthreads();
+#pragma unroll
+  for (int p = 0; p < DSIM_MAX_PEERS; ++p) {
+    if (sel[p] == 0ULL) continue;                                               // uniform
+    if ((sel[p] >> lane) & 1ULL) {
+      const int slot = wsum[p][wave] + (int)__popcll(sel[p] & ((1ULL << lane) - 1ULL));
+      if (slot < a.send_cap[p]) {
+        float* d = a.send + (long long)p * a.stride + DSIM_HALO_HDR + 3LL * slot;
+        d[0] = x; d[1] = y; d[2] = z;
+      }
+    }
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
     if (atomicAdd(&a.scratch[8], 1) == (int)gridDim.x - 1) {
       __threadfence();
+      unsigned* keys = reinterpret_cast<unsigned*>(a.scratch + 9);
       const float bx0 = fkey_inv(~atomicExch(&keys[0], 0u)), by0 = fkey_inv(~atomicExch(&keys[1], 0u));
       const float bx1 = fkey_inv(atomicExch(&keys[2], 0u)), by1 = fkey_inv(atomicExch(&keys[3], 0u));
       const float bv = fkey_inv(atomicExch(&keys[4], 0u));
@@ -2126,6 +2184,24 @@ __device__ __forceinline__ void halo_locate(const HaloK& h, int e, int& p, int& 
 __global__ __launch_bounds__(256) void k_dw_bin_halo(BinK b, HaloK h) {
   const int e = (int)(blockIdx.x * 256 + threadIdx.x);
   if (e >= h.off[DSIM_MAX_PEERS]) return;
+  if (e == 0) {
+    // The cell range that can hold halo entries, for the early exit of the halo pass (DW_CNT_EXTRA): every entry of peer q
+    // lies inside q's box, which rides in the message header — ONE thread turns the boxes into cell ranges (the same
+    // clamped floor as the binning: monotonic, so the range covers the entries' cells).  No atomics: thousands of
+    // same-address atomicMax from the entries themselves serialise (measured +7 us even wave-reduced and filtered).
+    int kx = 0, kX = 0, ky = 0, kY = 0;
+#pragma unroll
+    for (int q = 0; q < DSIM_MAX_PEERS; ++q) {
+      if (h.recv_cap[q] == 0) continue;
+      const float* hd = h.recv + (long long)q * h.stride;
+      if (__float_as_int(hd[0]) <= 0) continue;
+      const int x0 = min(max((int)floorf((hd[1] - b.xmin) * b.inv_cell), 0), b.nx - 1), x1 = min(max((int)floorf((hd[3] - b.xmin) * b.inv_cell), 0), b.nx - 1);
+      const int y0 = min(max((int)floorf((hd[2] - b.ymin) * b.inv_cell), 0), b.ny - 1), y1 = min(max((int)floorf((hd[4] - b.ymin) * b.inv_cell), 0), b.ny - 1);
+      kx = max(kx, b.nx - 1 - x0); kX = max(kX, x1); ky = max(ky, b.ny - 1 - y0); kY = max(kY, y1);
+    }
+    int* ext = b.count + b.nx * b.ny;
+    ext[1] = kx; ext[2] = kX; ext[3] = ky; ext[4] = kY;
+  }
   int p, k;
   halo_locate(h, e, p, k);
   const float* msg = h.recv + (long long)p * h.stride;
@@ -2436,7 +2512,7 @@ static void bin_next_prepare(dsim_ctx* ctx, int64_t n, const dsim_step_args* arg
   if (ctx->dw_prebin) {
     // an earlier step already filled this buffer and no dsim_downwash has consumed it (two steps in a row): start over,
     // so that the buffer never holds two generations of positions
-    (void)hipMemsetAsync(a->bin.count, 0, sizeof(int) * (size_t)(ncells + 2), st);
+    (void)hipMemsetAsync(a->bin.count, 0, sizeof(int) * (size_t)(ncells + DW_CNT_EXTRA), st);
     ctx->dw_prebin = false;
   }
   a->bin.xmin = g->xmin; a->bin.ymin = g->ymin; a->bin.inv_cell = 1.0f / g->cell; a->bin.nx = g->nx; a->bin.ny = g->ny;
@@ -2933,7 +3009,7 @@ int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny) {
   if (m < 0 || nx < 1 || ny < 1) return -1;
   const int64_t ncells = (int64_t)nx * ny;
   const int64_t sort_form = 2 * (ncells + 1) + ncells + 4 + 4 * m;   // count x2, cursor, 16-B alignment slack, float4[m]
-  const int64_t bucket_form = 2 * (ncells + 2) + 4 + 4 * ncells * DW_CAP + 4 * m;   // count x2, slack, buckets, overflow
+  const int64_t bucket_form = 2 * (ncells + DW_CNT_EXTRA) + 4 + 4 * ncells * DW_CAP + 4 * m;   // count x2, slack, buckets, overflow
   return dw_use_buckets(m, ncells) && bucket_form > sort_form ? bucket_form : sort_form;
 }
 
@@ -2944,7 +3020,7 @@ static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view
 static inline void halo_layout(int32_t* ws, long long ncells, long long n_local, int parity, BinK* b) {
   BinK loc;
   bucket_layout(ws, ncells, 0, &loc);
-  const long long cstride = ncells + 2;
+  const long long cstride = ncells + DW_CNT_EXTRA;
   uintptr_t sp = (uintptr_t)(loc.overflow + n_local);
   int* base = (int*)((sp + 15) & ~(uintptr_t)15);
   b->count = base + (long long)parity * cstride;
@@ -2956,8 +3032,8 @@ int64_t dsim_downwash_workspace_halo(int64_t n, int64_t h, int32_t nx, int32_t n
   if (n < 1 || h < 0 || nx < 1 || ny < 1) return -1;
   const int64_t ncells = (int64_t)nx * ny;
   if (!dw_use_buckets(n + h, ncells)) return -1;
-  const int64_t local = 2 * (ncells + 2) + 4 + 4 * ncells * DW_CAP + 4 * n;
-  const int64_t split = local + 4 + 2 * (ncells + 2) + 4 + 4 * ncells * DW_CAP + 4 * h;
+  const int64_t local = 2 * (ncells + DW_CNT_EXTRA) + 4 + 4 * ncells * DW_CAP + 4 * n;
+  const int64_t split = local + 4 + 2 * (ncells + DW_CNT_EXTRA) + 4 + 4 * ncells * DW_CAP + 4 * h;
   const int64_t one = dsim_downwash_workspace(n + h, nx, ny);      // DSIM_DW_ALL on the same buffer
   return split > one ? split : one;
 }
@@ -3039,7 +3115,7 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
     if (fresh) {
       if (g->phase == DSIM_DW_HALO_QUERY) return DSIM_E_ARG;          // HALO_BIN of this step comes first
       halo_layout(g->workspace, ncells, n, 0, &hb);
-      hipError_t e = hipMemsetAsync(hb.count, 0, sizeof(int) * 2 * (size_t)(ncells + 2), st_);
+      hipError_t e = hipMemsetAsync(hb.count, 0, sizeof(int) * 2 * (size_t)(ncells + DW_CNT_EXTRA), st_);
       if (e != hipSuccess) return (int)e;
       ctx->dwh_ws = g->workspace; ctx->dwh_cells = ncells; ctx->dw_local_m = n; ctx->dwh_parity = 0;
     }
@@ -3113,7 +3189,7 @@ int dsim_halo_pack(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, cons
   if (rc) return rc;
   halo_fill(plan, &h);
   h.n = n; h.counters = ctx->d_counters;
-  hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, h);
+  hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((n + DSIM_PACK_TPB - 1) / DSIM_PACK_TPB)), dim3(DSIM_PACK_TPB), 0, (hipStream_t)stream, h);
   return (int)hipGetLastError();
 }
 
@@ -3150,7 +3226,7 @@ static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view
   if (g->local_offset < 0 || g->local_offset + n > g->m || g->m >= (1LL << 31)) return DSIM_E_ARG;
   a.xmin = g->xmin; a.ymin = g->ymin; a.inv_cell = 1.0f / g->cell; a.nx = g->nx; a.ny = g->ny;
   const bool buckets = allow_buckets && dw_use_buckets(g->m, ncells);
-  const long long cstride = ncells + (buckets ? 2 : 1);      // the bucket form keeps the overflow length behind the cells
+  const long long cstride = ncells + (buckets ? DW_CNT_EXTRA : 1);      // the bucket form keeps the overflow length (and more) behind the cells
   // two count buffers alternate between calls; the one for the next call is zeroed by this call's first kernel
   const bool same = ctx->dw_ws == g->workspace && ctx->dw_cells == ncells && ctx->dw_mode == (buckets ? 1 : 0);
   const int cur = same ? ctx->dw_parity : 0;

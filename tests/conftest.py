@@ -32,5 +32,8 @@ def pytest_terminal_summary(terminalreporter):
         out = os.environ.get("DSIM_MARGINS_OUT")
         if out:
             import json
+            from tests.util import WHERE
             with open(out, "w") as fh:
                 json.dump({k: round(v, 4) for k, v in sorted(WORST.items())}, fh, indent=1)
+            with open(os.path.splitext(out)[0] + "_where.json", "w") as fh:
+                json.dump({k: v for k, v in sorted(WHERE.items())}, fh, indent=1)

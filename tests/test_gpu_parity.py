@@ -2163,7 +2163,25 @@ def test_wls_fallback_queue_of_a_large_fleet(gpu):
     # the clip decides the rest identically
     both_clipped = ((got[idx, 7:13] <= 0) | (got[idx, 7:13] >= 1)) & ((o[:, 7:13] <= 0) | (o[:, 7:13] >= 1))
     err = np.abs(got[idx, 7:13] - o[:, 7:13])
-    assert np.median(err) < 1e-5 and (err[both_clipped] == 0).all() and np.quantile(err, 0.99) < 2e-3
+    assert np.median(err) < 1e-5 and (err[both_clipped] == 0).all()
+    # A bound for EVERY sampled drone (round 2 accepted a q99): the device evaluates the virtual control nu in fp32 —
+    # its dominant terms are rates / dt, so a few ulps of the rates move nu by what the fp32 arithmetic may — and the
+    # active-set solution is piecewise linear in nu.  The oracle's own allocation, re-run on inputs moved by +-4 fp32
+    # ulps, shows per drone how far such a change carries the command: the device must stay within a small multiple.
+    from tests.util import WORST
+    spread = np.zeros_like(err)
+    O2 = orc.Oracle([t])
+    for trial in range(8):
+        rp, mp = rigid[idx].copy(), mem[idx].copy()
+        rp[:, 7:13] += rng.choice([-4.0, 4.0], rp[:, 7:13].shape) * ulp32(rp[:, 7:13])
+        mp[:, 0:6] += rng.choice([-4.0, 4.0], mp[:, 0:6].shape) * ulp32(mp[:, 0:6])
+        assert O2.control(rp, mp, tgt[idx], DT)[0] == 0
+        spread = np.maximum(spread, np.abs(mp[:, 7:13] - o[:, 7:13]))
+    tol = 4.0 * spread.max(1, keepdims=True) + REL_TOL * np.abs(o[:, 7:13] - mem[idx, 7:13]) + 4 * ulp32(1.0)
+    ratio = err / tol
+    WORST["wls fallback queue: per-drone bound"] = float(ratio.max())
+    assert ratio.max() <= 1.0, (float(ratio.max()), int(np.argmax(ratio.max(1))), float(err.max()), float(np.quantile(tol, 0.99)))
+    assert np.quantile(tol, 0.99) < 5e-3                          # ... and that bound is itself small for all but a few
     # a second call finds the queue emptied by the first
     nat.check(ctx.lib.dsim_control(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a), None, None))
     assert np.isfinite(st.mem_aos()).all()

@@ -129,3 +129,50 @@ def test_plane_contact_model_against_the_recorded_touchdown():
     if touching.any() and leave_rec < n_rec:
         leave = int(np.flatnonzero(touching)[-1]) + 1
         assert abs(leave - leave_rec) * dtc < 0.1, (leave, leave_rec)
+
+
+def _has(key):
+    return os.path.exists(FIXTURE) and key in np.load(FIXTURE, allow_pickle=False).files
+
+
+@pytest.mark.skipif(not _has("helpers_quat_in"), reason="the fixture holds no C8 helper table (record it with round 3's recorder)")
+def test_c8_helpers_match_pybullet_on_the_attitude_zoo():
+    """C8 pinned directly: the oracle's restatement of the three PyBullet helpers (the goldens of the control half were
+    generated with a stand-in for them, tests/golden/make_goldens.py:42-81) against the engine's own functions on the
+    recorded zoo — whole sphere, both signs of w, both gimbal branches and their edge, non-unit quaternions."""
+    g = np.load(FIXTURE, allow_pickle=False)
+    q = g["helpers_quat_in"]
+    e = np.array([orc.euler_from_quat(x) for x in q])
+    sarg = -2.0 * (q[:, 0] * q[:, 2] - q[:, 3] * q[:, 1])
+    off_edge = np.abs(np.abs(sarg) - 0.99999) > 1e-9                  # on the branch threshold Bullet itself is discontinuous
+    np.testing.assert_allclose(e[off_edge], g["helpers_euler_from_quat"][off_edge], rtol=0, atol=1e-12)
+    m = np.array([orc.matrix_from_quat(x).reshape(9) for x in q])
+    np.testing.assert_allclose(m, g["helpers_matrix_from_quat"], rtol=0, atol=1e-12)
+    qe = np.array([orc.quat_from_euler(x) for x in g["helpers_euler_in"]])
+    np.testing.assert_allclose(qe, g["helpers_quat_from_euler"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.skipif(not _has("hexa_state"), reason="the fixture holds no hexa_6DOF flight (record it with round 3's recorder)")
+def test_hexa_locked_joint_approximation_is_quantified():
+    """PyBullet flies hexa_6DOF as an articulated body (six revolute arm joints held by default motors,
+    hexa_6DOF.urdf:382-434); this repo flies the rigid composite with the joints locked.  Against the
+    recorded hover-and-step flight: how far the arm joints actually move in the engine, and how far one Env.step of the
+    rigid model is from the engine's, step by step from the engine's own previous state — the numbers are printed; the
+    bounds below are the ones under which the approximation was accepted (1 mrad of joint motion, 1e-3 relative per step)."""
+    g = np.load(FIXTURE, allow_pickle=False)
+    t = params.builtin_type("hexa_6DOF")
+    O = orc.Oracle([t])
+    aggr = int(g["hexa_aggr"])
+    joint_motion = float(np.abs(g["hexa_joint_angles"] - g["hexa_joint_angles"][0]).max())
+    prev = np.concatenate([g["hexa_init_xyz"][0], orc.quat_from_euler(g["hexa_init_rpy"][0]), np.zeros(6)])
+    worst = 0.0
+    for k in range(g["hexa_state"].shape[0]):
+        r = prev[None, :].copy()
+        a6 = g["hexa_action"][k][None, :].copy()
+        O.physics(r, O.reset_mem(1), aggr, DT, action=a6)
+        want = _rigid(g["hexa_state"][k])
+        inc = np.abs(want - prev)
+        worst = max(worst, float((np.abs(r[0] - want) / (inc + 1e-6)).max()))
+        prev = want
+    print(f"hexa_6DOF: arm joints move {joint_motion:.3e} rad in the engine; rigid-composite step differs by {worst:.3e} of the increment")
+    assert joint_motion < 1e-3 and worst < 1e-3

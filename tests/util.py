@@ -138,6 +138,10 @@ def increment_ratio(got, ref, prev, terms, k):
 
 
 WORST = {}     # test label -> worst ratio seen (printed by conftest at the end of the session)
+WHERE = {}     # test label -> where that worst ratio sits: block, field, the numbers (so that a thin margin can be traced
+               # to the term that produces it; written to DSIM_MARGINS_OUT beside the ratios)
+RIGID_NAMES = ["x", "y", "z", "qx", "qy", "qz", "qw", "vx", "vy", "vz", "wx", "wy", "wz"]
+MEM_NAMES = ["last_vx", "last_vy", "last_vz", "last_p", "last_q", "last_r", "last_thrust", "cmd0", "cmd1", "cmd2", "cmd3", "cmd4", "cmd5"]
 
 
 PLANE_SWEEPS = 24       # DSIM_PLANE_ITERS / ORC_PLANE_ITERS
@@ -187,12 +191,22 @@ def assert_step_parity(label, types, type_id, prev_rigid, prev_mem, tgt, got_rig
         tr, tm = tr + extra_terms[0], tm + extra_terms[1]
     rr = increment_ratio(got_rigid, ref_rigid, prev_rigid, tr, k)
     worst = float(rr.max())
-    where = ("rigid",) + tuple(int(x) for x in np.unravel_index(rr.argmax(), rr.shape))
+    i, f = (int(x) for x in np.unravel_index(rr.argmax(), rr.shape))
+    where = ("rigid", i, f)
+    detail = dict(field=RIGID_NAMES[f], drone=i, err=float(got_rigid[i, f] - ref_rigid[i, f]), increment=float(ref_rigid[i, f] - prev_rigid[i, f]),
+                  value=float(ref_rigid[i, f]), largest_term=float(tr[i, f]), k_ulp=float(k))
     if got_mem is not None:
-        rm = increment_ratio(got_mem, ref_mem, prev_mem, tm, k * tilt_gain(types, type_id, ref_rigid))
+        kk = k * tilt_gain(types, type_id, ref_rigid)
+        rm = increment_ratio(got_mem, ref_mem, prev_mem, tm, kk)
         if rm.max() > worst:
             worst = float(rm.max())
-            where = ("mem",) + tuple(int(x) for x in np.unravel_index(rm.argmax(), rm.shape))
+            i, f = (int(x) for x in np.unravel_index(rm.argmax(), rm.shape))
+            where = ("mem", i, f)
+            detail = dict(field=MEM_NAMES[f], drone=i, err=float(got_mem[i, f] - ref_mem[i, f]), increment=float(ref_mem[i, f] - prev_mem[i, f]),
+                          value=float(ref_mem[i, f]), largest_term=float(tm[i, f]), k_ulp=float(np.broadcast_to(kk, rm.shape)[i, f]))
+    if worst >= WORST.get(label, 0.0):
+        detail["ulp32_of_M"] = float(ulp32(max(abs(detail["value"]), abs(detail["value"] - detail["increment"]), detail["largest_term"], TINY)))
+        WHERE[label] = detail
     WORST[label] = max(WORST.get(label, 0.0), worst)
     assert worst <= 1.0, (label, worst, where)
     return worst

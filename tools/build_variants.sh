@@ -6,7 +6,9 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $ROOT/build
 while [ $# -ge 2 ]; do
-  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared $2 -o $ROOT/build/libdsim_$1.so $ROOT/dronesim_amd/csrc/dsim_api.hip
+  # (the flags of the default build, from __graft_entry__.HIPCC_FLAGS, so that a variant differs in what it is asked to)
+  FLAGS=$(cd $ROOT && python3 -c "import __graft_entry__ as g; print(' '.join(g.HIPCC_FLAGS))")
+  /opt/rocm/bin/hipcc $FLAGS $2 -o $ROOT/build/libdsim_$1.so $ROOT/dronesim_amd/csrc/dsim_api.hip
   echo "built build/libdsim_$1.so ($2)"
   shift 2
 done

@@ -62,6 +62,26 @@ d)
   done
   kt c5b --workload config5
   ;;
+e)
+  for round in 1 2 3; do
+    one "c5 auto" --workload config5
+    DSIM_STORAGE=caller one "c5 caller" --workload config5
+    one "c5 lowdensity" --workload config5 --slab-m 1024
+  done
+  kt c5e --workload config5
+  kt c5e_low --workload config5 --slab-m 1024
+  ;;
+f)
+  for round in 1 2 3; do
+    one "main tile64"
+    one "main tile256" --layout tile256
+    one "main tile1024" --layout tile1024
+    one "main tile4096" --layout tile4096
+    one "hexa tile64" --workload hexa
+    one "hexa tile1024" --workload hexa --layout tile1024
+    one "mixed tile1024" --workload mixed --layout tile1024
+  done
+  ;;
 b)
   DSIM_BENCH_BACKEND=gloo one "config5 2 gloo ranks, halo split" --workload config5 --gpus 2
   DSIM_BENCH_BACKEND=gloo DSIM_DW_SPLIT=0 one "config5 2 gloo ranks, halo one-grid" --workload config5 --gpus 2

@@ -12,9 +12,18 @@ switched off, and stores every Env.step's action, state vector and the controlle
 
     python tools/record_pybullet_trajectory.py --reference /path/to/dronesim --out tests/golden/pybullet_fly_INDI.npz
 
-240 physics steps = 48 control steps by default (--steps); the flight touches the ground plane around t = 0.35 s, which
-the fixture therefore covers (contact is not modelled here: tests compare up to `first_contact_step`).  Nothing is
-stubbed, vendored or re-implemented: without a real PyBullet the script refuses to run.
+360 physics steps = 72 control steps by default (--steps); the flight touches the ground plane around t = 0.35 s and
+leaves it about half a second later, which the fixture therefore covers (`contacts`, `first_contact_step`: the in-flight
+part pins P4, the touchdown interval is what DSIM_OPT_PLANE is compared with).  Nothing is stubbed, vendored or
+re-implemented: without a real PyBullet the script refuses to run.
+
+Round 3 additions, written into the same file:
+  * `helpers_*` — the three closed-form PyBullet helpers the controllers use (C8: INDIControl.py:225, 301, 388, 428) on a
+    seeded zoo of attitudes (whole sphere, both signs of w, both gimbal branches, non-unit quaternions):
+    p.getEulerFromQuaternion, p.getQuaternionFromEuler, p.getMatrixFromQuaternion — inputs and outputs;
+  * `hexa_*` — one hover-and-step flight of hexa_6DOF with the reference's own INDIControl_6DOF (PyBullet flies it as an
+    ARTICULATED body: six revolute arm joints held by default motors, hexa_6DOF.urdf:382-434; this repo flies the rigid
+    composite): states, actions, commands — what quantifies the locked-joint approximation.
 
 tests/test_p4_closure.py consumes the file and is skipped while it does not exist.
 """
@@ -30,7 +39,8 @@ def main(argv=None):
     ap.add_argument("--reference", default="/root/reference", help="checkout of enac-drones/dronesim")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                   "tests", "golden", "pybullet_fly_INDI.npz"))
-    ap.add_argument("--steps", type=int, default=48, help="control steps (x5 physics steps each)")
+    ap.add_argument("--steps", type=int, default=72, help="control steps (x5 physics steps each)")
+    ap.add_argument("--hexa-steps", type=int, default=96, help="control steps of the hexa_6DOF hover-and-step flight (0: skip)")
     ap.add_argument("--drone", default="robobee")
     a = ap.parse_args(argv)
     try:
@@ -81,8 +91,68 @@ def main(argv=None):
     out.update(init_xyz=init_xyz, init_rpy=init_rpy, sim_freq=sim_freq, ctrl_freq=ctrl_freq, aggr=aggr,
                first_contact_step=first, drone=a.drone,
                pybullet_api_version=np.int64(p.getAPIVersion()), numpy_version=np.__version__)
+    out.update(record_helpers(p))
+    if a.hexa_steps > 0:
+        out.update(record_hexa(p, a.hexa_steps, sim_freq, ctrl_freq))
     np.savez(a.out, **out)
     print(f"wrote {a.out}: {a.steps} control steps, first ground contact at step {first}")
+
+
+def record_helpers(p, seed=20260):
+    """C8: the three helpers on a seeded attitude zoo (inputs stored with the outputs, so the consumer needs no generator)."""
+    rng = np.random.default_rng(seed)
+    q = rng.normal(size=(2000, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)                          # whole sphere, w of both signs
+    rpy = np.stack([rng.uniform(-np.pi, np.pi, 400), np.zeros(400), rng.uniform(-np.pi, np.pi, 400)], 1)
+    sarg = np.concatenate([np.full(100, 1.0), 1.0 - rng.uniform(0, 8e-6, 100), 0.99999 - rng.uniform(3e-6, 5e-5, 200)])
+    rpy[:, 1] = np.arcsin(sarg * np.where(rng.uniform(size=400) < 0.5, -1.0, 1.0))       # both gimbal branches and their edge
+    qg = np.array([p.getQuaternionFromEuler(r.tolist()) for r in rpy])
+    qn = rng.normal(size=(400, 4))
+    qn = qn / np.linalg.norm(qn, axis=1, keepdims=True) * rng.uniform(0.5, 1.5, (400, 1))    # non-unit
+    quats = np.concatenate([q, qg, qn])
+    eulers_in = np.concatenate([rpy, rng.uniform(-np.pi, np.pi, (1000, 3))])
+    return {"helpers_quat_in": quats,
+            "helpers_euler_from_quat": np.array([p.getEulerFromQuaternion(x.tolist()) for x in quats]),
+            "helpers_matrix_from_quat": np.array([p.getMatrixFromQuaternion(x.tolist()) for x in quats]),
+            "helpers_euler_in": eulers_in,
+            "helpers_quat_from_euler": np.array([p.getQuaternionFromEuler(x.tolist()) for x in eulers_in])}
+
+
+def record_hexa(p, steps, sim_freq, ctrl_freq):
+    """hexa_6DOF, hover at its start for a third of the flight, then a 0.5 m step in x and 0.3 m in z
+    (examples/fly_hexa_6DOF.py drives the same classes), noise off."""
+    from dronesim.control.INDIControl_6DOF import INDIControl as INDIControl6
+    from dronesim.envs.BaseAviary import Physics
+    from dronesim.envs.CtrlAviary import CtrlAviary
+    aggr = int(sim_freq / ctrl_freq)
+    init_xyz, init_rpy = np.array([[0.0, 0.0, 1.0]]), np.zeros((1, 3))
+    env = CtrlAviary(drone_model=["hexa_6DOF"], num_drones=1, initial_xyzs=init_xyz, initial_rpys=init_rpy,
+                     physics=Physics.PYB, neighbourhood_radius=10, freq=sim_freq, aggregate_phy_steps=aggr,
+                     gui=False, record=False, obstacles=False, user_debug_gui=False)
+    real_normal = np.random.normal
+    np.random.normal = lambda loc=0.0, scale=1.0, size=None: np.zeros(size) if size is not None else 0.0
+    ctrl = INDIControl6(drone_model="hexa_6DOF")
+    action = {"0": np.full(6, 0.5)}                                       # INDIControl_6DOF.reset: cmd = 0.5
+    rec = {k: [] for k in ("hexa_action", "hexa_state", "hexa_cmd", "hexa_target_pos", "hexa_joint_angles")}
+    n_joints = p.getNumJoints(env.DRONE_IDS[0], physicsClientId=env.CLIENT)
+    try:
+        for k in range(steps):
+            obs, _, _, _ = env.step(action)
+            tpos = init_xyz[0] + (np.array([0.5, 0.0, 0.3]) if k >= steps // 3 else 0.0)
+            rec["hexa_action"].append(np.asarray(action["0"], dtype=np.float64).copy())
+            rec["hexa_state"].append(np.asarray(obs["0"]["state"], dtype=np.float64).copy())
+            rec["hexa_joint_angles"].append([p.getJointState(env.DRONE_IDS[0], j, physicsClientId=env.CLIENT)[0]
+                                             for j in range(n_joints)])
+            out = ctrl.computeControlFromState(control_timestep=aggr / sim_freq, state=obs["0"]["state"], target_pos=tpos)
+            action = {"0": out[0]}
+            rec["hexa_cmd"].append(np.asarray(out[0], dtype=np.float64).copy())
+            rec["hexa_target_pos"].append(tpos.copy())
+    finally:
+        np.random.normal = real_normal
+        env.close()
+    res = {k: np.asarray(v) for k, v in rec.items()}
+    res.update(hexa_init_xyz=init_xyz, hexa_init_rpy=init_rpy, hexa_aggr=aggr)
+    return res
 
 
 if __name__ == "__main__":
