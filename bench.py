@@ -72,6 +72,8 @@ def parse(argv=None):
     p.add_argument("--lib", default=None, help="a differently-tuned build of libdronesim_amd.so (A/B runs)")
     p.add_argument("--runs", choices=["auto", "one", "separate"], default="auto",
                    help="type-major storage: DSIM_OPT_RUNS_ONE_LAUNCH / _SEPARATE (A/B knob)")
+    p.add_argument("--mirror-peer", action="store_true",
+                   help="config5 on ONE rank with a synthetic mirrored neighbour (MirrorDist): traces the device-paced exchange path")
     p.add_argument("--replicas", type=int, default=0, help="override the number of vectorised env replicas (A/B runs)")
     p.add_argument("--dry-run", action="store_true",
                    help="host logic only (launcher, rendezvous, reductions, the JSON line); no device work — CPU tests")
@@ -279,6 +281,65 @@ def cpu_baseline(substeps, seconds=4.0):
         "reference_python_note": "reference INDIControl.computeControl alone: 8.2e3 calls/s/core (SURVEY.md 6, survey "
                                  "container); PyBullet Env.step not measurable (engine absent)",
     }
+
+
+class MirrorDist:
+    """A synthetic neighbour for ONE rank (``--mirror-peer``): the world continues mirrored beyond the slab edge x = edge, so
+    "the other rank" is this rank's own reflection — its box, its counts and its messages are this rank's, mirrored.  It
+    stands in for torch.distributed in downwash.HaloPlan with a wire that never leaves the device (a copy and three small
+    element-wise kernels on the side stream), so that the device-paced exchange path — select + pack, wire, halo binning
+    beside the local pass of the query, halo pass — can be traced and timed on one GPU without gloo's host staging.  Not a
+    multi-GPU measurement: there is no second device and no RCCL in it."""
+
+    class _Done:
+        def wait(self):
+            return None
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    isend, irecv = "isend", "irecv"
+
+    def __init__(self, edge):
+        self.edge = float(edge)
+
+    def is_initialized(self):
+        return True
+
+    def get_rank(self):
+        return 0
+
+    def get_world_size(self):
+        return 2
+
+    def get_backend(self):
+        return "mirror"
+
+    def all_gather_into_tensor(self, out, mine):
+        out[0] = mine.reshape(-1)
+        if out.shape[1] == 5:                       # xmin ymin xmax ymax vmax -> the reflection's box
+            out[1, 0], out[1, 2] = 2 * self.edge - mine.reshape(-1)[2], 2 * self.edge - mine.reshape(-1)[0]
+            out[1, 1], out[1, 3], out[1, 4] = mine.reshape(-1)[1], mine.reshape(-1)[3], mine.reshape(-1)[4]
+        else:                                       # counts [to rank 0, to rank 1] -> the reflection ships what I ship
+            out[1] = mine.reshape(-1).flip(0)
+
+    def batch_isend_irecv(self, ops):
+        """The wire: TWO device ops per step (anything more and the Python side of this stand-in, not the device, would pace
+        the loop): the count word, and the payload with x -> 2 edge - x.  The box words of the header keep what the last
+        resize seeded (the reflection's box as of then) — a synthetic neighbour does not need more."""
+        import torch
+        send = [o.tensor for o in ops if o.op == "isend"]
+        recv = [o.tensor for o in ops if o.op == "irecv"]
+        for s_, r_ in zip(send, recv):
+            k = s_.numel() - 8
+            if getattr(self, "_k", None) != k:
+                self._scale = torch.ones(k, device=s_.device); self._scale[0::3] = -1.0
+                self._off = torch.zeros(k, device=s_.device); self._off[0::3] = 2 * self.edge
+                self._k = k
+            r_[0:1].view(torch.int32).copy_(s_[0:1].view(torch.int32))
+            torch.addcmul(self._off, s_[8:], self._scale, out=r_[8:])
+        return [MirrorDist._Done()]
 
 
 def memory_yardstick(n_drones):
@@ -493,7 +554,8 @@ def main(argv=None):
     # (config5 only: one halo exchange of positions per step for the neighbour-downwash term)
     fl = Fleet(n_fleet, replicas, local, a.substeps, a.layout, sharding.rank_seed(a.noise_seed, rank),
                waypoints=a.workload == "config3", config5=a.workload == "config5",
-               dist=dist if a.workload == "config5" else None, rank=rank, hexa=a.workload == "hexa",
+               dist=(MirrorDist(a.slab_m) if (a.mirror_peer and world == 1) else dist) if a.workload == "config5" else None,
+               rank=rank, hexa=a.workload == "hexa",
                mixed=("type_major" if a.workload == "mixed_type_major" else a.workload == "mixed"), options=options,
                slab_m=a.slab_m)
     if a.workload == "two_call_loop":
@@ -526,7 +588,7 @@ def main(argv=None):
               "two_call_loop": "k_physics_fast (observation fused) + k_control_fast"}.get(a.workload, "k_step_fast")
     achieved = fl.n * bytes_per / launch_s / 1e9
     rank_rows = gather_ranks(dist, red_dev, [dev_s_local / steps_timed * 1e6, wall_local / steps_timed * 1e6])
-    exchange = exchange_report(fl, dist, red_dev) if (a.workload == "config5" and world > 1) else None
+    exchange = exchange_report(fl, dist, red_dev) if (a.workload == "config5" and (world > 1 or a.mirror_peer)) else None
 
     if rank == 0:
         traffic, traffic_source = None, None
@@ -562,6 +624,9 @@ def main(argv=None):
         }
         if exchange is not None:
             out["exchange"] = exchange
+        if a.mirror_peer:
+            out["config"]["synthetic_neighbour"] = ("--mirror-peer: ONE rank whose neighbour is its own reflection across the slab edge "
+                                                    "(MirrorDist: a device-side wire); traces the exchange path, not a multi-GPU run")
     else:
         out = {}
     if world > 1 and a.workload == "config2x1024" and not a.no_also:

@@ -18,8 +18,11 @@
 
 // minimum waves per SIMD the fused kernel is compiled for (2nd __launch_bounds__ argument):
 // bounds the VGPR budget (512 / waves); tuned on MI355X, see DESIGN.md
+// (round 3, A/B of 3 / 4 / 5 / 6 on the final build, profiles/r03_ab_waves.txt: indifferent for one sub-step per launch,
+// 153.5-154.5 us whatever the bound; with the examples' five sub-steps the looped kernel fits 95 VGPRs at 5 and runs
+// 241 us instead of 248 at 4 (110 VGPRs); no instance spills at 5)
 #ifndef DSIM_STEP_WAVES
-#define DSIM_STEP_WAVES 4
+#define DSIM_STEP_WAVES 5
 #endif
 #ifndef DSIM_GEN_WAVES
 #define DSIM_GEN_WAVES 2
@@ -302,10 +305,14 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
   if (!NOISE) hexa_wrench(T, cmd, nullptr, F, tau);
   // The state holds what PyBullet reports — the BASE link's centre of mass (dsim_type_params.base_offset); the composite
   // body is integrated about its own: p = p_b - R d, v = v_b - w x (R d) in front of the sub-steps, and back behind them.
-  {
-    const V3 o = mul(matrix_from_quat(s.q), v3(T.base_off[0], T.base_off[1], T.base_off[2]));
-    s.pos = s.pos - o; s.vel = s.vel - cross(s.w, o);
-  }
+  // The position never makes the round trip: p_b' = p_b + sum(dt v_com) + (R' d - R d) — the sub-steps move the stored
+  // position by the composite's displacement and the CHANGE of the offset is added behind them (millimetres, where
+  // subtracting and re-adding the offset itself costs two roundings at the magnitude of the position: 1.4 ulp32(x) at
+  // x = 34 m was the worst margin of the hexa kernels, 0.70 of the step's bar).  With the plane the contact geometry
+  // wants the composite's position itself.
+  const V3 o0 = mul(matrix_from_quat(s.q), v3(T.base_off[0], T.base_off[1], T.base_off[2]));
+  if (PLANE) s.pos = s.pos - o0;
+  s.vel = s.vel - cross(s.w, o0);
   const int n_sub = ONE ? 1 : a.substeps;
   for (int k = 0; k < n_sub; ++k) {
     if (NOISE) {
@@ -322,7 +329,7 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
   }
   {
     const V3 o = mul(matrix_from_quat(s.q), v3(T.base_off[0], T.base_off[1], T.base_off[2]));
-    s.pos = s.pos + o; s.vel = s.vel + cross(s.w, o);
+    s.pos = s.pos + (PLANE ? o : o - o0); s.vel = s.vel + cross(s.w, o);
   }
 }
 

@@ -2636,9 +2636,14 @@ def test_every_instance_of_the_single_type_step_kernels(gpu, sub, seed):
     # k_step_hexa<NOISE, NT, S1, ACT>
     _sweep_case(gpu, f"sweep hexa plain[{sub},{seed}]", [hx], None, n, sub, seed, 0)
     _sweep_case(gpu, f"sweep hexa action[{sub},{seed}]", [hx], None, n, sub, seed, 0, action=act6)
-    # k_step_run<HEXA, NOISE, NT, S1>: type-major runs
+    # type-major runs: k_step_runs<NOISE, NT, S1> (all runs in one launch, the default) and k_step_run<HEXA, NOISE, NT, S1>
+    # (one launch per run: DSIM_OPT_RUNS_SEPARATE); aligned runs, and runs that begin and end inside tiles
     tid = np.repeat(np.array([0, 1], dtype=np.uint8), 256)
-    _sweep_case(gpu, f"sweep runs[{sub},{seed}]", [rb, hx], tid, n, sub, seed, 0, runs=[(0, 256, 0), (256, 256, 1)])
+    tid2 = np.array([0] * 200 + [1] * 312, dtype=np.uint8)
+    for name, opt in (("one launch", 0), ("separate", nat.OPT_RUNS_SEPARATE)):
+        _sweep_case(gpu, f"sweep runs {name}[{sub},{seed}]", [rb, hx], tid, n, sub, seed, opt, runs=[(0, 256, 0), (256, 256, 1)])
+        _sweep_case(gpu, f"sweep runs sharing a tile, {name}[{sub},{seed}]", [rb, hx], tid2, n, sub, seed, opt,
+                    runs=[(0, 200, 0), (200, 312, 1)])
 
 
 @pytest.mark.parametrize("seed", [0, 7])

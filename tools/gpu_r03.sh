@@ -82,6 +82,14 @@ f)
     one "mixed tile1024" --workload mixed --layout tile1024
   done
   ;;
+g)
+  for round in 1 2 3; do
+    one "c5 alone" --workload config5
+    one "c5 mirror peer, split" --workload config5 --mirror-peer
+    DSIM_DW_SPLIT=0 one "c5 mirror peer, one grid" --workload config5 --mirror-peer
+  done
+  kt c5_mirror --workload config5 --mirror-peer
+  ;;
 b)
   DSIM_BENCH_BACKEND=gloo one "config5 2 gloo ranks, halo split" --workload config5 --gpus 2
   DSIM_BENCH_BACKEND=gloo DSIM_DW_SPLIT=0 one "config5 2 gloo ranks, halo one-grid" --workload config5 --gpus 2
