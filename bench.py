@@ -148,7 +148,7 @@ class Fleet:
                               device=device, layout=layout, noise_seed=noise_seed, dict_io=False, dist=dist,
                               chained=chained, downwash_exchange=os.environ.get("DSIM_DW_EXCHANGE", "halo"),
                               type_ids=type_ids, options=options, storage=storage or os.environ.get("DSIM_STORAGE", "auto"),
-                              downwash_split=os.environ.get("DSIM_DW_SPLIT", "1") != "0",
+                              downwash_split={"": None, "0": False, "1": True}[os.environ.get("DSIM_DW_SPLIT", "")],
                               defer_fallback=os.environ.get("DSIM_DEFER_FB", "0") != "0")
         if waypoints:
             self.tgt = WaypointTargets(self.env.ctx, self.n, g["target_pos"], g["target_vel"], g["target_acc"],
@@ -390,8 +390,10 @@ def exchange_report(fl, dist, red_dev, steps=20):
             "sent_per_step_max": max(sent), "sent_per_step_min": min(sent), "bytes_per_step_max": 12 * max(sent),
             "message_bytes_per_step_max": int(max(r[4] for r in rows)), "peers_max": int(max(r[5] for r in rows)),
             "recv_per_step_max": int(max(r[1] for r in rows)),
-            "side_stream_us_max": max(r[2] for r in rows), "side_stream_us_min": min(r[2] for r in rows),
-            "side_stream_note": "select + pack, grouped send/recv, halo binning on the side stream, beside the local pass of the query",
+            "exchange_span_us_max": max(r[2] for r in rows), "exchange_span_us_min": min(r[2] for r in rows),
+            "exchange_span_note": "from the start of select + pack to the end of the call that bins what arrived (two-pass query: the "
+                                  "wire and the local pass run side by side inside this span; one-pass query: pack, wire, binning and "
+                                  "the whole query)",
             "overflow": int(sum(r[3] for r in rows))}
 
 

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import Optional
 
 import torch
@@ -121,7 +122,7 @@ class HaloWire:
     def _bounds(self) -> None:
         raise NotImplementedError                 # -> self.bounds_dev: xmin, ymin, xmax, ymax, max |coordinate velocity|
 
-    def _pack(self) -> None:
+    def _pack(self, stream=None) -> None:
         raise NotImplementedError                 # self.send[p] = header + positions, for every p with send_cap[p] > 0
 
     def _overflow(self) -> int:
@@ -240,14 +241,15 @@ class HaloPlan(HaloWire):
     """HaloWire on the device, device-paced.  Everything per-step is preallocated and enqueued, nothing synchronises
     the host:
 
-        side stream:  dsim_halo_pack (selection against the peers' boxes + packing + headers, one launch) -> ONE grouped
-                      batch of isend/irecv on persistent per-peer buffers -> dsim_downwash(DSIM_DW_HALO_BIN)
+        main stream:  dsim_halo_pack (selection against the peers' boxes + packing + headers, one launch)
+        wire:         ONE grouped batch of isend/irecv on persistent per-peer buffers, behind the pack (RCCL's own stream)
         main stream:  dsim_downwash(DSIM_DW_LOCAL) — the local part of the query runs while the positions are on the
-                      wire — wait(side) -> dsim_downwash(DSIM_DW_HALO_QUERY) -> dsim_step
+                      wire — wait(wire) -> dsim_downwash(DSIM_DW_HALO_BIN) -> dsim_downwash(DSIM_DW_HALO_QUERY) -> dsim_step
 
     DSIM_Q_HALO_OVERFLOW counts what a message could not hold.  The gloo backend (rehearsal ranks sharing one GPU) stages
     the packed buffers through pinned host memory, which synchronises the host: a rehearsal of the logic, not of the
-    pacing."""
+    pacing; there and with bench.MirrorDist the wire runs on the main stream and the query is one pass over one grid
+    (Downwash.split = None: two passes only where a wire with real latency runs beside the first)."""
 
     def __init__(self, ctx, state, dist, dt_env: float, v_clamp: float, cutoff: float = CUTOFF, resize_every: int = 128,
                  headroom: float = 1.25, slack: int = 512):
@@ -257,18 +259,22 @@ class HaloPlan(HaloWire):
         self.plan = nat.HaloPlan()
         self.plan.world, self.plan.rank, self.plan.cap = self.world, self.rank, self.cap
         self.plan.send, self.plan.recv, self.plan.scratch = self.send.data_ptr(), self.recv.data_ptr(), self.scratch.data_ptr()
-        self.side = torch.cuda.Stream(device=ctx.device)
-        self.ev_ready = torch.cuda.Event()        # main -> side: the positions of this step are final
-        self.ev_halo = torch.cuda.Event()         # side -> main: the halo grid is filled
-        self.timing = None                        # a list: every step appends (start, end) events of its side-stream part
+        self.timing = None                        # a list: every step appends (start of the pack, end of the halo binning) events
+        self._pack_call = None
+        self._works = None
+        self._started = False
+        self.on_rccl = dist.get_backend() == "nccl"
 
     def _bounds(self) -> None:
         st = self.state
         nat.check(self.ctx.lib.dsim_fleet_bounds(self.ctx.handle, self.ctx.stream_ptr(), st.n, st.view(), self.bounds_dev.data_ptr()))
 
-    def _pack(self) -> None:
+    def _pack(self, stream=None) -> None:
         st = self.state
-        nat.check(self.ctx.lib.dsim_halo_pack(self.ctx.handle, self.ctx.stream_ptr(), st.n, st.view(), ctypes.byref(self.plan)))
+        if self._pack_call is None:
+            self._pack_call = (st.view(), ctypes.byref(self.plan))
+        nat.check(self.ctx.lib.dsim_halo_pack(self.ctx.handle, stream if stream is not None else self.ctx.stream_ptr(), st.n,
+                                              *self._pack_call))
 
     def _sync(self) -> None:
         torch.cuda.current_stream(self.ctx.device).synchronize()
@@ -284,37 +290,62 @@ class HaloPlan(HaloWire):
         """Positions that a message could not hold so far (synchronises the stream); 0 = nothing was ever missed."""
         return self.ctx.query(nat.QUERY_HALO_OVERFLOW)
 
-    def exchange(self) -> None:
-        """Select + pack, send/recv — enqueued on the side stream behind `ev_ready`; the caller bins what arrived
-        (DSIM_DW_HALO_BIN) on the same stream and records `ev_halo`."""
+    def start(self) -> None:
+        """Select + pack on the CURRENT stream, then the wire behind it — without waiting for it: the caller enqueues the
+        local pass of the query next, then `finish()`.  On RCCL the grouped batch runs on the collective library's own
+        stream, ordered behind the pack, and nobody waits for it until `finish()`.  The stand-in transports (gloo staging,
+        bench.MirrorDist) run on the current stream itself.
+
+        What the kernel traces of `bench.py --workload config5 --mirror-peer` taught about streams on this stack (one
+        MI355X, 65 536 drones, a wire of two small device ops): a stream that sits in a cross-stream
+        wait resumes 13-19 us after the signal — whatever the event's release scope, whatever the stream's priority — and a
+        pack that shares the CUs with the local pass takes 32 us instead of 16.  Pack + wire + halo binning on a side
+        stream beside the local pass: 101 us per step; everything on ONE stream with the two-pass query: 92 us; ONE
+        stream and ONE grid (no second pass): 80 us.  A second stream of our own never paid; only the collective
+        library's, which is not ours to remove, is used."""
         if self.due():
-            self.resize()                              # (main stream, host-synchronous, every resize_every steps)
-        main = torch.cuda.current_stream(self.ctx.device)
-        self.ev_ready.record(main)
-        self.side.wait_event(self.ev_ready)
+            self.resize()                              # (host-synchronous, every resize_every steps)
         self._age += 1
-        if self.timing is not None:
-            self._t0 = torch.cuda.Event(enable_timing=True)
-            self._t0.record(self.side)
+        self._works = None
+        self._started = bool(self._ops)
         if not self._ops:
             return
-        with torch.cuda.stream(self.side):
-            self._pack()
-            self._wire(self.side.synchronize)
+        main = torch.cuda.current_stream(self.ctx.device)
+        if self.timing is not None:
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record(main)
+        self._pack(main.cuda_stream)
+        if self.on_rccl:
+            self._works = self.dist.batch_isend_irecv(self._ops)       # RCCL's stream waits for the pack; nobody waits for RCCL yet
+        else:
+            self._wire(main.synchronize)
+
+    def finish(self) -> None:
+        """Orders the current stream behind the wire (what arrived is in `recv`)."""
+        if self._works:
+            for w in self._works:
+                w.wait()                                               # stream-level: the host runs on
+
+    def exchange(self) -> None:
+        self.start()
+        self.finish()
 
 
 class Downwash:
     """Evaluates formula P8 for the drones of one env/state block against world positions."""
 
     def __init__(self, ctx, state, type_id: Optional[torch.Tensor] = None, dist=None, cell: Optional[float] = None,
-                 box_refresh: int = 256, halo: Optional[HaloPlan] = None, split: bool = True):
+                 box_refresh: int = 256, halo: Optional[HaloPlan] = None, split: Optional[bool] = None):
         # cell = None: 5 m cells (half the cut-off, 5 x 5 cells scanned per drone: 30 % fewer candidate pairs than
         # 3 x 3 cells of 10 m) whenever the world's shape takes the bucket form of the grid, 10 m cells otherwise
         self.ctx, self.state, self.type_id, self.dist = ctx, state, type_id, dist
         self._auto_cell = cell is None
         self.cell = 0.5 * CUTOFF if cell is None else float(cell)
         self.halo = halo                 # None: all-gather of the world's positions (any index sharding)
-        self.split = bool(split)         # halo form: local pass beside the exchange, then a halo pass (False: one grid, one pass)
+        # halo form: a local pass beside the exchange, then a halo pass — or one grid, one pass behind the wire.  None: two
+        # passes on RCCL, whose wire has latency to hide (its own stream, its events), one pass for the stand-in transports
+        # (measured with bench.MirrorDist: 80 us per step against 92 with two passes on the same stream)
+        self.split = (halo is not None and getattr(halo, "on_rccl", False)) if split is None else bool(split)
         self.force = torch.zeros((3, state.n_pad), dtype=torch.float32, device=ctx.device)
         self._counts = None              # drones per rank (all-gather form; fetched once)
         self._last = None                # DownwashArgs of the last compute(): the grid a step kernel may fill for the next
@@ -323,6 +354,9 @@ class Downwash:
         self._box = None                 # (xmin, ymin, nx, ny): a search-efficiency hint, never a correctness input
         self._box_age, self._box_refresh = 0, box_refresh
         self._gather_out = None          # all-gather form: the preallocated [world * 3, n_max] receive buffer
+        self._single = None              # single-rank form: (args, state view, byref) reused while the grid stands
+        self._halo_args = None           # halo form: the three phases' argument blocks, rebuilt at a resize
+        self._last_ok = {}               # id(args) -> dsim_downwash_prebin_ok of its shape
 
     def _grid_box(self, wp, lo_hi=None):
         """Bounding box of the world in xy -> grid.  Drones that later leave the box are clamped to
@@ -413,7 +447,14 @@ class Downwash:
         grid cannot be filled ahead (no compute() yet, or a shape that takes the counting-sort form).  The library
         re-checks everything; a grid that changes after all (box refresh, halo resize) just means a full binning pass."""
         a = self._last
-        if a is None or not self.ctx.lib.dsim_downwash_prebin_ok(a.m, a.nx, a.ny):
+        if a is None:
+            return None
+        key = (id(a), a.m, a.nx, a.ny)
+        ok = self._last_ok.get(key)
+        if ok is None:
+            self._last_ok = {key: bool(self.ctx.lib.dsim_downwash_prebin_ok(a.m, a.nx, a.ny))}
+            ok = self._last_ok[key]
+        if not ok:
             return None
         self._prebin_version = self.state.version
         return ctypes.addressof(a)
@@ -421,6 +462,7 @@ class Downwash:
     def invalidate_prebin(self) -> None:
         """The state was changed by something other than the fused step that pre-binned it."""
         self._prebin_version = None
+        self._single = None
 
     def compute(self, world_pos: Optional[torch.Tensor] = None, local_offset: Optional[int] = None) -> torch.Tensor:
         """Returns the SoA [3, n_pad] body-frame force (x = y = 0) to pass as ``ext_force``.
@@ -428,11 +470,20 @@ class Downwash:
         ``local_offset`` (default: gathered from the ranks' states / the block alone)."""
         if self.halo is not None and world_pos is None:
             return self._compute_halo()
-        a = self._grid_args(world_pos, local_offset)
+        single = (world_pos is None and (self.dist is None or not self.dist.is_initialized() or self.dist.get_world_size() == 1))
+        if single and self._single is not None and self._box_age < self._box_refresh:
+            # the world is this fleet and the grid has not changed: the argument block of the last call is this call's
+            # (the Python side of a config-5 step is what paces small fleets: every struct that is not rebuilt counts)
+            a, view, ref = self._single
+            self._box_age += 1
+        else:
+            a = self._grid_args(world_pos, local_offset)
+            view, ref = self.state.view(), ctypes.byref(a)
+            self._single = (a, view, ref) if single else None
         a.prebinned = int(self._prebin_version is not None and self._prebin_version == self.state.version)
         self._prebin_version = None
-        nat.check(self.ctx.lib.dsim_downwash(self.ctx.handle, self.ctx.stream_ptr(), self.state.n, self.state.view(),
-                                             ctypes.byref(a), self.force.data_ptr()))
+        nat.check(self.ctx.lib.dsim_downwash(self.ctx.handle, self.ctx.stream_ptr(), self.state.n, view, ref,
+                                             self.force.data_ptr()))
         self._last = a
         return self.force
 
@@ -440,7 +491,7 @@ class Downwash:
         """Spatially sharded fleet: the rest of the world is what the halo plan's peers send (class HaloPlan)."""
         lib, h, st, hp = self.ctx.lib, self.ctx.handle, self.state, self.halo
         resized = hp.due()
-        hp.exchange()                                    # (resize when due: host-synchronous, rare) side stream: pack, send / recv
+        hp.start()                                       # (resize when due: host-synchronous, rare) pack; the wire behind it
         if resized:
             # the grid covers this rank's box grown by what can happen before the next resize on every side (what lies
             # beyond is clamped to the border cells: exact, see _grid_box); re-made from bounds that are on the host anyway
@@ -452,10 +503,13 @@ class Downwash:
                 self.cell = CUTOFF
                 self._halo_box = self._grid_box(None, ((b[0] - grow, b[1] - grow), (b[2] + grow, b[3] + grow)))
         box = self._halo_box
-        m = st.n + hp.halo_total()
-        if not lib.dsim_downwash_prebin_ok(m, box[2], box[3]):
+        if resized or self._halo_args is None:
+            self._halo_m = st.n + hp.halo_total()
+            self._halo_ok = bool(lib.dsim_downwash_prebin_ok(self._halo_m, box[2], box[3]))
+        m = self._halo_m
+        if not self._halo_ok:
             # a world too dense or too vast for the bucket form: one array, the counting-sort form (no overlap)
-            torch.cuda.current_stream(self.ctx.device).wait_stream(hp.side)
+            hp.finish()
             wp = torch.cat([st.raw_fields(0, 3), hp.received_positions()], dim=1).contiguous()
             m = wp.shape[1]
             a = self._fill(wp, m, 0, box)
@@ -465,32 +519,41 @@ class Downwash:
             nat.check(lib.dsim_downwash(h, self.ctx.stream_ptr(), st.n, st.view(), ctypes.byref(a), self.force.data_ptr()))
             self._last = None
             return self.force
-        a = self._fill(None, m, 0, box)
-        a.halo = ctypes.addressof(hp.plan)
-        self._workspace(a, lib.dsim_downwash_workspace_halo(st.n, hp.halo_total(), box[2], box[3]))
-        a.prebinned = int(self._prebin_version is not None and self._prebin_version == self.state.version)
+        if resized or self._halo_args is None:
+            blocks = []
+            for ph in (nat.DW_HALO_BIN, nat.DW_LOCAL, nat.DW_HALO_QUERY, nat.DW_ALL):
+                a = self._fill(None, m, 0, box)
+                a.halo = ctypes.addressof(hp.plan)
+                self._workspace(a, lib.dsim_downwash_workspace_halo(st.n, hp.halo_total(), box[2], box[3]))
+                a.phase = ph
+                blocks.append((a, ctypes.byref(a)))
+            self._halo_args = (blocks, st.view(), self.force.data_ptr())
+        (a_bin, r_bin), (a_loc, r_loc), (a_qry, r_qry), (a_all, r_all) = self._halo_args[0]
+        view, fptr = self._halo_args[1], self._halo_args[2]
+        pre = int(self._prebin_version is not None and self._prebin_version == self.state.version)
         self._prebin_version = None
         main = torch.cuda.current_stream(self.ctx.device)
+        sp = main.cuda_stream
         if not self.split:
-            main.wait_stream(hp.side)
-            a.phase = nat.DW_ALL
-            nat.check(lib.dsim_downwash(h, main.cuda_stream, st.n, st.view(), ctypes.byref(a), self.force.data_ptr()))
-            self._last = a
+            hp.finish()
+            a_all.prebinned = pre
+            nat.check(lib.dsim_downwash(h, sp, st.n, view, r_all, fptr))
+            if hp.timing is not None and hp._started:
+                t1 = torch.cuda.Event(enable_timing=True)
+                t1.record(main)
+                hp.timing.append((hp._t0, t1))
+            self._last = a_all
             return self.force
-        a.phase = nat.DW_HALO_BIN                        # side stream, behind the receives
-        nat.check(lib.dsim_downwash(h, hp.side.cuda_stream, st.n, st.view(), ctypes.byref(a), None))
-        hp.ev_halo.record(hp.side)
-        if hp.timing is not None:
+        a_loc.prebinned = pre
+        nat.check(lib.dsim_downwash(h, sp, st.n, view, r_loc, fptr))           # the local pass: runs while the positions travel
+        hp.finish()
+        nat.check(lib.dsim_downwash(h, sp, st.n, view, r_bin, None))           # what arrived -> the halo grid
+        if hp.timing is not None and hp._started:
             t1 = torch.cuda.Event(enable_timing=True)
-            t1.record(hp.side)
+            t1.record(main)
             hp.timing.append((hp._t0, t1))
-        a.phase = nat.DW_LOCAL                           # main stream: overlaps the exchange
-        nat.check(lib.dsim_downwash(h, main.cuda_stream, st.n, st.view(), ctypes.byref(a), self.force.data_ptr()))
-        main.wait_event(hp.ev_halo)
-        a.phase, a.prebinned = nat.DW_HALO_QUERY, 0
-        nat.check(lib.dsim_downwash(h, main.cuda_stream, st.n, st.view(), ctypes.byref(a), self.force.data_ptr()))
-        a.phase = nat.DW_LOCAL                           # what a step kernel that bins ahead is told about the next grid
-        self._last = a
+        nat.check(lib.dsim_downwash(h, sp, st.n, view, r_qry, fptr))           # the halo pass: force +=
+        self._last = a_loc                               # what a step kernel that bins ahead is told about the next grid
         return self.force
 
     def adjacency(self, radius: float, max_k: int = 0, world_pos: Optional[torch.Tensor] = None,

@@ -86,7 +86,7 @@ class CtrlAviary:
         options: int = 0,
         ground_plane: Optional[bool] = None,
         storage: str = "auto",
-        downwash_split: bool = True,
+        downwash_split: Optional[bool] = None,
         defer_fallback: bool = False,
     ):
         if gui or record or obstacles:
@@ -204,6 +204,7 @@ class CtrlAviary:
         self._chain_live = False          # last_vel / last_rates in HBM are stale
         self._chain_ok = False            # the previous operation was a fused step (memory consistent with the state)
         self._fused_plan = None           # cached argument block of the repeated step_fused() call
+        self._fused_plan_dw = None        # ... of a downwash fleet (force, counter and the next grid are refreshed per call)
         # Physics.PYB_DW: neighbour downwash (BaseAviary.py:534-536, 1736-1763); `dist` = an initialised
         # torch.distributed module when the world's fleet is sharded over several ranks
         self._downwash = None
@@ -290,6 +291,7 @@ class CtrlAviary:
         """Ends a chained sequence: last_vel / last_rates are written back into the state block."""
         self._join_fallback()
         self._fused_plan = None
+        self._fused_plan_dw = None
         if self._chain_live:
             nat.check(self.ctx.lib.dsim_materialize(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
                                                     self.state.view()))
@@ -299,6 +301,7 @@ class CtrlAviary:
         """BaseAviary._housekeeping (BaseAviary.py:640-714): zero counters, place every drone."""
         self._chain_live = self._chain_ok = False
         self._fused_plan = None
+        self._fused_plan_dw = None
         self.step_counter = 0
         self._env_steps = 0
         if getattr(self, "_downwash", None) is not None:
@@ -358,6 +361,19 @@ class CtrlAviary:
             self.step_counter += self.AGGR_PHY_STEPS * n_steps
             self._env_steps += n_steps
             return
+        pd = self._fused_plan_dw
+        if (action is None and pd is not None and self._downwash is not None and pd[5] is targets and pd[0] == key
+                and self._chain_ok and self._fb_stream is None and pd[6] == self._targets_ptrs(targets)):
+            # the same call again on a downwash fleet: the prepared argument block, with this step's force, counter and
+            # the grid the step kernel may fill (the Python side of a config-5 step is what paces a 65 536-drone shard)
+            _, args, sview, tview, ref = pd[:5]
+            self._downwash.compute()
+            args.step_index = self._env_steps
+            args.bin_next = self._downwash.bin_next_ptr()
+            nat.check(self.ctx.lib.dsim_step(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, sview, tview, ref))
+            self.step_counter += self.AGGR_PHY_STEPS
+            self._env_steps += 1
+            return
         wp = isinstance(targets, WaypointTargets)
         args = self.step_args(control_timestep, nat.OPT_BCAST_TGT if targets.broadcast else 0)
         args.n_steps = n_steps
@@ -392,6 +408,9 @@ class CtrlAviary:
         self._env_steps += n_steps
         # what the NEXT identical call would pass (a chained env switches to the chained form after this call)
         self._fused_plan = None
+        self._fused_plan_dw = None
+        if action is None and self._downwash is not None and not chain and not defer:
+            self._fused_plan_dw = (key, args, sview, tview, ctypes.byref(args), targets, self._targets_ptrs(targets))
         if action is None and self._downwash is None:
             nxt = nat.StepArgs.from_buffer_copy(args)
             if self._chained_enabled and chain:

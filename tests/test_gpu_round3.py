@@ -597,5 +597,5 @@ def test_bench_config5_line_two_gloo_ranks(gpu):
     assert d["n_gpus"] == 2 and d["dist"]["backend"] == "gloo" and d["value"] > 0
     ex = d["exchange"]
     assert ex["form"] == "halo" and 4500 < ex["sent_per_step_max"] < 6500 and ex["bytes_per_step_max"] == 12 * ex["sent_per_step_max"]
-    assert ex["overflow"] == 0 and ex["peers_max"] == 1 and ex["side_stream_us_max"] > 0
+    assert ex["overflow"] == 0 and ex["peers_max"] == 1 and ex["exchange_span_us_max"] > 0
     assert d["ranks"]["launch_us_min"] > 0 and d["ranks"]["launch_us_max"] >= d["ranks"]["launch_us_min"]

@@ -90,6 +90,28 @@ g)
   done
   kt c5_mirror --workload config5 --mirror-peer
   ;;
+h)
+  for round in 1 2 3; do
+    one "c5 mirror peer, split, side stream high priority" --workload config5 --mirror-peer
+    DSIM_HALO_PRIO=0 one "c5 mirror peer, split, normal priority" --workload config5 --mirror-peer
+  done
+  kt c5_mirror --workload config5 --mirror-peer
+  ;;
+i)
+  for round in 1 2 3; do
+    one "c5 mirror peer, device-scope events" --workload config5 --mirror-peer
+    DSIM_TORCH_EVENTS=1 one "c5 mirror peer, torch events" --workload config5 --mirror-peer
+  done
+  kt c5_mirror --workload config5 --mirror-peer
+  ;;
+j)
+  for round in 1 2 3; do
+    one "c5 mirror: wire on a side stream, split query" --workload config5 --mirror-peer
+    DSIM_HALO_ONE_STREAM=1 one "c5 mirror: ONE stream, split query" --workload config5 --mirror-peer
+    DSIM_HALO_ONE_STREAM=1 DSIM_DW_SPLIT=0 one "c5 mirror: ONE stream, one-grid query" --workload config5 --mirror-peer
+  done
+  DSIM_HALO_ONE_STREAM=1 DSIM_DW_SPLIT=0 kt c5_mirror_one --workload config5 --mirror-peer
+  ;;
 b)
   DSIM_BENCH_BACKEND=gloo one "config5 2 gloo ranks, halo split" --workload config5 --gpus 2
   DSIM_BENCH_BACKEND=gloo DSIM_DW_SPLIT=0 one "config5 2 gloo ranks, halo one-grid" --workload config5 --gpus 2
