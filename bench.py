@@ -471,7 +471,8 @@ def measure_variant(torch, local, layout, seed, steps, name, nf, rep, sub, wp, n
     """One entry of "baseline_configs" / "also": a fresh fleet, one warm region, then timed regions of k steps until
     they cover MIN_TIMED_S (sums reported, nothing picked)."""
     f2 = Fleet(nf, rep, local, sub, layout, seed, waypoints=wp, n_steps=ns,
-               config5=name.startswith("config5"), chained="chained" in name, hexa=name.startswith("hexa"),
+               config5=name.startswith("config5"), dist=(MirrorDist(128.0) if "mirrored_neighbour" in name else None),
+               chained="chained" in name, hexa=name.startswith("hexa"),
                mixed=("type_major" if "type_major" in name else name.startswith("mixed")), options=options,
                slab_m=(1024.0 if "lowdensity" in name else 128.0), storage=("caller" if "caller_order" in name else None))
     if "hipgraph" in name:
@@ -490,6 +491,8 @@ def measure_variant(torch, local, layout, seed, steps, name, nf, rep, sub, wp, n
                                               (241 if name.startswith("mixed") else BYTES_PER_DRONE_STEP)))
         e["hbm_frac"] = f2.n * bts / (d2 / (k2 * reg)) / 1e9 / HBM_PEAK_GBPS
         e["bytes_per_drone_step"] = bts
+    if "mirrored_neighbour" in name:
+        e["exchange"] = exchange_report(f2, None, "cpu", steps=20)
     f2.env.close()
     del f2
     return e
@@ -665,6 +668,10 @@ def main(argv=None):
                     # line (the 65 536 drones spread over the whole 1024 m box: an eighth of the density)
                     "config5_shard_65536_mixed_downwash": (65536, 1, 1, False, 1),
                     "config5_lowdensity_r01_definition": (65536, 1, 1, False, 1),
+                    # the same shard with a neighbour to exchange positions with — a SYNTHETIC one on this one GPU: the
+                    # rank's own reflection across the slab edge (MirrorDist: the wire is two small device ops).  What the
+                    # device-paced exchange path costs per step with a wire of no latency; not a multi-GPU number
+                    "config5_shard_65536_with_mirrored_neighbour": (65536, 1, 1, False, 1),
                     # DSIM_OPT_CHAINED: the six controller-memory fields that are functions of the stored
                     # rigid state are neither read nor written: 184 B of real traffic per drone-step
                     "config2x1024_chained_184B": (4096, 1024, 1, False, 1),
@@ -680,8 +687,11 @@ def main(argv=None):
                 also[name] = measure_variant(torch, local, a.layout, a.noise_seed, a.steps, name, *spec, options=options)
                 if name.startswith("config5"):
                     also[name]["note"] = ("a chain of three dependent launches on a 65 536-drone shard (neighbour query, step + grid "
-                                          "binning, WLS fallback): bound by the vector pipe of the query (profiles/r02_c5*_summary.json) "
+                                          "binning, WLS fallback): bound by the vector pipe of the query (profiles/r03_c5*_summary.json) "
                                           "and by launch latency, not by HBM — hbm_frac is reported for completeness")
+                if "mirrored_neighbour" in name:
+                    also[name]["note"] = ("the shard above + the halo exchange with a synthetic neighbour (its own reflection): "
+                                          "k_halo_pack, a device-side wire, halo binning, one-grid query, step, fallback on one stream")
                 if name.startswith("hexa"):
                     also[name]["note"] = ("248 B is the budgeted figure (SURVEY 8d); the 6-DOF law never reads the target "
                                           "acceleration and yaw, measured HBM traffic is 232 B per drone-step")

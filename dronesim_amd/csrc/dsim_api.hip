@@ -2079,38 +2079,51 @@ struct HaloK {
 // Select + pack, one launch.  For every peer p whose last known box (the header of p's last message, device memory)
 // grown by reach[p] holds this drone, the drone's position is appended to send[p]; the workgroups also reduce this rank's
 // own box, and the last one to finish writes the headers (count SELECTED, own box) and resets the scratch for the next
-// call.  Workgroups of 1 024 drones with ONE reservation per workgroup and peer: the slots are reserved by atomics on one
-// counter per peer, which the memory system serialises — reserved per wave (1 024 waves of a 65 536-drone shard, each
-// holding a few drones of the strip) the kernel took ~70 us; 64 reservations take ~3.
+// call.  The slots are reserved by atomics on one counter per peer, and same-address device-scope atomics are served one
+// after the other, ~70 ns each: reserved per wave (1 024 waves of a 65 536-drone shard, each holding a few drones of the
+// strip) the kernel took 70 us; per 1 024-drone workgroup 16 us, of which the two chains of 64 atomics (reservation,
+// completion ticket) were 9; a workgroup now takes DSIM_PACK_PER_THREAD x 1 024 drones (32 workgroups per shard; four per
+// thread spill: the eight peers' selection masks live in SGPRs): 12 us.
 #define DSIM_PACK_TPB 1024
+#define DSIM_PACK_PER_THREAD 2
 __global__ __launch_bounds__(DSIM_PACK_TPB) void k_halo_pack(HaloK a) {
-  constexpr int NW = DSIM_PACK_TPB / 64;
+  constexpr int NW = DSIM_PACK_TPB / 64, NJ = DSIM_PACK_PER_THREAD;
   __shared__ int wsum[DSIM_MAX_PEERS][NW];                 // per peer: selected per wave, then each wave's first slot
   __shared__ float wred[5][NW];
-  const long long i = (long long)blockIdx.x * DSIM_PACK_TPB + threadIdx.x;
-  const bool live = i < a.n;
-  float x = 0.0f, y = 0.0f, z = 0.0f, vm = 0.0f;
-  if (live) {
-    const float* q = a.st.base + kv_off(a.st, i);
-    const long long fs = a.st.field_stride;
-    x = q[0]; y = q[fs]; z = q[2 * fs];
-    vm = fmaxf(fmaxf(fabsf(q[7 * fs]), fabsf(q[8 * fs])), fabsf(q[9 * fs]));
-  }
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  unsigned long long sel[DSIM_MAX_PEERS];                  // (constant indices only: wave-uniform masks in SGPRs)
+  const long long i0 = (long long)blockIdx.x * (DSIM_PACK_TPB * NJ) + threadIdx.x;
+  float x[NJ], y[NJ], z[NJ], vm = 0.0f;
+  float xmin = __builtin_inff(), xmax = -__builtin_inff(), ymin = __builtin_inff(), ymax = -__builtin_inff();
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const long long i = i0 + (long long)j * DSIM_PACK_TPB;
+    x[j] = y[j] = z[j] = __builtin_nanf("");               // (a NaN is inside no box)
+    if (i < a.n) {
+      const float* q = a.st.base + kv_off(a.st, i);
+      const long long fs = a.st.field_stride;
+      x[j] = q[0]; y[j] = q[fs]; z[j] = q[2 * fs];
+      vm = fmaxf(vm, fmaxf(fmaxf(fabsf(q[7 * fs]), fabsf(q[8 * fs])), fabsf(q[9 * fs])));
+      xmin = fminf(xmin, x[j]); xmax = fmaxf(xmax, x[j]); ymin = fminf(ymin, y[j]); ymax = fmaxf(ymax, y[j]);
+    }
+  }
+  unsigned long long sel[DSIM_MAX_PEERS][NJ];              // (constant indices only: wave-uniform masks in SGPRs)
 #pragma unroll
   for (int p = 0; p < DSIM_MAX_PEERS; ++p) {
-    sel[p] = 0ULL;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) sel[p][j] = 0ULL;
     if (p >= a.world || p == a.rank || a.send_cap[p] == 0) { if (lane == 0) wsum[p][wave] = 0; continue; }   // uniform
     const float* hdr = a.recv + (long long)p * a.stride;                        // scalar loads
     const float r = a.reach[p];
-    const bool in = live && x >= hdr[1] - r && x <= hdr[3] + r && y >= hdr[2] - r && y <= hdr[4] + r;
-    sel[p] = __ballot(in);
-    if (lane == 0) wsum[p][wave] = (int)__popcll(sel[p]);
+    const float bx0 = hdr[1] - r, bx1 = hdr[3] + r, by0 = hdr[2] - r, by1 = hdr[4] + r;
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      sel[p][j] = __ballot(x[j] >= bx0 && x[j] <= bx1 && y[j] >= by0 && y[j] <= by1);
+      c += (int)__popcll(sel[p][j]);
+    }
+    if (lane == 0) wsum[p][wave] = c;
   }
   // own box: wave reduce here, workgroup and grid below
-  float xmin = live ? x : __builtin_inff(), xmax = live ? x : -__builtin_inff();
-  float ymin = live ? y : __builtin_inff(), ymax = live ? y : -__builtin_inff();
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     xmin = fminf(xmin, __shfl_xor(xmin, off)); ymin = fminf(ymin, __shfl_xor(ymin, off));
@@ -2144,38 +2157,47 @@ __global__ __launch_bounds__(DSIM_PACK_TPB) void k_halo_pack(HaloK a) {
   __syncthreads();
 #pragma unroll
   for (int p = 0; p < DSIM_MAX_PEERS; ++p) {
-    if (sel[p] == 0ULL) continue;                                               // uniform
-    if ((sel[p] >> lane) & 1ULL) {
-      const int slot = wsum[p][wave] + (int)__popcll(sel[p] & ((1ULL << lane) - 1ULL));
-      if (slot < a.send_cap[p]) {
-        float* d = a.send + (long long)p * a.stride + DSIM_HALO_HDR + 3LL * slot;
-        d[0] = x; d[1] = y; d[2] = z;
+    int before = 0;                                                              // selected by this wave in earlier rounds
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (sel[p][j] == 0ULL) continue;                                           // uniform
+      if ((sel[p][j] >> lane) & 1ULL) {
+        const int slot = wsum[p][wave] + before + (int)__popcll(sel[p][j] & ((1ULL << lane) - 1ULL));
+        if (slot < a.send_cap[p]) {
+          float* d = a.send + (long long)p * a.stride + DSIM_HALO_HDR + 3LL * slot;
+          d[0] = x[j]; d[1] = y[j]; d[2] = z[j];
+        }
       }
+      before += (int)__popcll(sel[p][j]);
     }
   }
+  // Completion ticket.  What the last workgroup reads of the others (counts, box keys) are device-scope atomics, complete
+  // when the barrier below lets the ticket be taken (returning atomics have returned, the rest are acknowledged at
+  // vmcnt(0)); the payload is read by nobody before the kernel ends: no fence is needed (and none is paid for).
+  __shared__ int last_block;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    if (atomicAdd(&a.scratch[8], 1) == (int)gridDim.x - 1) {
-      __threadfence();
-      unsigned* keys = reinterpret_cast<unsigned*>(a.scratch + 9);
-      const float bx0 = fkey_inv(~atomicExch(&keys[0], 0u)), by0 = fkey_inv(~atomicExch(&keys[1], 0u));
-      const float bx1 = fkey_inv(atomicExch(&keys[2], 0u)), by1 = fkey_inv(atomicExch(&keys[3], 0u));
-      const float bv = fkey_inv(atomicExch(&keys[4], 0u));
-      unsigned long long lost = 0;
+  if (threadIdx.x == 0) last_block = atomicAdd(&a.scratch[8], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (last_block && threadIdx.x < 64) {
+    // The last workgroup to finish writes the headers and resets the scratch; its atomic exchanges are independent and one
+    // wave issues them side by side (lanes 0-4 the box keys, lanes 8.. the peers' counts).
+    unsigned* keys = reinterpret_cast<unsigned*>(a.scratch + 9);
+    unsigned got = 0u;
+    if (lane < 5) got = atomicExch(&keys[lane], 0u);
+    else if (lane >= 8 && lane < 8 + DSIM_MAX_PEERS) got = (unsigned)atomicExch(&a.scratch[lane - 8], 0);
+    const float bx0 = fkey_inv(~__shfl(got, 0)), by0 = fkey_inv(~__shfl(got, 1));
+    const float bx1 = fkey_inv(__shfl(got, 2)), by1 = fkey_inv(__shfl(got, 3)), bv = fkey_inv(__shfl(got, 4));
+    int lost = 0;
 #pragma unroll
-      for (int p = 0; p < DSIM_MAX_PEERS; ++p) {
-        if (p >= a.world) continue;
-        const int c = atomicExch(&a.scratch[p], 0);
-        if (p == a.rank || a.send_cap[p] == 0) continue;
-        float* hdr = a.send + (long long)p * a.stride;
-        hdr[0] = __int_as_float(c); hdr[1] = bx0; hdr[2] = by0; hdr[3] = bx1; hdr[4] = by1; hdr[5] = bv; hdr[6] = 0.0f; hdr[7] = 0.0f;
-        if (c > a.send_cap[p]) lost += (unsigned long long)(c - a.send_cap[p]);
-      }
-      if (lost) atomicAdd(&a.counters[4], lost);                       // DSIM_Q_HALO_OVERFLOW
-      a.scratch[8] = 0;
-      __threadfence();
+    for (int p = 0; p < DSIM_MAX_PEERS; ++p) {
+      if ((int)lane != 8 + p || p >= a.world || p == a.rank || a.send_cap[p] == 0) continue;
+      const int c = (int)got;
+      float* hdr = a.send + (long long)p * a.stride;
+      hdr[0] = __int_as_float(c); hdr[1] = bx0; hdr[2] = by0; hdr[3] = bx1; hdr[4] = by1; hdr[5] = bv; hdr[6] = 0.0f; hdr[7] = 0.0f;
+      if (c > a.send_cap[p]) lost = c - a.send_cap[p];
     }
+    if (lost) atomicAdd(&a.counters[4], (unsigned long long)lost);       // DSIM_Q_HALO_OVERFLOW
+    if (lane == 0) atomicExch(&a.scratch[8], 0);
   }
 }
 // flat entry e over the messages' capacities -> (peer, slot): constant-index walk over the prefix (a dynamically
@@ -3196,7 +3218,8 @@ int dsim_halo_pack(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, cons
   if (rc) return rc;
   halo_fill(plan, &h);
   h.n = n; h.counters = ctx->d_counters;
-  hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((n + DSIM_PACK_TPB - 1) / DSIM_PACK_TPB)), dim3(DSIM_PACK_TPB), 0, (hipStream_t)stream, h);
+  const long long per_group = (long long)DSIM_PACK_TPB * DSIM_PACK_PER_THREAD;
+  hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((n + per_group - 1) / per_group)), dim3(DSIM_PACK_TPB), 0, (hipStream_t)stream, h);
   return (int)hipGetLastError();
 }
 

@@ -379,8 +379,10 @@ int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny);
  * device side of that exchange — selecting and packing the boundary drones, binning what arrived — and the caller moves
  * the packed buffers between ranks (RCCL send/recv; the library itself has no communicator).  Per Env.step, with no
  * host synchronisation anywhere:
- *     stream B:  dsim_halo_pack -> [send/recv of the caller] -> dsim_downwash(phase = DSIM_DW_HALO_BIN)
- *     stream A:  dsim_downwash(DSIM_DW_LOCAL)  ........ wait(B) -> dsim_downwash(DSIM_DW_HALO_QUERY) -> dsim_step(bin_next)
+ *     dsim_halo_pack -> [send/recv of the caller, on the collective library's stream] ............ wait for it
+ *                    -> dsim_downwash(DSIM_DW_LOCAL) (beside the wire) -> dsim_downwash(DSIM_DW_HALO_BIN)
+ *                    -> dsim_downwash(DSIM_DW_HALO_QUERY) -> dsim_step(bin_next)
+ * or, with a transport that has no latency to hide, pack -> wire -> dsim_downwash(DSIM_DW_ALL) -> dsim_step.
  * A message is a HEADER (DSIM_HALO_HDR floats: the number of positions that follow, and the sender's xy bounding box at
  * the time of sending) followed by xyz triples.  dsim_halo_pack selects, for every peer, the local drones inside that
  * peer's box — read from the header of the LAST message that peer sent, in device memory — grown by reach[p]; with a
@@ -394,8 +396,7 @@ int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny);
 enum {
   DSIM_DW_ALL = 0,          /* one grid, one query: local drones and whatever pos_all / the halo plan hold               */
   DSIM_DW_LOCAL = 1,        /* bin (unless pre-binned) and query the LOCAL drones only; force_out is written              */
-  DSIM_DW_HALO_BIN = 2,     /* bin the plan's received positions into the halo grid (touches nothing else: may run on
-                               another stream beside DSIM_DW_LOCAL of the same step)                                      */
+  DSIM_DW_HALO_BIN = 2,     /* bin the plan's received positions into the halo grid (touches nothing else)                 */
   DSIM_DW_HALO_QUERY = 3    /* local receivers against the halo grid; force_out += (after LOCAL and HALO_BIN)             */
 };
 typedef struct dsim_halo_plan {

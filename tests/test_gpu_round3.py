@@ -599,3 +599,27 @@ def test_bench_config5_line_two_gloo_ranks(gpu):
     assert ex["form"] == "halo" and 4500 < ex["sent_per_step_max"] < 6500 and ex["bytes_per_step_max"] == 12 * ex["sent_per_step_max"]
     assert ex["overflow"] == 0 and ex["peers_max"] == 1 and ex["exchange_span_us_max"] > 0
     assert d["ranks"]["launch_us_min"] > 0 and d["ranks"]["launch_us_max"] >= d["ranks"]["launch_us_min"]
+
+
+def test_sharded_downwash_example_runs_as_two_ranks(gpu):
+    """examples/fly_sharded_downwash_fleet.py under torch.distributed.run, two gloo ranks sharing the one GPU: both ranks
+    fly, ship the boundary strip only, lose nothing."""
+    import re
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "examples", "fly_sharded_downwash_fleet.py"),
+                        "--drones_per_rank", "16384", "--steps", "40", "--slab_m", "64", "--backend", "gloo"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("rank ")]
+    assert len(lines) == 2, p.stdout
+    for ln in lines:
+        m = re.search(r"ships (\d+) positions per step to (\d+) neighbour\(s\), overflow (\d+)", ln)
+        assert m and 0 < int(m.group(1)) < 16384 // 3 and int(m.group(2)) == 1 and int(m.group(3)) == 0, ln
+        assert "WLS failures 0" in ln

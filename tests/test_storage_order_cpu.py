@@ -1,0 +1,48 @@
+"""fleet.StorageOrder on the CPU: the permutation behind the transparent type-major storage of interleaved fleets (the GPU
+side is tests/test_gpu_round3.py) — a stable sort by type, inverse maps, the translation helpers, the run table it implies."""
+import numpy as np
+import torch
+
+from dronesim_amd.fleet import StorageOrder, type_major_order, type_runs
+
+
+def test_storage_order_is_a_stable_sort_by_type_and_its_maps_invert_each_other():
+    rng = np.random.default_rng(3)
+    for n, k in ((1, 1), (7, 3), (1500, 3), (4096, 2), (1000, 8)):
+        tid = rng.integers(0, k, n).astype(np.uint8)
+        o = StorageOrder(tid, "cpu")
+        assert o.n == n
+        # a permutation of [0, n), no padding slots
+        assert sorted(o.slot_np.tolist()) == list(range(n)) and sorted(o.drone_np.tolist()) == list(range(n))
+        np.testing.assert_array_equal(o.drone_np[o.slot_np], np.arange(n))
+        np.testing.assert_array_equal(o.slot_np[o.drone_np], np.arange(n))
+        # type-major, and stable inside a type (drones of one type keep their relative order)
+        np.testing.assert_array_equal(o.types_storage, np.sort(tid, kind="stable"))
+        for ty in range(k):
+            d = o.drone_np[o.types_storage == ty]
+            assert (np.diff(d) > 0).all()
+        runs = type_runs(o.types_storage)
+        assert [r[2] for r in runs] == sorted(set(tid.tolist())) and sum(r[1] for r in runs) == n
+        # translation helpers: values indexed by drone <-> by slot, along any dim
+        v = torch.arange(3 * n, dtype=torch.float32).reshape(3, n)
+        s = o.to_storage(v, 1)
+        np.testing.assert_array_equal(s.numpy()[:, o.slot_np], v.numpy())
+        np.testing.assert_array_equal(o.to_caller(s, 1).numpy(), v.numpy())
+        rows = torch.arange(n * 5, dtype=torch.float32).reshape(n, 5)
+        np.testing.assert_array_equal(o.to_caller(o.to_storage(rows, 0), 0).numpy(), rows.numpy())
+        np.testing.assert_array_equal(o.to_storage_np(np.arange(n)), o.drone_np)
+        # the noise key of a slot is the caller's index of the drone stored there; padding slots map to themselves
+        did = o.drone_id(n + 37).numpy()
+        np.testing.assert_array_equal(did[:n], o.drone_np)
+        np.testing.assert_array_equal(did[n:], np.arange(n, n + 37))
+
+
+def test_config5_composition_becomes_two_runs():
+    n = 65536
+    tid = (np.arange(n) % 2).astype(np.uint8)                     # even index quad, odd index hexa (BASELINE configs[4])
+    o = StorageOrder(tid, "cpu")
+    assert type_runs(o.types_storage) == [(0, n // 2, 0), (n // 2, n // 2, 1)]
+    np.testing.assert_array_equal(o.slot_np[0:6], [0, n // 2, 1, n // 2 + 1, 2, n // 2 + 2])
+    # the padded form of round 2 (groups aligned to 256, padding slots) is still there for callers that reorder themselves
+    slot, n_slots, slot_types = type_major_order(np.array([1, 0, 1, 1, 0], dtype=np.uint8))
+    assert n_slots == 512 and (slot_types[slot] == np.array([1, 0, 1, 1, 0])).all()
