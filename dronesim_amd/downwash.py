@@ -301,7 +301,7 @@ class HaloPlan(HaloWire):
         wait resumes 13-19 us after the signal — whatever the event's release scope, whatever the stream's priority — and a
         pack that shares the CUs with the local pass takes 32 us instead of 16.  Pack + wire + halo binning on a side
         stream beside the local pass: 101 us per step; everything on ONE stream with the two-pass query: 92 us; ONE
-        stream and ONE grid (no second pass): 80 us.  A second stream of our own never paid; only the collective
+        stream and ONE grid (no second pass): 76-80 us.  A second stream of our own never paid; only the collective
         library's, which is not ours to remove, is used."""
         if self.due():
             self.resize()                              # (host-synchronous, every resize_every steps)
@@ -344,7 +344,7 @@ class Downwash:
         self.halo = halo                 # None: all-gather of the world's positions (any index sharding)
         # halo form: a local pass beside the exchange, then a halo pass — or one grid, one pass behind the wire.  None: two
         # passes on RCCL, whose wire has latency to hide (its own stream, its events), one pass for the stand-in transports
-        # (measured with bench.MirrorDist: 80 us per step against 92 with two passes on the same stream)
+        # (measured with bench.MirrorDist: 76-80 us per step against 92 with two passes on the same stream)
         self.split = (halo is not None and getattr(halo, "on_rccl", False)) if split is None else bool(split)
         self.force = torch.zeros((3, state.n_pad), dtype=torch.float32, device=ctx.device)
         self._counts = None              # drones per rank (all-gather form; fetched once)

@@ -60,11 +60,12 @@ def main(argv=None):
     r = env.state.rigid_aos()
     drift = np.linalg.norm(r[:, 0:3] - xyz, axis=1)
     halo = env._downwash.halo
-    print(f"rank {rank}/{world}: {n} drones x {A.steps} env steps in {el:.2f} s ({n * A.steps / el:.3g} drone-steps/s); "
+    sys.stdout.write(f"rank {rank}/{world}: {n} drones x {A.steps} env steps in {el:.2f} s ({n * A.steps / el:.3g} drone-steps/s); "
           f"median drift from the hold point {np.median(drift):.3f} m; ground contacts {env.ground_contacts()}; WLS failures "
           f"{env.ctx.query(nat.QUERY_WLS_FAILURES)}"
           + (f"; ships {halo.sent_per_step} positions per step to {len(halo.messages())} neighbour(s), overflow {halo.overflow()}"
-             if halo is not None else ""))
+             if halo is not None else "") + "\n")
+    sys.stdout.flush()
     env.close()
     if world > 1:
         dist.barrier()

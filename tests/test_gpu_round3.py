@@ -617,9 +617,8 @@ def test_sharded_downwash_example_runs_as_two_ranks(gpu):
                         "--drones_per_rank", "16384", "--steps", "40", "--slab_m", "64", "--backend", "gloo"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("rank ")]
-    assert len(lines) == 2, p.stdout
-    for ln in lines:
-        m = re.search(r"ships (\d+) positions per step to (\d+) neighbour\(s\), overflow (\d+)", ln)
-        assert m and 0 < int(m.group(1)) < 16384 // 3 and int(m.group(2)) == 1 and int(m.group(3)) == 0, ln
-        assert "WLS failures 0" in ln
+    # (the two ranks write to one pipe: their lines may run into each other)
+    ships = re.findall(r"ships (\d+) positions per step to (\d+) neighbour\(s\), overflow (\d+)", p.stdout)
+    assert len(ships) == 2 and p.stdout.count("WLS failures 0") == 2 and len(re.findall(r"rank [01]/2:", p.stdout)) == 2, p.stdout
+    for sent, peers, lost in ships:
+        assert 0 < int(sent) < 16384 // 3 and int(peers) == 1 and int(lost) == 0, p.stdout
