@@ -425,9 +425,19 @@ class CtrlAviary:
         length), which is what a graph removes.  Kernel arguments are frozen at capture time, so the
         env-step counter that seeds the rotor noise is read from device memory (``step_index_dev``: captured step
         i uses counter + i) and advanced by ``steps`` by a one-thread node at the end of the graph.  Any fleet
-        composition, plain or waypoint targets; not with the neighbour-downwash exchange."""
-        if self._downwash is not None:
-            raise NotImplementedError("graph capture: fleets without the downwash exchange (it sizes buffers on the host)")
+        composition, plain or waypoint targets.  With the neighbour-downwash term (single rank): every captured step is
+        query -> step (which fills the next query's grid) -> fallback, ``steps`` must be even, and the grid's box is the one
+        measured at capture time — drones that leave it are clamped to its border cells, which costs search efficiency,
+        never exactness (``Downwash._grid_box``); capture again after the fleet has moved far."""
+        dw = self._downwash
+        if dw is not None:
+            world = dw.dist.get_world_size() if (dw.dist is not None and dw.dist.is_initialized()) else 1
+            if dw.halo is not None or world > 1:
+                raise NotImplementedError("graph capture with the neighbour-downwash term: single-rank fleets only (the "
+                                          "position exchange of a sharded fleet re-sizes its messages on the host)")
+            if steps % 2 or self._fb_stream is not None:
+                raise ValueError("graph capture with the neighbour-downwash term: an even number of steps (the grid's two "
+                                 "count buffers alternate) and no deferred fallback pass")
         # nothing may allocate under capture: the fallback queue of hexa fleets is reserved up front
         nat.check(self.ctx.lib.dsim_reserve(self.ctx.handle, self.ctx.stream_ptr(), self.state.n_pad))
         return FusedGraph(self, targets, steps, control_timestep)
@@ -583,6 +593,7 @@ class FusedGraph:
         self._sview = env.state.view()
         self._targets = targets
         lib, h, n = env.ctx.lib, env.ctx.handle, env.NUM_DRONES
+        dw = env._downwash
         self._graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -591,9 +602,24 @@ class FusedGraph:
             nat.check(lib.dsim_counter_add(h, side.cuda_stream, self._counter.data_ptr(), 0))
             with torch.cuda.graph(self._graph, stream=side):
                 sp = torch.cuda.current_stream(dev).cuda_stream
-                for i in range(steps):
-                    self._args.step_index = i          # frozen offset; the base is read from the device counter
-                    nat.check(lib.dsim_step(h, sp, n, self._sview, self._tview, ctypes.byref(self._args)))
+                refresh = None
+                if dw is not None:
+                    # The grid stands for the whole graph (no box re-measurement: that is a host read-back).  The first
+                    # query bins the fleet itself and the last step does not fill a grid ahead, so that a replay starts
+                    # from the count buffers it ends with: one of them in use, the other zeroed by the last query.
+                    refresh, dw._box_refresh = dw._box_refresh, 1 << 62
+                    dw._prebin_version = None
+                try:
+                    for i in range(steps):
+                        self._args.step_index = i          # frozen offset; the base is read from the device counter
+                        if dw is not None:
+                            self._args.ext_force = dw.compute().data_ptr()
+                            self._args.bin_next = dw.bin_next_ptr() if i + 1 < steps else None
+                        nat.check(lib.dsim_step(h, sp, n, self._sview, self._tview, ctypes.byref(self._args)))
+                finally:
+                    if dw is not None:
+                        dw._box_refresh = refresh
+                        dw._prebin_version = None
                 nat.check(lib.dsim_counter_add(h, sp, self._counter.data_ptr(), steps))
         torch.cuda.current_stream(dev).wait_stream(side)
         self._counter_host = 0

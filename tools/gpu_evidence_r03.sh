@@ -29,4 +29,13 @@ c)
   echo "kt 2rank rc=$?"; find $OUT/kt_c5_2rank -name "*kernel_stats.csv" | head
   tail -c 1500 $OUT/kt_c5_2rank.log
   ;;
+d)
+  # the whole GPU suite once more on the final tree, the remaining workloads' counter passes, and a long two-rank soak
+  DSIM_MARGINS_OUT=$OUT/margins.json timeout -k 10 900 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider > $OUT/pytest.log 2>&1
+  echo "pytest rc=$? $(tail -1 $OUT/pytest.log)"
+  bash tools/profile_sq.sh r03_hexa --workload hexa && bash tools/profile_sq.sh r03_sub5 --substeps 5 && \
+  bash tools/profile_sq.sh r03_config3 --workload config3 && bash tools/profile_sq.sh r03_config4 --workload config4
+  DSIM_BENCH_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --workload config5 --steps 3000 --warmup 20 --no-cpu-baseline --no-also > $OUT/soak_2rank_gloo.json 2> $OUT/soak_2rank_gloo.err
+  echo "soak rc=$?"; grep '^{' $OUT/soak_2rank_gloo.json | tail -1 | head -c 1500; echo
+  ;;
 esac
