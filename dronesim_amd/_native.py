@@ -18,7 +18,7 @@ EXPORTS = (
     "dsim_abi_version", "dsim_strerror", "dsim_create", "dsim_destroy", "dsim_reset", "dsim_step",
     "dsim_physics", "dsim_control", "dsim_control2", "dsim_step_adaptor", "dsim_traj_sample", "dsim_materialize",
     "dsim_counter_add", "dsim_reserve", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash",
-    "dsim_downwash_workspace", "dsim_downwash_prebin_ok", "dsim_adjacency", "dsim_wls_fallback", "dsim_fleet_bounds",
+    "dsim_downwash_workspace", "dsim_downwash_prebin_ok", "dsim_downwash_reset", "dsim_adjacency", "dsim_wls_fallback", "dsim_fleet_bounds",
     "dsim_halo_pack", "dsim_downwash_workspace_halo",
 )
 
@@ -149,6 +149,7 @@ def load(path: str = None) -> ctypes.CDLL:
     lib.dsim_control.argtypes = [vp, vp, i64, View, View, ctypes.POINTER(StepArgs), vp, vp]
     lib.dsim_control2.argtypes = [vp, vp, i64, View, View, ctypes.POINTER(StepArgs), vp, vp, vp]
     lib.dsim_downwash_prebin_ok.argtypes = [i64, i32, i32]
+    lib.dsim_downwash_reset.argtypes = [ctypes.c_void_p]
     lib.dsim_step_adaptor.argtypes = [vp, vp, i64, View, vp, i32, vp, ctypes.POINTER(StepArgs)]
     lib.dsim_traj_sample.argtypes = [vp, vp, i64, vp, vp, i32, vp, ctypes.c_double, vp, vp, View]
     lib.dsim_materialize.argtypes = [vp, vp, i64, View]

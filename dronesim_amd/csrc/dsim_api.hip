@@ -3195,6 +3195,13 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
   return (int)hipGetLastError();
 }
 
+int dsim_downwash_reset(dsim_ctx* ctx) {
+  if (!ctx) return DSIM_E_ARG;
+  ctx->dw_ws = nullptr; ctx->dw_cells = 0; ctx->dw_parity = 0; ctx->dw_prebin = false; ctx->dw_prebin_valid = false;
+  ctx->dwh_ws = nullptr;
+  return DSIM_OK;
+}
+
 int dsim_fleet_bounds(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float* out5) {
   if (!ctx || !out5 || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
   BoundsK a;

@@ -426,8 +426,8 @@ class CtrlAviary:
         env-step counter that seeds the rotor noise is read from device memory (``step_index_dev``: captured step
         i uses counter + i) and advanced by ``steps`` by a one-thread node at the end of the graph.  Any fleet
         composition, plain or waypoint targets.  With the neighbour-downwash term (single rank): every captured step is
-        query -> step (which fills the next query's grid) -> fallback, ``steps`` must be even, and the grid's box is the one
-        measured at capture time — drones that leave it are clamped to its border cells, which costs search efficiency,
+        query -> step (which fills the next query's grid) -> fallback, and the grid's box is the one measured at capture
+        time — drones that leave it are clamped to its border cells, which costs search efficiency,
         never exactness (``Downwash._grid_box``); capture again after the fleet has moved far."""
         dw = self._downwash
         if dw is not None:
@@ -435,9 +435,8 @@ class CtrlAviary:
             if dw.halo is not None or world > 1:
                 raise NotImplementedError("graph capture with the neighbour-downwash term: single-rank fleets only (the "
                                           "position exchange of a sharded fleet re-sizes its messages on the host)")
-            if steps % 2 or self._fb_stream is not None:
-                raise ValueError("graph capture with the neighbour-downwash term: an even number of steps (the grid's two "
-                                 "count buffers alternate) and no deferred fallback pass")
+            if self._fb_stream is not None:
+                raise ValueError("graph capture with the neighbour-downwash term: not with the deferred fallback pass")
         # nothing may allocate under capture: the fallback queue of hexa fleets is reserved up front
         nat.check(self.ctx.lib.dsim_reserve(self.ctx.handle, self.ctx.stream_ptr(), self.state.n_pad))
         return FusedGraph(self, targets, steps, control_timestep)
@@ -582,6 +581,9 @@ class FusedGraph:
         dev = env.ctx.device
         self._counter = torch.zeros((1,), dtype=torch.int64, device=dev)
         wp = isinstance(targets, WaypointTargets)
+        if env._downwash is not None:
+            env._downwash._box = None           # the eager query inside step_args measures the fleet's box afresh
+            env._downwash.invalidate_prebin()
         self._args = env.step_args(control_timestep, nat.OPT_BCAST_TGT if targets.broadcast else 0)
         self._args.step_index = 0
         self._args.step_index_dev = self._counter.data_ptr()
@@ -604,11 +606,12 @@ class FusedGraph:
                 sp = torch.cuda.current_stream(dev).cuda_stream
                 refresh = None
                 if dw is not None:
-                    # The grid stands for the whole graph (no box re-measurement: that is a host read-back).  The first
-                    # query bins the fleet itself and the last step does not fill a grid ahead, so that a replay starts
-                    # from the count buffers it ends with: one of them in use, the other zeroed by the last query.
+                    # The grid stands for the whole graph (no box re-measurement: that is a host read-back).  Captured
+                    # behind dsim_downwash_reset the first query clears both count buffers and bins the fleet itself, so a
+                    # replay assumes nothing about what ran before it; the last step fills no grid ahead.
                     refresh, dw._box_refresh = dw._box_refresh, 1 << 62
                     dw._prebin_version = None
+                    nat.check(lib.dsim_downwash_reset(h))
                 try:
                     for i in range(steps):
                         self._args.step_index = i          # frozen offset; the base is read from the device counter
@@ -620,6 +623,7 @@ class FusedGraph:
                     if dw is not None:
                         dw._box_refresh = refresh
                         dw._prebin_version = None
+                        nat.check(lib.dsim_downwash_reset(h))
                 nat.check(lib.dsim_counter_add(h, sp, self._counter.data_ptr(), steps))
         torch.cuda.current_stream(dev).wait_stream(side)
         self._counter_host = 0
@@ -630,6 +634,9 @@ class FusedGraph:
         if self._counter_host != env._env_steps:  # eager steps in between: realign the noise stream
             self._counter.fill_(env._env_steps)
         self._graph.replay()
+        if env._downwash is not None:      # the buffers are as the graph left them, not as the ctx last saw them
+            env._downwash._prebin_version = None
+            nat.check(env.ctx.lib.dsim_downwash_reset(env.ctx.handle))
         self._counter_host = env._env_steps + self.steps
         env._use_last_action = False
         env._chain_ok = True

@@ -427,6 +427,11 @@ int dsim_wls_fallback(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, c
 int dsim_downwash_prebin_ok(int64_t m, int32_t nx, int32_t ny);
 int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_downwash_args* args,
                   float* force_out);
+/* Forgets the ctx's bookkeeping of the neighbour grid (which of the two count buffers is current, whether a step has
+ * filled one ahead): the next dsim_downwash clears both and bins everything itself.  Host-side only, nothing is launched.
+ * For callers that replay a captured sequence of dsim_downwash / dsim_step calls (hipGraph): captured behind this call, the
+ * sequence starts from no assumption about the buffers, and called again after a replay, so does whatever follows. */
+int dsim_downwash_reset(dsim_ctx* ctx);
 
 /* Neighbourhood adjacency at fleet scale (BaseAviary._getAdjacencyMatrix, BaseAviary.py:901-921: drones
  * i != j are neighbours when |pos_i - pos_j| < neighbourhood_radius).  The reference returns the dense
