@@ -149,7 +149,8 @@ class Fleet:
                               chained=chained, downwash_exchange=os.environ.get("DSIM_DW_EXCHANGE", "halo"),
                               type_ids=type_ids, options=options, storage=storage or os.environ.get("DSIM_STORAGE", "auto"),
                               downwash_split={"": None, "0": False, "1": True}[os.environ.get("DSIM_DW_SPLIT", "")],
-                              defer_fallback=os.environ.get("DSIM_DEFER_FB", "0") != "0")
+                              defer_fallback=os.environ.get("DSIM_DEFER_FB", "0") != "0",
+                              placement=os.environ.get("DSIM_PLACEMENT", "1") != "0")
         if waypoints:
             self.tgt = WaypointTargets(self.env.ctx, self.n, g["target_pos"], g["target_vel"], g["target_acc"],
                                        g["target_yaw"], wp_counters=wp0, offsets=off)
@@ -627,6 +628,9 @@ def main(argv=None):
                          "kernel": kernel, "bytes_per_drone_step": bytes_per,
                          "launch_us": launch_s * 1e6},
         }
+        if fl.env.ctx.placement_log:
+            # where the fleet-sized arrays beside the state block were put, by measurement (dronesim_amd/placement.py)
+            out["placement"] = list(fl.env.ctx.placement_log)
         if exchange is not None:
             out["exchange"] = exchange
         if a.mirror_peer:
@@ -701,7 +705,8 @@ def main(argv=None):
             from dronesim_amd.envs import CtrlAviary
             xyz = grid_fleet(4096, 1024)
             env = CtrlAviary(["robobee"], xyz.shape[0], initial_xyzs=xyz, aggregate_phy_steps=1, noise_seed=a.noise_seed,
-                             dict_io=False, layout=a.layout, device=local, options=options)
+                             dict_io=False, layout=a.layout, device=local, options=options,
+                             placement=os.environ.get("DSIM_PLACEMENT", "1") != "0")
             ctrl = INDIControl("robobee", env=env)
             tpos = torch.from_numpy(np.ascontiguousarray(xyz.T.astype(np.float32))).to(env.ctx.device)
             cmd = torch.full((xyz.shape[0], 4), 0.4, device=env.ctx.device)
@@ -731,7 +736,8 @@ def main(argv=None):
                 "loop_us_device": el_dev / iters * 1e6,
                 "bytes_per_drone_step": 428, "hbm_frac": xyz.shape[0] * 428 / (el_dev / iters) / 1e9 / HBM_PEAK_GBPS,
                 "note": "physics 68 r + 148 w (13 rigid, 4 action | 13 rigid, 4 echo, 20-wide observation row); "
-                        "control 136 r + 76 w (13 + 11 + 10 | 11 memory, 4 cmd, 3 pos_e, yaw_e)"}
+                        "control 136 r + 76 w (13 + 11 + 10 | 11 memory, 4 cmd, 3 pos_e, yaw_e)",
+                "placement": list(env.ctx.placement_log)}
             env.close(); del env, ctrl
             out["also"] = also
         if world == 1 and not a.no_cpu_baseline:

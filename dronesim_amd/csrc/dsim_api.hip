@@ -401,6 +401,8 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
 
 __global__ void k_counter_add(unsigned long long* c, unsigned long long inc) { *c += inc; }
 
+typedef float vf4 __attribute__((ext_vector_type(4)));        // (a native vector: what the nontemporal builtins take)
+
 // The same fast form for a homogeneous morphing-hexa fleet (6-DOF INDI, first WLS iteration in closed form,
 // infeasible drones queued for k_wls_fallback): whole tiles, stored cmd as the action, one Env.step per
 // launch.  Compiled apart from the mixed-fleet kernel, whose quad branch and per-lane options cost it
@@ -1317,7 +1319,6 @@ __global__ __launch_bounds__(256, DSIM_PHYS_WAVES) void k_physics_fast(StepK a) 
   // banks exactly once), and the block goes out as five 16-byte stores per lane over consecutive addresses.  No
   // workgroup barrier — the block is the wave's own — and no index arithmetic per element (round 2: a __syncthreads,
   // twenty dword stores per lane and a division by W each; SQ_WAIT_ANY 0.36).
-  typedef float vf4 __attribute__((ext_vector_type(4)));       // (a native vector: what the nontemporal builtin takes)
   __shared__ __attribute__((aligned(16))) vf4 rows[OBS ? 4 * 64 * (W / 4) : 1];
   const DevType& T = a.types[0];
   const long long sfs = a.st.field_stride;

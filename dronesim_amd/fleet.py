@@ -43,6 +43,10 @@ class Context:
         # fleet type-major; every per-drone block built on this context for that fleet (state, targets, waypoint
         # counters) then translates between the caller's numbering and the storage slots
         self.order = None
+        # Placement (placement.py): where the observation rows of a large fleet lie relative to the state block is chosen
+        # by timing the real launch.  `placement` False: allocated plainly.  `placement_log`: one dict per search made.
+        self.placement = True
+        self.placement_log = []
 
     @property
     def handle(self):

@@ -652,6 +652,40 @@ def test_graph_replay_of_a_downwash_fleet(gpu, world):
         e.close()
 
 
+def test_observation_rows_are_placed_by_timing_zero_substep_passes(gpu):
+    """placement.place_rows (a fleet large enough for HBM placement to matter): the candidates are compared by passes of
+    the real Env.step launch with zero physics sub-steps, which leave the state bit for bit as it was, the echoed action
+    and the ground-contact count untouched from the caller's point of view; stepping afterwards gives exactly what an env
+    with plainly allocated rows gives."""
+    nat, fleet = gpu
+    from dronesim_amd.envs import CtrlAviary
+    from dronesim_amd.fleet import Targets
+    nd = 1 << 20                                                  # rows: 80 MB, above placement.MIN_BYTES
+    rng = np.random.default_rng(12)
+    xyz = np.stack([np.arange(nd) % 1024, np.arange(nd) // 1024, rng.uniform(-0.2, 3.0, nd)], 1).astype(np.float64)   # some on the ground
+    envs = [CtrlAviary(["robobee"], nd, initial_xyzs=xyz, aggregate_phy_steps=1, noise_seed=4, dict_io=False, placement=p)
+            for p in (True, False)]
+    obs = []
+    for e in envs:
+        t = Targets(e.ctx, nd, e.state.layout); t.set(pos=f32(xyz + 0.1).T, yaw=0.3)
+        e.step_fused(t, action=np.full((nd, 4), 0.4, dtype=np.float32))
+        before = e.state.data.view(torch.int32).clone()
+        la = e._last_action.clone()
+        gc0 = e.ground_contacts()
+        rows = e._obs_tensor()                                   # the search (placement=True) or a plain allocation
+        assert rows.shape == (nd, 20) and float(rows.abs().max()) == 0.0
+        assert torch.equal(e.state.data.view(torch.int32), before) and torch.equal(e._last_action, la) and e.ground_contacts() == gc0
+        o, _, _, _ = e.step(np.full((nd, 4), 0.5, dtype=np.float32))
+        obs.append(o.obs if hasattr(o, "obs") else o)
+    log = envs[0].ctx.placement_log
+    assert len(log) == 1 and 2 <= log[0]["candidates"] <= 6 and 0 <= log[0]["chosen"] < log[0]["candidates"]
+    assert all(t > 0 for t in log[0]["zero_substep_pass_us"]) and envs[1].ctx.placement_log == []
+    assert torch.equal(envs[0].state.data, envs[1].state.data) and torch.equal(obs[0], obs[1])
+    assert envs[0].ground_contacts() == envs[1].ground_contacts() > 0
+    for e in envs:
+        e.close()
+
+
 def test_sharded_downwash_example_runs_as_two_ranks(gpu):
     """examples/fly_sharded_downwash_fleet.py under torch.distributed.run, two gloo ranks sharing the one GPU: both ranks
     fly, ship the boundary strip only, lose nothing."""
