@@ -12,9 +12,15 @@ recorded as box-to-box spread of the reference-shaped loop (291-333 us in one an
 
 So the placement is chosen by timing the real launch: `dsim_physics` with ZERO physics sub-steps is the same kernel with the
 same memory streams — the state is read and written back bit for bit, the action is clipped and echoed, the rows are
-written — and changes nothing.  `place_rows` allocates a few candidates for the rows (the later ones behind some ballast,
-so that they come from other blocks), times three such passes on each, keeps the fastest and releases the rest.  Only
-for fleets whose rows are at least `MIN_BYTES`: smaller fleets are bound by launch latency, not by HBM.
+written — and changes nothing.  `place_rows` allocates candidates for the rows one after the other, holding them all so that
+the walk moves through device memory (up to 24 GiB, transient), times three such passes on each, stops at the first that
+is clearly faster than the first one (or clearly slower: then the first one was right), keeps it and releases the rest.
+Only for fleets whose rows are at least `MIN_BYTES`: smaller fleets are bound by launch latency, not by HBM.
+
+The same holds for what computeControl WRITES beside the state block whose controller memory it updates (command, position
+error, yaw error: 32 bytes per drone; `tools/placement_probe_ctrl.py`: 144.7 us as allocated, 136 us with the outputs
+elsewhere, the targets — which are only read — indifferent).  That launch has no neutral form, so INDIControl takes a
+snapshot of the state block, times real passes on the candidates and puts the snapshot back.
 """
 from __future__ import annotations
 
@@ -22,19 +28,25 @@ from typing import Callable, Optional
 
 import torch
 
-MIN_BYTES = 64 << 20                          # rows (and state) at least this large, or the array is allocated plainly
-BALLAST_GIB = (0, 0, 1, 2, 4, 4)              # allocated (and held) in front of candidate k: the walk leaves the first blocks
-GOOD_ENOUGH = 0.93                            # a candidate this much faster than the first one ends the search
+MIN_BYTES = 64 << 20                          # arrays at least this large, or they are allocated plainly
+WALK_BYTES = 24 << 30                         # candidates held at once while searching (transient): crosses a 16 GiB region
+CLEARLY = 0.93                                # one candidate this much faster than another: the two cases are apart, stop
 
 
-def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int = 3, report: Optional[list] = None) -> torch.Tensor:
-    """A zeroed fp32 array of `shape`.  `trial(rows)` enqueues ONE zero-sub-step pass of the real kernel writing its rows
-    to `rows`; candidates are compared by the time of `passes` of them behind one untimed pass."""
-    cands, times, ballast = [], [], []
-    for gib in BALLAST_GIB:
+def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int = 3, report: Optional[list] = None,
+               label: str = "observation rows", walk_bytes: int = WALK_BYTES) -> torch.Tensor:
+    """A zeroed fp32 array of `shape`.  `trial(array)` enqueues ONE pass of the real kernel writing its output to `array`
+    (Env.step: a zero-sub-step pass; computeControl: a real pass, the caller restores the state afterwards).  Candidates
+    are allocated one after the other and all held, so that the walk moves through device memory; each is timed over
+    `passes` passes behind one untimed pass; the walk ends as soon as one candidate is clearly faster than the first (it
+    is kept) or clearly slower (the first is kept), or when `walk_bytes` are held (the fastest is kept)."""
+    nbytes = 4
+    for d in shape:
+        nbytes *= int(d)
+    cands, times = [], []
+    chosen = None
+    while chosen is None and (len(cands) + 1) * nbytes <= max(walk_bytes, 2 * nbytes):
         try:
-            if gib:
-                ballast.append(torch.empty((gib << 30,), dtype=torch.uint8, device=device))
             c = torch.empty(tuple(shape), dtype=torch.float32, device=device)
         except torch.cuda.OutOfMemoryError:
             break
@@ -47,15 +59,20 @@ def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int
         e1.synchronize()
         cands.append(c)
         times.append(e0.elapsed_time(e1) * 1e3 / passes)
-        if len(times) > 1 and times[-1] < GOOD_ENOUGH * times[0]:
-            break
-    chosen = min(range(len(times)), key=times.__getitem__)
+        if times[-1] < CLEARLY * times[0]:
+            chosen = len(times) - 1
+        elif times[0] < CLEARLY * times[-1]:
+            chosen = 0
+    if chosen is None:
+        chosen = min(range(len(times)), key=times.__getitem__)
     keep = cands[chosen]
     if report is not None:
-        report.append({"array": "observation rows", "bytes": 4 * keep.numel(), "candidates": len(cands), "chosen": chosen,
-                       "zero_substep_pass_us": [round(t, 1) for t in times]})
+        shown = times if len(times) <= 12 else times[:4] + times[-4:]
+        report.append({"array": label, "bytes": nbytes, "candidates": len(cands), "chosen": chosen,
+                       "chosen_pass_us": round(times[chosen], 1), "first_pass_us": round(times[0], 1),
+                       "pass_us" if len(times) <= 12 else "pass_us_first4_last4": [round(t, 1) for t in shown]})
     c = None
-    del cands, ballast
+    del cands
     torch.cuda.empty_cache()                  # what was not kept goes back to the device
     keep.zero_()
     return keep
