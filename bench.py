@@ -703,6 +703,12 @@ def main(argv=None):
             # (two launches: physics with the observation rows fused, control with the command handed back in place)
             from dronesim_amd.control import INDIControl
             from dronesim_amd.envs import CtrlAviary
+            # (what the earlier entries left in PyTorch's allocator cache goes back to the device first: this env's arrays
+            # then come from whole fresh blocks, as they would in a process that runs this loop alone — the placement
+            # search of dronesim_amd/placement.py has little to choose from when every array is pieced together from
+            # fragments of many regions)
+            gc.collect()
+            torch.cuda.empty_cache()
             xyz = grid_fleet(4096, 1024)
             env = CtrlAviary(["robobee"], xyz.shape[0], initial_xyzs=xyz, aggregate_phy_steps=1, noise_seed=a.noise_seed,
                              dict_io=False, layout=a.layout, device=local, options=options,

@@ -45,6 +45,7 @@ def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int
         nbytes *= int(d)
     cands, times = [], []
     chosen = None
+    torch.cuda.empty_cache()                  # candidates from whole device blocks, not from pieces the allocator has cached
     while chosen is None and (len(cands) + 1) * nbytes <= max(walk_bytes, 2 * nbytes):
         try:
             c = torch.empty(tuple(shape), dtype=torch.float32, device=device)

@@ -95,6 +95,23 @@ __global__ __launch_bounds__(TPB) void k_blk_work(float* st, const float* tg, lo
   for (int f = 0; f < FS; ++f) __builtin_nontemporal_store(o[f], ps + f * B);
 }
 
+// K1d: the headline shape with the new state written to ANOTHER array (ping-pong) instead of in place
+__global__ __launch_bounds__(256) void k_tile_pp(const float* st, const float* tg, float* out, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* ps = st + (i >> 6) * (FS * 64) + (i & 63);
+  const float* pt = tg + (i >> 6) * (FT * 64) + (i & 63);
+  float* po = out + (i >> 6) * (FS * 64) + (i & 63);
+  float v[FS + FT], o[FS];
+#pragma unroll
+  for (int f = 0; f < FS; ++f) v[f] = __builtin_nontemporal_load(ps + f * 64);
+#pragma unroll
+  for (int f = 0; f < FT; ++f) v[FS + f] = __builtin_nontemporal_load(pt + f * 64);
+  mix(v, FS + FT, o, FS);
+#pragma unroll
+  for (int f = 0; f < FS; ++f) __builtin_nontemporal_store(o[f], po + f * 64);
+}
+
 // K2: wave tiles, 16 B per lane global accesses, transposed through wave-private LDS
 template <bool NT>
 __global__ __launch_bounds__(256) void k_tile_lds(float* st, const float* tg, long long n) {
@@ -396,12 +413,18 @@ int main(int argc, char** argv) {
     float* sink; CK(hipMalloc(&sink, 256));
     const long long n4 = (256u << 20) / 16;
     const dim3 g4((unsigned)((n4 + 255) / 256));
-    for (size_t D = sz_st + 2 * sz_a; D + sz_r <= total; D += 128ull << 20) {
+    for (size_t D = sz_st + 2 * sz_a; D + sz_r <= total; D += 512ull << 20) {
       float* rows = (float*)(arena + D);
       const float t3 = time_it([&] { hipLaunchKernelGGL(k_env_shape<true>, g, b, 0, 0, st, act, echo, rows, n); }, 6);
       const float tp = time_it([&] { hipLaunchKernelGGL(k_pair<3>, g4, b, 0, 0, (f4*)arena, (f4*)(arena + D), sink, n4); }, 6);
       const float tq = time_it([&] { hipLaunchKernelGGL(k_pair<4>, g4, b, 0, 0, (f4*)arena, (f4*)(arena + D), sink, n4); }, 6);
-      printf("D = %6zu MiB  Env.step shape %.1f us   pair rw a + w b %.1f us   pair rw a + r b %.1f us\n", D >> 20, t3 * 1e3, tp * 1e3, tq * 1e3);
+      float tpp = 0.f, tin = 0.f;
+      if (D + sz_st <= total) {
+        const float* tgp = (const float*)(arena + sz_st);            // targets right behind the state (inside act / echo's place)
+        tpp = time_it([&] { hipLaunchKernelGGL(k_tile_pp, g, b, 0, 0, (const float*)st, tgp, (float*)(arena + D), n); }, 6);
+        tin = time_it([&] { hipLaunchKernelGGL(k_tile<true>, g, b, 0, 0, st, tgp, n); }, 6);
+      }
+      printf("D = %6zu MiB  Env.step shape %.1f us   pair rw a + w b %.1f us   pair rw a + r b %.1f us   headline shape in place %.1f us, written to D %.1f us\n", D >> 20, t3 * 1e3, tp * 1e3, tq * 1e3, tin * 1e3, tpp * 1e3);
     }
     return 0;
   }
