@@ -33,13 +33,25 @@ WALK_BYTES = 24 << 30                         # candidates held at once while se
 CLEARLY = 0.93                                # one candidate this much faster than another: the two cases are apart, stop
 
 
+def _event_timer(trial, c, passes: int) -> float:
+    """Microseconds per pass: `passes` passes behind one untimed pass, between two events on the current stream."""
+    trial(c)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(passes):
+        trial(c)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / passes
+
+
 def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int = 3, report: Optional[list] = None,
-               label: str = "observation rows", walk_bytes: int = WALK_BYTES) -> torch.Tensor:
+               label: str = "observation rows", walk_bytes: int = WALK_BYTES, timer=None) -> torch.Tensor:
     """A zeroed fp32 array of `shape`.  `trial(array)` enqueues ONE pass of the real kernel writing its output to `array`
     (Env.step: a zero-sub-step pass; computeControl: a real pass, the caller restores the state afterwards).  Candidates
     are allocated one after the other and all held, so that the walk moves through device memory; each is timed over
     `passes` passes behind one untimed pass; the walk ends as soon as one candidate is clearly faster than the first (it
-    is kept) or clearly slower (the first is kept), or when `walk_bytes` are held (the fastest is kept)."""
+    is kept) or clearly slower (the first is kept), or when `walk_bytes` are held (the fastest is kept).  `timer(trial, candidate, passes)`: the clock (tests)."""
     nbytes = 4
     for d in shape:
         nbytes *= int(d)
@@ -51,15 +63,8 @@ def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int
             c = torch.empty(tuple(shape), dtype=torch.float32, device=device)
         except torch.cuda.OutOfMemoryError:
             break
-        trial(c)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(passes):
-            trial(c)
-        e1.record()
-        e1.synchronize()
         cands.append(c)
-        times.append(e0.elapsed_time(e1) * 1e3 / passes)
+        times.append((timer or _event_timer)(trial, c, passes))
         if times[-1] < CLEARLY * times[0]:
             chosen = len(times) - 1
         elif times[0] < CLEARLY * times[-1]:

@@ -1,0 +1,45 @@
+"""Host logic of dronesim_amd/placement.py (which candidate the walk keeps, when it stops), with a scripted clock: no
+device needed.  What the placement is worth is measured on the GPU (tests/test_gpu_round3.py, profiles/r03_placement_*)."""
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from dronesim_amd import placement  # noqa: E402
+
+
+def walk(times, shape=(1024, 20), walk_bytes=None):
+    """Runs place_rows on the CPU with the i-th candidate 'taking' times[i] microseconds; returns (report, array, passes seen)."""
+    seen, log = [], []
+    it = iter(times)
+
+    def timer(trial, c, passes):
+        trial(c)
+        seen.append(passes)
+        return next(it)
+    touched = []
+    out = placement.place_rows("cpu", shape, lambda c: touched.append(c.data_ptr()), report=log,
+                               walk_bytes=walk_bytes if walk_bytes is not None else 4 * shape[0] * shape[1] * len(times), timer=timer)
+    return log[0], out, touched
+
+
+def test_walk_stops_at_the_first_clearly_faster_candidate():
+    rep, out, touched = walk([165.0, 164.0, 166.0, 142.0, 141.0, 150.0])
+    assert rep["candidates"] == 4 and rep["chosen"] == 3 and rep["chosen_pass_us"] == 142.0 and rep["first_pass_us"] == 165.0
+    assert out.shape == (1024, 20) and float(out.abs().max()) == 0.0 and out.data_ptr() == touched[3]
+
+
+def test_first_candidate_is_kept_as_soon_as_a_later_one_is_clearly_slower():
+    rep, out, touched = walk([142.0, 143.0, 166.0, 120.0])
+    assert rep["candidates"] == 3 and rep["chosen"] == 0 and out.data_ptr() == touched[0]
+
+
+def test_fastest_of_a_flat_walk_is_kept_when_the_budget_is_spent():
+    times = [160.0, 161.0, 158.5, 159.0, 162.0]
+    rep, out, touched = walk(times)
+    assert rep["candidates"] == 5 and rep["chosen"] == 2 and out.data_ptr() == touched[2]
+    # the budget counts what is held at once: two candidates' worth of bytes -> two candidates
+    rep, _, _ = walk(times, walk_bytes=2 * 4 * 1024 * 20)
+    assert rep["candidates"] == 2 and rep["chosen"] == 0
+    # a long walk reports its first and last four timings only
+    rep, _, _ = walk([160.0 + 0.01 * k for k in range(20)])
+    assert rep["candidates"] == 20 and "pass_us_first4_last4" in rep and len(rep["pass_us_first4_last4"]) == 8
