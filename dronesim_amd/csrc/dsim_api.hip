@@ -1727,6 +1727,22 @@ __device__ __forceinline__ float dw_pair(float4 p, float x, float y, float z, fl
   const float term = -(K * (inv * b2)) * DSIM_EXP2((-0.5f * 1.44269504088896341f) * dd * (inv * dz2));   // :1753, 1755
   return hit ? term : 0.0f;
 }
+// The same term for the banded loop, accumulated: the exponent's -1/2 log2(e) is folded into the coefficients of beta
+// (d1s = d1 S, d2s = d2 S with S^2 = 2 ln 2, scaled once per receiver group: exp(-dd / (2 beta^2)) = exp2(-dd / beta_s^2)),
+// and the rejected lanes' term is selected away in front of ONE fused multiply-add: 20 vector instructions per candidate
+// instead of 22, with a loop whose control is scalar (the callers' trip count is wave-uniform).
+#define DW_BETA_SCALE 1.17741002251547469101f      // sqrt(2 ln 2)
+__device__ __forceinline__ float dw_pair_acc(float4 p, float x, float y, float z, float d1s, float d2s, float acc) {
+  const float dz = p.z - z, dx = p.x - x, dy = p.y - y;
+  const float dd = dx * dx + dy * dy;
+  const bool hit = dz > 0.0f && dd < DW_CUTOFF * DW_CUTOFF;     // :1752
+  const float dzs = hit ? dz : 1.0f;
+  const float beta = d1s * dzs + d2s;                           // :1754, scaled
+  const float dz2 = dzs * dzs, b2 = fmaxf(beta * beta, 1e-12f);
+  const float inv = DSIM_RCP(dz2 * b2);
+  const float e = DSIM_EXP2(-(dd * (inv * dz2)));               // :1755
+  return __builtin_fmaf(-(inv * b2), hit ? e : 0.0f, acc);     // :1753
+}
 // (Measured and rejected: the same loop in PACKED fp32 — two candidates per v_pk_add/mul/fma_f32 on an x | y | z LDS
 // image read 8 bytes at a time, 16 packed instructions per candidate pair instead of ~50 scalar ones: 135 us instead of
 // 50 us at BASELINE config 5's density.  On gfx950 a v_pk_*_f32 costs far more issue time than the two scalar
@@ -1859,7 +1875,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
     const int G = (cnt_c + DW_RPG - 1) / DW_RPG;
     // (measured and rejected: sending the halo pass — few candidates — down the plain path below: 65.5 against 62.1 us for
     // the three phases; the bands save more pairs than their set-up costs even there)
-    if (whole && G >= 2 && total <= DW_ENT_PER_THREAD * TPB) {
+    if (whole && G >= 2 && total + 2 * DW_LPB <= DW_ENT_PER_THREAD * TPB) {         // (room for the sentinels behind the last band)
       const unsigned lane = t & 63u;
       const int w = __builtin_amdgcn_readfirstlane((int)(t >> 6));
       int my_ty = -1;
@@ -1887,6 +1903,10 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
       }
       __syncthreads();
       // ---- fill by band: the entries wait in registers while their bands are counted ----
+      // (Measured and rejected: letting this second round trip ride on the first — slots [0, 40) of every neighbour bucket
+      // fetched at fixed addresses before the counts are known, 1 000 loads per cell instead of ~625, what lies beyond a
+      // count dropped afterwards: 47.6 against 46.0 us for the chain.  The extra traffic and the eight entries per thread
+      // held across the sort — 80 VGPRs only under a launch bound — cost more than the round trip they hide.)
       float4 ent[DW_ENT_PER_THREAD];
       unsigned bands = 0;                                                              // 4 bits per entry
       {
@@ -1925,6 +1945,11 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
       }
       if (w == 0) rty[lane] = my_ty;
       __syncthreads();
+      if (t < 2 * DW_LPB) {                  // sentinels behind the last band (below everything: no term), see the pair loop
+        int placed = 0;
+        for (int k = 1; k <= G; ++k) placed += bcnt[k];
+        tile[placed + (int)t] = make_float4(0.0f, 0.0f, -__builtin_inff(), 0.0f);
+      }
 #pragma unroll
       for (int q = 0; q < DW_ENT_PER_THREAD; ++q) {
         const int band = (int)((bands >> (4 * q)) & 15u);
@@ -1952,13 +1977,15 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
         if (have) {
           K = coef[ty][0];
           const float d1 = coef[ty][1], d2c = coef[ty][2];
-          int e = sub8;
-          for (; e + DW_LPB < lim; e += 2 * DW_LPB) {
-            const float4 p0 = tile[e], p1 = tile[e + DW_LPB];
-            fz += dw_pair(p0, me.x, me.y, me.z, 1.0f, d1, d2c);
-            fz += dw_pair(p1, me.x, me.y, me.z, 1.0f, d1, d2c);
+          const float d1s = d1 * DW_BETA_SCALE, d2s = d2c * DW_BETA_SCALE;
+          // sixteen entries per trip whatever the lane: what lies between lim and the next multiple of 16 is either an
+          // entry of a lower band (not above ANY receiver of this group: dz <= 0, no term) or one of the sentinels behind
+          // the last band — so the trip count is the wave's, and the loop control scalar
+          for (int base = 0; base < lim; base += 2 * DW_LPB) {
+            const float4 p0 = tile[base + sub8], p1 = tile[base + DW_LPB + sub8];
+            fz = dw_pair_acc(p0, me.x, me.y, me.z, d1s, d2s, fz);
+            fz = dw_pair_acc(p1, me.x, me.y, me.z, d1s, d2s, fz);
           }
-          if (e < lim) fz += dw_pair(tile[e], me.x, me.y, me.z, 1.0f, d1, d2c);
           for (int k = sub8; k < n_ovf; k += DW_LPB) fz += dw_pair(cnd.overflow[k], me.x, me.y, me.z, 1.0f, d1, d2c);
         }
 #pragma unroll
@@ -2005,13 +2032,14 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
       if (have) {
         K = coef[ty][0]; d1 = coef[ty][1]; d2c = coef[ty][2];                          // (LDS: written before the first barrier)
         const int lim = min(tile_cap, total - base);
+        const float d1s = d1 * DW_BETA_SCALE, d2s = d2c * DW_BETA_SCALE;
         int e = sub_p;
         for (; e + lpb < lim; e += 2 * lpb) {                                          // two candidates in flight per lane
           const float4 p0 = tile[e], p1 = tile[e + lpb];
-          fz += dw_pair(p0, me.x, me.y, me.z, 1.0f, d1, d2c);
-          fz += dw_pair(p1, me.x, me.y, me.z, 1.0f, d1, d2c);
+          fz = dw_pair_acc(p0, me.x, me.y, me.z, d1s, d2s, fz);
+          fz = dw_pair_acc(p1, me.x, me.y, me.z, d1s, d2s, fz);
         }
-        if (e < lim) fz += dw_pair(tile[e], me.x, me.y, me.z, 1.0f, d1, d2c);
+        if (e < lim) fz = dw_pair_acc(tile[e], me.x, me.y, me.z, d1s, d2s, fz);
       }
     }
     if (have)
