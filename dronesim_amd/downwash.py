@@ -310,15 +310,14 @@ class HaloPlan(HaloWire):
         self._started = bool(self._ops)
         if not self._ops:
             return
-        main = torch.cuda.current_stream(self.ctx.device)
         if self.timing is not None:
             self._t0 = torch.cuda.Event(enable_timing=True)
-            self._t0.record(main)
-        self._pack(main.cuda_stream)
+            self._t0.record(torch.cuda.current_stream(self.ctx.device))
+        self._pack(self.ctx.stream_ptr())
         if self.on_rccl:
             self._works = self.dist.batch_isend_irecv(self._ops)       # RCCL's stream waits for the pack; nobody waits for RCCL yet
         else:
-            self._wire(main.synchronize)
+            self._wire(torch.cuda.current_stream(self.ctx.device).synchronize)
 
     def finish(self) -> None:
         """Orders the current stream behind the wire (what arrived is in `recv`)."""
@@ -532,15 +531,14 @@ class Downwash:
         view, fptr = self._halo_args[1], self._halo_args[2]
         pre = int(self._prebin_version is not None and self._prebin_version == self.state.version)
         self._prebin_version = None
-        main = torch.cuda.current_stream(self.ctx.device)
-        sp = main.cuda_stream
+        sp = self.ctx.stream_ptr()
         if not self.split:
             hp.finish()
             a_all.prebinned = pre
             nat.check(lib.dsim_downwash(h, sp, st.n, view, r_all, fptr))
             if hp.timing is not None and hp._started:
                 t1 = torch.cuda.Event(enable_timing=True)
-                t1.record(main)
+                t1.record(torch.cuda.current_stream(self.ctx.device))
                 hp.timing.append((hp._t0, t1))
             self._last = a_all
             return self.force
@@ -550,7 +548,7 @@ class Downwash:
         nat.check(lib.dsim_downwash(h, sp, st.n, view, r_bin, None))           # what arrived -> the halo grid
         if hp.timing is not None and hp._started:
             t1 = torch.cuda.Event(enable_timing=True)
-            t1.record(main)
+            t1.record(torch.cuda.current_stream(self.ctx.device))
             hp.timing.append((hp._t0, t1))
         nat.check(lib.dsim_downwash(h, sp, st.n, view, r_qry, fptr))           # the halo pass: force +=
         self._last = a_loc                               # what a step kernel that bins ahead is told about the next grid

@@ -19,6 +19,9 @@ F_POS, F_QUAT, F_VEL, F_ANGVEL = 0, 3, 7, 10
 F_LAST_VEL, F_LAST_RATES, F_LAST_THRUST, F_CMD = 13, 16, 19, 20
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def pad_to(n: int, m: int = 256) -> int:
     """The C-ABI needs n_pad % 64 == 0; whole 256-drone tiles keep the entire fleet on the
     fused kernel's fast path (a ragged tail costs one extra small launch)."""
@@ -53,6 +56,11 @@ class Context:
         return self._h
 
     def stream_ptr(self) -> int:
+        """The current stream of this device as a raw hipStream_t.  (torch.cuda.current_stream().cuda_stream builds a
+        Stream object per call: 1.9 us, a quarter of the Python side of a launch; the raw accessor — the one PyTorch's own
+        generated code uses — answers in 0.06 us.)"""
+        if _RAW_STREAM is not None:
+            return _RAW_STREAM(self.device.index)
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def query(self, what: int) -> int:
