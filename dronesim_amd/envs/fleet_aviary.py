@@ -652,6 +652,9 @@ class FusedGraph:
                         dw._box_refresh = refresh
                         dw._prebin_version = None
                         nat.check(lib.dsim_downwash_reset(h))
+                        # the captured launches hold these addresses: an eager step that later re-measures the box and
+                        # outgrows the workspace allocates a new one — this one must outlive the graph
+                        self._keepalive = (dw._ws, dw.force, dw.type_id)
                 nat.check(lib.dsim_counter_add(h, sp, self._counter.data_ptr(), steps))
         torch.cuda.current_stream(dev).wait_stream(side)
         self._counter_host = 0
