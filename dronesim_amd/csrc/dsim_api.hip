@@ -1787,9 +1787,11 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
   __shared__ int nb_cell[DW_NBR], nb_cnt[DW_NBR];
   __shared__ float coef[DSIM_MAX_TYPES][4];                                            // (K, DW2, DW3) of every type
   __shared__ float4 recv[BAND ? DW_CAP : 1];                                           // receivers, sorted by height
-  __shared__ int rty[BAND ? DW_CAP : 1];                                               // their types (-1: not mine to serve)
+  __shared__ __attribute__((aligned(16))) int rty[BAND ? DW_CAP : 4];                  // their types (-1: not mine to serve); before
+  float* const skey = reinterpret_cast<float*>(rty);                                   // that, the heights while they are ranked (the
+                                                                                       // tile's 12 KB + this must stay within 11 cells per CU)
   __shared__ float zlo[BAND ? DW_MAXG : 1];                                            // lowest receiver of every group
-  __shared__ int bcnt[BAND ? DW_MAXG + 1 : 1], bcur[BAND ? DW_MAXG + 1 : 1];           // entries per band; placement cursors
+  __shared__ int wcnt[BAND ? TPB / 64 : 1][BAND ? DW_MAXG + 1 : 1];                    // entries per band, per wave
   constexpr int RPB = TPB / DW_LPB;                                                    // receivers per pass
   const int ncells = b.nx * b.ny;
   const unsigned t = threadIdx.x;
@@ -1878,37 +1880,10 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
     if (whole && G >= 2 && total + 2 * DW_LPB <= DW_ENT_PER_THREAD * TPB) {         // (room for the sentinels behind the last band)
       const unsigned lane = t & 63u;
       const int w = __builtin_amdgcn_readfirstlane((int)(t >> 6));
-      int my_ty = -1;
-      if (w == 0) {
-        // ---- sort the receivers by height: bitonic network over the wave, key (z, slot) ----
-        float key = (int)lane < cnt_c ? mine.z : __builtin_inff();
-        int idx = (int)lane;
-#pragma unroll
-        for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-          for (int j = k >> 1; j > 0; j >>= 1) {
-            const float ok = __shfl_xor(key, j);
-            const int oi = __shfl_xor(idx, j);
-            const bool want_min = (((int)lane & j) == 0) == (((int)lane & k) == 0);
-            const bool lt = key < ok || (key == ok && idx < oi);
-            if (want_min != lt) { key = ok; idx = oi; }
-          }
-        }
-        const float4 srt = make_float4(__shfl(mine.x, idx), __shfl(mine.y, idx), __shfl(mine.z, idx), __shfl(mine.w, idx));
-        recv[lane] = srt;
-        if ((lane & (DW_RPG - 1)) == 0) zlo[lane / DW_RPG] = key;
-        if (lane <= DW_MAXG) { bcnt[lane] = 0; bcur[lane] = 0; }
-        const long long i = (long long)__float_as_int(srt.w) - a.local_offset;
-        if ((int)lane < cnt_c && i >= 0 && i < a.n) my_ty = a.type_id ? (int)a.type_id[i] : 0;   // (lands during the fill)
-      }
-      __syncthreads();
-      // ---- fill by band: the entries wait in registers while their bands are counted ----
-      // (Measured and rejected: letting this second round trip ride on the first — slots [0, 40) of every neighbour bucket
-      // fetched at fixed addresses before the counts are known, 1 000 loads per cell instead of ~625, what lies beyond a
-      // count dropped afterwards: 47.6 against 46.0 us for the chain.  The extra traffic and the eight entries per thread
-      // held across the sort — 80 VGPRs only under a launch bound — cost more than the round trip they hide.)
+      int my_ty = -1, rank = 0;
+      // the fill's loads are issued first: their round trip runs beside the ordering of the receivers below (which needs
+      // nothing of them; with the shuffle network — 74 VGPRs — holding six entries across it did not pay, at 58 it does)
       float4 ent[DW_ENT_PER_THREAD];
-      unsigned bands = 0;                                                              // 4 bits per entry
       {
         int k = 0, acc = 0;                                                            // (the thread's entries ascend: the walk
 #pragma unroll                                                                         //  over the neighbour counts resumes)
@@ -1921,6 +1896,45 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
           }
         }
       }
+      if (w == 0) {
+        // ---- order the receivers by height: every lane counts the receivers below its own (key (z, slot); the keys are
+        // read back from LDS as broadcasts, four at a time) and scatters its entry to that rank.  A bitonic network on
+        // shuffles did the same in 21 exchange stages — 250 instructions and 46 trips through the LDS crossbar, on one wave
+        // while the other waits; the count is 25 receivers x 1.5 instructions. ----
+        const bool real = (int)lane < cnt_c;
+        const float key = real ? mine.z : __builtin_inff();
+        skey[lane] = key;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int j = 0; j < cnt_c; j += 4) {
+          const float4 k4 = *reinterpret_cast<const float4*>(&skey[j]);                 // (beyond cnt_c: +inf, below nobody)
+          rank += (k4.x < key || (k4.x == key && j < (int)lane)) ? 1 : 0;
+          rank += (k4.y < key || (k4.y == key && j + 1 < (int)lane)) ? 1 : 0;
+          rank += (k4.z < key || (k4.z == key && j + 2 < (int)lane)) ? 1 : 0;
+          rank += (k4.w < key || (k4.w == key && j + 3 < (int)lane)) ? 1 : 0;
+        }
+        if (real) {
+          recv[rank] = mine;
+          if ((rank & (DW_RPG - 1)) == 0) zlo[rank / DW_RPG] = key;
+          const long long i = (long long)__float_as_int(mine.w) - a.local_offset;
+          if (i >= 0 && i < a.n) my_ty = a.type_id ? (int)a.type_id[i] : 0;             // (lands during the fill)
+        } else rank = (int)lane;                                                        // (slots behind the receivers: nobody's)
+      }
+      __syncthreads();
+      // ---- fill by band: the entries wait in registers while their bands are counted ----
+      // (Measured and rejected: letting this second round trip ride on the first — slots [0, 40) of every neighbour bucket
+      // fetched at fixed addresses before the counts are known, 1 000 loads per cell instead of ~625, what lies beyond a
+      // count dropped afterwards: 47.6 against 46.0 us for the chain.  The extra traffic and the eight entries per thread
+      // held across the sort — 80 VGPRs only under a launch bound — cost more than the round trip they hide.)
+      unsigned bands = 0;                                                              // 4 bits per entry
+      // Counting and placing without one LDS atomic: a band's members among a wave's 64 entries are a ballot, their number
+      // a population count, a member's place its rank in the mask.  (Per-lane LDS atomics on the 4-8 band counters — same
+      // address for most of a wave, 1 536 of them per cell, eleven cells per CU on one LDS pipe — were a third of the
+      // kernel: 31.1 -> see DESIGN.md.)
+      int wave_cnt[DW_MAXG + 1];                                                       // wave-uniform
+#pragma unroll
+      for (int k = 0; k <= DW_MAXG; ++k) wave_cnt[k] = 0;
       // A candidate further than the cut-off from every point of THIS cell is useless to all of its receivers: the
       // 5 x 5 cells around a 5 m cell cover 625 m^2, the cell grown by 10 m 539 m^2 (the corner cells lose two thirds of
       // their area) — 14 % fewer pair evaluations for one distance test per candidate.  (Border cells also hold the
@@ -1938,25 +1952,53 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
           const float ox = fmaxf(fmaxf(bx0 - ent[q].x, ent[q].x - bx1), 0.0f), oy = fmaxf(fmaxf(by0 - ent[q].y, ent[q].y - by1), 0.0f);
           if (ox * ox + oy * oy < REACH2) {
             for (int g = 0; g < G; ++g) band += zlo[g] < ent[q].z ? 1 : 0;
-            if (band > 0) atomicAdd(&bcnt[band], 1);
           }
         }
         bands |= (unsigned)band << (4 * q);
+#pragma unroll
+        for (int k = 1; k <= DW_MAXG; ++k)
+          if (k <= G) wave_cnt[k] += (int)__popcll(__ballot(band == k));
       }
-      if (w == 0) rty[lane] = my_ty;
+      if (w == 0) rty[rank] = my_ty;
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 1; k <= DW_MAXG; ++k) wcnt[w][k] = wave_cnt[k];
+      }
       __syncthreads();
-      if (t < 2 * DW_LPB) {                  // sentinels behind the last band (below everything: no term), see the pair loop
-        int placed = 0;
-        for (int k = 1; k <= G; ++k) placed += bcnt[k];
-        tile[placed + (int)t] = make_float4(0.0f, 0.0f, -__builtin_inff(), 0.0f);
+      constexpr int NWV = TPB / 64;
+      int bstart[DW_MAXG + 1];                                                         // where a band begins (bands above it first)
+#pragma unroll
+      for (int k = DW_MAXG; k >= 1; --k) {
+        int tot = 0;
+        if (k <= G)
+          for (int v = 0; v < NWV; ++v) tot += wcnt[v][k];
+        wave_cnt[k] = tot;                                                             // from here on: the band's total
+      }
+      // bstart[k] = number of entries in bands above k; this wave's first slot in band k lies behind the lower waves' entries
+      {
+        int acc = 0;
+#pragma unroll
+        for (int k = DW_MAXG; k >= 1; --k) { bstart[k] = acc; acc += wave_cnt[k]; }
+        if (t < 2 * DW_LPB)                  // sentinels behind the last band (below everything: no term), see the pair loop
+          tile[acc + (int)t] = make_float4(0.0f, 0.0f, -__builtin_inff(), 0.0f);
+      }
+      int wbase[DW_MAXG + 1];
+#pragma unroll
+      for (int k = 1; k <= DW_MAXG; ++k) {
+        int below = 0;
+        if (k <= G)
+          for (int v = 0; v < NWV; ++v) below += v < w ? wcnt[v][k] : 0;
+        wbase[k] = bstart[k] + below;
       }
 #pragma unroll
       for (int q = 0; q < DW_ENT_PER_THREAD; ++q) {
         const int band = (int)((bands >> (4 * q)) & 15u);
-        if (band > 0) {
-          int start = 0;                                                               // bands above this one come first
-          for (int k = band + 1; k <= G; ++k) start += bcnt[k];
-          tile[start + atomicAdd(&bcur[band], 1)] = ent[q];
+#pragma unroll
+        for (int k = 1; k <= DW_MAXG; ++k) {
+          if (k > G) continue;
+          const unsigned long long m = __ballot(band == k);
+          if (band == k) tile[wbase[k] + (int)__popcll(m & ((1ULL << lane) - 1ULL))] = ent[q];
+          wbase[k] += (int)__popcll(m);
         }
       }
       __syncthreads();
@@ -1967,7 +2009,8 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
         const int g = rd * NW + ((rd & 1) ? NW - 1 - w : w);
         if (g >= G) continue;
         int lim = 0;                                                                   // end of band g + 1
-        for (int k = g + 1; k <= G; ++k) lim += bcnt[k];
+#pragma unroll
+        for (int k = 1; k <= DW_MAXG; ++k) lim += (k > g && k <= G) ? wave_cnt[k] : 0;
         const int r = g * DW_RPG + rg;
         const float4 me = recv[r];
         const int ty = rty[r];
