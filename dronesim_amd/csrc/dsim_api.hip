@@ -1902,7 +1902,8 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
         // shuffles did the same in 21 exchange stages — 250 instructions and 46 trips through the LDS crossbar, on one wave
         // while the other waits; the count is 25 receivers x 1.5 instructions. ----
         const bool real = (int)lane < cnt_c;
-        const float key = real ? mine.z : __builtin_inff();
+        // (a NaN height ranks as the highest finite one: every receiver keeps a slot of its own)
+        const float key = real ? (mine.z == mine.z ? mine.z : 3.402823466e38f) : __builtin_inff();
         skey[lane] = key;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
