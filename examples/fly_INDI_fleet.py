@@ -42,8 +42,13 @@ if __name__ == "__main__":
     START = time.time()
     k = 0
     if A.fused:
+        import torch
+        from dronesim_amd.fleet import frozen
+        # the hover targets never change: on the device once, and promised unchanged (fleet.frozen), so that every later
+        # set() copies nothing; only the yaw ramp — one constant per step — is filled
+        pos_dev = frozen(torch.from_numpy(np.ascontiguousarray(target_pos.T)).to(env.ctx.device))
         for i in range(0, int(A.duration_sec * env.SIM_FREQ), AGGR):
-            tgt.set(pos=target_pos.T, yaw=0.4 + k / 200.0)                  # TARGET_RPYS[wp], :165-167
+            tgt.set(pos=pos_dev, yaw=0.4 + k / 200.0)                       # TARGET_RPYS[wp], :165-167
             env.step_fused(tgt, control_timestep=CTRL_EVERY_N_STEPS * env.TIMESTEP,
                            action=np.full((n, 4), 0.4, dtype=np.float32) if k == 0 else None)   # :214
             k += 1
