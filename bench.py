@@ -361,7 +361,7 @@ def two_call_child(a):
     reduced to the entry the default line carries."""
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "two_call_loop", "--steps", str(max(50, a.steps // 2)),
            "--warmup", str(a.warmup), "--no-also", "--no-cpu-baseline", "--layout", a.layout, "--noise-seed", str(a.noise_seed),
-           "--stream", a.stream]
+           "--stream", a.stream] + (["--lib", a.lib] if a.lib else [])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     try:
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
