@@ -1764,9 +1764,9 @@ __device__ __forceinline__ float dw_pair_acc(float4 p, float x, float y, float z
 #define DW_NBR 25                      // (2 * 2 + 1)^2 cells at most
 #define DW_OVF_GROUPS 16
 // BAND (dense worlds): the term needs the candidate ABOVE the receiver, so half of all pairs are rejected on dz alone.
-// The cell's receivers are sorted by height (one wave, a bitonic network on shuffles) and taken in groups of
-// DW_RPG = 8; a candidate's band is the number of groups whose lowest receiver is below it, the tile is laid out by
-// band, highest first (counted and placed with LDS atomics while the entries wait in registers), and group g reads
+// The cell's receivers are ordered by height (one wave: every lane counts the receivers below its own) and taken in
+// groups of DW_RPG = 8; a candidate's band is the number of groups whose lowest receiver is below it, the tile is laid
+// out by band, highest first (counted and placed by ballots while the entries wait in registers), and group g reads
 // only the prefix that holds bands > g: the lowest group scans everything, the highest almost nothing.  The groups
 // are dealt to the waves in snake order so that both waves get the same work.  ~48 % fewer pair evaluations at
 // BASELINE config 5's density (25 receivers = 4 groups per cell).
