@@ -200,6 +200,7 @@ class CtrlAviary:
         self._use_last_action = True
         self._obs_buf = None      # [N, 16+n_act], allocated on the first observe()
         self._ground_trial = 0    # ground contacts counted by the placement trials of _obs_tensor (not Env.steps)
+        self._graph_made = False  # a captured hipGraph holds the state block's address: it is not moved any more
         self._adjacency = None    # grid for neighbors(), built on first use
         self._action_keep = None  # keeps a zero-copy action tensor alive while the launch that reads it is queued
         # chained fused stepping (DSIM_OPT_CHAINED): consecutive step_fused() calls skip the six
@@ -444,6 +445,7 @@ class CtrlAviary:
                 raise ValueError("graph capture with the neighbour-downwash term: not with the deferred fallback pass")
         # nothing may allocate under capture: the fallback queue of hexa fleets is reserved up front
         nat.check(self.ctx.lib.dsim_reserve(self.ctx.handle, self.ctx.stream_ptr(), self.state.n_pad))
+        self._graph_made = True
         return FusedGraph(self, targets, steps, control_timestep)
 
     def ground_contacts(self) -> int:
@@ -494,7 +496,27 @@ class CtrlAviary:
                     and self.n_act == 4 and self._downwash is None and self._phys_options == 0):
                 before = self.ctx.query(nat.QUERY_GROUND_CONTACTS)
                 echo = self._last_action.clone()          # the passes echo the (clipped) action buffer: put back below
-                self._obs_buf = placement.place_rows(self.ctx.device, shape, self._rows_trial, report=self.ctx.placement_log)
+                log = self.ctx.placement_log
+                self._obs_buf = placement.place_rows(self.ctx.device, shape, self._rows_trial, report=log)
+                if log and log[-1]["chosen_pass_us"] > 0.95 * log[-1]["first_pass_us"] and not self._graph_made:
+                    # Every candidate timed alike.  Either all of them are good — or the STATE block itself lies across two
+                    # regions of device memory (one process in ten), and then no place for the rows is.  One more try with
+                    # the state in a fresh allocation (same contents: the passes change nothing); the better pair stays.
+                    rows1, state1, best1 = self._obs_buf, self.state.data, log[-1]["chosen_pass_us"]
+                    self._obs_buf = None
+                    torch.cuda.empty_cache()
+                    self.state.data = torch.empty_like(state1)
+                    self.state.data.copy_(state1)
+                    self._fused_plan = self._fused_plan_dw = None
+                    rows2 = placement.place_rows(self.ctx.device, shape, self._rows_trial, report=log)
+                    log[-1]["state_block"] = "moved to a fresh allocation"
+                    if log[-1]["chosen_pass_us"] < 0.95 * best1:
+                        self._obs_buf = rows2
+                    else:
+                        self.state.data, self._obs_buf = state1, rows1
+                        log[-1]["state_block"] = "a fresh allocation was no better: kept where it was"
+                    del rows1, rows2, state1
+                    torch.cuda.empty_cache()
                 self._last_action.copy_(echo)
                 # (a drone that sits on the ground is counted by every pass, also by these: not Env.steps)
                 self._ground_trial += self.ctx.query(nat.QUERY_GROUND_CONTACTS) - before

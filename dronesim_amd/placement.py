@@ -15,7 +15,9 @@ same memory streams — the state is read and written back bit for bit, the acti
 written — and changes nothing.  `place_rows` allocates candidates for the rows one after the other, holding them all so that
 the walk moves through device memory (up to 24 GiB, transient), times three such passes on each, stops at the first that
 is clearly faster than the first one (or clearly slower: then the first one was right), keeps it and releases the rest.
-Only for fleets whose rows are at least `MIN_BYTES`: smaller fleets are bound by launch latency, not by HBM.
+When every candidate times alike the state block itself may lie across two regions (one process in ten): CtrlAviary then
+moves it to a fresh allocation (same contents) and walks once more, keeping the better pair.  Only for fleets whose rows
+are at least `MIN_BYTES`: smaller fleets are bound by launch latency, not by HBM.
 
 The same holds for what computeControl WRITES beside the state block whose controller memory it updates (command, position
 error, yaw error: 32 bytes per drone; `tools/placement_probe_ctrl.py`: 144.7 us as allocated, 136 us with the outputs
