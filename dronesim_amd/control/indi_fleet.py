@@ -111,6 +111,14 @@ class INDIControl(BaseControl):
         if not (self.ctx.placement and self._type_id is None and self.ctx.n_act == 4 and 4 * 8 * n_pad >= placement.MIN_BYTES
                 and type(self) is INDIControl):
             return
+        tail = getattr(self.env, "_written_tail", None) if self.env is not None else None
+        if tail is not None and tuple(tail.shape) == (8, n_pad):
+            # the env has placed its observation rows and left room behind them: the same allocation suits these arrays
+            tail.zero_()
+            self._cmd, self._pos_e, self._yaw_e = tail[0:4], tail[4:7], tail[7]
+            self.ctx.placement_log.append({"array": "computeControl outputs", "bytes": 4 * tail.numel(),
+                                           "placed": "behind the env's observation rows (one allocation, one search)"})
+            return
         snap = st.data.clone()
         view, tview, ref = st.view(), self._targets.view(), ctypes.byref(a)
         lib, h = self.ctx.lib, self.ctx.handle

@@ -201,6 +201,7 @@ class CtrlAviary:
         self._obs_buf = None      # [N, 16+n_act], allocated on the first observe()
         self._ground_trial = 0    # ground contacts counted by the placement trials of _obs_tensor (not Env.steps)
         self._graph_made = False  # a captured hipGraph holds the state block's address: it is not moved any more
+        self._written_tail = None  # [8, n_pad] behind the placed observation rows: a bound controller's outputs go there
         self._adjacency = None    # grid for neighbors(), built on first use
         self._action_keep = None  # keeps a zero-copy action tensor alive while the launch that reads it is queued
         # chained fused stepping (DSIM_OPT_CHAINED): consecutive step_fused() calls skip the six
@@ -497,25 +498,33 @@ class CtrlAviary:
                 before = self.ctx.query(nat.QUERY_GROUND_CONTACTS)
                 echo = self._last_action.clone()          # the passes echo the (clipped) action buffer: put back below
                 log = self.ctx.placement_log
-                self._obs_buf = placement.place_rows(self.ctx.device, shape, self._rows_trial, report=log)
-                if log and log[-1]["chosen_pass_us"] > 0.95 * log[-1]["first_pass_us"] and not self._graph_made:
+                # (one allocation for everything that is written beside the state block: the rows, and behind them the
+                # 8 x n_pad floats a bound INDIControl writes — command, position error, yaw error; what suits the one
+                # suits the other, and the controller need not search)
+                n_rows, n_tail = shape[0] * shape[1], 8 * self.state.n_pad
+                flat = (n_rows + n_tail,)
+
+                def split(block):
+                    self._obs_buf, self._written_tail = block[:n_rows].view(shape), block[n_rows:].view(8, self.state.n_pad)
+                split(placement.place_rows(self.ctx.device, flat, self._rows_trial, report=log))
+                if log and log[-1]["decided_by"] == "all alike" and not self._graph_made:
                     # Every candidate timed alike.  Either all of them are good — or the STATE block itself lies across two
                     # regions of device memory (one process in ten), and then no place for the rows is.  One more try with
                     # the state in a fresh allocation (same contents: the passes change nothing); the better pair stays.
-                    rows1, state1, best1 = self._obs_buf, self.state.data, log[-1]["chosen_pass_us"]
-                    self._obs_buf = None
+                    rows1, tail1, state1, best1 = self._obs_buf, self._written_tail, self.state.data, log[-1]["chosen_pass_us"]
+                    self._obs_buf = self._written_tail = None
                     torch.cuda.empty_cache()
                     self.state.data = torch.empty_like(state1)
                     self.state.data.copy_(state1)
                     self._fused_plan = self._fused_plan_dw = None
-                    rows2 = placement.place_rows(self.ctx.device, shape, self._rows_trial, report=log)
+                    block2 = placement.place_rows(self.ctx.device, flat, self._rows_trial, report=log)
                     log[-1]["state_block"] = "moved to a fresh allocation"
                     if log[-1]["chosen_pass_us"] < 0.95 * best1:
-                        self._obs_buf = rows2
+                        split(block2)
                     else:
-                        self.state.data, self._obs_buf = state1, rows1
+                        self.state.data, self._obs_buf, self._written_tail = state1, rows1, tail1
                         log[-1]["state_block"] = "a fresh allocation was no better: kept where it was"
-                    del rows1, rows2, state1
+                    del rows1, tail1, block2, state1
                     torch.cuda.empty_cache()
                 self._last_action.copy_(echo)
                 # (a drone that sits on the ground is counted by every pass, also by these: not Env.steps)

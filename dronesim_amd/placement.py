@@ -21,8 +21,9 @@ are at least `MIN_BYTES`: smaller fleets are bound by launch latency, not by HBM
 
 The same holds for what computeControl WRITES beside the state block whose controller memory it updates (command, position
 error, yaw error: 32 bytes per drone; `tools/placement_probe_ctrl.py`: 144.7 us as allocated, 136 us with the outputs
-elsewhere, the targets — which are only read — indifferent).  That launch has no neutral form, so INDIControl takes a
-snapshot of the state block, times real passes on the candidates and puts the snapshot back.
+elsewhere, the targets — which are only read — indifferent).  A controller bound to an env takes the 8 x n_pad floats the env
+left behind its placed rows (one allocation, one search); one without an env searches for itself: that launch has no
+neutral form, so it takes a snapshot of the state block, times real passes on the candidates and puts the snapshot back.
 """
 from __future__ import annotations
 
@@ -58,7 +59,7 @@ def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int
     for d in shape:
         nbytes *= int(d)
     cands, times = [], []
-    chosen = None
+    chosen, decided = None, ""
     torch.cuda.empty_cache()                  # candidates from whole device blocks, not from pieces the allocator has cached
     while chosen is None and (len(cands) + 1) * nbytes <= max(walk_bytes, 2 * nbytes):
         try:
@@ -68,16 +69,16 @@ def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int
         cands.append(c)
         times.append((timer or _event_timer)(trial, c, passes))
         if times[-1] < CLEARLY * times[0]:
-            chosen = len(times) - 1
+            chosen, decided = len(times) - 1, "a candidate clearly faster than the first"
         elif times[0] < CLEARLY * times[-1]:
-            chosen = 0
+            chosen, decided = 0, "a candidate clearly slower than the first"
     if chosen is None:
-        chosen = min(range(len(times)), key=times.__getitem__)
+        chosen, decided = min(range(len(times)), key=times.__getitem__), "all alike"
     keep = cands[chosen]
     if report is not None:
         shown = times if len(times) <= 12 else times[:4] + times[-4:]
         report.append({"array": label, "bytes": nbytes, "candidates": len(cands), "chosen": chosen,
-                       "chosen_pass_us": round(times[chosen], 1), "first_pass_us": round(times[0], 1),
+                       "decided_by": decided, "chosen_pass_us": round(times[chosen], 1), "first_pass_us": round(times[0], 1),
                        "pass_us" if len(times) <= 12 else "pass_us_first4_last4": [round(t, 1) for t in shown]})
     c = None
     del cands

@@ -724,7 +724,7 @@ def test_state_block_is_tried_elsewhere_when_every_candidate_for_the_rows_times_
         out = real(device, shape, trial, **kw)
         calls.append(len(calls))
         if len(calls) == 1 and kw.get("report"):
-            kw["report"][-1]["chosen_pass_us"] = kw["report"][-1]["first_pass_us"]
+            kw["report"][-1]["decided_by"] = "all alike"
         return out
     monkeypatch.setattr(placement, "place_rows", flat_first)
     envs = [CtrlAviary(["robobee"], nd, initial_xyzs=xyz, aggregate_phy_steps=1, noise_seed=9, dict_io=False, placement=p)
@@ -739,6 +739,7 @@ def test_state_block_is_tried_elsewhere_when_every_candidate_for_the_rows_times_
     log = envs[0].ctx.placement_log
     assert len(calls) == 2 and len(log) == 2 and "state_block" in log[1] and not envs[1].moved
     assert envs[0].moved == (log[1]["state_block"] == "moved to a fresh allocation")
+    assert envs[0]._written_tail.shape == (8, envs[0].state.n_pad) and envs[1]._written_tail is None
     assert torch.equal(envs[0].state.data, envs[1].state.data) and torch.equal(obs[0], obs[1])
     assert envs[0].ground_contacts() == envs[1].ground_contacts()
     for e in envs:
