@@ -275,6 +275,7 @@ class Targets(BlockedSoA):
             self.order, self.pre_access, self.version = None, None, 0
         else:
             super().__init__(n, nat.NT, ctx.device, layout, pad, order=ctx.order)
+            self._placed = False      # CtrlAviary.step_fused may re-allocate `data` once, by trial (placement.py)
 
     def view(self) -> nat.View:
         if not self.broadcast:

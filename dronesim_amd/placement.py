@@ -49,12 +49,14 @@ def _event_timer(trial, c, passes: int) -> float:
 
 
 def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int = 3, report: Optional[list] = None,
-               label: str = "observation rows", walk_bytes: int = WALK_BYTES, timer=None) -> torch.Tensor:
+               label: str = "observation rows", walk_bytes: int = WALK_BYTES, timer=None,
+               clearly: float = CLEARLY) -> torch.Tensor:
     """A zeroed fp32 array of `shape`.  `trial(array)` enqueues ONE pass of the real kernel writing its output to `array`
     (Env.step: a zero-sub-step pass; computeControl: a real pass, the caller restores the state afterwards).  Candidates
     are allocated one after the other and all held, so that the walk moves through device memory; each is timed over
     `passes` passes behind one untimed pass; the walk ends as soon as one candidate is clearly faster than the first (it
-    is kept) or clearly slower (the first is kept), or when `walk_bytes` are held (the fastest is kept).  `timer(trial, candidate, passes)`: the clock (tests)."""
+    is kept) or clearly slower (the first is kept), or when `walk_bytes` are held (the fastest is kept).  `timer(trial, candidate, passes)`: the clock (tests).
+    `clearly`: the ratio that counts as clear (arrays READ beside the state block are only 3-4 % apart: 0.975)."""
     nbytes = 4
     for d in shape:
         nbytes *= int(d)
@@ -68,9 +70,9 @@ def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int
             break
         cands.append(c)
         times.append((timer or _event_timer)(trial, c, passes))
-        if times[-1] < CLEARLY * times[0]:
+        if times[-1] < clearly * times[0]:
             chosen, decided = len(times) - 1, "a candidate clearly faster than the first"
-        elif times[0] < CLEARLY * times[-1]:
+        elif times[0] < clearly * times[-1]:
             chosen, decided = 0, "a candidate clearly slower than the first"
     if chosen is None:
         chosen, decided = min(range(len(times)), key=times.__getitem__), "all alike"

@@ -670,7 +670,9 @@ def test_observation_rows_are_placed_by_timing_zero_substep_passes(gpu):
     obs = []
     for e in envs:
         t = Targets(e.ctx, nd, e.state.layout); t.set(pos=f32(xyz + 0.1).T, yaw=0.3)
-        e.step_fused(t, action=np.full((nd, 4), 0.4, dtype=np.float32))
+        tg_before = t.data.clone()
+        e.step_fused(t, action=np.full((nd, 4), 0.4, dtype=np.float32))      # (placement=True: the targets are placed by trial first)
+        assert torch.equal(t.data, tg_before)
         before = e.state.data.view(torch.int32).clone()
         la = e._last_action.clone()
         gc0 = e.ground_contacts()
@@ -680,8 +682,9 @@ def test_observation_rows_are_placed_by_timing_zero_substep_passes(gpu):
         o, _, _, _ = e.step(np.full((nd, 4), 0.5, dtype=np.float32))
         obs.append(o.obs if hasattr(o, "obs") else o)
     log = envs[0].ctx.placement_log
-    assert [r["array"] for r in log] in (["observation rows"], ["observation rows"] * 2)      # (twice: every candidate timed alike and
-    for r in log:                                                                                #  the state block was tried elsewhere)
+    arrays = [r["array"] for r in log]
+    assert arrays[0] == "per-drone targets" and arrays[1:] in (["observation rows"], ["observation rows"] * 2)   # (twice: every candidate
+    for r in log:                                                                 #  timed alike and the state block was tried elsewhere)
         assert 2 <= r["candidates"] and 0 <= r["chosen"] < r["candidates"] and 0 < r["chosen_pass_us"] <= r["first_pass_us"]
     assert envs[1].ctx.placement_log == []
     assert torch.equal(envs[0].state.data, envs[1].state.data) and torch.equal(obs[0], obs[1])
@@ -699,7 +702,7 @@ def test_observation_rows_are_placed_by_timing_zero_substep_passes(gpu):
             e.step(cmd)
             cmd, pos_e, yaw_e = ctrl.computeControlFromState(1 / 240, None, target_pos=tp, target_rpy=np.array([0.0, 0.0, 0.3]))
         res.append((cmd.clone(), pos_e.clone(), yaw_e.clone()))
-    assert [r["array"] for r in envs[0].ctx.placement_log if r["array"] != "observation rows"] == ["computeControl outputs"]
+    assert [r["array"] for r in envs[0].ctx.placement_log if r["array"] != "observation rows"] == ["per-drone targets", "computeControl outputs"]
     assert envs[1].ctx.placement_log == []
     assert torch.equal(envs[0].state.data, envs[1].state.data)
     for x, y in zip(res[0], res[1]):
