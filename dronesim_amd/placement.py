@@ -21,7 +21,9 @@ are at least `MIN_BYTES`: smaller fleets are bound by launch latency, not by HBM
 
 The same holds for what computeControl WRITES beside the state block whose controller memory it updates (command, position
 error, yaw error: 32 bytes per drone; `tools/placement_probe_ctrl.py`: 144.7 us as allocated, 136 us with the outputs
-elsewhere, the targets — which are only read — indifferent).  A controller bound to an env takes the 8 x n_pad floats the env
+elsewhere, the targets — which are only read — indifferent).  The per-drone targets of the fused step are READ beside the state (same region
+wanted): CtrlAviary.step_fused places them by real passes behind a snapshot of the state block too (8 GiB walk; the first
+candidate, right behind the state, is the good one five times in six).  A controller bound to an env takes the 8 x n_pad floats the env
 left behind its placed rows (one allocation, one search); one without an env searches for itself: that launch has no
 neutral form, so it takes a snapshot of the state block, times real passes on the candidates and puts the snapshot back.
 """
