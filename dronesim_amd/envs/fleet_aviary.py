@@ -563,7 +563,7 @@ class CtrlAviary:
             tview.base = c.data_ptr()
             nat.check(self.ctx.lib.dsim_step(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, sview, tview, ref))
         keep = placement.place_rows(self.ctx.device, tuple(old.shape), trial, report=self.ctx.placement_log,
-                                    label="per-drone targets", clearly=0.975, walk_bytes=8 << 30)
+                                    label="per-drone targets", clearly=0.0, walk_bytes=4 << 30)
         keep.copy_(old)
         targets.data = keep
         self.state.data.copy_(snap)
