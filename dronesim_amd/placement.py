@@ -1,4 +1,4 @@
-"""Where the observation rows of a large fleet lie in HBM relative to its state block.
+"""Where the arrays a large fleet streams beside its state block lie in HBM.
 
 Measured on MI355X (tools/membench.hip --bigsweep / --pairs / --regions, tools/placement_probe.py, tools/arena_probe.py;
 profiles/r03_placement_*.txt): the Env.step launch of a 4 194 304-drone fleet (k_physics_fast: state
@@ -21,11 +21,17 @@ are at least `MIN_BYTES`: smaller fleets are bound by launch latency, not by HBM
 
 The same holds for what computeControl WRITES beside the state block whose controller memory it updates (command, position
 error, yaw error: 32 bytes per drone; `tools/placement_probe_ctrl.py`: 144.7 us as allocated, 136 us with the outputs
-elsewhere, the targets — which are only read — indifferent).  The per-drone targets of the fused step are READ beside the state (same region
-wanted): CtrlAviary.step_fused places them by real passes behind a snapshot of the state block too (8 GiB walk; the first
-candidate, right behind the state, is the good one five times in six).  A controller bound to an env takes the 8 x n_pad floats the env
-left behind its placed rows (one allocation, one search); one without an env searches for itself: that launch has no
-neutral form, so it takes a snapshot of the state block, times real passes on the candidates and puts the snapshot back.
+elsewhere).  A controller bound to an env takes the 8 x n_pad floats the env left behind its placed rows (one allocation,
+one search); one without an env searches for itself: that launch has no neutral form, so it takes a snapshot of the state
+block, times real passes on the candidates and puts the snapshot back.
+
+The per-drone targets of the fused step are READ beside the state, and there the SAME region is the good case: 154, 158 or
+164 us per launch by where they lie (tools/state_probe.py), and the first candidate — right behind the state — may be the
+middle one.  CtrlAviary.step_fused places them at its first call: real passes behind a snapshot of the state block on every
+candidate of a 4 GiB walk (25 of them, no early end), the fastest kept.  One box of the round gave 155 / 158 / 164 us from
+process to process without it and 154.1-154.8 us in six of six with it (profiles/r03_repeat_headline_8_processes.txt).
+
+The search can only FIND a place: on one box of the round no candidate for the rows within 16 GiB was a good one.
 """
 from __future__ import annotations
 
