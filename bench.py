@@ -75,6 +75,9 @@ def parse(argv=None):
     p.add_argument("--mirror-peer", action="store_true",
                    help="config5 on ONE rank with a synthetic mirrored neighbour (MirrorDist): traces the device-paced exchange path")
     p.add_argument("--replicas", type=int, default=0, help="override the number of vectorised env replicas (A/B runs)")
+    p.add_argument("--two-call-kind", default="quad", choices=["quad", "hexa", "mixed", "config5"],
+                   help="--workload two_call_loop: the fleet the reference-shaped loop runs on (4 194 304 quads / morphing hexas / "
+                        "interleaved quads + hexas; or the 65 536-drone config-5 shard with the downwash term)")
     p.add_argument("--dry-run", action="store_true",
                    help="host logic only (launcher, rendezvous, reductions, the JSON line); no device work — CPU tests")
     return p.parse_args(argv)
@@ -174,9 +177,9 @@ class Fleet:
         from dronesim_amd.control import INDIControl
         from dronesim_amd.fleet import frozen
         torch = self.torch
-        ctrl = INDIControl("robobee", env=self.env)
+        ctrl = INDIControl(self.env.types[-1].name, env=self.env)     # one controller object for the whole fleet, whatever its types
         tpos = frozen(self.tgt.fields(0, 3).contiguous())      # the same hover target every iteration: copied once
-        state = {"cmd": torch.full((self.n, 4), 0.4, device=self.env.ctx.device)}
+        state = {"cmd": torch.full((self.n, self.env.n_act), 0.4, device=self.env.ctx.device)}
         yaw = np.array([0, 0, 0.4])
 
         def one():
@@ -356,10 +359,11 @@ def memory_yardstick(n_drones):
         return {"device_copy_GBps": None, "yardstick_error": repr(e)[:200]}
 
 
-def two_call_child(a):
-    """`bench.py --workload two_call_loop` as a child process (this one keeps its fleets but is idle meanwhile): its line,
-    reduced to the entry the default line carries."""
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "two_call_loop", "--steps", str(max(50, a.steps // 2)),
+def two_call_child(a, kind="quad"):
+    """`bench.py --workload two_call_loop --two-call-kind KIND` as a child process (this one keeps its fleets but is idle
+    meanwhile): its line, reduced to the entry the default line carries."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "two_call_loop", "--two-call-kind", kind,
+           "--steps", str(max(50, a.steps // 2)),
            "--warmup", str(a.warmup), "--no-also", "--no-cpu-baseline", "--layout", a.layout, "--noise-seed", str(a.noise_seed),
            "--stream", a.stream] + (["--lib", a.lib] if a.lib else [])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
@@ -367,11 +371,11 @@ def two_call_child(a):
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
         d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
         return {"drone_steps_per_s": d["value"], "loop_us": d["ms_per_step"] * 1e3, "steps_timed": d["steps_timed"],
-                "loop_us_device": d["roofline"]["launch_us"], "bytes_per_drone_step": 428, "hbm_frac": d["roofline"]["frac"],
-                "measured_in": "a child process running `bench.py --workload two_call_loop` alone",
-                "note": "physics 68 r + 148 w (13 rigid, 4 action | 13 rigid, 4 echo, 20-wide observation row); "
-                        "control 136 r + 76 w (13 + 11 + 10 | 11 memory, 4 cmd, 3 pos_e, yaw_e)",
-                "placement": d.get("placement")}
+                "drones": d["config"]["drones_per_gpu"], "loop_us_device": d["roofline"]["launch_us"],
+                "bytes_per_drone_step": TWO_CALL_BYTES[kind][0], "hbm_frac": d["roofline"]["frac"],
+                "kernel": d["roofline"]["kernel"],
+                "measured_in": f"a child process running `bench.py --workload two_call_loop --two-call-kind {kind}` alone",
+                "note": TWO_CALL_BYTES[kind][1], "placement": d.get("placement")}
     except Exception as e:          # an extra must not cost the headline
         return {"error": repr(e)[:300]}
 
@@ -473,6 +477,18 @@ class Watchdog:
         return False
 
 
+# the reference-shaped loop: algorithmic bytes per drone and loop iteration, and what they are
+#   Env.step      reads 13 rigid + n_act action floats; writes 13 rigid + the echoed action + the (16 + table n_act)-wide row
+#   computeControl reads 13 rigid + (7 + n_act) controller memory + 10 targets; writes the memory, the command, pos_e, yaw_e
+TWO_CALL_BYTES = {
+    "quad": (428, "physics 68 r + 148 w (13 rigid, 4 action | 13 rigid, 4 echo, 20-wide row); control 136 r + 76 w "
+                  "(13 + 11 + 10 | 11 memory, 4 cmd, 3 pos_e, yaw_e)"),
+    "hexa": (476, "physics 76 r + 164 w (13 rigid, 6 action | 13 rigid, 6 echo, 22-wide row); control 144 r + 92 w "
+                  "(13 + 13 + 10 | 13 memory, 6 cmd, 3 pos_e, yaw_e)"),
+    "mixed": (468, "average of a quad (68 r + 164 w; 136 r + 84 w: rows and command arrays are those of a six-actuator "
+                   "table) and a hexa (476), + 4 B for the caller's drone number"),
+    "config5": (480, "as mixed, + 12 B for the downwash force the Env.step launch reads"),
+}
 WORKLOAD_TEXT = {
     "config2x1024": "configs[1] 4096 robobee INDI hover x 1024 vectorised envs/GPU",
     "config2": "configs[1] 4096 robobee INDI hover (single fleet)",
@@ -573,16 +589,19 @@ def main(argv=None):
     n_fleet, replicas = {"config2x1024": (4096, 1024), "config2": (4096, 1), "config3": (65536, 1), "config4": (4096, 16),
                          "config5": (65536, 1), "hexa": (4096, 1024), "mixed": (4096, 1024),
                          "mixed_type_major": (4096, 1024), "two_call_loop": (4096, 1024)}[a.workload]
+    tck = a.two_call_kind if a.workload == "two_call_loop" else None
+    if tck == "config5":
+        n_fleet, replicas = 65536, 1
     if a.replicas > 0:
         replicas = a.replicas
     from dronesim_amd import sharding
     # weak scaling: every rank owns a same-sized contiguous shard of the N-GPU fleet; no data-path collective
     # (config5 only: one halo exchange of positions per step for the neighbour-downwash term)
     fl = Fleet(n_fleet, replicas, local, a.substeps, a.layout, sharding.rank_seed(a.noise_seed, rank),
-               waypoints=a.workload == "config3", config5=a.workload == "config5",
+               waypoints=a.workload == "config3", config5=a.workload == "config5" or tck == "config5",
                dist=(MirrorDist(a.slab_m) if (a.mirror_peer and world == 1) else dist) if a.workload == "config5" else None,
-               rank=rank, hexa=a.workload == "hexa",
-               mixed=("type_major" if a.workload == "mixed_type_major" else a.workload == "mixed"), options=options,
+               rank=rank, hexa=a.workload == "hexa" or tck == "hexa",
+               mixed=("type_major" if a.workload == "mixed_type_major" else (a.workload == "mixed" or tck == "mixed")), options=options,
                slab_m=a.slab_m)
     if a.workload == "two_call_loop":
         fl.make_two_call_loop()
@@ -600,7 +619,7 @@ def main(argv=None):
     # config 5: half quads (232 B) half hexas (248 B) + 1 B type id + the 12 B downwash force the step kernel reads;
     # its step is a chain of kernels (neighbour query, step + grid binning, WLS fallback), timed as a whole
     bytes_per = {"config5": 253, "hexa": 248, "mixed": 241, "mixed_type_major": 241,
-                 "two_call_loop": 428}.get(a.workload, BYTES_PER_DRONE_STEP)
+                 "two_call_loop": TWO_CALL_BYTES[a.two_call_kind][0]}.get(a.workload, BYTES_PER_DRONE_STEP)
     mixed_k = ("k_step_lean" if a.generic_mixed else "k_step_mixed" if a.mixed_v1 else "k_step_mixed2" if a.mixed_ring
                else "k_step_mixed3" if (a.mixed_v3 or a.layout != "tile64") else "k_step_mixed4")
     if fl.env.order is not None:
@@ -611,7 +630,9 @@ def main(argv=None):
               "hexa": "k_step_hexa (+ k_wls_fallback)",
               "mixed": f"{mixed_k} (+ k_wls_fallback)",
               "mixed_type_major": "k_step_run x2 (+ k_wls_fallback)",
-              "two_call_loop": "k_physics_fast (observation fused) + k_control_fast"}.get(a.workload, "k_step_fast")
+              "two_call_loop": ("k_physics_fast (observation fused) + k_control_fast" if tck == "quad" else
+                                ("k_dw_query_cell, " if tck == "config5" else "") +
+                                "k_physics_runs (observation fused) + k_control_runs (+ k_wls_fallback)")}.get(a.workload, "k_step_fast")
     achieved = fl.n * bytes_per / launch_s / 1e9
     rank_rows = gather_ranks(dist, red_dev, [dev_s_local / steps_timed * 1e6, wall_local / steps_timed * 1e6])
     exchange = exchange_report(fl, dist, red_dev) if (a.workload == "config5" and (world > 1 or a.mirror_peer)) else None
@@ -726,6 +747,15 @@ def main(argv=None):
             # process — dozens of fleets built and dropped — every fresh allocation is pieced together from fragments of
             # many regions, which a process that runs the loop from its start never sees.
             also["config2x1024_env_step_then_computeControl"] = two_call_child(a)
+            # the same loop on the other fleet kinds (examples/fly_hexa_6DOF.py:214-221; BASELINE config 5's composition):
+            # Env.step and computeControl on the run kernels, rows / command / errors in the caller's numbering straight from
+            # the launches
+            also["hexa_env_step_then_computeControl"] = two_call_child(a, "hexa")
+            also["mixed_interleaved_env_step_then_computeControl"] = two_call_child(a, "mixed")
+            also["config5_shard_two_call"] = two_call_child(a, "config5")
+            if isinstance(also.get("config5_shard_65536_mixed_downwash"), dict) and "loop_us_device" in also["config5_shard_two_call"]:
+                also["config5_shard_two_call"]["ratio_to_fused_chain"] = (
+                    also["config5_shard_two_call"]["loop_us_device"] / also["config5_shard_65536_mixed_downwash"]["launch_us"])
             out["also"] = also
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.substeps)

@@ -34,6 +34,7 @@ TUNING_MASK = (OPT_STREAM_ON | OPT_STREAM_OFF | OPT_GENERIC_MIXED | OPT_MIXED_V1
 OPT_PLANE = 1 << 10        # ground-plane contact (product-defined model, oracle/dsim_oracle.c:orc_plane_contact)
 OPT_DEFER_FALLBACK = 1 << 11   # the caller launches dsim_wls_fallback itself (scheduling only)
 OPT_RUNS_ONE_LAUNCH, OPT_RUNS_SEPARATE = 1 << 12, 1 << 13     # tuning knobs of type-major storage
+OPT_CALLER_IO = 1 << 14    # dsim_physics / dsim_control2: action, rows, command, errors indexed by drone_id[i] (the caller's numbering)
 ADAPT_VELOCITY, ADAPT_RPYT = 0, 1
 QUERY_WLS_FALLBACKS, QUERY_WLS_FAILURES, QUERY_GROUND_CONTACTS, QUERY_HALO_OVERFLOW = 0, 1, 2, 3
 

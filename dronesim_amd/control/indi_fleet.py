@@ -99,8 +99,22 @@ class INDIControl(BaseControl):
         super().reset()
         st = self.state
         st.set_fields(13, torch.zeros((6, st.n), device=self.ctx.device))
+        tid = getattr(self.env, "type_ids_caller", None) if self.env is not None else None
+        if tid is not None and len(self.env.types) > 1:
+            # a heterogeneous fleet (one controller object for the whole of it): every drone gets the reset values of ITS
+            # type's controller class (INDIControl.py:127-129 / INDIControl_6DOF.py:232-234)
+            types = self.env.types
+            thrust = np.array([t.reset_thrust for t in types], dtype=np.float32)[tid]
+            cmd = np.zeros((st.n_fields - 20, st.n), dtype=np.float32)
+            for k, t in enumerate(types):
+                cmd[: t.n_act, tid == k] = t.reset_cmd
+            st.set_fields(19, torch.from_numpy(thrust).reshape(1, -1))
+            st.set_fields(20, torch.from_numpy(cmd))
+            return
         st.set_fields(19, torch.full((1, st.n), self.type.reset_thrust, device=self.ctx.device))
-        st.set_fields(20, torch.full((st.n_fields - 20, st.n), self.type.reset_cmd, device=self.ctx.device))
+        cmd = torch.zeros((st.n_fields - 20, st.n), device=self.ctx.device)
+        cmd[: self.type.n_act] = self.type.reset_cmd
+        st.set_fields(20, cmd)
 
     def _place_outputs(self, a) -> None:
         """Large homogeneous quad fleets: where the arrays this launch WRITES (command, position error, yaw error) lie
@@ -142,7 +156,7 @@ class INDIControl(BaseControl):
         if self.env is not None:
             # the controller memory it is about to differentiate against must be the stored one: a chained
             # step_fused() sequence leaves last_vel / last_rates stale until materialized
-            self.env.materialize()
+            self.env.materialize()          # (also joins a deferred WLS fallback pass: this launch reads the commands)
             self.env._chain_ok = False
         if cur_pos is not None:                       # explicit state (stand-alone use)
             st.set_fields(0, _as3(cur_pos, n, dev))
@@ -170,6 +184,13 @@ class INDIControl(BaseControl):
         a.noise_replay, a.action = None, None
         a.type_id = self._type_id.data_ptr() if self._type_id is not None else None
         a.options = getattr(self.env, "_tuning", 0)
+        runs = getattr(self.env, "_runs", None) if self.env is not None else None
+        if runs is not None:        # a fleet stored as runs of one type: the single-type bodies (k_control_runs)
+            a.runs, a.n_runs = ctypes.addressof(runs), len(runs)
+        caller_io = bool(getattr(self.env, "_caller_io", False)) if self.env is not None else False
+        if caller_io:               # the triple comes back in the caller's numbering straight from the launch
+            a.options |= nat.OPT_CALLER_IO
+            a.drone_id = st.order.drone_id(st.n_pad).data_ptr()
         if not self._outputs_placed:
             self._outputs_placed = True
             self._place_outputs(a)
@@ -177,7 +198,7 @@ class INDIControl(BaseControl):
                                              self._targets.view(), ctypes.byref(a), self._pos_e.data_ptr(),
                                              self._yaw_e.data_ptr(), self._cmd.data_ptr()))
         order = st.order
-        if order is None:
+        if order is None or caller_io:
             return self._cmd[:, :n].T, self._pos_e[:, :n].T, self._yaw_e[:n]
         # a fleet stored in another order than the caller's: the triple goes back in the caller's numbering; the env
         # recognises the command tensor when it comes back as the next action and takes the storage-order array as is

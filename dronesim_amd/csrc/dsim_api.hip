@@ -27,6 +27,9 @@
 #ifndef DSIM_GEN_WAVES
 #define DSIM_GEN_WAVES 2
 #endif
+#ifndef DSIM_IO_ROWS_NT
+#define DSIM_IO_ROWS_NT 0      // rows scattered to the caller's numbering: streaming hint or not
+#endif
 
 struct dsim_ctx {
   int device;
@@ -51,6 +54,10 @@ struct dsim_ctx {
   const int32_t* dwh_ws;                  // ... and the workspace / shape it was zeroed for
   long long dwh_cells;
   unsigned* d_bounds;                     // dsim_fleet_bounds: 5 order-preserving keys + a ticket
+  int* d_block_map;                       // RunTab.block_map of the last side-by-side launch (DSIM_OPT_CALLER_IO), and what it was made for
+  int* h_block_map;
+  int block_map_cap, block_map_blocks, block_map_runs;
+  dsim_type_run block_map_key[DSIM_MAX_TYPES];
   dsim_type_params h_types[DSIM_MAX_TYPES];
 };
 
@@ -142,7 +149,8 @@ struct StepK {
   float* pos_e_out;           // control kernel only
   float* yaw_e_out;
   float* cmd_out;             // control kernel only: SoA [n_act][n_pad] copy of the new command, or null
-  float* obs_out;             // physics kernel: fused observation rows [n][obs_width], or null
+  float* obs_out;             // physics kernel: fused observation rows [n][obs_w], or null
+  int obs_w;                  // 16 + the table's largest actuator count: width of an observation row / rows of echo, cmd_out
   long long n;                // drones (rows of obs_out)
   FbList fb;                  // deferred WLS fallbacks (hexa)
   long long n_pad;
@@ -160,6 +168,7 @@ struct StepK {
   long long lo, last;         // run kernels: first drone of the run (the launch starts at the tile that holds it), one past its last
   int run_type;               // run kernels: the run's type
   const int* drone_id;        // the caller's index of storage slot i (keys the noise counter), or null = i
+  const int* io_id;           // DSIM_OPT_CALLER_IO: = drone_id, the per-drone arrays beside the state are indexed by it; else null
   unsigned hexa_types;        // bit t set: type t of the table is a morphing hexa (26 state fields in use)
   BinK bin;                   // grid of the next Env.step's downwash (k_step_mixed / k_step_run), count = null: none
 };
@@ -1143,7 +1152,9 @@ __global__ __launch_bounds__(128, S1 ? 4 : 3) void k_step_mixed4(StepK a) {
 
 // Type-major storage (dsim_step_args.runs): a run of one type is stepped by the single-type law of its kind,
 // the fast form (no partition, no waterfall, per-type constants in SGPRs); ext = optional downwash force.
-template <bool HEXA, bool NOISE, bool NT, bool S1>
+// ACT: an explicit action for the physics part (dsim_step_args.action: the first iteration of the example loop), clipped as
+// CtrlAviary._preprocessAction does; the controller memory keeps its own cmd (k_step_runs only: a template flag, as in k_step_fast)
+template <bool HEXA, bool NOISE, bool NT, bool S1, bool ACT = false>
 __device__ __forceinline__ void run_body(const StepK& a, long long i0, long long lo, long long last, int run_type) {
   const long long i = i0 + threadIdx.x;
   if (i >= last || i < lo) return;          // (a run may begin and end inside a tile: the neighbouring run's lanes take the rest)
@@ -1166,11 +1177,14 @@ __device__ __forceinline__ void run_body(const StepK& a, long long i0, long long
   V3 pos_e;
   float yaw_e;
   const long long nid = NOISE ? noise_id(a, i) : -1LL;
+  float act[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) act[j] = ACT ? clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]) : m.cmd[j];   // CtrlAviary.py:258-263
   if constexpr (HEXA) {
-    hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, step_index, ext, nid);
+    hexa_substeps<NOISE, false, S1>(T, a, i, s, act, step_index, ext, nid);
     indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
   } else {
-    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, step_index, ext, nullptr, nid);
+    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, act, step_index, ext, nullptr, nid);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   const unsigned so = pin_lane_offset(sl);
@@ -1192,21 +1206,40 @@ struct RunTab {
   long long first[DSIM_MAX_TYPES], lo[DSIM_MAX_TYPES], last[DSIM_MAX_TYPES];
   int type[DSIM_MAX_TYPES];
   unsigned hexa_mask;
+  // null: workgroup b serves the runs one after the other (blk0).  Else [blocks] device ints, (tile << 3) | run: the runs are
+  // served SIDE BY SIDE, each at a rate proportional to its size.  For DSIM_OPT_CALLER_IO: a drone's outputs go to its caller
+  // index, and the drones of every run are spread over the caller's whole range (even index quad, odd index hexa ...), so
+  // one run alone fills every other 88-byte row, every other dword of the command arrays — partial memory bursts, which
+  // cost a read-modify-write each (measured: Env.step of 4 194 304 interleaved drones 351 us run after run).  Side by
+  // side, the runs' halves of a line arrive within microseconds of each other and meet in the memory-side cache.
+  const int* block_map;
 };
-template <bool NOISE, bool NT, bool S1>
+// the run a workgroup belongs to: constant-index walk over the table, everything wave-uniform (SGPRs).  A macro, not a
+// function: a kernel argument handed on by reference is copied to scratch (264 bytes per lane) before the walk.
+struct RunOf { long long i0, lo, last; int type; bool hexa; };
+#define DSIM_RUN_OF_BLOCK(rt, ro, BIDX)                                                                             \
+  RunOf ro;                                                                                                         \
+  {                                                                                                                 \
+    const int bidx_ = __builtin_amdgcn_readfirstlane((int)(BIDX));                                                  \
+    int r_ = 0, tile_ = -1;                                                                                         \
+    if (rt.block_map) { const int e_ = rt.block_map[bidx_]; r_ = e_ & 7; tile_ = e_ >> 3; }                         \
+    else { _Pragma("unroll") for (int q = 1; q < DSIM_MAX_TYPES; ++q) if (bidx_ >= rt.blk0[q]) r_ = q; }            \
+    r_ = __builtin_amdgcn_readfirstlane(r_);                                                                        \
+    long long first_ = rt.first[0];                                                                                 \
+    int b0_ = rt.blk0[0];                                                                                           \
+    ro.lo = rt.lo[0]; ro.last = rt.last[0]; ro.type = rt.type[0];                                                   \
+    _Pragma("unroll") for (int q = 1; q < DSIM_MAX_TYPES; ++q)                                                      \
+      if (q == r_) { first_ = rt.first[q]; ro.lo = rt.lo[q]; ro.last = rt.last[q]; ro.type = rt.type[q]; b0_ = rt.blk0[q]; } \
+    if (!rt.block_map) tile_ = bidx_ - b0_;                                                                         \
+    ro.i0 = first_ + (long long)__builtin_amdgcn_readfirstlane(tile_) * 256;                                        \
+    ro.hexa = (rt.hexa_mask >> r_) & 1u;                                                                            \
+    if (tile_ < 0) ro.last = ro.lo = 0;                 /* a padding entry of the map: nothing to serve */          \
+  }
+template <bool NOISE, bool NT, bool S1, bool ACT>
 __global__ __launch_bounds__(256, 3) void k_step_runs(StepK a, RunTab rt) {
-  int r = 0;
-#pragma unroll
-  for (int q = 1; q < DSIM_MAX_TYPES; ++q) if ((int)blockIdx.x >= rt.blk0[q]) r = q;
-  r = __builtin_amdgcn_readfirstlane(r);
-  long long first = rt.first[0], lo = rt.lo[0], last = rt.last[0];
-  int type = rt.type[0], b0 = rt.blk0[0];
-#pragma unroll
-  for (int q = 1; q < DSIM_MAX_TYPES; ++q)
-    if (q == r) { first = rt.first[q]; lo = rt.lo[q]; last = rt.last[q]; type = rt.type[q]; b0 = rt.blk0[q]; }
-  const long long i0 = first + (long long)((int)blockIdx.x - b0) * 256;
-  if ((rt.hexa_mask >> r) & 1u) run_body<true, NOISE, NT, S1>(a, i0, lo, last, type);
-  else run_body<false, NOISE, NT, S1>(a, i0, lo, last, type);
+  DSIM_RUN_OF_BLOCK(rt, ro, blockIdx.x);
+  if (ro.hexa) run_body<true, NOISE, NT, S1, ACT>(a, ro.i0, ro.lo, ro.last, ro.type);
+  else run_body<false, NOISE, NT, S1, ACT>(a, ro.i0, ro.lo, ro.last, ro.type);
 }
 
 // ---- Env.step only ---------------------------------------------------------
@@ -1284,14 +1317,15 @@ __device__ __forceinline__ void control_gen_body(const DevType& T, const StepK& 
     for (int j = 0; j < NACT; ++j) a.cmd_out[(long long)j * a.n_pad + i] = m.cmd[j];
   }
 }
-template <bool UNIFORM, int NACT>
+// (per-lane types only: a homogeneous fleet is one run of k_control_runs)
+template <int NACT>
 __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_control_gen(StepK a) {
   const long long i0 = (long long)blockIdx.x * 256;
-  const unsigned p = tile_slot<UNIFORM>(a.type_id, i0, a.n_pad);
+  const unsigned p = tile_slot<false>(a.type_id, i0, a.n_pad);
   const long long i = i0 + p;
   if (i >= a.n_pad) return;
   const Addr ad = make_addr(a, i0, p);
-  DSIM_FOR_MY_TYPE(UNIFORM, a, i, (control_gen_body<NACT>(T, a, i, ad)));
+  DSIM_FOR_MY_TYPE(false, a, i, (control_gen_body<NACT>(T, a, i, ad)));
 }
 
 // ---- the reference-shaped two-call loop, fast forms ------------------------------------------------------------------
@@ -1401,6 +1435,195 @@ __global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_control_fast(StepK a) 
   if (WANT_YAW) stg<NT>(a.yaw_e_out + i0, lo, yaw_e);
 }
 
+// ---- the same two-call loop for every other fleet kind: runs of one type --------------------------------------------------
+// examples/fly_hexa_6DOF.py:214-221 is the same loop on the morphing hexa; BASELINE config 5 flies quads and hexas
+// together with the neighbour-downwash term.  The fleet is stored as runs of one type each (dsim_step_args.runs: what
+// CtrlAviary makes of an interleaved fleet; a homogeneous fleet is ONE run), a workgroup runs the Env.step / computeControl
+// of the run it falls in — the single-type body, per-type constants in SGPRs, the fused kernels' scalar-base addressing —
+// and the launch serves all runs (RunTab, as k_step_runs).  Runs may begin and end inside a tile: a lane outside
+// [lo, last) computes nothing and stores nothing, the neighbouring run's workgroup takes it.
+//   k_physics_runs  13 rigid + n_act action floats in (+ the body-frame force of the downwash term), 13 rigid + n_act
+//                   echoed action floats and the observation row of the NEW state out (20 wide for a quad-only table, 22
+//                   wide with a morphing hexa in it; BaseAviary.py:780-790); noise keyed by the caller's drone index;
+//                   optionally the next neighbour grid filled from the new positions (bin_next).
+//   k_control_runs  13 + (11 | 13) + 10 in, controller memory + command + pos_e + yaw_e out; a hexa whose first WLS
+//                   iteration leaves the box is queued for k_wls_fallback exactly as in k_step_hexa.
+// Observation rows: 88-byte rows are 8-byte but not 16-byte aligned, and a run boundary inside a wave splits the wave's
+// block of rows at a row boundary — so the wave-private LDS transpose of k_physics_fast is done in 8-byte pieces here
+// (every piece belongs to exactly one row): each lane writes its row as W / 2 pieces, the block leaves as W / 2 stores of
+// 8 bytes per lane over consecutive addresses, and a piece is stored when its row is one of this run's.
+typedef float vf2 __attribute__((ext_vector_type(2)));
+#define DSIM_OBS_WMAX 22
+// IO (DSIM_OPT_CALLER_IO): the action is gathered from, and rows / command / errors are scattered to, the CALLER's drone
+// number io_id[i].  The drones of a run are spread over the caller's whole range (even index quad, odd index hexa ...), so one
+// run alone fills every other 88-byte row and every other dword of the command arrays: partial memory bursts, a
+// read-modify-write each (measured, 4 194 304 interleaved drones: Env.step 351 us with the runs served one after the other
+// against 190 us for a fleet of one type).  The IO instances therefore serve the runs SIDE BY SIDE (RunTab.block_map) with
+// TWO tiles per 512-thread workgroup — neighbours in the map, i.e. tiles of different runs that cover the same stretch of
+// the caller's range — and write the scattered arrays with the default cache policy, so that the halves of a line meet in
+// the XCD's L2 before they leave for memory.  t = the thread's index inside its tile.
+template <bool HEXA, bool NOISE, bool NT, bool OBS, bool IO>
+__device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro, float* rows_wave, unsigned t) {
+  constexpr int NA = HEXA ? 6 : 4;
+  const long long i0 = ro.i0, i = i0 + t;
+  const long long w0 = i0 + (long long)(t & ~63u);                     // first drone of this wave
+  if (w0 >= ro.last || w0 + 64 <= ro.lo) return;                       // (wave-uniform) nothing of this run in the wave
+  const bool live = i >= ro.lo && i < ro.last;
+  const int W = HEXA ? 22 : a.obs_w;                                   // row width: 20 for a quad-only table, 22 with a hexa in it
+  const unsigned lane = t & 63u;
+  if (live) {
+    const DevType& T = a.types[ro.type];
+    const long long sfs = a.st.field_stride;
+    const unsigned sl = 4u * kv_lane(a.st, t);
+    float* const sb = a.st.base + kv_off(a.st, i0);
+    Rigid s;
+    load_rigid<NT>(sb, sfs, sl, s);
+    float cmd[NA];
+    long long id = i;
+    if (IO) id = a.io_id[i];
+    if (IO && a.action) {                     // the action is indexed by the caller's drone number: a gather
+#pragma unroll
+      for (int j = 0; j < NA; ++j) cmd[j] = clampf(a.action[(long long)j * a.n_pad + id], T.pmin[j], T.pmax[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const float raw = a.action ? ldg<NT>(a.action + (long long)j * a.n_pad + i0, 4u * t) : ldg<NT>(sb + (20 + j) * sfs, sl);
+        cmd[j] = clampf(raw, T.pmin[j], T.pmax[j]);                                     // CtrlAviary.py:258-263
+      }
+    }
+    V3 ext = v3(0, 0, 0);
+    if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
+    unsigned long long step_index = a.step_index;
+    if (NOISE && a.step_index_dev) step_index += *a.step_index_dev;
+    const long long nid = NOISE ? noise_id(a, i) : -1LL;
+    if constexpr (HEXA) hexa_substeps<NOISE, false>(T, a, i, s, cmd, step_index, ext, nid);
+    else quad_substeps<NOISE ? 1 : 0>(T, a, i, s, cmd, step_index, ext, nullptr, nid);
+    ground_watch(T, s, a.fb.counters, i < a.n);
+    const unsigned so = pin_lane_offset(sl);
+    store_rigid<NT>(sb, sfs, so, s);
+    if (a.echo) {                                                                       // BaseAviary.py:545
+#pragma unroll
+      for (int j = 0; j < NA; ++j) stg<NT>(a.echo + (long long)j * a.n_pad + i0, 4u * t, cmd[j]);
+      if (!HEXA && W == 22) {                 // a quad of a table with a six-actuator type: its rows 4, 5 hold zeros
+        stg<NT>(a.echo + 4LL * a.n_pad + i0, 4u * t, 0.0f); stg<NT>(a.echo + 5LL * a.n_pad + i0, 4u * t, 0.0f);
+      }
+    }
+    if (a.bin.count && i < a.n) bin_entry(a.bin, s.pos.x, s.pos.y, s.pos.z, a.bin.local_offset + i);   // next step's grid
+    if (OBS) {
+      const Euler e = euler_from_quat<true>(s.q);                                       // BaseAviary.py:729
+      vf2* r = reinterpret_cast<vf2*>(rows_wave + lane * (unsigned)W);
+      r[0] = vf2{s.pos.x, s.pos.y}; r[1] = vf2{s.pos.z, s.q.x}; r[2] = vf2{s.q.y, s.q.z}; r[3] = vf2{s.q.w, e.roll};
+      r[4] = vf2{e.pitch, e.yaw}; r[5] = vf2{s.vel.x, s.vel.y}; r[6] = vf2{s.vel.z, s.w.x}; r[7] = vf2{s.w.y, s.w.z};
+      r[8] = vf2{cmd[0], cmd[1]}; r[9] = vf2{cmd[2], cmd[3]};
+      if constexpr (HEXA) r[10] = vf2{cmd[4], cmd[5]};
+      else if (W == 22) r[10] = vf2{0.0f, 0.0f};
+      if (IO) reinterpret_cast<int*>(rows_wave + 64 * DSIM_OBS_WMAX)[lane] = (int)id;  // where this row goes
+    }
+  }
+  if (OBS) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's own LDS writes, then its own reads: in order
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned hw = (unsigned)W >> 1;                                               // pieces per row
+    const long long r_lo = ro.lo > w0 ? ro.lo - w0 : 0;                                 // this run's rows of the wave's block
+    const long long r_hi = min(min(ro.last, a.n) - w0, 64LL);
+    const unsigned p_lo = (unsigned)r_lo * hw, p_hi = r_hi > 0 ? (unsigned)r_hi * hw : 0u;
+    const vf2* blk = reinterpret_cast<const vf2*>(rows_wave);
+    if (IO) {
+      // row r of the block is row io_id[w0 + r] of the output — hw consecutive lanes still write one row's 8 hw
+      // consecutive bytes.  (p / hw by multiply-shift: exact for p < 704 with these constants.)
+      const int* ids = reinterpret_cast<const int*>(rows_wave + 64 * DSIM_OBS_WMAX);
+      const unsigned mul = hw == 11u ? 5958u : 6554u;
+      for (unsigned k = 0; k < hw; ++k) {
+        const unsigned p = k * 64u + lane;
+        if (p >= p_lo && p < p_hi) {
+          const unsigned row = (p * mul) >> 16;
+          vf2* d = reinterpret_cast<vf2*>(a.obs_out + (long long)ids[row] * W) + (p - row * hw);
+          const vf2 v = blk[p];      // (default cache policy: the other runs' halves of these lines are on their way)
+          if (NT && DSIM_IO_ROWS_NT) __builtin_nontemporal_store(v, d); else *d = v;
+        }
+      }
+    } else {
+      vf2* dst = reinterpret_cast<vf2*>(a.obs_out + w0 * W);
+      for (unsigned k = 0; k < hw; ++k) {
+        const unsigned p = k * 64u + lane;
+        if (p >= p_lo && p < p_hi) {
+          const vf2 v = blk[p];
+          if (NT && DSIM_OBS_STREAM) __builtin_nontemporal_store(v, dst + p); else dst[p] = v;
+        }
+      }
+    }
+  }
+}
+#ifndef DSIM_PRUNS_WAVES
+#define DSIM_PRUNS_WAVES 3
+#endif
+template <bool NOISE, bool NT, bool OBS, bool IO>
+__global__ __launch_bounds__(IO ? 512 : 256, DSIM_PRUNS_WAVES) void k_physics_runs(StepK a, RunTab rt) {
+  constexpr int PER_WAVE = 64 * DSIM_OBS_WMAX + (IO ? 64 : 0);          // per wave: 64 rows (+ their 64 destinations)
+  __shared__ __attribute__((aligned(16))) float rows[OBS ? (IO ? 8 : 4) * PER_WAVE : 2];
+  DSIM_RUN_OF_BLOCK(rt, ro, IO ? 2 * blockIdx.x + (threadIdx.x >> 8) : blockIdx.x);
+  float* rw = rows + (OBS ? (threadIdx.x >> 6) * PER_WAVE : 0);
+  const unsigned t = IO ? (threadIdx.x & 255u) : threadIdx.x;
+  if (ro.hexa) physics_run_body<true, NOISE, NT, OBS, IO>(a, ro, rw, t);
+  else physics_run_body<false, NOISE, NT, OBS, IO>(a, ro, rw, t);
+}
+
+template <bool HEXA, bool NT, bool WANT_YAW, bool IO>
+__device__ __forceinline__ void control_run_body(const StepK& a, const RunOf& ro, unsigned t) {
+  constexpr int NA = HEXA ? 6 : 4;
+  const long long i0 = ro.i0, i = i0 + t;
+  if (i >= ro.last || i < ro.lo) return;
+  const DevType& T = a.types[ro.type];
+  const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
+  const unsigned sl = 4u * kv_lane(a.st, t), tl = 4u * kv_lane(a.tg, t);
+  float* const sb = a.st.base + kv_off(a.st, i0);
+  const float* const tb = a.tg.base + kv_off(a.tg, i0);
+  Rigid s;
+  CtrlMem<NA> m;
+  Target tg;
+  load_rigid<NT>(sb, sfs, sl, s);
+  load_mem<NA, NT>(sb, sfs, sl, m);
+  load_target<NT>(tb, tfs, tl, tg);
+  V3 pos_e;
+  float yaw_e = 0.0f;
+  if constexpr (HEXA) indi_hexa<WANT_YAW>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
+  else indi_quad<WANT_YAW>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  const unsigned so = pin_lane_offset(sl);
+  store_mem<NA, NT>(sb, sfs, so, m);
+  if (IO) {                                   // the outputs go to the caller's drone number (default cache policy, see above)
+    const long long id = a.io_id[i];
+    if (a.cmd_out) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) a.cmd_out[(long long)j * a.n_pad + id] = m.cmd[j];
+      if (!HEXA && a.obs_w == 22) { a.cmd_out[4LL * a.n_pad + id] = 0.0f; a.cmd_out[5LL * a.n_pad + id] = 0.0f; }
+    }
+    if (a.pos_e_out) { a.pos_e_out[id] = pos_e.x; a.pos_e_out[a.n_pad + id] = pos_e.y; a.pos_e_out[2 * a.n_pad + id] = pos_e.z; }
+    if (WANT_YAW) a.yaw_e_out[id] = yaw_e;
+    return;
+  }
+  const unsigned lo4 = 4u * t;
+  if (a.cmd_out) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) stg<NT>(a.cmd_out + (long long)j * a.n_pad + i0, lo4, m.cmd[j]);
+    if (!HEXA && a.obs_w == 22) {             // a quad of a table with a six-actuator type: its rows 4, 5 hold zeros
+      stg<NT>(a.cmd_out + 4LL * a.n_pad + i0, lo4, 0.0f); stg<NT>(a.cmd_out + 5LL * a.n_pad + i0, lo4, 0.0f);
+    }
+  }
+  if (a.pos_e_out) {
+    stg<NT>(a.pos_e_out + i0, lo4, pos_e.x); stg<NT>(a.pos_e_out + a.n_pad + i0, lo4, pos_e.y);
+    stg<NT>(a.pos_e_out + 2 * a.n_pad + i0, lo4, pos_e.z);
+  }
+  if (WANT_YAW) stg<NT>(a.yaw_e_out + i0, lo4, yaw_e);
+}
+template <bool NT, bool WANT_YAW, bool IO>
+__global__ __launch_bounds__(IO ? 512 : 256, DSIM_PRUNS_WAVES) void k_control_runs(StepK a, RunTab rt) {
+  DSIM_RUN_OF_BLOCK(rt, ro, IO ? 2 * blockIdx.x + (threadIdx.x >> 8) : blockIdx.x);
+  const unsigned t = IO ? (threadIdx.x & 255u) : threadIdx.x;
+  if (ro.hexa) control_run_body<true, NT, WANT_YAW, IO>(a, ro, t);
+  else control_run_body<false, NT, WANT_YAW, IO>(a, ro, t);
+}
+
 // ---- Env.step of the alternate action adaptors (VelocityAviary / RPYTAviary) --------------
 // control (inside _preprocessAction) on the CURRENT state, then the physics with the new command
 template <int MODE, bool NOISE, bool PLANE>
@@ -1452,7 +1675,7 @@ __global__ __launch_bounds__(256, PLANE ? 1 : DSIM_GEN_WAVES) void k_adaptor(Ste
 // unconditional fence-and-ticket epilogue of round 1 cost).  Otherwise the grid (sized for the chip by the host:
 // up to one 64-lane workgroup per CU, 144 KB of LDS each) strides over the queue, and the last workgroup to finish
 // empties it for the next step.
-struct FbK { KView st; const DevType* types; const uint8_t* type_id; FbList fb; float* cmd_out; long long n_pad; };
+struct FbK { KView st; const DevType* types; const uint8_t* type_id; FbList fb; float* cmd_out; long long n_pad; const int* io_id; };
 #define DSIM_FB_LANES 64
 __global__ __launch_bounds__(DSIM_FB_LANES) void k_wls_fallback(FbK a) {
   const unsigned long long cnt = *a.fb.count;
@@ -1473,7 +1696,7 @@ __global__ __launch_bounds__(DSIM_FB_LANES) void k_wls_fallback(FbK a) {
       for (int j = 0; j < 6; ++j) {
         const float c = clampf(cmd[j] + du[j], T.pmin[j], T.pmax[j]);
         p[(20 + j) * fs] = c;
-        if (a.cmd_out) a.cmd_out[(long long)j * a.n_pad + i] = c;   // computeControl's first return value (dsim_control2)
+        if (a.cmd_out) a.cmd_out[(long long)j * a.n_pad + (a.io_id ? (long long)a.io_id[i] : i)] = c;   // computeControl's first return value (dsim_control2)
       }
     }
     else atomicAdd(&a.fb.counters[1], 1ULL);   // the reference would raise here; cmd is left unchanged
@@ -2488,6 +2711,7 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
   c->dw_prebin_geo[0] = c->dw_prebin_geo[1] = c->dw_prebin_geo[2] = 0.0f;
   c->dw_prebin_nx = c->dw_prebin_ny = 0; c->dw_local_m = 0; c->dwh_parity = 0; c->dwh_ws = nullptr; c->dwh_cells = 0;
   c->d_bounds = nullptr;
+  c->d_block_map = nullptr; c->h_block_map = nullptr; c->block_map_cap = 0; c->block_map_blocks = 0; c->block_map_runs = 0;
   { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->n_cu = v; }
   DevType h[DSIM_MAX_TYPES];
   for (int t = 0; t < n_types; ++t) { c->h_types[t] = types[t]; to_dev(types[t], &h[t]); }
@@ -2517,6 +2741,8 @@ int dsim_destroy(dsim_ctx* ctx) {
   (void)hipFree(ctx->d_counters);
   (void)hipFree(ctx->d_bounds);
   if (ctx->d_fb) (void)hipFree(ctx->d_fb);
+  if (ctx->d_block_map) (void)hipFree(ctx->d_block_map);
+  free(ctx->h_block_map);
   delete ctx;
   return (int)e;
 }
@@ -2585,7 +2811,7 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
   for (int t = 0; t < ctx->n_types; ++t) a->hexa_types |= (ctx->h_types[t].kind == DSIM_KIND_HEXA6DOF ? 1u : 0u) << t;
   a->types = ctx->d_types; a->type_id = args->type_id; a->noise_replay = args->noise_replay;
   a->action = args->action; a->echo = nullptr; a->pos_e_out = nullptr; a->yaw_e_out = nullptr;
-  a->cmd_out = nullptr; a->obs_out = nullptr; a->n = n;
+  a->cmd_out = nullptr; a->obs_out = nullptr; a->obs_w = 16 + ctx->max_act; a->n = n;
   a->fb.entries = ctx->d_fb; a->fb.count = ctx->d_counters + 2; a->fb.counters = ctx->d_counters;
   a->n_pad = state.n_pad; a->first = 0; a->seed = args->noise_seed;
   a->wp_table = args->wp_table; a->wp_counter = args->wp_counter; a->wp_offset = args->wp_offset;
@@ -2598,6 +2824,7 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
   memset(&a->bin, 0, sizeof(a->bin));
   a->lo = 0; a->last = a->n_pad; a->run_type = 0;
   a->drone_id = args->drone_id;
+  a->io_id = (args->options & DSIM_OPT_CALLER_IO) ? args->drone_id : nullptr;
   return DSIM_OK;
 }
 
@@ -2648,7 +2875,7 @@ static void fb_finish(dsim_ctx* ctx, const StepK& a, hipStream_t st) {
   if (a.options & DSIM_OPT_DEFER_FALLBACK) return;          // the caller launches dsim_wls_fallback itself
   FbK f;
   f.st = a.st; f.types = a.types; f.type_id = a.type_id; f.fb = a.fb;
-  f.cmd_out = a.cmd_out; f.n_pad = a.n_pad;
+  f.cmd_out = a.cmd_out; f.n_pad = a.n_pad; f.io_id = a.io_id;
   f.fb.entries = ctx->d_fb;
   // one workgroup per 64 possible entries, at most one per CU (each holds 144 KB of LDS): a start-up transient that
   // queues a large part of a big fleet is worked off by the whole chip, an empty queue costs one scalar load per group
@@ -2672,11 +2899,81 @@ static void fb_finish(dsim_ctx* ctx, const StepK& a, hipStream_t st) {
     }                                                                                                   \
   } while (0)
 
+// Lays the runs of a type-major fleet out over the workgroups of ONE launch (RunTab): run r takes the whole 256-drone
+// tiles from the one that holds its first drone to the one that holds its last.  Returns the number of workgroups, or a
+// negative error code.  n_runs <= DSIM_MAX_TYPES.
+static int make_runtab(const dsim_ctx* ctx, long long n_pad, const dsim_type_run* runs, int n_runs, RunTab* rt, bool* any_hexa) {
+  memset(rt, 0, sizeof(*rt));
+  *any_hexa = false;
+  if (n_runs < 1 || n_runs > DSIM_MAX_TYPES) return DSIM_E_ARG;
+  int blocks = 0;
+  for (int r = 0; r < DSIM_MAX_TYPES; ++r) {
+    rt->blk0[r] = blocks;
+    if (r >= n_runs) continue;
+    const dsim_type_run& run = runs[r];
+    if (run.first < 0 || run.count < 0 || run.first + run.count > n_pad || run.type < 0 || run.type >= ctx->n_types) return DSIM_E_ARG;
+    rt->first[r] = run.first & ~255LL; rt->lo[r] = run.first; rt->last[r] = run.first + run.count; rt->type[r] = run.type;
+    if (ctx->h_types[run.type].kind == DSIM_KIND_HEXA6DOF) { rt->hexa_mask |= 1u << r; *any_hexa = true; }
+    blocks += run.count > 0 ? (int)((rt->last[r] - rt->first[r] + 255) / 256) : 0;
+  }
+  rt->blk0[DSIM_MAX_TYPES] = blocks;
+  return blocks;
+}
+
+// RunTab.block_map: the workgroups of the runs dealt side by side, eight at a time to the run that is furthest behind
+// (progress = tiles served / tiles of the run), so that every run sweeps the caller's index range at the same pace.  Kept
+// by the ctx and re-made only when the runs change; the upload is ordered on the caller's stream.
+static int side_by_side_map(dsim_ctx* ctx, hipStream_t st, const dsim_type_run* runs, int n_runs, RunTab* rt) {
+  const int blocks = rt->blk0[DSIM_MAX_TYPES] + (rt->blk0[DSIM_MAX_TYPES] & 1);      // (two entries per workgroup: an odd count is padded)
+  rt->block_map = nullptr;
+  if (blocks < 2) return DSIM_OK;
+  bool same = ctx->d_block_map && ctx->block_map_blocks == blocks && ctx->block_map_runs == n_runs;
+  for (int r = 0; same && r < n_runs; ++r)
+    same = ctx->block_map_key[r].first == runs[r].first && ctx->block_map_key[r].count == runs[r].count && ctx->block_map_key[r].type == runs[r].type;
+  if (!same) {
+    if (ctx->block_map_cap < blocks) {
+      hipError_t e = hipStreamSynchronize(st);                 // (a launch in flight may still read the old table)
+      if (e != hipSuccess) return (int)e;
+      if (ctx->d_block_map) (void)hipFree(ctx->d_block_map);
+      free(ctx->h_block_map);
+      ctx->d_block_map = nullptr; ctx->h_block_map = nullptr; ctx->block_map_cap = 0;
+      ctx->h_block_map = (int*)malloc(sizeof(int) * (size_t)blocks);
+      if (!ctx->h_block_map) return (int)hipErrorOutOfMemory;
+      e = hipMalloc((void**)&ctx->d_block_map, sizeof(int) * (size_t)blocks);
+      if (e != hipSuccess) return (int)e;
+      ctx->block_map_cap = blocks;
+    } else {
+      hipError_t e = hipStreamSynchronize(st);
+      if (e != hipSuccess) return (int)e;
+    }
+    int next[DSIM_MAX_TYPES], total[DSIM_MAX_TYPES];
+    for (int r = 0; r < DSIM_MAX_TYPES; ++r) { next[r] = 0; total[r] = r < n_runs ? rt->blk0[r + 1] - rt->blk0[r] : 0; }
+    // workgroup w serves entries 2 w and 2 w + 1: one tile of each of the two runs that are furthest behind (progress =
+    // tiles served / tiles of the run), so that every run sweeps the caller's index range at the same pace and the two
+    // tiles of a workgroup cover the same stretch of it
+    for (int b = 0; b < blocks; ++b) {
+      int pick = -1;
+      for (int r = 0; r < n_runs; ++r) {
+        if (next[r] >= total[r]) continue;
+        if (pick < 0 || (long long)next[r] * total[pick] < (long long)next[pick] * total[r]) pick = r;
+      }
+      ctx->h_block_map[b] = pick < 0 ? -8 : ((next[pick]++ << 3) | pick);              // (-8: tile -1, nothing to serve)
+    }
+    hipError_t e = hipMemcpyAsync(ctx->d_block_map, ctx->h_block_map, sizeof(int) * (size_t)blocks, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    ctx->block_map_blocks = blocks; ctx->block_map_runs = n_runs;
+    for (int r = 0; r < n_runs; ++r) ctx->block_map_key[r] = runs[r];
+  }
+  rt->block_map = ctx->d_block_map;
+  return DSIM_OK;
+}
+
 int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
               const dsim_step_args* args) {
   StepK a;
   int rc = fill_stepk(ctx, n, state, &targets, args, &a);
   if (rc) return rc;
+  if (args->options & DSIM_OPT_CALLER_IO) return DSIM_E_UNSUPPORTED;     // (dsim_physics / dsim_control2 only)
   ctx->dw_prebin_valid = false;      // the positions move: a grid binned before this call is stale (bin_next_commit re-validates)
   const bool noise = args->noise_seed != 0 || args->noise_replay != nullptr;
   const bool uni = args->type_id == nullptr;
@@ -2691,18 +2988,21 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   if ((args->options & DSIM_OPT_CHAINED) && (!uni || six || args->action || args->noise_replay || args->ext_force ||
                                              phys_opts || (state.n_pad % 256)))
     return DSIM_E_UNSUPPORTED;                          // chained stepping is a fast-path-only mode
-  const bool plain = !args->action && !args->noise_replay && !a.wp_table && a.n_steps == 1 && !phys_opts && a.tg.base &&
-                     !(args->options & DSIM_OPT_CHAINED);
+  const bool runs_ok = !args->noise_replay && !a.wp_table && a.n_steps == 1 && !phys_opts && a.tg.base &&
+                       !(args->options & DSIM_OPT_CHAINED);
+  const bool plain = runs_ok && !args->action;
   const dsim_type_run* runs = args->runs;
   int n_runs = args->n_runs;
   dsim_type_run whole;
-  if (!(runs && n_runs > 0) && uni && plain && args->ext_force) {
+  if (!(runs && n_runs > 0) && uni && runs_ok && args->ext_force) {
     // a homogeneous fleet with an external (downwash) force: ONE run of its only type — the single-type kernel with
     // the force input and the fused neighbour-grid binning, instead of the general kernel
     whole.first = 0; whole.count = a.n_pad; whole.type = 0; whole._pad = 0;
     runs = &whole; n_runs = 1;
   }
-  if (runs && n_runs > 0 && plain) {
+  // (an explicit action — the first iteration of the example loop, fly_INDI.py:214 — is served by the ACT instances of the
+  // one-launch form; beyond DSIM_MAX_TYPES runs it goes to the general kernel)
+  if (runs && n_runs > 0 && runs_ok && (!args->action || n_runs <= DSIM_MAX_TYPES)) {
     // type-major storage: one single-type launch per run
     const bool nt = stream_policy(args, state.n_pad, 240.0);
     bool any_hexa = false;
@@ -2721,30 +3021,23 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     // (measured on MI355X, 50 % quads + 50 % hexas: 65 536 drones 12.0 us against 9.5 + 9.0 us for two dependent launches;
     // 4 194 304 drones 160.1 against 165.2 us — the launch boundary between the runs costs more than the registers the
     // second law adds (83 VGPRs, 5 waves per SIMD, against 74 and 6): one launch is the default at every size)
-    const bool one_launch = !(args->options & DSIM_OPT_RUNS_SEPARATE);
-    if (n_runs >= 2 && n_runs <= DSIM_MAX_TYPES && one_launch) {
-      // small fleet, several runs: one launch for all of them (k_step_runs)
+    const bool one_launch = !(args->options & DSIM_OPT_RUNS_SEPARATE) || args->action;
+    if (n_runs <= DSIM_MAX_TYPES && (n_runs >= 2 || args->action) && one_launch) {
+      // several runs (or an explicit action): one launch for all of them (k_step_runs)
       RunTab rt;
-      memset(&rt, 0, sizeof(rt));
-      int blocks = 0;
-      for (int r = 0; r < DSIM_MAX_TYPES; ++r) {
-        rt.blk0[r] = blocks;
-        if (r >= n_runs) continue;
-        const dsim_type_run& run = runs[r];
-        rt.first[r] = run.first & ~255LL; rt.lo[r] = run.first; rt.last[r] = run.first + run.count; rt.type[r] = run.type;
-        if (ctx->h_types[run.type].kind == DSIM_KIND_HEXA6DOF) rt.hexa_mask |= 1u << r;
-        blocks += run.count > 0 ? (int)grid_for(rt.last[r] - rt.first[r]) : 0;
-      }
-      rt.blk0[DSIM_MAX_TYPES] = blocks;
+      const int blocks = make_runtab(ctx, a.n_pad, runs, n_runs, &rt, &any_hexa);
+      if (blocks < 0) return blocks;
       if (blocks > 0) {
         const dim3 g((unsigned)blocks);
-#define DSIM_RUNS_CASE(S_)                                                                              \
-  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_runs<true, true, S_>), g, b, 0, st_, a, rt);     \
-                    else hipLaunchKernelGGL((k_step_runs<true, false, S_>), g, b, 0, st_, a, rt); }     \
-       else { if (nt) hipLaunchKernelGGL((k_step_runs<false, true, S_>), g, b, 0, st_, a, rt);          \
-              else hipLaunchKernelGGL((k_step_runs<false, false, S_>), g, b, 0, st_, a, rt); } } while (0)
+#define DSIM_RUNS_CASE2(S_, A_)                                                                              \
+  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_runs<true, true, S_, A_>), g, b, 0, st_, a, rt);     \
+                    else hipLaunchKernelGGL((k_step_runs<true, false, S_, A_>), g, b, 0, st_, a, rt); }     \
+       else { if (nt) hipLaunchKernelGGL((k_step_runs<false, true, S_, A_>), g, b, 0, st_, a, rt);          \
+              else hipLaunchKernelGGL((k_step_runs<false, false, S_, A_>), g, b, 0, st_, a, rt); } } while (0)
+#define DSIM_RUNS_CASE(S_) do { if (args->action) DSIM_RUNS_CASE2(S_, true); else DSIM_RUNS_CASE2(S_, false); } while (0)
         if (a.substeps == 1) DSIM_RUNS_CASE(true); else DSIM_RUNS_CASE(false);
 #undef DSIM_RUNS_CASE
+#undef DSIM_RUNS_CASE2
       }
       if (any_hexa) fb_finish(ctx, a, st_);
       bin_next_commit(ctx, n, args, a);
@@ -2982,8 +3275,9 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
   if (args->obs_out && args->obs_width != obs_w) return DSIM_E_ARG;
   const bool noise = args->noise_seed != 0 || args->noise_replay != nullptr;
   const hipStream_t st_ = (hipStream_t)stream;
+  if ((args->options & DSIM_OPT_CALLER_IO) && !args->drone_id) return DSIM_E_ARG;
   if (args->type_id == nullptr && ctx->max_act == 4 && !args->noise_replay && !args->ext_force && !phys_opts &&
-      (a.n_pad % 256) == 0) {
+      (a.n_pad % 256) == 0 && !args->bin_next && !args->drone_id && !(args->options & DSIM_OPT_CALLER_IO)) {
     // homogeneous quad fleet in whole tiles: the fast form, observation fused (16-byte stores: any torch allocation is
     // aligned far beyond that; a misaligned caller buffer gets the rows from the observation kernel behind the step)
     const bool obs_fused = args->obs_out && ((uintptr_t)args->obs_out & 15u) == 0;
@@ -2998,6 +3292,45 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
     if (args->obs_out && !obs_fused) return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, obs_w, 0);
     return (int)hipGetLastError();
   }
+  // Every other fleet kind on the fast form: runs of one type (dsim_step_args.runs), or a homogeneous fleet as ONE run —
+  // morphing hexas, type-major quad + hexa fleets, fleets with the downwash force, ragged tails.  The observation rows are
+  // written by the same launch; the new positions may fill the next neighbour grid (bin_next).
+  {
+    const dsim_type_run* runs = args->runs;
+    int n_runs = args->n_runs;
+    dsim_type_run whole;
+    if (!(runs && n_runs > 0 && n_runs <= DSIM_MAX_TYPES) && args->type_id == nullptr) {
+      whole.first = 0; whole.count = a.n_pad; whole.type = 0; whole._pad = 0;
+      runs = &whole; n_runs = 1;
+    }
+    if (runs && n_runs > 0 && n_runs <= DSIM_MAX_TYPES && !args->noise_replay && !phys_opts) {
+      RunTab rt;
+      bool any_hexa = false;
+      const int blocks = make_runtab(ctx, a.n_pad, runs, n_runs, &rt, &any_hexa);
+      if (blocks < 0) return blocks;
+      if (a.io_id) { rc = side_by_side_map(ctx, st_, runs, n_runs, &rt); if (rc) return rc; }
+      const bool obs_fused = args->obs_out && ((uintptr_t)args->obs_out & 7u) == 0;     // (8-byte pieces of the rows)
+      a.obs_out = obs_fused ? args->obs_out : nullptr;
+      const bool nt = stream_policy(args, state.n_pad, args->obs_out ? 240.0 : 152.0);
+      bin_next_prepare(ctx, n, args, &a, st_);
+      if (blocks > 0) {
+        const dim3 g((unsigned)blocks), b(256);
+#define DSIM_PRUNS_CASE(N_, T_) do {                                                                                           \
+          if (a.io_id) { const dim3 g2((unsigned)((blocks + 1) / 2)), b2(512);                                                 \
+                         if (a.obs_out) hipLaunchKernelGGL((k_physics_runs<N_, T_, true, true>), g2, b2, 0, st_, a, rt);       \
+                         else hipLaunchKernelGGL((k_physics_runs<N_, T_, false, true>), g2, b2, 0, st_, a, rt); }               \
+          else { if (a.obs_out) hipLaunchKernelGGL((k_physics_runs<N_, T_, true, false>), g, b, 0, st_, a, rt);               \
+                 else hipLaunchKernelGGL((k_physics_runs<N_, T_, false, false>), g, b, 0, st_, a, rt); } } while (0)
+        if (noise) { if (nt) DSIM_PRUNS_CASE(true, true); else DSIM_PRUNS_CASE(true, false); }
+        else { if (nt) DSIM_PRUNS_CASE(false, true); else DSIM_PRUNS_CASE(false, false); }
+#undef DSIM_PRUNS_CASE
+      }
+      bin_next_commit(ctx, n, args, a);
+      if (args->obs_out && !obs_fused) return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, obs_w, 0);
+      return (int)hipGetLastError();
+    }
+  }
+  if (a.io_id) return DSIM_E_UNSUPPORTED;            // the caller's numbering is served by the run kernels only
   const dim3 g(grid_for(a.n_pad));
   if (args->options & DSIM_OPT_PLANE) DSIM_LAUNCH_GEN(k_physics_plane, noise, args->type_id == nullptr, ctx->max_act == 6, g, a, st_);
   else DSIM_LAUNCH_GEN(k_physics_gen, noise, args->type_id == nullptr, ctx->max_act == 6, g, a, st_);
@@ -3016,6 +3349,7 @@ int dsim_step_adaptor(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, c
     return DSIM_E_UNSUPPORTED;        // plain PYB physics (+ the plane): refuse what the adaptor kernels would silently drop
   int rc = fill_stepk(ctx, n, state, nullptr, args, &a);
   if (rc) return rc;
+  if (args->options & DSIM_OPT_CALLER_IO) return DSIM_E_UNSUPPORTED;
   ctx->dw_prebin_valid = false;
   a.action = action; a.echo = last_action_out;
   const bool noise = args->noise_seed != 0, uni = args->type_id == nullptr;
@@ -3048,7 +3382,8 @@ int dsim_control2(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_
   const dim3 g(grid_for(a.n_pad)), b(256);
   const hipStream_t st_ = (hipStream_t)stream;
   const bool uni = args->type_id == nullptr;
-  if (uni && ctx->max_act == 4 && (a.n_pad % 256) == 0 && a.tg.base) {
+  if ((args->options & DSIM_OPT_CALLER_IO) && !args->drone_id) return DSIM_E_ARG;
+  if (uni && ctx->max_act == 4 && (a.n_pad % 256) == 0 && a.tg.base && !a.io_id) {
     const bool nt = stream_policy(args, state.n_pad, 212.0);
     const dim3 gt((unsigned)(a.n_pad / 256));
     if (yaw_e_out) { if (nt) hipLaunchKernelGGL((k_control_fast<true, true>), gt, b, 0, st_, a);
@@ -3057,16 +3392,50 @@ int dsim_control2(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_
            else hipLaunchKernelGGL((k_control_fast<false, false>), gt, b, 0, st_, a); }
     return (int)hipGetLastError();
   }
+  {
+    // every other fleet kind: runs of one type (or a homogeneous fleet as one run) on the single-type bodies (k_control_runs)
+    const dsim_type_run* runs = args->runs;
+    int n_runs = args->n_runs;
+    dsim_type_run whole;
+    if (!(runs && n_runs > 0 && n_runs <= DSIM_MAX_TYPES) && uni) {
+      whole.first = 0; whole.count = a.n_pad; whole.type = 0; whole._pad = 0;
+      runs = &whole; n_runs = 1;
+    }
+    if (runs && n_runs > 0 && n_runs <= DSIM_MAX_TYPES) {
+      RunTab rt;
+      bool any_hexa = false;
+      const int blocks = make_runtab(ctx, a.n_pad, runs, n_runs, &rt, &any_hexa);
+      if (blocks < 0) return blocks;
+      if (any_hexa) {
+        rc = fb_prepare(ctx, a.n_pad, st_);
+        if (rc) return rc;
+        a.fb.entries = ctx->d_fb;
+      }
+      if (a.io_id) { rc = side_by_side_map(ctx, st_, runs, n_runs, &rt); if (rc) return rc; }
+      const bool nt = stream_policy(args, state.n_pad, 236.0);
+      if (blocks > 0) {
+        const dim3 gr((unsigned)blocks);
+#define DSIM_CRUNS_CASE(T_, Y_) do {                                                                                         \
+          if (a.io_id) hipLaunchKernelGGL((k_control_runs<T_, Y_, true>), dim3((unsigned)((blocks + 1) / 2)), dim3(512), 0, st_, a, rt); \
+          else hipLaunchKernelGGL((k_control_runs<T_, Y_, false>), gr, b, 0, st_, a, rt); } while (0)
+        if (yaw_e_out) { if (nt) DSIM_CRUNS_CASE(true, true); else DSIM_CRUNS_CASE(false, true); }
+        else { if (nt) DSIM_CRUNS_CASE(true, false); else DSIM_CRUNS_CASE(false, false); }
+#undef DSIM_CRUNS_CASE
+      }
+      if (any_hexa) fb_finish(ctx, a, st_);
+      return (int)hipGetLastError();
+    }
+  }
+  // what is left: per-lane types without usable runs (the caller's own order of a heterogeneous fleet)
+  if (a.io_id) return DSIM_E_UNSUPPORTED;
   if (ctx->max_act == 6) {
     rc = fb_prepare(ctx, a.n_pad, st_);
     if (rc) return rc;
     a.fb.entries = ctx->d_fb;
-    if (uni) hipLaunchKernelGGL((k_control_gen<true, 6>), g, b, 0, st_, a);
-    else hipLaunchKernelGGL((k_control_gen<false, 6>), g, b, 0, st_, a);
+    hipLaunchKernelGGL((k_control_gen<6>), g, b, 0, st_, a);
     fb_finish(ctx, a, st_);
   }
-  else { if (uni) hipLaunchKernelGGL((k_control_gen<true, 4>), g, b, 0, st_, a);
-         else hipLaunchKernelGGL((k_control_gen<false, 4>), g, b, 0, st_, a); }
+  else hipLaunchKernelGGL((k_control_gen<4>), g, b, 0, st_, a);
   return (int)hipGetLastError();
 }
 

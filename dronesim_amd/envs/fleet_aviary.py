@@ -134,6 +134,7 @@ class CtrlAviary:
                 tid[i] = self._type_names.index(key)
         self.drones = [types[k] for k in tid] if num_drones <= DICT_IO_MAX_DRONES else None
         self.types = types
+        self.type_ids_caller = np.array(tid, dtype=np.uint8)      # per drone, in the caller's numbering
         self.G = 9.8                                    # BaseAviary.py:182
         self.SIM_FREQ = freq
         self.TIMESTEP = 1.0 / freq
@@ -193,6 +194,12 @@ class CtrlAviary:
                     arr[k].first, arr[k].count, arr[k].type = f, c, ty
                 self._runs = arr
         self.n_act = self.ctx.n_act
+        # A fleet stored in another order than the caller's: Env.step and a bound computeControl take and return their
+        # per-drone arrays (action, observation rows, command, errors) in the CALLER's numbering straight from the kernels
+        # (DSIM_OPT_CALLER_IO: the run kernels gather / scatter by drone_id) — no second pass over them.  Where the run
+        # kernels do not serve the fleet (more than 8 runs, drag / ground / plane options) the host translates instead.
+        self._caller_io = (self.order is not None and self._runs is not None and len(self._runs) <= 8
+                           and self._phys_options == 0)
         self._action_buf = torch.zeros((self.n_act, self.state.n_pad), dtype=torch.float32, device=self.ctx.device)
         # the env's own last_clipped_action (BaseAviary.py:660-663, 545): separate from the
         # controller's cmd memory, exactly as env and controller are separate objects upstream
@@ -327,10 +334,14 @@ class CtrlAviary:
         """BaseAviary.step (BaseAviary.py:428-555) with Physics.PYB."""
         self.materialize()
         self._chain_ok = False
-        if self._downwash is not None:
-            self._downwash.invalidate_prebin()
         args = self.step_args()
-        args.action = self._action_ptr(action)
+        if self._caller_io:
+            args.options |= nat.OPT_CALLER_IO
+        args.action = self._action_ptr(action, self._caller_io)
+        if self._downwash is not None:
+            # the physics launch fills the next Env.step's neighbour grid from the new positions (the library keeps its
+            # own record of what was binned when, and bins afresh when anything moved the drones in between)
+            args.bin_next = self._downwash.bin_next_ptr()
         # the observation rows are written by the physics launch itself (BaseAviary.py:547-555 returns them from step)
         obs = self._obs_tensor()
         args.obs_out, args.obs_width = obs.data_ptr(), 16 + self.n_act
@@ -339,7 +350,8 @@ class CtrlAviary:
         self._use_last_action = True
         self.step_counter += self.AGGR_PHY_STEPS
         self._env_steps += 1
-        return self._computeObs(self._rows_to_caller(obs)), self._computeReward(), self._computeDone(), self._computeInfo()
+        return (self._computeObs(obs if self._caller_io else self._rows_to_caller(obs)), self._computeReward(),
+                self._computeDone(), self._computeInfo())
 
     def step_fused(self, targets, control_timestep: Optional[float] = None, action=None, n_steps: int = 1):
         """One launch = ``env.step(action)`` followed by ``computeControl`` for every drone:
@@ -474,19 +486,20 @@ class CtrlAviary:
                     targets.offsets.data_ptr() if targets.offsets is not None else 0, targets.n_wp)
         return (targets.data.data_ptr(), tuple(targets.data.shape))
 
-    def _action_ptr(self, action) -> int:
+    def _action_ptr(self, action, caller_order: bool = False) -> int:
         """Device pointer of the action as SoA [n_act][n_pad].  A tensor that already IS such an array (the command
-        a bound ``INDIControl`` returns is the transposed view of one) is passed through without a copy."""
+        a bound ``INDIControl`` returns is the transposed view of one) is passed through without a copy.
+        ``caller_order``: the launch indexes the action by the caller's drone number itself (DSIM_OPT_CALLER_IO)."""
         tok = getattr(self, "_cmd_token", None)
-        if tok is not None and action is tok[0] and action._version == tok[1]:
+        if not caller_order and tok is not None and action is tok[0] and action._version == tok[1]:
             return tok[2].data_ptr()     # the command a bound controller just returned: its storage-order array, no copy
-        if self.order is None and torch.is_tensor(action) and action.is_cuda and action.dtype == torch.float32:
+        if (self.order is None or caller_order) and torch.is_tensor(action) and action.is_cuda and action.dtype == torch.float32:
             base = action.T if (action.ndim == 2 and action.shape[1] == self.n_act and action.shape[0] != self.n_act) else action
             if (base.ndim == 2 and base.shape[0] == self.n_act and base.stride() == (self.state.n_pad, 1)
                     and base.shape[1] <= self.state.n_pad and base.shape[1] >= self.NUM_DRONES):
                 self._action_keep = action
                 return base.data_ptr()
-        self._load_action(action)
+        self._load_action(action, caller_order)
         return self._action_buf.data_ptr()
 
     def _obs_tensor(self) -> torch.Tensor:
@@ -581,7 +594,7 @@ class CtrlAviary:
         nat.check(self.ctx.lib.dsim_physics(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
                                             self.state.view(), self._last_action.data_ptr(), ctypes.byref(args)))
 
-    def _load_action(self, action) -> None:
+    def _load_action(self, action, caller_order: bool = False) -> None:
         n = self.NUM_DRONES
         if isinstance(action, dict):                      # CtrlAviary.py:258-263 format
             a = np.zeros((self.n_act, n), dtype=np.float32)
@@ -593,7 +606,7 @@ class CtrlAviary:
             t = torch.as_tensor(action, dtype=torch.float32, device=self.ctx.device)
             if t.shape == (n, self.n_act):
                 t = t.T
-        self._action_buf[:, :n] = t if self.order is None else self.order.to_storage(t, 1)
+        self._action_buf[:, :n] = t if (self.order is None or caller_order) else self.order.to_storage(t, 1)
 
     def _rows_to_caller(self, rows: torch.Tensor) -> torch.Tensor:
         """Observation rows as the kernels write them (one per storage slot) -> the caller's numbering."""
@@ -601,12 +614,18 @@ class CtrlAviary:
 
     def observe(self) -> torch.Tensor:
         """[N, 16+n_act] rows of _getDroneStateVector (BaseAviary.py:780-790), on device."""
-        self._obs_tensor()
+        buf = self._obs_tensor()
+        if self.order is not None:
+            # (rows per storage slot first, then gathered into the caller's numbering: not through the buffer Env.step
+            # hands out, which holds the caller's numbering already when the run kernels wrote it)
+            if getattr(self, "_obs_slots", None) is None:
+                self._obs_slots = torch.zeros_like(buf)
+            buf = self._obs_slots
         self._join_fallback()
         la = self._last_action.data_ptr() if self._use_last_action else None
         nat.check(self.ctx.lib.dsim_observe(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
-                                            self.state.view(), la, self._obs_buf.data_ptr(), 16 + self.n_act))
-        return self._rows_to_caller(self._obs_buf)
+                                            self.state.view(), la, buf.data_ptr(), 16 + self.n_act))
+        return self._rows_to_caller(buf)
 
     def neighbors(self, max_k: Optional[int] = None):
         """Fleet-scale form of the observation's ``neighbors`` entry (BaseAviary._getAdjacencyMatrix,

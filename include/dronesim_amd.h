@@ -162,6 +162,16 @@ enum {
                                        contact pipeline cannot be restated or pinned here.  Served
                                        by the k_step_plane / k_physics_plane / k_adaptor kernels; every airframe kind;
                                        not combined with DSIM_OPT_CHAINED.                                            */
+  /* -- numbering of the per-drone arrays beside the state (dsim_physics, dsim_control2) -------------------------------------
+   * A host class may STORE a heterogeneous fleet type-major (runs) behind its caller's numbering (dsim_step_args.drone_id).
+   * With this bit the per-drone arrays those two entry points take and return besides the state and target views — the
+   * action, obs_out, cmd_out, pos_e_out, yaw_e_out — are indexed by the CALLER's drone number drone_id[i] instead of the
+   * storage slot i: Env.step() returns its observation rows and computeControl() its triple in the caller's order with no
+   * second pass over them (BaseAviary.py:547-555, INDIControl.py:227), and the command goes from the one to the other as
+   * it is.  last_action_out stays in storage order (it is the env's own memory, read back by dsim_observe).  Needs
+   * drone_id and a fleet that the run kernels serve (runs given or one type; no noise replay, no drag / ground / plane
+   * option): DSIM_E_UNSUPPORTED otherwise.                                                                            */
+  DSIM_OPT_CALLER_IO   = 1u << 14,
   /* -- scheduling (results do not depend on it) ---------------------------------------------------------------------- */
   DSIM_OPT_DEFER_FALLBACK = 1u << 11 /* dsim_step / dsim_control2 of a table with a morphing hexa do NOT launch the deferred
                                        WLS fallback pass behind the step; the caller launches dsim_wls_fallback itself —

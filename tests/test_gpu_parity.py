@@ -2035,8 +2035,9 @@ def test_env_step_fused_observation_and_zero_copy_command(gpu, layout, noise):
 
 
 def test_fused_observation_general_kernels_agree(gpu):
-    """dsim_physics with obs_out on fleets that take the general kernel (ragged size, mixed types): the rows equal
-    dsim_observe's."""
+    """dsim_physics with obs_out on a ragged mixed fleet handed over interleaved (stored type-major: the run kernels write
+    the rows themselves, in the caller's numbering): the rows equal dsim_observe's — the copies bit for bit, the Euler angles
+    (evaluated by another kernel's instruction stream) within rounding."""
     from dronesim_amd.envs import CtrlAviary
     n = 333
     rng = np.random.default_rng(19)
@@ -2047,7 +2048,10 @@ def test_fused_observation_general_kernels_agree(gpu):
     act = torch.from_numpy(rng.uniform(0.3, 0.6, (n, 6)).astype(np.float32)).to(env.ctx.device)
     for _ in range(3):
         obs, *_ = env.step(act)
-        np.testing.assert_array_equal(obs.cpu().numpy(), env.observe().cpu().numpy())     # both from k_observe here
+        a_, b_ = obs.cpu().numpy(), env.observe().cpu().numpy()
+        cp = [c for c in range(22) if not 7 <= c < 10]
+        np.testing.assert_array_equal(a_[:, cp], b_[:, cp])
+        np.testing.assert_allclose(a_[:, 7:10], b_[:, 7:10], rtol=0, atol=2e-6)
     O = orc.Oracle(env.types)
     last = np.zeros((n, 6)); last[:, :] = act.double().cpu().numpy(); last[tid == 0, 4:6] = 0.0
     _check_obs_rows("fused_obs_general", O, obs.double().cpu().numpy(), env.state.rigid_aos(), last, tid, env.types)

@@ -167,8 +167,10 @@ def test_reordered_fleet_waypoints_neighbours_controller_and_logger(gpu, golden_
         env._ctrl_out = (cmd.cpu().numpy(), pos_e.cpu().numpy(), yaw_e.cpu().numpy())
         obs, _, _, _ = env.step(cmd)
         env._obs_after = obs.state.cpu().numpy()                      # (neighbors_k > 0: a FleetObs)
-        if env.order is not None:
+        if env.order is not None and not env._caller_io:
             assert env._cmd_token is not None and env._cmd_token[0] is cmd
+        if env._caller_io:          # the command came back in the caller's numbering straight from the launch: a view, no copy
+            assert cmd.data_ptr() == ctrl._cmd.data_ptr()
     for a_, c_ in zip(env_a._ctrl_out, env_c._ctrl_out):
         np.testing.assert_allclose(a_, c_, rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(env_a._ctrl_out[1], f32(xyz) - rc[:, 0:3], rtol=0, atol=2e-4)      # pos_e really is per caller drone
