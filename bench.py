@@ -46,6 +46,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBPS = 6290.0    # MI355X_MICROARCH.md: the float4-copy rate that guide measured (what a kernel can reach)
 BYTES_PER_DRONE_STEP = 232      # read 13+11+10 floats, write 13+11 floats (quad, per-drone targets)
+WATCHDOG_RC = 3                 # exit code of every rank when a collective section hangs (Watchdog)
 MIN_TIMED_S = 0.05              # the timed region is repeated (whole K-step regions) until it covers this much
 WORKLOADS = ["config2x1024", "config2", "config3", "config4", "config5", "hexa", "mixed", "mixed_type_major", "two_call_loop"]
 
@@ -450,10 +451,41 @@ def config5_all_ranks(a, local, rank, world, dist, red_dev, barrier, options):
     return e
 
 
+def rccl_selftest(dist, fl, red_dev):
+    """World size 1 on the real backend: the device-side collectives the N-rank path uses, each checked — the all-gather of
+    positions of the downwash term's all-gather form (downwash.Downwash._gather, its RCCL branch), and ONE grouped batch
+    of isend / irecv on slices of persistent halo buffers (the wire of downwash.HaloWire), here from the rank to itself."""
+    import torch
+    from dronesim_amd import _native as nat
+    from dronesim_amd.downwash import Downwash
+    env = fl.env
+    dev = env.ctx.device
+    out = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+    dw = Downwash(env.ctx, env.state, env._type_id, dist)
+    dw._counts = [env.state.n]
+    pos = env.state.raw_fields(0, 3).contiguous()
+    got = dw._gather(pos)
+    out["all_gather_positions_ok"] = bool(torch.equal(got, pos)) and dist.get_backend() == "nccl"
+    cap = 4096
+    send = torch.arange(nat.HALO_HDR + 3 * cap, dtype=torch.float32, device=dev)
+    recv = torch.zeros_like(send)
+    k = nat.HALO_HDR + 3 * 1024                                  # a message shorter than its buffer, as a halo message is
+    ops = [dist.P2POp(dist.isend, send[:k], 0), dist.P2POp(dist.irecv, recv[:k], 0)]
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    torch.cuda.synchronize()
+    out["grouped_isend_irecv_ok"] = bool(torch.equal(recv[:k], send[:k])) and float(recv[k:].abs().sum()) == 0.0
+    t = torch.tensor([3.0, 1.0], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out["all_reduce_on"] = str(t.device)
+    out["ipc_mode_legacy_env"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    return out
+
+
 class Watchdog:
     """A section that every rank must finish together (a collective workload behind the headline): if it does not within
     `seconds`, rank 0 prints the line it already has — the headline measurement must not be lost to a hang in an extra —
-    and every rank leaves with exit code 0."""
+    and every rank leaves with a NON-ZERO exit code (WATCHDOG_RC): a hung collective is a failed run, whatever was printed."""
 
     def __init__(self, seconds, rank, line):
         import threading
@@ -466,7 +498,7 @@ class Watchdog:
         if self.rank == 0:
             self.line["config5_all_ranks"] = {"error": f"did not finish within {self.seconds} s; abandoned"}
             print(json.dumps(self.line), flush=True)
-        os._exit(0)
+        os._exit(WATCHDOG_RC)
 
     def __enter__(self):
         self.t.start()
@@ -538,7 +570,7 @@ def measure_variant(torch, local, layout, seed, steps, name, nf, rep, sub, wp, n
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     a = parse(argv)
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (a.gpus > 1 or os.environ.get("DSIM_BENCH_FORCE_DIST", "0") != "0") and "WORLD_SIZE" not in os.environ and not a.dry_run:
         # not started by a launcher: start the ranks as children — nothing in THIS process has touched the GPU
         sys.exit(launch_ranks(a, argv))
     rank = int(os.environ.get("RANK", "0"))
@@ -561,7 +593,10 @@ def main(argv=None):
     if rank == 0:
         graft.build()
     local = local % max(1, torch.cuda.device_count())
-    if world > 1:
+    # DSIM_BENCH_FORCE_DIST=1: the process group is made at world size 1 too, so that a one-GPU box runs every collective
+    # of the N-rank path once on its real backend (RCCL): barrier, the MAX reduction, the per-rank all-gather
+    force_dist = os.environ.get("DSIM_BENCH_FORCE_DIST", "0") != "0" and "RANK" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         if backend == "nccl":
@@ -674,6 +709,8 @@ def main(argv=None):
             out["placement"] = list(fl.env.ctx.placement_log)
         if exchange is not None:
             out["exchange"] = exchange
+        if force_dist and world == 1:
+            out["rccl_selftest"] = rccl_selftest(dist, fl, red_dev)
         if a.mirror_peer:
             out["config"]["synthetic_neighbour"] = ("--mirror-peer: ONE rank whose neighbour is its own reflection across the slab edge "
                                                     "(MirrorDist: a device-side wire); traces the exchange path, not a multi-GPU run")

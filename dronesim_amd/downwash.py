@@ -82,8 +82,8 @@ class HaloWire:
     batch of isend / irecv moves the buffers.  Message sizes are fixed on the host (capacities with headroom); the
     count travels in the header.  Only `resize` synchronises the host, every `resize_every` steps: it all-gathers the
     boxes (seeding the headers), lets `_pack` count what would travel, all-gathers the counts and re-makes the capacities;
-    a pair of ranks whose boxes are further apart than cut-off + v_clamp x dt_env x resize_every cannot meet before the
-    next resize and exchanges nothing.  A selection that outgrows its capacity in between is dropped AND counted
+    a pair of ranks whose boxes are further apart than cut-off + 2 x v_clamp x dt_env x resize_every (both may move, towards
+    each other) cannot meet before the next resize and exchanges nothing.  A selection that outgrows its capacity in between is dropped AND counted
     (`_overflow`): 0 certifies that nothing was missed; a non-zero count raises at the next resize."""
 
     def __init__(self, dist, device, cap: int, dt_env: float, v_clamp: float, cutoff: float = CUTOFF, resize_every: int = 128,
@@ -162,7 +162,8 @@ class HaloWire:
         self._all_gather(self.bounds_all, self.bounds_dev)
         b = self.bounds_all.cpu().numpy()
         self.bounds_host = b
-        far = self.cutoff + self.v_clamp * self.dt_env * self.resize_every
+        # (BOTH boxes may move towards each other at the clamp: the gap closes by up to 2 v_clamp dt_env per step)
+        far = self.cutoff + 2.0 * self.v_clamp * self.dt_env * self.resize_every
         talk = [False] * nat.MAX_PEERS
         for p in range(self.world):
             if p != self.rank:

@@ -7,6 +7,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 
 def _run(args, env=None, timeout=240):
@@ -58,16 +60,19 @@ def test_eight_ranks_dry_run_config5():
 
 def test_watchdog_saves_the_headline_when_an_extra_section_hangs():
     """bench.py measures config 5 on all ranks BEHIND the headline of a multi-GPU run; if that collective section hangs,
-    rank 0 still prints the line it has and every rank leaves with exit code 0."""
+    rank 0 still prints the line it has — and every rank leaves with a NON-ZERO exit code: a hung collective must not
+    read as a successful run."""
     code = ("import sys, time, json; sys.path.insert(0, %r); import bench\n"
             "line = {'metric': 'm', 'value': 1.5}\n"
             "with bench.Watchdog(0.5, 0, line):\n"
             "    time.sleep(30)\n"
             "print('not reached')\n") % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
-    assert r.returncode == 0 and "not reached" not in r.stdout
+    import bench
+    assert bench.WATCHDOG_RC != 0
+    assert r.returncode == bench.WATCHDOG_RC and "not reached" not in r.stdout
     d = _json_line(r.stdout)
     assert d["value"] == 1.5 and "abandoned" in d["config5_all_ranks"]["error"]
     code2 = code.replace("bench.Watchdog(0.5, 0, line)", "bench.Watchdog(0.5, 3, line)")
     r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=60)
-    assert r.returncode == 0 and r.stdout.strip() == ""           # the other ranks leave quietly
+    assert r.returncode == bench.WATCHDOG_RC and r.stdout.strip() == ""           # the other ranks print nothing, and fail too

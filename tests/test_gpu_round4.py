@@ -389,3 +389,32 @@ def test_reordered_fleet_over_the_plane_is_translated_by_the_host(gpu):
         env.close()
     for a_, c_ in zip(out["auto"], out["caller"]):
         np.testing.assert_allclose(a_, c_, rtol=3e-4, atol=3e-5)
+
+
+def test_rccl_runs_at_world_size_one(gpu):
+    """The collective backend of the multi-GPU path (RCCL: torch.distributed backend "nccl") on the hardware that is here: a
+    child started by torch.distributed.run — one rank — makes the process group on the device, runs the default bench line
+    through its N-rank code path (barrier, MAX all-reduce and the per-rank all-gather on DEVICE tensors), then the
+    device-side all-gather of the downwash term's positions and one grouped isend / irecv batch on slices of halo-sized
+    buffers, and destroys the group.  Proves that the stack's RCCL loads and moves device memory here (and that
+    HSA_ENABLE_IPC_MODE_LEGACY=0 is what it wants); it is not a scaling measurement."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DSIM_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "config4", "--steps", "20",
+           "--warmup", "3", "--no-also", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["dist"]["backend"] == "nccl" and d["dist"]["world_size"] == 1 and d["n_gpus"] == 1
+    st = d["rccl_selftest"]
+    assert st["backend"] == "nccl" and st["all_gather_positions_ok"] and st["grouped_isend_irecv_ok"], st
+    assert st["all_reduce_on"].startswith("cuda")
+    assert d["value"] > 1e8

@@ -189,6 +189,66 @@ def test_halo_exchange_equals_allgather_gloo():
     assert out[0][1] < 300 + 300 and out[0][3] < 300                           # a strict subset travels
 
 
+def _approach_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from dronesim_amd import params
+    from dronesim_amd.downwash import gather_positions
+    from oracle import oracle as orc
+    n, vmax, dt, every = 200, 100.0, 1.0 / 240.0, 8
+    window = vmax * dt * every                              # what ONE box can travel between two resizes: 3.33 m
+    gap = 10.0 + 1.5 * window                               # further apart than cut-off + 1 window, closer than cut-off + 2 windows
+    rng = np.random.default_rng(7 + rank)
+    x0 = 0.0 if rank == 0 else 40.0 + gap
+    pos = np.stack([rng.uniform(x0, x0 + 40.0, n), rng.uniform(0, 20, n), rng.uniform(0.5, 8, n)])
+    pos[0, :20] = x0 + (40.0 if rank == 0 else 0.0)          # a row of drones right on the facing edge
+    O = orc.Oracle([params.builtin_type("robobee")])
+    halo = _cpu_halo_class()(dist, n, dt_env=dt, v_clamp=vmax, resize_every=every, slack=64)
+    ok, cross = True, 0
+    for step in range(every):                              # ONE window: no second resize comes to the rescue
+        loc = torch.from_numpy(pos.astype(np.float32))
+        halo.pos, halo.vel = loc, torch.full((3, n), float(vmax))
+        halo.exchange()
+        got = torch.cat([loc, halo.received_positions()], dim=1)
+        world_pos = gather_positions(loc, dist)
+        rigid = np.zeros((n, 13)); rigid[:, 0:3] = loc.numpy().T; rigid[:, 6] = 1.0
+        f_halo = O.downwash(rigid, got.numpy().T.astype(np.float64))
+        f_all = O.downwash(rigid, world_pos.numpy().T.astype(np.float64))
+        ok = ok and np.allclose(f_halo, f_all, rtol=1e-12, atol=0)
+        # (the P8 term of a pair 9-10 m apart is below fp64 resolution of the local sum: the force alone would not notice a
+        # dropped pair — so the SET is checked: every remote drone within the cut-off of a local one must have arrived)
+        b, e = rank * n, (rank + 1) * n
+        remote = torch.cat([world_pos[:, :b], world_pos[:, e:]], dim=1).numpy()
+        d = np.hypot(remote[0][None, :] - loc.numpy()[0][:, None], remote[1][None, :] - loc.numpy()[1][:, None])
+        need = remote[:, (d < 10.0).any(0)]
+        have = set(map(tuple, halo.received_positions().numpy().T.tolist()))
+        ok = ok and all(tuple(c) in have for c in need.T.tolist())
+        cross += need.shape[1]                              # remote drones that really are inside the cut-off of a local one
+        pos[0] += (1.0 if rank == 0 else -1.0) * vmax * dt    # both slabs rush towards each other at the clamp
+    out[rank] = (ok, cross, halo.messages(), halo.lost)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_slabs_approaching_from_both_sides_keep_talking_gloo():
+    """two ranks whose boxes are cut-off + 1.5 windows apart at a resize (a window = what one box can travel at the
+    velocity clamp until the next resize) close to within the cut-off before it when BOTH move: they must be talking —
+    the silence threshold is cut-off + TWO windows — and the halo force equals the all-gather force at every step."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_approach_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        ok, cross, peers, lost = out[r]
+        assert ok and lost == 0, (r, out[r])
+        assert peers == [1 - r]
+    assert out[0][1] + out[1][1] > 0          # the case has teeth: pairs across the ranks did come inside the cut-off
+
+
 def _uneven_gather_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
