@@ -64,15 +64,12 @@ def parse(argv=None):
     p.add_argument("--no-also", action="store_true")
     p.add_argument("--stream", choices=["auto", "on", "off"], default="auto",
                    help="nontemporal state accesses: DSIM_OPT_STREAM_ON/_OFF (A/B knob; default: the library's size rule)")
-    p.add_argument("--generic-mixed", action="store_true", help="mixed fleets: DSIM_OPT_GENERIC_MIXED (A/B knob)")
-    p.add_argument("--mixed-v1", action="store_true", help="mixed fleets: DSIM_OPT_MIXED_V1, the round-1 staged kernel (A/B knob)")
-    p.add_argument("--mixed-ring", action="store_true", help="mixed fleets: DSIM_OPT_MIXED_RING, the persistent LDS-DMA ring (A/B knob)")
-    p.add_argument("--mixed-v3", action="store_true", help="mixed fleets: DSIM_OPT_MIXED_V3, the three-wave LDS-DMA-staged form (A/B knob)")
+    p.add_argument("--variant", default="", choices=["", "generic", "mixed-v1", "mixed-ring", "mixed-v3", "runs-separate"],
+                   help="A/B knob of a measured-and-rejected kernel form; needs --lib pointing at a build made with "
+                        "-DDSIM_WITH_VARIANTS (tools/variants/, tools/build_variants.sh): the product library ignores it")
     p.add_argument("--slab-m", type=float, default=128.0,
                    help="config5: width of a rank's slab; 128 = the config's density, 1024 = round 1's definition of the line")
     p.add_argument("--lib", default=None, help="a differently-tuned build of libdronesim_amd.so (A/B runs)")
-    p.add_argument("--runs", choices=["auto", "one", "separate"], default="auto",
-                   help="type-major storage: DSIM_OPT_RUNS_ONE_LAUNCH / _SEPARATE (A/B knob)")
     p.add_argument("--mirror-peer", action="store_true",
                    help="config5 on ONE rank with a synthetic mirrored neighbour (MirrorDist): traces the device-paced exchange path")
     p.add_argument("--replicas", type=int, default=0, help="override the number of vectorised env replicas (A/B runs)")
@@ -613,11 +610,8 @@ def main(argv=None):
     from dronesim_amd import _native as nat
     nat.load(a.lib)
     options = {"auto": 0, "on": nat.OPT_STREAM_ON, "off": nat.OPT_STREAM_OFF}[a.stream]
-    options |= nat.OPT_GENERIC_MIXED if a.generic_mixed else 0
-    options |= nat.OPT_MIXED_V1 if a.mixed_v1 else 0
-    options |= nat.OPT_MIXED_RING if a.mixed_ring else 0
-    options |= nat.OPT_MIXED_V3 if a.mixed_v3 else 0
-    options |= {"auto": 0, "one": nat.OPT_RUNS_ONE_LAUNCH, "separate": nat.OPT_RUNS_SEPARATE}[a.runs]
+    options |= {"": 0, "generic": nat.VAR_GENERIC, "mixed-v1": nat.VAR_MIXED_V1, "mixed-ring": nat.VAR_MIXED_RING,
+                "mixed-v3": nat.VAR_MIXED_V3, "runs-separate": nat.VAR_RUNS_SEPARATE}[a.variant]
     barrier = (lambda: dist.barrier()) if dist else None
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
@@ -655,12 +649,12 @@ def main(argv=None):
     # its step is a chain of kernels (neighbour query, step + grid binning, WLS fallback), timed as a whole
     bytes_per = {"config5": 253, "hexa": 248, "mixed": 241, "mixed_type_major": 241,
                  "two_call_loop": TWO_CALL_BYTES[a.two_call_kind][0]}.get(a.workload, BYTES_PER_DRONE_STEP)
-    mixed_k = ("k_step_lean" if a.generic_mixed else "k_step_mixed" if a.mixed_v1 else "k_step_mixed2" if a.mixed_ring
-               else "k_step_mixed3" if (a.mixed_v3 or a.layout != "tile64") else "k_step_mixed4")
+    mixed_k = {"generic": "k_step_lean", "mixed-v1": "k_step_mixed", "mixed-ring": "k_step_mixed2", "mixed-v3": "k_step_mixed3"}.get(
+        a.variant, "k_step_mixed3" if a.layout != "tile64" else "k_step_mixed4")
     if fl.env.order is not None:
         # the interleaved fleet is STORED type-major behind the caller's numbering (fleet.StorageOrder): one single-type
         # launch per type; + 4 B per drone-step for the caller's index that keys the noise stream
-        mixed_k = "k_step_run x2 (type-major storage behind the caller's interleaved order)"
+        mixed_k = "k_step_runs (type-major storage behind the caller's interleaved order, all runs in one launch)"
     kernel = {"config5": f"k_dw_query_cell, {mixed_k} (+ fused grid binning), k_wls_fallback",
               "hexa": "k_step_hexa (+ k_wls_fallback)",
               "mixed": f"{mixed_k} (+ k_wls_fallback)",

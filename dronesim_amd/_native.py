@@ -22,18 +22,19 @@ EXPORTS = (
     "dsim_halo_pack", "dsim_downwash_workspace_halo",
 )
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_PEERS = 8
 HALO_HDR = 8           # header floats of a halo message (DSIM_HALO_HDR)
 DW_ALL, DW_LOCAL, DW_HALO_BIN, DW_HALO_QUERY = 0, 1, 2, 3
 NF_QUAD, NF_HEXA, NT = 24, 26, 10
 OPT_DRAG, OPT_GROUND, OPT_BCAST_TGT, OPT_CHAINED = 1, 2, 4, 8
-OPT_STREAM_ON, OPT_STREAM_OFF, OPT_GENERIC_MIXED, OPT_MIXED_V1, OPT_MIXED_RING, OPT_MIXED_V3 = 16, 32, 64, 128, 256, 512   # tuning knobs
-TUNING_MASK = (OPT_STREAM_ON | OPT_STREAM_OFF | OPT_GENERIC_MIXED | OPT_MIXED_V1 | OPT_MIXED_RING | OPT_MIXED_V3
-               | (1 << 12) | (1 << 13))   # (results do not depend on them)
+OPT_STREAM_ON, OPT_STREAM_OFF = 16, 32      # tuning knobs (results do not depend on them)
+# A/B knobs of measured-and-rejected kernel forms: honoured only by a library built with -DDSIM_WITH_VARIANTS
+# (tools/variants/dsim_variants.inc, tools/build_variants.sh); the product library ignores them
+VAR_GENERIC, VAR_MIXED_V1, VAR_MIXED_RING, VAR_MIXED_V3, VAR_RUNS_SEPARATE = 64, 128, 256, 512, 1 << 13
+TUNING_MASK = OPT_STREAM_ON | OPT_STREAM_OFF | VAR_GENERIC | VAR_MIXED_V1 | VAR_MIXED_RING | VAR_MIXED_V3 | VAR_RUNS_SEPARATE
 OPT_PLANE = 1 << 10        # ground-plane contact (product-defined model, oracle/dsim_oracle.c:orc_plane_contact)
 OPT_DEFER_FALLBACK = 1 << 11   # the caller launches dsim_wls_fallback itself (scheduling only)
-OPT_RUNS_ONE_LAUNCH, OPT_RUNS_SEPARATE = 1 << 12, 1 << 13     # tuning knobs of type-major storage
 OPT_CALLER_IO = 1 << 14    # dsim_physics / dsim_control2: action, rows, command, errors indexed by drone_id[i] (the caller's numbering)
 ADAPT_VELOCITY, ADAPT_RPYT = 0, 1
 QUERY_WLS_FALLBACKS, QUERY_WLS_FAILURES, QUERY_GROUND_CONTACTS, QUERY_HALO_OVERFLOW = 0, 1, 2, 3

@@ -623,156 +623,12 @@ __global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_step_lean(StepK a) {
   DSIM_FOR_MY_TYPE(UNIFORM, a, i, (step_gen_body<NOISE, NACT, false>(T, a, i, ad)));
 }
 
-// Mixed fleets, plain stepping (stored cmd as the action, one Env.step per launch).  The tile is partitioned
-// by type (above) and STAGED THROUGH LDS: every lane loads the fields of its natural drone (whole cache
-// lines per wave, streaming) and writes them to the LDS column of the slot that will process that drone;
-// after the barrier each wave reads its columns and runs the complete law of ITS type's kind — compiled as
-// two separate bodies, quads of a 6-actuator table touch 24 fields, not 26 — writes the results back to its
-// columns, and after a second barrier the natural lanes store them, coalesced again.  36 KB of LDS per
-// 256-drone tile; every line of the state crosses HBM once per direction.
-// (Measured and rejected on MI355X, 4.2 M drones, even index quad / odd index hexa: gathering the permuted
-// drones straight from global memory — the half-used lines are evicted between the two waves that share
-// them, 322 us, no better than no partition at all, 414 us with nontemporal loads; one launch per type with
-// the other types' waves retiring at once, 490 us: every line is pulled once per launch; compute waves storing their
-// results straight to global memory — half-filled lines from two waves — instead of returning them through LDS,
-// which would save the second barrier: 275 vs 236 us.)
-#define DSIM_STAGE_FIELDS 36
-#ifndef DSIM_MIXED_WAVES
-#define DSIM_MIXED_WAVES 3
-#endif
-template <bool HEXA, bool NOISE, int TILE, bool S1>
-__device__ __forceinline__ void staged_body(const DevType& T, const StepK& a, long long i,
-                                            float (*stage)[TILE], unsigned t, bool active) {
-  constexpr int NA = HEXA ? 6 : 4;
-  Rigid s;
-  CtrlMem<NA> m;
-  Target tg;
-  s.pos = v3(stage[0][t], stage[1][t], stage[2][t]);
-  s.q = Q4{stage[3][t], stage[4][t], stage[5][t], stage[6][t]};
-  s.vel = v3(stage[7][t], stage[8][t], stage[9][t]);
-  s.w = v3(stage[10][t], stage[11][t], stage[12][t]);
-  m.last_vel = v3(stage[13][t], stage[14][t], stage[15][t]);
-  m.last_rates = v3(stage[16][t], stage[17][t], stage[18][t]);
-  m.last_thrust = stage[19][t];
-#pragma unroll
-  for (int j = 0; j < NA; ++j) m.cmd[j] = stage[20 + j][t];
-  tg.pos = v3(stage[26][t], stage[27][t], stage[28][t]);
-  tg.vel = v3(stage[29][t], stage[30][t], stage[31][t]);
-  tg.acc = v3(stage[32][t], stage[33][t], stage[34][t]);
-  tg.yaw = stage[35][t];
-  V3 ext = v3(0, 0, 0);
-  if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
-  V3 pos_e;
-  float yaw_e;
-  if constexpr (HEXA) {
-    hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
-    ground_watch(T, s, a.fb.counters, active && i < a.n);
-    indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, active ? i : -1LL);
-  } else {
-    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
-    ground_watch(T, s, a.fb.counters, active && i < a.n);
-    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  }
-  if (!active) return;
-  stage[0][t] = s.pos.x; stage[1][t] = s.pos.y; stage[2][t] = s.pos.z;
-  stage[3][t] = s.q.x; stage[4][t] = s.q.y; stage[5][t] = s.q.z; stage[6][t] = s.q.w;
-  stage[7][t] = s.vel.x; stage[8][t] = s.vel.y; stage[9][t] = s.vel.z;
-  stage[10][t] = s.w.x; stage[11][t] = s.w.y; stage[12][t] = s.w.z;
-  stage[13][t] = m.last_vel.x; stage[14][t] = m.last_vel.y; stage[15][t] = m.last_vel.z;
-  stage[16][t] = m.last_rates.x; stage[17][t] = m.last_rates.y; stage[18][t] = m.last_rates.z;
-  stage[19][t] = m.last_thrust;
-#pragma unroll
-  for (int j = 0; j < NA; ++j) stage[20 + j][t] = m.cmd[j];
-}
-// WT = waves per workgroup = 2 natural waves (the tile is 128 drones) + one spare wave per additional type of the
-// table: every type's drones start at a wave boundary of the slot space, so EVERY wave holds one type and runs
-// one law in uniform control flow with no loop around it (a wave whose type's run ends inside it idles the rest
-// of its lanes; spare waves without drones retire at once).  With the two laws inside a per-wave loop over the
-// types present (or under a per-lane branch) the compiler needs 168 VGPRs + 100-300 B of spills at 3 waves/SIMD —
-// loop-invariant code motion stretches live ranges over both laws; in straight-line form it needs 133.
-template <bool NOISE, bool NT, int WT, bool S1>
-__global__ __launch_bounds__(64 * WT, DSIM_MIXED_WAVES) void k_step_mixed(StepK a) {
-  constexpr int TILE = 128, SLOTS = 64 * WT;
-  __shared__ float stage[DSIM_STAGE_FIELDS][SLOTS];
-  __shared__ unsigned char slot_drone[SLOTS];
-  __shared__ unsigned short cnt[2][DSIM_MAX_TYPES];
-  const long long i0 = a.first + (long long)blockIdx.x * TILE;
-  const unsigned t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const bool nat_ok = t < TILE && i0 + t < a.n_pad;
-  const int nat_t = nat_ok ? min((int)a.type_id[i0 + t], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
-  unsigned rank = 0, c_mine = 0;
-  if (w < 2) {                                   // wave-uniform
-    const unsigned long long lt = (1ULL << lane) - 1ULL;
-#pragma unroll
-    for (int ty = 0; ty < DSIM_MAX_TYPES; ++ty) {
-      const unsigned long long mask = __ballot(nat_t == ty);
-      if (nat_t == ty) rank = (unsigned)__popcll(mask & lt);
-      if ((int)lane == ty) c_mine = (unsigned)__popcll(mask);
-    }
-    if (lane < DSIM_MAX_TYPES) cnt[w][lane] = (unsigned short)c_mine;
-  }
-  slot_drone[t] = 255;
-  __syncthreads();
-  // slot space: type ty owns ceil(count/64) whole waves, types in ascending order
-  unsigned dest = 0, acc_w = 0;
-  int wave_t = -1;
-#pragma unroll
-  for (int ty = 0; ty < DSIM_MAX_TYPES; ++ty) {
-    const unsigned c0 = cnt[0][ty], tot = c0 + cnt[1][ty], nw = (tot + 63) >> 6;
-    if (nat_t == ty) dest = acc_w * 64 + (w == 1 ? c0 : 0u) + rank;
-    if (w >= acc_w && w < acc_w + nw) wave_t = ty;
-    acc_w += nw;
-  }
-  const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
-  const unsigned sl = 4u * kv_lane(a.st, t), tl = 4u * kv_lane(a.tg, t);
-  float* const sb = a.st.base + kv_off(a.st, i0);
-  const float* const tb = a.tg.base + kv_off(a.tg, i0);
-  const bool nat_hexa = nat_ok && ((a.hexa_types >> nat_t) & 1u);
-  if (nat_ok) {
-    slot_drone[dest] = (unsigned char)t;
-#pragma unroll
-    for (int f = 0; f < 24; ++f) stage[f][dest] = ldg<NT>(sb + f * sfs, sl);
-    if (nat_hexa) { stage[24][dest] = ldg<NT>(sb + 24 * sfs, sl); stage[25][dest] = ldg<NT>(sb + 25 * sfs, sl); }
-#pragma unroll
-    for (int f = 0; f < 10; ++f) stage[26 + f][dest] = ldg<NT>(tb + f * tfs, tl);
-  }
-  __syncthreads();
-  wave_t = __builtin_amdgcn_readfirstlane(wave_t);
-  if (wave_t >= 0) {
-    const unsigned d = slot_drone[t];
-    const bool active = d != 255;                // idle lanes behind the end of the type's run: same law, nothing kept
-    const long long i = i0 + (active ? d : 0u);
-    if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
-    const DevType& T = a.types[wave_t];
-    if (T.kind == DSIM_DEV_KIND_HEXA) staged_body<true, NOISE, SLOTS, S1>(T, a, i, stage, t, active);
-    else staged_body<false, NOISE, SLOTS, S1>(T, a, i, stage, t, active);
-  }
-  __syncthreads();
-  if (nat_ok) {
-    const unsigned so = pin_lane_offset(sl);
-#pragma unroll
-    for (int f = 0; f < 24; ++f) stg<NT>(sb + f * sfs, so, stage[f][dest]);
-    if (nat_hexa) { stg<NT>(sb + 24 * sfs, so, stage[24][dest]); stg<NT>(sb + 25 * sfs, so, stage[25][dest]); }
-    if (a.bin.count && i0 + t < a.n)                                          // the next step's neighbour grid
-      bin_entry(a.bin, stage[0][dest], stage[1][dest], stage[2][dest], a.bin.local_offset + i0 + t);
-  }
-}
-
-// ---- mixed fleets, second form: LDS-DMA staging, software-pipelined tiles -------------------------------------------
-// The first form above is bound by memory-level parallelism: a workgroup has bytes in flight only during its load
-// phase (about a third of its life), and a CU holds ~30 KB in flight on average against the ~50 KB that 6 TB/s times
-// the loaded HBM latency asks for (63 % of the wave cycles parked at the barriers: profiles/r01f_sq_counters.json).
-// Here workgroups are PERSISTENT and walk the 128-drone tiles of the fleet with a two-deep LDS ring:
-//   * tile k+1 is brought in by LDS-DMA (global_load_lds_dword: no VGPR round trip, 256-byte rows land in LDS in
-//     NATURAL drone order) while tile k is being computed and stored — a whole tile per workgroup is in flight all
-//     the time (4 workgroups x 17 KB per CU);
-//   * the DMAs are issued by wave 2 (never a storing wave), so its vmcnt(0) before the barrier waits for the tile and
-//     for nothing else — the natural waves' result stores are never waited for;
-//   * the partition by type needs no LDS table and no barrier of its own: EVERY wave ballots the tile's type ids
-//     itself (masks in SGPRs), owns whole waves of one type as before, and lane r of a compute wave finds the r-th
-//     drone of its type by a select-the-r-th-set-bit on the two 64-bit masks, then gathers that drone's column;
-//   * results go back to the same columns, and after the second barrier the natural waves store whole rows.
-// Two barriers per tile instead of three, none of them behind an HBM round trip.
+// ---- mixed fleets kept in the caller's own order (storage = "caller") ----------------------------------------------------------
+// A tile is partitioned by type so that every wave runs ONE law in uniform control flow, and staged through LDS so that HBM
+// only ever sees whole lines.  Two forms serve the product: k_step_mixed4 (wave-tiled layout: two waves per tile, LDS-DMA
+// staging) and k_step_mixed3 (any other layout: row DMAs).  Round 1's VGPR-staged form and round 2's persistent LDS-DMA ring
+// were measured slower and live in tools/variants/ (built only with -DDSIM_WITH_VARIANTS).
+// select-the-r-th-set-bit: lane r of a compute wave finds the r-th drone of its type in the tile's ballot masks
 __device__ __forceinline__ unsigned nth_set_bit64(unsigned long long m, unsigned r) {     // position of the r-th (0-based) set bit
   unsigned pos = 0;
   unsigned w = (unsigned)m;
@@ -856,82 +712,6 @@ __device__ __forceinline__ void staged_body2(const DevType& T, const StepK& a, l
   for (int j = 0; j < NA; ++j) st[20 + j][c] = m.cmd[j];
 }
 #define DSIM_MIXED2_TYPES 4            // the launcher takes this form for tables of up to four types
-// Requires the wave-tiled layout for state and targets (block = 64, field_stride = 64: the rows of a block are
-// contiguous) and a 26-field state; the launcher falls back to the first form otherwise.
-template <bool NOISE, bool NT, int WT, bool S1>
-__global__ __launch_bounds__(64 * WT, 3) void k_step_mixed2(StepK a, long long n_tiles) {
-  constexpr int TILE = 128;
-  __shared__ __attribute__((aligned(16))) Stage64 ring[2][2];                // [slot][half]: 2 x 20 KB
-  const unsigned t = threadIdx.x, w = t >> 6, lane = t & 63;
-  if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
-  constexpr int AUX = NT ? 2 : 0;                                           // nt on the DMA reads of once-read state
-
-  // wave 2 brings tile `tile` into ring slot `buf`: per 64-drone half, 7 DMAs of 1 KB for the 26 state rows (6.5 KB,
-  // the last one half-masked) and 3 for the 10 target rows
-  auto issue_dma = [&](long long tile, int buf) {
-    const long long i0 = a.first + tile * TILE;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const long long ih = i0 + 64 * h;
-      if (ih >= a.n_pad) continue;                                          // wave-uniform: n_pad is a multiple of 64
-      dma_block64<AUX>(a.st.base + (ih >> 6) * a.st.block_stride, a.tg.base + (ih >> 6) * a.tg.block_stride,
-                       ring[buf][h], lane);
-    }
-  };
-
-  long long tile = blockIdx.x;
-  int buf = 0;
-  if (w == 2 && tile < n_tiles) issue_dma(tile, 0);
-  for (; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
-    const long long i0 = a.first + tile * TILE;
-    // ---- partition: every wave ballots both halves itself; the masks are wave-uniform (SGPRs)
-    const int t0 = (i0 + lane < a.n_pad) ? min((int)a.type_id[i0 + lane], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
-    const int t1 = (i0 + 64 + lane < a.n_pad) ? min((int)a.type_id[i0 + 64 + lane], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
-    int wave_t = -1;
-    unsigned d = 0;
-    bool active = false;
-    unsigned acc_w = 0;
-#pragma unroll
-    for (int ty = 0; ty < DSIM_MIXED2_TYPES; ++ty) {
-      const unsigned long long m0 = __ballot(t0 == ty), m1 = __ballot(t1 == ty);
-      const unsigned c0 = (unsigned)__popcll(m0), tot = c0 + (unsigned)__popcll(m1), nw = (tot + 63) >> 6;
-      if (w >= acc_w && w < acc_w + nw) {                           // wave-uniform: this wave runs type ty
-        wave_t = ty;
-        const unsigned r = (w - acc_w) * 64 + lane;
-        active = r < tot;
-        const unsigned rr = active ? r : 0u;
-        d = rr < c0 ? nth_set_bit64(m0, rr) : 64u + nth_set_bit64(m1, rr - c0);
-      }
-      acc_w += nw;
-    }
-    // ---- the tile has landed (only wave 2 has DMAs in flight; nobody waits for result stores)
-    if (w == 2) __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0), lgkmcnt / expcnt untouched
-    __syncthreads();
-    if (w == 2 && tile + gridDim.x < n_tiles) issue_dma(tile + gridDim.x, buf ^ 1);
-    // ---- compute: one type, one law per wave, uniform control flow
-    wave_t = __builtin_amdgcn_readfirstlane(wave_t);
-    if (wave_t >= 0) {
-      const long long i = i0 + d;
-      const DevType& T = a.types[wave_t];
-      if (T.kind == DSIM_DEV_KIND_HEXA) staged_body2<true, NOISE, S1>(T, a, i, ring[buf], d, active);
-      else staged_body2<false, NOISE, S1>(T, a, i, ring[buf], d, active);
-    }
-    __syncthreads();
-    // ---- natural lanes store whole rows
-    if (t < TILE && i0 + t < a.n_pad) {
-      const int nt_ = min((int)a.type_id[i0 + t], DSIM_MAX_TYPES - 1);       // (re-read: not kept live across the laws)
-      const bool nat_hexa = (a.hexa_types >> nt_) & 1u;
-      float* sp = a.st.base + ((i0 + t) >> 6) * a.st.block_stride + lane;
-      float (*rows)[64] = ring[buf][w].st;
-#pragma unroll
-      for (int f = 0; f < 24; ++f) stg<NT>(sp + f * 64, 0u, rows[f][lane]);
-      if (nat_hexa) { stg<NT>(sp + 24 * 64, 0u, rows[24][lane]); stg<NT>(sp + 25 * 64, 0u, rows[25][lane]); }
-      if (a.bin.count && i0 + t < a.n)
-        bin_entry(a.bin, rows[0][lane], rows[1][lane], rows[2][lane], a.bin.local_offset + i0 + t);
-    }
-  }
-}
-
 // ---- mixed fleets, third form: one tile per workgroup, LDS-DMA staging, partition by ballots ---------------------------
 // The ring above keeps a tile per workgroup in flight at all times, but its 37 KB of LDS leave a CU only 12 waves, and
 // with two barriers per tile three waves per SIMD cannot keep the vector pipe busy: it measured SLOWER (227 us) than the
@@ -1200,7 +980,7 @@ __global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void
 // All the runs of a type-major fleet in ONE launch: a workgroup finds its run by its index (constant-index walk over the
 // table, everything wave-uniform) and runs that run's law.  A 65 536-drone shard of BASELINE config 5 is two runs of 128
 // workgroups: 9.5 + 9.0 us as two dependent launches, 12.0 us as one; at 4 194 304 drones 160.1 against 165.2 us.  One
-// launch per run (k_step_run) stays as DSIM_OPT_RUNS_SEPARATE and for fleets with a single run.
+// launch per run (k_step_run) serves fleets with a single run (and more than DSIM_MAX_TYPES of them).
 struct RunTab {
   int blk0[DSIM_MAX_TYPES + 1];            // first workgroup of run q (blk0[q] = the total for q >= n_runs)
   long long first[DSIM_MAX_TYPES], lo[DSIM_MAX_TYPES], last[DSIM_MAX_TYPES];
@@ -2677,6 +2457,16 @@ static void to_dev(const dsim_type_params& p, DevType* d) {
   d->watch_below = (float)(p.collision_below + p.base_offset[2]);    // (the offset of the shipped hexa is along body z)
 }
 
+// measured-and-rejected kernel forms, for A/B builds only (tools/variants/; never in the product library)
+#ifdef DSIM_WITH_VARIANTS
+#include "../../tools/variants/dsim_variants.inc"
+#define DSIM_VARIANT_GENERIC(args) (((args)->options & DSIM_VAR_GENERIC) != 0)
+#define DSIM_VARIANT_RUNS_SEPARATE(args) (((args)->options & DSIM_VAR_RUNS_SEPARATE) != 0)
+#else
+#define DSIM_VARIANT_GENERIC(args) false
+#define DSIM_VARIANT_RUNS_SEPARATE(args) false
+#endif
+
 extern "C" {
 
 int dsim_abi_version(void) { return DSIM_ABI_VERSION; }
@@ -3026,7 +2816,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     // (measured on MI355X, 50 % quads + 50 % hexas: 65 536 drones 12.0 us against 9.5 + 9.0 us for two dependent launches;
     // 4 194 304 drones 160.1 against 165.2 us — the launch boundary between the runs costs more than the registers the
     // second law adds (83 VGPRs, 5 waves per SIMD, against 74 and 6): one launch is the default at every size)
-    const bool one_launch = !(args->options & DSIM_OPT_RUNS_SEPARATE) || args->action;
+    const bool one_launch = !DSIM_VARIANT_RUNS_SEPARATE(args) || args->action;
     if (n_runs <= DSIM_MAX_TYPES && (n_runs >= 2 || args->action) && one_launch) {
       // several runs (or an explicit action): one launch for all of them (k_step_runs)
       RunTab rt;
@@ -3119,7 +2909,9 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     a.first = first;
     const dim3 g(grid_for(a.n_pad - first));
     const bool lean = !args->action && !args->noise_replay && !a.wp_table && a.n_steps == 1 && !phys_opts;
-    if (lean && !uni && a.tg.base && ctx->n_types <= 4 && !(args->options & DSIM_OPT_GENERIC_MIXED)) {
+    if (lean && !uni && a.tg.base && ctx->n_types <= 4 && ctx->max_act == 6 && !DSIM_VARIANT_GENERIC(args)) {
+      // a heterogeneous fleet kept in the CALLER's own order (CtrlAviary(storage="caller"); storage="auto" stores it
+      // type-major and never comes here): the LDS-staged kernels, which partition every tile by type
       const bool nt = stream_policy(args, state.n_pad, 240.0);
       bool any_hexa = false;
       for (int t = 0; t < ctx->n_types; ++t) any_hexa |= ctx->h_types[t].kind == DSIM_KIND_HEXA6DOF;
@@ -3129,12 +2921,19 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
         a.fb.entries = ctx->d_fb;
       }
       if (first == 0) bin_next_prepare(ctx, n, args, &a, st_);      // (the whole fleet goes through this kernel)
-      // the LDS-DMA ring moves whole 1 KB row groups: it needs the wave-tiled layout [n/64][F][64] for the state
-      // (26 fields: a table with a morphing hexa) and for per-drone targets
-      const bool tiled = state.block == 64 && state.field_stride == 64 && ctx->max_act == 6 &&
+      // LDS-DMA of whole 1 KB row groups needs the wave-tiled layout [n/64][F][64] for the state (26 fields: a table with
+      // a morphing hexa) and for per-drone targets
+      const bool tiled = state.block == 64 && state.field_stride == 64 &&
                          !(args->options & DSIM_OPT_BCAST_TGT) && targets.block == 64 && targets.field_stride == 64;
-      if (tiled && !(args->options & (DSIM_OPT_MIXED_V1 | DSIM_OPT_MIXED_RING | DSIM_OPT_MIXED_V3))) {
-        // fourth form: two waves per tile, slot groups dealt round-robin (wave-tiled layout)
+#ifdef DSIM_WITH_VARIANTS
+      if (dsim_variants_mixed(ctx, st_, a, args, noise, nt, tiled, first)) {
+        if (any_hexa) fb_finish(ctx, a, st_);
+        bin_next_commit(ctx, n, args, a);
+        return (int)hipGetLastError();
+      }
+#endif
+      if (tiled) {
+        // two waves per tile, slot groups dealt round-robin (wave-tiled layout)
         const dim3 gm((unsigned)((a.n_pad - first + 127) / 128)), bm(128);
 #define DSIM_MIXED4_CASE3(S_, Y_, B_)                                                                             \
   do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed4<true, true, S_, Y_, B_>), gm, bm, 0, st_, a);            \
@@ -3148,59 +2947,23 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
 #undef DSIM_MIXED4_CASE
 #undef DSIM_MIXED4_CASE2
 #undef DSIM_MIXED4_CASE3
-        if (any_hexa) fb_finish(ctx, a, st_);
-        bin_next_commit(ctx, n, args, a);
-        return (int)hipGetLastError();
-      }
-      if (!(args->options & (DSIM_OPT_MIXED_V1 | DSIM_OPT_MIXED_RING)) && ctx->max_act == 6) {
-        // third form: one tile per workgroup, LDS-DMA staging in natural order, ballot partition
+      } else {
+        // any other layout: one tile per workgroup, row DMAs in natural order, ballot partition
         const dim3 gm((unsigned)((a.n_pad - first + 127) / 128));
-#define DSIM_MIXED3_CASE3(W_, S_, T_)                                                                             \
+#define DSIM_MIXED3_CASE2(W_, S_)                                                                                  \
   do { const dim3 bm(64 * W_);                                                                                    \
-       if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed3<true, true, W_, S_, T_>), gm, bm, 0, st_, a);        \
-                    else hipLaunchKernelGGL((k_step_mixed3<true, false, W_, S_, T_>), gm, bm, 0, st_, a); }        \
-       else { if (nt) hipLaunchKernelGGL((k_step_mixed3<false, true, W_, S_, T_>), gm, bm, 0, st_, a);             \
-              else hipLaunchKernelGGL((k_step_mixed3<false, false, W_, S_, T_>), gm, bm, 0, st_, a); } } while (0)
-#define DSIM_MIXED3_CASE2(W_, S_) do { if (tiled) DSIM_MIXED3_CASE3(W_, S_, true); else DSIM_MIXED3_CASE3(W_, S_, false); } while (0)
+       if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed3<true, true, W_, S_, false>), gm, bm, 0, st_, a);     \
+                    else hipLaunchKernelGGL((k_step_mixed3<true, false, W_, S_, false>), gm, bm, 0, st_, a); }     \
+       else { if (nt) hipLaunchKernelGGL((k_step_mixed3<false, true, W_, S_, false>), gm, bm, 0, st_, a);          \
+              else hipLaunchKernelGGL((k_step_mixed3<false, false, W_, S_, false>), gm, bm, 0, st_, a); } } while (0)
 #define DSIM_MIXED3_CASE(W_) do { if (a.substeps == 1) DSIM_MIXED3_CASE2(W_, true); else DSIM_MIXED3_CASE2(W_, false); } while (0)
         if (ctx->n_types == 2) DSIM_MIXED3_CASE(3); else if (ctx->n_types == 3) DSIM_MIXED3_CASE(4); else DSIM_MIXED3_CASE(5);
 #undef DSIM_MIXED3_CASE
 #undef DSIM_MIXED3_CASE2
-#undef DSIM_MIXED3_CASE3
-        if (any_hexa) fb_finish(ctx, a, st_);
-        bin_next_commit(ctx, n, args, a);
-        return (int)hipGetLastError();
       }
-      if (tiled && (args->options & DSIM_OPT_MIXED_RING)) {
-        // persistent workgroups, LDS-DMA ring (k_step_mixed2): 4 per CU (37 KB of LDS each)
-        const long long n_tiles = (a.n_pad - first + 127) / 128;
-        const long long cap = 4LL * ctx->n_cu;
-#define DSIM_MIXED2_CASE2(W_, S_)                                                                                \
-  do { const dim3 gm((unsigned)(n_tiles < cap ? n_tiles : cap)), bm(64 * W_);                                    \
-       if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed2<true, true, W_, S_>), gm, bm, 0, st_, a, n_tiles);  \
-                    else hipLaunchKernelGGL((k_step_mixed2<true, false, W_, S_>), gm, bm, 0, st_, a, n_tiles); }  \
-       else { if (nt) hipLaunchKernelGGL((k_step_mixed2<false, true, W_, S_>), gm, bm, 0, st_, a, n_tiles);       \
-              else hipLaunchKernelGGL((k_step_mixed2<false, false, W_, S_>), gm, bm, 0, st_, a, n_tiles); } } while (0)
-#define DSIM_MIXED2_CASE(W_) do { if (a.substeps == 1) DSIM_MIXED2_CASE2(W_, true); else DSIM_MIXED2_CASE2(W_, false); } while (0)
-        if (ctx->n_types == 2) DSIM_MIXED2_CASE(3); else if (ctx->n_types == 3) DSIM_MIXED2_CASE(4); else DSIM_MIXED2_CASE(5);
-#undef DSIM_MIXED2_CASE
-#undef DSIM_MIXED2_CASE2
-        if (any_hexa) fb_finish(ctx, a, st_);
-        bin_next_commit(ctx, n, args, a);
-        return (int)hipGetLastError();
-      }
-#define DSIM_MIXED_CASE2(W_, S_)                                                                                  \
-  do { const dim3 gm((unsigned)((a.n_pad - first + 127) / 128)), bm(64 * W_);                                    \
-       if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed<true, true, W_, S_>), gm, bm, 0, st_, a);            \
-                    else hipLaunchKernelGGL((k_step_mixed<true, false, W_, S_>), gm, bm, 0, st_, a); }            \
-       else { if (nt) hipLaunchKernelGGL((k_step_mixed<false, true, W_, S_>), gm, bm, 0, st_, a);                 \
-              else hipLaunchKernelGGL((k_step_mixed<false, false, W_, S_>), gm, bm, 0, st_, a); } } while (0)
-#define DSIM_MIXED_CASE(W_) do { if (a.substeps == 1) DSIM_MIXED_CASE2(W_, true); else DSIM_MIXED_CASE2(W_, false); } while (0)
-      if (ctx->n_types == 2) DSIM_MIXED_CASE(3); else if (ctx->n_types == 3) DSIM_MIXED_CASE(4); else DSIM_MIXED_CASE(5);
-#undef DSIM_MIXED_CASE
-#undef DSIM_MIXED_CASE2
       if (any_hexa) fb_finish(ctx, a, st_);
       bin_next_commit(ctx, n, args, a);
+      return (int)hipGetLastError();
     } else if (!six) {
       if (lean) DSIM_LAUNCH_GEN(k_step_lean, noise, uni, false, g, a, st_);
       else if (plane) DSIM_LAUNCH_GEN(k_step_plane, noise, uni, false, g, a, st_);

@@ -108,7 +108,7 @@ class CtrlAviary:
         self.ground_plane = bool(ground_plane)
         if self.ground_plane:
             self._phys_options |= nat.OPT_PLANE
-        # tuning bits handed to every call (nat.OPT_STREAM_ON/_OFF, nat.OPT_GENERIC_MIXED); results do not depend on them
+        # tuning bits handed to every call (nat.OPT_STREAM_ON/_OFF; the A/B knobs of a variants build); results do not depend on them
         self._tuning = int(options) & nat.TUNING_MASK
         self.neighbors_k = int(neighbors_k)
         if isinstance(drone_model, (str, DroneType)):

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DSIM_ABI_VERSION 5
+#define DSIM_ABI_VERSION 6
 #define DSIM_MAX_ACT 6     /* actuators per vehicle (quad 4, morphing hexa 6) */
 #define DSIM_MAX_TYPES 8
 
@@ -143,17 +143,8 @@ enum {
   DSIM_OPT_STREAM_ON   = 1u << 4,   /* force nontemporal (streaming) loads/stores of the state; default: on when one
                                        step's traffic exceeds what the 256 MB Infinity Cache keeps between steps   */
   DSIM_OPT_STREAM_OFF  = 1u << 5,   /* force the default cache policy                                              */
-  DSIM_OPT_GENERIC_MIXED = 1u << 6, /* mixed fleets: use the general per-lane-type kernel instead of the LDS-staged
-                                       one (A/B knob)                                                              */
-  DSIM_OPT_MIXED_V1    = 1u << 7,   /* mixed fleets: the round-1 form of the LDS-staged kernel (one tile per workgroup,
-                                       VGPR staging, three barriers) (A/B knob)                                    */
-  DSIM_OPT_MIXED_RING  = 1u << 8,   /* mixed fleets, wave-tiled layout: persistent workgroups with a two-deep LDS-DMA
-                                       ring (A/B knob; measured slower than the default form)                      */
-  DSIM_OPT_MIXED_V3    = 1u << 9,   /* mixed fleets, wave-tiled layout: the three-wave form of the LDS-DMA-staged kernel
-                                       (what other layouts get) instead of the two-wave one (A/B knob)             */
-  DSIM_OPT_RUNS_ONE_LAUNCH = 1u << 12, /* type-major storage (runs): all runs in ONE launch holding every law (the default;
-                                       the bit is kept for symmetry) (A/B knob)                                           */
-  DSIM_OPT_RUNS_SEPARATE = 1u << 13, /* ... one single-law launch per run (A/B knob)                                      */
+  /* (bits 6-9, 12, 13: A/B knobs of measured-and-rejected kernel forms; honoured only by a library built with
+   * -DDSIM_WITH_VARIANTS, tools/variants/dsim_variants.inc — the product ignores them)                              */
   /* -- physics (changes results) ------------------------------------------------------------------------------------ */
   DSIM_OPT_PLANE       = 1u << 10,  /* ground plane z = 0 with contact and friction, as the reference's world has
                                        (BaseAviary.py:680 loads plane.urdf, collisions on).  A PRODUCT-DEFINED contact

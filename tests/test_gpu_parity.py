@@ -533,15 +533,13 @@ def test_hexa_fused_step_vs_oracle(gpu, substeps, layout):
     ctx.close()
 
 
-@pytest.mark.parametrize("layout,form", [("soa", "default"), ("tile64", "default"), ("tile64", "v1"), ("soa", "v1"),
-                                         ("tile64", "ring"), ("tile64", "v3")])
+@pytest.mark.parametrize("layout,form", [("soa", "default"), ("tile64", "default")])
 @pytest.mark.parametrize("sub", [1, 2])
 def test_mixed_fleet_vs_oracle(gpu, sub, layout, form):
-    """Config 5 layout: even index robobee (quad INDI), odd index hexa_6DOF (6DOF INDI + WLS), one
-    type_id byte per drone; in-kernel noise on.  Every form of the mixed-fleet kernel: the default (LDS-DMA staging in
-    natural order, partition by ballots: two waves per tile with 1 KB DMAs on the wave-tiled layout, three waves with
-    row DMAs otherwise or under DSIM_OPT_MIXED_V3), round 1's staged kernel (DSIM_OPT_MIXED_V1) and the persistent
-    LDS-DMA ring (DSIM_OPT_MIXED_RING)."""
+    """Config 5 layout kept in the caller's own order: even index robobee (quad INDI), odd index hexa_6DOF (6DOF INDI +
+    WLS), one type_id byte per drone; in-kernel noise on.  Both forms of the mixed-fleet kernel the product ships (LDS-DMA
+    staging in natural order, partition by ballots): two waves per tile with 1 KB DMAs on the wave-tiled layout
+    (k_step_mixed4), three waves with row DMAs otherwise (k_step_mixed3).  (Rounds 1-2's other forms: tools/variants/.)"""
     nat, fleet = gpu
     n = 3000
     types = [params.builtin_type("robobee"), params.builtin_type("hexa_6DOF")]
@@ -558,7 +556,7 @@ def test_mixed_fleet_vs_oracle(gpu, sub, layout, form):
     tid_dev[:n] = torch.from_numpy(tid)
     seed, sidx = 99, 5
     a = _args(nat, sub, DT, float(np.float32(sub / 240)), seed=seed, step_index=sidx, type_id=tid_dev,
-              options={"default": 0, "v1": nat.OPT_MIXED_V1, "ring": nat.OPT_MIXED_RING, "v3": nat.OPT_MIXED_V3}[form])
+              options=0)
     nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n, st.view(), tg.view(), ctypes.byref(a)))
     O = orc.Oracle(types)
     nz = np.zeros((n, sub, 12))
@@ -2511,8 +2509,7 @@ def test_plane_with_waypoints_multi_step_launches_and_fused_rows(gpu, golden_dir
 @pytest.mark.parametrize("fleet_kind", ["quad", "hexa", "mixed"])
 def test_tuning_options_do_not_change_results(gpu, fleet_kind):
     """DSIM_OPT_STREAM_ON / _OFF select the streaming or the default cache policy of the same kernel: bit-identical
-    states.  DSIM_OPT_GENERIC_MIXED steps a mixed fleet with the general kernel instead of the staged one: the same
-    step within the step's bar."""
+    states.  The A/B knob bits of a variants build (tools/variants/) are IGNORED by the product library: same bits again."""
     nat, fleet = gpu
     names = {"quad": ["robobee"], "hexa": ["hexa_6DOF"], "mixed": ["robobee", "hexa_6DOF"]}[fleet_kind]
     types = [params.builtin_type(m) for m in names]
@@ -2523,7 +2520,8 @@ def test_tuning_options_do_not_change_results(gpu, fleet_kind):
     if tid is not None:
         mem[tid == 0, 11:13] = 0.0
     out = {}
-    for name, opt in (("on", nat.OPT_STREAM_ON), ("off", nat.OPT_STREAM_OFF), ("generic", nat.OPT_GENERIC_MIXED)):
+    for name, opt in (("on", nat.OPT_STREAM_ON), ("off", nat.OPT_STREAM_OFF),
+                      ("generic", nat.OPT_STREAM_OFF | nat.VAR_GENERIC | nat.VAR_MIXED_V1 | nat.VAR_MIXED_RING | nat.VAR_RUNS_SEPARATE)):
         if name == "generic" and fleet_kind != "mixed":
             continue
         ctx = fleet.Context(types)
@@ -2541,8 +2539,8 @@ def test_tuning_options_do_not_change_results(gpu, fleet_kind):
     np.testing.assert_array_equal(out["on"][0], out["off"][0])
     np.testing.assert_array_equal(out["on"][1], out["off"][1])
     if "generic" in out:
-        assert_step_parity("generic_mixed_vs_staged", types, tid, rigid, mem, tgt, out["generic"][0], out["generic"][1],
-                           out["on"][0], out["on"][1], DT, float(np.float32(2 / 240)), 2)
+        np.testing.assert_array_equal(out["generic"][0], out["off"][0])
+        np.testing.assert_array_equal(out["generic"][1], out["off"][1])
 
 
 # ---------------------------------------------------------------------------
@@ -2640,30 +2638,33 @@ def test_every_instance_of_the_single_type_step_kernels(gpu, sub, seed):
     # k_step_hexa<NOISE, NT, S1, ACT>
     _sweep_case(gpu, f"sweep hexa plain[{sub},{seed}]", [hx], None, n, sub, seed, 0)
     _sweep_case(gpu, f"sweep hexa action[{sub},{seed}]", [hx], None, n, sub, seed, 0, action=act6)
-    # type-major runs: k_step_runs<NOISE, NT, S1> (all runs in one launch, the default) and k_step_run<HEXA, NOISE, NT, S1>
-    # (one launch per run: DSIM_OPT_RUNS_SEPARATE); aligned runs, and runs that begin and end inside tiles
+    # type-major runs: k_step_runs<NOISE, NT, S1, ACT> (all runs in one launch); aligned runs, and runs that begin and end
+    # inside tiles.  k_step_run<HEXA, NOISE, NT, S1> (one launch per run) serves a fleet that is ONE run: a homogeneous fleet
+    # with the downwash force as input, and more runs than one launch holds (nine runs of two types here)
     tid = np.repeat(np.array([0, 1], dtype=np.uint8), 256)
     tid2 = np.array([0] * 200 + [1] * 312, dtype=np.uint8)
-    for name, opt in (("one launch", 0), ("separate", nat.OPT_RUNS_SEPARATE)):
-        _sweep_case(gpu, f"sweep runs {name}[{sub},{seed}]", [rb, hx], tid, n, sub, seed, opt, runs=[(0, 256, 0), (256, 256, 1)])
-        _sweep_case(gpu, f"sweep runs sharing a tile, {name}[{sub},{seed}]", [rb, hx], tid2, n, sub, seed, opt,
-                    runs=[(0, 200, 0), (200, 312, 1)])
+    _sweep_case(gpu, f"sweep runs one launch[{sub},{seed}]", [rb, hx], tid, n, sub, seed, 0, runs=[(0, 256, 0), (256, 256, 1)])
+    _sweep_case(gpu, f"sweep runs sharing a tile, one launch[{sub},{seed}]", [rb, hx], tid2, n, sub, seed, 0,
+                runs=[(0, 200, 0), (200, 312, 1)])
+    cuts = [0, 50, 120, 180, 256, 300, 350, 420, 470, 512]
+    tid9 = np.concatenate([np.full(b - a_, k % 2, dtype=np.uint8) for k, (a_, b) in enumerate(zip(cuts[:-1], cuts[1:]))])
+    _sweep_case(gpu, f"sweep nine runs, one launch each[{sub},{seed}]", [rb, hx], tid9, n, sub, seed, 0,
+                runs=[(a_, b - a_, k % 2) for k, (a_, b) in enumerate(zip(cuts[:-1], cuts[1:]))])
 
 
 @pytest.mark.parametrize("seed", [0, 7])
 @pytest.mark.parametrize("sub", [1, 2])
 @pytest.mark.parametrize("n_types", [2, 3, 4])
 def test_every_instance_of_the_mixed_fleet_kernels(gpu, n_types, sub, seed):
-    """k_step_mixed4 / mixed3 / mixed / mixed2 <NOISE, NT, waves | types, S1, ...>: every form, 2-4 types, on the layouts
-    that select them."""
+    """k_step_mixed4 / k_step_mixed3 <NOISE, NT, waves | types, S1, ...>: both forms the product ships, 2-4 types, on the
+    layouts that select them."""
     import dataclasses
     nat, fleet = gpu
     rb, hx, te = params.builtin_type("robobee"), params.builtin_type("hexa_6DOF"), params.builtin_type("tello")
     types = [rb, hx, te, dataclasses.replace(rb, name="rb2", kp_pos=1.3, mass=0.8)][:n_types]
     n = 640
     tid = np.random.default_rng(n_types).integers(0, n_types, n).astype(np.uint8)
-    for form, opt, layout in (("v4", 0, "tile64"), ("v3", nat.OPT_MIXED_V3, "tile64"), ("v3 soa", 0, "soa"),
-                              ("v1", nat.OPT_MIXED_V1, "tile64"), ("v1 soa", nat.OPT_MIXED_V1, "soa"), ("ring", nat.OPT_MIXED_RING, "tile64")):
+    for form, opt, layout in (("v4", 0, "tile64"), ("v3 soa", 0, "soa")):
         _sweep_case(gpu, f"sweep mixed {form}[{n_types},{sub},{seed}]", types, tid, n, sub, seed, opt, layout=layout)
 
 
@@ -2803,7 +2804,7 @@ def test_every_instance_of_the_two_call_adaptor_and_general_kernels(gpu, seed):
         assert_control_parity(f"sweep control_fast[{want_yaw}]", [rb], None, rigid, mem, tgt, gm, m, dtc)
         np.testing.assert_array_equal(gcmd[:, :n].T, gm[:, 7:11].astype(np.float32))
 
-    # ---- two quad types, per-lane: general step (explicit action), lean step (DSIM_OPT_GENERIC_MIXED), Env.step, control,
+    # ---- two quad types, per-lane: general step (explicit action), lean step (a quad-only mixed table takes it), Env.step, control,
     # the adaptors — and the same over the plane
     types = [rb, te]
     n2 = 600
@@ -2865,7 +2866,7 @@ def test_every_instance_of_the_two_call_adaptor_and_general_kernels(gpu, seed):
             assert np.abs(gm[:, 7:11] - m[:, 7:11]).max() < 1e-3
 
     def lean(ctx, st, tg, tdev, pol):
-        a = _args(nat, 2, DT, dtc, options=pol | nat.OPT_GENERIC_MIXED, seed=seed, step_index=1, type_id=tdev)
+        a = _args(nat, 2, DT, dtc, options=pol, seed=seed, step_index=1, type_id=tdev)
         nat.check(ctx.lib.dsim_step(ctx.handle, _stream(ctx), n2, st.view(), tg.view(), ctypes.byref(a)))
         return st.rigid_aos(), st.mem_aos()
     rigid, mem, tgt, (gr, gm) = run(types, tid, n2, lean)
@@ -2888,6 +2889,7 @@ def test_every_instance_of_the_two_call_adaptor_and_general_kernels(gpu, seed):
 def test_every_instance_of_the_tail_kernels(gpu, seed):
     """Ragged fleets (n_pad not a multiple of 256: the general kernels serve the tail, or everything below one tile) of
     one type and of quads + hexas, plain and with an explicit action, and computeControl on them."""
+    import dataclasses
     nat, fleet = gpu
     rb, hx = params.builtin_type("robobee"), params.builtin_type("hexa_6DOF")
     n = 300                                                       # n_pad = 320: one whole tile + a 64-drone tail
@@ -2899,7 +2901,9 @@ def test_every_instance_of_the_tail_kernels(gpu, seed):
         _sweep_case(gpu, f"sweep tail quad action[{seed}]", [rb], None, n, 2, seed, 0, action=act4, n_steps=2, layout=layout, pad=64)
         _sweep_case(gpu, f"sweep tail hexa[{seed}]", [hx], None, n, 2, seed, 0, layout=layout, pad=64)
         _sweep_case(gpu, f"sweep tail hexa action[{seed}]", [hx], None, n, 2, seed, 0, action=act6, layout=layout, pad=64)
-        _sweep_case(gpu, f"sweep generic mixed[{seed}]", [rb, hx], tid, n, 2, seed, nat.OPT_GENERIC_MIXED, layout=layout, pad=64)
+        five = [rb, hx] + [dataclasses.replace(rb, name=f"rb{k}", kp_pos=1.0 + 0.1 * k) for k in range(3)]
+        _sweep_case(gpu, f"sweep generic mixed, five types[{seed}]", five, (np.arange(n) % 5).astype(np.uint8), n, 2, seed, 0,
+                    layout=layout, pad=64)
         _sweep_case(gpu, f"sweep mixed action[{seed}]", [rb, hx], tid, n, 2, seed, 0, action=act6, layout=layout, pad=64)
     if seed:
         return
