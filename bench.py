@@ -567,7 +567,7 @@ def measure_variant(torch, local, layout, seed, steps, name, nf, rep, sub, wp, n
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     a = parse(argv)
-    if (a.gpus > 1 or os.environ.get("DSIM_BENCH_FORCE_DIST", "0") != "0") and "WORLD_SIZE" not in os.environ and not a.dry_run:
+    if (a.gpus > 1 or (os.environ.get("DSIM_BENCH_FORCE_DIST", "0") != "0" and not a.dry_run)) and "WORLD_SIZE" not in os.environ:
         # not started by a launcher: start the ranks as children — nothing in THIS process has touched the GPU
         sys.exit(launch_ranks(a, argv))
     rank = int(os.environ.get("RANK", "0"))

@@ -568,11 +568,12 @@ __device__ __forceinline__ void step_gen_body(const DevType& T, const StepK& a, 
     if (FULL && a.wp_table) waypoint_target(a, i, wp, tg);
     V3 pos_e;
     float yaw_e;
-    if (NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA) {     // wave-uniform branch
+    if (NACT == 6 && T.kind != DSIM_DEV_KIND_QUAD) {     // wave-uniform branch: morphing-hexa physics (both hexa kinds)
       if constexpr (NACT == 6) {
         hexa_substeps<NOISE, FULL, false, PLANE>(T, a, i, s, act, a.step_index + k, ext, NOISE ? noise_id(a, i) : -1LL);
         ground_watch(T, s, a.fb.counters, i < a.n);
-        indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
+        if (T.kind == DSIM_DEV_KIND_HEXA) indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
+        else indi_quad<false, 6>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);         // hexa_6DOF_simple: the quad law on six actuators
       }
     } else {
       quad_substeps<NOISE ? (FULL ? 2 : 1) : 0, NACT, FULL, 0, PLANE>(T, a, i, s, act, a.step_index + k, ext, nullptr,
@@ -934,8 +935,10 @@ __global__ __launch_bounds__(128, S1 ? 4 : 3) void k_step_mixed4(StepK a) {
 // the fast form (no partition, no waterfall, per-type constants in SGPRs); ext = optional downwash force.
 // ACT: an explicit action for the physics part (dsim_step_args.action: the first iteration of the example loop), clipped as
 // CtrlAviary._preprocessAction does; the controller memory keeps its own cmd (k_step_runs only: a template flag, as in k_step_fast)
-template <bool HEXA, bool NOISE, bool NT, bool S1, bool ACT = false>
+// KIND: DSIM_DEV_KIND_* of the run's type — 2 = morphing-hexa physics with the quad law on its six actuators
+template <int KIND, bool NOISE, bool NT, bool S1, bool ACT = false>
 __device__ __forceinline__ void run_body(const StepK& a, long long i0, long long lo, long long last, int run_type) {
+  constexpr bool HEXA = KIND != DSIM_DEV_KIND_QUAD;            // six actuators, morphing-hexa physics
   const long long i = i0 + threadIdx.x;
   if (i >= last || i < lo) return;          // (a run may begin and end inside a tile: the neighbouring run's lanes take the rest)
   const DevType& T = a.types[run_type];
@@ -962,7 +965,8 @@ __device__ __forceinline__ void run_body(const StepK& a, long long i0, long long
   for (int j = 0; j < NA; ++j) act[j] = ACT ? clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]) : m.cmd[j];   // CtrlAviary.py:258-263
   if constexpr (HEXA) {
     hexa_substeps<NOISE, false, S1>(T, a, i, s, act, step_index, ext, nid);
-    indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
+    if constexpr (KIND == DSIM_DEV_KIND_HEXA) indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
+    else indi_quad<false, 6>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   } else {
     quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, act, step_index, ext, nullptr, nid);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
@@ -973,9 +977,9 @@ __device__ __forceinline__ void run_body(const StepK& a, long long i0, long long
   ground_watch(T, s, a.fb.counters, i < a.n);
   if (a.bin.count && i < a.n) bin_entry(a.bin, s.pos.x, s.pos.y, s.pos.z, a.bin.local_offset + i);   // next step's grid
 }
-template <bool HEXA, bool NOISE, bool NT, bool S1>
-__global__ __launch_bounds__(256, HEXA ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void k_step_run(StepK a) {
-  run_body<HEXA, NOISE, NT, S1>(a, a.first + (long long)blockIdx.x * 256, a.lo, a.last, a.run_type);
+template <int KIND, bool NOISE, bool NT, bool S1>
+__global__ __launch_bounds__(256, KIND ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void k_step_run(StepK a) {
+  run_body<KIND, NOISE, NT, S1>(a, a.first + (long long)blockIdx.x * 256, a.lo, a.last, a.run_type);
 }
 // All the runs of a type-major fleet in ONE launch: a workgroup finds its run by its index (constant-index walk over the
 // table, everything wave-uniform) and runs that run's law.  A 65 536-drone shard of BASELINE config 5 is two runs of 128
@@ -985,7 +989,8 @@ struct RunTab {
   int blk0[DSIM_MAX_TYPES + 1];            // first workgroup of run q (blk0[q] = the total for q >= n_runs)
   long long first[DSIM_MAX_TYPES], lo[DSIM_MAX_TYPES], last[DSIM_MAX_TYPES];
   int type[DSIM_MAX_TYPES];
-  unsigned hexa_mask;
+  unsigned hexa_mask;        // bit q: run q flies morphing-hexa physics (six actuators: DSIM_KIND_HEXA6DOF and _HEXA_QUADLAW)
+  unsigned quadlaw6_mask;    // bit q: ... with the quad law on its six actuators (DSIM_KIND_HEXA_QUADLAW: k_control_runs)
   // null: workgroup b serves the runs one after the other (blk0).  Else [blocks] device ints, (tile << 3) | run: the runs are
   // served SIDE BY SIDE, each at a rate proportional to its size.  For DSIM_OPT_CALLER_IO: a drone's outputs go to its caller
   // index, and the drones of every run are spread over the caller's whole range (even index quad, odd index hexa ...), so
@@ -996,7 +1001,7 @@ struct RunTab {
 };
 // the run a workgroup belongs to: constant-index walk over the table, everything wave-uniform (SGPRs).  A macro, not a
 // function: a kernel argument handed on by reference is copied to scratch (264 bytes per lane) before the walk.
-struct RunOf { long long i0, lo, last; int type; bool hexa; };
+struct RunOf { long long i0, lo, last; int type; bool hexa, quadlaw6; };
 #define DSIM_RUN_OF_BLOCK(rt, ro, BIDX)                                                                             \
   RunOf ro;                                                                                                         \
   {                                                                                                                 \
@@ -1013,13 +1018,14 @@ struct RunOf { long long i0, lo, last; int type; bool hexa; };
     if (!rt.block_map) tile_ = bidx_ - b0_;                                                                         \
     ro.i0 = first_ + (long long)__builtin_amdgcn_readfirstlane(tile_) * 256;                                        \
     ro.hexa = (rt.hexa_mask >> r_) & 1u;                                                                            \
+    ro.quadlaw6 = (rt.quadlaw6_mask >> r_) & 1u;                                                                    \
     if (tile_ < 0) ro.last = ro.lo = 0;                 /* a padding entry of the map: nothing to serve */          \
   }
 template <bool NOISE, bool NT, bool S1, bool ACT>
 __global__ __launch_bounds__(256, 3) void k_step_runs(StepK a, RunTab rt) {
   DSIM_RUN_OF_BLOCK(rt, ro, blockIdx.x);
-  if (ro.hexa) run_body<true, NOISE, NT, S1, ACT>(a, ro.i0, ro.lo, ro.last, ro.type);
-  else run_body<false, NOISE, NT, S1, ACT>(a, ro.i0, ro.lo, ro.last, ro.type);
+  if (ro.hexa) run_body<DSIM_DEV_KIND_HEXA, NOISE, NT, S1, ACT>(a, ro.i0, ro.lo, ro.last, ro.type);
+  else run_body<DSIM_DEV_KIND_QUAD, NOISE, NT, S1, ACT>(a, ro.i0, ro.lo, ro.last, ro.type);
 }
 
 // ---- Env.step only ---------------------------------------------------------
@@ -1033,7 +1039,7 @@ __device__ __forceinline__ void physics_gen_body(const DevType& T, const StepK& 
   preprocess_action<NACT>(T, raw, cmd);
   V3 ext = v3(0, 0, 0);
   if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
-  if (NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA) {
+  if (NACT == 6 && T.kind != DSIM_DEV_KIND_QUAD) {
     if constexpr (NACT == 6) hexa_substeps<NOISE, true, false, PLANE>(T, a, i, s, cmd, a.step_index, ext, NOISE ? noise_id(a, i) : -1LL);
   } else {
     float prev[4];       // last_clipped_action of the previous step (drag of sub-step 0); this step's action without it
@@ -1349,8 +1355,9 @@ __global__ __launch_bounds__(IO ? 512 : 256, DSIM_PRUNS_WAVES) void k_physics_ru
   else physics_run_body<false, NOISE, NT, OBS, IO>(a, ro, rw, t);
 }
 
-template <bool HEXA, bool NT, bool WANT_YAW, bool IO>
+template <int KIND, bool NT, bool WANT_YAW, bool IO>
 __device__ __forceinline__ void control_run_body(const StepK& a, const RunOf& ro, unsigned t) {
+  constexpr bool HEXA = KIND != DSIM_DEV_KIND_QUAD;            // six actuators
   constexpr int NA = HEXA ? 6 : 4;
   const long long i0 = ro.i0, i = i0 + t;
   if (i >= ro.last || i < ro.lo) return;
@@ -1367,8 +1374,8 @@ __device__ __forceinline__ void control_run_body(const StepK& a, const RunOf& ro
   load_target<NT>(tb, tfs, tl, tg);
   V3 pos_e;
   float yaw_e = 0.0f;
-  if constexpr (HEXA) indi_hexa<WANT_YAW>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
-  else indi_quad<WANT_YAW>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  if constexpr (KIND == DSIM_DEV_KIND_HEXA) indi_hexa<WANT_YAW>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
+  else indi_quad<WANT_YAW, NA>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);       // (NA = 6: hexa_6DOF_simple)
   const unsigned so = pin_lane_offset(sl);
   store_mem<NA, NT>(sb, sfs, so, m);
   if (IO) {                                   // the outputs go to the caller's drone number (default cache policy, see above)
@@ -1400,8 +1407,9 @@ template <bool NT, bool WANT_YAW, bool IO>
 __global__ __launch_bounds__(IO ? 512 : 256, DSIM_PRUNS_WAVES) void k_control_runs(StepK a, RunTab rt) {
   DSIM_RUN_OF_BLOCK(rt, ro, IO ? 2 * blockIdx.x + (threadIdx.x >> 8) : blockIdx.x);
   const unsigned t = IO ? (threadIdx.x & 255u) : threadIdx.x;
-  if (ro.hexa) control_run_body<true, NT, WANT_YAW, IO>(a, ro, t);
-  else control_run_body<false, NT, WANT_YAW, IO>(a, ro, t);
+  if (ro.quadlaw6) control_run_body<DSIM_DEV_KIND_HEXA_QUADLAW, NT, WANT_YAW, IO>(a, ro, t);
+  else if (ro.hexa) control_run_body<DSIM_DEV_KIND_HEXA, NT, WANT_YAW, IO>(a, ro, t);
+  else control_run_body<DSIM_DEV_KIND_QUAD, NT, WANT_YAW, IO>(a, ro, t);
 }
 
 // ---- Env.step of the alternate action adaptors (VelocityAviary / RPYTAviary) --------------
@@ -2490,7 +2498,10 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
   for (int t = 0; t < n_types; ++t) {
     if (!(types[t].mass > 0)) return DSIM_E_TYPES;
     if (types[t].kind == DSIM_KIND_QUAD) { if (types[t].n_act != 4) return DSIM_E_TYPES; }
-    else if (types[t].kind == DSIM_KIND_HEXA6DOF) { if (types[t].n_act != 6) return DSIM_E_TYPES; max_act = 6; }
+    else if (types[t].kind == DSIM_KIND_HEXA6DOF || types[t].kind == DSIM_KIND_HEXA_QUADLAW) {
+      if (types[t].n_act != 6) return DSIM_E_TYPES;
+      max_act = 6;
+    }
     else return DSIM_E_TYPES;
     for (int k = 0; k < 3; ++k) if (!(types[t].inertia[k] > 0)) return DSIM_E_TYPES;
   }
@@ -2603,7 +2614,7 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
     memset(&a->tg, 0, sizeof(a->tg));
   }
   a->hexa_types = 0;
-  for (int t = 0; t < ctx->n_types; ++t) a->hexa_types |= (ctx->h_types[t].kind == DSIM_KIND_HEXA6DOF ? 1u : 0u) << t;
+  for (int t = 0; t < ctx->n_types; ++t) a->hexa_types |= (ctx->h_types[t].kind != DSIM_KIND_QUAD ? 1u : 0u) << t;
   a->types = ctx->d_types; a->type_id = args->type_id; a->noise_replay = args->noise_replay;
   a->action = args->action; a->echo = nullptr; a->pos_e_out = nullptr; a->yaw_e_out = nullptr;
   a->cmd_out = nullptr; a->obs_out = nullptr; a->obs_w = 16 + ctx->max_act; a->n = n;
@@ -2708,7 +2719,10 @@ static int make_runtab(const dsim_ctx* ctx, long long n_pad, const dsim_type_run
     const dsim_type_run& run = runs[r];
     if (run.first < 0 || run.count < 0 || run.first + run.count > n_pad || run.type < 0 || run.type >= ctx->n_types) return DSIM_E_ARG;
     rt->first[r] = run.first & ~255LL; rt->lo[r] = run.first; rt->last[r] = run.first + run.count; rt->type[r] = run.type;
-    if (ctx->h_types[run.type].kind == DSIM_KIND_HEXA6DOF) { rt->hexa_mask |= 1u << r; *any_hexa = true; }
+    const int kind = ctx->h_types[run.type].kind;
+    if (kind != DSIM_KIND_QUAD) rt->hexa_mask |= 1u << r;
+    if (kind == DSIM_KIND_HEXA_QUADLAW) rt->quadlaw6_mask |= 1u << r;
+    if (kind == DSIM_KIND_HEXA6DOF) *any_hexa = true;                 // (the WLS fallback queue is the 6-DOF law's)
     blocks += run.count > 0 ? (int)((rt->last[r] - rt->first[r] + 255) / 256) : 0;
   }
   rt->blk0[DSIM_MAX_TYPES] = blocks;
@@ -2789,15 +2803,17 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   const dsim_type_run* runs = args->runs;
   int n_runs = args->n_runs;
   dsim_type_run whole;
-  if (!(runs && n_runs > 0) && uni && runs_ok && args->ext_force) {
-    // a homogeneous fleet with an external (downwash) force: ONE run of its only type — the single-type kernel with
-    // the force input and the fused neighbour-grid binning, instead of the general kernel
+  bool any_quadlaw6 = false;             // a DSIM_KIND_HEXA_QUADLAW type in the table: served by the per-run kernels (k_step_run)
+  for (int t = 0; t < ctx->n_types; ++t) any_quadlaw6 |= ctx->h_types[t].kind == DSIM_KIND_HEXA_QUADLAW;
+  if (!(runs && n_runs > 0) && uni && runs_ok && (args->ext_force || (any_quadlaw6 && !args->action))) {
+    // a homogeneous fleet with an external (downwash) force, or of hexa_6DOF_simple: ONE run of its only type — the
+    // single-type kernel with the force input and the fused neighbour-grid binning, instead of the general kernel
     whole.first = 0; whole.count = a.n_pad; whole.type = 0; whole._pad = 0;
     runs = &whole; n_runs = 1;
   }
   // (an explicit action — the first iteration of the example loop, fly_INDI.py:214 — is served by the ACT instances of the
   // one-launch form; beyond DSIM_MAX_TYPES runs it goes to the general kernel)
-  if (runs && n_runs > 0 && runs_ok && (!args->action || n_runs <= DSIM_MAX_TYPES)) {
+  if (runs && n_runs > 0 && runs_ok && (!args->action || (n_runs <= DSIM_MAX_TYPES && !any_quadlaw6))) {
     // type-major storage: one single-type launch per run
     const bool nt = stream_policy(args, state.n_pad, 240.0);
     bool any_hexa = false;
@@ -2816,7 +2832,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     // (measured on MI355X, 50 % quads + 50 % hexas: 65 536 drones 12.0 us against 9.5 + 9.0 us for two dependent launches;
     // 4 194 304 drones 160.1 against 165.2 us — the launch boundary between the runs costs more than the registers the
     // second law adds (83 VGPRs, 5 waves per SIMD, against 74 and 6): one launch is the default at every size)
-    const bool one_launch = !DSIM_VARIANT_RUNS_SEPARATE(args) || args->action;
+    const bool one_launch = (!DSIM_VARIANT_RUNS_SEPARATE(args) || args->action) && !any_quadlaw6;
     if (n_runs <= DSIM_MAX_TYPES && (n_runs >= 2 || args->action) && one_launch) {
       // several runs (or an explicit action): one launch for all of them (k_step_runs)
       RunTab rt;
@@ -2851,7 +2867,10 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
       // [lo, last) retire, so two runs may share a tile (each launch takes its own lanes of it)
       a.first = run.first & ~255LL; a.lo = run.first; a.last = run.first + run.count; a.run_type = run.type;
       const dim3 g(grid_for(a.last - a.first));
-      if (ctx->h_types[run.type].kind == DSIM_KIND_HEXA6DOF) DSIM_RUN_CASE(true); else DSIM_RUN_CASE(false);
+      const int kind = ctx->h_types[run.type].kind;
+      if (kind == DSIM_KIND_HEXA6DOF) DSIM_RUN_CASE(DSIM_DEV_KIND_HEXA);
+      else if (kind == DSIM_KIND_HEXA_QUADLAW) DSIM_RUN_CASE(DSIM_DEV_KIND_HEXA_QUADLAW);
+      else DSIM_RUN_CASE(DSIM_DEV_KIND_QUAD);
     }
 #undef DSIM_RUN_CASE
 #undef DSIM_RUN_CASE2
@@ -2909,7 +2928,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     a.first = first;
     const dim3 g(grid_for(a.n_pad - first));
     const bool lean = !args->action && !args->noise_replay && !a.wp_table && a.n_steps == 1 && !phys_opts;
-    if (lean && !uni && a.tg.base && ctx->n_types <= 4 && ctx->max_act == 6 && !DSIM_VARIANT_GENERIC(args)) {
+    if (lean && !uni && a.tg.base && ctx->n_types <= 4 && ctx->max_act == 6 && !any_quadlaw6 && !DSIM_VARIANT_GENERIC(args)) {
       // a heterogeneous fleet kept in the CALLER's own order (CtrlAviary(storage="caller"); storage="auto" stores it
       // type-major and never comes here): the LDS-staged kernels, which partition every tile by type
       const bool nt = stream_policy(args, state.n_pad, 240.0);

@@ -13,6 +13,7 @@
 #define DSIM_MAX_ACT 6
 #define DSIM_DEV_KIND_QUAD 0
 #define DSIM_DEV_KIND_HEXA 1
+#define DSIM_DEV_KIND_HEXA_QUADLAW 2      // morphing-hexa physics, the quad law on six actuators (hexa_6DOF_simple.urdf)
 
 // fp32 image of dsim_type_params (include/dronesim_amd.h), with the reciprocals
 // the kernel wants.  Lives in device memory; with a homogeneous fleet the address
@@ -425,8 +426,10 @@ __device__ __forceinline__ void indi_rate(const DevType& T, float inv_dt, const 
   v[3] = thrust - m.last_thrust;                                               // :454
   m.last_rates = wb;                                                           // :442
   m.last_thrust = thrust;                                                      // :455
+  // (NACT = 6: hexa_6DOF_simple flies the quad law on six actuators — G1 is 4 x 6, pinv(G1 / 0.05) 6 x 4; a real quad's rows
+  // 4, 5 of a six-wide table are zero, and so are its limits: its last two commands stay 0)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {                                                // :459, 486-487
+  for (int j = 0; j < NACT; ++j) {                                             // :459, 486-487
     const float du = T.alloc[j][0] * v[0] + T.alloc[j][1] * v[1] + T.alloc[j][2] * v[2] + T.alloc[j][3] * v[3];
     m.cmd[j] = clampf(m.cmd[j] + du, T.pmin[j], T.pmax[j]);
   }

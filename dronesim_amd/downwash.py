@@ -10,9 +10,10 @@ with a uniform-grid neighbour search (dsim_downwash).  Nothing else of the state
 
 The reference's loop is O(N^2) over the whole world, per drone, per sub-step, and is dead code in
 the fork; the intended semantics are kept: receivers use their own type's coefficients, the force
-acts along the receiver's body z axis at the COM.  Deviation (documented in DESIGN.md): the force is
-evaluated once per Env.step from the positions at the start of the step and held over its
-sub-steps (identical for phys_substeps = 1).
+acts along the receiver's body z axis at the COM, and it is evaluated per physics SUB-STEP from the
+positions at the start of that sub-step, as the reference's loop refreshes them (BaseAviary.py:510-536):
+with AGGR_PHY_STEPS > 1 the env launches one [query -> one-sub-step physics] pair per sub-step
+(envs/fleet_aviary.py); one evaluation serves a launch.
 """
 from __future__ import annotations
 

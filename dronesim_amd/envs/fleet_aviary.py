@@ -211,6 +211,7 @@ class CtrlAviary:
         self._written_tail = None  # [8, n_pad] behind the placed observation rows: a bound controller's outputs go there
         self._adjacency = None    # grid for neighbors(), built on first use
         self._action_keep = None  # keeps a zero-copy action tensor alive while the launch that reads it is queued
+        self._action_ptr_last = None
         # chained fused stepping (DSIM_OPT_CHAINED): consecutive step_fused() calls skip the six
         # controller-memory fields that are functions of the stored rigid state (184 instead of 232
         # bytes per drone-step); anything else first calls materialize()
@@ -274,6 +275,16 @@ class CtrlAviary:
         self._fb_done.record(self._fb_stream)
         self._fb_event = self._fb_done
 
+    def _dw_substepped(self) -> bool:
+        """The neighbour-downwash term with several physics sub-steps per Env.step: evaluated per sub-step (see step())."""
+        return self._downwash is not None and self.AGGR_PHY_STEPS > 1
+
+    def _substep_args(self, args: nat.StepArgs, s_: int) -> None:
+        """`args` (of this Env.step) for its sub-step s_ as a launch of its own: one sub-step, and the rotor-noise counter
+        the multi-sub-step launch would have used there (step_index x AGGR_PHY_STEPS + s_)."""
+        args.phys_substeps = 1
+        args.step_index = self._env_steps * self.AGGR_PHY_STEPS + s_
+
     def step_args(self, dt_ctrl: Optional[float] = None, options: int = 0) -> nat.StepArgs:
         a = nat.StepArgs()
         a.phys_substeps = self.AGGR_PHY_STEPS
@@ -334,19 +345,29 @@ class CtrlAviary:
         """BaseAviary.step (BaseAviary.py:428-555) with Physics.PYB."""
         self.materialize()
         self._chain_ok = False
-        args = self.step_args()
-        if self._caller_io:
-            args.options |= nat.OPT_CALLER_IO
-        args.action = self._action_ptr(action, self._caller_io)
-        if self._downwash is not None:
-            # the physics launch fills the next Env.step's neighbour grid from the new positions (the library keeps its
-            # own record of what was binned when, and bins afresh when anything moved the drones in between)
-            args.bin_next = self._downwash.bin_next_ptr()
-        # the observation rows are written by the physics launch itself (BaseAviary.py:547-555 returns them from step)
+        # The neighbour-downwash term is evaluated per PHYSICS SUB-STEP, as the reference loops it (BaseAviary.py:510-536:
+        # with AGGR_PHY_STEPS > 1 the positions are refreshed and _downwash applied inside the sub-step loop): one
+        # [query -> one-sub-step physics] pair of launches per sub-step, the observation rows from the last one.  Without the
+        # term (or with one sub-step) the whole Env.step is ONE launch.
+        passes = self.AGGR_PHY_STEPS if self._dw_substepped() else 1
         obs = self._obs_tensor()
-        args.obs_out, args.obs_width = obs.data_ptr(), 16 + self.n_act
-        nat.check(self.ctx.lib.dsim_physics(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
-                                            self.state.view(), self._last_action.data_ptr(), ctypes.byref(args)))
+        for s_ in range(passes):
+            args = self.step_args()
+            if passes > 1:
+                self._substep_args(args, s_)
+            if self._caller_io:
+                args.options |= nat.OPT_CALLER_IO
+            args.action = self._action_ptr(action, self._caller_io) if s_ == 0 else self._action_ptr_last
+            self._action_ptr_last = args.action
+            if self._downwash is not None:
+                # the physics launch fills the next neighbour grid from the new positions (the library keeps its own
+                # record of what was binned when, and bins afresh when anything moved the drones in between)
+                args.bin_next = self._downwash.bin_next_ptr()
+            if s_ == passes - 1:
+                # the observation rows are written by the physics launch itself (BaseAviary.py:547-555 returns them from step)
+                args.obs_out, args.obs_width = obs.data_ptr(), 16 + self.n_act
+            nat.check(self.ctx.lib.dsim_physics(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
+                                                self.state.view(), self._last_action.data_ptr(), ctypes.byref(args)))
         self._use_last_action = True
         self.step_counter += self.AGGR_PHY_STEPS
         self._env_steps += 1
@@ -383,7 +404,8 @@ class CtrlAviary:
             self._env_steps += n_steps
             return
         pd = self._fused_plan_dw
-        if (action is None and pd is not None and self._downwash is not None and pd[5] is targets and pd[0] == key
+        if (action is None and pd is not None and self._downwash is not None and not self._dw_substepped()
+                and pd[5] is targets and pd[0] == key
                 and self._chain_ok and self._fb_stream is None and pd[6] == self._targets_ptrs(targets)):
             # the same call again on a downwash fleet: the prepared argument block, with this step's force, counter and
             # the grid the step kernel may fill (the Python side of a config-5 step is what paces a 65 536-drone shard)
@@ -396,7 +418,24 @@ class CtrlAviary:
             self._env_steps += 1
             return
         wp = isinstance(targets, WaypointTargets)
+        if self._dw_substepped():
+            # the downwash term per physics sub-step (see step()): all sub-steps but the last as Env.step-only launches
+            # behind their own neighbour query, the last one fused with the control law
+            self._use_last_action = False
+            self.materialize()
+            act_ptr = None
+            for s_ in range(self.AGGR_PHY_STEPS - 1):
+                pa = self.step_args(control_timestep)
+                self._substep_args(pa, s_)
+                if action is not None:
+                    act_ptr = self._action_ptr(action) if s_ == 0 else act_ptr
+                    pa.action = act_ptr
+                pa.bin_next = self._downwash.bin_next_ptr()
+                nat.check(self.ctx.lib.dsim_physics(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
+                                                    self.state.view(), None, ctypes.byref(pa)))
         args = self.step_args(control_timestep, nat.OPT_BCAST_TGT if targets.broadcast else 0)
+        if self._dw_substepped():
+            self._substep_args(args, self.AGGR_PHY_STEPS - 1)
         args.n_steps = n_steps
         if wp:
             targets.fill(args)
@@ -430,7 +469,7 @@ class CtrlAviary:
         # what the NEXT identical call would pass (a chained env switches to the chained form after this call)
         self._fused_plan = None
         self._fused_plan_dw = None
-        if action is None and self._downwash is not None and not chain and not defer:
+        if action is None and self._downwash is not None and not chain and not defer and not self._dw_substepped():
             self._fused_plan_dw = (key, args, sview, tview, ctypes.byref(args), targets, self._targets_ptrs(targets))
         if action is None and self._downwash is None:
             nxt = nat.StepArgs.from_buffer_copy(args)
@@ -458,6 +497,9 @@ class CtrlAviary:
                                           "position exchange of a sharded fleet re-sizes its messages on the host)")
             if self._fb_stream is not None:
                 raise ValueError("graph capture with the neighbour-downwash term: not with the deferred fallback pass")
+            if self._dw_substepped():
+                raise NotImplementedError("graph capture with the neighbour-downwash term and several physics sub-steps per "
+                                          "Env.step (the term is evaluated per sub-step: step_fused() launches them one by one)")
         # nothing may allocate under capture: the fallback queue of hexa fleets is reserved up front
         nat.check(self.ctx.lib.dsim_reserve(self.ctx.handle, self.ctx.stream_ptr(), self.state.n_pad))
         self._graph_made = True

@@ -29,6 +29,7 @@ import numpy as np
 MAX_ACT = 6
 KIND_QUAD = 0
 KIND_HEXA6DOF = 1
+KIND_HEXA_QUADLAW = 2     # morphing-hexa physics, quad INDI law on six actuators (hexa_6DOF_simple.urdf)
 
 # Bullet's btMultiBody defaults are float literals (0.04f) held in double
 # precision builds; keeping the exact fp32 value makes fp32 (GPU) and fp64
@@ -140,7 +141,7 @@ class DroneType:
         INDIControl.py:459 computes it every call (a per-type constant).
         hexa: M1 of :meth:`wls_first_iteration`."""
         B = self.G1 / 0.05
-        if self.kind == KIND_QUAD:
+        if self.kind != KIND_HEXA6DOF:          # the quad law, on four or (hexa_6DOF_simple) six actuators: [n_act][4]
             return np.linalg.pinv(B)
         return self.wls_first_iteration()[0]
 
@@ -309,7 +310,25 @@ def _hexa_6dof() -> DroneType:
     )
 
 
-_BUILTIN_FACTORIES = {"robobee": _robobee, "tello": _tello, "hexa_6DOF": _hexa_6dof}
+def _hexa_6dof_simple() -> DroneType:
+    # dronesim/assets/hexa_6DOF_simple.urdf: the same airframe, link for link, as hexa_6DOF.urdf; its <control> block
+    # (:28-33) declares output_nr = 4 — roll, pitch, yaw, thrust rows of G1 over the six rotors — and
+    # examples/fly_hexa_6DOF_simple.py:18 flies it with the QUAD controller class (INDIControl.py, actuator_nr = 6):
+    # pinv(G1 / 0.05) is 6 x 4, the controller memory starts from zero like a quad's (INDIControl.py:127-129).
+    t = _hexa_6dof()
+    return DroneType(
+        name="hexa_6DOF_simple", kind=KIND_HEXA_QUADLAW, n_act=6, mass=t.mass, ctrl_mass=t.ctrl_mass, inertia=t.inertia,
+        kf=t.kf, km=t.km, pwm2rpm_scale=t.pwm2rpm_scale, pwm2rpm_const=t.pwm2rpm_const, pwm_min=t.pwm_min, pwm_max=t.pwm_max,
+        rotor_pos=t.rotor_pos, rotor_axis=t.rotor_axis, rotor_spin=t.rotor_spin,
+        G1=np.array([[-7.5, -15.0, -7.5, 7.5, 15.0, 7.5], [-13.0, 0.0, 13.0, 13.0, 0.0, -13.0],
+                     [-5.0, 5.0, -5.0, 5.0, -5.0, 5.0], [1.7, 1.7, 1.7, 1.7, 1.7, 1.7]]),
+        kp_pos=t.kp_pos, kd_pos=t.kd_pos, att_gain=t.att_gain, rate_gain=t.rate_gain,
+        prop_radius=t.prop_radius, reset_thrust=0.0, reset_cmd=0.0,
+        collision_radius=t.collision_radius, collision_below=t.collision_below, base_offset=t.base_offset, **_AERO,
+    )
+
+
+_BUILTIN_FACTORIES = {"robobee": _robobee, "tello": _tello, "hexa_6DOF": _hexa_6dof, "hexa_6DOF_simple": _hexa_6dof_simple}
 
 
 def builtin_type(name: str) -> DroneType:
@@ -414,9 +433,8 @@ def parse_urdf(path: str) -> DroneType:
     lim = list(ctrl.find("pwm/limit").attrib.values())
 
     is_hexa = "morphing_hexa" in conf
-    if is_hexa and n_out != 6:
-        raise ValueError("morphing_hexa with output_nr != 6 (hexa_6DOF_simple: quad law on six actuators) "
-                         "is not on the hot path")
+    if is_hexa and n_out not in (4, 6):
+        raise ValueError(f"morphing_hexa with output_nr = {n_out}: neither the 6-DOF law (6) nor the quad law (4)")
     if not is_hexa and "quad" not in conf:
         raise ValueError(f"vehicle configuration {conf!r} is outside the hot path (quad / morphing_hexa only)")
     rotor_links = [order[i] for i in (range(1, 2 * n_act, 2) if is_hexa else range(n_act))]
@@ -443,7 +461,9 @@ def parse_urdf(path: str) -> DroneType:
         mass, inertia = M, tuple(np.diag(J))
         rotor_pos = [tuple(np.array(p) - C) for p in rotor_pos]
         spin = tuple(-1.0 if j % 2 == 0 else 1.0 for j in range(n_act))  # BaseAviary.py:1439-1440
-        kind, rt, rc = KIND_HEXA6DOF, 0.3, 0.5
+        # output_nr = 6: the 6-DOF law (INDIControl_6DOF.py, reset 0.3 / 0.5 :232-234); output_nr = 4: the quad law on six
+        # actuators (INDIControl.py, reset 0 / 0 :127-129) — hexa_6DOF_simple.urdf
+        kind, rt, rc = (KIND_HEXA6DOF, 0.3, 0.5) if n_out == 6 else (KIND_HEXA_QUADLAW, 0.0, 0.0)
     else:
         mass, inertia = m0, tuple(diag0)
         spin = _QUAD_SPIN

@@ -84,11 +84,18 @@ typedef struct dsim_view {
  * Filled by the host from the vehicle URDF exactly as the reference does
  * (BaseAviary._parseURDFParameters, BaseAviary.py:2041-2140;
  *  INDIControl._parseURDFControlParameters, INDIControl.py:55-106).            */
-enum { DSIM_KIND_QUAD = 0, DSIM_KIND_HEXA6DOF = 1 };
+enum {
+  DSIM_KIND_QUAD = 0,          /* quad physics (BaseAviary.py:1477-1543) + the quad INDI law (INDIControl.py)                    */
+  DSIM_KIND_HEXA6DOF = 1,      /* morphing-hexa physics (BaseAviary.py:1389-1457) + the 6-DOF INDI law with WLS allocation
+                                  (INDIControl_6DOF.py): hexa_6DOF.urdf                                                        */
+  DSIM_KIND_HEXA_QUADLAW = 2   /* morphing-hexa physics + the QUAD law on six actuators — G1 is 4 x 6, alloc = pinv(G1/0.05)
+                                  is 6 x 4, every one of the six commands is incremented and clipped (INDIControl.py:457-487
+                                  with actuator_nr = 6): hexa_6DOF_simple.urdf:25-34, examples/fly_hexa_6DOF_simple.py:18   */
+};
 
 typedef struct dsim_type_params {
   int32_t kind;                       /* DSIM_KIND_*                                        */
-  int32_t n_act;                      /* 4 | 6   (indi actuator_nr)                         */
+  int32_t n_act;                      /* 4 | 6   (indi actuator_nr); 6 for both hexa kinds   */
   double  mass;                       /* total rigid-body mass used by the integrator       */
   double  inertia[3];                 /* principal moments (URDF ixx,iyy,izz)               */
   double  kf, km;                     /* thrust / drag-torque coefficients                  */

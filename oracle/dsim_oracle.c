@@ -247,8 +247,8 @@ void orc_indi_position(const dsim_type_params* P, double dt, const double pos[3]
 /* C4: INDIControl._INDIRateControl, INDIControl.py:413-490 */
 void orc_indi_rate(const dsim_type_params* P, double dt, double thrust, const double quat[4],
                    const double ang_vel_world[3], const double rate_sp[3], orc_ctrl_mem* mem) {
-  double R[9], wb[3], v[4], Gs[16], Gp[16];
-  const int na = P->n_act; /* 4 */
+  double R[9], wb[3], v[4], Gs[4 * DSIM_MAX_ACT], Gp[4 * DSIM_MAX_ACT];
+  const int na = P->n_act; /* 4; 6 for hexa_6DOF_simple (self.indi_actuator_nr, INDIControl.py:70, 128) */
   orc_matrix_from_quat(quat, R);                          /* :428 */
   for (int k = 0; k < 3; ++k)                             /* :430  R.T.dot(w) */
     wb[k] = R[0 * 3 + k] * ang_vel_world[0] + R[1 * 3 + k] * ang_vel_world[1] + R[2 * 3 + k] * ang_vel_world[2];
@@ -744,7 +744,9 @@ void orc_physics_substep(const dsim_type_params* P, double dt, double rigid[13],
     cross3(w, o, wo);
     for (int k = 0; k < 3; ++k) { pos[k] -= o[k]; v[k] -= wo[k]; }
   }
-  if (P->kind == DSIM_KIND_HEXA6DOF) orc_hexa_wrench(P, cmd, fn, mn, F, tau, rpm);
+  /* BaseAviary._physics dispatches on the URDF's configuration type (BaseAviary.py:925-969): both hexa kinds are
+     "morphing_hexa" (hexa_6DOF.urdf:25, hexa_6DOF_simple.urdf:25) */
+  if (P->kind != DSIM_KIND_QUAD) orc_hexa_wrench(P, cmd, fn, mn, F, tau, rpm);
   else orc_quad_wrench(P, cmd, fn, mn, F, tau, rpm);
   if (options & DSIM_OPT_GROUND) { /* BaseAviary.py:528-529: extra thrust per rotor link */
     double dF[DSIM_MAX_ACT];
@@ -933,6 +935,30 @@ void orc_downwash(const dsim_type_params* types, const uint8_t* type_id, int64_t
     }
     fz_out[i] = fz;
   }
+}
+
+/* Env.step with the neighbour-downwash term (Physics.PYB_DW), as BaseAviary.step loops it (BaseAviary.py:510-536): with
+ * AGGR_PHY_STEPS > 1 the kinematic information is refreshed at the top of EVERY sub-step (:513-520) and _downwash(i) reads
+ * those refreshed positions (:534-536, 1747-1751) — the term is evaluated per sub-step, from the positions at the start of
+ * that sub-step (with one sub-step: from the positions the previous Env.step left, :547).  The world is the n drones of
+ * `rigid`.  action / mem / noise [n][substeps][12] / last_action_out as orc_physics_batch. */
+int orc_physics_downwash_batch(const dsim_type_params* types, const uint8_t* type_id, int64_t n, int substeps, double dt,
+                               double* rigid, const double* action, const double* mem, const double* noise,
+                               uint32_t options, double* last_action_out, int nthreads) {
+  double* fz = (double*)malloc(sizeof(double) * (size_t)n);
+  double* pos = (double*)malloc(sizeof(double) * 3 * (size_t)n);
+  double* ext = (double*)calloc((size_t)n * 3, sizeof(double));
+  double* nz = noise ? (double*)malloc(sizeof(double) * 12 * (size_t)n) : NULL;
+  if (!fz || !pos || !ext || (noise && !nz)) { free(fz); free(pos); free(ext); free(nz); return -1; }
+  for (int s = 0; s < substeps; ++s) {
+    for (int64_t i = 0; i < n; ++i) memcpy(pos + 3 * i, rigid + 13 * i, sizeof(double) * 3);
+    orc_downwash(types, type_id, n, rigid, pos, n, fz, nthreads);
+    for (int64_t i = 0; i < n; ++i) ext[3 * i + 2] = fz[i];
+    if (noise) for (int64_t i = 0; i < n; ++i) memcpy(nz + 12 * i, noise + (i * substeps + s) * 12, sizeof(double) * 12);
+    orc_physics_batch(types, type_id, n, 1, dt, rigid, action, mem, nz, options, last_action_out, ext, nthreads);
+  }
+  free(fz); free(pos); free(ext); free(nz);
+  return 0;
 }
 
 /* BaseAviary._dynamics, BaseAviary.py:1767-1828: the reference's OWN explicit rigid-body model

@@ -199,6 +199,19 @@ class Oracle:
         return self._L.orc_physics_batch(self._c_types, _p(type_id, _U8), n, substeps, dt, _p(rigid),
                                          _p(act), _p(mem), _p(nz), options, _p(last_action), _p(ef), nthreads)
 
+    def physics_downwash(self, rigid, mem, substeps, dt, action=None, noise=None, options=0, type_id=None, last_action=None,
+                         nthreads=1):
+        """Env.step with the neighbour-downwash term evaluated per physics sub-step among the drones of `rigid`
+        (BaseAviary.py:510-536); arguments as physics()."""
+        n = rigid.shape[0]
+        f = self._L.orc_physics_downwash_batch
+        f.argtypes = [ctypes.POINTER(TypeParamsC), _U8, ctypes.c_int64, ctypes.c_int, ctypes.c_double, _D, _D, _D, _D,
+                      ctypes.c_uint32, _D, ctypes.c_int]
+        act = None if action is None else _c(action)
+        nz = None if noise is None else _c(noise)
+        return f(self._c_types, _p(type_id, _U8), n, substeps, dt, _p(rigid), _p(act), _p(mem), _p(nz), options,
+                 _p(last_action), nthreads)
+
     def adaptor_step(self, mode, rigid, mem, action, substeps, dt_phys, dt_ctrl, type_id=None, nthreads=1):
         """Env.step of VelocityAviary (mode 0) / RPYTAviary (mode 1); action [n,4]."""
         return self._L.orc_adaptor_step_batch(self._c_types, _p(type_id, _U8), rigid.shape[0], mode, substeps,

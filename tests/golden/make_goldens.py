@@ -442,6 +442,42 @@ def capture_env_side():
         for name in ("vel", "rpyt"):
             out.update({f"{model}_ad_{name}_cmd_out": res[name][0], f"{model}_ad_{name}_last_vel_out": res[name][1],
                         f"{model}_ad_{name}_last_rates_out": res[name][2], f"{model}_ad_{name}_last_thrust_out": res[name][3]})
+    # ---- the fourth shipped airframe, hexa_6DOF_simple (the same links and joints as hexa_6DOF, a four-output control
+    #      block): parser scalars and the force map, from their own generator so that everything above stays bit for bit ----
+    rng = np.random.default_rng(32)
+    model = "hexa_6DOF_simple"
+    d = drone_of(model)
+    for k in ("M", "L", "KF", "KM", "MAX_SPEED_KMH", "GND_EFF_COEFF", "PROP_RADIUS", "DW_COEFF_1",
+              "DW_COEFF_2", "DW_COEFF_3", "INDI_ACTUATOR_NR", "INDI_OUTPUT_NR"):
+        out[f"{model}_{k}"] = np.array(getattr(d, k))
+    for k in ("J", "DRAG_COEFF", "PWM2RPM_SCALE", "PWM2RPM_CONST", "G1", "MIN_PWM", "MAX_PWM"):
+        out[f"{model}_{k}"] = np.array(getattr(d, k), dtype=np.float64)
+    out[f"{model}_TYPE"] = np.array(d.TYPE)
+    Fake = type("Fake", (), {"_quad_copter_physics": BaseAviary._quad_copter_physics,
+                             "_morphing_hexa_physics": BaseAviary._morphing_hexa_physics})
+    fake = Fake()
+    fake.drones, fake.DRONE_IDS, fake.CLIENT = [d], [7], 0
+    n_act, K = d.INDI_ACTUATOR_NR, 24
+    cmds = rng.uniform(np.array(d.MIN_PWM), np.array(d.MAX_PWM), (K, n_act))
+    cmds[0] = 0.1                                             # the example's initial action (fly_hexa_6DOF_simple.py:206-208)
+    cmds[1] = np.array(d.MAX_PWM)
+    cmds[2] = np.array(d.MIN_PWM)
+    seeds = 7000 + np.arange(K)
+    rec_kind, rec_link, rec_vec, rec_pos, rec_flag, fn, mn = [], [], [], [], [], [], []
+    for i in range(K):
+        np.random.seed(int(seeds[i]))
+        calls.clear()
+        BaseAviary._physics(fake, cmds[i].copy(), 0)
+        rec_kind.append([c[0] for c in calls]); rec_link.append([c[1] for c in calls])
+        rec_vec.append([c[2] for c in calls]); rec_pos.append([c[3] for c in calls])
+        rec_flag.append([c[4] for c in calls])
+        np.random.seed(int(seeds[i]))
+        fn.append(np.random.normal(0, 0.01, n_act))
+        mn.append(np.random.normal(0, 0.001, n_act))
+    out.update({f"{model}_fm_cmd": cmds, f"{model}_fm_seed": seeds, f"{model}_fm_kind": np.array(rec_kind),
+                f"{model}_fm_link": np.array(rec_link), f"{model}_fm_vec": np.array(rec_vec),
+                f"{model}_fm_pos": np.array(rec_pos), f"{model}_fm_flag": np.array(rec_flag),
+                f"{model}_fm_f_noise": np.array(fn), f"{model}_fm_m_noise": np.array(mn)})
     np.savez(os.path.join(OUT, "env_side.npz"), **out)
     print("env-side goldens written")
 
@@ -548,9 +584,11 @@ def main():
         ("robobee", INDIControl, False, 0.0, 0.0, 11),
         ("tello", INDIControl, False, 0.0, 0.0, 12),
         ("hexa_6DOF", INDIControl_6DOF, True, 0.3, 0.5, 13),
+        # the fourth shipped airframe: the QUAD controller class on six actuators (examples/fly_hexa_6DOF_simple.py:18, 202)
+        ("hexa_6DOF_simple", INDIControl, False, 0.0, 0.0, 14),
     ]:
         rng = np.random.default_rng(seed)
-        n_act = 6 if six else 4
+        n_act = 6 if (six or model == "hexa_6DOF_simple") else 4
         cases = make_cases(rng, 192, n_act, rt, rc)
         out = run_quad(cls, model, cases, six)
         cases.update(out)

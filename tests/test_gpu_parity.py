@@ -77,7 +77,7 @@ def _wrap_diff(a, b):
     return np.minimum(d, np.abs(d - 2 * math.pi))       # a yaw error within rounding of +-pi may land on either side
 
 
-@pytest.mark.parametrize("model", ["robobee", "tello"])
+@pytest.mark.parametrize("model", ["robobee", "tello", "hexa_6DOF_simple"])
 @pytest.mark.parametrize("layout", ["soa", "tile64"])
 def test_control_vs_golden(gpu, golden_dir, model, layout):
     """computeControl against the vectors the reference's own INDIControl produced.  Three links, each per case:
@@ -93,7 +93,7 @@ def test_control_vs_golden(gpu, golden_dir, model, layout):
     n = g["pos"].shape[0]
     rigid = np.concatenate([g["pos"], g["quat"], g["vel"], g["ang_vel"]], 1)
     mem = np.zeros((n, 13))
-    mem[:, 0:3], mem[:, 3:6], mem[:, 6], mem[:, 7:11] = g["last_vel"], g["last_rates"], g["last_thrust"], g["cmd"]
+    mem[:, 0:3], mem[:, 3:6], mem[:, 6], mem[:, 7:7 + t.n_act] = g["last_vel"], g["last_rates"], g["last_thrust"], g["cmd"]
     tgt = np.concatenate([g["target_pos"], g["target_vel"], g["target_acc"], g["target_rpy"][:, 2:3]], 1)
     for dt in np.unique(g["dt"]):
         sel = np.where(g["dt"] == dt)[0]
@@ -118,7 +118,7 @@ def test_control_vs_golden(gpu, golden_dir, model, layout):
         # (2) the pin
         o64 = mem[sel].copy()
         rc, pe64, ye64 = O.control(rigid[sel].copy(), o64, tgt[sel], float(dt))
-        gold = _golden_mem(g, sel, 4)
+        gold = _golden_mem(g, sel, t.n_act)
         assert rc == 0 and np.abs(o64 - gold).max() < 1e-9 and np.abs(pe64 - g["pos_e"][sel]).max() < 1e-12
         # (3) against the reference's numbers, slack = measured input-rounding effect, per case and field
         assert_control_parity(f"control_golden[{model},{layout}] vs reference", [t], None, r32, m32, t32, got, gold, dt32,
@@ -187,7 +187,7 @@ def test_roll_sweep_through_the_pinv_singularity(gpu, golden_dir):
     ctx.close()
 
 
-@pytest.mark.parametrize("model", ["robobee", "tello"])
+@pytest.mark.parametrize("model", ["robobee", "tello", "hexa_6DOF_simple"])
 def test_control_sequence_vs_golden(gpu, golden_dir, model):
     """Controller memory recursion over 60 calls (reference-generated sequence)."""
     nat, fleet = gpu
@@ -215,7 +215,7 @@ def test_control_sequence_vs_golden(gpu, golden_dir, model):
         assert O.control(rigid, o, tgt, dt)[0] == 0
         assert_control_parity(f"control_sequence[{model}]", [t], None, rigid, m0, tgt, got, o, dt)   # every call at the bar
         # and the recursion as a whole stays on the reference's own 60-call sequence (accumulated, absolute)
-        assert np.abs(got[:, 7:11] - g["cmd_out"][:, k]).max() < 1e-4, k
+        assert np.abs(got[:, 7:7 + t.n_act] - g["cmd_out"][:, k]).max() < 1e-4, k
         assert np.abs(got[:, 6] - g["last_thrust_out"][:, k]).max() < 1e-4 * (1 + np.abs(g["last_thrust_out"][:, k]).max()), k
     ctx.close()
 
@@ -383,7 +383,7 @@ def test_noise_replay_vs_oracle(gpu):
     ctx.close()
 
 
-@pytest.mark.parametrize("model", ["robobee", "tello", "hexa_6DOF"])
+@pytest.mark.parametrize("model", ["robobee", "tello", "hexa_6DOF", "hexa_6DOF_simple"])
 def test_force_map_vs_reference_recorded_calls(gpu, golden_dir, model):
     """The wrench the kernel applies == the sum of the applyExternalForce/applyExternalTorque calls the
     reference's own _physics made for the same command and noise draws (tests/golden/env_side.npz):
@@ -1693,6 +1693,9 @@ def test_fleet_examples_fly(gpu):
     assert np.abs(vel - want).max() < 0.1 * np.linalg.norm(want) + 0.02
     err_xy, err_z, tilt, fallbacks = load("fly_hexa_6DOF_fleet").main(["--num_drones", "700", "--duration_sec", "4"])
     assert err_xy.max() < 0.8 and err_z.max() < 0.05 and np.degrees(tilt.max()) < 3.0 and fallbacks == 0
+    # the fourth shipped airframe through the reference-shaped two-call loop (the quad controller class on six actuators)
+    err_xy, err_z, tilt = load("fly_hexa_6DOF_simple_fleet").main(["--num_drones", "700", "--duration_sec", "6"])
+    assert np.isfinite(err_xy).all() and np.median(err_xy) < 0.5 and err_z.max() < 0.3 and np.degrees(tilt.max()) < 30.0
 
 
 def test_c_caller_without_python_or_torch(gpu, tmp_path):
@@ -2638,6 +2641,15 @@ def test_every_instance_of_the_single_type_step_kernels(gpu, sub, seed):
     # k_step_hexa<NOISE, NT, S1, ACT>
     _sweep_case(gpu, f"sweep hexa plain[{sub},{seed}]", [hx], None, n, sub, seed, 0)
     _sweep_case(gpu, f"sweep hexa action[{sub},{seed}]", [hx], None, n, sub, seed, 0, action=act6)
+    # hexa_6DOF_simple (morphing-hexa physics, the quad law on six actuators): k_step_run<2, ..> for a fleet of it and for
+    # runs that hold it (one launch per run), the general kernel with an explicit action
+    hs = params.builtin_type("hexa_6DOF_simple")
+    _sweep_case(gpu, f"sweep hexa_simple plain[{sub},{seed}]", [hs], None, n, sub, seed, 0)
+    _sweep_case(gpu, f"sweep hexa_simple action[{sub},{seed}]", [hs], None, n, sub, seed, 0, action=act6)
+    tid3 = np.array([0] * 150 + [1] * 170 + [2] * 192, dtype=np.uint8)
+    _sweep_case(gpu, f"sweep runs of three kinds[{sub},{seed}]", [rb, hx, hs], tid3, n, sub, seed, 0,
+                runs=[(0, 150, 0), (150, 170, 1), (320, 192, 2)])
+    _sweep_case(gpu, f"sweep three kinds per lane[{sub},{seed}]", [rb, hx, hs], (np.arange(n) % 3).astype(np.uint8), n, sub, seed, 0)
     # type-major runs: k_step_runs<NOISE, NT, S1, ACT> (all runs in one launch); aligned runs, and runs that begin and end
     # inside tiles.  k_step_run<HEXA, NOISE, NT, S1> (one launch per run) serves a fleet that is ONE run: a homogeneous fleet
     # with the downwash force as input, and more runs than one launch holds (nine runs of two types here)

@@ -43,6 +43,30 @@ def _noise_by_id(O, types, tid, ids, seed, step_index, sub):
     return nz
 
 
+def _downwash_part(O, types, tid, r0, r1, sub):
+    """[n, 13]: how much of one Env.step's increment is the neighbour-downwash force's doing (per drone: the larger of the
+    force at the start and at the end of the step, over the mass, times the time it acts) — that part is itself an fp32
+    sum of exp() terms and only known to REL_TOL (tests/util.py:increment_ratio).  Plus, for the sub-steps behind the
+    first: the device's and the oracle's positions differ by fp32 rounding there, and the term of a nearly vertical close
+    pair (alpha ~ 1 / dz^2) turns that into a force difference of its own — measured by moving every receiver two fp32
+    ulps up and down against the others."""
+    from tests.util import REL_TOL, ulp32
+    n = r0.shape[0]
+    m = np.array([t.mass for t in types])[tid] if tid is not None else np.full(n, types[0].mass)
+    f0, f1 = O.downwash(r0, r0[:, 0:3], type_id=tid), O.downwash(r1, r1[:, 0:3], type_id=tid)
+    f = np.maximum(np.abs(f0), np.abs(f1))
+    sens = np.zeros(n)
+    if sub > 1:
+        for sign in (1.0, -1.0):
+            rp = r1.copy()
+            rp[:, 2] += sign * 2 * ulp32(r1[:, 2])
+            sens = np.maximum(sens, np.abs(O.downwash(rp, r1[:, 0:3], type_id=tid) - f1))
+    part = np.zeros((n, 13))
+    part[:, 7:10] = ((f + sens / REL_TOL) / m * DT * sub)[:, None]
+    part[:, 0:3] = part[:, 7:10] * DT * sub
+    return part
+
+
 def _runs_arr(nat, runs):
     arr = (nat.TypeRun * len(runs))()
     for k, (f, c, ty) in enumerate(runs):
@@ -188,6 +212,12 @@ def test_two_call_loop_on_runs_vs_oracle(gpu, sub, seed):
     # two QUAD types as runs: 20-wide rows through the same kernels
     tid4 = np.array([0] * 300 + [1] * 212, dtype=np.uint8)
     _two_call_case(gpu, "two-call two quad types" + s, [rb, te], tid4, [(0, 300, 0), (300, 212, 1)], 512, sub, seed)
+    # hexa_6DOF_simple: morphing-hexa physics + the quad law on six actuators — alone, and as one of three kinds of runs
+    hs = params.builtin_type("hexa_6DOF_simple")
+    _two_call_case(gpu, "two-call hexa_simple" + s, [hs], None, None, 512, sub, seed)
+    tid5 = np.array([0] * 150 + [1] * 170 + [2] * 192, dtype=np.uint8)
+    _two_call_case(gpu, "two-call three kinds" + s, [rb, hx, hs], tid5, [(0, 150, 0), (150, 170, 1), (320, 192, 2)], 512, sub, seed,
+                   ids=True, caller_io=True)
     # a row block that is not 8-byte aligned: the rows come from the observation kernel behind the step
     _two_call_case(gpu, "two-call hexa misaligned rows" + s, [hx], None, None, 512, sub, seed, align_obs=1)
     del dataclasses
@@ -280,7 +310,7 @@ def test_two_call_physics_fills_the_next_neighbour_grid(gpu):
     ctx.close()
 
 
-@pytest.mark.parametrize("kind", ["hexa", "mixed", "mixed_downwash"])
+@pytest.mark.parametrize("kind", ["hexa", "hexa_simple", "mixed", "mixed_downwash"])
 def test_env_step_then_computeControl_loop_on_every_fleet_kind(gpu, kind):
     """The reference-shaped surfaces end to end (examples/fly_hexa_6DOF.py:214-221): obs = env.step(action); action =
     ctrl.computeControlFromState(obs) for 12 iterations on a hexa fleet, an interleaved quad + hexa fleet (stored
@@ -296,6 +326,8 @@ def test_env_step_then_computeControl_loop_on_every_fleet_kind(gpu, kind):
     rng = np.random.default_rng(17)
     if kind == "hexa":
         models, tid, types = ["hexa_6DOF"], None, [hx]
+    elif kind == "hexa_simple":      # examples/fly_hexa_6DOF_simple.py:202-221
+        models, tid, types = ["hexa_6DOF_simple"], None, [params.builtin_type("hexa_6DOF_simple")]
     else:
         models, tid, types = ["robobee", "hexa_6DOF"], (np.arange(n) % 2).astype(np.uint8), [rb, hx]
     xyz = np.stack([rng.uniform(0, 60, n), rng.uniform(0, 60, n), rng.uniform(2, 12, n)], 1)
@@ -317,17 +349,16 @@ def test_env_step_then_computeControl_loop_on_every_fleet_kind(gpu, kind):
         a6 = np.zeros((n, 6)); a6[:, :na] = action.double().cpu().numpy()
         obs, _, _, _ = env.step(action)
         r1 = env.state.rigid_aos()
-        ext = None
-        if kind == "mixed_downwash":
-            fz = O.downwash(r0, r0[:, 0:3], type_id=tid)
-            ext = np.zeros((n, 3)); ext[:, 2] = f32(fz)
         r = r0.copy()
         last = np.zeros((n, 6))
-        O.physics(r, m0, sub, DT, action=a6, type_id=tid, last_action=last, ext_force=ext)
-        # the downwash force enters the velocity update like one more rotor thrust: |fz| / m joins the accelerations
-        more = float((np.abs(ext[:, 2]) / np.array([t.mass for t in types])[tid]).max()) / 9.8 if ext is not None else 0.0
+        fz = None
+        if kind == "mixed_downwash":                 # the term per physics sub-step, as the reference loops it
+            fz = O.downwash(r0, r0[:, 0:3], type_id=tid)
+            assert O.physics_downwash(r, m0, sub, DT, action=a6, type_id=tid, last_action=last) == 0
+        else:
+            O.physics(r, m0, sub, DT, action=a6, type_id=tid, last_action=last)
         assert_step_parity(f"env.step loop[{kind}]", types, tid, r0, m0, tg, r1, None, r, None, DT, dtc, sub, control=False,
-                           action=a6[:, :na], k=K_ULP * sub * (1.0 + more))
+                           action=a6[:, :na], part_rigid=_downwash_part(O, types, tid, r0, r, sub) if fz is not None else None)
         _check_obs_rows(f"env.step loop rows[{kind}]", O, obs.double().cpu().numpy(), r1, last, tid, types)
         action, pos_e, yaw_e = ctrl.computeControlFromState(dtc, None, target_pos=tp, target_rpy=np.array([0, 0, 0.2]))
         m1 = env.state.mem_aos()
@@ -418,3 +449,64 @@ def test_rccl_runs_at_world_size_one(gpu):
     assert st["backend"] == "nccl" and st["all_gather_positions_ok"] and st["grouped_isend_irecv_ok"], st
     assert st["all_reduce_on"].startswith("cuda")
     assert d["value"] > 1e8
+
+
+@pytest.mark.parametrize("surface", ["step_fused", "two_call"])
+def test_downwash_is_evaluated_per_physics_substep(gpu, surface):
+    """Physics.PYB_DW with AGGR_PHY_STEPS = 5 (what examples/fly_INDI.py's defaults select): the reference refreshes the
+    positions and applies _downwash INSIDE the sub-step loop (BaseAviary.py:510-536), so the force follows the drones through
+    the sub-steps.  The env launches [query -> one sub-step] pairs; checked per Env.step against the oracle that evaluates
+    the term per sub-step (orc_physics_downwash_batch), noise on, from the device's own previous state — and the result
+    must differ measurably from holding the first sub-step's force (the round-3 behaviour)."""
+    nat, fleet = gpu
+    from dronesim_amd.control import INDIControl
+    from dronesim_amd.envs import CtrlAviary, Physics
+    from dronesim_amd.fleet import Targets, frozen
+    rb, hx = params.builtin_type("robobee"), params.builtin_type("hexa_6DOF")
+    types = [rb, hx]
+    n, sub, seed = 900, 5, 11
+    rng = np.random.default_rng(29)
+    tid = (np.arange(n) % 2).astype(np.uint8)
+    # dense columns of drones, the upper ones descending fast on the lower ones: the term changes within one Env.step
+    xyz = np.stack([rng.uniform(0, 12, n), rng.uniform(0, 12, n), rng.uniform(1.0, 6.0, n)], 1)
+    vel = np.zeros((n, 3)); vel[:, 2] = rng.uniform(-6.0, 2.0, n)
+    env = CtrlAviary(["robobee", "hexa_6DOF"], n, initial_xyzs=xyz, initial_vels=vel, aggregate_phy_steps=sub, noise_seed=seed,
+                     dict_io=False, type_ids=tid, physics=Physics.PYB_DW, layout="tile64")
+    O = orc.Oracle(types)
+    dtc = float(np.float32(sub / 240))
+    tpos = f32(xyz)
+    tg_np = np.concatenate([tpos, np.zeros((n, 6)), np.zeros((n, 1))], 1)
+    tg = Targets(env.ctx, n, "tile64")
+    tg.set(pos=tpos.T, yaw=0.0)
+    ctrl = INDIControl("hexa_6DOF", env=env) if surface == "two_call" else None
+    if ctrl is not None:
+        env._housekeeping()          # (the controller's reset wrote the memory of a fresh fleet; positions and velocities again)
+    action = torch.full((n, 6), 0.45, device=env.ctx.device)
+    action[torch.from_numpy(tid == 0).to(env.ctx.device), 4:] = 0.0
+    held_differs = 0.0
+    for k in range(4):
+        r0, m0 = env.state.rigid_aos(), env.state.mem_aos()
+        a6 = action.double().cpu().numpy() if (surface == "two_call" or k == 0) else None
+        if surface == "two_call":
+            env.step(action)
+        else:
+            env.step_fused(tg, action=action if k == 0 else None)
+        r1 = env.state.rigid_aos()
+        nz = _noise_by_id(O, types, tid, np.arange(n), seed, k, sub)
+        r = r0.copy()
+        assert O.physics_downwash(r, m0, sub, DT, action=a6, noise=nz, type_id=tid) == 0
+        # what holding the force of the first sub-step would have given (round 3)
+        rh = r0.copy()
+        fz = O.downwash(r0, r0[:, 0:3], type_id=tid)
+        ext = np.zeros((n, 3)); ext[:, 2] = fz
+        O.physics(rh, m0, sub, DT, action=a6, noise=nz, type_id=tid, ext_force=ext)
+        held_differs = max(held_differs, float(np.abs(rh[:, 9] - r[:, 9]).max()))
+        applied = a6[:, :6] if a6 is not None else m0[:, 7:13]
+        assert_step_parity(f"downwash per sub-step[{surface}]", types, tid, r0, m0, tg_np, r1, None, r, None, DT, dtc, sub,
+                           control=False, action=applied, part_rigid=_downwash_part(O, types, tid, r0, r, sub))
+        if surface == "two_call":
+            action, _, _ = ctrl.computeControlFromState(dtc, None, target_pos=frozen(torch.from_numpy(tpos.astype(np.float32)).to(env.ctx.device)))
+    assert held_differs > 1e-4          # m/s: the case tells the two semantics apart by far more than the bar
+    with pytest.raises(NotImplementedError):
+        env.capture_fused(tg, 4)
+    env.close()

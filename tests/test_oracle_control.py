@@ -39,7 +39,7 @@ def test_pinv_matches_numpy():
     np.testing.assert_allclose(orc.pinv(A), np.linalg.pinv(A), rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("model", ["robobee", "tello"])
+@pytest.mark.parametrize("model", ["robobee", "tello", "hexa_6DOF_simple"])
 def test_ctrl_params_match_reference(golden_dir, model):
     g = _load(golden_dir, f"ctrl_params_{model}.npz")
     t = params.builtin_type(model)
@@ -62,15 +62,19 @@ def _mem_from_case(g, i, n_act):
     return mem
 
 
-@pytest.mark.parametrize("model", ["robobee", "tello"])
+@pytest.mark.parametrize("model", ["robobee", "tello", "hexa_6DOF_simple"])
 def test_indi_single_call(golden_dir, model):
+    """The quad law of INDIControl.py — on four actuators, and on the six of hexa_6DOF_simple (examples/
+    fly_hexa_6DOF_simple.py:18: G1 is 4 x 6, pinv(G1 / 0.05) 6 x 4, all six commands incremented and clipped)."""
     g = _load(golden_dir, f"indi_single_{model}.npz")
     t = params.builtin_type(model)
     O = orc.Oracle([t])
     n = g["pos"].shape[0]
+    na = t.n_act
+    assert g["cmd_out"].shape[1] == na
     for i in range(n):
         # C2 alone
-        mem = _mem_from_case(g, i, 4)
+        mem = _mem_from_case(g, i, na)
         thrust, te, pe = orc.indi_position(t, float(g["dt"][i]), g["pos"][i], g["quat"][i], g["vel"][i],
                                            g["target_pos"][i], g["target_rpy"][i], g["target_vel"][i],
                                            g["target_acc"][i], mem)
@@ -80,14 +84,14 @@ def test_indi_single_call(golden_dir, model):
         np.testing.assert_array_equal(pe, g["pos_e"][i])
     # C1 batch
     rigid = np.concatenate([g["pos"], g["quat"], g["vel"], g["ang_vel"]], 1)
-    mem = np.stack([_mem_from_case(g, i, 4) for i in range(n)])
+    mem = np.stack([_mem_from_case(g, i, na) for i in range(n)])
     tgt = np.concatenate([g["target_pos"], g["target_vel"], g["target_acc"], g["target_rpy"][:, 2:3]], 1)
     for dt in np.unique(g["dt"]):
         sel = np.where(g["dt"] == dt)[0]
         r, m, tg = rigid[sel].copy(), mem[sel].copy(), tgt[sel].copy()
         rc, pos_e, yaw_e = O.control(r, m, tg, float(dt))
         assert rc == 0
-        np.testing.assert_allclose(m[:, 7:11], g["cmd_out"][sel], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(m[:, 7:7 + na], g["cmd_out"][sel], rtol=0, atol=1e-8)
         np.testing.assert_array_equal(pos_e, g["pos_e"][sel])
         np.testing.assert_allclose(yaw_e, g["yaw_e"][sel], rtol=0, atol=1e-12)
         np.testing.assert_array_equal(m[:, 0:3], g["last_vel_out"][sel])
@@ -96,7 +100,7 @@ def test_indi_single_call(golden_dir, model):
                                    atol=TOL * (1 + np.abs(g["last_thrust_out"][sel]).max()))
 
 
-@pytest.mark.parametrize("model", ["robobee", "tello"])
+@pytest.mark.parametrize("model", ["robobee", "tello", "hexa_6DOF_simple"])
 def test_indi_sequence(golden_dir, model):
     g = _load(golden_dir, f"indi_sequence_{model}.npz")
     t = params.builtin_type(model)
@@ -109,7 +113,7 @@ def test_indi_sequence(golden_dir, model):
                               g["target_rpy"][:, k, 2:3]], 1)
         rc, pos_e, yaw_e = O.control(rigid.copy(), mem, tgt, float(g["dt"]))
         assert rc == 0
-        np.testing.assert_allclose(mem[:, 7:11], g["cmd_out"][:, k], rtol=0, atol=1e-8, err_msg=f"step {k}")
+        np.testing.assert_allclose(mem[:, 7:7 + t.n_act], g["cmd_out"][:, k], rtol=0, atol=1e-8, err_msg=f"step {k}")
         np.testing.assert_allclose(yaw_e, g["yaw_e"][:, k], rtol=0, atol=1e-12)
         np.testing.assert_allclose(mem[:, 6], g["last_thrust_out"][:, k], rtol=0, atol=1e-8)
 
@@ -208,7 +212,7 @@ def test_golden_fixtures_regenerate_bit_identically(tmp_path):
             else:
                 sys.modules[k] = v
     files = sorted(glob.glob(os.path.join(here, "*.npz")))
-    assert len(files) == 14
+    assert len(files) == 17
     for f in files:
         a, b = np.load(f, allow_pickle=True), np.load(os.path.join(str(tmp_path), os.path.basename(f)), allow_pickle=True)
         assert set(a.files) == set(b.files), f

@@ -22,7 +22,7 @@ def _d(a):
     return a.ctypes.data_as(D)
 
 
-@pytest.mark.parametrize("model", ["robobee", "tello", "hexa_6DOF"])
+@pytest.mark.parametrize("model", ["robobee", "tello", "hexa_6DOF", "hexa_6DOF_simple"])
 def test_type_table_matches_reference_urdf_parser(model):
     """P0: the build's own URDF reader vs BaseAviary._parseURDFParameters."""
     t = params.builtin_type(model)
@@ -38,7 +38,7 @@ def test_type_table_matches_reference_urdf_parser(model):
     assert t.gnd_eff_coeff == float(g("GND_EFF_COEFF")) and t.prop_radius == float(g("PROP_RADIUS"))
     np.testing.assert_array_equal(np.asarray(t.dw_coeff), [g("DW_COEFF_1"), g("DW_COEFF_2"), g("DW_COEFF_3")])
     assert t.max_speed_kmh == float(g("MAX_SPEED_KMH"))
-    if model != "hexa_6DOF":
+    if not model.startswith("hexa_6DOF"):
         # quads: one massive link.  (hexa: the reference's parser reads the FIRST link only, 0.2 kg, a value the
         # path never uses; Bullet sums all links of the URDF, 0.86 kg, which is what the type table carries)
         assert t.mass == float(g("M"))
@@ -70,15 +70,15 @@ def test_quad_force_map_vs_reference_calls(model):
         np.testing.assert_allclose(tau, tau_ref, rtol=1e-12, atol=1e-16)
 
 
-def test_hexa_force_map_vs_reference_calls():
+@pytest.mark.parametrize("m", ["hexa_6DOF", "hexa_6DOF_simple"])
+def test_hexa_force_map_vs_reference_calls(m):
     """P3: per prop j one LINK_FRAME force [0,0,F_j] and one LINK_FRAME torque [0,0,±tau_j] on link 2j+1;
-    the link frames (tilted props) come from the URDF joints."""
-    t = params.builtin_type("hexa_6DOF")
+    the link frames (tilted props) come from the URDF joints.  Both morphing-hexa URDFs (the same links and joints)."""
+    t = params.builtin_type(m)
     P = t.to_c()
     f = orc.lib().orc_hexa_wrench
     f.argtypes = [ctypes.POINTER(type(P)), D, D, D, D, D, D]
     r, ax = np.asarray(t.rotor_pos)[:6], np.asarray(t.rotor_axis)[:6]
-    m = "hexa_6DOF"
     for i in range(G[f"{m}_fm_cmd"].shape[0]):
         kind, link, vec = G[f"{m}_fm_kind"][i], G[f"{m}_fm_link"][i], G[f"{m}_fm_vec"][i]
         assert list(kind) == [0, 1] * 6 and list(link) == [1, 1, 3, 3, 5, 5, 7, 7, 9, 9, 11, 11]
