@@ -273,6 +273,10 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
   const uint64_t noise_key = (uint64_t)(nid >= 0 ? nid : i);
   V3 F, tau;
   if (NOISE == 0) quad_wrench(T, cmd, nullptr, F, tau);   // cmd is constant over the sub-steps
+  // (several sub-steps with noise: the noise-free part of the map once, the normals' part per sub-step)
+  constexpr bool SPLIT = NOISE != 0 && NSUB != 1 && !OPTS;
+  QuadBase qb = QuadBase{0.0f, V3{0.0f, 0.0f, 0.0f}};
+  if (SPLIT) qb = quad_wrench_base(T, cmd);
   const int n_sub = NSUB > 0 ? NSUB : a.substeps;
   for (int k = 0; k < n_sub; ++k) {
     if (NOISE != 0) {
@@ -286,7 +290,7 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
       } else {
         noise_normals<4>(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);   // N(0,.01) | N(0,.001)
       }
-      quad_wrench(T, cmd, nz, F, tau);
+      if (SPLIT) quad_wrench_noise(T, qb, nz, F, tau); else quad_wrench(T, cmd, nz, F, tau);
     }
     if (OPTS && (PLANE || (a.options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)))) {
       V3 F2 = F + ext, tau2 = tau;
@@ -312,6 +316,9 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
   const uint64_t noise_key = (uint64_t)(nid >= 0 ? nid : i);
   V3 F, tau;
   if (!NOISE) hexa_wrench(T, cmd, nullptr, F, tau);
+  constexpr bool SPLIT = NOISE && !ONE;
+  HexaBase hb = HexaBase{V3{0.0f, 0.0f, 0.0f}, V3{0.0f, 0.0f, 0.0f}};
+  if (SPLIT) hb = hexa_wrench_base(T, cmd);
   // The state holds what PyBullet reports — the BASE link's centre of mass (dsim_type_params.base_offset); the composite
   // body is integrated about its own: p = p_b - R d, v = v_b - w x (R d) in front of the sub-steps, and back behind them.
   // The position never makes the round trip: p_b' = p_b + sum(dt v_com) + (R' d - R d) — the sub-steps move the stored
@@ -332,7 +339,7 @@ __device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, 
       } else {
         noise_normals<6>(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);   // N(0,.01) | N(0,.001)
       }
-      hexa_wrench(T, cmd, nz, F, tau);
+      if (SPLIT) hexa_wrench_noise(T, hb, nz, F, tau); else hexa_wrench(T, cmd, nz, F, tau);
     }
     bullet_step<PLANE>(T, a.dt_phys, s, F + ext, tau);
   }
@@ -2447,6 +2454,7 @@ static void to_dev(const dsim_type_params& p, DevType* d) {
     d->rxa[j][0] = (float)(r[1] * ax[2] - r[2] * ax[1]);
     d->rxa[j][1] = (float)(r[2] * ax[0] - r[0] * ax[2]);
     d->rxa[j][2] = (float)(r[0] * ax[1] - r[1] * ax[0]);
+    if (j < 4) for (int k = 0; k < 3; ++k) d->rsum[k] += (float)r[k];
     for (int i = 0; i < DSIM_MAX_ACT; ++i) {
       d->alloc[j][i] = (float)p.alloc[j][i];
       d->alloc2[j][i] = (float)p.alloc2[j][i];

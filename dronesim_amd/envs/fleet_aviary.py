@@ -243,7 +243,9 @@ class CtrlAviary:
                 # inline — the two cross-stream events cost more than the ~2 us launch they take off the chain.
                 self._fb_stream = torch.cuda.Stream(device=self.ctx.device)
                 self._fb_done, self._fb_go = torch.cuda.Event(), torch.cuda.Event()
-                self.state.pre_access = self._join_fallback
+        # the host accessors of the state block (state.pos, .mem_aos(), set_fields ...) see a CONSISTENT block: a deferred
+        # fallback pass joined, and the six fields a chained sequence leaves stale written back first
+        self.state.pre_access = self._before_host_access
         self.step_counter = 0
         self._env_steps = 0
         # what the ctx owns for this fleet size is allocated now, not inside the first step
@@ -257,6 +259,11 @@ class CtrlAviary:
             a = self.order.to_storage_np(a)
         t[:, : self.NUM_DRONES] = torch.from_numpy(np.ascontiguousarray(a.T)).float()
         return t.to(self.ctx.device)
+
+    def _before_host_access(self) -> None:
+        self._join_fallback()
+        if self._chain_live:
+            self.materialize()
 
     def _join_fallback(self) -> None:
         """Orders the current stream behind a deferred WLS fallback pass (see __init__)."""
