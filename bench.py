@@ -357,23 +357,46 @@ def memory_yardstick(n_drones):
         return {"device_copy_GBps": None, "yardstick_error": repr(e)[:200]}
 
 
-def two_call_child(a, kind="quad"):
+def child_line(a, extra, placement=True, timeout=300):
+    """`bench.py <extra>` as a child process (this one keeps its fleets but is idle meanwhile), placement by trial on or off
+    (DSIM_PLACEMENT): its JSON line."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--warmup", str(a.warmup), "--no-also", "--no-cpu-baseline", "--layout", a.layout,
+           "--noise-seed", str(a.noise_seed), "--stream", a.stream] + (["--lib", a.lib] if a.lib else []) + list(extra)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "DSIM_BENCH_FORCE_DIST")}
+    env["DSIM_PLACEMENT"] = "1" if placement else "0"
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def placement_cost(log):
+    """What the searches of a run cost: seconds spent, and the most device memory held at once (transient)."""
+    rows = [r for r in (log or []) if "seconds" in r]
+    return {"placement_s": round(sum(r["seconds"] for r in rows), 3), "placement_peak_bytes": max([r.get("peak_bytes", 0) for r in rows] + [0]),
+            "searches": len(rows)}
+
+
+def two_call_child(a, kind="quad", placement=True):
     """`bench.py --workload two_call_loop --two-call-kind KIND` as a child process (this one keeps its fleets but is idle
     meanwhile): its line, reduced to the entry the default line carries."""
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "two_call_loop", "--two-call-kind", kind,
            "--steps", str(max(50, a.steps // 2)),
            "--warmup", str(a.warmup), "--no-also", "--no-cpu-baseline", "--layout", a.layout, "--noise-seed", str(a.noise_seed),
            "--stream", a.stream] + (["--lib", a.lib] if a.lib else [])
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "DSIM_BENCH_FORCE_DIST")}
+    env["DSIM_PLACEMENT"] = "1" if placement else "0"
     try:
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
         d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-        return {"drone_steps_per_s": d["value"], "loop_us": d["ms_per_step"] * 1e3, "steps_timed": d["steps_timed"],
-                "drones": d["config"]["drones_per_gpu"], "loop_us_device": d["roofline"]["launch_us"],
-                "bytes_per_drone_step": TWO_CALL_BYTES[kind][0], "hbm_frac": d["roofline"]["frac"],
-                "kernel": d["roofline"]["kernel"],
-                "measured_in": f"a child process running `bench.py --workload two_call_loop --two-call-kind {kind}` alone",
-                "note": TWO_CALL_BYTES[kind][1], "placement": d.get("placement")}
+        e = {"drone_steps_per_s": d["value"], "loop_us": d["ms_per_step"] * 1e3, "steps_timed": d["steps_timed"],
+             "drones": d["config"]["drones_per_gpu"], "loop_us_device": d["roofline"]["launch_us"],
+             "bytes_per_drone_step": TWO_CALL_BYTES[kind][0], "hbm_frac": d["roofline"]["frac"],
+             "kernel": d["roofline"]["kernel"], "placement_by_trial": bool(placement),
+             "measured_in": f"a child process running `bench.py --workload two_call_loop --two-call-kind {kind}` alone"}
+        if placement:
+            e.update(note=TWO_CALL_BYTES[kind][1], placement=d.get("placement"), placement_cost=placement_cost(d.get("placement")))
+        return e
     except Exception as e:          # an extra must not cost the headline
         return {"error": repr(e)[:300]}
 
@@ -699,8 +722,10 @@ def main(argv=None):
                          "launch_us": launch_s * 1e6},
         }
         if fl.env.ctx.placement_log:
-            # where the fleet-sized arrays beside the state block were put, by measurement (dronesim_amd/placement.py)
+            # where the fleet-sized arrays beside the state block were put, by measurement (dronesim_amd/placement.py), and
+            # what the searches cost (seconds; device memory held at once while walking — transient, straight from the driver)
             out["placement"] = list(fl.env.ctx.placement_log)
+            out["placement_cost"] = placement_cost(fl.env.ctx.placement_log)
         if exchange is not None:
             out["exchange"] = exchange
         if force_dist and world == 1:
@@ -784,6 +809,21 @@ def main(argv=None):
             also["hexa_env_step_then_computeControl"] = two_call_child(a, "hexa")
             also["mixed_interleaved_env_step_then_computeControl"] = two_call_child(a, "mixed")
             also["config5_shard_two_call"] = two_call_child(a, "config5")
+            # placement by trial ON (above, the default) and OFF, from the same process tree: what the search buys on THIS box
+            off = {}
+            try:
+                d0 = child_line(a, ["--steps", str(a.steps)], placement=False)
+                off["headline"] = {"launch_us": d0["roofline"]["launch_us"], "hbm_frac": d0["roofline"]["frac"],
+                                   "drone_steps_per_s": d0["value"], "with_placement_launch_us": launch_s * 1e6}
+            except Exception as e:
+                off["headline"] = {"error": repr(e)[:200]}
+            for kind, name in (("quad", "config2x1024_env_step_then_computeControl"), ("hexa", "hexa_env_step_then_computeControl"),
+                               ("mixed", "mixed_interleaved_env_step_then_computeControl")):
+                e0 = two_call_child(a, kind, placement=False)
+                off[name] = {k: e0.get(k) for k in ("loop_us_device", "hbm_frac", "drone_steps_per_s", "error") if k in e0}
+                if "loop_us_device" in e0 and "loop_us_device" in also.get(name, {}):
+                    off[name]["with_placement_loop_us_device"] = also[name]["loop_us_device"]
+            also["without_placement_by_trial"] = off
             if isinstance(also.get("config5_shard_65536_mixed_downwash"), dict) and "loop_us_device" in also["config5_shard_two_call"]:
                 also["config5_shard_two_call"]["ratio_to_fused_chain"] = (
                     also["config5_shard_two_call"]["loop_us_device"] / also["config5_shard_65536_mixed_downwash"]["launch_us"])

@@ -19,7 +19,7 @@ EXPORTS = (
     "dsim_physics", "dsim_control", "dsim_control2", "dsim_step_adaptor", "dsim_traj_sample", "dsim_materialize",
     "dsim_counter_add", "dsim_reserve", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash",
     "dsim_downwash_workspace", "dsim_downwash_prebin_ok", "dsim_downwash_reset", "dsim_adjacency", "dsim_wls_fallback", "dsim_fleet_bounds",
-    "dsim_halo_pack", "dsim_downwash_workspace_halo",
+    "dsim_halo_pack", "dsim_downwash_workspace_halo", "dsim_dev_alloc", "dsim_dev_free",
 )
 
 ABI_VERSION = 6
@@ -167,6 +167,8 @@ def load(path: str = None) -> ctypes.CDLL:
     lib.dsim_wls_fallback.argtypes = [vp, vp, i64, View, vp, vp]
     lib.dsim_fleet_bounds.argtypes = [vp, vp, i64, View, vp]
     lib.dsim_halo_pack.argtypes = [vp, vp, i64, View, ctypes.POINTER(HaloPlan)]
+    lib.dsim_dev_alloc.argtypes = [vp, i64, ctypes.POINTER(vp)]
+    lib.dsim_dev_free.argtypes = [vp, vp]
     lib.dsim_downwash_workspace_halo.restype = ctypes.c_int64
     lib.dsim_downwash_workspace_halo.argtypes = [i64, i64, i32, i32]
     if lib.dsim_abi_version() != ABI_VERSION:

@@ -117,33 +117,37 @@ class INDIControl(BaseControl):
         st.set_fields(20, cmd)
 
     def _place_outputs(self, a) -> None:
-        """Large homogeneous quad fleets: where the arrays this launch WRITES (command, position error, yaw error) lie
-        relative to the state block whose controller memory it updates is worth ~6 % of it (placement.py).  The launch has
-        no neutral form, so: snapshot of the state block, real passes on a few candidates, snapshot back."""
+        """Large fleets: where the arrays this launch WRITES (command, position error, yaw error) lie relative to the state
+        block whose controller memory it updates is worth ~6 % of it (placement.py).  A controller bound to an env takes the
+        room the env left behind its placed observation rows (one allocation, one search); a stand-alone one searches for
+        itself — the launch has no neutral form, so: snapshot of the state block, real passes on a few candidates,
+        snapshot back."""
         from .. import placement
-        st, n_pad = self.state, self.state.n_pad
-        if not (self.ctx.placement and self._type_id is None and self.ctx.n_act == 4 and 4 * 8 * n_pad >= placement.MIN_BYTES
-                and type(self) is INDIControl):
+        st, n_pad, na = self.state, self.state.n_pad, self.ctx.n_act
+        if not self.ctx.placement:
             return
+        if self.env is not None and self.env._written_tail is None and self.env._placement_applies(4 * self.n * (16 + na)):
+            self.env._obs_tensor()                       # (the env places its rows, and the room behind them, now)
         tail = getattr(self.env, "_written_tail", None) if self.env is not None else None
-        if tail is not None and tuple(tail.shape) == (8, n_pad):
-            # the env has placed its observation rows and left room behind them: the same allocation suits these arrays
+        if tail is not None and tuple(tail.shape) == (na + 4, n_pad):
             tail.zero_()
-            self._cmd, self._pos_e, self._yaw_e = tail[0:4], tail[4:7], tail[7]
+            self._cmd, self._pos_e, self._yaw_e = tail[0:na], tail[na:na + 3], tail[na + 3]
             self.ctx.placement_log.append({"array": "computeControl outputs", "bytes": 4 * tail.numel(),
                                            "placed": "behind the env's observation rows (one allocation, one search)"})
+            return
+        if not (self.env is None and self._type_id is None and 4 * (na + 4) * n_pad >= placement.MIN_BYTES):
             return
         snap = st.data.clone()
         view, tview, ref = st.view(), self._targets.view(), ctypes.byref(a)
         lib, h = self.ctx.lib, self.ctx.handle
 
-        def trial(c):      # c: [8, n_pad] = cmd (4) | pos_e (3) | yaw_e (1)
-            nat.check(lib.dsim_control2(h, self.ctx.stream_ptr(), self.n, view, tview, ref, c[4:7].data_ptr(), c[7].data_ptr(),
-                                        c[0:4].data_ptr()))
-        keep = placement.place_rows(self.ctx.device, (8, n_pad), trial, report=self.ctx.placement_log,
-                                    label="computeControl outputs")
+        def trial(c):      # c: [n_act + 4, n_pad] = cmd | pos_e (3) | yaw_e (1)
+            nat.check(lib.dsim_control2(h, self.ctx.stream_ptr(), self.n, view, tview, ref, c[na:na + 3].data_ptr(),
+                                        c[na + 3].data_ptr(), c[0:na].data_ptr()))
+        keep = placement.place_rows(self.ctx.device, (na + 4, n_pad), trial, report=self.ctx.placement_log,
+                                    label="computeControl outputs", ctx=self.ctx)
         st.data.copy_(snap)
-        self._cmd, self._pos_e, self._yaw_e = keep[0:4], keep[4:7], keep[7]
+        self._cmd, self._pos_e, self._yaw_e = keep[0:na], keep[na:na + 3], keep[na + 3]
 
     def computeControl(self, control_timestep, cur_pos, cur_quat, cur_vel, cur_ang_vel, target_pos,
                        target_vel=np.zeros(3), target_acc=np.zeros(3), target_rpy=np.zeros(3),

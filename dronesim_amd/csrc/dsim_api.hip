@@ -2561,6 +2561,18 @@ int dsim_destroy(dsim_ctx* ctx) {
   return (int)e;
 }
 
+int dsim_dev_alloc(dsim_ctx* ctx, int64_t bytes, void** out) {
+  if (!ctx || !out || bytes <= 0) return DSIM_E_ARG;
+  *out = nullptr;
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e == hipSuccess) e = hipMalloc(out, (size_t)bytes);
+  return (int)e;
+}
+int dsim_dev_free(dsim_ctx* ctx, void* ptr) {
+  if (!ctx) return DSIM_E_ARG;
+  return ptr ? (int)hipFree(ptr) : DSIM_OK;           // (hipFree waits for the work that may still use the block)
+}
+
 int dsim_query(dsim_ctx* ctx, void* stream, int32_t what, int64_t* value_out) {
   if (!ctx || !value_out || what < 0 || what > 3) return DSIM_E_ARG;
   unsigned long long h[8 + DSIM_GROUND_SHARDS];

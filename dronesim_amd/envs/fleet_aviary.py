@@ -208,7 +208,7 @@ class CtrlAviary:
         self._obs_buf = None      # [N, 16+n_act], allocated on the first observe()
         self._ground_trial = 0    # ground contacts counted by the placement trials of _obs_tensor (not Env.steps)
         self._graph_made = False  # a captured hipGraph holds the state block's address: it is not moved any more
-        self._written_tail = None  # [8, n_pad] behind the placed observation rows: a bound controller's outputs go there
+        self._written_tail = None  # [n_act + 4, n_pad] behind the placed observation rows: a bound controller's outputs go there
         self._adjacency = None    # grid for neighbors(), built on first use
         self._action_keep = None  # keeps a zero-copy action tensor alive while the launch that reads it is queued
         self._action_ptr_last = None
@@ -551,45 +551,78 @@ class CtrlAviary:
         self._load_action(action, caller_order)
         return self._action_buf.data_ptr()
 
+    def _placement_applies(self, nbytes: int) -> bool:
+        """Arrays written beside the state block are placed by trial (placement.py) for fleets that are bound by HBM and that
+        the fast kernels serve: large ones, without the downwash chain, without the drag / ground / plane options."""
+        from .. import placement
+        served = self._type_id is None or (self._runs is not None and len(self._runs) <= 8)
+        return bool(self.ctx.placement and nbytes >= placement.MIN_BYTES and served and self._downwash is None
+                    and self._phys_options == 0)
+
+    def _move_state(self, new_block: torch.Tensor) -> None:
+        """The state block into another allocation (same contents).  Everything that holds its address is dropped: the
+        prepared argument blocks of the fused step, the downwash and halo plans' cached views."""
+        assert not self._chain_live and not self._graph_made, "the state block is pinned (chained sequence / captured graph)"
+        new_block.copy_(self.state.data)
+        self.state.data = new_block
+        self._fused_plan = self._fused_plan_dw = None
+        dw = self._downwash
+        if dw is not None:
+            dw._single = dw._halo_args = None
+            if dw.halo is not None:
+                dw.halo._pack_call = None
+
     def _obs_tensor(self) -> torch.Tensor:
         if self._obs_buf is None:
             shape = (self.NUM_DRONES, 16 + self.n_act)
             from .. import placement
-            # a large homogeneous quad fleet (k_physics_fast writes the rows beside the state it updates in place): WHERE
-            # the rows lie is worth 10-15 % of that launch and is chosen by timing it (placement.py)
-            if (self.ctx.placement and 4 * shape[0] * shape[1] >= placement.MIN_BYTES and self._type_id is None
-                    and self.n_act == 4 and self._downwash is None and self._phys_options == 0):
+            # a large fleet on the fast kernels (the Env.step launch writes the rows beside the state it updates in place):
+            # WHERE the rows lie is worth 10-15 % of that launch and is chosen by timing it (placement.py)
+            if self._placement_applies(4 * shape[0] * shape[1]):
+                self.materialize()
                 before = self.ctx.query(nat.QUERY_GROUND_CONTACTS)
                 echo = self._last_action.clone()          # the passes echo the (clipped) action buffer: put back below
+                # Zero-sub-step passes change nothing on a quad fleet (the state is read and written back bit for bit); on
+                # the morphing hexa the base-link / composite offset makes the round trip of the velocity round: a snapshot
+                # of the state block is put back behind the passes.
+                snap = None if (self.n_act == 4 and self._type_id is None) else self.state.data.clone()
                 log = self.ctx.placement_log
                 # (one allocation for everything that is written beside the state block: the rows, and behind them the
-                # 8 x n_pad floats a bound INDIControl writes — command, position error, yaw error; what suits the one
-                # suits the other, and the controller need not search)
-                n_rows, n_tail = shape[0] * shape[1], 8 * self.state.n_pad
+                # (n_act + 4) x n_pad floats a bound INDIControl writes — command, position error, yaw error; what suits the
+                # one suits the other, and the controller need not search)
+                n_rows, n_tail = shape[0] * shape[1], (self.n_act + 4) * self.state.n_pad
                 flat = (n_rows + n_tail,)
 
                 def split(block):
-                    self._obs_buf, self._written_tail = block[:n_rows].view(shape), block[n_rows:].view(8, self.state.n_pad)
-                split(placement.place_rows(self.ctx.device, flat, self._rows_trial, report=log))
+                    self._obs_buf = block[:n_rows].view(shape)
+                    self._written_tail = block[n_rows:].view(self.n_act + 4, self.state.n_pad)
+                split(placement.place_rows(self.ctx.device, flat, self._rows_trial, report=log, ctx=self.ctx))
                 if log and log[-1]["decided_by"] == "all alike" and not self._graph_made:
                     # Every candidate timed alike.  Either all of them are good — or the STATE block itself lies across two
                     # regions of device memory (one process in ten), and then no place for the rows is.  One more try with
                     # the state in a fresh allocation (same contents: the passes change nothing); the better pair stays.
                     rows1, tail1, state1, best1 = self._obs_buf, self._written_tail, self.state.data, log[-1]["chosen_pass_us"]
                     self._obs_buf = self._written_tail = None
-                    torch.cuda.empty_cache()
-                    self.state.data = torch.empty_like(state1)
-                    self.state.data.copy_(state1)
-                    self._fused_plan = self._fused_plan_dw = None
-                    block2 = placement.place_rows(self.ctx.device, flat, self._rows_trial, report=log)
-                    log[-1]["state_block"] = "moved to a fresh allocation"
-                    if log[-1]["chosen_pass_us"] < 0.95 * best1:
-                        split(block2)
+                    try:
+                        fresh = placement._DriverBlock(self.ctx, tuple(state1.shape)).tensor()
+                    except MemoryError:
+                        fresh = None
+                    if fresh is not None:
+                        self._move_state(fresh)
+                        block2 = placement.place_rows(self.ctx.device, flat, self._rows_trial, report=log, ctx=self.ctx)
+                        log[-1]["state_block"] = "moved to a fresh allocation"
+                        if log[-1]["chosen_pass_us"] < 0.95 * best1:
+                            split(block2)
+                        else:
+                            self._move_state(state1)
+                            self._obs_buf, self._written_tail = rows1, tail1
+                            log[-1]["state_block"] = "a fresh allocation was no better: kept where it was"
+                        del block2
                     else:
-                        self.state.data, self._obs_buf, self._written_tail = state1, rows1, tail1
-                        log[-1]["state_block"] = "a fresh allocation was no better: kept where it was"
-                    del rows1, tail1, block2, state1
-                    torch.cuda.empty_cache()
+                        self._obs_buf, self._written_tail = rows1, tail1
+                    del rows1, tail1, state1, fresh
+                if snap is not None:
+                    self.state.data.copy_(snap)
                 self._last_action.copy_(echo)
                 # (a drone that sits on the ground is counted by every pass, also by these: not Env.steps)
                 self._ground_trial += self.ctx.query(nat.QUERY_GROUND_CONTACTS) - before
@@ -625,7 +658,7 @@ class CtrlAviary:
             tview.base = c.data_ptr()
             nat.check(self.ctx.lib.dsim_step(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, sview, tview, ref))
         keep = placement.place_rows(self.ctx.device, tuple(old.shape), trial, report=self.ctx.placement_log,
-                                    label="per-drone targets", clearly=0.0, walk_bytes=4 << 30)
+                                    label="per-drone targets", clearly=0.0, walk_bytes=4 << 30, ctx=self.ctx)
         keep.copy_(old)
         targets.data = keep
         self.state.data.copy_(snap)
@@ -638,6 +671,8 @@ class CtrlAviary:
         memory streams, the state read and written back bit for bit (placement.place_rows times it)."""
         args = self.step_args()
         args.phys_substeps = 0
+        if self._caller_io:
+            args.options |= nat.OPT_CALLER_IO
         args.action = self._action_buf.data_ptr()
         args.obs_out, args.obs_width = rows.data_ptr(), 16 + self.n_act
         nat.check(self.ctx.lib.dsim_physics(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,

@@ -31,17 +31,58 @@ middle one.  CtrlAviary.step_fused places them at its first call: real passes be
 candidate of a 4 GiB walk (25 of them, no early end), the fastest kept.  One box of the round gave 155 / 158 / 164 us from
 process to process without it and 154.1-154.8 us in six of six with it (profiles/r03_repeat_headline_8_processes.txt).
 
-The search can only FIND a place: on one box of the round no candidate for the rows within 16 GiB was a good one.
+The search can only FIND a place: on one box of round 3 no candidate for the rows within 16 GiB was a good one.
+
+Round 4 — bounded and self-contained.  Candidates come straight from the driver (`dsim_dev_alloc`: hipMalloc on the ctx's
+device) and the ones not kept go straight back (`dsim_dev_free`): PyTorch's caching allocator is not involved, nothing
+calls `torch.cuda.empty_cache()`, a co-resident policy network keeps its cached blocks.  The walk holds at most
+min(WALK_BYTES, WALK_FRACTION of the device memory that is free when it starts) and never less than two candidates' worth
+(else there is nothing to choose from: the array is allocated plainly); an allocation failure ends the walk with what it has;
+a walk that could time nothing falls back to a plain zeroed array.  Every search reports what it cost: `seconds`,
+`peak_bytes`.
 """
 from __future__ import annotations
 
+import ctypes
+import time
 from typing import Callable, Optional
 
 import torch
 
 MIN_BYTES = 64 << 20                          # arrays at least this large, or they are allocated plainly
 WALK_BYTES = 16 << 30                         # candidates held at once while searching (transient); good places mostly turn up within 2-3 GiB
+WALK_FRACTION = 0.10                          # ... and never more than this share of the free device memory
 CLEARLY = 0.93                                # one candidate this much faster than another: the two cases are apart, stop
+
+
+class _DriverBlock:
+    """A device allocation made through the library (hipMalloc) and handed to PyTorch as a tensor by the CUDA array
+    interface: the tensor keeps this object alive, and the block goes back to the driver when the last tensor on it dies."""
+
+    def __init__(self, ctx, shape):
+        self.ctx, self.shape = ctx, tuple(int(d) for d in shape)
+        n = 4
+        for d in self.shape:
+            n *= d
+        self.nbytes = n
+        ptr = ctypes.c_void_p()
+        rc = ctx.lib.dsim_dev_alloc(ctx.handle, n, ctypes.byref(ptr))
+        if rc != 0 or not ptr.value:
+            raise MemoryError(f"dsim_dev_alloc({n}) -> {rc}")
+        self.ptr = int(ptr.value)
+        self.__cuda_array_interface__ = {"shape": self.shape, "typestr": "<f4", "data": (self.ptr, False), "version": 2,
+                                         "strides": None}
+
+    def tensor(self) -> torch.Tensor:
+        return torch.as_tensor(self, device=self.ctx.device)
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.handle:
+                self.ctx.lib.dsim_dev_free(self.ctx.handle, ctypes.c_void_p(self.ptr))
+        except Exception:
+            pass
+        self.ptr = 0
 
 
 def _event_timer(trial, c, passes: int) -> float:
@@ -56,43 +97,68 @@ def _event_timer(trial, c, passes: int) -> float:
     return e0.elapsed_time(e1) * 1e3 / passes
 
 
+def _free_bytes(device) -> int:
+    if torch.device(device).type != "cuda":
+        return 1 << 62
+    return int(torch.cuda.mem_get_info(device)[0])
+
+
 def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int = 3, report: Optional[list] = None,
                label: str = "observation rows", walk_bytes: int = WALK_BYTES, timer=None,
-               clearly: float = CLEARLY) -> torch.Tensor:
+               clearly: float = CLEARLY, ctx=None, free_bytes: Optional[int] = None) -> torch.Tensor:
     """A zeroed fp32 array of `shape`.  `trial(array)` enqueues ONE pass of the real kernel writing its output to `array`
-    (Env.step: a zero-sub-step pass; computeControl: a real pass, the caller restores the state afterwards).  Candidates
-    are allocated one after the other and all held, so that the walk moves through device memory; each is timed over
-    `passes` passes behind one untimed pass; the walk ends as soon as one candidate is clearly faster than the first (it
-    is kept) or when `walk_bytes` are held (the fastest is kept).  (A candidate clearly SLOWER than the first does not end it:
-    there are more than two levels — 154 / 158 / 164 us for the fused step by where its targets lie — and the first may be
-    the middle one.)  `timer(trial, candidate, passes)`: the clock (tests).
-    `clearly`: the ratio that counts as clear; 0: no early end, the whole walk."""
+    (the caller restores whatever the passes change).  Candidates are allocated one after the other and all held, so that
+    the walk moves through device memory; each is timed over `passes` passes behind one untimed pass; the walk ends as soon
+    as one candidate is clearly faster than the first (it is kept), when the budget is held (the fastest is kept), or when
+    the driver has no more to give.  (A candidate clearly SLOWER than the first does not end it: there are more than two
+    levels — 154 / 158 / 164 us for the fused step by where its targets lie — and the first may be the middle one.)
+    `ctx`: the fleet's Context — candidates come from the driver through it (dsim_dev_alloc), not from PyTorch's caching
+    allocator; None (CPU tests): torch.empty.  `timer(trial, candidate, passes)`: the clock (tests).  `clearly`: the ratio
+    that counts as clear; 0: no early end, the whole walk.  `free_bytes`: the free device memory to budget against (tests)."""
+    t_start = time.perf_counter()
     nbytes = 4
     for d in shape:
         nbytes *= int(d)
-    cands, times = [], []
+    free = _free_bytes(device) if free_bytes is None else int(free_bytes)
+    budget = min(int(walk_bytes), int(WALK_FRACTION * free))
+    cands, blocks, times = [], [], []
     chosen, decided = None, ""
-    torch.cuda.empty_cache()                  # candidates from whole device blocks, not from pieces the allocator has cached
-    while chosen is None and (len(cands) + 1) * nbytes <= max(walk_bytes, 2 * nbytes):
-        try:
-            c = torch.empty(tuple(shape), dtype=torch.float32, device=device)
-        except torch.cuda.OutOfMemoryError:
-            break
-        cands.append(c)
-        times.append((timer or _event_timer)(trial, c, passes))
-        if clearly > 0.0 and times[-1] < clearly * times[0]:
-            chosen, decided = len(times) - 1, "a candidate clearly faster than the first"
+    if budget >= 2 * nbytes:
+        while chosen is None and (len(cands) + 1) * nbytes <= budget:
+            try:
+                if ctx is not None:
+                    blk = _DriverBlock(ctx, shape)
+                    c = blk.tensor()
+                else:
+                    blk, c = None, torch.empty(tuple(shape), dtype=torch.float32, device=device)
+            except (MemoryError, RuntimeError):             # (torch.cuda.OutOfMemoryError is a RuntimeError)
+                break
+            cands.append(c); blocks.append(blk)
+            times.append((timer or _event_timer)(trial, c, passes))
+            if clearly > 0.0 and times[-1] < clearly * times[0]:
+                chosen, decided = len(times) - 1, "a candidate clearly faster than the first"
+    if not times:
+        # nothing to choose from (too little free memory for two candidates, or the driver refused the first): plainly
+        keep = torch.zeros(tuple(shape), dtype=torch.float32, device=device)
+        if report is not None:
+            report.append({"array": label, "bytes": nbytes, "candidates": 0, "chosen": None, "decided_by": "no walk: allocated plainly",
+                           "free_bytes": free, "budget_bytes": budget, "peak_bytes": 0,
+                           "seconds": round(time.perf_counter() - t_start, 4)})
+        return keep
     if chosen is None:
         chosen = min(range(len(times)), key=times.__getitem__)
         decided = "the fastest of the walk" if times[chosen] < CLEARLY * max(times) else "all alike"
     keep = cands[chosen]
+    peak = len(cands) * nbytes
+    n_c = len(cands)
+    c = blk = None
+    del cands, blocks                         # what was not kept goes back to the driver (the tensors were the only references)
+    keep.zero_()
     if report is not None:
         shown = times if len(times) <= 12 else times[:4] + times[-4:]
-        report.append({"array": label, "bytes": nbytes, "candidates": len(cands), "chosen": chosen,
+        report.append({"array": label, "bytes": nbytes, "candidates": n_c, "chosen": chosen,
                        "decided_by": decided, "chosen_pass_us": round(times[chosen], 1), "first_pass_us": round(times[0], 1),
-                       "pass_us" if len(times) <= 12 else "pass_us_first4_last4": [round(t, 1) for t in shown]})
-    c = None
-    del cands
-    torch.cuda.empty_cache()                  # what was not kept goes back to the device
-    keep.zero_()
+                       "pass_us" if len(times) <= 12 else "pass_us_first4_last4": [round(t, 1) for t in shown],
+                       "budget_bytes": budget, "peak_bytes": peak, "seconds": round(time.perf_counter() - t_start, 4),
+                       "memory": "driver (dsim_dev_alloc)" if ctx is not None else "torch"})
     return keep

@@ -260,6 +260,13 @@ const char* dsim_strerror(int code);
 int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n_types);
 int dsim_destroy(dsim_ctx* ctx);
 
+/* Plain device allocations straight from the driver (hipMalloc / hipFree on the ctx's device), outside any caching
+ * allocator of the host framework.  (No counterpart in the reference.)  For host classes that choose WHERE a fleet-sized
+ * array lies by trial (dronesim_amd/placement.py): candidates that are not kept go back to the driver at once, and no
+ * framework-wide cache has to be emptied to walk through device memory.  The caller owns what it allocates. */
+int dsim_dev_alloc(dsim_ctx* ctx, int64_t bytes, void** out);
+int dsim_dev_free(dsim_ctx* ctx, void* ptr);
+
 /* reset(): BaseAviary._housekeeping (BaseAviary.py:640-714) + INDIControl.reset
  * (INDIControl.py:109-146).  init_* are device SoA [3][n_pad]; init_vel and
  * init_cmd nullable (zeros / controller reset value).  Writes every field.       */
