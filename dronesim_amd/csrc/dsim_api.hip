@@ -278,6 +278,7 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
   QuadBase qb = QuadBase{0.0f, V3{0.0f, 0.0f, 0.0f}};
   if (SPLIT) qb = quad_wrench_base(T, cmd);
   const int n_sub = NSUB > 0 ? NSUB : a.substeps;
+  uint32_t nb[4] = {0u, 0u, 0u, 0u};       // the Threefry block: ONE serves two consecutive sub-steps (dsim_device.h:noise_normals)
   for (int k = 0; k < n_sub; ++k) {
     if (NOISE != 0) {
       float nz[8];
@@ -288,7 +289,9 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
           nz[4 + j] = a.noise_replay[((long long)k * 2 * NROW + NROW + j) * a.n_pad + i];
         }
       } else {
-        noise_normals<4>(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);   // N(0,.01) | N(0,.001)
+        const uint64_t sub = step_index * (uint64_t)a.substeps + (uint64_t)k;          // (wave-uniform)
+        if (k == 0 || (sub & 1ull) == 0) noise_block(a.seed, noise_key, sub >> 1, nb);  // a new block every other sub-step
+        quad_normals_from_block(nb, (sub & 1ull) != 0, nz);                             // N(0,.01) | N(0,.001)
       }
       if (SPLIT) quad_wrench_noise(T, qb, nz, F, tau); else quad_wrench(T, cmd, nz, F, tau);
     }

@@ -168,41 +168,57 @@ __device__ __forceinline__ void threefry4x32_12(uint32_t x[4], uint32_t k0, uint
     }
   }
 }
-// One 32-bit word -> two normals of standard deviation SIGMA (Box-Muller): radius from the high 16 bits
-// (u1 = (h+1)/65536 in (0,1], so |n| <= sqrt(2 ln 65536) = 4.71 sigma), angle from the low 16.
-// The hardware transcendentals take the angle in revolutions and log in base 2; the deviation is folded into the
-// radius: sigma sqrt(-2 ln u1) = sqrt(-sigma^2 2 ln2 log2(u1)) — no multiplication of the normals afterwards (8
-// instructions per sub-step less than scaling unit normals).  (u1 keeps its own 1/65536: folded in as
-// 16 - log2(h + 1) the subtraction costs the small normals a decimal digit, measured at 1.8 x the step's bar.)
-template <int SIGMA_E3>      // the deviation in thousandths: 10 = rotor force noise, 1 = rotor moment noise, 1000 = unit
-__device__ __forceinline__ void box_muller16(uint32_t w, float& n0, float& n1) {
-  constexpr float S2 = (SIGMA_E3 * 1e-3f) * (SIGMA_E3 * 1e-3f) * 1.38629436111989061883f;     // sigma^2 2 ln2
-  const float u1 = (float)((w >> 16) + 1u) * (1.0f / 65536.0f);
-  const float u2 = (float)(w & 0xFFFFu) * (1.0f / 65536.0f);
+// 16 bits -> two normals of standard deviation SIGMA (Box-Muller): radius from the HIGH byte (u1 = (h + 1) / 256 in
+// (0, 1]), angle from the LOW byte (u2 = l / 256 revolutions).  Round 4: 8 + 8 bits per pair instead of 16 + 16 — one
+// Threefry block (128 bits) now yields SIXTEEN normals: both sub-steps of a pair of consecutive quad sub-steps, or all
+// twelve normals of a hexa sub-step from one block instead of two; the generator was 85 of the 336 vector instructions a
+// quad sub-step cost, and the examples' five sub-steps per control are bound by vector issue.  What the coarser
+// grid does to the distribution (256 radii x 256 directions; exact, oracle/dsim_oracle.c mirrors it): mean 0, variance
+// sigma^2 exactly (the radius is scaled by DSIM_BM8_CORR = 2 / E[-2 ln u1] = 1.01463...: the 256-point mean of -2 ln u1 is
+// 1.9712, not 2), |n| <= 3.354 sigma, kurtosis 2.922 instead of 3, the two normals of a pair uncorrelated (E cos sin = 0 over
+// 256 directions).  The rotor noise is a 0.01 N / 0.001 N m perturbation of a 1.8 N thrust (BaseAviary.py:1518-1521): its
+// fourth moment is not what a trajectory depends on.
+// The hardware transcendentals take the angle in revolutions and log in base 2; the deviation is folded into the radius:
+// sigma sqrt(-2 corr ln u1) = sqrt(-sigma^2 2 ln2 corr log2(u1)).  v_cvt_f32_ubyteN converts a byte of the word in ONE
+// instruction.
+#define DSIM_BM8_S2 1.4065790595805696f          // 2 ln 2 x DSIM_BM8_CORR
+template <int SIGMA_E3, int HALF>      // the deviation in thousandths (10 = rotor force noise, 1 = rotor moment noise); which 16 bits of w
+__device__ __forceinline__ void box_muller8(uint32_t w, float& n0, float& n1) {
+  constexpr float S2 = (SIGMA_E3 * 1e-3f) * (SIGMA_E3 * 1e-3f) * DSIM_BM8_S2;
+  const float h = (float)((w >> (HALF ? 24 : 8)) & 0xFFu);      // (selected as v_cvt_f32_ubyte3 / _ubyte1)
+  const float l = (float)((w >> (HALF ? 16 : 0)) & 0xFFu);
+  const float u1 = (h + 1.0f) * (1.0f / 256.0f);
+  const float u2 = l * (1.0f / 256.0f);
   const float r = DSIM_SQRT(-S2 * __builtin_amdgcn_logf(u1));
   n0 = r * __builtin_amdgcn_cosf(u2);
   n1 = r * __builtin_amdgcn_sinf(u2);
 }
-// unit normals for (drone, sub-step counter): out[0..n_act) force noise, out[n_act..2 n_act) moment
-// noise.  One Threefry4x32-12 block yields 8 normals (a quad's whole sub-step), a hexa needs two.
-// out[0 .. NACT): force noise ~ N(0, 0.01), out[NACT .. 2 NACT): moment noise ~ N(0, 0.001)   (BaseAviary.py:1518-1521, 1429-1430)
+// normals for (drone, sub-step counter): out[0 .. NACT): force noise ~ N(0, 0.01), out[NACT .. 2 NACT): moment noise ~
+// N(0, 0.001)   (BaseAviary.py:1518-1521, 1429-1430).  Block = Threefry4x32-12(key = seed, counter = (drone, block index)).
+//   quad (8 normals per sub-step):  block index = sub >> 1; the even sub-step takes words 0, 1, the odd one words 2, 3:
+//                                   force normals from the first word of its pair, moment normals from the second
+//   hexa (12 normals per sub-step): block index = sub; force normals from words 0 and the low half of 1, moment normals
+//                                   from the high half of 1 and word 2 (word 3 unused)
+__device__ __forceinline__ void noise_block(uint64_t seed, uint64_t drone, uint64_t blk, uint32_t c[4]) {
+  c[0] = (uint32_t)drone; c[1] = (uint32_t)(drone >> 32); c[2] = (uint32_t)blk; c[3] = (uint32_t)(blk >> 32);
+  threefry4x32_12(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+// the eight normals of a quad sub-step from its half of the block (odd: the sub-step counter is odd; wave-uniform)
+__device__ __forceinline__ void quad_normals_from_block(const uint32_t c[4], bool odd, float* out) {
+  const uint32_t wf = odd ? c[2] : c[0], wm = odd ? c[3] : c[1];
+  box_muller8<10, 0>(wf, out[0], out[1]); box_muller8<10, 1>(wf, out[2], out[3]);
+  box_muller8<1, 0>(wm, out[4], out[5]); box_muller8<1, 1>(wm, out[6], out[7]);
+}
 template <int NACT>
 __device__ __forceinline__ void noise_normals(uint64_t seed, uint64_t drone, uint64_t sub, float* out) {
-  constexpr int NSTREAM = (2 * NACT + 7) / 8;
-#pragma unroll
-  for (int s = 0; s < NSTREAM; ++s) {
-    uint32_t c[4] = {(uint32_t)drone, (uint32_t)(drone >> 32) ^ ((uint32_t)s << 24), (uint32_t)sub,
-                     (uint32_t)(sub >> 32)};
-    threefry4x32_12(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    float n[8];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {            // (NACT is even: a pair never straddles the force / moment boundary)
-      if (8 * s + 2 * w < NACT) box_muller16<10>(c[w], n[2 * w], n[2 * w + 1]);
-      else box_muller16<1>(c[w], n[2 * w], n[2 * w + 1]);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (8 * s + j < 2 * NACT) out[8 * s + j] = n[j];
+  const uint64_t blk = NACT == 4 ? (sub >> 1) : sub;
+  uint32_t c[4];
+  noise_block(seed, drone, blk, c);
+  if constexpr (NACT == 4) {
+    quad_normals_from_block(c, (sub & 1ull) != 0, out);
+  } else {
+    box_muller8<10, 0>(c[0], out[0], out[1]); box_muller8<10, 1>(c[0], out[2], out[3]); box_muller8<10, 0>(c[1], out[4], out[5]);
+    box_muller8<1, 1>(c[1], out[6], out[7]); box_muller8<1, 0>(c[2], out[8], out[9]); box_muller8<1, 1>(c[2], out[10], out[11]);
   }
 }
 
@@ -263,11 +279,24 @@ __device__ __forceinline__ void quad_wrench(const DevType& T, const float cmd[4]
 //   tau = sum r_i x (0, 0, f0_i) + (0, 0, tz0)  +  sum r_i x (fx, fy, n_i) + (m0, m1, -m0 + m1 - m2 + m3)
 //   sum r_i x (fx, fy, n_i) = (sum r_iy n_i - fy Rz,  fx Rz - sum r_ix n_i,  fy Rx - fx Ry),   R = sum r_i
 // 22 vector instructions per sub-step instead of the 60 of the whole map.
+// The base is evaluated ONCE per Env.step and then enters every sub-step: its rounding would add up coherently over the
+// sub-steps (the four rotor moments, +-1.35 rad/s per sub-step each, cancel to ~1e-3: every product r x f is rounded at
+// its own magnitude), so the two cancelling sums are accumulated in fp64 and rounded once — a dozen fp64 operations per
+// Env.step.  The rotor forces themselves are the fp32 values the unsplit map uses.
 struct QuadBase { float Fz; V3 tau; };
 __device__ __forceinline__ QuadBase quad_wrench_base(const DevType& T, const float cmd[4]) {
-  V3 F, tau;
-  quad_wrench(T, cmd, nullptr, F, tau);
-  return QuadBase{F.z, tau};
+  double fz = 0.0, tx = 0.0, ty = 0.0;
+  float tz = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float rpm = T.scale[i] * cmd[i] + T.cnst[i];
+    const float f = rpm * rpm * T.kf, t = rpm * rpm * T.km;
+    fz += (double)f;
+    tx += (double)T.rpos[i][1] * (double)f;              // (r x (0, 0, f)).x =  r_y f
+    ty -= (double)T.rpos[i][0] * (double)f;              // (r x (0, 0, f)).y = -r_x f
+    tz += (i & 1) ? t : -t;                              // -t0 + t1 - t2 + t3 (:1527)
+  }
+  return QuadBase{(float)fz, V3{(float)tx, (float)ty, tz}};
 }
 __device__ __forceinline__ void quad_wrench_noise(const DevType& T, const QuadBase& b, const float nz[8], V3& F, V3& tau) {
   const float fx = nz[0], fy = nz[1];
@@ -540,9 +569,18 @@ __device__ __forceinline__ void hexa_wrench(const DevType& T, const float cmd[6]
 // the same split (see quad_wrench_base): rpm_j, hence f0_j and tq0_j, are constant over the sub-steps
 struct HexaBase { V3 F, tau; };
 __device__ __forceinline__ HexaBase hexa_wrench_base(const DevType& T, const float cmd[6]) {
-  HexaBase b;
-  hexa_wrench(T, cmd, nullptr, b.F, b.tau);
-  return b;
+  double F[3] = {0.0, 0.0, 0.0}, tau[3] = {0.0, 0.0, 0.0};      // (fp64 sums: see quad_wrench_base)
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float rpm = T.scale[j] * cmd[j] + T.cnst[j];
+    const float f = rpm * rpm * T.kf, tq = rpm * rpm * T.km * T.spin[j];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      F[k] += (double)f * (double)T.raxis[j][k];
+      tau[k] += (double)f * (double)T.rxa[j][k] + (double)tq * (double)T.raxis[j][k];
+    }
+  }
+  return HexaBase{V3{(float)F[0], (float)F[1], (float)F[2]}, V3{(float)tau[0], (float)tau[1], (float)tau[2]}};
 }
 __device__ __forceinline__ void hexa_wrench_noise(const DevType& T, const HexaBase& b, const float nz[12], V3& F, V3& tau) {
   F = b.F; tau = b.tau;

@@ -779,8 +779,8 @@ void orc_physics_substep(const dsim_type_params* P, double dt, double rigid[13],
 /* Product noise definition (NOT a reference restatement: the reference draws
  * from the unseeded global numpy RNG, BaseAviary.py:1518-1525, which cannot be
  * reproduced).  Threefry4x32-12 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
- * SC'11 — the Random123 generator; add/rotate/xor only) keyed by the seed, counter = (drone, substep
- * counter, stream), Box-Muller on 16+16-bit halves -> N(0,1) truncated at 4.71 sigma.
+ * SC'11 — the Random123 generator; add/rotate/xor only) keyed by the seed, counter = (drone, block index),
+ * Box-Muller on 8+8-bit halves -> unit-variance normals on a 256 x 256 grid, |n| <= 3.354 (orc_noise_normals).
  * Mirrors dsim_device.h so that tests can feed the oracle the very normals the kernel draws.
  * orc_threefry4x32 takes the round count so that the published known-answer vectors (13 and 20 rounds,
  * Random123 kat_vectors) pin the round function, rotation constants and key schedule
@@ -805,23 +805,35 @@ void orc_threefry4x32(uint32_t x[4], const uint32_t key[4], int rounds) {
     }
   }
 }
-/* unit normals for (drone, substep counter): out[2*n_act].  One block -> 8 normals: each
- * 32-bit word gives a Box-Muller pair, radius from its high 16 bits (u1 = (h+1)/65536 in (0,1]),
- * angle from its low 16 bits (u2 = l/65536 turns). */
+/* UNIT normals for (drone, sub-step counter): out[2 n_act] = f_noise[n_act] then m_noise[n_act] (the caller scales by 0.01 /
+ * 0.001).  16 bits make a Box-Muller pair: radius from the high byte (u1 = (h + 1) / 256 in (0, 1]), angle from the low byte
+ * (u2 = l / 256 revolutions); the radius is scaled by ORC_BM8_CORR = 2 / mean(-2 ln u1 over the 256 values) so that the
+ * variance is exactly 1 (|n| <= 3.354, kurtosis 2.922: dsim_device.h:box_muller8).  One block = 8 pairs:
+ *   quad: block index = sub_counter >> 1; the even sub-step takes words 0 (force) and 1 (moment), the odd one words 2 and 3;
+ *   hexa: block index = sub_counter; force normals from word 0 and the low half of word 1, moment normals from the high
+ *         half of word 1 and word 2.  Within a word the low 16 bits come first. */
+#define ORC_BM8_CORR 1.0146323169375748
+static void orc_bm8(uint32_t w, int half, double* n0, double* n1) {
+  const uint32_t v = half ? (w >> 16) : (w & 0xFFFFu);
+  const double u1 = ((double)(v >> 8) + 1.0) * (1.0 / 256.0);
+  const double u2 = (double)(v & 0xFFu) * (1.0 / 256.0);
+  const double r = sqrt(-2.0 * ORC_BM8_CORR * log(u1));
+  *n0 = r * cos(2 * ORC_PI * u2);
+  *n1 = r * sin(2 * ORC_PI * u2);
+}
 void orc_noise_normals(uint64_t seed, uint64_t drone, uint64_t sub_counter, int n_act, double* out) {
-  int produced = 0;
   const uint32_t key[4] = {(uint32_t)seed, (uint32_t)(seed >> 32), 0u, 0u};
-  for (uint32_t stream = 0; produced < 2 * n_act; ++stream) {
-    uint32_t c[4] = {(uint32_t)drone, (uint32_t)(drone >> 32) ^ (stream << 24), (uint32_t)sub_counter,
-                     (uint32_t)(sub_counter >> 32)};
-    orc_threefry4x32(c, key, 12);
-    for (int w = 0; w < 4 && produced < 2 * n_act; ++w) {
-      const double u1 = ((double)(c[w] >> 16) + 1.0) * (1.0 / 65536.0);
-      const double u2 = (double)(c[w] & 0xFFFFu) * (1.0 / 65536.0);
-      const double r = sqrt(-2.0 * log(u1));
-      out[produced++] = r * cos(2 * ORC_PI * u2);
-      if (produced < 2 * n_act) out[produced++] = r * sin(2 * ORC_PI * u2);
-    }
+  const uint64_t blk = n_act == 4 ? (sub_counter >> 1) : sub_counter;
+  uint32_t c[4] = {(uint32_t)drone, (uint32_t)(drone >> 32), (uint32_t)blk, (uint32_t)(blk >> 32)};
+  orc_threefry4x32(c, key, 12);
+  if (n_act == 4) {
+    const int odd = (int)(sub_counter & 1u);
+    const uint32_t wf = odd ? c[2] : c[0], wm = odd ? c[3] : c[1];
+    orc_bm8(wf, 0, out + 0, out + 1); orc_bm8(wf, 1, out + 2, out + 3);
+    orc_bm8(wm, 0, out + 4, out + 5); orc_bm8(wm, 1, out + 6, out + 7);
+  } else {
+    orc_bm8(c[0], 0, out + 0, out + 1); orc_bm8(c[0], 1, out + 2, out + 3); orc_bm8(c[1], 0, out + 4, out + 5);
+    orc_bm8(c[1], 1, out + 6, out + 7); orc_bm8(c[2], 0, out + 8, out + 9); orc_bm8(c[2], 1, out + 10, out + 11);
   }
 }
 

@@ -24,7 +24,7 @@ from dronesim_amd import params  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from tests.test_gpu_parity import _check_obs_rows  # noqa: E402
 from tests.test_gpu_round4 import _downwash_part, _noise_by_id  # noqa: E402
-from tests.util import K_ULP, assert_control_parity, assert_step_parity, f32  # noqa: E402
+from tests.util import K_ULP, assert_control_parity, assert_step_parity, f32, noise_terms  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 DT = float(np.float32(1.0 / 240.0))
@@ -107,7 +107,8 @@ class Loop:
         gr, gm = self.dev_state()
         part = _downwash_part(self.O, self.types, self.tid, r0, r, self.sub) if self.dw else None
         assert_step_parity(f"fuzz {self.kind} {label}", self.types, self.tid, r0, m0, self.tgt, gr, gm if control else None, r,
-                           m if control else None, DT, self.dtc, self.sub, control=control, action=applied, k=k, part_rigid=part)
+                           m if control else None, DT, self.dtc, self.sub, control=control, action=applied, k=k, part_rigid=part,
+                           extra_terms=noise_terms(self.types, self.tid, self.n, DT, self.sub))
 
     def action6(self, a):
         a6 = np.zeros((self.n, 6)); a6[:, :self.na] = a

@@ -316,15 +316,25 @@ def test_threefry_known_answers_and_noise_moments():
         f(x, U4(*key), rounds)
         assert list(x) == want, (rounds, [hex(v) for v in x])
     O = orc.Oracle([params.builtin_type("robobee")])
-    z = np.array([O.noise_normals(0x1234ABCD5, i, s, 4) for i in range(4000) for s in range(5)])   # 160 000 normals
+    z = np.array([O.noise_normals(0x1234ABCD5, i, s, 4) for i in range(4000) for s in range(6)])   # 192 000 normals
+    # 8 + 8-bit Box-Muller pairs (round 4): variance exactly 1 by construction, kurtosis 2.922, |n| <= 3.354
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01
-    assert abs((z ** 3).mean()) < 0.03 and abs((z ** 4).mean() - 3.0) < 0.08          # skewness, kurtosis
-    assert np.abs(z).max() <= math.sqrt(2 * math.log(65536.0)) + 1e-9                  # 16-bit radius: 4.71 sigma
-    c = np.corrcoef(z.T)                                                               # the 8 normals of a block
-    assert np.abs(c - np.eye(8)).max() < 0.035          # 20 000 blocks: sampling sigma 0.007, 28 pairs
-    lag = np.corrcoef(z[:-1, 0], z[1:, 0])[0, 1]                                       # consecutive counters
-    assert abs(lag) < 0.035
-    # a hexa draws a second block (stream 1) for normals 8..11
+    assert abs((z ** 3).mean()) < 0.03 and abs((z ** 4).mean() - 2.9221) < 0.06        # skewness, kurtosis of the 256 x 256 grid
+    assert np.abs(z).max() <= math.sqrt(2 * 1.0146323169375748 * math.log(256.0)) + 1e-9
+    c = np.corrcoef(z.T)                                                               # the 8 normals of a sub-step
+    assert np.abs(c - np.eye(8)).max() < 0.035          # 24 000 sub-steps: sampling sigma 0.0065, 28 pairs
+    lag = np.corrcoef(z[:-1, 0], z[1:, 0])[0, 1]                                       # consecutive counters: the two halves of one
+    assert abs(lag) < 0.035                                                            # block, then the next block
+    # an even sub-step and the odd one behind it share a block and draw from different words of it
+    a_, b_ = O.noise_normals(9, 5, 10, 4), O.noise_normals(9, 5, 11, 4)
+    assert len(set(np.round(np.concatenate([a_, b_]), 12))) == 16
+    # the exact population moments of the grid: every (radius byte, angle byte) pair is equally likely
+    k = (np.arange(256) + 1) / 256.0
+    r = np.sqrt(-2.0 * 1.0146323169375748 * np.log(k))
+    th = 2 * np.pi * np.arange(256) / 256.0
+    pop = (r[:, None] * np.cos(th)[None, :]).ravel()
+    assert abs(pop.var() - 1.0) < 1e-12 and abs(pop.mean()) < 1e-12 and abs((pop ** 4).mean() - 2.92211784903654) < 1e-9
+    # a hexa sub-step takes its twelve normals from one block
     h = O.noise_normals(77, 3, 9, 6)
     assert h.shape == (12,) and len(set(np.round(h, 12))) == 12
 

@@ -108,6 +108,27 @@ def step_terms(types, type_id, rigid, mem, tgt, dt_phys, dt_ctrl, substeps, cont
     return tr, tm
 
 
+NOISE_MAX_SIGMA = 3.3545       # |n| <= sqrt(2 corr ln 256) sigma: the 8 + 8-bit Box-Muller grid of the rotor noise (dsim_device.h:box_muller8)
+
+
+def noise_terms(types, type_id, n, dt_phys, substeps):
+    """([n,13], [n,13]) what the rotor noise adds to the magnitudes of step_terms (BaseAviary.py:1518-1525: f_noise ~ N(0, .01)
+    per rotor — and on the lateral axes of every rotor link —, m_noise ~ N(0, .001)): at zero command the noise IS the
+    largest term of the velocity and rate updates, and an increment that happens to be small (a draw near zero) must not
+    shrink the bar below the rounding of the terms that made it."""
+    tr, tm = np.zeros((n, 13)), np.zeros((n, 13))
+    tid = np.zeros(n, dtype=np.int64) if type_id is None else np.asarray(type_id).astype(np.int64)
+    for k, t in enumerate(types):
+        s = tid == k
+        fmax, mmax = NOISE_MAX_SIGMA * 0.01, NOISE_MAX_SIGMA * 0.001
+        arm = np.linalg.norm(np.asarray(t.rotor_pos)[: t.n_act], axis=1)
+        tr[s, 7:10] = t.n_act * fmax / t.mass * dt_phys
+        tr[s, 10:13] = (t.n_act * mmax + 2.0 * (arm * fmax).sum()) / min(t.inertia) * dt_phys
+        tr[s, 0:3] = tr[s, 7:10] * dt_phys * substeps
+        tm[s, 0:3], tm[s, 3:6] = tr[s, 7:10], tr[s, 10:13]
+    return tr, tm
+
+
 def tilt_gain(types, type_id, rigid):
     """[n,13] factor on the ulp term of the controller-memory fields: the quad law's pitch increment is
     w.a / (T cos^2(roll)) (INDIControl.py:314-339: det G = T^2 cos(roll)), so the fp32 rounding of cos(roll) reaches
