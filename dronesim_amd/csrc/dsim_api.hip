@@ -267,7 +267,8 @@ __device__ __forceinline__ int waypoint_next(int wp, int n_wp) { return wp < n_w
 template <int NOISE, int NROW = 4, bool OPTS = false, int NSUB = 0, bool PLANE = false>
 __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[4], unsigned long long step_index,
-                                              V3 ext = V3{0.0f, 0.0f, 0.0f}, const float* prev = nullptr, long long nid = -1) {
+                                              V3 ext = V3{0.0f, 0.0f, 0.0f}, const float* prev = nullptr, long long nid = -1,
+                                              const NoiseTab* tab = nullptr /* LDS tables of the Box-Muller pairs, or none */) {
   // nid: the drone's index in the caller's numbering when the fleet is stored in another order (StepK.drone_id): the
   // key of its noise stream.  -1 (a constant at the call sites of the single-order kernels) = i.
   const uint64_t noise_key = (uint64_t)(nid >= 0 ? nid : i);
@@ -291,7 +292,8 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
       } else {
         const uint64_t sub = step_index * (uint64_t)a.substeps + (uint64_t)k;          // (wave-uniform)
         if (k == 0 || (sub & 1ull) == 0) noise_block(a.seed, noise_key, sub >> 1, nb);  // a new block every other sub-step
-        quad_normals_from_block(nb, (sub & 1ull) != 0, nz);                             // N(0,.01) | N(0,.001)
+        if (tab) quad_normals_from_block_tab(*tab, nb, (sub & 1ull) != 0, nz);          // (the same bits, from LDS)
+        else quad_normals_from_block(nb, (sub & 1ull) != 0, nz);                        // N(0,.01) | N(0,.001)
       }
       if (SPLIT) quad_wrench_noise(T, qb, nz, F, tau); else quad_wrench(T, cmd, nz, F, tau);
     }
@@ -382,8 +384,14 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
   Rigid s;
   CtrlMem<4> m;
   Target tg;
+  // several sub-steps per launch (the examples' setting: vector-issue bound): the Box-Muller pairs from LDS tables
+  constexpr bool TAB = NOISE && (EXT || SUB != 1);
+  __shared__ NoiseTab ntab_[TAB ? 1 : 0 + 1];
+  const NoiseTab* const ntab = TAB ? &ntab_[0] : nullptr;
+  if (TAB) noise_tab_init(ntab_[0], threadIdx.x);
   load_rigid<NT>(sb, sfs, sl, s);
   load_mem<4, NT, CH>(sb, sfs, sl, m);
+  if (TAB) __syncthreads();
   if (CH) { m.last_vel = s.vel; m.last_rates = mulT(matrix_from_quat(s.q), s.w); }
   const long long i = i0 + threadIdx.x;
   if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;    // wave-uniform scalar load
@@ -395,9 +403,9 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
       float act[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) act[j] = clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]);   // CtrlAviary.py:258-263
-      quad_substeps<NOISE ? 1 : 0, 4, false, SUB>(T, a, i, s, act, a.step_index);
+      quad_substeps<NOISE ? 1 : 0, 4, false, SUB>(T, a, i, s, act, a.step_index, V3{0.0f, 0.0f, 0.0f}, nullptr, -1, ntab);
     } else {
-      quad_substeps<NOISE ? 1 : 0, 4, false, SUB>(T, a, i, s, m.cmd, a.step_index);    // stored cmd is already clipped
+      quad_substeps<NOISE ? 1 : 0, 4, false, SUB>(T, a, i, s, m.cmd, a.step_index, V3{0.0f, 0.0f, 0.0f}, nullptr, -1, ntab);    // stored cmd is already clipped
     }
     ground_watch(T, s, a.fb.counters, i < a.n);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
     if (a.wp_table) wp = a.wp_counter[i]; else load_target<NT>(tb, tfs, tl, tg);
     for (int k = 0; k < a.n_steps; ++k) {
       if (a.wp_table) waypoint_target(a, i, wp, tg);
-      quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index + k);
+      quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index + k, V3{0.0f, 0.0f, 0.0f}, nullptr, -1, ntab);
       ground_watch(T, s, a.fb.counters, i < a.n);
       indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
       wp = waypoint_next(wp, a.n_wp);

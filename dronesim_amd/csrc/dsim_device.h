@@ -209,6 +209,32 @@ __device__ __forceinline__ void quad_normals_from_block(const uint32_t c[4], boo
   box_muller8<10, 0>(wf, out[0], out[1]); box_muller8<10, 1>(wf, out[2], out[3]);
   box_muller8<1, 0>(wm, out[4], out[5]); box_muller8<1, 1>(wm, out[6], out[7]);
 }
+// The same normals from LDS tables (the kernels that loop over several sub-steps: the vector pipe bounds them, and the four
+// Box-Muller pairs of a sub-step are 16 transcendental instructions).  A pair is a function of two BYTES: 256 radii per
+// deviation, 256 directions — tabulated once per workgroup with the very expressions of box_muller8, so that a table entry
+// holds the bits the direct evaluation produces and the kernels with and without tables draw identical noise.
+struct NoiseTab { float2 rad[256]; float2 cs[256]; };          // rad[h] = (radius at sigma .01, at sigma .001); cs[l] = (cos, sin)
+__device__ __forceinline__ void noise_tab_init(NoiseTab& t, unsigned tid /* 0..255 */) {
+  constexpr float S2a = (10 * 1e-3f) * (10 * 1e-3f) * DSIM_BM8_S2, S2b = (1 * 1e-3f) * (1 * 1e-3f) * DSIM_BM8_S2;
+  const float b = (float)(tid & 0xFFu);
+  const float L = __builtin_amdgcn_logf((b + 1.0f) * (1.0f / 256.0f));
+  const float u2 = b * (1.0f / 256.0f);
+  t.rad[tid & 255u] = make_float2(DSIM_SQRT(-S2a * L), DSIM_SQRT(-S2b * L));
+  t.cs[tid & 255u] = make_float2(__builtin_amdgcn_cosf(u2), __builtin_amdgcn_sinf(u2));
+}
+template <bool MOMENT, int HALF>
+__device__ __forceinline__ void box_muller8_tab(const NoiseTab& t, uint32_t w, float& n0, float& n1) {
+  const float2 rr = t.rad[(w >> (HALF ? 24 : 8)) & 0xFFu];
+  const float2 cs = t.cs[(w >> (HALF ? 16 : 0)) & 0xFFu];
+  const float r = MOMENT ? rr.y : rr.x;
+  n0 = r * cs.x;
+  n1 = r * cs.y;
+}
+__device__ __forceinline__ void quad_normals_from_block_tab(const NoiseTab& t, const uint32_t c[4], bool odd, float* out) {
+  const uint32_t wf = odd ? c[2] : c[0], wm = odd ? c[3] : c[1];
+  box_muller8_tab<false, 0>(t, wf, out[0], out[1]); box_muller8_tab<false, 1>(t, wf, out[2], out[3]);
+  box_muller8_tab<true, 0>(t, wm, out[4], out[5]); box_muller8_tab<true, 1>(t, wm, out[6], out[7]);
+}
 template <int NACT>
 __device__ __forceinline__ void noise_normals(uint64_t seed, uint64_t drone, uint64_t sub, float* out) {
   const uint64_t blk = NACT == 4 ? (sub >> 1) : sub;
