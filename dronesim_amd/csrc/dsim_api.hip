@@ -1266,7 +1266,7 @@ typedef float vf2 __attribute__((ext_vector_type(2)));
 // TWO tiles per 512-thread workgroup — neighbours in the map, i.e. tiles of different runs that cover the same stretch of
 // the caller's range — and write the scattered arrays with the default cache policy, so that the halves of a line meet in
 // the XCD's L2 before they leave for memory.  t = the thread's index inside its tile.
-template <bool HEXA, bool NOISE, bool NT, bool OBS, bool IO>
+template <bool HEXA, bool NOISE, bool NT, bool OBS, bool IO, bool S1>
 __device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro, float* rows_wave, unsigned t) {
   constexpr int NA = HEXA ? 6 : 4;
   const long long i0 = ro.i0, i = i0 + t;
@@ -1300,8 +1300,9 @@ __device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro
     unsigned long long step_index = a.step_index;
     if (NOISE && a.step_index_dev) step_index += *a.step_index_dev;
     const long long nid = NOISE ? noise_id(a, i) : -1LL;
-    if constexpr (HEXA) hexa_substeps<NOISE, false>(T, a, i, s, cmd, step_index, ext, nid);
-    else quad_substeps<NOISE ? 1 : 0>(T, a, i, s, cmd, step_index, ext, nullptr, nid);
+    // (S1: one sub-step per Env.step — BASELINE's metric definition — compiled straight-line, as in the fused kernels)
+    if constexpr (HEXA) hexa_substeps<NOISE, false, S1>(T, a, i, s, cmd, step_index, ext, nid);
+    else quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, cmd, step_index, ext, nullptr, nid);
     ground_watch(T, s, a.fb.counters, i < a.n);
     const unsigned so = pin_lane_offset(sl);
     store_rigid<NT>(sb, sfs, so, s);
@@ -1360,17 +1361,17 @@ __device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro
   }
 }
 #ifndef DSIM_PRUNS_WAVES
-#define DSIM_PRUNS_WAVES 3
+#define DSIM_PRUNS_WAVES 4
 #endif
-template <bool NOISE, bool NT, bool OBS, bool IO>
-__global__ __launch_bounds__(IO ? 512 : 256, DSIM_PRUNS_WAVES) void k_physics_runs(StepK a, RunTab rt) {
+template <bool NOISE, bool NT, bool OBS, bool IO, bool S1>
+__global__ __launch_bounds__(IO ? 512 : 256, S1 ? DSIM_PRUNS_WAVES : 3) void k_physics_runs(StepK a, RunTab rt) {
   constexpr int PER_WAVE = 64 * DSIM_OBS_WMAX + (IO ? 64 : 0);          // per wave: 64 rows (+ their 64 destinations)
   __shared__ __attribute__((aligned(16))) float rows[OBS ? (IO ? 8 : 4) * PER_WAVE : 2];
   DSIM_RUN_OF_BLOCK(rt, ro, IO ? 2 * blockIdx.x + (threadIdx.x >> 8) : blockIdx.x);
   float* rw = rows + (OBS ? (threadIdx.x >> 6) * PER_WAVE : 0);
   const unsigned t = IO ? (threadIdx.x & 255u) : threadIdx.x;
-  if (ro.hexa) physics_run_body<true, NOISE, NT, OBS, IO>(a, ro, rw, t);
-  else physics_run_body<false, NOISE, NT, OBS, IO>(a, ro, rw, t);
+  if (ro.hexa) physics_run_body<true, NOISE, NT, OBS, IO, S1>(a, ro, rw, t);
+  else physics_run_body<false, NOISE, NT, OBS, IO, S1>(a, ro, rw, t);
 }
 
 template <int KIND, bool NT, bool WANT_YAW, bool IO>
@@ -3133,15 +3134,17 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
       bin_next_prepare(ctx, n, args, &a, st_);
       if (blocks > 0) {
         const dim3 g((unsigned)blocks), b(256);
-#define DSIM_PRUNS_CASE(N_, T_) do {                                                                                           \
+#define DSIM_PRUNS_CASE2(N_, T_, S_) do {                                                                                      \
           if (a.io_id) { const dim3 g2((unsigned)((blocks + 1) / 2)), b2(512);                                                 \
-                         if (a.obs_out) hipLaunchKernelGGL((k_physics_runs<N_, T_, true, true>), g2, b2, 0, st_, a, rt);       \
-                         else hipLaunchKernelGGL((k_physics_runs<N_, T_, false, true>), g2, b2, 0, st_, a, rt); }               \
-          else { if (a.obs_out) hipLaunchKernelGGL((k_physics_runs<N_, T_, true, false>), g, b, 0, st_, a, rt);               \
-                 else hipLaunchKernelGGL((k_physics_runs<N_, T_, false, false>), g, b, 0, st_, a, rt); } } while (0)
+                         if (a.obs_out) hipLaunchKernelGGL((k_physics_runs<N_, T_, true, true, S_>), g2, b2, 0, st_, a, rt);   \
+                         else hipLaunchKernelGGL((k_physics_runs<N_, T_, false, true, S_>), g2, b2, 0, st_, a, rt); }           \
+          else { if (a.obs_out) hipLaunchKernelGGL((k_physics_runs<N_, T_, true, false, S_>), g, b, 0, st_, a, rt);           \
+                 else hipLaunchKernelGGL((k_physics_runs<N_, T_, false, false, S_>), g, b, 0, st_, a, rt); } } while (0)
+#define DSIM_PRUNS_CASE(N_, T_) do { if (a.substeps == 1) DSIM_PRUNS_CASE2(N_, T_, true); else DSIM_PRUNS_CASE2(N_, T_, false); } while (0)
         if (noise) { if (nt) DSIM_PRUNS_CASE(true, true); else DSIM_PRUNS_CASE(true, false); }
         else { if (nt) DSIM_PRUNS_CASE(false, true); else DSIM_PRUNS_CASE(false, false); }
 #undef DSIM_PRUNS_CASE
+#undef DSIM_PRUNS_CASE2
       }
       bin_next_commit(ctx, n, args, a);
       if (args->obs_out && !obs_fused) return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, obs_w, 0);
