@@ -1258,6 +1258,9 @@ __global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_control_fast(StepK a) 
 // 8 bytes per lane over consecutive addresses, and a piece is stored when its row is one of this run's.
 typedef float vf2 __attribute__((ext_vector_type(2)));
 #define DSIM_OBS_WMAX 22
+#ifndef DSIM_ROWS16
+#define DSIM_ROWS16 1          // whole blocks of rows leave in 16-byte pieces (A/B knob of the build)
+#endif
 // IO (DSIM_OPT_CALLER_IO): the action is gathered from, and rows / command / errors are scattered to, the CALLER's drone
 // number io_id[i].  The drones of a run are spread over the caller's whole range (even index quad, odd index hexa ...), so one
 // run alone fills every other 88-byte row and every other dword of the command arrays: partial memory bursts, a
@@ -1266,8 +1269,36 @@ typedef float vf2 __attribute__((ext_vector_type(2)));
 // TWO tiles per 512-thread workgroup — neighbours in the map, i.e. tiles of different runs that cover the same stretch of
 // the caller's range — and write the scattered arrays with the default cache policy, so that the halves of a line meet in
 // the XCD's L2 before they leave for memory.  t = the thread's index inside its tile.
+// Round 4, second form: the workgroup's two tiles cover (in a well-mixed fleet: exactly) one stretch of the caller's range, so
+// the scattered outputs are ASSEMBLED in LDS over a window of DSIM_IO_WIN caller indices that starts at the workgroup's
+// smallest one, and leave as whole lines (16-byte pieces with the streaming hint, like the rows of a single-type fleet); a
+// flag per window row says whether this workgroup produced it (a hole belongs to another workgroup and is not touched), and
+// a drone whose index falls outside the window writes its outputs itself, as before.  Correct for any order, fast where the
+// types are mixed evenly — the interleaved fleets BASELINE config 5 describes.
+#define DSIM_IO_WIN 512
+struct IoWin { float* win; unsigned char* flags; int base; };
+// The window starts at the smallest caller index among the workgroup's live lanes, rounded down to 4 (16-byte aligned rows
+// of any width, whole 16-byte pieces of the per-field arrays).  Every wave leaves its minimum in LDS and clears its share of
+// the flags BEFORE its arithmetic; the workgroup meets once behind it (io_window_base), fills the window, meets again and
+// writes it out — two barriers at the end of the waves' lives, none in front of their loads.
+__device__ __forceinline__ void io_window_min(int id_or_max, int* wmin, unsigned char* flags) {
+  int m = id_or_max;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63u) == 0) wmin[threadIdx.x >> 6] = m;
+  flags[threadIdx.x] = 0;
+}
+__device__ __forceinline__ int io_window_base(const int* wmin) {
+  __syncthreads();
+  int b = wmin[0];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) b = min(b, wmin[q]);
+  return __builtin_amdgcn_readfirstlane(b) & ~3;
+}
+struct IoRow { vf2 pc[11]; int id; bool have; };            // a lane's observation row on its way to the window
+struct IoCtl { float v[10]; int id; bool have; };            // a lane's command (6), position error (3), yaw error
 template <bool HEXA, bool NOISE, bool NT, bool OBS, bool IO, bool S1>
-__device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro, float* rows_wave, unsigned t) {
+__device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro, float* rows_wave, unsigned t, IoRow& io) {
   constexpr int NA = HEXA ? 6 : 4;
   const long long i0 = ro.i0, i = i0 + t;
   const long long w0 = i0 + (long long)(t & ~63u);                     // first drone of this wave
@@ -1314,18 +1345,26 @@ __device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro
       }
     }
     if (a.bin.count && i < a.n) bin_entry(a.bin, s.pos.x, s.pos.y, s.pos.z, a.bin.local_offset + i);   // next step's grid
-    if (OBS) {
+    if (OBS && (!IO || i < a.n)) {
       const Euler e = euler_from_quat<true>(s.q);                                       // BaseAviary.py:729
-      vf2* r = reinterpret_cast<vf2*>(rows_wave + lane * (unsigned)W);
-      r[0] = vf2{s.pos.x, s.pos.y}; r[1] = vf2{s.pos.z, s.q.x}; r[2] = vf2{s.q.y, s.q.z}; r[3] = vf2{s.q.w, e.roll};
-      r[4] = vf2{e.pitch, e.yaw}; r[5] = vf2{s.vel.x, s.vel.y}; r[6] = vf2{s.vel.z, s.w.x}; r[7] = vf2{s.w.y, s.w.z};
-      r[8] = vf2{cmd[0], cmd[1]}; r[9] = vf2{cmd[2], cmd[3]};
-      if constexpr (HEXA) r[10] = vf2{cmd[4], cmd[5]};
-      else if (W == 22) r[10] = vf2{0.0f, 0.0f};
-      if (IO) reinterpret_cast<int*>(rows_wave + 64 * DSIM_OBS_WMAX)[lane] = (int)id;  // where this row goes
+      vf2 pc[11];
+      pc[0] = vf2{s.pos.x, s.pos.y}; pc[1] = vf2{s.pos.z, s.q.x}; pc[2] = vf2{s.q.y, s.q.z}; pc[3] = vf2{s.q.w, e.roll};
+      pc[4] = vf2{e.pitch, e.yaw}; pc[5] = vf2{s.vel.x, s.vel.y}; pc[6] = vf2{s.vel.z, s.w.x}; pc[7] = vf2{s.w.y, s.w.z};
+      pc[8] = vf2{cmd[0], cmd[1]}; pc[9] = vf2{cmd[2], cmd[3]};
+      if constexpr (HEXA) pc[10] = vf2{cmd[4], cmd[5]}; else pc[10] = vf2{0.0f, 0.0f};
+      const int hw = W >> 1;
+      if (IO) {                               // the kernel puts it into the window, behind the workgroup's first barrier
+#pragma unroll
+        for (int k = 0; k < 11; ++k) io.pc[k] = pc[k];
+        io.id = (int)id; io.have = true;
+      } else {
+        vf2* r = reinterpret_cast<vf2*>(rows_wave + lane * (unsigned)W);
+#pragma unroll
+        for (int k = 0; k < 11; ++k) if (k < hw) r[k] = pc[k];
+      }
     }
   }
-  if (OBS) {
+  if (OBS && !IO) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's own LDS writes, then its own reads: in order
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1334,19 +1373,15 @@ __device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro
     const long long r_hi = min(min(ro.last, a.n) - w0, 64LL);
     const unsigned p_lo = (unsigned)r_lo * hw, p_hi = r_hi > 0 ? (unsigned)r_hi * hw : 0u;
     const vf2* blk = reinterpret_cast<const vf2*>(rows_wave);
-    if (IO) {
-      // row r of the block is row io_id[w0 + r] of the output — hw consecutive lanes still write one row's 8 hw
-      // consecutive bytes.  (p / hw by multiply-shift: exact for p < 704 with these constants.)
-      const int* ids = reinterpret_cast<const int*>(rows_wave + 64 * DSIM_OBS_WMAX);
-      const unsigned mul = hw == 11u ? 5958u : 6554u;
-      for (unsigned k = 0; k < hw; ++k) {
-        const unsigned p = k * 64u + lane;
-        if (p >= p_lo && p < p_hi) {
-          const unsigned row = (p * mul) >> 16;
-          vf2* d = reinterpret_cast<vf2*>(a.obs_out + (long long)ids[row] * W) + (p - row * hw);
-          const vf2 v = blk[p];      // (default cache policy: the other runs' halves of these lines are on their way)
-          if (NT && DSIM_IO_ROWS_NT) __builtin_nontemporal_store(v, d); else *d = v;
-        }
+    if (DSIM_ROWS16 && p_lo == 0u && p_hi == 64u * hw && ((uintptr_t)a.obs_out & 15u) == 0) {
+      // the whole block is this run's (every wave but those at a run's two ends): 64 rows of 80 / 88 bytes are 320 / 352
+      // 16-byte pieces behind a 16-byte aligned address (64 rows in front of every block), stored as such
+      const vf4* blk4 = reinterpret_cast<const vf4*>(rows_wave);
+      vf4* dst4 = reinterpret_cast<vf4*>(a.obs_out + w0 * W);
+      const unsigned n4 = 16u * (unsigned)W;
+      for (unsigned p = lane; p < n4; p += 64u) {
+        const vf4 v = blk4[p];
+        if (NT && DSIM_OBS_STREAM) __builtin_nontemporal_store(v, dst4 + p); else dst4[p] = v;
       }
     } else {
       vf2* dst = reinterpret_cast<vf2*>(a.obs_out + w0 * W);
@@ -1363,19 +1398,71 @@ __device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro
 #ifndef DSIM_PRUNS_WAVES
 #define DSIM_PRUNS_WAVES 4
 #endif
-template <bool NOISE, bool NT, bool OBS, bool IO, bool S1>
-__global__ __launch_bounds__(IO ? 512 : 256, S1 ? DSIM_PRUNS_WAVES : 3) void k_physics_runs(StepK a, RunTab rt) {
-  constexpr int PER_WAVE = 64 * DSIM_OBS_WMAX + (IO ? 64 : 0);          // per wave: 64 rows (+ their 64 destinations)
-  __shared__ __attribute__((aligned(16))) float rows[OBS ? (IO ? 8 : 4) * PER_WAVE : 2];
-  DSIM_RUN_OF_BLOCK(rt, ro, IO ? 2 * blockIdx.x + (threadIdx.x >> 8) : blockIdx.x);
-  float* rw = rows + (OBS ? (threadIdx.x >> 6) * PER_WAVE : 0);
-  const unsigned t = IO ? (threadIdx.x & 255u) : threadIdx.x;
-  if (ro.hexa) physics_run_body<true, NOISE, NT, OBS, IO, S1>(a, ro, rw, t);
-  else physics_run_body<false, NOISE, NT, OBS, IO, S1>(a, ro, rw, t);
+template <bool NOISE, bool NT, bool OBS, bool S1>
+__global__ __launch_bounds__(256, S1 ? DSIM_PRUNS_WAVES : 3) void k_physics_runs(StepK a, RunTab rt) {
+  __shared__ __attribute__((aligned(16))) float rows[OBS ? 4 * 64 * DSIM_OBS_WMAX : 2];   // per wave: 64 rows
+  DSIM_RUN_OF_BLOCK(rt, ro, blockIdx.x);
+  float* rw = rows + (OBS ? (threadIdx.x >> 6) * (64 * DSIM_OBS_WMAX) : 0);
+  IoRow none;
+  if (ro.hexa) physics_run_body<true, NOISE, NT, OBS, false, S1>(a, ro, rw, threadIdx.x, none);
+  else physics_run_body<false, NOISE, NT, OBS, false, S1>(a, ro, rw, threadIdx.x, none);
+}
+// DSIM_OPT_CALLER_IO: two tiles per workgroup (neighbours in the side-by-side map), the rows assembled over the window
+template <bool NOISE, bool NT, bool OBS, bool S1>
+__global__ __launch_bounds__(512, S1 ? DSIM_PRUNS_WAVES : 3) void k_physics_runs_io(StepK a, RunTab rt) {
+  __shared__ __attribute__((aligned(16))) float win[OBS ? DSIM_IO_WIN * DSIM_OBS_WMAX : 4];
+  __shared__ unsigned char flags[DSIM_IO_WIN];
+  __shared__ int wmin[8];
+  DSIM_RUN_OF_BLOCK(rt, ro, 2 * blockIdx.x + (threadIdx.x >> 8));
+  const unsigned t = threadIdx.x & 255u;
+  IoRow io;
+  io.have = false;
+  if (OBS) {
+    const long long i = ro.i0 + t;
+    io_window_min(i >= ro.lo && i < ro.last && i < a.n ? a.io_id[i] : 0x7fffffff, wmin, flags);
+  }
+  if (ro.hexa) physics_run_body<true, NOISE, NT, OBS, true, S1>(a, ro, nullptr, t, io);
+  else physics_run_body<false, NOISE, NT, OBS, true, S1>(a, ro, nullptr, t, io);
+  if (OBS) {
+    const int base = io_window_base(wmin);
+    const int hw = a.obs_w >> 1;
+    if (io.have) {
+      const unsigned slot = (unsigned)(io.id - base);                  // where this row goes: the window, or straight out
+      vf2* r;
+      if (slot < (unsigned)DSIM_IO_WIN) {
+        r = reinterpret_cast<vf2*>(win + slot * (unsigned)a.obs_w);
+#pragma unroll
+        for (int k = 0; k < 11; ++k) if (k < hw) r[k] = io.pc[k];
+        flags[slot] = 1;
+      } else {
+        vf2* g = reinterpret_cast<vf2*>(a.obs_out + (long long)io.id * a.obs_w);
+#pragma unroll
+        for (int k = 0; k < 11; ++k) if (k < hw) g[k] = io.pc[k];
+      }
+    }
+    __syncthreads();
+    // the window leaves in 16-byte pieces; a piece holds two 8-byte halves, each inside ONE row (rows are 80 / 88 bytes).
+    // (x / W by multiply-shift: exact for x < 11 272 with these constants.)
+    const unsigned W = (unsigned)a.obs_w, n4 = DSIM_IO_WIN * W / 4u, mul = W == 22u ? 2979u : 3277u;
+    const vf4* win4 = reinterpret_cast<const vf4*>(win);
+    float* const g = a.obs_out + (long long)base * W;
+    for (unsigned p = threadIdx.x; p < n4; p += 512u) {
+      const unsigned x = 4u * p;
+      const bool fa = flags[(x * mul) >> 16] != 0, fb = flags[((x + 2u) * mul) >> 16] != 0;
+      const bool whole = __ballot(fa && fb) == ~0ULL;     // 1 KB of whole pieces: streaming; holes: default policy (they merge in L2)
+      if (fa || fb) {
+        const vf4 v = win4[p];
+        if (fa && fb) {
+          if (NT && DSIM_OBS_STREAM && whole) __builtin_nontemporal_store(v, reinterpret_cast<vf4*>(g + x)); else *reinterpret_cast<vf4*>(g + x) = v;
+        } else if (fa) *reinterpret_cast<vf2*>(g + x) = vf2{v.x, v.y};
+        else *reinterpret_cast<vf2*>(g + x + 2u) = vf2{v.z, v.w};
+      }
+    }
+  }
 }
 
 template <int KIND, bool NT, bool WANT_YAW, bool IO>
-__device__ __forceinline__ void control_run_body(const StepK& a, const RunOf& ro, unsigned t) {
+__device__ __forceinline__ void control_run_body(const StepK& a, const RunOf& ro, unsigned t, IoCtl& io) {
   constexpr bool HEXA = KIND != DSIM_DEV_KIND_QUAD;            // six actuators
   constexpr int NA = HEXA ? 6 : 4;
   const long long i0 = ro.i0, i = i0 + t;
@@ -1397,15 +1484,12 @@ __device__ __forceinline__ void control_run_body(const StepK& a, const RunOf& ro
   else indi_quad<WANT_YAW, NA>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);       // (NA = 6: hexa_6DOF_simple)
   const unsigned so = pin_lane_offset(sl);
   store_mem<NA, NT>(sb, sfs, so, m);
-  if (IO) {                                   // the outputs go to the caller's drone number (default cache policy, see above)
-    const long long id = a.io_id[i];
-    if (a.cmd_out) {
+  if (IO) {                 // the outputs go to the caller's drone number: the kernel puts them into the window
 #pragma unroll
-      for (int j = 0; j < NA; ++j) a.cmd_out[(long long)j * a.n_pad + id] = m.cmd[j];
-      if (!HEXA && a.obs_w == 22) { a.cmd_out[4LL * a.n_pad + id] = 0.0f; a.cmd_out[5LL * a.n_pad + id] = 0.0f; }
-    }
-    if (a.pos_e_out) { a.pos_e_out[id] = pos_e.x; a.pos_e_out[a.n_pad + id] = pos_e.y; a.pos_e_out[2 * a.n_pad + id] = pos_e.z; }
-    if (WANT_YAW) a.yaw_e_out[id] = yaw_e;
+    for (int j = 0; j < NA; ++j) io.v[j] = m.cmd[j];
+    if (!HEXA) { io.v[4] = 0.0f; io.v[5] = 0.0f; }   // a quad of a table with a six-actuator type: its rows 4, 5 hold zeros
+    io.v[6] = pos_e.x; io.v[7] = pos_e.y; io.v[8] = pos_e.z; io.v[9] = yaw_e;
+    io.id = a.io_id[i]; io.have = true;
     return;
   }
   const unsigned lo4 = 4u * t;
@@ -1422,13 +1506,71 @@ __device__ __forceinline__ void control_run_body(const StepK& a, const RunOf& ro
   }
   if (WANT_YAW) stg<NT>(a.yaw_e_out + i0, lo4, yaw_e);
 }
-template <bool NT, bool WANT_YAW, bool IO>
-__global__ __launch_bounds__(IO ? 512 : 256, DSIM_PRUNS_WAVES) void k_control_runs(StepK a, RunTab rt) {
-  DSIM_RUN_OF_BLOCK(rt, ro, IO ? 2 * blockIdx.x + (threadIdx.x >> 8) : blockIdx.x);
-  const unsigned t = IO ? (threadIdx.x & 255u) : threadIdx.x;
-  if (ro.quadlaw6) control_run_body<DSIM_DEV_KIND_HEXA_QUADLAW, NT, WANT_YAW, IO>(a, ro, t);
-  else if (ro.hexa) control_run_body<DSIM_DEV_KIND_HEXA, NT, WANT_YAW, IO>(a, ro, t);
-  else control_run_body<DSIM_DEV_KIND_QUAD, NT, WANT_YAW, IO>(a, ro, t);
+template <bool NT, bool WANT_YAW>
+__global__ __launch_bounds__(256, DSIM_PRUNS_WAVES) void k_control_runs(StepK a, RunTab rt) {
+  DSIM_RUN_OF_BLOCK(rt, ro, blockIdx.x);
+  IoCtl none;
+  if (ro.quadlaw6) control_run_body<DSIM_DEV_KIND_HEXA_QUADLAW, NT, WANT_YAW, false>(a, ro, threadIdx.x, none);
+  else if (ro.hexa) control_run_body<DSIM_DEV_KIND_HEXA, NT, WANT_YAW, false>(a, ro, threadIdx.x, none);
+  else control_run_body<DSIM_DEV_KIND_QUAD, NT, WANT_YAW, false>(a, ro, threadIdx.x, none);
+}
+template <bool NT, bool WANT_YAW>
+__global__ __launch_bounds__(512, DSIM_PRUNS_WAVES) void k_control_runs_io(StepK a, RunTab rt) {
+  __shared__ float win[10 * DSIM_IO_WIN];     // field f of the window: win[f * DSIM_IO_WIN + slot]; 0-5 command, 6-8 pos_e, 9 yaw_e
+  __shared__ unsigned char flags[DSIM_IO_WIN];
+  __shared__ int wmin[8];
+  DSIM_RUN_OF_BLOCK(rt, ro, 2 * blockIdx.x + (threadIdx.x >> 8));
+  const unsigned t = threadIdx.x & 255u;
+  IoCtl io;
+  io.have = false;
+  {
+    const long long i = ro.i0 + t;
+    io_window_min(i >= ro.lo && i < ro.last ? a.io_id[i] : 0x7fffffff, wmin, flags);
+  }
+  if (ro.quadlaw6) control_run_body<DSIM_DEV_KIND_HEXA_QUADLAW, NT, WANT_YAW, true>(a, ro, t, io);
+  else if (ro.hexa) control_run_body<DSIM_DEV_KIND_HEXA, NT, WANT_YAW, true>(a, ro, t, io);
+  else control_run_body<DSIM_DEV_KIND_QUAD, NT, WANT_YAW, true>(a, ro, t, io);
+  const int base = io_window_base(wmin);
+  const int nc = a.obs_w - 16;                // rows of the command table: 4, or 6 with a six-actuator type in the fleet
+  if (io.have) {
+    const unsigned slot = (unsigned)(io.id - base);
+    if (slot < (unsigned)DSIM_IO_WIN) {
+#pragma unroll
+      for (int f = 0; f < 10; ++f) win[f * DSIM_IO_WIN + slot] = io.v[f];
+      flags[slot] = 1;
+    } else {                                  // outside the window: straight out (default cache policy, see above)
+      if (a.cmd_out) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) if (j < nc) a.cmd_out[(long long)j * a.n_pad + io.id] = io.v[j];
+      }
+      if (a.pos_e_out) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a.pos_e_out[(long long)j * a.n_pad + io.id] = io.v[6 + j];
+      }
+      if (WANT_YAW) a.yaw_e_out[io.id] = io.v[9];
+    }
+  }
+  __syncthreads();
+  // window row threadIdx.x: whole lines of every output array when all 64 rows of the wave were produced here (then with
+  // the streaming hint; a wave with holes leaves them to their owners and keeps the default policy, so that the parts of a
+  // line still meet in the cache)
+  const bool mine = flags[threadIdx.x] != 0;
+  const bool whole = __ballot(mine) == ~0ULL;
+  if (mine) {
+    const unsigned lo4 = 4u * threadIdx.x;
+#define DSIM_IO_OUT(PTR, F) do { float* ub_ = (PTR) + base; const float v_ = win[(F) * DSIM_IO_WIN + threadIdx.x];          \
+                                 if (whole) stg<NT>(ub_, lo4, v_); else stg<false>(ub_, lo4, v_); } while (0)
+    if (a.cmd_out) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) if (j < nc) DSIM_IO_OUT(a.cmd_out + (long long)j * a.n_pad, j);
+    }
+    if (a.pos_e_out) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) DSIM_IO_OUT(a.pos_e_out + (long long)j * a.n_pad, 6 + j);
+    }
+    if (WANT_YAW) DSIM_IO_OUT(a.yaw_e_out, 9);
+#undef DSIM_IO_OUT
+  }
 }
 
 // ---- Env.step of the alternate action adaptors (VelocityAviary / RPYTAviary) --------------
@@ -3128,6 +3270,7 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
       const int blocks = make_runtab(ctx, a.n_pad, runs, n_runs, &rt, &any_hexa);
       if (blocks < 0) return blocks;
       if (a.io_id) { rc = side_by_side_map(ctx, st_, runs, n_runs, &rt); if (rc) return rc; }
+      if (a.io_id && args->obs_out && ((uintptr_t)args->obs_out & 15u)) return DSIM_E_ARG;   // (the window's 16-byte pieces)
       const bool obs_fused = args->obs_out && ((uintptr_t)args->obs_out & 7u) == 0;     // (8-byte pieces of the rows)
       a.obs_out = obs_fused ? args->obs_out : nullptr;
       const bool nt = stream_policy(args, state.n_pad, args->obs_out ? 240.0 : 152.0);
@@ -3136,10 +3279,10 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
         const dim3 g((unsigned)blocks), b(256);
 #define DSIM_PRUNS_CASE2(N_, T_, S_) do {                                                                                      \
           if (a.io_id) { const dim3 g2((unsigned)((blocks + 1) / 2)), b2(512);                                                 \
-                         if (a.obs_out) hipLaunchKernelGGL((k_physics_runs<N_, T_, true, true, S_>), g2, b2, 0, st_, a, rt);   \
-                         else hipLaunchKernelGGL((k_physics_runs<N_, T_, false, true, S_>), g2, b2, 0, st_, a, rt); }           \
-          else { if (a.obs_out) hipLaunchKernelGGL((k_physics_runs<N_, T_, true, false, S_>), g, b, 0, st_, a, rt);           \
-                 else hipLaunchKernelGGL((k_physics_runs<N_, T_, false, false, S_>), g, b, 0, st_, a, rt); } } while (0)
+                         if (a.obs_out) hipLaunchKernelGGL((k_physics_runs_io<N_, T_, true, S_>), g2, b2, 0, st_, a, rt);      \
+                         else hipLaunchKernelGGL((k_physics_runs_io<N_, T_, false, S_>), g2, b2, 0, st_, a, rt); }              \
+          else { if (a.obs_out) hipLaunchKernelGGL((k_physics_runs<N_, T_, true, S_>), g, b, 0, st_, a, rt);                  \
+                 else hipLaunchKernelGGL((k_physics_runs<N_, T_, false, S_>), g, b, 0, st_, a, rt); } } while (0)
 #define DSIM_PRUNS_CASE(N_, T_) do { if (a.substeps == 1) DSIM_PRUNS_CASE2(N_, T_, true); else DSIM_PRUNS_CASE2(N_, T_, false); } while (0)
         if (noise) { if (nt) DSIM_PRUNS_CASE(true, true); else DSIM_PRUNS_CASE(true, false); }
         else { if (nt) DSIM_PRUNS_CASE(false, true); else DSIM_PRUNS_CASE(false, false); }
@@ -3237,8 +3380,8 @@ int dsim_control2(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_
       if (blocks > 0) {
         const dim3 gr((unsigned)blocks);
 #define DSIM_CRUNS_CASE(T_, Y_) do {                                                                                         \
-          if (a.io_id) hipLaunchKernelGGL((k_control_runs<T_, Y_, true>), dim3((unsigned)((blocks + 1) / 2)), dim3(512), 0, st_, a, rt); \
-          else hipLaunchKernelGGL((k_control_runs<T_, Y_, false>), gr, b, 0, st_, a, rt); } while (0)
+          if (a.io_id) hipLaunchKernelGGL((k_control_runs_io<T_, Y_>), dim3((unsigned)((blocks + 1) / 2)), dim3(512), 0, st_, a, rt); \
+          else hipLaunchKernelGGL((k_control_runs<T_, Y_>), gr, b, 0, st_, a, rt); } while (0)
         if (yaw_e_out) { if (nt) DSIM_CRUNS_CASE(true, true); else DSIM_CRUNS_CASE(false, true); }
         else { if (nt) DSIM_CRUNS_CASE(true, false); else DSIM_CRUNS_CASE(false, false); }
 #undef DSIM_CRUNS_CASE
