@@ -1265,17 +1265,26 @@ typedef float vf2 __attribute__((ext_vector_type(2)));
 // number io_id[i].  The drones of a run are spread over the caller's whole range (even index quad, odd index hexa ...), so one
 // run alone fills every other 88-byte row and every other dword of the command arrays: partial memory bursts, a
 // read-modify-write each (measured, 4 194 304 interleaved drones: Env.step 351 us with the runs served one after the other
-// against 190 us for a fleet of one type).  The IO instances therefore serve the runs SIDE BY SIDE (RunTab.block_map) with
-// TWO tiles per 512-thread workgroup — neighbours in the map, i.e. tiles of different runs that cover the same stretch of
-// the caller's range — and write the scattered arrays with the default cache policy, so that the halves of a line meet in
-// the XCD's L2 before they leave for memory.  t = the thread's index inside its tile.
-// Round 4, second form: the workgroup's two tiles cover (in a well-mixed fleet: exactly) one stretch of the caller's range, so
-// the scattered outputs are ASSEMBLED in LDS over a window of DSIM_IO_WIN caller indices that starts at the workgroup's
-// smallest one, and leave as whole lines (16-byte pieces with the streaming hint, like the rows of a single-type fleet); a
-// flag per window row says whether this workgroup produced it (a hole belongs to another workgroup and is not touched), and
-// a drone whose index falls outside the window writes its outputs itself, as before.  Correct for any order, fast where the
-// types are mixed evenly — the interleaved fleets BASELINE config 5 describes.
-#define DSIM_IO_WIN 512
+// against 190 us for a fleet of one type).  The IO instances therefore serve the runs SIDE BY SIDE (RunTab.block_map): a
+// workgroup works on the SAME stretch of two neighbouring tiles of the map, i.e. of two runs that cover the same stretch of
+// the caller's range.  First form: 512 threads = two whole tiles, the scattered arrays written with the default cache
+// policy so that the halves of a line meet in the XCD's L2 before they leave for memory (418-435 us per loop iteration,
+// traffic 1.14 x).  Second form, below: the outputs are ASSEMBLED in LDS over a window of DSIM_IO_WIN caller indices that
+// starts at the workgroup's smallest one, and leave as whole lines (16-byte pieces with the streaming hint, like the rows
+// of a single-type fleet); a flag per window row says whether this workgroup produced it (a hole belongs to another
+// workgroup and is not touched), and a drone whose index falls outside the window writes its outputs itself, as before.
+// Correct for any order, fast where the types are mixed evenly — the interleaved fleets BASELINE config 5 describes:
+// traffic 1.001 x algorithmic, and the smaller the workgroup the better (two barriers couple its waves; same-box A/B of the
+// loop: 512 threads 365 us, 256: 359, 128 — one wave of either tile, a window of 128 rows = 88 whole lines: 355 us).
+// t = the thread's index inside its tile.
+#ifndef DSIM_IO_WG
+#define DSIM_IO_WG 128         // threads per workgroup of the caller-order kernels: the same stretch of two neighbouring tiles of the map
+#endif
+#define DSIM_IO_WIN DSIM_IO_WG
+#define DSIM_IO_PARTS (512 / DSIM_IO_WG)          // workgroups per pair of tiles
+// map entry and index inside its tile of a thread: the workgroup's first half works on the pair's first tile
+#define DSIM_IO_ENTRY() (2 * (int)(blockIdx.x / DSIM_IO_PARTS) + (int)(threadIdx.x / (DSIM_IO_WG / 2)))
+#define DSIM_IO_T() ((blockIdx.x % DSIM_IO_PARTS) * (DSIM_IO_WG / 2) + (threadIdx.x % (DSIM_IO_WG / 2)))
 struct IoWin { float* win; unsigned char* flags; int base; };
 // The window starts at the smallest caller index among the workgroup's live lanes, rounded down to 4 (16-byte aligned rows
 // of any width, whole 16-byte pieces of the per-field arrays).  Every wave leaves its minimum in LDS and clears its share of
@@ -1292,7 +1301,7 @@ __device__ __forceinline__ int io_window_base(const int* wmin) {
   __syncthreads();
   int b = wmin[0];
 #pragma unroll
-  for (int q = 1; q < 8; ++q) b = min(b, wmin[q]);
+  for (int q = 1; q < DSIM_IO_WG / 64; ++q) b = min(b, wmin[q]);
   return __builtin_amdgcn_readfirstlane(b) & ~3;
 }
 struct IoRow { vf2 pc[11]; int id; bool have; };            // a lane's observation row on its way to the window
@@ -1398,6 +1407,9 @@ __device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro
 #ifndef DSIM_PRUNS_WAVES
 #define DSIM_PRUNS_WAVES 4
 #endif
+#ifndef DSIM_CRUNS_WAVES
+#define DSIM_CRUNS_WAVES 4
+#endif
 template <bool NOISE, bool NT, bool OBS, bool S1>
 __global__ __launch_bounds__(256, S1 ? DSIM_PRUNS_WAVES : 3) void k_physics_runs(StepK a, RunTab rt) {
   __shared__ __attribute__((aligned(16))) float rows[OBS ? 4 * 64 * DSIM_OBS_WMAX : 2];   // per wave: 64 rows
@@ -1407,14 +1419,14 @@ __global__ __launch_bounds__(256, S1 ? DSIM_PRUNS_WAVES : 3) void k_physics_runs
   if (ro.hexa) physics_run_body<true, NOISE, NT, OBS, false, S1>(a, ro, rw, threadIdx.x, none);
   else physics_run_body<false, NOISE, NT, OBS, false, S1>(a, ro, rw, threadIdx.x, none);
 }
-// DSIM_OPT_CALLER_IO: two tiles per workgroup (neighbours in the side-by-side map), the rows assembled over the window
+// DSIM_OPT_CALLER_IO: the same stretch of two neighbouring tiles of the side-by-side map, the rows assembled over the window
 template <bool NOISE, bool NT, bool OBS, bool S1>
-__global__ __launch_bounds__(512, S1 ? DSIM_PRUNS_WAVES : 3) void k_physics_runs_io(StepK a, RunTab rt) {
+__global__ __launch_bounds__(DSIM_IO_WG, S1 ? DSIM_PRUNS_WAVES : 3) void k_physics_runs_io(StepK a, RunTab rt) {
   __shared__ __attribute__((aligned(16))) float win[OBS ? DSIM_IO_WIN * DSIM_OBS_WMAX : 4];
   __shared__ unsigned char flags[DSIM_IO_WIN];
-  __shared__ int wmin[8];
-  DSIM_RUN_OF_BLOCK(rt, ro, 2 * blockIdx.x + (threadIdx.x >> 8));
-  const unsigned t = threadIdx.x & 255u;
+  __shared__ int wmin[DSIM_IO_WG / 64];
+  DSIM_RUN_OF_BLOCK(rt, ro, DSIM_IO_ENTRY());
+  const unsigned t = DSIM_IO_T();
   IoRow io;
   io.have = false;
   if (OBS) {
@@ -1446,7 +1458,7 @@ __global__ __launch_bounds__(512, S1 ? DSIM_PRUNS_WAVES : 3) void k_physics_runs
     const unsigned W = (unsigned)a.obs_w, n4 = DSIM_IO_WIN * W / 4u, mul = W == 22u ? 2979u : 3277u;
     const vf4* win4 = reinterpret_cast<const vf4*>(win);
     float* const g = a.obs_out + (long long)base * W;
-    for (unsigned p = threadIdx.x; p < n4; p += 512u) {
+    for (unsigned p = threadIdx.x; p < n4; p += (unsigned)DSIM_IO_WG) {
       const unsigned x = 4u * p;
       const bool fa = flags[(x * mul) >> 16] != 0, fb = flags[((x + 2u) * mul) >> 16] != 0;
       const bool whole = __ballot(fa && fb) == ~0ULL;     // 1 KB of whole pieces: streaming; holes: default policy (they merge in L2)
@@ -1507,7 +1519,7 @@ __device__ __forceinline__ void control_run_body(const StepK& a, const RunOf& ro
   if (WANT_YAW) stg<NT>(a.yaw_e_out + i0, lo4, yaw_e);
 }
 template <bool NT, bool WANT_YAW>
-__global__ __launch_bounds__(256, DSIM_PRUNS_WAVES) void k_control_runs(StepK a, RunTab rt) {
+__global__ __launch_bounds__(256, DSIM_CRUNS_WAVES) void k_control_runs(StepK a, RunTab rt) {
   DSIM_RUN_OF_BLOCK(rt, ro, blockIdx.x);
   IoCtl none;
   if (ro.quadlaw6) control_run_body<DSIM_DEV_KIND_HEXA_QUADLAW, NT, WANT_YAW, false>(a, ro, threadIdx.x, none);
@@ -1515,12 +1527,12 @@ __global__ __launch_bounds__(256, DSIM_PRUNS_WAVES) void k_control_runs(StepK a,
   else control_run_body<DSIM_DEV_KIND_QUAD, NT, WANT_YAW, false>(a, ro, threadIdx.x, none);
 }
 template <bool NT, bool WANT_YAW>
-__global__ __launch_bounds__(512, DSIM_PRUNS_WAVES) void k_control_runs_io(StepK a, RunTab rt) {
+__global__ __launch_bounds__(DSIM_IO_WG, DSIM_CRUNS_WAVES) void k_control_runs_io(StepK a, RunTab rt) {
   __shared__ float win[10 * DSIM_IO_WIN];     // field f of the window: win[f * DSIM_IO_WIN + slot]; 0-5 command, 6-8 pos_e, 9 yaw_e
   __shared__ unsigned char flags[DSIM_IO_WIN];
-  __shared__ int wmin[8];
-  DSIM_RUN_OF_BLOCK(rt, ro, 2 * blockIdx.x + (threadIdx.x >> 8));
-  const unsigned t = threadIdx.x & 255u;
+  __shared__ int wmin[DSIM_IO_WG / 64];
+  DSIM_RUN_OF_BLOCK(rt, ro, DSIM_IO_ENTRY());
+  const unsigned t = DSIM_IO_T();
   IoCtl io;
   io.have = false;
   {
@@ -3278,7 +3290,7 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
       if (blocks > 0) {
         const dim3 g((unsigned)blocks), b(256);
 #define DSIM_PRUNS_CASE2(N_, T_, S_) do {                                                                                      \
-          if (a.io_id) { const dim3 g2((unsigned)((blocks + 1) / 2)), b2(512);                                                 \
+          if (a.io_id) { const dim3 g2((unsigned)((blocks + 1) / 2) * DSIM_IO_PARTS), b2(DSIM_IO_WG);                                                 \
                          if (a.obs_out) hipLaunchKernelGGL((k_physics_runs_io<N_, T_, true, S_>), g2, b2, 0, st_, a, rt);      \
                          else hipLaunchKernelGGL((k_physics_runs_io<N_, T_, false, S_>), g2, b2, 0, st_, a, rt); }              \
           else { if (a.obs_out) hipLaunchKernelGGL((k_physics_runs<N_, T_, true, S_>), g, b, 0, st_, a, rt);                  \
@@ -3380,7 +3392,7 @@ int dsim_control2(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_
       if (blocks > 0) {
         const dim3 gr((unsigned)blocks);
 #define DSIM_CRUNS_CASE(T_, Y_) do {                                                                                         \
-          if (a.io_id) hipLaunchKernelGGL((k_control_runs_io<T_, Y_>), dim3((unsigned)((blocks + 1) / 2)), dim3(512), 0, st_, a, rt); \
+          if (a.io_id) hipLaunchKernelGGL((k_control_runs_io<T_, Y_>), dim3((unsigned)((blocks + 1) / 2) * DSIM_IO_PARTS), dim3(DSIM_IO_WG), 0, st_, a, rt); \
           else hipLaunchKernelGGL((k_control_runs<T_, Y_>), gr, b, 0, st_, a, rt); } while (0)
         if (yaw_e_out) { if (nt) DSIM_CRUNS_CASE(true, true); else DSIM_CRUNS_CASE(false, true); }
         else { if (nt) DSIM_CRUNS_CASE(true, false); else DSIM_CRUNS_CASE(false, false); }
