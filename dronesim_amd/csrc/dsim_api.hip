@@ -264,8 +264,8 @@ __device__ __forceinline__ int waypoint_next(int wp, int n_wp) { return wp < n_w
 // metric definition): without the loop the compiler keeps the headline kernel in 91 instead of 110 VGPRs
 // (5 waves/SIMD) and 836 instead of 887 vector instructions.  (Measured and rejected: 2 — no change, 198 us
 // either way; 5 — the unrolled body spills, 533 vs 310 us.)
-template <int NOISE, int NROW = 4, bool OPTS = false, int NSUB = 0, bool PLANE = false>
-__device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
+template <int NOISE, int NROW = 4, bool OPTS = false, int NSUB = 0, bool PLANE = false, class DT>
+__device__ __forceinline__ void quad_substeps(DT& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[4], unsigned long long step_index,
                                               V3 ext = V3{0.0f, 0.0f, 0.0f}, const float* prev = nullptr, long long nid = -1,
                                               const NoiseTab* tab = nullptr /* LDS tables of the Box-Muller pairs, or none */) {
@@ -314,8 +314,8 @@ __device__ __forceinline__ void quad_substeps(const DevType& T, const StepK& a, 
 }
 
 // the same for the morphing hexa (BaseAviary.py:1389-1457); replay rows: f[6], m[6]
-template <bool NOISE, bool REPLAY = true, bool ONE = false, bool PLANE = false>
-__device__ __forceinline__ void hexa_substeps(const DevType& T, const StepK& a, long long i, Rigid& s,
+template <bool NOISE, bool REPLAY = true, bool ONE = false, bool PLANE = false, class DT>
+__device__ __forceinline__ void hexa_substeps(DT& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[6], unsigned long long step_index,
                                               V3 ext = V3{0.0f, 0.0f, 0.0f}, long long nid = -1) {
   const uint64_t noise_key = (uint64_t)(nid >= 0 ? nid : i);
@@ -562,8 +562,8 @@ __device__ __forceinline__ Addr make_addr(const StepK& a, long long i0, unsigned
 }
 // FULL = false: the lean form for plain stepping of mixed fleets (stored cmd as the action, no
 // noise replay, no waypoint table, one Env.step per launch) — the options cost registers.
-template <bool NOISE, int NACT, bool FULL, bool PLANE = false>
-__device__ __forceinline__ void step_gen_body(const DevType& T, const StepK& a, long long i, const Addr& ad) {
+template <bool NOISE, int NACT, bool FULL, bool PLANE = false, class DT>
+__device__ __forceinline__ void step_gen_body(DT& T, const StepK& a, long long i, const Addr& ad) {
   Rigid s;
   CtrlMem<NACT> m;
   Target tg;
@@ -684,8 +684,8 @@ __device__ __forceinline__ void dma_block64(const float* state_block, const floa
   __builtin_amdgcn_global_load_lds(tp + 256, lt + 256, 16, 0, AUX);
   __builtin_amdgcn_global_load_lds(target_block + 512 + fold, lt + 512, 16, 0, AUX);                // rows 8, 9 (+ padding)
 }
-template <bool HEXA, bool NOISE, bool S1>
-__device__ __forceinline__ void staged_body2(const DevType& T, const StepK& a, long long i, Stage64* tile, unsigned d,
+template <bool HEXA, bool NOISE, bool S1, class DT>
+__device__ __forceinline__ void staged_body2(DT& T, const StepK& a, long long i, Stage64* tile, unsigned d,
                                              bool active) {
   constexpr int NA = HEXA ? 6 : 4;
   float (*st)[64] = tile[d >> 6].st;
@@ -841,8 +841,8 @@ __device__ __forceinline__ void dma_block64u(const float* state_block, const flo
   __builtin_amdgcn_global_load_lds(target_block + 8 * 64 + lane, lt + 8 * 64, 4, 0, AUX);           // rows 8, 9
   __builtin_amdgcn_global_load_lds(target_block + 9 * 64 + lane, lt + 9 * 64, 4, 0, AUX);
 }
-template <bool HEXA, bool NOISE, bool S1, bool BIN>
-__device__ __forceinline__ void staged_body4(const DevType& T, const StepK& a, long long i, Stage64u* tile, unsigned d,
+template <bool HEXA, bool NOISE, bool S1, bool BIN, class DT>
+__device__ __forceinline__ void staged_body4(DT& T, const StepK& a, long long i, Stage64u* tile, unsigned d,
                                              bool active) {
   constexpr int NA = HEXA ? 6 : 4;
   float (*st)[64] = tile[d >> 6].st;
@@ -959,7 +959,7 @@ __device__ __forceinline__ void run_body(const StepK& a, long long i0, long long
   constexpr bool HEXA = KIND != DSIM_DEV_KIND_QUAD;            // six actuators, morphing-hexa physics
   const long long i = i0 + threadIdx.x;
   if (i >= last || i < lo) return;          // (a run may begin and end inside a tile: the neighbouring run's lanes take the rest)
-  const DevType& T = a.types[run_type];
+  const DevType& T = a.types[run_type];     // (the constant address space — dsim_device.h, as in the two-call run kernels — costs this body SGPR spills)
   const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
   const unsigned sl = 4u * kv_lane(a.st, threadIdx.x), tl = 4u * kv_lane(a.tg, threadIdx.x);
   float* const sb = a.st.base + kv_off(a.st, i0);
@@ -1047,8 +1047,8 @@ __global__ __launch_bounds__(256, 3) void k_step_runs(StepK a, RunTab rt) {
 }
 
 // ---- Env.step only ---------------------------------------------------------
-template <bool NOISE, int NACT, bool PLANE = false>
-__device__ __forceinline__ void physics_gen_body(const DevType& T, const StepK& a, long long i, const Addr& ad) {
+template <bool NOISE, int NACT, bool PLANE = false, class DT>
+__device__ __forceinline__ void physics_gen_body(DT& T, const StepK& a, long long i, const Addr& ad) {
   Rigid s;
   load_rigid(ad.sb, ad.sfs, ad.sl, s);
   float raw[NACT], cmd[NACT];
@@ -1092,8 +1092,8 @@ __global__ __launch_bounds__(256, 1) void k_physics_plane(StepK a) {     // DSIM
 }
 
 // ---- computeControl only ----------------------------------------------------
-template <int NACT>
-__device__ __forceinline__ void control_gen_body(const DevType& T, const StepK& a, long long i, const Addr& ad) {
+template <int NACT, class DT>
+__device__ __forceinline__ void control_gen_body(DT& T, const StepK& a, long long i, const Addr& ad) {
   Rigid s;
   CtrlMem<NACT> m;
   Target tg;
@@ -1316,7 +1316,7 @@ __device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro
   const int W = HEXA ? 22 : a.obs_w;                                   // row width: 20 for a quad-only table, 22 with a hexa in it
   const unsigned lane = t & 63u;
   if (live) {
-    const DevType& T = a.types[ro.type];
+    CDevType& T = dev_type(a.types, ro.type);
     const long long sfs = a.st.field_stride;
     const unsigned sl = 4u * kv_lane(a.st, t);
     float* const sb = a.st.base + kv_off(a.st, i0);
@@ -1479,7 +1479,7 @@ __device__ __forceinline__ void control_run_body(const StepK& a, const RunOf& ro
   constexpr int NA = HEXA ? 6 : 4;
   const long long i0 = ro.i0, i = i0 + t;
   if (i >= ro.last || i < ro.lo) return;
-  const DevType& T = a.types[ro.type];
+  CDevType& T = dev_type(a.types, ro.type);
   const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
   const unsigned sl = 4u * kv_lane(a.st, t), tl = 4u * kv_lane(a.tg, t);
   float* const sb = a.st.base + kv_off(a.st, i0);
@@ -1587,8 +1587,8 @@ __global__ __launch_bounds__(DSIM_IO_WG, DSIM_CRUNS_WAVES) void k_control_runs_i
 
 // ---- Env.step of the alternate action adaptors (VelocityAviary / RPYTAviary) --------------
 // control (inside _preprocessAction) on the CURRENT state, then the physics with the new command
-template <int MODE, bool NOISE, bool PLANE>
-__device__ __forceinline__ void adaptor_body(const DevType& T, const StepK& a, long long i, const Addr& ad) {
+template <int MODE, bool NOISE, bool PLANE, class DT>
+__device__ __forceinline__ void adaptor_body(DT& T, const StepK& a, long long i, const Addr& ad) {
   Rigid s;
   CtrlMem<4> m;
   load_rigid(ad.sb, ad.sfs, ad.sl, s);

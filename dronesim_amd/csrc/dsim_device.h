@@ -41,6 +41,16 @@ struct DevType {
   float watch_below;                          // coll_below seen from the reported point (ground-plane watch)
 };
 
+// The table is written once (dsim_create) and only read by kernels, which read it through the CONSTANT address space.  A
+// load through a plain global pointer becomes a scalar load only when the compiler can show that nothing in the kernel wrote
+// memory in front of it, and that search gives up in the large multi-law kernels: in k_control_runs the ~130 constants of a
+// type arrived by VECTOR loads — 105 VGPRs, 4 waves per SIMD, against 57 for the same law alone in a kernel.  A load from
+// the constant address space needs no such proof.
+typedef const __attribute__((address_space(4))) DevType CDevType;
+__device__ __forceinline__ CDevType& dev_type(const DevType* table, int k) {
+  return *reinterpret_cast<CDevType*>(reinterpret_cast<uintptr_t>(table + k));
+}
+
 struct V3 { float x, y, z; };
 struct Q4 { float x, y, z, w; };   // xyzw, w last (dronesim/utils/math.py:6,25,47)
 struct M3 { float m[9]; };         // row-major, body -> world
@@ -259,7 +269,8 @@ struct Target { V3 pos, vel, acc; float yaw; };
 // model the plane (DSIM_OPT_PLANE does, in its own kernel instances), so an Env.step that ends with the vehicle's
 // collision cylinder at or below z = 0 is COUNTED: one atomic per wave that holds such a drone, on one of 64 counter shards (dsim_query sums them).
 #define DSIM_GROUND_SHARDS 64
-__device__ __forceinline__ void ground_watch(const DevType& T, const Rigid& s, unsigned long long* counters, bool live = true) {
+template <class DT>
+__device__ __forceinline__ void ground_watch(DT& T, const Rigid& s, unsigned long long* counters, bool live = true) {
   const float r22 = 1.0f - 2.0f * (s.q.x * s.q.x + s.q.y * s.q.y);                     // body z . world z (unit q)
   const float reach = T.watch_below * fabsf(r22) + T.coll_r * DSIM_SQRT(fmaxf(1.0f - r22 * r22, 0.0f));
   const bool hit = live && T.coll_r > 0.0f && s.pos.z <= reach;
@@ -269,8 +280,8 @@ __device__ __forceinline__ void ground_watch(const DevType& T, const Rigid& s, u
 }
 
 // P1: CtrlAviary._preprocessAction, CtrlAviary.py:258-263
-template <int NACT>
-__device__ __forceinline__ void preprocess_action(const DevType& T, const float* a, float* clipped) {
+template <int NACT, class DT>
+__device__ __forceinline__ void preprocess_action(DT& T, const float* a, float* clipped) {
 #pragma unroll
   for (int j = 0; j < NACT; ++j) clipped[j] = clampf(a[j], T.pmin[j], T.pmax[j]);
 }
@@ -279,7 +290,8 @@ __device__ __forceinline__ void preprocess_action(const DevType& T, const float*
 // Body-frame wrench about the COM = what the four link forces (applied at the prop
 // links' inertial origins, LINK_FRAME) and the base torque add up to.
 // nz: 8 scaled normals (f_noise[4] ~ N(0,.01), m_noise[4] ~ N(0,.001)) or nullptr.
-__device__ __forceinline__ void quad_wrench(const DevType& T, const float cmd[4], const float* nz, V3& F, V3& tau) {
+template <class DT>
+__device__ __forceinline__ void quad_wrench(DT& T, const float cmd[4], const float* nz, V3& F, V3& tau) {
   float f[4], t[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -310,7 +322,8 @@ __device__ __forceinline__ void quad_wrench(const DevType& T, const float cmd[4]
 // its own magnitude), so the two cancelling sums are accumulated in fp64 and rounded once — a dozen fp64 operations per
 // Env.step.  The rotor forces themselves are the fp32 values the unsplit map uses.
 struct QuadBase { float Fz; V3 tau; };
-__device__ __forceinline__ QuadBase quad_wrench_base(const DevType& T, const float cmd[4]) {
+template <class DT>
+__device__ __forceinline__ QuadBase quad_wrench_base(DT& T, const float cmd[4]) {
   double fz = 0.0, tx = 0.0, ty = 0.0;
   float tz = 0.0f;
 #pragma unroll
@@ -324,7 +337,8 @@ __device__ __forceinline__ QuadBase quad_wrench_base(const DevType& T, const flo
   }
   return QuadBase{(float)fz, V3{(float)tx, (float)ty, tz}};
 }
-__device__ __forceinline__ void quad_wrench_noise(const DevType& T, const QuadBase& b, const float nz[8], V3& F, V3& tau) {
+template <class DT>
+__device__ __forceinline__ void quad_wrench_noise(DT& T, const QuadBase& b, const float nz[8], V3& F, V3& tau) {
   const float fx = nz[0], fy = nz[1];
   F = v3(4.0f * fx, 4.0f * fy, b.Fz + ((nz[0] + nz[1]) + (nz[2] + nz[3])));
   const float sy = T.rpos[0][1] * nz[0] + T.rpos[1][1] * nz[1] + T.rpos[2][1] * nz[2] + T.rpos[3][1] * nz[3];
@@ -337,7 +351,8 @@ __device__ __forceinline__ void quad_wrench_noise(const DevType& T, const QuadBa
 // P7: BaseAviary._groundEffect, BaseAviary.py:1648-1699 (formula; dead code in the fork): per rotor
 // dF_i = kf rpm_i^2 GND_EFF_COEFF (PROP_RADIUS / (4 h_i))^2 along the link z axis at the rotor link,
 // h_i = rotor height clipped below at GND_EFF_H_CLIP, only while |roll|, |pitch| < pi/2.
-__device__ __forceinline__ void ground_effect_quad(const DevType& T, const Rigid& s, const float cmd[4], V3& F, V3& tau) {
+template <class DT>
+__device__ __forceinline__ void ground_effect_quad(DT& T, const Rigid& s, const float cmd[4], V3& F, V3& tau) {
   const Q4 q = s.q;
   const float sarg = -2.0f * (q.x * q.z - q.w * q.y);
   const float rb = q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z;      // cos(roll) > 0  <=>  |roll| < pi/2
@@ -357,7 +372,8 @@ __device__ __forceinline__ void ground_effect_quad(const DevType& T, const Rigid
 
 // P6: BaseAviary._drag, BaseAviary.py:1705-1732 (formula; dead code in the fork), restated literally:
 // drag = R . (-DRAG_COEFF * sum(2 pi rpm / 60) * v_world), handed to Bullet as a LINK_FRAME force at the COM.
-__device__ __forceinline__ V3 drag_quad(const DevType& T, const Rigid& s, const float last_cmd[4]) {
+template <class DT>
+__device__ __forceinline__ V3 drag_quad(DT& T, const Rigid& s, const float last_cmd[4]) {
   float w = 0.0f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) w += (T.scale[i] * last_cmd[i] + T.cnst[i]) * (6.28318530717958647692f / 60.0f);
@@ -379,7 +395,8 @@ struct SymM3 { float xx, xy, xz, yy, yz, zz; };
 __device__ __forceinline__ V3 mul(const SymM3& A, V3 b) {
   return v3(A.xx * b.x + A.xy * b.y + A.xz * b.z, A.xy * b.x + A.yy * b.y + A.yz * b.z, A.xz * b.x + A.yz * b.y + A.zz * b.z);
 }
-__device__ __forceinline__ void plane_contact(const DevType& T, float dt, const V3 pos, const Q4 q, V3& v, V3& w) {
+template <class DT>
+__device__ __forceinline__ void plane_contact(DT& T, float dt, const V3 pos, const Q4 q, V3& v, V3& w) {
   if (!(T.coll_r > 0.0f)) return;
   const M3 R = matrix_from_quat(q);
   const V3 a = v3(R.m[2], R.m[5], R.m[8]);                          // body z axis in the world
@@ -447,8 +464,8 @@ __device__ __forceinline__ void plane_contact(const DevType& T, float dt, const 
 
 // P4: one Bullet btMultiBody floating-base step [BULLET-INTERNAL, parity unpinned];
 // restated step by step in oracle/dsim_oracle.c:orc_bullet_step.  PLANE: with the contact solve (DSIM_OPT_PLANE).
-template <bool PLANE = false>
-__device__ __forceinline__ void bullet_step(const DevType& T, float dt, Rigid& s, V3 F_body, V3 tau_body) {
+template <bool PLANE = false, class DT>
+__device__ __forceinline__ void bullet_step(DT& T, float dt, Rigid& s, V3 F_body, V3 tau_body) {
   const M3 R = matrix_from_quat(s.q);
   const V3 wb = mulT(R, s.w);
   // linear: world-frame form of a_b + w_b x v_b (the m w x v bias cancels), |v_b| = |v|
@@ -494,8 +511,8 @@ __device__ __forceinline__ void bullet_step(const DevType& T, float dt, Rigid& s
 // C4: INDIControl._INDIRateControl, INDIControl.py:413-490 (also the whole of RPYTAviary's action
 // adaptor, RPYTAviary.py:181-193): body rates, finite-difference angular acceleration, the virtual
 // control v, du = pinv(G1/0.05) v, cmd += du, clip.
-template <int NACT = 4>
-__device__ __forceinline__ void indi_rate(const DevType& T, float inv_dt, const Rigid& s, V3 rate_sp, float thrust,
+template <int NACT = 4, class DT>
+__device__ __forceinline__ void indi_rate(DT& T, float inv_dt, const Rigid& s, V3 rate_sp, float thrust,
                                           CtrlMem<NACT>& m) {
   const M3 R = matrix_from_quat(s.q);                                          // :428
   const V3 wb = mulT(R, s.w);                                                  // :430
@@ -523,8 +540,8 @@ __device__ __forceinline__ void indi_rate(const DevType& T, float inv_dt, const 
 // quaternion, hence of quat_err, and quat_wrap_shortest (math.py:46-51) removes exactly that
 // sign.  The attitude error therefore depends on psi* alone, and the kernel evaluates
 // sincos(psi*/2) directly; psi itself (one more atan2) is computed only when yaw_e is wanted.
-template <bool WANT_YAW, int NACT = 4>
-__device__ __forceinline__ void indi_quad(const DevType& T, float dt, const Rigid& s, const Target& tg,
+template <bool WANT_YAW, int NACT = 4, class DT>
+__device__ __forceinline__ void indi_quad(DT& T, float dt, const Rigid& s, const Target& tg,
                                           CtrlMem<NACT>& m, V3& pos_e, float& yaw_e) {
   // ---- _INDIPositionControl, :278-296
   pos_e = tg.pos - s.pos;
@@ -578,7 +595,8 @@ __device__ __forceinline__ void indi_quad(const DevType& T, float dt, const Rigi
 // P3: BaseAviary._morphing_hexa_physics, BaseAviary.py:1398-1403, 1429-1457: force [0,0,F_j] and
 // torque [0,0,tau_j] in the tilted prop link frames (rigid composite body, see params.py).
 // nz: 12 scaled normals (f_noise[6], m_noise[6]) or nullptr.
-__device__ __forceinline__ void hexa_wrench(const DevType& T, const float cmd[6], const float* nz, V3& F, V3& tau) {
+template <class DT>
+__device__ __forceinline__ void hexa_wrench(DT& T, const float cmd[6], const float* nz, V3& F, V3& tau) {
   // F = sum_j f_j a_j ;  tau = sum_j f_j (r_j x a_j) + tq_j a_j   (a_j: rotor axis, r_j: lever arm; r_j x a_j is a
   // per-type constant, so the wrench is three 3x6 matrix-vector products instead of six cross products)
   F = v3(0, 0, 0); tau = v3(0, 0, 0);
@@ -594,7 +612,8 @@ __device__ __forceinline__ void hexa_wrench(const DevType& T, const float cmd[6]
 
 // the same split (see quad_wrench_base): rpm_j, hence f0_j and tq0_j, are constant over the sub-steps
 struct HexaBase { V3 F, tau; };
-__device__ __forceinline__ HexaBase hexa_wrench_base(const DevType& T, const float cmd[6]) {
+template <class DT>
+__device__ __forceinline__ HexaBase hexa_wrench_base(DT& T, const float cmd[6]) {
   double F[3] = {0.0, 0.0, 0.0}, tau[3] = {0.0, 0.0, 0.0};      // (fp64 sums: see quad_wrench_base)
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -608,7 +627,8 @@ __device__ __forceinline__ HexaBase hexa_wrench_base(const DevType& T, const flo
   }
   return HexaBase{V3{(float)F[0], (float)F[1], (float)F[2]}, V3{(float)tau[0], (float)tau[1], (float)tau[2]}};
 }
-__device__ __forceinline__ void hexa_wrench_noise(const DevType& T, const HexaBase& b, const float nz[12], V3& F, V3& tau) {
+template <class DT>
+__device__ __forceinline__ void hexa_wrench_noise(DT& T, const HexaBase& b, const float nz[12], V3& F, V3& tau) {
   F = b.F; tau = b.tau;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -635,7 +655,8 @@ struct WlsWork {
   double umin[6], umax[6];
   int free_index[6], lookup[6];
 };
-__device__ __forceinline__ int wls_active_set(const DevType& T, const float v[6], const float umin_[6],
+template <class DT>
+__device__ __forceinline__ int wls_active_set(DT& T, const float v[6], const float umin_[6],
                                            const float umax_[6], float u_out[6], WlsWork& ws) {
   const double gam = 100000.0;
   const double Wv[6] = {1000, 1000, 0.1, 10, 10, 100};          // INDIControl_6DOF.py:614
@@ -744,8 +765,8 @@ __device__ __forceinline__ int wls_active_set(const DevType& T, const float v[6]
 
 // C5: INDIControl_6DOF.computeControl, INDIControl_6DOF.py:259-634.
 // Infeasible first iterations are queued in `fb` (see FbList).
-template <bool WANT_YAW>
-__device__ __forceinline__ void indi_hexa(const DevType& T, float dt, const Rigid& s, const Target& tg,
+template <bool WANT_YAW, class DT>
+__device__ __forceinline__ void indi_hexa(DT& T, float dt, const Rigid& s, const Target& tg,
                                           CtrlMem<6>& m, V3& pos_e, float& yaw_e, const FbList& fb, long long drone) {
   pos_e = tg.pos - s.pos;                                                     // :397
   const float inv_dt = DSIM_RCP(dt);
