@@ -791,7 +791,7 @@ __global__ __launch_bounds__(64 * WT, S1 ? 4 : 3) void k_step_mixed3(StepK a) {
   __syncthreads();
   if (wave_t >= 0) {
     const long long i = i0 + d;
-    const DevType& T = a.types[wave_t];
+    CDevType& T = dev_type(a.types, wave_t);     // (constant address space, dsim_device.h: 122-156 -> 97-102 VGPRs, 238 -> 210 us)
     if (T.kind == DSIM_DEV_KIND_HEXA) staged_body2<true, NOISE, S1>(T, a, i, tile, d, active);
     else staged_body2<false, NOISE, S1>(T, a, i, tile, d, active);
   }
@@ -934,7 +934,7 @@ __global__ __launch_bounds__(128, S1 ? 4 : 3) void k_step_mixed4(StepK a) {
     const unsigned rr = active ? r : 0u;
     const unsigned d = rr < c0 ? nth_set_bit64(ma, rr) : 64u + nth_set_bit64(mb, rr - c0);
     const long long i = i0 + d;
-    const DevType& T = a.types[ty];
+    CDevType& T = dev_type(a.types, ty);         // (constant address space, dsim_device.h: 192 -> 182 us)
     if (T.kind == DSIM_DEV_KIND_HEXA) staged_body4<true, NOISE, S1, BIN>(T, a, i, tile, d, active);
     else staged_body4<false, NOISE, S1, BIN>(T, a, i, tile, d, active);
   }
@@ -959,7 +959,9 @@ __device__ __forceinline__ void run_body(const StepK& a, long long i0, long long
   constexpr bool HEXA = KIND != DSIM_DEV_KIND_QUAD;            // six actuators, morphing-hexa physics
   const long long i = i0 + threadIdx.x;
   if (i >= last || i < lo) return;          // (a run may begin and end inside a tile: the neighbouring run's lanes take the rest)
-  const DevType& T = a.types[run_type];     // (the constant address space — dsim_device.h, as in the two-call run kernels — costs this body SGPR spills)
+  // (the constant address space — dsim_device.h, as in the two-call run kernels — costs THIS body SGPR spills and a scratch
+  // reservation: k_step_runs 166.9 against 162.7 us on the interleaved fleet, same-box A/B)
+  const DevType& T = a.types[run_type];
   const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
   const unsigned sl = 4u * kv_lane(a.st, threadIdx.x), tl = 4u * kv_lane(a.tg, threadIdx.x);
   float* const sb = a.st.base + kv_off(a.st, i0);
