@@ -145,7 +145,7 @@ class INDIControl(BaseControl):
             nat.check(lib.dsim_control2(h, self.ctx.stream_ptr(), self.n, view, tview, ref, c[na:na + 3].data_ptr(),
                                         c[na + 3].data_ptr(), c[0:na].data_ptr()))
         keep = placement.place_rows(self.ctx.device, (na + 4, n_pad), trial, report=self.ctx.placement_log,
-                                    label="computeControl outputs", ctx=self.ctx)
+                                    label="computeControl outputs", ctx=self.ctx, stride_bytes=placement.STRIDE_BYTES)
         st.data.copy_(snap)
         self._cmd, self._pos_e, self._yaw_e = keep[0:na], keep[na:na + 3], keep[na + 3]
 

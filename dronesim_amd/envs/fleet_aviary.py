@@ -596,7 +596,8 @@ class CtrlAviary:
                 def split(block):
                     self._obs_buf = block[:n_rows].view(shape)
                     self._written_tail = block[n_rows:].view(self.n_act + 4, self.state.n_pad)
-                split(placement.place_rows(self.ctx.device, flat, self._rows_trial, report=log, ctx=self.ctx))
+                split(placement.place_rows(self.ctx.device, flat, self._rows_trial, report=log, ctx=self.ctx,
+                                           stride_bytes=placement.STRIDE_BYTES))
                 if log and log[-1]["decided_by"] == "all alike" and not self._graph_made:
                     # Every candidate timed alike.  Either all of them are good — or the STATE block itself lies across two
                     # regions of device memory (one process in ten), and then no place for the rows is.  One more try with
@@ -609,7 +610,8 @@ class CtrlAviary:
                         fresh = None
                     if fresh is not None:
                         self._move_state(fresh)
-                        block2 = placement.place_rows(self.ctx.device, flat, self._rows_trial, report=log, ctx=self.ctx)
+                        block2 = placement.place_rows(self.ctx.device, flat, self._rows_trial, report=log, ctx=self.ctx,
+                                                      stride_bytes=placement.STRIDE_BYTES)
                         log[-1]["state_block"] = "moved to a fresh allocation"
                         if log[-1]["chosen_pass_us"] < 0.95 * best1:
                             split(block2)

@@ -39,7 +39,10 @@ calls `torch.cuda.empty_cache()`, a co-resident policy network keeps its cached 
 min(WALK_BYTES, WALK_FRACTION of the device memory that is free when it starts) and never less than two candidates' worth
 (else there is nothing to choose from: the array is allocated plainly); an allocation failure ends the walk with what it has;
 a walk that could time nothing falls back to a plain zeroed array.  Every search reports what it cost: `seconds`,
-`peak_bytes`.
+`peak_bytes`.  The rows' walk strides (1 GiB of untimed ballast behind every candidate, `STRIDE_BYTES`) and may hold 34 GiB
+for the fraction of a second it takes: back-to-back candidates within 16 GiB — round 3's walk — all timed alike (159-165 us)
+on this round's boxes, where a striding walk finds 143 us from its third candidate on (tools/region_probe.py,
+profiles/r04_region_probe.txt): the walk has to LEAVE the 16 GiB region the state block lies in.
 """
 from __future__ import annotations
 
@@ -50,8 +53,9 @@ from typing import Callable, Optional
 import torch
 
 MIN_BYTES = 64 << 20                          # arrays at least this large, or they are allocated plainly
-WALK_BYTES = 16 << 30                         # candidates held at once while searching (transient); good places mostly turn up within 2-3 GiB
-WALK_FRACTION = 0.10                          # ... and never more than this share of the free device memory
+WALK_BYTES = 34 << 30                         # held at once while searching (transient): two 16 GiB regions and a candidate; good places mostly turn up within 3-4 GiB
+WALK_FRACTION = 0.125                         # ... and never more than this share of the free device memory
+STRIDE_BYTES = 1 << 30                        # untimed ballast between two candidates of the rows' walk: fewer, further apart
 CLEARLY = 0.93                                # one candidate this much faster than another: the two cases are apart, stop
 
 
@@ -105,7 +109,7 @@ def _free_bytes(device) -> int:
 
 def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int = 3, report: Optional[list] = None,
                label: str = "observation rows", walk_bytes: int = WALK_BYTES, timer=None,
-               clearly: float = CLEARLY, ctx=None, free_bytes: Optional[int] = None) -> torch.Tensor:
+               clearly: float = CLEARLY, ctx=None, free_bytes: Optional[int] = None, stride_bytes: int = 0) -> torch.Tensor:
     """A zeroed fp32 array of `shape`.  `trial(array)` enqueues ONE pass of the real kernel writing its output to `array`
     (the caller restores whatever the passes change).  Candidates are allocated one after the other and all held, so that
     the walk moves through device memory; each is timed over `passes` passes behind one untimed pass; the walk ends as soon
@@ -114,7 +118,11 @@ def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int
     levels — 154 / 158 / 164 us for the fused step by where its targets lie — and the first may be the middle one.)
     `ctx`: the fleet's Context — candidates come from the driver through it (dsim_dev_alloc), not from PyTorch's caching
     allocator; None (CPU tests): torch.empty.  `timer(trial, candidate, passes)`: the clock (tests).  `clearly`: the ratio
-    that counts as clear; 0: no early end, the whole walk.  `free_bytes`: the free device memory to budget against (tests)."""
+    that counts as clear; 0: no early end, the whole walk.  `free_bytes`: the free device memory to budget against (tests).
+    `stride_bytes`: an untimed ballast block of that size is allocated (and held, inside the budget) behind every candidate:
+    the walk then covers the budget with fewer candidates.  Round 4, tools/region_probe.py: 36 back-to-back 470 MB candidates
+    — 16 GiB, the old budget — all timed 159-165 us on boxes where a walk with 1 GiB strides finds 143 us from its third
+    candidate on: back-to-back allocations may never leave the 16 GiB region the state block lies in."""
     t_start = time.perf_counter()
     nbytes = 4
     for d in shape:
@@ -123,8 +131,9 @@ def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int
     budget = min(int(walk_bytes), int(WALK_FRACTION * free))
     cands, blocks, times = [], [], []
     chosen, decided = None, ""
+    held = 0
     if budget >= 2 * nbytes:
-        while chosen is None and (len(cands) + 1) * nbytes <= budget:
+        while chosen is None and held + nbytes <= budget:
             try:
                 if ctx is not None:
                     blk = _DriverBlock(ctx, shape)
@@ -134,9 +143,17 @@ def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int
             except (MemoryError, RuntimeError):             # (torch.cuda.OutOfMemoryError is a RuntimeError)
                 break
             cands.append(c); blocks.append(blk)
+            held += nbytes
             times.append((timer or _event_timer)(trial, c, passes))
             if clearly > 0.0 and times[-1] < clearly * times[0]:
                 chosen, decided = len(times) - 1, "a candidate clearly faster than the first"
+            elif stride_bytes > 0 and held + stride_bytes + nbytes <= budget:
+                try:
+                    blocks.append(_DriverBlock(ctx, (stride_bytes // 4,)) if ctx is not None else
+                                  torch.empty((stride_bytes // 4,), dtype=torch.float32, device=device))
+                    held += stride_bytes
+                except (MemoryError, RuntimeError):
+                    break
     if not times:
         # nothing to choose from (too little free memory for two candidates, or the driver refused the first): plainly
         keep = torch.zeros(tuple(shape), dtype=torch.float32, device=device)
@@ -149,7 +166,7 @@ def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int
         chosen = min(range(len(times)), key=times.__getitem__)
         decided = "the fastest of the walk" if times[chosen] < CLEARLY * max(times) else "all alike"
     keep = cands[chosen]
-    peak = len(cands) * nbytes
+    peak = held
     n_c = len(cands)
     c = blk = None
     del cands, blocks                         # what was not kept goes back to the driver (the tensors were the only references)

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Dev probe (round 4): why does every candidate of the rows' walk time alike on some boxes?  One 4 194 304-quad env,
+zero-sub-step passes of the Env.step launch (what placement.place_rows times) with
+  A  the rows as torch allocates them,
+  B  rows from the driver, 1 GiB of ballast between candidates, 28 GiB walked,
+  C  the STATE moved to a driver allocation, the same walk,
+  D  the action / echo arrays from the driver too.
+usage: python tools/region_probe.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dronesim_amd import placement  # noqa: E402
+from dronesim_amd.envs import CtrlAviary  # noqa: E402
+
+
+def main():
+    n = 4096 * 1024
+    ij = np.arange(n) % 4096
+    xyz = np.stack([(ij % 64) * 1.0, (ij // 64) * 1.0, np.full(n, 0.5)], 1)
+    env = CtrlAviary(["robobee"], n, initial_xyzs=xyz, aggregate_phy_steps=1, noise_seed=1, dict_io=False, layout="tile64",
+                     placement=False)
+    ctx = env.ctx
+    gib = 1 << 30
+
+    def t(rows):
+        return placement._event_timer(env._rows_trial, rows, 5)
+
+    def walk(tag, span_gib=28, ballast_gib=1.0):
+        keep, out = [], []
+        held = 0
+        while held < span_gib * gib:
+            c = placement._DriverBlock(ctx, (n, 28))
+            rows = c.tensor()
+            rows.zero_()
+            out.append(round(t(rows), 1))
+            keep.append(rows)
+            held += c.nbytes
+            b = placement._DriverBlock(ctx, (int(ballast_gib * gib) // 4,))
+            keep.append(b)
+            held += b.nbytes
+        print(tag, "state", hex(env.state.data.data_ptr()), out, flush=True)
+        del keep
+        torch.cuda.synchronize()
+
+    a = torch.zeros((n, 28), dtype=torch.float32, device=ctx.device)
+    print("A torch rows", hex(a.data_ptr()), round(t(a), 1), "state", hex(env.state.data.data_ptr()), flush=True)
+    walk("B driver rows")
+    blk = placement._DriverBlock(ctx, tuple(env.state.data.shape))
+    env._move_state(blk.tensor())
+    print("C state moved to the driver: torch rows", round(t(a), 1), flush=True)
+    walk("C driver rows")
+    for name in ("_action_buf", "_last_action"):
+        old = getattr(env, name)
+        nb = placement._DriverBlock(ctx, tuple(old.shape)).tensor()
+        nb.copy_(old)
+        setattr(env, name, nb)
+    print("D action + echo from the driver: torch rows", round(t(a), 1), flush=True)
+    walk("D driver rows", span_gib=12)
+
+
+if __name__ == "__main__":
+    main()
