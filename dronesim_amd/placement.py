@@ -176,6 +176,6 @@ def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int
         report.append({"array": label, "bytes": nbytes, "candidates": n_c, "chosen": chosen,
                        "decided_by": decided, "chosen_pass_us": round(times[chosen], 1), "first_pass_us": round(times[0], 1),
                        "pass_us" if len(times) <= 12 else "pass_us_first4_last4": [round(t, 1) for t in shown],
-                       "budget_bytes": budget, "peak_bytes": peak, "seconds": round(time.perf_counter() - t_start, 4),
-                       "memory": "driver (dsim_dev_alloc)" if ctx is not None else "torch"})
+                       "budget_bytes": budget, "peak_bytes": peak, "stride_bytes": int(stride_bytes),
+                       "seconds": round(time.perf_counter() - t_start, 4), "memory": "driver (dsim_dev_alloc)" if ctx is not None else "torch"})
     return keep

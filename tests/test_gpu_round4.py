@@ -544,7 +544,7 @@ def test_placement_of_rows_on_hexa_and_reordered_fleets_changes_nothing(gpu, kin
             assert [r["array"] for r in log if r["array"] != "observation rows"] == ["computeControl outputs"]
             rows = [r for r in log if r["array"] == "observation rows"]
             assert 1 <= len(rows) <= 2 and rows[0]["memory"].startswith("driver") and rows[0]["candidates"] >= 2
-            assert rows[0]["peak_bytes"] == rows[0]["candidates"] * rows[0]["bytes"] <= rows[0]["budget_bytes"]
+            assert rows[0]["candidates"] * rows[0]["bytes"] <= rows[0]["peak_bytes"] <= rows[0]["budget_bytes"]     # (+ the ballast strides)
             assert 0 < rows[0]["seconds"] < 30
             assert cmd.data_ptr() == e._written_tail.data_ptr()         # the command lives in the room behind the placed rows
         else:
