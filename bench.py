@@ -587,6 +587,43 @@ def measure_variant(torch, local, layout, seed, steps, name, nf, rep, sub, wp, n
     return e
 
 
+def measure_adaptor_env(torch, local, layout, seed, steps, cls_name):
+    """Env.step of the reference's alternate action adaptors (VelocityAviary.py:221-264 / RPYTAviary.py:181-193) on the
+    headline fleet: the (part of the) INDI law inside step() on the current state, the physics, the observation rows —
+    one launch (k_adaptor_fast), the [N, 4] action taken as the caller holds it.  304 B per drone-step: 24 state + 4 action
+    floats in, 24 state + 4 echoed command + 20 row floats out."""
+    import numpy as np
+    from dronesim_amd import envs
+    try:
+        n = 4096 * 1024
+        ij = np.arange(n) % 4096
+        xyz = np.stack([(ij % 64) * 1.0, (ij // 64) * 1.0, np.full(n, 0.5)], 1)
+        env = getattr(envs, cls_name)(["robobee"], n, initial_xyzs=xyz, aggregate_phy_steps=1, noise_seed=seed, dict_io=False,
+                                      layout=layout, device=local)
+        if cls_name == "VelocityAviary":
+            act = torch.tensor([1.0, 0.0, 0.2, 0.5], device=env.ctx.device).repeat(n, 1)
+        else:
+            act = torch.tensor([0.0, 0.0, 0.0, 9.81 * env.types[0].mass], device=env.ctx.device).repeat(n, 1)
+        k = max(20, steps // 2)
+        for _ in range(10):
+            env.step(act)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(k):
+            env.step(act)
+        e1.record()
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / k
+        out = {"drone_steps_per_s": n / us * 1e6, "env_step_us": us, "drones": n, "phys_substeps": 1, "steps_timed": k,
+               "bytes_per_drone_step": 304, "hbm_frac": n * 304 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+               "kernel": "k_adaptor_fast (action rows in, observation rows out: one launch per Env.step)"}
+        env.close()
+        return out
+    except Exception as e:          # an extra must not cost the headline
+        return {"error": repr(e)[:300]}
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     a = parse(argv)
@@ -802,6 +839,8 @@ def main(argv=None):
             # relative to its state block is worth 10-15 % of it (dronesim_amd/placement.py), and at the end of THIS
             # process — dozens of fleets built and dropped — every fresh allocation is pieced together from fragments of
             # many regions, which a process that runs the loop from its start never sees.
+            also["velocity_aviary_env_step_4194304"] = measure_adaptor_env(torch, local, a.layout, a.noise_seed, a.steps, "VelocityAviary")
+            also["rpyt_aviary_env_step_4194304"] = measure_adaptor_env(torch, local, a.layout, a.noise_seed, a.steps, "RPYTAviary")
             also["config2x1024_env_step_then_computeControl"] = two_call_child(a)
             # the same loop on the other fleet kinds (examples/fly_hexa_6DOF.py:214-221; BASELINE config 5's composition):
             # Env.step and computeControl on the run kernels, rows / command / errors in the caller's numbering straight from

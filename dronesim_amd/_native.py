@@ -36,6 +36,7 @@ TUNING_MASK = OPT_STREAM_ON | OPT_STREAM_OFF | VAR_GENERIC | VAR_MIXED_V1 | VAR_
 OPT_PLANE = 1 << 10        # ground-plane contact (product-defined model, oracle/dsim_oracle.c:orc_plane_contact)
 OPT_DEFER_FALLBACK = 1 << 11   # the caller launches dsim_wls_fallback itself (scheduling only)
 OPT_CALLER_IO = 1 << 14    # dsim_physics / dsim_control2: action, rows, command, errors indexed by drone_id[i] (the caller's numbering)
+OPT_ACTION_ROWS = 1 << 15  # dsim_step_adaptor: the action row-major [n][4]
 ADAPT_VELOCITY, ADAPT_RPYT = 0, 1
 QUERY_WLS_FALLBACKS, QUERY_WLS_FAILURES, QUERY_GROUND_CONTACTS, QUERY_HALO_OVERFLOW = 0, 1, 2, 3
 

@@ -867,15 +867,31 @@ class _AdaptorAviary(CtrlAviary):
     def step(self, action):
         self.materialize()
         self._chain_ok = False
-        self._load_action(action)
         args = self.step_args(self.AGGR_PHY_STEPS * self.TIMESTEP)
+        # A homogeneous fleet in whole tiles steps in ONE launch that takes the action as the caller holds it ([N, 4] rows
+        # on the device: no transpose) and writes Env.step's observation rows itself (k_adaptor_fast).
+        one_launch = (not self.dict_io and self.order is None and len(self.types) == 1 and self.state.n_pad % 256 == 0
+                      and not self.ground_plane and self._type_id is None)
+        rows_in = (one_launch and isinstance(action, torch.Tensor) and action.dtype == torch.float32 and action.is_contiguous()
+                   and action.device == self.ctx.device and tuple(action.shape) == (self.NUM_DRONES, 4)
+                   and action.data_ptr() % 16 == 0)
+        if rows_in:
+            args.options |= nat.OPT_ACTION_ROWS
+            act_ptr = action.data_ptr()
+        else:
+            self._load_action(action)
+            act_ptr = self._action_buf.data_ptr()
+        obs = None
+        if one_launch:
+            obs = self._obs_tensor()
+            args.obs_out, args.obs_width = obs.data_ptr(), 20
         nat.check(self.ctx.lib.dsim_step_adaptor(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
-                                                 self.state.view(), self._action_buf.data_ptr(), self._MODE,
+                                                 self.state.view(), act_ptr, self._MODE,
                                                  self._last_action.data_ptr(), ctypes.byref(args)))
         self._use_last_action = True
         self.step_counter += self.AGGR_PHY_STEPS
         self._env_steps += 1
-        return self._computeObs(), self._computeReward(), self._computeDone(), self._computeInfo()
+        return self._computeObs(obs), self._computeReward(), self._computeDone(), self._computeInfo()
 
 
 class VelocityAviary(_AdaptorAviary):

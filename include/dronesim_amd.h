@@ -170,6 +170,10 @@ enum {
    * drone_id and a fleet that the run kernels serve (runs given or one type; no noise replay, no drag / ground / plane
    * option): DSIM_E_UNSUPPORTED otherwise.                                                                            */
   DSIM_OPT_CALLER_IO   = 1u << 14,
+  /* dsim_step_adaptor: `action` is row-major [n][4] — one 4-vector per drone, as VelocityAviary / RPYTAviary take it
+   * (VelocityAviary.py:221-264, RPYTAviary.py:181-193) — instead of field-major [4][n_pad]; 16-byte aligned.  Served by the
+   * one-launch form (homogeneous quad fleet in whole tiles, no DSIM_OPT_PLANE): DSIM_E_UNSUPPORTED otherwise.            */
+  DSIM_OPT_ACTION_ROWS = 1u << 15,
   /* -- scheduling (results do not depend on it) ---------------------------------------------------------------------- */
   DSIM_OPT_DEFER_FALLBACK = 1u << 11 /* dsim_step / dsim_control2 of a table with a morphing hexa do NOT launch the deferred
                                        WLS fallback pass behind the step; the caller launches dsim_wls_fallback itself —
@@ -311,7 +315,10 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state,
  *   DSIM_ADAPT_RPYT      RPYTAviary._preprocessAction (RPYTAviary.py:181-193): action = (p, q, r
  *       body-rate set-points, thrust) fed to _INDIRateControl only
  * dt_ctrl of args is the control_timestep (AGGR_PHY_STEPS * TIMESTEP).  Quad types only.
- * last_action_out (nullable, SoA [4][n_pad]) receives the applied command (last_clipped_action). */
+ * last_action_out (nullable, SoA [4][n_pad]) receives the applied command (last_clipped_action).
+ * args->obs_out (nullable, [n][20], obs_width = 20): Env.step's return value, the rows of _computeObs for the NEW state
+ * (BaseAviary.py:547-555, 780-790) — written by the same launch for a homogeneous fleet in whole tiles (which also takes the
+ * action row-major, DSIM_OPT_ACTION_ROWS), by the observation kernel behind the step otherwise. */
 enum { DSIM_ADAPT_VELOCITY = 0, DSIM_ADAPT_RPYT = 1 };
 int dsim_step_adaptor(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* action,
                       int32_t mode, float* last_action_out, const dsim_step_args* args);

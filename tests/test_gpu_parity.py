@@ -17,7 +17,7 @@ torch = pytest.importorskip("torch")
 
 from dronesim_amd import params  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
-from tests.util import (K_ULP, MEM_SCALE, RIGID_SCALE, assert_control_parity, assert_downwash, assert_step_parity,  # noqa: E402
+from tests.util import (K_ULP, noise_terms, MEM_SCALE, RIGID_SCALE, assert_control_parity, assert_downwash, assert_step_parity,  # noqa: E402
                         attitude_zoo, f32, random_fleet, rel_err, ulp32)
 
 pytestmark = pytest.mark.gpu
@@ -1534,16 +1534,23 @@ def test_env_and_controller_surfaces(gpu):
     env.close()
 
 
+@pytest.mark.parametrize("form", ["host action", "device rows", "device rows, streaming", "soa layout, noise"])
 @pytest.mark.parametrize("mode", ["velocity", "rpyt"])
-def test_action_adaptor_envs_vs_oracle(gpu, mode):
-    """VelocityAviary / RPYTAviary: control inside step() on the current state, then the physics."""
+def test_action_adaptor_envs_vs_oracle(gpu, mode, form):
+    """VelocityAviary / RPYTAviary: control inside step() on the current state, then the physics — ONE launch
+    (k_adaptor_fast) for a homogeneous fleet: the action field-major (a host array goes through the env's buffer) or as
+    the [N, 4] device tensor the caller holds (DSIM_OPT_ACTION_ROWS), Env.step's observation rows written by the same
+    launch; default and streaming cache policy, both layouts, noise on and off."""
     from dronesim_amd.envs import RPYTAviary, VelocityAviary
+    nat = gpu[0]
     n = 700
     rng = np.random.default_rng(71)
     xyz = np.stack([rng.uniform(-5, 5, n), rng.uniform(-5, 5, n), rng.uniform(1, 5, n)], 1)
     rpy = np.stack([rng.uniform(-0.2, 0.2, n), rng.uniform(-0.2, 0.2, n), rng.uniform(-3, 3, n)], 1)
     cls = VelocityAviary if mode == "velocity" else RPYTAviary
-    env = cls(["robobee"], n, initial_xyzs=xyz, initial_rpys=rpy, aggregate_phy_steps=5, noise_seed=0, dict_io=False)
+    seed = 9 if "noise" in form else 0
+    env = cls(["robobee"], n, initial_xyzs=xyz, initial_rpys=rpy, aggregate_phy_steps=5, noise_seed=seed, dict_io=False,
+              layout="soa" if "soa" in form else "tile64", options=nat.OPT_STREAM_ON if "streaming" in form else nat.OPT_STREAM_OFF)
     t = params.builtin_type("robobee")
     O = orc.Oracle([t])
     dtc = float(np.float32(5 * (1.0 / 240)))
@@ -1555,7 +1562,8 @@ def test_action_adaptor_envs_vs_oracle(gpu, mode):
             act = np.concatenate([rng.uniform(-0.5, 0.5, (n, 3)), rng.uniform(0.3, 0.6, (n, 1))], 1)
         act = f32(act)
         r0, m0 = env.state.rigid_aos(), env.state.mem_aos()    # every step from the device's previous state
-        obs, reward, done, info = env.step(torch.from_numpy(act.astype(np.float32)))
+        a_t = torch.from_numpy(act.astype(np.float32))
+        obs, reward, done, info = env.step(a_t.to(env.ctx.device) if "device" in form or k % 2 else a_t)
         got_r, got_m = env.state.rigid_aos(), env.state.mem_aos()
         # (a) the law inside _preprocessAction, on the state BEFORE the physics: the oracle's adaptor step with no
         # sub-steps is exactly that control call
@@ -1569,10 +1577,11 @@ def test_action_adaptor_envs_vs_oracle(gpu, mode):
         # (b) the physics with the command the DEVICE computed (its fp32 rounding is judged in (a), not again here)
         rigid = r0.copy()
         a6 = np.zeros((n, 6)); a6[:, :4] = got_m[:, 7:11]
-        O.physics(rigid, got_m.copy(), 5, DT, action=a6)
+        O.physics(rigid, got_m.copy(), 5, DT, action=a6, noise=_noise_block(O, [t], None, n, seed, k, 5) if seed else None)
         assert_step_parity(f"adaptor_env[{mode}] physics", [t], None, r0, got_m, tgt, got_r, None, rigid, None, DT, dtc, 5,
-                           control=False, action=got_m[:, 7:11])
-        np.testing.assert_array_equal(obs[:, 16:20].cpu().numpy(), env.state.mem_aos()[:, 7:11].astype(np.float32))  # echoed command
+                           control=False, action=got_m[:, 7:11], extra_terms=noise_terms([t], None, n, DT, 5) if seed else None)
+        # Env.step's return value: the rows of the NEW state with the applied command echoed, every column
+        _check_obs_rows(f"adaptor_env[{mode}] rows", O, obs.double().cpu().numpy(), f32(got_r), a6, None, [t])
     env.close()
 
 

@@ -553,3 +553,78 @@ def test_placement_of_rows_on_hexa_and_reordered_fleets_changes_nothing(gpu, kin
     for x, y in zip(res[0][:5], res[1][:5]):
         assert torch.equal(x, y)
     assert res[0][5] == res[1][5]
+
+
+@pytest.mark.parametrize("mode", ["velocity", "rpyt"])
+def test_every_instance_of_the_one_launch_adaptor_step(gpu, mode):
+    """k_adaptor_fast<MODE, NOISE, NT, OBS, AROWS> through dsim_step_adaptor: the action field-major or row-major
+    (DSIM_OPT_ACTION_ROWS), the observation rows of the NEW state fused or not, noise, both cache policies — control part
+    and physics part each against the oracle (VelocityAviary.py:221-264, RPYTAviary.py:181-193), rows against
+    orc_state_vector; a ragged fleet inside whole tiles."""
+    from tests.test_gpu_parity import _noise_block
+    from tests.util import noise_terms
+    nat, fleet = gpu
+    t = params.builtin_type("robobee")
+    O = orc.Oracle([t])
+    ctx = fleet.Context([t])
+    n, sub = 700, 2
+    dtc = float(np.float32(sub / 240))
+    m_id = nat.ADAPT_VELOCITY if mode == "velocity" else nat.ADAPT_RPYT
+    rng = np.random.default_rng(5)
+    for seed in (0, 3):
+        for pol in (nat.OPT_STREAM_ON, nat.OPT_STREAM_OFF):
+            for with_obs in (True, False):
+                for arows in (True, False):
+                    rigid, mem, _ = random_fleet(rng, n, n_act=4, tilt=0.3, rate=1.0)
+                    rigid, mem = f32(rigid), f32(mem)
+                    st = fleet.FleetState(ctx, n, "tile64")
+                    assert st.n_pad % 256 == 0
+                    st.load_aos(rigid, mem)
+                    if mode == "velocity":
+                        act = np.concatenate([rng.uniform(-1, 1, (n, 3)), rng.uniform(0, 0.3, (n, 1))], 1)
+                        act[0, 0:3] = 0.0
+                    else:
+                        act = np.concatenate([rng.uniform(-0.5, 0.5, (n, 3)), rng.uniform(0.3, 0.6, (n, 1))], 1)
+                    act = f32(act)
+                    if arows:
+                        adev = torch.from_numpy(act.astype(np.float32)).to(ctx.device).contiguous()
+                    else:
+                        adev = torch.zeros((4, st.n_pad), device=ctx.device)
+                        adev[:, :n] = torch.from_numpy(np.ascontiguousarray(act.T)).float()
+                    echo = torch.zeros((4, st.n_pad), device=ctx.device)
+                    obs = torch.full((n, 20), -7.0, device=ctx.device)
+                    a = _args(nat, sub, DT, dtc, options=pol | (nat.OPT_ACTION_ROWS if arows else 0), seed=seed, step_index=4)
+                    if with_obs:
+                        a.obs_out, a.obs_width = obs.data_ptr(), 20
+                    nat.check(ctx.lib.dsim_step_adaptor(ctx.handle, _stream(ctx), n, st.view(), adev.data_ptr(), m_id,
+                                                        echo.data_ptr(), ctypes.byref(a)))
+                    torch.cuda.synchronize()
+                    got_r, got_m = st.rigid_aos(), st.mem_aos()
+                    label = f"adaptor_fast[{mode},{seed},{pol},{with_obs},{arows}]"
+                    rc0, m_ref = rigid.copy(), mem.copy()
+                    assert O.adaptor_step(0 if mode == "velocity" else 1, rc0, m_ref, act, 0, DT, dtc) == 0
+                    tgt = np.concatenate([rigid[:, 0:3], np.zeros((n, 7))], 1)
+                    if mode == "velocity":
+                        nrm = np.linalg.norm(act[:, 0:3], axis=1, keepdims=True)
+                        tgt[:, 3:6] = t.max_speed_kmh / 3.6 * np.abs(act[:, 3:4]) * np.divide(act[:, 0:3], nrm, out=np.zeros((n, 3)),
+                                                                                              where=nrm > 0)
+                    assert_control_parity(label + " control", [t], None, rigid, mem, tgt, got_m, m_ref, dtc)
+                    r_ref = rigid.copy()
+                    a6 = np.zeros((n, 6)); a6[:, :4] = got_m[:, 7:11]
+                    O.physics(r_ref, got_m.copy(), sub, DT, action=a6, noise=_noise_block(O, [t], None, n, seed, 4, sub) if seed else None)
+                    assert_step_parity(label + " physics", [t], None, rigid, got_m, tgt, got_r, None, r_ref, None, DT, dtc, sub,
+                                       control=False, action=got_m[:, 7:11], extra_terms=noise_terms([t], None, n, DT, sub) if seed else None)
+                    np.testing.assert_array_equal(echo[:, :n].T.cpu().numpy(), got_m[:, 7:11].astype(np.float32))
+                    if with_obs:
+                        _check_obs_rows(label + " rows", O, obs.double().cpu().numpy(), f32(got_r), a6, None, [t])
+                    else:
+                        assert float(obs.min()) == -7.0 and float(obs.max()) == -7.0
+    # the general kernels take the action field-major only
+    t2 = params.builtin_type("tello")
+    ctx2 = fleet.Context([t, t2])
+    st2 = fleet.FleetState(ctx2, 512, "tile64")
+    tid = torch.zeros(st2.n_pad, dtype=torch.uint8, device=ctx2.device)
+    a = _args(nat, 1, DT, DT, options=nat.OPT_ACTION_ROWS, type_id=tid)
+    adev = torch.zeros((512, 4), device=ctx2.device)
+    assert ctx2.lib.dsim_step_adaptor(ctx2.handle, _stream(ctx2), 512, st2.view(), adev.data_ptr(), m_id, None, ctypes.byref(a)) == -5     # DSIM_E_UNSUPPORTED
+    ctx.close(); ctx2.close()
