@@ -147,7 +147,9 @@ def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int
             times.append((timer or _event_timer)(trial, c, passes))
             if clearly > 0.0 and times[-1] < clearly * times[0]:
                 chosen, decided = len(times) - 1, "a candidate clearly faster than the first"
-            elif stride_bytes > 0 and held + stride_bytes + nbytes <= budget:
+            elif stride_bytes > 0:
+                if held + stride_bytes + nbytes > budget:       # no room for another stride and a candidate behind it
+                    break
                 try:
                     blocks.append(_DriverBlock(ctx, (stride_bytes // 4,)) if ctx is not None else
                                   torch.empty((stride_bytes // 4,), dtype=torch.float32, device=device))

@@ -78,3 +78,23 @@ def test_walk_is_bounded_by_the_free_memory_and_falls_back_to_a_plain_allocation
     log = []
     out = placement.place_rows("cpu", (1024, 20), lambda c: None, report=log, timer=lambda t, c, p: 100.0, ctx=Ctx())
     assert log[0]["candidates"] == 0 and out.shape == (1024, 20) and float(out.abs().max()) == 0.0      # the very first one refused
+
+
+def test_a_striding_walk_covers_the_budget_with_fewer_candidates():
+    """Round 4: `stride_bytes` of untimed ballast behind every candidate (held, inside the budget): the walk leaves the
+    neighbourhood of its first candidates — the 16 GiB region of the state block — with a handful of timed candidates.  The
+    ballast counts in `peak_bytes`, never exceeds the budget, and a clearly faster candidate still ends the walk at once."""
+    nbytes = 4 * 1024 * 20
+    stride = 3 * nbytes
+    log = []
+    placement.place_rows("cpu", (1024, 20), lambda c: None, report=log, timer=lambda t, c, p: 100.0,
+                         free_bytes=int(10.5 * nbytes / placement.WALK_FRACTION), stride_bytes=stride)
+    # budget 10.5 candidates' worth: candidate (1) + ballast (3) + candidate + ballast + candidate = 9; a third ballast + candidate would be 13
+    assert log[0]["candidates"] == 3 and log[0]["peak_bytes"] == 3 * nbytes + 2 * stride <= log[0]["budget_bytes"]
+    assert log[0]["stride_bytes"] == stride
+    log = []
+    times = iter([160.0, 161.0, 143.0, 150.0])
+    placement.place_rows("cpu", (1024, 20), lambda c: None, report=log, timer=lambda t, c, p: next(times),
+                         free_bytes=int(100 * nbytes / placement.WALK_FRACTION), stride_bytes=stride)
+    assert log[0]["candidates"] == 3 and log[0]["chosen"] == 2 and log[0]["decided_by"].startswith("a candidate clearly faster")
+    assert log[0]["peak_bytes"] == 3 * nbytes + 2 * stride
