@@ -127,6 +127,16 @@ __device__ __forceinline__ void bin_entry(const BinK& b, float x, float y, float
   else b.overflow[atomicAdd(&b.count[b.nx * b.ny], 1)] = e;
 }
 
+// The same in two halves: the slot reservation is a device-scope atomic whose answer takes a memory round trip (1-2 us on a
+// shard-sized launch with one wave per SIMD); issued as soon as the new position is final, it travels while the control law
+// runs, and the entry is stored behind it.
+__device__ __forceinline__ int bin_reserve(const BinK& b, float x, float y) { return atomicAdd(&b.count[bin_cell(b, x, y)], 1); }
+__device__ __forceinline__ void bin_store(const BinK& b, int slot, float x, float y, float z, long long world_index) {
+  const float4 e = make_float4(x, y, z, __int_as_float((int)world_index));
+  if (slot < DW_CAP) b.buckets[(long long)bin_cell(b, x, y) * DW_CAP + slot] = e;
+  else b.overflow[atomicAdd(&b.count[b.nx * b.ny], 1)] = e;
+}
+
 // bucket form: grids of up to 65 536 cells with at most 5/8 DW_CAP = 40 entries per cell on average (BASELINE config 5:
 // one drone per m^2 = 25 per 5 m cell); the buckets take ncells * DW_CAP * 16 bytes of the workspace (67 MB at most)
 static inline bool dw_use_buckets(int64_t m, int64_t ncells) { return ncells <= 65536 && m <= ncells * (DW_CAP * 5 / 8); }
@@ -983,19 +993,23 @@ __device__ __forceinline__ void run_body(const StepK& a, long long i0, long long
   float act[NA];
 #pragma unroll
   for (int j = 0; j < NA; ++j) act[j] = ACT ? clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]) : m.cmd[j];   // CtrlAviary.py:258-263
+  const bool bin = a.bin.count && i < a.n;                   // the next step's grid: slot reserved here, entry stored below
+  int slot = 0;
   if constexpr (HEXA) {
     hexa_substeps<NOISE, false, S1>(T, a, i, s, act, step_index, ext, nid);
+    if (bin) slot = bin_reserve(a.bin, s.pos.x, s.pos.y);
     if constexpr (KIND == DSIM_DEV_KIND_HEXA) indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
     else indi_quad<false, 6>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   } else {
     quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, act, step_index, ext, nullptr, nid);
+    if (bin) slot = bin_reserve(a.bin, s.pos.x, s.pos.y);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   const unsigned so = pin_lane_offset(sl);
   store_rigid<NT>(sb, sfs, so, s);
   store_mem<NA, NT>(sb, sfs, so, m);
   ground_watch(T, s, a.fb.counters, i < a.n);
-  if (a.bin.count && i < a.n) bin_entry(a.bin, s.pos.x, s.pos.y, s.pos.z, a.bin.local_offset + i);   // next step's grid
+  if (bin) bin_store(a.bin, slot, s.pos.x, s.pos.y, s.pos.z, a.bin.local_offset + i);
 }
 template <int KIND, bool NOISE, bool NT, bool S1>
 __global__ __launch_bounds__(256, KIND ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void k_step_run(StepK a) {
@@ -1180,7 +1194,7 @@ __device__ __forceinline__ void obs_rows20_out(vf4* rows, const StepK& a, long l
     }
   }
 }
-template <bool NOISE, bool NT, bool OBS>
+template <bool NOISE, bool NT, bool OBS, bool AROWS>      // AROWS: the action row-major [n][4] (DSIM_OPT_ACTION_ROWS), one 16-byte load per lane
 __global__ __launch_bounds__(256, DSIM_PHYS_WAVES) void k_physics_fast(StepK a) {
   constexpr int W = 20;
   // Observation rows: each wave owns 64 consecutive rows = 5 120 contiguous bytes of the row-major [n][20] output.  Lane r
@@ -1198,11 +1212,20 @@ __global__ __launch_bounds__(256, DSIM_PHYS_WAVES) void k_physics_fast(StepK a) 
   Rigid s;
   load_rigid<NT>(sb, sfs, sl, s);
   float cmd[4];
+  if (AROWS) {
+    vf4 r = vf4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (i < a.n) {                                                       // (rows exist for real drones only)
+      const vf4* ar = reinterpret_cast<const vf4*>(a.action) + i0;
+      r = NT ? __builtin_nontemporal_load(ar + threadIdx.x) : ar[threadIdx.x];
+    }
+    cmd[0] = r.x; cmd[1] = r.y; cmd[2] = r.z; cmd[3] = r.w;
+  } else {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float raw = a.action ? ldg<NT>(a.action + (long long)j * a.n_pad + i0, 4u * threadIdx.x) : ldg<NT>(sb + (20 + j) * sfs, sl);
-    cmd[j] = clampf(raw, T.pmin[j], T.pmax[j]);                                       // CtrlAviary.py:258-263
+    for (int j = 0; j < 4; ++j)
+      cmd[j] = a.action ? ldg<NT>(a.action + (long long)j * a.n_pad + i0, 4u * threadIdx.x) : ldg<NT>(sb + (20 + j) * sfs, sl);
   }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cmd[j] = clampf(cmd[j], T.pmin[j], T.pmax[j]);           // CtrlAviary.py:258-263
   if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
   quad_substeps<NOISE ? 1 : 0>(T, a, i, s, cmd, a.step_index);
   ground_watch(T, s, a.fb.counters, i < a.n);
@@ -3314,6 +3337,8 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
   const bool noise = args->noise_seed != 0 || args->noise_replay != nullptr;
   const hipStream_t st_ = (hipStream_t)stream;
   if ((args->options & DSIM_OPT_CALLER_IO) && !args->drone_id) return DSIM_E_ARG;
+  const bool arows = (args->options & DSIM_OPT_ACTION_ROWS) != 0;
+  if (arows && (!args->action || ((uintptr_t)args->action & 15u))) return DSIM_E_ARG;
   if (args->type_id == nullptr && ctx->max_act == 4 && !args->noise_replay && !args->ext_force && !phys_opts &&
       (a.n_pad % 256) == 0 && !args->bin_next && !args->drone_id && !(args->options & DSIM_OPT_CALLER_IO)) {
     // homogeneous quad fleet in whole tiles: the fast form, observation fused (16-byte stores: any torch allocation is
@@ -3322,14 +3347,17 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
     a.obs_out = obs_fused ? args->obs_out : nullptr;
     const bool nt = stream_policy(args, state.n_pad, args->obs_out ? 216.0 : 136.0);
     const dim3 g((unsigned)(a.n_pad / 256)), b(256);
-#define DSIM_PHYS_CASE(N_, T_) do { if (a.obs_out) hipLaunchKernelGGL((k_physics_fast<N_, T_, true>), g, b, 0, st_, a);   \
-                                    else hipLaunchKernelGGL((k_physics_fast<N_, T_, false>), g, b, 0, st_, a); } while (0)
+#define DSIM_PHYS_CASE2(N_, T_, O_) do { if (arows) hipLaunchKernelGGL((k_physics_fast<N_, T_, O_, true>), g, b, 0, st_, a);   \
+                                         else hipLaunchKernelGGL((k_physics_fast<N_, T_, O_, false>), g, b, 0, st_, a); } while (0)
+#define DSIM_PHYS_CASE(N_, T_) do { if (a.obs_out) DSIM_PHYS_CASE2(N_, T_, true); else DSIM_PHYS_CASE2(N_, T_, false); } while (0)
     if (noise) { if (nt) DSIM_PHYS_CASE(true, true); else DSIM_PHYS_CASE(true, false); }
     else { if (nt) DSIM_PHYS_CASE(false, true); else DSIM_PHYS_CASE(false, false); }
 #undef DSIM_PHYS_CASE
+#undef DSIM_PHYS_CASE2
     if (args->obs_out && !obs_fused) return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, obs_w, 0);
     return (int)hipGetLastError();
   }
+  if (arows) return DSIM_E_UNSUPPORTED;               // (every other kernel takes the action field-major)
   // Every other fleet kind on the fast form: runs of one type (dsim_step_args.runs), or a homogeneous fleet as ONE run —
   // morphing hexas, type-major quad + hexa fleets, fleets with the downwash force, ragged tails.  The observation rows are
   // written by the same launch; the new positions may fill the next neighbour grid (bin_next).

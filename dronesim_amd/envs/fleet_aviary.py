@@ -364,7 +364,17 @@ class CtrlAviary:
                 self._substep_args(args, s_)
             if self._caller_io:
                 args.options |= nat.OPT_CALLER_IO
-            args.action = self._action_ptr(action, self._caller_io) if s_ == 0 else self._action_ptr_last
+            if s_ == 0:
+                # a homogeneous quad fleet on the fast kernel takes an [N, 4] device tensor as the caller holds it (no transpose)
+                self._rows_in = (self.n_act == 4 and self._type_id is None and self._downwash is None and self._phys_options == 0
+                                 and self.order is None and self.state.n_pad % 256 == 0 and torch.is_tensor(action)
+                                 and action.dtype == torch.float32 and action.is_contiguous() and action.device == self.ctx.device
+                                 and tuple(action.shape) == (self.NUM_DRONES, 4) and action.data_ptr() % 16 == 0
+                                 and not (getattr(self, "_cmd_token", None) is not None and action is self._cmd_token[0]))
+            if self._rows_in:
+                args.options |= nat.OPT_ACTION_ROWS
+                self._action_keep = action
+            args.action = (action.data_ptr() if self._rows_in else self._action_ptr(action, self._caller_io)) if s_ == 0 else self._action_ptr_last
             self._action_ptr_last = args.action
             if self._downwash is not None:
                 # the physics launch fills the next neighbour grid from the new positions (the library keeps its own

@@ -170,9 +170,10 @@ enum {
    * drone_id and a fleet that the run kernels serve (runs given or one type; no noise replay, no drag / ground / plane
    * option): DSIM_E_UNSUPPORTED otherwise.                                                                            */
   DSIM_OPT_CALLER_IO   = 1u << 14,
-  /* dsim_step_adaptor: `action` is row-major [n][4] — one 4-vector per drone, as VelocityAviary / RPYTAviary take it
-   * (VelocityAviary.py:221-264, RPYTAviary.py:181-193) — instead of field-major [4][n_pad]; 16-byte aligned.  Served by the
-   * one-launch form (homogeneous quad fleet in whole tiles, no DSIM_OPT_PLANE): DSIM_E_UNSUPPORTED otherwise.            */
+  /* dsim_physics / dsim_step_adaptor: `action` is row-major [n][4] — one 4-vector per drone, as Env.step is handed it
+   * (CtrlAviary.py:258-263, VelocityAviary.py:221-264, RPYTAviary.py:181-193) — instead of field-major [4][n_pad]; 16-byte
+   * aligned.  Served by the one-launch forms (homogeneous quad fleet in whole tiles, no physics option, no downwash inputs):
+   * DSIM_E_UNSUPPORTED otherwise.                                                                                        */
   DSIM_OPT_ACTION_ROWS = 1u << 15,
   /* -- scheduling (results do not depend on it) ---------------------------------------------------------------------- */
   DSIM_OPT_DEFER_FALLBACK = 1u << 11 /* dsim_step / dsim_control2 of a table with a morphing hexa do NOT launch the deferred

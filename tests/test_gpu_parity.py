@@ -2791,10 +2791,15 @@ def test_every_instance_of_the_two_call_adaptor_and_general_kernels(gpu, seed):
     n = 512
     act = f32(np.random.default_rng(9).uniform(0.3, 0.7, (n, 4)))
 
-    # ---- k_physics_fast<NOISE, NT, OBS> and k_control_fast<NT, WANT_YAW> (homogeneous quads, whole tiles)
-    for with_obs in (False, True):
+    # ---- k_physics_fast<NOISE, NT, OBS, AROWS> and k_control_fast<NT, WANT_YAW> (homogeneous quads, whole tiles); AROWS: the
+    # action as the [N, 4] array Env.step is handed (DSIM_OPT_ACTION_ROWS)
+    for with_obs, arows in ((False, False), (True, False), (False, True), (True, True)):
         def phys(ctx, st, tg, tdev, pol):
-            adev = torch.zeros((4, st.n_pad), device=ctx.device); adev[:, :n] = torch.from_numpy(np.ascontiguousarray(act.T)).float()
+            if arows:
+                adev = torch.from_numpy(act.astype(np.float32)).to(ctx.device).contiguous()
+                pol = pol | nat.OPT_ACTION_ROWS
+            else:
+                adev = torch.zeros((4, st.n_pad), device=ctx.device); adev[:, :n] = torch.from_numpy(np.ascontiguousarray(act.T)).float()
             echo = torch.zeros((4, st.n_pad), device=ctx.device)
             obs = torch.zeros((n, 20), device=ctx.device)
             a = _args(nat, 2, DT, dtc, options=pol, seed=seed, step_index=1, action=adev)
@@ -2806,7 +2811,7 @@ def test_every_instance_of_the_two_call_adaptor_and_general_kernels(gpu, seed):
         r = rigid.copy()
         a6 = np.zeros((n, 6)); a6[:, :4] = act
         O1.physics(r, mem, 2, DT, action=a6, noise=_noise_block(O1, [rb], None, n, seed, 1, 2) if seed else None)
-        assert_step_parity(f"sweep physics_fast[{with_obs},{seed}]", [rb], None, rigid, mem, tgt, gr, None, r, None, DT, dtc, 2,
+        assert_step_parity(f"sweep physics_fast[{with_obs},{arows},{seed}]", [rb], None, rigid, mem, tgt, gr, None, r, None, DT, dtc, 2,
                            control=False, action=act)
         np.testing.assert_array_equal(ge[:, :n].T, act)
         if with_obs:

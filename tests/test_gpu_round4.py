@@ -628,3 +628,29 @@ def test_every_instance_of_the_one_launch_adaptor_step(gpu, mode):
     adev = torch.zeros((512, 4), device=ctx2.device)
     assert ctx2.lib.dsim_step_adaptor(ctx2.handle, _stream(ctx2), 512, st2.view(), adev.data_ptr(), m_id, None, ctypes.byref(a)) == -5     # DSIM_E_UNSUPPORTED
     ctx.close(); ctx2.close()
+
+
+def test_env_step_takes_the_action_rows_as_the_caller_holds_them(gpu):
+    """CtrlAviary.step(action): an [N, 4] float32 device tensor goes to the launch as it is (DSIM_OPT_ACTION_ROWS,
+    k_physics_fast<.., AROWS>), anything else through the env's field-major buffer — same state, same rows, bit for bit;
+    the caller's tensor is not touched."""
+    from dronesim_amd.envs import CtrlAviary
+    n = 1024
+    rng = np.random.default_rng(3)
+    xyz = np.stack([rng.uniform(-5, 5, n), rng.uniform(-5, 5, n), rng.uniform(1, 5, n)], 1)
+    envs = [CtrlAviary(["robobee"], n, initial_xyzs=xyz, aggregate_phy_steps=2, noise_seed=5, dict_io=False, layout="tile64")
+            for _ in range(2)]
+    for k in range(4):
+        act = rng.uniform(0.2, 0.8, (n, 4)).astype(np.float32)
+        act[0] = [-1.0, 2.0, 0.5, 0.5]                        # clipped inside (CtrlAviary.py:258-263)
+        dev = torch.from_numpy(act).to(envs[0].ctx.device)
+        keep = dev.clone()
+        o0 = envs[0].step(dev)[0]
+        assert envs[0]._rows_in
+        o1 = envs[1].step(act)[0]
+        assert not envs[1]._rows_in
+        assert torch.equal(o0, o1) and torch.equal(dev, keep)
+        np.testing.assert_array_equal(envs[0].state.rigid_aos(), envs[1].state.rigid_aos())
+        np.testing.assert_array_equal(o0[:, 16:20].cpu().numpy(), np.clip(act, 0.0, 1.0))
+    for e in envs:
+        e.close()
