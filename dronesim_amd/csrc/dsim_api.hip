@@ -155,6 +155,7 @@ struct StepK {
   const uint8_t* type_id;
   const float* noise_replay;
   const float* action;        // SoA [n_act][n_pad] or null (= stored cmd)
+  int action_rows;            // DSIM_OPT_ACTION_ROWS: action is row-major [n][4] (the one-launch quad kernels only)
   float* echo;                // physics kernel: clipped action out, or null
   float* pos_e_out;           // control kernel only
   float* yaw_e_out;
@@ -1194,7 +1195,7 @@ __device__ __forceinline__ void obs_rows20_out(vf4* rows, const StepK& a, long l
     }
   }
 }
-template <bool NOISE, bool NT, bool OBS, bool AROWS>      // AROWS: the action row-major [n][4] (DSIM_OPT_ACTION_ROWS), one 16-byte load per lane
+template <bool NOISE, bool NT, bool OBS>
 __global__ __launch_bounds__(256, DSIM_PHYS_WAVES) void k_physics_fast(StepK a) {
   constexpr int W = 20;
   // Observation rows: each wave owns 64 consecutive rows = 5 120 contiguous bytes of the row-major [n][20] output.  Lane r
@@ -1212,7 +1213,7 @@ __global__ __launch_bounds__(256, DSIM_PHYS_WAVES) void k_physics_fast(StepK a) 
   Rigid s;
   load_rigid<NT>(sb, sfs, sl, s);
   float cmd[4];
-  if (AROWS) {
+  if (a.action_rows) {                // (wave-uniform) the action row-major [n][4] (DSIM_OPT_ACTION_ROWS): one 16-byte load per lane
     vf4 r = vf4{0.0f, 0.0f, 0.0f, 0.0f};
     if (i < a.n) {                                                       // (rows exist for real drones only)
       const vf4* ar = reinterpret_cast<const vf4*>(a.action) + i0;
@@ -1666,9 +1667,9 @@ __global__ __launch_bounds__(256, PLANE ? 1 : DSIM_GEN_WAVES) void k_adaptor(Ste
 // one 16-byte load per lane — and the 20-wide rows of the NEW state written by the same launch (OBS).  Before: a transpose of
 // the action (torch, 50 us), k_adaptor (147-160 us) and k_observe (125 us) per Env.step of 4 194 304 drones.
 //   reads 24 state + 4 action floats, writes 24 state + 4 echoed command + 20 row floats: 304 bytes per drone-step
-template <int MODE, bool NOISE, bool NT, bool OBS, bool AROWS>
+template <int MODE, bool NOISE, bool NT>
 __global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_adaptor_fast(StepK a) {
-  __shared__ __attribute__((aligned(16))) vf4 rows[OBS ? 4 * 64 * 5 : 1];
+  __shared__ __attribute__((aligned(16))) vf4 rows[4 * 64 * 5];
   const DevType& T = a.types[0];
   const long long sfs = a.st.field_stride;
   const unsigned sl = 4u * kv_lane(a.st, threadIdx.x);
@@ -1680,7 +1681,7 @@ __global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_adaptor_fast(StepK a) 
   load_rigid<NT>(sb, sfs, sl, s);
   load_mem<4, NT>(sb, sfs, sl, m);
   float v[4];
-  if (AROWS) {
+  if (a.action_rows) {                                                   // (wave-uniform)
     vf4 r = vf4{0.0f, 0.0f, 0.0f, 0.0f};
     if (i < a.n) {                                                       // (rows exist for real drones only)
       const vf4* ar = reinterpret_cast<const vf4*>(a.action) + i0;
@@ -1715,7 +1716,7 @@ __global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_adaptor_fast(StepK a) 
 #pragma unroll
     for (int j = 0; j < 4; ++j) stg<NT>(a.echo + (long long)j * a.n_pad + i0, 4u * threadIdx.x, m.cmd[j]);
   }
-  if (OBS) obs_rows20_out<NT>(rows, a, i0, s, m.cmd);
+  if (a.obs_out) obs_rows20_out<NT>(rows, a, i0, s, m.cmd);
 }
 
 // ---- deferred WLS fallbacks (hexa) -----------------------------------------------
@@ -2905,6 +2906,7 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
   a->lo = 0; a->last = a->n_pad; a->run_type = 0;
   a->drone_id = args->drone_id;
   a->io_id = (args->options & DSIM_OPT_CALLER_IO) ? args->drone_id : nullptr;
+  a->action_rows = (args->options & DSIM_OPT_ACTION_ROWS) ? 1 : 0;     // (honoured by the entry points that check it)
   return DSIM_OK;
 }
 
@@ -3347,13 +3349,11 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
     a.obs_out = obs_fused ? args->obs_out : nullptr;
     const bool nt = stream_policy(args, state.n_pad, args->obs_out ? 216.0 : 136.0);
     const dim3 g((unsigned)(a.n_pad / 256)), b(256);
-#define DSIM_PHYS_CASE2(N_, T_, O_) do { if (arows) hipLaunchKernelGGL((k_physics_fast<N_, T_, O_, true>), g, b, 0, st_, a);   \
-                                         else hipLaunchKernelGGL((k_physics_fast<N_, T_, O_, false>), g, b, 0, st_, a); } while (0)
-#define DSIM_PHYS_CASE(N_, T_) do { if (a.obs_out) DSIM_PHYS_CASE2(N_, T_, true); else DSIM_PHYS_CASE2(N_, T_, false); } while (0)
+#define DSIM_PHYS_CASE(N_, T_) do { if (a.obs_out) hipLaunchKernelGGL((k_physics_fast<N_, T_, true>), g, b, 0, st_, a);   \
+                                    else hipLaunchKernelGGL((k_physics_fast<N_, T_, false>), g, b, 0, st_, a); } while (0)
     if (noise) { if (nt) DSIM_PHYS_CASE(true, true); else DSIM_PHYS_CASE(true, false); }
     else { if (nt) DSIM_PHYS_CASE(false, true); else DSIM_PHYS_CASE(false, false); }
 #undef DSIM_PHYS_CASE
-#undef DSIM_PHYS_CASE2
     if (args->obs_out && !obs_fused) return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, obs_w, 0);
     return (int)hipGetLastError();
   }
@@ -3434,16 +3434,12 @@ int dsim_step_adaptor(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, c
     a.obs_out = obs_fused ? args->obs_out : nullptr;
     const bool nt = stream_policy(args, state.n_pad, args->obs_out ? 304.0 : 224.0);
     const dim3 gf((unsigned)(a.n_pad / 256));
-#define DSIM_AF4(M_, N_, T_, O_) do { if (arows) hipLaunchKernelGGL((k_adaptor_fast<M_, N_, T_, O_, true>), gf, b, 0, st_, a);   \
-                                      else hipLaunchKernelGGL((k_adaptor_fast<M_, N_, T_, O_, false>), gf, b, 0, st_, a); } while (0)
-#define DSIM_AF3(M_, N_, T_) do { if (a.obs_out) DSIM_AF4(M_, N_, T_, true); else DSIM_AF4(M_, N_, T_, false); } while (0)
-#define DSIM_AF2(M_, N_) do { if (nt) DSIM_AF3(M_, N_, true); else DSIM_AF3(M_, N_, false); } while (0)
+#define DSIM_AF2(M_, N_) do { if (nt) hipLaunchKernelGGL((k_adaptor_fast<M_, N_, true>), gf, b, 0, st_, a);                   \
+                              else hipLaunchKernelGGL((k_adaptor_fast<M_, N_, false>), gf, b, 0, st_, a); } while (0)
 #define DSIM_AF1(M_) do { if (noise) DSIM_AF2(M_, true); else DSIM_AF2(M_, false); } while (0)
     if (mode == DSIM_ADAPT_VELOCITY) DSIM_AF1(DSIM_ADAPT_VELOCITY); else DSIM_AF1(DSIM_ADAPT_RPYT);
 #undef DSIM_AF1
 #undef DSIM_AF2
-#undef DSIM_AF3
-#undef DSIM_AF4
     if (args->obs_out && !obs_fused) return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, 20, 0);
     return (int)hipGetLastError();
   }
