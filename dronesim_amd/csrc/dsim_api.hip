@@ -3390,7 +3390,19 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
   if (a.io_id) return DSIM_E_UNSUPPORTED;            // the caller's numbering is served by the run kernels only
   const dim3 g(grid_for(a.n_pad));
   if (args->options & DSIM_OPT_PLANE) DSIM_LAUNCH_GEN(k_physics_plane, noise, args->type_id == nullptr, ctx->max_act == 6, g, a, st_);
-  else DSIM_LAUNCH_GEN(k_physics_gen, noise, args->type_id == nullptr, ctx->max_act == 6, g, a, st_);
+  else {
+    // (written out: a homogeneous six-actuator fleet without noise never comes here — the run kernels above serve it unless
+    // a noise replay is given, which is NOISE = true — so k_physics_gen<false, true, 6> is not instantiated)
+    const dim3 b_(256);
+    const bool uni = args->type_id == nullptr, six = ctx->max_act == 6;
+    if (noise) {
+      if (uni) { if (six) hipLaunchKernelGGL((k_physics_gen<true, true, 6>), g, b_, 0, st_, a); else hipLaunchKernelGGL((k_physics_gen<true, true, 4>), g, b_, 0, st_, a); }
+      else { if (six) hipLaunchKernelGGL((k_physics_gen<true, false, 6>), g, b_, 0, st_, a); else hipLaunchKernelGGL((k_physics_gen<true, false, 4>), g, b_, 0, st_, a); }
+    } else {
+      if (uni) { if (six) return DSIM_E_UNSUPPORTED; hipLaunchKernelGGL((k_physics_gen<false, true, 4>), g, b_, 0, st_, a); }
+      else { if (six) hipLaunchKernelGGL((k_physics_gen<false, false, 6>), g, b_, 0, st_, a); else hipLaunchKernelGGL((k_physics_gen<false, false, 4>), g, b_, 0, st_, a); }
+    }
+  }
   if (args->obs_out)       // general fleets: the same rows by the observation kernel, behind the step on the stream
     return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, obs_w, 0);
   return (int)hipGetLastError();

@@ -206,6 +206,9 @@ def test_two_call_loop_on_runs_vs_oracle(gpu, sub, seed):
                    ids=True, ext=True, caller_io=True)
     _two_call_case(gpu, "two-call runs sharing a wave, soa" + s, [rb, hx], tid2, [(0, 200, 0), (200, 312, 1)], 512, sub, seed,
                    layout="soa", want_yaw=False)
+    # the caller's numbering without observation rows (k_physics_runs_io<.., OBS = false, ..>: the action gather alone)
+    _two_call_case(gpu, "two-call runs sharing a wave, caller io, no rows" + s, [rb, hx], tid2, [(0, 200, 0), (200, 312, 1)], 512, sub,
+                   seed, ids=True, caller_io=True, obs=False)
     # three runs, the middle one inside one wave; ragged end
     tid3 = np.array([1] * 70 + [0] * 30 + [1] * 337, dtype=np.uint8)
     _two_call_case(gpu, "two-call three runs" + s, [rb, hx], tid3, [(0, 70, 1), (70, 30, 0), (100, 337, 1)], 437, sub, seed, pad=64)
@@ -619,6 +622,37 @@ def test_every_instance_of_the_one_launch_adaptor_step(gpu, mode):
                         _check_obs_rows(label + " rows", O, obs.double().cpu().numpy(), f32(got_r), a6, None, [t])
                     else:
                         assert float(obs.min()) == -7.0 and float(obs.max()) == -7.0
+    # a homogeneous fleet that is NOT in whole tiles (n_pad = 704) goes to the general kernels (k_adaptor<.., UNIFORM = true>);
+    # the rows then come from the observation kernel behind the step
+    for seed in (0, 3):
+        rigid, mem, _ = random_fleet(rng, n, n_act=4, tilt=0.3, rate=1.0)
+        rigid, mem = f32(rigid), f32(mem)
+        st = fleet.FleetState(ctx, n, "soa", 64)
+        assert st.n_pad % 256 != 0
+        st.load_aos(rigid, mem)
+        act = f32(np.concatenate([rng.uniform(-0.5, 0.5, (n, 3)), rng.uniform(0.05, 0.3, (n, 1))], 1))
+        adev = torch.zeros((4, st.n_pad), device=ctx.device)
+        adev[:, :n] = torch.from_numpy(np.ascontiguousarray(act.T)).float()
+        echo = torch.zeros((4, st.n_pad), device=ctx.device)
+        obs = torch.full((n, 20), -7.0, device=ctx.device)
+        a = _args(nat, sub, DT, dtc, seed=seed, step_index=4)
+        a.obs_out, a.obs_width = obs.data_ptr(), 20
+        nat.check(ctx.lib.dsim_step_adaptor(ctx.handle, _stream(ctx), n, st.view(), adev.data_ptr(), m_id, echo.data_ptr(), ctypes.byref(a)))
+        torch.cuda.synchronize()
+        got_r, got_m = st.rigid_aos(), st.mem_aos()
+        rc0, m_ref = rigid.copy(), mem.copy()
+        assert O.adaptor_step(0 if mode == "velocity" else 1, rc0, m_ref, act, 0, DT, dtc) == 0
+        tgt = np.concatenate([rigid[:, 0:3], np.zeros((n, 7))], 1)
+        if mode == "velocity":
+            nrm = np.linalg.norm(act[:, 0:3], axis=1, keepdims=True)
+            tgt[:, 3:6] = t.max_speed_kmh / 3.6 * np.abs(act[:, 3:4]) * np.divide(act[:, 0:3], nrm, out=np.zeros((n, 3)), where=nrm > 0)
+        assert_control_parity(f"adaptor_gen[{mode},{seed}] control", [t], None, rigid, mem, tgt, got_m, m_ref, dtc)
+        r_ref = rigid.copy()
+        a6 = np.zeros((n, 6)); a6[:, :4] = got_m[:, 7:11]
+        O.physics(r_ref, got_m.copy(), sub, DT, action=a6, noise=_noise_block(O, [t], None, n, seed, 4, sub) if seed else None)
+        assert_step_parity(f"adaptor_gen[{mode},{seed}] physics", [t], None, rigid, got_m, tgt, got_r, None, r_ref, None, DT, dtc, sub,
+                           control=False, action=got_m[:, 7:11], extra_terms=noise_terms([t], None, n, DT, sub) if seed else None)
+        _check_obs_rows(f"adaptor_gen[{mode},{seed}] rows", O, obs.double().cpu().numpy(), f32(got_r), a6, None, [t])
     # the general kernels take the action field-major only
     t2 = params.builtin_type("tello")
     ctx2 = fleet.Context([t, t2])
