@@ -46,6 +46,30 @@ def main():
         del keep
         torch.cuda.synchronize()
 
+    if "--arena" in sys.argv:
+        # E: ONE driver allocation, the state at its start, the rows D GiB behind it (membench --bigsweep: good from 16 GiB on)
+        a0 = torch.zeros((n, 28), dtype=torch.float32, device=ctx.device)
+        print("A torch rows", round(t(a0), 1), flush=True)
+        nst = env.state.data.numel()
+        total = 24 * gib // 4
+        blk = placement._DriverBlock(ctx, (total,)).tensor()
+        old_state = env.state.data
+        env._move_state(blk[:nst].view(old_state.shape))
+        out = []
+        for d_gib in (1, 4, 8, 12, 15, 16, 17, 20, 22):
+            off = d_gib * gib // 4
+            rows = blk[off: off + n * 28].view(n, 28)
+            out.append((d_gib, round(t(rows), 1)))
+        print("E arena: state at 0, rows at D GiB:", out, flush=True)
+        # the state in the MIDDLE of the arena: rows 16 GiB in front of it
+        env._move_state(blk[20 * gib // 4: 20 * gib // 4 + nst].view(old_state.shape))
+        out = []
+        for d_gib in (0, 2, 3, 4, 8, 12, 18):
+            off = d_gib * gib // 4
+            rows = blk[off: off + n * 28].view(n, 28)
+            out.append((d_gib, round(t(rows), 1)))
+        print("E arena: state at 20 GiB, rows at D GiB:", out, flush=True)
+        return
     a = torch.zeros((n, 28), dtype=torch.float32, device=ctx.device)
     print("A torch rows", hex(a.data_ptr()), round(t(a), 1), "state", hex(env.state.data.data_ptr()), flush=True)
     walk("B driver rows")
