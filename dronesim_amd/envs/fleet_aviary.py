@@ -609,30 +609,26 @@ class CtrlAviary:
                 split(placement.place_rows(self.ctx.device, flat, self._rows_trial, report=log, ctx=self.ctx,
                                            stride_bytes=placement.STRIDE_BYTES))
                 if log and log[-1]["decided_by"] == "all alike" and not self._graph_made:
-                    # Every candidate timed alike.  Either all of them are good — or the STATE block itself lies across two
-                    # regions of device memory (one process in ten), and then no place for the rows is.  One more try with
-                    # the state in a fresh allocation (same contents: the passes change nothing); the better pair stays.
+                    # Every candidate of the walk timed alike: either all of them are good, or none is (separately allocated
+                    # blocks are whatever the memory manager makes them of).  Inside ONE allocation the rule is exact
+                    # (placement.py): device memory is organised in 16 GiB windows, and rows that lie one window behind the
+                    # state block are in the good place.  One more try with such an arena — the state block at its start,
+                    # the written arrays 16 GiB further on — kept only if it is clearly faster, because it HOLDS the 16 GiB
+                    # in between for the life of the env (reported: held_bytes); given back at once otherwise.
                     rows1, tail1, state1, best1 = self._obs_buf, self._written_tail, self.state.data, log[-1]["chosen_pass_us"]
-                    self._obs_buf = self._written_tail = None
-                    try:
-                        fresh = placement._DriverBlock(self.ctx, tuple(state1.shape)).tensor()
-                    except MemoryError:
-                        fresh = None
-                    if fresh is not None:
-                        self._move_state(fresh)
-                        block2 = placement.place_rows(self.ctx.device, flat, self._rows_trial, report=log, ctx=self.ctx,
-                                                      stride_bytes=placement.STRIDE_BYTES)
-                        log[-1]["state_block"] = "moved to a fresh allocation"
-                        if log[-1]["chosen_pass_us"] < 0.95 * best1:
-                            split(block2)
+                    arena = placement.window_arena(self.ctx, state1.numel(), n_rows + n_tail, report=log)
+                    if arena is not None:
+                        self._move_state(arena[0].view(state1.shape))
+                        t2 = placement._event_timer(self._rows_trial, arena[1][:n_rows].view(shape), 3)
+                        log[-1]["chosen_pass_us"], log[-1]["walk_best_us"] = round(t2, 1), best1
+                        if t2 < 0.95 * best1:
+                            arena[1].zero_()
+                            split(arena[1])
+                            log[-1]["decided_by"] = "the arena is clearly faster than the walk's best: kept"
                         else:
                             self._move_state(state1)
-                            self._obs_buf, self._written_tail = rows1, tail1
-                            log[-1]["state_block"] = "a fresh allocation was no better: kept where it was"
-                        del block2
-                    else:
-                        self._obs_buf, self._written_tail = rows1, tail1
-                    del rows1, tail1, state1, fresh
+                            log[-1].update(decided_by="the arena is no better than the walk's best: given back", held_bytes=0)
+                    del rows1, tail1, state1, arena
                 if snap is not None:
                     self.state.data.copy_(snap)
                 self._last_action.copy_(echo)

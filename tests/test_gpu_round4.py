@@ -544,9 +544,9 @@ def test_placement_of_rows_on_hexa_and_reordered_fleets_changes_nothing(gpu, kin
         res.append((e.state.data.clone(), obs.clone(), cmd.clone(), pos_e.clone(), yaw_e.clone(), e.ground_contacts()))
         if p:
             log = list(e.ctx.placement_log)
-            assert [r["array"] for r in log if r["array"] != "observation rows"] == ["computeControl outputs"]
+            assert [r["array"] for r in log if r["array"] != "observation rows" and not r["array"].startswith("arena")] == ["computeControl outputs"]
             rows = [r for r in log if r["array"] == "observation rows"]
-            assert 1 <= len(rows) <= 2 and rows[0]["memory"].startswith("driver") and rows[0]["candidates"] >= 2
+            assert len(rows) == 1 and rows[0]["memory"].startswith("driver") and rows[0]["candidates"] >= 2
             assert rows[0]["candidates"] * rows[0]["bytes"] <= rows[0]["peak_bytes"] <= rows[0]["budget_bytes"]     # (+ the ballast strides)
             assert 0 < rows[0]["seconds"] < 30
             assert cmd.data_ptr() == e._written_tail.data_ptr()         # the command lives in the room behind the placed rows
