@@ -318,7 +318,8 @@ __device__ __forceinline__ void quad_substeps(DT& T, const StepK& a, long long i
 template <bool NOISE, bool REPLAY = true, bool ONE = false, bool PLANE = false, class DT>
 __device__ __forceinline__ void hexa_substeps(DT& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[6], unsigned long long step_index,
-                                              V3 ext = V3{0.0f, 0.0f, 0.0f}, long long nid = -1) {
+                                              V3 ext = V3{0.0f, 0.0f, 0.0f}, long long nid = -1,
+                                              const NoiseTab* tab = nullptr /* LDS tables of the Box-Muller pairs, or none */) {
   const uint64_t noise_key = (uint64_t)(nid >= 0 ? nid : i);
   V3 F, tau;
   if (!NOISE) hexa_wrench(T, cmd, nullptr, F, tau);
@@ -342,6 +343,10 @@ __device__ __forceinline__ void hexa_substeps(DT& T, const StepK& a, long long i
       if (REPLAY && a.noise_replay) {
 #pragma unroll
         for (int j = 0; j < 12; ++j) nz[j] = a.noise_replay[((long long)k * 12 + j) * a.n_pad + i];
+      } else if (tab) {
+        uint32_t c[4];
+        noise_block(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, c);
+        hexa_normals_from_block_tab(*tab, c, nz);
       } else {
         noise_normals<6>(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);   // N(0,.01) | N(0,.001)
       }
@@ -446,12 +451,17 @@ __global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
   const long long i0 = (long long)blockIdx.x * 256;
   float* const sb = a.st.base + kv_off(a.st, i0);
   const float* const tb = a.tg.base + kv_off(a.tg, i0);
+  constexpr bool TAB = NOISE && !S1;          // several sub-steps per launch: the Box-Muller pairs from LDS tables (k_step_fast)
+  __shared__ NoiseTab ntab_[TAB ? 1 : 0 + 1];
+  const NoiseTab* const ntab = TAB ? &ntab_[0] : nullptr;
+  if (TAB) noise_tab_init(ntab_[0], threadIdx.x);
   Rigid s;
   CtrlMem<6> m;
   Target tg;
   load_rigid<NT>(sb, sfs, sl, s);
   load_mem<6, NT>(sb, sfs, sl, m);
   load_target<NT>(tb, tfs, tl, tg);
+  if (TAB) __syncthreads();
   const long long i = i0 + threadIdx.x;
   if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
   V3 pos_e;
@@ -460,9 +470,9 @@ __global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
     float act[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) act[j] = clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]);
-    hexa_substeps<NOISE, false, S1>(T, a, i, s, act, a.step_index);
+    hexa_substeps<NOISE, false, S1>(T, a, i, s, act, a.step_index, V3{0.0f, 0.0f, 0.0f}, -1, ntab);
   } else {
-    hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index);
+    hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, V3{0.0f, 0.0f, 0.0f}, -1, ntab);
   }
   indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
   const unsigned so = pin_lane_offset(sl);
@@ -950,13 +960,23 @@ __global__ __launch_bounds__(128, S1 ? 4 : 3) void k_step_mixed4(StepK a) {
   }
 }
 
+// Kernels that loop over several sub-steps take the Box-Muller pairs of the rotor noise from LDS tables (NoiseTab, dsim_device.h:
+// bit-identical to direct evaluation): filled by the whole workgroup before any lane leaves.  `ntab` = the tables, or null.
+#define DSIM_NOISE_TAB(ON, THREADS)                                                                  \
+  __shared__ NoiseTab ntab_[1];                                                                      \
+  const NoiseTab* const ntab = (ON) ? &ntab_[0] : nullptr;                                           \
+  if (ON) {                                                                                          \
+    for (unsigned e_ = threadIdx.x; e_ < 256u; e_ += (THREADS)) noise_tab_init(ntab_[0], e_);        \
+    __syncthreads();                                                                                 \
+  }
 // Type-major storage (dsim_step_args.runs): a run of one type is stepped by the single-type law of its kind,
 // the fast form (no partition, no waterfall, per-type constants in SGPRs); ext = optional downwash force.
 // ACT: an explicit action for the physics part (dsim_step_args.action: the first iteration of the example loop), clipped as
 // CtrlAviary._preprocessAction does; the controller memory keeps its own cmd (k_step_runs only: a template flag, as in k_step_fast)
 // KIND: DSIM_DEV_KIND_* of the run's type — 2 = morphing-hexa physics with the quad law on its six actuators
 template <int KIND, bool NOISE, bool NT, bool S1, bool ACT = false>
-__device__ __forceinline__ void run_body(const StepK& a, long long i0, long long lo, long long last, int run_type) {
+__device__ __forceinline__ void run_body(const StepK& a, long long i0, long long lo, long long last, int run_type,
+                                         const NoiseTab* tab = nullptr) {
   constexpr bool HEXA = KIND != DSIM_DEV_KIND_QUAD;            // six actuators, morphing-hexa physics
   const long long i = i0 + threadIdx.x;
   if (i >= last || i < lo) return;          // (a run may begin and end inside a tile: the neighbouring run's lanes take the rest)
@@ -985,11 +1005,11 @@ __device__ __forceinline__ void run_body(const StepK& a, long long i0, long long
 #pragma unroll
   for (int j = 0; j < NA; ++j) act[j] = ACT ? clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]) : m.cmd[j];   // CtrlAviary.py:258-263
   if constexpr (HEXA) {
-    hexa_substeps<NOISE, false, S1>(T, a, i, s, act, step_index, ext, nid);
+    hexa_substeps<NOISE, false, S1>(T, a, i, s, act, step_index, ext, nid, tab);
     if constexpr (KIND == DSIM_DEV_KIND_HEXA) indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
     else indi_quad<false, 6>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   } else {
-    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, act, step_index, ext, nullptr, nid);
+    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, act, step_index, ext, nullptr, nid, tab);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   const unsigned so = pin_lane_offset(sl);
@@ -1002,7 +1022,8 @@ __device__ __forceinline__ void run_body(const StepK& a, long long i0, long long
 }
 template <int KIND, bool NOISE, bool NT, bool S1>
 __global__ __launch_bounds__(256, KIND ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void k_step_run(StepK a) {
-  run_body<KIND, NOISE, NT, S1>(a, a.first + (long long)blockIdx.x * 256, a.lo, a.last, a.run_type);
+  DSIM_NOISE_TAB(NOISE && !S1, 256);
+  run_body<KIND, NOISE, NT, S1>(a, a.first + (long long)blockIdx.x * 256, a.lo, a.last, a.run_type, ntab);
 }
 // All the runs of a type-major fleet in ONE launch: a workgroup finds its run by its index (constant-index walk over the
 // table, everything wave-uniform) and runs that run's law.  A 65 536-drone shard of BASELINE config 5 is two runs of 128
@@ -1047,8 +1068,9 @@ struct RunOf { long long i0, lo, last; int type; bool hexa, quadlaw6; };
 template <bool NOISE, bool NT, bool S1, bool ACT>
 __global__ __launch_bounds__(256, 3) void k_step_runs(StepK a, RunTab rt) {
   DSIM_RUN_OF_BLOCK(rt, ro, blockIdx.x);
-  if (ro.hexa) run_body<DSIM_DEV_KIND_HEXA, NOISE, NT, S1, ACT>(a, ro.i0, ro.lo, ro.last, ro.type);
-  else run_body<DSIM_DEV_KIND_QUAD, NOISE, NT, S1, ACT>(a, ro.i0, ro.lo, ro.last, ro.type);
+  DSIM_NOISE_TAB(NOISE && !S1 && !ACT, 256);       // (the explicit-action instances: one step of an example loop; with the tables they spill)
+  if (ro.hexa) run_body<DSIM_DEV_KIND_HEXA, NOISE, NT, S1, ACT>(a, ro.i0, ro.lo, ro.last, ro.type, ntab);
+  else run_body<DSIM_DEV_KIND_QUAD, NOISE, NT, S1, ACT>(a, ro.i0, ro.lo, ro.last, ro.type, ntab);
 }
 
 // ---- Env.step only ---------------------------------------------------------
@@ -1326,7 +1348,8 @@ __device__ __forceinline__ int io_window_base(const int* wmin) {
 struct IoRow { vf2 pc[11]; int id; bool have; };            // a lane's observation row on its way to the window
 struct IoCtl { float v[10]; int id; bool have; };            // a lane's command (6), position error (3), yaw error
 template <bool HEXA, bool NOISE, bool NT, bool OBS, bool IO, bool S1>
-__device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro, float* rows_wave, unsigned t, IoRow& io) {
+__device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro, float* rows_wave, unsigned t, IoRow& io,
+                                                 const NoiseTab* tab = nullptr) {
   constexpr int NA = HEXA ? 6 : 4;
   const long long i0 = ro.i0, i = i0 + t;
   const long long w0 = i0 + (long long)(t & ~63u);                     // first drone of this wave
@@ -1360,8 +1383,8 @@ __device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro
     if (NOISE && a.step_index_dev) step_index += *a.step_index_dev;
     const long long nid = NOISE ? noise_id(a, i) : -1LL;
     // (S1: one sub-step per Env.step — BASELINE's metric definition — compiled straight-line, as in the fused kernels)
-    if constexpr (HEXA) hexa_substeps<NOISE, false, S1>(T, a, i, s, cmd, step_index, ext, nid);
-    else quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, cmd, step_index, ext, nullptr, nid);
+    if constexpr (HEXA) hexa_substeps<NOISE, false, S1>(T, a, i, s, cmd, step_index, ext, nid, tab);
+    else quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, cmd, step_index, ext, nullptr, nid, tab);
     ground_watch(T, s, a.fb.counters, i < a.n);
     const unsigned so = pin_lane_offset(sl);
     store_rigid<NT>(sb, sfs, so, s);
@@ -1435,8 +1458,9 @@ __global__ __launch_bounds__(256, S1 ? DSIM_PRUNS_WAVES : 3) void k_physics_runs
   DSIM_RUN_OF_BLOCK(rt, ro, blockIdx.x);
   float* rw = rows + (OBS ? (threadIdx.x >> 6) * (64 * DSIM_OBS_WMAX) : 0);
   IoRow none;
-  if (ro.hexa) physics_run_body<true, NOISE, NT, OBS, false, S1>(a, ro, rw, threadIdx.x, none);
-  else physics_run_body<false, NOISE, NT, OBS, false, S1>(a, ro, rw, threadIdx.x, none);
+  DSIM_NOISE_TAB(NOISE && !S1, 256);
+  if (ro.hexa) physics_run_body<true, NOISE, NT, OBS, false, S1>(a, ro, rw, threadIdx.x, none, ntab);
+  else physics_run_body<false, NOISE, NT, OBS, false, S1>(a, ro, rw, threadIdx.x, none, ntab);
 }
 // DSIM_OPT_CALLER_IO: the same stretch of two neighbouring tiles of the side-by-side map, the rows assembled over the window
 template <bool NOISE, bool NT, bool OBS, bool S1>
@@ -1452,8 +1476,9 @@ __global__ __launch_bounds__(DSIM_IO_WG, S1 ? DSIM_PRUNS_WAVES : 3) void k_physi
     const long long i = ro.i0 + t;
     io_window_min(i >= ro.lo && i < ro.last && i < a.n ? a.io_id[i] : 0x7fffffff, wmin, flags);
   }
-  if (ro.hexa) physics_run_body<true, NOISE, NT, OBS, true, S1>(a, ro, nullptr, t, io);
-  else physics_run_body<false, NOISE, NT, OBS, true, S1>(a, ro, nullptr, t, io);
+  DSIM_NOISE_TAB(NOISE && !S1, DSIM_IO_WG);
+  if (ro.hexa) physics_run_body<true, NOISE, NT, OBS, true, S1>(a, ro, nullptr, t, io, ntab);
+  else physics_run_body<false, NOISE, NT, OBS, true, S1>(a, ro, nullptr, t, io, ntab);
   if (OBS) {
     const int base = io_window_base(wmin);
     const int hw = a.obs_w >> 1;

@@ -245,6 +245,13 @@ __device__ __forceinline__ void quad_normals_from_block_tab(const NoiseTab& t, c
   box_muller8_tab<false, 0>(t, wf, out[0], out[1]); box_muller8_tab<false, 1>(t, wf, out[2], out[3]);
   box_muller8_tab<true, 0>(t, wm, out[4], out[5]); box_muller8_tab<true, 1>(t, wm, out[6], out[7]);
 }
+// the twelve normals of a hexa sub-step from the tables (the looped hexa kernels: without them the generator was 113 of the 281 us
+// five sub-steps of 4 194 304 hexas took); same words, same halves as noise_normals<6>
+__device__ __forceinline__ void hexa_normals_from_block_tab(const NoiseTab& t, const uint32_t c[4], float* out) {
+  box_muller8_tab<false, 0>(t, c[0], out[0], out[1]); box_muller8_tab<false, 1>(t, c[0], out[2], out[3]);
+  box_muller8_tab<false, 0>(t, c[1], out[4], out[5]); box_muller8_tab<true, 1>(t, c[1], out[6], out[7]);
+  box_muller8_tab<true, 0>(t, c[2], out[8], out[9]); box_muller8_tab<true, 1>(t, c[2], out[10], out[11]);
+}
 template <int NACT>
 __device__ __forceinline__ void noise_normals(uint64_t seed, uint64_t drone, uint64_t sub, float* out) {
   const uint64_t blk = NACT == 4 ? (sub >> 1) : sub;
