@@ -33,6 +33,7 @@ FLEETS = {
     # name: (models, type ids or None, sub-steps, physics with downwash, chained)
     "quad": (["robobee"], None, 2, False, True),
     "hexa": (["hexa_6DOF"], None, 1, False, False),
+    "hexa_simple": (["hexa_6DOF_simple"], None, 2, False, False),      # morphing-hexa physics, the quad law on six actuators
     "mixed": (["robobee", "hexa_6DOF"], "interleaved", 2, False, False),
     "mixed_dw": (["tello", "hexa_6DOF"], "random", 2, True, False),
 }
