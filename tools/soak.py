@@ -19,13 +19,26 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--only", default=None, help="comma-separated workload names")
     a = ap.parse_args()
     rows = []
+    only = [w for w in (a.only or "").split(",") if w]
     for name, kw, steps in (("config2x1024", dict(n_fleet=4096, replicas=1024, substeps=1), a.steps),
                             ("config2x1024_sub5", dict(n_fleet=4096, replicas=1024, substeps=5), a.steps // 2),
                             ("mixed_quad_hexa", dict(n_fleet=4096, replicas=1024, substeps=1, mixed=True), a.steps // 2),
-                            ("config5_shard", dict(n_fleet=65536, replicas=1, substeps=1, config5=True), a.steps)):
+                            ("config5_shard", dict(n_fleet=65536, replicas=1, substeps=1, config5=True), a.steps),
+                            # round 4: the reference-shaped two-call loop on the run kernels (hexa; interleaved, caller-order I/O;
+                            # five sub-steps: the looped instances with the noise tables)
+                            ("two_call_hexa", dict(n_fleet=4096, replicas=1024, substeps=1, hexa=True, two_call=True), a.steps // 4),
+                            ("two_call_mixed_interleaved", dict(n_fleet=4096, replicas=1024, substeps=1, mixed=True, two_call=True), a.steps // 4),
+                            ("two_call_mixed_interleaved_sub5", dict(n_fleet=4096, replicas=1024, substeps=5, mixed=True, two_call=True), a.steps // 8),
+                            ("two_call_config5_shard", dict(n_fleet=65536, replicas=1, substeps=1, config5=True, two_call=True), a.steps // 2)):
+        if only and name not in only:
+            continue
+        two_call = kw.pop("two_call", False)
         fl = bench.Fleet(kw.pop("n_fleet"), kw.pop("replicas"), 0, kw.pop("substeps"), "tile64", 1, **kw)
+        if two_call:
+            fl.make_two_call_loop()
         p0 = fl.env.state.raw_fields(0, 3).clone()
         t0 = time.perf_counter()
         for _ in range(steps):
