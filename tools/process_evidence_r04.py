@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAGS = {"r04_main": (4194304, 232), "r04_mixed": (4194304, 241), "r04_hexa": (4194304, 248), "r04_sub5": (4194304, 232),
+TAGS = {"r04_main": (4194304, 232), "r04_mixed": (4194304, 241), "r04_hexa": (4194304, 248), "r04_sub5": (4194304, 232), "r04_hexa_sub5": (4194304, 248),
         "r04_c5": (65536, 241), "r04_two_call_quad": (4194304, 428), "r04_two_call_hexa": (4194304, 476),
         "r04_two_call_mixed": (4194304, 468), "r04_two_call_config5": (65536, 480)}
 for tag, (n, b) in TAGS.items():
