@@ -794,6 +794,21 @@ def main(argv=None):
                     "configs[2]_65536_robobee_waypoints_sub2_32_env_steps_per_launch": (65536, 1, 2, True, 32),
                     "configs[3]_shard_65536_robobee_hover_sub1": (4096, 16, 1, False, 1)}.items():
                 base[name] = measure_variant(torch, local, a.layout, a.noise_seed, a.steps, name, *spec, options=options)
+            # configs[1] through the reference's own two surfaces (examples/fly_INDI.py:223-239: obs = env.step(cmd);
+            # cmd = ctrl.computeControlFromState(...)): two launches per iteration, paced by the Python around them
+            try:
+                f1 = Fleet(4096, 1, local, 5, a.layout, a.noise_seed)
+                f1.make_two_call_loop()
+                k1 = max(200, a.steps)
+                w1, d1, r1 = f1.timed(k1, 50, min_s=MIN_TIMED_S)
+                base["configs[1]_4096_robobee_hover_sub5_env_step_then_computeControl"] = {
+                    "drone_steps_per_s": f1.n * k1 * r1 / w1, "loop_us": w1 / (k1 * r1) * 1e6, "loop_us_device": d1 / (k1 * r1) * 1e6,
+                    "drones": f1.n, "phys_substeps": 5, "steps_timed": k1 * r1,
+                    "note": "host-paced: the prepared argument blocks of step() / computeControl() are re-launched (round 4: 24 -> 11.5 us)"}
+                f1.env.close()
+                del f1
+            except Exception as e:          # an extra must not cost the headline
+                base["configs[1]_4096_robobee_hover_sub5_env_step_then_computeControl"] = {"error": repr(e)[:300]}
             out["baseline_configs"] = base
             also = {}
             # yardsticks of THIS device, from the repo's own probe (tools/membench.hip, a child process): the float4-copy

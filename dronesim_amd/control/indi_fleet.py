@@ -57,6 +57,7 @@ class BaseControl:
         # computeControl returns, and Env.step takes it back as the action without a copy
         self._cmd = torch.zeros((self.ctx.n_act, self.state.n_pad), dtype=torch.float32, device=self.ctx.device)
         self._outputs_placed = False     # large quad fleets: the three arrays above are re-allocated by trial at the first call
+        self._plan = None                # the prepared launch of computeControl's repeated-call path
         self.reset()
 
     def reset(self):
@@ -162,6 +163,30 @@ class INDIControl(BaseControl):
             # step_fused() sequence leaves last_vel / last_rates stale until materialized
             self.env.materialize()          # (also joins a deferred WLS fallback pass: this launch reads the commands)
             self.env._chain_ok = False
+        # The loop of the reference's examples calls this every control period with the SAME targets
+        # (examples/fly_INDI.py:229-239), and at the reference's own fleet sizes the Python in front of the launch is what an
+        # iteration costs (4 096 quads: 13 us of it around a 4 us kernel).  When nothing that goes into the launch has changed
+        # since the last call — state read from the bound env, the same frozen target_pos, the same small host vectors (compared
+        # by content), the same buffers — the prepared argument block is launched again as it is.
+        key = None
+        if cur_pos is None and isinstance(target_pos, Frozen):
+            small = []
+            for x in (target_vel, target_acc, target_rpy):
+                if torch.is_tensor(x) or np.size(x) != 3:
+                    small = None
+                    break
+                small.append(np.asarray(x, dtype=np.float32).tobytes())
+            if small is not None:
+                key = (target_pos, float(control_timestep), small[0], small[1], small[2], st.data.data_ptr(),
+                       self._targets.data.data_ptr(), self._targets.version, id(getattr(self.env, "_runs", None)),
+                       getattr(self.env, "_tuning", 0), self._cmd.data_ptr() if self._cmd is not None else 0)
+                plan = self._plan
+                if plan is not None and plan[0] == key:
+                    nat.check(self.ctx.lib.dsim_control2(self.ctx.handle, self.ctx.stream_ptr(), n, plan[1], plan[2], plan[3],
+                                                         plan[4], plan[5], plan[6]))
+                    if plan[8] is not None:
+                        self.env._cmd_token = plan[8]
+                    return plan[7]
         if cur_pos is not None:                       # explicit state (stand-alone use)
             st.set_fields(0, _as3(cur_pos, n, dev))
             q = torch.as_tensor(np.asarray(cur_quat) if not torch.is_tensor(cur_quat) else cur_quat,
@@ -198,12 +223,18 @@ class INDIControl(BaseControl):
         if not self._outputs_placed:
             self._outputs_placed = True
             self._place_outputs(a)
-        nat.check(self.ctx.lib.dsim_control2(self.ctx.handle, self.ctx.stream_ptr(), n, st.view(),
-                                             self._targets.view(), ctypes.byref(a), self._pos_e.data_ptr(),
-                                             self._yaw_e.data_ptr(), self._cmd.data_ptr()))
+        sview, tview = st.view(), self._targets.view()
+        nat.check(self.ctx.lib.dsim_control2(self.ctx.handle, self.ctx.stream_ptr(), n, sview, tview, ctypes.byref(a),
+                                             self._pos_e.data_ptr(), self._yaw_e.data_ptr(), self._cmd.data_ptr()))
         order = st.order
         if order is None or caller_io:
-            return self._cmd[:, :n].T, self._pos_e[:, :n].T, self._yaw_e[:n]
+            out = (self._cmd[:, :n].T, self._pos_e[:, :n].T, self._yaw_e[:n])
+            if key is not None:
+                # (the key is completed with what this call settled: the buffers of the outputs and the targets' version)
+                key = key[:6] + (self._targets.data.data_ptr(), self._targets.version) + key[8:10] + (self._cmd.data_ptr(),)
+                self._plan = (key, sview, tview, ctypes.byref(a), self._pos_e.data_ptr(), self._yaw_e.data_ptr(),
+                              self._cmd.data_ptr(), out, None, a)
+            return out
         # a fleet stored in another order than the caller's: the triple goes back in the caller's numbering; the env
         # recognises the command tensor when it comes back as the next action and takes the storage-order array as is
         cmd = order.to_caller(self._cmd[:, :n], 1).T
