@@ -358,14 +358,21 @@ class CtrlAviary:
         # the same buffers: the prepared argument block is launched again with the step counter moved on (at the
         # reference's own fleet sizes the Python in front of the launch is most of what an iteration costs).
         plan = self._step_plan
-        if plan is not None and action is plan[1] and self._downwash is None and plan[0] == (
-                action.data_ptr(), self.state.data.data_ptr(), self._obs_buf.data_ptr(), self._last_action.data_ptr(),
-                self._phys_options, self._tuning, self.AGGR_PHY_STEPS, id(self._runs), self._caller_io, self.noise_seed):
+        if plan is not None and self._downwash is None and plan[0] == (
+                self.state.data.data_ptr(), self._obs_buf.data_ptr(), self._last_action.data_ptr(),
+                self._phys_options, self._tuning, self.AGGR_PHY_STEPS, id(self._runs), self._caller_io, self.noise_seed) and (
+                (action is plan[1] and action.data_ptr() == plan[7]) or (plan[8] and self._is_action_rows(action))):
+            # (the same tensor as last time — the command a bound controller returned — or, for a fleet that takes [N, 4] rows
+            # as the caller holds them, any such tensor: a policy's fresh output every step)
             self._join_fallback()
             args = plan[2]
             args.step_index = self._env_steps
+            if action is not plan[1]:
+                args.action = action.data_ptr()
+                self._action_keep = action
+                self._step_plan = plan[:1] + (action,) + plan[2:7] + (args.action,) + plan[8:]
             nat.check(self.ctx.lib.dsim_physics(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, plan[3],
-                                                plan[0][3], plan[4]))
+                                                plan[0][2], plan[4]))
             self._use_last_action = True
             self.step_counter += self.AGGR_PHY_STEPS
             self._env_steps += 1
@@ -385,9 +392,7 @@ class CtrlAviary:
             if s_ == 0:
                 # a homogeneous quad fleet on the fast kernel takes an [N, 4] device tensor as the caller holds it (no transpose)
                 self._rows_in = (self.n_act == 4 and self._type_id is None and self._downwash is None and self._phys_options == 0
-                                 and self.order is None and self.state.n_pad % 256 == 0 and torch.is_tensor(action)
-                                 and action.dtype == torch.float32 and action.is_contiguous() and action.device == self.ctx.device
-                                 and tuple(action.shape) == (self.NUM_DRONES, 4) and action.data_ptr() % 16 == 0
+                                 and self.order is None and self.state.n_pad % 256 == 0 and self._is_action_rows(action)
                                  and not (getattr(self, "_cmd_token", None) is not None and action is self._cmd_token[0]))
             if self._rows_in:
                 args.options |= nat.OPT_ACTION_ROWS
@@ -412,10 +417,17 @@ class CtrlAviary:
                 and args.action in (action.data_ptr(), getattr(action, "T", action).data_ptr())):
             # (only when the launch read the caller's tensor itself — the controller's command array or [N, 4] rows — and
             # handed out the rows it wrote: nothing was copied on the way in or out)
-            self._step_plan = ((action.data_ptr(), self.state.data.data_ptr(), obs.data_ptr(), self._last_action.data_ptr(),
+            self._step_plan = ((self.state.data.data_ptr(), obs.data_ptr(), self._last_action.data_ptr(),
                                 self._phys_options, self._tuning, self.AGGR_PHY_STEPS, id(self._runs), self._caller_io,
-                                self.noise_seed), action, args, self.state.view(), ctypes.byref(args), out, self._computeInfo())
+                                self.noise_seed), action, args, self.state.view(), ctypes.byref(args), out, self._computeInfo(),
+                               action.data_ptr(), bool(self._rows_in))
         return out, self._computeReward(), self._computeDone(), self._computeInfo()
+
+    def _is_action_rows(self, action) -> bool:
+        """An [N, 4] float32 device tensor, contiguous and 16-byte aligned: what DSIM_OPT_ACTION_ROWS takes as it is."""
+        return (torch.is_tensor(action) and action.dtype == torch.float32 and action.is_contiguous()
+                and action.device == self.ctx.device and tuple(action.shape) == (self.NUM_DRONES, 4)
+                and action.data_ptr() % 16 == 0)
 
     def step_fused(self, targets, control_timestep: Optional[float] = None, action=None, n_steps: int = 1):
         """One launch = ``env.step(action)`` followed by ``computeControl`` for every drone:
