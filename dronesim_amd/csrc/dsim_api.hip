@@ -1676,7 +1676,7 @@ __global__ __launch_bounds__(256, PLANE ? 1 : DSIM_GEN_WAVES) void k_adaptor(Ste
 
 // The same on a homogeneous quad fleet in whole tiles, as ONE launch that also returns Env.step's observation: the fused
 // kernels' addressing (scalar base + one lane offset, streaming accesses, constants in SGPRs), the action taken as the
-// caller holds it — AROWS: row-major [n][4] (VelocityAviary.py:221-264 / RPYTAviary.py:181-193 take one 4-vector per drone),
+// caller holds it — StepK.action_rows: row-major [n][4] (VelocityAviary.py:221-264 / RPYTAviary.py:181-193 take one 4-vector per drone),
 // one 16-byte load per lane — and the 20-wide rows of the NEW state written by the same launch (OBS).  Before: a transpose of
 // the action (torch, 50 us), k_adaptor (147-160 us) and k_observe (125 us) per Env.step of 4 194 304 drones.
 //   reads 24 state + 4 action floats, writes 24 state + 4 echoed command + 20 row floats: 304 bytes per drone-step

@@ -2791,7 +2791,7 @@ def test_every_instance_of_the_two_call_adaptor_and_general_kernels(gpu, seed):
     n = 512
     act = f32(np.random.default_rng(9).uniform(0.3, 0.7, (n, 4)))
 
-    # ---- k_physics_fast<NOISE, NT, OBS, AROWS> and k_control_fast<NT, WANT_YAW> (homogeneous quads, whole tiles); AROWS: the
+    # ---- k_physics_fast<NOISE, NT, OBS> and k_control_fast<NT, WANT_YAW> (homogeneous quads, whole tiles); arows: the
     # action as the [N, 4] array Env.step is handed (DSIM_OPT_ACTION_ROWS)
     for with_obs, arows in ((False, False), (True, False), (False, True), (True, True)):
         def phys(ctx, st, tg, tdev, pol):

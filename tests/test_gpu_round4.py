@@ -560,7 +560,7 @@ def test_placement_of_rows_on_hexa_and_reordered_fleets_changes_nothing(gpu, kin
 
 @pytest.mark.parametrize("mode", ["velocity", "rpyt"])
 def test_every_instance_of_the_one_launch_adaptor_step(gpu, mode):
-    """k_adaptor_fast<MODE, NOISE, NT, OBS, AROWS> through dsim_step_adaptor: the action field-major or row-major
+    """k_adaptor_fast<MODE, NOISE, NT> (+ its run-time switches: rows fused or not, action layout) through dsim_step_adaptor: the action field-major or row-major
     (DSIM_OPT_ACTION_ROWS), the observation rows of the NEW state fused or not, noise, both cache policies — control part
     and physics part each against the oracle (VelocityAviary.py:221-264, RPYTAviary.py:181-193), rows against
     orc_state_vector; a ragged fleet inside whole tiles."""
@@ -666,7 +666,7 @@ def test_every_instance_of_the_one_launch_adaptor_step(gpu, mode):
 
 def test_env_step_takes_the_action_rows_as_the_caller_holds_them(gpu):
     """CtrlAviary.step(action): an [N, 4] float32 device tensor goes to the launch as it is (DSIM_OPT_ACTION_ROWS,
-    k_physics_fast<.., AROWS>), anything else through the env's field-major buffer — same state, same rows, bit for bit;
+    k_physics_fast with StepK.action_rows), anything else through the env's field-major buffer — same state, same rows, bit for bit;
     the caller's tensor is not touched."""
     from dronesim_amd.envs import CtrlAviary
     n = 1024
