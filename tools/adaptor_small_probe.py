@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Dev probe (GPU box): Env.step of VelocityAviary at BASELINE's literal size (4 096 quads x 5 sub-steps), host-paced:
+microseconds per step with the action a fresh tensor every other step.  usage: python tools/adaptor_small_probe.py"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
