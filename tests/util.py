@@ -222,7 +222,23 @@ def assert_step_parity(label, types, type_id, prev_rigid, prev_mem, tgt, got_rig
                   value=float(ref_rigid[i, f]), largest_term=float(tr[i, f]), k_ulp=float(k))
     if got_mem is not None:
         kk = k * tilt_gain(types, type_id, ref_rigid)
-        rm = increment_ratio(got_mem, ref_mem, prev_mem, tm, kk)
+        # (the controller memory copies the new velocity into last_vel: what is only known to REL_TOL in the velocity — the
+        # part of its increment that came from the neighbour-downwash force — is only known to REL_TOL there too)
+        part_mem = None
+        if part_rigid is not None:
+            # ... and the law differentiates it: (v - last_vel) / dt_ctrl is the measured acceleration (INDIControl.py:285-291,
+            # INDIControl_6DOF.py:399-413), which goes into the thrust state and, through the allocation, into the commands
+            part_mem = np.zeros_like(ref_mem)
+            part_mem[:, 0:3] = part_rigid[:, 7:10]
+            pa = part_rigid[:, 7:10].sum(1) / dt_ctrl
+            part_mem[:, 6] = pa
+            tid_ = np.zeros(ref_mem.shape[0], dtype=np.int64) if type_id is None else np.asarray(type_id).astype(np.int64)
+            for k_, t_ in enumerate(types):
+                s_ = tid_ == k_
+                A_ = np.abs(np.asarray(t_.alloc, dtype=np.float64))
+                col = A_[: t_.n_act, 3] if t_.kind != 1 else A_[:6, 3:6].sum(1)
+                part_mem[np.ix_(s_, 7 + np.arange(t_.n_act))] = pa[s_, None] * col[None, :]
+        rm = increment_ratio(got_mem, ref_mem, prev_mem, tm, kk, part_mem)
         if rm.max() > worst:
             worst = float(rm.max())
             i, f = (int(x) for x in np.unravel_index(rm.argmax(), rm.shape))
