@@ -285,3 +285,82 @@ def test_random_call_sequences_against_the_oracle_model(kind, ops, seed):
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a HIP device; the product has no CPU fallback")
     Loop(kind, seed).run(ops)
+
+
+ADAPTOR_OPS = st.lists(st.one_of(
+    st.tuples(st.just("reset")),
+    st.tuples(st.just("step"), st.sampled_from(["host", "device", "device_same", "device_noncontiguous"])),
+    st.tuples(st.just("observe")),
+), min_size=3, max_size=12)
+
+
+@pytest.mark.parametrize("mode", ["velocity", "rpyt"])
+@settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(ops=ADAPTOR_OPS, seed=st.integers(0, 10_000))
+def test_random_call_sequences_of_the_adaptor_envs(mode, ops, seed):
+    """VelocityAviary / RPYTAviary: reset / step / observe in random order, the action handed over as a host array, as a
+    fresh [N, 4] device tensor, as the SAME device tensor again (the prepared launch of the one-launch step is re-used) or as
+    a non-contiguous view (goes through the env's buffer) — every step against the oracle (control part on the state before
+    the physics, physics part with the command the device computed), the returned rows against orc_state_vector."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device; the product has no CPU fallback")
+    from dronesim_amd.envs import RPYTAviary, VelocityAviary
+    from tests.test_gpu_parity import _noise_block
+    n, sub, noise_seed = 300, 2, 7
+    rng = np.random.default_rng(seed)
+    xyz = np.stack([rng.uniform(-5, 5, n), rng.uniform(-5, 5, n), rng.uniform(1, 5, n)], 1)
+    env = (VelocityAviary if mode == "velocity" else RPYTAviary)(["robobee"], n, initial_xyzs=xyz, aggregate_phy_steps=sub,
+                                                                   noise_seed=noise_seed, dict_io=False)
+    t = params.builtin_type("robobee")
+    O = orc.Oracle([t])
+    dtc = float(np.float32(sub / 240))
+    steps, same = 0, None
+    for op in ops:
+        if op[0] == "reset":
+            env.reset()
+            steps = 0
+            np.testing.assert_array_equal(env.state.rigid_aos()[:, 0:3], f32(xyz))
+            continue
+        if op[0] == "observe":
+            rows = env.observe().double().cpu().numpy()
+            r, m = env.state.rigid_aos(), env.state.mem_aos()
+            last = np.zeros((n, 6)); last[:, :4] = env._last_action[:, :n].T.double().cpu().numpy()
+            _check_obs_rows(f"fuzz adaptor[{mode}] observe", O, rows, r, last, None, [t])
+            continue
+        if mode == "velocity":
+            act = np.concatenate([rng.uniform(-1, 1, (n, 3)), rng.uniform(0, 0.3, (n, 1))], 1)
+        else:
+            act = np.concatenate([rng.uniform(-0.5, 0.5, (n, 3)), rng.uniform(0.3, 0.6, (n, 1))], 1)
+        act = f32(act)
+        a32 = torch.from_numpy(act.astype(np.float32))
+        if op[1] == "host":
+            handed = act.astype(np.float32)
+        elif op[1] == "device":
+            handed = a32.to(env.ctx.device)
+        elif op[1] == "device_same":
+            if same is None:
+                same = torch.zeros((n, 4), device=env.ctx.device)
+            same.copy_(a32)                                   # the same tensor object, new contents
+            handed = same
+        else:
+            wide = torch.zeros((n, 8), device=env.ctx.device)
+            wide[:, ::2] = a32.to(env.ctx.device)
+            handed = wide[:, ::2]
+        r0, m0 = env.state.rigid_aos(), env.state.mem_aos()
+        obs, _, _, _ = env.step(handed)
+        got_r, got_m = env.state.rigid_aos(), env.state.mem_aos()
+        rc0, m_ref = r0.copy(), m0.copy()
+        assert O.adaptor_step(0 if mode == "velocity" else 1, rc0, m_ref, act, 0, DT, dtc) == 0
+        tgt = np.concatenate([r0[:, 0:3], np.zeros((n, 7))], 1)
+        if mode == "velocity":
+            nrm = np.linalg.norm(act[:, 0:3], axis=1, keepdims=True)
+            tgt[:, 3:6] = t.max_speed_kmh / 3.6 * np.abs(act[:, 3:4]) * np.divide(act[:, 0:3], nrm, out=np.zeros((n, 3)), where=nrm > 0)
+        assert_control_parity(f"fuzz adaptor[{mode}] control", [t], None, r0, m0, tgt, got_m, m_ref, dtc)
+        r_ref = r0.copy()
+        a6 = np.zeros((n, 6)); a6[:, :4] = got_m[:, 7:11]
+        O.physics(r_ref, got_m.copy(), sub, DT, action=a6, noise=_noise_block(O, [t], None, n, noise_seed, steps, sub))
+        assert_step_parity(f"fuzz adaptor[{mode}] physics", [t], None, r0, got_m, tgt, got_r, None, r_ref, None, DT, dtc, sub,
+                           control=False, action=got_m[:, 7:11], extra_terms=noise_terms([t], None, n, DT, sub))
+        _check_obs_rows(f"fuzz adaptor[{mode}] rows", O, obs.double().cpu().numpy(), f32(got_r), a6, None, [t])
+        steps += 1
+    env.close()
