@@ -69,6 +69,20 @@ def main():
             rows = blk[off: off + n * 28].view(n, 28)
             out.append((d_gib, round(t(rows), 1)))
         print("E arena: state at 20 GiB, rows at D GiB:", out, flush=True)
+        # F: the OTHER arrays of the launch — the echoed action (written, 16 B per drone) and the action (read): state at the
+        # start of the arena, rows one window on; echo / action in the state's window or in the rows'
+        env._move_state(blk[:nst].view(old_state.shape))
+        rows = blk[17 * gib // 4: 17 * gib // 4 + n * 28].view(n, 28)
+        keep_la, keep_ab = env._last_action, env._action_buf
+        out = []
+        for name, e_gib, a_gib in (("echo+action as torch put them", None, None), ("echo in the state's window", 4, None),
+                                   ("echo in the rows' window", 19, None), ("echo and action in the state's window", 4, 5),
+                                   ("echo and action in the rows' window", 19, 20), ("echo rows' window, action state's", 19, 5)):
+            env._last_action = keep_la if e_gib is None else blk[e_gib * gib // 4: e_gib * gib // 4 + keep_la.numel()].view(keep_la.shape)
+            env._action_buf = keep_ab if a_gib is None else blk[a_gib * gib // 4: a_gib * gib // 4 + keep_ab.numel()].view(keep_ab.shape)
+            env._last_action.zero_(); env._action_buf.fill_(0.4)
+            out.append((name, round(t(rows), 1)))
+        print("F arena, state at 0, rows at 17 GiB:", out, flush=True)
         return
     a = torch.zeros((n, 28), dtype=torch.float32, device=ctx.device)
     print("A torch rows", hex(a.data_ptr()), round(t(a), 1), "state", hex(env.state.data.data_ptr()), flush=True)
