@@ -371,7 +371,7 @@ def child_line(a, extra, placement=True, timeout=300):
 
 def placement_cost(log):
     """What the searches of a run cost: seconds spent, the most device memory held at once (transient), and what stays
-    held for the life of the fleet (the 16 GiB window of an arena that was kept: placement.window_arena)."""
+    held for the life of the fleet (the room for two target blocks behind a placed fleet's state block)."""
     rows = [r for r in (log or []) if "seconds" in r]
     return {"placement_s": round(sum(r["seconds"] for r in rows), 3),
             "placement_peak_bytes": max([max(r.get("peak_bytes", 0), r.get("bytes", 0) if "held_bytes" in r else 0) for r in rows] + [0]),

@@ -42,10 +42,12 @@ a walk that could time nothing falls back to a plain zeroed array.  Every search
 `peak_bytes`.  The rows' walk strides (1 GiB of untimed ballast behind every candidate, `STRIDE_BYTES`) and may hold 34 GiB
 for the fraction of a second it takes: back-to-back candidates within 16 GiB — round 3's walk — all timed alike (159-165 us)
 on this round's boxes, where a striding walk finds 143 us from its third candidate on (tools/region_probe.py,
-profiles/r04_region_probe.txt): the walk has to LEAVE the 16 GiB region the state block lies in.  When even that walk finds
-every candidate alike, `window_arena` offers the one layout the probes show to be deterministic — state block and written
-arrays one 16 GiB window apart inside ONE allocation — which the caller keeps only where it clearly wins, since it holds the
-window in between.
+profiles/r04_region_probe.txt): the walk has to LEAVE the 16 GiB region the state block lies in.  (One arena — state block and written
+arrays one 16 GiB window apart inside ONE allocation, the layout the probes show to be the good one in a fresh process — was
+tried as a fallback for a walk that finds every candidate alike and never beat the walk's best inside the product: removed.)
+Arrays that are READ beside the state (the targets of the fused step and of computeControl) want the state's OWN window:
+CtrlAviary moves a large fleet's state block once into a driver allocation with room for two target blocks right behind it
+(`_ensure_read_room`), and the targets' searches compare that block with a 4 GiB walk.
 """
 from __future__ import annotations
 
@@ -185,33 +187,3 @@ def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int
                        "seconds": round(time.perf_counter() - t_start, 4), "memory": "driver (dsim_dev_alloc)" if ctx is not None else "torch"})
     return keep
 
-
-WINDOW_BYTES = 16 << 30                       # device memory is organised in windows of this size (tools/region_probe.py --arena)
-
-
-def window_arena(ctx, n_state: int, n_written: int, report: Optional[list] = None, free_bytes: Optional[int] = None):
-    """ONE driver allocation of 16 GiB + the written arrays: (its first `n_state` floats, the `n_written` floats that begin one
-    window further on), or None when that is more than WALK_FRACTION of the free memory or the driver refuses.  Measured
-    (profiles/r04_arena_probe.txt, three boxes): with the state block at the start of such an allocation, Env.step's zero-sub-step
-    pass takes 163-173 us with the rows anywhere below 16 GiB and 140-143 us from 16 GiB on.  The block in between is not used:
-    the caller keeps the arena only where it wins clearly (`held_bytes` in the report says what that costs)."""
-    t_start = time.perf_counter()
-    nbytes = WINDOW_BYTES + 4 * int(n_written)
-    free = _free_bytes(ctx.device) if free_bytes is None else int(free_bytes)
-    entry = {"array": "arena: state block + written arrays one 16 GiB window apart", "bytes": nbytes, "free_bytes": free,
-             "budget_bytes": int(WALK_FRACTION * free), "held_bytes": nbytes}
-    blk = None
-    if nbytes <= WALK_FRACTION * free and 4 * int(n_state) <= WINDOW_BYTES:
-        try:
-            blk = _DriverBlock(ctx, (nbytes // 4,)).tensor()
-        except (MemoryError, RuntimeError):
-            blk = None
-    if blk is None:
-        entry.update(decided_by="no arena: too large for the budget, or refused by the driver", held_bytes=0)
-        if report is not None:
-            report.append(entry)
-        return None
-    entry["seconds"] = round(time.perf_counter() - t_start, 4)
-    if report is not None:
-        report.append(entry)
-    return blk[: int(n_state)], blk[WINDOW_BYTES // 4: WINDOW_BYTES // 4 + int(n_written)]

@@ -683,10 +683,10 @@ def test_observation_rows_are_placed_by_timing_zero_substep_passes(gpu):
         assert torch.equal(e.state.data.view(torch.int32), before) and torch.equal(e._last_action, la) and e.ground_contacts() == gc0
         o, _, _, _ = e.step(np.full((nd, 4), 0.5, dtype=np.float32))
         obs.append(o.obs if hasattr(o, "obs") else o)
-    log = envs[0].ctx.placement_log
+    log = [r for r in envs[0].ctx.placement_log if not r["array"].startswith("state block")]   # (the state's own move: below)
+    assert len(log) + 1 == len(envs[0].ctx.placement_log) and envs[0].ctx.placement_log[0]["array"].startswith("state block")
     arrays = [r["array"] for r in log]
-    assert arrays[0] == "per-drone targets" and arrays[1] == "observation rows" and len(arrays) <= 3
-    assert len(arrays) == 2 or arrays[2].startswith("arena")      # (every candidate of the walk timed alike: one arena was tried too)
+    assert arrays == ["per-drone targets", "observation rows"]
     for r in log[:2]:
         assert 2 <= r["candidates"] and 0 <= r["chosen"] < r["candidates"] and 0 < r["chosen_pass_us"] <= r["first_pass_us"]
     assert envs[1].ctx.placement_log == []
@@ -706,7 +706,7 @@ def test_observation_rows_are_placed_by_timing_zero_substep_passes(gpu):
             cmd, pos_e, yaw_e = ctrl.computeControlFromState(1 / 240, None, target_pos=tp, target_rpy=np.array([0.0, 0.0, 0.3]))
         res.append((cmd.clone(), pos_e.clone(), yaw_e.clone()))
     assert [r["array"] for r in envs[0].ctx.placement_log
-            if r["array"] != "observation rows" and not r["array"].startswith("arena")] == ["per-drone targets", "computeControl outputs"]
+            if r["array"] != "observation rows" and not r["array"].startswith("state block")] in (["per-drone targets", "computeControl outputs"], ["per-drone targets", "computeControl outputs", "computeControl targets"])
     assert envs[1].ctx.placement_log == []
     assert torch.equal(envs[0].state.data, envs[1].state.data)
     for x, y in zip(res[0], res[1]):
@@ -715,43 +715,42 @@ def test_observation_rows_are_placed_by_timing_zero_substep_passes(gpu):
         e.close()
 
 
-def test_state_block_is_tried_elsewhere_when_every_candidate_for_the_rows_times_alike(gpu, monkeypatch):
-    """When the walk finds every candidate for the observation rows alike, none of them may be a good one: CtrlAviary then
-    tries ONE arena — a single driver allocation with the state block at its start and the written arrays one 16 GiB window
-    further on (round 3 moved the state to a fresh allocation and walked again) — and keeps it only if it is clearly faster.
-    Forced here by a walk that reports a flat result; whichever stays, the env steps exactly as one with plainly allocated
-    arrays does, and the report says what is held."""
+def test_state_block_of_a_placed_fleet_moves_once_into_its_own_allocation(gpu):
+    """A large fleet with placement on moves its state block ONCE into a driver allocation with room for two target blocks
+    behind it (arrays read beside the state want the state's own window of device memory: _ensure_read_room), before anything
+    is timed against it; the fused step's targets and a bound controller's targets may take that room.  Whatever the
+    searches decide, the env steps exactly as one with plainly allocated arrays does, and the report says what is held."""
     nat, fleet = gpu
-    from dronesim_amd import placement
+    from dronesim_amd.control import INDIControl
     from dronesim_amd.envs import CtrlAviary
-    nd = 1 << 20
-    xyz = np.stack([np.arange(nd) % 1024, np.arange(nd) // 1024, np.full(nd, 1.5)], 1).astype(np.float64)
-    real, calls = placement.place_rows, []
-
-    def flat_first(device, shape, trial, **kw):
-        out = real(device, shape, trial, **kw)
-        calls.append(len(calls))
-        if len(calls) == 1 and kw.get("report"):
-            kw["report"][-1]["decided_by"] = "all alike"
-        return out
-    monkeypatch.setattr(placement, "place_rows", flat_first)
+    from dronesim_amd.fleet import Targets, frozen
+    nd = 1 << 21
+    xyz = np.stack([np.arange(nd) % 2048, np.arange(nd) // 2048, np.full(nd, 1.5)], 1).astype(np.float64)
     envs = [CtrlAviary(["robobee"], nd, initial_xyzs=xyz, aggregate_phy_steps=1, noise_seed=9, dict_io=False, placement=p)
             for p in (True, False)]
-    obs = []
+    res = []
     for e in envs:
         ptr = e.state.data.data_ptr()
-        for a in (0.45, 0.5, 0.55):
-            o, _, _, _ = e.step(np.full((nd, 4), a, dtype=np.float32))
-        obs.append((o.obs if hasattr(o, "obs") else o).clone())
+        tg = Targets(e.ctx, nd)
+        tg.set(pos=torch.from_numpy(f32(xyz + 0.05).T.astype(np.float32)).to(e.ctx.device), yaw=0.1)
+        e.step_fused(tg, action=np.full((nd, 4), 0.45, dtype=np.float32))
+        e.step_fused(tg)
+        ctrl = INDIControl("robobee", env=e)
+        tp = frozen(torch.from_numpy(f32(xyz + 0.1)).to(e.ctx.device))
+        cmd = torch.full((nd, 4), 0.45, device=e.ctx.device)
+        for _ in range(3):
+            o, _, _, _ = e.step(cmd)
+            cmd, pos_e, yaw_e = ctrl.computeControlFromState(1 / 240, None, target_pos=tp, target_rpy=np.array([0.0, 0.0, 0.3]))
         e.moved = e.state.data.data_ptr() != ptr
+        res.append((e.state.data.clone(), o.clone(), cmd.clone(), pos_e.clone(), yaw_e.clone(), e.ground_contacts()))
     log = envs[0].ctx.placement_log
-    assert len(calls) == 1 and len(log) == 2 and log[1]["array"].startswith("arena") and not envs[1].moved
-    kept = log[1]["decided_by"].startswith("the arena is clearly faster")
-    assert envs[0].moved == kept and (log[1]["held_bytes"] > placement.WINDOW_BYTES) == kept
-    assert "walk_best_us" in log[1] and log[1]["bytes"] <= log[1]["budget_bytes"]
-    assert envs[0]._written_tail.shape == (8, envs[0].state.n_pad) and envs[1]._written_tail is None
-    assert torch.equal(envs[0].state.data, envs[1].state.data) and torch.equal(obs[0], obs[1])
-    assert envs[0].ground_contacts() == envs[1].ground_contacts()
+    assert envs[0].moved and not envs[1].moved and envs[1].ctx.placement_log == []
+    assert log[0]["array"].startswith("state block") and log[0]["held_bytes"] == 2 * 4 * nat.NT * envs[0].state.n_pad
+    assert [r["array"] for r in log[1:]] == ["per-drone targets", "observation rows", "computeControl outputs", "computeControl targets"]
+    for r in (log[1], log[4]):
+        assert r["behind_the_state_pass_us"] > 0 and r["candidates"] >= 2
+    for x, y in zip(res[0], res[1]):
+        assert (torch.equal(x, y) if torch.is_tensor(x) else x == y)
     for e in envs:
         e.close()
 

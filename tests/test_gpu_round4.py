@@ -544,7 +544,7 @@ def test_placement_of_rows_on_hexa_and_reordered_fleets_changes_nothing(gpu, kin
         res.append((e.state.data.clone(), obs.clone(), cmd.clone(), pos_e.clone(), yaw_e.clone(), e.ground_contacts()))
         if p:
             log = list(e.ctx.placement_log)
-            assert [r["array"] for r in log if r["array"] != "observation rows" and not r["array"].startswith("arena")] == ["computeControl outputs"]
+            assert [r["array"] for r in log if r["array"] != "observation rows" and not r["array"].startswith("state block")] in (["computeControl outputs"], ["computeControl outputs", "computeControl targets"])      # (targets: only from 64 MB on)
             rows = [r for r in log if r["array"] == "observation rows"]
             assert len(rows) == 1 and rows[0]["memory"].startswith("driver") and rows[0]["candidates"] >= 2
             assert rows[0]["candidates"] * rows[0]["bytes"] <= rows[0]["peak_bytes"] <= rows[0]["budget_bytes"]     # (+ the ballast strides)

@@ -83,6 +83,35 @@ def main():
             env._last_action.zero_(); env._action_buf.fill_(0.4)
             out.append((name, round(t(rows), 1)))
         print("F arena, state at 0, rows at 17 GiB:", out, flush=True)
+        env._last_action, env._action_buf = keep_la, keep_ab
+        # G: computeControl (k_control_fast): state at 0; its targets (read) and its outputs (written) in either window
+        from dronesim_amd.control import INDIControl
+        from dronesim_amd.fleet import frozen
+        ctrl = INDIControl("robobee", env=env)
+        tp = frozen(torch.from_numpy(xyz.astype(np.float32)).to(ctx.device))
+        ctrl._outputs_placed = True
+
+        def tc():
+            for _ in range(3):
+                ctrl.computeControlFromState(1 / 240, None, target_pos=tp)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                ctrl.computeControlFromState(1 / 240, None, target_pos=tp)
+            e1.record(); e1.synchronize()
+            return round(e0.elapsed_time(e1) * 100, 1)
+        out = [("as torch put them", tc())]
+        tdata, n_pad = ctrl._targets.data, env.state.n_pad
+        for name, t_gib, o_gib in (("targets state's window, outputs rows' window", 4, 19), ("targets rows' window, outputs rows' window", 21, 19),
+                                   ("targets state's window, outputs state's window", 4, 6), ("targets rows' window, outputs state's window", 21, 6)):
+            nt = blk[t_gib * gib // 4: t_gib * gib // 4 + tdata.numel()].view(tdata.shape)
+            nt.copy_(tdata)
+            ctrl._targets.data = nt
+            ob = blk[o_gib * gib // 4: o_gib * gib // 4 + 8 * n_pad].view(8, n_pad)
+            ctrl._cmd, ctrl._pos_e, ctrl._yaw_e = ob[0:4], ob[4:7], ob[7]
+            ctrl._plan = None
+            out.append((name, tc()))
+        print("G computeControl, state at 0:", out, flush=True)
         return
     a = torch.zeros((n, 28), dtype=torch.float32, device=ctx.device)
     print("A torch rows", hex(a.data_ptr()), round(t(a), 1), "state", hex(env.state.data.data_ptr()), flush=True)
