@@ -375,7 +375,7 @@ def placement_cost(log):
     rows = [r for r in (log or []) if "seconds" in r]
     return {"placement_s": round(sum(r["seconds"] for r in rows), 3),
             "placement_peak_bytes": max([max(r.get("peak_bytes", 0), r.get("bytes", 0) if "held_bytes" in r else 0) for r in rows] + [0]),
-            "placement_held_bytes": sum(r.get("held_bytes", 0) for r in rows), "searches": len(rows)}
+            "placement_held_bytes": sum(r.get("held_bytes", 0) for r in (log or [])), "searches": len(rows)}
 
 
 def two_call_child(a, kind="quad", placement=True):
