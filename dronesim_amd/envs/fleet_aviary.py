@@ -675,8 +675,20 @@ class CtrlAviary:
                 def split(block):
                     self._obs_buf = block[:n_rows].view(shape)
                     self._written_tail = block[n_rows:].view(self.n_act + 4, self.state.n_pad)
-                split(placement.place_rows(self.ctx.device, flat, self._rows_trial, report=log, ctx=self.ctx,
-                                           stride_bytes=placement.STRIDE_BYTES))
+                # (never worse than no search: the plain allocation is timed too and kept when the walk's best is not faster —
+                # on some boxes no block the driver hands out lies well, and PyTorch's may lie better)
+                plain = torch.zeros(flat, dtype=torch.float32, device=self.ctx.device)
+                t_plain = placement._event_timer(self._rows_trial, plain, 3)
+                block = placement.place_rows(self.ctx.device, flat, self._rows_trial, report=log, ctx=self.ctx,
+                                             stride_bytes=placement.STRIDE_BYTES)
+                if log:
+                    log[-1]["plain_pass_us"] = round(t_plain, 1)
+                    if t_plain <= 1.005 * log[-1].get("chosen_pass_us", 0.0):
+                        plain.zero_()
+                        block = plain
+                        log[-1]["decided_by"] = "the plain allocation is as fast as the walk's best: kept"
+                split(block)
+                del plain, block
                 # (When every candidate times alike there is nothing more to try.  Round 3 moved the state block to a fresh
                 # allocation and walked again; round 4 tried one arena — state block and written arrays one 16 GiB window apart
                 # in a single allocation, the layout tools/region_probe.py --arena shows to be the good one in a fresh process —

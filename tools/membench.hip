@@ -407,13 +407,15 @@ int main(int argc, char** argv) {
     // ONE 24 GB allocation; the state block at its start, the rows D bytes further on, D in steps of 128 MiB: is the
     // behaviour a function of the distance inside one allocation?
     const dim3 g((unsigned)((n + 255) / 256)), b(256);
-    const size_t total = 24ull << 30, sz_st = sizeof(float) * FS * n, sz_a = sizeof(float) * 4 * n, sz_r = sizeof(float) * 20 * n;
+    // (DSIM_SWEEP_GIB: a larger allocation and coarser steps, to look for windows wider than 16 GiB)
+    const char* sg = getenv("DSIM_SWEEP_GIB");
+    const size_t total = (sg ? (size_t)atoi(sg) : 24ull) << 30, sz_st = sizeof(float) * FS * n, sz_a = sizeof(float) * 4 * n, sz_r = sizeof(float) * 20 * n;
     char* arena; CK(hipMalloc(&arena, total)); CK(hipMemset(arena, 0, total));
     float* st = (float*)arena; float* act = (float*)(arena + sz_st); float* echo = (float*)(arena + sz_st + sz_a);
     float* sink; CK(hipMalloc(&sink, 256));
     const long long n4 = (256u << 20) / 16;
     const dim3 g4((unsigned)((n4 + 255) / 256));
-    for (size_t D = sz_st + 2 * sz_a; D + sz_r <= total; D += 512ull << 20) {
+    for (size_t D = sz_st + 2 * sz_a; D + sz_r <= total; D += (sg ? 4096ull : 512ull) << 20) {
       float* rows = (float*)(arena + D);
       const float t3 = time_it([&] { hipLaunchKernelGGL(k_env_shape<true>, g, b, 0, 0, st, act, echo, rows, n); }, 6);
       const float tp = time_it([&] { hipLaunchKernelGGL(k_pair<3>, g4, b, 0, 0, (f4*)arena, (f4*)(arena + D), sink, n4); }, 6);
