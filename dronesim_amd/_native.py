@@ -22,7 +22,7 @@ EXPORTS = (
     "dsim_halo_pack", "dsim_downwash_workspace_halo", "dsim_dev_alloc", "dsim_dev_free",
 )
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_PEERS = 8
 HALO_HDR = 8           # header floats of a halo message (DSIM_HALO_HDR)
 DW_ALL, DW_LOCAL, DW_HALO_BIN, DW_HALO_QUERY = 0, 1, 2, 3
@@ -37,6 +37,8 @@ OPT_PLANE = 1 << 10        # ground-plane contact (product-defined model, oracle
 OPT_DEFER_FALLBACK = 1 << 11   # the caller launches dsim_wls_fallback itself (scheduling only)
 OPT_CALLER_IO = 1 << 14    # dsim_physics / dsim_control2: action, rows, command, errors indexed by drone_id[i] (the caller's numbering)
 OPT_ACTION_ROWS = 1 << 15  # dsim_step_adaptor: the action row-major [n][4]
+OPT_DYN = 1 << 16          # Physics.DYN: BaseAviary._dynamics instead of the Bullet step (StepArgs.dyn_rpy_rates required)
+OPT_DYN_BODY_RATES = 1 << 17   # ... with ang_v = R(quat) rpy_rates instead of the reference's placeholder (-1, -1, -1)
 ADAPT_VELOCITY, ADAPT_RPYT = 0, 1
 QUERY_WLS_FALLBACKS, QUERY_WLS_FAILURES, QUERY_GROUND_CONTACTS, QUERY_HALO_OVERFLOW = 0, 1, 2, 3
 
@@ -77,6 +79,7 @@ class StepArgs(ctypes.Structure):
         ("obs_out", ctypes.c_void_p),
         ("bin_next", ctypes.c_void_p),
         ("drone_id", ctypes.c_void_p),
+        ("dyn_rpy_rates", ctypes.c_void_p),
     ]
 
 

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #include <new>
 
@@ -172,6 +173,7 @@ struct StepK {
   const int* io_id;           // DSIM_OPT_CALLER_IO: = drone_id, the per-drone arrays beside the state are indexed by it; else null
   unsigned hexa_types;        // bit t set: type t of the table is a morphing hexa (26 state fields in use)
   BinK bin;                   // grid of the next Env.step's downwash (k_step_mixed / k_step_run), count = null: none
+  float* dyn_rates;           // Physics.DYN: BaseAviary.rpy_rates, SoA [3][n_pad] in-out (k_dyn only)
 };
 
 // Global accesses.  NT = nontemporal (streaming) hint: each state field is read once and written
@@ -1116,6 +1118,71 @@ __global__ __launch_bounds__(256, 1) void k_physics_plane(StepK a) {     // DSIM
   if (i >= a.n_pad) return;
   const Addr ad = make_addr(a, i0, p);
   DSIM_FOR_MY_TYPE(UNIFORM, a, i, (physics_gen_body<NOISE, NACT, true>(T, a, i, ad)));
+}
+
+// ---- Physics.DYN ----------------------------------------------------------------------------------------------------------
+// BaseAviary.step with PHYSICS == Physics.DYN (BaseAviary.py:510-545: the loop calls _dynamics(clipped_action, i) per drone
+// and sub-step, :525-527, and skips p.stepSimulation, :541-543): the reference's own explicit model (dsim_device.h:dyn_substep)
+// on quad types, any fleet size (ragged tails included), per-lane type ids of a table of quads by the waterfall.  One kernel
+// family for both entry points:
+//   CTRL = false  dsim_physics: Env.step — the action clipped (CtrlAviary.py:258-263) and echoed, the sub-steps, the 13
+//                 rigid floats and the three rpy rates written back
+//   CTRL = true   dsim_step: the same followed by computeControl on the new state, as the example loop orders them
+//                 (examples/fly_INDI.py:223-239); an explicit action serves the physics part only
+// Reads 13 + 3 (+ 4 | + 11 + 10), writes 13 + 3 (+ 4 | + 11) floats per drone: bound by HBM like every other single-launch
+// form; no noise (the model has none), no ground-plane watch (the pose is SET, :1814-1819: no engine step, no contact).
+template <bool CTRL, bool NT, class DT>
+__device__ __forceinline__ void dyn_body(DT& T, const StepK& a, long long i0, const Addr& ad) {
+  // (per-drone arrays beside the state: wave-uniform base + the lane's byte offset, like the state's own accesses)
+  const unsigned lo = 4u * threadIdx.x;
+  float* const rb = a.dyn_rates + i0;
+  Rigid s;
+  load_rigid<NT>(ad.sb, ad.sfs, ad.sl, s);
+  V3 rr = v3(ldg<NT>(rb, lo), ldg<NT>(rb + a.n_pad, lo), ldg<NT>(rb + 2 * a.n_pad, lo));     // self.rpy_rates, :1785
+  CtrlMem<4> m;
+  Target tg;
+  float cmd[4];
+  if (CTRL) {
+    load_mem<4, NT>(ad.sb, ad.sfs, ad.sl, m);
+    load_target<NT>(ad.tb, ad.tfs, ad.tl, tg);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float raw = a.action ? ldg<NT>(a.action + (long long)j * a.n_pad + i0, lo)
+                               : (CTRL ? m.cmd[j] : ldg<NT>(ad.sb + (20 + j) * ad.sfs, ad.sl));
+    cmd[j] = clampf(raw, T.pmin[j], T.pmax[j]);                                               // CtrlAviary.py:258-263
+  }
+  const DynBase b = dyn_base(T, cmd);
+  for (int k = 0; k < a.substeps; ++k) dyn_substep(T, a.dt_phys, b, s, rr);
+  const V3 w_new = dyn_reported_ang_vel((a.options & DSIM_OPT_DYN_BODY_RATES) != 0, s.q, rr);  // :1821-1826
+  if (a.substeps > 0) s.w = w_new;
+  if (CTRL) {
+    V3 pos_e;
+    float yaw_e;
+    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  }
+  const unsigned so = pin_lane_offset(ad.sl), lo2 = pin_lane_offset(lo);
+  store_rigid<NT>(ad.sb, ad.sfs, so, s);
+  stg<NT>(rb, lo2, rr.x); stg<NT>(rb + a.n_pad, lo2, rr.y); stg<NT>(rb + 2 * a.n_pad, lo2, rr.z);   // :1828
+  if (CTRL) store_mem<4, NT>(ad.sb, ad.sfs, so, m);
+  if (!CTRL && a.echo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stg<NT>(a.echo + (long long)j * a.n_pad + i0, lo2, cmd[j]);    // last_clipped_action, :545
+  }
+}
+template <bool CTRL, bool NT>
+__global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_dyn(StepK a) {
+  const long long i0 = (long long)blockIdx.x * 256;
+  const long long i = i0 + threadIdx.x;
+  if (i >= a.n_pad) return;
+  const Addr ad = make_addr(a, i0, threadIdx.x);
+  // one body for homogeneous and mixed quad fleets: the wave peels one type per turn (a homogeneous fleet: one turn), the
+  // type's constants through the constant address space at a wave-uniform index (scalar loads)
+  const int my_t = a.type_id ? (int)a.type_id[i] : 0;
+  for (;;) {
+    const int cur_t = __builtin_amdgcn_readfirstlane(my_t);
+    if (my_t == cur_t) { dyn_body<CTRL, NT>(dev_type(a.types, cur_t), a, i0, ad); break; }
+  }
 }
 
 // ---- computeControl only ----------------------------------------------------
@@ -2739,6 +2806,14 @@ static void to_dev(const dsim_type_params& p, DevType* d) {
   d->mu_plane = (float)p.contact_friction;
   for (int k = 0; k < 3; ++k) d->base_off[k] = (float)p.base_offset[k];
   d->watch_below = (float)(p.collision_below + p.base_offset[2]);    // (the offset of the shipped hexa is along body z)
+  // Physics.DYN: the mixer of BaseAviary.py:1794-1803 as a lever per rotor
+  const double lx = p.dyn_mixer == DSIM_DYN_MIXER_PLUS ? p.arm : p.arm / sqrt(2.0);
+  const double mx_x[4] = {1, 1, -1, -1}, my_x[4] = {-1, 1, 1, -1}, mx_p[4] = {0, 1, 0, -1}, my_p[4] = {-1, 0, 1, 0};
+  for (int i = 0; i < 4; ++i) {
+    d->dyn_lever[0][i] = (float)((p.dyn_mixer == DSIM_DYN_MIXER_PLUS ? mx_p[i] : mx_x[i]) * lx);
+    d->dyn_lever[1][i] = (float)((p.dyn_mixer == DSIM_DYN_MIXER_PLUS ? my_p[i] : my_x[i]) * lx);
+  }
+  d->weight = (float)(p.gravity * p.mass);
 }
 
 // measured-and-rejected kernel forms, for A/B builds only (tools/variants/; never in the product library)
@@ -2920,6 +2995,7 @@ static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const ds
   a->drone_id = args->drone_id;
   a->io_id = (args->options & DSIM_OPT_CALLER_IO) ? args->drone_id : nullptr;
   a->action_rows = (args->options & DSIM_OPT_ACTION_ROWS) ? 1 : 0;     // (honoured by the entry points that check it)
+  a->dyn_rates = args->dyn_rpy_rates;
   return DSIM_OK;
 }
 
@@ -3066,11 +3142,34 @@ static int side_by_side_map(dsim_ctx* ctx, hipStream_t st, const dsim_type_run* 
   return DSIM_OK;
 }
 
+// Physics.DYN (DSIM_OPT_DYN): what the mode does not combine with is refused, not dropped
+static int dyn_check(const dsim_ctx* ctx, const dsim_step_args* args, const StepK& a) {
+  if (!args->dyn_rpy_rates) return DSIM_E_ARG;
+  if (ctx->max_act != 4) return DSIM_E_UNSUPPORTED;             // both mixers of BaseAviary.py:1794-1803 read forces[0..3]
+  if (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND | DSIM_OPT_PLANE | DSIM_OPT_CHAINED | DSIM_OPT_CALLER_IO | DSIM_OPT_ACTION_ROWS))
+    return DSIM_E_UNSUPPORTED;
+  if (args->ext_force || args->wp_table || a.n_steps > 1 || args->bin_next) return DSIM_E_UNSUPPORTED;   // (step_index_dev only moves the noise counter: no noise here)
+  return DSIM_OK;
+}
+static int dyn_launch(bool ctrl, const StepK& a, bool nt, hipStream_t st) {
+  const dim3 g(grid_for(a.n_pad)), b(256);
+  if (ctrl) { if (nt) hipLaunchKernelGGL((k_dyn<true, true>), g, b, 0, st, a); else hipLaunchKernelGGL((k_dyn<true, false>), g, b, 0, st, a); }
+  else { if (nt) hipLaunchKernelGGL((k_dyn<false, true>), g, b, 0, st, a); else hipLaunchKernelGGL((k_dyn<false, false>), g, b, 0, st, a); }
+  return (int)hipGetLastError();
+}
+
 int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
               const dsim_step_args* args) {
   StepK a;
   int rc = fill_stepk(ctx, n, state, &targets, args, &a);
   if (rc) return rc;
+  if (args->options & DSIM_OPT_DYN) {
+    rc = dyn_check(ctx, args, a);
+    if (rc) return rc;
+    if (!a.tg.base) return DSIM_E_ARG;
+    ctx->dw_prebin_valid = false;
+    return dyn_launch(true, a, stream_policy(args, state.n_pad, 256.0), (hipStream_t)stream);
+  }
   if (args->options & DSIM_OPT_CALLER_IO) return DSIM_E_UNSUPPORTED;     // (dsim_physics / dsim_control2 only)
   ctx->dw_prebin_valid = false;      // the positions move: a grid binned before this call is stale (bin_next_commit re-validates)
   const bool noise = args->noise_seed != 0 || args->noise_replay != nullptr;
@@ -3345,6 +3444,15 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
   if (rc) return rc;
   ctx->dw_prebin_valid = false;
   a.echo = last_action_out;
+  if (args->options & DSIM_OPT_DYN) {
+    rc = dyn_check(ctx, args, a);
+    if (rc) return rc;
+    if (args->obs_out && args->obs_width != 20) return DSIM_E_ARG;
+    rc = dyn_launch(false, a, stream_policy(args, state.n_pad, 160.0), (hipStream_t)stream);
+    if (rc) return rc;
+    if (args->obs_out) return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, 20, 0);
+    return DSIM_OK;
+  }
   const bool phys_opts = (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND | DSIM_OPT_PLANE)) != 0;
   if ((args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)) && ctx->max_act == 6) return DSIM_E_UNSUPPORTED;
   const int obs_w = 16 + ctx->max_act;
@@ -3443,7 +3551,7 @@ int dsim_step_adaptor(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, c
     return DSIM_E_UNSUPPORTED;        // plain PYB physics (+ the plane): refuse what the adaptor kernels would silently drop
   int rc = fill_stepk(ctx, n, state, nullptr, args, &a);
   if (rc) return rc;
-  if (args->options & DSIM_OPT_CALLER_IO) return DSIM_E_UNSUPPORTED;
+  if (args->options & (DSIM_OPT_CALLER_IO | DSIM_OPT_DYN)) return DSIM_E_UNSUPPORTED;   // (the adaptor envs fly Physics.PYB)
   ctx->dw_prebin_valid = false;
   a.action = action; a.echo = last_action_out;
   const bool noise = args->noise_seed != 0, uni = args->type_id == nullptr;

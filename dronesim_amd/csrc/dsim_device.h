@@ -39,6 +39,8 @@ struct DevType {
   float mu_plane;                             // DSIM_OPT_PLANE: Coulomb coefficient against the plane
   float base_off[3];                          // integrated COM -> the reported point (base link COM), body frame
   float watch_below;                          // coll_below seen from the reported point (ground-plane watch)
+  float dyn_lever[2][4];                      // Physics.DYN: x / y torque per unit force of rotor i (the mixer of BaseAviary.py:1794-1803 times its lever)
+  float weight;                               // Physics.DYN: GRAVITY = G M (BaseAviary.py:226)
 };
 
 // The table is written once (dsim_create) and only read by kernels, which read it through the CONSTANT address space.  A
@@ -513,6 +515,49 @@ __device__ __forceinline__ void bullet_step(DT& T, float dt, Rigid& s, V3 F_body
   n.z = cw * q.z + az * q.w + ax * q.y - ay * q.x;
   const float inv = DSIM_RSQ(n.x * n.x + n.y * n.y + n.z * n.z + n.w * n.w);
   s.q = Q4{n.x * inv, n.y * inv, n.z * inv, n.w * inv};
+}
+
+// D1: BaseAviary._dynamics, BaseAviary.py:1767-1828 — the reference's OWN explicit rigid-body model (Physics.DYN), restated
+// line for line in oracle/dsim_oracle.c:orc_dynamics and pinned there by tests/golden/dynamics.npz (the reference's function
+// run on recorded inputs).  The command is constant over the sub-steps of an Env.step (BaseAviary.py:510-545), so thrust and
+// the three mixer torques are formed once (DynBase; the x / y sums cancel to ~1e-3 of their terms: fp64, rounded once, as
+// quad_wrench_base does); the sub-step is the state update.  rr = self.rpy_rates; s.w is not touched.
+struct DynBase { float thrust; V3 tq; };
+template <class DT>
+__device__ __forceinline__ DynBase dyn_base(DT& T, const float cmd[4]) {
+  double th = 0.0, tx = 0.0, ty = 0.0;
+  float tz = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float rpm = T.scale[i] * cmd[i] + T.cnst[i];              // the fork's PWM -> RPM map, BaseAviary.py:1487-1490
+    const float f = rpm * rpm * T.kf, t = rpm * rpm * T.km;          // :1788, 1792
+    th += (double)f;                                                 // :1789
+    tx += (double)T.dyn_lever[0][i] * (double)f;                     // :1794-1803
+    ty += (double)T.dyn_lever[1][i] * (double)f;
+    tz += (i & 1) ? t : -t;                                          // :1793
+  }
+  return DynBase{(float)th, V3{(float)tx, (float)ty, tz}};
+}
+template <class DT>
+__device__ __forceinline__ void dyn_substep(DT& T, float dt, const DynBase& b, Rigid& s, V3& rr) {
+  const Euler e = euler_from_quat<true>(s.q);                        // self.rpy as _updateAndStoreKinematicInformation stores it, :729
+  const Q4 q = s.q;                                                  // third column of getMatrixFromQuaternion(quat), :1786
+  const float sc = 2.0f * DSIM_RCP(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  const V3 bz = v3((q.x * q.z + q.w * q.y) * sc, (q.y * q.z - q.w * q.x) * sc, 1.0f - (q.x * q.x + q.y * q.y) * sc);
+  const V3 acc = v3(bz.x * b.thrust * T.inv_mass, bz.y * b.thrust * T.inv_mass, (bz.z * b.thrust - T.weight) * T.inv_mass);   // :1790-1791, 1807
+  const V3 Jw = v3(T.J[0] * rr.x, T.J[1] * rr.y, T.J[2] * rr.z);
+  const V3 gy = cross(rr, Jw);                                       // :1805
+  const V3 rd = v3((b.tq.x - gy.x) * T.invJ[0], (b.tq.y - gy.y) * T.invJ[1], (b.tq.z - gy.z) * T.invJ[2]);   // :1806
+  s.vel = s.vel + dt * acc;                                          // :1809
+  rr = rr + dt * rd;                                                 // :1810
+  s.pos = s.pos + dt * s.vel;                                        // :1811
+  s.q = quat_from_euler(v3(e.roll + dt * rr.x, e.pitch + dt * rr.y, e.yaw + dt * rr.z));   // :1812, 1817
+}
+// what p.getBaseVelocity reports after a DYN step: the placeholder the reference stores (:1821-1826), or — the product's
+// flyable deviation, DSIM_OPT_DYN_BODY_RATES — the world-frame image of the rates the model treats as body rates
+__device__ __forceinline__ V3 dyn_reported_ang_vel(bool body_rates, Q4 q, V3 rr) {
+  if (!body_rates) return v3(-1.0f, -1.0f, -1.0f);
+  return mul(matrix_from_quat(q), rr);
 }
 
 // C4: INDIControl._INDIRateControl, INDIControl.py:413-490 (also the whole of RPYTAviary's action

@@ -89,16 +89,27 @@ class CtrlAviary:
         downwash_split: Optional[bool] = None,
         defer_fallback: bool = False,
         placement: bool = True,
+        dyn_ang_vel: str = "reference",
     ):
         if gui or record or obstacles:
             raise NotImplementedError("gui/record/obstacles are rendering features outside the hot path")
-        if physics == Physics.DYN:
-            raise NotImplementedError("Physics.DYN (explicit rpy-Euler model, CF2X/CF2P mixers only, dead code in the "
-                                      "reference: BaseAviary.py:1767-1828) is not on the path")
-        # the add-on terms of the PYB_* modes (dead code in the reference fork, intended formulas)
+        # the add-on terms of the PYB_* modes (dead code in the reference fork, intended formulas); Physics.DYN: the
+        # reference's own explicit model, BaseAviary._dynamics (BaseAviary.py:1767-1828; DSIM_OPT_DYN)
         self._phys_options = {Physics.PYB: 0, Physics.PYB_DW: 0, Physics.PYB_GND: nat.OPT_GROUND,
-                              Physics.PYB_DRAG: nat.OPT_DRAG,
+                              Physics.PYB_DRAG: nat.OPT_DRAG, Physics.DYN: nat.OPT_DYN,
                               Physics.PYB_GND_DRAG_DW: nat.OPT_GROUND | nat.OPT_DRAG}[physics]
+        if dyn_ang_vel not in ("reference", "body_rates"):
+            raise ValueError(dyn_ang_vel)
+        if physics == Physics.DYN:
+            # What the state vector's ang_v holds under DYN.  "reference": the placeholder (-1, -1, -1) the reference stores
+            # ("ang_vel not computed by DYN", BaseAviary.py:1821-1826) — what its INDI controller then reads, which is why that
+            # loop tumbles.  "body_rates": R(quat) rpy_rates, a product-defined deviation with which the mode is flyable.
+            if dyn_ang_vel == "body_rates":
+                self._phys_options |= nat.OPT_DYN_BODY_RATES
+            if ground_plane:
+                raise ValueError("Physics.DYN sets the pose itself and skips p.stepSimulation (BaseAviary.py:541-543, "
+                                 "1814-1819): the ground plane never acts")
+            ground_plane = False
         # The reference always loads plane.urdf (BaseAviary.py:660).  ground_plane=True enforces z = 0 by the contact
         # model of oracle/dsim_oracle.c:orc_plane_contact (DSIM_OPT_PLANE, the general kernels); None = on for the
         # reference-sized fleets that get dict observations, off for the large in-flight fleets of the fast kernels,
@@ -194,6 +205,13 @@ class CtrlAviary:
                     arr[k].first, arr[k].count, arr[k].type = f, c, ty
                 self._runs = arr
         self.n_act = self.ctx.n_act
+        # Physics.DYN: the model's own state beside pos / quat / vel, BaseAviary.rpy_rates (BaseAviary.py:670-671, 1785, 1828)
+        self._dyn_rates = None
+        if physics == Physics.DYN:
+            if self.n_act != 4:
+                raise NotImplementedError("Physics.DYN: both mixers of BaseAviary._dynamics read forces[0..3] "
+                                          "(BaseAviary.py:1794-1803) — four-rotor types only")
+            self._dyn_rates = torch.zeros((3, self.state.n_pad), dtype=torch.float32, device=self.ctx.device)
         # A fleet stored in another order than the caller's: Env.step and a bound computeControl take and return their
         # per-drone arrays (action, observation rows, command, errors) in the CALLER's numbering straight from the kernels
         # (DSIM_OPT_CALLER_IO: the run kernels gather / scatter by drone_id) — no second pass over them.  Where the run
@@ -313,6 +331,7 @@ class CtrlAviary:
             a.runs, a.n_runs = ctypes.addressof(self._runs), len(self._runs)
         a.obs_out, a.obs_width, a.bin_next = None, 0, None
         a.drone_id = self.order.drone_id(self.state.n_pad).data_ptr() if self.order is not None else None
+        a.dyn_rpy_rates = self._dyn_rates.data_ptr() if self._dyn_rates is not None else None
         return a
 
     # ------------------------------------------------------------------ gym surface
@@ -344,6 +363,8 @@ class CtrlAviary:
         pos, rpy = self._soa3(self.INIT_XYZS), self._soa3(self.INIT_RPYS)
         vel = self._soa3(self.INIT_VELS) if self.INIT_VELS is not None else None
         self._last_action.zero_()                      # BaseAviary.py:660-663
+        if getattr(self, "_dyn_rates", None) is not None:
+            self._dyn_rates.zero_()                    # BaseAviary.py:670-671
         self._use_last_action = True
         nat.check(self.ctx.lib.dsim_reset(
             self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, self.state.view(), pos.data_ptr(),
@@ -352,7 +373,7 @@ class CtrlAviary:
         torch.cuda.current_stream(self.ctx.device).synchronize()   # host buffers above go out of scope
 
     def step(self, action):
-        """BaseAviary.step (BaseAviary.py:428-555) with Physics.PYB."""
+        """BaseAviary.step (BaseAviary.py:428-555): Physics.PYB and its add-on modes, or Physics.DYN."""
         self.materialize()
         self._chain_ok = False
         # The reference-shaped loop hands step() the tensor computeControl returned, every iteration the same object over
@@ -560,6 +581,14 @@ class CtrlAviary:
         nat.check(self.ctx.lib.dsim_reserve(self.ctx.handle, self.ctx.stream_ptr(), self.state.n_pad))
         self._graph_made = True
         return FusedGraph(self, targets, steps, control_timestep)
+
+    @property
+    def rpy_rates(self) -> torch.Tensor:
+        """Physics.DYN: BaseAviary.rpy_rates (BaseAviary.py:670-671, 1828) as [3, N] in the caller's numbering."""
+        if self._dyn_rates is None:
+            raise AttributeError("rpy_rates exists with Physics.DYN only (BaseAviary.py:670-671)")
+        r = self._dyn_rates[:, : self.NUM_DRONES]
+        return r if self.order is None else self.order.to_caller(r, 1)
 
     def ground_contacts(self) -> int:
         """Drone x Env.steps so far that ended with the vehicle's collision cylinder at or below z = 0 (cumulative over

@@ -30,6 +30,7 @@ MAX_ACT = 6
 KIND_QUAD = 0
 KIND_HEXA6DOF = 1
 KIND_HEXA_QUADLAW = 2     # morphing-hexa physics, quad INDI law on six actuators (hexa_6DOF_simple.urdf)
+DYN_MIXER_X, DYN_MIXER_PLUS = 0, 1     # Physics.DYN: DroneModel.CF2X / CF2P-HB mixers (BaseAviary.py:1794-1803)
 
 # Bullet's btMultiBody defaults are float literals (0.04f) held in double
 # precision builds; keeping the exact fp32 value makes fp32 (GPU) and fp64
@@ -76,6 +77,9 @@ class TypeParamsC(ctypes.Structure):
         ("collision_below", ctypes.c_double),
         ("contact_friction", ctypes.c_double),
         ("base_offset", ctypes.c_double * 3),
+        ("arm", ctypes.c_double),
+        ("dyn_mixer", ctypes.c_int32),
+        ("_pad_dyn", ctypes.c_int32),
     ]
 
 
@@ -118,6 +122,8 @@ class DroneType:
     collision_below: float = 0.0     # ... and extent below the COM (ground-plane watch; 0 = none)
     contact_friction: float = 0.5    # DSIM_OPT_PLANE: plane.urdf lateral_friction 1.0 x PyBullet's default 0.5 for the vehicle
     base_offset: Sequence[float] = (0.0, 0.0, 0.0)   # integrated COM -> the point PyBullet reports (base link COM), body frame
+    arm: float = 0.0                 # URDF <properties arm=...> (BaseAviary.py:2058): the lever L of Physics.DYN's mixer
+    dyn_mixer: int = DYN_MIXER_X     # Physics.DYN: which mixer of BaseAviary.py:1794-1803 (the examples' help text: "default: CF2X")
     reset_thrust: float = 0.0        # INDIControl.reset (INDIControl.py:127); 6DOF 0.3 (:232)
     reset_cmd: float = 0.0           # INDIControl.py:129; 6DOF 0.5 (:234)
     alloc: np.ndarray = field(default=None)  # type: ignore[assignment]
@@ -210,6 +216,7 @@ class DroneType:
         c.contact_friction = self.contact_friction
         for j in range(3):
             c.base_offset[j] = float(self.base_offset[j])
+        c.arm, c.dyn_mixer = float(self.arm), int(self.dyn_mixer)
         return c
 
     @property
@@ -252,7 +259,7 @@ def _robobee() -> DroneType:
         G1=np.array([[50.0, 50.0, -50.0, -50.0], [-50.0, 50.0, 50.0, -50.0],
                      [-7.0, 7.0, -7.0, 7.0], [1.7, 1.7, 1.7, 1.7]]),
         kp_pos=1.0, kd_pos=2.2, att_gain=(7.0, 7.0, 5.0), rate_gain=(18.0, 18.0, 10.0),
-        prop_radius=3.31348e-2, collision_radius=0.15, collision_below=0.05, **_AERO,      # robobee.urdf:72-77
+        prop_radius=3.31348e-2, collision_radius=0.15, collision_below=0.05, arm=0.0635, **_AERO,      # robobee.urdf:72-77, 31
     )
 
 
@@ -270,7 +277,7 @@ def _tello() -> DroneType:
         G1=np.array([[30.0, 30.0, -30.0, -30.0], [-30.0, 30.0, 30.0, -30.0],
                      [-5.0, 5.0, -5.0, 5.0], [1.7, 1.7, 1.7, 1.7]]),
         kp_pos=1.7, kd_pos=2.5, att_gain=(10.0, 10.0, 4.0), rate_gain=(12.0, 12.0, 7.0),
-        prop_radius=3.31348e-2, collision_radius=0.0475, collision_below=0.0205, **_AERO,   # tello.urdf:68-73
+        prop_radius=3.31348e-2, collision_radius=0.0475, collision_below=0.0205, arm=0.0635, **_AERO,   # tello.urdf:68-73, 27
     )
 
 
@@ -303,7 +310,7 @@ def _hexa_6dof() -> DroneType:
                      [-5.0, 5.0, -5.0, 5.0, -5.0, 5.0], [-2.0, 4.0, -2.0, -2.0, 4.0, -2.0],
                      [-3.0, 0.0, 3.0, -3.0, 0.0, 3.0], [1.5, 1.5, 1.5, 1.5, 1.5, 1.5]]),
         kp_pos=1.7, kd_pos=2.5, att_gain=(10.0, 10.0, 5.0), rate_gain=(18.0, 18.0, 12.0),
-        prop_radius=6.7e-2, reset_thrust=0.3, reset_cmd=0.5,
+        prop_radius=6.7e-2, reset_thrust=0.3, reset_cmd=0.5, arm=1.0635,
         collision_radius=0.18986507827381124, collision_below=0.06903716345121234,   # all links' <collision> shapes
         base_offset=(-1.1106382076676865e-05, -1.111343640005967e-06, 0.010962836548787658),   # mainbody COM - composite COM
         **_AERO,
@@ -323,7 +330,7 @@ def _hexa_6dof_simple() -> DroneType:
         G1=np.array([[-7.5, -15.0, -7.5, 7.5, 15.0, 7.5], [-13.0, 0.0, 13.0, 13.0, 0.0, -13.0],
                      [-5.0, 5.0, -5.0, 5.0, -5.0, 5.0], [1.7, 1.7, 1.7, 1.7, 1.7, 1.7]]),
         kp_pos=t.kp_pos, kd_pos=t.kd_pos, att_gain=t.att_gain, rate_gain=t.rate_gain,
-        prop_radius=t.prop_radius, reset_thrust=0.0, reset_cmd=0.0,
+        prop_radius=t.prop_radius, reset_thrust=0.0, reset_cmd=0.0, arm=t.arm,
         collision_radius=t.collision_radius, collision_below=t.collision_below, base_offset=t.base_offset, **_AERO,
     )
 
@@ -505,7 +512,7 @@ def parse_urdf(path: str) -> DroneType:
         drag_coeff=(float(prop["drag_coeff_xy"]), float(prop["drag_coeff_xy"]), float(prop["drag_coeff_z"])),
         gnd_eff_coeff=float(prop["gnd_eff_coeff"]), prop_radius=float(prop["prop_radius"]),
         dw_coeff=(float(prop["dw_coeff_1"]), float(prop["dw_coeff_2"]), float(prop["dw_coeff_3"])),
-        max_speed_kmh=float(prop["max_speed_kmh"]),
+        max_speed_kmh=float(prop["max_speed_kmh"]), arm=float(prop["arm"]),
         reset_thrust=rt, reset_cmd=rc,
         collision_radius=coll_r, collision_below=coll_below,
         base_offset=tuple(float(x) for x in (com0 - C)) if is_hexa else (0.0, 0.0, 0.0),

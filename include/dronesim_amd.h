@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DSIM_ABI_VERSION 6
+#define DSIM_ABI_VERSION 7
 #define DSIM_MAX_ACT 6     /* actuators per vehicle (quad 4, morphing hexa 6) */
 #define DSIM_MAX_TYPES 8
 
@@ -133,7 +133,15 @@ typedef struct dsim_type_params {
    * links, whose centre of mass lies 11 mm below the base link's (hexa_6DOF.urdf).  mass, inertia, rotor_pos and the
    * collision cylinder are about the integrated centre of mass. */
   double  base_offset[3];
+  /* Physics.DYN (BaseAviary._dynamics, BaseAviary.py:1767-1828: the reference's own explicit rigid-body model, four-rotor
+   * types only): the URDF's `arm` attribute L (BaseAviary.py:2058; robobee / tello 0.0635 — NOT the rotor links' lever arms
+   * the PYB force map uses) and which of the two mixers of :1794-1803 turns the rotor forces into roll / pitch torques. */
+  double  arm;
+  int32_t dyn_mixer;                  /* DSIM_DYN_MIXER_X: (f0+f1-f2-f3, -f0+f1+f2-f3) L/sqrt 2 (DroneModel.CF2X, :1794-1800);
+                                         DSIM_DYN_MIXER_PLUS: (f1-f3, -f0+f2) L (CF2P / HB, :1801-1803)                    */
+  int32_t _pad_dyn;
 } dsim_type_params;
+enum { DSIM_DYN_MIXER_X = 0, DSIM_DYN_MIXER_PLUS = 1 };
 
 /* ---- step options ---------------------------------------------------------- */
 enum {
@@ -175,6 +183,29 @@ enum {
    * aligned.  Served by the one-launch forms (homogeneous quad fleet in whole tiles, no physics option, no downwash inputs):
    * DSIM_E_UNSUPPORTED otherwise.                                                                                        */
   DSIM_OPT_ACTION_ROWS = 1u << 15,
+  /* -- Physics.DYN (changes results) -----------------------------------------------------------------------------------
+   * dsim_physics / dsim_step integrate with the reference's OWN explicit model instead of the restated Bullet step:
+   * BaseAviary._dynamics (BaseAviary.py:1767-1828; dispatch :525-527, no p.stepSimulation :541-543), per physics sub-step
+   *     rpm = pwm2rpm_scale * clipped action + pwm2rpm_const   (the fork's PWM -> RPM map, BaseAviary.py:1487-1490; the
+   *                                                              function's argument is documented as RPMs, :1770-1775)
+   *     rpy = getEulerFromQuaternion(quat)                      (:513-520 / :547 refresh self.rpy from the engine, :729)
+   *     thrust = sum kf rpm^2 along body z (R from quat, :1786-1790);  force_world = R thrust - (0, 0, G M)
+   *     torques = mixer(forces; L) , z = -t0 + t1 - t2 + t3 (t = km rpm^2);  torques -= rpy_rates x (J rpy_rates)
+   *     vel += dt force_world / M;  rpy_rates += dt J^-1 torques;  pos += dt vel;  rpy += dt rpy_rates
+   *     quat = getQuaternionFromEuler(rpy)                      (:1814-1819)
+   * There is no rotor noise in this model (noise_seed / noise_replay are ignored) and no damping.  Four-rotor types only
+   * (both mixers read forces[0..3]): DSIM_E_UNSUPPORTED for a table with a six-actuator type, and with the drag / ground /
+   * plane options, ext_force, waypoint tables, n_steps > 1, DSIM_OPT_CHAINED, _CALLER_IO, _ACTION_ROWS, bin_next.
+   * The model's own state `rpy_rates` (BaseAviary.py:670-671, 1828: an env attribute beside pos / quat / vel) lives in
+   * dsim_step_args.dyn_rpy_rates, REQUIRED with this bit.  The angular-velocity fields of the state block hold what
+   * p.getBaseVelocity reports after the step: the reference stores the placeholder (-1, -1, -1) there ("ang_vel not computed
+   * by DYN", :1821-1826), so that is what observations show and what a controller reads — bit for bit the reference's
+   * behaviour, and the reason its INDI controller cannot close a loop on Physics.DYN.                                      */
+  DSIM_OPT_DYN         = 1u << 16,
+  /* With DSIM_OPT_DYN: a PRODUCT-DEFINED deviation that makes the mode flyable.  The angular-velocity fields receive
+   * R(quat_new) rpy_rates_new instead of the placeholder — the world-frame image of the rates, which the model's own torque
+   * equation treats as body rates (rpy_rates x J rpy_rates, :1805).  Off = the reference's (-1, -1, -1).                  */
+  DSIM_OPT_DYN_BODY_RATES = 1u << 17,
   /* -- scheduling (results do not depend on it) ---------------------------------------------------------------------- */
   DSIM_OPT_DEFER_FALLBACK = 1u << 11 /* dsim_step / dsim_control2 of a table with a morphing hexa do NOT launch the deferred
                                        WLS fallback pass behind the step; the caller launches dsim_wls_fallback itself —
@@ -252,6 +283,10 @@ typedef struct dsim_step_args {
    * host class may store a heterogeneous fleet type-major (runs) whatever order its caller uses; the rotor-noise
    * counter is then keyed by drone_id[i] instead of i, so that a drone draws the same noise wherever it is stored.   */
   const int32_t* drone_id;
+  /* -- Physics.DYN ------------------------------------------------------------------------------------------------------
+   * device SoA [3][n_pad], in-out; required with DSIM_OPT_DYN, ignored otherwise: BaseAviary.rpy_rates (BaseAviary.py:670-671
+   * zeroed by _housekeeping, :1785 read, :1828 written by _dynamics).  Caller-owned like every other per-drone array.  */
+  float* dyn_rpy_rates;
 } dsim_step_args;
 
 typedef struct dsim_ctx dsim_ctx;

@@ -130,6 +130,20 @@ def traj_sample(coeffs, TS, t, yaw_state):
     return out
 
 
+def dynamics(t: DroneType, dt, rpm, pos, quat, rpy, vel, rpy_rates):
+    """BaseAviary._dynamics (BaseAviary.py:1767-1828) for one drone: returns (pos, quat, vel, rpy_rates, rpy_sum) — what
+    the reference hands resetBasePositionAndOrientation / resetBaseVelocity, stores in self.rpy_rates, and the summed
+    angles in front of getQuaternionFromEuler."""
+    P = t.to_c()
+    pos, vel, rr = _c(pos).copy(), _c(vel).copy(), _c(rpy_rates).copy()
+    rpy_out, q_out = np.zeros(3), np.zeros(4)
+    f = lib().orc_dynamics
+    f.argtypes = [ctypes.POINTER(TypeParamsC), ctypes.c_double] + [_D] * 8
+    f.restype = None
+    f(ctypes.byref(P), float(dt), _p(_c(rpm)), _p(pos), _p(_c(quat)), _p(_c(rpy)), _p(vel), _p(rr), _p(rpy_out), _p(q_out))
+    return pos, q_out, vel, rr, rpy_out
+
+
 class CtrlMem(ctypes.Structure):
     _fields_ = [("last_vel", ctypes.c_double * 3), ("last_rates", ctypes.c_double * 3),
                 ("last_thrust", ctypes.c_double), ("cmd", ctypes.c_double * 6)]
@@ -235,6 +249,29 @@ class Oracle:
         return self._L.orc_step_batch(self._c_types, _p(type_id, _U8), n, substeps, dt_phys, dt_ctrl,
                                       _p(rigid), _p(mem), _p(_c(tgt)), bc, _p(nz), options, _p(act), _p(ef),
                                       nthreads)
+
+    def dyn_physics(self, rigid, rates, mem, substeps, dt, action=None, options=0, type_id=None, last_action=None,
+                    nthreads=1):
+        """Env.step on Physics.DYN (BaseAviary.py:510-545 with _dynamics, :1767-1828): rigid [n,13] and rates [n,3]
+        (self.rpy_rates) in-out; action [n,6] (None = stored cmd); options: nat.OPT_DYN_BODY_RATES or 0."""
+        f = self._L.orc_dyn_physics_batch
+        f.argtypes = [ctypes.POINTER(TypeParamsC), _U8, ctypes.c_int64, ctypes.c_int, ctypes.c_double, _D, _D, _D, _D,
+                      ctypes.c_uint32, _D, ctypes.c_int]
+        act = None if action is None else _c(action)
+        return f(self._c_types, _p(type_id, _U8), rigid.shape[0], substeps, dt, _p(rigid), _p(rates), _p(act), _p(mem),
+                 options, _p(last_action), nthreads)
+
+    def dyn_step(self, rigid, rates, mem, tgt, substeps, dt_phys, dt_ctrl, options=0, type_id=None, action=None,
+                 nthreads=1):
+        """The example loop body on Physics.DYN: Env.step then computeControl."""
+        f = self._L.orc_dyn_step_batch
+        f.argtypes = [ctypes.POINTER(TypeParamsC), _U8, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                      _D, _D, _D, _D, ctypes.c_int, ctypes.c_uint32, _D, ctypes.c_int]
+        n = rigid.shape[0]
+        bc = int(tgt.shape[0] == 1 and n != 1)
+        act = None if action is None else _c(action)
+        return f(self._c_types, _p(type_id, _U8), n, substeps, dt_phys, dt_ctrl, _p(rigid), _p(rates), _p(mem),
+                 _p(_c(tgt)), bc, options, _p(act), nthreads)
 
     def state_vector(self, rigid, last_action, type_id=None) -> np.ndarray:
         """_getDroneStateVector rows (BaseAviary.py:780-790): [n, 16 + max n_act] = pos3 quat4 rpy3 vel3 ang_v3

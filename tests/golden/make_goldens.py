@@ -512,8 +512,122 @@ def capture_roll_sweep():
     print("roll-sweep goldens written")
 
 
+def capture_dynamics():
+    """Physics.DYN: BaseAviary._dynamics (BaseAviary.py:1767-1828) and the step() loop around it (:510-547), the
+    reference's OWN explicit rigid-body integrator — the one whose arithmetic is Python in the reference tree, so the one
+    rigid-body mode that CAN be pinned here.  The branch is dead code in the fork for plumbing reasons: it reads self.KF,
+    self.KM, self.M, self.J, self.J_INV, self.L, self.GRAVITY and self.DRONE_MODEL, which the fork moved into
+    self.drones[i] or left commented out (:200-235), and it indexes the action as an array (:527) where CtrlAviary now
+    returns a dict.  Those attributes are supplied from the reference's own URDF parser; GRAVITY = G * M as the
+    commented line :226 defines it.  Under DYN the engine is a POSE STORE: the reference writes the new pose and
+    velocity with p.resetBasePositionAndOrientation / p.resetBaseVelocity (:1814-1826) and reads them back with
+    p.getBasePositionAndOrientation / p.getBaseVelocity (:726-732); p.stepSimulation is skipped (:541-543).  The
+    stand-in for those four calls stores and returns what it was given.
+
+    (A) single calls of _dynamics on seeded states — incl. quat / rpy pairs that do NOT belong together, which shows
+        that the rotation comes from self.quat and the angle sum from self.rpy — for both mixers;
+    (B) flights through the reference's own BaseAviary.step() loop (unbound, on an object carrying the attributes
+        above; _preprocessAction hands the RPM array through, as upstream's CtrlAviary does), AGGR_PHY_STEPS 5 and 1:
+        pins the refresh of self.rpy from the stored quaternion between sub-steps (:513-520, 729)."""
+    import pybullet as p
+    from dronesim.envs.BaseAviary import BaseAviary, Drone, DroneModel, Physics
+
+    store = {}
+    p.resetBasePositionAndOrientation = lambda body, pos, quat, physicsClientId=0: store.__setitem__(
+        ("pose", body), (tuple(float(x) for x in pos), tuple(float(x) for x in quat)))
+    p.resetBaseVelocity = lambda body, lin, ang, physicsClientId=0: store.__setitem__(
+        ("vel", body), (tuple(float(x) for x in lin), tuple(float(x) for x in ang)))
+    p.getBasePositionAndOrientation = lambda body, physicsClientId=0: store[("pose", body)]
+    p.getBaseVelocity = lambda body, physicsClientId=0: store[("vel", body)]
+
+    def drone_of(model):
+        return Drone(*BaseAviary._parseURDFParameters(None, model + ".urdf"))
+
+    def attrs(d, dm, dt):
+        return dict(KF=d.KF, KM=d.KM, M=d.M, J=d.J, J_INV=d.J_INV, L=d.L, GRAVITY=9.8 * d.M, DRONE_MODEL=dm, TIMESTEP=dt,
+                    CLIENT=0)
+
+    out = {}
+    rng = np.random.default_rng(41)
+    # ---- (A) single calls ----------------------------------------------------------------------------------------
+    K = 64
+    for model, dm, tag in (("robobee", DroneModel.CF2X, "robobee_x"), ("tello", DroneModel.CF2X, "tello_x"),
+                           ("robobee", DroneModel.CF2P, "robobee_plus"), ("tello", DroneModel.HB, "tello_hb")):
+        d = drone_of(model)
+        dt = 1 / 240
+        rpy = np.stack([rng.uniform(-1.3, 1.3, K), rng.uniform(-1.3, 1.3, K), rng.uniform(-math.pi, math.pi, K)], 1)
+        rpy[0] = 0.0
+        rpy[1] = (0.2, 1.5699, -0.7)                          # inside the gimbal clamp of getEulerFromQuaternion
+        rpy[2] = (0.0, 0.0, math.pi - 1e-4)                   # the angle sum crosses +pi
+        quat = np.stack([quat_from_euler(*e) for e in rpy])
+        rpy_in = np.stack([_getEulerFromQuaternion(q) for q in quat])   # what BaseAviary stores in self.rpy (:729)
+        rpy_in[3] = rpy_in[3] + (0.3, -0.2, 0.5)              # a pair that does not belong together
+        pos = rng.uniform(-5, 5, (K, 3))
+        vel = rng.uniform(-3, 3, (K, 3))
+        rates = rng.uniform(-4, 4, (K, 3))
+        rates[0] = 0.0
+        pwm = rng.uniform(0.0, 1.0, (K, 4))
+        pwm[0] = math.sqrt(d.M * 9.8 / (4 * d.KF)) / 20000.0   # hover
+        rpm = 20000.0 * pwm
+        o = {k: [] for k in ("pos", "quat", "vel", "ang_v", "rates")}
+        for i in range(K):
+            fake = type("Fake", (), {})()
+            fake.__dict__.update(attrs(d, dm, dt), DRONE_IDS=[5], pos=pos[i:i + 1].copy(), quat=quat[i:i + 1].copy(),
+                                 rpy=rpy_in[i:i + 1].copy(), vel=vel[i:i + 1].copy(), rpy_rates=rates[i:i + 1].copy())
+            store.clear()
+            BaseAviary._dynamics(fake, rpm[i].copy(), 0)
+            o["pos"].append(store[("pose", 5)][0]); o["quat"].append(store[("pose", 5)][1])
+            o["vel"].append(store[("vel", 5)][0]); o["ang_v"].append(store[("vel", 5)][1])
+            o["rates"].append(fake.rpy_rates[0].copy())
+        out.update({f"{tag}_dt": np.array(dt), f"{tag}_pos": pos, f"{tag}_quat": quat, f"{tag}_rpy": rpy_in, f"{tag}_vel": vel,
+                    f"{tag}_rates": rates, f"{tag}_pwm": pwm, f"{tag}_rpm": rpm,
+                    f"{tag}_mixer_plus": np.array(dm != DroneModel.CF2X)})
+        out.update({f"{tag}_{k}_out": np.array(v) for k, v in o.items()})
+
+    # ---- (B) flights through BaseAviary.step() -----------------------------------------------------------------------
+    d = drone_of("robobee")
+    hover = math.sqrt(d.M * 9.8 / (4 * d.KF)) / 20000.0
+    for tag, aggr, steps in (("flight5", 5, 48), ("flight1", 1, 120)):
+        N = 3
+        Fake = type("Fake", (), {"_dynamics": BaseAviary._dynamics,
+                                 "_updateAndStoreKinematicInformation": BaseAviary._updateAndStoreKinematicInformation,
+                                 "_preprocessAction": lambda self, a: a,       # upstream CtrlAviary: the RPM array as it is
+                                 "_computeObs": lambda self: None, "_computeReward": lambda self: -1,
+                                 "_computeDone": lambda self: False, "_computeInfo": lambda self: {}})
+        fake = Fake()
+        fake.__dict__.update(attrs(d, DroneModel.CF2X, 1 / 240), DRONE_IDS=[11, 12, 13], NUM_DRONES=N, RECORD=False, GUI=False,
+                             USER_DEBUG=False, USE_GUI_RPM=False, AGGR_PHY_STEPS=aggr, PHYSICS=Physics.DYN, step_counter=0,
+                             last_clipped_action=None)
+        pos0 = np.array([[0.0, 1.0, 0.5], [1.0, 0.0, 1.5], [-2.0, 0.5, 3.0]])
+        rpy0 = np.array([[0.0, 0.0, 0.0], [0.1, -0.05, 0.4], [-0.3, 0.2, 3.0]])
+        store.clear()
+        for k in range(N):        # what _housekeeping leaves: loadURDF at INIT_XYZS / INIT_RPYS, zero velocities (:640-714)
+            store[("pose", 11 + k)] = (tuple(pos0[k]), _getQuaternionFromEuler(rpy0[k]))
+            store[("vel", 11 + k)] = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0))
+        fake.pos, fake.quat, fake.rpy = np.zeros((N, 3)), np.zeros((N, 4)), np.zeros((N, 3))
+        fake.vel, fake.ang_v, fake.rpy_rates = np.zeros((N, 3)), np.zeros((N, 3)), np.zeros((N, 3))
+        BaseAviary._updateAndStoreKinematicInformation(fake)                   # reset() ends with it (:421)
+        init = np.concatenate([fake.pos, fake.quat, fake.rpy, fake.vel, fake.ang_v], 1).copy()
+        # smooth commands about hover: differential thrust that rolls / pitches / yaws the vehicles by a few tenths of a rad
+        t = np.arange(steps)[:, None, None] * (aggr / 240.0)
+        ph = rng.uniform(0, 2 * math.pi, (1, N, 4))
+        fr = rng.uniform(0.5, 3.0, (1, N, 4))
+        pwm = np.clip(hover * (1.0 + 0.02 * np.sin(2 * math.pi * fr * t + ph)) + rng.normal(0, 0.002, (steps, N, 4)), 0.0, 1.0)
+        rec = []
+        for k in range(steps):
+            BaseAviary.step(fake, 20000.0 * pwm[k])
+            rec.append(np.concatenate([fake.pos, fake.quat, fake.rpy, fake.vel, fake.ang_v, fake.rpy_rates], 1).copy())
+        assert fake.step_counter == steps * aggr
+        out.update({f"{tag}_aggr": np.array(aggr), f"{tag}_init": init, f"{tag}_pwm": pwm, f"{tag}_states": np.array(rec)})
+    np.savez(os.path.join(OUT, "dynamics.npz"), **out)
+    print("dynamics goldens written")
+
+
 def main():
     install_standins()
+    if len(sys.argv) > 1 and sys.argv[1] == "dyn":        # only the Physics.DYN file
+        capture_dynamics()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "env":        # only the env-side file
         capture_env_side()
         return
@@ -618,6 +732,7 @@ def main():
              target_yaw=np.array(Y), gates=gates)
     capture_env_side()
     capture_roll_sweep()
+    capture_dynamics()
     print("goldens written to", OUT)
 
 

@@ -212,7 +212,7 @@ def test_golden_fixtures_regenerate_bit_identically(tmp_path):
             else:
                 sys.modules[k] = v
     files = sorted(glob.glob(os.path.join(here, "*.npz")))
-    assert len(files) == 17
+    assert len(files) == 18
     for f in files:
         a, b = np.load(f, allow_pickle=True), np.load(os.path.join(str(tmp_path), os.path.basename(f)), allow_pickle=True)
         assert set(a.files) == set(b.files), f

@@ -214,14 +214,10 @@ def test_wrench_mapping_agrees_with_the_reference_dynamics_formula():
     P4) and one step of _dynamics must agree exactly (no damping at v = 0, no gyro at w = 0) — signs,
     lever arms, yaw-torque convention and semi-implicit order; with damping removed they stay together
     over a short manoeuvre up to the rpy-rate vs body-rate difference, which shrinks with the step."""
-    import ctypes
-    t = params.builtin_type("tello")          # symmetric X layout: L/sqrt(2) = 0.0475
+    t = params.builtin_type("tello")          # symmetric X layout: rotor levers (0.0475, 0.0475)
+    t.arm = 0.0475 * np.sqrt(2.0)             # the mixer's L / sqrt(2) on the PYB force map's own lever (the URDF's arm is 0.0635)
     t.lin_damping = t.ang_damping = 0.0
     O = orc.Oracle([t])
-    P = t.to_c()
-    D = ctypes.POINTER(ctypes.c_double)
-    f = orc.lib().orc_dynamics_step
-    f.argtypes = [ctypes.POINTER(type(P)), ctypes.c_double, ctypes.c_double, D, D, D, D, D]
     cmd = np.array([0.52, 0.47, 0.50, 0.49])
 
     def run(dt, steps):
@@ -230,8 +226,8 @@ def test_wrench_mapping_agrees_with_the_reference_dynamics_formula():
         rpm = 20000.0 * cmd
         for _ in range(steps):
             O.physics(r, m, 1, dt)
-            f(ctypes.byref(P), dt, 0.0475, rpm.ctypes.data_as(D), pos.ctypes.data_as(D), rpy.ctypes.data_as(D),
-              vel.ctypes.data_as(D), rr.ctypes.data_as(D))
+            # (the rpy SUM is carried here, not re-read from the quaternion: this test compares two integrators)
+            pos, _, vel, rr, rpy = orc.dynamics(t, dt, rpm, pos, orc.quat_from_euler(rpy), rpy, vel, rr)
         return r[0], pos, rpy, vel, rr
 
     r, pos, rpy, vel, rr = run(DT, 1)
