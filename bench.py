@@ -46,6 +46,12 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBPS = 6290.0    # MI355X_MICROARCH.md: the float4-copy rate that guide measured (what a kernel can reach)
 BYTES_PER_DRONE_STEP = 232      # read 13+11+10 floats, write 13+11 floats (quad, per-drone targets)
+# The neighbour query of config 5 is bound by vector issue, not by HBM.  Its unit of work is one (receiver, candidate) pair of
+# formula P8 (BaseAviary.py:1752-1755): 20 vector instructions in the kernel's loop, 18 full-rate and 2 transcendental
+# (v_rcp_f32, v_exp_f32).  Issue cost per wave64 instruction with 8 waves per SIMD, measured on MI355X with tools/valubench.hip
+# (profiles/r05_valubench.json; nominal 2.4 GHz cycles): v_fma_f32 2.82, v_exp_f32 / v_rcp_f32 9.4 -> 69.6 cycles per 64 pairs
+# per SIMD, 1 024 SIMDs: 2.26e12 pair evaluations per second if the vector pipes did nothing else.
+VALU_PAIR_PEAK = 256 * 4 * 2.4e9 * 64 / (18 * 2.82 + 2 * 9.4)
 WATCHDOG_RC = 3                 # exit code of every rank when a collective section hangs (Watchdog)
 MIN_TIMED_S = 0.05              # the timed region is repeated (whole K-step regions) until it covers this much
 WORKLOADS = ["config2x1024", "config2", "config3", "config4", "config5", "hexa", "mixed", "mixed_type_major", "two_call_loop"]
@@ -108,7 +114,8 @@ class Fleet:
     """A resident fleet + per-drone hover targets at the start position."""
 
     def __init__(self, n_fleet, replicas, device, substeps, layout, noise_seed, waypoints=False, n_steps=1,
-                 config5=False, dist=None, rank=0, chained=False, hexa=False, mixed=False, options=0, slab_m=128.0, storage=None):
+                 config5=False, dist=None, rank=0, chained=False, hexa=False, mixed=False, options=0, slab_m=128.0, storage=None,
+                 dyn=False):
         import torch
         from dronesim_amd.envs import CtrlAviary, Physics
         from dronesim_amd.fleet import Targets, WaypointTargets
@@ -137,6 +144,8 @@ class Fleet:
                             rng.uniform(0, 512, self.n), rng.uniform(0.5, 20.5, self.n)], 1)
             models, type_ids = ["robobee", "hexa_6DOF"], (np.arange(self.n) % 2).astype(np.uint8)
             physics = Physics.PYB_DW
+        if dyn:         # Physics.DYN: the reference's own explicit model (BaseAviary._dynamics), flyable form of ang_v
+            physics = Physics.DYN
         if waypoints:
             # config 3 (examples/fly_INDI_TrajectoryTrack.py): the reference's own 1200-row waypoint
             # table (fixture captured from its trajGen), gate 0 + grid offset, phase i*NUM_WP/6
@@ -151,7 +160,8 @@ class Fleet:
                               type_ids=type_ids, options=options, storage=storage or os.environ.get("DSIM_STORAGE", "auto"),
                               downwash_split={"": None, "0": False, "1": True}[os.environ.get("DSIM_DW_SPLIT", "")],
                               defer_fallback=os.environ.get("DSIM_DEFER_FB", "0") != "0",
-                              placement=os.environ.get("DSIM_PLACEMENT", "1") != "0")
+                              placement=os.environ.get("DSIM_PLACEMENT", "0") != "0",
+                              dyn_ang_vel="body_rates" if dyn else "reference")
         if waypoints:
             self.tgt = WaypointTargets(self.env.ctx, self.n, g["target_pos"], g["target_vel"], g["target_acc"],
                                        g["target_yaw"], wp_counters=wp0, offsets=off)
@@ -357,7 +367,7 @@ def memory_yardstick(n_drones):
         return {"device_copy_GBps": None, "yardstick_error": repr(e)[:200]}
 
 
-def child_line(a, extra, placement=True, timeout=300):
+def child_line(a, extra, placement=False, timeout=300):
     """`bench.py <extra>` as a child process (this one keeps its fleets but is idle meanwhile), placement by trial on or off
     (DSIM_PLACEMENT): its JSON line."""
     cmd = [sys.executable, os.path.abspath(__file__), "--warmup", str(a.warmup), "--no-also", "--no-cpu-baseline", "--layout", a.layout,
@@ -378,7 +388,7 @@ def placement_cost(log):
             "placement_held_bytes": sum(r.get("held_bytes", 0) for r in (log or [])), "searches": len(rows)}
 
 
-def two_call_child(a, kind="quad", placement=True):
+def two_call_child(a, kind="quad", placement=False):
     """`bench.py --workload two_call_loop --two-call-kind KIND` as a child process (this one keeps its fleets but is idle
     meanwhile): its line, reduced to the entry the default line carries."""
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "two_call_loop", "--two-call-kind", kind,
@@ -401,6 +411,25 @@ def two_call_child(a, kind="quad", placement=True):
         return e
     except Exception as e:          # an extra must not cost the headline
         return {"error": repr(e)[:300]}
+
+
+def self_check(world, gpus, backend_seen, backend_wanted, devices, rows_launch_us, extra=None, distinct_devices=True):
+    """What a first run on N devices must show for its line to mean what it says; every entry True or the line says which
+    is not (and the run leaves with SELF_CHECK_RC).  `devices`: the device ordinal every rank used."""
+    checks = {
+        "world_size_equals_gpus_flag": world == gpus,
+        "backend_is_" + str(backend_wanted): (backend_seen == backend_wanted) if world > 1 else True,
+        "every_rank_reported": len(devices) == world and len(rows_launch_us) == world,
+        # (RCCL wants one device per rank; a gloo rehearsal may share one GPU between its ranks: distinct_devices = False)
+        "one_device_per_rank": (len(set(int(d) for d in devices)) == len(devices)) if distinct_devices else True,
+        "every_rank_timed_something": all(u > 0.0 for u in rows_launch_us),
+    }
+    checks.update(extra or {})
+    failed = sorted(k for k, v in checks.items() if not v)
+    return {"ok": not failed, "failed": failed, "checks": checks}
+
+
+SELF_CHECK_RC = 4               # exit code when a multi-rank run's self-check fails (the line is still printed)
 
 
 def gather_ranks(dist, red_dev, values):
@@ -451,25 +480,41 @@ def config5_all_ranks(a, local, rank, world, dist, red_dev, barrier, options):
     multi-GPU run of the default line also says what the RCCL path does.  Every rank takes part (the exchange is
     collective); rank 0 gets the entry."""
     from dronesim_amd import sharding
-    fl5 = Fleet(65536, 1, local, 1, a.layout, sharding.rank_seed(a.noise_seed, rank), config5=True, dist=dist, rank=rank,
-                options=options)
     steps = max(20, a.steps // 2)
 
     def rule(first_wall):
         w, _ = sharding.reduce_step_times(dist, red_dev, first_wall, 0.0)
         return max(1, int(np.ceil(MIN_TIMED_S / max(w, 1e-9))))
-    wall_l, dev_l, regions = fl5.timed(steps, 10, barrier, min_s=MIN_TIMED_S, repeat_rule=rule)
-    wall, dev = sharding.reduce_step_times(dist, red_dev, wall_l, dev_l)
-    k = steps * regions
-    rows = gather_ranks(dist, red_dev, [dev_l / k * 1e6, wall_l / k * 1e6, fl5.env.ground_contacts()])
-    ex = exchange_report(fl5, dist, red_dev)
-    e = {"workload": WORKLOAD_TEXT["config5"], "drones_per_gpu": fl5.n, "n_gpus": world,
-         "drone_steps_per_s": sharding.aggregate_throughput([fl5.n] * world, k, wall), "ms_per_step": wall / k * 1e3,
-         "steps_timed": k, "step_chain_us_min": min(r[0] for r in rows), "step_chain_us_max": max(r[0] for r in rows),
-         "host_us_per_step_max": max(r[1] for r in rows), "ground_contacts": int(sum(r[2] for r in rows)), "exchange": ex,
+
+    def one(split):
+        # DSIM_DW_SPLIT as the Fleet reads it: "1" the two-pass query around the wire (the default on RCCL), "0" one grid behind it
+        os.environ["DSIM_DW_SPLIT"] = "1" if split else "0"
+        try:
+            fl5 = Fleet(65536, 1, local, 1, a.layout, sharding.rank_seed(a.noise_seed, rank), config5=True, dist=dist, rank=rank,
+                        options=options)
+        finally:
+            os.environ.pop("DSIM_DW_SPLIT", None)
+        wall_l, dev_l, regions = fl5.timed(steps, 10, barrier, min_s=MIN_TIMED_S, repeat_rule=rule)
+        wall, dev = sharding.reduce_step_times(dist, red_dev, wall_l, dev_l)
+        k = steps * regions
+        rows = gather_ranks(dist, red_dev, [dev_l / k * 1e6, wall_l / k * 1e6, fl5.env.ground_contacts()])
+        ex = exchange_report(fl5, dist, red_dev)
+        e = {"drones_per_gpu": fl5.n, "drone_steps_per_s": sharding.aggregate_throughput([fl5.n] * world, k, wall),
+             "ms_per_step": wall / k * 1e3, "steps_timed": k, "step_chain_us_per_rank": [round(r[0], 2) for r in rows],
+             "step_chain_us_min": min(r[0] for r in rows), "step_chain_us_max": max(r[0] for r in rows),
+             "host_us_per_step_max": max(r[1] for r in rows), "ground_contacts": int(sum(r[2] for r in rows)), "exchange": ex}
+        fl5.env.close()
+        return e
+    # both forms of the query in the one job, so that a single run on N devices answers which one the wire wants (DESIGN.md 6)
+    two_pass, one_grid = one(True), one(False)
+    best = two_pass if two_pass["drone_steps_per_s"] >= one_grid["drone_steps_per_s"] else one_grid
+    e = {"workload": WORKLOAD_TEXT["config5"], "n_gpus": world, "drones_per_gpu": best["drones_per_gpu"],
+         "drone_steps_per_s": best["drone_steps_per_s"], "ms_per_step": best["ms_per_step"],
+         "faster_form": "two-pass query around the wire" if best is two_pass else "one grid behind the wire",
+         "two_pass_query_around_the_wire": two_pass, "one_grid_behind_the_wire": one_grid,
+         "overflow_is_zero": two_pass["exchange"].get("overflow", 0) == 0 and one_grid["exchange"].get("overflow", 0) == 0,
          "kernel": "dsim_halo_pack + send/recv + halo binning (side stream) | k_dw_query_cell local pass, halo pass, "
                    "k_step_runs + fused grid binning, k_wls_fallback"}
-    fl5.env.close()
     return e
 
 
@@ -558,6 +603,45 @@ WORKLOAD_TEXT = {
 }
 
 
+def useful_pairs(torch, pos):
+    """Pairs (i, j) of formula P8 that contribute a term: j above i and within the 10 m cut-off in xy (BaseAviary.py:1752).
+    Brute force on the device, in slabs of receivers; pos [3, n]."""
+    n = pos.shape[1]
+    x, y, z = pos[0], pos[1], pos[2]
+    total = 0
+    for s_ in range(0, n, 2048):
+        e_ = min(n, s_ + 2048)
+        dz = z[None, :] - z[s_:e_, None]
+        dd = (x[None, :] - x[s_:e_, None]) ** 2 + (y[None, :] - y[s_:e_, None]) ** 2
+        total += int(((dz > 0) & (dd < 100.0)).sum())
+    return total
+
+
+def valu_roofline(torch, fl, chain_s):
+    """config 5: the vector-pipe roofline of the neighbour query (VALU_PAIR_PEAK above).  `achieved` = USEFUL pair
+    evaluations per second of the whole step chain — pairs that contribute a term of formula P8, counted by brute force on
+    this fleet's positions — the analogue of algorithmic bytes; `evaluated` = the pairs the query's loops really run (its
+    diagnostics counter, one extra untimed step), the analogue of measured traffic."""
+    dwn = fl.env._downwash
+    pos = fl.env.state.raw_fields(0, 3).contiguous()
+    useful = useful_pairs(torch, pos)
+    dwn.count_pairs(True)
+    fl.env._fused_plan_dw = None
+    fl.step()
+    torch.cuda.synchronize()
+    evaluated = int(dwn.pair_counter.item())
+    dwn.count_pairs(False)
+    fl.env._fused_plan_dw = None
+    achieved = useful / chain_s
+    return {"bound": "valu", "achieved": achieved, "peak": VALU_PAIR_PEAK, "unit": "pair evaluations/s", "frac": achieved / VALU_PAIR_PEAK,
+            "useful_pairs_per_step": useful, "evaluated_pairs_per_step": evaluated,
+            "evaluated_over_useful": evaluated / max(1, useful),
+            "frac_counting_evaluated_pairs": evaluated / chain_s / VALU_PAIR_PEAK,
+            "note": "per step CHAIN (neighbour query, step + grid binning, WLS fallback pass), not per query launch: the query is "
+                    "~30 of its ~45 us (profiles/r05_c5_*); peak = 1 024 SIMDs x 2.4 GHz x 64 lanes / 69.6 cycles per 64 pairs "
+                    "(18 full-rate + 2 transcendental instructions per pair; issue costs measured by tools/valubench.hip)"}
+
+
 def measure_variant(torch, local, layout, seed, steps, name, nf, rep, sub, wp, ns, options=0):
     """One entry of "baseline_configs" / "also": a fresh fleet, one warm region, then timed regions of k steps until
     they cover MIN_TIMED_S (sums reported, nothing picked)."""
@@ -565,7 +649,8 @@ def measure_variant(torch, local, layout, seed, steps, name, nf, rep, sub, wp, n
                config5=name.startswith("config5"), dist=(MirrorDist(128.0) if "mirrored_neighbour" in name else None),
                chained="chained" in name, hexa=name.startswith("hexa"),
                mixed=("type_major" if "type_major" in name else name.startswith("mixed")), options=options,
-               slab_m=(1024.0 if "lowdensity" in name else 128.0), storage=("caller" if "caller_order" in name else None))
+               slab_m=(1024.0 if "lowdensity" in name else 128.0), storage=("caller" if "caller_order" in name else None),
+               dyn=name.startswith("physics_dyn"))
     if "hipgraph" in name:
         f2.n_steps = 1
         f2.use_graph(ns)
@@ -577,13 +662,18 @@ def measure_variant(torch, local, layout, seed, steps, name, nf, rep, sub, wp, n
          "drones": f2.n, "phys_substeps": sub, "steps_timed": k2 * reg,
          "device_drone_steps_per_s": f2.n * k2 * reg * ns / d2}
     if ns == 1:
-        bts = 184 if "chained" in name else (248 if name.startswith("hexa") else
+        bts = 184 if "chained" in name else (256 if name.startswith("physics_dyn") else 248 if name.startswith("hexa") else
                                              (253 if name.startswith("config5") else
                                               (241 if name.startswith("mixed") else BYTES_PER_DRONE_STEP)))
         e["hbm_frac"] = f2.n * bts / (d2 / (k2 * reg)) / 1e9 / HBM_PEAK_GBPS
         e["bytes_per_drone_step"] = bts
     if "mirrored_neighbour" in name:
         e["exchange"] = exchange_report(f2, None, "cpu", steps=20)
+    if name.startswith("config5") and "mirrored" not in name:
+        try:
+            e["roofline"] = valu_roofline(torch, f2, d2 / (k2 * reg))
+        except Exception as ex:           # an extra must not cost the line
+            e["roofline"] = {"error": repr(ex)[:200]}
     f2.env.close()
     del f2
     return e
@@ -725,7 +815,8 @@ def main(argv=None):
                                 ("k_dw_query_cell, " if tck == "config5" else "") +
                                 "k_physics_runs (observation fused) + k_control_runs (+ k_wls_fallback)")}.get(a.workload, "k_step_fast")
     achieved = fl.n * bytes_per / launch_s / 1e9
-    rank_rows = gather_ranks(dist, red_dev, [dev_s_local / steps_timed * 1e6, wall_local / steps_timed * 1e6])
+    rank_rows = gather_ranks(dist, red_dev, [dev_s_local / steps_timed * 1e6, wall_local / steps_timed * 1e6,
+                                             float(torch.cuda.current_device()), float(rank)])
     exchange = exchange_report(fl, dist, red_dev) if (a.workload == "config5" and (world > 1 or a.mirror_peer)) else None
 
     if rank == 0:
@@ -749,7 +840,11 @@ def main(argv=None):
                        "noise_seed": a.noise_seed, "launches_per_step": 1, "parallelism": f"shard{world}"},
             "dist": dist_info,
             "ranks": {"launch_us_min": min(r[0] for r in rank_rows), "launch_us_max": max(r[0] for r in rank_rows),
-                      "host_us_per_step_min": min(r[1] for r in rank_rows), "host_us_per_step_max": max(r[1] for r in rank_rows)},
+                      "host_us_per_step_min": min(r[1] for r in rank_rows), "host_us_per_step_max": max(r[1] for r in rank_rows),
+                      "launch_us_per_rank": [round(r[0], 2) for r in rank_rows], "device_of_rank": [int(r[2]) for r in rank_rows],
+                      "seen": sorted(int(r[3]) for r in rank_rows)},
+            "self_check": self_check(world, a.gpus, dist_info.get("backend"), backend, [r[2] for r in rank_rows],
+                                     [r[0] for r in rank_rows], distinct_devices=backend == "nccl"),
             # drone-steps of the whole run (set-up, warm-up and timed regions) whose collision cylinder reached the ground
             # plane, which the flight kernels of large fleets do not model (DSIM_OPT_PLANE does, for landing-sized fleets):
             # 0 = every step of the workload lies in the domain the flight kernels cover
@@ -760,6 +855,11 @@ def main(argv=None):
                          "kernel": kernel, "bytes_per_drone_step": bytes_per,
                          "launch_us": launch_s * 1e6},
         }
+        if a.workload == "config5" and world == 1 and not a.mirror_peer:
+            try:
+                out["roofline_valu"] = valu_roofline(torch, fl, launch_s)
+            except Exception as ex:
+                out["roofline_valu"] = {"error": repr(ex)[:200]}
         if fl.env.ctx.placement_log:
             # where the fleet-sized arrays beside the state block were put, by measurement (dronesim_amd/placement.py), and
             # what the searches cost (seconds; device memory held at once while walking — transient, straight from the driver)
@@ -782,6 +882,12 @@ def main(argv=None):
                 e5 = {"error": repr(e)[:300]}
             if rank == 0:
                 out["config5_all_ranks"] = e5
+                if "overflow_is_zero" in e5:
+                    out["self_check"]["checks"]["config5_halo_overflow_is_zero"] = bool(e5["overflow_is_zero"])
+                if "error" in e5:
+                    out["self_check"]["checks"]["config5_all_ranks_ran"] = False
+                out["self_check"]["failed"] = sorted(k for k, v in out["self_check"]["checks"].items() if not v)
+                out["self_check"]["ok"] = not out["self_check"]["failed"]
     if rank == 0:
         if world == 1 and not a.no_also:
             # ---- BASELINE.json configs 1-3 at their LITERAL sizes and example settings --------------------------------
@@ -832,6 +938,10 @@ def main(argv=None):
                     "config2x1024_chained_184B": (4096, 1024, 1, False, 1),
                     # homogeneous morphing-hexa fleet: 6-DOF INDI + WLS allocation, 248 B/drone-step
                     "hexa_6DOF_4194304_indi6dof_wls": (4096, 1024, 1, False, 1),
+                    # Physics.DYN (row D1): BaseAviary._dynamics + INDI in one launch (k_dyn), the headline fleet; 232 B + the
+                    # model's own rpy_rates (3 floats in, 3 out) = 256 B per drone-step
+                    "physics_dyn_4194304_sub1": (4096, 1024, 1, False, 1),
+                    "physics_dyn_4194304_sub5": (4096, 1024, 5, False, 1),
                     # config 5's composition at roofline size, no downwash: 240 B average + 1 B type id.  The caller hands the
                     # fleet over interleaved (even index quad, odd index hexa); the env stores it type-major behind that
                     # numbering (fleet.StorageOrder) — and, for comparison, in the caller's own order (k_step_mixed4)
@@ -842,11 +952,14 @@ def main(argv=None):
                 also[name] = measure_variant(torch, local, a.layout, a.noise_seed, a.steps, name, *spec, options=options)
                 if name.startswith("config5"):
                     also[name]["note"] = ("a chain of three dependent launches on a 65 536-drone shard (neighbour query, step + grid "
-                                          "binning, WLS fallback): bound by the vector pipe of the query (profiles/r03_c5*_summary.json) "
-                                          "and by launch latency, not by HBM — hbm_frac is reported for completeness")
+                                          "binning, WLS fallback): bound by the vector pipe of the query and by launch latency, not by "
+                                          "HBM — its roofline is `roofline` (bound: valu); hbm_frac is kept for comparison with earlier rounds")
                 if "mirrored_neighbour" in name:
                     also[name]["note"] = ("the shard above + the halo exchange with a synthetic neighbour (its own reflection): "
                                           "k_halo_pack, a device-side wire, halo binning, one-grid query, step, fallback on one stream")
+                if name.startswith("physics_dyn"):
+                    also[name]["note"] = ("Physics.DYN: the reference's own explicit model (BaseAviary.py:1767-1828) + INDI, k_dyn; no rotor "
+                                          "noise in this model; ang_v reported as R(quat) rpy_rates (dyn_ang_vel='body_rates')")
                 if name.startswith("hexa"):
                     also[name]["note"] = ("248 B is the budgeted figure (SURVEY 8d); the 6-DOF law never reads the target "
                                           "acceleration and yaw, measured HBM traffic is 232 B per drone-step")
@@ -865,21 +978,14 @@ def main(argv=None):
             also["hexa_env_step_then_computeControl"] = two_call_child(a, "hexa")
             also["mixed_interleaved_env_step_then_computeControl"] = two_call_child(a, "mixed")
             also["config5_shard_two_call"] = two_call_child(a, "config5")
-            # placement by trial ON (above, the default) and OFF, from the same process tree: what the search buys on THIS box
-            off = {}
-            try:
-                d0 = child_line(a, ["--steps", str(a.steps)], placement=False)
-                off["headline"] = {"launch_us": d0["roofline"]["launch_us"], "hbm_frac": d0["roofline"]["frac"],
-                                   "drone_steps_per_s": d0["value"], "with_placement_launch_us": launch_s * 1e6}
-            except Exception as e:
-                off["headline"] = {"error": repr(e)[:200]}
-            for kind, name in (("quad", "config2x1024_env_step_then_computeControl"), ("hexa", "hexa_env_step_then_computeControl"),
-                               ("mixed", "mixed_interleaved_env_step_then_computeControl")):
-                e0 = two_call_child(a, kind, placement=False)
-                off[name] = {k: e0.get(k) for k in ("loop_us_device", "hbm_frac", "drone_steps_per_s", "error") if k in e0}
-                if "loop_us_device" in e0 and "loop_us_device" in also.get(name, {}):
-                    off[name]["with_placement_loop_us_device"] = also[name]["loop_us_device"]
-            also["without_placement_by_trial"] = off
+            # placement by trial (dronesim_amd/placement.py; OFF by default since round 5) switched ON for the one loop it
+            # moved most, from the same process tree: what the opt-in search is worth on THIS box
+            e1 = two_call_child(a, "quad", placement=True)
+            also["opt_in_placement_by_trial"] = {"config2x1024_env_step_then_computeControl": {
+                k: e1.get(k) for k in ("loop_us_device", "hbm_frac", "drone_steps_per_s", "placement_cost", "error") if k in e1}}
+            if "loop_us_device" in also.get("config2x1024_env_step_then_computeControl", {}):
+                also["opt_in_placement_by_trial"]["config2x1024_env_step_then_computeControl"]["default_loop_us_device"] = (
+                    also["config2x1024_env_step_then_computeControl"]["loop_us_device"])
             if isinstance(also.get("config5_shard_65536_mixed_downwash"), dict) and "loop_us_device" in also["config5_shard_two_call"]:
                 also["config5_shard_two_call"]["ratio_to_fused_chain"] = (
                     also["config5_shard_two_call"]["loop_us_device"] / also["config5_shard_65536_mixed_downwash"]["launch_us"])
@@ -887,9 +993,12 @@ def main(argv=None):
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.substeps)
         print(json.dumps(out))
+    failed = bool(rank == 0 and world > 1 and not out.get("self_check", {}).get("ok", True))
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        sys.exit(SELF_CHECK_RC)
 
 
 def dry_run(a, rank, world, backend):
@@ -908,17 +1017,25 @@ def dry_run(a, rank, world, backend):
         dist.barrier()
     wall = 1e-3 * (rank + 1)                 # synthetic and distinct per rank: the MAX reduction is observable
     wall_max, _ = sharding.reduce_step_times(dist, "cpu", wall, 0.0)
-    rows = gather_ranks(dist, "cpu", [wall * 1e6, float(rank)])          # the per-rank rows of the real line
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # (DSIM_DRY_RUN_SHARE_DEVICE=1: every rank reports device 0 — what a mis-launched run would look like — for the test of the self-check)
+    dev_id = 0 if os.environ.get("DSIM_DRY_RUN_SHARE_DEVICE", "0") != "0" else local
+    rows = gather_ranks(dist, "cpu", [wall * 1e6, float(rank), float(dev_id)])          # the per-rank rows of the real line
+    check = self_check(world, a.gpus, dist_info.get("backend"), "gloo", [r[2] for r in rows], [r[0] for r in rows])
     if rank == 0:
         print(json.dumps({"metric": "drone-steps/sec (num_drones x env steps/s)", "value": None, "unit": "drone-steps/s",
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "dry_run": True, "scaling": "weak",
                           "config": {"workload": WORKLOAD_TEXT[a.workload], "parallelism": f"shard{world}"},
                           "dist": dist_info, "wall_max_over_ranks_s": wall_max, "rank0_wall_s": wall,
                           "ranks": {"launch_us_min": min(r[0] for r in rows), "launch_us_max": max(r[0] for r in rows),
-                                    "seen": sorted(int(r[1]) for r in rows)}}))
+                                    "launch_us_per_rank": [r[0] for r in rows], "device_of_rank": [int(r[2]) for r in rows],
+                                    "seen": sorted(int(r[1]) for r in rows)},
+                          "self_check": check}))
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and world > 1 and not check["ok"]:
+        sys.exit(SELF_CHECK_RC)
 
 
 if __name__ == "__main__":

@@ -104,6 +104,7 @@ class DownwashArgs(ctypes.Structure):
         ("prebinned", ctypes.c_int32),
         ("phase", ctypes.c_int32),
         ("halo", ctypes.c_void_p),
+        ("pairs_evaluated", ctypes.c_void_p),
     ]
 
 

@@ -2003,6 +2003,7 @@ struct DwK {
   int* adj_list;     // [max_k][n_pad] or null
   int max_k;
   int n_types;       // length of types[]
+  unsigned long long* pairs;   // diagnostics: += pairs evaluated (dsim_downwash_args.pairs_evaluated), or null
 };
 // position component c of world entry j: from the gathered array, or (single-rank fleets, pos_all = null)
 // straight from the state block
@@ -2126,6 +2127,16 @@ __device__ __forceinline__ float dw_pair_acc(float4 p, float x, float y, float z
 #define DW_RPG 8
 #define DW_MAXG (DW_CAP / DW_RPG)
 #define DW_ENT_PER_THREAD 6            // ceil(768 / 128): the tile of the dense form, per thread
+// The dense form's LDS tile.  Round 5, from in-kernel stamps (tools/c5_query_timeline.py, profiles/r05_c5_timeline_*.txt): with
+// 768 entries of 16 bytes a workgroup took 14 000 B of LDS and a CU held ELEVEN — 2 816 slots for the 2 956 workgroups of a
+// 65 536-drone shard at BASELINE config 5's density (28 x 105 cells with the box's margin, + the overflow groups): the ~30 that
+// did not fit started 9-13 us late, lived their ~19 us like the others and ended the launch at 32 us where the first generation
+// ends at 26-28 (a 13 232 B workgroup still made eleven: the allocation granule is coarser than the arithmetic suggests).  The
+// banded path needs x, y, z of a candidate, not its index: its tile is three float planes, 12 bytes per entry — 768 entries in
+// 9 216 B, 10 928 B per workgroup with the static arrays, fourteen workgroups per CU by the arithmetic and at least the
+// thirteen that put every cell of the shard into ONE generation.  The plain path reads the same bytes as 576 entries of 16.
+#define DW_TILE_DENSE 768              // entries of the banded path's tile
+#define DW_TILE_DENSE_BYTES (DW_TILE_DENSE * 12)
 // Two grids: the RECEIVERS are the entries of grid b, the CANDIDATES those of grid cnd — the same grid in the one-pass
 // form; in the split form of a sharded fleet (DSIM_DW_LOCAL / DSIM_DW_HALO_QUERY) the local pass runs while the
 // neighbouring ranks' positions are still on the wire, and the second pass (accumulate: force += ) takes the local
@@ -2142,7 +2153,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
   __shared__ float4 recv[BAND ? DW_CAP : 1];                                           // receivers, sorted by height
   __shared__ __attribute__((aligned(16))) int rty[BAND ? DW_CAP : 4];                  // their types (-1: not mine to serve); before
   float* const skey = reinterpret_cast<float*>(rty);                                   // that, the heights while they are ranked (the
-                                                                                       // tile's 12 KB + this must stay within 11 cells per CU)
+                                                                                       // tile + this decide how many cells a CU holds: DW_TILE_DENSE)
   __shared__ float zlo[BAND ? DW_MAXG : 1];                                            // lowest receiver of every group
   __shared__ int wcnt[BAND ? TPB / 64 : 1][BAND ? DW_MAXG + 1 : 1];                    // entries per band, per wave
   constexpr int RPB = TPB / DW_LPB;                                                    // receivers per pass
@@ -2152,10 +2163,33 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
     const long long gid = (long long)blockIdx.x * TPB + t;
     for (long long z = gid; z < (long long)ncells + DW_CNT_EXTRA; z += (long long)gridDim.x * TPB) a.count_next[z] = 0;
   }
+  // (Measured and rejected, round 5: a STAGGERED start.  In-kernel stamps (tools/c5_query_timeline.py) show set-ups of 9 us
+  // and pair loops of 7.5 us in workgroups that live 19 us of a 30 us launch, all of them in the same phase at the same time;
+  // holding back three quarters of the workgroups by one, two and three stages of 1-3 us, so that one stage's pair loops run
+  // under the next one's set-ups, made the chain LONGER by almost exactly the last stage's delay — 47.7 / 50.9 / 54.7 us against
+  // 45.1 (profiles/r05_c5_stagger_ab.txt): the set-ups are not idle waiting, the instruction issue is busy throughout.)
+  // Which cell this workgroup serves.  The grid's outer ring is the box's margin (downwash.py:_grid_box grows the fleet's
+  // bounding box by one cell on every side): empty in the normal case, and in row-major order its cells come every nx-th
+  // index — dealt to the compute units in turn, some CUs get three empty cells and nine full ones, others twelve full ones,
+  // and the launch ends with the busiest CU (in-kernel stamps, tools/c5_query_timeline.py: last workgroup of a CU done after
+  // 21.6 us on the idlest, 31.5 us on the busiest).  The INTERIOR cells take the first workgroup indices, the ring the last:
+  // every CU gets its share of the full cells, and what starts last is what has nothing to do.  (Any order is correct.)
+  int c = (int)blockIdx.x;
+  if (c < ncells && b.nx > 2 && b.ny > 2) {
+    const int inx = b.nx - 2, n_in = inx * (b.ny - 2);
+    if (c < n_in) c = (c / inx + 1) * b.nx + (c % inx + 1);
+    else {
+      int r = c - n_in;                              // the ring: bottom row, top row, left column, right column
+      if (r < b.nx) c = r;
+      else if ((r -= b.nx) < b.nx) c = (b.ny - 1) * b.nx + r;
+      else if ((r -= b.nx) < b.ny - 2) c = (r + 1) * b.nx;
+      else c = (r - (b.ny - 2) + 1) * b.nx + b.nx - 1;
+    }
+  }
   if (accumulate && (int)blockIdx.x < ncells) {
     // halo pass: the cells that hold halo entries span [lo, hi] in each direction (kept by k_dw_bin_halo); a cell further
     // than the neighbourhood's reach from that range has nothing to add — most of a slab's cells: two scalar loads and out
-    const int cx_ = (int)blockIdx.x % b.nx, cy_ = (int)blockIdx.x / b.nx;
+    const int cx_ = c % b.nx, cy_ = c / b.nx;
     const int rg = rings;
     const int xlo = b.nx - 1 - cnd.count[ncells + 1], xhi = cnd.count[ncells + 2];
     const int ylo = b.ny - 1 - cnd.count[ncells + 3], yhi = cnd.count[ncells + 4];
@@ -2181,8 +2215,10 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
           const int cnt = min(cnd.count[cc], DW_CAP);
           const float4* __restrict__ src = cnd.buckets + (long long)cc * DW_CAP;
           for (int e = sub; e < cnt; e += DW_LPB) fz += dw_pair(src[e], m2.x, m2.y, m2.z, 1.0f, d1, d2c);
+          if (a.pairs && sub == 0) atomicAdd(a.pairs, (unsigned long long)cnt);
         }
       for (int e = sub; e < n_ovf_c; e += DW_LPB) fz += dw_pair(cnd.overflow[e], m2.x, m2.y, m2.z, 1.0f, d1, d2c);
+      if (a.pairs && sub == 0) atomicAdd(a.pairs, (unsigned long long)n_ovf_c);
 #pragma unroll
       for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
       if (sub == 0) dw_write(a, i, K * fz, accumulate);
@@ -2194,8 +2230,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
   // their type ids; their types' coefficients) and is two: the first trip brings the counts, the first pass's
   // receiver entries (speculatively: slot r of the bucket exists whether or not it is filled) and the coefficient
   // table of ALL types (to LDS); the second the tile and the receivers' type ids.
-  const int c = (int)blockIdx.x;                                                       // this workgroup's cell
-  const int cx = c % b.nx, cy = c / b.nx;
+  const int cx = c % b.nx, cy = c / b.nx;                                              // (c: this workgroup's cell, above)
   const int side = 2 * rings + 1, n_nb = side * side, centre = rings * side + rings;
   int n_ovf = 0;
   const float4 me_first = b.buckets[(long long)c * DW_CAP + r_in];                     // (r_in < RPB <= DW_CAP)
@@ -2230,7 +2265,12 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
     const int G = (cnt_c + DW_RPG - 1) / DW_RPG;
     // (measured and rejected: sending the halo pass — few candidates — down the plain path below: 65.5 against 62.1 us for
     // the three phases; the bands save more pairs than their set-up costs even there)
-    if (whole && G >= 2 && total + 2 * DW_LPB <= DW_ENT_PER_THREAD * TPB) {         // (room for the sentinels behind the last band)
+    // (the banded tile: three planes of band_cap floats in the same bytes the plain path uses as tile_cap entries of 16)
+    const int band_cap = tile_cap * 4 / 3;
+    float* const tpx = reinterpret_cast<float*>(tile);
+    float* const tpy = tpx + band_cap;
+    float* const tpz = tpy + band_cap;
+    if (total <= band_cap && G >= 2 && total + 2 * DW_LPB <= min(DW_ENT_PER_THREAD * TPB, band_cap)) {   // (room for the sentinels behind the last band)
       const unsigned lane = t & 63u;
       const int w = __builtin_amdgcn_readfirstlane((int)(t >> 6));
       int my_ty = -1, rank = 0;
@@ -2333,8 +2373,9 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
         int acc = 0;
 #pragma unroll
         for (int k = DW_MAXG; k >= 1; --k) { bstart[k] = acc; acc += wave_cnt[k]; }
-        if (t < 2 * DW_LPB)                  // sentinels behind the last band (below everything: no term), see the pair loop
-          tile[acc + (int)t] = make_float4(0.0f, 0.0f, -__builtin_inff(), 0.0f);
+        if (t < 2 * DW_LPB) {                // sentinels behind the last band (below everything: no term), see the pair loop
+          tpx[acc + (int)t] = 0.0f; tpy[acc + (int)t] = 0.0f; tpz[acc + (int)t] = -__builtin_inff();
+        }
       }
       int wbase[DW_MAXG + 1];
 #pragma unroll
@@ -2351,7 +2392,10 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
         for (int k = 1; k <= DW_MAXG; ++k) {
           if (k > G) continue;
           const unsigned long long m = __ballot(band == k);
-          if (band == k) tile[wbase[k] + (int)__popcll(m & ((1ULL << lane) - 1ULL))] = ent[q];
+          if (band == k) {
+            const int slot = wbase[k] + (int)__popcll(m & ((1ULL << lane) - 1ULL));
+            tpx[slot] = ent[q].x; tpy[slot] = ent[q].y; tpz[slot] = ent[q].z;
+          }
           wbase[k] += (int)__popcll(m);
         }
       }
@@ -2379,11 +2423,17 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
           // entry of a lower band (not above ANY receiver of this group: dz <= 0, no term) or one of the sentinels behind
           // the last band — so the trip count is the wave's, and the loop control scalar
           for (int base = 0; base < lim; base += 2 * DW_LPB) {
-            const float4 p0 = tile[base + sub8], p1 = tile[base + DW_LPB + sub8];
+            const int e0 = base + sub8;                     // (x, y, z of two candidates: three two-address LDS reads)
+            const float4 p0 = make_float4(tpx[e0], tpy[e0], tpz[e0], 0.0f);
+            const float4 p1 = make_float4(tpx[e0 + DW_LPB], tpy[e0 + DW_LPB], tpz[e0 + DW_LPB], 0.0f);
             fz = dw_pair_acc(p0, me.x, me.y, me.z, d1s, d2s, fz);
             fz = dw_pair_acc(p1, me.x, me.y, me.z, d1s, d2s, fz);
           }
           for (int k = sub8; k < n_ovf; k += DW_LPB) fz += dw_pair(cnd.overflow[k], me.x, me.y, me.z, 1.0f, d1, d2c);
+        }
+        if (a.pairs) {                 // (wave-uniform) what this group's loops evaluated: whole trips of sixteen, per receiver served
+          const int served = (int)__popcll(__ballot(have && sub8 == 0));
+          if (lane == 0) atomicAdd(a.pairs, (unsigned long long)served * (unsigned long long)(((lim + 2 * DW_LPB - 1) / (2 * DW_LPB)) * (2 * DW_LPB) + n_ovf));
         }
 #pragma unroll
         for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
@@ -2441,6 +2491,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
     }
     if (have)
       for (int k = sub_p; k < n_ovf; k += lpb) fz += dw_pair(cnd.overflow[k], me.x, me.y, me.z, 1.0f, d1, d2c);
+    if (a.pairs && have && sub_p == 0) atomicAdd(a.pairs, (unsigned long long)(total + n_ovf));
     for (int off = lpb / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
     if (have && sub_p == 0) dw_write(a, i, K * fz, accumulate);
     r0 += RPB >> sh;
@@ -2912,7 +2963,7 @@ int dsim_dev_alloc(dsim_ctx* ctx, int64_t bytes, void** out) {
   return (int)e;
 }
 int dsim_dev_free(dsim_ctx* ctx, void* ptr) {
-  if (!ctx) return DSIM_E_ARG;
+  (void)ctx;                                          // (may be NULL: a block may outlive the ctx it was allocated through)
   return ptr ? (int)hipFree(ptr) : DSIM_OK;           // (hipFree waits for the work that may still use the block)
 }
 
@@ -3769,7 +3820,7 @@ static void launch_query_cell(dsim_ctx* ctx, hipStream_t st_, const DwK& a, cons
   const double nb_mean = (double)m_candidates / (double)ncells * (2 * rings + 1) * (2 * rings + 1);
   const dim3 gq((unsigned)(ncells + DW_OVF_GROUPS));
   if (nb_mean <= 128.0) hipLaunchKernelGGL((k_dw_query_cell<64, false>), gq, dim3(64), 256 * sizeof(float4), st_, a, b, cnd, rings, 256, accumulate);
-  else hipLaunchKernelGGL((k_dw_query_cell<128, true>), gq, dim3(128), 768 * sizeof(float4), st_, a, b, cnd, rings, 768, accumulate);
+  else hipLaunchKernelGGL((k_dw_query_cell<128, true>), gq, dim3(128), DW_TILE_DENSE_BYTES, st_, a, b, cnd, rings, DW_TILE_DENSE_BYTES / (int)sizeof(float4), accumulate);
 }
 
 int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_downwash_args* g,
@@ -3830,6 +3881,7 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
     bucket_layout(g->workspace, ncells, 1 - ctx->dw_parity, &lb);
     lb.xmin = g->xmin; lb.ymin = g->ymin; lb.inv_cell = hb.inv_cell; lb.nx = g->nx; lb.ny = g->ny; lb.local_offset = 0;
     a.types = ctx->d_types; a.type_id = g->type_id; a.n_types = ctx->n_types;
+    a.pairs = (unsigned long long*)g->pairs_evaluated;
     a.m = g->m; a.n = n; a.n_pad = state.n_pad; a.local_offset = 0;
     a.xmin = g->xmin; a.ymin = g->ymin; a.inv_cell = hb.inv_cell; a.nx = g->nx; a.ny = g->ny;
     a.force_out = force_out;
@@ -3925,6 +3977,7 @@ static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view
   if (rc) return rc;
   const long long ncells = (long long)g->nx * g->ny;
   a.types = ctx->d_types; a.type_id = g->type_id; a.pos_all = g->pos_all; a.n_types = ctx->n_types;
+  a.pairs = (unsigned long long*)g->pairs_evaluated;
   a.m = g->m; a.m_pad = g->m_pad; a.n = n; a.n_pad = state.n_pad; a.local_offset = g->local_offset;
   if (g->local_offset < 0 || g->local_offset + n > g->m || g->m >= (1LL << 31)) return DSIM_E_ARG;
   a.xmin = g->xmin; a.ymin = g->ymin; a.inv_cell = 1.0f / g->cell; a.nx = g->nx; a.ny = g->ny;

@@ -358,6 +358,7 @@ class Downwash:
         self._single = None              # single-rank form: (args, state view, byref) reused while the grid stands
         self._halo_args = None           # halo form: the three phases' argument blocks, rebuilt at a resize
         self._last_ok = {}               # id(args) -> dsim_downwash_prebin_ok of its shape
+        self.pair_counter = None         # diagnostics (count_pairs): int64[1] the query adds its evaluated pairs to
 
     def _grid_box(self, wp, lo_hi=None):
         """Bounding box of the world in xy -> grid.  Drones that later leave the box are clamped to
@@ -389,6 +390,7 @@ class Downwash:
         a.type_id = self.type_id.data_ptr() if self.type_id is not None else None
         a.local_offset = int(local_offset or 0)
         a.prebinned, a.phase, a.halo = 0, nat.DW_ALL, None
+        a.pairs_evaluated = self.pair_counter.data_ptr() if self.pair_counter is not None else None
         return a
 
     def _workspace(self, a, need) -> None:
@@ -459,6 +461,12 @@ class Downwash:
             return None
         self._prebin_version = self.state.version
         return ctypes.addressof(a)
+
+    def count_pairs(self, on: bool = True) -> None:
+        """Diagnostics: have the query count the (receiver, candidate) pairs it evaluates into ``pair_counter`` (int64[1],
+        cumulative; dsim_downwash_args.pairs_evaluated).  Results do not change; bench.py's vector-pipe roofline reads it."""
+        self.pair_counter = torch.zeros((1,), dtype=torch.int64, device=self.ctx.device) if on else None
+        self._single = self._halo_args = None          # (the prepared argument blocks carry the pointer)
 
     def invalidate_prebin(self) -> None:
         """The state was changed by something other than the fused step that pre-binned it."""

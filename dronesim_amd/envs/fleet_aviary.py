@@ -88,7 +88,7 @@ class CtrlAviary:
         storage: str = "auto",
         downwash_split: Optional[bool] = None,
         defer_fallback: bool = False,
-        placement: bool = True,
+        placement: bool = False,
         dyn_ang_vel: str = "reference",
     ):
         if gui or record or obstacles:
@@ -184,8 +184,9 @@ class CtrlAviary:
             # plain SoA [F][n_pad] is the simplest view for small fleets; from a few hundred thousand drones on the
             # wave-tiled form [n/64][F][64] is 3-8 % faster (power-of-two field strides alias HBM channels)
             layout = "tile64" if num_drones >= 262144 else "soa"
-        # placement=True: where the observation rows of a large quad fleet lie relative to its state block is chosen by
-        # timing the Env.step launch on a few candidates (placement.py; from ~1 M drones on)
+        # placement=True (opt-in): where the observation rows of a large fleet lie relative to its state block is chosen by
+        # timing the Env.step launch on a few candidates (placement.py; from ~1 M drones on).  Off by default since round 5:
+        # on fresh boxes the search was worth between -10 % and +12 % of the two-call loop (BENCH_r04.json), a coin flip
         self.ctx.placement = bool(placement)
         self.state = FleetState(self.ctx, num_drones, layout)
         self._type_id = None

@@ -48,7 +48,8 @@ class Context:
         self.order = None
         # Placement (placement.py): where the observation rows of a large fleet lie relative to the state block is chosen
         # by timing the real launch.  `placement` False: allocated plainly.  `placement_log`: one dict per search made.
-        self.placement = True
+        self.placement = False                 # opt-in (CtrlAviary(placement=True) / a stand-alone controller sets it)
+        self.placement_walk_bytes = None       # the transient budget of a search; None = placement.WALK_BYTES (4 GiB)
         self.placement_log = []
 
     @property

@@ -58,7 +58,9 @@ from typing import Callable, Optional
 import torch
 
 MIN_BYTES = 64 << 20                          # arrays at least this large, or they are allocated plainly
-WALK_BYTES = 34 << 30                         # held at once while searching (transient): two 16 GiB regions and a candidate; good places mostly turn up within 3-4 GiB
+WALK_BYTES = 4 << 30                          # held at once while searching (transient).  Round 4 walked 34 GiB (two 16 GiB regions and a candidate): on
+                                              # fresh boxes that bought nothing reliable (BENCH_r04: -10.7 % to +3 %), so the opt-in default is small;
+                                              # Context.placement_walk_bytes overrides it
 WALK_FRACTION = 0.125                         # ... and never more than this share of the free device memory
 STRIDE_BYTES = 1 << 30                        # untimed ballast between two candidates of the rows' walk: fewer, further apart
 CLEARLY = 0.93                                # one candidate this much faster than another: the two cases are apart, stop
@@ -69,7 +71,7 @@ class _DriverBlock:
     interface: the tensor keeps this object alive, and the block goes back to the driver when the last tensor on it dies."""
 
     def __init__(self, ctx, shape):
-        self.ctx, self.shape = ctx, tuple(int(d) for d in shape)
+        self.ctx, self.lib, self.shape = ctx, ctx.lib, tuple(int(d) for d in shape)
         n = 4
         for d in self.shape:
             n *= d
@@ -86,9 +88,11 @@ class _DriverBlock:
         return torch.as_tensor(self, device=self.ctx.device)
 
     def __del__(self):
+        # (the block goes back whether or not its Context is still open: env.close() destroys the ctx, the tensors on the
+        # block are usually dropped afterwards — dsim_dev_free does not need the ctx)
         try:
-            if self.ptr and self.ctx.handle:
-                self.ctx.lib.dsim_dev_free(self.ctx.handle, ctypes.c_void_p(self.ptr))
+            if self.ptr:
+                self.lib.dsim_dev_free(None, ctypes.c_void_p(self.ptr))
         except Exception:
             pass
         self.ptr = 0
@@ -113,7 +117,7 @@ def _free_bytes(device) -> int:
 
 
 def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int = 3, report: Optional[list] = None,
-               label: str = "observation rows", walk_bytes: int = WALK_BYTES, timer=None,
+               label: str = "observation rows", walk_bytes: Optional[int] = None, timer=None,
                clearly: float = CLEARLY, ctx=None, free_bytes: Optional[int] = None, stride_bytes: int = 0) -> torch.Tensor:
     """A zeroed fp32 array of `shape`.  `trial(array)` enqueues ONE pass of the real kernel writing its output to `array`
     (the caller restores whatever the passes change).  Candidates are allocated one after the other and all held, so that
@@ -133,6 +137,8 @@ def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int
     for d in shape:
         nbytes *= int(d)
     free = _free_bytes(device) if free_bytes is None else int(free_bytes)
+    if walk_bytes is None:
+        walk_bytes = getattr(ctx, "placement_walk_bytes", None) or WALK_BYTES
     budget = min(int(walk_bytes), int(WALK_FRACTION * free))
     cands, blocks, times = [], [], []
     chosen, decided = None, ""

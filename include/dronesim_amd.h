@@ -303,7 +303,8 @@ int dsim_destroy(dsim_ctx* ctx);
 /* Plain device allocations straight from the driver (hipMalloc / hipFree on the ctx's device), outside any caching
  * allocator of the host framework.  (No counterpart in the reference.)  For host classes that choose WHERE a fleet-sized
  * array lies by trial (dronesim_amd/placement.py): candidates that are not kept go back to the driver at once, and no
- * framework-wide cache has to be emptied to walk through device memory.  The caller owns what it allocates. */
+ * framework-wide cache has to be emptied to walk through device memory.  The caller owns what it allocates; dsim_dev_free
+ * takes ctx == NULL too (a block may outlive the ctx it was allocated through: dsim_destroy frees nothing of the caller's). */
 int dsim_dev_alloc(dsim_ctx* ctx, int64_t bytes, void** out);
 int dsim_dev_free(dsim_ctx* ctx, void* ptr);
 
@@ -428,6 +429,10 @@ typedef struct dsim_downwash_args {
                                part of the query (see dsim_halo_plan)                                        */
   const struct dsim_halo_plan* halo;   /* nullable: the rest of the world is what the neighbouring ranks sent (pos_all must
                                be NULL, local_offset 0, m = n + the sum of the plan's recv_cap); bucket form only */
+  uint64_t* pairs_evaluated; /* nullable device counter, diagnostics only (results do not depend on it): += the number of
+                               (receiver, candidate) pairs whose term the query's loops evaluate in this call — the unit of
+                               the query's vector-pipe roofline (bench.py, config 5).  Bucket form only; one atomic per
+                               receiver group when given, one scalar test when not                                        */
 } dsim_downwash_args;
 int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny);
 

@@ -54,8 +54,31 @@ def test_eight_ranks_dry_run_config5():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 8 and d["dist"]["world_size"] == 8 and "configs[4]" in d["config"]["workload"]
-    assert d["ranks"]["seen"] == list(range(8))
+    assert d["ranks"]["seen"] == list(range(8)) and d["self_check"]["ok"] is True
     assert d["ranks"]["launch_us_min"] == 1e3 and d["ranks"]["launch_us_max"] == 8e3 and d["wall_max_over_ranks_s"] == 8e-3
+
+
+def test_eight_ranks_self_check_passes_and_catches_a_shared_device():
+    """The N-rank line checks itself (bench.self_check): world size = --gpus, the backend, one device per rank, every
+    rank's row present and timed.  Eight gloo ranks pass; the same run with every rank reporting device 0 — eight processes
+    on one GPU, what a mis-launched scaling run would be — prints its line, names the failed check and exits non-zero."""
+    import bench
+    r = _run(["--gpus", "8", "--steps", "3", "--warmup", "1", "--dry-run"], timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["self_check"]["ok"] is True and d["self_check"]["failed"] == []
+    assert d["ranks"]["device_of_rank"] == list(range(8)) and len(d["ranks"]["launch_us_per_rank"]) == 8
+    assert set(d["self_check"]["checks"]) >= {"world_size_equals_gpus_flag", "backend_is_gloo", "one_device_per_rank",
+                                              "every_rank_reported", "every_rank_timed_something"}
+    r = _run(["--gpus", "8", "--steps", "3", "--warmup", "1", "--dry-run"], env={"DSIM_DRY_RUN_SHARE_DEVICE": "1"}, timeout=400)
+    d = _json_line(r.stdout)
+    assert d["self_check"]["ok"] is False and d["self_check"]["failed"] == ["one_device_per_rank"]
+    assert r.returncode != 0
+    # the pure function: a wrong backend and a missing rank are named
+    c = bench.self_check(8, 8, "gloo", "nccl", list(range(7)), [1.0] * 7)
+    assert c["failed"] == ["backend_is_nccl", "every_rank_reported"]
+    assert bench.self_check(4, 8, "nccl", "nccl", [0, 1, 2, 3], [1.0] * 4)["failed"] == ["world_size_equals_gpus_flag"]
+    assert bench.self_check(1, 1, None, "nccl", [0], [150.0])["ok"]
 
 
 def test_watchdog_saves_the_headline_when_an_extra_section_hangs():

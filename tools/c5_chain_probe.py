@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""What each launch of config 5's chain costs IN the chain (dev helper): the 65 536-drone shard stepped (a) as the product does
+(query, step + grid binning, WLS fallback pass), (b) with the fallback pass left out (DSIM_OPT_DEFER_FALLBACK and nobody
+launching it: timing only — the queue is empty in this hover workload, so results do not change), (c) the fallback pass alone,
+back to back.  usage: python tools/c5_chain_probe.py [steps [lib]]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from dronesim_amd import _native as nat  # noqa: E402
+
+
+def timed(f, k):
+    for _ in range(20):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(k):
+        f()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / k
+
+
+def main():
+    k = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    if len(sys.argv) > 2:
+        nat.load(sys.argv[2])                      # an A/B build of the same ABI
+    fl = bench.Fleet(65536, 1, 0, 1, "tile64", 1, config5=True)
+    env = fl.env
+    print("chain, as the product steps it          %.2f us" % timed(fl.step, k))
+    env._tuning |= nat.OPT_DEFER_FALLBACK          # the step no longer launches the pass (and this probe does not either)
+    env._fused_plan_dw = None
+    print("chain without the fallback launch       %.2f us" % timed(fl.step, k))
+    env._tuning &= ~nat.OPT_DEFER_FALLBACK
+    env._fused_plan_dw = None
+    tid = env._type_id.data_ptr()
+
+    def fb():
+        nat.check(env.ctx.lib.dsim_wls_fallback(env.ctx.handle, env.ctx.stream_ptr(), env.NUM_DRONES, env.state.view(), tid, None))
+    print("fallback pass alone, back to back       %.2f us" % timed(fb, k))
+    print("chain again                             %.2f us" % timed(fl.step, k))
+
+
+if __name__ == "__main__":
+    main()
