@@ -19,7 +19,7 @@ EXPORTS = (
     "dsim_physics", "dsim_control", "dsim_control2", "dsim_step_adaptor", "dsim_traj_sample", "dsim_materialize",
     "dsim_counter_add", "dsim_reserve", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash",
     "dsim_downwash_workspace", "dsim_downwash_prebin_ok", "dsim_downwash_reset", "dsim_adjacency", "dsim_wls_fallback", "dsim_fleet_bounds",
-    "dsim_halo_pack", "dsim_downwash_workspace_halo", "dsim_dev_alloc", "dsim_dev_free",
+    "dsim_halo_pack", "dsim_downwash_workspace_halo", "dsim_dev_alloc", "dsim_dev_free", "dsim_noise_draw",
 )
 
 ABI_VERSION = 7
@@ -39,6 +39,7 @@ OPT_CALLER_IO = 1 << 14    # dsim_physics / dsim_control2: action, rows, command
 OPT_ACTION_ROWS = 1 << 15  # dsim_step_adaptor: the action row-major [n][4]
 OPT_DYN = 1 << 16          # Physics.DYN: BaseAviary._dynamics instead of the Bullet step (StepArgs.dyn_rpy_rates required)
 OPT_DYN_BODY_RATES = 1 << 17   # ... with ang_v = R(quat) rpy_rates instead of the reference's placeholder (-1, -1, -1)
+OPT_NOISE_FINE = 1 << 18   # rotor noise on the 16 + 16-bit Box-Muller lattice instead of the default 8 + 8-bit one (changes results)
 ADAPT_VELOCITY, ADAPT_RPYT = 0, 1
 QUERY_WLS_FALLBACKS, QUERY_WLS_FAILURES, QUERY_GROUND_CONTACTS, QUERY_HALO_OVERFLOW = 0, 1, 2, 3
 
@@ -174,6 +175,7 @@ def load(path: str = None) -> ctypes.CDLL:
     lib.dsim_halo_pack.argtypes = [vp, vp, i64, View, ctypes.POINTER(HaloPlan)]
     lib.dsim_dev_alloc.argtypes = [vp, i64, ctypes.POINTER(vp)]
     lib.dsim_dev_free.argtypes = [vp, vp]
+    lib.dsim_noise_draw.argtypes = [vp, vp, i64, i64, i32, ctypes.c_uint64, ctypes.c_uint64, i32, ctypes.c_uint32, vp, vp]
     lib.dsim_downwash_workspace_halo.restype = ctypes.c_int64
     lib.dsim_downwash_workspace_halo.argtypes = [i64, i64, i32, i32]
     if lib.dsim_abi_version() != ABI_VERSION:

@@ -267,7 +267,11 @@ __device__ __forceinline__ int waypoint_next(int wp, int n_wp) { return wp < n_w
 // metric definition): without the loop the compiler keeps the headline kernel in 91 instead of 110 VGPRs
 // (5 waves/SIMD) and 836 instead of 887 vector instructions.  (Measured and rejected: 2 — no change, 198 us
 // either way; 5 — the unrolled body spills, 533 vs 310 us.)
-template <int NOISE, int NROW = 4, bool OPTS = false, int NSUB = 0, bool PLANE = false, class DT>
+// FINE: whether this instance carries the 16 + 16-bit noise lattice (DSIM_OPT_NOISE_FINE, a wave-uniform run-time switch)
+// beside the default one.  -1 = the rule: the single-sub-step instances (bound by HBM: the second path is free) and the general
+// kernels (OPTS) do; the instances that loop over sub-steps on the fast paths — bound by vector issue, tuned to their register
+// budgets — do not, and the launchers hand a fine-lattice launch with several sub-steps to the general kernels.
+template <int NOISE, int NROW = 4, bool OPTS = false, int NSUB = 0, bool PLANE = false, int FINE = -1, class DT>
 __device__ __forceinline__ void quad_substeps(DT& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[4], unsigned long long step_index,
                                               V3 ext = V3{0.0f, 0.0f, 0.0f}, const float* prev = nullptr, long long nid = -1,
@@ -292,6 +296,8 @@ __device__ __forceinline__ void quad_substeps(DT& T, const StepK& a, long long i
           nz[j] = a.noise_replay[((long long)k * 2 * NROW + j) * a.n_pad + i];
           nz[4 + j] = a.noise_replay[((long long)k * 2 * NROW + NROW + j) * a.n_pad + i];
         }
+      } else if ((FINE >= 0 ? FINE != 0 : (NSUB == 1 || OPTS)) && (a.options & DSIM_OPT_NOISE_FINE)) {   // (wave-uniform) the 16 + 16-bit lattice
+        quad_normals_fine(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);
       } else {
         const uint64_t sub = step_index * (uint64_t)a.substeps + (uint64_t)k;          // (wave-uniform)
         if (k == 0 || (sub & 1ull) == 0) noise_block(a.seed, noise_key, sub >> 1, nb);  // a new block every other sub-step
@@ -345,6 +351,8 @@ __device__ __forceinline__ void hexa_substeps(DT& T, const StepK& a, long long i
       if (REPLAY && a.noise_replay) {
 #pragma unroll
         for (int j = 0; j < 12; ++j) nz[j] = a.noise_replay[((long long)k * 12 + j) * a.n_pad + i];
+      } else if ((ONE || REPLAY) && (a.options & DSIM_OPT_NOISE_FINE)) {   // (wave-uniform) the 16 + 16-bit lattice: the single-sub-step and the general instances
+        hexa_normals_fine(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);
       } else if (tab) {
         uint32_t c[4];
         noise_block(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, c);
@@ -435,6 +443,24 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
 }
 
 __global__ void k_counter_add(unsigned long long* c, unsigned long long inc) { *c += inc; }
+
+// dsim_noise_draw: the unit-variance normals of (drone, sub-step), through the very functions the step kernels call
+struct NoiseK { long long n, n_pad; int n_act, substeps; unsigned long long seed, step_index; unsigned options; const int* drone_id; float* out; };
+__global__ __launch_bounds__(256) void k_noise_draw(NoiseK a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const uint64_t key = (uint64_t)(a.drone_id ? (long long)a.drone_id[i] : i);
+  for (int k = 0; k < a.substeps; ++k) {
+    const uint64_t sub = a.step_index * (uint64_t)a.substeps + (uint64_t)k;
+    float nz[12];
+    const bool fine = (a.options & DSIM_OPT_NOISE_FINE) != 0;
+    if (a.n_act == 4) { if (fine) quad_normals_fine(a.seed, key, sub, nz); else noise_normals<4>(a.seed, key, sub, nz); }
+    else { if (fine) hexa_normals_fine(a.seed, key, sub, nz); else noise_normals<6>(a.seed, key, sub, nz); }
+    // (the functions return the normals already scaled by their deviations: .01 on the force rows, .001 on the moment rows)
+    for (int j = 0; j < 2 * a.n_act; ++j)
+      a.out[((long long)k * 2 * a.n_act + j) * a.n_pad + i] = nz[j] * (j < a.n_act ? 100.0f : 1000.0f);
+  }
+}
 
 typedef float vf4 __attribute__((ext_vector_type(4)));        // (a native vector: what the nontemporal builtins take)
 
@@ -1305,7 +1331,7 @@ __global__ __launch_bounds__(256, DSIM_PHYS_WAVES) void k_physics_fast(StepK a) 
 #pragma unroll
   for (int j = 0; j < 4; ++j) cmd[j] = clampf(cmd[j], T.pmin[j], T.pmax[j]);           // CtrlAviary.py:258-263
   if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
-  quad_substeps<NOISE ? 1 : 0>(T, a, i, s, cmd, a.step_index);
+  quad_substeps<NOISE ? 1 : 0, 4, false, 0, false, 1>(T, a, i, s, cmd, a.step_index);      // (both noise lattices)
   ground_watch(T, s, a.fb.counters, i < a.n);
   const unsigned so = pin_lane_offset(sl);
   store_rigid<NT>(sb, sfs, so, s);
@@ -1721,7 +1747,7 @@ __device__ __forceinline__ void adaptor_body(DT& T, const StepK& a, long long i,
   } else {                                                 // RPYTAviary.py:184-191
     indi_rate<4>(T, DSIM_RCP(a.dt_ctrl), s, v3(v[0], v[1], v[2]), v[3], m);
   }
-  quad_substeps<NOISE ? 1 : 0, 4, PLANE, 0, PLANE>(T, a, i, s, m.cmd, a.step_index, V3{0.0f, 0.0f, 0.0f}, nullptr,
+  quad_substeps<NOISE ? 1 : 0, 4, PLANE, 0, PLANE, 1>(T, a, i, s, m.cmd, a.step_index, V3{0.0f, 0.0f, 0.0f}, nullptr,
                                                    NOISE ? noise_id(a, i) : -1LL);
   ground_watch(T, s, a.fb.counters, i < a.n);
   store_rigid(ad.sb, ad.sfs, ad.sl, s);
@@ -3229,7 +3255,10 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   const hipStream_t st_ = (hipStream_t)stream;
   const dim3 b(256);
   long long first = 0;
-  const bool phys_opts = (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND | DSIM_OPT_PLANE)) != 0;
+  // DSIM_OPT_NOISE_FINE: carried by the single-sub-step instances of the fast kernels and by the general kernels (quad_substeps)
+  const bool fine = noise && !args->noise_replay && (args->options & DSIM_OPT_NOISE_FINE) != 0;
+  const bool fine_slow = fine && a.substeps != 1;       // several sub-steps per launch on the fine lattice: the general kernels
+  const bool phys_opts = (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND | DSIM_OPT_PLANE)) != 0 || fine_slow;
   const bool plane = (args->options & DSIM_OPT_PLANE) != 0;
   if ((args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)) && six)
     return DSIM_E_UNSUPPORTED;                          // the add-on formulas are written for the four-rotor links
@@ -3318,7 +3347,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     return (int)hipGetLastError();
   }
   const bool multi = a.wp_table != nullptr || a.n_steps > 1;
-  if (uni && !six && !(args->action && multi) && !args->noise_replay && !args->ext_force && !phys_opts) {
+  if (uni && !six && !(args->action && multi) && !args->noise_replay && !args->ext_force && !phys_opts && !(fine && multi)) {
     // fast path over the whole 256-drone tiles (an explicit action: the ACT instances of the plain form)
     const bool nt = stream_policy(args, state.n_pad, 232.0);
     const long long tiles = a.n_pad / 256;
@@ -3366,7 +3395,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
   if (first < a.n_pad) {   // ragged tail, or everything when the fast path does not apply
     a.first = first;
     const dim3 g(grid_for(a.n_pad - first));
-    const bool lean = !args->action && !args->noise_replay && !a.wp_table && a.n_steps == 1 && !phys_opts;
+    const bool lean = !args->action && !args->noise_replay && !a.wp_table && a.n_steps == 1 && !phys_opts;     // (fine_slow is a phys_opt)
     if (lean && !uni && a.tg.base && ctx->n_types <= 4 && ctx->max_act == 6 && !any_quadlaw6 && !DSIM_VARIANT_GENERIC(args)) {
       // a heterogeneous fleet kept in the CALLER's own order (CtrlAviary(storage="caller"); storage="auto" stores it
       // type-major and never comes here): the LDS-staged kernels, which partition every tile by type
@@ -3423,7 +3452,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
       bin_next_commit(ctx, n, args, a);
       return (int)hipGetLastError();
     } else if (!six) {
-      if (lean) DSIM_LAUNCH_GEN(k_step_lean, noise, uni, false, g, a, st_);
+      if (lean && !fine) DSIM_LAUNCH_GEN(k_step_lean, noise, uni, false, g, a, st_);     // (the lean body carries the default lattice only)
       else if (plane) DSIM_LAUNCH_GEN(k_step_plane, noise, uni, false, g, a, st_);
       else DSIM_LAUNCH_GEN(k_step_gen, noise, uni, false, g, a, st_);
     } else {
@@ -3438,7 +3467,7 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
           a.fb.entries = ctx->d_fb;
         }
         fb_open = false;
-        if (lean && !a.action) DSIM_LAUNCH_GEN(k_step_lean, noise, uni, true, g, a, st_);
+        if (lean && !a.action && !fine) DSIM_LAUNCH_GEN(k_step_lean, noise, uni, true, g, a, st_);
         else if (plane) DSIM_LAUNCH_GEN(k_step_plane, noise, uni, true, g, a, st_);
         else DSIM_LAUNCH_GEN(k_step_gen, noise, uni, true, g, a, st_);
         fb_finish(ctx, a, st_);
@@ -3468,6 +3497,16 @@ int dsim_wls_fallback(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, c
   a.types = ctx->d_types; a.type_id = type_id; a.n_pad = state.n_pad; a.cmd_out = cmd_out;
   a.fb.entries = ctx->d_fb; a.fb.count = ctx->d_counters + 2; a.fb.counters = ctx->d_counters;
   fb_finish(ctx, a, (hipStream_t)stream);
+  return (int)hipGetLastError();
+}
+
+int dsim_noise_draw(dsim_ctx* ctx, void* stream, int64_t n, int64_t n_pad, int32_t n_act, uint64_t noise_seed, uint64_t step_index,
+                    int32_t substeps, uint32_t options, const int32_t* drone_id, float* out) {
+  if (!ctx || !out || n <= 0 || n > n_pad || (n_act != 4 && n_act != 6) || substeps < 1 || noise_seed == 0) return DSIM_E_ARG;
+  NoiseK a;
+  a.n = n; a.n_pad = n_pad; a.n_act = n_act; a.substeps = substeps; a.seed = noise_seed; a.step_index = step_index;
+  a.options = options; a.drone_id = drone_id; a.out = out;
+  hipLaunchKernelGGL(k_noise_draw, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -3504,6 +3543,7 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
     if (args->obs_out) return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, 20, 0);
     return DSIM_OK;
   }
+  const bool fine_slow = (args->noise_seed != 0 && !args->noise_replay && (args->options & DSIM_OPT_NOISE_FINE) && a.substeps != 1);
   const bool phys_opts = (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND | DSIM_OPT_PLANE)) != 0;
   if ((args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)) && ctx->max_act == 6) return DSIM_E_UNSUPPORTED;
   const int obs_w = 16 + ctx->max_act;
@@ -3541,8 +3581,8 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
       whole.first = 0; whole.count = a.n_pad; whole.type = 0; whole._pad = 0;
       runs = &whole; n_runs = 1;
     }
-    if (runs && n_runs > 0 && n_runs <= DSIM_MAX_TYPES && !args->noise_replay && !phys_opts) {
-      RunTab rt;
+    if (runs && n_runs > 0 && n_runs <= DSIM_MAX_TYPES && !args->noise_replay && !phys_opts && !fine_slow) {   // (k_physics_fast above carries
+      RunTab rt;                                                                                              //  both lattices at any count)
       bool any_hexa = false;
       const int blocks = make_runtab(ctx, a.n_pad, runs, n_runs, &rt, &any_hexa);
       if (blocks < 0) return blocks;
@@ -3610,7 +3650,8 @@ int dsim_step_adaptor(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, c
   const hipStream_t st_ = (hipStream_t)stream;
   const bool arows = (args->options & DSIM_OPT_ACTION_ROWS) != 0;
   if (args->obs_out && args->obs_width != 20) return DSIM_E_ARG;
-  if (uni && (a.n_pad % 256) == 0 && !(args->options & DSIM_OPT_PLANE) && !args->drone_id &&
+  const bool fine = noise && (args->options & DSIM_OPT_NOISE_FINE) != 0;      // (k_adaptor_fast carries the default lattice only)
+  if (uni && (a.n_pad % 256) == 0 && !(args->options & DSIM_OPT_PLANE) && !args->drone_id && !fine &&
       (!arows || ((uintptr_t)action & 15u) == 0)) {
     // homogeneous quad fleet in whole tiles: ONE launch, the observation rows fused (16-byte stores; a misaligned caller
     // buffer gets them from the observation kernel behind the step), the action in either layout

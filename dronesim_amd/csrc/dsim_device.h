@@ -205,6 +205,41 @@ __device__ __forceinline__ void box_muller8(uint32_t w, float& n0, float& n1) {
   n0 = r * __builtin_amdgcn_cosf(u2);
   n1 = r * __builtin_amdgcn_sinf(u2);
 }
+// DSIM_OPT_NOISE_FINE: 32 bits -> two normals, radius from the HIGH 16 bits (u1 = (h + 1) / 65536), direction from the LOW 16
+// (u2 = l / 65536 revolutions): 2^32 distinct pairs, |n| <= sqrt(2 corr ln 65536) = 4.710 sigma, variance sigma^2 exactly
+// (DSIM_BM16_CORR = 2 / mean(-2 ln u1) = 1.0000986...), kurtosis 2.9987.  Evaluated, not tabulated (65 536 radii do not fit
+// the LDS budget of the looped kernels).  Mirrored by oracle/dsim_oracle.c:orc_bm16.
+#define DSIM_BM16_S2 1.3864311112001642f         // 2 ln 2 x DSIM_BM16_CORR
+template <int SIGMA_E3>
+__device__ __forceinline__ void box_muller16(uint32_t w, float& n0, float& n1) {
+  constexpr float S2 = (SIGMA_E3 * 1e-3f) * (SIGMA_E3 * 1e-3f) * DSIM_BM16_S2;
+  const float u1 = ((float)(w >> 16) + 1.0f) * (1.0f / 65536.0f);
+  const float u2 = (float)(w & 0xFFFFu) * (1.0f / 65536.0f);
+  const float r = DSIM_SQRT(-S2 * __builtin_amdgcn_logf(u1));
+  n0 = r * __builtin_amdgcn_cosf(u2);
+  n1 = r * __builtin_amdgcn_sinf(u2);
+}
+// the fine stream's blocks: counter word 3's top bit set (a domain of its own beside the default stream's blocks)
+__device__ __forceinline__ void noise_block_fine(uint64_t seed, uint64_t drone, uint64_t blk, uint32_t c[4]) {
+  c[0] = (uint32_t)drone; c[1] = (uint32_t)(drone >> 32); c[2] = (uint32_t)blk; c[3] = (uint32_t)(blk >> 32) | 0x80000000u;
+  threefry4x32_12(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+// quad sub-step `sub`: block `sub`; words 0, 1 -> the four force normals, words 2, 3 -> the four moment normals
+__device__ __forceinline__ void quad_normals_fine(uint64_t seed, uint64_t drone, uint64_t sub, float* out) {
+  uint32_t c[4];
+  noise_block_fine(seed, drone, sub, c);
+  box_muller16<10>(c[0], out[0], out[1]); box_muller16<10>(c[1], out[2], out[3]);
+  box_muller16<1>(c[2], out[4], out[5]); box_muller16<1>(c[3], out[6], out[7]);
+}
+// hexa sub-step `sub`: blocks 2 sub and 2 sub + 1; words 0-2 of the first -> the six force normals, word 3 of the first and
+// words 0, 1 of the second -> the six moment normals
+__device__ __forceinline__ void hexa_normals_fine(uint64_t seed, uint64_t drone, uint64_t sub, float* out) {
+  uint32_t c[4], d[4];
+  noise_block_fine(seed, drone, 2 * sub, c);
+  noise_block_fine(seed, drone, 2 * sub + 1, d);
+  box_muller16<10>(c[0], out[0], out[1]); box_muller16<10>(c[1], out[2], out[3]); box_muller16<10>(c[2], out[4], out[5]);
+  box_muller16<1>(c[3], out[6], out[7]); box_muller16<1>(d[0], out[8], out[9]); box_muller16<1>(d[1], out[10], out[11]);
+}
 // normals for (drone, sub-step counter): out[0 .. NACT): force noise ~ N(0, 0.01), out[NACT .. 2 NACT): moment noise ~
 // N(0, 0.001)   (BaseAviary.py:1518-1521, 1429-1430).  Block = Threefry4x32-12(key = seed, counter = (drone, block index)).
 //   quad (8 normals per sub-step):  block index = sub >> 1; the even sub-step takes words 0, 1, the odd one words 2, 3:

@@ -90,6 +90,7 @@ class CtrlAviary:
         defer_fallback: bool = False,
         placement: bool = False,
         dyn_ang_vel: str = "reference",
+        noise: str = "lattice256",
     ):
         if gui or record or obstacles:
             raise NotImplementedError("gui/record/obstacles are rendering features outside the hot path")
@@ -121,6 +122,15 @@ class CtrlAviary:
             self._phys_options |= nat.OPT_PLANE
         # tuning bits handed to every call (nat.OPT_STREAM_ON/_OFF; the A/B knobs of a variants build); results do not depend on them
         self._tuning = int(options) & nat.TUNING_MASK
+        # The rotor-noise stream is product-defined (the reference draws from numpy's unseeded global generator,
+        # BaseAviary.py:1518-1525): Box-Muller pairs on a lattice of 256 radii x 256 directions by default (|n| <= 3.35 sigma),
+        # noise="fine": 65 536 x 65 536 (|n| <= 4.71 sigma, DSIM_OPT_NOISE_FINE) — free on the single-sub-step kernels, a few
+        # per cent on the looped ones (include/dronesim_amd.h: noise_seed).  Rides with the tuning bits into every launch.
+        if noise not in ("lattice256", "fine"):
+            raise ValueError(noise)
+        self.noise = noise
+        if noise == "fine":
+            self._tuning |= nat.OPT_NOISE_FINE
         self.neighbors_k = int(neighbors_k)
         if isinstance(drone_model, (str, DroneType)):
             drone_model = [drone_model]
@@ -217,8 +227,9 @@ class CtrlAviary:
         # per-drone arrays (action, observation rows, command, errors) in the CALLER's numbering straight from the kernels
         # (DSIM_OPT_CALLER_IO: the run kernels gather / scatter by drone_id) — no second pass over them.  Where the run
         # kernels do not serve the fleet (more than 8 runs, drag / ground / plane options) the host translates instead.
+        # (a fine-lattice launch with several sub-steps goes to the general kernels, which index by storage slot)
         self._caller_io = (self.order is not None and self._runs is not None and len(self._runs) <= 8
-                           and self._phys_options == 0)
+                           and self._phys_options == 0 and not (self.noise == "fine" and self.AGGR_PHY_STEPS > 1))
         self._action_buf = torch.zeros((self.n_act, self.state.n_pad), dtype=torch.float32, device=self.ctx.device)
         # the env's own last_clipped_action (BaseAviary.py:660-663, 545): separate from the
         # controller's cmd memory, exactly as env and controller are separate objects upstream
@@ -999,7 +1010,8 @@ class _AdaptorAviary(CtrlAviary):
         # A homogeneous fleet in whole tiles steps in ONE launch that takes the action as the caller holds it ([N, 4] rows
         # on the device: no transpose) and writes Env.step's observation rows itself (k_adaptor_fast).
         one_launch = (not self.dict_io and self.order is None and len(self.types) == 1 and self.state.n_pad % 256 == 0
-                      and not self.ground_plane and self._type_id is None)
+                      and not self.ground_plane and self._type_id is None
+                      and not (self.noise == "fine" and self.noise_seed != 0))      # (k_adaptor_fast carries the default lattice only)
         rows_in = (one_launch and isinstance(action, torch.Tensor) and action.dtype == torch.float32 and action.is_contiguous()
                    and action.device == self.ctx.device and tuple(action.shape) == (self.NUM_DRONES, 4)
                    and action.data_ptr() % 16 == 0)

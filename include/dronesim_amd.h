@@ -206,6 +206,13 @@ enum {
    * R(quat_new) rpy_rates_new instead of the placeholder — the world-frame image of the rates, which the model's own torque
    * equation treats as body rates (rpy_rates x J rpy_rates, :1805).  Off = the reference's (-1, -1, -1).                  */
   DSIM_OPT_DYN_BODY_RATES = 1u << 17,
+  /* -- rotor noise (changes results) -------------------------------------------------------------------------------------
+   * The finer of the two lattices the rotor-noise normals are drawn on (see dsim_step_args.noise_seed): 16 + 16 bits per
+   * Box-Muller pair instead of 8 + 8, one Threefry block per quad sub-step (two per hexa sub-step) instead of one per two
+   * sub-steps (one per hexa sub-step), radius and direction evaluated, not tabulated.  Free on the single-sub-step kernels
+   * (HBM-bound); on the kernels that loop over sub-steps, which are bound by vector issue, it costs what DESIGN.md section 3
+   * records.  Honoured by every kernel that draws noise (a wave-uniform run-time switch).                                */
+  DSIM_OPT_NOISE_FINE  = 1u << 18,
   /* -- scheduling (results do not depend on it) ---------------------------------------------------------------------- */
   DSIM_OPT_DEFER_FALLBACK = 1u << 11 /* dsim_step / dsim_control2 of a table with a morphing hexa do NOT launch the deferred
                                        WLS fallback pass behind the step; the caller launches dsim_wls_fallback itself —
@@ -228,7 +235,19 @@ typedef struct dsim_step_args {
   float    dt_phys;         /* 1/SIM_FREQ  (BaseAviary.py:675)                                   */
   float    dt_ctrl;         /* control_timestep handed to computeControl (fly_INDI.py:231)       */
   uint32_t options;         /* DSIM_OPT_*                                                        */
-  uint64_t noise_seed;      /* 0 = rotor noise off; else counter-based N(0,.01)/N(0,.001) noise  */
+  uint64_t noise_seed;      /* 0 = rotor noise off; else counter-based noise, N(0, .01) on the rotor forces and N(0, .001) on
+                               the rotor moments per sub-step (BaseAviary.py:1518-1525, 1429-1432).  The reference draws
+                               np.random.normal from the unseeded global generator; here the stream is PRODUCT-DEFINED:
+                               Threefry4x32-12 keyed by the seed, counter = (drone, block), Box-Muller pairs on a LATTICE —
+                                 default   8 + 8 bits per pair: 256 radii x 256 directions = 65 536 distinct pairs, |n| <= 3.354
+                                           sigma (the reference's tails are unbounded: mass 8.0e-4 beyond 3.354 sigma; 2.06e-3
+                                           instead of 2.70e-3 beyond 3 sigma), variance exactly sigma^2 (the radius is rescaled),
+                                           kurtosis 2.922 instead of 3, an atom of 3 / 256 of the mass at 0, Kolmogorov
+                                           distance 6.0e-3 from the normal distribution;
+                                 DSIM_OPT_NOISE_FINE   16 + 16 bits per pair: 2^32 distinct pairs, |n| <= 4.710 sigma (mass 2.5e-6
+                                           beyond), kurtosis 2.9987, Kolmogorov distance below what 1e7 draws resolve (1.9e-4).
+                               tests/test_noise_distribution.py measures both against N(0, 1) (Kolmogorov distance, moments,
+                               tail mass) over 1e7 draws; dsim_noise_draw hands out the normals themselves.              */
   uint64_t step_index;      /* env-step counter, mixed into the noise counter                    */
   const float* noise_replay;/* nullable; [phys_substeps][2*n_act][n_pad] recorded normals (tests)*/
   const uint8_t* type_id;   /* nullable; per-drone index into the ctx type table (mixed fleets)  */
@@ -504,6 +523,15 @@ int dsim_downwash_reset(dsim_ctx* ctx);
  * >= radius; pos_all / workspace / local_offset as for dsim_downwash (type_id is ignored). */
 int dsim_adjacency(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_downwash_args* args,
                    float radius, int32_t* count_out, int32_t* list_out, int32_t max_k);
+
+/* The rotor-noise normals the step kernels draw (diagnostics / distribution studies; no counterpart in the reference, whose
+ * draws come from numpy's global generator): for drones [0, n) and the physics sub-steps [0, substeps) of Env.step number
+ * step_index, out [substeps][2 * n_act][n_pad] (device) receives the UNIT-variance normals — rows 0 .. n_act-1 the force noise,
+ * n_act .. 2 n_act - 1 the moment noise — exactly as a launch with the same noise_seed / step_index / phys_substeps / options
+ * (DSIM_OPT_NOISE_FINE or 0) scales and applies them: the layout dsim_step_args.noise_replay takes back, times the
+ * deviations.  n_act = 4 | 6.  drone_id nullable (the key of drone i's stream: dsim_step_args.drone_id).                 */
+int dsim_noise_draw(dsim_ctx* ctx, void* stream, int64_t n, int64_t n_pad, int32_t n_act, uint64_t noise_seed, uint64_t step_index,
+                    int32_t substeps, uint32_t options, const int32_t* drone_id, float* out);
 
 /* Diagnostics counters kept by the ctx (device-side, cumulative; this call synchronises `stream`):
  *   DSIM_Q_WLS_FALLBACKS  drones x steps whose 6DOF allocation left the first-iteration fast path and

@@ -837,6 +837,49 @@ void orc_noise_normals(uint64_t seed, uint64_t drone, uint64_t sub_counter, int 
   }
 }
 
+/* DSIM_OPT_NOISE_FINE (dsim_device.h:box_muller16, quad_normals_fine, hexa_normals_fine): 16 + 16 bits per pair — radius from
+ * the high half of a word (u1 = (h + 1) / 65536), direction from the low half; blocks in a domain of their own (counter word
+ * 3's top bit); quad: block `sub`, words 0, 1 force, 2, 3 moment; hexa: blocks 2 sub, 2 sub + 1. */
+#define ORC_BM16_CORR 1.000098644331326
+static void orc_bm16(uint32_t w, double* n0, double* n1) {
+  const double u1 = ((double)(w >> 16) + 1.0) * (1.0 / 65536.0);
+  const double u2 = (double)(w & 0xFFFFu) * (1.0 / 65536.0);
+  const double r = sqrt(-2.0 * ORC_BM16_CORR * log(u1));
+  *n0 = r * cos(2 * ORC_PI * u2);
+  *n1 = r * sin(2 * ORC_PI * u2);
+}
+static void fine_block(uint64_t seed, uint64_t drone, uint64_t blk, uint32_t c[4]) {
+  const uint32_t key[4] = {(uint32_t)seed, (uint32_t)(seed >> 32), 0u, 0u};
+  c[0] = (uint32_t)drone; c[1] = (uint32_t)(drone >> 32); c[2] = (uint32_t)blk; c[3] = (uint32_t)(blk >> 32) | 0x80000000u;
+  orc_threefry4x32(c, key, 12);
+}
+void orc_noise_normals_fine(uint64_t seed, uint64_t drone, uint64_t sub_counter, int n_act, double* out) {
+  uint32_t c[4], d[4];
+  if (n_act == 4) {
+    fine_block(seed, drone, sub_counter, c);
+    orc_bm16(c[0], out + 0, out + 1); orc_bm16(c[1], out + 2, out + 3); orc_bm16(c[2], out + 4, out + 5); orc_bm16(c[3], out + 6, out + 7);
+  } else {
+    fine_block(seed, drone, 2 * sub_counter, c);
+    fine_block(seed, drone, 2 * sub_counter + 1, d);
+    orc_bm16(c[0], out + 0, out + 1); orc_bm16(c[1], out + 2, out + 3); orc_bm16(c[2], out + 4, out + 5);
+    orc_bm16(c[3], out + 6, out + 7); orc_bm16(d[0], out + 8, out + 9); orc_bm16(d[1], out + 10, out + 11);
+  }
+}
+/* many draws at once (distribution tests): out [n_drones][n_sub][2 n_act] */
+void orc_noise_normals_batch(uint64_t seed, uint64_t drone0, int64_t n_drones, uint64_t sub0, int n_sub, int n_act, int fine,
+                             double* out, int nthreads) {
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n_drones; ++i)
+    for (int s = 0; s < n_sub; ++s) {
+      double* o = out + ((size_t)i * n_sub + s) * 2 * n_act;
+      if (fine) orc_noise_normals_fine(seed, drone0 + (uint64_t)i, sub0 + (uint64_t)s, n_act, o);
+      else orc_noise_normals(seed, drone0 + (uint64_t)i, sub0 + (uint64_t)s, n_act, o);
+    }
+}
+
 /* ======================================================================= */
 /* batch drivers (AoS fp64, OpenMP over drones) — used by tests and the
  * cpu_baseline leg of bench.py                                               */

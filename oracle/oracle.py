@@ -285,11 +285,24 @@ class Oracle:
         f(self._c_types, _p(type_id, _U8), n, _p(_c(rigid)), _p(_c(last_action)), width, _p(out))
         return out
 
-    def noise_normals(self, seed: int, drone: int, sub_counter: int, n_act: int) -> np.ndarray:
+    def noise_normals(self, seed: int, drone: int, sub_counter: int, n_act: int, fine: bool = False) -> np.ndarray:
+        """The unit-variance normals of (drone, sub-step counter): n_act force normals, then n_act moment normals.  fine:
+        the 16 + 16-bit lattice of DSIM_OPT_NOISE_FINE instead of the default 8 + 8-bit one."""
         out = np.zeros(2 * n_act)
-        f = self._L.orc_noise_normals
+        f = self._L.orc_noise_normals_fine if fine else self._L.orc_noise_normals
         f.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _D]
         f(seed, drone, sub_counter, n_act, _p(out))
+        return out
+
+    def noise_batch(self, seed: int, drone0: int, n_drones: int, sub0: int, n_sub: int, n_act: int, fine: bool = False,
+                    nthreads: int = 0) -> np.ndarray:
+        """[n_drones, n_sub, 2 n_act] normals of drones drone0.. and sub-step counters sub0.. (distribution tests)."""
+        out = np.zeros((n_drones, n_sub, 2 * n_act))
+        f = self._L.orc_noise_normals_batch
+        f.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                      _D, ctypes.c_int]
+        f.restype = None
+        f(seed, drone0, n_drones, sub0, n_sub, n_act, int(fine), _p(out), nthreads)
         return out
 
     @staticmethod
