@@ -271,7 +271,9 @@ __device__ __forceinline__ int waypoint_next(int wp, int n_wp) { return wp < n_w
 // beside the default one.  -1 = the rule: the single-sub-step instances (bound by HBM: the second path is free) and the general
 // kernels (OPTS) do; the instances that loop over sub-steps on the fast paths — bound by vector issue, tuned to their register
 // budgets — do not, and the launchers hand a fine-lattice launch with several sub-steps to the general kernels.
-template <int NOISE, int NROW = 4, bool OPTS = false, int NSUB = 0, bool PLANE = false, int FINE = -1, class DT>
+// LOOPED: the launcher picked this instance because the launch has SEVERAL sub-steps (its single-sub-step twin takes the others):
+// the loop carries the body-frame form of the step (dsim_device.h:bullet_step_body).
+template <int NOISE, int NROW = 4, bool OPTS = false, int NSUB = 0, bool PLANE = false, int FINE = -1, bool LOOPED = false, class DT>
 __device__ __forceinline__ void quad_substeps(DT& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[4], unsigned long long step_index,
                                               V3 ext = V3{0.0f, 0.0f, 0.0f}, const float* prev = nullptr, long long nid = -1,
@@ -287,6 +289,14 @@ __device__ __forceinline__ void quad_substeps(DT& T, const StepK& a, long long i
   if (SPLIT) qb = quad_wrench_base(T, cmd);
   const int n_sub = NSUB > 0 ? NSUB : a.substeps;
   uint32_t nb[4] = {0u, 0u, 0u, 0u};       // the Threefry block: ONE serves two consecutive sub-steps (dsim_device.h:noise_normals)
+  // the looped fast instances carry the body-frame form of the step across the sub-steps (dsim_device.h:bullet_step_body)
+  // (only where several sub-steps are certain: with one, w' = R' (R^T w + a_b dt) costs the stored angular velocity two more
+  // matrix roundings than w + R a_b dt and saves nothing.  The neutral zero-sub-step pass of the placement trials runs on
+  // k_physics_fast, which is not LOOPED: there the state goes back bit for bit.)
+  constexpr bool BODY_OK = LOOPED && !OPTS && !PLANE && NSUB != 1;
+  constexpr bool BODY = BODY_OK;
+  RigidB sb = RigidB{};
+  if (BODY) sb = body_begin(s);
   for (int k = 0; k < n_sub; ++k) {
     if (NOISE != 0) {
       float nz[8];
@@ -318,12 +328,14 @@ __device__ __forceinline__ void quad_substeps(DT& T, const StepK& a, long long i
       bullet_step<PLANE>(T, a.dt_phys, s, F2, tau2);
       continue;
     }
-    bullet_step(T, a.dt_phys, s, F + ext, tau);
+    if constexpr (BODY_OK) bullet_step_body(T, a.dt_phys, sb, F + ext, tau);      // (the loop runs: BODY holds)
+    else bullet_step(T, a.dt_phys, s, F + ext, tau);
   }
+  if (BODY) body_end(sb, s);
 }
 
 // the same for the morphing hexa (BaseAviary.py:1389-1457); replay rows: f[6], m[6]
-template <bool NOISE, bool REPLAY = true, bool ONE = false, bool PLANE = false, class DT>
+template <bool NOISE, bool REPLAY = true, bool ONE = false, bool PLANE = false, bool LOOPED = false, class DT>
 __device__ __forceinline__ void hexa_substeps(DT& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[6], unsigned long long step_index,
                                               V3 ext = V3{0.0f, 0.0f, 0.0f}, long long nid = -1,
@@ -345,6 +357,10 @@ __device__ __forceinline__ void hexa_substeps(DT& T, const StepK& a, long long i
   if (PLANE) s.pos = s.pos - o0;
   s.vel = s.vel - cross(s.w, o0);
   const int n_sub = ONE ? 1 : a.substeps;
+  constexpr bool BODY_OK = LOOPED && !ONE && !PLANE && !REPLAY;       // the looped fast instances (quad_substeps: LOOPED): dsim_device.h:bullet_step_body
+  constexpr bool BODY = BODY_OK;
+  RigidB sb = RigidB{};
+  if (BODY) sb = body_begin(s);
   for (int k = 0; k < n_sub; ++k) {
     if (NOISE) {
       float nz[12];
@@ -362,8 +378,10 @@ __device__ __forceinline__ void hexa_substeps(DT& T, const StepK& a, long long i
       }
       if (SPLIT) hexa_wrench_noise(T, hb, nz, F, tau); else hexa_wrench(T, cmd, nz, F, tau);
     }
-    bullet_step<PLANE>(T, a.dt_phys, s, F + ext, tau);
+    if constexpr (BODY_OK) bullet_step_body(T, a.dt_phys, sb, F + ext, tau);      // (the loop runs: BODY holds)
+    else bullet_step<PLANE>(T, a.dt_phys, s, F + ext, tau);
   }
+  if (BODY) body_end(sb, s);
   {
     const V3 o = mul(matrix_from_quat(s.q), v3(T.base_off[0], T.base_off[1], T.base_off[2]));
     s.pos = s.pos + (PLANE ? o : o - o0); s.vel = s.vel + cross(s.w, o);
@@ -419,9 +437,9 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
       float act[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) act[j] = clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]);   // CtrlAviary.py:258-263
-      quad_substeps<NOISE ? 1 : 0, 4, false, SUB>(T, a, i, s, act, a.step_index, V3{0.0f, 0.0f, 0.0f}, nullptr, -1, ntab);
+      quad_substeps<NOISE ? 1 : 0, 4, false, SUB, false, -1, SUB == 0>(T, a, i, s, act, a.step_index, V3{0.0f, 0.0f, 0.0f}, nullptr, -1, ntab);
     } else {
-      quad_substeps<NOISE ? 1 : 0, 4, false, SUB>(T, a, i, s, m.cmd, a.step_index, V3{0.0f, 0.0f, 0.0f}, nullptr, -1, ntab);    // stored cmd is already clipped
+      quad_substeps<NOISE ? 1 : 0, 4, false, SUB, false, -1, SUB == 0>(T, a, i, s, m.cmd, a.step_index, V3{0.0f, 0.0f, 0.0f}, nullptr, -1, ntab);    // stored cmd is already clipped
     }
     ground_watch(T, s, a.fb.counters, i < a.n);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
@@ -498,9 +516,9 @@ __global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
     float act[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) act[j] = clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]);
-    hexa_substeps<NOISE, false, S1>(T, a, i, s, act, a.step_index, V3{0.0f, 0.0f, 0.0f}, -1, ntab);
+    hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, act, a.step_index, V3{0.0f, 0.0f, 0.0f}, -1, ntab);
   } else {
-    hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, V3{0.0f, 0.0f, 0.0f}, -1, ntab);
+    hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, m.cmd, a.step_index, V3{0.0f, 0.0f, 0.0f}, -1, ntab);
   }
   indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
   const unsigned so = pin_lane_offset(sl);
@@ -751,10 +769,10 @@ __device__ __forceinline__ void staged_body2(DT& T, const StepK& a, long long i,
   V3 pos_e;
   float yaw_e;
   if constexpr (HEXA) {
-    hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
+    hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, m.cmd, a.step_index, ext);
     indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, active ? i : -1LL);
   } else {
-    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
+    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0, false, -1, !S1>(T, a, i, s, m.cmd, a.step_index, ext);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   ground_watch(T, s, a.fb.counters, active && i < a.n);      // (behind the law: in front of it it costs registers)
@@ -900,8 +918,8 @@ __device__ __forceinline__ void staged_body4(DT& T, const StepK& a, long long i,
   if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
   V3 pos_e;
   float yaw_e;
-  if constexpr (HEXA) hexa_substeps<NOISE, false, S1>(T, a, i, s, m.cmd, a.step_index, ext);
-  else quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, ext);
+  if constexpr (HEXA) hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, m.cmd, a.step_index, ext);
+  else quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0, false, -1, !S1>(T, a, i, s, m.cmd, a.step_index, ext);
   // what only the law reads — the rest of the controller memory and the targets — comes out of LDS BEHIND the sub-steps
   // (tied to their result): read in front of them it is 17 registers held through the physics
   asm volatile("" : "+v"(c) : "v"(s.pos.z));
@@ -1033,11 +1051,11 @@ __device__ __forceinline__ void run_body(const StepK& a, long long i0, long long
 #pragma unroll
   for (int j = 0; j < NA; ++j) act[j] = ACT ? clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]) : m.cmd[j];   // CtrlAviary.py:258-263
   if constexpr (HEXA) {
-    hexa_substeps<NOISE, false, S1>(T, a, i, s, act, step_index, ext, nid, tab);
+    hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, act, step_index, ext, nid, tab);
     if constexpr (KIND == DSIM_DEV_KIND_HEXA) indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
     else indi_quad<false, 6>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   } else {
-    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, act, step_index, ext, nullptr, nid, tab);
+    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0, false, -1, !S1>(T, a, i, s, act, step_index, ext, nullptr, nid, tab);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   const unsigned so = pin_lane_offset(sl);
@@ -1476,8 +1494,8 @@ __device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro
     if (NOISE && a.step_index_dev) step_index += *a.step_index_dev;
     const long long nid = NOISE ? noise_id(a, i) : -1LL;
     // (S1: one sub-step per Env.step — BASELINE's metric definition — compiled straight-line, as in the fused kernels)
-    if constexpr (HEXA) hexa_substeps<NOISE, false, S1>(T, a, i, s, cmd, step_index, ext, nid, tab);
-    else quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0>(T, a, i, s, cmd, step_index, ext, nullptr, nid, tab);
+    if constexpr (HEXA) hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, cmd, step_index, ext, nid, tab);
+    else quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0, false, -1, !S1>(T, a, i, s, cmd, step_index, ext, nullptr, nid, tab);
     ground_watch(T, s, a.fb.counters, i < a.n);
     const unsigned so = pin_lane_offset(sl);
     store_rigid<NT>(sb, sfs, so, s);

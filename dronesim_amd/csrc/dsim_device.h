@@ -595,6 +595,89 @@ __device__ __forceinline__ V3 dyn_reported_ang_vel(bool body_rates, Q4 q, V3 rr)
   return mul(matrix_from_quat(q), rr);
 }
 
+// P4 over SEVERAL sub-steps (the kernels that loop: the examples fly five per control step, examples/fly_INDI.py:139-141, and
+// those kernels are bound by vector issue).  The same step as bullet_step, arranged so that what the loop carries is what the
+// loop needs:
+//   * the angular velocity is carried in the BODY frame.  bullet_step turns the world-frame w into the body frame, adds the
+//     body-frame acceleration's image R a_b dt to the world-frame w, and the next sub-step turns it back: with R' = dR(w') R and
+//     dR(w') a rotation ABOUT w', R'^T w' = R^T w' = w_b + a_b dt — the body-frame rates simply accumulate, and R^T w, R a_b
+//     and the world-frame update leave the loop (one R^T w in front of it, one R w_b behind it);
+//   * the orientation increment is applied in the body frame, q (x) (a_b, c) = (R a_b, c) (x) q: the same rotation;
+//   * sin(h) / |w| and cos(h) of the exponential map are even series in h: they need h^2 = (dt / 2)^2 w.w, not |w| (Bullet's
+//     clamp of the rotation per step to pi / 4 is a minimum on h^2);
+//   * the quaternion is normalised once behind the loop (matrix_from_quat divides by |q|^2 anyway, and scaling commutes with
+//     the product): every sub-step of the oracle normalises, the results differ by roundings.
+// Bullet clamps every WORLD coordinate of the angular velocity to +-maxCoordinateVelocity (applyDeltaVeeMultiDof): while
+// |w_b| < maxv no coordinate can reach it; a lane beyond that (100 rad/s: a tumbling wreck) takes the world-frame detour.
+// 27 + 8 + 10 of the ~300 vector instructions of a sub-step less (profiles/r05_sub5_*).
+struct RigidB { V3 pos; Q4 q; V3 vel; V3 wb; };
+//   * the quaternion enters the loop normalised (the same rotation; the caller's may be any length: the reference's helpers
+//     do not normalise) and stays within roundings of unit length through it, so that 2 / |q|^2 of the rotation matrix is one
+//     Newton step from 1, 4 - 2 |q|^2 (error (1 - |q|^2)^2 ~ 1e-13), instead of a reciprocal per sub-step.
+__device__ __forceinline__ RigidB body_begin(const Rigid& s) {
+  const float inv = DSIM_RSQ(s.q.x * s.q.x + s.q.y * s.q.y + s.q.z * s.q.z + s.q.w * s.q.w);
+  const Q4 q = Q4{s.q.x * inv, s.q.y * inv, s.q.z * inv, s.q.w * inv};
+  return RigidB{s.pos, q, s.vel, mulT(matrix_from_quat(q), s.w)};
+}
+// matrix_from_quat for a quaternion within roundings of unit length (the loop's)
+__device__ __forceinline__ M3 matrix_from_near_unit_quat(Q4 q) {
+  const float d = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+  const float s = __builtin_fmaf(-2.0f, d, 4.0f);
+  const float xs = q.x * s, ys = q.y * s, zs = q.z * s;
+  const float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+  const float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
+  const float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+  M3 R;
+  R.m[0] = 1.0f - (yy + zz); R.m[1] = xy - wz;          R.m[2] = xz + wy;
+  R.m[3] = xy + wz;          R.m[4] = 1.0f - (xx + zz); R.m[5] = yz - wx;
+  R.m[6] = xz - wy;          R.m[7] = yz + wx;          R.m[8] = 1.0f - (xx + yy);
+  return R;
+}
+__device__ __forceinline__ void body_end(const RigidB& b, Rigid& s) {
+  const float inv = DSIM_RSQ(b.q.x * b.q.x + b.q.y * b.q.y + b.q.z * b.q.z + b.q.w * b.q.w);
+  s.pos = b.pos; s.vel = b.vel;
+  s.q = Q4{b.q.x * inv, b.q.y * inv, b.q.z * inv, b.q.w * inv};
+  s.w = mul(matrix_from_quat(s.q), b.wb);
+}
+template <class DT>
+__device__ __forceinline__ void bullet_step_body(DT& T, float dt, RigidB& s, V3 F_body, V3 tau_body) {
+  const M3 R = matrix_from_near_unit_quat(s.q);
+  const float vn = DSIM_SQRT(dot(s.vel, s.vel));
+  const V3 Fw = mul(R, F_body);
+  const float dl = T.clin + T.clin * vn;
+  const V3 vdot = v3(Fw.x * T.inv_mass - dl * s.vel.x, Fw.y * T.inv_mass - dl * s.vel.y, Fw.z * T.inv_mass - T.g - dl * s.vel.z);
+  const V3 wb = s.wb;
+  const float wn = DSIM_SQRT(dot(wb, wb));
+  const V3 Jw = v3(T.J[0] * wb.x, T.J[1] * wb.y, T.J[2] * wb.z);
+  const V3 gy = cross(wb, Jw);
+  const float da = T.cang + T.cang * wn;
+  const V3 ab = v3((tau_body.x - gy.x) * T.invJ[0] - da * wb.x, (tau_body.y - gy.y) * T.invJ[1] - da * wb.y,
+                   (tau_body.z - gy.z) * T.invJ[2] - da * wb.z);
+  V3 wn_b = wb + dt * ab;
+  float ww = dot(wn_b, wn_b);
+  if (!(ww < T.maxv * T.maxv)) {                           // (rare) a world coordinate may reach the clamp: the world-frame form
+    const V3 ww_ = mul(R, wn_b);
+    const V3 wc = v3(clampf(ww_.x, -T.maxv, T.maxv), clampf(ww_.y, -T.maxv, T.maxv), clampf(ww_.z, -T.maxv, T.maxv));
+    wn_b = mulT(R, wc);
+    ww = dot(wn_b, wn_b);
+  }
+  s.wb = wn_b;
+  s.vel = v3(clampf(s.vel.x + vdot.x * dt, -T.maxv, T.maxv), clampf(s.vel.y + vdot.y * dt, -T.maxv, T.maxv),
+             clampf(s.vel.z + vdot.z * dt, -T.maxv, T.maxv));
+  s.pos = s.pos + dt * s.vel;
+  // exponential map of w' dt in the body frame: h^2 = (dt / 2)^2 w'.w', clamped at (pi / 8)^2 (the rotation per step at pi / 4)
+  const float h2 = fminf(0.25f * dt * dt * ww, (0.5f * DSIM_PI_4) * (0.5f * DSIM_PI_4));
+  const float sinc = 1.0f + h2 * (-1.0f / 6.0f + h2 * (1.0f / 120.0f + h2 * (-1.0f / 5040.0f)));
+  const float cw = 1.0f + h2 * (-0.5f + h2 * (1.0f / 24.0f + h2 * (-1.0f / 720.0f)));      // (h^8 / 40320 <= 1.4e-8 at the clamp: below half an ulp of 1)
+  const float sc = 0.5f * dt * sinc;
+  const float ax = wn_b.x * sc, ay = wn_b.y * sc, az = wn_b.z * sc;
+  const Q4 q = s.q;                                        // n = q (x) (a, cw)
+  s.q = Q4{q.w * ax + q.x * cw + q.y * az - q.z * ay,
+           q.w * ay - q.x * az + q.y * cw + q.z * ax,
+           q.w * az + q.x * ay - q.y * ax + q.z * cw,
+           q.w * cw - q.x * ax - q.y * ay - q.z * az};
+}
+
 // C4: INDIControl._INDIRateControl, INDIControl.py:413-490 (also the whole of RPYTAviary's action
 // adaptor, RPYTAviary.py:181-193): body rates, finite-difference angular acceleration, the virtual
 // control v, du = pinv(G1/0.05) v, cmd += du, clip.
