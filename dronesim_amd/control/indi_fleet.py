@@ -12,6 +12,7 @@ positions / quaternions / velocities explicitly, as with the reference).
 from __future__ import annotations
 
 import ctypes
+from dataclasses import dataclass
 from typing import Optional, Union
 
 import numpy as np
@@ -20,6 +21,26 @@ import torch
 from .. import _native as nat
 from ..fleet import Context, FleetState, Frozen, Targets
 from ..params import DroneType, builtin_type
+
+
+@dataclass
+class _ControlPlan:
+    """The prepared launch of a repeated ``computeControl`` call of the reference-shaped loop (state read from the bound env,
+    the same frozen target_pos, the same small host vectors compared by content, the same buffers): launched again as it is."""
+
+    key: tuple
+    state_view: object
+    targets_view: object
+    args_ref: object            # ctypes.byref(args)
+    pos_e_ptr: int
+    yaw_e_ptr: int
+    cmd_ptr: int
+    out: tuple                  # the (cmd, pos_e, yaw_e) triple handed out
+    cmd_token: object           # what the env recognises when the command comes back as the next action, or None
+    args: object                # nat.StepArgs (kept alive)
+
+    def matches(self, key: tuple) -> bool:
+        return self.key == key
 
 
 def _as3(x, n, device) -> torch.Tensor:
@@ -244,12 +265,12 @@ class INDIControl(BaseControl):
                        self._targets.data.data_ptr(), self._targets.version, id(getattr(self.env, "_runs", None)),
                        getattr(self.env, "_tuning", 0), self._cmd.data_ptr() if self._cmd is not None else 0)
                 plan = self._plan
-                if plan is not None and plan[0] == key:
-                    nat.check(self.ctx.lib.dsim_control2(self.ctx.handle, self.ctx.stream_ptr(), n, plan[1], plan[2], plan[3],
-                                                         plan[4], plan[5], plan[6]))
-                    if plan[8] is not None:
-                        self.env._cmd_token = plan[8]
-                    return plan[7]
+                if plan is not None and plan.matches(key):
+                    nat.check(self.ctx.lib.dsim_control2(self.ctx.handle, self.ctx.stream_ptr(), n, plan.state_view, plan.targets_view,
+                                                         plan.args_ref, plan.pos_e_ptr, plan.yaw_e_ptr, plan.cmd_ptr))
+                    if plan.cmd_token is not None:
+                        self.env._cmd_token = plan.cmd_token
+                    return plan.out
         if cur_pos is not None:                       # explicit state (stand-alone use)
             st.set_fields(0, _as3(cur_pos, n, dev))
             q = torch.as_tensor(np.asarray(cur_quat) if not torch.is_tensor(cur_quat) else cur_quat,
@@ -296,8 +317,8 @@ class INDIControl(BaseControl):
             if key is not None:
                 # (the key is completed with what this call settled: the buffers of the outputs and the targets' version)
                 key = key[:6] + (self._targets.data.data_ptr(), self._targets.version) + key[8:10] + (self._cmd.data_ptr(),)
-                self._plan = (key, sview, tview, ctypes.byref(a), self._pos_e.data_ptr(), self._yaw_e.data_ptr(),
-                              self._cmd.data_ptr(), out, None, a)
+                self._plan = _ControlPlan(key, sview, tview, ctypes.byref(a), self._pos_e.data_ptr(), self._yaw_e.data_ptr(),
+                                          self._cmd.data_ptr(), out, None, a)
             return out
         # a fleet stored in another order than the caller's: the triple goes back in the caller's numbering; the env
         # recognises the command tensor when it comes back as the next action and takes the storage-order array as is

@@ -1,1 +1,3 @@
-from .fleet_aviary import CtrlAviary, FleetObs, Physics, RPYTAviary, VelocityAviary  # noqa: F401
+from .adaptor_aviary import RPYTAviary, VelocityAviary  # noqa: F401
+from .fleet_aviary import CtrlAviary, FleetObs, Physics  # noqa: F401
+from .fused_graph import FusedGraph  # noqa: F401

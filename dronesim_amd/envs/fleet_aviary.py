@@ -14,8 +14,8 @@ from __future__ import annotations
 
 import ctypes
 import os
-from enum import Enum
-from typing import NamedTuple, Optional, Sequence, Union
+from dataclasses import dataclass
+from typing import Optional, Sequence, Union
 
 import numpy as np
 import torch
@@ -23,19 +23,9 @@ import torch
 from .. import _native as nat
 from ..fleet import Context, FleetState, Targets, WaypointTargets
 from ..params import DroneType, builtin_type
-
-
-class Physics(Enum):
-    """dronesim/envs/BaseAviary.py:41-49.  Only PYB works in the reference fork
-    (every other branch is dead code there); the add-on terms are
-    exposed here as their intended formulas."""
-
-    PYB = "pyb"
-    DYN = "dyn"
-    PYB_GND = "pyb_gnd"
-    PYB_DRAG = "pyb_drag"
-    PYB_DW = "pyb_dw"
-    PYB_GND_DRAG_DW = "pyb_gnd_drag_dw"
+from ..placement import PlacedFleetArrays
+from .observation import FleetObs, FleetObservation  # noqa: F401
+from .physics import Physics
 
 
 # dict-of-ndarray I/O (the reference's format) is produced up to this many drones;
@@ -43,19 +33,46 @@ class Physics(Enum):
 DICT_IO_MAX_DRONES = 64
 
 
-class FleetObs(NamedTuple):
-    """Observation of a fleet in tensor mode when neighbour lists are requested (``neighbors_k`` > 0): what the
-    reference returns per drone as ``{"state": ..., "neighbors": ...}`` (CtrlAviary.py:225-232), for the whole fleet
-    on the device.  ``neighbor_count[i]`` = drones within NEIGHBOURHOOD_RADIUS of drone i (the row sum of the
-    reference's adjacency matrix minus the diagonal), ``neighbor_list[:, i]`` = up to ``neighbors_k`` of their indices
-    (-1 padded): the sparse form of the reference's dense O(N^2) row."""
+@dataclass
+class _StepPlan:
+    """The prepared launch of a repeated ``step(action)`` call (the reference-shaped loop hands step() the tensor computeControl
+    returned, every iteration the same object over the same buffers): launched again with the step counter moved on while
+    nothing it was built from has changed."""
 
-    state: torch.Tensor            # [N, 16 + n_act]
-    neighbor_count: torch.Tensor   # [N] int32
-    neighbor_list: torch.Tensor    # [neighbors_k, N] int32
+    key: tuple                  # what the argument block was built from: buffers, options, sub-steps, runs, seed (CtrlAviary._step_key)
+    action: object              # the action tensor of the last call (held: its identity cannot be recycled)
+    action_ptr: int             # ... and the device pointer the launch read
+    rows_in: bool               # the launch takes [N, 4] rows as the caller holds them: ANY such tensor may come next
+    args: object                # nat.StepArgs
+    state_view: object
+    args_ref: object            # ctypes.byref(args)
+    echo_ptr: int               # the env's last_clipped_action
+    out: object                 # the observation handed out
+    info: dict
+
+    def matches(self, key: tuple, action, is_rows) -> bool:
+        if key != self.key:
+            return False
+        return (action is self.action and action.data_ptr() == self.action_ptr) or (self.rows_in and is_rows(action))
 
 
-class CtrlAviary:
+@dataclass
+class _FusedPlan:
+    """The prepared launch of a repeated ``step_fused(targets)`` call."""
+
+    key: tuple                  # (control_timestep, n_steps, chained)
+    args: object
+    state_view: object
+    targets_view: object
+    args_ref: object
+    targets: object             # the targets object itself (compared by identity while it is alive)
+    targets_ptrs: tuple         # ... and the device pointers it was built from (a Targets whose tensor was swapped does not match)
+
+    def matches(self, key: tuple, targets, ptrs: tuple) -> bool:
+        return self.targets is targets and self.key == key and self.targets_ptrs == ptrs
+
+
+class CtrlAviary(PlacedFleetArrays, FleetObservation):
     """PWM-action fleet environment (reference: ``CtrlAviary``)."""
 
     def __init__(
@@ -392,25 +409,20 @@ class CtrlAviary:
         # the same buffers: the prepared argument block is launched again with the step counter moved on (at the
         # reference's own fleet sizes the Python in front of the launch is most of what an iteration costs).
         plan = self._step_plan
-        if plan is not None and self._downwash is None and plan[0] == (
-                self.state.data.data_ptr(), self._obs_buf.data_ptr(), self._last_action.data_ptr(),
-                self._phys_options, self._tuning, self.AGGR_PHY_STEPS, id(self._runs), self._caller_io, self.noise_seed) and (
-                (action is plan[1] and action.data_ptr() == plan[7]) or (plan[8] and self._is_action_rows(action))):
+        if plan is not None and self._downwash is None and plan.matches(self._step_key(), action, self._is_action_rows):
             # (the same tensor as last time — the command a bound controller returned — or, for a fleet that takes [N, 4] rows
             # as the caller holds them, any such tensor: a policy's fresh output every step)
             self._join_fallback()
-            args = plan[2]
-            args.step_index = self._env_steps
-            if action is not plan[1]:
-                args.action = action.data_ptr()
-                self._action_keep = action
-                self._step_plan = plan[:1] + (action,) + plan[2:7] + (args.action,) + plan[8:]
-            nat.check(self.ctx.lib.dsim_physics(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, plan[3],
-                                                plan[0][2], plan[4]))
+            plan.args.step_index = self._env_steps
+            if action is not plan.action:
+                plan.args.action = plan.action_ptr = action.data_ptr()
+                plan.action = self._action_keep = action
+            nat.check(self.ctx.lib.dsim_physics(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, plan.state_view,
+                                                plan.echo_ptr, plan.args_ref))
             self._use_last_action = True
             self.step_counter += self.AGGR_PHY_STEPS
             self._env_steps += 1
-            return plan[5], -1, False, plan[6]
+            return plan.out, self._computeReward(), self._computeDone(), plan.info
         # The neighbour-downwash term is evaluated per PHYSICS SUB-STEP, as the reference loops it (BaseAviary.py:510-536:
         # with AGGR_PHY_STEPS > 1 the positions are refreshed and _downwash applied inside the sub-step loop): one
         # [query -> one-sub-step physics] pair of launches per sub-step, the observation rows from the last one.  Without the
@@ -451,11 +463,15 @@ class CtrlAviary:
                 and args.action in (action.data_ptr(), getattr(action, "T", action).data_ptr())):
             # (only when the launch read the caller's tensor itself — the controller's command array or [N, 4] rows — and
             # handed out the rows it wrote: nothing was copied on the way in or out)
-            self._step_plan = ((self.state.data.data_ptr(), obs.data_ptr(), self._last_action.data_ptr(),
-                                self._phys_options, self._tuning, self.AGGR_PHY_STEPS, id(self._runs), self._caller_io,
-                                self.noise_seed), action, args, self.state.view(), ctypes.byref(args), out, self._computeInfo(),
-                               action.data_ptr(), bool(self._rows_in))
+            self._step_plan = _StepPlan(key=self._step_key(), action=action, action_ptr=action.data_ptr(), rows_in=bool(self._rows_in),
+                                        args=args, state_view=self.state.view(), args_ref=ctypes.byref(args),
+                                        echo_ptr=self._last_action.data_ptr(), out=out, info=self._computeInfo())
         return out, self._computeReward(), self._computeDone(), self._computeInfo()
+
+    def _step_key(self) -> tuple:
+        """What a prepared Env.step launch depends on besides the action (see _StepPlan)."""
+        return (self.state.data.data_ptr(), self._obs_buf.data_ptr() if self._obs_buf is not None else 0, self._last_action.data_ptr(),
+                self._phys_options, self._tuning, self.AGGR_PHY_STEPS, id(self._runs), self._caller_io, self.noise_seed)
 
     def _is_action_rows(self, action) -> bool:
         """An [N, 4] float32 device tensor, contiguous and 16-byte aligned: what DSIM_OPT_ACTION_ROWS takes as it is."""
@@ -483,26 +499,24 @@ class CtrlAviary:
         # are re-checked, so a Targets whose tensor was swapped does not either)
         key = (control_timestep, n_steps, self._chained_enabled)
         plan = self._fused_plan
-        if (action is None and plan is not None and plan[5] is targets and plan[0] == key and self._downwash is None
-                and self._chain_ok and (self._chain_live or not self._chained_enabled)
-                and plan[6] == self._targets_ptrs(targets)):
-            _, args, sview, tview, ref = plan[:5]
-            args.step_index = self._env_steps
-            nat.check(self.ctx.lib.dsim_step(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, sview, tview, ref))
+        if (action is None and plan is not None and self._downwash is None and self._chain_ok
+                and (self._chain_live or not self._chained_enabled) and plan.matches(key, targets, self._targets_ptrs(targets))):
+            plan.args.step_index = self._env_steps
+            nat.check(self.ctx.lib.dsim_step(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, plan.state_view,
+                                             plan.targets_view, plan.args_ref))
             self.step_counter += self.AGGR_PHY_STEPS * n_steps
             self._env_steps += n_steps
             return
         pd = self._fused_plan_dw
         if (action is None and pd is not None and self._downwash is not None and not self._dw_substepped()
-                and pd[5] is targets and pd[0] == key
-                and self._chain_ok and self._fb_stream is None and pd[6] == self._targets_ptrs(targets)):
+                and self._chain_ok and self._fb_stream is None and pd.matches(key, targets, self._targets_ptrs(targets))):
             # the same call again on a downwash fleet: the prepared argument block, with this step's force, counter and
             # the grid the step kernel may fill (the Python side of a config-5 step is what paces a 65 536-drone shard)
-            _, args, sview, tview, ref = pd[:5]
             self._downwash.compute()
-            args.step_index = self._env_steps
-            args.bin_next = self._downwash.bin_next_ptr()
-            nat.check(self.ctx.lib.dsim_step(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, sview, tview, ref))
+            pd.args.step_index = self._env_steps
+            pd.args.bin_next = self._downwash.bin_next_ptr()
+            nat.check(self.ctx.lib.dsim_step(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, pd.state_view,
+                                             pd.targets_view, pd.args_ref))
             self.step_counter += self.AGGR_PHY_STEPS
             self._env_steps += 1
             return
@@ -559,13 +573,13 @@ class CtrlAviary:
         self._fused_plan = None
         self._fused_plan_dw = None
         if action is None and self._downwash is not None and not chain and not defer and not self._dw_substepped():
-            self._fused_plan_dw = (key, args, sview, tview, ctypes.byref(args), targets, self._targets_ptrs(targets))
+            self._fused_plan_dw = _FusedPlan(key, args, sview, tview, ctypes.byref(args), targets, self._targets_ptrs(targets))
         if action is None and self._downwash is None:
             nxt = nat.StepArgs.from_buffer_copy(args)
             if self._chained_enabled and chain:
                 nxt.options |= nat.OPT_CHAINED
             if not self._chained_enabled or chain:
-                self._fused_plan = (key, nxt, sview, tview, ctypes.byref(nxt), targets, self._targets_ptrs(targets))
+                self._fused_plan = _FusedPlan(key, nxt, sview, tview, ctypes.byref(nxt), targets, self._targets_ptrs(targets))
 
     def capture_fused(self, targets, steps: int, control_timestep: Optional[float] = None):
         """Captures ``steps`` consecutive :meth:`step_fused` launches into ONE hipGraph and returns a
@@ -592,6 +606,7 @@ class CtrlAviary:
         # nothing may allocate under capture: the fallback queue of hexa fleets is reserved up front
         nat.check(self.ctx.lib.dsim_reserve(self.ctx.handle, self.ctx.stream_ptr(), self.state.n_pad))
         self._graph_made = True
+        from .fused_graph import FusedGraph
         return FusedGraph(self, targets, steps, control_timestep)
 
     @property
@@ -641,43 +656,6 @@ class CtrlAviary:
         self._load_action(action, caller_order)
         return self._action_buf.data_ptr()
 
-    def _placement_applies(self, nbytes: int) -> bool:
-        """Arrays written beside the state block are placed by trial (placement.py) for fleets that are bound by HBM and that
-        the fast kernels serve: large ones, without the downwash chain, without the drag / ground / plane options."""
-        from .. import placement
-        served = self._type_id is None or (self._runs is not None and len(self._runs) <= 8)
-        return bool(self.ctx.placement and nbytes >= placement.MIN_BYTES and served and self._downwash is None
-                    and self._phys_options == 0)
-
-    def _ensure_read_room(self) -> None:
-        """Arrays a launch READS beside the state block it updates — the targets of the fused step, of computeControl — want
-        the state's own 16 GiB window of device memory (placement.py; tools/region_probe.py --arena, G: computeControl 136 us
-        with its targets there, 143 us with them one window on), and where a separate allocation falls is the memory
-        manager's business.  So a large fleet's state block moves ONCE into a driver allocation with room for two target
-        blocks right behind it: the same allocation is the same window (but for the 1-in-20 case that a window boundary runs
-        through it, which the trials would show)."""
-        from .. import placement
-        if self._read_room is not None or self._chain_live or self._graph_made or not self.ctx.placement:
-            return
-        self._read_room = []
-        nst, ntg = self.state.data.numel(), nat.NT * self.state.n_pad
-        try:
-            blk = placement._DriverBlock(self.ctx, (nst + 2 * ntg,)).tensor()
-        except (MemoryError, RuntimeError):
-            return
-        self._move_state(blk[:nst].view(self.state.data.shape))
-        blk[nst:].zero_()
-        self._read_room = [blk[nst:nst + ntg], blk[nst + ntg:]]
-        self.ctx.placement_log.append({"array": "state block + room for two target blocks", "bytes": 4 * (nst + 2 * ntg),
-                                       "held_bytes": 4 * 2 * ntg, "placed": "one driver allocation"})
-
-    def _take_read_room(self, numel: int):
-        """One of the two target-sized blocks behind the state block (a flat fp32 tensor), or None."""
-        self._ensure_read_room()
-        if self._read_room and self._read_room[0].numel() == numel:
-            return self._read_room.pop(0)
-        return None
-
     def _move_state(self, new_block: torch.Tensor) -> None:
         """The state block into another allocation (same contents).  Everything that holds its address is dropped: the
         prepared argument blocks of the fused step, the downwash and halo plans' cached views."""
@@ -690,120 +668,6 @@ class CtrlAviary:
             dw._single = dw._halo_args = None
             if dw.halo is not None:
                 dw.halo._pack_call = None
-
-    def _obs_tensor(self) -> torch.Tensor:
-        if self._obs_buf is None:
-            shape = (self.NUM_DRONES, 16 + self.n_act)
-            from .. import placement
-            # a large fleet on the fast kernels (the Env.step launch writes the rows beside the state it updates in place):
-            # WHERE the rows lie is worth 10-15 % of that launch and is chosen by timing it (placement.py)
-            if self._placement_applies(4 * shape[0] * shape[1]):
-                self.materialize()
-                self._ensure_read_room()                  # (the state block in its final place before anything is timed against it)
-                before = self.ctx.query(nat.QUERY_GROUND_CONTACTS)
-                echo = self._last_action.clone()          # the passes echo the (clipped) action buffer: put back below
-                # Zero-sub-step passes change nothing on a quad fleet (the state is read and written back bit for bit); on
-                # the morphing hexa the base-link / composite offset makes the round trip of the velocity round: a snapshot
-                # of the state block is put back behind the passes.
-                snap = None if (self.n_act == 4 and self._type_id is None) else self.state.data.clone()
-                log = self.ctx.placement_log
-                # (one allocation for everything that is written beside the state block: the rows, and behind them the
-                # (n_act + 4) x n_pad floats a bound INDIControl writes — command, position error, yaw error; what suits the
-                # one suits the other, and the controller need not search)
-                n_rows, n_tail = shape[0] * shape[1], (self.n_act + 4) * self.state.n_pad
-                flat = (n_rows + n_tail,)
-
-                def split(block):
-                    self._obs_buf = block[:n_rows].view(shape)
-                    self._written_tail = block[n_rows:].view(self.n_act + 4, self.state.n_pad)
-                # (never worse than no search: the plain allocation is timed too and kept when the walk's best is not faster —
-                # on some boxes no block the driver hands out lies well, and PyTorch's may lie better)
-                plain = torch.zeros(flat, dtype=torch.float32, device=self.ctx.device)
-                t_plain = placement._event_timer(self._rows_trial, plain, 3)
-                block = placement.place_rows(self.ctx.device, flat, self._rows_trial, report=log, ctx=self.ctx,
-                                             stride_bytes=placement.STRIDE_BYTES)
-                if log:
-                    log[-1]["plain_pass_us"] = round(t_plain, 1)
-                    if t_plain <= 1.005 * log[-1].get("chosen_pass_us", 0.0):
-                        plain.zero_()
-                        block = plain
-                        log[-1]["decided_by"] = "the plain allocation is as fast as the walk's best: kept"
-                split(block)
-                del plain, block
-                # (When every candidate times alike there is nothing more to try.  Round 3 moved the state block to a fresh
-                # allocation and walked again; round 4 tried one arena — state block and written arrays one 16 GiB window apart
-                # in a single allocation, the layout tools/region_probe.py --arena shows to be the good one in a fresh process —
-                # and measured it in the product: it never beat the walk's best in any of two dozen processes (142-179 us against
-                # 140-158), so it is gone.  What did help is the state block's own move into a fresh driver allocation before
-                # the walk: _ensure_read_room.)
-                if snap is not None:
-                    self.state.data.copy_(snap)
-                self._last_action.copy_(echo)
-                # (a drone that sits on the ground is counted by every pass, also by these: not Env.steps)
-                self._ground_trial += self.ctx.query(nat.QUERY_GROUND_CONTACTS) - before
-            else:
-                self._obs_buf = torch.zeros(shape, dtype=torch.float32, device=self.ctx.device)
-        return self._obs_buf
-
-    def _place_targets(self, targets, control_timestep) -> None:
-        """Large homogeneous quad fleets, per-drone targets (READ beside the state block the fused step updates in place:
-        the SAME region of device memory is the good case, placement.py).  Allocated right behind the state they usually land
-        well — but not in every process: the same box gives the fused step at 154.6 or at 159 us by that alone.  The
-        launch has no neutral form: snapshot of the state block, real passes on candidates holding a copy of the targets,
-        snapshot back."""
-        from .. import placement
-        targets._placed = True
-        old = targets.data
-        if not (self.ctx.placement and isinstance(targets, Targets) and not targets.broadcast and targets.order is None
-                and 4 * old.numel() >= placement.MIN_BYTES and self._type_id is None and self.n_act == 4
-                and self._downwash is None and self._phys_options == 0 and not self._chained_enabled
-                and not self._graph_made):
-            return
-        self.materialize()
-        snap, echo = self.state.data.clone(), self._last_action.clone()
-        before = self.ctx.query(nat.QUERY_GROUND_CONTACTS)
-        args = self.step_args(control_timestep)
-        sview, tview, ref = self.state.view(), targets.view(), ctypes.byref(args)
-        filled = set()
-
-        def trial(c):
-            if c.data_ptr() not in filled:           # (the first pass on a candidate is the untimed one)
-                filled.add(c.data_ptr())
-                c.copy_(old)
-            tview.base = c.data_ptr()
-            nat.check(self.ctx.lib.dsim_step(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, sview, tview, ref))
-        room = self._take_read_room(old.numel())
-        t_room = None
-        if room is not None:                          # the block right behind the state, in the state's own allocation
-            room = room.view(old.shape)
-            sview = self.state.view()                 # (the state block may just have moved there)
-            t_room = placement._event_timer(trial, room, 3)
-        keep = placement.place_rows(self.ctx.device, tuple(old.shape), trial, report=self.ctx.placement_log,
-                                    label="per-drone targets", clearly=0.0, walk_bytes=4 << 30, ctx=self.ctx)
-        if t_room is not None:
-            rep = self.ctx.placement_log[-1]
-            rep["behind_the_state_pass_us"] = round(t_room, 1)
-            if t_room <= 1.01 * rep.get("chosen_pass_us", 0.0):
-                keep = room
-                rep["decided_by"] = "the block behind the state, in its allocation, is as fast as the walk's best: kept"
-        keep.copy_(old)
-        targets.data = keep
-        self.state.data.copy_(snap)
-        self._last_action.copy_(echo)
-        self._ground_trial += self.ctx.query(nat.QUERY_GROUND_CONTACTS) - before
-        self._fused_plan = self._fused_plan_dw = None
-
-    def _rows_trial(self, rows: torch.Tensor) -> None:
-        """One pass of the Env.step launch with ZERO physics sub-steps writing its rows to `rows`: the same kernel and
-        memory streams, the state read and written back bit for bit (placement.place_rows times it)."""
-        args = self.step_args()
-        args.phys_substeps = 0
-        if self._caller_io:
-            args.options |= nat.OPT_CALLER_IO
-        args.action = self._action_buf.data_ptr()
-        args.obs_out, args.obs_width = rows.data_ptr(), 16 + self.n_act
-        nat.check(self.ctx.lib.dsim_physics(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
-                                            self.state.view(), self._last_action.data_ptr(), ctypes.byref(args)))
 
     def _load_action(self, action, caller_order: bool = False) -> None:
         n = self.NUM_DRONES
@@ -819,73 +683,6 @@ class CtrlAviary:
                 t = t.T
         self._action_buf[:, :n] = t if (self.order is None or caller_order) else self.order.to_storage(t, 1)
 
-    def _rows_to_caller(self, rows: torch.Tensor) -> torch.Tensor:
-        """Observation rows as the kernels write them (one per storage slot) -> the caller's numbering."""
-        return rows if self.order is None else self.order.to_caller(rows, 0)
-
-    def observe(self) -> torch.Tensor:
-        """[N, 16+n_act] rows of _getDroneStateVector (BaseAviary.py:780-790), on device."""
-        buf = self._obs_tensor()
-        if self.order is not None:
-            # (rows per storage slot first, then gathered into the caller's numbering: not through the buffer Env.step
-            # hands out, which holds the caller's numbering already when the run kernels wrote it)
-            if getattr(self, "_obs_slots", None) is None:
-                self._obs_slots = torch.zeros_like(buf)
-            buf = self._obs_slots
-        self._join_fallback()
-        la = self._last_action.data_ptr() if self._use_last_action else None
-        nat.check(self.ctx.lib.dsim_observe(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
-                                            self.state.view(), la, buf.data_ptr(), 16 + self.n_act))
-        return self._rows_to_caller(buf)
-
-    def neighbors(self, max_k: Optional[int] = None):
-        """Fleet-scale form of the observation's ``neighbors`` entry (BaseAviary._getAdjacencyMatrix,
-        BaseAviary.py:901-921; CtrlAviary.py:225-231): (count [N] int32, list [max_k, N] int32, -1 padded) of the drones
-        within NEIGHBOURHOOD_RADIUS of each drone, by the uniform-grid query of dsim_adjacency."""
-        from ..downwash import Downwash
-        if not np.isfinite(self.NEIGHBOURHOOD_RADIUS):
-            raise ValueError("neighbourhood_radius is infinite: every drone neighbours every other (the reference's "
-                             "default); pass a finite radius for neighbour lists")
-        if self._adjacency is None:
-            self._adjacency = Downwash(self.ctx, self.state, self._type_id, None)
-        if self._downwash is not None:
-            self._downwash.invalidate_prebin()            # the adjacency pass re-uses the ctx's grid bookkeeping
-        k = self.neighbors_k if max_k is None else int(max_k)
-        cnt, lst = self._adjacency.adjacency(float(self.NEIGHBOURHOOD_RADIUS), max_k=k)
-        if self.order is not None:              # per-slot results of slot indices -> per-drone results of drone indices
-            cnt = self.order.to_caller(cnt, 0)
-            if lst is not None:
-                lst = self.order.to_caller(lst, 1).long()
-                lst = torch.where(lst >= 0, self.order.drone[lst.clamp(min=0)], lst).to(torch.int32)
-        return cnt, lst
-
-    def _getAdjacencyMatrix(self, pos: np.ndarray) -> np.ndarray:
-        """BaseAviary.py:901-921 — O(N^2), only produced in dict mode (small fleets)."""
-        d = np.linalg.norm(pos[:, None, :] - pos[None, :, :], axis=2)
-        adj = (d < self.NEIGHBOURHOOD_RADIUS).astype(np.float64)
-        np.fill_diagonal(adj, 1.0)
-        return adj
-
-    def _computeObs(self, obs=None):
-        obs = self.observe() if obs is None else obs
-        if not self.dict_io:
-            if self.neighbors_k > 0:
-                cnt, lst = self.neighbors()
-                return FleetObs(obs, cnt, lst)
-            return obs
-        o = obs.double().cpu().numpy()
-        self.pos, self.quat, self.rpy = o[:, 0:3], o[:, 3:7], o[:, 7:10]
-        self.vel, self.ang_v = o[:, 10:13], o[:, 13:16]
-        adj = self._getAdjacencyMatrix(self.pos)
-        out = {}
-        for i in range(self.NUM_DRONES):
-            na = self.drones[i].n_act
-            out[str(i)] = {"state": o[i, : 16 + na].copy(), "neighbors": adj[i, :]}
-        return out
-
-    def _getDroneStateVector(self, nth_drone: int) -> np.ndarray:
-        return self.observe()[nth_drone].double().cpu().numpy()
-
     @staticmethod
     def _computeReward():
         return -1                                   # CtrlAviary.py:267-279
@@ -897,164 +694,3 @@ class CtrlAviary:
     @staticmethod
     def _computeInfo():
         return {"answer": 42}                       # CtrlAviary.py:299-310
-
-
-class FusedGraph:
-    """A captured sequence of fused steps (see :meth:`CtrlAviary.capture_fused`)."""
-
-    def __init__(self, env: CtrlAviary, targets, steps: int, control_timestep):
-        self.env, self.steps = env, steps
-        env.materialize()
-        dev = env.ctx.device
-        self._counter = torch.zeros((1,), dtype=torch.int64, device=dev)
-        wp = isinstance(targets, WaypointTargets)
-        if env._downwash is not None:
-            env._downwash._box = None           # the eager query inside step_args measures the fleet's box afresh
-            env._downwash.invalidate_prebin()
-        self._args = env.step_args(control_timestep, nat.OPT_BCAST_TGT if targets.broadcast else 0)
-        self._args.step_index = 0
-        self._args.step_index_dev = self._counter.data_ptr()
-        if wp:
-            targets.fill(self._args)
-            self._tview = nat.View()
-        else:
-            self._tview = targets.view()
-        self._sview = env.state.view()
-        self._targets = targets
-        lib, h, n = env.ctx.lib, env.ctx.handle, env.NUM_DRONES
-        dw = env._downwash
-        self._graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            # one untimed eager pass on the side stream (lazy module loading must not happen under capture)
-            nat.check(lib.dsim_counter_add(h, side.cuda_stream, self._counter.data_ptr(), 0))
-            with torch.cuda.graph(self._graph, stream=side):
-                sp = torch.cuda.current_stream(dev).cuda_stream
-                refresh = None
-                if dw is not None:
-                    # The grid stands for the whole graph (no box re-measurement: that is a host read-back).  Captured
-                    # behind dsim_downwash_reset the first query clears both count buffers and bins the fleet itself, so a
-                    # replay assumes nothing about what ran before it; the last step fills no grid ahead.
-                    refresh, dw._box_refresh = dw._box_refresh, 1 << 62
-                    dw._prebin_version = None
-                    nat.check(lib.dsim_downwash_reset(h))
-                try:
-                    for i in range(steps):
-                        self._args.step_index = i          # frozen offset; the base is read from the device counter
-                        if dw is not None:
-                            self._args.ext_force = dw.compute().data_ptr()
-                            self._args.bin_next = dw.bin_next_ptr() if i + 1 < steps else None
-                        nat.check(lib.dsim_step(h, sp, n, self._sview, self._tview, ctypes.byref(self._args)))
-                finally:
-                    if dw is not None:
-                        dw._box_refresh = refresh
-                        dw._prebin_version = None
-                        nat.check(lib.dsim_downwash_reset(h))
-                        # the captured launches hold these addresses: an eager step that later re-measures the box and
-                        # outgrows the workspace allocates a new one — this one must outlive the graph
-                        self._keepalive = (dw._ws, dw.force, dw.type_id)
-                nat.check(lib.dsim_counter_add(h, sp, self._counter.data_ptr(), steps))
-        torch.cuda.current_stream(dev).wait_stream(side)
-        self._counter_host = 0
-
-    def replay(self) -> None:
-        env = self.env
-        env.materialize()
-        if self._counter_host != env._env_steps:  # eager steps in between: realign the noise stream
-            self._counter.fill_(env._env_steps)
-        self._graph.replay()
-        if env._downwash is not None:      # the buffers are as the graph left them, not as the ctx last saw them
-            env._downwash._prebin_version = None
-            nat.check(env.ctx.lib.dsim_downwash_reset(env.ctx.handle))
-        self._counter_host = env._env_steps + self.steps
-        env._use_last_action = False
-        env._chain_ok = True
-        env._fused_plan = None
-        env.step_counter += env.AGGR_PHY_STEPS * self.steps
-        env._env_steps += self.steps
-
-
-class _AdaptorAviary(CtrlAviary):
-    """Shared body of the two alternate action adaptors: the action is turned into a PWM command by
-    (part of) the INDI law INSIDE step() — on the current state — and the physics follows."""
-
-    _MODE = -1
-
-    def __init__(self, *a, **k):
-        super().__init__(*a, **k)
-        if self.PHYSICS != Physics.PYB:
-            # dsim_step_adaptor flies plain PYB (no drag / ground effect / downwash inputs): refuse instead of
-            # silently ignoring the mode the caller asked for
-            raise NotImplementedError(f"{type(self).__name__}: physics={self.PHYSICS} — the action-adaptor envs "
-                                      "support Physics.PYB only")
-
-    def step(self, action):
-        self.materialize()
-        self._chain_ok = False
-        plan = self._step_plan
-        if plan is not None and self._is_action_rows(action) and plan[0] == (
-                self.state.data.data_ptr(), self._obs_buf.data_ptr(), self._last_action.data_ptr(), self._tuning,
-                self.AGGR_PHY_STEPS, self.noise_seed):
-            # (the prepared launch of the one-launch form, re-used while nothing it was built from has changed; the action is
-            # a parameter of the call)
-            plan[1].step_index = self._env_steps
-            self._action_keep = action
-            nat.check(self.ctx.lib.dsim_step_adaptor(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, plan[2],
-                                                     action.data_ptr(), self._MODE, plan[0][2], plan[3]))
-            self._use_last_action = True
-            self.step_counter += self.AGGR_PHY_STEPS
-            self._env_steps += 1
-            return plan[4], -1, False, plan[5]
-        args = self.step_args(self.AGGR_PHY_STEPS * self.TIMESTEP)
-        # A homogeneous fleet in whole tiles steps in ONE launch that takes the action as the caller holds it ([N, 4] rows
-        # on the device: no transpose) and writes Env.step's observation rows itself (k_adaptor_fast).
-        one_launch = (not self.dict_io and self.order is None and len(self.types) == 1 and self.state.n_pad % 256 == 0
-                      and not self.ground_plane and self._type_id is None
-                      and not (self.noise == "fine" and self.noise_seed != 0))      # (k_adaptor_fast carries the default lattice only)
-        rows_in = (one_launch and isinstance(action, torch.Tensor) and action.dtype == torch.float32 and action.is_contiguous()
-                   and action.device == self.ctx.device and tuple(action.shape) == (self.NUM_DRONES, 4)
-                   and action.data_ptr() % 16 == 0)
-        if rows_in:
-            args.options |= nat.OPT_ACTION_ROWS
-            act_ptr = action.data_ptr()
-        else:
-            self._load_action(action)
-            act_ptr = self._action_buf.data_ptr()
-        obs = None
-        if one_launch:
-            obs = self._obs_tensor()
-            args.obs_out, args.obs_width = obs.data_ptr(), 20
-        nat.check(self.ctx.lib.dsim_step_adaptor(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
-                                                 self.state.view(), act_ptr, self._MODE,
-                                                 self._last_action.data_ptr(), ctypes.byref(args)))
-        self._use_last_action = True
-        self.step_counter += self.AGGR_PHY_STEPS
-        self._env_steps += 1
-        out = self._computeObs(obs)
-        self._step_plan = None
-        if rows_in and out is obs:
-            self._step_plan = ((self.state.data.data_ptr(), obs.data_ptr(), self._last_action.data_ptr(), self._tuning,
-                                self.AGGR_PHY_STEPS, self.noise_seed), args, self.state.view(), ctypes.byref(args), out,
-                               self._computeInfo())
-        return out, self._computeReward(), self._computeDone(), self._computeInfo()
-
-
-class VelocityAviary(_AdaptorAviary):
-    """dronesim/envs/VelocityAviary.py: action = (vx, vy, vz, speed fraction) per drone; the env runs
-    the full INDI law with target_pos = current position, target yaw = current yaw and
-    target_vel = SPEED_LIMIT |a3| unit(a0..2) (VelocityAviary.py:241-262), SPEED_LIMIT =
-    MAX_SPEED_KMH / 3.6 (:92-94)."""
-
-    _MODE = nat.ADAPT_VELOCITY
-
-    def __init__(self, *a, **k):
-        super().__init__(*a, **k)
-        self.SPEED_LIMIT = [t.max_speed_kmh * (1000 / 3600) for t in (self.drones or self.types)]
-
-
-class RPYTAviary(_AdaptorAviary):
-    """dronesim/envs/RPYTAviary.py: action = (p, q, r body-rate set-points, thrust) per drone, fed to
-    INDIControl._INDIRateControl only (RPYTAviary.py:181-193)."""
-
-    _MODE = nat.ADAPT_RPYT

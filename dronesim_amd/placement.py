@@ -57,6 +57,9 @@ from typing import Callable, Optional
 
 import torch
 
+from . import _native as nat
+from .fleet import Targets
+
 MIN_BYTES = 64 << 20                          # arrays at least this large, or they are allocated plainly
 WALK_BYTES = 4 << 30                          # held at once while searching (transient).  Round 4 walked 34 GiB (two 16 GiB regions and a candidate): on
                                               # fresh boxes that bought nothing reliable (BENCH_r04: -10.7 % to +3 %), so the opt-in default is small;
@@ -193,3 +196,150 @@ def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int
                        "seconds": round(time.perf_counter() - t_start, 4), "memory": "driver (dsim_dev_alloc)" if ctx is not None else "torch"})
     return keep
 
+
+
+class PlacedFleetArrays:
+    """What ``CtrlAviary`` does with the above (a mix-in: the env's own attributes — ctx, state, _last_action, _obs_buf, _runs,
+    _downwash, _phys_options ... — are used as they are).  Opt-in since round 5 (``CtrlAviary(placement=True)``): on fresh boxes
+    the searches were worth between -10 % and +12 % of the two-call loop (BENCH_r04.json)."""
+
+    def _placement_applies(self, nbytes: int) -> bool:
+        """Arrays written beside the state block are placed by trial (placement.py) for fleets that are bound by HBM and that
+        the fast kernels serve: large ones, without the downwash chain, without the drag / ground / plane options."""
+        served = self._type_id is None or (self._runs is not None and len(self._runs) <= 8)
+        return bool(self.ctx.placement and nbytes >= MIN_BYTES and served and self._downwash is None
+                    and self._phys_options == 0)
+
+    def _ensure_read_room(self) -> None:
+        """Arrays a launch READS beside the state block it updates — the targets of the fused step, of computeControl — want
+        the state's own 16 GiB window of device memory (placement.py; tools/region_probe.py --arena, G: computeControl 136 us
+        with its targets there, 143 us with them one window on), and where a separate allocation falls is the memory
+        manager's business.  So a large fleet's state block moves ONCE into a driver allocation with room for two target
+        blocks right behind it: the same allocation is the same window (but for the 1-in-20 case that a window boundary runs
+        through it, which the trials would show)."""
+        if self._read_room is not None or self._chain_live or self._graph_made or not self.ctx.placement:
+            return
+        self._read_room = []
+        nst, ntg = self.state.data.numel(), nat.NT * self.state.n_pad
+        try:
+            blk = _DriverBlock(self.ctx, (nst + 2 * ntg,)).tensor()
+        except (MemoryError, RuntimeError):
+            return
+        self._move_state(blk[:nst].view(self.state.data.shape))
+        blk[nst:].zero_()
+        self._read_room = [blk[nst:nst + ntg], blk[nst + ntg:]]
+        self.ctx.placement_log.append({"array": "state block + room for two target blocks", "bytes": 4 * (nst + 2 * ntg),
+                                       "held_bytes": 4 * 2 * ntg, "placed": "one driver allocation"})
+
+    def _take_read_room(self, numel: int):
+        """One of the two target-sized blocks behind the state block (a flat fp32 tensor), or None."""
+        self._ensure_read_room()
+        if self._read_room and self._read_room[0].numel() == numel:
+            return self._read_room.pop(0)
+        return None
+
+    def _place_obs_rows(self, shape) -> None:
+        """A large fleet on the fast kernels (the Env.step launch writes the rows beside the state it updates in place): WHERE
+        the rows lie is worth 10-15 % of that launch and is chosen by timing it."""
+        self.materialize()
+        self._ensure_read_room()                  # (the state block in its final place before anything is timed against it)
+        before = self.ctx.query(nat.QUERY_GROUND_CONTACTS)
+        echo = self._last_action.clone()          # the passes echo the (clipped) action buffer: put back below
+        # Zero-sub-step passes change nothing on a quad fleet (the state is read and written back bit for bit); on
+        # the morphing hexa the base-link / composite offset makes the round trip of the velocity round: a snapshot
+        # of the state block is put back behind the passes.
+        snap = None if (self.n_act == 4 and self._type_id is None) else self.state.data.clone()
+        log = self.ctx.placement_log
+        # (one allocation for everything that is written beside the state block: the rows, and behind them the
+        # (n_act + 4) x n_pad floats a bound INDIControl writes — command, position error, yaw error; what suits the
+        # one suits the other, and the controller need not search)
+        n_rows, n_tail = shape[0] * shape[1], (self.n_act + 4) * self.state.n_pad
+        flat = (n_rows + n_tail,)
+
+        def split(block):
+            self._obs_buf = block[:n_rows].view(shape)
+            self._written_tail = block[n_rows:].view(self.n_act + 4, self.state.n_pad)
+        # (never worse than no search: the plain allocation is timed too and kept when the walk's best is not faster —
+        # on some boxes no block the driver hands out lies well, and PyTorch's may lie better)
+        plain = torch.zeros(flat, dtype=torch.float32, device=self.ctx.device)
+        t_plain = _event_timer(self._rows_trial, plain, 3)
+        block = place_rows(self.ctx.device, flat, self._rows_trial, report=log, ctx=self.ctx,
+                                     stride_bytes=STRIDE_BYTES)
+        if log:
+            log[-1]["plain_pass_us"] = round(t_plain, 1)
+            if t_plain <= 1.005 * log[-1].get("chosen_pass_us", 0.0):
+                plain.zero_()
+                block = plain
+                log[-1]["decided_by"] = "the plain allocation is as fast as the walk's best: kept"
+        split(block)
+        del plain, block
+        # (When every candidate times alike there is nothing more to try.  Round 3 moved the state block to a fresh
+        # allocation and walked again; round 4 tried one arena — state block and written arrays one 16 GiB window apart
+        # in a single allocation, the layout tools/region_probe.py --arena shows to be the good one in a fresh process —
+        # and measured it in the product: it never beat the walk's best in any of two dozen processes (142-179 us against
+        # 140-158), so it is gone.  What did help is the state block's own move into a fresh driver allocation before
+        # the walk: _ensure_read_room.)
+        if snap is not None:
+            self.state.data.copy_(snap)
+        self._last_action.copy_(echo)
+        # (a drone that sits on the ground is counted by every pass, also by these: not Env.steps)
+        self._ground_trial += self.ctx.query(nat.QUERY_GROUND_CONTACTS) - before
+
+    def _place_targets(self, targets, control_timestep) -> None:
+        """Large homogeneous quad fleets, per-drone targets (READ beside the state block the fused step updates in place:
+        the SAME region of device memory is the good case, placement.py).  Allocated right behind the state they usually land
+        well — but not in every process: the same box gives the fused step at 154.6 or at 159 us by that alone.  The
+        launch has no neutral form: snapshot of the state block, real passes on candidates holding a copy of the targets,
+        snapshot back."""
+        targets._placed = True
+        old = targets.data
+        if not (self.ctx.placement and isinstance(targets, Targets) and not targets.broadcast and targets.order is None
+                and 4 * old.numel() >= MIN_BYTES and self._type_id is None and self.n_act == 4
+                and self._downwash is None and self._phys_options == 0 and not self._chained_enabled
+                and not self._graph_made):
+            return
+        self.materialize()
+        snap, echo = self.state.data.clone(), self._last_action.clone()
+        before = self.ctx.query(nat.QUERY_GROUND_CONTACTS)
+        args = self.step_args(control_timestep)
+        sview, tview, ref = self.state.view(), targets.view(), ctypes.byref(args)
+        filled = set()
+
+        def trial(c):
+            if c.data_ptr() not in filled:           # (the first pass on a candidate is the untimed one)
+                filled.add(c.data_ptr())
+                c.copy_(old)
+            tview.base = c.data_ptr()
+            nat.check(self.ctx.lib.dsim_step(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES, sview, tview, ref))
+        room = self._take_read_room(old.numel())
+        t_room = None
+        if room is not None:                          # the block right behind the state, in the state's own allocation
+            room = room.view(old.shape)
+            sview = self.state.view()                 # (the state block may just have moved there)
+            t_room = _event_timer(trial, room, 3)
+        keep = place_rows(self.ctx.device, tuple(old.shape), trial, report=self.ctx.placement_log,
+                                    label="per-drone targets", clearly=0.0, walk_bytes=4 << 30, ctx=self.ctx)
+        if t_room is not None:
+            rep = self.ctx.placement_log[-1]
+            rep["behind_the_state_pass_us"] = round(t_room, 1)
+            if t_room <= 1.01 * rep.get("chosen_pass_us", 0.0):
+                keep = room
+                rep["decided_by"] = "the block behind the state, in its allocation, is as fast as the walk's best: kept"
+        keep.copy_(old)
+        targets.data = keep
+        self.state.data.copy_(snap)
+        self._last_action.copy_(echo)
+        self._ground_trial += self.ctx.query(nat.QUERY_GROUND_CONTACTS) - before
+        self._fused_plan = self._fused_plan_dw = None
+
+    def _rows_trial(self, rows: torch.Tensor) -> None:
+        """One pass of the Env.step launch with ZERO physics sub-steps writing its rows to `rows`: the same kernel and
+        memory streams, the state read and written back bit for bit (place_rows times it)."""
+        args = self.step_args()
+        args.phys_substeps = 0
+        if self._caller_io:
+            args.options |= nat.OPT_CALLER_IO
+        args.action = self._action_buf.data_ptr()
+        args.obs_out, args.obs_width = rows.data_ptr(), 16 + self.n_act
+        nat.check(self.ctx.lib.dsim_physics(self.ctx.handle, self.ctx.stream_ptr(), self.NUM_DRONES,
+                                            self.state.view(), self._last_action.data_ptr(), ctypes.byref(args)))

@@ -23,7 +23,7 @@ from hypothesis import strategies as st  # noqa: E402
 from dronesim_amd import params  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from tests.test_gpu_parity import _check_obs_rows  # noqa: E402
-from tests.test_gpu_round4 import _downwash_part, _noise_by_id  # noqa: E402
+from tests.test_gpu_two_call_loop import _downwash_part, _noise_by_id  # noqa: E402
 from tests.util import K_ULP, assert_control_parity, assert_step_parity, f32, noise_terms  # noqa: E402
 
 pytestmark = pytest.mark.gpu

@@ -629,7 +629,7 @@ def test_type_major_runs_equal_mixed_kernel_and_oracle(gpu, sub):
     assert rel_err(results[0][0], results[1][0], RIGID_SCALE).max() < 0.2 * REL_TOL
     assert rel_err(results[0][1], results[1][1], MEM_SCALE).max() < 0.5 * REL_TOL
     # a run that leaves the fleet, or names a type the table does not hold, is refused (a run may START anywhere:
-    # tests/test_gpu_round3.py flies runs that share tiles)
+    # tests/test_gpu_storage_halo_placement.py flies runs that share tiles)
     ctx = fleet.Context(types)
     st, tg = fleet.FleetState(ctx, n_slots), fleet.Targets(ctx, n_slots)
     tid_dev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device)

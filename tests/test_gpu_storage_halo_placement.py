@@ -1,4 +1,4 @@
-"""GPU parity tests of round 3's additions (HIP path through the C-ABI vs the fp64 oracle, tests/util.py's bars):
+"""GPU parity tests of fleet STORAGE and SHARDING (HIP path through the C-ABI vs the fp64 oracle, tests/util.py's bars):
 transparent type-major storage of interleaved fleets, runs that share tiles, the device-paced halo exchange at BASELINE
 config 5's real shard size, the deferred WLS fallback pass, the fused observation store, and the staleness rules of the
 pre-binned neighbour grid.
@@ -776,3 +776,30 @@ def test_sharded_downwash_example_runs_as_two_ranks(gpu):
     assert len(ships) == 2 and p.stdout.count("WLS failures 0") == 2 and len(re.findall(r"rank [01]/2:", p.stdout)) == 2, p.stdout
     for sent, peers, lost in ships:
         assert 0 < int(sent) < 16384 // 3 and int(peers) == 1 and int(lost) == 0, p.stdout
+
+
+def test_driver_blocks_go_back_to_the_driver_after_the_env_is_closed(gpu):
+    """A placed fleet's arrays live on driver allocations (placement._DriverBlock) that PyTorch tensors keep alive.  env.close()
+    destroys the library context; the tensors are usually dropped AFTERWARDS — the blocks must still go back (they
+    leaked, ~1.3 GB per closed 4 M-drone env)."""
+    import gc
+    from dronesim_amd.envs import CtrlAviary
+    from dronesim_amd.fleet import Targets
+    nd = 1 << 21
+    xyz = np.stack([np.arange(nd) % 2048, np.arange(nd) // 2048, np.full(nd, 1.0)], 1).astype(np.float64)
+    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    env = CtrlAviary(["robobee"], nd, initial_xyzs=xyz, aggregate_phy_steps=1, noise_seed=4, dict_io=False, placement=True)
+    t = Targets(env.ctx, nd, "tile64")
+    t.set(pos=xyz.T.astype(np.float32), yaw=0.1)
+    env.step_fused(t, action=np.full((nd, 4), 0.4, dtype=np.float32))
+    env.step(torch.full((nd, 4), 0.45, device=env.ctx.device))
+    torch.cuda.synchronize()
+    assert any("driver" in str(r.get("memory", r.get("placed", ""))) for r in env.ctx.placement_log)
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert held > 300 << 20                                       # the fleet is there
+    env.close()                                                   # the ctx goes first ...
+    del env, t                                                    # ... the tensors on the driver blocks afterwards
+    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
+    leaked = free0 - torch.cuda.mem_get_info()[0]
+    assert leaked < 64 << 20, leaked                              # (allocator granularity; the blocks were ~0.5 GB)

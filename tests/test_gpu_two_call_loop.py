@@ -1,4 +1,4 @@
-"""GPU parity tests of round 4's additions (HIP path through the C-ABI vs the fp64 oracle, tests/util.py's bars): the
+"""GPU parity tests of the reference-shaped two-call loop (HIP path through the C-ABI vs the fp64 oracle, tests/util.py's bars): the
 reference-shaped two-call loop — obs = env.step(action); action = ctrl.computeControlFromState(obs)
 (examples/fly_INDI.py:223-239, examples/fly_hexa_6DOF.py:214-221) — on every fleet kind through the run kernels
 (k_physics_runs / k_control_runs), and the explicit-action instances of k_step_runs.

@@ -1,5 +1,5 @@
 """Host logic of dronesim_amd/placement.py (which candidate the walk keeps, when it stops), with a scripted clock: no
-device needed.  What the placement is worth is measured on the GPU (tests/test_gpu_round3.py, profiles/r03_placement_*)."""
+device needed.  What the placement is worth is measured on the GPU (tests/test_gpu_storage_halo_placement.py, profiles/r03_placement_*)."""
 import pytest
 
 torch = pytest.importorskip("torch")

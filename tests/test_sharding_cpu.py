@@ -82,7 +82,7 @@ def test_position_allgather_restores_global_order_gloo():
 
 def _cpu_halo_class():
     """HaloWire with its device operations done by torch on the host (test infrastructure: the product's HaloPlan does them
-    with dsim_fleet_bounds / dsim_halo_pack, which tests/test_gpu_round3.py checks against this same rule) — everything
+    with dsim_fleet_bounds / dsim_halo_pack, which tests/test_gpu_storage_halo_placement.py checks against this same rule) — everything
     else (resize protocol, who talks to whom, capacities, the grouped batch on persistent buffers) is the product's code."""
     from dronesim_amd import _native as nat
     from dronesim_amd.downwash import HaloWire

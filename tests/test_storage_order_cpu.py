@@ -1,5 +1,5 @@
 """fleet.StorageOrder on the CPU: the permutation behind the transparent type-major storage of interleaved fleets (the GPU
-side is tests/test_gpu_round3.py) — a stable sort by type, inverse maps, the translation helpers, the run table it implies."""
+side is tests/test_gpu_storage_halo_placement.py) — a stable sort by type, inverse maps, the translation helpers, the run table it implies."""
 import numpy as np
 import torch
 

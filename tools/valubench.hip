@@ -18,6 +18,15 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
     } else if (KIND == 1) {
       a0 = __builtin_amdgcn_exp2f(a0); a1 = __builtin_amdgcn_exp2f(a1); a2 = __builtin_amdgcn_exp2f(a2); a3 = __builtin_amdgcn_exp2f(a3);
       a4 = __builtin_amdgcn_exp2f(a4); a5 = __builtin_amdgcn_exp2f(a5); a6 = __builtin_amdgcn_exp2f(a6); a7 = __builtin_amdgcn_exp2f(a7);
+    } else if (KIND == 3) {          // v_pk_fma_f32: two fp32 FMAs per lane and instruction (counted as ONE instruction below)
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
+      const f2 mm = {m, m}, cc = {c, c};
+      for (int r = 0; r < 2; ++r) {
+        p0 = __builtin_elementwise_fma(p0, mm, cc); p1 = __builtin_elementwise_fma(p1, mm, cc);
+        p2 = __builtin_elementwise_fma(p2, mm, cc); p3 = __builtin_elementwise_fma(p3, mm, cc);
+      }
+      a0 = p0.x; a1 = p0.y; a2 = p1.x; a3 = p1.y; a4 = p2.x; a5 = p2.y; a6 = p3.x; a7 = p3.y;
     } else {
       a0 = __builtin_amdgcn_rcpf(a0); a1 = __builtin_amdgcn_rcpf(a1); a2 = __builtin_amdgcn_rcpf(a2); a3 = __builtin_amdgcn_rcpf(a3);
       a4 = __builtin_amdgcn_rcpf(a4); a5 = __builtin_amdgcn_rcpf(a5); a6 = __builtin_amdgcn_rcpf(a6); a7 = __builtin_amdgcn_rcpf(a7);
@@ -37,14 +46,15 @@ int main() {
   hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 20000;
   printf("{\"cus\": %d, \"clock_hz\": %.0f", cus, clk);
-  const char* names[3] = {"v_fma_f32", "v_exp_f32", "v_rcp_f32"};
-  for (int kind = 0; kind < 3; ++kind)
+  const char* names[4] = {"v_fma_f32", "v_exp_f32", "v_rcp_f32", "v_pk_fma_f32"};
+  for (int kind = 0; kind < 4; ++kind)
     for (int wps = 1; wps <= 8; wps *= 2) {          // workgroups of 4 waves: one wave per SIMD each; wps of them per CU
       const dim3 g(cus * wps), b(256);
       for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
         if (kind == 0) hipLaunchKernelGGL(k<0>, g, b, 0, 0, out, iters, 1.0f);
         else if (kind == 1) hipLaunchKernelGGL(k<1>, g, b, 0, 0, out, iters, 1.0f);
+        else if (kind == 3) hipLaunchKernelGGL(k<3>, g, b, 0, 0, out, iters, 1.0f);
         else hipLaunchKernelGGL(k<2>, g, b, 0, 0, out, iters, 1.0f);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
