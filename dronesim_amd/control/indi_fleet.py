@@ -161,7 +161,8 @@ class INDIControl(BaseControl):
             tview.base = c.data_ptr()
             nat.check(lib.dsim_control2(h, self.ctx.stream_ptr(), self.n, view, tview, ref, self._pos_e.data_ptr(),
                                         self._yaw_e.data_ptr(), self._cmd.data_ptr()))
-        room = self.env._take_read_room(old.numel()) if self.env is not None else None
+        # (the env's own predicate: no move of its state block for fleets the placement does not apply to)
+        room = (self.env._take_read_room(old.numel()) if (self.env is not None and self.env._placement_applies(4 * old.numel())) else None)
         t_room = None
         if room is not None:                          # the block right behind the state, in the state's own allocation
             room = room.view(old.shape)
@@ -306,8 +307,13 @@ class INDIControl(BaseControl):
             a.drone_id = st.order.drone_id(st.n_pad).data_ptr()
         if not self._outputs_placed:
             self._outputs_placed = True
-            self._place_outputs(a)
-            self._place_targets(a)
+            if self.ctx.placement:
+                # (the trials are real passes of this law: what they add to the WLS counters is not the fleet's history)
+                before = [self.ctx.query(w) for w in (nat.QUERY_WLS_FALLBACKS, nat.QUERY_WLS_FAILURES)]
+                self._place_outputs(a)
+                self._place_targets(a)
+                for w, b in zip((nat.QUERY_WLS_FALLBACKS, nat.QUERY_WLS_FAILURES), before):
+                    self.ctx.query_offsets[w] = self.ctx.query_offsets.get(w, 0) + self.ctx.query(w) - b
         sview, tview = st.view(), self._targets.view()
         nat.check(self.ctx.lib.dsim_control2(self.ctx.handle, self.ctx.stream_ptr(), n, sview, tview, ctypes.byref(a),
                                              self._pos_e.data_ptr(), self._yaw_e.data_ptr(), self._cmd.data_ptr()))

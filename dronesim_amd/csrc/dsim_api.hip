@@ -3189,9 +3189,11 @@ static int make_runtab(const dsim_ctx* ctx, long long n_pad, const dsim_type_run
   return blocks;
 }
 
-// RunTab.block_map: the workgroups of the runs dealt side by side, eight at a time to the run that is furthest behind
+// RunTab.block_map: the workgroups of the runs dealt side by side, one tile at a time to the run that is furthest behind
 // (progress = tiles served / tiles of the run), so that every run sweeps the caller's index range at the same pace.  Kept
-// by the ctx and re-made only when the runs change; the upload is ordered on the caller's stream.
+// by the ctx and re-made only when the runs change: that rare path waits for the whole DEVICE (a launch of this ctx on
+// another stream may still read the old table) and may allocate — so the first DSIM_OPT_CALLER_IO call with a new set of
+// runs must not sit inside a stream capture (include/dronesim_amd.h); the upload is ordered on the caller's stream.
 static int side_by_side_map(dsim_ctx* ctx, hipStream_t st, const dsim_type_run* runs, int n_runs, RunTab* rt) {
   const int blocks = rt->blk0[DSIM_MAX_TYPES] + (rt->blk0[DSIM_MAX_TYPES] & 1);      // (two entries per workgroup: an odd count is padded)
   rt->block_map = nullptr;
@@ -3201,7 +3203,7 @@ static int side_by_side_map(dsim_ctx* ctx, hipStream_t st, const dsim_type_run* 
     same = ctx->block_map_key[r].first == runs[r].first && ctx->block_map_key[r].count == runs[r].count && ctx->block_map_key[r].type == runs[r].type;
   if (!same) {
     if (ctx->block_map_cap < blocks) {
-      hipError_t e = hipStreamSynchronize(st);                 // (a launch in flight may still read the old table)
+      hipError_t e = hipDeviceSynchronize();                   // (a launch in flight, on any stream, may still read the old table)
       if (e != hipSuccess) return (int)e;
       if (ctx->d_block_map) (void)hipFree(ctx->d_block_map);
       free(ctx->h_block_map);
@@ -3212,7 +3214,7 @@ static int side_by_side_map(dsim_ctx* ctx, hipStream_t st, const dsim_type_run* 
       if (e != hipSuccess) return (int)e;
       ctx->block_map_cap = blocks;
     } else {
-      hipError_t e = hipStreamSynchronize(st);
+      hipError_t e = hipDeviceSynchronize();
       if (e != hipSuccess) return (int)e;
     }
     int next[DSIM_MAX_TYPES], total[DSIM_MAX_TYPES];

@@ -51,6 +51,7 @@ class Context:
         self.placement = False                 # opt-in (CtrlAviary(placement=True) / a stand-alone controller sets it)
         self.placement_walk_bytes = None       # the transient budget of a search; None = placement.WALK_BYTES (4 GiB)
         self.placement_log = []
+        self.query_offsets = {}                # counts that trial passes (placement.py) added to the device counters: subtracted by query()
 
     @property
     def handle(self):
@@ -69,7 +70,7 @@ class Context:
         WLS loop so far, nat.QUERY_WLS_FAILURES = those where it did not converge (the reference would raise)."""
         v = ctypes.c_int64(0)
         nat.check(self.lib.dsim_query(self._h, self.stream_ptr(), int(what), ctypes.byref(v)))
-        return int(v.value)
+        return int(v.value) - self.query_offsets.get(int(what), 0)     # (what placement trials counted is not the fleet's history)
 
     def close(self):
         if self._h:

@@ -176,7 +176,9 @@ enum {
    * second pass over them (BaseAviary.py:547-555, INDIControl.py:227), and the command goes from the one to the other as
    * it is.  last_action_out stays in storage order (it is the env's own memory, read back by dsim_observe).  Needs
    * drone_id and a fleet that the run kernels serve (runs given or one type; no noise replay, no drag / ground / plane
-   * option): DSIM_E_UNSUPPORTED otherwise.                                                                            */
+   * option): DSIM_E_UNSUPPORTED otherwise.  The first call with a NEW set of runs builds a small table the ctx keeps: it
+   * waits for the device and may allocate, so it must not sit inside a stream capture (every later call with the same
+   * runs may).                                                                                                        */
   DSIM_OPT_CALLER_IO   = 1u << 14,
   /* dsim_physics / dsim_step_adaptor: `action` is row-major [n][4] — one 4-vector per drone, as Env.step is handed it
    * (CtrlAviary.py:258-263, VelocityAviary.py:221-264, RPYTAviary.py:181-193) — instead of field-major [4][n_pad]; 16-byte

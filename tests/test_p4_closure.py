@@ -176,3 +176,53 @@ def test_hexa_locked_joint_approximation_is_quantified():
         prev = want
     print(f"hexa_6DOF: arm joints move {joint_motion:.3e} rad in the engine; rigid-composite step differs by {worst:.3e} of the increment")
     assert joint_motion < 1e-3 and worst < 1e-3
+
+
+@pytest.mark.skipif(not _has("dyn_states"), reason="the fixture holds no Physics.DYN flight (record it with round 5's recorder)")
+def test_dyn_flight_with_the_real_engine_as_the_pose_store():
+    """Row D1 against the engine: the reference's _dynamics / step() loop with the REAL PyBullet storing and returning the
+    pose (tests/golden/dynamics.npz was recorded with a stand-in store): the oracle's Env.step on Physics.DYN, step by step
+    from the recording's own previous state — the quaternion Bullet hands back, rpy = its getEulerFromQuaternion, the
+    placeholder angular velocity, rpy_rates."""
+    g = np.load(FIXTURE, allow_pickle=False)
+    t = params.builtin_type(str(g["drone"]))
+    assert t.arm == float(g["dyn_arm"])
+    O = orc.Oracle([t])
+    aggr = int(g["dyn_aggr"])
+    init, pwm, states = g["dyn_init"], g["dyn_pwm"], g["dyn_states"]
+    prev = np.concatenate([init[0:7], init[10:16]])
+    rates = np.zeros((1, 3))
+    for k in range(pwm.shape[0]):
+        r = prev[None, :].copy()
+        a6 = np.zeros((1, 6)); a6[0, :4] = pwm[k]
+        assert O.dyn_physics(r, rates, O.reset_mem(1), aggr, DT, action=a6) == 0
+        want = states[k]
+        np.testing.assert_allclose(r[0, 0:7], want[0:7], rtol=0, atol=1e-9, err_msg=f"pose, step {k}")
+        np.testing.assert_allclose(orc.euler_from_quat(r[0, 3:7]), want[7:10], rtol=0, atol=1e-9, err_msg=f"rpy, step {k}")
+        np.testing.assert_allclose(r[0, 7:10], want[10:13], rtol=0, atol=1e-9)
+        np.testing.assert_array_equal(want[13:16], -1.0)                        # what getBaseVelocity reports under DYN
+        np.testing.assert_allclose(rates[0], want[16:19], rtol=0, atol=1e-9)
+        prev = np.concatenate([want[0:7], want[10:16]])
+        rates = want[16:19][None, :].copy()
+
+
+@pytest.mark.skipif(not _has("noisy_state"), reason="the fixture holds no noisy flight (record it with round 5's recorder)")
+def test_noisy_flight_replays_through_the_oracle_with_the_recorded_draws():
+    """The fly_INDI.py flight with the rotor noise ON: the reference's own draws (f_noise[4], m_noise[4] per sub-step,
+    BaseAviary.py:1518-1521), fed to the oracle as a noise replay — every Env.step from the engine's own previous state must
+    land on the engine's next state: pins WHERE the normals enter the force map (rotor link z forces, the shared lateral
+    components of draws 0 and 1, the base torque) through the engine, not only through the recorded apply* calls."""
+    g = np.load(FIXTURE, allow_pickle=False)
+    t = params.builtin_type(str(g["drone"]))
+    O = orc.Oracle([t])
+    aggr = int(g["noisy_aggr"])
+    prev = np.concatenate([g["noisy_init_xyz"][0], orc.quat_from_euler(g["noisy_init_rpy"][0]), np.zeros(6)])
+    for k in range(g["noisy_state"].shape[0]):
+        r = prev[None, :].copy()
+        a6 = np.zeros((1, 6)); a6[0, :4] = g["noisy_action"][k]
+        nz = np.zeros((1, aggr, 12))
+        nz[0, :, 0:4], nz[0, :, 6:10] = g["noisy_f_noise"][k], g["noisy_m_noise"][k]
+        O.physics(r, O.reset_mem(1), aggr, DT, action=a6, noise=nz)
+        want = _rigid(g["noisy_state"][k])
+        np.testing.assert_allclose(r[0], want, rtol=0, atol=1e-9, err_msg=f"step {k}")
+        prev = want

@@ -25,6 +25,18 @@ Round 3 additions, written into the same file:
     ARTICULATED body: six revolute arm joints held by default motors, hexa_6DOF.urdf:382-434; this repo flies the rigid
     composite): states, actions, commands — what quantifies the locked-joint approximation.
 
+Round 5 additions, written into the same file:
+  * `dyn_*` — one flight on Physics.DYN (BaseAviary._dynamics, BaseAviary.py:1767-1828) with the REAL engine as the pose store
+    (p.resetBasePositionAndOrientation / resetBaseVelocity / getBase...): the branch is dead code in the fork for plumbing
+    reasons (it reads self.KF, self.M, self.J, self.J_INV, self.L, self.GRAVITY, self.DRONE_MODEL and indexes the action as an
+    array, :527), so those attributes are supplied from env.drones[0] and _preprocessAction hands an RPM array through — exactly
+    what tests/golden/make_goldens.py:capture_dynamics does with a stand-in store.  Pins the stand-in (does Bullet return the
+    quaternion it was given? the placeholder angular velocity?) and C8 inside that loop;
+  * `noisy_*` — the fly_INDI.py flight again with the rotor noise ON and every draw logged (np.random.normal wrapped: a seeded
+    generator, the normals stored per sub-step in the order the reference draws them, BaseAviary.py:1518-1521): states and
+    normals, so that the oracle and the kernels can be fed the very same draws (noise replay) — pins the noise ENTRY POINTS
+    of the force map inside the engine (which link, which frame), sub-step by sub-step.
+
 tests/test_p4_closure.py consumes the file and is skipped while it does not exist.
 """
 import argparse
@@ -94,6 +106,8 @@ def main(argv=None):
     out.update(record_helpers(p))
     if a.hexa_steps > 0:
         out.update(record_hexa(p, a.hexa_steps, sim_freq, ctrl_freq))
+    out.update(record_dyn(p, a.drone, sim_freq))
+    out.update(record_noisy(p, a.drone, sim_freq, ctrl_freq))
     np.savez(a.out, **out)
     print(f"wrote {a.out}: {a.steps} control steps, first ground contact at step {first}")
 
@@ -152,6 +166,82 @@ def record_hexa(p, steps, sim_freq, ctrl_freq):
         env.close()
     res = {k: np.asarray(v) for k, v in rec.items()}
     res.update(hexa_init_xyz=init_xyz, hexa_init_rpy=init_rpy, hexa_aggr=aggr)
+    return res
+
+
+def record_dyn(p, drone, sim_freq, steps=48, aggr=5):
+    """Physics.DYN with the real engine as the pose store (module docstring).  48 Env.steps of 5 sub-steps: smooth
+    differential thrust about hover, as tests/golden/make_goldens.py:capture_dynamics flies it."""
+    from dronesim.envs.BaseAviary import DroneModel, Physics
+    from dronesim.envs.CtrlAviary import CtrlAviary
+    init_xyz, init_rpy = np.array([[0.0, 1.0, 1.5]]), np.array([[0.1, -0.05, 0.4]])
+    env = CtrlAviary(drone_model=[drone], num_drones=1, initial_xyzs=init_xyz, initial_rpys=init_rpy, physics=Physics.DYN,
+                     neighbourhood_radius=10, freq=sim_freq, aggregate_phy_steps=aggr, gui=False, record=False, obstacles=False,
+                     user_debug_gui=False)
+    d = env.drones[0]
+    # what the fork left commented out (BaseAviary.py:200-235): the attributes _dynamics reads on self
+    env.KF, env.KM, env.M, env.J, env.J_INV, env.L = d.KF, d.KM, d.M, d.J, d.J_INV, d.L
+    env.GRAVITY, env.DRONE_MODEL = env.G * d.M, DroneModel.CF2X                      # :226; the examples' "default: CF2X"
+    env._preprocessAction = lambda action: action                                     # upstream CtrlAviary: the RPM array as it is
+    hover = np.sqrt(d.M * env.G / (4 * d.KF)) / 20000.0
+    rng = np.random.default_rng(41)
+    t = np.arange(steps)[:, None] * (aggr / sim_freq)
+    pwm = np.clip(hover * (1.0 + 0.02 * np.sin(2 * np.pi * rng.uniform(0.5, 3.0, (1, 4)) * t + rng.uniform(0, 2 * np.pi, (1, 4))))
+                  + rng.normal(0, 0.002, (steps, 4)), 0.0, 1.0)
+    init = np.concatenate([env.pos[0], env.quat[0], env.rpy[0], env.vel[0], env.ang_v[0]]).copy()
+    rec = []
+    try:
+        for k in range(steps):
+            env.step((20000.0 * pwm[k])[None, :])
+            rec.append(np.concatenate([env.pos[0], env.quat[0], env.rpy[0], env.vel[0], env.ang_v[0], env.rpy_rates[0]]).copy())
+    finally:
+        env.close()
+    return {"dyn_init": init, "dyn_pwm": pwm, "dyn_states": np.asarray(rec), "dyn_aggr": aggr, "dyn_arm": d.L}
+
+
+def record_noisy(p, drone, sim_freq, ctrl_freq, steps=48, seed=20265):
+    """The fly_INDI.py flight with the rotor noise ON and logged: np.random.normal is wrapped by a seeded generator that
+    records every draw; per physics sub-step the reference draws f_noise[4] ~ N(0, .01) then m_noise[4] ~ N(0, .001)
+    (BaseAviary.py:1518-1521).  Started at z = 2 m so that the ground plane stays out of it."""
+    from dronesim.control.INDIControl import INDIControl
+    from dronesim.envs.BaseAviary import Physics
+    from dronesim.envs.CtrlAviary import CtrlAviary
+    aggr = int(sim_freq / ctrl_freq)
+    init_xyz, init_rpy = np.array([[0.0, 1.0, 2.0]]), np.zeros((1, 3))
+    env = CtrlAviary(drone_model=[drone], num_drones=1, initial_xyzs=init_xyz, initial_rpys=init_rpy, physics=Physics.PYB,
+                     neighbourhood_radius=10, freq=sim_freq, aggregate_phy_steps=aggr, gui=False, record=False, obstacles=False,
+                     user_debug_gui=False)
+    gen = np.random.default_rng(seed)
+    draws = []
+    real_normal = np.random.normal
+
+    def logged(loc=0.0, scale=1.0, size=None):
+        v = gen.normal(loc, scale, size)
+        draws.append((float(scale), np.atleast_1d(np.asarray(v, dtype=np.float64)).copy()))
+        return v
+    np.random.normal = logged
+    ctrl = INDIControl(drone_model=drone)
+    action = {"0": np.array([0.4, 0.4, 0.4, 0.4])}
+    rec = {k: [] for k in ("noisy_action", "noisy_state", "noisy_cmd")}
+    try:
+        for k in range(steps):
+            obs, _, _, _ = env.step(action)
+            rec["noisy_action"].append(np.asarray(action["0"], dtype=np.float64).copy())
+            rec["noisy_state"].append(np.asarray(obs["0"]["state"], dtype=np.float64).copy())
+            cmd, _, _ = ctrl.computeControlFromState(control_timestep=aggr / sim_freq, state=obs["0"]["state"],
+                                                     target_pos=np.array([0.0, 0.0, 2.0]), target_rpy=np.array([0.0, 0.0, 0.4]))
+            action = {"0": cmd}
+            rec["noisy_cmd"].append(np.asarray(cmd, dtype=np.float64).copy())
+    finally:
+        np.random.normal = real_normal
+        env.close()
+    # the draws in order: (f_noise[4], m_noise[4]) per sub-step — anything else would mean the reference draws differently
+    assert len(draws) == 2 * steps * aggr and all(d[1].shape == (4,) for d in draws), "unexpected draw pattern"
+    assert all(abs(draws[2 * i][0] - 0.01) < 1e-12 and abs(draws[2 * i + 1][0] - 0.001) < 1e-12 for i in range(steps * aggr))
+    f = np.array([draws[2 * i][1] for i in range(steps * aggr)]).reshape(steps, aggr, 4)
+    m = np.array([draws[2 * i + 1][1] for i in range(steps * aggr)]).reshape(steps, aggr, 4)
+    res = {k: np.asarray(v) for k, v in rec.items()}
+    res.update(noisy_f_noise=f, noisy_m_noise=m, noisy_init_xyz=init_xyz, noisy_init_rpy=init_rpy, noisy_aggr=aggr, noisy_seed=seed)
     return res
 
 
