@@ -54,7 +54,7 @@ BYTES_PER_DRONE_STEP = 232      # read 13+11+10 floats, write 13+1
 VALU_PAIR_PEAK = 256 * 4 * 2.4e9 * 64 / (18 * 2.82 + 2 * 9.4)
 WATCHDOG_RC = 3                 # exit code of every rank when a collective section hangs (Watchdog)
 MIN_TIMED_S = 0.05              # the timed region is repeated (whole K-step regions) until it covers this much
-WORKLOADS = ["config2x1024", "config2", "config3", "config4", "config5", "hexa", "mixed", "mixed_type_major", "two_call_loop"]
+WORKLOADS = ["config2x1024", "config2", "config3", "config4", "config5", "hexa", "mixed", "mixed_type_major", "two_call_loop", "dyn"]
 
 
 def parse(argv=None):
@@ -598,6 +598,7 @@ WORKLOAD_TEXT = {
     "two_call_loop": "configs[1] x 1024 envs/GPU through the reference-shaped loop: obs = env.step(cmd); "
                      "cmd = ctrl.computeControlFromState(obs)",
     "hexa": "4096 hexa_6DOF (6-DOF INDI + WLS) hover x 1024 vectorised envs/GPU",
+    "dyn": "configs[1] x 1024 envs/GPU on Physics.DYN (the reference's explicit model, BaseAviary._dynamics) + INDI",
     "config5": "configs[4] shard: 65536/GPU, 50% robobee + 50% hexa_6DOF interleaved, neighbour downwash at the config's "
                "density (one drone per m^2: a 128 m x 512 m slab per GPU), halo exchange between neighbouring slabs",
 }
@@ -769,7 +770,7 @@ def main(argv=None):
 
     n_fleet, replicas = {"config2x1024": (4096, 1024), "config2": (4096, 1), "config3": (65536, 1), "config4": (4096, 16),
                          "config5": (65536, 1), "hexa": (4096, 1024), "mixed": (4096, 1024),
-                         "mixed_type_major": (4096, 1024), "two_call_loop": (4096, 1024)}[a.workload]
+                         "mixed_type_major": (4096, 1024), "two_call_loop": (4096, 1024), "dyn": (4096, 1024)}[a.workload]
     tck = a.two_call_kind if a.workload == "two_call_loop" else None
     if tck == "config5":
         n_fleet, replicas = 65536, 1
@@ -783,7 +784,7 @@ def main(argv=None):
                dist=(MirrorDist(a.slab_m) if (a.mirror_peer and world == 1) else dist) if a.workload == "config5" else None,
                rank=rank, hexa=a.workload == "hexa" or tck == "hexa",
                mixed=("type_major" if a.workload == "mixed_type_major" else (a.workload == "mixed" or tck == "mixed")), options=options,
-               slab_m=a.slab_m)
+               slab_m=a.slab_m, dyn=a.workload == "dyn")
     if a.workload == "two_call_loop":
         fl.make_two_call_loop()
 
@@ -799,7 +800,7 @@ def main(argv=None):
     launch_s = dev_s / steps_timed
     # config 5: half quads (232 B) half hexas (248 B) + 1 B type id + the 12 B downwash force the step kernel reads;
     # its step is a chain of kernels (neighbour query, step + grid binning, WLS fallback), timed as a whole
-    bytes_per = {"config5": 253, "hexa": 248, "mixed": 241, "mixed_type_major": 241,
+    bytes_per = {"config5": 253, "hexa": 248, "mixed": 241, "mixed_type_major": 241, "dyn": 256,
                  "two_call_loop": TWO_CALL_BYTES[a.two_call_kind][0]}.get(a.workload, BYTES_PER_DRONE_STEP)
     mixed_k = {"generic": "k_step_lean", "mixed-v1": "k_step_mixed", "mixed-ring": "k_step_mixed2", "mixed-v3": "k_step_mixed3"}.get(
         a.variant, "k_step_mixed3" if a.layout != "tile64" else "k_step_mixed4")
@@ -811,6 +812,7 @@ def main(argv=None):
               "hexa": "k_step_hexa (+ k_wls_fallback)",
               "mixed": f"{mixed_k} (+ k_wls_fallback)",
               "mixed_type_major": "k_step_run x2 (+ k_wls_fallback)",
+              "dyn": "k_dyn (Physics.DYN: BaseAviary._dynamics + INDI)",
               "two_call_loop": ("k_physics_fast (observation fused) + k_control_fast" if tck == "quad" else
                                 ("k_dw_query_cell, " if tck == "config5" else "") +
                                 "k_physics_runs (observation fused) + k_control_runs (+ k_wls_fallback)")}.get(a.workload, "k_step_fast")
