@@ -1164,71 +1164,6 @@ __global__ __launch_bounds__(256, 1) void k_physics_plane(StepK a) {     // DSIM
   DSIM_FOR_MY_TYPE(UNIFORM, a, i, (physics_gen_body<NOISE, NACT, true>(T, a, i, ad)));
 }
 
-// ---- Physics.DYN ----------------------------------------------------------------------------------------------------------
-// BaseAviary.step with PHYSICS == Physics.DYN (BaseAviary.py:510-545: the loop calls _dynamics(clipped_action, i) per drone
-// and sub-step, :525-527, and skips p.stepSimulation, :541-543): the reference's own explicit model (dsim_device.h:dyn_substep)
-// on quad types, any fleet size (ragged tails included), per-lane type ids of a table of quads by the waterfall.  One kernel
-// family for both entry points:
-//   CTRL = false  dsim_physics: Env.step — the action clipped (CtrlAviary.py:258-263) and echoed, the sub-steps, the 13
-//                 rigid floats and the three rpy rates written back
-//   CTRL = true   dsim_step: the same followed by computeControl on the new state, as the example loop orders them
-//                 (examples/fly_INDI.py:223-239); an explicit action serves the physics part only
-// Reads 13 + 3 (+ 4 | + 11 + 10), writes 13 + 3 (+ 4 | + 11) floats per drone: bound by HBM like every other single-launch
-// form; no noise (the model has none), no ground-plane watch (the pose is SET, :1814-1819: no engine step, no contact).
-template <bool CTRL, bool NT, class DT>
-__device__ __forceinline__ void dyn_body(DT& T, const StepK& a, long long i0, const Addr& ad) {
-  // (per-drone arrays beside the state: wave-uniform base + the lane's byte offset, like the state's own accesses)
-  const unsigned lo = 4u * threadIdx.x;
-  float* const rb = a.dyn_rates + i0;
-  Rigid s;
-  load_rigid<NT>(ad.sb, ad.sfs, ad.sl, s);
-  V3 rr = v3(ldg<NT>(rb, lo), ldg<NT>(rb + a.n_pad, lo), ldg<NT>(rb + 2 * a.n_pad, lo));     // self.rpy_rates, :1785
-  CtrlMem<4> m;
-  Target tg;
-  float cmd[4];
-  if (CTRL) {
-    load_mem<4, NT>(ad.sb, ad.sfs, ad.sl, m);
-    load_target<NT>(ad.tb, ad.tfs, ad.tl, tg);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float raw = a.action ? ldg<NT>(a.action + (long long)j * a.n_pad + i0, lo)
-                               : (CTRL ? m.cmd[j] : ldg<NT>(ad.sb + (20 + j) * ad.sfs, ad.sl));
-    cmd[j] = clampf(raw, T.pmin[j], T.pmax[j]);                                               // CtrlAviary.py:258-263
-  }
-  const DynBase b = dyn_base(T, cmd);
-  for (int k = 0; k < a.substeps; ++k) dyn_substep(T, a.dt_phys, b, s, rr);
-  const V3 w_new = dyn_reported_ang_vel((a.options & DSIM_OPT_DYN_BODY_RATES) != 0, s.q, rr);  // :1821-1826
-  if (a.substeps > 0) s.w = w_new;
-  if (CTRL) {
-    V3 pos_e;
-    float yaw_e;
-    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  }
-  const unsigned so = pin_lane_offset(ad.sl), lo2 = pin_lane_offset(lo);
-  store_rigid<NT>(ad.sb, ad.sfs, so, s);
-  stg<NT>(rb, lo2, rr.x); stg<NT>(rb + a.n_pad, lo2, rr.y); stg<NT>(rb + 2 * a.n_pad, lo2, rr.z);   // :1828
-  if (CTRL) store_mem<4, NT>(ad.sb, ad.sfs, so, m);
-  if (!CTRL && a.echo) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) stg<NT>(a.echo + (long long)j * a.n_pad + i0, lo2, cmd[j]);    // last_clipped_action, :545
-  }
-}
-template <bool CTRL, bool NT>
-__global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_dyn(StepK a) {
-  const long long i0 = (long long)blockIdx.x * 256;
-  const long long i = i0 + threadIdx.x;
-  if (i >= a.n_pad) return;
-  const Addr ad = make_addr(a, i0, threadIdx.x);
-  // one body for homogeneous and mixed quad fleets: the wave peels one type per turn (a homogeneous fleet: one turn), the
-  // type's constants through the constant address space at a wave-uniform index (scalar loads)
-  const int my_t = a.type_id ? (int)a.type_id[i] : 0;
-  for (;;) {
-    const int cur_t = __builtin_amdgcn_readfirstlane(my_t);
-    if (my_t == cur_t) { dyn_body<CTRL, NT>(dev_type(a.types, cur_t), a, i0, ad); break; }
-  }
-}
-
 // ---- computeControl only ----------------------------------------------------
 template <int NACT, class DT>
 __device__ __forceinline__ void control_gen_body(DT& T, const StepK& a, long long i, const Addr& ad) {
@@ -1316,6 +1251,78 @@ __device__ __forceinline__ void obs_rows20_out(vf4* rows, const StepK& a, long l
     }
   }
 }
+// ---- Physics.DYN ----------------------------------------------------------------------------------------------------------
+// BaseAviary.step with PHYSICS == Physics.DYN (BaseAviary.py:510-545: the loop calls _dynamics(clipped_action, i) per drone
+// and sub-step, :525-527, and skips p.stepSimulation, :541-543): the reference's own explicit model (dsim_device.h:dyn_substep)
+// on quad types, any fleet size (ragged tails included), per-lane type ids of a table of quads by the waterfall.  One kernel
+// family for both entry points:
+//   CTRL = false  dsim_physics: Env.step — the action clipped (CtrlAviary.py:258-263) and echoed, the sub-steps, the 13
+//                 rigid floats and the three rpy rates written back, optionally (OBS) the 20-wide rows Env.step returns
+//   CTRL = true   dsim_step: the same followed by computeControl on the new state, as the example loop orders them
+//                 (examples/fly_INDI.py:223-239); an explicit action serves the physics part only
+// Reads 13 + 3 (+ 4 | + 11 + 10), writes 13 + 3 (+ 4 | + 11) floats per drone: bound by HBM like every other single-launch
+// form; no noise (the model has none), no ground-plane watch (the pose is SET, :1814-1819: no engine step, no contact).
+struct Cmd4 { float c0, c1, c2, c3; };
+template <bool CTRL, bool NT, class DT>
+__device__ __forceinline__ void dyn_body(DT& T, const StepK& a, long long i0, const Addr& ad, Rigid& s, Cmd4& cmd_out) {
+  float cmd[4];
+  // (per-drone arrays beside the state: wave-uniform base + the lane's byte offset, like the state's own accesses)
+  const unsigned lo = 4u * threadIdx.x;
+  float* const rb = a.dyn_rates + i0;
+  load_rigid<NT>(ad.sb, ad.sfs, ad.sl, s);
+  V3 rr = v3(ldg<NT>(rb, lo), ldg<NT>(rb + a.n_pad, lo), ldg<NT>(rb + 2 * a.n_pad, lo));     // self.rpy_rates, :1785
+  CtrlMem<4> m;
+  Target tg;
+  if (CTRL) {
+    load_mem<4, NT>(ad.sb, ad.sfs, ad.sl, m);
+    load_target<NT>(ad.tb, ad.tfs, ad.tl, tg);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float raw = a.action ? ldg<NT>(a.action + (long long)j * a.n_pad + i0, lo)
+                               : (CTRL ? m.cmd[j] : ldg<NT>(ad.sb + (20 + j) * ad.sfs, ad.sl));
+    cmd[j] = clampf(raw, T.pmin[j], T.pmax[j]);                                               // CtrlAviary.py:258-263
+  }
+  const DynBase b = dyn_base(T, cmd);
+  for (int k = 0; k < a.substeps; ++k) dyn_substep(T, a.dt_phys, b, s, rr);
+  const V3 w_new = dyn_reported_ang_vel((a.options & DSIM_OPT_DYN_BODY_RATES) != 0, s.q, rr);  // :1821-1826
+  if (a.substeps > 0) s.w = w_new;
+  if (CTRL) {
+    V3 pos_e;
+    float yaw_e;
+    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
+  }
+  const unsigned so = pin_lane_offset(ad.sl), lo2 = pin_lane_offset(lo);
+  store_rigid<NT>(ad.sb, ad.sfs, so, s);
+  stg<NT>(rb, lo2, rr.x); stg<NT>(rb + a.n_pad, lo2, rr.y); stg<NT>(rb + 2 * a.n_pad, lo2, rr.z);   // :1828
+  if (CTRL) store_mem<4, NT>(ad.sb, ad.sfs, so, m);
+  if (!CTRL && a.echo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stg<NT>(a.echo + (long long)j * a.n_pad + i0, lo2, cmd[j]);    // last_clipped_action, :545
+  }
+  cmd_out = Cmd4{cmd[0], cmd[1], cmd[2], cmd[3]};
+}
+// OBS (Env.step only): the 20-wide observation rows of the NEW state written by the same launch (obs_rows20_out, as
+// k_physics_fast: the wave's 64 rows through its private LDS block, behind the type waterfall where the wave is whole again).
+template <bool CTRL, bool NT, bool OBS = false>
+__global__ __launch_bounds__(256, OBS ? 4 : DSIM_STEP_WAVES) void k_dyn(StepK a) {     // (OBS at 5 waves per SIMD: 12 B of scratch)
+  __shared__ __attribute__((aligned(16))) vf4 rows[OBS ? 4 * 64 * 5 : 1];
+  const long long i0 = (long long)blockIdx.x * 256;
+  const long long i = i0 + threadIdx.x;
+  if (i >= a.n_pad) return;                            // (n_pad is a multiple of 64: whole waves leave)
+  const Addr ad = make_addr(a, i0, threadIdx.x);
+  Rigid s_new;
+  Cmd4 c_new;
+  // one body for homogeneous and mixed quad fleets: the wave peels one type per turn (a homogeneous fleet: one turn), the
+  // type's constants through the constant address space at a wave-uniform index (scalar loads)
+  const int my_t = a.type_id ? (int)a.type_id[i] : 0;
+  for (;;) {
+    const int cur_t = __builtin_amdgcn_readfirstlane(my_t);
+    if (my_t == cur_t) { dyn_body<CTRL, NT>(dev_type(a.types, cur_t), a, i0, ad, s_new, c_new); break; }
+  }
+  if (OBS) { const float cmd_new[4] = {c_new.c0, c_new.c1, c_new.c2, c_new.c3}; obs_rows20_out<NT>(rows, a, i0, s_new, cmd_new); }
+}
+
 template <bool NOISE, bool NT, bool OBS>
 __global__ __launch_bounds__(256, DSIM_PHYS_WAVES) void k_physics_fast(StepK a) {
   constexpr int W = 20;
@@ -3251,6 +3258,7 @@ static int dyn_check(const dsim_ctx* ctx, const dsim_step_args* args, const Step
 static int dyn_launch(bool ctrl, const StepK& a, bool nt, hipStream_t st) {
   const dim3 g(grid_for(a.n_pad)), b(256);
   if (ctrl) { if (nt) hipLaunchKernelGGL((k_dyn<true, true>), g, b, 0, st, a); else hipLaunchKernelGGL((k_dyn<true, false>), g, b, 0, st, a); }
+  else if (a.obs_out) { if (nt) hipLaunchKernelGGL((k_dyn<false, true, true>), g, b, 0, st, a); else hipLaunchKernelGGL((k_dyn<false, false, true>), g, b, 0, st, a); }
   else { if (nt) hipLaunchKernelGGL((k_dyn<false, true>), g, b, 0, st, a); else hipLaunchKernelGGL((k_dyn<false, false>), g, b, 0, st, a); }
   return (int)hipGetLastError();
 }
@@ -3558,9 +3566,11 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
     rc = dyn_check(ctx, args, a);
     if (rc) return rc;
     if (args->obs_out && args->obs_width != 20) return DSIM_E_ARG;
-    rc = dyn_launch(false, a, stream_policy(args, state.n_pad, 160.0), (hipStream_t)stream);
+    const bool obs_fused = args->obs_out && ((uintptr_t)args->obs_out & 15u) == 0;       // (16-byte stores of the rows)
+    a.obs_out = obs_fused ? args->obs_out : nullptr;
+    rc = dyn_launch(false, a, stream_policy(args, state.n_pad, args->obs_out ? 240.0 : 160.0), (hipStream_t)stream);
     if (rc) return rc;
-    if (args->obs_out) return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, 20, 0);
+    if (args->obs_out && !obs_fused) return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, 20, 0);
     return DSIM_OK;
   }
   const bool fine_slow = (args->noise_seed != 0 && !args->noise_replay && (args->options & DSIM_OPT_NOISE_FINE) && a.substeps != 1);
