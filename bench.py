@@ -54,6 +54,7 @@ BYTES_PER_DRONE_STEP = 232      # read 13+11+10 floats, write 13+1
 VALU_PAIR_PEAK = 256 * 4 * 2.4e9 * 64 / (18 * 2.82 + 2 * 9.4)
 WATCHDOG_RC = 3                 # exit code of every rank when a collective section hangs (Watchdog)
 MIN_TIMED_S = 0.05              # the timed region is repeated (whole K-step regions) until it covers this much
+SETTLE_S = 0.3                  # "also" entries of chip-filling fleets: under load for this long before the timed regions (Fleet.timed)
 WORKLOADS = ["config2x1024", "config2", "config3", "config4", "config5", "hexa", "mixed", "mixed_type_major", "two_call_loop", "dyn"]
 
 
@@ -82,6 +83,9 @@ def parse(argv=None):
     p.add_argument("--two-call-kind", default="quad", choices=["quad", "hexa", "mixed", "config5"],
                    help="--workload two_call_loop: the fleet the reference-shaped loop runs on (4 194 304 quads / morphing hexas / "
                         "interleaved quads + hexas; or the 65 536-drone config-5 shard with the downwash term)")
+    p.add_argument("--settle-seconds", type=float, default=0.0,
+                   help="keep stepping, untimed, for this long behind the --warmup steps (Fleet.timed: the device's clocks "
+                        "settle ~0.1 s into a vector-heavy stretch); 0 = exactly --warmup steps, the driver's contract")
     p.add_argument("--dry-run", action="store_true",
                    help="host logic only (launcher, rendezvous, reductions, the JSON line); no device work — CPU tests")
     return p.parse_args(argv)
@@ -201,14 +205,24 @@ class Fleet:
         self.graph = self.env.capture_fused(self.tgt, steps)
         self.n_steps = steps
 
-    def timed(self, steps, warmup, barrier=None, min_s=0.0, repeat_rule=None):
+    def timed(self, steps, warmup, barrier=None, min_s=0.0, repeat_rule=None, settle_s=0.0):
         """W untimed warm-up steps, then regions of EXACTLY `steps` steps each, bracketed by barrier + device
         synchronisation on both sides, repeated until they cover `min_s` seconds.  Returns (wall seconds, device
         seconds, regions): sums over the regions; the device seconds come from events on the launch stream.
-        repeat_rule(region_wall_s) -> total number of regions (so that every rank runs the same number)."""
+        repeat_rule(region_wall_s) -> total number of regions (so that every rank runs the same number).
+        settle_s: keep stepping, untimed, for this long behind the warm-up steps.  A device that has been idle runs its first
+        launches at its top clock, throttles hard a few milliseconds into a vector-heavy stretch and settles ~100 ms later
+        (tools/clock_probe.py, profiles/r05_clock_*.txt: five sub-steps of 4 194 304 quads 154 us -> up to 238 us -> 169.7 us
+        for as long as the load lasts); a region timed right behind a short warm-up measures that episode, not the kernel."""
         torch = self.torch
         for _ in range(warmup):
             self.step()
+        if settle_s > 0.0:
+            t_end = time.perf_counter() + settle_s
+            while time.perf_counter() < t_end:
+                for _ in range(20):
+                    self.step()
+                torch.cuda.synchronize()
         # the collector stays off inside the timed regions (as timeit does): a collection that frees another variant's
         # graphs or fleet in the middle of a region stalls the host for tens of milliseconds (seen: 3x wall vs device)
         gc.collect()
@@ -394,7 +408,7 @@ def two_call_child(a, kind="quad", placement=False):
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "two_call_loop", "--two-call-kind", kind,
            "--steps", str(max(50, a.steps // 2)),
            "--warmup", str(a.warmup), "--no-also", "--no-cpu-baseline", "--layout", a.layout, "--noise-seed", str(a.noise_seed),
-           "--stream", a.stream] + (["--lib", a.lib] if a.lib else [])
+           "--stream", a.stream, "--settle-seconds", str(SETTLE_S)] + (["--lib", a.lib] if a.lib else [])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                                             "DSIM_BENCH_FORCE_DIST")}
     env["DSIM_PLACEMENT"] = "1" if placement else "0"
@@ -404,7 +418,7 @@ def two_call_child(a, kind="quad", placement=False):
         e = {"drone_steps_per_s": d["value"], "loop_us": d["ms_per_step"] * 1e3, "steps_timed": d["steps_timed"],
              "drones": d["config"]["drones_per_gpu"], "loop_us_device": d["roofline"]["launch_us"],
              "bytes_per_drone_step": TWO_CALL_BYTES[kind][0], "hbm_frac": d["roofline"]["frac"],
-             "kernel": d["roofline"]["kernel"], "placement_by_trial": bool(placement),
+             "kernel": d["roofline"]["kernel"], "placement_by_trial": bool(placement), "settled_for_s": d.get("settle_seconds"),
              "measured_in": f"a child process running `bench.py --workload two_call_loop --two-call-kind {kind}` alone"}
         if placement:
             e.update(note=TWO_CALL_BYTES[kind][1], placement=d.get("placement"), placement_cost=placement_cost(d.get("placement")))
@@ -657,11 +671,20 @@ def measure_variant(torch, local, layout, seed, steps, name, nf, rep, sub, wp, n
         f2.use_graph(ns)
     k2 = max(20, steps // 2)
     w2, d2, reg = f2.timed(k2, 10, min_s=MIN_TIMED_S)
+    from_idle_us = d2 / (k2 * reg) * 1e6
+    if f2.n >= (1 << 20):
+        # fleets that fill the chip: the regions above start a few launches after an idle device woke up (what rounds 1-4
+        # reported; kept as launch_us_from_idle); the entry's figures are those of a device that has been under this load
+        # for SETTLE_S (Fleet.timed: settle_s) — what a simulation that runs for longer than 0.1 s sees
+        w2, d2, reg = f2.timed(k2, 0, min_s=MIN_TIMED_S, settle_s=SETTLE_S)
     # drone_steps_per_s: from the host's clock around the regions; launch_us (and device_drone_steps_per_s): from the
     # events on the launch stream — they differ when the host, not the device, paces the loop (or hiccups)
     e = {"drone_steps_per_s": f2.n * k2 * reg * ns / w2, "launch_us": d2 / (k2 * reg) * 1e6, "env_steps_per_launch": ns,
          "drones": f2.n, "phys_substeps": sub, "steps_timed": k2 * reg,
          "device_drone_steps_per_s": f2.n * k2 * reg * ns / d2}
+    if f2.n >= (1 << 20):
+        e["launch_us_from_idle"] = from_idle_us
+        e["settled_for_s"] = SETTLE_S
     if ns == 1:
         bts = 184 if "chained" in name else (256 if name.startswith("physics_dyn") else 248 if name.startswith("hexa") else
                                              (253 if name.startswith("config5") else
@@ -698,9 +721,11 @@ def measure_adaptor_env(torch, local, layout, seed, steps, cls_name):
         else:
             act = torch.tensor([0.0, 0.0, 0.0, 9.81 * env.types[0].mass], device=env.ctx.device).repeat(n, 1)
         k = max(20, steps // 2)
-        for _ in range(10):
-            env.step(act)
-        torch.cuda.synchronize()
+        t_end = time.perf_counter() + SETTLE_S          # (under load for SETTLE_S before the timed region: Fleet.timed)
+        while time.perf_counter() < t_end:
+            for _ in range(10):
+                env.step(act)
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(k):
@@ -793,7 +818,8 @@ def main(argv=None):
         w, _ = sharding.reduce_step_times(dist, red_dev, first_wall, 0.0)
         return max(1, int(np.ceil(MIN_TIMED_S / max(w, 1e-9))))
 
-    wall_local, dev_s_local, regions = fl.timed(a.steps, a.warmup, barrier, min_s=MIN_TIMED_S, repeat_rule=repeat_rule)
+    wall_local, dev_s_local, regions = fl.timed(a.steps, a.warmup, barrier, min_s=MIN_TIMED_S, repeat_rule=repeat_rule,
+                                               settle_s=a.settle_seconds)
     wall, dev_s = sharding.reduce_step_times(dist, red_dev, wall_local, dev_s_local)  # MAX over ranks
     steps_timed = a.steps * regions
     value = sharding.aggregate_throughput([fl.n] * world, steps_timed, wall)
@@ -834,7 +860,7 @@ def main(argv=None):
             "metric": "drone-steps/sec (num_drones x env steps/s)", "value": value, "unit": "drone-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall / steps_timed * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "steps_timed": steps_timed, "timed_regions": regions,
+            "steps_timed": steps_timed, "timed_regions": regions, "settle_seconds": a.settle_seconds,
             "timing_note": f"regions of exactly --steps steps, each bracketed by barrier + device synchronisation, repeated "
                            f"until they cover {MIN_TIMED_S * 1e3:.0f} ms; value and ms_per_step are sums over all of them",
             "config": {"workload": WORKLOAD_TEXT[a.workload],

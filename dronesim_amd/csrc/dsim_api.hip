@@ -276,7 +276,8 @@ __device__ __forceinline__ int waypoint_next(int wp, int n_wp) { return wp < n_w
 template <int NOISE, int NROW = 4, bool OPTS = false, int NSUB = 0, bool PLANE = false, int FINE = -1, bool LOOPED = false, class DT>
 __device__ __forceinline__ void quad_substeps(DT& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[4], unsigned long long step_index,
-                                              V3 ext = V3{0.0f, 0.0f, 0.0f}, const float* prev = nullptr, long long nid = -1,
+                                              V3 ext = V3{-0.0f, -0.0f, -0.0f} /* x + -0 = x for EVERY x: a caller without a force pays no add */,
+                                              const float* prev = nullptr, long long nid = -1,
                                               const NoiseTab* tab = nullptr /* LDS tables of the Box-Muller pairs, or none */) {
   // nid: the drone's index in the caller's numbering when the fleet is stored in another order (StepK.drone_id): the
   // key of its noise stream.  -1 (a constant at the call sites of the single-order kernels) = i.
@@ -338,7 +339,7 @@ __device__ __forceinline__ void quad_substeps(DT& T, const StepK& a, long long i
 template <bool NOISE, bool REPLAY = true, bool ONE = false, bool PLANE = false, bool LOOPED = false, class DT>
 __device__ __forceinline__ void hexa_substeps(DT& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[6], unsigned long long step_index,
-                                              V3 ext = V3{0.0f, 0.0f, 0.0f}, long long nid = -1,
+                                              V3 ext = V3{-0.0f, -0.0f, -0.0f}, long long nid = -1,
                                               const NoiseTab* tab = nullptr /* LDS tables of the Box-Muller pairs, or none */) {
   const uint64_t noise_key = (uint64_t)(nid >= 0 ? nid : i);
   V3 F, tau;
@@ -437,9 +438,9 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
       float act[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) act[j] = clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]);   // CtrlAviary.py:258-263
-      quad_substeps<NOISE ? 1 : 0, 4, false, SUB, false, -1, SUB == 0>(T, a, i, s, act, a.step_index, V3{0.0f, 0.0f, 0.0f}, nullptr, -1, ntab);
+      quad_substeps<NOISE ? 1 : 0, 4, false, SUB, false, -1, SUB == 0>(T, a, i, s, act, a.step_index, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
     } else {
-      quad_substeps<NOISE ? 1 : 0, 4, false, SUB, false, -1, SUB == 0>(T, a, i, s, m.cmd, a.step_index, V3{0.0f, 0.0f, 0.0f}, nullptr, -1, ntab);    // stored cmd is already clipped
+      quad_substeps<NOISE ? 1 : 0, 4, false, SUB, false, -1, SUB == 0>(T, a, i, s, m.cmd, a.step_index, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);    // stored cmd is already clipped
     }
     ground_watch(T, s, a.fb.counters, i < a.n);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
     if (a.wp_table) wp = a.wp_counter[i]; else load_target<NT>(tb, tfs, tl, tg);
     for (int k = 0; k < a.n_steps; ++k) {
       if (a.wp_table) waypoint_target(a, i, wp, tg);
-      quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index + k, V3{0.0f, 0.0f, 0.0f}, nullptr, -1, ntab);
+      quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index + k, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
       ground_watch(T, s, a.fb.counters, i < a.n);
       indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
       wp = waypoint_next(wp, a.n_wp);
@@ -516,9 +517,9 @@ __global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
     float act[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) act[j] = clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]);
-    hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, act, a.step_index, V3{0.0f, 0.0f, 0.0f}, -1, ntab);
+    hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, act, a.step_index, V3{-0.0f, -0.0f, -0.0f}, -1, ntab);
   } else {
-    hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, m.cmd, a.step_index, V3{0.0f, 0.0f, 0.0f}, -1, ntab);
+    hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, m.cmd, a.step_index, V3{-0.0f, -0.0f, -0.0f}, -1, ntab);
   }
   indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
   const unsigned so = pin_lane_offset(sl);
@@ -1772,7 +1773,7 @@ __device__ __forceinline__ void adaptor_body(DT& T, const StepK& a, long long i,
   } else {                                                 // RPYTAviary.py:184-191
     indi_rate<4>(T, DSIM_RCP(a.dt_ctrl), s, v3(v[0], v[1], v[2]), v[3], m);
   }
-  quad_substeps<NOISE ? 1 : 0, 4, PLANE, 0, PLANE, 1>(T, a, i, s, m.cmd, a.step_index, V3{0.0f, 0.0f, 0.0f}, nullptr,
+  quad_substeps<NOISE ? 1 : 0, 4, PLANE, 0, PLANE, 1>(T, a, i, s, m.cmd, a.step_index, V3{-0.0f, -0.0f, -0.0f}, nullptr,
                                                    NOISE ? noise_id(a, i) : -1LL);
   ground_watch(T, s, a.fb.counters, i < a.n);
   store_rigid(ad.sb, ad.sfs, ad.sl, s);
@@ -2887,6 +2888,7 @@ static void to_dev(const dsim_type_params& p, DevType* d) {
     d->pmin[j] = (float)p.pwm_min[j]; d->pmax[j] = (float)p.pwm_max[j];
     d->spin[j] = (float)p.rotor_spin[j];
     for (int k = 0; k < 3; ++k) { d->rpos[j][k] = (float)p.rotor_pos[j][k]; d->raxis[j][k] = (float)p.rotor_axis[j][k]; }
+    for (int k = 0; k < 3; ++k) d->spax[j][k] = d->spin[j] * d->raxis[j][k];       // (exact: the spins are +-1)
     const double* r = p.rotor_pos[j]; const double* ax = p.rotor_axis[j];
     d->rxa[j][0] = (float)(r[1] * ax[2] - r[2] * ax[1]);
     d->rxa[j][1] = (float)(r[2] * ax[0] - r[0] * ax[2]);

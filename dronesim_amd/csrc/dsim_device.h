@@ -26,6 +26,7 @@ struct DevType {
   float scale[DSIM_MAX_ACT], cnst[DSIM_MAX_ACT], pmin[DSIM_MAX_ACT], pmax[DSIM_MAX_ACT];
   float rpos[DSIM_MAX_ACT][3], raxis[DSIM_MAX_ACT][3], spin[DSIM_MAX_ACT];
   float rxa[DSIM_MAX_ACT][3];                 // rpos x raxis: torque about the COM per unit thrust of rotor j
+  float spax[DSIM_MAX_ACT][3];                // spin_j raxis_j: reaction torque per unit rotor moment (hexa_wrench_noise)
   float rsum[3];                              // quads: sum of the four rotor positions (the lateral-noise lever, quad_wrench_noise)
   float alloc[DSIM_MAX_ACT][DSIM_MAX_ACT];    // quad: pinv(G1/0.05); hexa: M1 (u_opt = M1 v + M4 u0)
   float alloc2[DSIM_MAX_ACT][DSIM_MAX_ACT];   // hexa: M4
@@ -639,11 +640,25 @@ __device__ __forceinline__ void body_end(const RigidB& b, Rigid& s) {
   s.q = Q4{b.q.x * inv, b.q.y * inv, b.q.z * inv, b.q.w * inv};
   s.w = mul(matrix_from_quat(s.q), b.wb);
 }
+// R v for a quaternion within roundings of unit length, without the matrix: R = I + s (w [u]x + [u]x^2), u = (x, y, z), s = 2 / |q|^2
+// (what btMatrix3x3::setRotation spells out entry by entry), so R v = v + s (w t + u x t) with t = u x v: 23 vector instructions
+// against 26 for the matrix + 9 for the product — the looped step needs R for this ONE product only.
+__device__ __forceinline__ V3 rotate_near_unit(Q4 q, V3 v) {
+  const float d = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+  const float s = __builtin_fmaf(-2.0f, d, 4.0f);
+  const V3 u = v3(q.x, q.y, q.z);
+  const V3 t = cross(u, v);
+  const V3 c = cross(u, t);
+  return v3(__builtin_fmaf(s, __builtin_fmaf(q.w, t.x, c.x), v.x), __builtin_fmaf(s, __builtin_fmaf(q.w, t.y, c.y), v.y),
+            __builtin_fmaf(s, __builtin_fmaf(q.w, t.z, c.z), v.z));
+}
+// clamp to [-m, m] in ONE instruction (v_med3_f32; the max / min pair of clampf is two: LLVM forms the median only from
+// constants).  The same value for every finite input.
+__device__ __forceinline__ float clamp_sym(float v, float m) { return __builtin_amdgcn_fmed3f(v, -m, m); }
 template <class DT>
 __device__ __forceinline__ void bullet_step_body(DT& T, float dt, RigidB& s, V3 F_body, V3 tau_body) {
-  const M3 R = matrix_from_near_unit_quat(s.q);
   const float vn = DSIM_SQRT(dot(s.vel, s.vel));
-  const V3 Fw = mul(R, F_body);
+  const V3 Fw = rotate_near_unit(s.q, F_body);
   const float dl = T.clin + T.clin * vn;
   const V3 vdot = v3(Fw.x * T.inv_mass - dl * s.vel.x, Fw.y * T.inv_mass - dl * s.vel.y, Fw.z * T.inv_mass - T.g - dl * s.vel.z);
   const V3 wb = s.wb;
@@ -656,14 +671,14 @@ __device__ __forceinline__ void bullet_step_body(DT& T, float dt, RigidB& s, V3 
   V3 wn_b = wb + dt * ab;
   float ww = dot(wn_b, wn_b);
   if (!(ww < T.maxv * T.maxv)) {                           // (rare) a world coordinate may reach the clamp: the world-frame form
+    const M3 R = matrix_from_near_unit_quat(s.q);
     const V3 ww_ = mul(R, wn_b);
     const V3 wc = v3(clampf(ww_.x, -T.maxv, T.maxv), clampf(ww_.y, -T.maxv, T.maxv), clampf(ww_.z, -T.maxv, T.maxv));
     wn_b = mulT(R, wc);
     ww = dot(wn_b, wn_b);
   }
   s.wb = wn_b;
-  s.vel = v3(clampf(s.vel.x + vdot.x * dt, -T.maxv, T.maxv), clampf(s.vel.y + vdot.y * dt, -T.maxv, T.maxv),
-             clampf(s.vel.z + vdot.z * dt, -T.maxv, T.maxv));
+  s.vel = v3(clamp_sym(s.vel.x + vdot.x * dt, T.maxv), clamp_sym(s.vel.y + vdot.y * dt, T.maxv), clamp_sym(s.vel.z + vdot.z * dt, T.maxv));
   s.pos = s.pos + dt * s.vel;
   // exponential map of w' dt in the body frame: h^2 = (dt / 2)^2 w'.w', clamped at (pi / 8)^2 (the rotation per step at pi / 4)
   const float h2 = fminf(0.25f * dt * dt * ww, (0.5f * DSIM_PI_4) * (0.5f * DSIM_PI_4));
@@ -802,9 +817,9 @@ __device__ __forceinline__ void hexa_wrench_noise(DT& T, const HexaBase& b, cons
   F = b.F; tau = b.tau;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    const V3 ax = v3(T.raxis[j][0], T.raxis[j][1], T.raxis[j][2]);
-    F = F + nz[j] * ax;
-    tau = tau + nz[j] * v3(T.rxa[j][0], T.rxa[j][1], T.rxa[j][2]) + (nz[6 + j] * T.spin[j]) * ax;
+    // ((n spin_j) a_j = n (spin_j a_j) bit for bit: spin_j = +-1; the product is a per-type constant, DevType.spax)
+    F = F + nz[j] * v3(T.raxis[j][0], T.raxis[j][1], T.raxis[j][2]);
+    tau = tau + nz[j] * v3(T.rxa[j][0], T.rxa[j][1], T.rxa[j][2]) + nz[6 + j] * v3(T.spax[j][0], T.spax[j][1], T.spax[j][2]);
   }
 }
 

@@ -204,6 +204,34 @@ __global__ __launch_bounds__(256) void k_env_shape(float* st, const float* act, 
   }
 }
 
+// K6b: the same shape with the new state written to ANOTHER block (ping-pong) instead of in place: is it the read-modify-write
+// of the state beside the rows' write stream that the memory system dislikes, or reading and writing the same region at all?
+__global__ __launch_bounds__(256) void k_env_shape_pp(const float* st, float* st_out, const float* act, float* echo, float* rows, long long n) {
+  __shared__ f4 blk[4][20 * 16];
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* ps = st + (i >> 6) * (FS * 64) + (i & 63);
+  float* po = st_out + (i >> 6) * (FS * 64) + (i & 63);
+  float v[17], o[13];
+#pragma unroll
+  for (int f = 0; f < 13; ++f) v[f] = __builtin_nontemporal_load(ps + f * 64);
+#pragma unroll
+  for (int f = 0; f < 4; ++f) v[13 + f] = __builtin_nontemporal_load(act + f * n + i);
+  mix(v, 17, o, 13);
+#pragma unroll
+  for (int f = 0; f < 13; ++f) __builtin_nontemporal_store(o[f], po + f * 64);
+#pragma unroll
+  for (int f = 0; f < 4; ++f) __builtin_nontemporal_store(v[13 + f] + o[0] * 1e-9f, echo + f * n + i);
+  float* L = reinterpret_cast<float*>(blk[wave]);
+#pragma unroll
+  for (int f = 0; f < 20; ++f) L[lane * 20 + f] = f < 13 ? o[f] : v[f - 7] + o[1];
+  __builtin_amdgcn_wave_barrier();
+  f4* g = reinterpret_cast<f4*>(rows + (i - lane) * 20);
+#pragma unroll
+  for (int j = 0; j < 5; ++j) __builtin_nontemporal_store(blk[wave][j * 64 + lane], g + j * 64 + lane);
+}
+
 // K7: two buffers streamed side by side, one float4 per lane from / to each: MODE 0 read a + read b, 1 read a + write b,
 // 2 write a + write b, 3 read+write a + write b, 4 read+write a + read b
 template <int MODE>
@@ -427,6 +455,29 @@ int main(int argc, char** argv) {
         tin = time_it([&] { hipLaunchKernelGGL(k_tile<true>, g, b, 0, 0, st, tgp, n); }, 6);
       }
       printf("D = %6zu MiB  Env.step shape %.1f us   pair rw a + w b %.1f us   pair rw a + r b %.1f us   headline shape in place %.1f us, written to D %.1f us\n", D >> 20, t3 * 1e3, tp * 1e3, tq * 1e3, tin * 1e3, tpp * 1e3);
+    }
+    return 0;
+  }
+  bool envpp = false;
+  for (int k = 1; k < argc; ++k) if (!strcmp(argv[k], "--envpp")) envpp = true;
+  if (envpp) {
+    // ONE allocation (DSIM_SWEEP_GIB, default 40): the state block at its start; Env.step's shape in place and ping-pong
+    // (new state written E bytes on), rows D bytes on
+    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    const char* sg = getenv("DSIM_SWEEP_GIB");
+    const size_t total = (sg ? (size_t)atoi(sg) : 40ull) << 30, sz_st = sizeof(float) * FS * n, sz_a = sizeof(float) * 4 * n, sz_r = sizeof(float) * 20 * n;
+    char* arena; CK(hipMalloc(&arena, total)); CK(hipMemset(arena, 0, total));
+    float* st = (float*)arena; float* act = (float*)(arena + sz_st); float* echo = (float*)(arena + sz_st + sz_a);
+    const size_t GiB = 1ull << 30;
+    for (size_t E : {2 * GiB, 20 * GiB}) {
+      for (size_t D : {4 * GiB, 12 * GiB, 18 * GiB, 24 * GiB, 34 * GiB}) {
+        if (D + sz_r > total || E + sz_st > total) continue;
+        float* rows = (float*)(arena + D);
+        float* st2 = (float*)(arena + E);
+        const float t_in = time_it([&] { hipLaunchKernelGGL(k_env_shape<true>, g, b, 0, 0, st, act, echo, rows, n); }, 6);
+        const float t_pp = time_it([&] { hipLaunchKernelGGL(k_env_shape_pp, g, b, 0, 0, (const float*)st, st2, act, echo, rows, n); }, 6);
+        printf("new state at %2zu GiB, rows at %2zu GiB:  in place %.1f us   ping-pong %.1f us\n", E >> 30, D >> 30, t_in * 1e3, t_pp * 1e3);
+      }
     }
     return 0;
   }
