@@ -218,11 +218,7 @@ class Fleet:
         for _ in range(warmup):
             self.step()
         if settle_s > 0.0:
-            t_end = time.perf_counter() + settle_s
-            while time.perf_counter() < t_end:
-                for _ in range(20):
-                    self.step()
-                torch.cuda.synchronize()
+            return self._timed_settled(steps, barrier, min_s, repeat_rule, settle_s)
         # the collector stays off inside the timed regions (as timeit does): a collection that frees another variant's
         # graphs or fleet in the middle of a region stalls the host for tens of milliseconds (seen: 3x wall vs device)
         gc.collect()
@@ -256,6 +252,47 @@ class Fleet:
                 gc.enable()
         return wall_sum, dev_sum, regions
 
+
+    def _timed_settled(self, steps, barrier, min_s, repeat_rule, settle_s):
+        """The settled form of timed(): the device is kept under THIS load for settle_s and the timed launches follow without
+        a gap — the events that bracket them are recorded in the stream, the host synchronises only behind the last one.
+        (A synchronisation in front of every region lets the device idle for a moment, and a vector-heavy kernel then pays a
+        piece of the throttling episode again at every region's start: regions of 100 launches of the five-sub-step kernel
+        179 us per launch, the same launches back to back 168 us — 71 000 of them in 12.04 s of wall clock,
+        profiles/r05_clock_*.txt.)  Returns (device seconds, device seconds, regions): there is no host clock around a
+        region that begins in the middle of a busy stream."""
+        torch = self.torch
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            self.step()
+        e1.record()
+        torch.cuda.synchronize()
+        t_launch = max(e0.elapsed_time(e1) * 1e-3 / 20, 1e-7)
+        regions = repeat_rule(t_launch * steps) if repeat_rule else max(1, int(np.ceil(min_s / (t_launch * steps))))
+        n_settle = int(np.ceil(settle_s / t_launch))
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            if barrier:
+                barrier()
+            for _ in range(n_settle):
+                self.step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps * regions):
+                self.step()
+            e1.record()
+            if barrier:
+                barrier()
+            torch.cuda.synchronize()
+        finally:
+            if gc_was_on:
+                gc.enable()
+        dev = e0.elapsed_time(e1) * 1e-3
+        return dev, dev, regions
 
 def host_threads():
     """Threads this process may really use: affinity mask, cgroup CPU quota, and the GPU
@@ -720,12 +757,12 @@ def measure_adaptor_env(torch, local, layout, seed, steps, cls_name):
             act = torch.tensor([1.0, 0.0, 0.2, 0.5], device=env.ctx.device).repeat(n, 1)
         else:
             act = torch.tensor([0.0, 0.0, 0.0, 9.81 * env.types[0].mass], device=env.ctx.device).repeat(n, 1)
-        k = max(20, steps // 2)
-        t_end = time.perf_counter() + SETTLE_S          # (under load for SETTLE_S before the timed region: Fleet.timed)
-        while time.perf_counter() < t_end:
-            for _ in range(10):
-                env.step(act)
-            torch.cuda.synchronize()
+        k = max(300, steps // 2)
+        for _ in range(10):
+            env.step(act)
+        torch.cuda.synchronize()
+        for _ in range(int(SETTLE_S / 200e-6)):         # (under load for ~SETTLE_S, the timed launches right behind: Fleet.timed)
+            env.step(act)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(k):

@@ -2882,6 +2882,9 @@ static void to_dev(const dsim_type_params& p, DevType* d) {
     d->katt[k] = (float)p.att_gain[k]; d->krate[k] = (float)p.rate_gain[k];
     d->drag[k] = (float)p.drag_coeff[k]; d->dw[k] = (float)p.dw_coeff[k];
   }
+  d->gyro[0] = (float)((p.inertia[2] - p.inertia[1]) / p.inertia[0]);
+  d->gyro[1] = (float)((p.inertia[0] - p.inertia[2]) / p.inertia[1]);
+  d->gyro[2] = (float)((p.inertia[1] - p.inertia[0]) / p.inertia[2]);
   d->kf = (float)p.kf; d->km = (float)p.km;
   for (int j = 0; j < DSIM_MAX_ACT; ++j) {
     d->scale[j] = (float)p.pwm2rpm_scale[j]; d->cnst[j] = (float)p.pwm2rpm_const[j];

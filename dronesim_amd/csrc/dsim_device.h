@@ -22,6 +22,7 @@ struct DevType {
   int32_t kind, n_act;
   float mass, inv_mass;
   float J[3], invJ[3];
+  float gyro[3];                              // ((Jz - Jy) / Jx, (Jx - Jz) / Jy, (Jy - Jx) / Jz): Euler's equations (bullet_step_body)
   float kf, km;
   float scale[DSIM_MAX_ACT], cnst[DSIM_MAX_ACT], pmin[DSIM_MAX_ACT], pmax[DSIM_MAX_ACT];
   float rpos[DSIM_MAX_ACT][3], raxis[DSIM_MAX_ACT][3], spin[DSIM_MAX_ACT];
@@ -611,14 +612,15 @@ __device__ __forceinline__ V3 dyn_reported_ang_vel(bool body_rates, Q4 q, V3 rr)
 // Bullet clamps every WORLD coordinate of the angular velocity to +-maxCoordinateVelocity (applyDeltaVeeMultiDof): while
 // |w_b| < maxv no coordinate can reach it; a lane beyond that (100 rad/s: a tumbling wreck) takes the world-frame detour.
 // 27 + 8 + 10 of the ~300 vector instructions of a sub-step less (profiles/r05_sub5_*).
-struct RigidB { V3 pos; Q4 q; V3 vel; V3 wb; };
+struct RigidB { V3 pos; Q4 q; V3 vel; V3 wb; float ww; };      // ww = wb . wb (the exponential map of one sub-step needs it, the damping of the next one too)
 //   * the quaternion enters the loop normalised (the same rotation; the caller's may be any length: the reference's helpers
 //     do not normalise) and stays within roundings of unit length through it, so that 2 / |q|^2 of the rotation matrix is one
 //     Newton step from 1, 4 - 2 |q|^2 (error (1 - |q|^2)^2 ~ 1e-13), instead of a reciprocal per sub-step.
 __device__ __forceinline__ RigidB body_begin(const Rigid& s) {
   const float inv = DSIM_RSQ(s.q.x * s.q.x + s.q.y * s.q.y + s.q.z * s.q.z + s.q.w * s.q.w);
   const Q4 q = Q4{s.q.x * inv, s.q.y * inv, s.q.z * inv, s.q.w * inv};
-  return RigidB{s.pos, q, s.vel, mulT(matrix_from_quat(q), s.w)};
+  const V3 wb = mulT(matrix_from_quat(q), s.w);
+  return RigidB{s.pos, q, s.vel, wb, dot(wb, wb)};
 }
 // matrix_from_quat for a quaternion within roundings of unit length (the loop's)
 __device__ __forceinline__ M3 matrix_from_near_unit_quat(Q4 q) {
@@ -661,13 +663,15 @@ __device__ __forceinline__ void bullet_step_body(DT& T, float dt, RigidB& s, V3 
   const V3 Fw = rotate_near_unit(s.q, F_body);
   const float dl = T.clin + T.clin * vn;
   const V3 vdot = v3(Fw.x * T.inv_mass - dl * s.vel.x, Fw.y * T.inv_mass - dl * s.vel.y, Fw.z * T.inv_mass - T.g - dl * s.vel.z);
+  // angular: alpha_b = J^-1 (tau - w x J w) - c (1 + |w|) w, Euler's equations written out: (w x J w)_x / J_x = gyro_x w_y w_z with
+  // gyro = ((J_z - J_y) / J_x, (J_x - J_z) / J_y, (J_y - J_x) / J_z) a per-type constant — 16 instructions instead of 22, and
+  // the products of the rates enter unrounded by J
   const V3 wb = s.wb;
-  const float wn = DSIM_SQRT(dot(wb, wb));
-  const V3 Jw = v3(T.J[0] * wb.x, T.J[1] * wb.y, T.J[2] * wb.z);
-  const V3 gy = cross(wb, Jw);
+  const float wn = DSIM_SQRT(s.ww);
   const float da = T.cang + T.cang * wn;
-  const V3 ab = v3((tau_body.x - gy.x) * T.invJ[0] - da * wb.x, (tau_body.y - gy.y) * T.invJ[1] - da * wb.y,
-                   (tau_body.z - gy.z) * T.invJ[2] - da * wb.z);
+  const V3 ab = v3(__builtin_fmaf(-da, wb.x, __builtin_fmaf(-T.gyro[0], wb.y * wb.z, tau_body.x * T.invJ[0])),
+                   __builtin_fmaf(-da, wb.y, __builtin_fmaf(-T.gyro[1], wb.z * wb.x, tau_body.y * T.invJ[1])),
+                   __builtin_fmaf(-da, wb.z, __builtin_fmaf(-T.gyro[2], wb.x * wb.y, tau_body.z * T.invJ[2])));
   V3 wn_b = wb + dt * ab;
   float ww = dot(wn_b, wn_b);
   if (!(ww < T.maxv * T.maxv)) {                           // (rare) a world coordinate may reach the clamp: the world-frame form
@@ -677,7 +681,7 @@ __device__ __forceinline__ void bullet_step_body(DT& T, float dt, RigidB& s, V3 
     wn_b = mulT(R, wc);
     ww = dot(wn_b, wn_b);
   }
-  s.wb = wn_b;
+  s.wb = wn_b; s.ww = ww;
   s.vel = v3(clamp_sym(s.vel.x + vdot.x * dt, T.maxv), clamp_sym(s.vel.y + vdot.y * dt, T.maxv), clamp_sym(s.vel.z + vdot.z * dt, T.maxv));
   s.pos = s.pos + dt * s.vel;
   // exponential map of w' dt in the body frame: h^2 = (dt / 2)^2 w'.w', clamped at (pi / 8)^2 (the rotation per step at pi / 4)
