@@ -425,6 +425,10 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
   const NoiseTab* const ntab = TAB ? &ntab_[0] : nullptr;
   if (TAB) noise_tab_init(ntab_[0], threadIdx.x);
   load_rigid<NT>(sb, sfs, sl, s);
+  // (Measured and rejected, round 5: the loads only the control law needs — 7 controller-memory floats, 10 targets — issued BEHIND
+  // the sub-step loop of the looped instances instead of in front of it: 80 -> 74 VGPRs, still 6 waves per SIMD, 166.9 against
+  // 164.6 us for five sub-steps; forced to 7 waves (72 VGPRs, 16 B of scratch) 171.5 us; issued at the top of the last sub-step
+  // the compiler peels that iteration: 96 VGPRs and scratch.)
   load_mem<4, NT, CH>(sb, sfs, sl, m);
   if (TAB) __syncthreads();
   if (CH) { m.last_vel = s.vel; m.last_rates = mulT(matrix_from_quat(s.q), s.w); }
@@ -1324,7 +1328,10 @@ __global__ __launch_bounds__(256, OBS ? 4 : DSIM_STEP_WAVES) void k_dyn(StepK a)
   if (OBS) { const float cmd_new[4] = {c_new.c0, c_new.c1, c_new.c2, c_new.c3}; obs_rows20_out<NT>(rows, a, i0, s_new, cmd_new); }
 }
 
-template <bool NOISE, bool NT, bool OBS>
+// LOOP: the launch has SEVERAL sub-steps on the default noise lattice (the examples' five, examples/fly_INDI.py:139-141): the
+// instance that carries the body-frame form of the step and the Box-Muller tables (quad_substeps: LOOPED), as k_step_fast's
+// looped instances do — Env.step of 4 194 304 quads x 5 sub-steps was bound by vector issue on the single-sub-step body.
+template <bool NOISE, bool NT, bool OBS, bool LOOP = false>
 __global__ __launch_bounds__(256, DSIM_PHYS_WAVES) void k_physics_fast(StepK a) {
   constexpr int W = 20;
   // Observation rows: each wave owns 64 consecutive rows = 5 120 contiguous bytes of the row-major [n][20] output.  Lane r
@@ -1333,6 +1340,10 @@ __global__ __launch_bounds__(256, DSIM_PHYS_WAVES) void k_physics_fast(StepK a) 
   // workgroup barrier — the block is the wave's own — and no index arithmetic per element (round 2: a __syncthreads,
   // twenty dword stores per lane and a division by W each; SQ_WAIT_ANY 0.36).
   __shared__ __attribute__((aligned(16))) vf4 rows[OBS ? 4 * 64 * (W / 4) : 1];
+  constexpr bool TAB = NOISE && LOOP;
+  __shared__ NoiseTab ntab_[TAB ? 1 : 0 + 1];
+  const NoiseTab* const ntab = TAB ? &ntab_[0] : nullptr;
+  if (TAB) noise_tab_init(ntab_[0], threadIdx.x);
   const DevType& T = a.types[0];
   const long long sfs = a.st.field_stride;
   const unsigned sl = 4u * kv_lane(a.st, threadIdx.x);
@@ -1341,6 +1352,7 @@ __global__ __launch_bounds__(256, DSIM_PHYS_WAVES) void k_physics_fast(StepK a) 
   const long long i = i0 + threadIdx.x;
   Rigid s;
   load_rigid<NT>(sb, sfs, sl, s);
+  if (TAB) __syncthreads();
   float cmd[4];
   if (a.action_rows) {                // (wave-uniform) the action row-major [n][4] (DSIM_OPT_ACTION_ROWS): one 16-byte load per lane
     vf4 r = vf4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -1357,7 +1369,8 @@ __global__ __launch_bounds__(256, DSIM_PHYS_WAVES) void k_physics_fast(StepK a) 
 #pragma unroll
   for (int j = 0; j < 4; ++j) cmd[j] = clampf(cmd[j], T.pmin[j], T.pmax[j]);           // CtrlAviary.py:258-263
   if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
-  quad_substeps<NOISE ? 1 : 0, 4, false, 0, false, 1>(T, a, i, s, cmd, a.step_index);      // (both noise lattices)
+  if constexpr (LOOP) quad_substeps<NOISE ? 1 : 0, 4, false, 0, false, 0, true>(T, a, i, s, cmd, a.step_index, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
+  else quad_substeps<NOISE ? 1 : 0, 4, false, 0, false, 1>(T, a, i, s, cmd, a.step_index);      // (both noise lattices)
   ground_watch(T, s, a.fb.counters, i < a.n);
   const unsigned so = pin_lane_offset(sl);
   store_rigid<NT>(sb, sfs, so, s);
@@ -3596,8 +3609,12 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
     a.obs_out = obs_fused ? args->obs_out : nullptr;
     const bool nt = stream_policy(args, state.n_pad, args->obs_out ? 216.0 : 136.0);
     const dim3 g((unsigned)(a.n_pad / 256)), b(256);
-#define DSIM_PHYS_CASE(N_, T_) do { if (a.obs_out) hipLaunchKernelGGL((k_physics_fast<N_, T_, true>), g, b, 0, st_, a);   \
-                                    else hipLaunchKernelGGL((k_physics_fast<N_, T_, false>), g, b, 0, st_, a); } while (0)
+    const bool loop = a.substeps > 1 && !(noise && (args->options & DSIM_OPT_NOISE_FINE));      // (the looped instance: default lattice only)
+#define DSIM_PHYS_CASE(N_, T_) do {                                                                                     \
+      if (loop) { if (a.obs_out) hipLaunchKernelGGL((k_physics_fast<N_, T_, true, true>), g, b, 0, st_, a);             \
+                  else hipLaunchKernelGGL((k_physics_fast<N_, T_, false, true>), g, b, 0, st_, a); }                    \
+      else { if (a.obs_out) hipLaunchKernelGGL((k_physics_fast<N_, T_, true>), g, b, 0, st_, a);                        \
+             else hipLaunchKernelGGL((k_physics_fast<N_, T_, false>), g, b, 0, st_, a); } } while (0)
     if (noise) { if (nt) DSIM_PHYS_CASE(true, true); else DSIM_PHYS_CASE(true, false); }
     else { if (nt) DSIM_PHYS_CASE(false, true); else DSIM_PHYS_CASE(false, false); }
 #undef DSIM_PHYS_CASE

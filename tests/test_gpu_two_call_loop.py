@@ -691,3 +691,72 @@ def test_env_step_takes_the_action_rows_as_the_caller_holds_them(gpu):
         np.testing.assert_array_equal(o0[:, 16:20].cpu().numpy(), np.clip(act, 0.0, 1.0))
     for e in envs:
         e.close()
+
+
+@pytest.mark.gpu
+def test_env_step_of_a_quad_fleet_over_several_substeps_every_looped_instance(gpu):
+    """Env.step of a homogeneous quad fleet in whole tiles with the examples' five sub-steps (examples/fly_INDI.py:139-141,
+    BaseAviary.py:510-545) runs on the LOOPED instances of k_physics_fast (body-frame sub-step loop, Box-Muller tables):
+    noise on / off x streaming policy x rows fused or not, against the oracle at the step bar; the fine lattice and a single
+    sub-step keep to the plain instances (checked through the same bar); a zero-sub-step pass changes nothing."""
+    nat, fleet = gpu
+    from tests.test_gpu_parity import _noise_block
+    from tests.util import noise_terms
+    t = params.builtin_type("robobee")
+    ctx = fleet.Context([t])
+    O = orc.Oracle([t])
+    n, rng = 512, np.random.default_rng(77)
+    for sub in (5, 2, 1):
+        for seed in (0, 5):
+            for pol in (nat.OPT_STREAM_ON, nat.OPT_STREAM_OFF):
+                for with_obs in (True, False):
+                    for fine in ((False, True) if (seed and sub == 5) else (False,)):
+                        rigid, mem, _ = random_fleet(rng, n, n_act=4, tilt=0.3, rate=1.0)
+                        rigid, mem = f32(rigid), f32(mem)
+                        st = fleet.FleetState(ctx, n, "tile64")
+                        st.load_aos(rigid, mem)
+                        act = f32(rng.uniform(-0.1, 1.1, (n, 4)))
+                        adev = torch.zeros((4, st.n_pad), device=ctx.device)
+                        adev[:, :n] = torch.from_numpy(np.ascontiguousarray(act.T)).float()
+                        echo = torch.zeros((4, st.n_pad), device=ctx.device)
+                        obs = torch.full((n, 20), -7.0, device=ctx.device)
+                        a = _args(nat, sub, DT, DT * sub, options=pol | (nat.OPT_NOISE_FINE if fine else 0), seed=seed, step_index=3,
+                                  action=adev)
+                        if with_obs:
+                            a.obs_out, a.obs_width = obs.data_ptr(), 20
+                        nat.check(ctx.lib.dsim_physics(ctx.handle, _stream(ctx), n, st.view(), echo.data_ptr(), ctypes.byref(a)))
+                        torch.cuda.synchronize()
+                        got_r = st.rigid_aos()
+                        label = f"env_step_looped[{sub},{seed},{pol},{with_obs},{fine}]"
+                        a6 = np.zeros((n, 6)); a6[:, :4] = np.clip(act, 0, 1)
+                        nz = None
+                        if seed:
+                            if fine:
+                                nz = np.zeros((n, sub, 12))
+                                for i in range(n):
+                                    for s_ in range(sub):
+                                        u = O.noise_normals(seed, i, 3 * sub + s_, 4, fine=True)
+                                        nz[i, s_, 0:4], nz[i, s_, 6:10] = u[0:4] * 0.01, u[4:8] * 0.001
+                            else:
+                                nz = _noise_block(O, [t], None, n, seed, 3, sub)
+                        r_ref = rigid.copy()
+                        O.physics(r_ref, mem.copy(), sub, DT, action=a6, noise=nz)
+                        tgt = np.concatenate([rigid[:, 0:3], np.zeros((n, 7))], 1)
+                        assert_step_parity(label, [t], None, rigid, mem, tgt, got_r, None, r_ref, None, DT, DT * sub, sub,
+                                           control=False, action=a6[:, :4], extra_terms=noise_terms([t], None, n, DT, sub) if seed else None)
+                        np.testing.assert_array_equal(echo[:, :n].T.cpu().numpy(), a6[:, :4].astype(np.float32))
+                        np.testing.assert_array_equal(st.mem_aos(), mem)                  # controller memory untouched
+                        if with_obs:
+                            _check_obs_rows(label + " rows", O, obs.double().cpu().numpy(), f32(got_r), a6, None, [t])
+                        else:
+                            assert float(obs.min()) == -7.0 and float(obs.max()) == -7.0
+    # the neutral pass of the placement trials: zero sub-steps write the state back bit for bit (the plain instance)
+    rigid, mem, _ = random_fleet(rng, n, n_act=4, tilt=0.3, rate=1.0)
+    st = fleet.FleetState(ctx, n, "tile64")
+    st.load_aos(f32(rigid), f32(mem))
+    before = st.rigid_aos()
+    a = _args(nat, 0, DT, DT, seed=5)
+    nat.check(ctx.lib.dsim_physics(ctx.handle, _stream(ctx), n, st.view(), None, ctypes.byref(a)))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(st.rigid_aos(), before)
+    ctx.close()
