@@ -24,9 +24,19 @@ b)
   bash tools/profile_sq.sh r05_two_call_quad --workload two_call_loop
   ;;
 c)
-  bash tools/profile_sq.sh r05_sub5 --substeps 5 && bash tools/profile_sq.sh r05_c5 --workload config5 && \
-  bash tools/profile_sq.sh r05_hexa_sub5 --workload hexa --substeps 5 && bash tools/profile_sq.sh r05_dyn --workload dyn && \
+  export DSIM_PROFILE_BENCH="--steps 100 --warmup 5 --settle-seconds 0.3"      # (vector-heavy: profiled settled, bench.py Fleet.timed)
+  bash tools/profile_sq.sh r05_sub5 --substeps 5 && bash tools/profile_sq.sh r05_hexa_sub5 --workload hexa --substeps 5 && \
   bash tools/profile_sq.sh r05_dyn_sub5 --workload dyn --substeps 5
+  unset DSIM_PROFILE_BENCH
+  bash tools/profile_sq.sh r05_c5 --workload config5 && bash tools/profile_sq.sh r05_dyn --workload dyn
+  ;;
+f)
+  # launch duration against time under load (tools/clock_probe.py): what the device's power management does to each workload
+  for W in "config2x1024 1" "config2x1024 5" "hexa 1" "hexa 5" "mixed 5" "dyn 5"; do
+    set -- $W
+    timeout -k 10 120 python tools/clock_probe.py --workload $1 --substeps $2 --seconds 4 2>&1 | grep -v "t=\|amdgpu.ids" > $OUT/clock_$1_sub$2.txt
+    head -n 4 $OUT/clock_$1_sub$2.txt | cut -c1-260
+  done
   ;;
 e)
   bash tools/profile_sq.sh r05_mixed --workload mixed && bash tools/profile_sq.sh r05_hexa --workload hexa

@@ -9,7 +9,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
-B="bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-also $*"
+# DSIM_PROFILE_BENCH: the timing arguments of the profiled command (default: the driver's own; the vector-heavy workloads are
+# profiled settled, "--steps 100 --warmup 5 --settle-seconds 0.3": bench.py Fleet.timed)
+B="bench.py ${DSIM_PROFILE_BENCH:---steps 20 --warmup 5} --no-cpu-baseline --no-also $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $B > $OUT/kt.log 2>&1; echo "kt rc=$?"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VALU --output-format csv -d $OUT/sq1 -- python3 $B > $OUT/sq1.log 2>&1; echo "sq1 rc=$?"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_BUSY_CYCLES --output-format csv -d $OUT/sq2 -- python3 $B > $OUT/sq2.log 2>&1; echo "sq2 rc=$?"
