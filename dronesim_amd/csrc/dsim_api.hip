@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
     } else {
       quad_substeps<NOISE ? 1 : 0, 4, false, SUB, false, -1, SUB == 0>(T, a, i, s, m.cmd, a.step_index, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);    // stored cmd is already clipped
     }
-    ground_watch(T, s, a.fb.counters, i < a.n);
+    if (SUB == 1) ground_watch(T, s, a.fb.counters, i < a.n);     // (the single-sub-step instances: see the end of the kernel)
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   } else {
     int wp = 0;
@@ -463,6 +463,13 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
   const unsigned so = pin_lane_offset(sl);
   store_rigid<NT>(sb, sfs, so, s);
   store_mem<4, NT, CH>(sb, sfs, so, m);
+  // (the looped instances, at the very end: the counter's atomic between the physics and the law is a memory write in front of
+  // the law's type constants, which then arrive by VECTOR loads — 28 VGPRs of constants and a vmcnt(0) in the middle of the
+  // kernel, which a fleet of one wave per SIMD waits out in full: 4 096 quads x 5 sub-steps 6.37 -> 6.14 us per launch, 4 194 304
+  // 166.4 -> 163.7 us settled.  The single-sub-step instances keep the watch where it was: the headline kernel, on its memory
+  // floor with the constants in VGPRs, measured 153-157 us there and 161-162 us with the watch at the end — same box, two
+  // processes each, profiles/r05_ab_ground_watch_at_the_end.txt)
+  if (!EXT && SUB != 1) ground_watch(T, s, a.fb.counters, i < a.n);
 }
 
 __global__ void k_counter_add(unsigned long long* c, unsigned long long inc) { *c += inc; }
@@ -1032,7 +1039,8 @@ __device__ __forceinline__ void run_body(const StepK& a, long long i0, long long
   const long long i = i0 + threadIdx.x;
   if (i >= last || i < lo) return;          // (a run may begin and end inside a tile: the neighbouring run's lanes take the rest)
   // (the constant address space — dsim_device.h, as in the two-call run kernels — costs THIS body SGPR spills and a scratch
-  // reservation: k_step_runs 166.9 against 162.7 us on the interleaved fleet, same-box A/B)
+  // reservation: k_step_runs 166.9 against 162.7 us on the interleaved fleet, same-box A/B; and it buys a fleet of one wave per
+  // SIMD, which waits out every vector load of a constant in full, nothing either: config 5's chain 45.4 us both ways, round 5)
   const DevType& T = a.types[run_type];
   const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
   const unsigned sl = 4u * kv_lane(a.st, threadIdx.x), tl = 4u * kv_lane(a.tg, threadIdx.x);
