@@ -453,7 +453,10 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
     if (a.wp_table) wp = a.wp_counter[i]; else load_target<NT>(tb, tfs, tl, tg);
     for (int k = 0; k < a.n_steps; ++k) {
       if (a.wp_table) waypoint_target(a, i, wp, tg);
-      quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index + k, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
+      // (wave-uniform: several sub-steps take the body-frame loop, as the looped plain instances do — at BASELINE's literal sizes
+      // these launches are one wave per SIMD and their duration IS their instruction count; one sub-step keeps the world-frame step)
+      if (a.substeps > 1) quad_substeps<NOISE ? 1 : 0, 4, false, 0, false, -1, true>(T, a, i, s, m.cmd, a.step_index + k, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
+      else quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index + k, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
       ground_watch(T, s, a.fb.counters, i < a.n);
       indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
       wp = waypoint_next(wp, a.n_wp);
