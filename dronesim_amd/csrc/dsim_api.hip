@@ -504,6 +504,18 @@ typedef float vf4 __attribute__((ext_vector_type(4)));        // (a native vecto
 #ifndef DSIM_HEXA_WAVES
 #define DSIM_HEXA_WAVES 3
 #endif
+#ifndef DSIM_LATE_STORE_BASE
+#define DSIM_LATE_STORE_BASE 1
+#endif
+// p, as a wave-uniform value the compiler knows nothing about, available only behind `after`: the offset 0 goes through an empty
+// asm that also takes `after` in, and comes back through v_readfirstlane (which is what tells the compiler that it is uniform:
+// an asm's own output counts as divergent, and the loads behind it as per-lane loads)
+template <class P>
+__device__ __forceinline__ const P* opaque_after(const P* p, float after) {
+  int z = 0;
+  asm("" : "+v"(z) : "v"(after));
+  return reinterpret_cast<const P*>(reinterpret_cast<const char*>(p) + __builtin_amdgcn_readfirstlane(z));
+}
 template <bool NOISE, bool NT, bool S1, bool ACT = false>
 __global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
   const DevType& T = a.types[0];
@@ -536,9 +548,14 @@ __global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
     hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, m.cmd, a.step_index, V3{-0.0f, -0.0f, -0.0f}, -1, ntab);
   }
   indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
+  // The looped instances store through a base the compiler cannot see through, made behind the sub-steps (opaque_after): left to
+  // itself it keeps the 23 field addresses it formed for the loads (SGPR pairs) alive across the sub-step loop, runs out of SGPRs
+  // inside it and parks 46 of them in VGPR lanes — 92 v_writelane / v_readlane of the ~2 100 vector instructions a looped launch
+  // executes; formed again behind the loop they are 46 scalar adds.
+  float* const sb2 = (DSIM_LATE_STORE_BASE && !S1) ? const_cast<float*>(opaque_after(sb, s.pos.x)) : sb;
   const unsigned so = pin_lane_offset(sl);
-  store_rigid<NT>(sb, sfs, so, s);
-  store_mem<6, NT>(sb, sfs, so, m);
+  store_rigid<NT>(sb2, sfs, so, s);
+  store_mem<6, NT>(sb2, sfs, so, m);
   ground_watch(T, s, a.fb.counters, i < a.n);       // (at the very end: between the physics and the law it cost 44 VGPRs)
 }
 
@@ -1075,8 +1092,9 @@ __device__ __forceinline__ void run_body(const StepK& a, long long i0, long long
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   const unsigned so = pin_lane_offset(sl);
-  store_rigid<NT>(sb, sfs, so, s);
-  store_mem<NA, NT>(sb, sfs, so, m);
+  float* const sb2 = (DSIM_LATE_STORE_BASE && !S1) ? const_cast<float*>(opaque_after(sb, s.pos.x)) : sb;   // (k_step_hexa: the field addresses formed again behind the loop)
+  store_rigid<NT>(sb2, sfs, so, s);
+  store_mem<NA, NT>(sb2, sfs, so, m);
   ground_watch(T, s, a.fb.counters, i < a.n);
   // (measured and dropped: reserving the slot of the next grid right behind the physics, so that the atomic's round trip
   // rides under the control law — 45.4 against 45.7 us for the config-5 chain, and 36 bytes of scratch in two instances)
@@ -1530,7 +1548,8 @@ __device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro
     else quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0, false, -1, !S1>(T, a, i, s, cmd, step_index, ext, nullptr, nid, tab);
     ground_watch(T, s, a.fb.counters, i < a.n);
     const unsigned so = pin_lane_offset(sl);
-    store_rigid<NT>(sb, sfs, so, s);
+    float* const sb2 = (DSIM_LATE_STORE_BASE && !S1) ? const_cast<float*>(opaque_after(sb, s.pos.x)) : sb;   // (k_step_hexa)
+    store_rigid<NT>(sb2, sfs, so, s);
     if (a.echo) {                                                                       // BaseAviary.py:545
 #pragma unroll
       for (int j = 0; j < NA; ++j) stg<NT>(a.echo + (long long)j * a.n_pad + i0, 4u * t, cmd[j]);
