@@ -507,6 +507,9 @@ typedef float vf4 __attribute__((ext_vector_type(4)));        // (a native vecto
 #ifndef DSIM_LATE_STORE_BASE
 #define DSIM_LATE_STORE_BASE 1
 #endif
+#ifndef DSIM_LATE_STORE_BASE_S1
+#define DSIM_LATE_STORE_BASE_S1 0
+#endif
 // p, as a wave-uniform value the compiler knows nothing about, available only behind `after`: the offset 0 goes through an empty
 // asm that also takes `after` in, and comes back through v_readfirstlane (which is what tells the compiler that it is uniform:
 // an asm's own output counts as divergent, and the loads behind it as per-lane loads)
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
   // itself it keeps the 23 field addresses it formed for the loads (SGPR pairs) alive across the sub-step loop, runs out of SGPRs
   // inside it and parks 46 of them in VGPR lanes — 92 v_writelane / v_readlane of the ~2 100 vector instructions a looped launch
   // executes; formed again behind the loop they are 46 scalar adds.
-  float* const sb2 = (DSIM_LATE_STORE_BASE && !S1) ? const_cast<float*>(opaque_after(sb, s.pos.x)) : sb;
+  float* const sb2 = (DSIM_LATE_STORE_BASE && (!S1 || DSIM_LATE_STORE_BASE_S1)) ? const_cast<float*>(opaque_after(sb, s.pos.x)) : sb;
   const unsigned so = pin_lane_offset(sl);
   store_rigid<NT>(sb2, sfs, so, s);
   store_mem<6, NT>(sb2, sfs, so, m);
