@@ -2224,6 +2224,32 @@ def test_bench_launches_its_own_ranks(gpu):
     assert d["scaling"] == "weak" and "also" not in d
 
 
+def test_bench_settled_form_times_launches_right_behind_the_settling_load(gpu):
+    """`bench.py --settle-seconds S` (Fleet._timed_settled): the device is kept under the workload for S seconds, the timed
+    launches follow without a gap, device time from events in the stream; the line says so, counts whole regions of --steps
+    launches and agrees with the plain form to within what the device's clocks do to a short run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = {}
+    for settle in ("0", "0.05"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "config4", "--substeps", "5", "--steps", "10",
+                            "--warmup", "2", "--settle-seconds", settle, "--no-also", "--no-cpu-baseline"],
+                           capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        out[settle] = json.loads(lines[0])
+    a, b = out["0"], out["0.05"]
+    assert a["settle_seconds"] == 0.0 and b["settle_seconds"] == 0.05
+    for d in (a, b):
+        assert d["steps"] == 10 and d["steps_timed"] == 10 * d["timed_regions"] and d["steps_timed"] * d["ms_per_step"] >= 45.0
+        assert d["value"] > 1e8 and d["config"]["phys_substeps"] == 5 and d["config"]["drones_per_gpu"] == 65536
+    assert 0.5 < a["roofline"]["launch_us"] / b["roofline"]["launch_us"] < 2.0
+
+
 def test_ground_plane_watch_counts_what_pybullet_would_have_caught(gpu):
     """Plane contact is not modelled; the library counts instead every drone-step that ends with the
     vehicle's collision cylinder (robobee.urdf:72-77: radius 0.15 m, 0.1 m long) at or below z = 0: exact against the
