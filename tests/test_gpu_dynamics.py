@@ -150,7 +150,8 @@ def test_dyn_kernel_vs_reference_single_calls(gpu, golden_dir, tag):
         pwm = f32(g("pwm")[keep])
         act = _soa(np.concatenate([pwm, np.zeros((n, 2))], 1)[:, :4], st.n_pad, ctx.device)
         echo = torch.zeros((4, st.n_pad), device=ctx.device)
-        a = _args(nat, rates, 1, 0, action=act)
+        # (the streaming instances, k_dyn<.., NT = true, ..>, are what a large fleet runs: forced here on the tags of one mixer)
+        a = _args(nat, rates, 1, nat.OPT_STREAM_ON if tag.endswith("_x") else nat.OPT_STREAM_OFF, action=act)
         nat.check(ctx.lib.dsim_physics(ctx.handle, ctx.stream_ptr(), n, st.view(), echo.data_ptr(), ctypes.byref(a)))
         torch.cuda.synchronize()
         got_r, got_w = st.rigid_aos(), rates[:, :n].T.double().cpu().numpy()
@@ -198,7 +199,7 @@ def test_dyn_flights_vs_reference_step_loop(gpu, golden_dir, tag):
         prev_r, prev_w = st.rigid_aos(), rates[:, :n].T.double().cpu().numpy()
         p32 = f32(pwm[k])
         act = _soa(p32, st.n_pad, ctx.device)
-        a = _args(nat, rates, aggr, 0, action=act)
+        a = _args(nat, rates, aggr, nat.OPT_STREAM_ON if k % 2 else nat.OPT_STREAM_OFF, action=act)      # (both cache policies: the same results)
         a.obs_out, a.obs_width = obs.data_ptr(), 20
         nat.check(ctx.lib.dsim_physics(ctx.handle, ctx.stream_ptr(), n, st.view(), echo.data_ptr(), ctypes.byref(a)))
         torch.cuda.synchronize()
@@ -253,7 +254,7 @@ def test_dyn_fused_step_mixed_quad_types_vs_oracle(gpu, sub, layout, n, body):
         prev_r, prev_m, prev_w = st.rigid_aos(), st.mem_aos(), rates[:, :n].T.double().cpu().numpy()
         act = f32(rng.uniform(-0.1, 1.1, (n, 4))) if k == 0 else None
         act_dev = _soa(act, st.n_pad, ctx.device) if act is not None else None
-        a = _args(nat, rates, sub, opt, dt_ctrl=dt_ctrl, action=act_dev, type_id=tid_dev)
+        a = _args(nat, rates, sub, opt | (nat.OPT_STREAM_ON if k % 2 else nat.OPT_STREAM_OFF), dt_ctrl=dt_ctrl, action=act_dev, type_id=tid_dev)
         nat.check(ctx.lib.dsim_step(ctx.handle, ctx.stream_ptr(), n, st.view(), tg.view(), ctypes.byref(a)))
         torch.cuda.synchronize()
         got = (st.rigid_aos(), rates[:, :n].T.double().cpu().numpy(), st.mem_aos())

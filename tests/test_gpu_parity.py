@@ -2245,7 +2245,7 @@ def test_bench_settled_form_times_launches_right_behind_the_settling_load(gpu):
     a, b = out["0"], out["0.05"]
     assert a["settle_seconds"] == 0.0 and b["settle_seconds"] == 0.05
     for d in (a, b):
-        assert d["steps"] == 10 and d["steps_timed"] == 10 * d["timed_regions"] and d["steps_timed"] * d["ms_per_step"] >= 45.0
+        assert d["steps"] == 10 and d["steps_timed"] == 10 * d["timed_regions"] and d["steps_timed"] * d["ms_per_step"] >= 15.0     # (the count of regions comes from the first one's duration)
         assert d["value"] > 1e8 and d["config"]["phys_substeps"] == 5 and d["config"]["drones_per_gpu"] == 65536
     assert 0.5 < a["roofline"]["launch_us"] / b["roofline"]["launch_us"] < 2.0
 
