@@ -803,15 +803,20 @@ __device__ __forceinline__ void hexa_wrench(DT& T, const float cmd[6], const flo
 struct HexaBase { V3 F, tau; };
 template <class DT>
 __device__ __forceinline__ HexaBase hexa_wrench_base(DT& T, const float cmd[6]) {
-  double F[3] = {0.0, 0.0, 0.0}, tau[3] = {0.0, 0.0, 0.0};      // (fp64 sums: see quad_wrench_base)
+#ifdef DSIM_HEXA_BASE_FP32          // (A/B knob: what the fp64 sums cost)
+  typedef float acc_t;
+#else
+  typedef double acc_t;
+#endif
+  acc_t F[3] = {0.0, 0.0, 0.0}, tau[3] = {0.0, 0.0, 0.0};      // (fp64 sums: see quad_wrench_base)
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     const float rpm = T.scale[j] * cmd[j] + T.cnst[j];
     const float f = rpm * rpm * T.kf, tq = rpm * rpm * T.km * T.spin[j];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      F[k] += (double)f * (double)T.raxis[j][k];
-      tau[k] += (double)f * (double)T.rxa[j][k] + (double)tq * (double)T.raxis[j][k];
+      F[k] += (acc_t)f * (acc_t)T.raxis[j][k];
+      tau[k] += (acc_t)f * (acc_t)T.rxa[j][k] + (acc_t)tq * (acc_t)T.raxis[j][k];
     }
   }
   return HexaBase{V3{(float)F[0], (float)F[1], (float)F[2]}, V3{(float)tau[0], (float)tau[1], (float)tau[2]}};
