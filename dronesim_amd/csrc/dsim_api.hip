@@ -2942,6 +2942,7 @@ static void to_dev(const dsim_type_params& p, DevType* d) {
     d->rxa[j][0] = (float)(r[1] * ax[2] - r[2] * ax[1]);
     d->rxa[j][1] = (float)(r[2] * ax[0] - r[0] * ax[2]);
     d->rxa[j][2] = (float)(r[0] * ax[1] - r[1] * ax[0]);
+    for (int k = 0; k < 3; ++k) { d->raxis64[j][k] = (double)d->raxis[j][k]; d->rxa64[j][k] = (double)d->rxa[j][k]; }
     if (j < 4) for (int k = 0; k < 3; ++k) d->rsum[k] += (float)r[k];
     for (int i = 0; i < DSIM_MAX_ACT; ++i) {
       d->alloc[j][i] = (float)p.alloc[j][i];

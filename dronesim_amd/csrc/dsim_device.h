@@ -11,6 +11,9 @@
 #include "dsim_math.h"
 
 #define DSIM_MAX_ACT 6
+#ifndef DSIM_HEXA_BASE_CONST64
+#define DSIM_HEXA_BASE_CONST64 1
+#endif
 #define DSIM_DEV_KIND_QUAD 0
 #define DSIM_DEV_KIND_HEXA 1
 #define DSIM_DEV_KIND_HEXA_QUADLAW 2      // morphing-hexa physics, the quad law on six actuators (hexa_6DOF_simple.urdf)
@@ -28,6 +31,7 @@ struct DevType {
   float rpos[DSIM_MAX_ACT][3], raxis[DSIM_MAX_ACT][3], spin[DSIM_MAX_ACT];
   float rxa[DSIM_MAX_ACT][3];                 // rpos x raxis: torque about the COM per unit thrust of rotor j
   float spax[DSIM_MAX_ACT][3];                // spin_j raxis_j: reaction torque per unit rotor moment (hexa_wrench_noise)
+  double raxis64[DSIM_MAX_ACT][3], rxa64[DSIM_MAX_ACT][3];   // (double)raxis, (double)rxa — the fp32 values, widened (hexa_wrench_base)
   float rsum[3];                              // quads: sum of the four rotor positions (the lateral-noise lever, quad_wrench_noise)
   float alloc[DSIM_MAX_ACT][DSIM_MAX_ACT];    // quad: pinv(G1/0.05); hexa: M1 (u_opt = M1 v + M4 u0)
   float alloc2[DSIM_MAX_ACT][DSIM_MAX_ACT];   // hexa: M4
@@ -815,8 +819,13 @@ __device__ __forceinline__ HexaBase hexa_wrench_base(DT& T, const float cmd[6]) 
     const float f = rpm * rpm * T.kf, tq = rpm * rpm * T.km * T.spin[j];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
+#if defined(DSIM_HEXA_BASE_FP32) || !DSIM_HEXA_BASE_CONST64
       F[k] += (acc_t)f * (acc_t)T.raxis[j][k];
       tau[k] += (acc_t)f * (acc_t)T.rxa[j][k] + (acc_t)tq * (acc_t)T.raxis[j][k];
+#else
+      F[k] += (double)f * T.raxis64[j][k];                 // (the constants as doubles in the table: 36 conversions less per launch)
+      tau[k] += (double)f * T.rxa64[j][k] + (double)tq * T.raxis64[j][k];
+#endif
     }
   }
   return HexaBase{V3{(float)F[0], (float)F[1], (float)F[2]}, V3{(float)tau[0], (float)tau[1], (float)tau[2]}};
