@@ -382,7 +382,8 @@ __device__ __forceinline__ QuadBase quad_wrench_base(DT& T, const float cmd[4]) 
     const float f = rpm * rpm * T.kf, t = rpm * rpm * T.km;
     fz += (double)f;
     tx += (double)T.rpos[i][1] * (double)f;              // (r x (0, 0, f)).x =  r_y f
-    ty -= (double)T.rpos[i][0] * (double)f;              // (r x (0, 0, f)).y = -r_x f
+    ty -= (double)T.rpos[i][0] * (double)f;              // (r x (0, 0, f)).y = -r_x f   (the levers as doubles in the table, as
+                                                         // hexa_wrench_base has them: 24 vector instructions MORE here — not taken)
     tz += (i & 1) ? t : -t;                              // -t0 + t1 - t2 + t3 (:1527)
   }
   return QuadBase{(float)fz, V3{(float)tx, (float)ty, tz}};
