@@ -31,7 +31,6 @@ struct DevType {
   float rpos[DSIM_MAX_ACT][3], raxis[DSIM_MAX_ACT][3], spin[DSIM_MAX_ACT];
   float rxa[DSIM_MAX_ACT][3];                 // rpos x raxis: torque about the COM per unit thrust of rotor j
   float spax[DSIM_MAX_ACT][3];                // spin_j raxis_j: reaction torque per unit rotor moment (hexa_wrench_noise)
-  double raxis64[DSIM_MAX_ACT][3], rxa64[DSIM_MAX_ACT][3];   // (double)raxis, (double)rxa — the fp32 values, widened (hexa_wrench_base)
   float rsum[3];                              // quads: sum of the four rotor positions (the lateral-noise lever, quad_wrench_noise)
   float alloc[DSIM_MAX_ACT][DSIM_MAX_ACT];    // quad: pinv(G1/0.05); hexa: M1 (u_opt = M1 v + M4 u0)
   float alloc2[DSIM_MAX_ACT][DSIM_MAX_ACT];   // hexa: M4
@@ -47,6 +46,9 @@ struct DevType {
   float watch_below;                          // coll_below seen from the reported point (ground-plane watch)
   float dyn_lever[2][4];                      // Physics.DYN: x / y torque per unit force of rotor i (the mixer of BaseAviary.py:1794-1803 times its lever)
   float weight;                               // Physics.DYN: GRAVITY = G M (BaseAviary.py:226)
+  // (at the end: in the middle of the table they moved every offset behind them, and four instances of k_step_runs came back
+  // with a 36-byte scratch reservation)
+  double raxis64[DSIM_MAX_ACT][3], rxa64[DSIM_MAX_ACT][3];   // (double)raxis, (double)rxa — the fp32 values, widened (hexa_wrench_base)
 };
 
 // The table is written once (dsim_create) and only read by kernels, which read it through the CONSTANT address space.  A
