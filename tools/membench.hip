@@ -232,6 +232,43 @@ __global__ __launch_bounds__(256) void k_env_shape_pp(const float* st, float* st
   for (int j = 0; j < 5; ++j) __builtin_nontemporal_store(blk[wave][j * 64 + lane], g + j * 64 + lane);
 }
 
+// K6c: the Env.step shape under other cache policies / store orders — does any of them not care where the rows lie?
+//   MODE 0 all streaming (the product)   1 rows with the default policy   2 the state with the default policy (loads and stores)
+//   3 everything default   4 all streaming, the rows stored BEFORE the state   5 state loads default, every store streaming
+template <int MODE>
+__global__ __launch_bounds__(256) void k_env_shape_v(float* st, const float* act, float* echo, float* rows, long long n) {
+  __shared__ f4 blk[4][20 * 16];
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* ps = st + (i >> 6) * (FS * 64) + (i & 63);
+  constexpr bool ST_LD_NT = MODE == 0 || MODE == 1 || MODE == 4, ST_ST_NT = MODE == 0 || MODE == 1 || MODE == 4 || MODE == 5;
+  constexpr bool ROWS_NT = MODE == 0 || MODE == 2 || MODE == 4 || MODE == 5;
+  float v[17], o[13];
+#pragma unroll
+  for (int f = 0; f < 13; ++f) v[f] = ST_LD_NT ? __builtin_nontemporal_load(ps + f * 64) : ps[f * 64];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) v[13 + f] = __builtin_nontemporal_load(act + f * n + i);
+  mix(v, 17, o, 13);
+  float* L = reinterpret_cast<float*>(blk[wave]);
+#pragma unroll
+  for (int f = 0; f < 20; ++f) L[lane * 20 + f] = f < 13 ? o[f] : v[f - 7] + o[1];
+  __builtin_amdgcn_wave_barrier();
+  f4* g = reinterpret_cast<f4*>(rows + (i - lane) * 20);
+  if (MODE == 4) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) __builtin_nontemporal_store(blk[wave][j * 64 + lane], g + j * 64 + lane);
+  }
+#pragma unroll
+  for (int f = 0; f < 13; ++f) { if (ST_ST_NT) __builtin_nontemporal_store(o[f], ps + f * 64); else ps[f * 64] = o[f]; }
+#pragma unroll
+  for (int f = 0; f < 4; ++f) __builtin_nontemporal_store(v[13 + f] + o[0] * 1e-9f, echo + f * n + i);
+  if (MODE != 4) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { if (ROWS_NT) __builtin_nontemporal_store(blk[wave][j * 64 + lane], g + j * 64 + lane); else g[j * 64 + lane] = blk[wave][j * 64 + lane]; }
+  }
+}
+
 // K7: two buffers streamed side by side, one float4 per lane from / to each: MODE 0 read a + read b, 1 read a + write b,
 // 2 write a + write b, 3 read+write a + write b, 4 read+write a + read b
 template <int MODE>
@@ -458,6 +495,30 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  bool envvar = false;
+  for (int k = 1; k < argc; ++k) if (!strcmp(argv[k], "--envvar")) envvar = true;
+  if (envvar) {
+    // ONE allocation (DSIM_SWEEP_GIB, default 40): the state block at its start, the rows D bytes on; K6c's modes
+    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    const char* sg = getenv("DSIM_SWEEP_GIB");
+    const size_t total = (sg ? (size_t)atoi(sg) : 40ull) << 30, sz_st = sizeof(float) * FS * n, sz_a = sizeof(float) * 4 * n, sz_r = sizeof(float) * 20 * n;
+    char* arena; CK(hipMalloc(&arena, total)); CK(hipMemset(arena, 0, total));
+    float* st = (float*)arena; float* act = (float*)(arena + sz_st); float* echo = (float*)(arena + sz_st + sz_a);
+    const size_t GiB = 1ull << 30;
+    for (size_t D : {2 * GiB, 8 * GiB, 14 * GiB, 18 * GiB, 26 * GiB, 34 * GiB}) {
+      if (D + sz_r > total) continue;
+      float* rows = (float*)(arena + D);
+      const float t0 = time_it([&] { hipLaunchKernelGGL(k_env_shape_v<0>, g, b, 0, 0, st, act, echo, rows, n); }, 6);
+      const float t1 = time_it([&] { hipLaunchKernelGGL(k_env_shape_v<1>, g, b, 0, 0, st, act, echo, rows, n); }, 6);
+      const float t2 = time_it([&] { hipLaunchKernelGGL(k_env_shape_v<2>, g, b, 0, 0, st, act, echo, rows, n); }, 6);
+      const float t3 = time_it([&] { hipLaunchKernelGGL(k_env_shape_v<3>, g, b, 0, 0, st, act, echo, rows, n); }, 6);
+      const float t4 = time_it([&] { hipLaunchKernelGGL(k_env_shape_v<4>, g, b, 0, 0, st, act, echo, rows, n); }, 6);
+      const float t5 = time_it([&] { hipLaunchKernelGGL(k_env_shape_v<5>, g, b, 0, 0, st, act, echo, rows, n); }, 6);
+      printf("rows at %2zu GiB:  all streaming %.1f   rows default %.1f   state default %.1f   all default %.1f   rows first %.1f   state loads default %.1f us\n",
+             D >> 30, t0 * 1e3, t1 * 1e3, t2 * 1e3, t3 * 1e3, t4 * 1e3, t5 * 1e3);
+    }
+    return 0;
+  }
   bool envpp = false;
   for (int k = 1; k < argc; ++k) if (!strcmp(argv[k], "--envpp")) envpp = true;
   if (envpp) {
@@ -469,8 +530,8 @@ int main(int argc, char** argv) {
     char* arena; CK(hipMalloc(&arena, total)); CK(hipMemset(arena, 0, total));
     float* st = (float*)arena; float* act = (float*)(arena + sz_st); float* echo = (float*)(arena + sz_st + sz_a);
     const size_t GiB = 1ull << 30;
-    for (size_t E : {2 * GiB, 20 * GiB}) {
-      for (size_t D : {4 * GiB, 12 * GiB, 18 * GiB, 24 * GiB, 34 * GiB}) {
+    for (size_t E : {2 * GiB, 20 * GiB, 36 * GiB}) {
+      for (size_t D : {4 * GiB, 12 * GiB, 18 * GiB, 24 * GiB, 34 * GiB, 38 * GiB}) {
         if (D + sz_r > total || E + sz_st > total) continue;
         float* rows = (float*)(arena + D);
         float* st2 = (float*)(arena + E);
