@@ -2,46 +2,18 @@
 
 The vector-heavy kernels (five sub-steps per Env.step) start at one duration, pass through a throttled episode a few
 milliseconds into a busy stretch and settle at a third (profiles/r05_clock_*.txt): the device's power management, not the
-kernel.  This probe launches one workload back to back for `seconds`, times batches of 10 launches with events on the launch
-stream and samples the device's clocks / power from sysfs beside it (when the box lets an ordinary user read them).
+kernel.  This probe launches one workload back to back for `seconds` and times batches of 10 launches with events on the launch
+stream.  (The device's own clock / power readings are not used: on the pool's boxes the cards an ordinary user can read under
+/sys are not the leased device.)
 
 usage: python tools/clock_probe.py [--workload config2x1024|hexa|mixed|dyn] [--substeps 5] [--seconds 3] [--idle-ms 0]
 """
 import argparse
-import glob
 import os
 import sys
-import threading
 import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-
-
-def sysfs_sources():
-    out = {}
-    for card in sorted(glob.glob("/sys/class/drm/card*/device")):
-        for name in ("pp_dpm_sclk", "pp_dpm_mclk", "gpu_busy_percent"):
-            p = os.path.join(card, name)
-            if os.path.exists(p):
-                out.setdefault(name, p)
-        for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
-            for name in ("power1_average", "power1_input", "freq1_input", "temp1_input", "temp2_input"):
-                p = os.path.join(hw, name)
-                if os.path.exists(p):
-                    out.setdefault(name, p)
-    return out
-
-
-def read(p):
-    try:
-        with open(p) as f:
-            s = f.read().strip()
-        if "\n" in s:                       # pp_dpm_*: the active level carries a star
-            act = [l for l in s.splitlines() if l.endswith("*")]
-            return act[0] if act else s.splitlines()[-1]
-        return s
-    except OSError as e:
-        return "n/a(%s)" % e.errno
 
 
 def main():
@@ -62,16 +34,6 @@ def main():
     kw = dict(hexa=a.workload == "hexa", mixed=a.workload == "mixed", dyn=a.workload == "dyn")
     fl = bench.Fleet(4096, 1024, 0, a.substeps, "tile64", 1, **kw)
     torch.cuda.synchronize()
-    src = sysfs_sources()
-    samples, stop = [], threading.Event()
-
-    def sampler():
-        while not stop.is_set():
-            samples.append((time.perf_counter(), {k: read(p) for k, p in src.items()}))
-            stop.wait(0.1)
-
-    th = threading.Thread(target=sampler, daemon=True)
-    th.start()
     time.sleep(0.5)                         # the device idle for half a second in front of the run
     series = []
     t_begin = time.perf_counter()
@@ -94,7 +56,6 @@ def main():
         ev = []
         if a.idle_ms > 0 and n_batches % 200 == 0:
             time.sleep(a.idle_ms * 1e-3)
-    stop.set(); th.join()
     print("workload %s substeps %d: %d batches of %d launches in %.2f s" % (a.workload, a.substeps, len(series), a.batch, time.perf_counter() - t_begin))
     print("first 40 batches (us per launch): " + " ".join("%.0f" % s for s in series[:40]))
     step = max(1, len(series) // 60)
@@ -103,9 +64,6 @@ def main():
     s = np.array(series)
     q = len(s) // 4
     print("mean of quarters: " + " ".join("%.1f" % s[i * q:(i + 1) * q].mean() for i in range(4)) + "   min %.1f  median %.1f  max %.1f" % (s.min(), np.median(s), s.max()))
-    print("sysfs sources: %s" % sorted(src))
-    for t, d in samples[::max(1, len(samples) // 25)]:
-        print("  t=%6.2f s  " % (t - t_begin) + "  ".join("%s=%s" % (k, v) for k, v in sorted(d.items())))
     fl.env.close()
 
 
