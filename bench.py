@@ -127,6 +127,7 @@ class Fleet:
         self.n_steps = n_steps
         self.graph = None
         self.loop = None
+        self.ctrl = None
         xyz = grid_fleet(n_fleet, replicas)
         self.n = xyz.shape[0]
         models, physics, type_ids = ["robobee"], Physics.PYB, None
@@ -189,8 +190,15 @@ class Fleet:
         from dronesim_amd.control import INDIControl
         from dronesim_amd.fleet import frozen
         torch = self.torch
-        ctrl = INDIControl(self.env.types[-1].name, env=self.env)     # one controller object for the whole fleet, whatever its types
         tpos = frozen(self.tgt.fields(0, 3).contiguous())      # the same hover target every iteration: copied once
+        if getattr(self.tgt, "behind_the_state", False):
+            # this loop reads the CONTROLLER's targets beside the state, not the fused step's: the room behind the state block
+            # (fleet.FleetState) goes back to the context for them, as in a program that never made a fused-step Targets
+            room = self.tgt.data.view(-1)
+            room.zero_()
+            self.env.ctx.read_room = (room, self.tgt.n_pad, self.tgt.layout)
+            self.tgt = None
+        ctrl = self.ctrl = INDIControl(self.env.types[-1].name, env=self.env)     # one controller object for the whole fleet, whatever its types
         state = {"cmd": torch.full((self.n, self.env.n_act), 0.4, device=self.env.ctx.device)}
         yaw = np.array([0, 0, 0.4])
 
@@ -902,7 +910,10 @@ def main(argv=None):
                            f"until they cover {MIN_TIMED_S * 1e3:.0f} ms; value and ms_per_step are sums over all of them",
             "config": {"workload": WORKLOAD_TEXT[a.workload],
                        "drones_per_gpu": fl.n, "phys_substeps": a.substeps, "layout": a.layout,
-                       "noise_seed": a.noise_seed, "launches_per_step": 1, "parallelism": f"shard{world}"},
+                       "noise_seed": a.noise_seed, "launches_per_step": 1, "parallelism": f"shard{world}",
+                       # (fleet.FleetState: a large fleet's state block is allocated with room for one block of targets behind it)
+                       "targets_behind_the_state_block": bool(getattr(getattr(fl, "tgt", None), "behind_the_state", False)
+                                                              or getattr(getattr(getattr(fl, "ctrl", None), "_targets", None), "behind_the_state", False))},
             "dist": dist_info,
             "ranks": {"launch_us_min": min(r[0] for r in rank_rows), "launch_us_max": max(r[0] for r in rank_rows),
                       "host_us_per_step_min": min(r[1] for r in rank_rows), "host_us_per_step_max": max(r[1] for r in rank_rows),

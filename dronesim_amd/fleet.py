@@ -6,7 +6,8 @@ arithmetic happens in the HIP kernels behind the C-ABI.
 from __future__ import annotations
 
 import ctypes
-from typing import Sequence
+import os
+from typing import Optional, Sequence
 
 import numpy as np
 import torch
@@ -20,6 +21,9 @@ F_LAST_VEL, F_LAST_RATES, F_LAST_THRUST, F_CMD = 13, 16, 19, 20
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+READ_ROOM_MIN_DRONES = 1 << 20          # fleets from this size on keep room for one block of targets behind their state block (FleetState)
 
 
 def pad_to(n: int, m: int = 256) -> int:
@@ -52,6 +56,7 @@ class Context:
         self.placement_walk_bytes = None       # the transient budget of a search; None = placement.WALK_BYTES (4 GiB)
         self.placement_log = []
         self.query_offsets = {}                # counts that trial passes (placement.py) added to the device counters: subtracted by query()
+        self.read_room = None                  # (flat tensor, n_pad, layout): room for one block of targets behind a large fleet's state block (FleetState)
 
     @property
     def handle(self):
@@ -175,21 +180,34 @@ class BlockedSoA:
                                                    contiguous 4B-byte row; n_pad is rounded up to a multiple of B)
     """
 
-    def __init__(self, n: int, n_fields: int, device, layout: str = "soa", pad: int = 256, order=None):
+    def __init__(self, n: int, n_fields: int, device, layout: str = "soa", pad: int = 256, order=None, tail_fields: int = 0,
+                 storage: Optional[torch.Tensor] = None):
+        """tail_fields: that many more fields' worth of floats are allocated behind the block, in the SAME allocation
+        (`self.tail`, flat).  storage: a flat zeroed float32 tensor of exactly the block's size to live in instead of a fresh
+        allocation (a tail of another block)."""
         self.n, self.n_fields, self.layout = n, n_fields, layout
         self.version = 0            # bumped by every host-side write (set_fields): caches keyed on the contents check it
         self.order = order if (order is not None and order.n == n) else None    # StorageOrder: caller numbering <-> slots
         self.pre_access = None      # optional callable run before the block is read or written from the host side
+        self.tail = None
         if layout == "soa":
             self.block = 0
             self.n_pad = pad_to(n, pad)
-            self.data = torch.zeros((n_fields, self.n_pad), dtype=torch.float32, device=device)
+            shape = (n_fields, self.n_pad)
         elif layout.startswith("tile") and layout[4:].isdigit() and int(layout[4:]) in (64, 256, 1024, 4096):
             self.block = B = int(layout[4:])
             self.n_pad = pad_to(n, max(pad, B))
-            self.data = torch.zeros((self.n_pad // B, n_fields, B), dtype=torch.float32, device=device)
+            shape = (self.n_pad // B, n_fields, B)
         else:
             raise ValueError(layout)
+        numel = n_fields * self.n_pad
+        if storage is not None and storage.numel() == numel and storage.is_contiguous() and storage.device == torch.device(device):
+            self.data = storage.view(shape)
+        elif tail_fields > 0:
+            flat = torch.zeros(numel + tail_fields * self.n_pad, dtype=torch.float32, device=device)
+            self.data, self.tail = flat[:numel].view(shape), flat[numel:]
+        else:
+            self.data = torch.zeros(shape, dtype=torch.float32, device=device)
 
     def view(self) -> nat.View:
         v = nat.View()
@@ -239,8 +257,16 @@ class FleetState(BlockedSoA):
     controller memory of one INDIControl instance per drone (INDIControl.py:109-146)."""
 
     def __init__(self, ctx: Context, n: int, layout: str = "soa", pad: int = 256):
-        super().__init__(n, ctx.n_fields, ctx.device, layout, pad, order=ctx.order)
+        # A large fleet's state block is allocated with room for ONE block of targets right behind it, in the same allocation:
+        # an array a launch READS beside the state wants the state's own memory window (DESIGN.md 2: the fused step runs
+        # 153-154 us with its targets there and 158 or 164 us with them in whatever block the allocator hands out — three
+        # levels, by process), and the same allocation is the same window.  No search, no timing: the first per-drone Targets
+        # of this layout and size made on the context lives there (40 B per drone, held with the state).
+        big = pad_to(n, max(pad, 64)) >= READ_ROOM_MIN_DRONES and os.environ.get("DSIM_NO_READ_ROOM", "0") == "0"
+        super().__init__(n, ctx.n_fields, ctx.device, layout, pad, order=ctx.order, tail_fields=nat.NT if big else 0)
         self.ctx = ctx
+        if self.tail is not None:
+            ctx.read_room = (self.tail, self.n_pad, layout)
 
     pos = property(lambda s: s.fields(F_POS, 3))
     quat = property(lambda s: s.fields(F_QUAT, 4))
@@ -276,7 +302,11 @@ class Targets(BlockedSoA):
             self.data = torch.zeros((nat.NT, 1), dtype=torch.float32, device=ctx.device)
             self.order, self.pre_access, self.version = None, None, 0
         else:
-            super().__init__(n, nat.NT, ctx.device, layout, pad, order=ctx.order)
+            room, storage = getattr(ctx, "read_room", None), None
+            if room is not None and room[2] == layout and room[1] == pad_to(n, max(pad, int(layout[4:]) if layout != "soa" else pad)):
+                storage, ctx.read_room = room[0], None      # the room behind the state block (FleetState): taken once
+            super().__init__(n, nat.NT, ctx.device, layout, pad, order=ctx.order, storage=storage)
+            self.behind_the_state = storage is not None and self.data.data_ptr() == storage.data_ptr()
             self._placed = False      # CtrlAviary.step_fused may re-allocate `data` once, by trial (placement.py)
 
     def view(self) -> nat.View:
