@@ -297,7 +297,8 @@ __device__ __forceinline__ void quad_substeps(DT& T, const StepK& a, long long i
   constexpr bool BODY_OK = LOOPED && !OPTS && !PLANE && NSUB != 1;
   constexpr bool BODY = BODY_OK;
   RigidB sb = RigidB{};
-  if (BODY) sb = body_begin(s);
+  const bool body = BODY && n_sub > 0;     // (wave-uniform) a zero-sub-step pass hands the state back bit for bit (placement trials)
+  if (body) sb = body_begin(s);
   for (int k = 0; k < n_sub; ++k) {
     if (NOISE != 0) {
       float nz[8];
@@ -332,7 +333,7 @@ __device__ __forceinline__ void quad_substeps(DT& T, const StepK& a, long long i
     if constexpr (BODY_OK) bullet_step_body(T, a.dt_phys, sb, F + ext, tau);      // (the loop runs: BODY holds)
     else bullet_step(T, a.dt_phys, s, F + ext, tau);
   }
-  if (BODY) body_end(sb, s);
+  if (body) body_end(sb, s);
 }
 
 // the same for the morphing hexa (BaseAviary.py:1389-1457); replay rows: f[6], m[6]
@@ -354,6 +355,7 @@ __device__ __forceinline__ void hexa_substeps(DT& T, const StepK& a, long long i
   // subtracting and re-adding the offset itself costs two roundings at the magnitude of the position: 1.4 ulp32(x) at
   // x = 34 m was the worst margin of the hexa kernels, 0.70 of the step's bar).  With the plane the contact geometry
   // wants the composite's position itself.
+  if (!ONE && a.substeps <= 0) return;     // (wave-uniform) a zero-sub-step pass hands the state back bit for bit (placement trials)
   const V3 o0 = mul(matrix_from_quat(s.q), v3(T.base_off[0], T.base_off[1], T.base_off[2]));
   if (PLANE) s.pos = s.pos - o0;
   s.vel = s.vel - cross(s.w, o0);

@@ -692,7 +692,8 @@ __device__ __forceinline__ void bullet_step_body(DT& T, float dt, RigidB& s, V3 
   s.vel = v3(clamp_sym(s.vel.x + vdot.x * dt, T.maxv), clamp_sym(s.vel.y + vdot.y * dt, T.maxv), clamp_sym(s.vel.z + vdot.z * dt, T.maxv));
   s.pos = s.pos + dt * s.vel;
   // exponential map of w' dt in the body frame: h^2 = (dt / 2)^2 w'.w', clamped at (pi / 8)^2 (the rotation per step at pi / 4)
-  const float h2 = fminf(0.25f * dt * dt * ww, (0.5f * DSIM_PI_4) * (0.5f * DSIM_PI_4));
+  const float h2_free = 0.25f * dt * dt * ww;
+  const float h2 = fminf(h2_free, (0.5f * DSIM_PI_4) * (0.5f * DSIM_PI_4));
   const float sinc = 1.0f + h2 * (-1.0f / 6.0f + h2 * (1.0f / 120.0f + h2 * (-1.0f / 5040.0f)));
   const float cw = 1.0f + h2 * (-0.5f + h2 * (1.0f / 24.0f + h2 * (-1.0f / 720.0f)));      // (h^8 / 40320 <= 1.4e-8 at the clamp: below half an ulp of 1)
   const float sc = 0.5f * dt * sinc;
@@ -702,6 +703,16 @@ __device__ __forceinline__ void bullet_step_body(DT& T, float dt, RigidB& s, V3 
            q.w * ay - q.x * az + q.y * cw + q.z * ax,
            q.w * az + q.x * ay - q.y * ax + q.z * cw,
            q.w * cw - q.x * ax - q.y * ay - q.z * az};
+  // (rare) the rotation clamp engaged: Bullet scales the UNCLAMPED w by sin(h_c) / w_c, so the increment (a, cw) has length
+  // sqrt(cw^2 + (|w| / w_c)^2 sin^2 h_c) > 1 and Bullet normalises the product (pQuatUpdateFun: quat.normalize()).  The loop's
+  // quaternion must stay within roundings of unit length (rotate_near_unit's 4 - 2 |q|^2), so this lane normalises here —
+  // unreachable at 240 Hz (|w| <= 173 rad/s < pi / (4 dt) = 188), reachable through freq= below ~220 Hz.
+#ifndef DSIM_AB_NO_CLAMP_RENORM        // (A/B knob of the build: tests/test_gpu_envelope.py fails its pi4 regimes without this branch)
+  if (h2_free > (0.5f * DSIM_PI_4) * (0.5f * DSIM_PI_4)) {
+    const float inv = DSIM_RSQ(s.q.x * s.q.x + s.q.y * s.q.y + s.q.z * s.q.z + s.q.w * s.q.w);
+    s.q = Q4{s.q.x * inv, s.q.y * inv, s.q.z * inv, s.q.w * inv};
+  }
+#endif
 }
 
 // C4: INDIControl._INDIRateControl, INDIControl.py:413-490 (also the whole of RPYTAviary's action

@@ -1,0 +1,300 @@
+"""Row P4 over its WHOLE envelope, on the device: Bullet's floating-base step (p.stepSimulation, BaseAviary.py:542-543)
+has corners that gentle flight never reaches — the clamp of every world velocity coordinate to +-100
+(applyDeltaVeeMultiDof), the clamp of the rotation per step to pi/4 (reachable below ~220 Hz through freq=), the Taylor
+branch of the exponential map, non-unit quaternions, tumbling attitudes.  tests/test_oracle_physics.py checks them on the CPU
+oracle; here every kernel family that integrates the rigid body (the world-frame bullet_step and the body-frame loop
+bullet_step_body, dsim_device.h) runs them through the C-ABI against orc_bullet_step_ex at the increment bar of
+tests/util.py:assert_step_parity.  Then a config-5 style flight in which a near-vertical close pair (the singular end of the
+downwash formula, BaseAviary.py:1736-1763) throws a drone onto the velocity clamp: oracle == device step by step through it.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from dronesim_amd import params  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from tests.test_gpu_parity import _args, _check_obs_rows, _noise_block, _stream, _sweep_case  # noqa: E402
+from tests.util import K_ULP, assert_step_parity, f32, noise_terms, random_fleet  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device; the product has no CPU fallback")
+    from dronesim_amd import _native as nat
+    from dronesim_amd import fleet
+    return nat, fleet
+
+
+# regime -> (envelope of random_fleet, physics frequency)
+REGIMES = {
+    "omega_clamp": ("omega_clamp", 240.0),          # (i)   |w| coordinates at 90-130 rad/s
+    "vel_clamp": ("vel_clamp", 240.0),              # (ii)  |v| coordinates at 95-105 m/s
+    "pi4_100Hz": ("pi4", 100.0),                    # (iii) |w| dt > pi/4: dt = 1/100 s, |w| up to 170
+    "pi4_60Hz": ("pi4", 60.0),
+    "tiny_omega": ("tiny_omega", 240.0),            # (iv)  |w| < 1e-3
+    "non_unit": ("non_unit", 240.0),                # (v)   |q| in 0.5 .. 1.5
+    "tumbling": ("tumbling", 240.0),                # (vi)  tilt to pi
+    "wreck": ("wreck", 240.0),                      # all at once
+    "wreck_100Hz": ("wreck", 100.0),                # ... with the rotation clamp on top of the velocity clamps
+}
+
+
+def _types():
+    return params.builtin_type("robobee"), params.builtin_type("hexa_6DOF"), params.builtin_type("hexa_6DOF_simple"), params.builtin_type("tello")
+
+
+def _step_families(nat, gentle=False):
+    """name -> keywords of _sweep_case: every kernel family of dsim_step that integrates the rigid body (dsim_api.hip: dsim_step's
+    dispatch), single-sub-step and looped instances."""
+    rb, hx, hs, te = _types()
+    n = 512
+    act4 = f32(np.random.default_rng(1).uniform(0.3, 0.7, (n, 4)))
+    tid_runs = np.array([0] * 200 + [1] * 312, dtype=np.uint8)
+    tid_lane = (np.arange(n) % 2).astype(np.uint8)
+    fam = {}
+    for sub in (1, 5):
+        s = f"sub{sub}"
+        fam[f"k_step_fast {s}"] = dict(types=[rb], tid=None, sub=sub, options=0)
+        fam[f"k_step_fast ACT {s}"] = dict(types=[rb], tid=None, sub=sub, options=0, action=act4)
+        fam[f"k_step_fast CH {s}"] = dict(types=[te], tid=None, sub=sub, options=nat.OPT_CHAINED)
+        fam[f"k_step_hexa {s}"] = dict(types=[hx], tid=None, sub=sub, options=0)
+        fam[f"k_step_runs {s}"] = dict(types=[rb, hx], tid=tid_runs, sub=sub, options=0, runs=[(0, 200, 0), (200, 312, 1)])
+        fam[f"k_step_run quadlaw6 {s}"] = dict(types=[hs], tid=None, sub=sub, options=0)
+        fam[f"k_step_mixed4 {s}"] = dict(types=[rb, hx], tid=tid_lane, sub=sub, options=0, layout="tile64")
+        fam[f"k_step_mixed3 {s}"] = dict(types=[rb, hx], tid=tid_lane, sub=sub, options=0, layout="soa")
+        fam[f"k_step_lean tail {s}"] = dict(types=[rb], tid=None, sub=sub, options=0, n=200, pad=64)     # 3 tiles of 64 + a ragged one, all below 256
+    for sub in (1, 2, 5):
+        # the EXT instances (waypoint-table targets and / or several Env.steps per launch): one Env.step per launch here, so that the
+        # comparison starts from ONE common state (a second step in the same launch starts from the device's own first-step result,
+        # and at 130 rad/s the gyroscopic coupling turns its roundings into more than a step's bar: the several-steps-per-launch form
+        # is covered bit for bit by test_multi_step_launch_equals_single_steps and, in the regimes that do not amplify, below)
+        fam[f"k_step_fast EXT waypoints sub{sub}"] = dict(types=[rb], tid=None, sub=sub, options=0, waypoints=True)
+    fam["k_step_gen drag sub1"] = dict(types=[rb], tid=None, sub=1, options=nat.OPT_DRAG)
+    fam["k_step_gen drag+ground sub5"] = dict(types=[rb], tid=None, sub=5, options=nat.OPT_DRAG | nat.OPT_GROUND)
+    if gentle:
+        fam["k_step_fast EXT 2 steps sub2"] = dict(types=[rb], tid=None, sub=2, options=0, n_steps=2)
+        fam["k_step_fast EXT 2 steps sub1"] = dict(types=[rb], tid=None, sub=1, options=0, n_steps=2)
+        fam["k_step_gen ACT 2 steps sub2"] = dict(types=[rb], tid=None, sub=2, options=0, n_steps=2, action=act4)
+    return fam
+
+
+def _collect(failures, fn, *a, **kw):
+    """Every case of a regime runs (a failure of one kernel family must not hide the next one's); the test fails at the end."""
+    try:
+        fn(*a, **kw)
+    except AssertionError as e:
+        failures.append(str(e).split("\n")[0][:300])
+
+
+@pytest.mark.parametrize("regime", list(REGIMES))
+def test_integrator_envelope_vs_oracle_fused_step(gpu, regime):
+    """dsim_step (Env.step + computeControl in one launch) on every kernel family, one regime of the envelope."""
+    nat, fleet = gpu
+    env, hz = REGIMES[regime]
+    failures = []
+    for name, kw in _step_families(nat, gentle=regime in ("tiny_omega", "non_unit")).items():
+        kw = dict(kw)
+        n = kw.pop("n", 512)
+        for seed in ((0, 7) if regime in ("wreck", "omega_clamp") else (0,)):
+            _collect(failures, _sweep_case, gpu, f"envelope[{name}|{regime}|{seed}]", kw["types"], kw["tid"], n, kw["sub"], seed, kw["options"],
+                     action=kw.get("action"), n_steps=kw.get("n_steps", 1), runs=kw.get("runs"), layout=kw.get("layout", "tile64"),
+                     pad=kw.get("pad", 256), fleet_kw=dict(envelope=env), dt_phys=1.0 / hz, waypoints=kw.get("waypoints", False))
+    assert not failures, failures
+
+
+@pytest.mark.parametrize("regime", list(REGIMES))
+def test_integrator_envelope_vs_oracle_env_step(gpu, regime):
+    """dsim_physics (Env.step alone): k_physics_fast plain and LOOP (quad fleet in whole tiles), k_physics_runs (hexas; type-major
+    quads + hexas; a ragged quad fleet), k_physics_gen (per-lane types) — rows fused where the kernel fuses them."""
+    nat, fleet = gpu
+    env, hz = REGIMES[regime]
+    DT = float(np.float32(1.0 / hz))
+    rb, hx, hs, te = _types()
+    n = 512
+    tid_runs = np.array([0] * 200 + [1] * 312, dtype=np.uint8)
+    tid_lane = (np.arange(n) % 2).astype(np.uint8)
+    failures = []
+    cases = {
+        "k_physics_fast": ([rb], None, None, n),
+        "k_physics_runs hexa": ([hx], None, None, n),
+        "k_physics_runs quad+hexa": ([rb, hx], tid_runs, [(0, 200, 0), (200, 312, 1)], n),
+        "k_physics_runs ragged": ([te], None, None, 300),
+        "k_physics_gen per lane": ([rb, hx], tid_lane, None, n),
+    }
+    for name, (types, tid, runs, n_) in cases.items():
+        na = max(t.n_act for t in types)
+        O = orc.Oracle(types)
+        for sub in (1, 5):
+            for seed in ((0, 5) if regime in ("wreck", "omega_clamp") else (0,)):
+                rng = np.random.default_rng(1000 + sub + seed)
+                rigid, mem, _ = random_fleet(rng, n_, n_act=na, envelope=env)
+                if tid is not None:
+                    for k, t in enumerate(types):
+                        mem[tid == k, 7 + t.n_act:13] = 0.0
+                ctx = fleet.Context(types)
+                st = fleet.FleetState(ctx, n_, "tile64")
+                st.load_aos(rigid, mem)
+                act = f32(rng.uniform(-0.1, 1.1, (n_, na)))
+                if tid is not None:
+                    for k, t in enumerate(types):
+                        act[tid == k, t.n_act:] = 0.0
+                adev = torch.zeros((na, st.n_pad), device=ctx.device)
+                adev[:, :n_] = torch.from_numpy(np.ascontiguousarray(act.T)).float()
+                echo = torch.zeros((na, st.n_pad), device=ctx.device)
+                w = 16 + na
+                obs = torch.full((n_, w), -7.0, device=ctx.device)
+                tdev = None
+                if tid is not None:
+                    tdev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device); tdev[:n_] = torch.from_numpy(tid)
+                a = _args(nat, sub, DT, DT * sub, seed=seed, step_index=3, action=adev, type_id=tdev)
+                a.obs_out, a.obs_width = obs.data_ptr(), w
+                arr = None
+                if runs is not None:
+                    arr = (nat.TypeRun * len(runs))()
+                    for k, (f, c, ty) in enumerate(runs):
+                        arr[k].first, arr[k].count, arr[k].type = f, c, ty
+                    a.runs, a.n_runs = ctypes.addressof(arr), len(runs)
+                nat.check(ctx.lib.dsim_physics(ctx.handle, _stream(ctx), n_, st.view(), echo.data_ptr(), ctypes.byref(a)))
+                torch.cuda.synchronize()
+                got_r = st.rigid_aos()
+                label = f"envelope[{name} sub{sub}|{regime}|{seed}]"
+                a6 = np.zeros((n_, 6))
+                for k, t in enumerate(types):
+                    sel = slice(None) if tid is None else (tid == k)
+                    a6[sel, :t.n_act] = np.clip(act[sel, :t.n_act], np.asarray(t.pwm_min)[:t.n_act], np.asarray(t.pwm_max)[:t.n_act])
+                nz = _noise_block(O, types, tid, n_, seed, 3, sub) if seed else None
+                r_ref = rigid.copy()
+                O.physics(r_ref, mem.copy(), sub, DT, action=a6, noise=nz, type_id=tid)
+                tgt = np.concatenate([rigid[:, 0:3], np.zeros((n_, 7))], 1)
+                _collect(failures, assert_step_parity, label, types, tid, rigid, mem, tgt, got_r, None, r_ref, None, DT, DT * sub, sub, control=False,
+                         action=a6[:, :na], extra_terms=noise_terms(types, tid, n_, DT, sub) if seed else None)
+                np.testing.assert_array_equal(st.mem_aos(), mem)                  # controller memory untouched
+                _collect(failures, _check_obs_rows, label + " rows", O, obs.double().cpu().numpy(), f32(got_r), a6, tid, types)
+                ctx.close()
+    assert not failures, failures
+
+
+def test_zero_substep_pass_hands_the_state_back_bit_for_bit_on_every_fleet_kind(gpu):
+    """The placement trials time dsim_physics with ZERO sub-steps (dronesim_amd/placement.py): the state must go back bit for bit
+    on every kernel a fleet may reach, not only on k_physics_fast — the looped instances of the run kernels used to renormalise
+    the quaternion and turn w through R R^T w."""
+    nat, fleet = gpu
+    rb, hx, hs, te = _types()
+    tid_runs = np.array([0] * 200 + [1] * 312, dtype=np.uint8)
+    for name, types, tid, runs, n in (("quad tiles", [rb], None, None, 512), ("quad ragged", [rb], None, None, 300), ("hexa", [hx], None, None, 512),
+                                      ("hexa_simple", [hs], None, None, 512), ("runs", [rb, hx], tid_runs, [(0, 200, 0), (200, 312, 1)], 512)):
+        na = max(t.n_act for t in types)
+        for env in ("wreck", None):
+            rigid, mem, _ = random_fleet(np.random.default_rng(5), n, n_act=na, envelope=env)
+            ctx = fleet.Context(types)
+            st = fleet.FleetState(ctx, n, "tile64")
+            st.load_aos(rigid, mem)
+            before_r, before_m = st.rigid_aos(), st.mem_aos()
+            tdev = None
+            if tid is not None:
+                tdev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device); tdev[:n] = torch.from_numpy(tid)
+            a = _args(nat, 0, float(np.float32(1 / 240)), float(np.float32(1 / 240)), seed=5, type_id=tdev)
+            arr = None
+            if runs is not None:
+                arr = (nat.TypeRun * len(runs))()
+                for k, (f, c, ty) in enumerate(runs):
+                    arr[k].first, arr[k].count, arr[k].type = f, c, ty
+                a.runs, a.n_runs = ctypes.addressof(arr), len(runs)
+            nat.check(ctx.lib.dsim_physics(ctx.handle, _stream(ctx), n, st.view(), None, ctypes.byref(a)))
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(st.rigid_aos(), before_r, err_msg=f"{name} {env}")
+            np.testing.assert_array_equal(st.mem_aos(), before_m, err_msg=f"{name} {env}")
+            ctx.close()
+
+
+@pytest.mark.parametrize("sub,surface", [(1, "step_fused"), (5, "step_fused"), (2, "two_call")])
+def test_singular_downwash_pair_ejects_a_drone_through_the_velocity_clamp(gpu, sub, surface):
+    """Config 5's hazard (DESIGN: near-vertical close pairs of formula P8 throw drones out 'at tens of m/s within a few steps'):
+    alpha = DW1 (r / (4 dz))^2 diverges as dz -> 0, so a drone a few millimetres under another receives a force of kilonewtons:
+    within one sub-step its vertical velocity sits on Bullet's clamp (-100 m/s) while the pair separates.  A mixed quad + hexa
+    fleet with such pairs planted in it flies six Env.steps; oracle (the term evaluated per sub-step, orc_physics_downwash_batch,
+    then computeControl) and device are compared step by step, every step from the device's previous state, onto the clamp,
+    along it and off it again."""
+    from dronesim_amd.control import INDIControl
+    from dronesim_amd.envs import CtrlAviary, Physics
+    from dronesim_amd.fleet import Targets, frozen
+    from tests.test_gpu_two_call_loop import _downwash_part
+    nat, fleet = gpu
+    rb, hx = params.builtin_type("robobee"), params.builtin_type("hexa_6DOF")
+    types = [rb, hx]
+    n = 384
+    rng = np.random.default_rng(61)
+    tid = (np.arange(n) % 2).astype(np.uint8)
+    xyz = np.stack([rng.uniform(0, 40, n), rng.uniform(0, 40, n), rng.uniform(30.0, 45.0, n)], 1)
+    # planted pairs: one drone of (2k, 2k + 1) sits dz under the other, dz from 1 mm to 4.5 mm, a few millimetres off the vertical;
+    # the lower one is the hexa in even pairs, the quad in odd ones
+    pairs = 12
+    dz = np.geomspace(1e-3, 4.5e-3, pairs)
+    for k in range(pairs):
+        lo, hi = (2 * k + 1, 2 * k) if k % 2 == 0 else (2 * k, 2 * k + 1)
+        xyz[lo] = xyz[hi] + np.array([rng.uniform(-3e-3, 3e-3), rng.uniform(-3e-3, 3e-3), -dz[k]])
+    xyz = f32(xyz)
+    env = CtrlAviary(["robobee", "hexa_6DOF"], n, initial_xyzs=xyz, aggregate_phy_steps=sub, noise_seed=0, dict_io=False,
+                     type_ids=tid, physics=Physics.PYB_DW, layout="tile64")
+    O = orc.Oracle(types)
+    DT = float(np.float32(1 / 240))
+    dtc = float(np.float32(sub / 240))
+    tg_np = np.concatenate([xyz, np.zeros((n, 7))], 1)
+    tg = Targets(env.ctx, n, "tile64")
+    tg.set(pos=xyz.T, yaw=0.0)
+    ctrl = INDIControl("hexa_6DOF", env=env) if surface == "two_call" else None
+    if ctrl is not None:
+        env._housekeeping()
+    action = torch.full((n, 6), 0.45, device=env.ctx.device)
+    action[torch.from_numpy(tid == 0).to(env.ctx.device), 4:] = 0.0
+    mass = np.array([t.mass for t in types])[tid]
+    ejected_first, on_clamp, came_off = 0, 0, 0
+    was_fast = np.zeros(n, dtype=bool)
+    for k in range(6):
+        r0, m0 = env.state.rigid_aos(), env.state.mem_aos()
+        a6 = action.double().cpu().numpy() if (surface == "two_call" or k == 0) else None
+        if surface == "two_call":
+            env.step(action)
+        else:
+            env.step_fused(tg, action=action if k == 0 else None)
+        if surface == "two_call":
+            action, _, _ = ctrl.computeControlFromState(dtc, None, target_pos=frozen(torch.from_numpy(xyz.astype(np.float32)).to(env.ctx.device)))
+        r1, m1 = env.state.rigid_aos(), env.state.mem_aos()
+        r, m = r0.copy(), m0.copy()
+        assert O.physics_downwash(r, m, sub, DT, action=a6, type_id=tid) == 0
+        rc, _, _ = O.control(r, m, tg_np, dtc, type_id=tid)
+        assert rc == 0
+        applied = a6[:, :6] if a6 is not None else m0[:, 7:13]
+        part = _downwash_part(O, types, tid, r0, r, sub)
+        # the force of a planted pair is ~1e4 x the weight: |fz| / m dt joins the terms of the velocity update (capped at what the
+        # clamp lets through: the update is v + a dt, then the clamp)
+        fz = np.abs(O.downwash(r0, r0[:, 0:3], type_id=tid))
+        extra = np.zeros((n, 13)); extra[:, 7:10] = np.minimum(fz / mass * DT, 200.0)[:, None]; extra[:, 0:3] = extra[:, 7:10] * DT * sub
+        em = np.zeros((n, 13)); em[:, 0:3] = extra[:, 7:10]; em[:, 6] = extra[:, 7] / dtc
+        assert_step_parity(f"ejection[{sub},{surface}]", types, tid, r0, m0, tg_np, r1, m1, r, m, DT, dtc, sub,
+                           action=applied, part_rigid=part, extra_terms=(extra, em))
+        # the clamp bounds every coordinate (the state holds the BASE link's velocity: a hexa's is the clamped composite velocity
+        # + w x (R d), millimetres per second beyond it)
+        assert np.all(np.abs(r1[:, 7:10]) <= 100.0 + 1e-2)
+        # a drone that went through the clamp leaves the Env.step at -100 m/s (one sub-step) or what Bullet's damping, c (1 + |v|) v =
+        # 404 m/s^2 at 100 m/s, has made of it since (1.7 m/s per sub-step): far beyond anything the force-free fleet reaches
+        fast = r1[:, 9] < -85.0
+        np.testing.assert_array_equal(fast, r[:, 9] < -85.0)                     # the same lanes on both sides
+        if k == 0:
+            ejected_first = int(fast.sum())
+        on = np.abs(np.abs(r1[:, 9]) - 100.0) < 1e-2
+        np.testing.assert_array_equal(on, np.abs(np.abs(r[:, 9]) - 100.0) < 1e-2)  # ... and the same lanes ON the clamp at the end of the step
+        on_clamp += int(on.sum())
+        came_off += int((was_fast & (r1[:, 9] > -100.0 + 1e-2)).sum())
+        was_fast = fast
+    assert ejected_first >= pairs // 2, ejected_first     # the planted pairs threw their lower drones through the clamp in the first step
+    if sub == 1:
+        assert on_clamp >= pairs // 2, on_clamp           # ... which a single-sub-step Env.step ends ON the clamp
+    assert came_off >= pairs // 2, came_off               # ... and the following steps carry them off it again
+    env.close()

@@ -2597,10 +2597,16 @@ def _noise_block(O, types, tid, n, seed, step_index, sub):
     return nz
 
 
-def _sweep_case(gpu, label, types, tid, n, sub, seed, options, action=None, n_steps=1, runs=None, layout="tile64", pad=256):
+def _sweep_case(gpu, label, types, tid, n, sub, seed, options, action=None, n_steps=1, runs=None, layout="tile64", pad=256,
+                fleet_kw=None, dt_phys=None, waypoints=False):
+    """One dsim_step launch (both streaming policies, bit-identical) against the oracle at the step bar.  fleet_kw: keywords for
+    random_fleet (envelope= ...); dt_phys: the physics period (default 1/240 s; dt_ctrl = sub x dt_phys); waypoints: the targets
+    come from a three-row waypoint table + per-drone offsets (examples/fly_INDI_TrajectoryTrack.py:242-245) — the EXT instances of
+    the fast kernel, also for a single Env.step per launch."""
     nat, fleet = gpu
     na = max(t.n_act for t in types)
-    rigid, mem, tgt = random_fleet(np.random.default_rng(n + sub + seed), n, n_act=na, tilt=0.3, rate=1.0)
+    DT = float(np.float32(dt_phys)) if dt_phys is not None else globals()["DT"]
+    rigid, mem, tgt = random_fleet(np.random.default_rng(n + sub + seed), n, n_act=na, **(fleet_kw or dict(tilt=0.3, rate=1.0)))
     if tid is not None:
         for k, t in enumerate(types):
             mem[tid == k, 7 + t.n_act:13] = 0.0
@@ -2614,9 +2620,17 @@ def _sweep_case(gpu, label, types, tid, n, sub, seed, options, action=None, n_st
             R = np.array(orc.matrix_from_quat(rigid[i, 3:7])).reshape(3, 3)
             mem[i, 3:6] = f32(R.T @ rigid[i, 10:13])
         mem = f32(mem)
-    dtc = float(np.float32(sub / 240))
+    dtc = float(np.float32(sub / 240)) if dt_phys is None else float(np.float32(sub * DT))
     sidx = 4
     got = {}
+    wp_rows = wp_cnt = wp_off = None
+    if waypoints:
+        assert n_steps == 1
+        wrng = np.random.default_rng(seed + 99)
+        wp_rows = wrng.uniform(-0.5, 0.5, (3, 10)).astype(np.float32)
+        wp_cnt = wrng.integers(0, 3, n).astype(np.int32)
+        wp_off = (tgt[:, 0:3].astype(np.float32) - wp_rows[wp_cnt, 0:3]).astype(np.float32)
+        tgt = np.concatenate([(wp_rows[wp_cnt, 0:3] + wp_off).astype(np.float64), wp_rows[wp_cnt, 3:10].astype(np.float64)], 1)   # (fp32 sum, as the kernel forms it)
     for pol in (nat.OPT_STREAM_ON, nat.OPT_STREAM_OFF):
         ctx = fleet.Context(types)
         st, tg = fleet.FleetState(ctx, n, layout, pad), fleet.Targets(ctx, n, layout, pad=pad)
@@ -2630,6 +2644,9 @@ def _sweep_case(gpu, label, types, tid, n, sub, seed, options, action=None, n_st
             adev = torch.zeros((na, st.n_pad), device=ctx.device); adev[:, :n] = torch.from_numpy(np.ascontiguousarray(action.T)).float()
         a = _args(nat, sub, DT, dtc, options=options | pol, seed=seed, step_index=sidx, type_id=tdev, action=adev)
         a.n_steps = n_steps
+        if waypoints:
+            wp = fleet.WaypointTargets(ctx, n, wp_rows[:, 0:3], wp_rows[:, 3:6], wp_rows[:, 6:9], wp_rows[:, 9], wp_counters=wp_cnt, offsets=wp_off, pad=pad)
+            wp.fill(a)
         arr = None
         if runs is not None:
             arr = (nat.TypeRun * len(runs))()
@@ -2651,7 +2668,7 @@ def _sweep_case(gpu, label, types, tid, n, sub, seed, options, action=None, n_st
         a6 = None
         if action is not None and k == 0:
             a6 = np.zeros((n, 6)); a6[:, :na] = action
-        assert O.step(r, m, tgt, sub, DT, dtc, noise=nz, type_id=tid, action=a6) == 0
+        assert O.step(r, m, tgt, sub, DT, dtc, noise=nz, type_id=tid, action=a6, options=options & (nat.OPT_DRAG | nat.OPT_GROUND)) == 0
     if n_steps == 1:
         assert_step_parity(label, types, tid, rigid, mem, tgt, got[nat.OPT_STREAM_OFF][0], got[nat.OPT_STREAM_OFF][1], r, m,
                            DT, dtc, sub, action=action)

@@ -52,8 +52,8 @@ def step_terms(types, type_id, rigid, mem, tgt, dt_phys, dt_ctrl, substeps, cont
     (terms_rigid [n,13], terms_mem [n,13]).  Each entry is a sum of |coefficient| x |operand| over the
     operands of that field's update as the reference writes it (BaseAviary.py:1487-1543 wrench,
     p.stepSimulation, INDIControl.py:278-296, 433-459 / INDIControl_6DOF.py:399-413, 560-628):
-      vel      (g + sum_i F_i / m) dt                       gravity and thrust accelerations cancel at hover
-      ang vel  sum_i |r_i| F_i / J_min dt                   the rotor moments cancel pairwise
+      vel      (g + sum_i F_i / m + c (1 + |v|) |v|) dt      gravity and thrust accelerations cancel at hover
+      ang vel  (sum_i |r_i| F_i / J_min + gyro |w|^2 + c (1 + |w|) |w|) dt + |w|      the rotor moments cancel pairwise; |w|: R w_b
       quat     1
       thrust   |v| / dt_ctrl + kd (kp |pos_e| + |v*| + |v|) + |a*|     the finite-difference acceleration
       cmd_j    sum_i |alloc_ji| term(nu_i),   nu_{0..2}: krate (katt + |w|) + |w| / dt_ctrl,
@@ -79,10 +79,20 @@ def step_terms(types, type_id, rigid, mem, tgt, dt_phys, dt_ctrl, substeps, cont
         arm = np.linalg.norm(np.asarray(t.rotor_pos)[:na], axis=1)
         acc = (t.gravity + F.sum(1) / t.mass)
         alpha = ((F * arm).sum(1) + t.km * (rpm ** 2).sum(1)) / min(t.inertia)
+        # Bullet's damping m v (c + c |v|), J w (c + c |w|) and the gyroscopic term w x J w (row P4): negligible in gentle
+        # flight, the largest terms of the update near the velocity clamps (tests/util.py:random_fleet, envelope=)
+        J = np.asarray(t.inertia, dtype=np.float64)
+        gyro = max(abs(J[2] - J[1]) / J[0], abs(J[0] - J[2]) / J[1], abs(J[1] - J[0]) / J[2])
+        vn = np.linalg.norm(rigid[s, 7:10], axis=1)
+        acc = acc + t.lin_damping * (1.0 + vn) * vn
+        alpha = alpha + gyro * w[s] ** 2 + t.ang_damping * (1.0 + w[s]) * w[s]
         tr[s, 0:3] = (v[s] + acc * dt_phys * substeps)[:, None] * dt_phys
         tr[s, 3:7] = 1.0
         tr[s, 7:10] = (acc * dt_phys)[:, None]
-        tr[s, 10:13] = (alpha * dt_phys)[:, None]
+        # (every kernel turns w between the world and the body frame — the body-frame loop carries R^T w and stores R w_b — so every
+        # world coordinate of w is a sum of three products of magnitude up to |w|: at 130 rad/s the rounding of R alone is worth
+        # ulp32(130) in a coordinate that happens to be small)
+        tr[s, 10:13] = (alpha * dt_phys + w[s])[:, None]
         if not control:
             continue
         v_new = v[s] + acc * dt_phys * substeps                           # bound on |v| after the physics
@@ -275,13 +285,52 @@ def assert_control_parity(label, types, type_id, rigid, prev_mem, tgt, got_mem, 
     return worst
 
 
-def random_fleet(rng, n, n_act=4, tilt=0.5, speed=2.0, rate=1.5, spread=50.0):
-    """Seeded in-flight fleet state: rigid [n,13], mem [n,13], targets [n,10] (fp32-representable)."""
+ENVELOPES = ("omega_clamp", "vel_clamp", "pi4", "tiny_omega", "non_unit", "tumbling", "wreck")
+
+
+def random_fleet(rng, n, n_act=4, tilt=0.5, speed=2.0, rate=1.5, spread=50.0, envelope=None):
+    """Seeded in-flight fleet state: rigid [n,13], mem [n,13], targets [n,10] (fp32-representable).
+
+    envelope: None = gentle flight (the defaults above), or one of ENVELOPES — the corners of Bullet's floating-base
+    step (row P4, BaseAviary.py:542-543) that gentle flight never reaches:
+      "omega_clamp"  angular-velocity coordinates at 90-130 rad/s, mixed with lanes that have ONE such coordinate and
+                     lanes just under 100 rad/s (applyDeltaVeeMultiDof's clamp of every world coordinate to +-100; the
+                     body-frame loop's world-frame detour triggers on |w_b| >= 100)
+      "vel_clamp"    velocity coordinates at 95-105 m/s (the same clamp on the linear coordinates; damping pulls the
+                     ones under 100 away from it, thrust pushes some onto it)
+      "pi4"          |w| up to 170 rad/s in random directions: with dt_phys = 1/100 or 1/60 s the rotation per sub-step
+                     exceeds pi/4 and Bullet's angular-motion clamp engages (unreachable at 240 Hz)
+      "tiny_omega"   |w| < 1e-3 rad/s, some lanes exactly zero (Bullet's Taylor branch of the exponential map)
+      "non_unit"     quaternions of length 0.5-1.5 (the helpers do not normalise; Bullet's step does)
+      "tumbling"     attitudes over the whole sphere (tilt to pi), both signs of w
+      "wreck"        all of it at once: a tumbling lane with clamped rates and velocities and a non-unit quaternion"""
+    assert envelope is None or envelope in ENVELOPES, envelope
     rpy = np.stack([rng.uniform(-tilt, tilt, n), rng.uniform(-tilt, tilt, n), rng.uniform(-math.pi, math.pi, n)], 1)
     quat = np.stack([orc.quat_from_euler(r) for r in rpy]) if n <= 20000 else _quat_from_euler_np(rpy)
     pos = np.concatenate([rng.uniform(-spread, spread, (n, 2)), rng.uniform(0.5, 20.0, (n, 1))], 1)
     vel = rng.uniform(-speed, speed, (n, 3))
     om = rng.uniform(-rate, rate, (n, 3))
+    sign = lambda shape: np.where(rng.uniform(size=shape) < 0.5, -1.0, 1.0)
+    if envelope in ("tumbling", "wreck"):
+        quat = rng.normal(size=(n, 4))
+        quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    if envelope in ("non_unit", "wreck"):
+        quat = quat * rng.uniform(0.5, 1.5, (n, 1))
+    if envelope in ("omega_clamp", "wreck"):
+        big = sign((n, 3)) * rng.uniform(90.0, 130.0, (n, 3))
+        kind = rng.integers(0, 4, n)                      # 0, 1: every coordinate; 2: one coordinate; 3: |w| just under 100
+        one = np.zeros((n, 3)); one[np.arange(n), rng.integers(0, 3, n)] = 1.0
+        om = np.where((kind <= 1)[:, None], big, np.where((kind == 2)[:, None], one * big + (1 - one) * om, om))
+        d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        om = np.where((kind == 3)[:, None], d * rng.uniform(97.0, 101.0, (n, 1)), om)
+    if envelope in ("vel_clamp", "wreck"):
+        vel = sign((n, 3)) * rng.uniform(95.0, 105.0, (n, 3))
+    if envelope == "pi4":
+        d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        om = d * rng.uniform(40.0, 170.0, (n, 1))          # pi / (4 dt) = 78.5 rad/s at 100 Hz, 47.1 at 60 Hz
+    if envelope == "tiny_omega":
+        om = rng.uniform(-1.0, 1.0, (n, 3)) * (1e-3 / math.sqrt(3.0)) * rng.uniform(0.0, 1.0, (n, 1))
+        om[rng.uniform(size=n) < 0.1] = 0.0
     rigid = f32(np.concatenate([pos, quat, vel, om], 1))
     mem = np.zeros((n, 13))
     mem[:, 0:3] = rigid[:, 7:10] + rng.uniform(-0.02, 0.02, (n, 3))
