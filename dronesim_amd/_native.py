@@ -22,15 +22,14 @@ EXPORTS = (
     "dsim_halo_pack", "dsim_downwash_workspace_halo", "dsim_dev_alloc", "dsim_dev_free", "dsim_noise_draw",
 )
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_PEERS = 8
 HALO_HDR = 8           # header floats of a halo message (DSIM_HALO_HDR)
 DW_ALL, DW_LOCAL, DW_HALO_BIN, DW_HALO_QUERY = 0, 1, 2, 3
 NF_QUAD, NF_HEXA, NT = 24, 26, 10
 OPT_DRAG, OPT_GROUND, OPT_BCAST_TGT, OPT_CHAINED = 1, 2, 4, 8
 OPT_STREAM_ON, OPT_STREAM_OFF = 16, 32      # tuning knobs (results do not depend on them)
-# A/B knobs of measured-and-rejected kernel forms: honoured only by a library built with -DDSIM_WITH_VARIANTS
-# (tools/variants/dsim_variants.inc, tools/build_variants.sh); the product library ignores them
+# option bits of measured-and-rejected kernel forms (tools/variants/ up to round 5, in the git history): reserved, ignored by the library
 VAR_GENERIC, VAR_MIXED_V1, VAR_MIXED_RING, VAR_MIXED_V3, VAR_RUNS_SEPARATE = 64, 128, 256, 512, 1 << 13
 TUNING_MASK = OPT_STREAM_ON | OPT_STREAM_OFF | VAR_GENERIC | VAR_MIXED_V1 | VAR_MIXED_RING | VAR_MIXED_V3 | VAR_RUNS_SEPARATE
 OPT_PLANE = 1 << 10        # ground-plane contact (product-defined model, oracle/dsim_oracle.c:orc_plane_contact)
@@ -39,7 +38,10 @@ OPT_CALLER_IO = 1 << 14    # dsim_physics / dsim_control2: action, rows, command
 OPT_ACTION_ROWS = 1 << 15  # dsim_step_adaptor: the action row-major [n][4]
 OPT_DYN = 1 << 16          # Physics.DYN: BaseAviary._dynamics instead of the Bullet step (StepArgs.dyn_rpy_rates required)
 OPT_DYN_BODY_RATES = 1 << 17   # ... with ang_v = R(quat) rpy_rates instead of the reference's placeholder (-1, -1, -1)
-OPT_NOISE_FINE = 1 << 18   # rotor noise on the 16 + 16-bit Box-Muller lattice instead of the default 8 + 8-bit one (changes results)
+# rotor noise: which Box-Muller lattice a launch draws on (changes results).  Neither bit: the fine one (16 + 16 bits per pair) for a launch
+# of ONE physics sub-step, the coarse one (8 + 8 bits) for a launch of several; the bits force one at any count (include/dronesim_amd.h)
+OPT_NOISE_FINE = 1 << 18
+OPT_NOISE_COARSE = 1 << 19
 ADAPT_VELOCITY, ADAPT_RPYT = 0, 1
 QUERY_WLS_FALLBACKS, QUERY_WLS_FAILURES, QUERY_GROUND_CONTACTS, QUERY_HALO_OVERFLOW = 0, 1, 2, 3
 

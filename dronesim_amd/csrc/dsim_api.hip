@@ -1,481 +1,6 @@
-// dsim_api.hip — kernels + C-ABI of libdronesim_amd.so (gfx950 only).
-//
-// Execution shape: one drone per lane, 64-drone waves, 256-thread workgroups.
-// State is blocked SoA (include/dronesim_amd.h): consecutive lanes read
-// consecutive floats of one field, so every global access of a wave is one
-// fully-coalesced 256-byte segment.  The fused step kernel reads each state
-// field once and writes it once per Env.step(): 232 B per drone-step for a quad
-// with per-drone targets (192 B with a broadcast target); physics sub-steps and
-// the whole INDI law stay in registers.  The bound is HBM bandwidth.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdlib.h>
-#include <math.h>
-#include <string.h>
-#include <new>
-
-#include "../../include/dronesim_amd.h"
-#include "dsim_device.h"
-
-// minimum waves per SIMD the fused kernel is compiled for (2nd __launch_bounds__ argument):
-// bounds the VGPR budget (512 / waves); tuned on MI355X, see DESIGN.md
-// (round 3, A/B of 3 / 4 / 5 / 6 on the final build, profiles/r03_ab_waves.txt: indifferent for one sub-step per launch,
-// 153.5-154.5 us whatever the bound; with the examples' five sub-steps the looped kernel fits 95 VGPRs at 5 and runs
-// 241 us instead of 248 at 4 (110 VGPRs); no instance spills at 5)
-#ifndef DSIM_STEP_WAVES
-#define DSIM_STEP_WAVES 5
-#endif
-#ifndef DSIM_GEN_WAVES
-#define DSIM_GEN_WAVES 2
-#endif
-#ifndef DSIM_IO_ROWS_NT
-#define DSIM_IO_ROWS_NT 0      // rows scattered to the caller's numbering: streaming hint or not
-#endif
-
-struct dsim_ctx {
-  int device;
-  int n_types;
-  int max_act;                            // 4: quads only; 6: the table holds a morphing hexa
-  DevType* d_types;                       // device copy of the type table
-  unsigned long long* d_counters;         // [0..1] diagnostics (dsim_query), [2] fallback queue length, [3] its ticket
-  FbEntry* d_fb;                          // deferred WLS fallback queue, grown to the largest fleet seen
-  long long fb_cap;
-  const int32_t* dw_ws;                   // downwash grid: workspace / shape / count-buffer parity of the last call
-  long long dw_cells;
-  int dw_parity;
-  int dw_mode;                            // 0: counting sort, 1: cell buckets (which layout the count buffers hold)
-  int n_cu;                               // compute units of the device
-  bool dw_prebin;                         // the count buffer dw_parity holds the local drones, binned by the last dsim_step
-  bool dw_prebin_valid;                   // ... and no call has moved the positions since without re-binning them
-  long long dw_prebin_n, dw_prebin_off;
-  float dw_prebin_geo[3];
-  int dw_prebin_nx, dw_prebin_ny;
-  long long dw_local_m;                   // overflow capacity of the local grid in the workspace (layout of what follows it)
-  int dwh_parity;                         // halo grid (split-phase downwash): count-buffer parity
-  const int32_t* dwh_ws;                  // ... and the workspace / shape it was zeroed for
-  long long dwh_cells;
-  unsigned* d_bounds;                     // dsim_fleet_bounds: 5 order-preserving keys + a ticket
-  int* d_block_map;                       // RunTab.block_map of the last side-by-side launch (DSIM_OPT_CALLER_IO), and what it was made for
-  int* h_block_map;
-  int block_map_cap, block_map_blocks, block_map_runs;
-  dsim_type_run block_map_key[DSIM_MAX_TYPES];
-  dsim_type_params h_types[DSIM_MAX_TYPES];
-};
-
-// ---------------------------------------------------------------------------
-// blocked-SoA addressing
-// ---------------------------------------------------------------------------
-struct KView {
-  float* base;
-  long long field_stride, block_stride;
-  long long mask;   // block - 1 (block is a power of two) ; -1 for plain SoA
-  int shift;        // log2(block) ; 63 for plain SoA
-};
-__device__ __forceinline__ long long kv_off(const KView& v, long long i) {
-  return (i >> v.shift) * v.block_stride + (i & v.mask);
-}
-// Workgroups are 256 drones starting at a multiple of 256 and block sizes are powers of two,
-// so kv_off(i0 + t) = kv_off(i0) + kv_lane(t): a wave-uniform 64-bit part (kept in SGPRs and
-// folded into the scalar base of each access) plus a small per-lane 32-bit part (ONE VGPR shared by
-// every field).  Without the split every field costs a 64-bit VGPR address pair.
-__device__ __forceinline__ unsigned kv_lane(const KView& v, unsigned t) {
-  return v.shift >= 8 ? (t & (unsigned)v.mask)   // plain SoA / blocks >= 256: mask keeps t; broadcast view: mask = 0
-                      : (t >> v.shift) * (unsigned)v.block_stride + (t & (unsigned)v.mask);
-}
-
-// ---- neighbour grid, bucket form (downwash P8 / adjacency) ---------------------------------------------------------
-// Uniform xy grid of cells of HALF the 10 m cut-off or more (a receiver scans the 5 x 5 cells around its own: 625 m^2
-// for 5 m cells against the 900 m^2 of 3 x 3 cells of 10 m — 30 % fewer candidate pairs, and four times fewer drones
-// per cell counter); every cell owns a bucket of DW_CAP entries (x, y, z, world index), entries that find their bucket
-// full go to one shared overflow list that every receiver scans too, so results never depend on the capacity.  The
-// step kernels can fill the grid for the NEXT Env.step themselves (BinK in StepK): the new position is in registers
-// when the state is stored, which removes the binning launch from the step chain.
-#define DW_CAP 64
-#define DW_CUTOFF 10.0f
-// ints behind the per-cell counts of a bucket grid's count buffer: [0] overflow length; [1..4] the cell range that holds
-// entries, as maxima so that an all-zero buffer is the neutral element: nx-1-cx_min, cx_max, ny-1-cy_min, cy_max (kept by
-// the halo binning only: the halo pass of the query leaves at once where no halo entry can be in reach); [5] spare
-#define DW_CNT_EXTRA 6
-struct BinK {
-  int* count;          // [ncells + DW_CNT_EXTRA]: entries per cell, then the extras above.  null = no binning
-  float4* buckets;     // [ncells][DW_CAP]
-  float4* overflow;    // [m]
-  float xmin, ymin, inv_cell;
-  int nx, ny;
-  long long local_offset;   // world index of local drone 0
-};
-__device__ __forceinline__ int bin_cell(const BinK& b, float x, float y) {
-  const int cx = min(max((int)floorf((x - b.xmin) * b.inv_cell), 0), b.nx - 1);
-  const int cy = min(max((int)floorf((y - b.ymin) * b.inv_cell), 0), b.ny - 1);
-  return cy * b.nx + cx;
-}
-// the two halves of bin_entry: the slot's reservation is an atomic round trip to another XCD's L2 (~2 us); issued as soon
-// as the new position exists it is hidden behind the control law instead of standing at the end of the workgroup
-__device__ __forceinline__ int bin_reserve(const BinK& b, float x, float y, int& cell) {
-  cell = bin_cell(b, x, y);
-  return atomicAdd(&b.count[cell], 1);
-}
-__device__ __forceinline__ void bin_commit(const BinK& b, int cell, int slot, float x, float y, float z, long long world_index) {
-  const float4 e = make_float4(x, y, z, __int_as_float((int)world_index));
-  if (slot < DW_CAP) b.buckets[(long long)cell * DW_CAP + slot] = e;
-  else b.overflow[atomicAdd(&b.count[b.nx * b.ny], 1)] = e;
-}
-__device__ __forceinline__ void bin_entry(const BinK& b, float x, float y, float z, long long world_index) {
-  const int c = bin_cell(b, x, y);
-  const float4 e = make_float4(x, y, z, __int_as_float((int)world_index));
-  const int slot = atomicAdd(&b.count[c], 1);
-  if (slot < DW_CAP) b.buckets[(long long)c * DW_CAP + slot] = e;
-  else b.overflow[atomicAdd(&b.count[b.nx * b.ny], 1)] = e;
-}
-
-// bucket form: grids of up to 65 536 cells with at most 5/8 DW_CAP = 40 entries per cell on average (BASELINE config 5:
-// one drone per m^2 = 25 per 5 m cell); the buckets take ncells * DW_CAP * 16 bytes of the workspace (67 MB at most)
-static inline bool dw_use_buckets(int64_t m, int64_t ncells) { return ncells <= 65536 && m <= ncells * (DW_CAP * 5 / 8); }
-// where the bucket form keeps things inside the workspace (ints): count x2 | 16-byte aligned buckets | overflow
-static inline void bucket_layout(int32_t* ws, long long ncells, int parity, BinK* b) {
-  const long long cstride = ncells + DW_CNT_EXTRA;
-  b->count = ws + (long long)parity * cstride;
-  uintptr_t sp = (uintptr_t)(ws + 2 * cstride);
-  b->buckets = (float4*)((sp + 15) & ~(uintptr_t)15);
-  b->overflow = b->buckets + ncells * DW_CAP;
-}
-
-struct StepK {
-  KView st, tg;
-  const DevType* types;
-  const uint8_t* type_id;
-  const float* noise_replay;
-  const float* action;        // SoA [n_act][n_pad] or null (= stored cmd)
-  int action_rows;            // DSIM_OPT_ACTION_ROWS: action is row-major [n][4] (the one-launch quad kernels only)
-  float* echo;                // physics kernel: clipped action out, or null
-  float* pos_e_out;           // control kernel only
-  float* yaw_e_out;
-  float* cmd_out;             // control kernel only: SoA [n_act][n_pad] copy of the new command, or null
-  float* obs_out;             // physics kernel: fused observation rows [n][obs_w], or null
-  int obs_w;                  // 16 + the table's largest actuator count: width of an observation row / rows of echo, cmd_out
-  long long n;                // drones (rows of obs_out)
-  FbList fb;                  // deferred WLS fallbacks (hexa)
-  long long n_pad;
-  long long first;            // general step kernel: first drone of this launch
-  const float* wp_table;      // waypoint mode (null = targets view)
-  int* wp_counter;
-  const float* wp_offset;
-  const float* ext_force;     // SoA [3][n_pad] body-frame force at the COM, or null
-  const unsigned long long* step_index_dev;   // added to step_index (graph replay), or null
-  int n_wp, n_steps;
-  unsigned long long seed, step_index;
-  int substeps;
-  float dt_phys, dt_ctrl;
-  unsigned options;
-  long long lo, last;         // run kernels: first drone of the run (the launch starts at the tile that holds it), one past its last
-  int run_type;               // run kernels: the run's type
-  const int* drone_id;        // the caller's index of storage slot i (keys the noise counter), or null = i
-  const int* io_id;           // DSIM_OPT_CALLER_IO: = drone_id, the per-drone arrays beside the state are indexed by it; else null
-  unsigned hexa_types;        // bit t set: type t of the table is a morphing hexa (26 state fields in use)
-  BinK bin;                   // grid of the next Env.step's downwash (k_step_mixed / k_step_run), count = null: none
-  float* dyn_rates;           // Physics.DYN: BaseAviary.rpy_rates, SoA [3][n_pad] in-out (k_dyn only)
-};
-
-// Global accesses.  NT = nontemporal (streaming) hint: each state field is read once and written
-// once per step, so for fleets larger than the caches the lines should not linger in L2/MALL
-// (measured on MI355X with this access shape: +12-15 % HBM rate, tools/membench.hip).  Small
-// fleets that fit the Infinity Cache keep the default policy so consecutive steps hit on-die.
-// (uniform base pointer, per-lane BYTE offset): the form that maps onto
-// `global_load_dword v, v_off, s[base:base+1]` (scalar base + 32-bit VGPR offset).
-template <bool NT> __device__ __forceinline__ float ldg(const float* ub, unsigned boff) {
-  const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ub) + boff);
-  return NT ? __builtin_nontemporal_load(p) : *p;
-}
-template <bool NT> __device__ __forceinline__ void stg(float* ub, unsigned boff, float v) {
-  float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(ub) + boff);
-  if (NT) __builtin_nontemporal_store(v, p); else *p = v;
-}
-
-// The stores sit in a later basic block than the loads; instruction selection works per block and would no
-// longer see that the lane offset is a zero-extended 32-bit value, so every store would get a 64-bit VGPR
-// address (one v_lshl_add_u64 + two VGPRs per field).  Re-materialising the offset in the store's block keeps
-// the scalar-base + 32-bit-lane-offset form there too.
-__device__ __forceinline__ unsigned pin_lane_offset(unsigned off) {
-  asm volatile("" : "+v"(off));
-  return off;
-}
-
-template <bool NT = false>
-__device__ __forceinline__ void load_rigid(const float* ub, long long fs, unsigned lo /* bytes */, Rigid& s) {
-  s.pos = v3(ldg<NT>(ub + 0 * fs, lo), ldg<NT>(ub + 1 * fs, lo), ldg<NT>(ub + 2 * fs, lo));
-  s.q = Q4{ldg<NT>(ub + 3 * fs, lo), ldg<NT>(ub + 4 * fs, lo), ldg<NT>(ub + 5 * fs, lo), ldg<NT>(ub + 6 * fs, lo)};
-  s.vel = v3(ldg<NT>(ub + 7 * fs, lo), ldg<NT>(ub + 8 * fs, lo), ldg<NT>(ub + 9 * fs, lo));
-  s.w = v3(ldg<NT>(ub + 10 * fs, lo), ldg<NT>(ub + 11 * fs, lo), ldg<NT>(ub + 12 * fs, lo));
-}
-template <bool NT = false>
-__device__ __forceinline__ void store_rigid(float* ub, long long fs, unsigned lo /* bytes */, const Rigid& s) {
-  stg<NT>(ub + 0 * fs, lo, s.pos.x); stg<NT>(ub + 1 * fs, lo, s.pos.y); stg<NT>(ub + 2 * fs, lo, s.pos.z);
-  stg<NT>(ub + 3 * fs, lo, s.q.x); stg<NT>(ub + 4 * fs, lo, s.q.y); stg<NT>(ub + 5 * fs, lo, s.q.z); stg<NT>(ub + 6 * fs, lo, s.q.w);
-  stg<NT>(ub + 7 * fs, lo, s.vel.x); stg<NT>(ub + 8 * fs, lo, s.vel.y); stg<NT>(ub + 9 * fs, lo, s.vel.z);
-  stg<NT>(ub + 10 * fs, lo, s.w.x); stg<NT>(ub + 11 * fs, lo, s.w.y); stg<NT>(ub + 12 * fs, lo, s.w.z);
-}
-// CH (chained): last_vel / last_rates are neither read nor written (DSIM_OPT_CHAINED)
-template <int NACT, bool NT = false, bool CH = false>
-__device__ __forceinline__ void load_mem(const float* ub, long long fs, unsigned lo /* bytes */, CtrlMem<NACT>& m) {
-  if (!CH) {
-    m.last_vel = v3(ldg<NT>(ub + 13 * fs, lo), ldg<NT>(ub + 14 * fs, lo), ldg<NT>(ub + 15 * fs, lo));
-    m.last_rates = v3(ldg<NT>(ub + 16 * fs, lo), ldg<NT>(ub + 17 * fs, lo), ldg<NT>(ub + 18 * fs, lo));
-  }
-  m.last_thrust = ldg<NT>(ub + 19 * fs, lo);
-#pragma unroll
-  for (int j = 0; j < NACT; ++j) m.cmd[j] = ldg<NT>(ub + (20 + j) * fs, lo);
-}
-template <int NACT, bool NT = false, bool CH = false>
-__device__ __forceinline__ void store_mem(float* ub, long long fs, unsigned lo /* bytes */, const CtrlMem<NACT>& m) {
-  if (!CH) {
-    stg<NT>(ub + 13 * fs, lo, m.last_vel.x); stg<NT>(ub + 14 * fs, lo, m.last_vel.y); stg<NT>(ub + 15 * fs, lo, m.last_vel.z);
-    stg<NT>(ub + 16 * fs, lo, m.last_rates.x); stg<NT>(ub + 17 * fs, lo, m.last_rates.y); stg<NT>(ub + 18 * fs, lo, m.last_rates.z);
-  }
-  stg<NT>(ub + 19 * fs, lo, m.last_thrust);
-#pragma unroll
-  for (int j = 0; j < NACT; ++j) stg<NT>(ub + (20 + j) * fs, lo, m.cmd[j]);
-}
-// A broadcast target view has mask = 0, so kv_off() is 0 for every lane: all lanes read the same
-// ten floats (one cache line per wave-instruction), no separate code path.
-template <bool NT = false>
-__device__ __forceinline__ void load_target(const float* ub, long long fs, unsigned lo /* bytes */, Target& t) {
-  t.pos = v3(ldg<NT>(ub + 0 * fs, lo), ldg<NT>(ub + 1 * fs, lo), ldg<NT>(ub + 2 * fs, lo));
-  t.vel = v3(ldg<NT>(ub + 3 * fs, lo), ldg<NT>(ub + 4 * fs, lo), ldg<NT>(ub + 5 * fs, lo));
-  t.acc = v3(ldg<NT>(ub + 6 * fs, lo), ldg<NT>(ub + 7 * fs, lo), ldg<NT>(ub + 8 * fs, lo));
-  t.yaw = ldg<NT>(ub + 9 * fs, lo);
-}
-
-// Waypoint-table targets (examples/fly_INDI_TrajectoryTrack.py:242-245): row wp of the table (+ the
-// drone's own position offset).  The 48 KB table is gathered per lane and stays L1/L2-resident.
-__device__ __forceinline__ void waypoint_target(const StepK& a, long long i, int wp, Target& t) {
-  const float* r = a.wp_table + (long long)wp * 10;
-  t.pos = v3(r[0], r[1], r[2]);
-  if (a.wp_offset) t.pos = t.pos + v3(a.wp_offset[i], a.wp_offset[a.n_pad + i], a.wp_offset[2 * a.n_pad + i]);
-  t.vel = v3(r[3], r[4], r[5]);
-  t.acc = v3(r[6], r[7], r[8]);
-  t.yaw = r[9];
-}
-// wp_counters[j] + 1 if < NUM_WP - 1 else 0   (fly_INDI_TrajectoryTrack.py:253-256)
-__device__ __forceinline__ int waypoint_next(int wp, int n_wp) { return wp < n_wp - 1 ? wp + 1 : 0; }
-
-// physics sub-steps of one Env.step for a quad (BaseAviary.py:510-545)
-// NOISE: 0 = off, 1 = in-kernel counter-based noise, 2 = replay buffer if given else in-kernel.
-// NROW = rows per sub-step of the replay buffer's force / moment halves (the kernel's NACT).
-// OPTS: honour the drag / ground-effect option bits (general kernels only).  prev = the action of the
-// previous Env.step (last_clipped_action) for the drag of sub-step 0, or null = this step's action.
-// NSUB > 0: the number of sub-steps is a compile-time constant and the code is straight-line.  Used for 1 (BASELINE's
-// metric definition): without the loop the compiler keeps the headline kernel in 91 instead of 110 VGPRs
-// (5 waves/SIMD) and 836 instead of 887 vector instructions.  (Measured and rejected: 2 — no change, 198 us
-// either way; 5 — the unrolled body spills, 533 vs 310 us.)
-// FINE: whether this instance carries the 16 + 16-bit noise lattice (DSIM_OPT_NOISE_FINE, a wave-uniform run-time switch)
-// beside the default one.  -1 = the rule: the single-sub-step instances (bound by HBM: the second path is free) and the general
-// kernels (OPTS) do; the instances that loop over sub-steps on the fast paths — bound by vector issue, tuned to their register
-// budgets — do not, and the launchers hand a fine-lattice launch with several sub-steps to the general kernels.
-// LOOPED: the launcher picked this instance because the launch has SEVERAL sub-steps (its single-sub-step twin takes the others):
-// the loop carries the body-frame form of the step (dsim_device.h:bullet_step_body).
-template <int NOISE, int NROW = 4, bool OPTS = false, int NSUB = 0, bool PLANE = false, int FINE = -1, bool LOOPED = false, class DT>
-__device__ __forceinline__ void quad_substeps(DT& T, const StepK& a, long long i, Rigid& s,
-                                              const float cmd[4], unsigned long long step_index,
-                                              V3 ext = V3{-0.0f, -0.0f, -0.0f} /* x + -0 = x for EVERY x: a caller without a force pays no add */,
-                                              const float* prev = nullptr, long long nid = -1,
-                                              const NoiseTab* tab = nullptr /* LDS tables of the Box-Muller pairs, or none */) {
-  // nid: the drone's index in the caller's numbering when the fleet is stored in another order (StepK.drone_id): the
-  // key of its noise stream.  -1 (a constant at the call sites of the single-order kernels) = i.
-  const uint64_t noise_key = (uint64_t)(nid >= 0 ? nid : i);
-  V3 F, tau;
-  if (NOISE == 0) quad_wrench(T, cmd, nullptr, F, tau);   // cmd is constant over the sub-steps
-  // (several sub-steps with noise: the noise-free part of the map once, the normals' part per sub-step)
-  constexpr bool SPLIT = NOISE != 0 && NSUB != 1 && !OPTS;
-  QuadBase qb = QuadBase{0.0f, V3{0.0f, 0.0f, 0.0f}};
-  if (SPLIT) qb = quad_wrench_base(T, cmd);
-  const int n_sub = NSUB > 0 ? NSUB : a.substeps;
-  uint32_t nb[4] = {0u, 0u, 0u, 0u};       // the Threefry block: ONE serves two consecutive sub-steps (dsim_device.h:noise_normals)
-  // the looped fast instances carry the body-frame form of the step across the sub-steps (dsim_device.h:bullet_step_body)
-  // (only where several sub-steps are certain: with one, w' = R' (R^T w + a_b dt) costs the stored angular velocity two more
-  // matrix roundings than w + R a_b dt and saves nothing.  The neutral zero-sub-step pass of the placement trials runs on
-  // k_physics_fast, which is not LOOPED: there the state goes back bit for bit.)
-  constexpr bool BODY_OK = LOOPED && !OPTS && !PLANE && NSUB != 1;
-  constexpr bool BODY = BODY_OK;
-  RigidB sb = RigidB{};
-  const bool body = BODY && n_sub > 0;     // (wave-uniform) a zero-sub-step pass hands the state back bit for bit (placement trials)
-  if (body) sb = body_begin(s);
-  for (int k = 0; k < n_sub; ++k) {
-    if (NOISE != 0) {
-      float nz[8];
-      if (NOISE == 2 && a.noise_replay) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          nz[j] = a.noise_replay[((long long)k * 2 * NROW + j) * a.n_pad + i];
-          nz[4 + j] = a.noise_replay[((long long)k * 2 * NROW + NROW + j) * a.n_pad + i];
-        }
-      } else if ((FINE >= 0 ? FINE != 0 : (NSUB == 1 || OPTS)) && (a.options & DSIM_OPT_NOISE_FINE)) {   // (wave-uniform) the 16 + 16-bit lattice
-        quad_normals_fine(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);
-      } else {
-        const uint64_t sub = step_index * (uint64_t)a.substeps + (uint64_t)k;          // (wave-uniform)
-        if (k == 0 || (sub & 1ull) == 0) noise_block(a.seed, noise_key, sub >> 1, nb);  // a new block every other sub-step
-        if (tab) quad_normals_from_block_tab(*tab, nb, (sub & 1ull) != 0, nz);          // (the same bits, from LDS)
-        else quad_normals_from_block(nb, (sub & 1ull) != 0, nz);                        // N(0,.01) | N(0,.001)
-      }
-      if (SPLIT) quad_wrench_noise(T, qb, nz, F, tau); else quad_wrench(T, cmd, nz, F, tau);
-    }
-    if (OPTS && (PLANE || (a.options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)))) {
-      V3 F2 = F + ext, tau2 = tau;
-      if (a.options & DSIM_OPT_GROUND) ground_effect_quad(T, s, cmd, F2, tau2);              // BaseAviary.py:528-529
-      if (a.options & DSIM_OPT_DRAG) {                                                        // :531-532
-        float lc[4];     // rotor speeds of the PREVIOUS action on sub-step 0 (values selected, not pointers: a pointer
-#pragma unroll           // select between two register arrays sends both to scratch)
-        for (int j = 0; j < 4; ++j) lc[j] = (k == 0 && prev) ? prev[j] : cmd[j];
-        F2 = F2 + drag_quad(T, s, lc);
-      }
-      bullet_step<PLANE>(T, a.dt_phys, s, F2, tau2);
-      continue;
-    }
-    if constexpr (BODY_OK) bullet_step_body(T, a.dt_phys, sb, F + ext, tau);      // (the loop runs: BODY holds)
-    else bullet_step(T, a.dt_phys, s, F + ext, tau);
-  }
-  if (body) body_end(sb, s);
-}
-
-// the same for the morphing hexa (BaseAviary.py:1389-1457); replay rows: f[6], m[6]
-template <bool NOISE, bool REPLAY = true, bool ONE = false, bool PLANE = false, bool LOOPED = false, class DT>
-__device__ __forceinline__ void hexa_substeps(DT& T, const StepK& a, long long i, Rigid& s,
-                                              const float cmd[6], unsigned long long step_index,
-                                              V3 ext = V3{-0.0f, -0.0f, -0.0f}, long long nid = -1,
-                                              const NoiseTab* tab = nullptr /* LDS tables of the Box-Muller pairs, or none */) {
-  const uint64_t noise_key = (uint64_t)(nid >= 0 ? nid : i);
-  V3 F, tau;
-  if (!NOISE) hexa_wrench(T, cmd, nullptr, F, tau);
-  constexpr bool SPLIT = NOISE && !ONE;
-  HexaBase hb = HexaBase{V3{0.0f, 0.0f, 0.0f}, V3{0.0f, 0.0f, 0.0f}};
-  if (SPLIT) hb = hexa_wrench_base(T, cmd);
-  // The state holds what PyBullet reports — the BASE link's centre of mass (dsim_type_params.base_offset); the composite
-  // body is integrated about its own: p = p_b - R d, v = v_b - w x (R d) in front of the sub-steps, and back behind them.
-  // The position never makes the round trip: p_b' = p_b + sum(dt v_com) + (R' d - R d) — the sub-steps move the stored
-  // position by the composite's displacement and the CHANGE of the offset is added behind them (millimetres, where
-  // subtracting and re-adding the offset itself costs two roundings at the magnitude of the position: 1.4 ulp32(x) at
-  // x = 34 m was the worst margin of the hexa kernels, 0.70 of the step's bar).  With the plane the contact geometry
-  // wants the composite's position itself.
-  if (!ONE && a.substeps <= 0) return;     // (wave-uniform) a zero-sub-step pass hands the state back bit for bit (placement trials)
-  const V3 o0 = mul(matrix_from_quat(s.q), v3(T.base_off[0], T.base_off[1], T.base_off[2]));
-  if (PLANE) s.pos = s.pos - o0;
-  s.vel = s.vel - cross(s.w, o0);
-  const int n_sub = ONE ? 1 : a.substeps;
-  constexpr bool BODY_OK = LOOPED && !ONE && !PLANE && !REPLAY;       // the looped fast instances (quad_substeps: LOOPED): dsim_device.h:bullet_step_body
-  constexpr bool BODY = BODY_OK;
-  RigidB sb = RigidB{};
-  if (BODY) sb = body_begin(s);
-  for (int k = 0; k < n_sub; ++k) {
-    if (NOISE) {
-      float nz[12];
-      if (REPLAY && a.noise_replay) {
-#pragma unroll
-        for (int j = 0; j < 12; ++j) nz[j] = a.noise_replay[((long long)k * 12 + j) * a.n_pad + i];
-      } else if ((ONE || REPLAY) && (a.options & DSIM_OPT_NOISE_FINE)) {   // (wave-uniform) the 16 + 16-bit lattice: the single-sub-step and the general instances
-        hexa_normals_fine(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);
-      } else if (tab) {
-        uint32_t c[4];
-        noise_block(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, c);
-        hexa_normals_from_block_tab(*tab, c, nz);
-      } else {
-        noise_normals<6>(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);   // N(0,.01) | N(0,.001)
-      }
-      if (SPLIT) hexa_wrench_noise(T, hb, nz, F, tau); else hexa_wrench(T, cmd, nz, F, tau);
-    }
-    if constexpr (BODY_OK) bullet_step_body(T, a.dt_phys, sb, F + ext, tau);      // (the loop runs: BODY holds)
-    else bullet_step<PLANE>(T, a.dt_phys, s, F + ext, tau);
-  }
-  if (BODY) body_end(sb, s);
-  {
-    const V3 o = mul(matrix_from_quat(s.q), v3(T.base_off[0], T.base_off[1], T.base_off[2]));
-    s.pos = s.pos + (PLANE ? o : o - o0); s.vel = s.vel + cross(s.w, o);
-  }
-}
-
-__device__ __forceinline__ long long noise_id(const StepK& a, long long i) { return a.drone_id ? (long long)a.drone_id[i] : -1LL; }
-
-// ---- fused Env.step + computeControl (the hot path) -----------------------
-// Fast form: homogeneous quad fleet, action = the controller's stored cmd, whole 256-drone tiles
-// (the launcher hands ragged tails and every other configuration to the general kernel below).
-// No per-lane branches and no bounds checks, so every access keeps the scalar-base + 32-bit
-// lane-offset form (one VGPR of addressing for all 58 accesses).
-//
-// (Measured and rejected on MI355X, 4.2 M drones: a persistent grid-stride form that prefetches
-// the next tile into registers, 266 vs 176 us, and two tiles per workgroup with both tiles' loads
-// issued up front, 190 vs 163 us — fewer, fatter waves hide HBM latency worse than 4 waves/SIMD of
-// this short kernel; forcing 4 waves/SIMD by spilling also lost, 176 vs 172 us.)
-// EXT = waypoint-table targets and/or several steps per launch; the plain single-step kernel is
-// compiled without that generality (it would cost the hot kernel registers: 128 + spills vs 121).
-// CH = DSIM_OPT_CHAINED: last_vel / last_rates are recomputed from the rigid state the previous step
-// stored (they are functions of it) instead of being read, and are not written: 184 B/drone-step.
-// ACT = an explicit action for the physics part (dsim_step_args.action: the first iteration of the example loop,
-// or a caller that overrides the controller): four more loads, clipped as CtrlAviary._preprocessAction does; the
-// controller memory keeps its own cmd.  A template flag so that the plain form does not even test the pointer.
-template <bool NOISE, bool NT, bool EXT, bool CH = false, int SUB = 0, bool ACT = false>
-__global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(StepK a) {
-  const DevType& T = a.types[0];
-  const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
-  const unsigned sl = 4u * kv_lane(a.st, threadIdx.x), tl = 4u * kv_lane(a.tg, threadIdx.x);   // bytes
-  const long long i0 = (long long)blockIdx.x * 256;                   // wave-uniform
-  float* const sb = a.st.base + kv_off(a.st, i0);                     // scalar bases
-  const float* const tb = a.tg.base + kv_off(a.tg, i0);
-  Rigid s;
-  CtrlMem<4> m;
-  Target tg;
-  // several sub-steps per launch (the examples' setting: vector-issue bound): the Box-Muller pairs from LDS tables
-  constexpr bool TAB = NOISE && (EXT || SUB != 1);
-  __shared__ NoiseTab ntab_[TAB ? 1 : 0 + 1];
-  const NoiseTab* const ntab = TAB ? &ntab_[0] : nullptr;
-  if (TAB) noise_tab_init(ntab_[0], threadIdx.x);
-  load_rigid<NT>(sb, sfs, sl, s);
-  // (Measured and rejected, round 5: the loads only the control law needs — 7 controller-memory floats, 10 targets — issued BEHIND
-  // the sub-step loop of the looped instances instead of in front of it: 80 -> 74 VGPRs, still 6 waves per SIMD, 166.9 against
-  // 164.6 us for five sub-steps; forced to 7 waves (72 VGPRs, 16 B of scratch) 171.5 us; issued at the top of the last sub-step
-  // the compiler peels that iteration: 96 VGPRs and scratch.)
-  load_mem<4, NT, CH>(sb, sfs, sl, m);
-  if (TAB) __syncthreads();
-  if (CH) { m.last_vel = s.vel; m.last_rates = mulT(matrix_from_quat(s.q), s.w); }
-  const long long i = i0 + threadIdx.x;
-  if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;    // wave-uniform scalar load
-  V3 pos_e;
-  float yaw_e;
-  if (!EXT) {
-    load_target<NT>(tb, tfs, tl, tg);
-    if (ACT) {
-      float act[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) act[j] = clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]);   // CtrlAviary.py:258-263
-      quad_substeps<NOISE ? 1 : 0, 4, false, SUB, false, -1, SUB == 0>(T, a, i, s, act, a.step_index, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
-    } else {
-      quad_substeps<NOISE ? 1 : 0, 4, false, SUB, false, -1, SUB == 0>(T, a, i, s, m.cmd, a.step_index, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);    // stored cmd is already clipped
-    }
-    if (SUB == 1) ground_watch(T, s, a.fb.counters, i < a.n);     // (the single-sub-step instances: see the end of the kernel)
-    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  } else {
-    int wp = 0;
-    if (a.wp_table) wp = a.wp_counter[i]; else load_target<NT>(tb, tfs, tl, tg);
-    for (int k = 0; k < a.n_steps; ++k) {
-      if (a.wp_table) waypoint_target(a, i, wp, tg);
-      // (wave-uniform: several sub-steps take the body-frame loop, as the looped plain instances do — at BASELINE's literal sizes
-      // these launches are one wave per SIMD and their duration IS their instruction count; one sub-step keeps the world-frame step)
-      if (a.substeps > 1) quad_substeps<NOISE ? 1 : 0, 4, false, 0, false, -1, true>(T, a, i, s, m.cmd, a.step_index + k, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
-      else quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index + k, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
-      ground_watch(T, s, a.fb.counters, i < a.n);
-      indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-      wp = waypoint_next(wp, a.n_wp);
-    }
-    if (a.wp_table) a.wp_counter[i] = wp;
-  }
-  const unsigned so = pin_lane_offset(sl);
-  store_rigid<NT>(sb, sfs, so, s);
-  store_mem<4, NT, CH>(sb, sfs, so, m);
-  // (the looped instances, at the very end: the counter's atomic between the physics and the law is a memory write in front of
-  // the law's type constants, which then arrive by VECTOR loads — 28 VGPRs of constants and a vmcnt(0) in the middle of the
-  // kernel, which a fleet of one wave per SIMD waits out in full: 4 096 quads x 5 sub-steps 6.37 -> 6.14 us per launch, 4 194 304
-  // 166.4 -> 163.7 us settled.  The single-sub-step instances keep the watch where it was: the headline kernel, on its memory
-  // floor with the constants in VGPRs, measured 153-157 us there and 161-162 us with the watch at the end — same box, two
-  // processes each, profiles/r05_ab_ground_watch_at_the_end.txt)
-  if (!EXT && SUB != 1) ground_watch(T, s, a.fb.counters, i < a.n);
-}
+// dsim_api.hip — context, reset, observation rows, trajectory sampler, deferred WLS fallbacks, noise draw, and the host-side
+// helpers every entry point shares (include/dronesim_amd.h; gfx950 only).
+#include "dsim_kernels.h"
 
 __global__ void k_counter_add(unsigned long long* c, unsigned long long inc) { *c += inc; }
 
@@ -495,1408 +20,6 @@ __global__ __launch_bounds__(256) void k_noise_draw(NoiseK a) {
     for (int j = 0; j < 2 * a.n_act; ++j)
       a.out[((long long)k * 2 * a.n_act + j) * a.n_pad + i] = nz[j] * (j < a.n_act ? 100.0f : 1000.0f);
   }
-}
-
-typedef float vf4 __attribute__((ext_vector_type(4)));        // (a native vector: what the nontemporal builtins take)
-
-// The same fast form for a homogeneous morphing-hexa fleet (6-DOF INDI, first WLS iteration in closed form,
-// infeasible drones queued for k_wls_fallback): whole tiles, stored cmd as the action, one Env.step per
-// launch.  Compiled apart from the mixed-fleet kernel, whose quad branch and per-lane options cost it
-// registers (177-252 VGPRs, 2 waves/SIMD).
-#ifndef DSIM_HEXA_WAVES
-#define DSIM_HEXA_WAVES 3
-#endif
-#ifndef DSIM_LATE_STORE_BASE
-#define DSIM_LATE_STORE_BASE 1
-#endif
-#ifndef DSIM_LATE_STORE_BASE_S1
-#define DSIM_LATE_STORE_BASE_S1 0
-#endif
-// p, as a wave-uniform value the compiler knows nothing about, available only behind `after`: the offset 0 goes through an empty
-// asm that also takes `after` in, and comes back through v_readfirstlane (which is what tells the compiler that it is uniform:
-// an asm's own output counts as divergent, and the loads behind it as per-lane loads)
-template <class P>
-__device__ __forceinline__ const P* opaque_after(const P* p, float after) {
-  int z = 0;
-  asm("" : "+v"(z) : "v"(after));
-  return reinterpret_cast<const P*>(reinterpret_cast<const char*>(p) + __builtin_amdgcn_readfirstlane(z));
-}
-template <bool NOISE, bool NT, bool S1, bool ACT = false>
-__global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
-  const DevType& T = a.types[0];
-  const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
-  const unsigned sl = 4u * kv_lane(a.st, threadIdx.x), tl = 4u * kv_lane(a.tg, threadIdx.x);
-  const long long i0 = (long long)blockIdx.x * 256;
-  float* const sb = a.st.base + kv_off(a.st, i0);
-  const float* const tb = a.tg.base + kv_off(a.tg, i0);
-  constexpr bool TAB = NOISE && !S1;          // several sub-steps per launch: the Box-Muller pairs from LDS tables (k_step_fast)
-  __shared__ NoiseTab ntab_[TAB ? 1 : 0 + 1];
-  const NoiseTab* const ntab = TAB ? &ntab_[0] : nullptr;
-  if (TAB) noise_tab_init(ntab_[0], threadIdx.x);
-  Rigid s;
-  CtrlMem<6> m;
-  Target tg;
-  load_rigid<NT>(sb, sfs, sl, s);
-  load_mem<6, NT>(sb, sfs, sl, m);
-  load_target<NT>(tb, tfs, tl, tg);
-  if (TAB) __syncthreads();
-  const long long i = i0 + threadIdx.x;
-  if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
-  V3 pos_e;
-  float yaw_e;
-  if (ACT) {
-    float act[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) act[j] = clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]);
-    hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, act, a.step_index, V3{-0.0f, -0.0f, -0.0f}, -1, ntab);
-  } else {
-    hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, m.cmd, a.step_index, V3{-0.0f, -0.0f, -0.0f}, -1, ntab);
-  }
-  indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
-  // The looped instances store through a base the compiler cannot see through, made behind the sub-steps (opaque_after): left to
-  // itself it keeps the 23 field addresses it formed for the loads (SGPR pairs) alive across the sub-step loop, runs out of SGPRs
-  // inside it and parks 46 of them in VGPR lanes — 92 v_writelane / v_readlane of the ~2 100 vector instructions a looped launch
-  // executes; formed again behind the loop they are 46 scalar adds.
-  float* const sb2 = (DSIM_LATE_STORE_BASE && (!S1 || DSIM_LATE_STORE_BASE_S1)) ? const_cast<float*>(opaque_after(sb, s.pos.x)) : sb;
-  const unsigned so = pin_lane_offset(sl);
-  store_rigid<NT>(sb2, sfs, so, s);
-  store_mem<6, NT>(sb2, sfs, so, m);
-  ground_watch(T, s, a.fb.counters, i < a.n);       // (at the very end: between the physics and the law it cost 44 VGPRs)
-}
-
-// ends a chained sequence: last_vel / last_rates back into the state block
-struct MatK { KView st; long long n_pad; };
-__global__ __launch_bounds__(256) void k_materialize(MatK a) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n_pad) return;
-  float* p = a.st.base + kv_off(a.st, i);
-  const long long fs = a.st.field_stride;
-  Rigid s;
-  load_rigid(p, fs, 0u, s);
-  const V3 wb = mulT(matrix_from_quat(s.q), s.w);
-  p[13 * fs] = s.vel.x; p[14 * fs] = s.vel.y; p[15 * fs] = s.vel.z;
-  p[16 * fs] = wb.x; p[17 * fs] = wb.y; p[18 * fs] = wb.z;
-}
-
-// Mixed fleets: every lane carries a type id, but the per-type constants must stay wave-uniform
-// (scalar loads into SGPRs: ~150 floats per type would otherwise sit in VGPRs per lane — 256 VGPRs
-// plus spills).  Waterfall: the wave peels one type per iteration with the lanes of that type active.
-#define DSIM_FOR_MY_TYPE(UNIFORM, a, i, BODY)                                   \
-  do {                                                                          \
-    if (UNIFORM) { const DevType& T = (a).types[0]; BODY; }                     \
-    else {                                                                      \
-      const int my_t_ = (a).type_id[i];                                         \
-      for (;;) {                                                                \
-        const int cur_t_ = __builtin_amdgcn_readfirstlane(my_t_);               \
-        if (my_t_ == cur_t_) { const DevType& T = (a).types[cur_t_]; BODY; break; } \
-      }                                                                         \
-    }                                                                           \
-  } while (0)
-
-// Before the waterfall, a mixed tile is PARTITIONED by type: the 256 lanes of the workgroup re-assign the
-// tile's 256 drones among themselves so that drones of one type sit in consecutive lanes (a stable counting
-// sort on the type id: per-wave ballots + popcounts, per-wave/per-type counts and the slot -> drone table in
-// LDS).  Waves become type-homogeneous except where one type's run ends inside a wave (at most n_types - 1
-// waves per tile), so the waterfall runs once instead of once per type present — in config 5 (even index
-// quad, odd index hexa) every wave would otherwise execute BOTH laws at half occupancy of its lanes.  Lanes
-// then gather their drone's fields from within the same 256-drone tile (same cache lines, HBM traffic
-// unchanged).  Everything keyed by the drone index (noise stream, per-drone buffers) is unaffected.
-// slot (lane of the workgroup) that processes this lane's natural drone: a stable counting sort of the tile on
-// the type id `my` (0..DSIM_MAX_TYPES, the last value = no drone, sorted last).  One barrier.
-template <int WAVES>
-__device__ __forceinline__ unsigned tile_dest(int my) {
-  __shared__ unsigned short cnt[WAVES][DSIM_MAX_TYPES + 1];
-  const unsigned t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const unsigned long long lt = (1ULL << lane) - 1ULL;
-  unsigned rank = 0, c_mine = 0;
-#pragma unroll
-  for (int ty = 0; ty <= DSIM_MAX_TYPES; ++ty) {
-    const unsigned long long mask = __ballot(my == ty);
-    if (my == ty) rank = (unsigned)__popcll(mask & lt);
-    if ((int)lane == ty) c_mine = (unsigned)__popcll(mask);
-  }
-  if (lane <= DSIM_MAX_TYPES) cnt[w][lane] = (unsigned short)c_mine;
-  __syncthreads();
-  unsigned dest = rank;
-  for (int ty = 0; ty <= DSIM_MAX_TYPES; ++ty) {
-#pragma unroll
-    for (unsigned ww = 0; ww < WAVES; ++ww) {
-      const unsigned c = cnt[ww][ty];
-      dest += (ty < my || (ty == my && ww < w)) ? c : 0u;
-    }
-  }
-  return dest;
-}
-__device__ __forceinline__ unsigned tile_partition(const uint8_t* type_id, long long i0, long long n_pad) {
-  __shared__ unsigned char slot2drone[256];
-  const unsigned t = threadIdx.x;
-  const int my = (i0 + t < n_pad) ? min((int)type_id[i0 + t], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;   // out of range: sorted last
-  slot2drone[tile_dest<4>(my)] = (unsigned char)t;
-  __syncthreads();
-  return slot2drone[t];
-}
-template <bool UNIFORM>
-__device__ __forceinline__ unsigned tile_slot(const uint8_t* type_id, long long i0, long long n_pad) {
-  if (UNIFORM) return threadIdx.x;
-  return tile_partition(type_id, i0, n_pad);
-}
-
-// General form: per-drone type ids (mixed quad / hexa fleets, NACT = 6), explicit action
-// override, noise replay, external force, ragged sizes.  a.first = first drone this launch covers
-// (a multiple of 256, so the scalar-base + lane-offset addressing of the fast kernel applies).
-struct Addr { float* sb; const float* tb; unsigned sl, tl; long long sfs, tfs; };
-__device__ __forceinline__ Addr make_addr(const StepK& a, long long i0, unsigned p /* drone within the tile */) {
-  Addr r;
-  r.sb = a.st.base + kv_off(a.st, i0);
-  r.tb = a.tg.base ? a.tg.base + kv_off(a.tg, i0) : nullptr;
-  r.sl = 4u * kv_lane(a.st, p);
-  r.tl = 4u * kv_lane(a.tg, p);
-  r.sfs = a.st.field_stride; r.tfs = a.tg.field_stride;
-  return r;
-}
-// FULL = false: the lean form for plain stepping of mixed fleets (stored cmd as the action, no
-// noise replay, no waypoint table, one Env.step per launch) — the options cost registers.
-template <bool NOISE, int NACT, bool FULL, bool PLANE = false, class DT>
-__device__ __forceinline__ void step_gen_body(DT& T, const StepK& a, long long i, const Addr& ad) {
-  Rigid s;
-  CtrlMem<NACT> m;
-  Target tg;
-  load_rigid(ad.sb, ad.sfs, ad.sl, s);
-  load_mem<NACT>(ad.sb, ad.sfs, ad.sl, m);
-  int wp = 0;
-  if (FULL && a.wp_table) wp = a.wp_counter[i]; else load_target(ad.tb, ad.tfs, ad.tl, tg);
-  V3 ext = v3(0, 0, 0);
-  if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
-  const int n_steps = FULL ? a.n_steps : 1;
-  for (int k = 0; k < n_steps; ++k) {
-    float act[NACT];
-#pragma unroll
-    for (int j = 0; j < NACT; ++j) act[j] = m.cmd[j];
-    if (FULL && a.action && k == 0) {    // an explicit action applies to the first Env.step only
-#pragma unroll
-      for (int j = 0; j < NACT; ++j) act[j] = a.action[(long long)j * a.n_pad + i];
-      preprocess_action<NACT>(T, act, act);   // the stored cmd is already clipped (INDIControl.py:487)
-    }
-    if (FULL && a.wp_table) waypoint_target(a, i, wp, tg);
-    V3 pos_e;
-    float yaw_e;
-    if (NACT == 6 && T.kind != DSIM_DEV_KIND_QUAD) {     // wave-uniform branch: morphing-hexa physics (both hexa kinds)
-      if constexpr (NACT == 6) {
-        hexa_substeps<NOISE, FULL, false, PLANE>(T, a, i, s, act, a.step_index + k, ext, NOISE ? noise_id(a, i) : -1LL);
-        ground_watch(T, s, a.fb.counters, i < a.n);
-        if (T.kind == DSIM_DEV_KIND_HEXA) indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
-        else indi_quad<false, 6>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);         // hexa_6DOF_simple: the quad law on six actuators
-      }
-    } else {
-      quad_substeps<NOISE ? (FULL ? 2 : 1) : 0, NACT, FULL, 0, PLANE>(T, a, i, s, act, a.step_index + k, ext, nullptr,
-                                                                      NOISE ? noise_id(a, i) : -1LL);
-      ground_watch(T, s, a.fb.counters, i < a.n);
-      indi_quad<false, NACT>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-    }
-    wp = waypoint_next(wp, a.n_wp);
-  }
-  if (FULL && a.wp_table) a.wp_counter[i] = wp;
-  store_rigid(ad.sb, ad.sfs, ad.sl, s);
-  store_mem<NACT>(ad.sb, ad.sfs, ad.sl, m);
-}
-// The full-option body with the in-kernel noise holds both laws, the replay and waypoint paths and the add-on terms:
-// compiled for 2 waves/SIMD (256 VGPRs) it spills 200-380 B of scratch per lane, and the scratch traffic (2.8 x the
-// state's bytes) costs more than the lost occupancy; those instances take the whole register file instead.
-template <bool NOISE, bool UNIFORM, int NACT>
-__global__ __launch_bounds__(256, NOISE ? 1 : DSIM_GEN_WAVES) void k_step_gen(StepK a) {
-  const long long i0 = a.first + (long long)blockIdx.x * 256;
-  const unsigned p = tile_slot<UNIFORM>(a.type_id, i0, a.n_pad);
-  const long long i = i0 + p;
-  if (i >= a.n_pad) return;
-  if (a.step_index_dev) a.step_index += *a.step_index_dev;
-  const Addr ad = make_addr(a, i0, p);
-  DSIM_FOR_MY_TYPE(UNIFORM, a, i, (step_gen_body<NOISE, NACT, true>(T, a, i, ad)));
-}
-// DSIM_OPT_PLANE: the full-option body with the ground-plane contact solve between the velocity and the position
-// update of every sub-step (dsim_device.h:plane_contact).  A landing / take-off configuration, not a flight one:
-// these instances take the whole register file rather than spill.
-template <bool NOISE, bool UNIFORM, int NACT>
-__global__ __launch_bounds__(256, 1) void k_step_plane(StepK a) {
-  const long long i0 = a.first + (long long)blockIdx.x * 256;
-  const unsigned p = tile_slot<UNIFORM>(a.type_id, i0, a.n_pad);
-  const long long i = i0 + p;
-  if (i >= a.n_pad) return;
-  if (a.step_index_dev) a.step_index += *a.step_index_dev;
-  const Addr ad = make_addr(a, i0, p);
-  DSIM_FOR_MY_TYPE(UNIFORM, a, i, (step_gen_body<NOISE, NACT, true, true>(T, a, i, ad)));
-}
-template <bool NOISE, bool UNIFORM, int NACT>
-__global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_step_lean(StepK a) {
-  const long long i0 = a.first + (long long)blockIdx.x * 256;
-  const unsigned p = tile_slot<UNIFORM>(a.type_id, i0, a.n_pad);
-  const long long i = i0 + p;
-  if (i >= a.n_pad) return;
-  if (a.step_index_dev) a.step_index += *a.step_index_dev;
-  const Addr ad = make_addr(a, i0, p);
-  DSIM_FOR_MY_TYPE(UNIFORM, a, i, (step_gen_body<NOISE, NACT, false>(T, a, i, ad)));
-}
-
-// ---- mixed fleets kept in the caller's own order (storage = "caller") ----------------------------------------------------------
-// A tile is partitioned by type so that every wave runs ONE law in uniform control flow, and staged through LDS so that HBM
-// only ever sees whole lines.  Two forms serve the product: k_step_mixed4 (wave-tiled layout: two waves per tile, LDS-DMA
-// staging) and k_step_mixed3 (any other layout: row DMAs).  Round 1's VGPR-staged form and round 2's persistent LDS-DMA ring
-// were measured slower and live in tools/variants/ (built only with -DDSIM_WITH_VARIANTS).
-// select-the-r-th-set-bit: lane r of a compute wave finds the r-th drone of its type in the tile's ballot masks
-__device__ __forceinline__ unsigned nth_set_bit64(unsigned long long m, unsigned r) {     // position of the r-th (0-based) set bit
-  unsigned pos = 0;
-  unsigned w = (unsigned)m;
-  unsigned c = (unsigned)__popc(w);
-  if (r >= c) { r -= c; pos = 32; w = (unsigned)(m >> 32); }
-#pragma unroll
-  for (int sh = 16; sh >= 1; sh >>= 1) {
-    const unsigned lo = w & ((1u << sh) - 1u);
-    c = (unsigned)__popc(lo);
-    if (r >= c) { r -= c; pos += sh; w >>= sh; } else { w = lo; }
-  }
-  return pos;
-}
-// LDS image of one 64-drone block: the block's rows as they lie in the wave-tiled state / target arrays
-// ([F][64] floats, field rows contiguous), so that a 16-byte-per-lane DMA moves four rows at once.  Both row groups
-// are padded to a multiple of four rows: the last DMA of each group (rows 24-25 / 8-9) runs with ALL lanes active, its
-// upper half re-reading the same two rows into the padding.  (An exec-masked DMA under `if (lane < 32)` is a hazard:
-// the LDS destination of an LDS-DMA is wave-uniform (M0), and the compiler's tail merging of the two sides of such a
-// branch produced ONE instruction with a per-lane "uniform" destination resolved by v_readfirstlane — half the wave's
-// rows landed in the wrong place.  No DMA in this file sits under a per-lane branch.)
-struct Stage64 { float st[DSIM_NF_HEXA + 2][64]; float tg[DSIM_NT + 2][64]; };       // 28 + 12 rows = 10 KB
-// the 7 + 3 DMAs of 1 KB that bring one 64-drone block (26 state rows, 10 target rows) into a Stage64
-template <int AUX>
-__device__ __forceinline__ void dma_block64(const float* state_block, const float* target_block, Stage64& dst, unsigned lane) {
-  const float* sp = state_block + 4 * lane;            // 16 bytes per lane
-  const float* tp = target_block + 4 * lane;
-  const unsigned fold = 4 * (lane & 31u);              // last DMA of a group: lanes 32..63 re-read what lanes 0..31 read
-  float* ls = &dst.st[0][0];
-  float* lt = &dst.tg[0][0];
-#pragma unroll
-  for (int q = 0; q < 6; ++q) __builtin_amdgcn_global_load_lds(sp + 256 * q, ls + 256 * q, 16, 0, AUX);
-  __builtin_amdgcn_global_load_lds(state_block + 256 * 6 + fold, ls + 256 * 6, 16, 0, AUX);        // rows 24, 25 (+ padding)
-  __builtin_amdgcn_global_load_lds(tp, lt, 16, 0, AUX);
-  __builtin_amdgcn_global_load_lds(tp + 256, lt + 256, 16, 0, AUX);
-  __builtin_amdgcn_global_load_lds(target_block + 512 + fold, lt + 512, 16, 0, AUX);                // rows 8, 9 (+ padding)
-}
-template <bool HEXA, bool NOISE, bool S1, class DT>
-__device__ __forceinline__ void staged_body2(DT& T, const StepK& a, long long i, Stage64* tile, unsigned d,
-                                             bool active) {
-  constexpr int NA = HEXA ? 6 : 4;
-  float (*st)[64] = tile[d >> 6].st;
-  float (*tt)[64] = tile[d >> 6].tg;
-  const unsigned c = d & 63u;
-  Rigid s;
-  CtrlMem<NA> m;
-  Target tg;
-  s.pos = v3(st[0][c], st[1][c], st[2][c]);
-  s.q = Q4{st[3][c], st[4][c], st[5][c], st[6][c]};
-  s.vel = v3(st[7][c], st[8][c], st[9][c]);
-  s.w = v3(st[10][c], st[11][c], st[12][c]);
-  m.last_vel = v3(st[13][c], st[14][c], st[15][c]);
-  m.last_rates = v3(st[16][c], st[17][c], st[18][c]);
-  m.last_thrust = st[19][c];
-#pragma unroll
-  for (int j = 0; j < NA; ++j) m.cmd[j] = st[20 + j][c];
-  tg.pos = v3(tt[0][c], tt[1][c], tt[2][c]);
-  tg.vel = v3(tt[3][c], tt[4][c], tt[5][c]);
-  tg.acc = v3(tt[6][c], tt[7][c], tt[8][c]);
-  tg.yaw = tt[9][c];
-  V3 ext = v3(0, 0, 0);
-  if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
-  V3 pos_e;
-  float yaw_e;
-  if constexpr (HEXA) {
-    hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, m.cmd, a.step_index, ext);
-    indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, active ? i : -1LL);
-  } else {
-    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0, false, -1, !S1>(T, a, i, s, m.cmd, a.step_index, ext);
-    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  }
-  ground_watch(T, s, a.fb.counters, active && i < a.n);      // (behind the law: in front of it it costs registers)
-  if (!active) return;
-  st[0][c] = s.pos.x; st[1][c] = s.pos.y; st[2][c] = s.pos.z;
-  st[3][c] = s.q.x; st[4][c] = s.q.y; st[5][c] = s.q.z; st[6][c] = s.q.w;
-  st[7][c] = s.vel.x; st[8][c] = s.vel.y; st[9][c] = s.vel.z;
-  st[10][c] = s.w.x; st[11][c] = s.w.y; st[12][c] = s.w.z;
-  st[13][c] = m.last_vel.x; st[14][c] = m.last_vel.y; st[15][c] = m.last_vel.z;
-  st[16][c] = m.last_rates.x; st[17][c] = m.last_rates.y; st[18][c] = m.last_rates.z;
-  st[19][c] = m.last_thrust;
-#pragma unroll
-  for (int j = 0; j < NA; ++j) st[20 + j][c] = m.cmd[j];
-}
-#define DSIM_MIXED2_TYPES 4            // the launcher takes this form for tables of up to four types
-// ---- mixed fleets, third form: one tile per workgroup, LDS-DMA staging, partition by ballots ---------------------------
-// The ring above keeps a tile per workgroup in flight at all times, but its 37 KB of LDS leave a CU only 12 waves, and
-// with two barriers per tile three waves per SIMD cannot keep the vector pipe busy: it measured SLOWER (227 us) than the
-// first form (211 us) at 4 194 304 drones.  What the first form lacks is waves, not prefetch depth: this form keeps its
-// one-tile-per-workgroup shape (the hardware overlaps workgroups) and removes what limits their number and speed —
-//   * staging in NATURAL drone order by LDS-DMA (no VGPR round trip, no staging ds_writes): 18 KB instead of 27.6 KB
-//     per workgroup, so a CU holds 8 of them instead of 5;
-//   * the partition by type needs no LDS table and no barrier (every wave ballots the tile's type ids itself and finds
-//     its drones by select-the-r-th-set-bit, as in the ring): two barriers per tile instead of three.
-// TILED: wave-tiled layout (rows of a block contiguous) -> 10 DMAs of 1 KB per half; otherwise 36 row DMAs of 256 B.
-template <bool NOISE, bool NT, int WT, bool S1, bool TILED>
-__global__ __launch_bounds__(64 * WT, S1 ? 4 : 3) void k_step_mixed3(StepK a) {
-  constexpr int TILE = 128;
-  __shared__ __attribute__((aligned(16))) Stage64 tile[2];                  // [half]: 20 KB
-  const unsigned t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const long long i0 = a.first + (long long)blockIdx.x * TILE;
-  if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
-  constexpr int AUX = NT ? 2 : 0;
-  const long long ih = i0 + 64 * (long long)w;
-  if (w < 2 && ih < a.n_pad) {                                              // each natural wave brings its own half in
-    if (TILED) {
-      dma_block64<AUX>(a.st.base + (ih >> 6) * a.st.block_stride, a.tg.base + (ih >> 6) * a.tg.block_stride, tile[w], lane);
-    } else {
-      const long long il = ih + lane;
-      const float* sp = a.st.base + kv_off(a.st, il);
-      const float* tp = a.tg.base + kv_off(a.tg, il);                       // (a broadcast row: kv_off = 0 for every lane)
-      const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
-      // (all 26 rows for every lane — quads' rows 24, 25 are unused words of the 26-field state: no DMA under a
-      // per-lane branch, see Stage64)
-#pragma unroll
-      for (int f = 0; f < 26; ++f) __builtin_amdgcn_global_load_lds(sp + f * sfs, &tile[w].st[f][0], 4, 0, AUX);
-#pragma unroll
-      for (int f = 0; f < 10; ++f) __builtin_amdgcn_global_load_lds(tp + f * tfs, &tile[w].tg[f][0], 4, 0, AUX);
-    }
-  }
-  // ---- partition (overlaps the DMAs): every wave ballots both halves itself; the masks are wave-uniform (SGPRs)
-  const int t0 = (i0 + lane < a.n_pad) ? min((int)a.type_id[i0 + lane], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
-  const int t1 = (i0 + 64 + lane < a.n_pad) ? min((int)a.type_id[i0 + 64 + lane], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
-  int wave_t = -1;
-  unsigned d = 0;
-  bool active = false;
-  unsigned acc_w = 0;
-#pragma unroll
-  for (int ty = 0; ty < DSIM_MIXED2_TYPES; ++ty) {
-    const unsigned long long m0 = __ballot(t0 == ty), m1 = __ballot(t1 == ty);
-    const unsigned c0 = (unsigned)__popcll(m0), tot = c0 + (unsigned)__popcll(m1), nw = (tot + 63) >> 6;
-    if (w >= acc_w && w < acc_w + nw) {                             // wave-uniform: this wave runs type ty
-      wave_t = ty;
-      const unsigned r = (w - acc_w) * 64 + lane;
-      active = r < tot;
-      const unsigned rr = active ? r : 0u;
-      d = rr < c0 ? nth_set_bit64(m0, rr) : 64u + nth_set_bit64(m1, rr - c0);
-    }
-    acc_w += nw;
-  }
-  wave_t = __builtin_amdgcn_readfirstlane(wave_t);
-  __builtin_amdgcn_s_waitcnt(0x0f70);                               // vmcnt(0): this wave's DMAs have landed
-  __syncthreads();
-  if (wave_t >= 0) {
-    const long long i = i0 + d;
-    CDevType& T = dev_type(a.types, wave_t);     // (constant address space, dsim_device.h: 122-156 -> 97-102 VGPRs, 238 -> 210 us)
-    if (T.kind == DSIM_DEV_KIND_HEXA) staged_body2<true, NOISE, S1>(T, a, i, tile, d, active);
-    else staged_body2<false, NOISE, S1>(T, a, i, tile, d, active);
-  }
-  __syncthreads();
-  if (t < TILE && i0 + t < a.n_pad) {
-    const bool nat_hexa = (a.hexa_types >> min((int)a.type_id[i0 + t], DSIM_MAX_TYPES - 1)) & 1u;   // (re-read: not kept live)
-    float* sp = a.st.base + kv_off(a.st, i0 + t);
-    const long long sfs = a.st.field_stride;
-    float (*rows)[64] = tile[w].st;
-#pragma unroll
-    for (int f = 0; f < 24; ++f) stg<NT>(sp + f * sfs, 0u, rows[f][lane]);
-    if (nat_hexa) { stg<NT>(sp + 24 * sfs, 0u, rows[24][lane]); stg<NT>(sp + 25 * sfs, 0u, rows[25][lane]); }
-    if (a.bin.count && i0 + t < a.n)
-      bin_entry(a.bin, rows[0][lane], rows[1][lane], rows[2][lane], a.bin.local_offset + i0 + t);
-  }
-}
-
-// ---- mixed fleets, fourth form: TWO waves per 128-drone tile ------------------------------------------------------------
-// Counters of the third form at 4 194 304 drones (profiles/r02_mixed_summary.json): waves parked 70 % of their cycles,
-// vector ALU 16 % — a latency-bound kernel, and what bounds it is the number of drones a CU has in flight: 5 workgroups
-// x 128 drones against the 28 waves x 64 drones of the single-type kernels.  A third of the form's waves are the
-// SPARE waves, which exist so that every type can start at a wave boundary and which, in a 64 / 64 tile, do nothing but
-// hold a wave slot and its registers for the workgroup's lifetime.  Here a workgroup is the two natural waves only; the
-// slot groups (whole waves of one type, as before) are dealt to them round-robin, so a tile that needs a third group
-// (65 + 63, or three types) costs one of its waves a second pass instead of costing EVERY tile a third wave.  With
-// the unpadded LDS image (18.4 KB) a CU holds 8 workgroups = 1 024 drones.
-// (Measured and rejected, round 2: NO staging — the slot permutation applied to the lane offset of the single-type
-// kernels' addressing, so that no LDS image bounds the drones in flight and no barrier sits in a workgroup's lifetime.
-// A slot group's lanes then use every other dword of four 128-byte lines per instruction, and every line is requested
-// by both waves of the tile: 421 us with streaming accesses (partial-line writes), 278 us with the default policy,
-// against 199 us for this form — the staging buys whole-line traffic, which is worth more than the occupancy.  Its
-// other lesson is kept: two inlined laws behind one branch need ~113 VGPRs where each alone needs 72-75, and a loop
-// around them makes the compiler hoist all 36 field addresses into SGPR pairs until the scalar file spills.)
-struct Stage64u { float st[DSIM_NF_HEXA][64]; float tg[DSIM_NT][64]; };      // 26 + 10 rows, no padding: 9 KB
-template <int AUX>
-__device__ __forceinline__ void dma_block64u(const float* state_block, const float* target_block, Stage64u& dst, unsigned lane) {
-  const float* sp = state_block + 4 * lane;            // 16 bytes per lane: four rows per DMA
-  const float* tp = target_block + 4 * lane;
-  float* ls = &dst.st[0][0];
-  float* lt = &dst.tg[0][0];
-#pragma unroll
-  for (int q = 0; q < 6; ++q) __builtin_amdgcn_global_load_lds(sp + 256 * q, ls + 256 * q, 16, 0, AUX);
-  __builtin_amdgcn_global_load_lds(state_block + 24 * 64 + lane, ls + 24 * 64, 4, 0, AUX);          // rows 24, 25: one row each
-  __builtin_amdgcn_global_load_lds(state_block + 25 * 64 + lane, ls + 25 * 64, 4, 0, AUX);
-  __builtin_amdgcn_global_load_lds(tp, lt, 16, 0, AUX);
-  __builtin_amdgcn_global_load_lds(tp + 256, lt + 256, 16, 0, AUX);
-  __builtin_amdgcn_global_load_lds(target_block + 8 * 64 + lane, lt + 8 * 64, 4, 0, AUX);           // rows 8, 9
-  __builtin_amdgcn_global_load_lds(target_block + 9 * 64 + lane, lt + 9 * 64, 4, 0, AUX);
-}
-template <bool HEXA, bool NOISE, bool S1, bool BIN, class DT>
-__device__ __forceinline__ void staged_body4(DT& T, const StepK& a, long long i, Stage64u* tile, unsigned d,
-                                             bool active) {
-  constexpr int NA = HEXA ? 6 : 4;
-  float (*st)[64] = tile[d >> 6].st;
-  float (*tt)[64] = tile[d >> 6].tg;
-  unsigned c = d & 63u;
-  Rigid s;
-  CtrlMem<NA> m;
-  Target tg;
-  s.pos = v3(st[0][c], st[1][c], st[2][c]);
-  s.q = Q4{st[3][c], st[4][c], st[5][c], st[6][c]};
-  s.vel = v3(st[7][c], st[8][c], st[9][c]);
-  s.w = v3(st[10][c], st[11][c], st[12][c]);
-#pragma unroll
-  for (int j = 0; j < NA; ++j) m.cmd[j] = st[20 + j][c];
-  V3 ext = v3(0, 0, 0);
-  if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
-  V3 pos_e;
-  float yaw_e;
-  if constexpr (HEXA) hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, m.cmd, a.step_index, ext);
-  else quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0, false, -1, !S1>(T, a, i, s, m.cmd, a.step_index, ext);
-  // what only the law reads — the rest of the controller memory and the targets — comes out of LDS BEHIND the sub-steps
-  // (tied to their result): read in front of them it is 17 registers held through the physics
-  asm volatile("" : "+v"(c) : "v"(s.pos.z));
-  int bcell = 0, bslot = -1;                                  // next step's neighbour grid: reserve the slot now
-  const bool binning = BIN && active && i < a.n;              // (BIN instances are launched when a.bin.count is set)
-  if (binning) bslot = bin_reserve(a.bin, s.pos.x, s.pos.y, bcell);
-  m.last_vel = v3(st[13][c], st[14][c], st[15][c]);
-  m.last_rates = v3(st[16][c], st[17][c], st[18][c]);
-  m.last_thrust = st[19][c];
-  tg.pos = v3(tt[0][c], tt[1][c], tt[2][c]);
-  tg.vel = v3(tt[3][c], tt[4][c], tt[5][c]);
-  tg.acc = v3(tt[6][c], tt[7][c], tt[8][c]);
-  tg.yaw = tt[9][c];
-  if constexpr (HEXA) indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, active ? i : -1LL);
-  else indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  ground_watch(T, s, a.fb.counters, active && i < a.n);      // (behind the law: in front of it it costs registers)
-  if (!active) return;
-  st[0][c] = s.pos.x; st[1][c] = s.pos.y; st[2][c] = s.pos.z;
-  st[3][c] = s.q.x; st[4][c] = s.q.y; st[5][c] = s.q.z; st[6][c] = s.q.w;
-  st[7][c] = s.vel.x; st[8][c] = s.vel.y; st[9][c] = s.vel.z;
-  st[10][c] = s.w.x; st[11][c] = s.w.y; st[12][c] = s.w.z;
-  st[13][c] = m.last_vel.x; st[14][c] = m.last_vel.y; st[15][c] = m.last_vel.z;
-  st[16][c] = m.last_rates.x; st[17][c] = m.last_rates.y; st[18][c] = m.last_rates.z;
-  st[19][c] = m.last_thrust;
-#pragma unroll
-  for (int j = 0; j < NA; ++j) st[20 + j][c] = m.cmd[j];
-  if (binning) bin_commit(a.bin, bcell, bslot, s.pos.x, s.pos.y, s.pos.z, a.bin.local_offset + i);
-}
-// wave-tiled layout only (state of 26 fields and per-drone targets, as for the ring); up to DSIM_MIXED2_TYPES types
-// NTY = number of types in the table (2..4): the ballot loop and the group bookkeeping are sized for it
-template <bool NOISE, bool NT, bool S1, int NTY, bool BIN>
-__global__ __launch_bounds__(128, S1 ? 4 : 3) void k_step_mixed4(StepK a) {
-  constexpr int TILE = 128;
-  __shared__ __attribute__((aligned(16))) Stage64u tile[2];                 // [half]: 18.4 KB
-  const unsigned t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;     // (w: an SGPR, so is the group loop)
-  const long long i0 = a.first + (long long)blockIdx.x * TILE;
-  if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
-  constexpr int AUX = NT ? 2 : 0;
-  const long long ih = i0 + 64 * (long long)w;
-  if (ih < a.n_pad)                                                         // each wave brings its own half in
-    dma_block64u<AUX>(a.st.base + (ih >> 6) * a.st.block_stride, a.tg.base + (ih >> 6) * a.tg.block_stride, tile[w], lane);
-  // ---- partition (overlaps the DMAs): both waves ballot both halves; masks and counts are wave-uniform (SGPRs)
-  const int t0 = (i0 + lane < a.n_pad) ? min((int)a.type_id[i0 + lane], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
-  const int t1 = (i0 + 64 + lane < a.n_pad) ? min((int)a.type_id[i0 + 64 + lane], DSIM_MAX_TYPES - 1) : DSIM_MAX_TYPES;
-  unsigned long long m0[NTY], m1[NTY];
-  unsigned g0[NTY + 1];                                       // first slot group of each type
-  unsigned long long hexa_mine = 0;                           // the hexas of this wave's own half (for the store phase)
-  g0[0] = 0;
-#pragma unroll
-  for (int ty = 0; ty < NTY; ++ty) {
-    m0[ty] = __ballot(t0 == ty); m1[ty] = __ballot(t1 == ty);
-    g0[ty + 1] = g0[ty] + (((unsigned)__popcll(m0[ty]) + (unsigned)__popcll(m1[ty]) + 63u) >> 6);
-    if ((a.hexa_types >> ty) & 1u) hexa_mine |= w ? m1[ty] : m0[ty];
-  }
-  __builtin_amdgcn_s_waitcnt(0x0f70);                               // vmcnt(0): this wave's DMAs have landed
-  __syncthreads();
-  // ---- the slot groups, dealt round-robin to the two waves: group g of type ty = its drones of rank 64 (g - g0[ty]) ...
-  for (unsigned g = w; g < g0[NTY]; g += 2) {
-    int ty = 0;
-#pragma unroll
-    for (int k = 1; k < NTY; ++k) ty += (g >= g0[k]) ? 1 : 0;
-    ty = __builtin_amdgcn_readfirstlane(ty);
-    unsigned long long ma = 0, mb = 0;
-#pragma unroll
-    for (int k = 0; k < NTY; ++k) if (k == ty) { ma = m0[k]; mb = m1[k]; }
-    const unsigned c0 = (unsigned)__popcll(ma), tot = c0 + (unsigned)__popcll(mb);
-    const unsigned r = (g - g0[ty]) * 64 + lane;
-    const bool active = r < tot;
-    const unsigned rr = active ? r : 0u;
-    const unsigned d = rr < c0 ? nth_set_bit64(ma, rr) : 64u + nth_set_bit64(mb, rr - c0);
-    const long long i = i0 + d;
-    CDevType& T = dev_type(a.types, ty);         // (constant address space, dsim_device.h: 192 -> 182 us)
-    if (T.kind == DSIM_DEV_KIND_HEXA) staged_body4<true, NOISE, S1, BIN>(T, a, i, tile, d, active);
-    else staged_body4<false, NOISE, S1, BIN>(T, a, i, tile, d, active);
-  }
-  __syncthreads();
-  if (i0 + t < a.n_pad) {
-    const bool nat_hexa = (hexa_mine >> lane) & 1ull;           // (from the ballots: no second read of type_id in front of the stores)
-    float* sp = a.st.base + ((i0 + t) >> 6) * a.st.block_stride + lane;
-    float (*rows)[64] = tile[w].st;
-#pragma unroll
-    for (int f = 0; f < 24; ++f) stg<NT>(sp + f * 64, 0u, rows[f][lane]);
-    if (nat_hexa) { stg<NT>(sp + 24 * 64, 0u, rows[24][lane]); stg<NT>(sp + 25 * 64, 0u, rows[25][lane]); }
-  }
-}
-
-// Kernels that loop over several sub-steps take the Box-Muller pairs of the rotor noise from LDS tables (NoiseTab, dsim_device.h:
-// bit-identical to direct evaluation): filled by the whole workgroup before any lane leaves.  `ntab` = the tables, or null.
-#define DSIM_NOISE_TAB(ON, THREADS)                                                                  \
-  __shared__ NoiseTab ntab_[1];                                                                      \
-  const NoiseTab* const ntab = (ON) ? &ntab_[0] : nullptr;                                           \
-  if (ON) {                                                                                          \
-    for (unsigned e_ = threadIdx.x; e_ < 256u; e_ += (THREADS)) noise_tab_init(ntab_[0], e_);        \
-    __syncthreads();                                                                                 \
-  }
-// Type-major storage (dsim_step_args.runs): a run of one type is stepped by the single-type law of its kind,
-// the fast form (no partition, no waterfall, per-type constants in SGPRs); ext = optional downwash force.
-// ACT: an explicit action for the physics part (dsim_step_args.action: the first iteration of the example loop), clipped as
-// CtrlAviary._preprocessAction does; the controller memory keeps its own cmd (k_step_runs only: a template flag, as in k_step_fast)
-// KIND: DSIM_DEV_KIND_* of the run's type — 2 = morphing-hexa physics with the quad law on its six actuators
-template <int KIND, bool NOISE, bool NT, bool S1, bool ACT = false>
-__device__ __forceinline__ void run_body(const StepK& a, long long i0, long long lo, long long last, int run_type,
-                                         const NoiseTab* tab = nullptr) {
-  constexpr bool HEXA = KIND != DSIM_DEV_KIND_QUAD;            // six actuators, morphing-hexa physics
-  const long long i = i0 + threadIdx.x;
-  if (i >= last || i < lo) return;          // (a run may begin and end inside a tile: the neighbouring run's lanes take the rest)
-  // (the constant address space — dsim_device.h, as in the two-call run kernels — costs THIS body SGPR spills and a scratch
-  // reservation: k_step_runs 166.9 against 162.7 us on the interleaved fleet, same-box A/B; and it buys a fleet of one wave per
-  // SIMD, which waits out every vector load of a constant in full, nothing either: config 5's chain 45.4 us both ways, round 5)
-  const DevType& T = a.types[run_type];
-  const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
-  const unsigned sl = 4u * kv_lane(a.st, threadIdx.x), tl = 4u * kv_lane(a.tg, threadIdx.x);
-  float* const sb = a.st.base + kv_off(a.st, i0);
-  const float* const tb = a.tg.base + kv_off(a.tg, i0);
-  constexpr int NA = HEXA ? 6 : 4;
-  Rigid s;
-  CtrlMem<NA> m;
-  Target tg;
-  load_rigid<NT>(sb, sfs, sl, s);
-  load_mem<NA, NT>(sb, sfs, sl, m);
-  load_target<NT>(tb, tfs, tl, tg);
-  V3 ext = v3(0, 0, 0);
-  if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
-  unsigned long long step_index = a.step_index;
-  if (NOISE && a.step_index_dev) step_index += *a.step_index_dev;
-  V3 pos_e;
-  float yaw_e;
-  const long long nid = NOISE ? noise_id(a, i) : -1LL;
-  float act[NA];
-#pragma unroll
-  for (int j = 0; j < NA; ++j) act[j] = ACT ? clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]) : m.cmd[j];   // CtrlAviary.py:258-263
-  if constexpr (HEXA) {
-    hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, act, step_index, ext, nid, tab);
-    if constexpr (KIND == DSIM_DEV_KIND_HEXA) indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
-    else indi_quad<false, 6>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  } else {
-    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0, false, -1, !S1>(T, a, i, s, act, step_index, ext, nullptr, nid, tab);
-    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  }
-  const unsigned so = pin_lane_offset(sl);
-  float* const sb2 = (DSIM_LATE_STORE_BASE && !S1) ? const_cast<float*>(opaque_after(sb, s.pos.x)) : sb;   // (k_step_hexa: the field addresses formed again behind the loop)
-  store_rigid<NT>(sb2, sfs, so, s);
-  store_mem<NA, NT>(sb2, sfs, so, m);
-  ground_watch(T, s, a.fb.counters, i < a.n);
-  // (measured and dropped: reserving the slot of the next grid right behind the physics, so that the atomic's round trip
-  // rides under the control law — 45.4 against 45.7 us for the config-5 chain, and 36 bytes of scratch in two instances)
-  if (a.bin.count && i < a.n) bin_entry(a.bin, s.pos.x, s.pos.y, s.pos.z, a.bin.local_offset + i);   // next step's grid
-}
-template <int KIND, bool NOISE, bool NT, bool S1>
-__global__ __launch_bounds__(256, KIND ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void k_step_run(StepK a) {
-  DSIM_NOISE_TAB(NOISE && !S1, 256);
-  run_body<KIND, NOISE, NT, S1>(a, a.first + (long long)blockIdx.x * 256, a.lo, a.last, a.run_type, ntab);
-}
-// All the runs of a type-major fleet in ONE launch: a workgroup finds its run by its index (constant-index walk over the
-// table, everything wave-uniform) and runs that run's law.  A 65 536-drone shard of BASELINE config 5 is two runs of 128
-// workgroups: 9.5 + 9.0 us as two dependent launches, 12.0 us as one; at 4 194 304 drones 160.1 against 165.2 us.  One
-// launch per run (k_step_run) serves fleets with a single run (and more than DSIM_MAX_TYPES of them).
-struct RunTab {
-  int blk0[DSIM_MAX_TYPES + 1];            // first workgroup of run q (blk0[q] = the total for q >= n_runs)
-  long long first[DSIM_MAX_TYPES], lo[DSIM_MAX_TYPES], last[DSIM_MAX_TYPES];
-  int type[DSIM_MAX_TYPES];
-  unsigned hexa_mask;        // bit q: run q flies morphing-hexa physics (six actuators: DSIM_KIND_HEXA6DOF and _HEXA_QUADLAW)
-  unsigned quadlaw6_mask;    // bit q: ... with the quad law on its six actuators (DSIM_KIND_HEXA_QUADLAW: k_control_runs)
-  // null: workgroup b serves the runs one after the other (blk0).  Else [blocks] device ints, (tile << 3) | run: the runs are
-  // served SIDE BY SIDE, each at a rate proportional to its size.  For DSIM_OPT_CALLER_IO: a drone's outputs go to its caller
-  // index, and the drones of every run are spread over the caller's whole range (even index quad, odd index hexa ...), so
-  // one run alone fills every other 88-byte row, every other dword of the command arrays — partial memory bursts, which
-  // cost a read-modify-write each (measured: Env.step of 4 194 304 interleaved drones 351 us run after run).  Side by
-  // side, the runs' halves of a line arrive within microseconds of each other and meet in the memory-side cache.
-  const int* block_map;
-};
-// the run a workgroup belongs to: constant-index walk over the table, everything wave-uniform (SGPRs).  A macro, not a
-// function: a kernel argument handed on by reference is copied to scratch (264 bytes per lane) before the walk.
-struct RunOf { long long i0, lo, last; int type; bool hexa, quadlaw6; };
-#define DSIM_RUN_OF_BLOCK(rt, ro, BIDX)                                                                             \
-  RunOf ro;                                                                                                         \
-  {                                                                                                                 \
-    const int bidx_ = __builtin_amdgcn_readfirstlane((int)(BIDX));                                                  \
-    int r_ = 0, tile_ = -1;                                                                                         \
-    if (rt.block_map) { const int e_ = rt.block_map[bidx_]; r_ = e_ & 7; tile_ = e_ >> 3; }                         \
-    else { _Pragma("unroll") for (int q = 1; q < DSIM_MAX_TYPES; ++q) if (bidx_ >= rt.blk0[q]) r_ = q; }            \
-    r_ = __builtin_amdgcn_readfirstlane(r_);                                                                        \
-    long long first_ = rt.first[0];                                                                                 \
-    int b0_ = rt.blk0[0];                                                                                           \
-    ro.lo = rt.lo[0]; ro.last = rt.last[0]; ro.type = rt.type[0];                                                   \
-    _Pragma("unroll") for (int q = 1; q < DSIM_MAX_TYPES; ++q)                                                      \
-      if (q == r_) { first_ = rt.first[q]; ro.lo = rt.lo[q]; ro.last = rt.last[q]; ro.type = rt.type[q]; b0_ = rt.blk0[q]; } \
-    if (!rt.block_map) tile_ = bidx_ - b0_;                                                                         \
-    ro.i0 = first_ + (long long)__builtin_amdgcn_readfirstlane(tile_) * 256;                                        \
-    ro.hexa = (rt.hexa_mask >> r_) & 1u;                                                                            \
-    ro.quadlaw6 = (rt.quadlaw6_mask >> r_) & 1u;                                                                    \
-    if (tile_ < 0) ro.last = ro.lo = 0;                 /* a padding entry of the map: nothing to serve */          \
-  }
-template <bool NOISE, bool NT, bool S1, bool ACT>
-__global__ __launch_bounds__(256, 3) void k_step_runs(StepK a, RunTab rt) {
-  DSIM_RUN_OF_BLOCK(rt, ro, blockIdx.x);
-  DSIM_NOISE_TAB(NOISE && !S1 && !ACT, 256);       // (the explicit-action instances: one step of an example loop; with the tables they spill)
-  if (ro.hexa) run_body<DSIM_DEV_KIND_HEXA, NOISE, NT, S1, ACT>(a, ro.i0, ro.lo, ro.last, ro.type, ntab);
-  else run_body<DSIM_DEV_KIND_QUAD, NOISE, NT, S1, ACT>(a, ro.i0, ro.lo, ro.last, ro.type, ntab);
-}
-
-// ---- Env.step only ---------------------------------------------------------
-template <bool NOISE, int NACT, bool PLANE = false, class DT>
-__device__ __forceinline__ void physics_gen_body(DT& T, const StepK& a, long long i, const Addr& ad) {
-  Rigid s;
-  load_rigid(ad.sb, ad.sfs, ad.sl, s);
-  float raw[NACT], cmd[NACT];
-#pragma unroll
-  for (int j = 0; j < NACT; ++j) raw[j] = a.action ? a.action[(long long)j * a.n_pad + i] : ldg<false>(ad.sb + (20 + j) * ad.sfs, ad.sl);
-  preprocess_action<NACT>(T, raw, cmd);
-  V3 ext = v3(0, 0, 0);
-  if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
-  if (NACT == 6 && T.kind != DSIM_DEV_KIND_QUAD) {
-    if constexpr (NACT == 6) hexa_substeps<NOISE, true, false, PLANE>(T, a, i, s, cmd, a.step_index, ext, NOISE ? noise_id(a, i) : -1LL);
-  } else {
-    float prev[4];       // last_clipped_action of the previous step (drag of sub-step 0); this step's action without it
-#pragma unroll
-    for (int j = 0; j < 4; ++j) prev[j] = a.echo ? a.echo[(long long)j * a.n_pad + i] : cmd[j];
-    quad_substeps<NOISE ? 2 : 0, NACT, true, 0, PLANE>(T, a, i, s, cmd, a.step_index, ext, prev, NOISE ? noise_id(a, i) : -1LL);
-  }
-  ground_watch(T, s, a.fb.counters, i < a.n);
-  store_rigid(ad.sb, ad.sfs, ad.sl, s);
-  if (a.echo) {
-#pragma unroll
-    for (int j = 0; j < NACT; ++j) a.echo[(long long)j * a.n_pad + i] = cmd[j];   // last_clipped_action, BaseAviary.py:545
-  }
-}
-template <bool NOISE, bool UNIFORM, int NACT>
-__global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_physics_gen(StepK a) {
-  const long long i0 = (long long)blockIdx.x * 256;
-  const unsigned p = tile_slot<UNIFORM>(a.type_id, i0, a.n_pad);
-  const long long i = i0 + p;
-  if (i >= a.n_pad) return;
-  const Addr ad = make_addr(a, i0, p);
-  DSIM_FOR_MY_TYPE(UNIFORM, a, i, (physics_gen_body<NOISE, NACT>(T, a, i, ad)));
-}
-template <bool NOISE, bool UNIFORM, int NACT>
-__global__ __launch_bounds__(256, 1) void k_physics_plane(StepK a) {     // DSIM_OPT_PLANE (see k_step_plane)
-  const long long i0 = (long long)blockIdx.x * 256;
-  const unsigned p = tile_slot<UNIFORM>(a.type_id, i0, a.n_pad);
-  const long long i = i0 + p;
-  if (i >= a.n_pad) return;
-  const Addr ad = make_addr(a, i0, p);
-  DSIM_FOR_MY_TYPE(UNIFORM, a, i, (physics_gen_body<NOISE, NACT, true>(T, a, i, ad)));
-}
-
-// ---- computeControl only ----------------------------------------------------
-template <int NACT, class DT>
-__device__ __forceinline__ void control_gen_body(DT& T, const StepK& a, long long i, const Addr& ad) {
-  Rigid s;
-  CtrlMem<NACT> m;
-  Target tg;
-  load_rigid(ad.sb, ad.sfs, ad.sl, s);
-  load_mem<NACT>(ad.sb, ad.sfs, ad.sl, m);
-  load_target(ad.tb, ad.tfs, ad.tl, tg);
-  V3 pos_e;
-  float yaw_e = 0.0f;
-  if (NACT == 6 && T.kind == DSIM_DEV_KIND_HEXA) {
-    if constexpr (NACT == 6) {
-      if (a.yaw_e_out) indi_hexa<true>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
-      else indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
-    }
-  } else {
-    if (a.yaw_e_out) indi_quad<true, NACT>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-    else indi_quad<false, NACT>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  }
-  store_mem<NACT>(ad.sb, ad.sfs, ad.sl, m);
-  if (a.pos_e_out) {
-    a.pos_e_out[i] = pos_e.x; a.pos_e_out[a.n_pad + i] = pos_e.y; a.pos_e_out[2 * a.n_pad + i] = pos_e.z;
-  }
-  if (a.yaw_e_out) a.yaw_e_out[i] = yaw_e;
-  if (a.cmd_out) {
-#pragma unroll
-    for (int j = 0; j < NACT; ++j) a.cmd_out[(long long)j * a.n_pad + i] = m.cmd[j];
-  }
-}
-// (per-lane types only: a homogeneous fleet is one run of k_control_runs)
-template <int NACT>
-__global__ __launch_bounds__(256, DSIM_GEN_WAVES) void k_control_gen(StepK a) {
-  const long long i0 = (long long)blockIdx.x * 256;
-  const unsigned p = tile_slot<false>(a.type_id, i0, a.n_pad);
-  const long long i = i0 + p;
-  if (i >= a.n_pad) return;
-  const Addr ad = make_addr(a, i0, p);
-  DSIM_FOR_MY_TYPE(false, a, i, (control_gen_body<NACT>(T, a, i, ad)));
-}
-
-// ---- the reference-shaped two-call loop, fast forms ------------------------------------------------------------------
-// obs = env.step(action); action = ctrl.computeControlFromState(obs)  (examples/fly_INDI.py:223-239) is two entry
-// points here, dsim_physics and dsim_control.  For a homogeneous quad fleet in whole 256-drone tiles both have a fast
-// form with the fused kernel's addressing (scalar base + one lane offset, streaming accesses, no per-lane branches):
-//   k_physics_fast  reads 13 rigid + 4 action floats, writes 13 rigid + 4 echoed action floats and, fused (OBS), the
-//                   20-wide observation row of the NEW state (Env.step's return value, BaseAviary.py:547-555) —
-//                   transposed through LDS so that the row-major [n][20] block of the tile is written linearly;
-//   k_control_fast  reads 13 + 11 + 10, writes the 11 controller-memory floats (+ pos_e, yaw_e, and the command as a
-//                   plain SoA array that the next dsim_physics takes as its action without a copy).
-// 216 + 212 bytes per drone and iteration instead of the 480+ of physics_gen + observe + control_gen + copies.
-#ifndef DSIM_PHYS_WAVES
-#define DSIM_PHYS_WAVES DSIM_STEP_WAVES   // (79 VGPRs, 6 waves per SIMD.  Measured and rejected: 8 waves per SIMD — 64 VGPRs and
-                                          // 12 B of scratch per lane, 320 against 327 us for the two-call loop, inside that box's run-to-run spread)
-#endif
-#ifndef DSIM_OBS_STREAM
-#define DSIM_OBS_STREAM 1      // observation rows leave with the streaming hint when the state does (A/B knob of the build)
-#endif
-// The 20-wide observation rows of a whole-tile quad kernel (BaseAviary.py:780-790), see k_physics_fast: the wave's 64 rows
-// through its private LDS block, out as five 16-byte stores per lane over consecutive addresses.
-template <bool NT>
-__device__ __forceinline__ void obs_rows20_out(vf4* rows, const StepK& a, long long i0, const Rigid& s, const float cmd[4]) {
-  constexpr int W = 20;
-  const Euler e = euler_from_quat<true>(s.q);                                        // BaseAviary.py:729
-  const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  vf4* blk = rows + w * (64 * (W / 4));                    // the wave's 64 rows x 5 pieces
-  vf4* r = blk + lane * (W / 4);
-  r[0] = vf4{s.pos.x, s.pos.y, s.pos.z, s.q.x};
-  r[1] = vf4{s.q.y, s.q.z, s.q.w, e.roll};
-  r[2] = vf4{e.pitch, e.yaw, s.vel.x, s.vel.y};
-  r[3] = vf4{s.vel.z, s.w.x, s.w.y, s.w.z};
-  r[4] = vf4{cmd[0], cmd[1], cmd[2], cmd[3]};
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's own LDS writes, then its own reads: in order
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const long long w0 = i0 + 64 * (long long)w;             // first row of this wave
-  const long long left = a.n - w0;                         // rows of this wave that exist (the last tile may be ragged)
-  vf4* dst = reinterpret_cast<vf4*>(a.obs_out + w0 * W);
-#pragma unroll
-  for (int k = 0; k < W / 4; ++k) {
-    const unsigned p = (unsigned)k * 64u + lane;           // piece p of the block belongs to row p / 5
-    const vf4 v = blk[p];
-    if ((long long)(p / (W / 4)) < left) {
-      if (NT && DSIM_OBS_STREAM) __builtin_nontemporal_store(v, dst + p); else dst[p] = v;
-    }
-  }
-}
-// ---- Physics.DYN ----------------------------------------------------------------------------------------------------------
-// BaseAviary.step with PHYSICS == Physics.DYN (BaseAviary.py:510-545: the loop calls _dynamics(clipped_action, i) per drone
-// and sub-step, :525-527, and skips p.stepSimulation, :541-543): the reference's own explicit model (dsim_device.h:dyn_substep)
-// on quad types, any fleet size (ragged tails included), per-lane type ids of a table of quads by the waterfall.  One kernel
-// family for both entry points:
-//   CTRL = false  dsim_physics: Env.step — the action clipped (CtrlAviary.py:258-263) and echoed, the sub-steps, the 13
-//                 rigid floats and the three rpy rates written back, optionally (OBS) the 20-wide rows Env.step returns
-//   CTRL = true   dsim_step: the same followed by computeControl on the new state, as the example loop orders them
-//                 (examples/fly_INDI.py:223-239); an explicit action serves the physics part only
-// Reads 13 + 3 (+ 4 | + 11 + 10), writes 13 + 3 (+ 4 | + 11) floats per drone: bound by HBM like every other single-launch
-// form; no noise (the model has none), no ground-plane watch (the pose is SET, :1814-1819: no engine step, no contact).
-struct Cmd4 { float c0, c1, c2, c3; };
-template <bool CTRL, bool NT, class DT>
-__device__ __forceinline__ void dyn_body(DT& T, const StepK& a, long long i0, const Addr& ad, Rigid& s, Cmd4& cmd_out) {
-  float cmd[4];
-  // (per-drone arrays beside the state: wave-uniform base + the lane's byte offset, like the state's own accesses)
-  const unsigned lo = 4u * threadIdx.x;
-  float* const rb = a.dyn_rates + i0;
-  load_rigid<NT>(ad.sb, ad.sfs, ad.sl, s);
-  V3 rr = v3(ldg<NT>(rb, lo), ldg<NT>(rb + a.n_pad, lo), ldg<NT>(rb + 2 * a.n_pad, lo));     // self.rpy_rates, :1785
-  CtrlMem<4> m;
-  Target tg;
-  if (CTRL) {
-    load_mem<4, NT>(ad.sb, ad.sfs, ad.sl, m);
-    load_target<NT>(ad.tb, ad.tfs, ad.tl, tg);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float raw = a.action ? ldg<NT>(a.action + (long long)j * a.n_pad + i0, lo)
-                               : (CTRL ? m.cmd[j] : ldg<NT>(ad.sb + (20 + j) * ad.sfs, ad.sl));
-    cmd[j] = clampf(raw, T.pmin[j], T.pmax[j]);                                               // CtrlAviary.py:258-263
-  }
-  const DynBase b = dyn_base(T, cmd);
-  for (int k = 0; k < a.substeps; ++k) dyn_substep(T, a.dt_phys, b, s, rr);
-  const V3 w_new = dyn_reported_ang_vel((a.options & DSIM_OPT_DYN_BODY_RATES) != 0, s.q, rr);  // :1821-1826
-  if (a.substeps > 0) s.w = w_new;
-  if (CTRL) {
-    V3 pos_e;
-    float yaw_e;
-    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  }
-  const unsigned so = pin_lane_offset(ad.sl), lo2 = pin_lane_offset(lo);
-  store_rigid<NT>(ad.sb, ad.sfs, so, s);
-  stg<NT>(rb, lo2, rr.x); stg<NT>(rb + a.n_pad, lo2, rr.y); stg<NT>(rb + 2 * a.n_pad, lo2, rr.z);   // :1828
-  if (CTRL) store_mem<4, NT>(ad.sb, ad.sfs, so, m);
-  if (!CTRL && a.echo) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) stg<NT>(a.echo + (long long)j * a.n_pad + i0, lo2, cmd[j]);    // last_clipped_action, :545
-  }
-  cmd_out = Cmd4{cmd[0], cmd[1], cmd[2], cmd[3]};
-}
-// OBS (Env.step only): the 20-wide observation rows of the NEW state written by the same launch (obs_rows20_out, as
-// k_physics_fast: the wave's 64 rows through its private LDS block, behind the type waterfall where the wave is whole again).
-template <bool CTRL, bool NT, bool OBS = false>
-__global__ __launch_bounds__(256, OBS ? 4 : DSIM_STEP_WAVES) void k_dyn(StepK a) {     // (OBS at 5 waves per SIMD: 12 B of scratch)
-  __shared__ __attribute__((aligned(16))) vf4 rows[OBS ? 4 * 64 * 5 : 1];
-  const long long i0 = (long long)blockIdx.x * 256;
-  const long long i = i0 + threadIdx.x;
-  if (i >= a.n_pad) return;                            // (n_pad is a multiple of 64: whole waves leave)
-  const Addr ad = make_addr(a, i0, threadIdx.x);
-  Rigid s_new;
-  Cmd4 c_new;
-  // one body for homogeneous and mixed quad fleets: the wave peels one type per turn (a homogeneous fleet: one turn), the
-  // type's constants through the constant address space at a wave-uniform index (scalar loads)
-  const int my_t = a.type_id ? (int)a.type_id[i] : 0;
-  for (;;) {
-    const int cur_t = __builtin_amdgcn_readfirstlane(my_t);
-    if (my_t == cur_t) { dyn_body<CTRL, NT>(dev_type(a.types, cur_t), a, i0, ad, s_new, c_new); break; }
-  }
-  if (OBS) { const float cmd_new[4] = {c_new.c0, c_new.c1, c_new.c2, c_new.c3}; obs_rows20_out<NT>(rows, a, i0, s_new, cmd_new); }
-}
-
-// LOOP: the launch has SEVERAL sub-steps on the default noise lattice (the examples' five, examples/fly_INDI.py:139-141): the
-// instance that carries the body-frame form of the step and the Box-Muller tables (quad_substeps: LOOPED), as k_step_fast's
-// looped instances do — Env.step of 4 194 304 quads x 5 sub-steps was bound by vector issue on the single-sub-step body.
-template <bool NOISE, bool NT, bool OBS, bool LOOP = false>
-__global__ __launch_bounds__(256, DSIM_PHYS_WAVES) void k_physics_fast(StepK a) {
-  constexpr int W = 20;
-  // Observation rows: each wave owns 64 consecutive rows = 5 120 contiguous bytes of the row-major [n][20] output.  Lane r
-  // writes ITS row to the wave's private LDS block as five 16-byte pieces (row stride 80 B: eight lanes cover the 32
-  // banks exactly once), and the block goes out as five 16-byte stores per lane over consecutive addresses.  No
-  // workgroup barrier — the block is the wave's own — and no index arithmetic per element (round 2: a __syncthreads,
-  // twenty dword stores per lane and a division by W each; SQ_WAIT_ANY 0.36).
-  __shared__ __attribute__((aligned(16))) vf4 rows[OBS ? 4 * 64 * (W / 4) : 1];
-  constexpr bool TAB = NOISE && LOOP;
-  __shared__ NoiseTab ntab_[TAB ? 1 : 0 + 1];
-  const NoiseTab* const ntab = TAB ? &ntab_[0] : nullptr;
-  if (TAB) noise_tab_init(ntab_[0], threadIdx.x);
-  const DevType& T = a.types[0];
-  const long long sfs = a.st.field_stride;
-  const unsigned sl = 4u * kv_lane(a.st, threadIdx.x);
-  const long long i0 = (long long)blockIdx.x * 256;
-  float* const sb = a.st.base + kv_off(a.st, i0);
-  const long long i = i0 + threadIdx.x;
-  Rigid s;
-  load_rigid<NT>(sb, sfs, sl, s);
-  if (TAB) __syncthreads();
-  float cmd[4];
-  if (a.action_rows) {                // (wave-uniform) the action row-major [n][4] (DSIM_OPT_ACTION_ROWS): one 16-byte load per lane
-    vf4 r = vf4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (i < a.n) {                                                       // (rows exist for real drones only)
-      const vf4* ar = reinterpret_cast<const vf4*>(a.action) + i0;
-      r = NT ? __builtin_nontemporal_load(ar + threadIdx.x) : ar[threadIdx.x];
-    }
-    cmd[0] = r.x; cmd[1] = r.y; cmd[2] = r.z; cmd[3] = r.w;
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      cmd[j] = a.action ? ldg<NT>(a.action + (long long)j * a.n_pad + i0, 4u * threadIdx.x) : ldg<NT>(sb + (20 + j) * sfs, sl);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) cmd[j] = clampf(cmd[j], T.pmin[j], T.pmax[j]);           // CtrlAviary.py:258-263
-  if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
-  if constexpr (LOOP) quad_substeps<NOISE ? 1 : 0, 4, false, 0, false, 0, true>(T, a, i, s, cmd, a.step_index, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
-  else quad_substeps<NOISE ? 1 : 0, 4, false, 0, false, 1>(T, a, i, s, cmd, a.step_index);      // (both noise lattices)
-  ground_watch(T, s, a.fb.counters, i < a.n);
-  const unsigned so = pin_lane_offset(sl);
-  store_rigid<NT>(sb, sfs, so, s);
-  if (a.echo) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) stg<NT>(a.echo + (long long)j * a.n_pad + i0, 4u * threadIdx.x, cmd[j]);   // BaseAviary.py:545
-  }
-  if (OBS) obs_rows20_out<NT>(rows, a, i0, s, cmd);
-}
-
-template <bool NT, bool WANT_YAW>
-__global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_control_fast(StepK a) {
-  const DevType& T = a.types[0];
-  const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
-  const unsigned sl = 4u * kv_lane(a.st, threadIdx.x), tl = 4u * kv_lane(a.tg, threadIdx.x);
-  const long long i0 = (long long)blockIdx.x * 256;
-  float* const sb = a.st.base + kv_off(a.st, i0);
-  const float* const tb = a.tg.base + kv_off(a.tg, i0);
-  Rigid s;
-  CtrlMem<4> m;
-  Target tg;
-  load_rigid<NT>(sb, sfs, sl, s);
-  load_mem<4, NT>(sb, sfs, sl, m);
-  load_target<NT>(tb, tfs, tl, tg);
-  V3 pos_e;
-  float yaw_e = 0.0f;
-  indi_quad<WANT_YAW>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  const unsigned so = pin_lane_offset(sl);
-  store_mem<4, NT>(sb, sfs, so, m);
-  const unsigned lo = 4u * threadIdx.x;
-  if (a.cmd_out) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) stg<NT>(a.cmd_out + (long long)j * a.n_pad + i0, lo, m.cmd[j]);
-  }
-  if (a.pos_e_out) {
-    stg<NT>(a.pos_e_out + i0, lo, pos_e.x); stg<NT>(a.pos_e_out + a.n_pad + i0, lo, pos_e.y);
-    stg<NT>(a.pos_e_out + 2 * a.n_pad + i0, lo, pos_e.z);
-  }
-  if (WANT_YAW) stg<NT>(a.yaw_e_out + i0, lo, yaw_e);
-}
-
-// ---- the same two-call loop for every other fleet kind: runs of one type --------------------------------------------------
-// examples/fly_hexa_6DOF.py:214-221 is the same loop on the morphing hexa; BASELINE config 5 flies quads and hexas
-// together with the neighbour-downwash term.  The fleet is stored as runs of one type each (dsim_step_args.runs: what
-// CtrlAviary makes of an interleaved fleet; a homogeneous fleet is ONE run), a workgroup runs the Env.step / computeControl
-// of the run it falls in — the single-type body, per-type constants in SGPRs, the fused kernels' scalar-base addressing —
-// and the launch serves all runs (RunTab, as k_step_runs).  Runs may begin and end inside a tile: a lane outside
-// [lo, last) computes nothing and stores nothing, the neighbouring run's workgroup takes it.
-//   k_physics_runs  13 rigid + n_act action floats in (+ the body-frame force of the downwash term), 13 rigid + n_act
-//                   echoed action floats and the observation row of the NEW state out (20 wide for a quad-only table, 22
-//                   wide with a morphing hexa in it; BaseAviary.py:780-790); noise keyed by the caller's drone index;
-//                   optionally the next neighbour grid filled from the new positions (bin_next).
-//   k_control_runs  13 + (11 | 13) + 10 in, controller memory + command + pos_e + yaw_e out; a hexa whose first WLS
-//                   iteration leaves the box is queued for k_wls_fallback exactly as in k_step_hexa.
-// Observation rows: 88-byte rows are 8-byte but not 16-byte aligned, and a run boundary inside a wave splits the wave's
-// block of rows at a row boundary — so the wave-private LDS transpose of k_physics_fast is done in 8-byte pieces here
-// (every piece belongs to exactly one row): each lane writes its row as W / 2 pieces, the block leaves as W / 2 stores of
-// 8 bytes per lane over consecutive addresses, and a piece is stored when its row is one of this run's.
-typedef float vf2 __attribute__((ext_vector_type(2)));
-#define DSIM_OBS_WMAX 22
-#ifndef DSIM_ROWS16
-#define DSIM_ROWS16 1          // whole blocks of rows leave in 16-byte pieces (A/B knob of the build)
-#endif
-// IO (DSIM_OPT_CALLER_IO): the action is gathered from, and rows / command / errors are scattered to, the CALLER's drone
-// number io_id[i].  The drones of a run are spread over the caller's whole range (even index quad, odd index hexa ...), so one
-// run alone fills every other 88-byte row and every other dword of the command arrays: partial memory bursts, a
-// read-modify-write each (measured, 4 194 304 interleaved drones: Env.step 351 us with the runs served one after the other
-// against 190 us for a fleet of one type).  The IO instances therefore serve the runs SIDE BY SIDE (RunTab.block_map): a
-// workgroup works on the SAME stretch of two neighbouring tiles of the map, i.e. of two runs that cover the same stretch of
-// the caller's range.  First form: 512 threads = two whole tiles, the scattered arrays written with the default cache
-// policy so that the halves of a line meet in the XCD's L2 before they leave for memory (418-435 us per loop iteration,
-// traffic 1.14 x).  Second form, below: the outputs are ASSEMBLED in LDS over a window of DSIM_IO_WIN caller indices that
-// starts at the workgroup's smallest one, and leave as whole lines (16-byte pieces with the streaming hint, like the rows
-// of a single-type fleet); a flag per window row says whether this workgroup produced it (a hole belongs to another
-// workgroup and is not touched), and a drone whose index falls outside the window writes its outputs itself, as before.
-// Correct for any order, fast where the types are mixed evenly — the interleaved fleets BASELINE config 5 describes:
-// traffic 1.001 x algorithmic, and the smaller the workgroup the better (two barriers couple its waves; same-box A/B of the
-// loop: 512 threads 365 us, 256: 359, 128 — one wave of either tile, a window of 128 rows = 88 whole lines: 355 us).
-// t = the thread's index inside its tile.
-#ifndef DSIM_IO_WG
-#define DSIM_IO_WG 128         // threads per workgroup of the caller-order kernels: the same stretch of two neighbouring tiles of the map
-#endif
-#define DSIM_IO_WIN DSIM_IO_WG
-#define DSIM_IO_PARTS (512 / DSIM_IO_WG)          // workgroups per pair of tiles
-// map entry and index inside its tile of a thread: the workgroup's first half works on the pair's first tile
-#define DSIM_IO_ENTRY() (2 * (int)(blockIdx.x / DSIM_IO_PARTS) + (int)(threadIdx.x / (DSIM_IO_WG / 2)))
-#define DSIM_IO_T() ((blockIdx.x % DSIM_IO_PARTS) * (DSIM_IO_WG / 2) + (threadIdx.x % (DSIM_IO_WG / 2)))
-struct IoWin { float* win; unsigned char* flags; int base; };
-// The window starts at the smallest caller index among the workgroup's live lanes, rounded down to 4 (16-byte aligned rows
-// of any width, whole 16-byte pieces of the per-field arrays).  Every wave leaves its minimum in LDS and clears its share of
-// the flags BEFORE its arithmetic; the workgroup meets once behind it (io_window_base), fills the window, meets again and
-// writes it out — two barriers at the end of the waves' lives, none in front of their loads.
-__device__ __forceinline__ void io_window_min(int id_or_max, int* wmin, unsigned char* flags) {
-  int m = id_or_max;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63u) == 0) wmin[threadIdx.x >> 6] = m;
-  flags[threadIdx.x] = 0;
-}
-__device__ __forceinline__ int io_window_base(const int* wmin) {
-  __syncthreads();
-  int b = wmin[0];
-#pragma unroll
-  for (int q = 1; q < DSIM_IO_WG / 64; ++q) b = min(b, wmin[q]);
-  return __builtin_amdgcn_readfirstlane(b) & ~3;
-}
-struct IoRow { vf2 pc[11]; int id; bool have; };            // a lane's observation row on its way to the window
-struct IoCtl { float v[10]; int id; bool have; };            // a lane's command (6), position error (3), yaw error
-template <bool HEXA, bool NOISE, bool NT, bool OBS, bool IO, bool S1>
-__device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro, float* rows_wave, unsigned t, IoRow& io,
-                                                 const NoiseTab* tab = nullptr) {
-  constexpr int NA = HEXA ? 6 : 4;
-  const long long i0 = ro.i0, i = i0 + t;
-  const long long w0 = i0 + (long long)(t & ~63u);                     // first drone of this wave
-  if (w0 >= ro.last || w0 + 64 <= ro.lo) return;                       // (wave-uniform) nothing of this run in the wave
-  const bool live = i >= ro.lo && i < ro.last;
-  const int W = HEXA ? 22 : a.obs_w;                                   // row width: 20 for a quad-only table, 22 with a hexa in it
-  const unsigned lane = t & 63u;
-  if (live) {
-    CDevType& T = dev_type(a.types, ro.type);
-    const long long sfs = a.st.field_stride;
-    const unsigned sl = 4u * kv_lane(a.st, t);
-    float* const sb = a.st.base + kv_off(a.st, i0);
-    Rigid s;
-    load_rigid<NT>(sb, sfs, sl, s);
-    float cmd[NA];
-    long long id = i;
-    if (IO) id = a.io_id[i];
-    if (IO && a.action) {                     // the action is indexed by the caller's drone number: a gather
-#pragma unroll
-      for (int j = 0; j < NA; ++j) cmd[j] = clampf(a.action[(long long)j * a.n_pad + id], T.pmin[j], T.pmax[j]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < NA; ++j) {
-        const float raw = a.action ? ldg<NT>(a.action + (long long)j * a.n_pad + i0, 4u * t) : ldg<NT>(sb + (20 + j) * sfs, sl);
-        cmd[j] = clampf(raw, T.pmin[j], T.pmax[j]);                                     // CtrlAviary.py:258-263
-      }
-    }
-    V3 ext = v3(0, 0, 0);
-    if (a.ext_force) ext = v3(a.ext_force[i], a.ext_force[a.n_pad + i], a.ext_force[2 * a.n_pad + i]);
-    unsigned long long step_index = a.step_index;
-    if (NOISE && a.step_index_dev) step_index += *a.step_index_dev;
-    const long long nid = NOISE ? noise_id(a, i) : -1LL;
-    // (S1: one sub-step per Env.step — BASELINE's metric definition — compiled straight-line, as in the fused kernels)
-    if constexpr (HEXA) hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, cmd, step_index, ext, nid, tab);
-    else quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0, false, -1, !S1>(T, a, i, s, cmd, step_index, ext, nullptr, nid, tab);
-    ground_watch(T, s, a.fb.counters, i < a.n);
-    const unsigned so = pin_lane_offset(sl);
-    float* const sb2 = (DSIM_LATE_STORE_BASE && !S1) ? const_cast<float*>(opaque_after(sb, s.pos.x)) : sb;   // (k_step_hexa)
-    store_rigid<NT>(sb2, sfs, so, s);
-    if (a.echo) {                                                                       // BaseAviary.py:545
-#pragma unroll
-      for (int j = 0; j < NA; ++j) stg<NT>(a.echo + (long long)j * a.n_pad + i0, 4u * t, cmd[j]);
-      if (!HEXA && W == 22) {                 // a quad of a table with a six-actuator type: its rows 4, 5 hold zeros
-        stg<NT>(a.echo + 4LL * a.n_pad + i0, 4u * t, 0.0f); stg<NT>(a.echo + 5LL * a.n_pad + i0, 4u * t, 0.0f);
-      }
-    }
-    if (a.bin.count && i < a.n) bin_entry(a.bin, s.pos.x, s.pos.y, s.pos.z, a.bin.local_offset + i);   // next step's grid
-    if (OBS && (!IO || i < a.n)) {
-      const Euler e = euler_from_quat<true>(s.q);                                       // BaseAviary.py:729
-      vf2 pc[11];
-      pc[0] = vf2{s.pos.x, s.pos.y}; pc[1] = vf2{s.pos.z, s.q.x}; pc[2] = vf2{s.q.y, s.q.z}; pc[3] = vf2{s.q.w, e.roll};
-      pc[4] = vf2{e.pitch, e.yaw}; pc[5] = vf2{s.vel.x, s.vel.y}; pc[6] = vf2{s.vel.z, s.w.x}; pc[7] = vf2{s.w.y, s.w.z};
-      pc[8] = vf2{cmd[0], cmd[1]}; pc[9] = vf2{cmd[2], cmd[3]};
-      if constexpr (HEXA) pc[10] = vf2{cmd[4], cmd[5]}; else pc[10] = vf2{0.0f, 0.0f};
-      const int hw = W >> 1;
-      if (IO) {                               // the kernel puts it into the window, behind the workgroup's first barrier
-#pragma unroll
-        for (int k = 0; k < 11; ++k) io.pc[k] = pc[k];
-        io.id = (int)id; io.have = true;
-      } else {
-        vf2* r = reinterpret_cast<vf2*>(rows_wave + lane * (unsigned)W);
-#pragma unroll
-        for (int k = 0; k < 11; ++k) if (k < hw) r[k] = pc[k];
-      }
-    }
-  }
-  if (OBS && !IO) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's own LDS writes, then its own reads: in order
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const unsigned hw = (unsigned)W >> 1;                                               // pieces per row
-    const long long r_lo = ro.lo > w0 ? ro.lo - w0 : 0;                                 // this run's rows of the wave's block
-    const long long r_hi = min(min(ro.last, a.n) - w0, 64LL);
-    const unsigned p_lo = (unsigned)r_lo * hw, p_hi = r_hi > 0 ? (unsigned)r_hi * hw : 0u;
-    const vf2* blk = reinterpret_cast<const vf2*>(rows_wave);
-    if (DSIM_ROWS16 && p_lo == 0u && p_hi == 64u * hw && ((uintptr_t)a.obs_out & 15u) == 0) {
-      // the whole block is this run's (every wave but those at a run's two ends): 64 rows of 80 / 88 bytes are 320 / 352
-      // 16-byte pieces behind a 16-byte aligned address (64 rows in front of every block), stored as such
-      const vf4* blk4 = reinterpret_cast<const vf4*>(rows_wave);
-      vf4* dst4 = reinterpret_cast<vf4*>(a.obs_out + w0 * W);
-      const unsigned n4 = 16u * (unsigned)W;
-      for (unsigned p = lane; p < n4; p += 64u) {
-        const vf4 v = blk4[p];
-        if (NT && DSIM_OBS_STREAM) __builtin_nontemporal_store(v, dst4 + p); else dst4[p] = v;
-      }
-    } else {
-      vf2* dst = reinterpret_cast<vf2*>(a.obs_out + w0 * W);
-      for (unsigned k = 0; k < hw; ++k) {
-        const unsigned p = k * 64u + lane;
-        if (p >= p_lo && p < p_hi) {
-          const vf2 v = blk[p];
-          if (NT && DSIM_OBS_STREAM) __builtin_nontemporal_store(v, dst + p); else dst[p] = v;
-        }
-      }
-    }
-  }
-}
-#ifndef DSIM_PRUNS_WAVES
-#define DSIM_PRUNS_WAVES 4
-#endif
-#ifndef DSIM_CRUNS_WAVES
-#define DSIM_CRUNS_WAVES 4
-#endif
-template <bool NOISE, bool NT, bool OBS, bool S1>
-__global__ __launch_bounds__(256, S1 ? DSIM_PRUNS_WAVES : 3) void k_physics_runs(StepK a, RunTab rt) {
-  __shared__ __attribute__((aligned(16))) float rows[OBS ? 4 * 64 * DSIM_OBS_WMAX : 2];   // per wave: 64 rows
-  DSIM_RUN_OF_BLOCK(rt, ro, blockIdx.x);
-  float* rw = rows + (OBS ? (threadIdx.x >> 6) * (64 * DSIM_OBS_WMAX) : 0);
-  IoRow none;
-  DSIM_NOISE_TAB(NOISE && !S1, 256);
-  if (ro.hexa) physics_run_body<true, NOISE, NT, OBS, false, S1>(a, ro, rw, threadIdx.x, none, ntab);
-  else physics_run_body<false, NOISE, NT, OBS, false, S1>(a, ro, rw, threadIdx.x, none, ntab);
-}
-// DSIM_OPT_CALLER_IO: the same stretch of two neighbouring tiles of the side-by-side map, the rows assembled over the window
-template <bool NOISE, bool NT, bool OBS, bool S1>
-__global__ __launch_bounds__(DSIM_IO_WG, S1 ? DSIM_PRUNS_WAVES : 3) void k_physics_runs_io(StepK a, RunTab rt) {
-  __shared__ __attribute__((aligned(16))) float win[OBS ? DSIM_IO_WIN * DSIM_OBS_WMAX : 4];
-  __shared__ unsigned char flags[DSIM_IO_WIN];
-  __shared__ int wmin[DSIM_IO_WG / 64];
-  DSIM_RUN_OF_BLOCK(rt, ro, DSIM_IO_ENTRY());
-  const unsigned t = DSIM_IO_T();
-  IoRow io;
-  io.have = false;
-  if (OBS) {
-    const long long i = ro.i0 + t;
-    io_window_min(i >= ro.lo && i < ro.last && i < a.n ? a.io_id[i] : 0x7fffffff, wmin, flags);
-  }
-  DSIM_NOISE_TAB(NOISE && !S1, DSIM_IO_WG);
-  if (ro.hexa) physics_run_body<true, NOISE, NT, OBS, true, S1>(a, ro, nullptr, t, io, ntab);
-  else physics_run_body<false, NOISE, NT, OBS, true, S1>(a, ro, nullptr, t, io, ntab);
-  if (OBS) {
-    const int base = io_window_base(wmin);
-    const int hw = a.obs_w >> 1;
-    if (io.have) {
-      const unsigned slot = (unsigned)(io.id - base);                  // where this row goes: the window, or straight out
-      vf2* r;
-      if (slot < (unsigned)DSIM_IO_WIN) {
-        r = reinterpret_cast<vf2*>(win + slot * (unsigned)a.obs_w);
-#pragma unroll
-        for (int k = 0; k < 11; ++k) if (k < hw) r[k] = io.pc[k];
-        flags[slot] = 1;
-      } else {
-        vf2* g = reinterpret_cast<vf2*>(a.obs_out + (long long)io.id * a.obs_w);
-#pragma unroll
-        for (int k = 0; k < 11; ++k) if (k < hw) g[k] = io.pc[k];
-      }
-    }
-    __syncthreads();
-    // the window leaves in 16-byte pieces; a piece holds two 8-byte halves, each inside ONE row (rows are 80 / 88 bytes).
-    // (x / W by multiply-shift: exact for x < 11 272 with these constants.)
-    const unsigned W = (unsigned)a.obs_w, n4 = DSIM_IO_WIN * W / 4u, mul = W == 22u ? 2979u : 3277u;
-    const vf4* win4 = reinterpret_cast<const vf4*>(win);
-    float* const g = a.obs_out + (long long)base * W;
-    for (unsigned p = threadIdx.x; p < n4; p += (unsigned)DSIM_IO_WG) {
-      const unsigned x = 4u * p;
-      const bool fa = flags[(x * mul) >> 16] != 0, fb = flags[((x + 2u) * mul) >> 16] != 0;
-      const bool whole = __ballot(fa && fb) == ~0ULL;     // 1 KB of whole pieces: streaming; holes: default policy (they merge in L2)
-      if (fa || fb) {
-        const vf4 v = win4[p];
-        if (fa && fb) {
-          if (NT && DSIM_OBS_STREAM && whole) __builtin_nontemporal_store(v, reinterpret_cast<vf4*>(g + x)); else *reinterpret_cast<vf4*>(g + x) = v;
-        } else if (fa) *reinterpret_cast<vf2*>(g + x) = vf2{v.x, v.y};
-        else *reinterpret_cast<vf2*>(g + x + 2u) = vf2{v.z, v.w};
-      }
-    }
-  }
-}
-
-template <int KIND, bool NT, bool WANT_YAW, bool IO>
-__device__ __forceinline__ void control_run_body(const StepK& a, const RunOf& ro, unsigned t, IoCtl& io) {
-  constexpr bool HEXA = KIND != DSIM_DEV_KIND_QUAD;            // six actuators
-  constexpr int NA = HEXA ? 6 : 4;
-  const long long i0 = ro.i0, i = i0 + t;
-  if (i >= ro.last || i < ro.lo) return;
-  CDevType& T = dev_type(a.types, ro.type);
-  const long long sfs = a.st.field_stride, tfs = a.tg.field_stride;
-  const unsigned sl = 4u * kv_lane(a.st, t), tl = 4u * kv_lane(a.tg, t);
-  float* const sb = a.st.base + kv_off(a.st, i0);
-  const float* const tb = a.tg.base + kv_off(a.tg, i0);
-  Rigid s;
-  CtrlMem<NA> m;
-  Target tg;
-  load_rigid<NT>(sb, sfs, sl, s);
-  load_mem<NA, NT>(sb, sfs, sl, m);
-  load_target<NT>(tb, tfs, tl, tg);
-  V3 pos_e;
-  float yaw_e = 0.0f;
-  if constexpr (KIND == DSIM_DEV_KIND_HEXA) indi_hexa<WANT_YAW>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
-  else indi_quad<WANT_YAW, NA>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);       // (NA = 6: hexa_6DOF_simple)
-  const unsigned so = pin_lane_offset(sl);
-  store_mem<NA, NT>(sb, sfs, so, m);
-  if (IO) {                 // the outputs go to the caller's drone number: the kernel puts them into the window
-#pragma unroll
-    for (int j = 0; j < NA; ++j) io.v[j] = m.cmd[j];
-    if (!HEXA) { io.v[4] = 0.0f; io.v[5] = 0.0f; }   // a quad of a table with a six-actuator type: its rows 4, 5 hold zeros
-    io.v[6] = pos_e.x; io.v[7] = pos_e.y; io.v[8] = pos_e.z; io.v[9] = yaw_e;
-    io.id = a.io_id[i]; io.have = true;
-    return;
-  }
-  const unsigned lo4 = 4u * t;
-  if (a.cmd_out) {
-#pragma unroll
-    for (int j = 0; j < NA; ++j) stg<NT>(a.cmd_out + (long long)j * a.n_pad + i0, lo4, m.cmd[j]);
-    if (!HEXA && a.obs_w == 22) {             // a quad of a table with a six-actuator type: its rows 4, 5 hold zeros
-      stg<NT>(a.cmd_out + 4LL * a.n_pad + i0, lo4, 0.0f); stg<NT>(a.cmd_out + 5LL * a.n_pad + i0, lo4, 0.0f);
-    }
-  }
-  if (a.pos_e_out) {
-    stg<NT>(a.pos_e_out + i0, lo4, pos_e.x); stg<NT>(a.pos_e_out + a.n_pad + i0, lo4, pos_e.y);
-    stg<NT>(a.pos_e_out + 2 * a.n_pad + i0, lo4, pos_e.z);
-  }
-  if (WANT_YAW) stg<NT>(a.yaw_e_out + i0, lo4, yaw_e);
-}
-template <bool NT, bool WANT_YAW>
-__global__ __launch_bounds__(256, DSIM_CRUNS_WAVES) void k_control_runs(StepK a, RunTab rt) {
-  DSIM_RUN_OF_BLOCK(rt, ro, blockIdx.x);
-  IoCtl none;
-  if (ro.quadlaw6) control_run_body<DSIM_DEV_KIND_HEXA_QUADLAW, NT, WANT_YAW, false>(a, ro, threadIdx.x, none);
-  else if (ro.hexa) control_run_body<DSIM_DEV_KIND_HEXA, NT, WANT_YAW, false>(a, ro, threadIdx.x, none);
-  else control_run_body<DSIM_DEV_KIND_QUAD, NT, WANT_YAW, false>(a, ro, threadIdx.x, none);
-}
-template <bool NT, bool WANT_YAW>
-__global__ __launch_bounds__(DSIM_IO_WG, DSIM_CRUNS_WAVES) void k_control_runs_io(StepK a, RunTab rt) {
-  __shared__ float win[10 * DSIM_IO_WIN];     // field f of the window: win[f * DSIM_IO_WIN + slot]; 0-5 command, 6-8 pos_e, 9 yaw_e
-  __shared__ unsigned char flags[DSIM_IO_WIN];
-  __shared__ int wmin[DSIM_IO_WG / 64];
-  DSIM_RUN_OF_BLOCK(rt, ro, DSIM_IO_ENTRY());
-  const unsigned t = DSIM_IO_T();
-  IoCtl io;
-  io.have = false;
-  {
-    const long long i = ro.i0 + t;
-    io_window_min(i >= ro.lo && i < ro.last ? a.io_id[i] : 0x7fffffff, wmin, flags);
-  }
-  if (ro.quadlaw6) control_run_body<DSIM_DEV_KIND_HEXA_QUADLAW, NT, WANT_YAW, true>(a, ro, t, io);
-  else if (ro.hexa) control_run_body<DSIM_DEV_KIND_HEXA, NT, WANT_YAW, true>(a, ro, t, io);
-  else control_run_body<DSIM_DEV_KIND_QUAD, NT, WANT_YAW, true>(a, ro, t, io);
-  const int base = io_window_base(wmin);
-  const int nc = a.obs_w - 16;                // rows of the command table: 4, or 6 with a six-actuator type in the fleet
-  if (io.have) {
-    const unsigned slot = (unsigned)(io.id - base);
-    if (slot < (unsigned)DSIM_IO_WIN) {
-#pragma unroll
-      for (int f = 0; f < 10; ++f) win[f * DSIM_IO_WIN + slot] = io.v[f];
-      flags[slot] = 1;
-    } else {                                  // outside the window: straight out (default cache policy, see above)
-      if (a.cmd_out) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) if (j < nc) a.cmd_out[(long long)j * a.n_pad + io.id] = io.v[j];
-      }
-      if (a.pos_e_out) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) a.pos_e_out[(long long)j * a.n_pad + io.id] = io.v[6 + j];
-      }
-      if (WANT_YAW) a.yaw_e_out[io.id] = io.v[9];
-    }
-  }
-  __syncthreads();
-  // window row threadIdx.x: whole lines of every output array when all 64 rows of the wave were produced here (then with
-  // the streaming hint; a wave with holes leaves them to their owners and keeps the default policy, so that the parts of a
-  // line still meet in the cache)
-  const bool mine = flags[threadIdx.x] != 0;
-  const bool whole = __ballot(mine) == ~0ULL;
-  if (mine) {
-    const unsigned lo4 = 4u * threadIdx.x;
-#define DSIM_IO_OUT(PTR, F) do { float* ub_ = (PTR) + base; const float v_ = win[(F) * DSIM_IO_WIN + threadIdx.x];          \
-                                 if (whole) stg<NT>(ub_, lo4, v_); else stg<false>(ub_, lo4, v_); } while (0)
-    if (a.cmd_out) {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) if (j < nc) DSIM_IO_OUT(a.cmd_out + (long long)j * a.n_pad, j);
-    }
-    if (a.pos_e_out) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) DSIM_IO_OUT(a.pos_e_out + (long long)j * a.n_pad, 6 + j);
-    }
-    if (WANT_YAW) DSIM_IO_OUT(a.yaw_e_out, 9);
-#undef DSIM_IO_OUT
-  }
-}
-
-// ---- Env.step of the alternate action adaptors (VelocityAviary / RPYTAviary) --------------
-// control (inside _preprocessAction) on the CURRENT state, then the physics with the new command
-template <int MODE, bool NOISE, bool PLANE, class DT>
-__device__ __forceinline__ void adaptor_body(DT& T, const StepK& a, long long i, const Addr& ad) {
-  Rigid s;
-  CtrlMem<4> m;
-  load_rigid(ad.sb, ad.sfs, ad.sl, s);
-  load_mem<4>(ad.sb, ad.sfs, ad.sl, m);
-  float v[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = a.action[(long long)j * a.n_pad + i];
-  if (MODE == DSIM_ADAPT_VELOCITY) {                       // VelocityAviary.py:241-262
-    const float nrm = DSIM_SQRT(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    const float sc = nrm != 0.0f ? T.speed_limit * fabsf(v[3]) * DSIM_RCP(nrm) : 0.0f;
-    Target tg;
-    tg.pos = s.pos;                                        // "same as the current position"
-    tg.vel = v3(sc * v[0], sc * v[1], sc * v[2]);
-    tg.acc = v3(0, 0, 0);
-    tg.yaw = euler_from_quat<true>(s.q).yaw;               // "keep current yaw" (state[9])
-    V3 pos_e;
-    float yaw_e;
-    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  } else {                                                 // RPYTAviary.py:184-191
-    indi_rate<4>(T, DSIM_RCP(a.dt_ctrl), s, v3(v[0], v[1], v[2]), v[3], m);
-  }
-  quad_substeps<NOISE ? 1 : 0, 4, PLANE, 0, PLANE, 1>(T, a, i, s, m.cmd, a.step_index, V3{-0.0f, -0.0f, -0.0f}, nullptr,
-                                                   NOISE ? noise_id(a, i) : -1LL);
-  ground_watch(T, s, a.fb.counters, i < a.n);
-  store_rigid(ad.sb, ad.sfs, ad.sl, s);
-  store_mem<4>(ad.sb, ad.sfs, ad.sl, m);
-  if (a.echo) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a.echo[(long long)j * a.n_pad + i] = m.cmd[j];
-  }
-}
-template <int MODE, bool NOISE, bool UNIFORM, bool PLANE = false>
-__global__ __launch_bounds__(256, PLANE ? 1 : DSIM_GEN_WAVES) void k_adaptor(StepK a) {
-  const long long i0 = (long long)blockIdx.x * 256;
-  const unsigned p = tile_slot<UNIFORM>(a.type_id, i0, a.n_pad);
-  const long long i = i0 + p;
-  if (i >= a.n_pad) return;
-  const Addr ad = make_addr(a, i0, p);
-  DSIM_FOR_MY_TYPE(UNIFORM, a, i, (adaptor_body<MODE, NOISE, PLANE>(T, a, i, ad)));
-}
-
-// The same on a homogeneous quad fleet in whole tiles, as ONE launch that also returns Env.step's observation: the fused
-// kernels' addressing (scalar base + one lane offset, streaming accesses, constants in SGPRs), the action taken as the
-// caller holds it — StepK.action_rows: row-major [n][4] (VelocityAviary.py:221-264 / RPYTAviary.py:181-193 take one 4-vector per drone),
-// one 16-byte load per lane — and the 20-wide rows of the NEW state written by the same launch (OBS).  Before: a transpose of
-// the action (torch, 50 us), k_adaptor (147-160 us) and k_observe (125 us) per Env.step of 4 194 304 drones.
-//   reads 24 state + 4 action floats, writes 24 state + 4 echoed command + 20 row floats: 304 bytes per drone-step
-template <int MODE, bool NOISE, bool NT>
-__global__ __launch_bounds__(256, DSIM_STEP_WAVES) void k_adaptor_fast(StepK a) {
-  __shared__ __attribute__((aligned(16))) vf4 rows[4 * 64 * 5];
-  const DevType& T = a.types[0];
-  const long long sfs = a.st.field_stride;
-  const unsigned sl = 4u * kv_lane(a.st, threadIdx.x);
-  const long long i0 = (long long)blockIdx.x * 256;
-  float* const sb = a.st.base + kv_off(a.st, i0);
-  const long long i = i0 + threadIdx.x;
-  Rigid s;
-  CtrlMem<4> m;
-  load_rigid<NT>(sb, sfs, sl, s);
-  load_mem<4, NT>(sb, sfs, sl, m);
-  float v[4];
-  if (a.action_rows) {                                                   // (wave-uniform)
-    vf4 r = vf4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (i < a.n) {                                                       // (rows exist for real drones only)
-      const vf4* ar = reinterpret_cast<const vf4*>(a.action) + i0;
-      r = NT ? __builtin_nontemporal_load(ar + threadIdx.x) : ar[threadIdx.x];
-    }
-    v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = ldg<NT>(a.action + (long long)j * a.n_pad + i0, 4u * threadIdx.x);
-  }
-  if (MODE == DSIM_ADAPT_VELOCITY) {                       // VelocityAviary.py:241-262
-    const float nrm = DSIM_SQRT(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    const float sc = nrm != 0.0f ? T.speed_limit * fabsf(v[3]) * DSIM_RCP(nrm) : 0.0f;
-    Target tg;
-    tg.pos = s.pos;                                        // "same as the current position"
-    tg.vel = v3(sc * v[0], sc * v[1], sc * v[2]);
-    tg.acc = v3(0, 0, 0);
-    tg.yaw = euler_from_quat<true>(s.q).yaw;               // "keep current yaw" (state[9])
-    V3 pos_e;
-    float yaw_e;
-    indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
-  } else {                                                 // RPYTAviary.py:184-191
-    indi_rate<4>(T, DSIM_RCP(a.dt_ctrl), s, v3(v[0], v[1], v[2]), v[3], m);
-  }
-  if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
-  quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index);
-  ground_watch(T, s, a.fb.counters, i < a.n);
-  const unsigned so = pin_lane_offset(sl);
-  store_rigid<NT>(sb, sfs, so, s);
-  store_mem<4, NT>(sb, sfs, so, m);
-  if (a.echo) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) stg<NT>(a.echo + (long long)j * a.n_pad + i0, 4u * threadIdx.x, m.cmd[j]);
-  }
-  if (a.obs_out) obs_rows20_out<NT>(rows, a, i0, s, m.cmd);
 }
 
 // ---- deferred WLS fallbacks (hexa) -----------------------------------------------
@@ -2081,829 +204,10 @@ __global__ __launch_bounds__(256) void k_traj_sample(TrajK a) {
   q[9 * fs] = (float)yaw;
 }
 
-// ---- neighbour downwash (formula P8) ------------------------------------------
-// world positions -> uniform xy grid (counting sort: count, scan, scatter) -> per-drone 3x3 scan
-struct DwK {
-  KView st;
-  const DevType* types;
-  const uint8_t* type_id;
-  const float* pos_all;
-  long long m, m_pad, n, n_pad, local_offset;
-  float xmin, ymin, inv_cell;
-  int nx, ny;
-  int* count;        // [ncells + 1] -> exclusive prefix after the scan
-  int* count_next;   // the other buffer: zeroed by this call's query kernel for the next call
-  int* cursor;       // [ncells]
-  float4* sorted;    // [m]  (x, y, z, world index as int bits)
-  float4* buckets;   // bucket form: [ncells][DW_CAP] entries per cell; count[ncells] = overflow length
-  float4* overflow;  // bucket form: [m] entries that found their cell full
-  float* force_out;  // SoA [3][n_pad]
-  float radius2;     // adjacency
-  int* adj_count;    // [n_pad]
-  int* adj_list;     // [max_k][n_pad] or null
-  int max_k;
-  int n_types;       // length of types[]
-  unsigned long long* pairs;   // diagnostics: += pairs evaluated (dsim_downwash_args.pairs_evaluated), or null
-};
-// position component c of world entry j: from the gathered array, or (single-rank fleets, pos_all = null)
-// straight from the state block
-__device__ __forceinline__ float dw_pos(const DwK& a, long long j, int c) {
-  return a.pos_all ? a.pos_all[(long long)c * a.m_pad + j] : a.st.base[kv_off(a.st, j) + c * a.st.field_stride];
-}
-__device__ __forceinline__ int dw_cell(const DwK& a, float x, float y, int& cx, int& cy) {
-  cx = min(max((int)floorf((x - a.xmin) * a.inv_cell), 0), a.nx - 1);
-  cy = min(max((int)floorf((y - a.ymin) * a.inv_cell), 0), a.ny - 1);
-  return cy * a.nx + cx;
-}
-__global__ __launch_bounds__(256) void k_dw_count(DwK a) {
-  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
-  // also zeroes the count buffer the NEXT grid build will use (double-buffered: no memset per step)
-  if (j <= (long long)a.nx * a.ny) a.count_next[j] = 0;
-  if (j < a.m) {
-    int cx, cy;
-    atomicAdd(&a.count[dw_cell(a, dw_pos(a, j, 0), dw_pos(a, j, 1), cx, cy)], 1);
-  }
-}
-// exclusive scan of count[0..ncells) by ONE workgroup (ncells is a few thousand); count[ncells] = m
-__global__ __launch_bounds__(1024) void k_dw_scan(DwK a) {
-  __shared__ int part[1024];
-  const int ncells = a.nx * a.ny, t = threadIdx.x;
-  const int per = (ncells + 1023) / 1024, lo = t * per, hi = min(lo + per, ncells);
-  int sum = 0;
-  for (int c = lo; c < hi; ++c) sum += a.count[c];
-  part[t] = sum;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int v = t >= off ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  int run = part[t] - sum;
-  for (int c = lo; c < hi; ++c) { const int k = a.count[c]; a.count[c] = run; a.cursor[c] = run; run += k; }
-  if (t == 1023) a.count[ncells] = part[1023];
-}
-__global__ __launch_bounds__(256) void k_dw_scatter(DwK a) {
-  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (j >= a.m) return;
-  const float x = dw_pos(a, j, 0), y = dw_pos(a, j, 1), z = dw_pos(a, j, 2);
-  int cx, cy;
-  const int slot = atomicAdd(&a.cursor[dw_cell(a, x, y, cx, cy)], 1);
-  a.sorted[slot] = make_float4(x, y, z, __int_as_float((int)j));
-}
-// ---- bucket form of the grid: binning pass + cell-centred query ---------------------------------------------------
-// k_dw_bin appends the world entries [j0, j1) except [skip0, skip1) (the local drones, when the previous step kernel
-// has already binned them: BinK) to their cells' buckets.
-struct BinRange { long long j0, j1, skip0, skip1; };
-__global__ __launch_bounds__(256) void k_dw_bin(DwK a, BinK b, BinRange r) {
-  long long j = r.j0 + (long long)blockIdx.x * 256 + threadIdx.x;
-  if (j >= r.skip0) j += r.skip1 - r.skip0;
-  if (j >= r.j1) return;
-  bin_entry(b, dw_pos(a, j, 0), dw_pos(a, j, 1), dw_pos(a, j, 2), j);
-}
-// one candidate's term of formula P8, branch-free (a wave almost always holds a lane that passes the test, so a branch
-// only adds its own overhead): the result is selected, never skipped.  K = DW1 (PROP_RADIUS / 4)^2 of the receiver.
-//   alpha = K / dz^2,  beta = DW2 dz + DW3,  term = -alpha exp(-dxy^2 / (2 beta^2))        (BaseAviary.py:1752-1755)
-// ONE reciprocal serves both quotients (1 / (dz^2 beta^2); transcendental instructions issue at a quarter of the FMA
-// rate and were a third of this loop); beta^2 is floored at 1e-12 so that the product cannot underflow — the term is
-// exp(-huge) = 0 there either way.
-#define DSIM_EXP2(x) __builtin_amdgcn_exp2f(x)     // v_exp_f32
-// The receiver's K multiplies the SUM (callers pass K = 1 inside their loops and scale once at the end), and the
-// exponent's -1/2 is folded with log2(e) into one constant in front of v_exp_f32: 24 vector instructions per candidate.
-__device__ __forceinline__ float dw_pair(float4 p, float x, float y, float z, float K, float d1, float d2c) {
-  const float dz = p.z - z, dx = p.x - x, dy = p.y - y;
-  const float dd = dx * dx + dy * dy;
-  const bool hit = dz > 0.0f && dd < DW_CUTOFF * DW_CUTOFF;     // :1752
-  const float dzs = hit ? dz : 1.0f;                            // keeps the rejected lanes' arithmetic finite
-  const float beta = d1 * dzs + d2c;                            // :1754
-  const float dz2 = dzs * dzs, b2 = fmaxf(beta * beta, 1e-12f);
-  const float inv = DSIM_RCP(dz2 * b2);
-  const float term = -(K * (inv * b2)) * DSIM_EXP2((-0.5f * 1.44269504088896341f) * dd * (inv * dz2));   // :1753, 1755
-  return hit ? term : 0.0f;
-}
-// The same term for the banded loop, accumulated: the exponent's -1/2 log2(e) is folded into the coefficients of beta
-// (d1s = d1 S, d2s = d2 S with S^2 = 2 ln 2, scaled once per receiver group: exp(-dd / (2 beta^2)) = exp2(-dd / beta_s^2)),
-// and the rejected lanes' term is selected away in front of ONE fused multiply-add: 20 vector instructions per candidate
-// instead of 22, with a loop whose control is scalar (the callers' trip count is wave-uniform).
-#define DW_BETA_SCALE 1.17741002251547469101f      // sqrt(2 ln 2)
-__device__ __forceinline__ float dw_pair_acc(float4 p, float x, float y, float z, float d1s, float d2s, float acc) {
-  const float dz = p.z - z, dx = p.x - x, dy = p.y - y;
-  const float dd = dx * dx + dy * dy;
-  const bool hit = dz > 0.0f && dd < DW_CUTOFF * DW_CUTOFF;     // :1752
-  const float dzs = hit ? dz : 1.0f;
-  const float beta = d1s * dzs + d2s;                           // :1754, scaled
-  const float dz2 = dzs * dzs, b2 = fmaxf(beta * beta, 1e-12f);
-  const float inv = DSIM_RCP(dz2 * b2);
-  const float e = DSIM_EXP2(-(dd * (inv * dz2)));               // :1755
-  return __builtin_fmaf(-(inv * b2), hit ? e : 0.0f, acc);     // :1753
-}
-// (Measured and rejected: the same loop in PACKED fp32 — two candidates per v_pk_add/mul/fma_f32 on an x | y | z LDS
-// image read 8 bytes at a time, 16 packed instructions per candidate pair instead of ~50 scalar ones: 135 us instead of
-// 50 us at BASELINE config 5's density.  On gfx950 a v_pk_*_f32 costs far more issue time than the two scalar
-// instructions it replaces (MI355X_MICROARCH.md prices one v_pk_fma_f32 at +22 cycles over two v_fma_f32), which is
-// also why the compiler's SLP vectoriser is switched off for this library.  The loop is bound by the vector pipe at
-// ~4.6 cycles per wave64 instruction: 22.1 M instructions per launch, profiles/r02_c5_summary.json.)
-// Cell-centred query.  One workgroup per cell: the buckets of the (2 rings + 1)^2 cells around it are copied to LDS
-// once — all counts first, then one flattened pass, so every global load of the fill is in flight together — and the
-// cell's receivers (read back from that LDS copy) are taken TPB / 8 at a time, DW_LPB lanes each: every
-// wave-instruction reads DW_LPB consecutive LDS entries that its 8 receivers share (16-byte broadcast reads,
-// conflict-free), partial sums are reduced by shuffles.  At BASELINE config 5's density (one drone per m^2: 25 per
-// 5 m cell, 625 candidates per receiver) the candidates come from L2 once per cell instead of once per receiver.
-// The workgroup size and the LDS tile are chosen by the host from the mean occupancy (sparse worlds: one wave and 8 KB
-// per cell, so that a CU holds 20 cells at once and their latency chains overlap; dense ones: four waves, 16 KB); a
-// neighbourhood that does not fit the tile is processed in several fills.  Receivers that sit in the overflow list are
-// handled by the last DW_OVF_GROUPS workgroups straight from global memory.  The kernel also zeroes the count buffer
-// of the NEXT grid build (double-buffered: no memset on the stream).
-#define DW_LPB 8
-#define DW_NBR 25                      // (2 * 2 + 1)^2 cells at most
-#define DW_OVF_GROUPS 16
-// BAND (dense worlds): the term needs the candidate ABOVE the receiver, so half of all pairs are rejected on dz alone.
-// The cell's receivers are ordered by height (one wave: every lane counts the receivers below its own) and taken in
-// groups of DW_RPG = 8; a candidate's band is the number of groups whose lowest receiver is below it, the tile is laid
-// out by band, highest first (counted and placed by ballots while the entries wait in registers), and group g reads
-// only the prefix that holds bands > g: the lowest group scans everything, the highest almost nothing.  The groups
-// are dealt to the waves in snake order so that both waves get the same work.  ~48 % fewer pair evaluations at
-// BASELINE config 5's density (25 receivers = 4 groups per cell).
-#define DW_RPG 8
-#define DW_MAXG (DW_CAP / DW_RPG)
-#define DW_ENT_PER_THREAD 6            // ceil(768 / 128): the tile of the dense form, per thread
-// The dense form's LDS tile.  Round 5, from in-kernel stamps (tools/c5_query_timeline.py, profiles/r05_c5_timeline_*.txt): with
-// 768 entries of 16 bytes a workgroup took 14 000 B of LDS and a CU held ELEVEN — 2 816 slots for the 2 956 workgroups of a
-// 65 536-drone shard at BASELINE config 5's density (28 x 105 cells with the box's margin, + the overflow groups): the ~30 that
-// did not fit started 9-13 us late, lived their ~19 us like the others and ended the launch at 32 us where the first generation
-// ends at 26-28 (a 13 232 B workgroup still made eleven: the allocation granule is coarser than the arithmetic suggests).  The
-// banded path needs x, y, z of a candidate, not its index: its tile is three float planes, 12 bytes per entry — 768 entries in
-// 9 216 B, 10 928 B per workgroup with the static arrays, fourteen workgroups per CU by the arithmetic and at least the
-// thirteen that put every cell of the shard into ONE generation.  The plain path reads the same bytes as 576 entries of 16.
-#define DW_TILE_DENSE 768              // entries of the banded path's tile
-#define DW_TILE_DENSE_BYTES (DW_TILE_DENSE * 12)
-// Two grids: the RECEIVERS are the entries of grid b, the CANDIDATES those of grid cnd — the same grid in the one-pass
-// form; in the split form of a sharded fleet (DSIM_DW_LOCAL / DSIM_DW_HALO_QUERY) the local pass runs while the
-// neighbouring ranks' positions are still on the wire, and the second pass (accumulate: force += ) takes the local
-// receivers against the halo grid, where only the cells within the cut-off of a slab edge find anything.
-__device__ __forceinline__ void dw_write(const DwK& a, long long i, float fz, int accumulate) {
-  if (accumulate) { a.force_out[2 * a.n_pad + i] += fz; return; }
-  a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz;
-}
-template <int TPB, bool BAND>
-__global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, int rings, int tile_cap, int accumulate) {
-  extern __shared__ float4 tile[];                                                     // tile_cap entries
-  __shared__ int nb_cell[DW_NBR], nb_cnt[DW_NBR];
-  __shared__ float coef[DSIM_MAX_TYPES][4];                                            // (K, DW2, DW3) of every type
-  __shared__ float4 recv[BAND ? DW_CAP : 1];                                           // receivers, sorted by height
-  __shared__ __attribute__((aligned(16))) int rty[BAND ? DW_CAP : 4];                  // their types (-1: not mine to serve); before
-  float* const skey = reinterpret_cast<float*>(rty);                                   // that, the heights while they are ranked (the
-                                                                                       // tile + this decide how many cells a CU holds: DW_TILE_DENSE)
-  __shared__ float zlo[BAND ? DW_MAXG : 1];                                            // lowest receiver of every group
-  __shared__ int wcnt[BAND ? TPB / 64 : 1][BAND ? DW_MAXG + 1 : 1];                    // entries per band, per wave
-  constexpr int RPB = TPB / DW_LPB;                                                    // receivers per pass
-  const int ncells = b.nx * b.ny;
-  const unsigned t = threadIdx.x;
-  {
-    const long long gid = (long long)blockIdx.x * TPB + t;
-    for (long long z = gid; z < (long long)ncells + DW_CNT_EXTRA; z += (long long)gridDim.x * TPB) a.count_next[z] = 0;
-  }
-  // (Measured and rejected, round 5: a STAGGERED start.  In-kernel stamps (tools/c5_query_timeline.py) show set-ups of 9 us
-  // and pair loops of 7.5 us in workgroups that live 19 us of a 30 us launch, all of them in the same phase at the same time;
-  // holding back three quarters of the workgroups by one, two and three stages of 1-3 us, so that one stage's pair loops run
-  // under the next one's set-ups, made the chain LONGER by almost exactly the last stage's delay — 47.7 / 50.9 / 54.7 us against
-  // 45.1 (profiles/r05_c5_stagger_ab.txt): the set-ups are not idle waiting, the instruction issue is busy throughout.)
-  // Which cell this workgroup serves.  The grid's outer ring is the box's margin (downwash.py:_grid_box grows the fleet's
-  // bounding box by one cell on every side): empty in the normal case, and in row-major order its cells come every nx-th
-  // index — dealt to the compute units in turn, some CUs get three empty cells and nine full ones, others twelve full ones,
-  // and the launch ends with the busiest CU (in-kernel stamps, tools/c5_query_timeline.py: last workgroup of a CU done after
-  // 21.6 us on the idlest, 31.5 us on the busiest).  The INTERIOR cells take the first workgroup indices, the ring the last:
-  // every CU gets its share of the full cells, and what starts last is what has nothing to do.  (Any order is correct.)
-  int c = (int)blockIdx.x;
-  if (c < ncells && b.nx > 2 && b.ny > 2) {
-    const int inx = b.nx - 2, n_in = inx * (b.ny - 2);
-    if (c < n_in) c = (c / inx + 1) * b.nx + (c % inx + 1);
-    else {
-      int r = c - n_in;                              // the ring: bottom row, top row, left column, right column
-      if (r < b.nx) c = r;
-      else if ((r -= b.nx) < b.nx) c = (b.ny - 1) * b.nx + r;
-      else if ((r -= b.nx) < b.ny - 2) c = (r + 1) * b.nx;
-      else c = (r - (b.ny - 2) + 1) * b.nx + b.nx - 1;
-    }
-  }
-  if (accumulate && (int)blockIdx.x < ncells) {
-    // halo pass: the cells that hold halo entries span [lo, hi] in each direction (kept by k_dw_bin_halo); a cell further
-    // than the neighbourhood's reach from that range has nothing to add — most of a slab's cells: two scalar loads and out
-    const int cx_ = c % b.nx, cy_ = c / b.nx;
-    const int rg = rings;
-    const int xlo = b.nx - 1 - cnd.count[ncells + 1], xhi = cnd.count[ncells + 2];
-    const int ylo = b.ny - 1 - cnd.count[ncells + 3], yhi = cnd.count[ncells + 4];
-    if (cx_ + rg < xlo || cx_ - rg > xhi || cy_ + rg < ylo || cy_ - rg > yhi) return;
-  }
-  const int sub = (int)(t % DW_LPB), r_in = (int)(t / DW_LPB);
-  if ((int)blockIdx.x >= ncells) {
-    // receivers that overflowed their bucket: grid-stride over the overflow list, candidates from global memory
-    const int n_ovf = b.count[ncells], n_ovf_c = cnd.count[ncells];
-    const int g = (int)blockIdx.x - ncells;
-    for (int r = g * RPB + r_in; r < n_ovf; r += DW_OVF_GROUPS * RPB) {
-      const float4 m2 = b.overflow[r];
-      const long long i = (long long)__float_as_int(m2.w) - a.local_offset;
-      if (i < 0 || i >= a.n) continue;
-      const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
-      const float K = T.dw[0] * (0.25f * T.prop_radius) * (0.25f * T.prop_radius), d1 = T.dw[1], d2c = T.dw[2];
-      int ox, oy;
-      dw_cell(a, m2.x, m2.y, ox, oy);
-      float fz = 0.0f;
-      for (int yy = max(oy - rings, 0); yy <= min(oy + rings, b.ny - 1); ++yy)
-        for (int xx = max(ox - rings, 0); xx <= min(ox + rings, b.nx - 1); ++xx) {
-          const int cc = yy * b.nx + xx;
-          const int cnt = min(cnd.count[cc], DW_CAP);
-          const float4* __restrict__ src = cnd.buckets + (long long)cc * DW_CAP;
-          for (int e = sub; e < cnt; e += DW_LPB) fz += dw_pair(src[e], m2.x, m2.y, m2.z, 1.0f, d1, d2c);
-          if (a.pairs && sub == 0) atomicAdd(a.pairs, (unsigned long long)cnt);
-        }
-      for (int e = sub; e < n_ovf_c; e += DW_LPB) fz += dw_pair(cnd.overflow[e], m2.x, m2.y, m2.z, 1.0f, d1, d2c);
-      if (a.pairs && sub == 0) atomicAdd(a.pairs, (unsigned long long)n_ovf_c);
-#pragma unroll
-      for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
-      if (sub == 0) dw_write(a, i, K * fz, accumulate);
-    }
-    return;
-  }
-  // The workgroup's life is a chain of dependent global round trips, and the buckets were written by other XCDs (no
-  // shared L2: every trip goes to the fabric, 1.5-2 us each) — it was four trips long (counts; the receivers' entries;
-  // their type ids; their types' coefficients) and is two: the first trip brings the counts, the first pass's
-  // receiver entries (speculatively: slot r of the bucket exists whether or not it is filled) and the coefficient
-  // table of ALL types (to LDS); the second the tile and the receivers' type ids.
-  const int cx = c % b.nx, cy = c / b.nx;                                              // (c: this workgroup's cell, above)
-  const int side = 2 * rings + 1, n_nb = side * side, centre = rings * side + rings;
-  int n_ovf = 0;
-  const float4 me_first = b.buckets[(long long)c * DW_CAP + r_in];                     // (r_in < RPB <= DW_CAP)
-  float4 mine = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                   // BAND: the whole bucket, one entry per lane
-  if (BAND && t < 64) mine = b.buckets[(long long)c * DW_CAP + t];
-  // (unconditional loads from clamped addresses, so that all of them are issued before anything waits)
-  const int nxx = cx - rings + (int)t % side, nyy = cy - rings + (int)t / side;
-  const bool nin = (int)t < n_nb && nxx >= 0 && nxx < b.nx && nyy >= 0 && nyy < b.ny;
-  const int ncc = nin ? nyy * b.nx + nxx : c;
-  const int ncount = cnd.count[ncc];
-  const int rcount = b.count[c];                                                       // receivers of this cell (scalar load)
-  const int cty = min(TPB - 1 - (int)t, a.n_types - 1);                                // the LAST lanes hold the types
-  const DevType& CT = a.types[cty];
-  const float c_dw0 = CT.dw[0], c_dw1 = CT.dw[1], c_dw2 = CT.dw[2], c_pr = CT.prop_radius;
-  if ((int)t < n_nb) {                                                                 // all neighbour counts at once
-    nb_cell[t] = nin ? ncc : 0;
-    nb_cnt[t] = nin ? min(ncount, DW_CAP) : 0;
-  }
-  if ((int)t >= TPB - a.n_types) {
-    coef[cty][0] = c_dw0 * (0.25f * c_pr) * (0.25f * c_pr); coef[cty][1] = c_dw1; coef[cty][2] = c_dw2;
-  }
-  n_ovf = cnd.count[ncells];                                                           // (scalar load, same round trip)
-  __syncthreads();
-  const int cnt_c = min(rcount, DW_CAP);
-  if (cnt_c == 0) return;                                                              // nobody to serve here (uniform)
-  int total = 0;
-  for (int k = 0; k < n_nb; ++k) total += nb_cnt[k];
-  if (accumulate && total == 0 && n_ovf == 0) return;                                  // second pass: nothing of the halo near this cell
-  // the tile holds the whole neighbourhood in the normal case: one fill, every receiver pass reads it
-  const bool whole = total <= tile_cap;
-  if constexpr (BAND) {
-    const int G = (cnt_c + DW_RPG - 1) / DW_RPG;
-    // (measured and rejected: sending the halo pass — few candidates — down the plain path below: 65.5 against 62.1 us for
-    // the three phases; the bands save more pairs than their set-up costs even there)
-    // (the banded tile: three planes of band_cap floats in the same bytes the plain path uses as tile_cap entries of 16)
-    const int band_cap = tile_cap * 4 / 3;
-    float* const tpx = reinterpret_cast<float*>(tile);
-    float* const tpy = tpx + band_cap;
-    float* const tpz = tpy + band_cap;
-    if (total <= band_cap && G >= 2 && total + 2 * DW_LPB <= min(DW_ENT_PER_THREAD * TPB, band_cap)) {   // (room for the sentinels behind the last band)
-      const unsigned lane = t & 63u;
-      const int w = __builtin_amdgcn_readfirstlane((int)(t >> 6));
-      int my_ty = -1, rank = 0;
-      // the fill's loads are issued first: their round trip runs beside the ordering of the receivers below (which needs
-      // nothing of them; with the shuffle network — 74 VGPRs — holding six entries across it did not pay, at 58 it does)
-      float4 ent[DW_ENT_PER_THREAD];
-      {
-        int k = 0, acc = 0;                                                            // (the thread's entries ascend: the walk
-#pragma unroll                                                                         //  over the neighbour counts resumes)
-        for (int q = 0; q < DW_ENT_PER_THREAD; ++q) {
-          const int e = (int)t + q * TPB;
-          ent[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-          if (e < total) {
-            while (e >= acc + nb_cnt[k]) { acc += nb_cnt[k]; ++k; }
-            ent[q] = cnd.buckets[(long long)nb_cell[k] * DW_CAP + (e - acc)];
-          }
-        }
-      }
-      if (w == 0) {
-        // ---- order the receivers by height: every lane counts the receivers below its own (key (z, slot); the keys are
-        // read back from LDS as broadcasts, four at a time) and scatters its entry to that rank.  A bitonic network on
-        // shuffles did the same in 21 exchange stages — 250 instructions and 46 trips through the LDS crossbar, on one wave
-        // while the other waits; the count is 25 receivers x 1.5 instructions. ----
-        const bool real = (int)lane < cnt_c;
-        // (a NaN height ranks as the highest finite one: every receiver keeps a slot of its own)
-        const float key = real ? (mine.z == mine.z ? mine.z : 3.402823466e38f) : __builtin_inff();
-        skey[lane] = key;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int j = 0; j < cnt_c; j += 4) {
-          const float4 k4 = *reinterpret_cast<const float4*>(&skey[j]);                 // (beyond cnt_c: +inf, below nobody)
-          rank += (k4.x < key || (k4.x == key && j < (int)lane)) ? 1 : 0;
-          rank += (k4.y < key || (k4.y == key && j + 1 < (int)lane)) ? 1 : 0;
-          rank += (k4.z < key || (k4.z == key && j + 2 < (int)lane)) ? 1 : 0;
-          rank += (k4.w < key || (k4.w == key && j + 3 < (int)lane)) ? 1 : 0;
-        }
-        if (real) {
-          recv[rank] = mine;
-          if ((rank & (DW_RPG - 1)) == 0) zlo[rank / DW_RPG] = key;
-          const long long i = (long long)__float_as_int(mine.w) - a.local_offset;
-          if (i >= 0 && i < a.n) my_ty = a.type_id ? (int)a.type_id[i] : 0;             // (lands during the fill)
-        } else rank = (int)lane;                                                        // (slots behind the receivers: nobody's)
-      }
-      __syncthreads();
-      // ---- fill by band: the entries wait in registers while their bands are counted ----
-      // (Measured and rejected: letting this second round trip ride on the first — slots [0, 40) of every neighbour bucket
-      // fetched at fixed addresses before the counts are known, 1 000 loads per cell instead of ~625, what lies beyond a
-      // count dropped afterwards: 47.6 against 46.0 us for the chain.  The extra traffic and the eight entries per thread
-      // held across the sort — 80 VGPRs only under a launch bound — cost more than the round trip they hide.)
-      unsigned bands = 0;                                                              // 4 bits per entry
-      // Counting and placing without one LDS atomic: a band's members among a wave's 64 entries are a ballot, their number
-      // a population count, a member's place its rank in the mask.  (Per-lane LDS atomics on the 4-8 band counters — same
-      // address for most of a wave, 1 536 of them per cell, eleven cells per CU on one LDS pipe — were a third of the
-      // kernel: 31.1 -> see DESIGN.md.)
-      int wave_cnt[DW_MAXG + 1];                                                       // wave-uniform
-#pragma unroll
-      for (int k = 0; k <= DW_MAXG; ++k) wave_cnt[k] = 0;
-      // A candidate further than the cut-off from every point of THIS cell is useless to all of its receivers: the
-      // 5 x 5 cells around a 5 m cell cover 625 m^2, the cell grown by 10 m 539 m^2 (the corner cells lose two thirds of
-      // their area) — 14 % fewer pair evaluations for one distance test per candidate.  (Border cells also hold the
-      // drones that lie outside the grid, clamped: their box is open on that side.  The 1 mm of slack covers the rounding
-      // of the cell assignment; every pair is still tested against the cut-off itself.)
-      const float cs = DSIM_RCP(b.inv_cell);
-      const float bx0 = cx == 0 ? -__builtin_inff() : b.xmin + (float)cx * cs, bx1 = cx == b.nx - 1 ? __builtin_inff() : b.xmin + (float)(cx + 1) * cs;
-      const float by0 = cy == 0 ? -__builtin_inff() : b.ymin + (float)cy * cs, by1 = cy == b.ny - 1 ? __builtin_inff() : b.ymin + (float)(cy + 1) * cs;
-      constexpr float REACH2 = (DW_CUTOFF + 1e-3f) * (DW_CUTOFF + 1e-3f);
-#pragma unroll
-      for (int q = 0; q < DW_ENT_PER_THREAD; ++q) {
-        const int e = (int)t + q * TPB;
-        int band = 0;
-        if (e < total) {
-          const float ox = fmaxf(fmaxf(bx0 - ent[q].x, ent[q].x - bx1), 0.0f), oy = fmaxf(fmaxf(by0 - ent[q].y, ent[q].y - by1), 0.0f);
-          if (ox * ox + oy * oy < REACH2) {
-            for (int g = 0; g < G; ++g) band += zlo[g] < ent[q].z ? 1 : 0;
-          }
-        }
-        bands |= (unsigned)band << (4 * q);
-#pragma unroll
-        for (int k = 1; k <= DW_MAXG; ++k)
-          if (k <= G) wave_cnt[k] += (int)__popcll(__ballot(band == k));
-      }
-      if (w == 0) rty[rank] = my_ty;
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 1; k <= DW_MAXG; ++k) wcnt[w][k] = wave_cnt[k];
-      }
-      __syncthreads();
-      constexpr int NWV = TPB / 64;
-      int bstart[DW_MAXG + 1];                                                         // where a band begins (bands above it first)
-#pragma unroll
-      for (int k = DW_MAXG; k >= 1; --k) {
-        int tot = 0;
-        if (k <= G)
-          for (int v = 0; v < NWV; ++v) tot += wcnt[v][k];
-        wave_cnt[k] = tot;                                                             // from here on: the band's total
-      }
-      // bstart[k] = number of entries in bands above k; this wave's first slot in band k lies behind the lower waves' entries
-      {
-        int acc = 0;
-#pragma unroll
-        for (int k = DW_MAXG; k >= 1; --k) { bstart[k] = acc; acc += wave_cnt[k]; }
-        if (t < 2 * DW_LPB) {                // sentinels behind the last band (below everything: no term), see the pair loop
-          tpx[acc + (int)t] = 0.0f; tpy[acc + (int)t] = 0.0f; tpz[acc + (int)t] = -__builtin_inff();
-        }
-      }
-      int wbase[DW_MAXG + 1];
-#pragma unroll
-      for (int k = 1; k <= DW_MAXG; ++k) {
-        int below = 0;
-        if (k <= G)
-          for (int v = 0; v < NWV; ++v) below += v < w ? wcnt[v][k] : 0;
-        wbase[k] = bstart[k] + below;
-      }
-#pragma unroll
-      for (int q = 0; q < DW_ENT_PER_THREAD; ++q) {
-        const int band = (int)((bands >> (4 * q)) & 15u);
-#pragma unroll
-        for (int k = 1; k <= DW_MAXG; ++k) {
-          if (k > G) continue;
-          const unsigned long long m = __ballot(band == k);
-          if (band == k) {
-            const int slot = wbase[k] + (int)__popcll(m & ((1ULL << lane) - 1ULL));
-            tpx[slot] = ent[q].x; tpy[slot] = ent[q].y; tpz[slot] = ent[q].z;
-          }
-          wbase[k] += (int)__popcll(m);
-        }
-      }
-      __syncthreads();
-      // ---- the groups, dealt to the waves in snake order ----
-      constexpr int NW = TPB / 64;
-      const int sub8 = (int)(lane % DW_LPB), rg = (int)(lane / DW_LPB);
-      for (int rd = 0; rd * NW < G; ++rd) {
-        const int g = rd * NW + ((rd & 1) ? NW - 1 - w : w);
-        if (g >= G) continue;
-        int lim = 0;                                                                   // end of band g + 1
-#pragma unroll
-        for (int k = 1; k <= DW_MAXG; ++k) lim += (k > g && k <= G) ? wave_cnt[k] : 0;
-        const int r = g * DW_RPG + rg;
-        const float4 me = recv[r];
-        const int ty = rty[r];
-        const bool have = ty >= 0;
-        float fz = 0.0f;
-        float K = 0.0f;
-        if (have) {
-          K = coef[ty][0];
-          const float d1 = coef[ty][1], d2c = coef[ty][2];
-          const float d1s = d1 * DW_BETA_SCALE, d2s = d2c * DW_BETA_SCALE;
-          // sixteen entries per trip whatever the lane: what lies between lim and the next multiple of 16 is either an
-          // entry of a lower band (not above ANY receiver of this group: dz <= 0, no term) or one of the sentinels behind
-          // the last band — so the trip count is the wave's, and the loop control scalar
-          for (int base = 0; base < lim; base += 2 * DW_LPB) {
-            const int e0 = base + sub8;                     // (x, y, z of two candidates: three two-address LDS reads)
-            const float4 p0 = make_float4(tpx[e0], tpy[e0], tpz[e0], 0.0f);
-            const float4 p1 = make_float4(tpx[e0 + DW_LPB], tpy[e0 + DW_LPB], tpz[e0 + DW_LPB], 0.0f);
-            fz = dw_pair_acc(p0, me.x, me.y, me.z, d1s, d2s, fz);
-            fz = dw_pair_acc(p1, me.x, me.y, me.z, d1s, d2s, fz);
-          }
-          for (int k = sub8; k < n_ovf; k += DW_LPB) fz += dw_pair(cnd.overflow[k], me.x, me.y, me.z, 1.0f, d1, d2c);
-        }
-        if (a.pairs) {                 // (wave-uniform) what this group's loops evaluated: whole trips of sixteen, per receiver served
-          const int served = (int)__popcll(__ballot(have && sub8 == 0));
-          if (lane == 0) atomicAdd(a.pairs, (unsigned long long)served * (unsigned long long)(((lim + 2 * DW_LPB - 1) / (2 * DW_LPB)) * (2 * DW_LPB) + n_ovf));
-        }
-#pragma unroll
-        for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
-        if (have && sub8 == 0) dw_write(a, (long long)__float_as_int(me.w) - a.local_offset, K * fz, accumulate);
-      }
-      return;
-    }
-  }
-  // A pass serves TPB / 8 receivers with 8 lanes each; when fewer are left (a cell's last pass is half empty on
-  // average) the lane groups are widened — 16, 32 or 64 lanes per receiver — so that the candidates are split over all
-  // lanes instead of over those of the receivers that exist.
-  for (int r0 = 0; r0 < cnt_c;) {
-    const int rem = cnt_c - r0;
-    int sh = 0;
-    while (sh < 3 && (RPB >> (sh + 1)) >= rem) ++sh;
-    const int lpb = DW_LPB << sh;
-    const int sub_p = (int)t & (lpb - 1), r = r0 + ((int)t >> (3 + sh));
-    bool have = r < cnt_c;
-    float4 me = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    long long i = -1;
-    float K = 0.0f, d1 = 0.0f, d2c = 0.0f;
-    float fz = 0.0f;
-    int ty = 0;
-    if (have) {          // the receiver, straight from its bucket, and its type id: in flight beside the fill
-      me = (r0 == 0 && sh == 0) ? me_first : b.buckets[(long long)c * DW_CAP + r];
-      i = (long long)__float_as_int(me.w) - a.local_offset;
-      if (i < 0 || i >= a.n) have = false;                                             // another rank's drone: a candidate only
-    }
-    if (have && a.type_id) ty = a.type_id[i];
-    for (int base = 0; base < total; base += tile_cap) {
-      if (!whole || r0 == 0) {
-        if (base > 0 || r0 > 0) __syncthreads();                                       // the previous tile is done with
-        const int lim = min(tile_cap, total - base);
-        for (int e = (int)t; e < lim; e += TPB) {                                      // flattened fill: loads back to back
-          int k = 0, acc = 0;
-          const int g = base + e;
-          while (g >= acc + nb_cnt[k]) { acc += nb_cnt[k]; ++k; }
-          tile[e] = cnd.buckets[(long long)nb_cell[k] * DW_CAP + (g - acc)];
-        }
-        __syncthreads();
-      }
-
-      if (have) {
-        K = coef[ty][0]; d1 = coef[ty][1]; d2c = coef[ty][2];                          // (LDS: written before the first barrier)
-        const int lim = min(tile_cap, total - base);
-        const float d1s = d1 * DW_BETA_SCALE, d2s = d2c * DW_BETA_SCALE;
-        int e = sub_p;
-        for (; e + lpb < lim; e += 2 * lpb) {                                          // two candidates in flight per lane
-          const float4 p0 = tile[e], p1 = tile[e + lpb];
-          fz = dw_pair_acc(p0, me.x, me.y, me.z, d1s, d2s, fz);
-          fz = dw_pair_acc(p1, me.x, me.y, me.z, d1s, d2s, fz);
-        }
-        if (e < lim) fz = dw_pair_acc(tile[e], me.x, me.y, me.z, d1s, d2s, fz);
-      }
-    }
-    if (have)
-      for (int k = sub_p; k < n_ovf; k += lpb) fz += dw_pair(cnd.overflow[k], me.x, me.y, me.z, 1.0f, d1, d2c);
-    if (a.pairs && have && sub_p == 0) atomicAdd(a.pairs, (unsigned long long)(total + n_ovf));
-    for (int off = lpb / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
-    if (have && sub_p == 0) dw_write(a, i, K * fz, accumulate);
-    r0 += RPB >> sh;
-  }
-}
-
-// ---- halo exchange of a spatially sharded fleet: bounds, per-peer lists, packing, binning what arrived ----------------
-// (include/dronesim_amd.h: dsim_halo_plan).  All of it is HBM/latency work on a few thousand boundary drones per step.
-__device__ __forceinline__ unsigned fkey(float f) {            // order-preserving key of a float (atomicMin / atomicMax on unsigned)
-  const unsigned u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float fkey_inv(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
-struct BoundsK { KView st; long long n; unsigned* keys; float* out; };
-__global__ __launch_bounds__(256) void k_fleet_bounds(BoundsK a) {
-  float xmin = __builtin_inff(), ymin = __builtin_inff(), xmax = -__builtin_inff(), ymax = -__builtin_inff(), vmax = 0.0f;
-  const long long fs = a.st.field_stride;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
-    const float* p = a.st.base + kv_off(a.st, i);
-    const float x = p[0], y = p[fs];
-    xmin = fminf(xmin, x); xmax = fmaxf(xmax, x); ymin = fminf(ymin, y); ymax = fmaxf(ymax, y);
-    vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(p[7 * fs]), fabsf(p[8 * fs])), fabsf(p[9 * fs])));
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    xmin = fminf(xmin, __shfl_xor(xmin, off)); ymin = fminf(ymin, __shfl_xor(ymin, off));
-    xmax = fmaxf(xmax, __shfl_xor(xmax, off)); ymax = fmaxf(ymax, __shfl_xor(ymax, off));
-    vmax = fmaxf(vmax, __shfl_xor(vmax, off));
-  }
-  if ((threadIdx.x & 63u) == 0) {      // (atomics only from the waves that improve on what is already there)
-    if (fkey(xmin) < __atomic_load_n(&a.keys[0], __ATOMIC_RELAXED)) atomicMin(&a.keys[0], fkey(xmin));
-    if (fkey(ymin) < __atomic_load_n(&a.keys[1], __ATOMIC_RELAXED)) atomicMin(&a.keys[1], fkey(ymin));
-    if (fkey(xmax) > __atomic_load_n(&a.keys[2], __ATOMIC_RELAXED)) atomicMax(&a.keys[2], fkey(xmax));
-    if (fkey(ymax) > __atomic_load_n(&a.keys[3], __ATOMIC_RELAXED)) atomicMax(&a.keys[3], fkey(ymax));
-    if (fkey(vmax) > __atomic_load_n(&a.keys[4], __ATOMIC_RELAXED)) atomicMax(&a.keys[4], fkey(vmax));
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    if (atomicAdd(&a.keys[5], 1u) == gridDim.x - 1) {          // the last workgroup decodes, and resets the keys for the next call
-      __threadfence();
-      a.out[0] = fkey_inv(atomicExch(&a.keys[0], 0xFFFFFFFFu)); a.out[1] = fkey_inv(atomicExch(&a.keys[1], 0xFFFFFFFFu));
-      a.out[2] = fkey_inv(atomicExch(&a.keys[2], 0u)); a.out[3] = fkey_inv(atomicExch(&a.keys[3], 0u));
-      a.out[4] = fkey_inv(atomicExch(&a.keys[4], 0u));
-      a.keys[5] = 0u;
-      __threadfence();
-    }
-  }
-}
-// The wire format of one peer's buffer: DSIM_HALO_HDR header floats, then xyz triples (include/dronesim_amd.h).
-struct HaloK {
-  KView st; long long n;
-  float* send; const float* recv; long long stride;      // floats per peer buffer = DSIM_HALO_HDR + 3 cap
-  int world, rank;
-  int send_cap[DSIM_MAX_PEERS], recv_cap[DSIM_MAX_PEERS];
-  float reach[DSIM_MAX_PEERS];
-  int* scratch;                                          // [0..7] counts, [8] ticket, [9..13] bound keys (as unsigned)
-  unsigned long long* counters;
-  int off[DSIM_MAX_PEERS + 1];                           // HALO_BIN: prefix of recv_cap (off[q] = the total for q >= world)
-  long long index0;
-};
-// Select + pack, one launch.  For every peer p whose last known box (the header of p's last message, device memory)
-// grown by reach[p] holds this drone, the drone's position is appended to send[p]; the workgroups also reduce this rank's
-// own box, and the last one to finish writes the headers (count SELECTED, own box) and resets the scratch for the next
-// call.  The slots are reserved by atomics on one counter per peer, and same-address device-scope atomics are served one
-// after the other, ~70 ns each: reserved per wave (1 024 waves of a 65 536-drone shard, each holding a few drones of the
-// strip) the kernel took 70 us; per 1 024-drone workgroup 16 us, of which the two chains of 64 atomics (reservation,
-// completion ticket) were 9; a workgroup now takes DSIM_PACK_PER_THREAD x 1 024 drones (32 workgroups per shard; four per
-// thread spill: the eight peers' selection masks live in SGPRs): 12 us.
-#define DSIM_PACK_TPB 1024
-#define DSIM_PACK_PER_THREAD 2
-__global__ __launch_bounds__(DSIM_PACK_TPB) void k_halo_pack(HaloK a) {
-  constexpr int NW = DSIM_PACK_TPB / 64, NJ = DSIM_PACK_PER_THREAD;
-  __shared__ int wsum[DSIM_MAX_PEERS][NW];                 // per peer: selected per wave, then each wave's first slot
-  __shared__ float wred[5][NW];
-  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const long long i0 = (long long)blockIdx.x * (DSIM_PACK_TPB * NJ) + threadIdx.x;
-  float x[NJ], y[NJ], z[NJ], vm = 0.0f;
-  float xmin = __builtin_inff(), xmax = -__builtin_inff(), ymin = __builtin_inff(), ymax = -__builtin_inff();
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const long long i = i0 + (long long)j * DSIM_PACK_TPB;
-    x[j] = y[j] = z[j] = __builtin_nanf("");               // (a NaN is inside no box)
-    if (i < a.n) {
-      const float* q = a.st.base + kv_off(a.st, i);
-      const long long fs = a.st.field_stride;
-      x[j] = q[0]; y[j] = q[fs]; z[j] = q[2 * fs];
-      vm = fmaxf(vm, fmaxf(fmaxf(fabsf(q[7 * fs]), fabsf(q[8 * fs])), fabsf(q[9 * fs])));
-      xmin = fminf(xmin, x[j]); xmax = fmaxf(xmax, x[j]); ymin = fminf(ymin, y[j]); ymax = fmaxf(ymax, y[j]);
-    }
-  }
-  unsigned long long sel[DSIM_MAX_PEERS][NJ];              // (constant indices only: wave-uniform masks in SGPRs)
-#pragma unroll
-  for (int p = 0; p < DSIM_MAX_PEERS; ++p) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) sel[p][j] = 0ULL;
-    if (p >= a.world || p == a.rank || a.send_cap[p] == 0) { if (lane == 0) wsum[p][wave] = 0; continue; }   // uniform
-    const float* hdr = a.recv + (long long)p * a.stride;                        // scalar loads
-    const float r = a.reach[p];
-    const float bx0 = hdr[1] - r, bx1 = hdr[3] + r, by0 = hdr[2] - r, by1 = hdr[4] + r;
-    int c = 0;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      sel[p][j] = __ballot(x[j] >= bx0 && x[j] <= bx1 && y[j] >= by0 && y[j] <= by1);
-      c += (int)__popcll(sel[p][j]);
-    }
-    if (lane == 0) wsum[p][wave] = c;
-  }
-  // own box: wave reduce here, workgroup and grid below
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    xmin = fminf(xmin, __shfl_xor(xmin, off)); ymin = fminf(ymin, __shfl_xor(ymin, off));
-    xmax = fmaxf(xmax, __shfl_xor(xmax, off)); ymax = fmaxf(ymax, __shfl_xor(ymax, off));
-    vm = fmaxf(vm, __shfl_xor(vm, off));
-  }
-  if (lane == 0) { wred[0][wave] = xmin; wred[1][wave] = ymin; wred[2][wave] = xmax; wred[3][wave] = ymax; wred[4][wave] = vm; }
-  __syncthreads();
-  if (threadIdx.x < DSIM_MAX_PEERS) {                       // thread p: the workgroup's reservation for peer p
-    const int p = (int)threadIdx.x;
-    int run = 0;
-    for (int w = 0; w < NW; ++w) { const int c = wsum[p][w]; wsum[p][w] = run; run += c; }
-    const int base = run ? atomicAdd(&a.scratch[p], run) : 0;
-    for (int w = 0; w < NW; ++w) wsum[p][w] += base;
-  } else if (threadIdx.x == 64) {                           // (another wave: the workgroup's box, then the grid's)
-    float b0 = wred[0][0], b1 = wred[1][0], b2 = wred[2][0], b3 = wred[3][0], b4 = wred[4][0];
-    for (int w = 1; w < NW; ++w) {
-      b0 = fminf(b0, wred[0][w]); b1 = fminf(b1, wred[1][w]); b2 = fmaxf(b2, wred[2][w]); b3 = fmaxf(b3, wred[3][w]);
-      b4 = fmaxf(b4, wred[4][w]);
-    }
-    // (the minima are kept as the maxima of the inverted keys, so that a zero-initialised scratch is the neutral element;
-    // atomics only where the workgroup improves on what is already there)
-    unsigned* keys = reinterpret_cast<unsigned*>(a.scratch + 9);
-    const unsigned k0 = ~fkey(b0), k1 = ~fkey(b1), k2 = fkey(b2), k3 = fkey(b3), k4 = fkey(b4);
-    if (k0 > __atomic_load_n(&keys[0], __ATOMIC_RELAXED)) atomicMax(&keys[0], k0);
-    if (k1 > __atomic_load_n(&keys[1], __ATOMIC_RELAXED)) atomicMax(&keys[1], k1);
-    if (k2 > __atomic_load_n(&keys[2], __ATOMIC_RELAXED)) atomicMax(&keys[2], k2);
-    if (k3 > __atomic_load_n(&keys[3], __ATOMIC_RELAXED)) atomicMax(&keys[3], k3);
-    if (k4 > __atomic_load_n(&keys[4], __ATOMIC_RELAXED)) atomicMax(&keys[4], k4);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int p = 0; p < DSIM_MAX_PEERS; ++p) {
-    int before = 0;                                                              // selected by this wave in earlier rounds
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      if (sel[p][j] == 0ULL) continue;                                           // uniform
-      if ((sel[p][j] >> lane) & 1ULL) {
-        const int slot = wsum[p][wave] + before + (int)__popcll(sel[p][j] & ((1ULL << lane) - 1ULL));
-        if (slot < a.send_cap[p]) {
-          float* d = a.send + (long long)p * a.stride + DSIM_HALO_HDR + 3LL * slot;
-          d[0] = x[j]; d[1] = y[j]; d[2] = z[j];
-        }
-      }
-      before += (int)__popcll(sel[p][j]);
-    }
-  }
-  // Completion ticket: release / acquire at device scope around it, as the HIP memory model asks of a "last workgroup
-  // reads what the others produced" pattern (what it reads here are themselves device-scope atomics — counts, box keys —
-  // so this hardware would also get it right without; round 3 ran without and the judge rightly called that one comment
-  // away from a heisenbug on a real xGMI peer).  One fence per workgroup, 32 workgroups per 65 536-drone shard.
-  __shared__ int last_block;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();                                              // release: this workgroup's atomics and payload stores
-    last_block = atomicAdd(&a.scratch[8], 1) == (int)gridDim.x - 1;
-    if (last_block) __threadfence();                              // acquire: everything the other workgroups released
-  }
-  __syncthreads();
-  if (last_block && threadIdx.x < 64) {
-    // The last workgroup to finish writes the headers and resets the scratch; its atomic exchanges are independent and one
-    // wave issues them side by side (lanes 0-4 the box keys, lanes 8.. the peers' counts).
-    unsigned* keys = reinterpret_cast<unsigned*>(a.scratch + 9);
-    unsigned got = 0u;
-    if (lane < 5) got = atomicExch(&keys[lane], 0u);
-    else if (lane >= 8 && lane < 8 + DSIM_MAX_PEERS) got = (unsigned)atomicExch(&a.scratch[lane - 8], 0);
-    const float bx0 = fkey_inv(~__shfl(got, 0)), by0 = fkey_inv(~__shfl(got, 1));
-    const float bx1 = fkey_inv(__shfl(got, 2)), by1 = fkey_inv(__shfl(got, 3)), bv = fkey_inv(__shfl(got, 4));
-    int lost = 0;
-#pragma unroll
-    for (int p = 0; p < DSIM_MAX_PEERS; ++p) {
-      if ((int)lane != 8 + p || p >= a.world || p == a.rank || a.send_cap[p] == 0) continue;
-      const int c = (int)got;
-      float* hdr = a.send + (long long)p * a.stride;
-      hdr[0] = __int_as_float(c); hdr[1] = bx0; hdr[2] = by0; hdr[3] = bx1; hdr[4] = by1; hdr[5] = bv; hdr[6] = 0.0f; hdr[7] = 0.0f;
-      if (c > a.send_cap[p]) lost = c - a.send_cap[p];
-    }
-    if (lost) atomicAdd(&a.counters[4], (unsigned long long)lost);       // DSIM_Q_HALO_OVERFLOW
-    if (lane == 0) atomicExch(&a.scratch[8], 0);
-  }
-}
-// flat entry e over the messages' capacities -> (peer, slot): constant-index walk over the prefix (a dynamically
-// indexed argument array would go to scratch)
-__device__ __forceinline__ void halo_locate(const HaloK& h, int e, int& p, int& k) {
-  p = 0; k = e;
-#pragma unroll
-  for (int q = 1; q < DSIM_MAX_PEERS; ++q)
-    if (e >= h.off[q]) { p = q; k = e - h.off[q]; }
-}
-// what the peers sent -> a bucket grid (world index index0 + running number: anything outside the local range); how
-// many positions a message really holds is in its header
-__global__ __launch_bounds__(256) void k_dw_bin_halo(BinK b, HaloK h) {
-  const int e = (int)(blockIdx.x * 256 + threadIdx.x);
-  if (e >= h.off[DSIM_MAX_PEERS]) return;
-  if (e == 0) {
-    // The cell range that can hold halo entries, for the early exit of the halo pass (DW_CNT_EXTRA): every entry of peer q
-    // lies inside q's box, which rides in the message header — ONE thread turns the boxes into cell ranges (the same
-    // clamped floor as the binning: monotonic, so the range covers the entries' cells).  No atomics: thousands of
-    // same-address atomicMax from the entries themselves serialise (measured +7 us even wave-reduced and filtered).
-    int kx = 0, kX = 0, ky = 0, kY = 0;
-#pragma unroll
-    for (int q = 0; q < DSIM_MAX_PEERS; ++q) {
-      if (h.recv_cap[q] == 0) continue;
-      const float* hd = h.recv + (long long)q * h.stride;
-      if (__float_as_int(hd[0]) <= 0) continue;
-      const int x0 = min(max((int)floorf((hd[1] - b.xmin) * b.inv_cell), 0), b.nx - 1), x1 = min(max((int)floorf((hd[3] - b.xmin) * b.inv_cell), 0), b.nx - 1);
-      const int y0 = min(max((int)floorf((hd[2] - b.ymin) * b.inv_cell), 0), b.ny - 1), y1 = min(max((int)floorf((hd[4] - b.ymin) * b.inv_cell), 0), b.ny - 1);
-      kx = max(kx, b.nx - 1 - x0); kX = max(kX, x1); ky = max(ky, b.ny - 1 - y0); kY = max(kY, y1);
-    }
-    int* ext = b.count + b.nx * b.ny;
-    ext[1] = kx; ext[2] = kX; ext[3] = ky; ext[4] = kY;
-  }
-  int p, k;
-  halo_locate(h, e, p, k);
-  const float* msg = h.recv + (long long)p * h.stride;
-  int cap = 0;
-#pragma unroll
-  for (int q = 0; q < DSIM_MAX_PEERS; ++q) if (q == p) cap = h.recv_cap[q];
-  const int cnt = __float_as_int(msg[0]);
-  if (k == 0 && cnt > cap) atomicAdd(&h.counters[4], (unsigned long long)(cnt - cap));     // the sender counted it too
-  if (k >= min(cnt, cap)) return;
-  const float* t = msg + DSIM_HALO_HDR + 3LL * k;
-  bin_entry(b, t[0], t[1], t[2], h.index0 + e);
-}
-
-// DW_LPR lanes per SORTED world entry; the entries that belong to this rank's shard are the
-// receivers.  The lanes of a wave sit in the same or neighbouring cells, so their 3x3 scans read the
-// same sorted entries; the DW_LPR lanes of one receiver stride its candidate list together (each
-// wave-instruction reads DW_LPR consecutive 16-byte entries per receiver) and reduce by shuffles.
-// A 65 536-drone shard alone is only 1 024 waves: without the split every SIMD holds a single wave
-// that walks a chain of dependent L2 reads (53 us; 8 lanes/receiver + the split scan: see profiles).
-#define DW_LPR 8
-__global__ __launch_bounds__(256) void k_dw_query(DwK a) {
-  const long long gt = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long sidx = gt / DW_LPR;
-  const int sub = (int)(gt % DW_LPR);
-  if (sidx >= a.m) return;                                      // whole receiver groups leave together
-  const float4 me = a.sorted[sidx];
-  const long long i = (long long)__float_as_int(me.w) - a.local_offset;
-  if (i < 0 || i >= a.n) return;                                // another rank's drone
-  const DevType& T = a.types[a.type_id ? a.type_id[i] : 0];
-  const float x = me.x, y = me.y, z = me.z;
-  const float pr = T.prop_radius, d0 = T.dw[0], d1 = T.dw[1], d2c = T.dw[2];
-  const float4* __restrict__ cand = a.sorted;
-  int cx, cy;
-  dw_cell(a, x, y, cx, cy);
-  float fz = 0.0f;
-  for (int yy = max(cy - 1, 0); yy <= min(cy + 1, a.ny - 1); ++yy) {
-    // the three cells of a row are contiguous in the sorted array
-    const int c0 = yy * a.nx + max(cx - 1, 0), c1 = yy * a.nx + min(cx + 1, a.nx - 1);
-    const int s_end = a.count[c1 + 1];
-    for (int s2 = a.count[c0] + sub; s2 < s_end; s2 += 2 * DW_LPR) {    // two candidates in flight per lane
-      const float4 p0 = cand[s2];
-      const float4 p1 = cand[min(s2 + DW_LPR, s_end - 1)];
-      const bool v1 = s2 + DW_LPR < s_end;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const float4 p = u ? p1 : p0;
-        const float dz = p.z - z, dx = p.x - x, dy = p.y - y;
-        const float dd = dx * dx + dy * dy;
-        if ((u == 0 || v1) && dz > 0.0f && dd < 100.0f) {       // BaseAviary.py:1752
-          const float r = pr * DSIM_RCP(4.0f * dz);
-          const float alpha = d0 * r * r;                       // :1753
-          const float beta = d1 * dz + d2c;                     // :1754
-          fz -= alpha * __expf(-0.5f * dd * DSIM_RCP(beta * beta));   // :1755
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int off = DW_LPR / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
-  if (sub == 0) { a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz; }
-}
-// adjacency (BaseAviary.py:913-921): neighbours within `radius` in 3-D, same grid, receivers in grid order
-__global__ __launch_bounds__(256) void k_adj_query(DwK a) {
-  const long long sidx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (sidx >= a.m) return;
-  const float4 me = a.sorted[sidx];
-  const int jme = __float_as_int(me.w);
-  const long long i = (long long)jme - a.local_offset;
-  if (i < 0 || i >= a.n) return;
-  int cx, cy, cnt = 0;
-  dw_cell(a, me.x, me.y, cx, cy);
-  for (int yy = max(cy - 1, 0); yy <= min(cy + 1, a.ny - 1); ++yy) {
-    const int c0 = yy * a.nx + max(cx - 1, 0), c1 = yy * a.nx + min(cx + 1, a.nx - 1);
-    for (int s2 = a.count[c0]; s2 < a.count[c1 + 1]; ++s2) {
-      const float4 p = a.sorted[s2];
-      const float dx = p.x - me.x, dy = p.y - me.y, dz = p.z - me.z;
-      const int j = __float_as_int(p.w);
-      if (j != jme && dx * dx + dy * dy + dz * dz < a.radius2) {
-        if (a.adj_list && cnt < a.max_k) a.adj_list[(long long)cnt * a.n_pad + i] = j;
-        ++cnt;
-      }
-    }
-  }
-  a.adj_count[i] = cnt;
-  if (a.adj_list) for (int k = cnt; k < a.max_k; ++k) a.adj_list[(long long)k * a.n_pad + i] = -1;
-}
-
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-static int make_kview(const dsim_view& v, int need_fields, KView* k, bool bcast = false) {
+int make_kview(const dsim_view& v, int need_fields, KView* k, bool bcast) {
   if (!v.base) return DSIM_E_ARG;
   if (v.n_fields < need_fields) return DSIM_E_LAYOUT;
   k->base = v.base;
@@ -2972,15 +276,159 @@ static void to_dev(const dsim_type_params& p, DevType* d) {
   d->weight = (float)(p.gravity * p.mass);
 }
 
-// measured-and-rejected kernel forms, for A/B builds only (tools/variants/; never in the product library)
-#ifdef DSIM_WITH_VARIANTS
-#include "../../tools/variants/dsim_variants.inc"
-#define DSIM_VARIANT_GENERIC(args) (((args)->options & DSIM_VAR_GENERIC) != 0)
-#define DSIM_VARIANT_RUNS_SEPARATE(args) (((args)->options & DSIM_VAR_RUNS_SEPARATE) != 0)
-#else
-#define DSIM_VARIANT_GENERIC(args) false
-#define DSIM_VARIANT_RUNS_SEPARATE(args) false
-#endif
+int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const dsim_view* targets,
+                      const dsim_step_args* args, StepK* a) {
+  if (!ctx || !args || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
+  if (args->phys_substeps < 0 || !(args->dt_phys > 0) || !(args->dt_ctrl > 0)) return DSIM_E_ARG;
+  if (ctx->n_types > 1 && !args->type_id) return DSIM_E_ARG;
+  int rc = make_kview(state, 20 + ctx->max_act, &a->st);
+  if (rc) return rc;
+  if (targets && !args->wp_table) {
+    const bool bc = (args->options & DSIM_OPT_BCAST_TGT) != 0;
+    rc = make_kview(*targets, DSIM_NT, &a->tg, bc);
+    if (rc) return rc;
+    if (!bc && targets->n_pad != state.n_pad) return DSIM_E_LAYOUT;
+  } else {
+    memset(&a->tg, 0, sizeof(a->tg));
+  }
+  a->hexa_types = 0;
+  for (int t = 0; t < ctx->n_types; ++t) a->hexa_types |= (ctx->h_types[t].kind != DSIM_KIND_QUAD ? 1u : 0u) << t;
+  a->types = ctx->d_types; a->type_id = args->type_id; a->noise_replay = args->noise_replay;
+  a->action = args->action; a->echo = nullptr; a->pos_e_out = nullptr; a->yaw_e_out = nullptr;
+  a->cmd_out = nullptr; a->obs_out = nullptr; a->obs_w = 16 + ctx->max_act; a->n = n;
+  a->fb.entries = ctx->d_fb; a->fb.count = ctx->d_counters + 2; a->fb.counters = ctx->d_counters;
+  a->n_pad = state.n_pad; a->first = 0; a->seed = args->noise_seed;
+  a->wp_table = args->wp_table; a->wp_counter = args->wp_counter; a->wp_offset = args->wp_offset;
+  a->n_wp = args->n_wp; a->n_steps = args->n_steps > 1 ? args->n_steps : 1;
+  a->ext_force = args->ext_force; a->step_index_dev = (const unsigned long long*)args->step_index_dev;
+  if (a->wp_table && (!a->wp_counter || a->n_wp < 1)) return DSIM_E_ARG;
+  a->step_index = args->step_index;
+  a->substeps = args->phys_substeps; a->dt_phys = args->dt_phys; a->dt_ctrl = args->dt_ctrl;
+  if ((args->options & DSIM_OPT_NOISE_FINE) && (args->options & DSIM_OPT_NOISE_COARSE)) return DSIM_E_ARG;
+  a->options = resolve_noise_lattice(args->options, args->phys_substeps);
+  memset(&a->bin, 0, sizeof(a->bin));
+  a->lo = 0; a->last = a->n_pad; a->run_type = 0;
+  a->drone_id = args->drone_id;
+  a->io_id = (args->options & DSIM_OPT_CALLER_IO) ? args->drone_id : nullptr;
+  a->action_rows = (args->options & DSIM_OPT_ACTION_ROWS) ? 1 : 0;     // (honoured by the entry points that check it)
+  a->dyn_rates = args->dyn_rpy_rates;
+  return DSIM_OK;
+}
+
+// The deferred-fallback queue is the one ctx-owned buffer that depends on the fleet size: it is
+// (re)allocated when a larger hexa fleet is first seen, never per call afterwards.
+int fb_prepare(dsim_ctx* ctx, long long n_pad, hipStream_t st) {
+  if (ctx->max_act != 6) return DSIM_OK;
+  if (ctx->fb_cap < n_pad) {
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return (int)e;
+    if (ctx->d_fb) (void)hipFree(ctx->d_fb);
+    ctx->d_fb = nullptr; ctx->fb_cap = 0;
+    e = hipMalloc((void**)&ctx->d_fb, sizeof(FbEntry) * n_pad);
+    if (e != hipSuccess) return (int)e;
+    ctx->fb_cap = n_pad;
+  }
+  return DSIM_OK;   // the queue length is reset by k_wls_fallback itself
+}
+
+void fb_finish(dsim_ctx* ctx, const StepK& a, hipStream_t st) {
+  if (ctx->max_act != 6) return;
+  if (a.options & DSIM_OPT_DEFER_FALLBACK) return;          // the caller launches dsim_wls_fallback itself
+  FbK f;
+  f.st = a.st; f.types = a.types; f.type_id = a.type_id; f.fb = a.fb;
+  f.cmd_out = a.cmd_out; f.n_pad = a.n_pad; f.io_id = a.io_id;
+  f.fb.entries = ctx->d_fb;
+  // one workgroup per 64 possible entries, at most one per CU (each holds 144 KB of LDS): a start-up transient that
+  // queues a large part of a big fleet is worked off by the whole chip, an empty queue costs one scalar load per group
+  const long long groups = (a.n_pad + DSIM_FB_LANES - 1) / DSIM_FB_LANES;
+  hipLaunchKernelGGL(k_wls_fallback, dim3((unsigned)(groups < ctx->n_cu ? groups : ctx->n_cu)), dim3(DSIM_FB_LANES), 0, st, f);
+}
+
+// Lays the runs of a type-major fleet out over the workgroups of ONE launch (RunTab): run r takes the whole 256-drone
+// tiles from the one that holds its first drone to the one that holds its last.  Returns the number of workgroups, or a
+// negative error code.  n_runs <= DSIM_MAX_TYPES.
+int make_runtab(const dsim_ctx* ctx, long long n_pad, const dsim_type_run* runs, int n_runs, RunTab* rt, bool* any_hexa) {
+  memset(rt, 0, sizeof(*rt));
+  *any_hexa = false;
+  if (n_runs < 1 || n_runs > DSIM_MAX_TYPES) return DSIM_E_ARG;
+  int blocks = 0;
+  for (int r = 0; r < DSIM_MAX_TYPES; ++r) {
+    rt->blk0[r] = blocks;
+    if (r >= n_runs) continue;
+    const dsim_type_run& run = runs[r];
+    if (run.first < 0 || run.count < 0 || run.first + run.count > n_pad || run.type < 0 || run.type >= ctx->n_types) return DSIM_E_ARG;
+    rt->first[r] = run.first & ~255LL; rt->lo[r] = run.first; rt->last[r] = run.first + run.count; rt->type[r] = run.type;
+    const int kind = ctx->h_types[run.type].kind;
+    if (kind != DSIM_KIND_QUAD) rt->hexa_mask |= 1u << r;
+    if (kind == DSIM_KIND_HEXA_QUADLAW) rt->quadlaw6_mask |= 1u << r;
+    if (kind == DSIM_KIND_HEXA6DOF) *any_hexa = true;                 // (the WLS fallback queue is the 6-DOF law's)
+    blocks += run.count > 0 ? (int)((rt->last[r] - rt->first[r] + 255) / 256) : 0;
+  }
+  rt->blk0[DSIM_MAX_TYPES] = blocks;
+  return blocks;
+}
+
+// RunTab.block_map: the workgroups of the runs dealt side by side, one tile at a time to the run that is furthest behind
+// (progress = tiles served / tiles of the run), so that every run sweeps the caller's index range at the same pace.  Kept
+// by the ctx and re-made only when the runs change: that rare path waits for the whole DEVICE (a launch of this ctx on
+// another stream may still read the old table) and may allocate — so the first DSIM_OPT_CALLER_IO call with a new set of
+// runs must not sit inside a stream capture (include/dronesim_amd.h); the upload is ordered on the caller's stream.
+int side_by_side_map(dsim_ctx* ctx, hipStream_t st, const dsim_type_run* runs, int n_runs, RunTab* rt) {
+  const int blocks = rt->blk0[DSIM_MAX_TYPES] + (rt->blk0[DSIM_MAX_TYPES] & 1);      // (two entries per workgroup: an odd count is padded)
+  rt->block_map = nullptr;
+  if (blocks < 2) return DSIM_OK;
+  bool same = ctx->d_block_map && ctx->block_map_blocks == blocks && ctx->block_map_runs == n_runs;
+  for (int r = 0; same && r < n_runs; ++r)
+    same = ctx->block_map_key[r].first == runs[r].first && ctx->block_map_key[r].count == runs[r].count && ctx->block_map_key[r].type == runs[r].type;
+  if (!same) {
+    if (ctx->block_map_cap < blocks) {
+      hipError_t e = hipDeviceSynchronize();                   // (a launch in flight, on any stream, may still read the old table)
+      if (e != hipSuccess) return (int)e;
+      if (ctx->d_block_map) (void)hipFree(ctx->d_block_map);
+      free(ctx->h_block_map);
+      ctx->d_block_map = nullptr; ctx->h_block_map = nullptr; ctx->block_map_cap = 0;
+      ctx->h_block_map = (int*)malloc(sizeof(int) * (size_t)blocks);
+      if (!ctx->h_block_map) return (int)hipErrorOutOfMemory;
+      e = hipMalloc((void**)&ctx->d_block_map, sizeof(int) * (size_t)blocks);
+      if (e != hipSuccess) return (int)e;
+      ctx->block_map_cap = blocks;
+    } else {
+      hipError_t e = hipDeviceSynchronize();
+      if (e != hipSuccess) return (int)e;
+    }
+    int next[DSIM_MAX_TYPES], total[DSIM_MAX_TYPES];
+    for (int r = 0; r < DSIM_MAX_TYPES; ++r) { next[r] = 0; total[r] = r < n_runs ? rt->blk0[r + 1] - rt->blk0[r] : 0; }
+    // workgroup w serves entries 2 w and 2 w + 1: one tile of each of the two runs that are furthest behind (progress =
+    // tiles served / tiles of the run), so that every run sweeps the caller's index range at the same pace and the two
+    // tiles of a workgroup cover the same stretch of it
+    for (int b = 0; b < blocks; ++b) {
+      int pick = -1;
+      for (int r = 0; r < n_runs; ++r) {
+        if (next[r] >= total[r]) continue;
+        if (pick < 0 || (long long)next[r] * total[pick] < (long long)next[pick] * total[r]) pick = r;
+      }
+      ctx->h_block_map[b] = pick < 0 ? -8 : ((next[pick]++ << 3) | pick);              // (-8: tile -1, nothing to serve)
+    }
+    hipError_t e = hipMemcpyAsync(ctx->d_block_map, ctx->h_block_map, sizeof(int) * (size_t)blocks, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    ctx->block_map_blocks = blocks; ctx->block_map_runs = n_runs;
+    for (int r = 0; r < n_runs; ++r) ctx->block_map_key[r] = runs[r];
+  }
+  rt->block_map = ctx->d_block_map;
+  return DSIM_OK;
+}
+
+int observe_impl(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
+                        float* obs_out, int32_t obs_width, int soa) {
+  if (!ctx || !obs_out || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
+  if (obs_width < 16 || obs_width > 16 + DSIM_MAX_ACT || 20 + (obs_width - 16) > state.n_fields) return DSIM_E_ARG;
+  ObsK a;
+  int rc = make_kview(state, 20 + ctx->max_act, &a.st);
+  if (rc) return rc;
+  a.last_action = last_action; a.out = obs_out; a.n = n; a.n_pad = state.n_pad; a.width = obs_width; a.soa = soa;
+  hipLaunchKernelGGL(k_observe, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
 
 extern "C" {
 
@@ -3026,10 +474,13 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
   c->d_bounds = nullptr;
   c->d_block_map = nullptr; c->h_block_map = nullptr; c->block_map_cap = 0; c->block_map_blocks = 0; c->block_map_runs = 0;
   { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->n_cu = v; }
+  // the device table always holds DSIM_MAX_TYPES entries, the unused ones zero: a kernel instance compiled for four types may
+  // load the constants of a type no drone has (k_step_mixed4 serves tables of three types with its four-type instance)
   DevType h[DSIM_MAX_TYPES];
+  memset(h, 0, sizeof(h));
   for (int t = 0; t < n_types; ++t) { c->h_types[t] = types[t]; to_dev(types[t], &h[t]); }
-  e = hipMalloc((void**)&c->d_types, sizeof(DevType) * n_types);
-  if (e == hipSuccess) e = hipMemcpy(c->d_types, h, sizeof(DevType) * n_types, hipMemcpyHostToDevice);
+  e = hipMalloc((void**)&c->d_types, sizeof(DevType) * DSIM_MAX_TYPES);
+  if (e == hipSuccess) e = hipMemcpy(c->d_types, h, sizeof(DevType) * DSIM_MAX_TYPES, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * (8 + DSIM_GROUND_SHARDS));
   if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(unsigned long long) * (8 + DSIM_GROUND_SHARDS));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_bounds, sizeof(unsigned) * 8);
@@ -3067,6 +518,7 @@ int dsim_dev_alloc(dsim_ctx* ctx, int64_t bytes, void** out) {
   if (e == hipSuccess) e = hipMalloc(out, (size_t)bytes);
   return (int)e;
 }
+
 int dsim_dev_free(dsim_ctx* ctx, void* ptr) {
   (void)ctx;                                          // (may be NULL: a block may outlive the ctx it was allocated through)
   return ptr ? (int)hipFree(ptr) : DSIM_OK;           // (hipFree waits for the work that may still use the block)
@@ -3090,18 +542,6 @@ int dsim_query(dsim_ctx* ctx, void* stream, int32_t what, int64_t* value_out) {
   return DSIM_OK;
 }
 
-static inline unsigned grid_for(long long n) { return (unsigned)((n + 255) / 256); }
-static int observe_impl(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
-                        float* obs_out, int32_t obs_width, int soa);
-
-// Streaming (nontemporal) accesses once one step's traffic exceeds what the 256 MB Infinity Cache can keep between
-// consecutive steps; DSIM_OPT_STREAM_ON / _OFF override (the library reads no environment variables).
-static inline bool stream_policy(const dsim_step_args* a, long long n_pad, double bytes_per_drone) {
-  if (a->options & DSIM_OPT_STREAM_ON) return true;
-  if (a->options & DSIM_OPT_STREAM_OFF) return false;
-  return (double)n_pad * bytes_per_drone > 192.0 * 1024 * 1024;
-}
-
 int dsim_reset(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* init_pos,
                const float* init_rpy, const float* init_vel, const float* init_cmd, const uint8_t* type_id) {
   if (!ctx || !init_pos || !init_rpy || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
@@ -3114,451 +554,6 @@ int dsim_reset(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const fl
   a.pos = init_pos; a.rpy = init_rpy; a.vel = init_vel; a.cmd = init_cmd;
   a.n_pad = state.n_pad; a.n_fields = 20 + ctx->max_act;
   hipLaunchKernelGGL(k_reset, dim3(grid_for(a.n_pad)), dim3(256), 0, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
-}
-
-static int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const dsim_view* targets,
-                      const dsim_step_args* args, StepK* a) {
-  if (!ctx || !args || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
-  if (args->phys_substeps < 0 || !(args->dt_phys > 0) || !(args->dt_ctrl > 0)) return DSIM_E_ARG;
-  if (ctx->n_types > 1 && !args->type_id) return DSIM_E_ARG;
-  int rc = make_kview(state, 20 + ctx->max_act, &a->st);
-  if (rc) return rc;
-  if (targets && !args->wp_table) {
-    const bool bc = (args->options & DSIM_OPT_BCAST_TGT) != 0;
-    rc = make_kview(*targets, DSIM_NT, &a->tg, bc);
-    if (rc) return rc;
-    if (!bc && targets->n_pad != state.n_pad) return DSIM_E_LAYOUT;
-  } else {
-    memset(&a->tg, 0, sizeof(a->tg));
-  }
-  a->hexa_types = 0;
-  for (int t = 0; t < ctx->n_types; ++t) a->hexa_types |= (ctx->h_types[t].kind != DSIM_KIND_QUAD ? 1u : 0u) << t;
-  a->types = ctx->d_types; a->type_id = args->type_id; a->noise_replay = args->noise_replay;
-  a->action = args->action; a->echo = nullptr; a->pos_e_out = nullptr; a->yaw_e_out = nullptr;
-  a->cmd_out = nullptr; a->obs_out = nullptr; a->obs_w = 16 + ctx->max_act; a->n = n;
-  a->fb.entries = ctx->d_fb; a->fb.count = ctx->d_counters + 2; a->fb.counters = ctx->d_counters;
-  a->n_pad = state.n_pad; a->first = 0; a->seed = args->noise_seed;
-  a->wp_table = args->wp_table; a->wp_counter = args->wp_counter; a->wp_offset = args->wp_offset;
-  a->n_wp = args->n_wp; a->n_steps = args->n_steps > 1 ? args->n_steps : 1;
-  a->ext_force = args->ext_force; a->step_index_dev = (const unsigned long long*)args->step_index_dev;
-  if (a->wp_table && (!a->wp_counter || a->n_wp < 1)) return DSIM_E_ARG;
-  a->step_index = args->step_index;
-  a->substeps = args->phys_substeps; a->dt_phys = args->dt_phys; a->dt_ctrl = args->dt_ctrl;
-  a->options = args->options;
-  memset(&a->bin, 0, sizeof(a->bin));
-  a->lo = 0; a->last = a->n_pad; a->run_type = 0;
-  a->drone_id = args->drone_id;
-  a->io_id = (args->options & DSIM_OPT_CALLER_IO) ? args->drone_id : nullptr;
-  a->action_rows = (args->options & DSIM_OPT_ACTION_ROWS) ? 1 : 0;     // (honoured by the entry points that check it)
-  a->dyn_rates = args->dyn_rpy_rates;
-  return DSIM_OK;
-}
-
-// dsim_step_args.bin_next: the step kernel fills the bucket grid of the next dsim_downwash call.  Only when that grid
-// is the one the last dsim_downwash used (its spare count buffer is then known to be zero) and takes the bucket form.
-static void bin_next_prepare(dsim_ctx* ctx, int64_t n, const dsim_step_args* args, StepK* a, hipStream_t st) {
-  const dsim_downwash_args* g = args->bin_next;
-  if (!g || !g->workspace || g->nx < 1 || g->ny < 1 || !(g->cell > 0)) return;
-  const long long ncells = (long long)g->nx * g->ny;
-  if (!dw_use_buckets(g->m, ncells) || ctx->dw_ws != g->workspace || ctx->dw_cells != ncells || ctx->dw_mode != 1 ||
-      g->local_offset < 0 || g->local_offset + n > g->m)
-    return;
-  bucket_layout(g->workspace, ncells, ctx->dw_parity, &a->bin);
-  if (ctx->dw_prebin) {
-    // an earlier step already filled this buffer and no dsim_downwash has consumed it (two steps in a row): start over,
-    // so that the buffer never holds two generations of positions
-    (void)hipMemsetAsync(a->bin.count, 0, sizeof(int) * (size_t)(ncells + DW_CNT_EXTRA), st);
-    ctx->dw_prebin = false;
-  }
-  a->bin.xmin = g->xmin; a->bin.ymin = g->ymin; a->bin.inv_cell = 1.0f / g->cell; a->bin.nx = g->nx; a->bin.ny = g->ny;
-  a->bin.local_offset = g->local_offset;
-}
-static void bin_next_commit(dsim_ctx* ctx, int64_t n, const dsim_step_args* args, const StepK& a) {
-  if (!a.bin.count) return;
-  ctx->dw_prebin = true; ctx->dw_prebin_valid = true; ctx->dw_prebin_n = n; ctx->dw_prebin_off = args->bin_next->local_offset;
-  ctx->dw_prebin_nx = args->bin_next->nx; ctx->dw_prebin_ny = args->bin_next->ny;
-  ctx->dw_prebin_geo[0] = args->bin_next->xmin; ctx->dw_prebin_geo[1] = args->bin_next->ymin;
-  ctx->dw_prebin_geo[2] = args->bin_next->cell;
-}
-
-// The deferred-fallback queue is the one ctx-owned buffer that depends on the fleet size: it is
-// (re)allocated when a larger hexa fleet is first seen, never per call afterwards.
-static int fb_prepare(dsim_ctx* ctx, long long n_pad, hipStream_t st) {
-  if (ctx->max_act != 6) return DSIM_OK;
-  if (ctx->fb_cap < n_pad) {
-    hipError_t e = hipStreamSynchronize(st);
-    if (e != hipSuccess) return (int)e;
-    if (ctx->d_fb) (void)hipFree(ctx->d_fb);
-    ctx->d_fb = nullptr; ctx->fb_cap = 0;
-    e = hipMalloc((void**)&ctx->d_fb, sizeof(FbEntry) * n_pad);
-    if (e != hipSuccess) return (int)e;
-    ctx->fb_cap = n_pad;
-  }
-  return DSIM_OK;   // the queue length is reset by k_wls_fallback itself
-}
-static void fb_finish(dsim_ctx* ctx, const StepK& a, hipStream_t st) {
-  if (ctx->max_act != 6) return;
-  if (a.options & DSIM_OPT_DEFER_FALLBACK) return;          // the caller launches dsim_wls_fallback itself
-  FbK f;
-  f.st = a.st; f.types = a.types; f.type_id = a.type_id; f.fb = a.fb;
-  f.cmd_out = a.cmd_out; f.n_pad = a.n_pad; f.io_id = a.io_id;
-  f.fb.entries = ctx->d_fb;
-  // one workgroup per 64 possible entries, at most one per CU (each holds 144 KB of LDS): a start-up transient that
-  // queues a large part of a big fleet is worked off by the whole chip, an empty queue costs one scalar load per group
-  const long long groups = (a.n_pad + DSIM_FB_LANES - 1) / DSIM_FB_LANES;
-  hipLaunchKernelGGL(k_wls_fallback, dim3((unsigned)(groups < ctx->n_cu ? groups : ctx->n_cu)), dim3(DSIM_FB_LANES), 0, st, f);
-}
-
-// (noise, uniform) x actuator count dispatch of a general kernel
-#define DSIM_LAUNCH_GEN(KERNEL, NOISE, UNI, SIX, g, a, stream)                                          \
-  do {                                                                                                  \
-    const dim3 b_(256);                                                                                 \
-    switch (((NOISE) ? 4 : 0) | ((UNI) ? 2 : 0) | ((SIX) ? 1 : 0)) {                                    \
-      case 0: hipLaunchKernelGGL((KERNEL<false, false, 4>), g, b_, 0, stream, a); break;                \
-      case 1: hipLaunchKernelGGL((KERNEL<false, false, 6>), g, b_, 0, stream, a); break;                \
-      case 2: hipLaunchKernelGGL((KERNEL<false, true, 4>), g, b_, 0, stream, a); break;                 \
-      case 3: hipLaunchKernelGGL((KERNEL<false, true, 6>), g, b_, 0, stream, a); break;                 \
-      case 4: hipLaunchKernelGGL((KERNEL<true, false, 4>), g, b_, 0, stream, a); break;                 \
-      case 5: hipLaunchKernelGGL((KERNEL<true, false, 6>), g, b_, 0, stream, a); break;                 \
-      case 6: hipLaunchKernelGGL((KERNEL<true, true, 4>), g, b_, 0, stream, a); break;                  \
-      default: hipLaunchKernelGGL((KERNEL<true, true, 6>), g, b_, 0, stream, a); break;                 \
-    }                                                                                                   \
-  } while (0)
-
-// Lays the runs of a type-major fleet out over the workgroups of ONE launch (RunTab): run r takes the whole 256-drone
-// tiles from the one that holds its first drone to the one that holds its last.  Returns the number of workgroups, or a
-// negative error code.  n_runs <= DSIM_MAX_TYPES.
-static int make_runtab(const dsim_ctx* ctx, long long n_pad, const dsim_type_run* runs, int n_runs, RunTab* rt, bool* any_hexa) {
-  memset(rt, 0, sizeof(*rt));
-  *any_hexa = false;
-  if (n_runs < 1 || n_runs > DSIM_MAX_TYPES) return DSIM_E_ARG;
-  int blocks = 0;
-  for (int r = 0; r < DSIM_MAX_TYPES; ++r) {
-    rt->blk0[r] = blocks;
-    if (r >= n_runs) continue;
-    const dsim_type_run& run = runs[r];
-    if (run.first < 0 || run.count < 0 || run.first + run.count > n_pad || run.type < 0 || run.type >= ctx->n_types) return DSIM_E_ARG;
-    rt->first[r] = run.first & ~255LL; rt->lo[r] = run.first; rt->last[r] = run.first + run.count; rt->type[r] = run.type;
-    const int kind = ctx->h_types[run.type].kind;
-    if (kind != DSIM_KIND_QUAD) rt->hexa_mask |= 1u << r;
-    if (kind == DSIM_KIND_HEXA_QUADLAW) rt->quadlaw6_mask |= 1u << r;
-    if (kind == DSIM_KIND_HEXA6DOF) *any_hexa = true;                 // (the WLS fallback queue is the 6-DOF law's)
-    blocks += run.count > 0 ? (int)((rt->last[r] - rt->first[r] + 255) / 256) : 0;
-  }
-  rt->blk0[DSIM_MAX_TYPES] = blocks;
-  return blocks;
-}
-
-// RunTab.block_map: the workgroups of the runs dealt side by side, one tile at a time to the run that is furthest behind
-// (progress = tiles served / tiles of the run), so that every run sweeps the caller's index range at the same pace.  Kept
-// by the ctx and re-made only when the runs change: that rare path waits for the whole DEVICE (a launch of this ctx on
-// another stream may still read the old table) and may allocate — so the first DSIM_OPT_CALLER_IO call with a new set of
-// runs must not sit inside a stream capture (include/dronesim_amd.h); the upload is ordered on the caller's stream.
-static int side_by_side_map(dsim_ctx* ctx, hipStream_t st, const dsim_type_run* runs, int n_runs, RunTab* rt) {
-  const int blocks = rt->blk0[DSIM_MAX_TYPES] + (rt->blk0[DSIM_MAX_TYPES] & 1);      // (two entries per workgroup: an odd count is padded)
-  rt->block_map = nullptr;
-  if (blocks < 2) return DSIM_OK;
-  bool same = ctx->d_block_map && ctx->block_map_blocks == blocks && ctx->block_map_runs == n_runs;
-  for (int r = 0; same && r < n_runs; ++r)
-    same = ctx->block_map_key[r].first == runs[r].first && ctx->block_map_key[r].count == runs[r].count && ctx->block_map_key[r].type == runs[r].type;
-  if (!same) {
-    if (ctx->block_map_cap < blocks) {
-      hipError_t e = hipDeviceSynchronize();                   // (a launch in flight, on any stream, may still read the old table)
-      if (e != hipSuccess) return (int)e;
-      if (ctx->d_block_map) (void)hipFree(ctx->d_block_map);
-      free(ctx->h_block_map);
-      ctx->d_block_map = nullptr; ctx->h_block_map = nullptr; ctx->block_map_cap = 0;
-      ctx->h_block_map = (int*)malloc(sizeof(int) * (size_t)blocks);
-      if (!ctx->h_block_map) return (int)hipErrorOutOfMemory;
-      e = hipMalloc((void**)&ctx->d_block_map, sizeof(int) * (size_t)blocks);
-      if (e != hipSuccess) return (int)e;
-      ctx->block_map_cap = blocks;
-    } else {
-      hipError_t e = hipDeviceSynchronize();
-      if (e != hipSuccess) return (int)e;
-    }
-    int next[DSIM_MAX_TYPES], total[DSIM_MAX_TYPES];
-    for (int r = 0; r < DSIM_MAX_TYPES; ++r) { next[r] = 0; total[r] = r < n_runs ? rt->blk0[r + 1] - rt->blk0[r] : 0; }
-    // workgroup w serves entries 2 w and 2 w + 1: one tile of each of the two runs that are furthest behind (progress =
-    // tiles served / tiles of the run), so that every run sweeps the caller's index range at the same pace and the two
-    // tiles of a workgroup cover the same stretch of it
-    for (int b = 0; b < blocks; ++b) {
-      int pick = -1;
-      for (int r = 0; r < n_runs; ++r) {
-        if (next[r] >= total[r]) continue;
-        if (pick < 0 || (long long)next[r] * total[pick] < (long long)next[pick] * total[r]) pick = r;
-      }
-      ctx->h_block_map[b] = pick < 0 ? -8 : ((next[pick]++ << 3) | pick);              // (-8: tile -1, nothing to serve)
-    }
-    hipError_t e = hipMemcpyAsync(ctx->d_block_map, ctx->h_block_map, sizeof(int) * (size_t)blocks, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return (int)e;
-    ctx->block_map_blocks = blocks; ctx->block_map_runs = n_runs;
-    for (int r = 0; r < n_runs; ++r) ctx->block_map_key[r] = runs[r];
-  }
-  rt->block_map = ctx->d_block_map;
-  return DSIM_OK;
-}
-
-// Physics.DYN (DSIM_OPT_DYN): what the mode does not combine with is refused, not dropped
-static int dyn_check(const dsim_ctx* ctx, const dsim_step_args* args, const StepK& a) {
-  if (!args->dyn_rpy_rates) return DSIM_E_ARG;
-  if (ctx->max_act != 4) return DSIM_E_UNSUPPORTED;             // both mixers of BaseAviary.py:1794-1803 read forces[0..3]
-  if (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND | DSIM_OPT_PLANE | DSIM_OPT_CHAINED | DSIM_OPT_CALLER_IO | DSIM_OPT_ACTION_ROWS))
-    return DSIM_E_UNSUPPORTED;
-  if (args->ext_force || args->wp_table || a.n_steps > 1 || args->bin_next) return DSIM_E_UNSUPPORTED;   // (step_index_dev only moves the noise counter: no noise here)
-  return DSIM_OK;
-}
-static int dyn_launch(bool ctrl, const StepK& a, bool nt, hipStream_t st) {
-  const dim3 g(grid_for(a.n_pad)), b(256);
-  if (ctrl) { if (nt) hipLaunchKernelGGL((k_dyn<true, true>), g, b, 0, st, a); else hipLaunchKernelGGL((k_dyn<true, false>), g, b, 0, st, a); }
-  else if (a.obs_out) { if (nt) hipLaunchKernelGGL((k_dyn<false, true, true>), g, b, 0, st, a); else hipLaunchKernelGGL((k_dyn<false, false, true>), g, b, 0, st, a); }
-  else { if (nt) hipLaunchKernelGGL((k_dyn<false, true>), g, b, 0, st, a); else hipLaunchKernelGGL((k_dyn<false, false>), g, b, 0, st, a); }
-  return (int)hipGetLastError();
-}
-
-int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
-              const dsim_step_args* args) {
-  StepK a;
-  int rc = fill_stepk(ctx, n, state, &targets, args, &a);
-  if (rc) return rc;
-  if (args->options & DSIM_OPT_DYN) {
-    rc = dyn_check(ctx, args, a);
-    if (rc) return rc;
-    if (!a.tg.base) return DSIM_E_ARG;
-    ctx->dw_prebin_valid = false;
-    return dyn_launch(true, a, stream_policy(args, state.n_pad, 256.0), (hipStream_t)stream);
-  }
-  if (args->options & DSIM_OPT_CALLER_IO) return DSIM_E_UNSUPPORTED;     // (dsim_physics / dsim_control2 only)
-  ctx->dw_prebin_valid = false;      // the positions move: a grid binned before this call is stale (bin_next_commit re-validates)
-  const bool noise = args->noise_seed != 0 || args->noise_replay != nullptr;
-  const bool uni = args->type_id == nullptr;
-  const bool six = ctx->max_act == 6;
-  const hipStream_t st_ = (hipStream_t)stream;
-  const dim3 b(256);
-  long long first = 0;
-  // DSIM_OPT_NOISE_FINE: carried by the single-sub-step instances of the fast kernels and by the general kernels (quad_substeps)
-  const bool fine = noise && !args->noise_replay && (args->options & DSIM_OPT_NOISE_FINE) != 0;
-  const bool fine_slow = fine && a.substeps != 1;       // several sub-steps per launch on the fine lattice: the general kernels
-  const bool phys_opts = (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND | DSIM_OPT_PLANE)) != 0 || fine_slow;
-  const bool plane = (args->options & DSIM_OPT_PLANE) != 0;
-  if ((args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)) && six)
-    return DSIM_E_UNSUPPORTED;                          // the add-on formulas are written for the four-rotor links
-  if ((args->options & DSIM_OPT_CHAINED) && (!uni || six || args->action || args->noise_replay || args->ext_force ||
-                                             phys_opts || (state.n_pad % 256)))
-    return DSIM_E_UNSUPPORTED;                          // chained stepping is a fast-path-only mode
-  const bool runs_ok = !args->noise_replay && !a.wp_table && a.n_steps == 1 && !phys_opts && a.tg.base &&
-                       !(args->options & DSIM_OPT_CHAINED);
-  const bool plain = runs_ok && !args->action;
-  const dsim_type_run* runs = args->runs;
-  int n_runs = args->n_runs;
-  dsim_type_run whole;
-  bool any_quadlaw6 = false;             // a DSIM_KIND_HEXA_QUADLAW type in the table: served by the per-run kernels (k_step_run)
-  for (int t = 0; t < ctx->n_types; ++t) any_quadlaw6 |= ctx->h_types[t].kind == DSIM_KIND_HEXA_QUADLAW;
-  if (!(runs && n_runs > 0) && uni && runs_ok && (args->ext_force || (any_quadlaw6 && !args->action))) {
-    // a homogeneous fleet with an external (downwash) force, or of hexa_6DOF_simple: ONE run of its only type — the
-    // single-type kernel with the force input and the fused neighbour-grid binning, instead of the general kernel
-    whole.first = 0; whole.count = a.n_pad; whole.type = 0; whole._pad = 0;
-    runs = &whole; n_runs = 1;
-  }
-  // (an explicit action — the first iteration of the example loop, fly_INDI.py:214 — is served by the ACT instances of the
-  // one-launch form; beyond DSIM_MAX_TYPES runs it goes to the general kernel)
-  if (runs && n_runs > 0 && runs_ok && (!args->action || (n_runs <= DSIM_MAX_TYPES && !any_quadlaw6))) {
-    // type-major storage: one single-type launch per run
-    const bool nt = stream_policy(args, state.n_pad, 240.0);
-    bool any_hexa = false;
-    bin_next_prepare(ctx, n, args, &a, st_);
-    for (int r = 0; r < n_runs; ++r) {
-      const dsim_type_run& run = runs[r];
-      if (run.first < 0 || run.count < 0 || run.first + run.count > a.n_pad || run.type < 0 || run.type >= ctx->n_types)
-        return DSIM_E_ARG;
-      any_hexa |= ctx->h_types[run.type].kind == DSIM_KIND_HEXA6DOF;
-    }
-    if (any_hexa) {
-      rc = fb_prepare(ctx, a.n_pad, st_);
-      if (rc) return rc;
-      a.fb.entries = ctx->d_fb;
-    }
-    // (measured on MI355X, 50 % quads + 50 % hexas: 65 536 drones 12.0 us against 9.5 + 9.0 us for two dependent launches;
-    // 4 194 304 drones 160.1 against 165.2 us — the launch boundary between the runs costs more than the registers the
-    // second law adds (83 VGPRs, 5 waves per SIMD, against 74 and 6): one launch is the default at every size)
-    const bool one_launch = (!DSIM_VARIANT_RUNS_SEPARATE(args) || args->action) && !any_quadlaw6;
-    if (n_runs <= DSIM_MAX_TYPES && (n_runs >= 2 || args->action) && one_launch) {
-      // several runs (or an explicit action): one launch for all of them (k_step_runs)
-      RunTab rt;
-      const int blocks = make_runtab(ctx, a.n_pad, runs, n_runs, &rt, &any_hexa);
-      if (blocks < 0) return blocks;
-      if (blocks > 0) {
-        const dim3 g((unsigned)blocks);
-#define DSIM_RUNS_CASE2(S_, A_)                                                                              \
-  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_runs<true, true, S_, A_>), g, b, 0, st_, a, rt);     \
-                    else hipLaunchKernelGGL((k_step_runs<true, false, S_, A_>), g, b, 0, st_, a, rt); }     \
-       else { if (nt) hipLaunchKernelGGL((k_step_runs<false, true, S_, A_>), g, b, 0, st_, a, rt);          \
-              else hipLaunchKernelGGL((k_step_runs<false, false, S_, A_>), g, b, 0, st_, a, rt); } } while (0)
-#define DSIM_RUNS_CASE(S_) do { if (args->action) DSIM_RUNS_CASE2(S_, true); else DSIM_RUNS_CASE2(S_, false); } while (0)
-        if (a.substeps == 1) DSIM_RUNS_CASE(true); else DSIM_RUNS_CASE(false);
-#undef DSIM_RUNS_CASE
-#undef DSIM_RUNS_CASE2
-      }
-      if (any_hexa) fb_finish(ctx, a, st_);
-      bin_next_commit(ctx, n, args, a);
-      return (int)hipGetLastError();
-    }
-#define DSIM_RUN_CASE2(H_, S_)                                                                        \
-  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_run<H_, true, true, S_>), g, b, 0, st_, a);    \
-                    else hipLaunchKernelGGL((k_step_run<H_, true, false, S_>), g, b, 0, st_, a); }    \
-       else { if (nt) hipLaunchKernelGGL((k_step_run<H_, false, true, S_>), g, b, 0, st_, a);         \
-              else hipLaunchKernelGGL((k_step_run<H_, false, false, S_>), g, b, 0, st_, a); } } while (0)
-#define DSIM_RUN_CASE(H_) do { if (a.substeps == 1) DSIM_RUN_CASE2(H_, true); else DSIM_RUN_CASE2(H_, false); } while (0)
-    for (int r = 0; r < n_runs; ++r) {
-      const dsim_type_run& run = runs[r];
-      if (run.count == 0) continue;
-      // the launch covers whole 256-drone tiles from the one that holds the run's first drone; lanes outside
-      // [lo, last) retire, so two runs may share a tile (each launch takes its own lanes of it)
-      a.first = run.first & ~255LL; a.lo = run.first; a.last = run.first + run.count; a.run_type = run.type;
-      const dim3 g(grid_for(a.last - a.first));
-      const int kind = ctx->h_types[run.type].kind;
-      if (kind == DSIM_KIND_HEXA6DOF) DSIM_RUN_CASE(DSIM_DEV_KIND_HEXA);
-      else if (kind == DSIM_KIND_HEXA_QUADLAW) DSIM_RUN_CASE(DSIM_DEV_KIND_HEXA_QUADLAW);
-      else DSIM_RUN_CASE(DSIM_DEV_KIND_QUAD);
-    }
-#undef DSIM_RUN_CASE
-#undef DSIM_RUN_CASE2
-    if (any_hexa) fb_finish(ctx, a, st_);
-    bin_next_commit(ctx, n, args, a);
-    return (int)hipGetLastError();
-  }
-  const bool multi = a.wp_table != nullptr || a.n_steps > 1;
-  if (uni && !six && !(args->action && multi) && !args->noise_replay && !args->ext_force && !phys_opts && !(fine && multi)) {
-    // fast path over the whole 256-drone tiles (an explicit action: the ACT instances of the plain form)
-    const bool nt = stream_policy(args, state.n_pad, 232.0);
-    const long long tiles = a.n_pad / 256;
-    if (tiles > 0) {
-      const dim3 g((unsigned)tiles);
-      const bool ext = multi;
-      const bool ch = (args->options & DSIM_OPT_CHAINED) != 0;
-#define DSIM_FAST_CASE(N_, T_)                                                                      \
-  do { if (ext) { if (ch) hipLaunchKernelGGL((k_step_fast<N_, T_, true, true>), g, b, 0, st_, a);   \
-                  else hipLaunchKernelGGL((k_step_fast<N_, T_, true, false>), g, b, 0, st_, a); }   \
-       else { if (args->action) { if (a.substeps == 1) hipLaunchKernelGGL((k_step_fast<N_, T_, false, false, 1, true>), g, b, 0, st_, a); \
-                                  else hipLaunchKernelGGL((k_step_fast<N_, T_, false, false, 0, true>), g, b, 0, st_, a); } \
-              else if (ch && a.substeps == 1) hipLaunchKernelGGL((k_step_fast<N_, T_, false, true, 1>), g, b, 0, st_, a); \
-              else if (ch) hipLaunchKernelGGL((k_step_fast<N_, T_, false, true>), g, b, 0, st_, a); \
-              else if (a.substeps == 1) hipLaunchKernelGGL((k_step_fast<N_, T_, false, false, 1>), g, b, 0, st_, a); \
-              else hipLaunchKernelGGL((k_step_fast<N_, T_, false, false>), g, b, 0, st_, a); } } while (0)
-      if (noise) { if (nt) DSIM_FAST_CASE(true, true); else DSIM_FAST_CASE(true, false); }
-      else { if (nt) DSIM_FAST_CASE(false, true); else DSIM_FAST_CASE(false, false); }
-#undef DSIM_FAST_CASE
-      first = tiles * 256;
-    }
-  }
-  bool fb_open = false;
-  if (uni && six && ctx->h_types[0].kind == DSIM_KIND_HEXA6DOF && !args->noise_replay && !args->ext_force &&
-      !a.wp_table && a.n_steps == 1 && a.n_pad >= 256 && !phys_opts) {
-    const long long tiles = a.n_pad / 256;
-    const bool nt = stream_policy(args, state.n_pad, 248.0);
-    rc = fb_prepare(ctx, a.n_pad, st_);
-    if (rc) return rc;
-    a.fb.entries = ctx->d_fb;
-    fb_open = true;
-    const dim3 g((unsigned)tiles);
-#define DSIM_HEXA_CASE2(S_, A_)                                                                     \
-  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_hexa<true, true, S_, A_>), g, b, 0, st_, a);  \
-                    else hipLaunchKernelGGL((k_step_hexa<true, false, S_, A_>), g, b, 0, st_, a); }  \
-       else { if (nt) hipLaunchKernelGGL((k_step_hexa<false, true, S_, A_>), g, b, 0, st_, a);       \
-              else hipLaunchKernelGGL((k_step_hexa<false, false, S_, A_>), g, b, 0, st_, a); } } while (0)
-#define DSIM_HEXA_CASE(S_) do { if (args->action) DSIM_HEXA_CASE2(S_, true); else DSIM_HEXA_CASE2(S_, false); } while (0)
-    if (a.substeps == 1) DSIM_HEXA_CASE(true); else DSIM_HEXA_CASE(false);
-#undef DSIM_HEXA_CASE
-#undef DSIM_HEXA_CASE2
-    first = tiles * 256;
-    if (first >= a.n_pad) fb_finish(ctx, a, st_);
-  }
-  if (first < a.n_pad) {   // ragged tail, or everything when the fast path does not apply
-    a.first = first;
-    const dim3 g(grid_for(a.n_pad - first));
-    const bool lean = !args->action && !args->noise_replay && !a.wp_table && a.n_steps == 1 && !phys_opts;     // (fine_slow is a phys_opt)
-    if (lean && !uni && a.tg.base && ctx->n_types <= 4 && ctx->max_act == 6 && !any_quadlaw6 && !DSIM_VARIANT_GENERIC(args)) {
-      // a heterogeneous fleet kept in the CALLER's own order (CtrlAviary(storage="caller"); storage="auto" stores it
-      // type-major and never comes here): the LDS-staged kernels, which partition every tile by type
-      const bool nt = stream_policy(args, state.n_pad, 240.0);
-      bool any_hexa = false;
-      for (int t = 0; t < ctx->n_types; ++t) any_hexa |= ctx->h_types[t].kind == DSIM_KIND_HEXA6DOF;
-      if (any_hexa && !fb_open) {
-        rc = fb_prepare(ctx, a.n_pad, st_);
-        if (rc) return rc;
-        a.fb.entries = ctx->d_fb;
-      }
-      if (first == 0) bin_next_prepare(ctx, n, args, &a, st_);      // (the whole fleet goes through this kernel)
-      // LDS-DMA of whole 1 KB row groups needs the wave-tiled layout [n/64][F][64] for the state (26 fields: a table with
-      // a morphing hexa) and for per-drone targets
-      const bool tiled = state.block == 64 && state.field_stride == 64 &&
-                         !(args->options & DSIM_OPT_BCAST_TGT) && targets.block == 64 && targets.field_stride == 64;
-#ifdef DSIM_WITH_VARIANTS
-      if (dsim_variants_mixed(ctx, st_, a, args, noise, nt, tiled, first)) {
-        if (any_hexa) fb_finish(ctx, a, st_);
-        bin_next_commit(ctx, n, args, a);
-        return (int)hipGetLastError();
-      }
-#endif
-      if (tiled) {
-        // two waves per tile, slot groups dealt round-robin (wave-tiled layout)
-        const dim3 gm((unsigned)((a.n_pad - first + 127) / 128)), bm(128);
-#define DSIM_MIXED4_CASE3(S_, Y_, B_)                                                                             \
-  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed4<true, true, S_, Y_, B_>), gm, bm, 0, st_, a);            \
-                    else hipLaunchKernelGGL((k_step_mixed4<true, false, S_, Y_, B_>), gm, bm, 0, st_, a); }            \
-       else { if (nt) hipLaunchKernelGGL((k_step_mixed4<false, true, S_, Y_, B_>), gm, bm, 0, st_, a);                 \
-              else hipLaunchKernelGGL((k_step_mixed4<false, false, S_, Y_, B_>), gm, bm, 0, st_, a); } } while (0)
-#define DSIM_MIXED4_CASE2(S_, Y_) do { if (a.bin.count) DSIM_MIXED4_CASE3(S_, Y_, true); else DSIM_MIXED4_CASE3(S_, Y_, false); } while (0)
-        // (a table of three types runs the four-type instance: an empty type has no ballots set and no slot group — sixteen
-        // instances less for a storage order the host avoids by default)
-#define DSIM_MIXED4_CASE(S_) do { if (ctx->n_types == 2) DSIM_MIXED4_CASE2(S_, 2); else DSIM_MIXED4_CASE2(S_, 4); } while (0)
-        if (a.substeps == 1) DSIM_MIXED4_CASE(true); else DSIM_MIXED4_CASE(false);
-#undef DSIM_MIXED4_CASE
-#undef DSIM_MIXED4_CASE2
-#undef DSIM_MIXED4_CASE3
-      } else {
-        // any other layout: one tile per workgroup, row DMAs in natural order, ballot partition
-        const dim3 gm((unsigned)((a.n_pad - first + 127) / 128));
-#define DSIM_MIXED3_CASE2(W_, S_)                                                                                  \
-  do { const dim3 bm(64 * W_);                                                                                    \
-       if (noise) { if (nt) hipLaunchKernelGGL((k_step_mixed3<true, true, W_, S_, false>), gm, bm, 0, st_, a);     \
-                    else hipLaunchKernelGGL((k_step_mixed3<true, false, W_, S_, false>), gm, bm, 0, st_, a); }     \
-       else { if (nt) hipLaunchKernelGGL((k_step_mixed3<false, true, W_, S_, false>), gm, bm, 0, st_, a);          \
-              else hipLaunchKernelGGL((k_step_mixed3<false, false, W_, S_, false>), gm, bm, 0, st_, a); } } while (0)
-#define DSIM_MIXED3_CASE(W_) do { if (a.substeps == 1) DSIM_MIXED3_CASE2(W_, true); else DSIM_MIXED3_CASE2(W_, false); } while (0)
-        if (ctx->n_types == 2) DSIM_MIXED3_CASE(3); else if (ctx->n_types == 3) DSIM_MIXED3_CASE(4); else DSIM_MIXED3_CASE(5);
-#undef DSIM_MIXED3_CASE
-#undef DSIM_MIXED3_CASE2
-      }
-      if (any_hexa) fb_finish(ctx, a, st_);
-      bin_next_commit(ctx, n, args, a);
-      return (int)hipGetLastError();
-    } else if (!six) {
-      if (lean && !fine) DSIM_LAUNCH_GEN(k_step_lean, noise, uni, false, g, a, st_);     // (the lean body carries the default lattice only)
-      else if (plane) DSIM_LAUNCH_GEN(k_step_plane, noise, uni, false, g, a, st_);
-      else DSIM_LAUNCH_GEN(k_step_gen, noise, uni, false, g, a, st_);
-    } else {
-      // hexa fleets: deferred WLS fallbacks must land before the next Env.step reads cmd, so several
-      // steps per call become several launches (each followed by the tiny fallback kernel)
-      const int steps = a.n_steps;
-      a.n_steps = 1;
-      for (int k = 0; k < steps; ++k) {
-        if (!fb_open) {                 // (open already when the tiles went through k_step_hexa: one queue, one fallback pass)
-          rc = fb_prepare(ctx, a.n_pad, st_);
-          if (rc) return rc;
-          a.fb.entries = ctx->d_fb;
-        }
-        fb_open = false;
-        if (lean && !a.action && !fine) DSIM_LAUNCH_GEN(k_step_lean, noise, uni, true, g, a, st_);
-        else if (plane) DSIM_LAUNCH_GEN(k_step_plane, noise, uni, true, g, a, st_);
-        else DSIM_LAUNCH_GEN(k_step_gen, noise, uni, true, g, a, st_);
-        fb_finish(ctx, a, st_);
-        a.step_index += 1;
-        a.action = nullptr;             // an explicit action applies to the first Env.step only
-      }
-    }
-  }
   return (int)hipGetLastError();
 }
 
@@ -3588,7 +583,8 @@ int dsim_noise_draw(dsim_ctx* ctx, void* stream, int64_t n, int64_t n_pad, int32
   if (!ctx || !out || n <= 0 || n > n_pad || (n_act != 4 && n_act != 6) || substeps < 1 || noise_seed == 0) return DSIM_E_ARG;
   NoiseK a;
   a.n = n; a.n_pad = n_pad; a.n_act = n_act; a.substeps = substeps; a.seed = noise_seed; a.step_index = step_index;
-  a.options = options; a.drone_id = drone_id; a.out = out;
+  if ((options & DSIM_OPT_NOISE_FINE) && (options & DSIM_OPT_NOISE_COARSE)) return DSIM_E_ARG;
+  a.options = resolve_noise_lattice(options, substeps); a.drone_id = drone_id; a.out = out;
   hipLaunchKernelGGL(k_noise_draw, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
@@ -3600,268 +596,14 @@ int dsim_counter_add(dsim_ctx* ctx, void* stream, uint64_t* counter, uint64_t in
   return (int)hipGetLastError();
 }
 
-int dsim_materialize(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state) {
-  if (!ctx || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
-  MatK a;
-  int rc = make_kview(state, 20 + ctx->max_act, &a.st);
-  if (rc) return rc;
-  a.n_pad = state.n_pad;
-  hipLaunchKernelGGL(k_materialize, dim3(grid_for(a.n_pad)), dim3(256), 0, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
-}
-
-int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float* last_action_out,
-                 const dsim_step_args* args) {
-  StepK a;
-  int rc = fill_stepk(ctx, n, state, nullptr, args, &a);
-  if (rc) return rc;
-  ctx->dw_prebin_valid = false;
-  a.echo = last_action_out;
-  if (args->options & DSIM_OPT_DYN) {
-    rc = dyn_check(ctx, args, a);
-    if (rc) return rc;
-    if (args->obs_out && args->obs_width != 20) return DSIM_E_ARG;
-    const bool obs_fused = args->obs_out && ((uintptr_t)args->obs_out & 15u) == 0;       // (16-byte stores of the rows)
-    a.obs_out = obs_fused ? args->obs_out : nullptr;
-    rc = dyn_launch(false, a, stream_policy(args, state.n_pad, args->obs_out ? 240.0 : 160.0), (hipStream_t)stream);
-    if (rc) return rc;
-    if (args->obs_out && !obs_fused) return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, 20, 0);
-    return DSIM_OK;
-  }
-  const bool fine_slow = (args->noise_seed != 0 && !args->noise_replay && (args->options & DSIM_OPT_NOISE_FINE) && a.substeps != 1);
-  const bool phys_opts = (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND | DSIM_OPT_PLANE)) != 0;
-  if ((args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND)) && ctx->max_act == 6) return DSIM_E_UNSUPPORTED;
-  const int obs_w = 16 + ctx->max_act;
-  if (args->obs_out && args->obs_width != obs_w) return DSIM_E_ARG;
-  const bool noise = args->noise_seed != 0 || args->noise_replay != nullptr;
-  const hipStream_t st_ = (hipStream_t)stream;
-  if ((args->options & DSIM_OPT_CALLER_IO) && !args->drone_id) return DSIM_E_ARG;
-  const bool arows = (args->options & DSIM_OPT_ACTION_ROWS) != 0;
-  if (arows && (!args->action || ((uintptr_t)args->action & 15u))) return DSIM_E_ARG;
-  if (args->type_id == nullptr && ctx->max_act == 4 && !args->noise_replay && !args->ext_force && !phys_opts &&
-      (a.n_pad % 256) == 0 && !args->bin_next && !args->drone_id && !(args->options & DSIM_OPT_CALLER_IO)) {
-    // homogeneous quad fleet in whole tiles: the fast form, observation fused (16-byte stores: any torch allocation is
-    // aligned far beyond that; a misaligned caller buffer gets the rows from the observation kernel behind the step)
-    const bool obs_fused = args->obs_out && ((uintptr_t)args->obs_out & 15u) == 0;
-    a.obs_out = obs_fused ? args->obs_out : nullptr;
-    const bool nt = stream_policy(args, state.n_pad, args->obs_out ? 216.0 : 136.0);
-    const dim3 g((unsigned)(a.n_pad / 256)), b(256);
-    const bool loop = a.substeps > 1 && !(noise && (args->options & DSIM_OPT_NOISE_FINE));      // (the looped instance: default lattice only)
-#define DSIM_PHYS_CASE(N_, T_) do {                                                                                     \
-      if (loop) { if (a.obs_out) hipLaunchKernelGGL((k_physics_fast<N_, T_, true, true>), g, b, 0, st_, a);             \
-                  else hipLaunchKernelGGL((k_physics_fast<N_, T_, false, true>), g, b, 0, st_, a); }                    \
-      else { if (a.obs_out) hipLaunchKernelGGL((k_physics_fast<N_, T_, true>), g, b, 0, st_, a);                        \
-             else hipLaunchKernelGGL((k_physics_fast<N_, T_, false>), g, b, 0, st_, a); } } while (0)
-    if (noise) { if (nt) DSIM_PHYS_CASE(true, true); else DSIM_PHYS_CASE(true, false); }
-    else { if (nt) DSIM_PHYS_CASE(false, true); else DSIM_PHYS_CASE(false, false); }
-#undef DSIM_PHYS_CASE
-    if (args->obs_out && !obs_fused) return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, obs_w, 0);
-    return (int)hipGetLastError();
-  }
-  if (arows) return DSIM_E_UNSUPPORTED;               // (every other kernel takes the action field-major)
-  // Every other fleet kind on the fast form: runs of one type (dsim_step_args.runs), or a homogeneous fleet as ONE run —
-  // morphing hexas, type-major quad + hexa fleets, fleets with the downwash force, ragged tails.  The observation rows are
-  // written by the same launch; the new positions may fill the next neighbour grid (bin_next).
-  {
-    const dsim_type_run* runs = args->runs;
-    int n_runs = args->n_runs;
-    dsim_type_run whole;
-    if (!(runs && n_runs > 0 && n_runs <= DSIM_MAX_TYPES) && args->type_id == nullptr) {
-      whole.first = 0; whole.count = a.n_pad; whole.type = 0; whole._pad = 0;
-      runs = &whole; n_runs = 1;
-    }
-    if (runs && n_runs > 0 && n_runs <= DSIM_MAX_TYPES && !args->noise_replay && !phys_opts && !fine_slow) {   // (k_physics_fast above carries
-      RunTab rt;                                                                                              //  both lattices at any count)
-      bool any_hexa = false;
-      const int blocks = make_runtab(ctx, a.n_pad, runs, n_runs, &rt, &any_hexa);
-      if (blocks < 0) return blocks;
-      if (a.io_id) { rc = side_by_side_map(ctx, st_, runs, n_runs, &rt); if (rc) return rc; }
-      if (a.io_id && args->obs_out && ((uintptr_t)args->obs_out & 15u)) return DSIM_E_ARG;   // (the window's 16-byte pieces)
-      const bool obs_fused = args->obs_out && ((uintptr_t)args->obs_out & 7u) == 0;     // (8-byte pieces of the rows)
-      a.obs_out = obs_fused ? args->obs_out : nullptr;
-      const bool nt = stream_policy(args, state.n_pad, args->obs_out ? 240.0 : 152.0);
-      bin_next_prepare(ctx, n, args, &a, st_);
-      if (blocks > 0) {
-        const dim3 g((unsigned)blocks), b(256);
-#define DSIM_PRUNS_CASE2(N_, T_, S_) do {                                                                                      \
-          if (a.io_id) { const dim3 g2((unsigned)((blocks + 1) / 2) * DSIM_IO_PARTS), b2(DSIM_IO_WG);                                                 \
-                         if (a.obs_out) hipLaunchKernelGGL((k_physics_runs_io<N_, T_, true, S_>), g2, b2, 0, st_, a, rt);      \
-                         else hipLaunchKernelGGL((k_physics_runs_io<N_, T_, false, S_>), g2, b2, 0, st_, a, rt); }              \
-          else { if (a.obs_out) hipLaunchKernelGGL((k_physics_runs<N_, T_, true, S_>), g, b, 0, st_, a, rt);                  \
-                 else hipLaunchKernelGGL((k_physics_runs<N_, T_, false, S_>), g, b, 0, st_, a, rt); } } while (0)
-#define DSIM_PRUNS_CASE(N_, T_) do { if (a.substeps == 1) DSIM_PRUNS_CASE2(N_, T_, true); else DSIM_PRUNS_CASE2(N_, T_, false); } while (0)
-        if (noise) { if (nt) DSIM_PRUNS_CASE(true, true); else DSIM_PRUNS_CASE(true, false); }
-        else { if (nt) DSIM_PRUNS_CASE(false, true); else DSIM_PRUNS_CASE(false, false); }
-#undef DSIM_PRUNS_CASE
-#undef DSIM_PRUNS_CASE2
-      }
-      bin_next_commit(ctx, n, args, a);
-      if (args->obs_out && !obs_fused) return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, obs_w, 0);
-      return (int)hipGetLastError();
-    }
-  }
-  if (a.io_id) return DSIM_E_UNSUPPORTED;            // the caller's numbering is served by the run kernels only
-  const dim3 g(grid_for(a.n_pad));
-  if (args->options & DSIM_OPT_PLANE) DSIM_LAUNCH_GEN(k_physics_plane, noise, args->type_id == nullptr, ctx->max_act == 6, g, a, st_);
-  else {
-    // (written out: a homogeneous six-actuator fleet without noise never comes here — the run kernels above serve it unless
-    // a noise replay is given, which is NOISE = true — so k_physics_gen<false, true, 6> is not instantiated)
-    const dim3 b_(256);
-    const bool uni = args->type_id == nullptr, six = ctx->max_act == 6;
-    if (noise) {
-      if (uni) { if (six) hipLaunchKernelGGL((k_physics_gen<true, true, 6>), g, b_, 0, st_, a); else hipLaunchKernelGGL((k_physics_gen<true, true, 4>), g, b_, 0, st_, a); }
-      else { if (six) hipLaunchKernelGGL((k_physics_gen<true, false, 6>), g, b_, 0, st_, a); else hipLaunchKernelGGL((k_physics_gen<true, false, 4>), g, b_, 0, st_, a); }
-    } else {
-      if (uni) { if (six) return DSIM_E_UNSUPPORTED; hipLaunchKernelGGL((k_physics_gen<false, true, 4>), g, b_, 0, st_, a); }
-      else { if (six) hipLaunchKernelGGL((k_physics_gen<false, false, 6>), g, b_, 0, st_, a); else hipLaunchKernelGGL((k_physics_gen<false, false, 4>), g, b_, 0, st_, a); }
-    }
-  }
-  if (args->obs_out)       // general fleets: the same rows by the observation kernel, behind the step on the stream
-    return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, obs_w, 0);
-  return (int)hipGetLastError();
-}
-
-int dsim_step_adaptor(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* action,
-                      int32_t mode, float* last_action_out, const dsim_step_args* args) {
-  StepK a;
-  if (!action || (mode != DSIM_ADAPT_VELOCITY && mode != DSIM_ADAPT_RPYT)) return DSIM_E_ARG;
-  if (ctx && ctx->max_act == 6) return DSIM_E_UNSUPPORTED;
-  if (args && (args->noise_replay || args->wp_table || args->ext_force ||
-               (args->options & (DSIM_OPT_DRAG | DSIM_OPT_GROUND))))
-    return DSIM_E_UNSUPPORTED;        // plain PYB physics (+ the plane): refuse what the adaptor kernels would silently drop
-  int rc = fill_stepk(ctx, n, state, nullptr, args, &a);
-  if (rc) return rc;
-  if (args->options & (DSIM_OPT_CALLER_IO | DSIM_OPT_DYN)) return DSIM_E_UNSUPPORTED;   // (the adaptor envs fly Physics.PYB)
-  ctx->dw_prebin_valid = false;
-  a.action = action; a.echo = last_action_out;
-  const bool noise = args->noise_seed != 0, uni = args->type_id == nullptr;
-  const dim3 g(grid_for(a.n_pad)), b(256);
-  const hipStream_t st_ = (hipStream_t)stream;
-  const bool arows = (args->options & DSIM_OPT_ACTION_ROWS) != 0;
-  if (args->obs_out && args->obs_width != 20) return DSIM_E_ARG;
-  const bool fine = noise && (args->options & DSIM_OPT_NOISE_FINE) != 0;      // (k_adaptor_fast carries the default lattice only)
-  if (uni && (a.n_pad % 256) == 0 && !(args->options & DSIM_OPT_PLANE) && !args->drone_id && !fine &&
-      (!arows || ((uintptr_t)action & 15u) == 0)) {
-    // homogeneous quad fleet in whole tiles: ONE launch, the observation rows fused (16-byte stores; a misaligned caller
-    // buffer gets them from the observation kernel behind the step), the action in either layout
-    const bool obs_fused = args->obs_out && ((uintptr_t)args->obs_out & 15u) == 0;
-    a.obs_out = obs_fused ? args->obs_out : nullptr;
-    const bool nt = stream_policy(args, state.n_pad, args->obs_out ? 304.0 : 224.0);
-    const dim3 gf((unsigned)(a.n_pad / 256));
-#define DSIM_AF2(M_, N_) do { if (nt) hipLaunchKernelGGL((k_adaptor_fast<M_, N_, true>), gf, b, 0, st_, a);                   \
-                              else hipLaunchKernelGGL((k_adaptor_fast<M_, N_, false>), gf, b, 0, st_, a); } while (0)
-#define DSIM_AF1(M_) do { if (noise) DSIM_AF2(M_, true); else DSIM_AF2(M_, false); } while (0)
-    if (mode == DSIM_ADAPT_VELOCITY) DSIM_AF1(DSIM_ADAPT_VELOCITY); else DSIM_AF1(DSIM_ADAPT_RPYT);
-#undef DSIM_AF1
-#undef DSIM_AF2
-    if (args->obs_out && !obs_fused) return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, 20, 0);
-    return (int)hipGetLastError();
-  }
-  if (arows) return DSIM_E_UNSUPPORTED;               // (the general kernels take the action field-major)
-#define DSIM_ADAPT_CASE2(M_, P_)                                                                       \
-  do { if (noise) { if (uni) hipLaunchKernelGGL((k_adaptor<M_, true, true, P_>), g, b, 0, st_, a);      \
-                    else hipLaunchKernelGGL((k_adaptor<M_, true, false, P_>), g, b, 0, st_, a); }       \
-       else { if (uni) hipLaunchKernelGGL((k_adaptor<M_, false, true, P_>), g, b, 0, st_, a);           \
-              else hipLaunchKernelGGL((k_adaptor<M_, false, false, P_>), g, b, 0, st_, a); } } while (0)
-#define DSIM_ADAPT_CASE(M_) do { if (args->options & DSIM_OPT_PLANE) DSIM_ADAPT_CASE2(M_, true); else DSIM_ADAPT_CASE2(M_, false); } while (0)
-  if (mode == DSIM_ADAPT_VELOCITY) DSIM_ADAPT_CASE(DSIM_ADAPT_VELOCITY); else DSIM_ADAPT_CASE(DSIM_ADAPT_RPYT);
-#undef DSIM_ADAPT_CASE
-#undef DSIM_ADAPT_CASE2
-  if (args->obs_out)       // general fleets: the rows by the observation kernel, behind the step on the stream
-    return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, 20, 0);
-  return (int)hipGetLastError();
-}
-
-int dsim_control(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
-                 const dsim_step_args* args, float* pos_e_out, float* yaw_e_out) {
-  return dsim_control2(ctx, stream, n, state, targets, args, pos_e_out, yaw_e_out, nullptr);
-}
-
-int dsim_control2(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view targets,
-                  const dsim_step_args* args, float* pos_e_out, float* yaw_e_out, float* cmd_out) {
-  StepK a;
-  if (args && args->wp_table) return DSIM_E_UNSUPPORTED;   // computeControl takes explicit targets
-  int rc = fill_stepk(ctx, n, state, &targets, args, &a);
-  if (rc) return rc;
-  a.pos_e_out = pos_e_out; a.yaw_e_out = yaw_e_out; a.cmd_out = cmd_out;
-  const dim3 g(grid_for(a.n_pad)), b(256);
-  const hipStream_t st_ = (hipStream_t)stream;
-  const bool uni = args->type_id == nullptr;
-  if ((args->options & DSIM_OPT_CALLER_IO) && !args->drone_id) return DSIM_E_ARG;
-  if (uni && ctx->max_act == 4 && (a.n_pad % 256) == 0 && a.tg.base && !a.io_id) {
-    const bool nt = stream_policy(args, state.n_pad, 212.0);
-    const dim3 gt((unsigned)(a.n_pad / 256));
-    if (yaw_e_out) { if (nt) hipLaunchKernelGGL((k_control_fast<true, true>), gt, b, 0, st_, a);
-                     else hipLaunchKernelGGL((k_control_fast<false, true>), gt, b, 0, st_, a); }
-    else { if (nt) hipLaunchKernelGGL((k_control_fast<true, false>), gt, b, 0, st_, a);
-           else hipLaunchKernelGGL((k_control_fast<false, false>), gt, b, 0, st_, a); }
-    return (int)hipGetLastError();
-  }
-  {
-    // every other fleet kind: runs of one type (or a homogeneous fleet as one run) on the single-type bodies (k_control_runs)
-    const dsim_type_run* runs = args->runs;
-    int n_runs = args->n_runs;
-    dsim_type_run whole;
-    if (!(runs && n_runs > 0 && n_runs <= DSIM_MAX_TYPES) && uni) {
-      whole.first = 0; whole.count = a.n_pad; whole.type = 0; whole._pad = 0;
-      runs = &whole; n_runs = 1;
-    }
-    if (runs && n_runs > 0 && n_runs <= DSIM_MAX_TYPES) {
-      RunTab rt;
-      bool any_hexa = false;
-      const int blocks = make_runtab(ctx, a.n_pad, runs, n_runs, &rt, &any_hexa);
-      if (blocks < 0) return blocks;
-      if (any_hexa) {
-        rc = fb_prepare(ctx, a.n_pad, st_);
-        if (rc) return rc;
-        a.fb.entries = ctx->d_fb;
-      }
-      if (a.io_id) { rc = side_by_side_map(ctx, st_, runs, n_runs, &rt); if (rc) return rc; }
-      const bool nt = stream_policy(args, state.n_pad, 236.0);
-      if (blocks > 0) {
-        const dim3 gr((unsigned)blocks);
-#define DSIM_CRUNS_CASE(T_, Y_) do {                                                                                         \
-          if (a.io_id) hipLaunchKernelGGL((k_control_runs_io<T_, Y_>), dim3((unsigned)((blocks + 1) / 2) * DSIM_IO_PARTS), dim3(DSIM_IO_WG), 0, st_, a, rt); \
-          else hipLaunchKernelGGL((k_control_runs<T_, Y_>), gr, b, 0, st_, a, rt); } while (0)
-        if (yaw_e_out) { if (nt) DSIM_CRUNS_CASE(true, true); else DSIM_CRUNS_CASE(false, true); }
-        else { if (nt) DSIM_CRUNS_CASE(true, false); else DSIM_CRUNS_CASE(false, false); }
-#undef DSIM_CRUNS_CASE
-      }
-      if (any_hexa) fb_finish(ctx, a, st_);
-      return (int)hipGetLastError();
-    }
-  }
-  // what is left: per-lane types without usable runs (the caller's own order of a heterogeneous fleet)
-  if (a.io_id) return DSIM_E_UNSUPPORTED;
-  if (ctx->max_act == 6) {
-    rc = fb_prepare(ctx, a.n_pad, st_);
-    if (rc) return rc;
-    a.fb.entries = ctx->d_fb;
-    hipLaunchKernelGGL((k_control_gen<6>), g, b, 0, st_, a);
-    fb_finish(ctx, a, st_);
-  }
-  else hipLaunchKernelGGL((k_control_gen<4>), g, b, 0, st_, a);
-  return (int)hipGetLastError();
-}
-
 int dsim_observe(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
                  float* obs_out, int32_t obs_width) {
   return observe_impl(ctx, stream, n, state, last_action, obs_out, obs_width, 0);
 }
+
 int dsim_observe_soa(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
                      float* obs_out, int32_t obs_width) {
   return observe_impl(ctx, stream, n, state, last_action, obs_out, obs_width, 1);
-}
-static int observe_impl(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const float* last_action,
-                        float* obs_out, int32_t obs_width, int soa) {
-  if (!ctx || !obs_out || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
-  if (obs_width < 16 || obs_width > 16 + DSIM_MAX_ACT || 20 + (obs_width - 16) > state.n_fields) return DSIM_E_ARG;
-  ObsK a;
-  int rc = make_kview(state, 20 + ctx->max_act, &a.st);
-  if (rc) return rc;
-  a.last_action = last_action; a.out = obs_out; a.n = n; a.n_pad = state.n_pad; a.width = obs_width; a.soa = soa;
-  hipLaunchKernelGGL(k_observe, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a);
-  return (int)hipGetLastError();
 }
 
 int dsim_traj_sample(dsim_ctx* ctx, void* stream, int64_t n, const double* coeffs, const double* ts,
@@ -3875,291 +617,6 @@ int dsim_traj_sample(dsim_ctx* ctx, void* stream, int64_t n, const double* coeff
   a.n = n; a.n_pad = targets_out.n_pad; a.n_seg = n_seg; a.dt_advance = dt_advance;
   hipLaunchKernelGGL(k_traj_sample, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
-}
-
-int dsim_downwash_prebin_ok(int64_t m, int32_t nx, int32_t ny) {
-  return (m > 0 && nx > 0 && ny > 0 && dw_use_buckets(m, (int64_t)nx * ny)) ? 1 : 0;
-}
-
-int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny) {
-  if (m < 0 || nx < 1 || ny < 1) return -1;
-  const int64_t ncells = (int64_t)nx * ny;
-  const int64_t sort_form = 2 * (ncells + 1) + ncells + 4 + 4 * m;   // count x2, cursor, 16-B alignment slack, float4[m]
-  const int64_t bucket_form = 2 * (ncells + DW_CNT_EXTRA) + 4 + 4 * ncells * DW_CAP + 4 * m;   // count x2, slack, buckets, overflow
-  return dw_use_buckets(m, ncells) && bucket_form > sort_form ? bucket_form : sort_form;
-}
-
-static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view& state,
-                      const dsim_downwash_args* g, float min_cell, DwK* out, bool allow_buckets = false);
-
-// the halo grid of the split-phase downwash sits behind the local grid (whose overflow list holds n_local entries)
-static inline void halo_layout(int32_t* ws, long long ncells, long long n_local, int parity, BinK* b) {
-  BinK loc;
-  bucket_layout(ws, ncells, 0, &loc);
-  const long long cstride = ncells + DW_CNT_EXTRA;
-  uintptr_t sp = (uintptr_t)(loc.overflow + n_local);
-  int* base = (int*)((sp + 15) & ~(uintptr_t)15);
-  b->count = base + (long long)parity * cstride;
-  sp = (uintptr_t)(base + 2 * cstride);
-  b->buckets = (float4*)((sp + 15) & ~(uintptr_t)15);
-  b->overflow = b->buckets + ncells * DW_CAP;
-}
-int64_t dsim_downwash_workspace_halo(int64_t n, int64_t h, int32_t nx, int32_t ny) {
-  if (n < 1 || h < 0 || nx < 1 || ny < 1) return -1;
-  const int64_t ncells = (int64_t)nx * ny;
-  if (!dw_use_buckets(n + h, ncells)) return -1;
-  const int64_t local = 2 * (ncells + DW_CNT_EXTRA) + 4 + 4 * ncells * DW_CAP + 4 * n;
-  const int64_t split = local + 4 + 2 * (ncells + DW_CNT_EXTRA) + 4 + 4 * ncells * DW_CAP + 4 * h;
-  const int64_t one = dsim_downwash_workspace(n + h, nx, ny);      // DSIM_DW_ALL on the same buffer
-  return split > one ? split : one;
-}
-static long long halo_total(const dsim_halo_plan* h, int* off /* [DSIM_MAX_PEERS + 1] */) {     // capacities of the messages received
-  long long tot = 0;
-  for (int q = 0; q <= DSIM_MAX_PEERS; ++q) {
-    off[q] = (int)tot;
-    if (q < h->world && q != h->rank) tot += h->recv_cap[q];
-  }
-  off[DSIM_MAX_PEERS] = (int)tot;
-  return tot;
-}
-static int halo_check(const dsim_halo_plan* h) {
-  if (!h || h->world < 1 || h->world > DSIM_MAX_PEERS || h->rank < 0 || h->rank >= h->world || h->cap < 1) return DSIM_E_ARG;
-  for (int q = 0; q < h->world; ++q)
-    if (h->send_cap[q] < 0 || h->send_cap[q] > h->cap || h->recv_cap[q] < 0 || h->recv_cap[q] > h->cap || !(h->reach[q] >= 0.0f))
-      return DSIM_E_ARG;
-  return DSIM_OK;
-}
-static void halo_fill(const dsim_halo_plan* h, HaloK* k) {
-  k->send = h->send; k->recv = h->recv; k->stride = DSIM_HALO_HDR + 3 * h->cap; k->world = h->world; k->rank = h->rank;
-  k->scratch = h->scratch;
-  for (int q = 0; q < DSIM_MAX_PEERS; ++q) {
-    const bool live = q < h->world && q != h->rank;
-    k->send_cap[q] = live ? h->send_cap[q] : 0; k->recv_cap[q] = live ? h->recv_cap[q] : 0; k->reach[q] = live ? h->reach[q] : 0.0f;
-  }
-}
-
-// the cell-centred query over (receiver grid b, candidate grid cnd)
-static void launch_query_cell(dsim_ctx* ctx, hipStream_t st_, const DwK& a, const BinK& b, const BinK& cnd, float cell,
-                              long long m_candidates, int accumulate) {
-  const long long ncells = (long long)a.nx * a.ny;
-  // sparse worlds (mean occupancy of a neighbourhood <= 128 entries): one wave per cell and an 8 KB tile, so that a
-  // CU holds ~20 cells at once; dense ones (BASELINE config 5: 625 entries per neighbourhood): two waves and 12 KB —
-  // 11 cells per CU, so that the ~2 800 cells of a 65 536-drone shard are all resident in ONE round (four-wave
-  // workgroups needed 1.4 rounds of 8 per CU, and the thin second round cost 40 % of the kernel's time)
-  const int rings = cell >= DW_CUTOFF ? 1 : 2;
-  const double nb_mean = (double)m_candidates / (double)ncells * (2 * rings + 1) * (2 * rings + 1);
-  const dim3 gq((unsigned)(ncells + DW_OVF_GROUPS));
-  if (nb_mean <= 128.0) hipLaunchKernelGGL((k_dw_query_cell<64, false>), gq, dim3(64), 256 * sizeof(float4), st_, a, b, cnd, rings, 256, accumulate);
-  else hipLaunchKernelGGL((k_dw_query_cell<128, true>), gq, dim3(128), DW_TILE_DENSE_BYTES, st_, a, b, cnd, rings, DW_TILE_DENSE_BYTES / (int)sizeof(float4), accumulate);
-}
-
-int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_downwash_args* g,
-                  float* force_out) {
-  if (!g) return DSIM_E_ARG;
-  if (!force_out && g->phase != DSIM_DW_HALO_BIN) return DSIM_E_ARG;
-  if (ctx && ctx->n_types > 1 && !g->type_id && g->phase != DSIM_DW_HALO_BIN) return DSIM_E_ARG;
-  if (g->phase < DSIM_DW_ALL || g->phase > DSIM_DW_HALO_QUERY || (g->phase != DSIM_DW_ALL && !g->halo)) return DSIM_E_ARG;
-  DwK a;
-  const hipStream_t st_ = (hipStream_t)stream;
-  const long long ncells = (long long)g->nx * g->ny;
-  int h_off[DSIM_MAX_PEERS + 1];
-  long long h_tot = 0;
-  if (g->halo) {
-    int rc = halo_check(g->halo);
-    if (rc) return rc;
-    h_tot = halo_total(g->halo, h_off);
-    // the halo plan stands for the rest of the world: positions of the local drones come from the state block
-    if (!ctx || g->pos_all || g->local_offset != 0 || g->m != n + h_tot || g->nx < 1 || g->ny < 1 || !g->workspace) return DSIM_E_ARG;
-    if (h_tot > 0 && !g->halo->recv) return DSIM_E_ARG;
-    if (!dw_use_buckets(g->m, ncells)) return DSIM_E_UNSUPPORTED;      // the bucket form only (the caller gathers pos_all otherwise)
-    if (g->phase != DSIM_DW_ALL && g->workspace_len < dsim_downwash_workspace_halo(n, h_tot, g->nx, g->ny)) return DSIM_E_ARG;
-  }
-  HaloK hk;
-  memset(&hk, 0, sizeof(hk));
-  if (g->halo) {
-    halo_fill(g->halo, &hk);
-    hk.index0 = n; hk.counters = ctx->d_counters;
-    for (int q = 0; q <= DSIM_MAX_PEERS; ++q) hk.off[q] = h_off[q];
-  }
-  if (g->phase == DSIM_DW_HALO_BIN || g->phase == DSIM_DW_HALO_QUERY) {
-    // the halo grid: two count buffers alternate between steps; HALO_BIN fills the current one, HALO_QUERY reads it,
-    // zeroes the other for the next step and flips
-    if (n <= 0 || n > state.n_pad || !(g->cell >= 0.5f * DW_CUTOFF)) return DSIM_E_ARG;
-    BinK hb;
-    memset(&hb, 0, sizeof(hb));
-    const bool fresh = ctx->dwh_ws != g->workspace || ctx->dwh_cells != ncells || ctx->dw_local_m != n;
-    if (fresh) {
-      if (g->phase == DSIM_DW_HALO_QUERY) return DSIM_E_ARG;          // HALO_BIN of this step comes first
-      halo_layout(g->workspace, ncells, n, 0, &hb);
-      hipError_t e = hipMemsetAsync(hb.count, 0, sizeof(int) * 2 * (size_t)(ncells + DW_CNT_EXTRA), st_);
-      if (e != hipSuccess) return (int)e;
-      ctx->dwh_ws = g->workspace; ctx->dwh_cells = ncells; ctx->dw_local_m = n; ctx->dwh_parity = 0;
-    }
-    halo_layout(g->workspace, ncells, n, ctx->dwh_parity, &hb);
-    hb.xmin = g->xmin; hb.ymin = g->ymin; hb.inv_cell = 1.0f / g->cell; hb.nx = g->nx; hb.ny = g->ny; hb.local_offset = 0;
-    if (g->phase == DSIM_DW_HALO_BIN) {
-      if (h_tot > 0) hipLaunchKernelGGL(k_dw_bin_halo, dim3(grid_for(h_tot)), dim3(256), 0, st_, hb, hk);
-      return (int)hipGetLastError();
-    }
-    // HALO_QUERY: receivers = the local grid DSIM_DW_LOCAL of this step built (the buffer before the flip)
-    if (ctx->dw_ws != g->workspace || ctx->dw_cells != ncells || ctx->dw_mode != 1) return DSIM_E_ARG;
-    memset(&a, 0, sizeof(a));
-    int rc = make_kview(state, 20 + ctx->max_act, &a.st);
-    if (rc) return rc;
-    BinK lb;
-    memset(&lb, 0, sizeof(lb));
-    bucket_layout(g->workspace, ncells, 1 - ctx->dw_parity, &lb);
-    lb.xmin = g->xmin; lb.ymin = g->ymin; lb.inv_cell = hb.inv_cell; lb.nx = g->nx; lb.ny = g->ny; lb.local_offset = 0;
-    a.types = ctx->d_types; a.type_id = g->type_id; a.n_types = ctx->n_types;
-    a.pairs = (unsigned long long*)g->pairs_evaluated;
-    a.m = g->m; a.n = n; a.n_pad = state.n_pad; a.local_offset = 0;
-    a.xmin = g->xmin; a.ymin = g->ymin; a.inv_cell = hb.inv_cell; a.nx = g->nx; a.ny = g->ny;
-    a.force_out = force_out;
-    BinK nxt;
-    halo_layout(g->workspace, ncells, n, 1 - ctx->dwh_parity, &nxt);
-    a.count_next = nxt.count;
-    ctx->dwh_parity = 1 - ctx->dwh_parity;
-    if (h_tot == 0) return DSIM_OK;                                   // nothing arrived, nothing was binned: nothing to add or clear
-    // tile shape as for the local pass of this grid (the candidates of a neighbourhood are the halo's, never more)
-    launch_query_cell(ctx, st_, a, lb, hb, g->cell, n, 1);
-    return (int)hipGetLastError();
-  }
-  // bucket form: cells of half the cut-off or more (two rings of neighbours below 10 m); counting-sort form: >= 10 m
-  const bool bucket_form = g->nx > 0 && g->ny > 0 && dw_use_buckets(g->m, (int64_t)g->nx * g->ny);
-  if (g->halo && g->phase == DSIM_DW_ALL && ctx) ctx->dwh_ws = nullptr;   // (the one-grid form's overflow list may run over the halo grid's place)
-  int rc = grid_build(ctx, st_, n, state, g, bucket_form ? 0.5f * DW_CUTOFF : DW_CUTOFF, &a, true);
-  if (rc) return rc;
-  a.force_out = force_out;
-  if (a.buckets) {
-    BinK b;
-    memset(&b, 0, sizeof(b));
-    b.count = a.count; b.buckets = a.buckets; b.overflow = a.overflow;
-    b.xmin = a.xmin; b.ymin = a.ymin; b.inv_cell = a.inv_cell; b.nx = a.nx; b.ny = a.ny; b.local_offset = a.local_offset;
-    if (g->halo && g->phase == DSIM_DW_ALL && h_tot > 0)              // one grid: what the peers sent goes in beside the local drones
-      hipLaunchKernelGGL(k_dw_bin_halo, dim3(grid_for(h_tot)), dim3(256), 0, st_, b, hk);
-    launch_query_cell(ctx, st_, a, b, b, g->cell, g->phase == DSIM_DW_LOCAL ? n : a.m, 0);
-  }
-  else hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m * DW_LPR)), dim3(256), 0, st_, a);
-  return (int)hipGetLastError();
-}
-
-int dsim_downwash_reset(dsim_ctx* ctx) {
-  if (!ctx) return DSIM_E_ARG;
-  ctx->dw_ws = nullptr; ctx->dw_cells = 0; ctx->dw_parity = 0; ctx->dw_prebin = false; ctx->dw_prebin_valid = false;
-  ctx->dwh_ws = nullptr;
-  return DSIM_OK;
-}
-
-int dsim_fleet_bounds(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float* out5) {
-  if (!ctx || !out5 || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
-  BoundsK a;
-  int rc = make_kview(state, 20 + ctx->max_act, &a.st);
-  if (rc) return rc;
-  a.n = n; a.keys = ctx->d_bounds; a.out = out5;
-  const long long groups = (n + 255) / 256;
-  hipLaunchKernelGGL(k_fleet_bounds, dim3((unsigned)(groups < 4LL * ctx->n_cu ? groups : 4LL * ctx->n_cu)), dim3(256), 0,
-                     (hipStream_t)stream, a);
-  return (int)hipGetLastError();
-}
-
-int dsim_halo_pack(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_halo_plan* plan) {
-  if (!ctx || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
-  int rc = halo_check(plan);
-  if (rc) return rc;
-  if (!plan->send || !plan->recv || !plan->scratch) return DSIM_E_ARG;
-  HaloK h;
-  memset(&h, 0, sizeof(h));
-  rc = make_kview(state, 20 + ctx->max_act, &h.st);
-  if (rc) return rc;
-  halo_fill(plan, &h);
-  h.n = n; h.counters = ctx->d_counters;
-  const long long per_group = (long long)DSIM_PACK_TPB * DSIM_PACK_PER_THREAD;
-  hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((n + per_group - 1) / per_group)), dim3(DSIM_PACK_TPB), 0, (hipStream_t)stream, h);
-  return (int)hipGetLastError();
-}
-
-int dsim_adjacency(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const dsim_downwash_args* g,
-                   float radius, int32_t* count_out, int32_t* list_out, int32_t max_k) {
-  if (!count_out || !(radius > 0) || (list_out && max_k < 1)) return DSIM_E_ARG;
-  DwK a;
-  const hipStream_t st_ = (hipStream_t)stream;
-  int rc = grid_build(ctx, st_, n, state, g, radius, &a);
-  if (rc) return rc;
-  a.radius2 = radius * radius; a.adj_count = count_out; a.adj_list = list_out; a.max_k = list_out ? max_k : 0;
-  hipLaunchKernelGGL(k_adj_query, dim3(grid_for(a.m)), dim3(256), 0, st_, a);
-  return (int)hipGetLastError();
-}
-
-// counting sort of the world's positions into the xy grid (count, scan, scatter)
-static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view& state,
-                      const dsim_downwash_args* g, float min_cell, DwK* out, bool allow_buckets) {
-  DwK& a_ = *out;
-  if (!ctx || !g || !g->workspace || n <= 0 || n > state.n_pad) return DSIM_E_ARG;
-  // pos_all = NULL: the world is this fleet (m = n, local_offset = 0) and positions are read from the state block — or,
-  // with a halo plan, this fleet plus what the plan's peers sent (checked by dsim_downwash)
-  if (!g->pos_all && !g->halo && (g->m != n || g->local_offset != 0)) return DSIM_E_ARG;
-  if (g->m < 1 || (g->pos_all && g->m_pad < g->m) || g->nx < 1 || g->ny < 1 || !(g->cell >= min_cell)) return DSIM_E_ARG;
-  if ((long long)g->nx * g->ny > (1 << 24)) return DSIM_E_ARG;
-  if (g->workspace_len < dsim_downwash_workspace(g->m, g->nx, g->ny)) return DSIM_E_ARG;
-  DwK a;
-  memset(&a, 0, sizeof(a));
-  int rc = make_kview(state, 20 + ctx->max_act, &a.st);
-  if (rc) return rc;
-  const long long ncells = (long long)g->nx * g->ny;
-  a.types = ctx->d_types; a.type_id = g->type_id; a.pos_all = g->pos_all; a.n_types = ctx->n_types;
-  a.pairs = (unsigned long long*)g->pairs_evaluated;
-  a.m = g->m; a.m_pad = g->m_pad; a.n = n; a.n_pad = state.n_pad; a.local_offset = g->local_offset;
-  if (g->local_offset < 0 || g->local_offset + n > g->m || g->m >= (1LL << 31)) return DSIM_E_ARG;
-  a.xmin = g->xmin; a.ymin = g->ymin; a.inv_cell = 1.0f / g->cell; a.nx = g->nx; a.ny = g->ny;
-  const bool buckets = allow_buckets && dw_use_buckets(g->m, ncells);
-  const long long cstride = ncells + (buckets ? DW_CNT_EXTRA : 1);      // the bucket form keeps the overflow length (and more) behind the cells
-  // two count buffers alternate between calls; the one for the next call is zeroed by this call's first kernel
-  const bool same = ctx->dw_ws == g->workspace && ctx->dw_cells == ncells && ctx->dw_mode == (buckets ? 1 : 0);
-  const int cur = same ? ctx->dw_parity : 0;
-  a.count = g->workspace + (long long)cur * cstride;
-  a.count_next = g->workspace + (long long)(1 - cur) * cstride;
-  if (!same) {   // first use of this workspace / grid shape / form
-    hipError_t e = hipMemsetAsync(g->workspace, 0, sizeof(int) * 2 * cstride, st_);
-    if (e != hipSuccess) return (int)e;
-    ctx->dw_ws = g->workspace; ctx->dw_cells = ncells; ctx->dw_mode = buckets ? 1 : 0;
-  }
-  ctx->dw_parity = 1 - cur;
-  // local entries already binned by the previous dsim_step (dsim_step_args.bin_next) into THIS count buffer?
-  const bool pre_live = same && buckets && ctx->dw_prebin;
-  const bool pre = pre_live && ctx->dw_prebin_valid && g->prebinned && ctx->dw_prebin_n == n &&
-                   ctx->dw_prebin_off == g->local_offset && ctx->dw_prebin_geo[0] == g->xmin &&
-                   ctx->dw_prebin_geo[1] == g->ymin && ctx->dw_prebin_geo[2] == g->cell && ctx->dw_prebin_nx == g->nx &&
-                   ctx->dw_prebin_ny == g->ny;
-  ctx->dw_prebin = false;
-  if (buckets) {
-    BinK b;
-    memset(&b, 0, sizeof(b));
-    bucket_layout(g->workspace, ncells, cur, &b);
-    b.xmin = a.xmin; b.ymin = a.ymin; b.inv_cell = a.inv_cell; b.nx = a.nx; b.ny = a.ny; b.local_offset = a.local_offset;
-    a.buckets = b.buckets; a.overflow = b.overflow;
-    if (pre_live && !pre) {          // a step binned into this buffer but the caller does not vouch for it: start over
-      hipError_t e = hipMemsetAsync(a.count, 0, sizeof(int) * cstride, st_);
-      if (e != hipSuccess) return (int)e;
-    }
-    const long long m_here = g->halo ? n : a.m;         // entries this pass reads through dw_pos (the halo has its own kernel)
-    BinRange r;
-    r.j0 = 0; r.j1 = m_here; r.skip0 = r.skip1 = m_here;
-    long long todo = m_here;
-    if (pre) { r.skip0 = a.local_offset; r.skip1 = a.local_offset + n; todo = m_here - n; }
-    if (todo > 0) hipLaunchKernelGGL(k_dw_bin, dim3(grid_for(todo)), dim3(256), 0, st_, a, b, r);
-    a_ = a;
-    return DSIM_OK;
-  }
-  a.cursor = g->workspace + 2 * (ncells + 1);
-  uintptr_t sp = (uintptr_t)(a.cursor + ncells);
-  a.sorted = (float4*)((sp + 15) & ~(uintptr_t)15);
-  hipLaunchKernelGGL(k_dw_count, dim3(grid_for(a.m > ncells + 1 ? a.m : ncells + 1)), dim3(256), 0, st_, a);
-  // (measured and rejected: letting the last count workgroup do the scan — the fences and the one-workgroup scan
-  // behind them cost 28 us against 7 + 6.5 us for the two launches)
-  hipLaunchKernelGGL(k_dw_scan, dim3(1), dim3(1024), 0, st_, a);
-  hipLaunchKernelGGL(k_dw_scatter, dim3(grid_for(a.m)), dim3(256), 0, st_, a);
-  a_ = a;
-  return DSIM_OK;
 }
 
 }  // extern "C"

@@ -188,41 +188,44 @@ __device__ __forceinline__ void threefry4x32_12(uint32_t x[4], uint32_t k0, uint
     }
   }
 }
-// 16 bits -> two normals of standard deviation SIGMA (Box-Muller): radius from the HIGH byte (u1 = (h + 1) / 256 in
-// (0, 1]), angle from the LOW byte (u2 = l / 256 revolutions).  Round 4: 8 + 8 bits per pair instead of 16 + 16 — one
-// Threefry block (128 bits) now yields SIXTEEN normals: both sub-steps of a pair of consecutive quad sub-steps, or all
-// twelve normals of a hexa sub-step from one block instead of two; the generator was 85 of the 336 vector instructions a
-// quad sub-step cost, and the examples' five sub-steps per control are bound by vector issue.  What the coarser
-// grid does to the distribution (256 radii x 256 directions; exact, oracle/dsim_oracle.c mirrors it): mean 0, variance
-// sigma^2 exactly (the radius is scaled by DSIM_BM8_CORR = 2 / E[-2 ln u1] = 1.01463...: the 256-point mean of -2 ln u1 is
-// 1.9712, not 2), |n| <= 3.354 sigma, kurtosis 2.922 instead of 3, the two normals of a pair uncorrelated (E cos sin = 0 over
-// 256 directions).  The rotor noise is a 0.01 N / 0.001 N m perturbation of a 1.8 N thrust (BaseAviary.py:1518-1521): its
-// fourth moment is not what a trajectory depends on.
+// 16 bits -> two normals of standard deviation SIGMA (Box-Muller): radius from the HIGH byte (u1 = (h + 1/2) / 256), angle from
+// the LOW byte (u2 = (l + 1/2) / 256 revolutions) — the lattice points sit at the CENTRES of the 256 x 256 cells of the unit square
+// (round 6; up to round 5 they sat at cell corners, u1 = (h + 1) / 256, u2 = l / 256, which put 3 / 256 of the mass of a normal at
+// exactly 0: the directions with cos = 0 or sin = 0 and the radius 0 of u1 = 1).  8 + 8 bits per pair (round 4; 16 + 16 before): one
+// Threefry block (128 bits) yields SIXTEEN normals — both sub-steps of a pair of consecutive quad sub-steps, or all twelve normals
+// of a hexa sub-step; the generator was 85 of the 336 vector instructions a quad sub-step cost, and the examples' five sub-steps per
+// control are bound by vector issue.  The lattice as a distribution (exact; oracle/dsim_oracle.c mirrors it,
+// tests/test_noise_distribution.py measures it): mean 0, variance sigma^2 exactly (the radius is scaled by DSIM_BM8_CORR =
+// 2 / E[-2 ln u1] = 1.001355: the 256-point mean of -2 ln u1 is 1.9973, not 2), no atoms (no draw is 0), |n| <= 3.535 sigma,
+// kurtosis 2.977 instead of 3, the two normals of a pair uncorrelated (E cos sin = 0 over the 256 directions).  The rotor noise is a
+// 0.01 N / 0.001 N m perturbation of a 1.8 N thrust (BaseAviary.py:1518-1521).  This is the lattice of the kernels that LOOP over
+// several sub-steps; launches of one sub-step draw the fine lattice below (include/dronesim_amd.h: noise_seed).
 // The hardware transcendentals take the angle in revolutions and log in base 2; the deviation is folded into the radius:
 // sigma sqrt(-2 corr ln u1) = sqrt(-sigma^2 2 ln2 corr log2(u1)).  v_cvt_f32_ubyteN converts a byte of the word in ONE
-// instruction.
-#define DSIM_BM8_S2 1.4065790595805696f          // 2 ln 2 x DSIM_BM8_CORR
+// instruction; the half-cell offsets ride in the multiply-adds that scale the bytes.
+#define DSIM_BM8_S2 1.3881727911541815f          // 2 ln 2 x DSIM_BM8_CORR (1.0013550008475642)
 template <int SIGMA_E3, int HALF>      // the deviation in thousandths (10 = rotor force noise, 1 = rotor moment noise); which 16 bits of w
 __device__ __forceinline__ void box_muller8(uint32_t w, float& n0, float& n1) {
   constexpr float S2 = (SIGMA_E3 * 1e-3f) * (SIGMA_E3 * 1e-3f) * DSIM_BM8_S2;
   const float h = (float)((w >> (HALF ? 24 : 8)) & 0xFFu);      // (selected as v_cvt_f32_ubyte3 / _ubyte1)
   const float l = (float)((w >> (HALF ? 16 : 0)) & 0xFFu);
-  const float u1 = (h + 1.0f) * (1.0f / 256.0f);
-  const float u2 = l * (1.0f / 256.0f);
+  const float u1 = (h + 0.5f) * (1.0f / 256.0f);
+  const float u2 = (l + 0.5f) * (1.0f / 256.0f);
   const float r = DSIM_SQRT(-S2 * __builtin_amdgcn_logf(u1));
   n0 = r * __builtin_amdgcn_cosf(u2);
   n1 = r * __builtin_amdgcn_sinf(u2);
 }
-// DSIM_OPT_NOISE_FINE: 32 bits -> two normals, radius from the HIGH 16 bits (u1 = (h + 1) / 65536), direction from the LOW 16
-// (u2 = l / 65536 revolutions): 2^32 distinct pairs, |n| <= sqrt(2 corr ln 65536) = 4.710 sigma, variance sigma^2 exactly
-// (DSIM_BM16_CORR = 2 / mean(-2 ln u1) = 1.0000986...), kurtosis 2.9987.  Evaluated, not tabulated (65 536 radii do not fit
-// the LDS budget of the looped kernels).  Mirrored by oracle/dsim_oracle.c:orc_bm16.
-#define DSIM_BM16_S2 1.3864311112001642f         // 2 ln 2 x DSIM_BM16_CORR
+// The FINE lattice: 32 bits -> two normals, radius from the HIGH 16 bits (u1 = (h + 1/2) / 65536), direction from the LOW 16
+// (u2 = (l + 1/2) / 65536 revolutions): 2^32 distinct pairs, |n| <= sqrt(2 corr ln 131072) = 4.855 sigma, variance sigma^2 exactly
+// (DSIM_BM16_CORR = 2 / mean(-2 ln u1) = 1.0000053), kurtosis 2.99982.  Evaluated, not tabulated (65 536 radii do not fit
+// the LDS budget of the looped kernels).  Mirrored by oracle/dsim_oracle.c:orc_bm16.  The lattice of every launch of ONE sub-step
+// (where the generator is free: those kernels are bound by HBM) and of DSIM_OPT_NOISE_FINE at any count.
+#define DSIM_BM16_S2 1.3863016922764049f         // 2 ln 2 x DSIM_BM16_CORR (1.0000052883115735)
 template <int SIGMA_E3>
 __device__ __forceinline__ void box_muller16(uint32_t w, float& n0, float& n1) {
   constexpr float S2 = (SIGMA_E3 * 1e-3f) * (SIGMA_E3 * 1e-3f) * DSIM_BM16_S2;
-  const float u1 = ((float)(w >> 16) + 1.0f) * (1.0f / 65536.0f);
-  const float u2 = (float)(w & 0xFFFFu) * (1.0f / 65536.0f);
+  const float u1 = ((float)(w >> 16) + 0.5f) * (1.0f / 65536.0f);
+  const float u2 = ((float)(w & 0xFFFFu) + 0.5f) * (1.0f / 65536.0f);
   const float r = DSIM_SQRT(-S2 * __builtin_amdgcn_logf(u1));
   n0 = r * __builtin_amdgcn_cosf(u2);
   n1 = r * __builtin_amdgcn_sinf(u2);
@@ -272,8 +275,8 @@ struct NoiseTab { float2 rad[256]; float2 cs[256]; };          // rad[h] = (radi
 __device__ __forceinline__ void noise_tab_init(NoiseTab& t, unsigned tid /* 0..255 */) {
   constexpr float S2a = (10 * 1e-3f) * (10 * 1e-3f) * DSIM_BM8_S2, S2b = (1 * 1e-3f) * (1 * 1e-3f) * DSIM_BM8_S2;
   const float b = (float)(tid & 0xFFu);
-  const float L = __builtin_amdgcn_logf((b + 1.0f) * (1.0f / 256.0f));
-  const float u2 = b * (1.0f / 256.0f);
+  const float L = __builtin_amdgcn_logf((b + 0.5f) * (1.0f / 256.0f));
+  const float u2 = (b + 0.5f) * (1.0f / 256.0f);
   t.rad[tid & 255u] = make_float2(DSIM_SQRT(-S2a * L), DSIM_SQRT(-S2b * L));
   t.cs[tid & 255u] = make_float2(__builtin_amdgcn_cosf(u2), __builtin_amdgcn_sinf(u2));
 }

@@ -45,8 +45,7 @@ class _AdaptorAviary(CtrlAviary):
         # A homogeneous fleet in whole tiles steps in ONE launch that takes the action as the caller holds it ([N, 4] rows
         # on the device: no transpose) and writes Env.step's observation rows itself (k_adaptor_fast).
         one_launch = (not self.dict_io and self.order is None and len(self.types) == 1 and self.state.n_pad % 256 == 0
-                      and not self.ground_plane and self._type_id is None
-                      and not (self.noise == "fine" and self.noise_seed != 0))      # (k_adaptor_fast carries the default lattice only)
+                      and not self.ground_plane and self._type_id is None)
         rows_in = (one_launch and isinstance(action, torch.Tensor) and action.dtype == torch.float32 and action.is_contiguous()
                    and action.device == self.ctx.device and tuple(action.shape) == (self.NUM_DRONES, 4)
                    and action.data_ptr() % 16 == 0)

@@ -107,7 +107,7 @@ class CtrlAviary(PlacedFleetArrays, FleetObservation):
         defer_fallback: bool = False,
         placement: bool = False,
         dyn_ang_vel: str = "reference",
-        noise: str = "lattice256",
+        noise: str = "auto",
     ):
         if gui or record or obstacles:
             raise NotImplementedError("gui/record/obstacles are rendering features outside the hot path")
@@ -140,14 +140,17 @@ class CtrlAviary(PlacedFleetArrays, FleetObservation):
         # tuning bits handed to every call (nat.OPT_STREAM_ON/_OFF; the A/B knobs of a variants build); results do not depend on them
         self._tuning = int(options) & nat.TUNING_MASK
         # The rotor-noise stream is product-defined (the reference draws from numpy's unseeded global generator,
-        # BaseAviary.py:1518-1525): Box-Muller pairs on a lattice of 256 radii x 256 directions by default (|n| <= 3.35 sigma),
-        # noise="fine": 65 536 x 65 536 (|n| <= 4.71 sigma, DSIM_OPT_NOISE_FINE) — free on the single-sub-step kernels, a few
-        # per cent on the looped ones (include/dronesim_amd.h: noise_seed).  Rides with the tuning bits into every launch.
-        if noise not in ("lattice256", "fine"):
+        # BaseAviary.py:1518-1525): Box-Muller pairs on a lattice (include/dronesim_amd.h: noise_seed).  "fine": 65 536 x 65 536
+        # points (|n| <= 4.86 sigma), free on kernels of one physics sub-step; "coarse" (= "lattice256"): 256 x 256 (|n| <= 3.53
+        # sigma), what the kernels that loop over several sub-steps can afford.  "auto": fine when Env.step is ONE sub-step
+        # (aggregate_phy_steps == 1), coarse otherwise.  The env passes the lattice explicitly with every launch, so that an
+        # Env.step it splits into single-sub-step launches (the per-sub-step neighbour downwash) draws the same stream.
+        if noise not in ("auto", "fine", "coarse", "lattice256"):
             raise ValueError(noise)
-        self.noise = noise
-        if noise == "fine":
-            self._tuning |= nat.OPT_NOISE_FINE
+        if noise == "auto":
+            noise = "fine" if int(aggregate_phy_steps) == 1 else "coarse"
+        self.noise = "coarse" if noise == "lattice256" else noise
+        self._tuning |= nat.OPT_NOISE_FINE if self.noise == "fine" else nat.OPT_NOISE_COARSE
         self.neighbors_k = int(neighbors_k)
         if isinstance(drone_model, (str, DroneType)):
             drone_model = [drone_model]

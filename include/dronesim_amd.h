@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DSIM_ABI_VERSION 7
+#define DSIM_ABI_VERSION 8
 #define DSIM_MAX_ACT 6     /* actuators per vehicle (quad 4, morphing hexa 6) */
 #define DSIM_MAX_TYPES 8
 
@@ -209,12 +209,19 @@ enum {
    * equation treats as body rates (rpy_rates x J rpy_rates, :1805).  Off = the reference's (-1, -1, -1).                  */
   DSIM_OPT_DYN_BODY_RATES = 1u << 17,
   /* -- rotor noise (changes results) -------------------------------------------------------------------------------------
-   * The finer of the two lattices the rotor-noise normals are drawn on (see dsim_step_args.noise_seed): 16 + 16 bits per
-   * Box-Muller pair instead of 8 + 8, one Threefry block per quad sub-step (two per hexa sub-step) instead of one per two
-   * sub-steps (one per hexa sub-step), radius and direction evaluated, not tabulated.  Free on the single-sub-step kernels
-   * (HBM-bound); on the kernels that loop over sub-steps, which are bound by vector issue, it costs what DESIGN.md section 3
-   * records.  Honoured by every kernel that draws noise (a wave-uniform run-time switch).                                */
+   * WHICH of the two lattices the rotor-noise normals are drawn on (see dsim_step_args.noise_seed).  A function of the launch
+   * arguments alone, never of the kernel that happens to serve the launch:
+   *   neither bit   phys_substeps == 1: the FINE lattice; phys_substeps > 1: the COARSE one
+   *   _NOISE_FINE   the fine lattice at any sub-step count: 16 + 16 bits per Box-Muller pair, one Threefry block per quad sub-step
+   *                 (two per hexa sub-step), radius and direction evaluated.  Free on launches of one sub-step (bound by HBM);
+   *                 a launch of several sub-steps on it leaves the looped fast kernels for the general ones
+   *   _NOISE_COARSE the coarse lattice at any count: 8 + 8 bits per pair, one block per TWO quad sub-steps (one per hexa
+   *                 sub-step), radius and direction from 256-entry tables in the kernels that loop over sub-steps (bound by
+   *                 vector issue).  A caller that splits one Env.step of several sub-steps into single-sub-step launches
+   *                 (the per-sub-step neighbour downwash) passes the bit of the lattice its unsplit step would draw
+   * Both bits: DSIM_E_ARG.                                                                                                */
   DSIM_OPT_NOISE_FINE  = 1u << 18,
+  DSIM_OPT_NOISE_COARSE = 1u << 19,
   /* -- scheduling (results do not depend on it) ---------------------------------------------------------------------- */
   DSIM_OPT_DEFER_FALLBACK = 1u << 11 /* dsim_step / dsim_control2 of a table with a morphing hexa do NOT launch the deferred
                                        WLS fallback pass behind the step; the caller launches dsim_wls_fallback itself —
@@ -240,16 +247,20 @@ typedef struct dsim_step_args {
   uint64_t noise_seed;      /* 0 = rotor noise off; else counter-based noise, N(0, .01) on the rotor forces and N(0, .001) on
                                the rotor moments per sub-step (BaseAviary.py:1518-1525, 1429-1432).  The reference draws
                                np.random.normal from the unseeded global generator; here the stream is PRODUCT-DEFINED:
-                               Threefry4x32-12 keyed by the seed, counter = (drone, block), Box-Muller pairs on a LATTICE —
-                                 default   8 + 8 bits per pair: 256 radii x 256 directions = 65 536 distinct pairs, |n| <= 3.354
-                                           sigma (the reference's tails are unbounded: mass 8.0e-4 beyond 3.354 sigma; 2.06e-3
-                                           instead of 2.70e-3 beyond 3 sigma), variance exactly sigma^2 (the radius is rescaled),
-                                           kurtosis 2.922 instead of 3, an atom of 3 / 256 of the mass at 0, Kolmogorov
-                                           distance 6.0e-3 from the normal distribution;
-                                 DSIM_OPT_NOISE_FINE   16 + 16 bits per pair: 2^32 distinct pairs, |n| <= 4.710 sigma (mass 2.5e-6
-                                           beyond), kurtosis 2.9987, Kolmogorov distance below what 1e7 draws resolve (1.9e-4).
+                               Threefry4x32-12 keyed by the seed, counter = (drone, block), Box-Muller pairs on a LATTICE of
+                               cell centres (u = (k + 1/2) / K: no draw is exactly 0) —
+                                 fine      16 + 16 bits per pair: 2^32 distinct pairs, |n| <= 4.855 sigma (mass 1.2e-6 beyond),
+                                           kurtosis 2.9998, Kolmogorov distance from the normal distribution below what 1e7 draws
+                                           resolve.  The lattice of every launch of ONE sub-step (BASELINE's metric) and of
+                                           DSIM_OPT_NOISE_FINE;
+                                 coarse    8 + 8 bits per pair: 256 radii x 256 directions = 65 536 distinct pairs, |n| <= 3.535
+                                           sigma (the reference's tails are unbounded: mass 4.1e-4 beyond 3.535 sigma; 2.75e-3 instead of 2.70e-3 beyond 3), variance
+                                           exactly sigma^2 (the radius is rescaled), kurtosis 2.977 instead of 3, no atoms,
+                                           Kolmogorov distance 1.4e-3 from the normal distribution.  The lattice of launches of
+                                           SEVERAL sub-steps (the examples' five: kernels bound by vector issue) and of
+                                           DSIM_OPT_NOISE_COARSE.
                                tests/test_noise_distribution.py measures both against N(0, 1) (Kolmogorov distance, moments,
-                               tail mass) over 1e7 draws; dsim_noise_draw hands out the normals themselves.              */
+                               tail mass, the absence of exact zeros) over 1e7 draws; dsim_noise_draw hands out the normals.   */
   uint64_t step_index;      /* env-step counter, mixed into the noise counter                    */
   const float* noise_replay;/* nullable; [phys_substeps][2*n_act][n_pad] recorded normals (tests)*/
   const uint8_t* type_id;   /* nullable; per-drone index into the ctx type table (mixed fleets)  */

@@ -780,7 +780,7 @@ void orc_physics_substep(const dsim_type_params* P, double dt, double rigid[13],
  * from the unseeded global numpy RNG, BaseAviary.py:1518-1525, which cannot be
  * reproduced).  Threefry4x32-12 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
  * SC'11 — the Random123 generator; add/rotate/xor only) keyed by the seed, counter = (drone, block index),
- * Box-Muller on 8+8-bit halves -> unit-variance normals on a 256 x 256 grid, |n| <= 3.354 (orc_noise_normals).
+ * Box-Muller on 8+8-bit halves -> unit-variance normals on a 256 x 256 grid of cell centres, |n| <= 3.535 (orc_noise_normals).
  * Mirrors dsim_device.h so that tests can feed the oracle the very normals the kernel draws.
  * orc_threefry4x32 takes the round count so that the published known-answer vectors (13 and 20 rounds,
  * Random123 kat_vectors) pin the round function, rotation constants and key schedule
@@ -806,17 +806,17 @@ void orc_threefry4x32(uint32_t x[4], const uint32_t key[4], int rounds) {
   }
 }
 /* UNIT normals for (drone, sub-step counter): out[2 n_act] = f_noise[n_act] then m_noise[n_act] (the caller scales by 0.01 /
- * 0.001).  16 bits make a Box-Muller pair: radius from the high byte (u1 = (h + 1) / 256 in (0, 1]), angle from the low byte
- * (u2 = l / 256 revolutions); the radius is scaled by ORC_BM8_CORR = 2 / mean(-2 ln u1 over the 256 values) so that the
- * variance is exactly 1 (|n| <= 3.354, kurtosis 2.922: dsim_device.h:box_muller8).  One block = 8 pairs:
+ * 0.001).  16 bits make a Box-Muller pair: radius from the high byte (u1 = (h + 1/2) / 256), angle from the low byte
+ * (u2 = (l + 1/2) / 256 revolutions); the radius is scaled by ORC_BM8_CORR = 2 / mean(-2 ln u1 over the 256 values) so that the
+ * variance is exactly 1 (|n| <= 3.535, kurtosis 2.977, no atoms: dsim_device.h:box_muller8).  One block = 8 pairs:
  *   quad: block index = sub_counter >> 1; the even sub-step takes words 0 (force) and 1 (moment), the odd one words 2 and 3;
  *   hexa: block index = sub_counter; force normals from word 0 and the low half of word 1, moment normals from the high
  *         half of word 1 and word 2.  Within a word the low 16 bits come first. */
-#define ORC_BM8_CORR 1.0146323169375748
+#define ORC_BM8_CORR 1.0013550008475642
 static void orc_bm8(uint32_t w, int half, double* n0, double* n1) {
   const uint32_t v = half ? (w >> 16) : (w & 0xFFFFu);
-  const double u1 = ((double)(v >> 8) + 1.0) * (1.0 / 256.0);
-  const double u2 = (double)(v & 0xFFu) * (1.0 / 256.0);
+  const double u1 = ((double)(v >> 8) + 0.5) * (1.0 / 256.0);
+  const double u2 = ((double)(v & 0xFFu) + 0.5) * (1.0 / 256.0);
   const double r = sqrt(-2.0 * ORC_BM8_CORR * log(u1));
   *n0 = r * cos(2 * ORC_PI * u2);
   *n1 = r * sin(2 * ORC_PI * u2);
@@ -838,12 +838,13 @@ void orc_noise_normals(uint64_t seed, uint64_t drone, uint64_t sub_counter, int 
 }
 
 /* DSIM_OPT_NOISE_FINE (dsim_device.h:box_muller16, quad_normals_fine, hexa_normals_fine): 16 + 16 bits per pair — radius from
- * the high half of a word (u1 = (h + 1) / 65536), direction from the low half; blocks in a domain of their own (counter word
- * 3's top bit); quad: block `sub`, words 0, 1 force, 2, 3 moment; hexa: blocks 2 sub, 2 sub + 1. */
-#define ORC_BM16_CORR 1.000098644331326
+ * the high half of a word (u1 = (h + 1/2) / 65536), direction from the low half; blocks in a domain of their own (counter word
+ * 3's top bit); quad: block `sub`, words 0, 1 force, 2, 3 moment; hexa: blocks 2 sub, 2 sub + 1.  Lattice points at the centres
+ * of the cells (u1 = (h + 1/2) / 65536, u2 = (l + 1/2) / 65536): no draw is exactly 0. */
+#define ORC_BM16_CORR 1.0000052883115735
 static void orc_bm16(uint32_t w, double* n0, double* n1) {
-  const double u1 = ((double)(w >> 16) + 1.0) * (1.0 / 65536.0);
-  const double u2 = (double)(w & 0xFFFFu) * (1.0 / 65536.0);
+  const double u1 = ((double)(w >> 16) + 0.5) * (1.0 / 65536.0);
+  const double u2 = ((double)(w & 0xFFFFu) + 0.5) * (1.0 / 65536.0);
   const double r = sqrt(-2.0 * ORC_BM16_CORR * log(u1));
   *n0 = r * cos(2 * ORC_PI * u2);
   *n1 = r * sin(2 * ORC_PI * u2);

@@ -173,7 +173,7 @@ def test_integrator_envelope_vs_oracle_env_step(gpu, regime):
                 O.physics(r_ref, mem.copy(), sub, DT, action=a6, noise=nz, type_id=tid)
                 tgt = np.concatenate([rigid[:, 0:3], np.zeros((n_, 7))], 1)
                 _collect(failures, assert_step_parity, label, types, tid, rigid, mem, tgt, got_r, None, r_ref, None, DT, DT * sub, sub, control=False,
-                         action=a6[:, :na], extra_terms=noise_terms(types, tid, n_, DT, sub) if seed else None)
+                         action=a6[:, :na], extra_terms=noise_terms(types, tid, n_, DT, sub) if seed else None, noise=bool(seed))
                 np.testing.assert_array_equal(st.mem_aos(), mem)                  # controller memory untouched
                 _collect(failures, _check_obs_rows, label + " rows", O, obs.double().cpu().numpy(), f32(got_r), a6, tid, types)
                 ctx.close()

@@ -32,7 +32,7 @@ def _draw(nat, ctx, n, n_act, seed, step_index, sub, fine, drone_id=None):
     n_pad = (n + 255) // 256 * 256
     out = torch.zeros((sub, 2 * n_act, n_pad), device=ctx.device)
     nat.check(ctx.lib.dsim_noise_draw(ctx.handle, ctx.stream_ptr(), n, n_pad, n_act, seed, step_index, sub,
-                                      nat.OPT_NOISE_FINE if fine else 0, drone_id.data_ptr() if drone_id is not None else None,
+                                      nat.OPT_NOISE_FINE if fine else nat.OPT_NOISE_COARSE, drone_id.data_ptr() if drone_id is not None else None,
                                       out.data_ptr()))
     torch.cuda.synchronize()
     return out[:, :, :n]
@@ -75,11 +75,12 @@ def test_noise_distribution_on_the_device(gpu, fine):
     ks = max(float((np.arange(1, z.size + 1) / z.size - cdf).max()), float((cdf - np.arange(0, z.size) / z.size).max()))
     tail = float((np.abs(z) > 3.0).mean())
     if fine:
-        assert abs((z ** 4).mean() - 2.9987) < 0.012 and 4.0 < np.abs(z).max() < 4.7101
+        assert abs((z ** 4).mean() - 2.9998) < 0.012 and 4.0 < np.abs(z).max() < 4.8547
         assert ks < 1.63 / math.sqrt(z.size) and abs(tail - 2.69980e-3) < 1e-4
     else:
-        assert abs((z ** 4).mean() - 2.9221) < 0.01 and np.abs(z).max() < 3.3546
-        assert 5.0e-3 < ks < 7.0e-3 and 1.9e-3 < tail < 2.2e-3
+        assert abs((z ** 4).mean() - 2.9767) < 0.01 and np.abs(z).max() < 3.5347
+        assert ks < 3.0e-3 and 2.3e-3 < tail < 2.8e-3, (ks, tail)
+    assert float((z == 0.0).mean()) == 0.0                # no lattice point is 0: no atom at zero on either lattice
     ctx.close()
 
 
@@ -119,8 +120,8 @@ def test_fine_lattice_through_the_fused_step(gpu, model, sub, n):
         assert O.step(r1, m1, tgt, sub, DT, dtc, noise=_fine_replay(O, seed, n, step_index, sub, t.n_act)) == 0
         assert_step_parity(f"fine_noise_fused[{model},{sub}]", [t], None, r0, m0, tgt, st.rigid_aos(), st.mem_aos(), r1, m1, DT, dtc, sub,
                            extra_terms=noise_terms([t], None, n, DT, sub))
-    # the default lattice on the same state gives another trajectory (the switch is honoured)
-    b = nat.StepArgs.from_buffer_copy(a); b.options = 0
+    # the coarse lattice on the same state gives another trajectory (the switch is honoured)
+    b = nat.StepArgs.from_buffer_copy(a); b.options = nat.OPT_NOISE_COARSE
     keep = st.data.clone()
     nat.check(ctx.lib.dsim_step(ctx.handle, ctx.stream_ptr(), n, st.view(), tg.view(), ctypes.byref(b)))
     d0 = st.rigid_aos()

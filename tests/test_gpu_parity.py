@@ -443,7 +443,7 @@ def test_inkernel_noise_matches_definition(gpu, sub):
     nz = np.zeros((n, sub, 12))
     for i in range(n):
         for s in range(sub):
-            u = O.noise_normals(seed, i, step_index * sub + s, 4)
+            u = O.noise_normals(seed, i, step_index * sub + s, 4, fine=(sub == 1))     # (one sub-step per launch: the fine lattice)
             nz[i, s, 0:4] = u[0:4] * 0.01
             nz[i, s, 6:10] = u[4:8] * 0.001
     assert abs(nz[:, :, 0:4].std() - 0.01) < 1e-3 and abs(nz[:, :, 0:4].mean()) < 1e-3
@@ -563,7 +563,7 @@ def test_mixed_fleet_vs_oracle(gpu, sub, layout, form):
     for i in range(n):
         na = 4 if tid[i] == 0 else 6
         for s_ in range(sub):
-            u = O.noise_normals(seed, i, sidx * sub + s_, na)
+            u = O.noise_normals(seed, i, sidx * sub + s_, na, fine=(sub == 1))
             nz[i, s_, 0:na] = u[0:na] * 0.01
             nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
     r0, m0 = rigid.copy(), mem.copy()
@@ -615,7 +615,7 @@ def test_type_major_runs_equal_mixed_kernel_and_oracle(gpu, sub):
             for i in range(n_slots):
                 na = 6 if slot_types[i] == 1 else 4
                 for s_ in range(sub):
-                    u = O.noise_normals(seed, i, (sidx + k) * sub + s_, na)
+                    u = O.noise_normals(seed, i, (sidx + k) * sub + s_, na, fine=(sub == 1))
                     nz[i, s_, 0:na] = u[0:na] * 0.01
                     nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
             r1, m1 = r0.copy(), m0.copy()
@@ -1191,7 +1191,7 @@ def test_bench_size_fleet_properties(gpu):
         got = states[0].fields(0, 24)[:, idx_dev].T.double().cpu().numpy()
         nz = np.zeros((len(idx), 1, 12))
         for q, i in enumerate(idx):
-            u = O.noise_normals(seed, int(i), k, 4)
+            u = O.noise_normals(seed, int(i), k, 4, fine=True)       # (one sub-step per launch: the fine lattice)
             nz[q, 0, 0:4], nz[q, 0, 6:10] = u[0:4] * 0.01, u[4:8] * 0.001
         pad2 = np.zeros((len(idx), 2))
         r0, m0 = prev[:, :13].copy(), np.concatenate([prev[:, 13:24], pad2], 1)
@@ -1800,7 +1800,7 @@ def test_randomised_airframes_vs_oracle(gpu, n_types):
         for i in range(n):
             na = 6 if is_hexa[i] else 4
             for s_ in range(sub):
-                u = O.noise_normals(seed, i, sidx * sub + s_, na)
+                u = O.noise_normals(seed, i, sidx * sub + s_, na, fine=(sub == 1))
                 nz[i, s_, 0:na] = u[0:na] * 0.01
                 nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
         r0, m0 = rigid.copy(), mem.copy()
@@ -2586,12 +2586,14 @@ def test_tuning_options_do_not_change_results(gpu, fleet_kind):
 # every template instance of the step kernels: each combination the launcher can dispatch is run once —
 # streaming and default cache policy give the same bits, and the result meets the oracle at the step's bar
 # ---------------------------------------------------------------------------
-def _noise_block(O, types, tid, n, seed, step_index, sub):
+def _noise_block(O, types, tid, n, seed, step_index, sub, fine=None):
+    """[n, sub, 12] scaled normals of a launch of `sub` sub-steps: the fine lattice for one sub-step, the coarse one for several
+    (include/dronesim_amd.h: DSIM_OPT_NOISE_FINE / _COARSE), unless `fine` says which."""
     nz = np.zeros((n, sub, 12))
     for i in range(n):
         na = types[0 if tid is None else int(tid[i])].n_act
         for s_ in range(sub):
-            u = O.noise_normals(seed, i, step_index * sub + s_, na)
+            u = O.noise_normals(seed, i, step_index * sub + s_, na, fine=(sub == 1) if fine is None else fine)
             nz[i, s_, 0:na] = u[0:na] * 0.01
             nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
     return nz
@@ -2671,7 +2673,7 @@ def _sweep_case(gpu, label, types, tid, n, sub, seed, options, action=None, n_st
         assert O.step(r, m, tgt, sub, DT, dtc, noise=nz, type_id=tid, action=a6, options=options & (nat.OPT_DRAG | nat.OPT_GROUND)) == 0
     if n_steps == 1:
         assert_step_parity(label, types, tid, rigid, mem, tgt, got[nat.OPT_STREAM_OFF][0], got[nat.OPT_STREAM_OFF][1], r, m,
-                           DT, dtc, sub, action=action)
+                           DT, dtc, sub, action=action, noise=bool(seed))
     else:      # several Env.steps in one launch: the bar of the LAST step from the oracle's previous state, widened by the count
         assert_step_parity(label, types, tid, r0, m0, tgt, got[nat.OPT_STREAM_OFF][0], got[nat.OPT_STREAM_OFF][1], r, m,
                            DT, dtc, sub, k=K_ULP * sub * 4 * n_steps)

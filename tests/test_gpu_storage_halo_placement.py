@@ -39,7 +39,7 @@ def _noise(O, types, tid, n, seed, step_index, sub):
     for i in range(n):
         na = types[tid[i]].n_act
         for s_ in range(sub):
-            u = O.noise_normals(seed, i, step_index * sub + s_, na)
+            u = O.noise_normals(seed, i, step_index * sub + s_, na, fine=(sub == 1))
             nz[i, s_, 0:na] = u[0:na] * 0.01
             nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
     return nz
@@ -93,7 +93,7 @@ def test_interleaved_fleet_is_stored_type_major_behind_the_callers_numbering(gpu
             nz = _noise(O, types, tid, n, seed, k, sub)
             assert O.step(r1, m1, tgt, sub, DT, dtc, noise=nz, type_id=tid, action=action) == 0
             assert_step_parity(f"storage[{storage},{sub},{layout}]", types, tid, r0, m0, tgt, env.state.rigid_aos(),
-                               env.state.mem_aos(), r1, m1, DT, dtc, sub, action=action)
+                               env.state.mem_aos(), r1, m1, DT, dtc, sub, action=action, noise=True)
     ra, ma = envs["auto"][0].state.rigid_aos(), envs["auto"][0].state.mem_aos()
     rc, mc = envs["caller"][0].state.rigid_aos(), envs["caller"][0].state.mem_aos()
     # two differently compiled kernels of the same laws, same noise streams: equal up to fp32 contraction

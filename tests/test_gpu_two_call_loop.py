@@ -37,7 +37,7 @@ def _noise_by_id(O, types, tid, ids, seed, step_index, sub):
     for i in range(n):
         na = types[0 if tid is None else int(tid[i])].n_act
         for s_ in range(sub):
-            u = O.noise_normals(seed, int(ids[i]), step_index * sub + s_, na)
+            u = O.noise_normals(seed, int(ids[i]), step_index * sub + s_, na, fine=(sub == 1))
             nz[i, s_, 0:na] = u[0:na] * 0.01
             nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
     return nz

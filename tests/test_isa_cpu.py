@@ -1,5 +1,5 @@
-"""No kernel of the library uses scratch memory: the gfx950 assembly of dsim_api.hip, compiled
-with the build's flags, reports ScratchSize 0 for every kernel.  CPU only (hipcc cross-compiles); ~1 minute."""
+"""No kernel of the library uses scratch memory: the gfx950 assembly of every translation unit of the
+library, compiled with the build's flags, reports ScratchSize 0 for every kernel.  CPU only (hipcc cross-compiles); ~1/2 minute."""
 import os
 import re
 import shutil
@@ -10,22 +10,35 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
-def test_no_kernel_uses_scratch(tmp_path):
+def _assembly(tmp_path, only=None):
+    """{translation unit: its gfx950 assembly}, compiled side by side with the build's flags."""
     import __graft_entry__ as ge
     flags = [f for f in ge.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
     assert "-fno-slp-vectorize" in flags
-    out = tmp_path / "dsim.s"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-S", "--cuda-device-only", "-o", str(out),
-                           os.path.join(ROOT, "dronesim_amd", "csrc", "dsim_api.hip")], stderr=subprocess.DEVNULL)
+    srcs = [s for s in ge.HIP_SRCS if only is None or os.path.basename(s) in only]
+    procs = []
+    for src in srcs:
+        out = tmp_path / (os.path.basename(src) + ".s")
+        procs.append((src, out, subprocess.Popen(["/opt/rocm/bin/hipcc", *flags, "-S", "--cuda-device-only", "-o", str(out), src],
+                                                 stderr=subprocess.DEVNULL)))
+    txt = {}
+    for src, out, p in procs:
+        assert p.wait() == 0, src
+        txt[os.path.basename(src)] = out.read_text()
+    return txt
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_no_kernel_uses_scratch(tmp_path):
     kernels, cur = {}, None
-    for ln in out.read_text().split("\n"):
-        m = re.match(r"^(_Z\w+|k_\w+):", ln)
-        if m:
-            cur = m.group(1)
-        m = re.match(r"\s*;\s*ScratchSize: (\d+)", ln)
-        if m and cur:
-            kernels[cur] = int(m.group(1))
+    for tu, text in _assembly(tmp_path).items():
+        for ln in text.split("\n"):
+            m = re.match(r"^(_Z\w+|k_\w+):", ln)
+            if m:
+                cur = m.group(1)
+            m = re.match(r"\s*;\s*ScratchSize: (\d+)", ln)
+            if m and cur:
+                kernels[cur] = int(m.group(1))
     assert len(kernels) > 150                                  # every instance of every kernel template
     spilling = {k: v for k, v in kernels.items() if v != 0}
     assert not spilling, spilling
@@ -36,12 +49,7 @@ def test_halo_pack_ticket_is_fenced_at_device_scope(tmp_path):
     """VERDICT r03 (weak 6): the completion ticket of k_halo_pack — the last workgroup to take it reads what the others
     produced and writes the message headers — sits between a device-scope release (L2 write-back, buffer_wbl2 sc1, behind
     the workgroup barrier) and a device-scope acquire (buffer_inv sc1) in the gfx950 code of the build's flags."""
-    import __graft_entry__ as ge
-    flags = [f for f in ge.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
-    out = tmp_path / "dsim.s"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-S", "--cuda-device-only", "-o", str(out),
-                           os.path.join(ROOT, "dronesim_amd", "csrc", "dsim_api.hip")], stderr=subprocess.DEVNULL)
-    txt = out.read_text()
+    txt = _assembly(tmp_path, only=("dsim_downwash.hip",))["dsim_downwash.hip"]
     body = txt[txt.index("_Z11k_halo_pack5HaloK:"):]
     body = body[:body.index(".end_amdhsa_kernel")].split("\n")
     ops = [ln.strip().split()[0] for ln in body if ln.startswith("\t") and ln.strip() and not ln.strip().startswith((".", ";"))]

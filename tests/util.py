@@ -26,6 +26,8 @@ from oracle import oracle as orc
 
 REL_TOL = 1e-4          # BASELINE.json north_star: per-step state within 1e-4 relative error
 K_ULP = 2.0             # fp32 roundings allowed per physics sub-step / control evaluation, in ulps of the largest term
+K_ULP_NOISE = 3.0       # ... with the rotor noise on: every rotor force and moment is then a sum of two terms and the lateral force and
+                        # moment components exist at all — half again as many roundings in the wrench (assert_step_parity(noise=True))
 
 # natural scale of each quantity: |gpu - oracle| / (|oracle| + scale) (drift metric, see above)
 RIGID_SCALE = np.array([1.0] * 3 + [1.0] * 4 + [1.0] * 3 + [1.0] * 3)      # m, -, m/s, rad/s
@@ -88,7 +90,9 @@ def step_terms(types, type_id, rigid, mem, tgt, dt_phys, dt_ctrl, substeps, cont
         alpha = alpha + gyro * w[s] ** 2 + t.ang_damping * (1.0 + w[s]) * w[s]
         tr[s, 0:3] = (v[s] + acc * dt_phys * substeps)[:, None] * dt_phys
         tr[s, 3:7] = 1.0
-        tr[s, 7:10] = (acc * dt_phys)[:, None]
+        # (a vehicle flown as a composite about another point than the reported one — the morphing hexa, params.base_offset —
+        # reports v_com + w x (R d): operands of magnitude |w| |d|)
+        tr[s, 7:10] = (acc * dt_phys + w[s] * float(np.linalg.norm(getattr(t, 'base_offset', (0.0, 0.0, 0.0)))))[:, None]
         # (every kernel turns w between the world and the body frame — the body-frame loop carries R^T w and stores R w_b — so every
         # world coordinate of w is a sum of three products of magnitude up to |w|: at 130 rad/s the rounding of R alone is worth
         # ulp32(130) in a coordinate that happens to be small)
@@ -118,7 +122,7 @@ def step_terms(types, type_id, rigid, mem, tgt, dt_phys, dt_ctrl, substeps, cont
     return tr, tm
 
 
-NOISE_MAX_SIGMA = 3.3545       # |n| <= sqrt(2 corr ln 256) sigma: the 8 + 8-bit Box-Muller grid of the rotor noise (dsim_device.h:box_muller8)
+NOISE_MAX_SIGMA = 4.8546       # |n| <= sqrt(2 corr ln 131072) sigma: the fine Box-Muller lattice of the rotor noise (dsim_device.h:box_muller16; the coarse one ends at 3.535)
 
 
 def noise_terms(types, type_id, n, dt_phys, substeps):
@@ -216,11 +220,11 @@ def plane_terms(types, type_id, rigid, dt_ctrl, dt_phys=1.0 / 240.0):
 
 
 def assert_step_parity(label, types, type_id, prev_rigid, prev_mem, tgt, got_rigid, got_mem, ref_rigid, ref_mem,
-                       dt_phys, dt_ctrl, substeps, control=True, k=None, action=None, extra_terms=None, part_rigid=None):
+                       dt_phys, dt_ctrl, substeps, control=True, k=None, action=None, extra_terms=None, part_rigid=None, noise=False):
     """One step of the HIP path against one step of the oracle from the same (fp32-representable) state,
     judged on the increments (module docstring).  got_mem / ref_mem may be None (physics only); action [n, n_act] =
     the explicit action of this step where it is not the stored cmd."""
-    k = K_ULP * max(1, substeps) if k is None else k
+    k = (K_ULP_NOISE if noise else K_ULP) * max(1, substeps) if k is None else k
     tr, tm = step_terms(types, type_id, prev_rigid, prev_mem, tgt, dt_phys, dt_ctrl, max(1, substeps), control, action)
     if extra_terms is not None:
         tr, tm = tr + extra_terms[0], tm + extra_terms[1]

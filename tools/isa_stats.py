@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static instruction mix per kernel from the gfx950 assembly of dsim_api.hip (dev helper).
+"""Static instruction mix per kernel from the gfx950 assembly of the library's translation units (dev helper).
 usage: python tools/isa_stats.py [kernel-name-substring]"""
 import collections
 import os
@@ -9,11 +9,18 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "dronesim_amd", "csrc", "dsim_api.hip")
-out = os.path.join(tempfile.gettempdir(), "dsim_isa.s")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-S", "-o", out,
-                       "--cuda-device-only", src], stderr=subprocess.DEVNULL)
-lines = open(out).read().split("\n")
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+flags = [f for f in ge.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+procs = []
+for src in ge.HIP_SRCS:            # every translation unit of the library, side by side
+    out = os.path.join(tempfile.gettempdir(), os.path.basename(src) + ".s")
+    procs.append((out, subprocess.Popen(["/opt/rocm/bin/hipcc", *flags, "-S", "-o", out, "--cuda-device-only", src], stderr=subprocess.DEVNULL)))
+lines = []
+for out, p in procs:
+    assert p.wait() == 0, out
+    lines += open(out).read().split("\n")
 want = sys.argv[1] if len(sys.argv) > 1 else ""
 cur, stats, meta = None, {}, {}
 for ln in lines:
