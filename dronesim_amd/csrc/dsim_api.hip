@@ -15,7 +15,10 @@ __global__ __launch_bounds__(256) void k_noise_draw(NoiseK a) {
     float nz[12];
     const bool fine = (a.options & DSIM_OPT_NOISE_FINE) != 0;
     if (a.n_act == 4) { if (fine) quad_normals_fine(a.seed, key, sub, nz); else noise_normals<4>(a.seed, key, sub, nz); }
-    else { if (fine) hexa_normals_fine(a.seed, key, sub, nz); else noise_normals<6>(a.seed, key, sub, nz); }
+    else {                                 // six-actuator kinds: rows 0 .. 5 the six normals of the body wrench, rows 6 .. 11 zero
+      if (fine) { hexa_z_fine(a.seed, key, sub, nz); for (int j = 6; j < 12; ++j) nz[j] = 0.0f; }
+      else noise_normals<6>(a.seed, key, sub, nz);
+    }
     // (the functions return the normals already scaled by their deviations: .01 on the force rows, .001 on the moment rows)
     for (int j = 0; j < 2 * a.n_act; ++j)
       a.out[((long long)k * 2 * a.n_act + j) * a.n_pad + i] = nz[j] * (j < a.n_act ? 100.0f : 1000.0f);
@@ -274,6 +277,29 @@ static void to_dev(const dsim_type_params& p, DevType* d) {
     d->dyn_lever[1][i] = (float)((p.dyn_mixer == DSIM_DYN_MIXER_PLUS ? my_p[i] : my_x[i]) * lx);
   }
   d->weight = (float)(p.gravity * p.mass);
+  // Six-actuator kinds: the Cholesky factor of the covariance of the body wrench that the per-rotor noise of
+  // BaseAviary.py:1429-1457 adds up to (dsim_device.h:noise_normals, hexa_wrench_z).  W = M n, column j of M = (a_j, r_j x a_j) for the
+  // force normal of rotor j (deviation 0.01), (0, spin_j a_j) for its moment normal (0.001), from the SAME fp32 constants
+  // hexa_wrench multiplies; cov = M diag(sigma^2) M^T; L L^T = cov, stored over 0.01 (the normals arrive scaled by 0.01).
+  if (p.n_act == 6) {
+    double M[6][12], cov[6][6], L[6][6];
+    for (int j = 0; j < 6; ++j)
+      for (int k = 0; k < 3; ++k) {
+        M[k][j] = 0.01 * (double)d->raxis[j][k]; M[3 + k][j] = 0.01 * (double)d->rxa[j][k];
+        M[k][6 + j] = 0.0; M[3 + k][6 + j] = 0.001 * (double)d->spax[j][k];
+      }
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c) { double acc = 0.0; for (int j = 0; j < 12; ++j) acc += M[r][j] * M[c][j]; cov[r][c] = acc; L[r][c] = 0.0; }
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c <= r; ++c) {
+        double acc = cov[r][c];
+        for (int k = 0; k < c; ++k) acc -= L[r][k] * L[c][k];
+        L[r][c] = r == c ? sqrt(acc > 0.0 ? acc : 0.0) : (L[c][c] > 0.0 ? acc / L[c][c] : 0.0);      // (a degenerate geometry: that direction gets no noise)
+      }
+    int q = 0;
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c <= r; ++c) d->nchol[q++] = (float)(L[r][c] / 0.01);
+  }
 }
 
 int fill_stepk(dsim_ctx* ctx, int64_t n, const dsim_view& state, const dsim_view* targets,

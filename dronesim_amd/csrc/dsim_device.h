@@ -46,6 +46,8 @@ struct DevType {
   float watch_below;                          // coll_below seen from the reported point (ground-plane watch)
   float dyn_lever[2][4];                      // Physics.DYN: x / y torque per unit force of rotor i (the mixer of BaseAviary.py:1794-1803 times its lever)
   float weight;                               // Physics.DYN: GRAVITY = G M (BaseAviary.py:226)
+  float nchol[22];                            // six-actuator types: Cholesky factor of the body-wrench covariance of the rotor noise, lower
+                                              // triangle row by row, over 0.01 (hexa_wrench_z); [21] pads the doubles behind it
   // (at the end: in the middle of the table they moved every offset behind them, and four instances of k_step_runs came back
   // with a 36-byte scratch reservation)
   double raxis64[DSIM_MAX_ACT][3], rxa64[DSIM_MAX_ACT][3];   // (double)raxis, (double)rxa — the fp32 values, widened (hexa_wrench_base)
@@ -242,21 +244,24 @@ __device__ __forceinline__ void quad_normals_fine(uint64_t seed, uint64_t drone,
   box_muller16<10>(c[0], out[0], out[1]); box_muller16<10>(c[1], out[2], out[3]);
   box_muller16<1>(c[2], out[4], out[5]); box_muller16<1>(c[3], out[6], out[7]);
 }
-// hexa sub-step `sub`: blocks 2 sub and 2 sub + 1; words 0-2 of the first -> the six force normals, word 3 of the first and
-// words 0, 1 of the second -> the six moment normals
-__device__ __forceinline__ void hexa_normals_fine(uint64_t seed, uint64_t drone, uint64_t sub, float* out) {
-  uint32_t c[4], d[4];
-  noise_block_fine(seed, drone, 2 * sub, c);
-  noise_block_fine(seed, drone, 2 * sub + 1, d);
-  box_muller16<10>(c[0], out[0], out[1]); box_muller16<10>(c[1], out[2], out[3]); box_muller16<10>(c[2], out[4], out[5]);
-  box_muller16<1>(c[3], out[6], out[7]); box_muller16<1>(d[0], out[8], out[9]); box_muller16<1>(d[1], out[10], out[11]);
+// hexa sub-step `sub` on the fine lattice: block `sub`; words 0, 1, 2 -> the six normals of the body wrench (hexa_wrench_z), scaled
+// by 0.01 like the force normals (the factor's rows are stored over 0.01)
+__device__ __forceinline__ void hexa_z_fine(uint64_t seed, uint64_t drone, uint64_t sub, float* z) {
+  uint32_t c[4];
+  noise_block_fine(seed, drone, sub, c);
+  box_muller16<10>(c[0], z[0], z[1]); box_muller16<10>(c[1], z[2], z[3]); box_muller16<10>(c[2], z[4], z[5]);
 }
-// normals for (drone, sub-step counter): out[0 .. NACT): force noise ~ N(0, 0.01), out[NACT .. 2 NACT): moment noise ~
-// N(0, 0.001)   (BaseAviary.py:1518-1521, 1429-1430).  Block = Threefry4x32-12(key = seed, counter = (drone, block index)).
-//   quad (8 normals per sub-step):  block index = sub >> 1; the even sub-step takes words 0, 1, the odd one words 2, 3:
-//                                   force normals from the first word of its pair, moment normals from the second
-//   hexa (12 normals per sub-step): block index = sub; force normals from words 0 and the low half of 1, moment normals
-//                                   from the high half of 1 and word 2 (word 3 unused)
+// normals for (drone, sub-step counter).  Block = Threefry4x32-12(key = seed, counter = (drone, block index)), block index =
+// sub >> 1 for EVERY vehicle kind: the even sub-step takes words 0, 1 of the block, the odd one words 2, 3.
+//   quad (8 normals per sub-step: out[0 .. 4) force noise ~ N(0, 0.01), out[4 .. 8) moment noise ~ N(0, 0.001), BaseAviary.py:1518-1521):
+//         force normals from the first word of the pair, moment normals from the second
+//   six-actuator kinds (BaseAviary.py:1429-1430 draws twelve normals, one force and one moment per rotor): the twelve enter the rigid
+//         composite only through the body wrench they add up to, W = M n with M the 6 x 12 map of hexa_wrench — a Gaussian
+//         6-vector of covariance M diag(sigma^2) M^T.  The stream draws THAT vector: six unit normals z (both halves of the first
+//         word, the low half of the second; the high half is unused) and W = L z, L the Cholesky factor of the covariance
+//         (DevType.nchol, hexa_wrench_z) — the same distribution of the wrench, hence of the flight, from half the random bits,
+//         half the Box-Muller pairs and 21 instead of 54 multiply-adds per sub-step.  Per-rotor normals remain an INPUT
+//         (dsim_step_args.noise_replay, the general kernels: hexa_wrench).
 __device__ __forceinline__ void noise_block(uint64_t seed, uint64_t drone, uint64_t blk, uint32_t c[4]) {
   c[0] = (uint32_t)drone; c[1] = (uint32_t)(drone >> 32); c[2] = (uint32_t)blk; c[3] = (uint32_t)(blk >> 32);
   threefry4x32_12(c, (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -293,23 +298,29 @@ __device__ __forceinline__ void quad_normals_from_block_tab(const NoiseTab& t, c
   box_muller8_tab<false, 0>(t, wf, out[0], out[1]); box_muller8_tab<false, 1>(t, wf, out[2], out[3]);
   box_muller8_tab<true, 0>(t, wm, out[4], out[5]); box_muller8_tab<true, 1>(t, wm, out[6], out[7]);
 }
-// the twelve normals of a hexa sub-step from the tables (the looped hexa kernels: without them the generator was 113 of the 281 us
-// five sub-steps of 4 194 304 hexas took); same words, same halves as noise_normals<6>
-__device__ __forceinline__ void hexa_normals_from_block_tab(const NoiseTab& t, const uint32_t c[4], float* out) {
-  box_muller8_tab<false, 0>(t, c[0], out[0], out[1]); box_muller8_tab<false, 1>(t, c[0], out[2], out[3]);
-  box_muller8_tab<false, 0>(t, c[1], out[4], out[5]); box_muller8_tab<true, 1>(t, c[1], out[6], out[7]);
-  box_muller8_tab<true, 0>(t, c[2], out[8], out[9]); box_muller8_tab<true, 1>(t, c[2], out[10], out[11]);
+// the six wrench normals of a hexa sub-step from its half of the block (odd: the sub-step counter is odd; wave-uniform), directly
+// and from the tables (the looped hexa kernels: without tables the generator was 113 of the 281 us five sub-steps of 4 194 304
+// hexas took); scaled by 0.01 (the force tables)
+__device__ __forceinline__ void hexa_z_from_block(const uint32_t c[4], bool odd, float* z) {
+  const uint32_t wa = odd ? c[2] : c[0], wb = odd ? c[3] : c[1];
+  box_muller8<10, 0>(wa, z[0], z[1]); box_muller8<10, 1>(wa, z[2], z[3]); box_muller8<10, 0>(wb, z[4], z[5]);
 }
+__device__ __forceinline__ void hexa_z_from_block_tab(const NoiseTab& t, const uint32_t c[4], bool odd, float* z) {
+  const uint32_t wa = odd ? c[2] : c[0], wb = odd ? c[3] : c[1];
+  box_muller8_tab<false, 0>(t, wa, z[0], z[1]); box_muller8_tab<false, 1>(t, wa, z[2], z[3]); box_muller8_tab<false, 0>(t, wb, z[4], z[5]);
+}
+// (dsim_noise_draw, the general kernels) out[2 NACT]: the normals of (drone, sub), scaled by their deviations; six-actuator kinds:
+// out[0 .. 6) = 0.01 z, out[6 .. 12) = 0
 template <int NACT>
 __device__ __forceinline__ void noise_normals(uint64_t seed, uint64_t drone, uint64_t sub, float* out) {
-  const uint64_t blk = NACT == 4 ? (sub >> 1) : sub;
   uint32_t c[4];
-  noise_block(seed, drone, blk, c);
+  noise_block(seed, drone, sub >> 1, c);
   if constexpr (NACT == 4) {
     quad_normals_from_block(c, (sub & 1ull) != 0, out);
   } else {
-    box_muller8<10, 0>(c[0], out[0], out[1]); box_muller8<10, 1>(c[0], out[2], out[3]); box_muller8<10, 0>(c[1], out[4], out[5]);
-    box_muller8<1, 1>(c[1], out[6], out[7]); box_muller8<1, 0>(c[2], out[8], out[9]); box_muller8<1, 1>(c[2], out[10], out[11]);
+    hexa_z_from_block(c, (sub & 1ull) != 0, out);
+#pragma unroll
+    for (int j = 6; j < 12; ++j) out[j] = 0.0f;
   }
 }
 
@@ -856,6 +867,23 @@ __device__ __forceinline__ void hexa_wrench_noise(DT& T, const HexaBase& b, cons
     F = F + nz[j] * v3(T.raxis[j][0], T.raxis[j][1], T.raxis[j][2]);
     tau = tau + nz[j] * v3(T.rxa[j][0], T.rxa[j][1], T.rxa[j][2]) + nz[6 + j] * v3(T.spax[j][0], T.spax[j][1], T.spax[j][2]);
   }
+}
+
+// The default noise streams of the six-actuator kinds (see noise_normals): W = L z added to the noise-free wrench, z = six normals of
+// deviation 0.01, L = DevType.nchol (rows of the lower triangle: W = (F, tau)) — 21 multiply-adds.
+template <class DT>
+__device__ __forceinline__ void hexa_wrench_z(DT& T, const V3 F0, const V3 tau0, const float z[6], V3& F, V3& tau) {
+  // (T may live in the constant address space: the factor is indexed through T, never through a plain pointer)
+#define DSIM_L(k) T.nchol[k]
+  F.x = __builtin_fmaf(DSIM_L(0), z[0], F0.x);
+  F.y = __builtin_fmaf(DSIM_L(2), z[1], __builtin_fmaf(DSIM_L(1), z[0], F0.y));
+  F.z = __builtin_fmaf(DSIM_L(5), z[2], __builtin_fmaf(DSIM_L(4), z[1], __builtin_fmaf(DSIM_L(3), z[0], F0.z)));
+  tau.x = __builtin_fmaf(DSIM_L(9), z[3], __builtin_fmaf(DSIM_L(8), z[2], __builtin_fmaf(DSIM_L(7), z[1], __builtin_fmaf(DSIM_L(6), z[0], tau0.x))));
+  tau.y = __builtin_fmaf(DSIM_L(14), z[4], __builtin_fmaf(DSIM_L(13), z[3], __builtin_fmaf(DSIM_L(12), z[2], __builtin_fmaf(DSIM_L(11), z[1],
+          __builtin_fmaf(DSIM_L(10), z[0], tau0.y)))));
+  tau.z = __builtin_fmaf(DSIM_L(20), z[5], __builtin_fmaf(DSIM_L(19), z[4], __builtin_fmaf(DSIM_L(18), z[3], __builtin_fmaf(DSIM_L(17), z[2],
+          __builtin_fmaf(DSIM_L(16), z[1], __builtin_fmaf(DSIM_L(15), z[0], tau0.z))))));
+#undef DSIM_L
 }
 
 // Drones whose WLS allocation leaves the closed-form first iteration are queued here and finished by

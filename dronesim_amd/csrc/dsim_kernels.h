@@ -284,7 +284,9 @@ __device__ __forceinline__ int waypoint_next(int wp, int n_wp) { return wp < n_w
 // tuned to their register budgets; the launchers hand a fine-lattice launch of several sub-steps to the general kernels.
 // LOOPED: the launcher picked this instance because the launch has SEVERAL sub-steps (its single-sub-step twin takes the others):
 // the loop carries the body-frame form of the step (dsim_device.h:bullet_step_body).
-template <int NOISE, int NROW = 4, bool OPTS = false, int NSUB = 0, bool PLANE = false, int FINE = -1, bool LOOPED = false, class DT>
+// TABS: whether `tab` points at the tables — 1 yes, 0 no, -1 ask the pointer (an LDS address is never known to be non-null at
+// compile time: left to the pointer, BOTH forms of the Box-Muller pairs are compiled into every looped instance)
+template <int NOISE, int NROW = 4, bool OPTS = false, int NSUB = 0, bool PLANE = false, int FINE = -1, bool LOOPED = false, int TABS = -1, class DT>
 __device__ __forceinline__ void quad_substeps(DT& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[4], unsigned long long step_index,
                                               V3 ext = V3{-0.0f, -0.0f, -0.0f} /* x + -0 = x for EVERY x: a caller without a force pays no add */,
@@ -324,7 +326,7 @@ __device__ __forceinline__ void quad_substeps(DT& T, const StepK& a, long long i
       } else {
         const uint64_t sub = step_index * (uint64_t)a.substeps + (uint64_t)k;          // (wave-uniform)
         if (k == 0 || (sub & 1ull) == 0) noise_block(a.seed, noise_key, sub >> 1, nb);  // a new block every other sub-step
-        if (tab) quad_normals_from_block_tab(*tab, nb, (sub & 1ull) != 0, nz);          // (the same bits, from LDS)
+        if (TABS < 0 ? tab != nullptr : TABS != 0) quad_normals_from_block_tab(*tab, nb, (sub & 1ull) != 0, nz);          // (the same bits, from LDS)
         else quad_normals_from_block(nb, (sub & 1ull) != 0, nz);                        // N(0,.01) | N(0,.001)
       }
       if (SPLIT) quad_wrench_noise(T, qb, nz, F, tau); else quad_wrench(T, cmd, nz, F, tau);
@@ -348,7 +350,7 @@ __device__ __forceinline__ void quad_substeps(DT& T, const StepK& a, long long i
 }
 
 // the same for the morphing hexa (BaseAviary.py:1389-1457); replay rows: f[6], m[6]
-template <bool NOISE, bool REPLAY = true, bool ONE = false, bool PLANE = false, bool LOOPED = false, class DT>
+template <bool NOISE, bool REPLAY = true, bool ONE = false, bool PLANE = false, bool LOOPED = false, int TABS = -1, class DT>
 __device__ __forceinline__ void hexa_substeps(DT& T, const StepK& a, long long i, Rigid& s,
                                               const float cmd[6], unsigned long long step_index,
                                               V3 ext = V3{-0.0f, -0.0f, -0.0f}, long long nid = -1,
@@ -375,22 +377,32 @@ __device__ __forceinline__ void hexa_substeps(DT& T, const StepK& a, long long i
   constexpr bool BODY = BODY_OK;
   RigidB sb = RigidB{};
   if (BODY) sb = body_begin(s);
+  // the noise-free wrench of the default streams (the command is constant over the sub-steps): split off once per Env.step
+  V3 F0 = V3{0.0f, 0.0f, 0.0f}, tau0 = V3{0.0f, 0.0f, 0.0f};
+  if (NOISE) {
+    if (SPLIT) { F0 = hb.F; tau0 = hb.tau; }
+    else if (!(REPLAY && a.noise_replay)) hexa_wrench(T, cmd, nullptr, F0, tau0);
+  }
+  uint32_t nb[4] = {0u, 0u, 0u, 0u};       // the Threefry block: ONE serves two consecutive sub-steps (dsim_device.h:noise_normals)
   for (int k = 0; k < n_sub; ++k) {
     if (NOISE) {
-      float nz[12];
-      if (REPLAY && a.noise_replay) {
+      if (REPLAY && a.noise_replay) {          // per-rotor normals as an input: f[6], m[6] (BaseAviary.py:1429-1430)
+        float nz[12];
 #pragma unroll
         for (int j = 0; j < 12; ++j) nz[j] = a.noise_replay[((long long)k * 12 + j) * a.n_pad + i];
-      } else if ((ONE || REPLAY || !LOOPED) && (a.options & DSIM_OPT_NOISE_FINE)) {   // (wave-uniform) the 16 + 16-bit lattice: every instance but the looped fast ones
-        hexa_normals_fine(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);
-      } else if (tab) {
-        uint32_t c[4];
-        noise_block(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, c);
-        hexa_normals_from_block_tab(*tab, c, nz);
-      } else {
-        noise_normals<6>(a.seed, noise_key, step_index * (uint64_t)a.substeps + (uint64_t)k, nz);   // N(0,.01) | N(0,.001)
+        if (SPLIT) hexa_wrench_noise(T, hb, nz, F, tau); else hexa_wrench(T, cmd, nz, F, tau);
+      } else {                                 // the default streams: the six normals of the body wrench (dsim_device.h:noise_normals)
+        float z[6];
+        const uint64_t sub = step_index * (uint64_t)a.substeps + (uint64_t)k;          // (wave-uniform)
+        if ((ONE || REPLAY || !LOOPED) && (a.options & DSIM_OPT_NOISE_FINE)) {           // (wave-uniform) the fine lattice: every instance but the looped fast ones
+          hexa_z_fine(a.seed, noise_key, sub, z);
+        } else {
+          if (k == 0 || (sub & 1ull) == 0) noise_block(a.seed, noise_key, sub >> 1, nb);  // a new block every other sub-step
+          if (TABS < 0 ? tab != nullptr : TABS != 0) hexa_z_from_block_tab(*tab, nb, (sub & 1ull) != 0, z);
+          else hexa_z_from_block(nb, (sub & 1ull) != 0, z);
+        }
+        hexa_wrench_z(T, F0, tau0, z, F, tau);
       }
-      if (SPLIT) hexa_wrench_noise(T, hb, nz, F, tau); else hexa_wrench(T, cmd, nz, F, tau);
     }
     if constexpr (BODY_OK) bullet_step_body(T, a.dt_phys, sb, F + ext, tau);      // (the loop runs: BODY holds)
     else bullet_step<PLANE>(T, a.dt_phys, s, F + ext, tau);

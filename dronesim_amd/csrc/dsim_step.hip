@@ -53,9 +53,9 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
       float act[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) act[j] = clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]);   // CtrlAviary.py:258-263
-      quad_substeps<NOISE ? 1 : 0, 4, false, SUB, false, -1, SUB == 0>(T, a, i, s, act, a.step_index, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
+      quad_substeps<NOISE ? 1 : 0, 4, false, SUB, false, -1, SUB == 0, TAB ? 1 : 0>(T, a, i, s, act, a.step_index, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
     } else {
-      quad_substeps<NOISE ? 1 : 0, 4, false, SUB, false, -1, SUB == 0>(T, a, i, s, m.cmd, a.step_index, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);    // stored cmd is already clipped
+      quad_substeps<NOISE ? 1 : 0, 4, false, SUB, false, -1, SUB == 0, TAB ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);    // stored cmd is already clipped
     }
     if (SUB == 1) ground_watch(T, s, a.fb.counters, i < a.n);     // (the single-sub-step instances: see the end of the kernel)
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256, EXT ? 3 : DSIM_STEP_WAVES) void k_step_fast(St
       if (a.wp_table) waypoint_target(a, i, wp, tg);
       // (wave-uniform: several sub-steps take the body-frame loop, as the looped plain instances do — at BASELINE's literal sizes
       // these launches are one wave per SIMD and their duration IS their instruction count; one sub-step keeps the world-frame step)
-      if (a.substeps > 1) quad_substeps<NOISE ? 1 : 0, 4, false, 0, false, -1, true>(T, a, i, s, m.cmd, a.step_index + k, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
-      else quad_substeps<NOISE ? 1 : 0>(T, a, i, s, m.cmd, a.step_index + k, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
+      if (a.substeps > 1) quad_substeps<NOISE ? 1 : 0, 4, false, 0, false, -1, true, TAB ? 1 : 0>(T, a, i, s, m.cmd, a.step_index + k, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
+      else quad_substeps<NOISE ? 1 : 0, 4, false, 0, false, -1, false, TAB ? 1 : 0>(T, a, i, s, m.cmd, a.step_index + k, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
       ground_watch(T, s, a.fb.counters, i < a.n);
       indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
       wp = waypoint_next(wp, a.n_wp);
@@ -117,9 +117,9 @@ __global__ __launch_bounds__(256, DSIM_HEXA_WAVES) void k_step_hexa(StepK a) {
     float act[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) act[j] = clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]);
-    hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, act, a.step_index, V3{-0.0f, -0.0f, -0.0f}, -1, ntab);
+    hexa_substeps<NOISE, false, S1, false, !S1, TAB ? 1 : 0>(T, a, i, s, act, a.step_index, V3{-0.0f, -0.0f, -0.0f}, -1, ntab);
   } else {
-    hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, m.cmd, a.step_index, V3{-0.0f, -0.0f, -0.0f}, -1, ntab);
+    hexa_substeps<NOISE, false, S1, false, !S1, TAB ? 1 : 0>(T, a, i, s, m.cmd, a.step_index, V3{-0.0f, -0.0f, -0.0f}, -1, ntab);
   }
   indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
   // The looped instances store through a base the compiler cannot see through, made behind the sub-steps (opaque_after): left to
@@ -184,11 +184,11 @@ __device__ __forceinline__ void run_body(const StepK& a, long long i0, long long
 #pragma unroll
   for (int j = 0; j < NA; ++j) act[j] = ACT ? clampf(a.action[(long long)j * a.n_pad + i], T.pmin[j], T.pmax[j]) : m.cmd[j];   // CtrlAviary.py:258-263
   if constexpr (HEXA) {
-    hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, act, step_index, ext, nid, tab);
+    hexa_substeps<NOISE, false, S1, false, !S1, (NOISE && !S1 && !ACT) ? 1 : 0>(T, a, i, s, act, step_index, ext, nid, tab);      // (the tables exist where the kernels make them: DSIM_NOISE_TAB)
     if constexpr (KIND == DSIM_DEV_KIND_HEXA) indi_hexa<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e, a.fb, i);
     else indi_quad<false, 6>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   } else {
-    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0, false, -1, !S1>(T, a, i, s, act, step_index, ext, nullptr, nid, tab);
+    quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0, false, -1, !S1, (NOISE && !S1 && !ACT) ? 1 : 0>(T, a, i, s, act, step_index, ext, nullptr, nid, tab);
     indi_quad<false>(T, a.dt_ctrl, s, tg, m, pos_e, yaw_e);
   }
   const unsigned so = pin_lane_offset(sl);

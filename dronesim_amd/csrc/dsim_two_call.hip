@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, DSIM_PHYS_WAVES) void k_physics_fast(StepK a) 
 #pragma unroll
   for (int j = 0; j < 4; ++j) cmd[j] = clampf(cmd[j], T.pmin[j], T.pmax[j]);           // CtrlAviary.py:258-263
   if (NOISE && a.step_index_dev) a.step_index += *a.step_index_dev;
-  if constexpr (LOOP) quad_substeps<NOISE ? 1 : 0, 4, false, 0, false, 0, true>(T, a, i, s, cmd, a.step_index, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
+  if constexpr (LOOP) quad_substeps<NOISE ? 1 : 0, 4, false, 0, false, 0, true, TAB ? 1 : 0>(T, a, i, s, cmd, a.step_index, V3{-0.0f, -0.0f, -0.0f}, nullptr, -1, ntab);
   else quad_substeps<NOISE ? 1 : 0, 4, false, 0, false, 1>(T, a, i, s, cmd, a.step_index);      // (both noise lattices)
   ground_watch(T, s, a.fb.counters, i < a.n);
   const unsigned so = pin_lane_offset(sl);
@@ -393,8 +393,8 @@ __device__ __forceinline__ void physics_run_body(const StepK& a, const RunOf& ro
     if (NOISE && a.step_index_dev) step_index += *a.step_index_dev;
     const long long nid = NOISE ? noise_id(a, i) : -1LL;
     // (S1: one sub-step per Env.step — BASELINE's metric definition — compiled straight-line, as in the fused kernels)
-    if constexpr (HEXA) hexa_substeps<NOISE, false, S1, false, !S1>(T, a, i, s, cmd, step_index, ext, nid, tab);
-    else quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0, false, -1, !S1>(T, a, i, s, cmd, step_index, ext, nullptr, nid, tab);
+    if constexpr (HEXA) hexa_substeps<NOISE, false, S1, false, !S1, (NOISE && !S1) ? 1 : 0>(T, a, i, s, cmd, step_index, ext, nid, tab);
+    else quad_substeps<NOISE ? 1 : 0, 4, false, S1 ? 1 : 0, false, -1, !S1, (NOISE && !S1) ? 1 : 0>(T, a, i, s, cmd, step_index, ext, nullptr, nid, tab);
     ground_watch(T, s, a.fb.counters, i < a.n);
     const unsigned so = pin_lane_offset(sl);
     float* const sb2 = (DSIM_LATE_STORE_BASE && !S1) ? const_cast<float*>(opaque_after(sb, s.pos.x)) : sb;   // (k_step_hexa)

@@ -259,7 +259,15 @@ typedef struct dsim_step_args {
                                            Kolmogorov distance 1.4e-3 from the normal distribution.  The lattice of launches of
                                            SEVERAL sub-steps (the examples' five: kernels bound by vector issue) and of
                                            DSIM_OPT_NOISE_COARSE.
-                               tests/test_noise_distribution.py measures both against N(0, 1) (Kolmogorov distance, moments,
+                               WHAT is drawn: a quad's eight normals per sub-step, one per rotor force and rotor moment as the
+                               reference draws them (BaseAviary.py:1518-1521).  The six-actuator kinds draw SIX: the reference's twelve
+                               per-rotor normals (:1429-1430) enter the rigid composite only through the body wrench they add up
+                               to, a Gaussian 6-vector; the stream draws that vector (W = L z, L the Cholesky factor of its
+                               covariance, computed from the type's rotor geometry by dsim_create) — the same distribution of the
+                               wrench, hence of the flight, from half the bits (tests/test_noise_distribution.py:
+                               test_hexa_wrench_noise_has_the_covariance_of_the_per_rotor_noise).  Per-rotor normals remain an
+                               input: noise_replay.
+                               tests/test_noise_distribution.py measures both lattices against N(0, 1) (Kolmogorov distance, moments,
                                tail mass, the absence of exact zeros) over 1e7 draws; dsim_noise_draw hands out the normals.   */
   uint64_t step_index;      /* env-step counter, mixed into the noise counter                    */
   const float* noise_replay;/* nullable; [phys_substeps][2*n_act][n_pad] recorded normals (tests)*/
@@ -539,9 +547,10 @@ int dsim_adjacency(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, cons
 
 /* The rotor-noise normals the step kernels draw (diagnostics / distribution studies; no counterpart in the reference, whose
  * draws come from numpy's global generator): for drones [0, n) and the physics sub-steps [0, substeps) of Env.step number
- * step_index, out [substeps][2 * n_act][n_pad] (device) receives the UNIT-variance normals — rows 0 .. n_act-1 the force noise,
- * n_act .. 2 n_act - 1 the moment noise — exactly as a launch with the same noise_seed / step_index / phys_substeps / options
- * (DSIM_OPT_NOISE_FINE or 0) scales and applies them: the layout dsim_step_args.noise_replay takes back, times the
+ * step_index, out [substeps][2 * n_act][n_pad] (device) receives the UNIT-variance normals — n_act = 4: rows 0 .. 3 the force noise,
+ * 4 .. 7 the moment noise; n_act = 6: rows 0 .. 5 the six normals z of the body wrench (dsim_step_args.noise_seed), rows 6 .. 11 zero —
+ * exactly as a launch with the same noise_seed / step_index / phys_substeps / options (DSIM_OPT_NOISE_FINE / _COARSE or neither)
+ * draws them.  (dsim_step_args.noise_replay takes PER-ROTOR values, [substeps][2 * n_act][n_pad] times the
  * deviations.  n_act = 4 | 6.  drone_id nullable (the key of drone i's stream: dsim_step_args.drone_id).                 */
 int dsim_noise_draw(dsim_ctx* ctx, void* stream, int64_t n, int64_t n_pad, int32_t n_act, uint64_t noise_seed, uint64_t step_index,
                     int32_t substeps, uint32_t options, const int32_t* drone_id, float* out);

@@ -809,9 +809,10 @@ void orc_threefry4x32(uint32_t x[4], const uint32_t key[4], int rounds) {
  * 0.001).  16 bits make a Box-Muller pair: radius from the high byte (u1 = (h + 1/2) / 256), angle from the low byte
  * (u2 = (l + 1/2) / 256 revolutions); the radius is scaled by ORC_BM8_CORR = 2 / mean(-2 ln u1 over the 256 values) so that the
  * variance is exactly 1 (|n| <= 3.535, kurtosis 2.977, no atoms: dsim_device.h:box_muller8).  One block = 8 pairs:
- *   quad: block index = sub_counter >> 1; the even sub-step takes words 0 (force) and 1 (moment), the odd one words 2 and 3;
- *   hexa: block index = sub_counter; force normals from word 0 and the low half of word 1, moment normals from the high
- *         half of word 1 and word 2.  Within a word the low 16 bits come first. */
+ *   block index = sub_counter >> 1; the even sub-step takes words 0 and 1, the odd one words 2 and 3;
+ *   quad: force normals from the first word, moment normals from the second;
+ *   six-actuator kinds: SIX normals (first word, low half of the second) — those of the body wrench, see below.
+ *   Within a word the low 16 bits come first. */
 #define ORC_BM8_CORR 1.0013550008475642
 static void orc_bm8(uint32_t w, int half, double* n0, double* n1) {
   const uint32_t v = half ? (w >> 16) : (w & 0xFFFFu);
@@ -823,23 +824,25 @@ static void orc_bm8(uint32_t w, int half, double* n0, double* n1) {
 }
 void orc_noise_normals(uint64_t seed, uint64_t drone, uint64_t sub_counter, int n_act, double* out) {
   const uint32_t key[4] = {(uint32_t)seed, (uint32_t)(seed >> 32), 0u, 0u};
-  const uint64_t blk = n_act == 4 ? (sub_counter >> 1) : sub_counter;
+  const uint64_t blk = sub_counter >> 1;
   uint32_t c[4] = {(uint32_t)drone, (uint32_t)(drone >> 32), (uint32_t)blk, (uint32_t)(blk >> 32)};
   orc_threefry4x32(c, key, 12);
+  const int odd = (int)(sub_counter & 1u);
+  const uint32_t wa = odd ? c[2] : c[0], wb = odd ? c[3] : c[1];
   if (n_act == 4) {
-    const int odd = (int)(sub_counter & 1u);
-    const uint32_t wf = odd ? c[2] : c[0], wm = odd ? c[3] : c[1];
-    orc_bm8(wf, 0, out + 0, out + 1); orc_bm8(wf, 1, out + 2, out + 3);
-    orc_bm8(wm, 0, out + 4, out + 5); orc_bm8(wm, 1, out + 6, out + 7);
+    orc_bm8(wa, 0, out + 0, out + 1); orc_bm8(wa, 1, out + 2, out + 3);
+    orc_bm8(wb, 0, out + 4, out + 5); orc_bm8(wb, 1, out + 6, out + 7);
   } else {
-    orc_bm8(c[0], 0, out + 0, out + 1); orc_bm8(c[0], 1, out + 2, out + 3); orc_bm8(c[1], 0, out + 4, out + 5);
-    orc_bm8(c[1], 1, out + 6, out + 7); orc_bm8(c[2], 0, out + 8, out + 9); orc_bm8(c[2], 1, out + 10, out + 11);
+    /* six-actuator kinds: the six unit normals z of the BODY WRENCH (dsim_device.h:noise_normals: W = L z, L the Cholesky factor
+     * of the covariance of what the twelve per-rotor normals of BaseAviary.py:1429-1430 add up to); out[6 .. 12) = 0 */
+    orc_bm8(wa, 0, out + 0, out + 1); orc_bm8(wa, 1, out + 2, out + 3); orc_bm8(wb, 0, out + 4, out + 5);
+    for (int j = 6; j < 12; ++j) out[j] = 0.0;
   }
 }
 
 /* DSIM_OPT_NOISE_FINE (dsim_device.h:box_muller16, quad_normals_fine, hexa_normals_fine): 16 + 16 bits per pair — radius from
  * the high half of a word (u1 = (h + 1/2) / 65536), direction from the low half; blocks in a domain of their own (counter word
- * 3's top bit); quad: block `sub`, words 0, 1 force, 2, 3 moment; hexa: blocks 2 sub, 2 sub + 1.  Lattice points at the centres
+ * 3's top bit), block `sub`; quad: words 0, 1 force, 2, 3 moment; six-actuator kinds: words 0, 1, 2.  Lattice points at the centres
  * of the cells (u1 = (h + 1/2) / 65536, u2 = (l + 1/2) / 65536): no draw is exactly 0. */
 #define ORC_BM16_CORR 1.0000052883115735
 static void orc_bm16(uint32_t w, double* n0, double* n1) {
@@ -855,15 +858,13 @@ static void fine_block(uint64_t seed, uint64_t drone, uint64_t blk, uint32_t c[4
   orc_threefry4x32(c, key, 12);
 }
 void orc_noise_normals_fine(uint64_t seed, uint64_t drone, uint64_t sub_counter, int n_act, double* out) {
-  uint32_t c[4], d[4];
+  uint32_t c[4];
+  fine_block(seed, drone, sub_counter, c);
   if (n_act == 4) {
-    fine_block(seed, drone, sub_counter, c);
     orc_bm16(c[0], out + 0, out + 1); orc_bm16(c[1], out + 2, out + 3); orc_bm16(c[2], out + 4, out + 5); orc_bm16(c[3], out + 6, out + 7);
-  } else {
-    fine_block(seed, drone, 2 * sub_counter, c);
-    fine_block(seed, drone, 2 * sub_counter + 1, d);
+  } else {                       /* the six normals of the body wrench (orc_noise_normals), words 0, 1, 2; out[6 .. 12) = 0 */
     orc_bm16(c[0], out + 0, out + 1); orc_bm16(c[1], out + 2, out + 3); orc_bm16(c[2], out + 4, out + 5);
-    orc_bm16(c[3], out + 6, out + 7); orc_bm16(d[0], out + 8, out + 9); orc_bm16(d[1], out + 10, out + 11);
+    for (int j = 6; j < 12; ++j) out[j] = 0.0;
   }
 }
 /* many draws at once (distribution tests): out [n_drones][n_sub][2 n_act] */

@@ -13,7 +13,7 @@ torch = pytest.importorskip("torch")
 
 from dronesim_amd import params  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
-from tests.util import assert_step_parity, noise_terms, random_fleet  # noqa: E402
+from tests.util import assert_step_parity, noise_terms, random_fleet, rotor_noise  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 DT = float(np.float32(1.0 / 240.0))
@@ -84,13 +84,16 @@ def test_noise_distribution_on_the_device(gpu, fine):
     ctx.close()
 
 
-def _fine_replay(O, seed, n, step_index, sub, n_act, ids=None):
+def _fine_replay(O, seed, n, step_index, sub, t, ids=None):
+    """[n, sub, 12] per-rotor noise values of a fine-lattice launch of type t (tests/util.py:rotor_noise)"""
+    n_act = t.n_act
     nz = np.zeros((n, sub, 12))
     b = O.noise_batch(seed, 0, n, step_index * sub, sub, n_act, fine=True)
     if ids is not None:
         b = np.stack([O.noise_batch(seed, int(i), 1, step_index * sub, sub, n_act, fine=True)[0] for i in ids])
-    nz[:, :, 0:n_act] = b[:, :, 0:n_act] * 0.01
-    nz[:, :, 6:6 + n_act] = b[:, :, n_act:2 * n_act] * 0.001
+    for i in range(n):
+        for s_ in range(sub):
+            nz[i, s_, 0:n_act], nz[i, s_, 6:6 + n_act] = rotor_noise(t, b[i, s_])
     return nz
 
 
@@ -117,7 +120,7 @@ def test_fine_lattice_through_the_fused_step(gpu, model, sub, n):
         nat.check(ctx.lib.dsim_step(ctx.handle, ctx.stream_ptr(), n, st.view(), tg.view(), ctypes.byref(a)))
         torch.cuda.synchronize()
         r1, m1 = r0.copy(), m0.copy()
-        assert O.step(r1, m1, tgt, sub, DT, dtc, noise=_fine_replay(O, seed, n, step_index, sub, t.n_act)) == 0
+        assert O.step(r1, m1, tgt, sub, DT, dtc, noise=_fine_replay(O, seed, n, step_index, sub, t)) == 0
         assert_step_parity(f"fine_noise_fused[{model},{sub}]", [t], None, r0, m0, tgt, st.rigid_aos(), st.mem_aos(), r1, m1, DT, dtc, sub,
                            extra_terms=noise_terms([t], None, n, DT, sub))
     # the coarse lattice on the same state gives another trajectory (the switch is honoured)
@@ -152,7 +155,7 @@ def test_fine_lattice_through_the_two_call_loop_and_the_adaptors(gpu, sub):
         env.step(act)
         r1 = r0.copy()
         a6 = np.zeros((n, 6)); a6[:, :4] = act.cpu().numpy()
-        O.physics(r1, m0, sub, DT, action=a6, noise=_fine_replay(O, seed, n, k, sub, 4))
+        O.physics(r1, m0, sub, DT, action=a6, noise=_fine_replay(O, seed, n, k, sub, params.builtin_type("robobee")))
         assert_step_parity(f"fine_noise_env_step[{sub}]", [t], None, r0, m0, np.zeros((1, 10)), env.state.rigid_aos(), None, r1, None, DT,
                            DT * sub, sub, control=False, action=a6[:, :4], extra_terms=noise_terms([t], None, n, DT, sub))
     env.close()
@@ -170,8 +173,8 @@ def test_fine_lattice_through_the_two_call_loop_and_the_adaptors(gpu, sub):
         for i in range(n):
             na = 4 if tid[i] == 0 else 6
             b = O.noise_batch(seed, i, 1, k * sub, sub, na, fine=True)[0]
-            nz[i, :, 0:na] = b[:, 0:na] * 0.01
-            nz[i, :, 6:6 + na] = b[:, na:2 * na] * 0.001
+            for s_ in range(sub):
+                nz[i, s_, 0:na], nz[i, s_, 6:6 + na] = rotor_noise(env.types[int(tid[i])], b[s_])
         O.physics(r1, m0, sub, DT, action=act.astype(np.float32).astype(np.float64), noise=nz, type_id=tid)
         assert_step_parity(f"fine_noise_env_step_mixed[{sub}]", env.types, tid, r0, m0, np.zeros((1, 10)), env.state.rigid_aos(), None, r1, None,
                            DT, DT * sub, sub, control=False, action=act.astype(np.float32).astype(np.float64),
@@ -189,7 +192,7 @@ def test_fine_lattice_through_the_two_call_loop_and_the_adaptors(gpu, sub):
         # the adaptor's law on the current state, then the physics with the fine stream (orc_adaptor_step_batch is noise-free:
         # the control part through it with zero sub-steps, the physics through orc_physics_batch)
         O.adaptor_step(0, r1, m1, act.astype(np.float64), 0, DT, float(np.float32(DT * sub)))
-        O.physics(r1, m1, sub, DT, noise=_fine_replay(O, seed, n, k, sub, 4))
+        O.physics(r1, m1, sub, DT, noise=_fine_replay(O, seed, n, k, sub, params.builtin_type("robobee")))
         assert_step_parity(f"fine_noise_velocity_aviary[{sub}]", [t], None, r0, m0, np.zeros((1, 10)), env.state.rigid_aos(), None, r1, None,
                            DT, DT * sub, sub, control=False, action=m1[:, 7:11], extra_terms=noise_terms([t], None, n, DT, sub))
     env.close()

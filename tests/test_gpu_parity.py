@@ -18,7 +18,7 @@ torch = pytest.importorskip("torch")
 from dronesim_amd import params  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from tests.util import (K_ULP, noise_terms, MEM_SCALE, RIGID_SCALE, assert_control_parity, assert_downwash, assert_step_parity,  # noqa: E402
-                        attitude_zoo, f32, random_fleet, rel_err, ulp32)
+                        attitude_zoo, f32, random_fleet, rel_err, rotor_noise, ulp32)
 
 pytestmark = pytest.mark.gpu
 
@@ -564,8 +564,7 @@ def test_mixed_fleet_vs_oracle(gpu, sub, layout, form):
         na = 4 if tid[i] == 0 else 6
         for s_ in range(sub):
             u = O.noise_normals(seed, i, sidx * sub + s_, na, fine=(sub == 1))
-            nz[i, s_, 0:na] = u[0:na] * 0.01
-            nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
+            nz[i, s_, 0:na], nz[i, s_, 6:6 + na] = rotor_noise(types[int(tid[i])], u)
     r0, m0 = rigid.copy(), mem.copy()
     assert O.step(rigid, mem, tgt, sub, DT, float(np.float32(sub / 240)), noise=nz, type_id=tid) == 0
     assert_step_parity(f"mixed_fleet[{sub},{layout},{form}]", types, tid, r0, m0, tgt, st.rigid_aos(), st.mem_aos(), rigid, mem, DT,
@@ -616,8 +615,7 @@ def test_type_major_runs_equal_mixed_kernel_and_oracle(gpu, sub):
                 na = 6 if slot_types[i] == 1 else 4
                 for s_ in range(sub):
                     u = O.noise_normals(seed, i, (sidx + k) * sub + s_, na, fine=(sub == 1))
-                    nz[i, s_, 0:na] = u[0:na] * 0.01
-                    nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
+                    nz[i, s_, 0:na], nz[i, s_, 6:6 + na] = rotor_noise(types[int(slot_types[i])] if int(slot_types[i]) < len(types) else types[0], u)
             r1, m1 = r0.copy(), m0.copy()
             assert O.step(r1, m1, tgt, sub, DT, dtc, noise=nz, type_id=slot_types) == 0
             assert_step_parity(f"type_major[{sub},runs={use_runs}]", types, slot_types, r0, m0, tgt, st.rigid_aos(),
@@ -1801,8 +1799,7 @@ def test_randomised_airframes_vs_oracle(gpu, n_types):
             na = 6 if is_hexa[i] else 4
             for s_ in range(sub):
                 u = O.noise_normals(seed, i, sidx * sub + s_, na, fine=(sub == 1))
-                nz[i, s_, 0:na] = u[0:na] * 0.01
-                nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
+                nz[i, s_, 0:na], nz[i, s_, 6:6 + na] = rotor_noise(types[int(tid[i])], u)
         r0, m0 = rigid.copy(), mem.copy()
         assert O.step(rigid, mem, tgt, sub, DT, float(np.float32(sub / 240)), noise=nz, type_id=tid) == 0
         assert_step_parity(f"random_airframes[{n_types},{sub}]", types, tid, r0, m0, tgt, st.rigid_aos(), st.mem_aos(),
@@ -2594,8 +2591,7 @@ def _noise_block(O, types, tid, n, seed, step_index, sub, fine=None):
         na = types[0 if tid is None else int(tid[i])].n_act
         for s_ in range(sub):
             u = O.noise_normals(seed, i, step_index * sub + s_, na, fine=(sub == 1) if fine is None else fine)
-            nz[i, s_, 0:na] = u[0:na] * 0.01
-            nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
+            nz[i, s_, 0:na], nz[i, s_, 6:6 + na] = rotor_noise(types[0 if tid is None else int(tid[i])], u)
     return nz
 
 

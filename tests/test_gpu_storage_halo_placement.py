@@ -16,7 +16,7 @@ torch = pytest.importorskip("torch")
 
 from dronesim_amd import params  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
-from tests.util import (K_ULP, MEM_SCALE, REL_TOL, RIGID_SCALE, assert_downwash, assert_step_parity, f32, random_fleet,  # noqa: E402
+from tests.util import (K_ULP, MEM_SCALE, REL_TOL, RIGID_SCALE, assert_downwash, assert_step_parity, f32, random_fleet, rotor_noise,  # noqa: E402
                         rel_err, ulp32)
 
 pytestmark = pytest.mark.gpu
@@ -40,8 +40,7 @@ def _noise(O, types, tid, n, seed, step_index, sub):
         na = types[tid[i]].n_act
         for s_ in range(sub):
             u = O.noise_normals(seed, i, step_index * sub + s_, na, fine=(sub == 1))
-            nz[i, s_, 0:na] = u[0:na] * 0.01
-            nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
+            nz[i, s_, 0:na], nz[i, s_, 6:6 + na] = rotor_noise(types[tid[i]], u)
     return nz
 
 

@@ -14,7 +14,7 @@ torch = pytest.importorskip("torch")
 from dronesim_amd import params  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from tests.test_gpu_parity import _args, _check_obs_rows, _stream  # noqa: E402
-from tests.util import (K_ULP, assert_control_parity, assert_downwash, assert_step_parity, f32, random_fleet)  # noqa: E402
+from tests.util import (K_ULP, assert_control_parity, assert_downwash, assert_step_parity, f32, random_fleet, rotor_noise)  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,8 +38,7 @@ def _noise_by_id(O, types, tid, ids, seed, step_index, sub):
         na = types[0 if tid is None else int(tid[i])].n_act
         for s_ in range(sub):
             u = O.noise_normals(seed, int(ids[i]), step_index * sub + s_, na, fine=(sub == 1))
-            nz[i, s_, 0:na] = u[0:na] * 0.01
-            nz[i, s_, 6:6 + na] = u[na:2 * na] * 0.001
+            nz[i, s_, 0:na], nz[i, s_, 6:6 + na] = rotor_noise(types[0 if tid is None else int(tid[i])], u)
     return nz
 
 

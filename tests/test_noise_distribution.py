@@ -78,20 +78,53 @@ def test_fine_lattice_65536x65536_against_the_normal_distribution():
 
 
 def test_hexa_streams_and_the_two_lattices_are_distinct_streams():
-    """Twelve normals per hexa sub-step on either lattice (one block, resp. two); the fine stream's blocks live in a counter
-    domain of their own: no draw of it repeats a draw of the default stream."""
+    """Six-actuator types draw SIX normals per sub-step on either lattice — those of the body wrench the twelve per-rotor normals of
+    BaseAviary.py:1429-1430 add up to (dsim_device.h:noise_normals); rows 6 .. 11 of what the oracle hands out are zero.  The fine
+    stream's blocks live in a counter domain of their own: no draw of it repeats a draw of the coarse stream."""
     O = orc.Oracle([params.builtin_type("hexa_6DOF")])
     a = O.noise_batch(77, 0, 2000, 0, 4, 6, fine=False)
     b = O.noise_batch(77, 0, 2000, 0, 4, 6, fine=True)
     assert a.shape == b.shape == (2000, 4, 12)
     for z in (a, b):
+        assert np.all(z[:, :, 6:] == 0.0)
+        z = z[:, :, :6]
         assert abs(z.mean()) < 0.01 and abs(z.var() - 1.0) < 0.02
-        assert np.abs(np.corrcoef(z.reshape(-1, 12).T) - np.eye(12)).max() < 0.05
-    assert abs(np.corrcoef(a.ravel(), b.ravel())[0, 1]) < 0.01
+        assert np.abs(np.corrcoef(z.reshape(-1, 6).T) - np.eye(6)).max() < 0.05
+    assert abs(np.corrcoef(a[:, :, :6].ravel(), b[:, :, :6].ravel())[0, 1]) < 0.01
     assert np.abs(a).max() < 3.54 and np.abs(b).max() > 3.54
+    # consecutive sub-steps share a block of the coarse stream (even: words 0, 1; odd: words 2, 3) and are independent draws
+    lag = np.corrcoef(a[:, 0, :6].ravel(), a[:, 1, :6].ravel())[0, 1]
+    assert abs(lag) < 0.03
     # the single-draw entry point agrees with the batch one
     np.testing.assert_array_equal(O.noise_normals(77, 5, 2, 6, fine=True), b[5, 2])
     np.testing.assert_array_equal(O.noise_normals(77, 5, 2, 6), a[5, 2])
+
+
+def test_hexa_wrench_noise_has_the_covariance_of_the_per_rotor_noise():
+    """W = L z (the device's factor, tests/util.py:hexa_noise_maps follows dsim_api.hip:to_dev) has the covariance of the wrench that twelve
+    independent per-rotor normals — N(0, 0.01) on every rotor force, N(0, 0.001) on every rotor moment, BaseAviary.py:1429-1457 — add
+    up to under the oracle's per-rotor map; and the per-rotor values the tests hand to the oracle reproduce W exactly."""
+    from tests.util import hexa_noise_maps, rotor_noise
+    for name in ("hexa_6DOF", "hexa_6DOF_simple"):
+        t = params.builtin_type(name)
+        L, P = hexa_noise_maps(t)
+        r, a, sp = np.asarray(t.rotor_pos)[:6], np.asarray(t.rotor_axis)[:6], np.asarray(t.rotor_spin)[:6]
+        M = np.zeros((6, 12))
+        M[0:3, 0:6], M[3:6, 0:6], M[3:6, 6:12] = a.T, np.cross(r, a).T, (sp[:, None] * a).T
+        sig = np.array([0.01] * 6 + [0.001] * 6)
+        cov = (M * sig) @ (M * sig).T
+        assert np.abs(L @ L.T - cov).max() < 2e-6 * np.abs(cov).max()             # (fp32 image of the geometry and of the factor)
+        assert np.allclose(np.triu(L, 1), 0.0) and np.all(np.diag(L) > 0.0)
+        z = np.random.default_rng(0).normal(size=6)
+        f, m = rotor_noise(t, np.concatenate([z, np.zeros(6)]))
+        assert np.abs(M @ np.concatenate([f, m]) - L @ z).max() < 1e-12 * np.abs(L).max()
+        # sampled: the wrench of per-rotor draws against L z
+        rng = np.random.default_rng(1)
+        n12 = rng.normal(size=(200000, 12)) * sig
+        Wa = n12 @ M.T
+        Wb = rng.normal(size=(200000, 6)) @ L.T
+        ca, cb = np.cov(Wa.T), np.cov(Wb.T)
+        assert np.abs(ca - cb).max() < 0.02 * np.sqrt(np.outer(np.diag(cov), np.diag(cov))).max()
 
 
 def test_population_moments_of_the_fine_lattice_are_exact():

@@ -330,9 +330,9 @@ def test_threefry_known_answers_and_noise_moments():
     th = 2 * np.pi * (np.arange(256) + 0.5) / 256.0
     pop = (r[:, None] * np.cos(th)[None, :]).ravel()
     assert abs(pop.var() - 1.0) < 1e-12 and abs(pop.mean()) < 1e-12 and abs((pop ** 4).mean() - 2.9766571967915207) < 1e-9 and np.abs(pop).min() > 7e-4
-    # a hexa sub-step takes its twelve normals from one block
+    # a six-actuator sub-step takes the six normals of its body wrench from its half of a block (rows 6 .. 11: zero)
     h = O.noise_normals(77, 3, 9, 6)
-    assert h.shape == (12,) and len(set(np.round(h, 12))) == 12
+    assert h.shape == (12,) and len(set(np.round(h[:6], 12))) == 6 and np.all(h[6:] == 0.0)
 
 
 # ---------------------------------------------------------------------------

@@ -125,6 +125,47 @@ def step_terms(types, type_id, rigid, mem, tgt, dt_phys, dt_ctrl, substeps, cont
 NOISE_MAX_SIGMA = 4.8546       # |n| <= sqrt(2 corr ln 131072) sigma: the fine Box-Muller lattice of the rotor noise (dsim_device.h:box_muller16; the coarse one ends at 3.535)
 
 
+_ROTOR_NOISE_MAPS = {}
+
+
+def hexa_noise_maps(t):
+    """Six-actuator types draw the noise of the BODY WRENCH (dsim_device.h:noise_normals): W = L z, z six unit normals, L the Cholesky
+    factor of M diag(sigma^2) M^T, M the 6 x 12 map from the per-rotor force / moment noise of BaseAviary.py:1429-1457 to the wrench.
+    Returns (L [6,6] as the device holds it, P [12,6]): P z = per-rotor noise values (f[6] in N, m[6] in N m) whose wrench under the
+    ORACLE's per-rotor map is L z — what the tests hand to the (unchanged) oracle.  L follows dsim_api.hip:to_dev step by step: M
+    from the fp32 images of the rotor axes and of r x a, the factor rounded to fp32 over 0.01."""
+    key = (np.asarray(t.rotor_pos, dtype=np.float64).tobytes(), np.asarray(t.rotor_axis, dtype=np.float64).tobytes(),
+           np.asarray(t.rotor_spin, dtype=np.float64).tobytes())
+    if key in _ROTOR_NOISE_MAPS:
+        return _ROTOR_NOISE_MAPS[key]
+    r = np.asarray(t.rotor_pos, dtype=np.float64)[:6]
+    a = np.asarray(t.rotor_axis, dtype=np.float64)[:6]
+    sp = np.asarray(t.rotor_spin, dtype=np.float64)[:6]
+    sig = np.array([0.01] * 6 + [0.001] * 6)
+    a32, rxa32 = f32(a), f32(np.cross(r, a))
+    M32 = np.zeros((6, 12))
+    M32[0:3, 0:6], M32[3:6, 0:6], M32[3:6, 6:12] = a32.T, rxa32.T, (sp[:, None] * a32).T
+    L = np.linalg.cholesky((M32 * sig) @ (M32 * sig).T)
+    L = f32(L / 0.01) * 0.01
+    M = np.zeros((6, 12))                                       # the oracle's map: fp64 geometry, actual forces and moments
+    M[0:3, 0:6], M[3:6, 0:6], M[3:6, 6:12] = a.T, np.cross(r, a).T, (sp[:, None] * a).T
+    S = np.diag(sig ** 2)
+    P = S @ M.T @ np.linalg.solve(M @ S @ M.T, L)
+    _ROTOR_NOISE_MAPS[key] = (L, P)
+    return L, P
+
+
+def rotor_noise(t, u):
+    """(f_noise[n_act], m_noise[n_act]), in N and N m, of one sub-step from the unit normals u = Oracle.noise_normals(...) of the
+    launch: quads draw them per rotor (BaseAviary.py:1518-1521); six-actuator types draw the six normals of the body wrench, and the
+    per-rotor values returned here add up to exactly that wrench under the oracle's map (hexa_noise_maps)."""
+    na = t.n_act
+    if na == 4:
+        return u[0:4] * 0.01, u[4:8] * 0.001
+    n = hexa_noise_maps(t)[1] @ np.asarray(u[0:6], dtype=np.float64)
+    return n[0:6], n[6:12]
+
+
 def noise_terms(types, type_id, n, dt_phys, substeps):
     """([n,13], [n,13]) what the rotor noise adds to the magnitudes of step_terms (BaseAviary.py:1518-1525: f_noise ~ N(0, .01)
     per rotor — and on the lateral axes of every rotor link —, m_noise ~ N(0, .001)): at zero command the noise IS the
@@ -138,6 +179,10 @@ def noise_terms(types, type_id, n, dt_phys, substeps):
         arm = np.linalg.norm(np.asarray(t.rotor_pos)[: t.n_act], axis=1)
         tr[s, 7:10] = t.n_act * fmax / t.mass * dt_phys
         tr[s, 10:13] = (t.n_act * mmax + 2.0 * (arm * fmax).sum()) / min(t.inertia) * dt_phys
+        if t.n_act == 6:            # the wrench W = L z, |z_j| <= NOISE_MAX_SIGMA: row sums of |L|
+            w = np.abs(hexa_noise_maps(t)[0]).sum(1) * NOISE_MAX_SIGMA
+            tr[s, 7:10] = w[0:3].max() / t.mass * dt_phys
+            tr[s, 10:13] = w[3:6].max() / min(t.inertia) * dt_phys
         tr[s, 0:3] = tr[s, 7:10] * dt_phys * substeps
         tm[s, 0:3], tm[s, 3:6] = tr[s, 7:10], tr[s, 10:13]
     return tr, tm
