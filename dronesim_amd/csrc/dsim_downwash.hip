@@ -148,7 +148,7 @@ __device__ __forceinline__ float dw_pair_acc(float4 p, float x, float y, float z
 #define DW_RPG 8
 #define DW_MAXG (DW_CAP / DW_RPG)
 #define DW_ENT_PER_THREAD 6            // ceil(768 / 128): the tile of the dense form, per thread
-// The dense form's LDS tile.  Round 5, from in-kernel stamps (tools/c5_query_timeline.py, profiles/r05_c5_timeline_*.txt): with
+// The dense form's LDS tile.  Round 5, from in-kernel stamps (round 5's stamped build of this kernel, in the git history, profiles/r05_c5_timeline_*.txt): with
 // 768 entries of 16 bytes a workgroup took 14 000 B of LDS and a CU held ELEVEN — 2 816 slots for the 2 956 workgroups of a
 // 65 536-drone shard at BASELINE config 5's density (28 x 105 cells with the box's margin, + the overflow groups): the ~30 that
 // did not fit started 9-13 us late, lived their ~19 us like the others and ended the launch at 32 us where the first generation
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
     const long long gid = (long long)blockIdx.x * TPB + t;
     for (long long z = gid; z < (long long)ncells + DW_CNT_EXTRA; z += (long long)gridDim.x * TPB) a.count_next[z] = 0;
   }
-  // (Measured and rejected, round 5: a STAGGERED start.  In-kernel stamps (tools/c5_query_timeline.py) show set-ups of 9 us
+  // (Measured and rejected, round 5: a STAGGERED start.  In-kernel stamps (round 5's stamped build of this kernel, in the git history) show set-ups of 9 us
   // and pair loops of 7.5 us in workgroups that live 19 us of a 30 us launch, all of them in the same phase at the same time;
   // holding back three quarters of the workgroups by one, two and three stages of 1-3 us, so that one stage's pair loops run
   // under the next one's set-ups, made the chain LONGER by almost exactly the last stage's delay — 47.7 / 50.9 / 54.7 us against
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
   // Which cell this workgroup serves.  The grid's outer ring is the box's margin (downwash.py:_grid_box grows the fleet's
   // bounding box by one cell on every side): empty in the normal case, and in row-major order its cells come every nx-th
   // index — dealt to the compute units in turn, some CUs get three empty cells and nine full ones, others twelve full ones,
-  // and the launch ends with the busiest CU (in-kernel stamps, tools/c5_query_timeline.py: last workgroup of a CU done after
+  // and the launch ends with the busiest CU (in-kernel stamps, round 5's stamped build of this kernel, in the git history: last workgroup of a CU done after
   // 21.6 us on the idlest, 31.5 us on the busiest).  The INTERIOR cells take the first workgroup indices, the ring the last:
   // every CU gets its share of the full cells, and what starts last is what has nothing to do.  (Any order is correct.)
   int c = (int)blockIdx.x;

@@ -1,6 +1,6 @@
 """Where the arrays a large fleet streams beside its state block lie in HBM.
 
-Measured on MI355X (tools/membench.hip --bigsweep / --pairs / --regions, tools/placement_probe.py, tools/arena_probe.py;
+Measured on MI355X (tools/membench.hip --bigsweep / --pairs / --regions, the placement / arena probes of rounds 3-5, in the git history up to 48ba88d;
 profiles/r03_placement_*.txt): the Env.step launch of a 4 194 304-drone fleet (k_physics_fast: state
 updated in place, 80-byte observation rows written beside it) takes 144-150 us or 166-169 us — and up to 204 us —
 depending on nothing but WHERE the rows' allocation lies relative to the state's.  Inside one 24 GB allocation two
@@ -20,13 +20,13 @@ moves it to a fresh allocation (same contents) and walks once more, keeping the 
 are at least `MIN_BYTES`: smaller fleets are bound by launch latency, not by HBM.
 
 The same holds for what computeControl WRITES beside the state block whose controller memory it updates (command, position
-error, yaw error: 32 bytes per drone; `tools/placement_probe_ctrl.py`: 144.7 us as allocated, 136 us with the outputs
+error, yaw error: 32 bytes per drone; round 3's control-output probe: 144.7 us as allocated, 136 us with the outputs
 elsewhere).  A controller bound to an env takes the 8 x n_pad floats the env left behind its placed rows (one allocation,
 one search); one without an env searches for itself: that launch has no neutral form, so it takes a snapshot of the state
 block, times real passes on the candidates and puts the snapshot back.
 
 The per-drone targets of the fused step are READ beside the state, and there the SAME region is the good case: 154, 158 or
-164 us per launch by where they lie (tools/state_probe.py), and the first candidate — right behind the state — may be the
+164 us per launch by where they lie (round 3's state probe), and the first candidate — right behind the state — may be the
 middle one.  CtrlAviary.step_fused places them at its first call: real passes behind a snapshot of the state block on every
 candidate of a 4 GiB walk (25 of them, no early end), the fastest kept.  One box of the round gave 155 / 158 / 164 us from
 process to process without it and 154.1-154.8 us in six of six with it (profiles/r03_repeat_headline_8_processes.txt).
@@ -41,7 +41,7 @@ min(WALK_BYTES, WALK_FRACTION of the device memory that is free when it starts) 
 a walk that could time nothing falls back to a plain zeroed array.  Every search reports what it cost: `seconds`,
 `peak_bytes`.  The rows' walk strides (1 GiB of untimed ballast behind every candidate, `STRIDE_BYTES`) and may hold 34 GiB
 for the fraction of a second it takes: back-to-back candidates within 16 GiB — round 3's walk — all timed alike (159-165 us)
-on this round's boxes, where a striding walk finds 143 us from its third candidate on (tools/region_probe.py,
+on this round's boxes, where a striding walk finds 143 us from its third candidate on (round 4's region probe,
 profiles/r04_region_probe.txt): the walk has to LEAVE the 16 GiB region the state block lies in.  (One arena — state block and written
 arrays one 16 GiB window apart inside ONE allocation, the layout the probes show to be the good one in a fresh process — was
 tried as a fallback for a walk that finds every candidate alike and never beat the walk's best inside the product: removed.)
@@ -132,7 +132,7 @@ def place_rows(device, shape, trial: Callable[[torch.Tensor], None], passes: int
     allocator; None (CPU tests): torch.empty.  `timer(trial, candidate, passes)`: the clock (tests).  `clearly`: the ratio
     that counts as clear; 0: no early end, the whole walk.  `free_bytes`: the free device memory to budget against (tests).
     `stride_bytes`: an untimed ballast block of that size is allocated (and held, inside the budget) behind every candidate:
-    the walk then covers the budget with fewer candidates.  Round 4, tools/region_probe.py: 36 back-to-back 470 MB candidates
+    the walk then covers the budget with fewer candidates.  Round 4, round 4's region probe: 36 back-to-back 470 MB candidates
     — 16 GiB, the old budget — all timed 159-165 us on boxes where a walk with 1 GiB strides finds 143 us from its third
     candidate on: back-to-back allocations may never leave the 16 GiB region the state block lies in."""
     t_start = time.perf_counter()
@@ -212,7 +212,7 @@ class PlacedFleetArrays:
 
     def _ensure_read_room(self) -> None:
         """Arrays a launch READS beside the state block it updates — the targets of the fused step, of computeControl — want
-        the state's own 16 GiB window of device memory (placement.py; tools/region_probe.py --arena, G: computeControl 136 us
+        the state's own 16 GiB window of device memory (placement.py; round 4's region probe, arena mode, G: computeControl 136 us
         with its targets there, 143 us with them one window on), and where a separate allocation falls is the memory
         manager's business.  So a large fleet's state block moves ONCE into a driver allocation with room for two target
         blocks right behind it: the same allocation is the same window (but for the 1-in-20 case that a window boundary runs
@@ -275,7 +275,7 @@ class PlacedFleetArrays:
         del plain, block
         # (When every candidate times alike there is nothing more to try.  Round 3 moved the state block to a fresh
         # allocation and walked again; round 4 tried one arena — state block and written arrays one 16 GiB window apart
-        # in a single allocation, the layout tools/region_probe.py --arena shows to be the good one in a fresh process —
+        # in a single allocation, the layout round 4's region probe, arena mode shows to be the good one in a fresh process —
         # and measured it in the product: it never beat the walk's best in any of two dozen processes (142-179 us against
         # 140-158), so it is gone.  What did help is the state block's own move into a fresh driver allocation before
         # the walk: _ensure_read_room.)

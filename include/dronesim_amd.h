@@ -159,7 +159,7 @@ enum {
                                        step's traffic exceeds what the 256 MB Infinity Cache keeps between steps   */
   DSIM_OPT_STREAM_OFF  = 1u << 5,   /* force the default cache policy                                              */
   /* (bits 6-9, 12, 13: A/B knobs of measured-and-rejected kernel forms; honoured only by a library built with
-   * -DDSIM_WITH_VARIANTS, tools/variants/dsim_variants.inc — the product ignores them)                              */
+   * tools/variants/ in the git history up to round 5 — the library ignores them)                              */
   /* -- physics (changes results) ------------------------------------------------------------------------------------ */
   DSIM_OPT_PLANE       = 1u << 10,  /* ground plane z = 0 with contact and friction, as the reference's world has
                                        (BaseAviary.py:680 loads plane.urdf, collisions on).  A PRODUCT-DEFINED contact

@@ -539,7 +539,7 @@ def test_mixed_fleet_vs_oracle(gpu, sub, layout, form):
     """Config 5 layout kept in the caller's own order: even index robobee (quad INDI), odd index hexa_6DOF (6DOF INDI +
     WLS), one type_id byte per drone; in-kernel noise on.  Both forms of the mixed-fleet kernel the product ships (LDS-DMA
     staging in natural order, partition by ballots): two waves per tile with 1 KB DMAs on the wave-tiled layout
-    (k_step_mixed4), three waves with row DMAs otherwise (k_step_mixed3).  (Rounds 1-2's other forms: tools/variants/.)"""
+    (k_step_mixed4), three waves with row DMAs otherwise (k_step_mixed3).  (Rounds 1-2's other forms: in the git history, tools/variants/ up to round 5.)"""
     nat, fleet = gpu
     n = 3000
     types = [params.builtin_type("robobee"), params.builtin_type("hexa_6DOF")]
@@ -2545,7 +2545,7 @@ def test_plane_with_waypoints_multi_step_launches_and_fused_rows(gpu, golden_dir
 @pytest.mark.parametrize("fleet_kind", ["quad", "hexa", "mixed"])
 def test_tuning_options_do_not_change_results(gpu, fleet_kind):
     """DSIM_OPT_STREAM_ON / _OFF select the streaming or the default cache policy of the same kernel: bit-identical
-    states.  The A/B knob bits of a variants build (tools/variants/) are IGNORED by the product library: same bits again."""
+    states.  The option bits of the measured-and-rejected kernel forms of rounds 1-2 are IGNORED by the library: same bits again."""
     nat, fleet = gpu
     names = {"quad": ["robobee"], "hexa": ["hexa_6DOF"], "mixed": ["robobee", "hexa_6DOF"]}[fleet_kind]
     types = [params.builtin_type(m) for m in names]

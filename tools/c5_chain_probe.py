@@ -2,7 +2,7 @@
 """What each launch of config 5's chain costs IN the chain (dev helper): the 65 536-drone shard stepped (a) as the product does
 (query, step + grid binning, WLS fallback pass), (b) with the fallback pass left out (DSIM_OPT_DEFER_FALLBACK and nobody
 launching it: timing only — the queue is empty in this hover workload, so results do not change), (c) the fallback pass alone,
-back to back.  usage: python tools/c5_chain_probe.py [steps [lib]]"""
+back to back, (d) with Env.step and computeControl as separate launches.  usage: python tools/c5_chain_probe.py [steps [lib]]"""
 import ctypes
 import os
 import sys
@@ -47,6 +47,26 @@ def main():
         nat.check(env.ctx.lib.dsim_wls_fallback(env.ctx.handle, env.ctx.stream_ptr(), env.NUM_DRONES, env.state.view(), tid, None))
     print("fallback pass alone, back to back       %.2f us" % timed(fb, k))
     print("chain again                             %.2f us" % timed(fl.step, k))
+    # (d) the chain with Env.step and computeControl as separate launches: query -> physics (force in, next grid out) -> control ->
+    # fallback.  Under rocprofv3 --kernel-trace (round 6): k_step_runs 13.24 us against k_physics_runs 11.97 + k_control_runs 5.37 —
+    # a control law riding in the next query's shadow would take 1.3 us off the chain, not the 5 us round 5 hoped for
+    tg = fl.tgt
+    cmd_out = torch.zeros((env.n_act, env.state.n_pad), device=env.ctx.device)
+    pe = torch.zeros((3, env.state.n_pad), device=env.ctx.device)
+    ye = torch.zeros(env.state.n_pad, device=env.ctx.device)
+
+    def split():
+        a = env.step_args(None)
+        a.bin_next = env._downwash.bin_next_ptr()
+        nat.check(env.ctx.lib.dsim_physics(env.ctx.handle, env.ctx.stream_ptr(), env.NUM_DRONES, env.state.view(), None, ctypes.byref(a)))
+        b = nat.StepArgs.from_buffer_copy(a)
+        b.ext_force = None
+        b.bin_next = None
+        nat.check(env.ctx.lib.dsim_control2(env.ctx.handle, env.ctx.stream_ptr(), env.NUM_DRONES, env.state.view(), tg.view(), ctypes.byref(b),
+                                            pe.data_ptr(), ye.data_ptr(), cmd_out.data_ptr()))
+        env._env_steps += 1
+    env._fused_plan_dw = None
+    print("query, physics, control, fallback apart %.2f us" % timed(split, k))
 
 
 if __name__ == "__main__":
