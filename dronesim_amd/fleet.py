@@ -78,6 +78,7 @@ class Context:
         return int(v.value) - self.query_offsets.get(int(what), 0)     # (what placement trials counted is not the fleet's history)
 
     def close(self):
+        self.read_room = None                  # (a view of a state allocation: dropped with the context, so that the block can go)
         if self._h:
             self.lib.dsim_destroy(self._h)
             self._h = ctypes.c_void_p()
@@ -306,8 +307,14 @@ class Targets(BlockedSoA):
             if room is not None and room[2] == layout and room[1] == pad_to(n, max(pad, int(layout[4:]) if layout != "soa" else pad)):
                 storage, ctx.read_room = room[0], None      # the room behind the state block (FleetState): taken once
             super().__init__(n, nat.NT, ctx.device, layout, pad, order=ctx.order, storage=storage)
-            self.behind_the_state = storage is not None and self.data.data_ptr() == storage.data_ptr()
+            self._room_ptr = storage.data_ptr() if storage is not None else None
             self._placed = False      # CtrlAviary.step_fused may re-allocate `data` once, by trial (placement.py)
+
+    @property
+    def behind_the_state(self) -> bool:
+        """Whether the targets lie in the room behind the fleet's state block (FleetState) — asked of the tensor itself, so that a
+        Targets whose data was re-allocated since (placement by trial) says no."""
+        return getattr(self, "_room_ptr", None) is not None and self.data.data_ptr() == self._room_ptr
 
     def view(self) -> nat.View:
         if not self.broadcast:
