@@ -1038,6 +1038,9 @@ def main(argv=None):
                     "config2x1024_chained_184B": (4096, 1024, 1, False, 1),
                     # homogeneous morphing-hexa fleet: 6-DOF INDI + WLS allocation, 248 B/drone-step
                     "hexa_6DOF_4194304_indi6dof_wls": (4096, 1024, 1, False, 1),
+                    # ... with the examples' five sub-steps per Env.step (examples/fly_hexa_6DOF.py): the looped k_step_hexa,
+                    # bound by vector issue at the sustained clock (round 5: 197-208 us; round 6: wrench-level noise, tables by template)
+                    "hexa_6DOF_4194304_sub5": (4096, 1024, 5, False, 1),
                     # Physics.DYN (row D1): BaseAviary._dynamics + INDI in one launch (k_dyn), the headline fleet; 232 B + the
                     # model's own rpy_rates (3 floats in, 3 out) = 256 B per drone-step
                     "physics_dyn_4194304_sub1": (4096, 1024, 1, False, 1),
@@ -1046,6 +1049,7 @@ def main(argv=None):
                     # fleet over interleaved (even index quad, odd index hexa); the env stores it type-major behind that
                     # numbering (fleet.StorageOrder) — and, for comparison, in the caller's own order (k_step_mixed4)
                     "mixed_quad_hexa_4194304": (4096, 1024, 1, False, 1),
+                    "mixed_quad_hexa_4194304_sub5": (4096, 1024, 5, False, 1),
                     "mixed_quad_hexa_4194304_caller_order_storage": (4096, 1024, 1, False, 1),
                     # the same fleet in type-major storage: one single-type launch per type
                     "mixed_quad_hexa_4194304_type_major": (4096, 1024, 1, False, 1)}.items():

@@ -279,8 +279,12 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     }
     // (measured on MI355X, 50 % quads + 50 % hexas: 65 536 drones 12.0 us against 9.5 + 9.0 us for two dependent launches;
     // 4 194 304 drones 160.1 against 165.2 us — the launch boundary between the runs costs more than the registers the
-    // second law adds (83 VGPRs, 5 waves per SIMD, against 74 and 6): one launch is the default at every size)
-    const bool one_launch = !any_quadlaw6;
+    // second law adds (83 VGPRs, 5 waves per SIMD, against 74 and 6): one launch is the default at every size for ONE sub-step.
+    // With several sub-steps the launch is bound by vector issue and the looped instances differ more: k_step_runs 102 VGPRs, 4 waves
+    // per SIMD, against 76 / 6 (quads) and 89 / 5 (hexas) for the single-law k_step_run — a fleet that fills the chip then takes
+    // one launch per run (round 6: 4 194 304 interleaved quads + hexas x 5 sub-steps))
+    const bool per_run_pays = a.substeps > 1 && a.n_pad >= (1LL << 20) && !args->action;
+    const bool one_launch = !any_quadlaw6 && !per_run_pays;
     if (n_runs <= DSIM_MAX_TYPES && (n_runs >= 2 || args->action) && one_launch) {
       // several runs (or an explicit action): one launch for all of them (k_step_runs)
       RunTab rt;

@@ -298,3 +298,15 @@ def test_singular_downwash_pair_ejects_a_drone_through_the_velocity_clamp(gpu, s
         assert on_clamp >= pairs // 2, on_clamp           # ... which a single-sub-step Env.step ends ON the clamp
     assert came_off >= pairs // 2, came_off               # ... and the following steps carry them off it again
     env.close()
+
+
+def test_chip_filling_mixed_fleet_over_several_substeps_takes_one_launch_per_run(gpu):
+    """dsim_step's rule (dsim_step.hip: per_run_pays): a type-major fleet of a million drones or more with several sub-steps per
+    Env.step is stepped by one single-law launch per run (k_step_run: 76 / 89 VGPRs) instead of the all-runs kernel (102) — the same
+    arithmetic, checked here against the oracle on every drone, runs that begin and end inside tiles."""
+    nat, fleet = gpu
+    rb, hx, hs, te = _types()
+    n = (1 << 20) + 300
+    cut = 524288 + 77
+    tid = np.concatenate([np.zeros(cut, dtype=np.uint8), np.ones(n - cut, dtype=np.uint8)])
+    _sweep_case(gpu, "per-run launches of a 2^20 mixed fleet[2]", [rb, hx], tid, n, 2, 0, 0, runs=[(0, cut, 0), (cut, n - cut, 1)])
