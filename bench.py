@@ -92,6 +92,26 @@ def parse(argv=None):
 # ----------------------------------------------------------------------------------------------------------------
 # launcher: N ranks as child processes, started before this process touches the GPU
 # ----------------------------------------------------------------------------------------------------------------
+_REAL_STDOUT = None
+
+
+def protect_stdout():
+    """stdout carries the JSON line and nothing else: whatever a library prints on file descriptor 1 from here on (RCCL's version
+    banner at communicator creation) goes to stderr."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    if _REAL_STDOUT is None:
+        print(line, flush=True)
+    else:
+        os.write(_REAL_STDOUT, (line + "\n").encode())
+
+
 def launch_ranks(a, argv):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -622,7 +642,7 @@ class Watchdog:
     def fire(self):
         if self.rank == 0:
             self.line["config5_all_ranks"] = {"error": f"did not finish within {self.seconds} s; abandoned"}
-            print(json.dumps(self.line), flush=True)
+            emit(json.dumps(self.line))
         os._exit(WATCHDOG_RC)
 
     def __enter__(self):
@@ -830,6 +850,7 @@ def main(argv=None):
     dist_info = {"world_size": 1, "backend": None}
     if a.dry_run:
         return dry_run(a, rank, world, backend)
+    protect_stdout()
     import __graft_entry__ as graft
     if a.lib:
         from dronesim_amd import _native as nat0
@@ -1098,7 +1119,7 @@ def main(argv=None):
             out["also"] = also
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.substeps)
-        print(json.dumps(out))
+        emit(json.dumps(out))
     failed = bool(rank == 0 and world > 1 and not out.get("self_check", {}).get("ok", True))
     if dist:
         dist.barrier()

@@ -260,7 +260,8 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     runs = &whole; n_runs = 1;
   }
   // (an explicit action — the first iteration of the example loop, fly_INDI.py:214 — is served by the ACT instances of the
-  // one-launch form; beyond DSIM_MAX_TYPES runs it goes to the general kernel)
+  // one-launch form; beyond DSIM_MAX_TYPES runs it goes to the general kernel.  The ACT instances exist with the default cache
+  // policy only: an explicit action is ONE step of a loop, the streaming hint would buy it nothing and cost twelve instances)
   if (runs && n_runs > 0 && runs_ok && (!args->action || (n_runs <= DSIM_MAX_TYPES && !any_quadlaw6))) {
     // type-major storage: one single-type launch per run
     const bool nt = stream_policy(args, state.n_pad, 240.0);
@@ -293,9 +294,9 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
       if (blocks > 0) {
         const dim3 g((unsigned)blocks);
 #define DSIM_RUNS_CASE2(S_, A_)                                                                              \
-  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_runs<true, true, S_, A_>), g, b, 0, st_, a, rt);     \
+  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_runs<true, !A_, S_, A_>), g, b, 0, st_, a, rt);     \
                     else hipLaunchKernelGGL((k_step_runs<true, false, S_, A_>), g, b, 0, st_, a, rt); }     \
-       else { if (nt) hipLaunchKernelGGL((k_step_runs<false, true, S_, A_>), g, b, 0, st_, a, rt);          \
+       else { if (nt) hipLaunchKernelGGL((k_step_runs<false, !A_, S_, A_>), g, b, 0, st_, a, rt);          \
               else hipLaunchKernelGGL((k_step_runs<false, false, S_, A_>), g, b, 0, st_, a, rt); } } while (0)
 #define DSIM_RUNS_CASE(S_) do { if (args->action) DSIM_RUNS_CASE2(S_, true); else DSIM_RUNS_CASE2(S_, false); } while (0)
         if (a.substeps == 1) DSIM_RUNS_CASE(true); else DSIM_RUNS_CASE(false);
@@ -342,8 +343,8 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
 #define DSIM_FAST_CASE(N_, T_)                                                                      \
   do { if (ext) { if (ch) hipLaunchKernelGGL((k_step_fast<N_, T_, true, true>), g, b, 0, st_, a);   \
                   else hipLaunchKernelGGL((k_step_fast<N_, T_, true, false>), g, b, 0, st_, a); }   \
-       else { if (args->action) { if (a.substeps == 1) hipLaunchKernelGGL((k_step_fast<N_, T_, false, false, 1, true>), g, b, 0, st_, a); \
-                                  else hipLaunchKernelGGL((k_step_fast<N_, T_, false, false, 0, true>), g, b, 0, st_, a); } \
+       else { if (args->action) { if (a.substeps == 1) hipLaunchKernelGGL((k_step_fast<N_, false, false, false, 1, true>), g, b, 0, st_, a); \
+                                  else hipLaunchKernelGGL((k_step_fast<N_, false, false, false, 0, true>), g, b, 0, st_, a); } \
               else if (ch && a.substeps == 1) hipLaunchKernelGGL((k_step_fast<N_, T_, false, true, 1>), g, b, 0, st_, a); \
               else if (ch) hipLaunchKernelGGL((k_step_fast<N_, T_, false, true>), g, b, 0, st_, a); \
               else if (a.substeps == 1) hipLaunchKernelGGL((k_step_fast<N_, T_, false, false, 1>), g, b, 0, st_, a); \
@@ -365,9 +366,9 @@ int dsim_step(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, dsim_view
     fb_open = true;
     const dim3 g((unsigned)tiles);
 #define DSIM_HEXA_CASE2(S_, A_)                                                                     \
-  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_hexa<true, true, S_, A_>), g, b, 0, st_, a);  \
+  do { if (noise) { if (nt) hipLaunchKernelGGL((k_step_hexa<true, !A_, S_, A_>), g, b, 0, st_, a);  \
                     else hipLaunchKernelGGL((k_step_hexa<true, false, S_, A_>), g, b, 0, st_, a); }  \
-       else { if (nt) hipLaunchKernelGGL((k_step_hexa<false, true, S_, A_>), g, b, 0, st_, a);       \
+       else { if (nt) hipLaunchKernelGGL((k_step_hexa<false, !A_, S_, A_>), g, b, 0, st_, a);       \
               else hipLaunchKernelGGL((k_step_hexa<false, false, S_, A_>), g, b, 0, st_, a); } } while (0)
 #define DSIM_HEXA_CASE(S_) do { if (args->action) DSIM_HEXA_CASE2(S_, true); else DSIM_HEXA_CASE2(S_, false); } while (0)
     if (a.substeps == 1) DSIM_HEXA_CASE(true); else DSIM_HEXA_CASE(false);
