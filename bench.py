@@ -943,7 +943,7 @@ def main(argv=None):
             if tj.get("workload") == a.workload and tj.get("layout", "soa") == a.layout:
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_source = (f"{tj.get('source')}: FETCH_SIZE x2 + WRITE_SIZE of this kernel from SEPARATE rocprofv3 --pmc "
-                                  "passes of this command (tools/profile_gpu.sh), not measured in this run")
+                                  "passes of this command (tools/profile_sq.sh), not measured in this run")
         out = {
             "metric": "drone-steps/sec (num_drones x env steps/s)", "value": value, "unit": "drone-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall / steps_timed * 1e3,
