@@ -443,7 +443,7 @@ __device__ __forceinline__ const P* opaque_after(const P* p, float after) {
   do {                                                                          \
     if (UNIFORM) { const DevType& T = (a).types[0]; BODY; }                     \
     else {                                                                      \
-      const int my_t_ = (a).type_id[i];                                         \
+      const int my_t_ = (a).type_id ? (int)(a).type_id[i] : 0;                  \
       for (;;) {                                                                \
         const int cur_t_ = __builtin_amdgcn_readfirstlane(my_t_);               \
         if (my_t_ == cur_t_) { const DevType& T = (a).types[cur_t_]; BODY; break; } \
@@ -495,7 +495,7 @@ __device__ __forceinline__ unsigned tile_partition(const uint8_t* type_id, long 
 }
 template <bool UNIFORM>
 __device__ __forceinline__ unsigned tile_slot(const uint8_t* type_id, long long i0, long long n_pad) {
-  if (UNIFORM) return threadIdx.x;
+  if (UNIFORM || !type_id) return threadIdx.x;       // (a homogeneous fleet on an any-fleet instance: wave-uniform, no partition)
   return tile_partition(type_id, i0, n_pad);
 }
 
@@ -599,6 +599,20 @@ static inline bool stream_policy(const dsim_step_args* a, long long n_pad, doubl
   if (a->options & DSIM_OPT_STREAM_OFF) return false;
   return (double)n_pad * bytes_per_drone > 192.0 * 1024 * 1024;
 }
+
+// ... of a general kernel that serves homogeneous and mixed fleets with ONE instance per (noise, actuator count): the type waterfall
+// runs once for a homogeneous fleet (type_id null: type 0), its partition is skipped — these kernels are not on a measured path, and
+// the UNIFORM specialisation doubled their instance count (round 6: 293 -> ... instances)
+#define DSIM_LAUNCH_GEN_ANY(KERNEL, NOISE, SIX, g, a, stream)                                           \
+  do {                                                                                                  \
+    const dim3 b_(256);                                                                                 \
+    switch (((NOISE) ? 2 : 0) | ((SIX) ? 1 : 0)) {                                                      \
+      case 0: hipLaunchKernelGGL((KERNEL<false, false, 4>), g, b_, 0, stream, a); break;                \
+      case 1: hipLaunchKernelGGL((KERNEL<false, false, 6>), g, b_, 0, stream, a); break;                \
+      case 2: hipLaunchKernelGGL((KERNEL<true, false, 4>), g, b_, 0, stream, a); break;                 \
+      default: hipLaunchKernelGGL((KERNEL<true, false, 6>), g, b_, 0, stream, a); break;                \
+    }                                                                                                   \
+  } while (0)
 
 // (noise, uniform) x actuator count dispatch of a general kernel
 #define DSIM_LAUNCH_GEN(KERNEL, NOISE, UNI, SIX, g, a, stream)                                          \

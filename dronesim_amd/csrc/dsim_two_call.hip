@@ -858,20 +858,8 @@ int dsim_physics(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, float*
   }
   if (a.io_id) return DSIM_E_UNSUPPORTED;            // the caller's numbering is served by the run kernels only
   const dim3 g(grid_for(a.n_pad));
-  if (args->options & DSIM_OPT_PLANE) DSIM_LAUNCH_GEN(k_physics_plane, noise, args->type_id == nullptr, ctx->max_act == 6, g, a, st_);
-  else {
-    // (written out: a homogeneous six-actuator fleet without noise never comes here — the run kernels above serve it unless
-    // a noise replay is given, which is NOISE = true — so k_physics_gen<false, true, 6> is not instantiated)
-    const dim3 b_(256);
-    const bool uni = args->type_id == nullptr, six = ctx->max_act == 6;
-    if (noise) {
-      if (uni) { if (six) hipLaunchKernelGGL((k_physics_gen<true, true, 6>), g, b_, 0, st_, a); else hipLaunchKernelGGL((k_physics_gen<true, true, 4>), g, b_, 0, st_, a); }
-      else { if (six) hipLaunchKernelGGL((k_physics_gen<true, false, 6>), g, b_, 0, st_, a); else hipLaunchKernelGGL((k_physics_gen<true, false, 4>), g, b_, 0, st_, a); }
-    } else {
-      if (uni) { if (six) return DSIM_E_UNSUPPORTED; hipLaunchKernelGGL((k_physics_gen<false, true, 4>), g, b_, 0, st_, a); }
-      else { if (six) hipLaunchKernelGGL((k_physics_gen<false, false, 6>), g, b_, 0, st_, a); else hipLaunchKernelGGL((k_physics_gen<false, false, 4>), g, b_, 0, st_, a); }
-    }
-  }
+  if (args->options & DSIM_OPT_PLANE) DSIM_LAUNCH_GEN_ANY(k_physics_plane, noise, ctx->max_act == 6, g, a, st_);
+  else DSIM_LAUNCH_GEN_ANY(k_physics_gen, noise, ctx->max_act == 6, g, a, st_);
   if (args->obs_out)       // general fleets: the same rows by the observation kernel, behind the step on the stream
     return observe_impl(ctx, stream, n, state, last_action_out, args->obs_out, obs_w, 0);
   return (int)hipGetLastError();
@@ -915,10 +903,8 @@ int dsim_step_adaptor(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, c
   }
   if (arows) return DSIM_E_UNSUPPORTED;               // (the general kernels take the action field-major)
 #define DSIM_ADAPT_CASE2(M_, P_)                                                                       \
-  do { if (noise) { if (uni) hipLaunchKernelGGL((k_adaptor<M_, true, true, P_>), g, b, 0, st_, a);      \
-                    else hipLaunchKernelGGL((k_adaptor<M_, true, false, P_>), g, b, 0, st_, a); }       \
-       else { if (uni) hipLaunchKernelGGL((k_adaptor<M_, false, true, P_>), g, b, 0, st_, a);           \
-              else hipLaunchKernelGGL((k_adaptor<M_, false, false, P_>), g, b, 0, st_, a); } } while (0)
+  do { if (noise) hipLaunchKernelGGL((k_adaptor<M_, true, false, P_>), g, b, 0, st_, a);                \
+       else hipLaunchKernelGGL((k_adaptor<M_, false, false, P_>), g, b, 0, st_, a); } while (0)       /* (one instance for homogeneous and mixed fleets: DSIM_LAUNCH_GEN_ANY) */
 #define DSIM_ADAPT_CASE(M_) do { if (args->options & DSIM_OPT_PLANE) DSIM_ADAPT_CASE2(M_, true); else DSIM_ADAPT_CASE2(M_, false); } while (0)
   if (mode == DSIM_ADAPT_VELOCITY) DSIM_ADAPT_CASE(DSIM_ADAPT_VELOCITY); else DSIM_ADAPT_CASE(DSIM_ADAPT_RPYT);
 #undef DSIM_ADAPT_CASE
