@@ -443,6 +443,12 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
           // sixteen entries per trip whatever the lane: what lies between lim and the next multiple of 16 is either an
           // entry of a lower band (not above ANY receiver of this group: dz <= 0, no term) or one of the sentinels behind
           // the last band — so the trip count is the wave's, and the loop control scalar
+          // (Measured and rejected, round 6: the next trip's six LDS reads issued in front of this trip's arithmetic — software
+          // pipelining of the reads.  45.4 -> 47.6 us for the chain, same box, twice: the other four or five waves of the SIMD already
+          // hide a trip's LDS latency, and the loop is bound by issue — the rotation of the prefetched values and the clamp of the
+          // look-ahead index are instructions it cannot afford.  Phase by phase (builds that return behind each barrier, rocprofv3
+          // counters): 0.30 M vector instructions to the first barrier, 1.95 M for the fill's address walk and the ranking, 0.92 M for
+          // reach test and bands, 1.03 M for placing, 7.8 M for the pair loops of the 21.5 M evaluated pairs — 23 per pair.)
           for (int base = 0; base < lim; base += 2 * DW_LPB) {
             const int e0 = base + sub8;                     // (x, y, z of two candidates: three two-address LDS reads)
             const float4 p0 = make_float4(tpx[e0], tpy[e0], tpz[e0], 0.0f);
