@@ -310,3 +310,55 @@ def test_chip_filling_mixed_fleet_over_several_substeps_takes_one_launch_per_run
     cut = 524288 + 77
     tid = np.concatenate([np.zeros(cut, dtype=np.uint8), np.ones(n - cut, dtype=np.uint8)])
     _sweep_case(gpu, "per-run launches of a 2^20 mixed fleet[2]", [rb, hx], tid, n, 2, 0, 0, runs=[(0, cut, 0), (cut, n - cut, 1)])
+
+
+@pytest.mark.parametrize("mode", ["velocity", "rpyt"])
+def test_integrator_envelope_vs_oracle_action_adaptors(gpu, mode):
+    """dsim_step_adaptor (VelocityAviary.py:221-264, RPYTAviary.py:181-193: the law on the CURRENT state, then the physics): the one-launch
+    kernel of whole-tile fleets (k_adaptor_fast) and the general one (k_adaptor, a ragged fleet) through the corners of the envelope — the
+    control part and the physics part each against the oracle, one and five sub-steps, noise off and on."""
+    from tests.util import assert_control_parity
+    nat, fleet = gpu
+    t = params.builtin_type("robobee")
+    O = orc.Oracle([t])
+    m_id = nat.ADAPT_VELOCITY if mode == "velocity" else nat.ADAPT_RPYT
+    failures = []
+    for regime in ("omega_clamp", "vel_clamp", "pi4_100Hz", "tumbling", "wreck"):
+        env, hz = REGIMES[regime]
+        DT = float(np.float32(1.0 / hz))
+        for n, layout, pad in ((512, "tile64", 256), (300, "soa", 64)):
+            for sub in (1, 5):
+                for seed in (0, 3):
+                    rng = np.random.default_rng(31 + sub + seed)
+                    dtc = float(np.float32(sub * DT))
+                    rigid, mem, _ = random_fleet(rng, n, n_act=4, envelope=env)
+                    ctx = fleet.Context([t])
+                    st = fleet.FleetState(ctx, n, layout, pad)
+                    st.load_aos(rigid, mem)
+                    if mode == "velocity":
+                        act = np.concatenate([rng.uniform(-1, 1, (n, 3)), rng.uniform(0, 0.3, (n, 1))], 1)
+                    else:
+                        act = np.concatenate([rng.uniform(-0.5, 0.5, (n, 3)), rng.uniform(0.3, 0.6, (n, 1))], 1)
+                    act = f32(act)
+                    adev = torch.zeros((4, st.n_pad), device=ctx.device)
+                    adev[:, :n] = torch.from_numpy(np.ascontiguousarray(act.T)).float()
+                    echo = torch.zeros((4, st.n_pad), device=ctx.device)
+                    a = _args(nat, sub, DT, dtc, seed=seed, step_index=4)
+                    nat.check(ctx.lib.dsim_step_adaptor(ctx.handle, _stream(ctx), n, st.view(), adev.data_ptr(), m_id, echo.data_ptr(), ctypes.byref(a)))
+                    torch.cuda.synchronize()
+                    got_r, got_m = st.rigid_aos(), st.mem_aos()
+                    label = f"envelope[k_adaptor {mode} {layout} sub{sub}|{regime}|{seed}]"
+                    rc0, m_ref = rigid.copy(), mem.copy()
+                    assert O.adaptor_step(0 if mode == "velocity" else 1, rc0, m_ref, act, 0, DT, dtc) == 0
+                    tgt = np.concatenate([rigid[:, 0:3], np.zeros((n, 7))], 1)
+                    if mode == "velocity":
+                        nrm = np.linalg.norm(act[:, 0:3], axis=1, keepdims=True)
+                        tgt[:, 3:6] = t.max_speed_kmh / 3.6 * np.abs(act[:, 3:4]) * np.divide(act[:, 0:3], nrm, out=np.zeros((n, 3)), where=nrm > 0)
+                    _collect(failures, assert_control_parity, label + " control", [t], None, rigid, mem, tgt, got_m, m_ref, dtc)
+                    r_ref = rigid.copy()
+                    a6 = np.zeros((n, 6)); a6[:, :4] = got_m[:, 7:11]
+                    O.physics(r_ref, got_m.copy(), sub, DT, action=a6, noise=_noise_block(O, [t], None, n, seed, 4, sub) if seed else None)
+                    _collect(failures, assert_step_parity, label + " physics", [t], None, rigid, got_m, tgt, got_r, None, r_ref, None, DT, dtc, sub,
+                             control=False, action=got_m[:, 7:11], extra_terms=noise_terms([t], None, n, DT, sub) if seed else None, noise=bool(seed))
+                    ctx.close()
+    assert not failures, failures
