@@ -20,12 +20,14 @@ EXPORTS = (
     "dsim_counter_add", "dsim_reserve", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash",
     "dsim_downwash_workspace", "dsim_downwash_prebin_ok", "dsim_downwash_reset", "dsim_adjacency", "dsim_wls_fallback", "dsim_fleet_bounds",
     "dsim_halo_pack", "dsim_downwash_workspace_halo", "dsim_dev_alloc", "dsim_dev_free", "dsim_noise_draw",
+    "dsim_downwash_keep_workspace", "dsim_downwash_keep_ok",
 )
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_PEERS = 8
 HALO_HDR = 8           # header floats of a halo message (DSIM_HALO_HDR)
 DW_ALL, DW_LOCAL, DW_HALO_BIN, DW_HALO_QUERY = 0, 1, 2, 3
+DW_KEEP_OFF, DW_KEEP_BUILD, DW_KEEP_REUSE = 0, 1, 2      # dsim_downwash_args.keep
 NF_QUAD, NF_HEXA, NT = 24, 26, 10
 OPT_DRAG, OPT_GROUND, OPT_BCAST_TGT, OPT_CHAINED = 1, 2, 4, 8
 OPT_STREAM_ON, OPT_STREAM_OFF = 16, 32      # tuning knobs (results do not depend on them)
@@ -44,6 +46,7 @@ OPT_NOISE_FINE = 1 << 18
 OPT_NOISE_COARSE = 1 << 19
 ADAPT_VELOCITY, ADAPT_RPYT = 0, 1
 QUERY_WLS_FALLBACKS, QUERY_WLS_FAILURES, QUERY_GROUND_CONTACTS, QUERY_HALO_OVERFLOW = 0, 1, 2, 3
+QUERY_DW_REUSES, QUERY_DW_MOVERS = 4, 5
 
 
 class View(ctypes.Structure):
@@ -108,6 +111,10 @@ class DownwashArgs(ctypes.Structure):
         ("phase", ctypes.c_int32),
         ("halo", ctypes.c_void_p),
         ("pairs_evaluated", ctypes.c_void_p),
+        ("keep", ctypes.c_int32),
+        ("keep_skin", ctypes.c_float),
+        ("keep_ws", ctypes.c_void_p),
+        ("keep_ws_len", ctypes.c_int64),
     ]
 
 
@@ -180,6 +187,9 @@ def load(path: str = None) -> ctypes.CDLL:
     lib.dsim_noise_draw.argtypes = [vp, vp, i64, i64, i32, ctypes.c_uint64, ctypes.c_uint64, i32, ctypes.c_uint32, vp, vp]
     lib.dsim_downwash_workspace_halo.restype = ctypes.c_int64
     lib.dsim_downwash_workspace_halo.argtypes = [i64, i64, i32, i32]
+    lib.dsim_downwash_keep_workspace.restype = ctypes.c_int64
+    lib.dsim_downwash_keep_workspace.argtypes = [i64, i32, i32]
+    lib.dsim_downwash_keep_ok.argtypes = [i64, i32, i32, ctypes.c_float, ctypes.c_float]
     if lib.dsim_abi_version() != ABI_VERSION:
         raise ImportError(f"libdronesim_amd.so ABI {lib.dsim_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

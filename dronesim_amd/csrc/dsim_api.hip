@@ -496,7 +496,8 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
   c->d_fb = nullptr; c->fb_cap = 0; c->dw_ws = nullptr; c->dw_cells = 0; c->dw_parity = 0; c->dw_mode = 0;
   c->n_cu = 256; c->dw_prebin = false; c->dw_prebin_valid = false; c->dw_prebin_n = 0; c->dw_prebin_off = 0;
   c->dw_prebin_geo[0] = c->dw_prebin_geo[1] = c->dw_prebin_geo[2] = 0.0f;
-  c->dw_prebin_nx = c->dw_prebin_ny = 0; c->dw_local_m = 0; c->dwh_parity = 0; c->dwh_ws = nullptr; c->dwh_cells = 0;
+  c->dw_prebin_nx = c->dw_prebin_ny = 0; c->dw_local_m = 0; c->dw_prebin_kind = 0; c->dw_reuses = 0; c->dw_keep_ws = nullptr; c->dw_keep_cells = c->dw_keep_n = 0;
+  c->dw_keep_geo[0] = c->dw_keep_geo[1] = c->dw_keep_geo[2] = c->dw_keep_geo[3] = 0.0f; c->dw_keep_nx = c->dw_keep_ny = 0; c->dwh_parity = 0; c->dwh_ws = nullptr; c->dwh_cells = 0;
   c->d_bounds = nullptr;
   c->d_block_map = nullptr; c->h_block_map = nullptr; c->block_map_cap = 0; c->block_map_blocks = 0; c->block_map_runs = 0;
   { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->n_cu = v; }
@@ -551,7 +552,7 @@ int dsim_dev_free(dsim_ctx* ctx, void* ptr) {
 }
 
 int dsim_query(dsim_ctx* ctx, void* stream, int32_t what, int64_t* value_out) {
-  if (!ctx || !value_out || what < 0 || what > 3) return DSIM_E_ARG;
+  if (!ctx || !value_out || what < 0 || what > DSIM_Q_DW_MOVERS) return DSIM_E_ARG;
   unsigned long long h[8 + DSIM_GROUND_SHARDS];
   hipError_t e = hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream);
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
@@ -562,6 +563,10 @@ int dsim_query(dsim_ctx* ctx, void* stream, int32_t what, int64_t* value_out) {
     *value_out = (int64_t)sum;
   } else if (what == DSIM_Q_HALO_OVERFLOW) {
     *value_out = (int64_t)h[4];
+  } else if (what == DSIM_Q_DW_REUSES) {
+    *value_out = (int64_t)ctx->dw_reuses;
+  } else if (what == DSIM_Q_DW_MOVERS) {
+    *value_out = (int64_t)h[5];
   } else {
     *value_out = (int64_t)h[what];
   }

@@ -25,6 +25,7 @@ struct DwK {
   int max_k;
   int n_types;       // length of types[]
   unsigned long long* pairs;   // diagnostics: += pairs evaluated (dsim_downwash_args.pairs_evaluated), or null
+  int keep_mode;               // host: DSIM_DW_KEEP_* as grid_build resolved it for this call
 };
 // position component c of world entry j: from the gathered array, or (single-rank fleets, pos_all = null)
 // straight from the state block
@@ -166,8 +167,29 @@ __device__ __forceinline__ void dw_write(const DwK& a, long long i, float fz, in
   if (accumulate) { a.force_out[2 * a.n_pad + i] += fz; return; }
   a.force_out[i] = 0.0f; a.force_out[a.n_pad + i] = 0.0f; a.force_out[2 * a.n_pad + i] = fz;
 }
-template <int TPB, bool BAND>
-__global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, int rings, int tile_cap, int accumulate) {
+// KEEP (dsim_downwash_args.keep = DSIM_DW_KEEP_BUILD; dsim_kernels.h "kept candidate lists"): the banded path also WRITES what it worked
+// out, for the REUSE queries that follow (k_dw_query_kept).  Its reach test and its band test are widened by twice the skin (a
+// receiver and a candidate may each move by the skin before they leave the lists), candidates below every receiver are kept as
+// band 0 behind band 1 instead of being dropped, cells without receivers make their list too (somebody may arrive), and seven
+// entries per thread wait in registers instead of six (the host makes the cells skin larger, so that two rings still cover the
+// widened reach).  A neighbourhood too full for the banded tile goes down the plain path and leaves an UNBANDED list (flags 0).
+#define DW_LBAND_MAX (DW_TILE_DENSE - DW_MOV_TILE - 2 * DW_LPB)      // candidates of a banded list (the REUSE tile's room)
+__device__ __forceinline__ int dw_block_cell(const BinK& b, int ncells, int c) {
+  if (c < ncells && b.nx > 2 && b.ny > 2) {
+    const int inx = b.nx - 2, n_in = inx * (b.ny - 2);
+    if (c < n_in) c = (c / inx + 1) * b.nx + (c % inx + 1);
+    else {
+      int r = c - n_in;                              // the ring: bottom row, top row, left column, right column
+      if (r < b.nx) c = r;
+      else if ((r -= b.nx) < b.nx) c = (b.ny - 1) * b.nx + r;
+      else if ((r -= b.nx) < b.ny - 2) c = (r + 1) * b.nx;
+      else c = (r - (b.ny - 2) + 1) * b.nx + b.nx - 1;
+    }
+  }
+  return c;
+}
+template <int TPB, bool BAND, bool KEEP = false>
+__global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, int rings, int tile_cap, int accumulate, KeepK kp) {
   extern __shared__ float4 tile[];                                                     // tile_cap entries
   __shared__ int nb_cell[DW_NBR], nb_cnt[DW_NBR];
   __shared__ float coef[DSIM_MAX_TYPES][4];                                            // (K, DW2, DW3) of every type
@@ -177,6 +199,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
                                                                                        // tile + this decide how many cells a CU holds: DW_TILE_DENSE)
   __shared__ float zlo[BAND ? DW_MAXG : 1];                                            // lowest receiver of every group
   __shared__ int wcnt[BAND ? TPB / 64 : 1][BAND ? DW_MAXG + 1 : 1];                    // entries per band, per wave
+  __shared__ int xcnt[KEEP ? TPB / 64 : 1], xfill;                                     // KEEP: entries beyond the list's table
   constexpr int RPB = TPB / DW_LPB;                                                    // receivers per pass
   const int ncells = b.nx * b.ny;
   const unsigned t = threadIdx.x;
@@ -195,18 +218,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
   // and the launch ends with the busiest CU (in-kernel stamps, round 5's stamped build of this kernel, in the git history: last workgroup of a CU done after
   // 21.6 us on the idlest, 31.5 us on the busiest).  The INTERIOR cells take the first workgroup indices, the ring the last:
   // every CU gets its share of the full cells, and what starts last is what has nothing to do.  (Any order is correct.)
-  int c = (int)blockIdx.x;
-  if (c < ncells && b.nx > 2 && b.ny > 2) {
-    const int inx = b.nx - 2, n_in = inx * (b.ny - 2);
-    if (c < n_in) c = (c / inx + 1) * b.nx + (c % inx + 1);
-    else {
-      int r = c - n_in;                              // the ring: bottom row, top row, left column, right column
-      if (r < b.nx) c = r;
-      else if ((r -= b.nx) < b.nx) c = (b.ny - 1) * b.nx + r;
-      else if ((r -= b.nx) < b.ny - 2) c = (r + 1) * b.nx;
-      else c = (r - (b.ny - 2) + 1) * b.nx + b.nx - 1;
-    }
-  }
+  const int c = dw_block_cell(b, ncells, (int)blockIdx.x);
   if (accumulate && (int)blockIdx.x < ncells) {
     // halo pass: the cells that hold halo entries span [lo, hi] in each direction (kept by k_dw_bin_halo); a cell further
     // than the neighbourhood's reach from that range has nothing to add — most of a slab's cells: two scalar loads and out
@@ -243,6 +255,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
 #pragma unroll
       for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
       if (sub == 0) dw_write(a, i, K * fz, accumulate);
+      if (KEEP && sub == 0) kp.pbuild[i] = make_float4(__builtin_nanf(""), 0.0f, 0.0f, __int_as_float(-1));   // in no list, no bucket slot: a mover from the start
     }
     return;
   }
@@ -276,9 +289,11 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
   n_ovf = cnd.count[ncells];                                                           // (scalar load, same round trip)
   __syncthreads();
   const int cnt_c = min(rcount, DW_CAP);
-  if (cnt_c == 0) return;                                                              // nobody to serve here (uniform)
+  if (cnt_c == 0 && !KEEP) return;                                                     // nobody to serve here (uniform)
   int total = 0;
   for (int k = 0; k < n_nb; ++k) total += nb_cnt[k];
+  int* const L = KEEP ? kp.lists + (long long)c * DW_LSTRIDE : nullptr;
+  constexpr int EPT = KEEP ? DW_ENT_PER_THREAD + 1 : DW_ENT_PER_THREAD;
   if (accumulate && total == 0 && n_ovf == 0) return;                                  // second pass: nothing of the halo near this cell
   // the tile holds the whole neighbourhood in the normal case: one fill, every receiver pass reads it
   const bool whole = total <= tile_cap;
@@ -291,22 +306,25 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
     float* const tpx = reinterpret_cast<float*>(tile);
     float* const tpy = tpx + band_cap;
     float* const tpz = tpy + band_cap;
-    if (total <= band_cap && G >= 2 && total + 2 * DW_LPB <= min(DW_ENT_PER_THREAD * TPB, band_cap)) {   // (room for the sentinels behind the last band)
+    // (KEEP: what has to fit the tile is what passes the reach test, known after the counting below)
+    if (KEEP ? total <= EPT * TPB
+             : (total <= band_cap && G >= 2 && total + 2 * DW_LPB <= min(EPT * TPB, band_cap))) {   // (room for the sentinels behind the last band)
       const unsigned lane = t & 63u;
       const int w = __builtin_amdgcn_readfirstlane((int)(t >> 6));
       int my_ty = -1, rank = 0;
       // the fill's loads are issued first: their round trip runs beside the ordering of the receivers below (which needs
       // nothing of them; with the shuffle network — 74 VGPRs — holding six entries across it did not pay, at 58 it does)
-      float4 ent[DW_ENT_PER_THREAD];
+      float4 ent[EPT];
       {
         int k = 0, acc = 0;                                                            // (the thread's entries ascend: the walk
 #pragma unroll                                                                         //  over the neighbour counts resumes)
-        for (int q = 0; q < DW_ENT_PER_THREAD; ++q) {
+        for (int q = 0; q < EPT; ++q) {
           const int e = (int)t + q * TPB;
           ent[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
           if (e < total) {
             while (e >= acc + nb_cnt[k]) { acc += nb_cnt[k]; ++k; }
             ent[q] = cnd.buckets[(long long)nb_cell[k] * DW_CAP + (e - acc)];
+            if constexpr (KEEP) ent[q].w = __int_as_float(k * DW_CAP + (e - acc));       // (neighbour, slot): where the list keeps its tile position
           }
         }
       }
@@ -334,6 +352,10 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
           if ((rank & (DW_RPG - 1)) == 0) zlo[rank / DW_RPG] = key;
           const long long i = (long long)__float_as_int(mine.w) - a.local_offset;
           if (i >= 0 && i < a.n) my_ty = a.type_id ? (int)a.type_id[i] : 0;             // (lands during the fill)
+          if constexpr (KEEP) {       // (slot -> rank; the drone's bucket slot is where REUSE steps refresh its position)
+            L[DW_LRECV + lane] = rank;
+            if (i >= 0 && i < a.n) kp.pbuild[i] = make_float4(mine.x, mine.y, mine.z, __int_as_float(c * DW_CAP + (int)lane));
+          }
         } else rank = (int)lane;                                                        // (slots behind the receivers: nobody's)
       }
       __syncthreads();
@@ -342,7 +364,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
       // fetched at fixed addresses before the counts are known, 1 000 loads per cell instead of ~625, what lies beyond a
       // count dropped afterwards: 47.6 against 46.0 us for the chain.  The extra traffic and the eight entries per thread
       // held across the sort — 80 VGPRs only under a launch bound — cost more than the round trip they hide.)
-      unsigned bands = 0;                                                              // 4 bits per entry
+      unsigned bands = 0;                                                              // 4 bits per entry (15: out of reach)
       // Counting and placing without one LDS atomic: a band's members among a wave's 64 entries are a ballot, their number
       // a population count, a member's place its rank in the mask.  (Per-lane LDS atomics on the 4-8 band counters — same
       // address for most of a wave, 1 536 of them per cell, eleven cells per CU on one LDS pipe — were a third of the
@@ -350,6 +372,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
       int wave_cnt[DW_MAXG + 1];                                                       // wave-uniform
 #pragma unroll
       for (int k = 0; k <= DW_MAXG; ++k) wave_cnt[k] = 0;
+      int n_xtra = 0;
       // A candidate further than the cut-off from every point of THIS cell is useless to all of its receivers: the
       // 5 x 5 cells around a 5 m cell cover 625 m^2, the cell grown by 10 m 539 m^2 (the corner cells lose two thirds of
       // their area) — 14 % fewer pair evaluations for one distance test per candidate.  (Border cells also hold the
@@ -358,66 +381,105 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
       const float cs = DSIM_RCP(b.inv_cell);
       const float bx0 = cx == 0 ? -__builtin_inff() : b.xmin + (float)cx * cs, bx1 = cx == b.nx - 1 ? __builtin_inff() : b.xmin + (float)(cx + 1) * cs;
       const float by0 = cy == 0 ? -__builtin_inff() : b.ymin + (float)cy * cs, by1 = cy == b.ny - 1 ? __builtin_inff() : b.ymin + (float)(cy + 1) * cs;
-      constexpr float REACH2 = (DW_CUTOFF + 1e-3f) * (DW_CUTOFF + 1e-3f);
+      const float skin2x = KEEP ? 2.0f * kp.skin : 0.0f;
+      const float REACH2 = (DW_CUTOFF + skin2x + 1e-3f) * (DW_CUTOFF + skin2x + 1e-3f);
 #pragma unroll
-      for (int q = 0; q < DW_ENT_PER_THREAD; ++q) {
+      for (int q = 0; q < EPT; ++q) {
         const int e = (int)t + q * TPB;
-        int band = 0;
+        int band = KEEP ? 15 : 0;
         if (e < total) {
           const float ox = fmaxf(fmaxf(bx0 - ent[q].x, ent[q].x - bx1), 0.0f), oy = fmaxf(fmaxf(by0 - ent[q].y, ent[q].y - by1), 0.0f);
           if (ox * ox + oy * oy < REACH2) {
-            for (int g = 0; g < G; ++g) band += zlo[g] < ent[q].z ? 1 : 0;
+            band = 0;
+            for (int g = 0; g < G; ++g) band += zlo[g] - skin2x < ent[q].z ? 1 : 0;
           }
         }
         bands |= (unsigned)band << (4 * q);
 #pragma unroll
-        for (int k = 1; k <= DW_MAXG; ++k)
+        for (int k = KEEP ? 0 : 1; k <= DW_MAXG; ++k)
           if (k <= G) wave_cnt[k] += (int)__popcll(__ballot(band == k));
+        // (entries in reach beyond the slots the list's table covers: kept as (bucket slot, tile position) pairs behind it)
+        if constexpr (KEEP) n_xtra += (int)__popcll(__ballot(band != 15 && (__float_as_int(ent[q].w) & (DW_CAP - 1)) >= DW_LSLOTS));
       }
       if (w == 0) rty[rank] = my_ty;
+      if (KEEP && w == 0 && (int)lane < cnt_c) L[DW_LRTY + lane] = my_ty;
       if (lane == 0) {
 #pragma unroll
-        for (int k = 1; k <= DW_MAXG; ++k) wcnt[w][k] = wave_cnt[k];
+        for (int k = KEEP ? 0 : 1; k <= DW_MAXG; ++k) wcnt[w][k] = wave_cnt[k];
+        if constexpr (KEEP) { xcnt[w] = n_xtra; if (w == 0) xfill = 0; }
       }
       __syncthreads();
       constexpr int NWV = TPB / 64;
+      constexpr int K0 = KEEP ? 0 : 1;                                                  // the lowest band that is placed
       int bstart[DW_MAXG + 1];                                                         // where a band begins (bands above it first)
 #pragma unroll
-      for (int k = DW_MAXG; k >= 1; --k) {
+      for (int k = DW_MAXG; k >= K0; --k) {
         int tot = 0;
         if (k <= G)
           for (int v = 0; v < NWV; ++v) tot += wcnt[v][k];
         wave_cnt[k] = tot;                                                             // from here on: the band's total
       }
+      int kept = 0;
+#pragma unroll
+      for (int k = DW_MAXG; k >= K0; --k) kept += wave_cnt[k];
+      if constexpr (KEEP) { n_xtra = 0; for (int v = 0; v < NWV; ++v) n_xtra += xcnt[v]; }
+      // (KEEP: a neighbourhood whose candidates in reach do not fit the REUSE tile, or the list's table, goes down the plain
+      // path — uniform, and the tile is still untouched)
+      if (!KEEP || (kept <= DW_LBAND_MAX && n_xtra <= DW_LXTRA)) {
       // bstart[k] = number of entries in bands above k; this wave's first slot in band k lies behind the lower waves' entries
       {
         int acc = 0;
 #pragma unroll
-        for (int k = DW_MAXG; k >= 1; --k) { bstart[k] = acc; acc += wave_cnt[k]; }
+        for (int k = DW_MAXG; k >= K0; --k) { bstart[k] = acc; acc += wave_cnt[k]; }
         if (t < 2 * DW_LPB) {                // sentinels behind the last band (below everything: no term), see the pair loop
           tpx[acc + (int)t] = 0.0f; tpy[acc + (int)t] = 0.0f; tpz[acc + (int)t] = -__builtin_inff();
+        }
+        if (KEEP && t < DW_LHDR) {           // the list's header
+          int hv = t == 0 ? cnt_c : t == 1 ? kept : t == 2 ? G : t == 3 ? 1 : t == 12 ? n_xtra : 0;
+#pragma unroll
+          for (int k = 1; k <= DW_MAXG; ++k) hv = (int)t == 3 + k ? wave_cnt[k] : hv;
+          L[t] = hv;
         }
       }
       int wbase[DW_MAXG + 1];
 #pragma unroll
-      for (int k = 1; k <= DW_MAXG; ++k) {
+      for (int k = K0; k <= DW_MAXG; ++k) {
         int below = 0;
         if (k <= G)
           for (int v = 0; v < NWV; ++v) below += v < w ? wcnt[v][k] : 0;
         wbase[k] = bstart[k] + below;
       }
 #pragma unroll
-      for (int q = 0; q < DW_ENT_PER_THREAD; ++q) {
+      for (int q = 0; q < EPT; ++q) {
         const int band = (int)((bands >> (4 * q)) & 15u);
+        int placed = -1;
 #pragma unroll
-        for (int k = 1; k <= DW_MAXG; ++k) {
+        for (int k = K0; k <= DW_MAXG; ++k) {
           if (k > G) continue;
           const unsigned long long m = __ballot(band == k);
           if (band == k) {
             const int slot = wbase[k] + (int)__popcll(m & ((1ULL << lane) - 1ULL));
             tpx[slot] = ent[q].x; tpy[slot] = ent[q].y; tpz[slot] = ent[q].z;
+            if constexpr (KEEP) placed = slot;
           }
           wbase[k] += (int)__popcll(m);
+        }
+        if constexpr (KEEP) {
+          // the list: tile position of (neighbour k, slot s), -1 = not in reach; slots beyond the table as pairs behind it
+          const int code = __float_as_int(ent[q].w), kk = code >> 6, ss = code & (DW_CAP - 1);
+          if ((int)t + q * TPB < total) {
+            if (ss < DW_LSLOTS) L[DW_LCAND + kk * DW_LSLOTS + ss] = placed;
+            else if (placed >= 0) {
+              const int x = atomicAdd(&xfill, 1);
+              L[DW_LXTRA0 + 2 * x] = nb_cell[kk] * DW_CAP + ss; L[DW_LXTRA0 + 2 * x + 1] = placed;
+            }
+          }
+        }
+      }
+      if constexpr (KEEP) {          // the table's slots that no entry fills
+        for (int j = (int)t; j < DW_NBR * DW_LSLOTS; j += TPB) {
+          const int kk = j / DW_LSLOTS, ss = j - kk * DW_LSLOTS;
+          if (kk >= n_nb || ss >= nb_cnt[kk]) L[DW_LCAND + j] = -1;
         }
       }
       __syncthreads();
@@ -467,7 +529,26 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
         if (have && sub8 == 0) dw_write(a, (long long)__float_as_int(me.w) - a.local_offset, K * fz, accumulate);
       }
       return;
+      }   // (kept <= DW_LBAND_MAX)
     }
+  }
+  if constexpr (KEEP) {
+    // the plain path's list: every entry of the neighbourhood, unbanded; the receivers in bucket order
+    __syncthreads();                                                                   // (the banded attempt read nb_cnt / skey)
+    for (int e = (int)t; e < total; e += TPB) {
+      int k = 0, acc = 0;
+      while (e >= acc + nb_cnt[k]) { acc += nb_cnt[k]; ++k; }
+      L[DW_LCAND + e] = nb_cell[k] * DW_CAP + (e - acc);
+    }
+    if ((int)t < cnt_c) {
+      const float4 m2 = b.buckets[(long long)c * DW_CAP + t];
+      const long long i = (long long)__float_as_int(m2.w) - a.local_offset;
+      const bool loc = i >= 0 && i < a.n;
+      L[DW_LRECV + t] = (int)t;
+      L[DW_LRTY + t] = loc ? (a.type_id ? (int)a.type_id[i] : 0) : -1;
+      if (loc) kp.pbuild[i] = make_float4(m2.x, m2.y, m2.z, __int_as_float(c * DW_CAP + (int)t));
+    }
+    if (t < DW_LHDR) L[t] = t == 0 ? cnt_c : t == 1 ? total : t == 2 ? (cnt_c + DW_RPG - 1) / DW_RPG : 0;
   }
   // A pass serves TPB / 8 receivers with 8 lanes each; when fewer are left (a cell's last pass is half empty on
   // average) the lane groups are widened — 16, 32 or 64 lanes per receiver — so that the candidates are split over all
@@ -523,6 +604,203 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
     if (have && sub_p == 0) dw_write(a, i, K * fz, accumulate);
     r0 += RPB >> sh;
   }
+}
+
+// ---- REUSE query: the kept lists of an earlier BUILD query, current positions (dsim_kernels.h "kept candidate lists") ----
+// One workgroup per cell, as the BUILD query, and the same pair loops; in front of them TWO round trips and no arithmetic to
+// speak of: the list (header, receivers, the first 768 candidate indices from fixed addresses, the first overflow entries —
+// everything before anything waits), then the gather of the current positions straight into the tile.  The tile of the first
+// fill begins with the MOVERS (the overflow list: drones that have left the skin, z = -inf in fresh[]), padded to a trip of
+// sixteen, so that every group reads them like a band above all others — the common case, at most DW_MOV_TILE of them; more are
+// read from global memory inside the loops, as the BUILD query reads its overflow list.  A mover is served by the workgroup of
+// the cell it is in NOW (the receivers DW_CAP .. of this kernel, against the whole list: band 0 included), in batches of the
+// overflow list; a list longer than a tile (unbanded lists of crowded neighbourhoods) takes several fills, the partial sums wait
+// in LDS.  Neither happens in a fleet that keeps its density: they are what makes the result independent of every capacity.
+#define DW_KEPT_CHUNK (DW_TILE_DENSE - DW_MOV_TILE - 2 * DW_LPB)     // list entries per fill (= DW_LBAND_MAX: a banded list is one fill)
+#define DW_KEPT_RECV (DW_CAP + DW_MOV_TILE)
+template <int TPB>
+__global__ __launch_bounds__(TPB, 7) void k_dw_query_kept(DwK a, BinK b, KeepK kp) {
+  __shared__ float tp[3 * DW_TILE_DENSE];
+  __shared__ float coef[DSIM_MAX_TYPES][4];
+  __shared__ float4 recv[DW_KEPT_RECV];                                                // [0, DW_CAP): the list's; behind them: movers that are here now
+  __shared__ int rty[DW_KEPT_RECV];
+  __shared__ float facc[DW_KEPT_RECV];
+  __shared__ int mv_n[2];
+  float* const tpx = tp;
+  float* const tpy = tp + DW_TILE_DENSE;
+  float* const tpz = tp + 2 * DW_TILE_DENSE;
+  constexpr int NSLOT = DW_NBR * DW_LSLOTS;                                              // the table of a banded list
+  constexpr int EPT = (NSLOT + TPB - 1) / TPB;
+  const int ncells = b.nx * b.ny;
+  const unsigned t = threadIdx.x;
+  {
+    const long long gid = (long long)blockIdx.x * TPB + t;
+    for (long long z = gid; z < (long long)ncells + DW_CNT_EXTRA; z += (long long)gridDim.x * TPB) a.count_next[z] = 0;
+  }
+  const int c = dw_block_cell(b, ncells, (int)blockIdx.x);
+  const int cx = c % b.nx, cy = c / b.nx;
+  const int* __restrict__ const L = kp.lists + (long long)c * DW_LSTRIDE;
+  const unsigned lane = t & 63u;
+  const int w = __builtin_amdgcn_readfirstlane((int)(t >> 6));
+  constexpr int NW = TPB / 64;
+  const int sub8 = (int)(lane % DW_LPB), rg = (int)(lane / DW_LPB);
+  // ---- the ONE round trip of a banded list: header, table and the bucket entries the table speaks of (addresses that depend on
+  // nothing loaded), the cell's own bucket (the receivers), the first overflow entries, the types' coefficients ----
+  const int cnt_c = L[0], total = L[1], G = L[2], flags = L[3], n_xtra = L[12];
+  int nbk[DW_MAXG + 1];
+#pragma unroll
+  for (int k = 1; k <= DW_MAXG; ++k) nbk[k] = L[3 + k];
+  const int n_ovf = b.count[ncells];
+  int tq[EPT];
+  float px[EPT], py[EPT], pz[EPT];
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    const int j = (int)t + q * TPB;
+    const int kk = j / DW_LSLOTS, ss = j - kk * DW_LSLOTS;
+    const int nxx = cx - 2 + kk % 5, nyy = cy - 2 + kk / 5;
+    const bool in = j < NSLOT && nxx >= 0 && nxx < b.nx && nyy >= 0 && nyy < b.ny;
+    tq[q] = -1; px[q] = py[q] = pz[q] = 0.0f;
+    if (in) {
+      tq[q] = L[DW_LCAND + j];
+      const float4 v = b.buckets[(long long)(nyy * b.nx + nxx) * DW_CAP + ss];
+      px[q] = v.x; py[q] = v.y; pz[q] = v.z;
+    }
+  }
+  float4 me0 = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+  int rrank = 0, rt = -1;
+  if (t < DW_CAP) { me0 = b.buckets[(long long)c * DW_CAP + t]; rrank = L[DW_LRECV + t]; rt = L[DW_LRTY + t]; }
+  float4 mv = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+  if (t < DW_MOV_TILE && (long long)t < a.n) mv = b.overflow[t];                         // (speculative: the list holds a.n entries)
+  const int cty = min(TPB - 1 - (int)t, a.n_types - 1);                                  // the LAST lanes hold the types
+  const DevType& CT = a.types[cty];
+  const float c_dw0 = CT.dw[0], c_dw1 = CT.dw[1], c_dw2 = CT.dw[2], c_pr = CT.prop_radius;
+  if ((int)t >= TPB - a.n_types) {
+    coef[cty][0] = c_dw0 * (0.25f * c_pr) * (0.25f * c_pr); coef[cty][1] = c_dw1; coef[cty][2] = c_dw2;
+  }
+  if (blockIdx.x == 0 && t == 0 && n_ovf > 0) atomicAdd(&kp.counters[5], (unsigned long long)n_ovf);      // DSIM_Q_DW_MOVERS
+  const bool banded = (flags & 1) != 0;
+  const bool mov_lds = n_ovf <= DW_MOV_TILE;
+  const int P = mov_lds ? n_ovf : 0;                                                     // movers in front of the first fill
+  const int nfills = (!banded && total > DW_KEPT_CHUNK) ? (total + DW_KEPT_CHUNK - 1) / DW_KEPT_CHUNK : 1;
+  const int nbatch = n_ovf > DW_MOV_TILE ? (n_ovf + DW_MOV_TILE - 1) / DW_MOV_TILE : 1;
+  // the movers of DW_MOV_TILE overflow entries that are in this cell now: receivers DW_CAP .. (one wave looks)
+  auto movers_here = [&](float4 e, int batch) {
+    const int k = batch * DW_MOV_TILE + (int)lane;
+    const long long i = (long long)__float_as_int(e.w) - a.local_offset;
+    const bool here = lane < DW_MOV_TILE && k < n_ovf && i >= 0 && i < a.n && bin_cell(b, e.x, e.y) == c;
+    const unsigned long long m = __ballot(here);
+    const int pos = (int)__popcll(m & ((1ULL << lane) - 1ULL)), cnt = (int)__popcll(m);
+    if (here) {
+      recv[DW_CAP + pos] = make_float4(e.x, e.y, e.z, __int_as_float((int)i));
+      rty[DW_CAP + pos] = a.type_id ? (int)a.type_id[i] : 0;
+    }
+    if (lane < DW_MOV_TILE) {
+      if ((int)lane >= cnt) rty[DW_CAP + lane] = -1;
+      facc[DW_CAP + lane] = 0.0f;
+    }
+    if (lane == 0) mv_n[batch & 1] = cnt;
+  };
+  if (w == 0) {
+    movers_here(mv, 0);
+    // the list's receivers: a mover among them (z = -inf) is passed over here and served where it is now
+    const bool real = (int)lane < cnt_c;
+    const long long i = (long long)__float_as_int(me0.w) - a.local_offset;
+    if (real) {
+      recv[rrank] = make_float4(me0.x, me0.y, me0.z, __int_as_float((int)i));
+      rty[rrank] = (i >= 0 && i < a.n && me0.z != -__builtin_inff()) ? rt : -1;
+    } else rty[lane] = -1;                                                               // (ranks [0, cnt_c) are the receivers': the rest is nobody's)
+    facc[lane] = 0.0f;
+  }
+  // the movers, the sentinels and (banded) the candidates of the table go straight into the tile
+  if ((int)t < P) { tpx[t] = mv.x; tpy[t] = mv.y; tpz[t] = mv.z; }
+  int tile_holds = -1;                                                                   // which fill the tile holds (uniform)
+  if (banded) {
+    if (t < 2 * DW_LPB) { tpx[P + total + (int)t] = 0.0f; tpy[P + total + (int)t] = 0.0f; tpz[P + total + (int)t] = -__builtin_inff(); }
+#pragma unroll
+    for (int q = 0; q < EPT; ++q)
+      if (tq[q] >= 0) { tpx[P + tq[q]] = px[q]; tpy[P + tq[q]] = py[q]; tpz[P + tq[q]] = pz[q]; }
+    for (int x = (int)t; x < n_xtra; x += TPB) {                                         // (rare: a second trip for slots beyond the table)
+      const float4 v = b.buckets[L[DW_LXTRA0 + 2 * x]];
+      const int at = P + L[DW_LXTRA0 + 2 * x + 1];
+      tpx[at] = v.x; tpy[at] = v.y; tpz[at] = v.z;
+    }
+    tile_holds = 0;
+  }
+  for (int batch = 0; batch < nbatch; ++batch) {
+    if (batch > 0 && w == 0) {
+      const int k = batch * DW_MOV_TILE + (int)lane;
+      movers_here((lane < DW_MOV_TILE && k < n_ovf) ? b.overflow[k] : make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1)), batch);
+    }
+    __syncthreads();
+    const int mvn = __builtin_amdgcn_readfirstlane(mv_n[batch & 1]);
+    const int Gr = batch == 0 ? (cnt_c + DW_RPG - 1) / DW_RPG : 0, Gm = (mvn + DW_RPG - 1) / DW_RPG, Gt = Gr + Gm;
+    for (int f = 0; f < (Gt > 0 ? nfills : 0); ++f) {                                    // (Gt == 0: nobody to serve — uniform)
+      const int lo = f * DW_KEPT_CHUNK, len = banded ? total : min(total - lo, DW_KEPT_CHUNK);   // this fill's piece of the list
+      const int P_f = f == 0 ? P : 0;
+      if (tile_holds != f) {                                                             // (unbanded lists: bucket slots, two trips a fill)
+        if (tile_holds >= 0) __syncthreads();                                            // the previous tile is done with
+        tile_holds = f;
+        for (int e = (int)t; e < len; e += TPB) {
+          const float4 v = b.buckets[L[DW_LCAND + lo + e]];
+          tpx[P_f + e] = v.x; tpy[P_f + e] = v.y; tpz[P_f + e] = v.z;
+        }
+        if (f == 0 && (int)t < P_f) { tpx[t] = mv.x; tpy[t] = mv.y; tpz[t] = mv.z; }
+        if (t < 2 * DW_LPB) {                                                            // sentinels behind the last entry
+          tpx[P_f + len + (int)t] = 0.0f; tpy[P_f + len + (int)t] = 0.0f; tpz[P_f + len + (int)t] = -__builtin_inff();
+        }
+        __syncthreads();
+      }
+      // ---- the groups: the list's in snake order over the waves, then the movers' ----
+      for (int rd = 0; rd * NW < Gt; ++rd) {
+        const int gq = rd * NW + ((rd & 1) ? NW - 1 - w : w);
+        if (gq >= Gt) continue;
+        const bool regular = gq < Gr;
+        const int r = regular ? gq * DW_RPG + rg : DW_CAP + (gq - Gr) * DW_RPG + rg;
+        int llim = total;                                                                // end of this group's part of the list
+        if (regular && banded) {
+          llim = 0;
+#pragma unroll
+          for (int k = 1; k <= DW_MAXG; ++k) llim += (k > gq && k <= G) ? nbk[k] : 0;
+        }
+        const int lim = P_f + min(max(llim - lo, 0), len);
+        const float4 me = recv[r];
+        const int ty = rty[r];
+        const bool have = ty >= 0;
+        float fz = 0.0f, K = 0.0f;
+        if (have) {
+          K = coef[ty][0];
+          const float d1 = coef[ty][1], d2c = coef[ty][2];
+          const float d1s = d1 * DW_BETA_SCALE, d2s = d2c * DW_BETA_SCALE;
+          for (int base = 0; base < lim; base += 2 * DW_LPB) {                           // (as the BUILD query's loop)
+            const int e0 = base + sub8;
+            const float4 p0 = make_float4(tpx[e0], tpy[e0], tpz[e0], 0.0f);
+            const float4 p1 = make_float4(tpx[e0 + DW_LPB], tpy[e0 + DW_LPB], tpz[e0 + DW_LPB], 0.0f);
+            fz = dw_pair_acc(p0, me.x, me.y, me.z, d1s, d2s, fz);
+            fz = dw_pair_acc(p1, me.x, me.y, me.z, d1s, d2s, fz);
+          }
+          if (!mov_lds && f == 0)
+            for (int k = sub8; k < n_ovf; k += DW_LPB) fz += dw_pair(b.overflow[k], me.x, me.y, me.z, 1.0f, d1, d2c);
+        }
+        if (a.pairs) {
+          const int served = (int)__popcll(__ballot(have && sub8 == 0));
+          if (lane == 0) atomicAdd(a.pairs, (unsigned long long)served * (unsigned long long)(((lim + 2 * DW_LPB - 1) / (2 * DW_LPB)) * (2 * DW_LPB) + ((!mov_lds && f == 0) ? n_ovf : 0)));
+        }
+#pragma unroll
+        for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
+        if (have && sub8 == 0) {
+          if (nfills > 1) { fz += facc[r]; facc[r] = fz; }
+          if (f == nfills - 1) dw_write(a, (long long)__float_as_int(me.w), K * fz, 0);
+        }
+      }
+    }
+    if (nbatch > 1) __syncthreads();                                                     // the next batch rewrites the movers' receivers
+  }
+}
+// the refresh a REUSE query needs when no step kernel has made it (BinK.pbuild): the local drones' current positions
+__global__ __launch_bounds__(256) void k_dw_refresh(DwK a, BinK b) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.n) return;
+  bin_refresh(b, dw_pos(a, j, 0), dw_pos(a, j, 1), dw_pos(a, j, 2), b.local_offset + j);
 }
 
 // ---- halo exchange of a spatially sharded fleet: bounds, per-peer lists, packing, binning what arrived ----------------
@@ -833,6 +1111,38 @@ __global__ __launch_bounds__(256) void k_adj_query(DwK a) {
 static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view& state,
                       const dsim_downwash_args* g, float min_cell, DwK* out, bool allow_buckets = false);
 
+// ---- kept candidate lists (dsim_downwash_args.keep) ----
+static inline int dw_rings(float cell) { return cell >= DW_CUTOFF ? 1 : 2; }
+static inline bool dw_dense(int64_t m, int64_t ncells, float cell) {          // the banded two-wave query (launch_query_cell)
+  const int side = 2 * dw_rings(cell) + 1;
+  return (double)m / (double)ncells * side * side > 128.0;
+}
+static bool keep_shape_ok(int64_t m, int32_t nx, int32_t ny, float cell, float skin) {
+  if (m < 1 || nx < 1 || ny < 1 || !(skin > 0.0f) || !(cell > 0.0f)) return false;
+  const int64_t ncells = (int64_t)nx * ny;
+  // (cells below the cut-off: the lists' table is laid out for the 5 x 5 neighbourhood of two rings)
+  return dw_use_buckets(m, ncells) && dw_dense(m, ncells, cell) && cell < DW_CUTOFF && 2.0f * cell >= DW_CUTOFF + 2.0f * skin;
+}
+// the call's own claim to kept lists: the world is this fleet alone, the shape takes them, the buffer is large enough
+static bool keep_usable(const dsim_downwash_args* g, int64_t n, int64_t n_pad) {
+  return g->keep != DSIM_DW_KEEP_OFF && !g->pos_all && !g->halo && g->phase == DSIM_DW_ALL && g->m == n && g->local_offset == 0 &&
+         g->keep_ws && keep_shape_ok(g->m, g->nx, g->ny, g->cell, g->keep_skin) &&
+         g->keep_ws_len >= dsim_downwash_keep_workspace(n_pad, g->nx, g->ny);
+}
+// ... and whether the lists of the last BUILD query are this grid's
+static bool keep_lists_valid(const dsim_ctx* ctx, const dsim_downwash_args* g, int64_t n) {
+  return ctx->dw_keep_ws && ctx->dw_keep_ws == g->keep_ws && ctx->dw_keep_cells == (long long)g->nx * g->ny && ctx->dw_keep_n == n &&
+         ctx->dw_keep_nx == g->nx && ctx->dw_keep_ny == g->ny && ctx->dw_keep_geo[0] == g->xmin && ctx->dw_keep_geo[1] == g->ymin &&
+         ctx->dw_keep_geo[2] == g->cell && ctx->dw_keep_geo[3] == g->keep_skin;
+}
+static void keep_layout(const dsim_downwash_args* g, int64_t n_pad, KeepK* kp) {
+  uintptr_t sp = ((uintptr_t)g->keep_ws + 15) & ~(uintptr_t)15;
+  kp->pbuild = (float4*)sp;
+  kp->lists = (int*)(kp->pbuild + n_pad);
+  kp->skin = g->keep_skin;
+  kp->counters = nullptr;
+}
+
 // dsim_step_args.bin_next: the step kernel fills the bucket grid of the next dsim_downwash call.  Only when that grid
 // is the one the last dsim_downwash used (its spare count buffer is then known to be zero) and takes the bucket form.
 void bin_next_prepare(dsim_ctx* ctx, int64_t n, const dsim_step_args* args, StepK* a, hipStream_t st) {
@@ -851,6 +1161,14 @@ void bin_next_prepare(dsim_ctx* ctx, int64_t n, const dsim_step_args* args, Step
   }
   a->bin.xmin = g->xmin; a->bin.ymin = g->ymin; a->bin.inv_cell = 1.0f / g->cell; a->bin.nx = g->nx; a->bin.ny = g->ny;
   a->bin.local_offset = g->local_offset;
+  // the next query re-uses kept lists: this step refreshes their positions instead of binning (BinK.pbuild)
+  bool any_quadlaw6 = false;          // (its step kernel has no refreshing form: dsim_step.hip run_body)
+  for (int t = 0; t < ctx->n_types; ++t) any_quadlaw6 |= ctx->h_types[t].kind == DSIM_KIND_HEXA_QUADLAW;
+  if (g->keep == DSIM_DW_KEEP_REUSE && !any_quadlaw6 && keep_usable(g, n, a->n_pad) && keep_lists_valid(ctx, g, n)) {
+    KeepK kp;
+    keep_layout(g, a->n_pad, &kp);
+    a->bin.pbuild = kp.pbuild; a->bin.skin2 = g->keep_skin * g->keep_skin;
+  }
 }
 
 void bin_next_commit(dsim_ctx* ctx, int64_t n, const dsim_step_args* args, const StepK& a) {
@@ -859,6 +1177,7 @@ void bin_next_commit(dsim_ctx* ctx, int64_t n, const dsim_step_args* args, const
   ctx->dw_prebin_nx = args->bin_next->nx; ctx->dw_prebin_ny = args->bin_next->ny;
   ctx->dw_prebin_geo[0] = args->bin_next->xmin; ctx->dw_prebin_geo[1] = args->bin_next->ymin;
   ctx->dw_prebin_geo[2] = args->bin_next->cell;
+  ctx->dw_prebin_kind = a.bin.pbuild ? 1 : 0;
 }
 
 // the halo grid of the split-phase downwash sits behind the local grid (whose overflow list holds n_local entries)
@@ -903,17 +1222,20 @@ static void halo_fill(const dsim_halo_plan* h, HaloK* k) {
 
 // the cell-centred query over (receiver grid b, candidate grid cnd)
 static void launch_query_cell(dsim_ctx* ctx, hipStream_t st_, const DwK& a, const BinK& b, const BinK& cnd, float cell,
-                              long long m_candidates, int accumulate) {
+                              long long m_candidates, int accumulate, const KeepK* keep = nullptr) {
   const long long ncells = (long long)a.nx * a.ny;
   // sparse worlds (mean occupancy of a neighbourhood <= 128 entries): one wave per cell and an 8 KB tile, so that a
   // CU holds ~20 cells at once; dense ones (BASELINE config 5: 625 entries per neighbourhood): two waves and 12 KB —
   // 11 cells per CU, so that the ~2 800 cells of a 65 536-drone shard are all resident in ONE round (four-wave
   // workgroups needed 1.4 rounds of 8 per CU, and the thin second round cost 40 % of the kernel's time)
-  const int rings = cell >= DW_CUTOFF ? 1 : 2;
-  const double nb_mean = (double)m_candidates / (double)ncells * (2 * rings + 1) * (2 * rings + 1);
+  const int rings = dw_rings(cell);
   const dim3 gq((unsigned)(ncells + DW_OVF_GROUPS));
-  if (nb_mean <= 128.0) hipLaunchKernelGGL((k_dw_query_cell<64, false>), gq, dim3(64), 256 * sizeof(float4), st_, a, b, cnd, rings, 256, accumulate);
-  else hipLaunchKernelGGL((k_dw_query_cell<128, true>), gq, dim3(128), DW_TILE_DENSE_BYTES, st_, a, b, cnd, rings, DW_TILE_DENSE_BYTES / (int)sizeof(float4), accumulate);
+  KeepK kp;
+  memset(&kp, 0, sizeof(kp));
+  if (keep)      // (keep_usable: a dense world)
+    hipLaunchKernelGGL((k_dw_query_cell<128, true, true>), gq, dim3(128), DW_TILE_DENSE_BYTES, st_, a, b, cnd, rings, DW_TILE_DENSE_BYTES / (int)sizeof(float4), accumulate, *keep);
+  else if (!dw_dense(m_candidates, ncells, cell)) hipLaunchKernelGGL((k_dw_query_cell<64, false>), gq, dim3(64), 256 * sizeof(float4), st_, a, b, cnd, rings, 256, accumulate, kp);
+  else hipLaunchKernelGGL((k_dw_query_cell<128, true>), gq, dim3(128), DW_TILE_DENSE_BYTES, st_, a, b, cnd, rings, DW_TILE_DENSE_BYTES / (int)sizeof(float4), accumulate, kp);
 }
 
 // counting sort of the world's positions into the xy grid (count, scan, scatter)
@@ -963,15 +1285,34 @@ static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view
     bucket_layout(g->workspace, ncells, cur, &b);
     b.xmin = a.xmin; b.ymin = a.ymin; b.inv_cell = a.inv_cell; b.nx = a.nx; b.ny = a.ny; b.local_offset = a.local_offset;
     a.buckets = b.buckets; a.overflow = b.overflow;
-    if (pre_live && !pre) {          // a step binned into this buffer but the caller does not vouch for it: start over
+    // kept lists: a REUSE needs lists of this very grid, and the step in front of it must have REFRESHED the positions (kind 1) where
+    // a BUILD or a plain query needs them BINNED (kind 0).  A step that binned in front of a REUSE makes it a BUILD (its grid is
+    // fresh: new lists cost nothing extra); a step that refreshed in front of anything else is not vouched for.
+    int mode = keep_usable(g, n, state.n_pad) ? g->keep : DSIM_DW_KEEP_OFF;
+    if (mode == DSIM_DW_KEEP_REUSE && !keep_lists_valid(ctx, g, n)) mode = DSIM_DW_KEEP_BUILD;
+    const bool refreshed = ctx->dw_prebin_kind == 1;
+    if (mode == DSIM_DW_KEEP_REUSE && pre && !refreshed) mode = DSIM_DW_KEEP_BUILD;
+    const bool pre_ok = pre && (refreshed == (mode == DSIM_DW_KEEP_REUSE));
+    a.keep_mode = mode;
+    if (pre_live && !pre_ok) {       // a step filled this buffer but not with what this call needs, or the caller does not vouch for it
       hipError_t e = hipMemsetAsync(a.count, 0, sizeof(int) * cstride, st_);
       if (e != hipSuccess) return (int)e;
+    }
+    if (mode == DSIM_DW_KEEP_REUSE) {
+      if (!pre_ok) {
+        KeepK kp;
+        keep_layout(g, state.n_pad, &kp);
+        b.pbuild = kp.pbuild; b.skin2 = g->keep_skin * g->keep_skin;
+        hipLaunchKernelGGL(k_dw_refresh, dim3(grid_for(n)), dim3(256), 0, st_, a, b);
+      }
+      a_ = a;
+      return DSIM_OK;
     }
     const long long m_here = g->halo ? n : a.m;         // entries this pass reads through dw_pos (the halo has its own kernel)
     BinRange r;
     r.j0 = 0; r.j1 = m_here; r.skip0 = r.skip1 = m_here;
     long long todo = m_here;
-    if (pre) { r.skip0 = a.local_offset; r.skip1 = a.local_offset + n; todo = m_here - n; }
+    if (pre_ok) { r.skip0 = a.local_offset; r.skip1 = a.local_offset + n; todo = m_here - n; }
     if (todo > 0) hipLaunchKernelGGL(k_dw_bin, dim3(grid_for(todo)), dim3(256), 0, st_, a, b, r);
     a_ = a;
     return DSIM_OK;
@@ -1000,6 +1341,15 @@ int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny) {
   const int64_t sort_form = 2 * (ncells + 1) + ncells + 4 + 4 * m;   // count x2, cursor, 16-B alignment slack, float4[m]
   const int64_t bucket_form = 2 * (ncells + DW_CNT_EXTRA) + 4 + 4 * ncells * DW_CAP + 4 * m;   // count x2, slack, buckets, overflow
   return dw_use_buckets(m, ncells) && bucket_form > sort_form ? bucket_form : sort_form;
+}
+
+int64_t dsim_downwash_keep_workspace(int64_t n_pad, int32_t nx, int32_t ny) {
+  if (n_pad < 1 || nx < 1 || ny < 1) return -1;
+  return 4 + 4 * n_pad + (int64_t)nx * ny * DW_LSTRIDE;        // alignment slack | pbuild: float4 [n_pad] | the lists
+}
+
+int dsim_downwash_keep_ok(int64_t m, int32_t nx, int32_t ny, float cell, float keep_skin) {
+  return keep_shape_ok(m, nx, ny, cell, keep_skin) ? 1 : 0;
 }
 
 int64_t dsim_downwash_workspace_halo(int64_t n, int64_t h, int32_t nx, int32_t ny) {
@@ -1096,7 +1446,21 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
     b.xmin = a.xmin; b.ymin = a.ymin; b.inv_cell = a.inv_cell; b.nx = a.nx; b.ny = a.ny; b.local_offset = a.local_offset;
     if (g->halo && g->phase == DSIM_DW_ALL && h_tot > 0)              // one grid: what the peers sent goes in beside the local drones
       hipLaunchKernelGGL(k_dw_bin_halo, dim3(grid_for(h_tot)), dim3(256), 0, st_, b, hk);
-    launch_query_cell(ctx, st_, a, b, b, g->cell, g->phase == DSIM_DW_LOCAL ? n : a.m, 0);
+    if (a.keep_mode != DSIM_DW_KEEP_OFF) {
+      KeepK kp;
+      keep_layout(g, state.n_pad, &kp);
+      if (a.keep_mode == DSIM_DW_KEEP_REUSE) {
+        kp.counters = ctx->d_counters;
+        ++ctx->dw_reuses;
+        hipLaunchKernelGGL((k_dw_query_kept<128>), dim3((unsigned)ncells), dim3(128), 0, st_, a, b, kp);
+      }
+      else {
+        launch_query_cell(ctx, st_, a, b, b, g->cell, a.m, 0, &kp);
+        ctx->dw_keep_ws = g->keep_ws; ctx->dw_keep_cells = ncells; ctx->dw_keep_n = n; ctx->dw_keep_nx = g->nx; ctx->dw_keep_ny = g->ny;
+        ctx->dw_keep_geo[0] = g->xmin; ctx->dw_keep_geo[1] = g->ymin; ctx->dw_keep_geo[2] = g->cell; ctx->dw_keep_geo[3] = g->keep_skin;
+      }
+    }
+    else launch_query_cell(ctx, st_, a, b, b, g->cell, g->phase == DSIM_DW_LOCAL ? n : a.m, 0);
   }
   else hipLaunchKernelGGL(k_dw_query, dim3(grid_for(a.m * DW_LPR)), dim3(256), 0, st_, a);
   return (int)hipGetLastError();
@@ -1105,6 +1469,7 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
 int dsim_downwash_reset(dsim_ctx* ctx) {
   if (!ctx) return DSIM_E_ARG;
   ctx->dw_ws = nullptr; ctx->dw_cells = 0; ctx->dw_parity = 0; ctx->dw_prebin = false; ctx->dw_prebin_valid = false;
+  ctx->dw_keep_ws = nullptr; ctx->dw_prebin_kind = 0;
   ctx->dwh_ws = nullptr;
   return DSIM_OK;
 }

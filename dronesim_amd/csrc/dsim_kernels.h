@@ -62,6 +62,12 @@ struct dsim_ctx {
   float dw_prebin_geo[3];
   int dw_prebin_nx, dw_prebin_ny;
   long long dw_local_m;                   // overflow capacity of the local grid in the workspace (layout of what follows it)
+  int dw_prebin_kind;                     // what that dsim_step did: 0 binned the drones, 1 refreshed the kept lists' positions (BinK.pbuild)
+  const int32_t* dw_keep_ws;              // kept candidate lists (dsim_downwash_args.keep): the buffer / grid / fleet of the last BUILD query, null: none
+  long long dw_keep_cells, dw_keep_n;
+  float dw_keep_geo[4];                   // xmin, ymin, cell, skin
+  int dw_keep_nx, dw_keep_ny;
+  long long dw_reuses;                    // DSIM_Q_DW_REUSES
   int dwh_parity;                         // halo grid (split-phase downwash): count-buffer parity
   const int32_t* dwh_ws;                  // ... and the workspace / shape it was zeroed for
   long long dwh_cells;
@@ -114,7 +120,50 @@ struct BinK {
   float xmin, ymin, inv_cell;
   int nx, ny;
   long long local_offset;   // world index of local drone 0
+  // Kept candidate lists (dsim_downwash_args.keep, DW_KEEP below): the NEXT query re-uses the lists of an earlier one, so this
+  // step does not bin.  It REFRESHES: fresh[i] = the new position, and a drone that has moved further than the lists' skin from
+  // where it was when they were made (pbuild[i]) leaves them — z = -inf in fresh[] (as a candidate it is above nobody, as a
+  // receiver its cell passes it over) and an entry in the overflow list, which every receiver scans and whose members are
+  // served where they are NOW.  The fresh position goes where the drone's entry was when the lists were made: its slot of
+  // `buckets` (pbuild[i].w; -1: it had none).  null = the step bins.
+  const float4* pbuild;     // [n_pad] (x, y, z when the lists were made, bucket slot as int bits)
+  float skin2;              // skin^2
 };
+// ---- kept candidate lists ----------------------------------------------------------------------------
+// A fleet moves centimetres per Env.step: which candidates a cell's receivers have to look at, and in which height band each lies,
+// changes slowly.  A BUILD query (the banded cell-centred query, with its reach and band tests widened by the skin) writes, per
+// cell, what it worked out — the receivers in height order with their types, the candidates in band order (band 0, below every
+// receiver, included: a drone that arrives later may need it) — and the following REUSE queries read that list, gather the
+// CURRENT positions and go straight to the pair loops: no bucket counts, no address walk, no ranking, no reach test, no band
+// placement (4.2 M of the 12 M vector instructions of a config-5 query) and, in the step kernel, no atomic round trip for a bucket
+// slot.  Exact for ANY motion: every pair is still tested against the cut-off and the height order on current positions; the lists
+// only have to be SUPERSETS, which the skin guarantees for drones that stayed within it and the overflow list for those that
+// did not.  Layout of a cell's list (int32 words):
+#define DW_LHDR 16                        // [0] receivers [1] candidates in the tile [2] groups G [3] flags (1: banded) [4..11] band 1..8 totals [12] pairs behind the table
+#define DW_LRECV DW_LHDR                  // [DW_CAP] slot of the cell's own bucket -> the receiver's place in height order
+#define DW_LRTY (DW_LHDR + DW_CAP)        // [DW_CAP] slot -> type
+#define DW_LCAND (DW_LHDR + 2 * DW_CAP)   // banded: [25][DW_LSLOTS] (neighbour, slot) -> place in the tile (bands G .. 1, then 0), -1: not in reach;
+#define DW_LSLOTS 48                      //   then up to DW_LXTRA (bucket slot, place) pairs for slots >= DW_LSLOTS.  The positions themselves stay
+#define DW_LXTRA0 (DW_LCAND + 25 * DW_LSLOTS)   //   in the grid's BUCKETS, refreshed in place by the steps: a REUSE query's loads depend on nothing
+#define DW_LXTRA 64                       //   it has to wait for — ONE round trip to the pair loops.  Unbanded (crowded neighbourhoods): [<= DW_LCAP]
+#define DW_LCAP (25 * DW_CAP)             //   bucket slots of every entry of the 5 x 5 cells, any order
+#define DW_LSTRIDE (DW_LCAND + DW_LCAP)
+#define DW_MOV_TILE 32                    // overflow entries (movers) a REUSE workgroup keeps in front of its tile
+struct KeepK {
+  int* lists;               // [ncells][DW_LSTRIDE]
+  float4* pbuild;           // [n_pad] positions when the lists were made (NaN: never in a list), .w = the drone's bucket slot
+  float skin;
+  unsigned long long* counters;   // the ctx's diagnostics ([5]: DSIM_Q_DW_MOVERS)
+};
+__device__ __forceinline__ void bin_refresh(const BinK& b, float x, float y, float z, long long world_index) {
+  const long long i = world_index - b.local_offset;
+  const float4 pb = b.pbuild[i];
+  const float dx = x - pb.x, dy = y - pb.y, dz = z - pb.z;
+  const bool stay = dx * dx + dy * dy + dz * dz <= b.skin2;            // (NaN anywhere: a mover)
+  const int home = __float_as_int(pb.w);
+  if (home >= 0) b.buckets[home] = make_float4(x, y, stay ? z : -__builtin_inff(), __int_as_float((int)world_index));
+  if (!stay) b.overflow[atomicAdd(&b.count[b.nx * b.ny], 1)] = make_float4(x, y, z, __int_as_float((int)world_index));
+}
 __device__ __forceinline__ int bin_cell(const BinK& b, float x, float y) {
   const int cx = min(max((int)floorf((x - b.xmin) * b.inv_cell), 0), b.nx - 1);
   const int cy = min(max((int)floorf((y - b.ymin) * b.inv_cell), 0), b.ny - 1);
@@ -123,15 +172,21 @@ __device__ __forceinline__ int bin_cell(const BinK& b, float x, float y) {
 // the two halves of bin_entry: the slot's reservation is an atomic round trip to another XCD's L2 (~2 us); issued as soon
 // as the new position exists it is hidden behind the control law instead of standing at the end of the workgroup
 __device__ __forceinline__ int bin_reserve(const BinK& b, float x, float y, int& cell) {
+  cell = 0;
+  if (b.pbuild) return 0;
   cell = bin_cell(b, x, y);
   return atomicAdd(&b.count[cell], 1);
 }
 __device__ __forceinline__ void bin_commit(const BinK& b, int cell, int slot, float x, float y, float z, long long world_index) {
+  if (b.pbuild) { bin_refresh(b, x, y, z, world_index); return; }
   const float4 e = make_float4(x, y, z, __int_as_float((int)world_index));
   if (slot < DW_CAP) b.buckets[(long long)cell * DW_CAP + slot] = e;
   else b.overflow[atomicAdd(&b.count[b.nx * b.ny], 1)] = e;
 }
+// (REFRESH = false: an instance that cannot afford the second form — the host then never asks it to, bin_next_prepare)
+template <bool REFRESH = true>
 __device__ __forceinline__ void bin_entry(const BinK& b, float x, float y, float z, long long world_index) {
+  if (REFRESH && b.pbuild) { bin_refresh(b, x, y, z, world_index); return; }
   const int c = bin_cell(b, x, y);
   const float4 e = make_float4(x, y, z, __int_as_float((int)world_index));
   const int slot = atomicAdd(&b.count[c], 1);

@@ -198,7 +198,8 @@ __device__ __forceinline__ void run_body(const StepK& a, long long i0, long long
   ground_watch(T, s, a.fb.counters, i < a.n);
   // (measured and dropped: reserving the slot of the next grid right behind the physics, so that the atomic's round trip
   // rides under the control law — 45.4 against 45.7 us for the config-5 chain, and 36 bytes of scratch in two instances)
-  if (a.bin.count && i < a.n) bin_entry(a.bin, s.pos.x, s.pos.y, s.pos.z, a.bin.local_offset + i);   // next step's grid
+  // (the quad law on six actuators has no registers left for the refreshing form of kept lists: 20 bytes of scratch)
+  if (a.bin.count && i < a.n) bin_entry<KIND != DSIM_DEV_KIND_HEXA_QUADLAW>(a.bin, s.pos.x, s.pos.y, s.pos.z, a.bin.local_offset + i);   // next step's grid
 }
 template <int KIND, bool NOISE, bool NT, bool S1>
 __global__ __launch_bounds__(256, KIND ? DSIM_HEXA_WAVES : DSIM_STEP_WAVES) void k_step_run(StepK a) {

@@ -336,7 +336,8 @@ class Downwash:
     """Evaluates formula P8 for the drones of one env/state block against world positions."""
 
     def __init__(self, ctx, state, type_id: Optional[torch.Tensor] = None, dist=None, cell: Optional[float] = None,
-                 box_refresh: int = 256, halo: Optional[HaloPlan] = None, split: Optional[bool] = None):
+                 box_refresh: int = 256, halo: Optional[HaloPlan] = None, split: Optional[bool] = None,
+                 keep_lists: int = 0, keep_skin: float = 0.25):
         # cell = None: 5 m cells (half the cut-off, 5 x 5 cells scanned per drone: 30 % fewer candidate pairs than
         # 3 x 3 cells of 10 m) whenever the world's shape takes the bucket form of the grid, 10 m cells otherwise
         self.ctx, self.state, self.type_id, self.dist = ctx, state, type_id, dist
@@ -359,6 +360,14 @@ class Downwash:
         self._halo_args = None           # halo form: the three phases' argument blocks, rebuilt at a resize
         self._last_ok = {}               # id(args) -> dsim_downwash_prebin_ok of its shape
         self.pair_counter = None         # diagnostics (count_pairs): int64[1] the query adds its evaluated pairs to
+        # kept candidate lists (dsim_downwash_args.keep; single-rank fleets at a density that takes the banded query): one
+        # BUILD query serves keep_lists Env.steps, the others re-use its lists on refreshed positions.  Exact for any motion
+        # (a drone that leaves the skin is handed to the overflow list); how often to BUILD only decides how long that list gets.
+        self.keep_lists, self.keep_skin = max(int(keep_lists), 0), float(keep_skin)
+        if self.keep_lists > 1 and self._auto_cell:
+            self.cell = 0.5 * CUTOFF + self.keep_skin          # two rings of cells cover the reach widened by twice the skin
+        self._keep_ws = None
+        self._keep_age = 0               # queries since the last BUILD
 
     def _grid_box(self, wp, lo_hi=None):
         """Bounding box of the world in xy -> grid.  Drones that later leave the box are clamped to
@@ -428,6 +437,13 @@ class Downwash:
         a = self._fill(wp, m, local_offset, box)
         self._workspace(a, self.ctx.lib.dsim_downwash_workspace(m, box[2], box[3]))
         self._keep = wp                     # the kernels read it asynchronously on the stream
+        if single and self.keep_lists > 1 and self.ctx.lib.dsim_downwash_keep_ok(m, box[2], box[3], self.cell, self.keep_skin):
+            need = int(self.ctx.lib.dsim_downwash_keep_workspace(st.n_pad, box[2], box[3]))
+            if self._keep_ws is None or self._keep_ws.numel() < need:
+                self._keep_ws = torch.empty((need,), dtype=torch.int32, device=self.ctx.device)
+            a.keep, a.keep_skin = nat.DW_KEEP_BUILD, self.keep_skin
+            a.keep_ws, a.keep_ws_len = self._keep_ws.data_ptr(), self._keep_ws.numel()
+            self._keep_age = 0
         return a
 
     def _gather(self, local_pos: torch.Tensor) -> torch.Tensor:
@@ -493,6 +509,11 @@ class Downwash:
         self._prebin_version = None
         nat.check(self.ctx.lib.dsim_downwash(self.ctx.handle, self.ctx.stream_ptr(), self.state.n, view, ref,
                                              self.force.data_ptr()))
+        if a.keep != nat.DW_KEEP_OFF:
+            # what the NEXT query of this grid will be — known now, because the step in between has to be told (bin_next: it
+            # refreshes the lists' positions in front of a REUSE and bins in front of a BUILD)
+            self._keep_age = 0 if a.keep == nat.DW_KEEP_BUILD else self._keep_age + 1
+            a.keep = nat.DW_KEEP_BUILD if self._keep_age + 1 >= self.keep_lists else nat.DW_KEEP_REUSE
         self._last = a
         return self.force
 

@@ -108,6 +108,8 @@ class CtrlAviary(PlacedFleetArrays, FleetObservation):
         placement: bool = False,
         dyn_ang_vel: str = "reference",
         noise: str = "auto",
+        downwash_keep: Optional[int] = None,
+        downwash_skin: float = 0.25,
     ):
         if gui or record or obstacles:
             raise NotImplementedError("gui/record/obstacles are rendering features outside the hot path")
@@ -286,7 +288,14 @@ class CtrlAviary(PlacedFleetArrays, FleetObservation):
                                 max(t.max_coord_vel for t in self.types))
             elif downwash_exchange not in ("allgather", "halo"):
                 raise ValueError(downwash_exchange)
-            self._downwash = Downwash(self.ctx, self.state, self._type_id, dist, halo=halo, split=downwash_split)
+            # downwash_keep = K: one neighbour query in K makes per-cell candidate lists that the other K - 1 re-use on refreshed
+            # positions (downwash.Downwash, dsim_downwash_args.keep: exact for any motion; single-rank fleets at a density that takes the
+            # banded query, otherwise ignored).  None: the DSIM_DW_KEEP environment variable, else off.
+            if downwash_keep is None:
+                downwash_keep = int(os.environ.get("DSIM_DW_KEEP", "0"))
+                downwash_skin = float(os.environ.get("DSIM_DW_SKIN", downwash_skin))
+            self._downwash = Downwash(self.ctx, self.state, self._type_id, dist, halo=halo, split=downwash_split,
+                                      keep_lists=downwash_keep if halo is None else 0, keep_skin=downwash_skin)
             if self.n_act == 6 and defer_fallback:
                 # option (off by default): the WLS fallback pass of a step (normally an empty queue) runs on a side stream
                 # beside the NEXT step's neighbour query instead of between the two on one stream

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DSIM_ABI_VERSION 8
+#define DSIM_ABI_VERSION 9
 #define DSIM_MAX_ACT 6     /* actuators per vehicle (quad 4, morphing hexa 6) */
 #define DSIM_MAX_TYPES 8
 
@@ -473,7 +473,28 @@ typedef struct dsim_downwash_args {
                                (receiver, candidate) pairs whose term the query's loops evaluate in this call — the unit of
                                the query's vector-pipe roofline (bench.py, config 5).  Bucket form only; one atomic per
                                receiver group when given, one scalar test when not                                        */
+  /* -- kept candidate lists (no counterpart in the reference, whose loop is O(N^2) per drone) ---------------------------------
+   * A fleet moves centimetres per Env.step, so WHICH candidates the receivers of a cell have to look at changes slowly.
+   * DSIM_DW_KEEP_BUILD: the query also writes, per cell, the list it worked out (receivers in height order, candidates in
+   * height-band order), with its reach and band tests widened by 2 keep_skin.  DSIM_DW_KEEP_REUSE: the query reads the lists of
+   * the last BUILD call on this grid, gathers the CURRENT positions and goes straight to the pair loops; nothing is binned — a
+   * dsim_step that is given this block as bin_next refreshes the positions instead (and saves the atomic round trip for a bucket
+   * slot).  EXACT for any motion: every pair is still tested against the cut-off and the height order on current positions;
+   * a drone that has moved further than keep_skin from where it was at the BUILD leaves the lists for the overflow list, which
+   * every receiver scans, and is served where it is now.  How often to BUILD is the caller's choice (performance only: the
+   * more drones have left the skin, the longer the overflow scan).  Honoured where dsim_downwash_keep_ok() != 0 (the world is
+   * this fleet alone: pos_all = NULL, no halo plan; bucket form at a density that takes the banded query; cells of
+   * 5 m + keep_skin or more, so that two rings of cells cover the widened reach), otherwise ignored; a REUSE without usable
+   * lists (none made yet, another grid or fleet size) is answered as a BUILD.  keep_ws: caller-owned,
+   * dsim_downwash_keep_workspace(n_pad, nx, ny) int32 entries, owned by the library between a BUILD and the last REUSE. */
+  int32_t  keep;            /* DSIM_DW_KEEP_* */
+  float    keep_skin;       /* metres, > 0 */
+  int32_t* keep_ws;
+  int64_t  keep_ws_len;
 } dsim_downwash_args;
+enum { DSIM_DW_KEEP_OFF = 0, DSIM_DW_KEEP_BUILD = 1, DSIM_DW_KEEP_REUSE = 2 };
+int64_t dsim_downwash_keep_workspace(int64_t n_pad, int32_t nx, int32_t ny);
+int     dsim_downwash_keep_ok(int64_t m, int32_t nx, int32_t ny, float cell, float keep_skin);
 int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny);
 
 /* ---- halo exchange of a spatially sharded fleet (BASELINE config 5: slabs along x, one rank per GPU) -----------------
@@ -563,8 +584,12 @@ int dsim_noise_draw(dsim_ctx* ctx, void* stream, int64_t n, int64_t n_pad, int32
  *   DSIM_Q_GROUND_CONTACTS  drone x Env.steps that ended with the vehicle's collision cylinder at or below z = 0, where
  *                         PyBullet's ground plane would have acted (see dsim_type_params.collision_radius)
  *   DSIM_Q_HALO_OVERFLOW  positions dsim_halo_pack selected but could not ship (send_cap too small), or received
- *                         headers that announced more than recv_cap: the force of that step may have missed pairs   */
-enum { DSIM_Q_WLS_FALLBACKS = 0, DSIM_Q_WLS_FAILURES = 1, DSIM_Q_GROUND_CONTACTS = 2, DSIM_Q_HALO_OVERFLOW = 3 };
+ *                         headers that announced more than recv_cap: the force of that step may have missed pairs
+ *   DSIM_Q_DW_REUSES      dsim_downwash calls answered from kept candidate lists (dsim_downwash_args.keep)
+ *   DSIM_Q_DW_MOVERS      overflow-list entries those calls found, summed: drones that had left the lists' skin (performance
+ *                         only — results do not depend on it; / DSIM_Q_DW_REUSES = the mean length every receiver scanned)      */
+enum { DSIM_Q_WLS_FALLBACKS = 0, DSIM_Q_WLS_FAILURES = 1, DSIM_Q_GROUND_CONTACTS = 2, DSIM_Q_HALO_OVERFLOW = 3,
+       DSIM_Q_DW_REUSES = 4, DSIM_Q_DW_MOVERS = 5 };
 int dsim_query(dsim_ctx* ctx, void* stream, int32_t what, int64_t* value_out);
 
 /* error codes */

@@ -1,0 +1,239 @@
+"""Kept candidate lists of the neighbour downwash (dsim_downwash_args.keep; formula P8, BaseAviary.py:1736-1763): one BUILD
+query writes per-cell candidate lists, the REUSE queries that follow gather current positions and run the pair loops only.
+The claim under test is EXACTNESS FOR ANY MOTION: whatever the drones did since the BUILD — crept inside the skin, swapped
+heights, jumped across the world, left the grid, became NaN, crowded into one cell — the force equals the brute-force sum of
+the oracle on the CURRENT positions, at the same bar as the plain query."""
+import numpy as np
+import pytest
+import torch
+
+from dronesim_amd import params
+from oracle import oracle as orc
+from tests.util import assert_downwash, f32, random_fleet
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device; the product has no CPU fallback")
+    from dronesim_amd import _native as nat
+    from dronesim_amd import fleet
+    return nat, fleet
+
+
+def _world(rng, n, side, zmax=20.5):
+    rigid, mem, _ = random_fleet(rng, n, n_act=6)
+    rigid[:, 0] = f32(rng.uniform(0, side, n)); rigid[:, 1] = f32(rng.uniform(0, side, n)); rigid[:, 2] = f32(rng.uniform(0.5, zmax, n))
+    return rigid, mem
+
+
+def _setup(gpu, n, side, seed, keep=8, skin=0.25, zmax=20.5, patch=None):
+    nat, fleet = gpu
+    from dronesim_amd.downwash import Downwash
+    types = [params.builtin_type("robobee"), params.builtin_type("hexa_6DOF")]
+    ctx = fleet.Context(types)
+    st = fleet.FleetState(ctx, n)
+    rng = np.random.default_rng(seed)
+    rigid, mem = _world(rng, n, side, zmax)
+    if patch is not None:
+        k, lo, hi = patch
+        rigid[:k, 0] = f32(rng.uniform(lo, hi, k)); rigid[:k, 1] = f32(rng.uniform(lo, hi, k))
+    st.load_aos(rigid, mem)
+    tid = (rng.random(n) < 0.5).astype(np.uint8)
+    tid_dev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device); tid_dev[:n] = torch.from_numpy(tid)
+    dw = Downwash(ctx, st, tid_dev, keep_lists=keep, keep_skin=skin)
+    return nat, ctx, st, dw, types, tid, rigid, rng
+
+
+def _check(label, dw, st, types, tid, pos, n):
+    """moves the fleet to `pos` (a host write: nothing refreshed the lists' positions, the query does it itself) and compares"""
+    pos = f32(pos)                    # (what the device holds: the callers add to their copy in fp64)
+    st.set_fields(0, torch.from_numpy(np.ascontiguousarray(pos.T)).float())
+    f = dw.compute().cpu().numpy()
+    rigid = np.zeros((n, 13)); rigid[:, 0:3] = pos
+    finite = np.isfinite(pos).all(1)
+    ref = orc.Oracle(types).downwash(rigid[finite], pos[finite], type_id=tid[finite])
+    assert_downwash(label, f[2, :n][finite], ref, types, tid[finite], pos[finite], pos[finite])
+    assert np.all(f[2, :n][~finite] == 0.0) and np.all(f[0:2, :n] == 0.0)
+    return ref
+
+
+def _reuses(nat, ctx):
+    return ctx.query(nat.QUERY_DW_REUSES), ctx.query(nat.QUERY_DW_MOVERS)
+
+
+def test_reuse_equals_bruteforce_through_every_kind_of_motion(gpu):
+    n, side = 5200, 80.0                                                                  # 0.8 drones per m^2: the banded query
+    nat, ctx, st, dw, types, tid, rigid, rng = _setup(gpu, n, side, 41)
+    pos = rigid[:, 0:3].astype(np.float64).copy()
+    pos = f32(pos)
+    _check("kept lists: the BUILD query", dw, st, types, tid, pos, n)
+    assert dw._last.cell == 5.25 and dw._last.keep == nat.DW_KEEP_REUSE                   # what the next query will be
+    assert _reuses(nat, ctx) == (0, 0)
+    # 1: everybody creeps inside the skin (|d| <= 0.24 m in total over three queries), heights reshuffle locally
+    for k in range(3):
+        pos = f32(pos + rng.uniform(-0.045, 0.045, pos.shape))
+        _check(f"kept lists: creep {k}", dw, st, types, tid, pos, n)
+    r, m = _reuses(nat, ctx)
+    assert r == 3 and m == 0
+    # 1b: a dozen leave the skin: the movers ride in front of every workgroup's tile
+    pos = pos.copy()
+    pos[700:712] += f32(rng.uniform(0.3, 0.9, (12, 3)))
+    pos[712:720, 0:2] = f32([12.0, 60.0]) + f32(rng.uniform(0, 2, (8, 2)))                # eight of them meet in one cell
+    _check("kept lists: a few movers", dw, st, types, tid, pos, n)
+    r, m = _reuses(nat, ctx)
+    assert r == 4 and m == 20
+    # 2: some leave the skin by a little, some jump across the world, some leave the grid, two swap places, one is NaN
+    pos = pos.copy()
+    pos[10:30] += f32(rng.uniform(0.3, 0.6, (20, 3)))
+    pos[100:110, 0:2] = f32(rng.uniform(0, side, (10, 2)))
+    pos[200:204, 0] = f32([-40.0, side + 55.0, -3.0, side + 7.0]); pos[204, 1] = -25.0
+    pos[[300, 301]] = pos[[301, 300]]
+    pos[400] = np.nan
+    pos[500:520, 2] = f32(rng.uniform(0.5, 20.5, 20))                                     # new heights: the band order is stale
+    _check("kept lists: movers", dw, st, types, tid, pos, n)
+    r, m = _reuses(nat, ctx)
+    assert r == 5 and 20 + 70 <= m <= 20 + 90
+    # 3: many movers (more than the tile keeps in front): the overflow list is read from memory, in batches
+    pos = pos.copy()
+    pos[1000:1400, 0:2] += f32(rng.uniform(-3, 3, (400, 2)))
+    pos[400] = pos[401] + f32([0.0, 0.0, 0.5])                                             # back from NaN, right above a neighbour
+    _check("kept lists: many movers", dw, st, types, tid, pos, n)
+    # 4: thirty-odd of them in ONE cell, above and below its residents
+    pos = pos.copy()
+    pos[2000:2040, 0:2] = f32([41.0, 41.0]) + f32(rng.uniform(0, 3, (40, 2)))
+    _check("kept lists: a crowd arrives in one cell", dw, st, types, tid, pos, n)
+    r, m = _reuses(nat, ctx)
+    assert r == 7 and dw._last.keep == nat.DW_KEEP_BUILD
+    # the ninth query BUILDs again: everybody is back in a list
+    _check("kept lists: rebuilt", dw, st, types, tid, pos, n)
+    assert _reuses(nat, ctx) == (7, m)
+    pos = f32(pos + rng.uniform(-0.02, 0.02, pos.shape))
+    _check("kept lists: after the rebuild", dw, st, types, tid, pos, n)
+    assert _reuses(nat, ctx) == (8, m)                                                     # nobody outside the new skin
+    ctx.close()
+
+
+@pytest.mark.parametrize("heights", ["flat", "two_layers", "ties"])
+def test_reuse_with_degenerate_heights(gpu, heights):
+    n, side = 5200, 80.0
+    nat, ctx, st, dw, types, tid, rigid, rng = _setup(gpu, n, side, {"flat": 5, "two_layers": 6, "ties": 7}[heights])
+    z = {"flat": np.full(n, 3.0), "two_layers": np.where(rng.random(n) < 0.5, 2.0, 2.5) + rng.uniform(0, 1e-3, n),
+         "ties": np.round(rng.uniform(0.5, 6.5, n) * 2) / 2}[heights]
+    pos = f32(rigid[:, 0:3]); pos[:, 2] = f32(z)
+    _check(f"kept lists[{heights}]: build", dw, st, types, tid, pos, n)
+    for k in range(3):
+        pos = pos.copy()
+        pos[:, 0:2] += f32(rng.uniform(-0.05, 0.05, (n, 2)))
+        if heights != "flat":
+            pos[:, 2] += f32(rng.choice([-0.05, 0.0, 0.05], n))                           # ties break and re-form
+        ref = _check(f"kept lists[{heights}]: reuse {k}", dw, st, types, tid, pos, n)
+        assert (np.abs(ref).max() == 0.0) == (heights == "flat")
+    assert _reuses(nat, ctx)[0] == 3
+    ctx.close()
+
+
+def test_crowded_neighbourhoods_leave_unbanded_lists_and_full_buckets(gpu):
+    """1 500 of 4 000 drones in a 24 m square (2.6 per m^2: more than the banded tile holds, cells with more drones than
+    a bucket: those sit in the overflow list from the BUILD on) — the lists of that corner are unbanded and longer than one fill."""
+    n, side = 4000, 70.0
+    nat, ctx, st, dw, types, tid, rigid, rng = _setup(gpu, n, side, 43, patch=(1500, 20.0, 44.0))
+    pos = f32(rigid[:, 0:3])
+    _check("kept lists crowded: build", dw, st, types, tid, pos, n)
+    for k in range(3):
+        pos = f32(pos + rng.uniform(-0.06, 0.06, pos.shape))
+        if k == 1:
+            pos[0:12, 0:2] += f32([9.0, -7.0])                                            # residents of the crowd move house
+        _check(f"kept lists crowded: reuse {k}", dw, st, types, tid, pos, n)
+    r, m = _reuses(nat, ctx)
+    assert r == 3 and m > 3 * 100                                                          # the buckets' overflow is there every time
+    ctx.close()
+
+
+def test_empty_cells_and_a_sparse_rim(gpu):
+    """A fleet with a hole in the middle and stragglers far outside: cells without receivers make lists too, and a drone
+    that flies into one (or beyond the grid) is served there."""
+    n, side = 5200, 80.0
+    nat, ctx, st, dw, types, tid, rigid, rng = _setup(gpu, n, side, 44)
+    pos = f32(rigid[:, 0:3])
+    hole = (np.abs(pos[:, 0] - 40) < 9) & (np.abs(pos[:, 1] - 40) < 9)
+    pos[hole, 0] += 18.5
+    pos[:6, 0:2] = f32([[-11, -11], [93, 40], [40, 94], [-9, 88], [91, 92], [40, -10]])     # (beyond the cut-off from everybody)
+    _check("kept lists hole: build", dw, st, types, tid, pos, n)
+    pos = pos.copy()
+    pos[50:58, 0:2] = f32([40.0, 40.0]) + f32(rng.uniform(-4, 4, (8, 2)))                 # into the hole
+    pos[58:60, 0:2] = f32([[-12.5, -11.5], [99, 44]])                                      # out to the stragglers, one beyond the grid
+    pos[0, 0:2] = f32([40.0, 41.0])                                                       # a straggler comes home
+    _check("kept lists hole: arrivals", dw, st, types, tid, pos, n)
+    pos = f32(pos + rng.uniform(-0.03, 0.03, pos.shape))
+    _check("kept lists hole: reuse 2", dw, st, types, tid, pos, n)
+    assert _reuses(nat, ctx)[0] == 2
+    ctx.close()
+
+
+def _fly(gpu, keep, steps, planted, sub=1):
+    from dronesim_amd.envs import CtrlAviary, Physics
+    from dronesim_amd.fleet import Targets
+    n = 4096
+    rng = np.random.default_rng(77)
+    xyz = np.stack([rng.uniform(0, 64, n), rng.uniform(0, 64, n), rng.uniform(0.5, 20.5, n)], 1)
+    if planted:          # near-vertical pairs a few millimetres apart in xy: the P8 term is singular, the lower drone is thrown out
+        for k in range(6):
+            xyz[2 * k + 1] = xyz[2 * k] + [1e-3 * (k + 1), 0.0, -(0.004 + 0.001 * k)]
+    tid = (np.arange(n) % 2).astype(np.uint8)
+    env = CtrlAviary(["robobee", "hexa_6DOF"], n, initial_xyzs=xyz, physics=Physics.PYB_DW, noise_seed=3, dict_io=False,
+                     type_ids=tid, aggregate_phy_steps=sub, downwash_keep=keep)
+    tg = Targets(env.ctx, n); tg.set(pos=f32(xyz).T, yaw=0.2)
+    out = []
+    for k in range(steps):
+        env.step_fused(tg)
+        if k % 5 == 4 or k == steps - 1:
+            out.append(env.state.rigid_aos().copy())
+    nat = gpu[0]
+    stats = (env.ctx.query(nat.QUERY_DW_REUSES), env.ctx.query(nat.QUERY_DW_MOVERS))
+    env.close()
+    return out, stats
+
+
+@pytest.mark.parametrize("planted", [False, True])
+def test_a_flight_with_kept_lists_is_the_flight_without(gpu, planted):
+    """Env-level: the step kernels refresh the lists' positions (no binning, no refresh launch); 23 Env.steps with one BUILD in
+    six against the same flight with a BUILD-free plain query every step.  The two differ by the order of a sum only."""
+    ref, s0 = _fly(gpu, 0, 23, planted)
+    got, s1 = _fly(gpu, 6, 23, planted)
+    assert s0 == (0, 0) and s1[0] == 23 - 4                                                # steps 0, 6, 12, 18 BUILD
+    if planted:
+        assert s1[1] > 10                                                                  # the ejected drones left the skin
+        v = np.abs(ref[-1][:12, 7:10]).max()
+        assert v > 5.0, v                                                                  # ... at speed
+    for a, b in zip(ref, got):
+        assert np.isfinite(b).all()
+        # (positions to a few ulp of 64 m, velocities to 1e-5 of the ejection speeds)
+        np.testing.assert_allclose(b[:, 0:3], a[:, 0:3], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(b[:, 7:10], a[:, 7:10], rtol=2e-4, atol=2e-4)
+
+
+def test_sub_stepped_flight_with_kept_lists(gpu):
+    """aggregate_phy_steps = 3: one query per physics SUB-step (the reference refreshes the positions per sub-step), every one of
+    them a link of the same BUILD / REUSE chain."""
+    ref, _ = _fly(gpu, 0, 8, False, sub=3)
+    got, s1 = _fly(gpu, 6, 8, False, sub=3)
+    assert s1[0] == 24 - 4
+    for a, b in zip(ref, got):
+        np.testing.assert_allclose(b[:, 0:3], a[:, 0:3], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(b[:, 7:10], a[:, 7:10], rtol=2e-4, atol=2e-4)
+
+
+def test_keep_is_ignored_where_the_lists_do_not_apply(gpu):
+    """a sparse world (the one-wave query), a world given as pos_all: plain queries, same results, no REUSE counted"""
+    nat, fleet = gpu
+    n, side = 3000, 300.0
+    nat, ctx, st, dw, types, tid, rigid, rng = _setup(gpu, n, side, 45)
+    pos = f32(rigid[:, 0:3])
+    for k in range(3):
+        pos = f32(pos + rng.uniform(-0.05, 0.05, pos.shape))
+        _check(f"kept lists sparse {k}", dw, st, types, tid, pos, n)
+    assert _reuses(nat, ctx) == (0, 0) and dw._last.keep == nat.DW_KEEP_OFF
+    ctx.close()
