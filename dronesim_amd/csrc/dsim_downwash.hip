@@ -173,7 +173,7 @@ __device__ __forceinline__ void dw_write(const DwK& a, long long i, float fz, in
 // band 0 behind band 1 instead of being dropped, cells without receivers make their list too (somebody may arrive), and seven
 // entries per thread wait in registers instead of six (the host makes the cells skin larger, so that two rings still cover the
 // widened reach).  A neighbourhood too full for the banded tile goes down the plain path and leaves an UNBANDED list (flags 0).
-#define DW_LBAND_MAX (DW_TILE_DENSE - DW_MOV_TILE - 2 * DW_LPB)      // candidates of a banded list (the REUSE tile's room)
+#define DW_LBAND_MAX (DW_TILE_DENSE - DW_MOV_TILE - 4 * DW_LPB)      // candidates of a banded list (the REUSE tile: list, sentinels, movers, sentinels)
 __device__ __forceinline__ int dw_block_cell(const BinK& b, int ncells, int c) {
   if (c < ncells && b.nx > 2 && b.ny > 2) {
     const int inx = b.nx - 2, n_in = inx * (b.ny - 2);
@@ -199,7 +199,6 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
                                                                                        // tile + this decide how many cells a CU holds: DW_TILE_DENSE)
   __shared__ float zlo[BAND ? DW_MAXG : 1];                                            // lowest receiver of every group
   __shared__ int wcnt[BAND ? TPB / 64 : 1][BAND ? DW_MAXG + 1 : 1];                    // entries per band, per wave
-  __shared__ int xcnt[KEEP ? TPB / 64 : 1], xfill;                                     // KEEP: entries beyond the list's table
   constexpr int RPB = TPB / DW_LPB;                                                    // receivers per pass
   const int ncells = b.nx * b.ny;
   const unsigned t = threadIdx.x;
@@ -372,7 +371,6 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
       int wave_cnt[DW_MAXG + 1];                                                       // wave-uniform
 #pragma unroll
       for (int k = 0; k <= DW_MAXG; ++k) wave_cnt[k] = 0;
-      int n_xtra = 0;
       // A candidate further than the cut-off from every point of THIS cell is useless to all of its receivers: the
       // 5 x 5 cells around a 5 m cell cover 625 m^2, the cell grown by 10 m 539 m^2 (the corner cells lose two thirds of
       // their area) — 14 % fewer pair evaluations for one distance test per candidate.  (Border cells also hold the
@@ -398,15 +396,12 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
 #pragma unroll
         for (int k = KEEP ? 0 : 1; k <= DW_MAXG; ++k)
           if (k <= G) wave_cnt[k] += (int)__popcll(__ballot(band == k));
-        // (entries in reach beyond the slots the list's table covers: kept as (bucket slot, tile position) pairs behind it)
-        if constexpr (KEEP) n_xtra += (int)__popcll(__ballot(band != 15 && (__float_as_int(ent[q].w) & (DW_CAP - 1)) >= DW_LSLOTS));
       }
       if (w == 0) rty[rank] = my_ty;
       if (KEEP && w == 0 && (int)lane < cnt_c) L[DW_LRTY + lane] = my_ty;
       if (lane == 0) {
 #pragma unroll
         for (int k = KEEP ? 0 : 1; k <= DW_MAXG; ++k) wcnt[w][k] = wave_cnt[k];
-        if constexpr (KEEP) { xcnt[w] = n_xtra; if (w == 0) xfill = 0; }
       }
       __syncthreads();
       constexpr int NWV = TPB / 64;
@@ -422,10 +417,9 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
       int kept = 0;
 #pragma unroll
       for (int k = DW_MAXG; k >= K0; --k) kept += wave_cnt[k];
-      if constexpr (KEEP) { n_xtra = 0; for (int v = 0; v < NWV; ++v) n_xtra += xcnt[v]; }
-      // (KEEP: a neighbourhood whose candidates in reach do not fit the REUSE tile, or the list's table, goes down the plain
-      // path — uniform, and the tile is still untouched)
-      if (!KEEP || (kept <= DW_LBAND_MAX && n_xtra <= DW_LXTRA)) {
+      // (KEEP: a neighbourhood whose candidates in reach do not fit the REUSE tile goes down the plain path — uniform, and the
+      // tile is still untouched)
+      if (!KEEP || kept <= DW_LBAND_MAX) {
       // bstart[k] = number of entries in bands above k; this wave's first slot in band k lies behind the lower waves' entries
       {
         int acc = 0;
@@ -434,8 +428,8 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
         if (t < 2 * DW_LPB) {                // sentinels behind the last band (below everything: no term), see the pair loop
           tpx[acc + (int)t] = 0.0f; tpy[acc + (int)t] = 0.0f; tpz[acc + (int)t] = -__builtin_inff();
         }
-        if (KEEP && t < DW_LHDR) {           // the list's header
-          int hv = t == 0 ? cnt_c : t == 1 ? kept : t == 2 ? G : t == 3 ? 1 : t == 12 ? n_xtra : 0;
+        if (KEEP && t < 16) {                // the list's header
+          int hv = t == 0 ? cnt_c : t == 1 ? kept : t == 2 ? G : t == 3 ? 1 : 0;
 #pragma unroll
           for (int k = 1; k <= DW_MAXG; ++k) hv = (int)t == 3 + k ? wave_cnt[k] : hv;
           L[t] = hv;
@@ -467,19 +461,13 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
         if constexpr (KEEP) {
           // the list: tile position of (neighbour k, slot s), -1 = not in reach; slots beyond the table as pairs behind it
           const int code = __float_as_int(ent[q].w), kk = code >> 6, ss = code & (DW_CAP - 1);
-          if ((int)t + q * TPB < total) {
-            if (ss < DW_LSLOTS) L[DW_LCAND + kk * DW_LSLOTS + ss] = placed;
-            else if (placed >= 0) {
-              const int x = atomicAdd(&xfill, 1);
-              L[DW_LXTRA0 + 2 * x] = nb_cell[kk] * DW_CAP + ss; L[DW_LXTRA0 + 2 * x + 1] = placed;
-            }
-          }
+          if ((int)t + q * TPB < total) reinterpret_cast<unsigned short*>(L + DW_LCAND)[kk * DW_CAP + ss] = (unsigned short)placed;   // (-1: 0xFFFF)
         }
       }
       if constexpr (KEEP) {          // the table's slots that no entry fills
-        for (int j = (int)t; j < DW_NBR * DW_LSLOTS; j += TPB) {
-          const int kk = j / DW_LSLOTS, ss = j - kk * DW_LSLOTS;
-          if (kk >= n_nb || ss >= nb_cnt[kk]) L[DW_LCAND + j] = -1;
+        for (int j = (int)t; j < DW_NBR * DW_CAP; j += TPB) {
+          const int kk = j / DW_CAP, ss = j - kk * DW_CAP;
+          if (kk >= n_nb || ss >= nb_cnt[kk]) reinterpret_cast<unsigned short*>(L + DW_LCAND)[j] = (unsigned short)0xFFFFu;
         }
       }
       __syncthreads();
@@ -548,7 +536,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
       L[DW_LRTY + t] = loc ? (a.type_id ? (int)a.type_id[i] : 0) : -1;
       if (loc) kp.pbuild[i] = make_float4(m2.x, m2.y, m2.z, __int_as_float(c * DW_CAP + (int)t));
     }
-    if (t < DW_LHDR) L[t] = t == 0 ? cnt_c : t == 1 ? total : t == 2 ? (cnt_c + DW_RPG - 1) / DW_RPG : 0;
+    if (t < 16) L[t] = t == 0 ? cnt_c : t == 1 ? total : t == 2 ? (cnt_c + DW_RPG - 1) / DW_RPG : 0;
   }
   // A pass serves TPB / 8 receivers with 8 lanes each; when fewer are left (a cell's last pass is half empty on
   // average) the lane groups are widened — 16, 32 or 64 lanes per receiver — so that the candidates are split over all
@@ -607,16 +595,23 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
 }
 
 // ---- REUSE query: the kept lists of an earlier BUILD query, current positions (dsim_kernels.h "kept candidate lists") ----
-// One workgroup per cell, as the BUILD query, and the same pair loops; in front of them TWO round trips and no arithmetic to
-// speak of: the list (header, receivers, the first 768 candidate indices from fixed addresses, the first overflow entries —
-// everything before anything waits), then the gather of the current positions straight into the tile.  The tile of the first
-// fill begins with the MOVERS (the overflow list: drones that have left the skin, z = -inf in fresh[]), padded to a trip of
-// sixteen, so that every group reads them like a band above all others — the common case, at most DW_MOV_TILE of them; more are
-// read from global memory inside the loops, as the BUILD query reads its overflow list.  A mover is served by the workgroup of
-// the cell it is in NOW (the receivers DW_CAP .. of this kernel, against the whole list: band 0 included), in batches of the
-// overflow list; a list longer than a tile (unbanded lists of crowded neighbourhoods) takes several fills, the partial sums wait
-// in LDS.  Neither happens in a fleet that keeps its density: they are what makes the result independent of every capacity.
-#define DW_KEPT_CHUNK (DW_TILE_DENSE - DW_MOV_TILE - 2 * DW_LPB)     // list entries per fill (= DW_LBAND_MAX: a banded list is one fill)
+// One workgroup per cell, as the BUILD query, and the same pair loops; in front of them loads whose addresses depend on nothing
+// loaded — the list's header and table, the bucket entries the table speaks of (refreshed in place by the steps), the cell's own
+// bucket (the receivers), the first overflow entries — and stores that put every candidate where the table says.  No counts, no
+// walk, no ranking, no reach test, no band placement.  Measured on a config-5 shard (65 536 drones, one per m^2; rocprofv3):
+// 27.7 us and 10.1 M vector instructions against the plain query's 30.1 us and 12.0 M, a BUILD 41.6 us; the step kernel that
+// refreshes instead of binning 10.5 us against 13.2 (no atomic round trip for a bucket slot).
+// A list longer than a tile (the unbanded lists of crowded neighbourhoods: bucket slots in list order) takes several fills of two
+// round trips each, the partial sums wait in LDS.
+// (Measured and rejected, round 6: ONE row per receiver — the tile positions of the candidates inside THAT receiver's widened
+// disc, uint16 pairs streamed from memory four trips ahead: 26 % fewer pair evaluations (16.0 M against 21.5 M), 4 % less time;
+// the per-lane LDS reads conflict four times as often, a BUILD took 67 us and the rows 57 KB a cell.  The table as one flat
+// index per thread: 35 vector instructions a slot, 2.2 M of 9 M — neighbour by wave and slot by lane makes all of it scalar.
+// The positions gathered from a per-drone array through an index list: a second, TA-bound round trip of 6.6 us.  All thirteen
+// neighbours of a wave in one go: 80 registers, six waves, 0.6 us.  Half of the workgroups held back so that their loads run
+// under the others' pair loops: longer by the delay, 3.4 us -> +1.6, 6.8 -> +4.6.)
+#define DW_KEPT_CHUNK DW_LBAND_MAX                                   // list entries per fill (a banded list is one fill)
+#define DW_MOV_AT (DW_TILE_DENSE - DW_MOV_TILE - 2 * DW_LPB)         // where the movers in reach ride in the tile: behind the list and its sentinels
 #define DW_KEPT_RECV (DW_CAP + DW_MOV_TILE)
 template <int TPB>
 __global__ __launch_bounds__(TPB, 7) void k_dw_query_kept(DwK a, BinK b, KeepK kp) {
@@ -629,8 +624,6 @@ __global__ __launch_bounds__(TPB, 7) void k_dw_query_kept(DwK a, BinK b, KeepK k
   float* const tpx = tp;
   float* const tpy = tp + DW_TILE_DENSE;
   float* const tpz = tp + 2 * DW_TILE_DENSE;
-  constexpr int NSLOT = DW_NBR * DW_LSLOTS;                                              // the table of a banded list
-  constexpr int EPT = (NSLOT + TPB - 1) / TPB;
   const int ncells = b.nx * b.ny;
   const unsigned t = threadIdx.x;
   {
@@ -646,31 +639,37 @@ __global__ __launch_bounds__(TPB, 7) void k_dw_query_kept(DwK a, BinK b, KeepK k
   const int sub8 = (int)(lane % DW_LPB), rg = (int)(lane / DW_LPB);
   // ---- the ONE round trip of a banded list: header, table and the bucket entries the table speaks of (addresses that depend on
   // nothing loaded), the cell's own bucket (the receivers), the first overflow entries, the types' coefficients ----
-  const int cnt_c = L[0], total = L[1], G = L[2], flags = L[3], n_xtra = L[12];
+  const int cnt_c = L[0], total = L[1], G = L[2], flags = L[3];
   int nbk[DW_MAXG + 1];
 #pragma unroll
   for (int k = 1; k <= DW_MAXG; ++k) nbk[k] = L[3 + k];
   const int n_ovf = b.count[ncells];
-  int tq[EPT];
-  float px[EPT], py[EPT], pz[EPT];
+  // The table of a banded list, by neighbour and bucket slot: neighbour 2 q + w is this WAVE's, the lane is the slot — which cell,
+  // whether it exists and both base addresses are scalar arithmetic (as one flat index per thread the same loads cost 35 vector
+  // instructions each: 2.2 M of a query's 9 M).  Thirteen neighbours in two halves: all at once are 65 registers.
+  constexpr int NQ = (DW_NBR + NW - 1) / NW, QA = (NQ + 1) / 2;
+  const unsigned short* __restrict__ const tab = reinterpret_cast<const unsigned short*>(L + DW_LCAND);
+  int tq[QA];
+  float px[QA], py[QA], pz[QA];
+  auto table_load = [&](int q0, int nq) {
 #pragma unroll
-  for (int q = 0; q < EPT; ++q) {
-    const int j = (int)t + q * TPB;
-    const int kk = j / DW_LSLOTS, ss = j - kk * DW_LSLOTS;
-    const int nxx = cx - 2 + kk % 5, nyy = cy - 2 + kk / 5;
-    const bool in = j < NSLOT && nxx >= 0 && nxx < b.nx && nyy >= 0 && nyy < b.ny;
-    tq[q] = -1; px[q] = py[q] = pz[q] = 0.0f;
-    if (in) {
-      tq[q] = L[DW_LCAND + j];
-      const float4 v = b.buckets[(long long)(nyy * b.nx + nxx) * DW_CAP + ss];
-      px[q] = v.x; py[q] = v.y; pz[q] = v.z;
+    for (int q = 0; q < QA; ++q) {
+      tq[q] = 0xFFFF; px[q] = py[q] = pz[q] = 0.0f;
+      const int kk = (q0 + q) * NW + w;
+      const int nxx = cx - 2 + kk % 5, nyy = cy - 2 + kk / 5;
+      if (q < nq && kk < DW_NBR && nxx >= 0 && nxx < b.nx && nyy >= 0 && nyy < b.ny) {     // (uniform)
+        tq[q] = tab[kk * DW_CAP + (int)lane];
+        const float* __restrict__ const v = reinterpret_cast<const float*>(b.buckets + (long long)(nyy * b.nx + nxx) * DW_CAP + lane);
+        px[q] = v[0]; py[q] = v[1]; pz[q] = v[2];                                          // (three dwords: the fourth would cost a register a slot)
+      }
     }
-  }
+  };
+  table_load(0, QA);
   float4 me0 = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
   int rrank = 0, rt = -1;
   if (t < DW_CAP) { me0 = b.buckets[(long long)c * DW_CAP + t]; rrank = L[DW_LRECV + t]; rt = L[DW_LRTY + t]; }
   float4 mv = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
-  if (t < DW_MOV_TILE && (long long)t < a.n) mv = b.overflow[t];                         // (speculative: the list holds a.n entries)
+  if (t < 64 && (long long)t < a.n) mv = b.overflow[t];                                  // (speculative: the list holds a.n entries)
   const int cty = min(TPB - 1 - (int)t, a.n_types - 1);                                  // the LAST lanes hold the types
   const DevType& CT = a.types[cty];
   const float c_dw0 = CT.dw[0], c_dw1 = CT.dw[1], c_dw2 = CT.dw[2], c_pr = CT.prop_radius;
@@ -679,29 +678,52 @@ __global__ __launch_bounds__(TPB, 7) void k_dw_query_kept(DwK a, BinK b, KeepK k
   }
   if (blockIdx.x == 0 && t == 0 && n_ovf > 0) atomicAdd(&kp.counters[5], (unsigned long long)n_ovf);      // DSIM_Q_DW_MOVERS
   const bool banded = (flags & 1) != 0;
-  const bool mov_lds = n_ovf <= DW_MOV_TILE;
-  const int P = mov_lds ? n_ovf : 0;                                                     // movers in front of the first fill
   const int nfills = (!banded && total > DW_KEPT_CHUNK) ? (total + DW_KEPT_CHUNK - 1) / DW_KEPT_CHUNK : 1;
-  const int nbatch = n_ovf > DW_MOV_TILE ? (n_ovf + DW_MOV_TILE - 1) / DW_MOV_TILE : 1;
-  // the movers of DW_MOV_TILE overflow entries that are in this cell now: receivers DW_CAP .. (one wave looks)
-  auto movers_here = [&](float4 e, int batch) {
-    const int k = batch * DW_MOV_TILE + (int)lane;
-    const long long i = (long long)__float_as_int(e.w) - a.local_offset;
-    const bool here = lane < DW_MOV_TILE && k < n_ovf && i >= 0 && i < a.n && bin_cell(b, e.x, e.y) == c;
-    const unsigned long long m = __ballot(here);
-    const int pos = (int)__popcll(m & ((1ULL << lane) - 1ULL)), cnt = (int)__popcll(m);
-    if (here) {
-      recv[DW_CAP + pos] = make_float4(e.x, e.y, e.z, __int_as_float((int)i));
-      rty[DW_CAP + pos] = a.type_id ? (int)a.type_id[i] : 0;
+  // ---- the MOVERS (the overflow list: drones that have left the skin), looked at by one wave.  As CANDIDATES they matter to this
+  // cell's receivers only from within the cut-off (+ the skin a receiver may have drifted out of its cell's box): those ride behind the
+  // list in the tile, DW_MOV_TILE of them — more are read from memory inside the loops, as the BUILD query reads its overflow list.
+  // As RECEIVERS they are served by the cell they are in NOW (receivers DW_CAP .. of this kernel, against the whole list: band 0
+  // included), DW_MOV_TILE a pass.  A fleet that keeps its density has a handful of either; the passes and the fall-back are what
+  // makes the result independent of every capacity. ----
+  const float cs = DSIM_RCP(b.inv_cell);
+  const float bx0 = cx == 0 ? -__builtin_inff() : b.xmin + (float)cx * cs, bx1 = cx == b.nx - 1 ? __builtin_inff() : b.xmin + (float)(cx + 1) * cs;
+  const float by0 = cy == 0 ? -__builtin_inff() : b.ymin + (float)cy * cs, by1 = cy == b.ny - 1 ? __builtin_inff() : b.ymin + (float)(cy + 1) * cs;
+  const float RN2 = (DW_CUTOFF + kp.skin + 1e-3f) * (DW_CUTOFF + kp.skin + 1e-3f);
+  auto movers = [&](int pass) {                      // (wave 0)
+    if (lane < DW_MOV_TILE) { rty[DW_CAP + lane] = -1; facc[DW_CAP + lane] = 0.0f; }
+    int seen = 0, near_n = 0;                        // (uniform)
+    for (int k0 = 0; k0 < n_ovf; k0 += 64) {
+      float4 e = mv;
+      if (k0 > 0) e = (k0 + (int)lane < n_ovf) ? b.overflow[k0 + lane] : make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+      const bool valid = k0 + (int)lane < n_ovf;
+      const long long i = (long long)__float_as_int(e.w) - a.local_offset;
+      if (pass == 0) {
+        const float ox = fmaxf(fmaxf(bx0 - e.x, e.x - bx1), 0.0f), oy = fmaxf(fmaxf(by0 - e.y, e.y - by1), 0.0f);
+        const bool near = valid && ox * ox + oy * oy < RN2;
+        const unsigned long long mn = __ballot(near);
+        const int at = near_n + (int)__popcll(mn & ((1ULL << lane) - 1ULL));
+        if (near && at < DW_MOV_TILE) { tpx[DW_MOV_AT + at] = e.x; tpy[DW_MOV_AT + at] = e.y; tpz[DW_MOV_AT + at] = e.z; }
+        near_n += (int)__popcll(mn);
+      }
+      const bool here = valid && i >= 0 && i < a.n && bin_cell(b, e.x, e.y) == c;
+      const unsigned long long mh = __ballot(here);
+      const int ord = seen + (int)__popcll(mh & ((1ULL << lane) - 1ULL)) - pass * DW_MOV_TILE;
+      if (here && ord >= 0 && ord < DW_MOV_TILE) {
+        recv[DW_CAP + ord] = make_float4(e.x, e.y, e.z, __int_as_float((int)i));
+        rty[DW_CAP + ord] = a.type_id ? (int)a.type_id[i] : 0;
+      }
+      seen += (int)__popcll(mh);
     }
-    if (lane < DW_MOV_TILE) {
-      if ((int)lane >= cnt) rty[DW_CAP + lane] = -1;
-      facc[DW_CAP + lane] = 0.0f;
+    if (pass == 0) {
+      if (lane < 2 * DW_LPB) {                       // sentinels behind the movers
+        const int at = DW_MOV_AT + min(near_n, DW_MOV_TILE) + (int)lane;
+        tpx[at] = 0.0f; tpy[at] = 0.0f; tpz[at] = -__builtin_inff();
+      }
+      if (lane == 0) { mv_n[0] = seen; mv_n[1] = near_n; }
     }
-    if (lane == 0) mv_n[batch & 1] = cnt;
   };
   if (w == 0) {
-    movers_here(mv, 0);
+    movers(0);
     // the list's receivers: a mover among them (z = -inf) is passed over here and served where it is now
     const bool real = (int)lane < cnt_c;
     const long long i = (long long)__float_as_int(me0.w) - a.local_offset;
@@ -711,43 +733,40 @@ __global__ __launch_bounds__(TPB, 7) void k_dw_query_kept(DwK a, BinK b, KeepK k
     } else rty[lane] = -1;                                                               // (ranks [0, cnt_c) are the receivers': the rest is nobody's)
     facc[lane] = 0.0f;
   }
-  // the movers, the sentinels and (banded) the candidates of the table go straight into the tile
-  if ((int)t < P) { tpx[t] = mv.x; tpy[t] = mv.y; tpz[t] = mv.z; }
+  // (banded) the candidates of the table go straight into the tile, the sentinels behind them
   int tile_holds = -1;                                                                   // which fill the tile holds (uniform)
   if (banded) {
-    if (t < 2 * DW_LPB) { tpx[P + total + (int)t] = 0.0f; tpy[P + total + (int)t] = 0.0f; tpz[P + total + (int)t] = -__builtin_inff(); }
+    if (t < 2 * DW_LPB) { tpx[total + (int)t] = 0.0f; tpy[total + (int)t] = 0.0f; tpz[total + (int)t] = -__builtin_inff(); }
 #pragma unroll
-    for (int q = 0; q < EPT; ++q)
-      if (tq[q] >= 0) { tpx[P + tq[q]] = px[q]; tpy[P + tq[q]] = py[q]; tpz[P + tq[q]] = pz[q]; }
-    for (int x = (int)t; x < n_xtra; x += TPB) {                                         // (rare: a second trip for slots beyond the table)
-      const float4 v = b.buckets[L[DW_LXTRA0 + 2 * x]];
-      const int at = P + L[DW_LXTRA0 + 2 * x + 1];
-      tpx[at] = v.x; tpy[at] = v.y; tpz[at] = v.z;
+    for (int q = 0; q < QA; ++q)
+      if (tq[q] != 0xFFFF) { tpx[tq[q]] = px[q]; tpy[tq[q]] = py[q]; tpz[tq[q]] = pz[q]; }
+    if constexpr (QA < NQ) {
+      table_load(QA, NQ - QA);
+#pragma unroll
+      for (int q = 0; q < QA; ++q)
+        if (tq[q] != 0xFFFF) { tpx[tq[q]] = px[q]; tpy[tq[q]] = py[q]; tpz[tq[q]] = pz[q]; }
     }
     tile_holds = 0;
   }
-  for (int batch = 0; batch < nbatch; ++batch) {
-    if (batch > 0 && w == 0) {
-      const int k = batch * DW_MOV_TILE + (int)lane;
-      movers_here((lane < DW_MOV_TILE && k < n_ovf) ? b.overflow[k] : make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1)), batch);
-    }
+  int npass = 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    if (pass > 0 && w == 0) movers(pass);
     __syncthreads();
-    const int mvn = __builtin_amdgcn_readfirstlane(mv_n[batch & 1]);
-    const int Gr = batch == 0 ? (cnt_c + DW_RPG - 1) / DW_RPG : 0, Gm = (mvn + DW_RPG - 1) / DW_RPG, Gt = Gr + Gm;
+    const int mv_here = __builtin_amdgcn_readfirstlane(mv_n[0]), mv_near = __builtin_amdgcn_readfirstlane(mv_n[1]);
+    npass = max(1, (mv_here + DW_MOV_TILE - 1) / DW_MOV_TILE);
+    const bool mov_lds = mv_near <= DW_MOV_TILE;
+    const int mvn = min(max(mv_here - pass * DW_MOV_TILE, 0), DW_MOV_TILE);
+    const int Gr = pass == 0 ? (cnt_c + DW_RPG - 1) / DW_RPG : 0, Gm = (mvn + DW_RPG - 1) / DW_RPG, Gt = Gr + Gm;
     for (int f = 0; f < (Gt > 0 ? nfills : 0); ++f) {                                    // (Gt == 0: nobody to serve — uniform)
       const int lo = f * DW_KEPT_CHUNK, len = banded ? total : min(total - lo, DW_KEPT_CHUNK);   // this fill's piece of the list
-      const int P_f = f == 0 ? P : 0;
       if (tile_holds != f) {                                                             // (unbanded lists: bucket slots, two trips a fill)
         if (tile_holds >= 0) __syncthreads();                                            // the previous tile is done with
         tile_holds = f;
         for (int e = (int)t; e < len; e += TPB) {
           const float4 v = b.buckets[L[DW_LCAND + lo + e]];
-          tpx[P_f + e] = v.x; tpy[P_f + e] = v.y; tpz[P_f + e] = v.z;
+          tpx[e] = v.x; tpy[e] = v.y; tpz[e] = v.z;
         }
-        if (f == 0 && (int)t < P_f) { tpx[t] = mv.x; tpy[t] = mv.y; tpz[t] = mv.z; }
-        if (t < 2 * DW_LPB) {                                                            // sentinels behind the last entry
-          tpx[P_f + len + (int)t] = 0.0f; tpy[P_f + len + (int)t] = 0.0f; tpz[P_f + len + (int)t] = -__builtin_inff();
-        }
+        if (t < 2 * DW_LPB) { tpx[len + (int)t] = 0.0f; tpy[len + (int)t] = 0.0f; tpz[len + (int)t] = -__builtin_inff(); }   // sentinels behind the last entry
         __syncthreads();
       }
       // ---- the groups: the list's in snake order over the waves, then the movers' ----
@@ -762,7 +781,8 @@ __global__ __launch_bounds__(TPB, 7) void k_dw_query_kept(DwK a, BinK b, KeepK k
 #pragma unroll
           for (int k = 1; k <= DW_MAXG; ++k) llim += (k > gq && k <= G) ? nbk[k] : 0;
         }
-        const int lim = P_f + min(max(llim - lo, 0), len);
+        const int lim = min(max(llim - lo, 0), len);
+        const int mlim = (f == 0 && mov_lds) ? mv_near : 0;                              // the movers in reach, behind the list
         const float4 me = recv[r];
         const int ty = rty[r];
         const bool have = ty >= 0;
@@ -778,12 +798,18 @@ __global__ __launch_bounds__(TPB, 7) void k_dw_query_kept(DwK a, BinK b, KeepK k
             fz = dw_pair_acc(p0, me.x, me.y, me.z, d1s, d2s, fz);
             fz = dw_pair_acc(p1, me.x, me.y, me.z, d1s, d2s, fz);
           }
+          for (int base = 0; base < mlim; base += 2 * DW_LPB) {
+            const int e0 = DW_MOV_AT + base + sub8;
+            fz = dw_pair_acc(make_float4(tpx[e0], tpy[e0], tpz[e0], 0.0f), me.x, me.y, me.z, d1s, d2s, fz);
+            fz = dw_pair_acc(make_float4(tpx[e0 + DW_LPB], tpy[e0 + DW_LPB], tpz[e0 + DW_LPB], 0.0f), me.x, me.y, me.z, d1s, d2s, fz);
+          }
           if (!mov_lds && f == 0)
             for (int k = sub8; k < n_ovf; k += DW_LPB) fz += dw_pair(b.overflow[k], me.x, me.y, me.z, 1.0f, d1, d2c);
         }
         if (a.pairs) {
           const int served = (int)__popcll(__ballot(have && sub8 == 0));
-          if (lane == 0) atomicAdd(a.pairs, (unsigned long long)served * (unsigned long long)(((lim + 2 * DW_LPB - 1) / (2 * DW_LPB)) * (2 * DW_LPB) + ((!mov_lds && f == 0) ? n_ovf : 0)));
+          const int ev = ((lim + 2 * DW_LPB - 1) / (2 * DW_LPB) + (mlim + 2 * DW_LPB - 1) / (2 * DW_LPB)) * (2 * DW_LPB) + ((!mov_lds && f == 0) ? n_ovf : 0);
+          if (lane == 0) atomicAdd(a.pairs, (unsigned long long)served * (unsigned long long)ev);
         }
 #pragma unroll
         for (int off = DW_LPB / 2; off > 0; off >>= 1) fz += __shfl_xor(fz, off);
@@ -793,7 +819,7 @@ __global__ __launch_bounds__(TPB, 7) void k_dw_query_kept(DwK a, BinK b, KeepK k
         }
       }
     }
-    if (nbatch > 1) __syncthreads();                                                     // the next batch rewrites the movers' receivers
+    if (npass > 1) __syncthreads();                                                      // the next pass rewrites the movers' receivers
   }
 }
 // the refresh a REUSE query needs when no step kernel has made it (BinK.pbuild): the local drones' current positions

@@ -120,35 +120,33 @@ struct BinK {
   float xmin, ymin, inv_cell;
   int nx, ny;
   long long local_offset;   // world index of local drone 0
-  // Kept candidate lists (dsim_downwash_args.keep, DW_KEEP below): the NEXT query re-uses the lists of an earlier one, so this
-  // step does not bin.  It REFRESHES: fresh[i] = the new position, and a drone that has moved further than the lists' skin from
-  // where it was when they were made (pbuild[i]) leaves them — z = -inf in fresh[] (as a candidate it is above nobody, as a
-  // receiver its cell passes it over) and an entry in the overflow list, which every receiver scans and whose members are
-  // served where they are NOW.  The fresh position goes where the drone's entry was when the lists were made: its slot of
-  // `buckets` (pbuild[i].w; -1: it had none).  null = the step bins.
+  // Kept candidate lists (dsim_downwash_args.keep, "kept candidate lists" below): the NEXT query re-uses the lists of an earlier
+  // one, so this step does not bin.  It REFRESHES: the drone's new position goes where its entry was when the lists were made —
+  // its slot of `buckets` (pbuild[i].w; -1: it had none) — and a drone that has moved further than the lists' skin from where it
+  // was then (pbuild[i]) leaves them: z = -inf in its slot (as a candidate it is above nobody, as a receiver its cell passes it
+  // over) and an entry in the overflow list, whose members are candidates wherever they are in reach and are served by the cell
+  // they are in NOW.  null = the step bins.
   const float4* pbuild;     // [n_pad] (x, y, z when the lists were made, bucket slot as int bits)
   float skin2;              // skin^2
 };
 // ---- kept candidate lists ----------------------------------------------------------------------------
 // A fleet moves centimetres per Env.step: which candidates a cell's receivers have to look at, and in which height band each lies,
-// changes slowly.  A BUILD query (the banded cell-centred query, with its reach and band tests widened by the skin) writes, per
-// cell, what it worked out — the receivers in height order with their types, the candidates in band order (band 0, below every
-// receiver, included: a drone that arrives later may need it) — and the following REUSE queries read that list, gather the
-// CURRENT positions and go straight to the pair loops: no bucket counts, no address walk, no ranking, no reach test, no band
-// placement (4.2 M of the 12 M vector instructions of a config-5 query) and, in the step kernel, no atomic round trip for a bucket
-// slot.  Exact for ANY motion: every pair is still tested against the cut-off and the height order on current positions; the lists
-// only have to be SUPERSETS, which the skin guarantees for drones that stayed within it and the overflow list for those that
-// did not.  Layout of a cell's list (int32 words):
-#define DW_LHDR 16                        // [0] receivers [1] candidates in the tile [2] groups G [3] flags (1: banded) [4..11] band 1..8 totals [12] pairs behind the table
+// changes slowly.  A BUILD query (the banded cell-centred query, with its reach and band tests widened by twice the skin) writes, per
+// cell, what it worked out — for every slot of the cell's own bucket the receiver's place in height order and its type, for every
+// slot of the 25 neighbouring buckets the candidate's place in the tile (band 0, below every receiver, included: a drone that
+// arrives later may need it) — and the following REUSE queries (k_dw_query_kept) load the table and the buckets side by side and go
+// straight to the pair loops.  The steps in between keep the buckets current (BinK.pbuild above).  Exact for ANY motion: every pair
+// is still tested against the cut-off and the height order on current positions; the lists only have to be SUPERSETS, which the
+// skin guarantees for drones that stayed within it and the overflow list for those that did not.  A cell's list (int32 words):
+#define DW_LHDR 16                        // [0] receivers [1] candidates in the tile [2] groups G [3] flags (1: banded) [4..11] band 1..8 totals
 #define DW_LRECV DW_LHDR                  // [DW_CAP] slot of the cell's own bucket -> the receiver's place in height order
 #define DW_LRTY (DW_LHDR + DW_CAP)        // [DW_CAP] slot -> type
-#define DW_LCAND (DW_LHDR + 2 * DW_CAP)   // banded: [25][DW_LSLOTS] (neighbour, slot) -> place in the tile (bands G .. 1, then 0), -1: not in reach;
-#define DW_LSLOTS 48                      //   then up to DW_LXTRA (bucket slot, place) pairs for slots >= DW_LSLOTS.  The positions themselves stay
-#define DW_LXTRA0 (DW_LCAND + 25 * DW_LSLOTS)   //   in the grid's BUCKETS, refreshed in place by the steps: a REUSE query's loads depend on nothing
-#define DW_LXTRA 64                       //   it has to wait for — ONE round trip to the pair loops.  Unbanded (crowded neighbourhoods): [<= DW_LCAP]
+#define DW_LCAND (DW_LHDR + 2 * DW_CAP)   // banded: uint16 [25][DW_CAP] (neighbour, bucket slot) -> place in the tile (bands G .. 1, then 0), 0xFFFF: not in
+                                          //   reach.  The positions themselves stay in the grid's BUCKETS, refreshed in place by the steps: what a
+                                          //   REUSE query loads depends on nothing it has to wait for.  Unbanded (crowded neighbourhoods): [<= DW_LCAP]
 #define DW_LCAP (25 * DW_CAP)             //   bucket slots of every entry of the 5 x 5 cells, any order
 #define DW_LSTRIDE (DW_LCAND + DW_LCAP)
-#define DW_MOV_TILE 32                    // overflow entries (movers) a REUSE workgroup keeps in front of its tile
+#define DW_MOV_TILE 32                    // movers (overflow entries) in reach of a cell that a REUSE workgroup keeps in its tile
 struct KeepK {
   int* lists;               // [ncells][DW_LSTRIDE]
   float4* pbuild;           // [n_pad] positions when the lists were made (NaN: never in a list), .w = the drone's bucket slot

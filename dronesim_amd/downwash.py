@@ -337,7 +337,7 @@ class Downwash:
 
     def __init__(self, ctx, state, type_id: Optional[torch.Tensor] = None, dist=None, cell: Optional[float] = None,
                  box_refresh: int = 256, halo: Optional[HaloPlan] = None, split: Optional[bool] = None,
-                 keep_lists: int = 0, keep_skin: float = 0.25):
+                 keep_lists: int = 0, keep_skin: float = 0.1):
         # cell = None: 5 m cells (half the cut-off, 5 x 5 cells scanned per drone: 30 % fewer candidate pairs than
         # 3 x 3 cells of 10 m) whenever the world's shape takes the bucket form of the grid, 10 m cells otherwise
         self.ctx, self.state, self.type_id, self.dist = ctx, state, type_id, dist

@@ -109,7 +109,7 @@ class CtrlAviary(PlacedFleetArrays, FleetObservation):
         dyn_ang_vel: str = "reference",
         noise: str = "auto",
         downwash_keep: Optional[int] = None,
-        downwash_skin: float = 0.25,
+        downwash_skin: float = 0.1,
     ):
         if gui or record or obstacles:
             raise NotImplementedError("gui/record/obstacles are rendering features outside the hot path")
@@ -290,9 +290,9 @@ class CtrlAviary(PlacedFleetArrays, FleetObservation):
                 raise ValueError(downwash_exchange)
             # downwash_keep = K: one neighbour query in K makes per-cell candidate lists that the other K - 1 re-use on refreshed
             # positions (downwash.Downwash, dsim_downwash_args.keep: exact for any motion; single-rank fleets at a density that takes the
-            # banded query, otherwise ignored).  None: the DSIM_DW_KEEP environment variable, else off.
+            # banded query, otherwise ignored).  0 or 1: off.  None: the DSIM_DW_KEEP environment variable, else 32.
             if downwash_keep is None:
-                downwash_keep = int(os.environ.get("DSIM_DW_KEEP", "0"))
+                downwash_keep = int(os.environ.get("DSIM_DW_KEEP", "32"))
                 downwash_skin = float(os.environ.get("DSIM_DW_SKIN", downwash_skin))
             self._downwash = Downwash(self.ctx, self.state, self._type_id, dist, halo=halo, split=downwash_split,
                                       keep_lists=downwash_keep if halo is None else 0, keep_skin=downwash_skin)
