@@ -137,7 +137,7 @@ class Fleet:
 
     def __init__(self, n_fleet, replicas, device, substeps, layout, noise_seed, waypoints=False, n_steps=1,
                  config5=False, dist=None, rank=0, chained=False, hexa=False, mixed=False, options=0, slab_m=128.0, storage=None,
-                 dyn=False):
+                 dyn=False, dw_keep=None):
         import torch
         from dronesim_amd.envs import CtrlAviary, Physics
         from dronesim_amd.fleet import Targets, WaypointTargets
@@ -184,7 +184,7 @@ class Fleet:
                               downwash_split={"": None, "0": False, "1": True}[os.environ.get("DSIM_DW_SPLIT", "")],
                               defer_fallback=os.environ.get("DSIM_DEFER_FB", "0") != "0",
                               placement=os.environ.get("DSIM_PLACEMENT", "0") != "0",
-                              dyn_ang_vel="body_rates" if dyn else "reference")
+                              dyn_ang_vel="body_rates" if dyn else "reference", downwash_keep=dw_keep)
         if waypoints:
             self.tgt = WaypointTargets(self.env.ctx, self.n, g["target_pos"], g["target_vel"], g["target_acc"],
                                        g["target_yaw"], wp_counters=wp0, offsets=off)
@@ -708,18 +708,22 @@ def valu_roofline(torch, fl, chain_s):
     useful = useful_pairs(torch, pos)
     dwn.count_pairs(True)
     fl.env._fused_plan_dw = None
+    fl.step()                              # (with kept lists: the query that makes them — the ones that follow are the common case)
+    torch.cuda.synchronize()
+    first = int(dwn.pair_counter.item())
     fl.step()
     torch.cuda.synchronize()
-    evaluated = int(dwn.pair_counter.item())
+    evaluated = int(dwn.pair_counter.item()) - first
     dwn.count_pairs(False)
     fl.env._fused_plan_dw = None
     achieved = useful / chain_s
     return {"bound": "valu", "achieved": achieved, "peak": VALU_PAIR_PEAK, "unit": "pair evaluations/s", "frac": achieved / VALU_PAIR_PEAK,
             "useful_pairs_per_step": useful, "evaluated_pairs_per_step": evaluated,
             "evaluated_over_useful": evaluated / max(1, useful),
+            "evaluated_pairs_of_a_query_that_makes_lists": first if dwn.keep_lists > 1 else None,
             "frac_counting_evaluated_pairs": evaluated / chain_s / VALU_PAIR_PEAK,
-            "note": "per step CHAIN (neighbour query, step + grid binning, WLS fallback pass), not per query launch: the query is "
-                    "~30 of its ~45 us (profiles/r05_c5_*); peak = 1 024 SIMDs x 2.4 GHz x 64 lanes / 69.6 cycles per 64 pairs "
+            "note": "per step CHAIN (neighbour query, step + grid binning or list refresh, WLS fallback pass), not per query launch: the "
+                    "query is ~28 of its ~42 us with kept lists, ~30 of ~46 without (profiles/r06_c5_*); peak = 1 024 SIMDs x 2.4 GHz x 64 lanes / 69.6 cycles per 64 pairs "
                     "(18 full-rate + 2 transcendental instructions per pair; issue costs measured by tools/valubench.hip)"}
 
 
@@ -744,7 +748,7 @@ def measure_variant(torch, local, layout, seed, steps, name, nf, rep, sub, wp, n
                chained="chained" in name, hexa=name.startswith("hexa"),
                mixed=("type_major" if "type_major" in name else name.startswith("mixed")), options=options,
                slab_m=(1024.0 if "lowdensity" in name else 128.0), storage=("caller" if "caller_order" in name else None),
-               dyn=name.startswith("physics_dyn"))
+               dyn=name.startswith("physics_dyn"), dw_keep=(0 if "plain_query" in name else None))
     if "hipgraph" in name:
         f2.n_steps = 1
         f2.use_graph(ns)
@@ -781,6 +785,13 @@ def measure_variant(torch, local, layout, seed, steps, name, nf, rep, sub, wp, n
                                   f"{mt['source']}); hbm_frac_budgeted on the budget")
     if "mirrored_neighbour" in name:
         e["exchange"] = exchange_report(f2, None, "cpu", steps=20)
+    if name.startswith("config5") and f2.env._downwash is not None:
+        dwn = f2.env._downwash
+        q = f2.env.ctx.query
+        from dronesim_amd import _native as nat
+        reuses = q(nat.QUERY_DW_REUSES)
+        e["kept_lists"] = {"one_query_in": dwn.keep_lists, "skin_m": dwn.keep_skin, "queries_answered_from_lists": reuses,
+                           "mean_drones_outside_the_skin": (q(nat.QUERY_DW_MOVERS) / reuses) if reuses else None} if dwn.keep_lists > 1 else None
     if name.startswith("config5") and "mirrored" not in name:
         try:
             e["roofline"] = valu_roofline(torch, f2, d2 / (k2 * reg))
@@ -921,14 +932,15 @@ def main(argv=None):
         # the interleaved fleet is STORED type-major behind the caller's numbering (fleet.StorageOrder): one single-type
         # launch per type; + 4 B per drone-step for the caller's index that keys the noise stream
         mixed_k = "k_step_runs (type-major storage behind the caller's interleaved order, all runs in one launch)"
-    kernel = {"config5": f"k_dw_query_cell, {mixed_k} (+ fused grid binning), k_wls_fallback",
+    kernel = {"config5": f"k_dw_query_kept (kept lists; k_dw_query_cell one step in {os.environ.get('DSIM_DW_KEEP', '32')}), {mixed_k} "
+                         "(+ the lists' refresh / grid binning), k_wls_fallback",
               "hexa": "k_step_hexa (+ k_wls_fallback)",
               "mixed": f"{mixed_k} (+ k_wls_fallback)",
               "mixed_type_major": "k_step_run x2 (+ k_wls_fallback)",
               "dyn": "k_dyn (Physics.DYN: BaseAviary._dynamics + INDI)",
               "two_call_loop": ("k_physics_fast (observation fused) + k_control_fast" if tck == "quad" else
                                 "k_dyn (Env.step on Physics.DYN, observation fused) + k_control_fast" if tck == "dyn" else
-                                ("k_dw_query_cell, " if tck == "config5" else "") +
+                                ("k_dw_query_kept / k_dw_query_cell, " if tck == "config5" else "") +
                                 "k_physics_runs (observation fused) + k_control_runs (+ k_wls_fallback)")}.get(a.workload, "k_step_fast")
     achieved = fl.n * bytes_per / launch_s / 1e9
     rank_rows = gather_ranks(dist, red_dev, [dev_s_local / steps_timed * 1e6, wall_local / steps_timed * 1e6,
@@ -1049,6 +1061,8 @@ def main(argv=None):
                     # configs[4] shard at the config's density (128 m slab), and the round-1 definition of the same
                     # line (the 65 536 drones spread over the whole 1024 m box: an eighth of the density)
                     "config5_shard_65536_mixed_downwash": (65536, 1, 1, False, 1),
+                    # ... with the neighbour query made from scratch every step (downwash_keep = 0: what every round up to 5 measured)
+                    "config5_shard_65536_plain_query_every_step": (65536, 1, 1, False, 1),
                     "config5_lowdensity_r01_definition": (65536, 1, 1, False, 1),
                     # the same shard with a neighbour to exchange positions with — a SYNTHETIC one on this one GPU: the
                     # rank's own reflection across the slab edge (MirrorDist: the wire is two small device ops).  What the
@@ -1077,8 +1091,9 @@ def main(argv=None):
                 also[name] = measure_variant(torch, local, a.layout, a.noise_seed, a.steps, name, *spec, options=options)
                 if name.startswith("config5"):
                     also[name]["note"] = ("a chain of three dependent launches on a 65 536-drone shard (neighbour query, step + grid "
-                                          "binning, WLS fallback): bound by the vector pipe of the query and by launch latency, not by "
-                                          "HBM — its roofline is `roofline` (bound: valu); hbm_frac is kept for comparison with earlier rounds")
+                                          "binning or list refresh, WLS fallback): bound by the vector pipe of the query and by launch "
+                                          "latency, not by HBM — its roofline is `roofline` (bound: valu); hbm_frac is kept for "
+                                          "comparison with earlier rounds")
                 if "mirrored_neighbour" in name:
                     also[name]["note"] = ("the shard above + the halo exchange with a synthetic neighbour (its own reflection): "
                                           "k_halo_pack, a device-side wire, halo binning, one-grid query, step, fallback on one stream")

@@ -314,8 +314,9 @@ typedef struct dsim_step_args {
   float*  obs_out;
   /* -- neighbour grid for the NEXT Env.step (dsim_step only) --------------------------------------------------------
    * nullable: the grid description of the next dsim_downwash call.  The step kernel then appends the NEW position of
-   * every local drone to its cell's bucket while the position is still in registers, and that dsim_downwash call
-   * (same workspace and shape, args->prebinned = 1) skips the binning launch for the local drones.  Honoured on the
+   * every local drone to its cell's bucket while the position is still in registers (or, when that call will re-use kept
+   * candidate lists — its keep field says DSIM_DW_KEEP_REUSE —, refreshes the drone's bucket entry in place), and that
+   * dsim_downwash call (same workspace and shape, args->prebinned = 1) skips the binning launch for the local drones.  Honoured on the
    * bucket form of the grid only (dsim_downwash_prebin_ok() != 0); otherwise ignored.                                */
   const struct dsim_downwash_args* bin_next;
   /* -- storage order --------------------------------------------------------------------------------------------------
@@ -477,14 +478,14 @@ typedef struct dsim_downwash_args {
    * A fleet moves centimetres per Env.step, so WHICH candidates the receivers of a cell have to look at changes slowly.
    * DSIM_DW_KEEP_BUILD: the query also writes, per cell, the list it worked out (receivers in height order, candidates in
    * height-band order), with its reach and band tests widened by 2 keep_skin.  DSIM_DW_KEEP_REUSE: the query reads the lists of
-   * the last BUILD call on this grid, gathers the CURRENT positions and goes straight to the pair loops; nothing is binned — a
-   * dsim_step that is given this block as bin_next refreshes the positions instead (and saves the atomic round trip for a bucket
-   * slot).  EXACT for any motion: every pair is still tested against the cut-off and the height order on current positions;
+   * the last BUILD call on this grid and the CURRENT positions and goes straight to the pair loops; nothing is binned — a
+   * dsim_step that is given this block as bin_next refreshes every drone's position in the grid's buckets IN PLACE instead (no
+   * atomic round trip for a bucket slot); a call that finds no such step in front of it refreshes them itself.  EXACT for any motion: every pair is still tested against the cut-off and the height order on current positions;
    * a drone that has moved further than keep_skin from where it was at the BUILD leaves the lists for the overflow list, which
    * every receiver scans, and is served where it is now.  How often to BUILD is the caller's choice (performance only: the
    * more drones have left the skin, the longer the overflow scan).  Honoured where dsim_downwash_keep_ok() != 0 (the world is
    * this fleet alone: pos_all = NULL, no halo plan; bucket form at a density that takes the banded query; cells of
-   * 5 m + keep_skin or more, so that two rings of cells cover the widened reach), otherwise ignored; a REUSE without usable
+   * 5 m + keep_skin or more — two rings of cells cover the widened reach — and below 10 m), otherwise ignored; a REUSE without usable
    * lists (none made yet, another grid or fleet size) is answered as a BUILD.  keep_ws: caller-owned,
    * dsim_downwash_keep_workspace(n_pad, nx, ny) int32 entries, owned by the library between a BUILD and the last REUSE. */
   int32_t  keep;            /* DSIM_DW_KEEP_* */

@@ -2,7 +2,7 @@
 """What each launch of config 5's chain costs IN the chain (dev helper): the 65 536-drone shard stepped (a) as the product does
 (query, step + grid binning, WLS fallback pass), (b) with the fallback pass left out (DSIM_OPT_DEFER_FALLBACK and nobody
 launching it: timing only — the queue is empty in this hover workload, so results do not change), (c) the fallback pass alone,
-back to back, (d) with Env.step and computeControl as separate launches.  usage: python tools/c5_chain_probe.py [steps [lib]]"""
+back to back, (d) with Env.step and computeControl as separate launches — in front of them the chain with kept candidate lists (the default).  usage: python tools/c5_chain_probe.py [steps [lib]]"""
 import ctypes
 import os
 import sys
@@ -33,9 +33,17 @@ def main():
     k = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     if len(sys.argv) > 2:
         nat.load(sys.argv[2])                      # an A/B build of the same ABI
-    fl = bench.Fleet(65536, 1, 0, 1, "tile64", 1, config5=True)
+    fk = bench.Fleet(65536, 1, 0, 1, "tile64", 1, config5=True)                   # the default: kept candidate lists
+    print("chain, as the product steps it          %.2f us   (kept lists: one query in %d makes them, skin %.2f m)"
+          % (timed(fk.step, k), fk.env._downwash.keep_lists, fk.env._downwash.keep_skin))
+    r = fk.env.ctx.query(nat.QUERY_DW_REUSES)
+    print("   queries answered from the lists %d, mean drones outside the skin %.1f" % (r, fk.env.ctx.query(nat.QUERY_DW_MOVERS) / max(r, 1)))
+    fk.env.close()
+    del fk
+    # everything below: the neighbour query made from scratch every step (downwash_keep = 0), as rounds 1-5 stepped it
+    fl = bench.Fleet(65536, 1, 0, 1, "tile64", 1, config5=True, dw_keep=0)
     env = fl.env
-    print("chain, as the product steps it          %.2f us" % timed(fl.step, k))
+    print("chain with a plain query every step     %.2f us" % timed(fl.step, k))
     env._tuning |= nat.OPT_DEFER_FALLBACK          # the step no longer launches the pass (and this probe does not either)
     env._fused_plan_dw = None
     print("chain without the fallback launch       %.2f us" % timed(fl.step, k))
