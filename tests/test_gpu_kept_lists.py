@@ -237,3 +237,92 @@ def test_keep_is_ignored_where_the_lists_do_not_apply(gpu):
         _check(f"kept lists sparse {k}", dw, st, types, tid, pos, n)
     assert _reuses(nat, ctx) == (0, 0) and dw._last.keep == nat.DW_KEEP_OFF
     ctx.close()
+
+
+def _sequence(gpu, keep, storage):
+    """an env driven through everything that can happen between two queries: fused steps, the two-call loop's Env.step, a host
+    write to the state, a reset — the downwash force checked against the brute-force oracle after each, the states returned"""
+    from dronesim_amd.envs import CtrlAviary, Physics
+    from dronesim_amd.fleet import Targets
+    nat = gpu[0]
+    n = 2048
+    rng = np.random.default_rng(91)
+    xyz = np.stack([rng.uniform(0, 45, n), rng.uniform(0, 45, n), rng.uniform(0.5, 12, n)], 1)
+    tid = (np.arange(n) % 2).astype(np.uint8)
+    env = CtrlAviary(["robobee", "hexa_6DOF"], n, initial_xyzs=xyz, physics=Physics.PYB_DW, noise_seed=5, dict_io=False,
+                     type_ids=tid, downwash_keep=keep, storage=storage)
+    tg = Targets(env.ctx, n); tg.set(pos=f32(xyz).T, yaw=0.1)
+    O = orc.Oracle(env.types)
+    states = []
+
+    def check(label):
+        f = env._downwash.compute()[2, :n]
+        f = (f if env.order is None else env.order.to_caller(f, 0)).cpu().numpy()          # (the force is per storage slot)
+        r = env.state.rigid_aos()
+        ref = O.downwash(r, r[:, 0:3], type_id=tid)
+        assert_downwash(f"kept lists sequence[{keep},{storage}]: {label}", f, ref, env.types, tid, r[:, 0:3], r[:, 0:3])
+        states.append(r.copy())
+
+    for _ in range(3):
+        env.step_fused(tg)
+    check("fused steps")
+    check("two queries in a row")
+    env.step_fused(tg); env.step_fused(tg)
+    cmd = torch.full((n, 6), 0.45, device=env.ctx.device)
+    for _ in range(3):
+        env.step(cmd)                                                                      # Env.step of the two-call loop
+    check("Env.step")
+    env.step_fused(tg)
+    moved = env.state.fields(0, 3).clone(); moved[0] += 2.5; moved[2] = moved[2].flip(0)
+    env.state.set_fields(0, moved)                                                         # a host write behind the lists
+    check("host write")
+    for _ in range(2):
+        env.step_fused(tg)
+    env.reset()
+    check("reset")
+    for _ in range(5):
+        env.step_fused(tg)
+    check("flight after the reset")
+    stats = (env.ctx.query(nat.QUERY_DW_REUSES), env.ctx.query(nat.QUERY_DW_MOVERS))
+    env.close()
+    return states, stats
+
+
+@pytest.mark.parametrize("storage", ["auto", "caller"])
+def test_everything_that_can_happen_between_two_queries(gpu, storage):
+    ref, s0 = _sequence(gpu, 0, storage)
+    got, s1 = _sequence(gpu, 4, storage)
+    assert s0[0] == 0 and s1[0] >= 10
+    for a, b in zip(ref, got):
+        np.testing.assert_allclose(b[:, 0:3], a[:, 0:3], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(b[:, 7:10], a[:, 7:10], rtol=1e-4, atol=1e-4)
+
+
+def test_the_library_answers_a_reuse_it_cannot_serve_as_a_build(gpu):
+    """REUSE is a request: without lists of this very grid (none made yet, forgotten by dsim_downwash_reset, another buffer) the call is
+    answered as a BUILD; with a buffer too small for the lists, as a plain query.  Same force every time."""
+    n, side = 5200, 80.0
+    nat, ctx, st, dw, types, tid, rigid, rng = _setup(gpu, n, side, 46)
+    pos = f32(rigid[:, 0:3])
+    _check("kept lists requests: build", dw, st, types, tid, pos, n)
+    a = dw._last
+    assert a.keep == nat.DW_KEEP_REUSE
+    nat.check(ctx.lib.dsim_downwash_reset(ctx.handle))                                    # the library forgets its lists
+    pos = f32(pos + rng.uniform(-0.05, 0.05, pos.shape))
+    _check("kept lists requests: reuse after a reset", dw, st, types, tid, pos, n)
+    assert _reuses(nat, ctx)[0] == 0                                                      # ... it was a BUILD
+    pos = f32(pos + rng.uniform(-0.05, 0.05, pos.shape))
+    _check("kept lists requests: reuse", dw, st, types, tid, pos, n)
+    assert _reuses(nat, ctx)[0] == 1
+    keep_ws = dw._keep_ws
+    dw._keep_ws = torch.empty_like(keep_ws)                                               # another buffer: not where the lists are
+    a.keep_ws = dw._keep_ws.data_ptr()
+    pos = f32(pos + rng.uniform(-0.05, 0.05, pos.shape))
+    _check("kept lists requests: reuse from another buffer", dw, st, types, tid, pos, n)
+    assert _reuses(nat, ctx)[0] == 1
+    a.keep_ws_len = 1000                                                                  # too small: a plain query
+    a.keep = nat.DW_KEEP_REUSE
+    pos = f32(pos + rng.uniform(-0.05, 0.05, pos.shape))
+    _check("kept lists requests: buffer too small", dw, st, types, tid, pos, n)
+    assert _reuses(nat, ctx)[0] == 1
+    ctx.close()
