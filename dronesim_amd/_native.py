@@ -20,7 +20,7 @@ EXPORTS = (
     "dsim_counter_add", "dsim_reserve", "dsim_observe", "dsim_observe_soa", "dsim_query", "dsim_downwash",
     "dsim_downwash_workspace", "dsim_downwash_prebin_ok", "dsim_downwash_reset", "dsim_adjacency", "dsim_wls_fallback", "dsim_fleet_bounds",
     "dsim_halo_pack", "dsim_downwash_workspace_halo", "dsim_dev_alloc", "dsim_dev_free", "dsim_noise_draw",
-    "dsim_downwash_keep_workspace", "dsim_downwash_keep_ok",
+    "dsim_downwash_keep_workspace", "dsim_downwash_keep_ok", "dsim_downwash_keep_stats",
 )
 
 ABI_VERSION = 9
@@ -190,6 +190,7 @@ def load(path: str = None) -> ctypes.CDLL:
     lib.dsim_downwash_keep_workspace.restype = ctypes.c_int64
     lib.dsim_downwash_keep_workspace.argtypes = [i64, i32, i32]
     lib.dsim_downwash_keep_ok.argtypes = [i64, i32, i32, ctypes.c_float, ctypes.c_float]
+    lib.dsim_downwash_keep_stats.argtypes = [vp] + [ctypes.POINTER(ctypes.c_int64)] * 4
     if lib.dsim_abi_version() != ABI_VERSION:
         raise ImportError(f"libdronesim_amd.so ABI {lib.dsim_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

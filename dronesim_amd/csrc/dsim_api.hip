@@ -496,7 +496,7 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
   c->d_fb = nullptr; c->fb_cap = 0; c->dw_ws = nullptr; c->dw_cells = 0; c->dw_parity = 0; c->dw_mode = 0;
   c->n_cu = 256; c->dw_prebin = false; c->dw_prebin_valid = false; c->dw_prebin_n = 0; c->dw_prebin_off = 0;
   c->dw_prebin_geo[0] = c->dw_prebin_geo[1] = c->dw_prebin_geo[2] = 0.0f;
-  c->dw_prebin_nx = c->dw_prebin_ny = 0; c->dw_local_m = 0; c->dw_prebin_kind = 0; c->dw_reuses = 0; c->dw_keep_ws = nullptr; c->dw_keep_cells = c->dw_keep_n = 0;
+  c->dw_prebin_nx = c->dw_prebin_ny = 0; c->dw_local_m = 0; c->dw_prebin_kind = 0; c->dw_reuses = 0; c->h_keep_fb = nullptr; c->d_keep_fb = nullptr; c->dw_keep_ws = nullptr; c->dw_keep_cells = c->dw_keep_n = 0;
   c->dw_keep_geo[0] = c->dw_keep_geo[1] = c->dw_keep_geo[2] = c->dw_keep_geo[3] = 0.0f; c->dw_keep_nx = c->dw_keep_ny = 0; c->dwh_parity = 0; c->dwh_ws = nullptr; c->dwh_cells = 0;
   c->d_bounds = nullptr;
   c->d_block_map = nullptr; c->h_block_map = nullptr; c->block_map_cap = 0; c->block_map_blocks = 0; c->block_map_runs = 0;
@@ -511,6 +511,18 @@ int dsim_create(dsim_ctx** out, int device, const dsim_type_params* types, int n
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * (8 + DSIM_GROUND_SHARDS));
   if (e == hipSuccess) e = hipMemset(c->d_counters, 0, sizeof(unsigned long long) * (8 + DSIM_GROUND_SHARDS));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_bounds, sizeof(unsigned) * 8);
+  if (e == hipSuccess) {
+    // two ints of host memory the REUSE queries of the neighbour downwash report into (dsim_downwash_keep_stats): best effort —
+    // without it the statistics read as "nothing known"
+    void* hp = nullptr;
+    void* dp = nullptr;
+    if (hipHostMalloc(&hp, 4 * sizeof(int), hipHostMallocMapped) == hipSuccess) {
+      memset(hp, 0, 4 * sizeof(int));
+      if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) { c->h_keep_fb = (volatile int*)hp; c->d_keep_fb = (int*)dp; }
+      else (void)hipHostFree(hp);
+    }
+    (void)hipGetLastError();
+  }
   if (e == hipSuccess) {
     const unsigned init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u};     // min keys, max keys, ticket
     e = hipMemcpy(c->d_bounds, init, sizeof(init), hipMemcpyHostToDevice);
@@ -531,6 +543,7 @@ int dsim_destroy(dsim_ctx* ctx) {
   hipError_t e = hipFree(ctx->d_types);
   (void)hipFree(ctx->d_counters);
   (void)hipFree(ctx->d_bounds);
+  if (ctx->h_keep_fb) (void)hipHostFree((void*)ctx->h_keep_fb);
   if (ctx->d_fb) (void)hipFree(ctx->d_fb);
   if (ctx->d_block_map) (void)hipFree(ctx->d_block_map);
   free(ctx->h_block_map);

@@ -676,7 +676,10 @@ __global__ __launch_bounds__(TPB, 7) void k_dw_query_kept(DwK a, BinK b, KeepK k
   if ((int)t >= TPB - a.n_types) {
     coef[cty][0] = c_dw0 * (0.25f * c_pr) * (0.25f * c_pr); coef[cty][1] = c_dw1; coef[cty][2] = c_dw2;
   }
-  if (blockIdx.x == 0 && t == 0 && n_ovf > 0) atomicAdd(&kp.counters[5], (unsigned long long)n_ovf);      // DSIM_Q_DW_MOVERS
+  if (blockIdx.x == 0 && t == 0) {
+    if (n_ovf > 0) atomicAdd(&kp.counters[5], (unsigned long long)n_ovf);                // DSIM_Q_DW_MOVERS
+    if (kp.feedback) { kp.feedback[0] = n_ovf; kp.feedback[2] = b.count[ncells + 5]; kp.feedback[1] = kp.seq; }   // (host memory: dsim_downwash_keep_stats)
+  }
   const bool banded = (flags & 1) != 0;
   const int nfills = (!banded && total > DW_KEPT_CHUNK) ? (total + DW_KEPT_CHUNK - 1) / DW_KEPT_CHUNK : 1;
   // ---- the MOVERS (the overflow list: drones that have left the skin), looked at by one wave.  As CANDIDATES they matter to this
@@ -1167,6 +1170,7 @@ static void keep_layout(const dsim_downwash_args* g, int64_t n_pad, KeepK* kp) {
   kp->lists = (int*)(kp->pbuild + n_pad);
   kp->skin = g->keep_skin;
   kp->counters = nullptr;
+  kp->feedback = nullptr; kp->seq = 0;
 }
 
 // dsim_step_args.bin_next: the step kernel fills the bucket grid of the next dsim_downwash call.  Only when that grid
@@ -1374,6 +1378,17 @@ int64_t dsim_downwash_keep_workspace(int64_t n_pad, int32_t nx, int32_t ny) {
   return 4 + 4 * n_pad + (int64_t)nx * ny * DW_LSTRIDE;        // alignment slack | pbuild: float4 [n_pad] | the lists
 }
 
+int dsim_downwash_keep_stats(dsim_ctx* ctx, int64_t* outside_skin, int64_t* half_way, int64_t* of_query, int64_t* queries) {
+  if (!ctx || !outside_skin || !half_way || !of_query || !queries) return DSIM_E_ARG;
+  *queries = ctx->dw_reuses;
+  *outside_skin = -1; *half_way = -1; *of_query = 0;
+  if (ctx->h_keep_fb) {           // (loads of host memory the device writes: no synchronisation; the triple may be torn by one query)
+    const int q = ctx->h_keep_fb[1];
+    *outside_skin = ctx->h_keep_fb[0]; *half_way = ctx->h_keep_fb[2]; *of_query = q;
+  }
+  return DSIM_OK;
+}
+
 int dsim_downwash_keep_ok(int64_t m, int32_t nx, int32_t ny, float cell, float keep_skin) {
   return keep_shape_ok(m, nx, ny, cell, keep_skin) ? 1 : 0;
 }
@@ -1478,6 +1493,7 @@ int dsim_downwash(dsim_ctx* ctx, void* stream, int64_t n, dsim_view state, const
       if (a.keep_mode == DSIM_DW_KEEP_REUSE) {
         kp.counters = ctx->d_counters;
         ++ctx->dw_reuses;
+        kp.feedback = ctx->d_keep_fb; kp.seq = (int)(ctx->dw_reuses & 0x7fffffff);
         hipLaunchKernelGGL((k_dw_query_kept<128>), dim3((unsigned)ncells), dim3(128), 0, st_, a, b, kp);
       }
       else {

@@ -68,6 +68,8 @@ struct dsim_ctx {
   float dw_keep_geo[4];                   // xmin, ymin, cell, skin
   int dw_keep_nx, dw_keep_ny;
   long long dw_reuses;                    // DSIM_Q_DW_REUSES
+  volatile int* h_keep_fb;                // host memory the device writes into (mapped): [0] overflow length the last finished REUSE query saw, [1] which query
+  int* d_keep_fb;                         // ... as the device addresses it (null: no feedback)
   int dwh_parity;                         // halo grid (split-phase downwash): count-buffer parity
   const int32_t* dwh_ws;                  // ... and the workspace / shape it was zeroed for
   long long dwh_cells;
@@ -111,7 +113,8 @@ __device__ __forceinline__ unsigned kv_lane(const KView& v, unsigned t) {
 #define DW_CUTOFF 10.0f
 // ints behind the per-cell counts of a bucket grid's count buffer: [0] overflow length; [1..4] the cell range that holds
 // entries, as maxima so that an all-zero buffer is the neutral element: nx-1-cx_min, cx_max, ny-1-cy_min, cy_max (kept by
-// the halo binning only: the halo pass of the query leaves at once where no halo entry can be in reach); [5] spare
+// the halo binning only: the halo pass of the query leaves at once where no halo entry can be in reach); [5] kept lists: the
+// drones a refresh found more than half the skin from where they were when the lists were made
 #define DW_CNT_EXTRA 6
 struct BinK {
   int* count;          // [ncells + DW_CNT_EXTRA]: entries per cell, then the extras above.  null = no binning
@@ -152,12 +155,19 @@ struct KeepK {
   float4* pbuild;           // [n_pad] positions when the lists were made (NaN: never in a list), .w = the drone's bucket slot
   float skin;
   unsigned long long* counters;   // the ctx's diagnostics ([5]: DSIM_Q_DW_MOVERS)
+  int* feedback;                  // nullable, host-mapped: [0] = the overflow length this REUSE query finds, [1] = seq (dsim_downwash_keep_stats)
+  int seq;
 };
 __device__ __forceinline__ void bin_refresh(const BinK& b, float x, float y, float z, long long world_index) {
   const long long i = world_index - b.local_offset;
   const float4 pb = b.pbuild[i];
   const float dx = x - pb.x, dy = y - pb.y, dz = z - pb.z;
-  const bool stay = dx * dx + dy * dy + dz * dz <= b.skin2;            // (NaN anywhere: a mover)
+  const float d2 = dx * dx + dy * dy + dz * dz;
+  const bool stay = d2 <= b.skin2;                                     // (NaN anywhere: a mover)
+  // how many are HALF WAY out: what a host that paces the BUILDs reads before a fleet on the march leaves the skin together
+  // (dsim_downwash_keep_stats; one atomic per wave that has any)
+  const unsigned long long half = __ballot(!(d2 <= 0.25f * b.skin2)), me = 1ULL << __lane_id();
+  if ((half & me) && !(half & (me - 1ULL))) atomicAdd(&b.count[b.nx * b.ny + 5], (int)__popcll(half));
   const int home = __float_as_int(pb.w);
   if (home >= 0) b.buckets[home] = make_float4(x, y, stay ? z : -__builtin_inff(), __int_as_float((int)world_index));
   if (!stay) b.overflow[atomicAdd(&b.count[b.nx * b.ny], 1)] = make_float4(x, y, z, __int_as_float((int)world_index));

@@ -27,6 +27,7 @@ import torch
 from . import _native as nat
 
 CUTOFF = 10.0     # BaseAviary.py:1752: "Ignore drones more than 10 meters away"
+KEEP_RUN_AHEAD = 12   # kept candidate lists: list-served queries the host may be ahead of the device (Downwash._keep_next)
 
 
 def shard_counts(n_local: int, dist=None):
@@ -337,7 +338,7 @@ class Downwash:
 
     def __init__(self, ctx, state, type_id: Optional[torch.Tensor] = None, dist=None, cell: Optional[float] = None,
                  box_refresh: int = 256, halo: Optional[HaloPlan] = None, split: Optional[bool] = None,
-                 keep_lists: int = 0, keep_skin: float = 0.1):
+                 keep_lists: int = 0, keep_skin: float = 0.1, keep_movers: int = 48):
         # cell = None: 5 m cells (half the cut-off, 5 x 5 cells scanned per drone: 30 % fewer candidate pairs than
         # 3 x 3 cells of 10 m) whenever the world's shape takes the bucket form of the grid, 10 m cells otherwise
         self.ctx, self.state, self.type_id, self.dist = ctx, state, type_id, dist
@@ -368,6 +369,16 @@ class Downwash:
             self.cell = 0.5 * CUTOFF + self.keep_skin          # two rings of cells cover the reach widened by twice the skin
         self._keep_ws = None
         self._keep_age = 0               # queries since the last BUILD
+        # Pacing.  The lists serve a fleet that HOVERS for keep_lists queries; one in coordinated motion leaves any skin within a few
+        # steps, every drone joins the overflow list and a REUSE costs many times a BUILD.  The device reports how long that list
+        # was and how many drones were half way out (dsim_downwash_keep_stats: host memory it writes, nothing synchronises); above
+        # keep_movers (or with a sixteenth of the fleet half way out) the next query BUILDs and the period shrinks to what the fleet's
+        # motion allows, growing back a quarter at a time; a period below 3 suspends the lists.
+        self.keep_movers = int(keep_movers)
+        self._keep_period = self.keep_lists
+        self._keep_seq0 = 0              # REUSE queries enqueued before the last BUILD: later readings are about ITS lists
+        self._keep_off = 0               # > 0: plain queries for that many calls, then another try
+        self._keep_stats = (ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64())
 
     def _grid_box(self, wp, lo_hi=None):
         """Bounding box of the world in xy -> grid.  Drones that later leave the box are clamped to
@@ -509,13 +520,54 @@ class Downwash:
         self._prebin_version = None
         nat.check(self.ctx.lib.dsim_downwash(self.ctx.handle, self.ctx.stream_ptr(), self.state.n, view, ref,
                                              self.force.data_ptr()))
-        if a.keep != nat.DW_KEEP_OFF:
-            # what the NEXT query of this grid will be — known now, because the step in between has to be told (bin_next: it
-            # refreshes the lists' positions in front of a REUSE and bins in front of a BUILD)
-            self._keep_age = 0 if a.keep == nat.DW_KEEP_BUILD else self._keep_age + 1
-            a.keep = nat.DW_KEEP_BUILD if self._keep_age + 1 >= self.keep_lists else nat.DW_KEEP_REUSE
+        if a.keep_ws:
+            self._keep_next(a)
         self._last = a
         return self.force
+
+    def _keep_next(self, a) -> None:
+        """What the NEXT query of this grid will be — decided now, because the step in between has to be told (bin_next: it refreshes
+        the lists' positions in front of a REUSE and bins in front of a BUILD or a plain query).
+
+        The device's reports are as old as the host is ahead of it, and a fleet that starts to march leaves the skin within a handful
+        of steps: the host therefore stays at most KEEP_RUN_AHEAD list-served queries ahead of the device while lists are in use (it
+        polls the report's sequence number; nothing is synchronised, and 12 queued steps are half a millisecond of device work), a
+        period that proved too long is remembered, and it grows back only while the reports are fresh."""
+        if self._keep_off > 0:                           # suspended: plain queries, then another try with a short period
+            self._keep_off -= 1
+            a.keep = nat.DW_KEEP_OFF if self._keep_off > 0 else nat.DW_KEEP_BUILD
+            return
+        out, half, ofq, q = self._keep_stats
+        stats = self.ctx.lib.dsim_downwash_keep_stats
+        refs = (ctypes.byref(out), ctypes.byref(half), ctypes.byref(ofq), ctypes.byref(q))
+        stats(self.ctx.handle, *refs)
+        spins = 0
+        while out.value >= 0 and q.value - ofq.value > KEEP_RUN_AHEAD:
+            spins += 1
+            if spins == 64 and self.ctx.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                break                                    # (a capture: nothing runs, nothing will be reported)
+            stats(self.ctx.handle, *refs)
+        if a.keep == nat.DW_KEEP_BUILD:
+            self._keep_age, self._keep_seq0 = 0, q.value
+        else:
+            self._keep_age += 1
+        # (a reading of THESE lists: the overflow list too long already, or a sixteenth of the fleet half way out — at the age the
+        # lists had when it was taken, which is what the period learns)
+        crowded = ofq.value > self._keep_seq0 and (out.value > self.keep_movers or
+                                                  half.value > max(4 * self.keep_movers, self.state.n // 16))
+        if crowded:
+            self._keep_period = max(ofq.value - self._keep_seq0, 1)
+            if self._keep_period < 3:                   # (a BUILD every other query costs more than plain queries do)
+                self._keep_off, self._keep_period = 256, 4
+                a.keep = nat.DW_KEEP_OFF
+                return
+            a.keep = nat.DW_KEEP_BUILD
+        elif self._keep_age + 1 >= self._keep_period:
+            a.keep = nat.DW_KEEP_BUILD
+            if q.value - ofq.value <= 2:                 # (fresh reports: probe a longer period)
+                self._keep_period = min(self.keep_lists, self._keep_period + max(1, self._keep_period // 4))
+        else:
+            a.keep = nat.DW_KEEP_REUSE
 
     def _compute_halo(self) -> torch.Tensor:
         """Spatially sharded fleet: the rest of the world is what the halo plan's peers send (class HaloPlan)."""

@@ -495,6 +495,14 @@ typedef struct dsim_downwash_args {
 } dsim_downwash_args;
 enum { DSIM_DW_KEEP_OFF = 0, DSIM_DW_KEEP_BUILD = 1, DSIM_DW_KEEP_REUSE = 2 };
 int64_t dsim_downwash_keep_workspace(int64_t n_pad, int32_t nx, int32_t ny);
+/* How the lists are holding up, WITHOUT synchronising anything: *queries = the REUSE calls enqueued so far; *outside_skin = the
+ * length of the overflow list that REUSE call number *of_query (1-based; 0: none has finished) found — the drones that had left the
+ * skin, which every later call until the next BUILD will find too, and more; *half_way = the drones the refresh in front of that
+ * call found further than HALF the skin from where they were when the lists were made (the warning: a fleet in coordinated motion
+ * leaves any skin together, and a REUSE call whose overflow list holds the fleet costs a hundred plain ones).  The device writes
+ * the three into host memory when that query starts; a caller that paces its BUILDs by them (dronesim_amd/downwash.py) reads values
+ * a query or two old, which is what such pacing needs.  -1: no feedback memory. */
+int     dsim_downwash_keep_stats(dsim_ctx* ctx, int64_t* outside_skin, int64_t* half_way, int64_t* of_query, int64_t* queries);
 int     dsim_downwash_keep_ok(int64_t m, int32_t nx, int32_t ny, float cell, float keep_skin);
 int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny);
 

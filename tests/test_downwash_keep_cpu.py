@@ -12,6 +12,8 @@ from dronesim_amd.downwash import Downwash
 class _Lib:
     def __init__(self, ok=1):
         self.calls, self.ok = [], ok
+        self.movers = lambda reuses: 3
+        self.half = lambda reuses: 5
 
     def dsim_downwash_prebin_ok(self, m, nx, ny):
         return 1
@@ -25,6 +27,12 @@ class _Lib:
 
     def dsim_downwash_keep_workspace(self, n_pad, nx, ny):
         return 128
+
+    def dsim_downwash_keep_stats(self, handle, out, half, ofq, q):
+        reuses = sum(1 for c in self.calls if c[0] == 2)
+        seen = max(reuses - 1, 0)                                                    # the device is one query behind the host
+        out._obj.value, half._obj.value, ofq._obj.value, q._obj.value = self.movers(seen), self.half(seen), seen, reuses
+        return 0
 
     def dsim_downwash(self, handle, stream, n, view, ref, force):
         a = ref._obj
@@ -95,3 +103,44 @@ def test_off_where_the_shape_or_the_caller_says_so():
     lib, st, dw = _dw(8)
     dw.compute(torch.rand((3, 2000)) * 40.0, local_offset=100)                               # a world given by the caller: plain query
     assert lib.calls[0][0] == 0
+
+
+def test_a_fleet_in_motion_shortens_the_period_and_then_suspends_the_lists():
+    lib, st, dw = _dw(32)
+    since = {"build": 0}
+
+    def movers(reuses):                                  # every drone leaves the skin after six steps
+        return 0 if reuses - since["build"] < 6 else 1600
+    lib.movers = movers
+    kinds = []
+    for k in range(40):
+        dw.compute(); dw.bin_next_ptr()
+        kinds.append(lib.calls[-1][0])
+        if kinds[-1] == 1:
+            since["build"] = sum(1 for c in lib.calls if c[0] == 2)
+    assert kinds[:9] == [1, 2, 2, 2, 2, 2, 2, 2, 1]      # the report of the sixth REUSE is read a query late: the ninth query BUILDs
+    gaps = [j - i for i, j in zip([i for i, k in enumerate(kinds) if k == 1][:-1], [i for i, k in enumerate(kinds) if k == 1][1:])]
+    assert max(gaps[1:]) <= 8 and min(gaps) >= 5         # the period follows the motion
+    lib.movers = lambda reuses: 1600                     # ... and a fleet that leaves the skin at once gets plain queries
+    for k in range(30):
+        dw.compute(); dw.bin_next_ptr()
+    assert [c[0] for c in lib.calls[-8:]] == [0] * 8
+
+
+def test_a_sixteenth_of_the_fleet_half_way_out_builds_before_anybody_has_left():
+    lib, st, dw = _dw(32)
+    since = {"build": 0}
+    lib.half = lambda reuses: 0 if reuses - since["build"] < 3 else 1600           # the whole fleet half way out after three steps
+    kinds = []
+    for k in range(24):
+        dw.compute(); dw.bin_next_ptr()
+        kinds.append(lib.calls[-1][0])
+        if kinds[-1] == 1:
+            since["build"] = sum(1 for c in lib.calls if c[0] == 2)
+    assert kinds[:9] == [1, 2, 2, 2, 2, 1, 2, 2, 1]      # read a query late; the period learns the age of the reading: three
+    assert 0 not in kinds                                                          # a period of three or four is still worth it
+    lib.half = lambda reuses: 60                                                   # a few stragglers: nothing to act on
+    n0 = len(lib.calls)
+    for k in range(40):
+        dw.compute(); dw.bin_next_ptr()
+    assert [c[0] for c in lib.calls[n0:]].count(1) <= 8

@@ -43,7 +43,8 @@ def _setup(gpu, n, side, seed, keep=8, skin=0.25, zmax=20.5, patch=None):
     st.load_aos(rigid, mem)
     tid = (rng.random(n) < 0.5).astype(np.uint8)
     tid_dev = torch.zeros(st.n_pad, dtype=torch.uint8, device=ctx.device); tid_dev[:n] = torch.from_numpy(tid)
-    dw = Downwash(ctx, st, tid_dev, keep_lists=keep, keep_skin=skin)
+    # (keep_movers: the host's pacing of the BUILDs by the device's reports is switched off — these tests say which query does what)
+    dw = Downwash(ctx, st, tid_dev, keep_lists=keep, keep_skin=skin, keep_movers=1 << 30)
     return nat, ctx, st, dw, types, tid, rigid, rng
 
 
@@ -326,3 +327,41 @@ def test_the_library_answers_a_reuse_it_cannot_serve_as_a_build(gpu):
     _check("kept lists requests: buffer too small", dw, st, types, tid, pos, n)
     assert _reuses(nat, ctx)[0] == 1
     ctx.close()
+
+
+def _march(gpu, keep):
+    from dronesim_amd.envs import CtrlAviary, Physics
+    from dronesim_amd.fleet import Targets
+    nat = gpu[0]
+    n = 4096
+    rng = np.random.default_rng(93)
+    xyz = np.stack([rng.uniform(0, 64, n), rng.uniform(0, 64, n), rng.uniform(0.5, 20.5, n)], 1)
+    tid = (np.arange(n) % 2).astype(np.uint8)
+    env = CtrlAviary(["robobee", "hexa_6DOF"], n, initial_xyzs=xyz, physics=Physics.PYB_DW, noise_seed=7, dict_io=False,
+                     type_ids=tid, downwash_keep=keep)
+    vel = torch.zeros((3, n)); vel[0] = 4.0; vel[1] = -1.0                                 # the whole fleet on the march: 2 cm a step
+    env.state.set_fields(7, vel)
+    tg = Targets(env.ctx, n); tg.set(pos=f32(xyz + [3.0, -0.75, 0.0]).T, vel=np.tile(f32([[4.0], [-1.0], [0.0]]), (1, n)), yaw=0.0)
+    kinds = []
+    for k in range(70):
+        env.step_fused(tg)
+        kinds.append(int(env._downwash._last.keep))                                        # (what the NEXT query will be)
+    r = env.state.rigid_aos().copy()
+    stats = (env.ctx.query(nat.QUERY_DW_REUSES), env.ctx.query(nat.QUERY_DW_MOVERS))
+    env.close()
+    return r, stats, kinds
+
+
+def test_a_fleet_on_the_march_paces_its_own_builds(gpu):
+    """Every drone would leave the 0.1 m skin within six steps: the device's report of how many are HALF WAY out (host memory, nothing
+    synchronises; the host stays at most twelve queries ahead of it) makes the host BUILD every few queries instead of the K = 32 it
+    was given — once the period is learnt nobody reaches the overflow list — and the flight is the flight with plain queries."""
+    ref, s0, _ = _march(gpu, 0)
+    got, s1, kinds = _march(gpu, 32)
+    assert s0 == (0, 0)
+    builds = [i for i, k in enumerate(kinds) if k == 1]
+    assert len(builds) >= 5 and max(j - i for i, j in zip(builds[:-1], builds[1:])) <= 20, kinds
+    assert s1[0] >= 30                                                                     # ... and most queries still came from lists
+    assert s1[1] <= 2 * 4096, s1                           # the overflow list held the fleet at most twice (the first time round, before the period was learnt)
+    np.testing.assert_allclose(got[:, 0:3], ref[:, 0:3], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(got[:, 7:10], ref[:, 7:10], rtol=2e-4, atol=2e-4)
