@@ -27,7 +27,7 @@ import torch
 from . import _native as nat
 
 CUTOFF = 10.0     # BaseAviary.py:1752: "Ignore drones more than 10 meters away"
-KEEP_RUN_AHEAD = 12   # kept candidate lists: list-served queries the host may be ahead of the device (Downwash._keep_next)
+KEEP_RUN_AHEAD = 8    # kept candidate lists: list-served queries the host may be ahead of the device (Downwash._keep_next)
 
 
 def shard_counts(n_local: int, dist=None):
@@ -531,7 +531,7 @@ class Downwash:
 
         The device's reports are as old as the host is ahead of it, and a fleet that starts to march leaves the skin within a handful
         of steps: the host therefore stays at most KEEP_RUN_AHEAD list-served queries ahead of the device while lists are in use (it
-        polls the report's sequence number; nothing is synchronised, and 12 queued steps are half a millisecond of device work), a
+        polls the report's sequence number; nothing is synchronised, and 8 queued steps are a third of a millisecond of device work), a
         period that proved too long is remembered, and it grows back only while the reports are fresh."""
         if self._keep_off > 0:                           # suspended: plain queries, then another try with a short period
             self._keep_off -= 1

@@ -354,7 +354,7 @@ def _march(gpu, keep):
 
 def test_a_fleet_on_the_march_paces_its_own_builds(gpu):
     """Every drone would leave the 0.1 m skin within six steps: the device's report of how many are HALF WAY out (host memory, nothing
-    synchronises; the host stays at most twelve queries ahead of it) makes the host BUILD every few queries instead of the K = 32 it
+    synchronises; the host stays at most eight queries ahead of it) makes the host BUILD every few queries instead of the K = 32 it
     was given — once the period is learnt nobody reaches the overflow list — and the flight is the flight with plain queries."""
     ref, s0, _ = _march(gpu, 0)
     got, s1, kinds = _march(gpu, 32)
