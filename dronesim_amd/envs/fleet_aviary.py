@@ -615,6 +615,11 @@ class CtrlAviary(PlacedFleetArrays, FleetObservation):
             if self._dw_substepped():
                 raise NotImplementedError("graph capture with the neighbour-downwash term and several physics sub-steps per "
                                           "Env.step (the term is evaluated per sub-step: step_fused() launches them one by one)")
+            # kept candidate lists pace their BUILDs by what the device reports while it runs; a captured sequence is fixed:
+            # the queries of a graph are made from scratch
+            if dw.keep_lists > 1:
+                dw.keep_lists = 0
+                dw.invalidate_prebin()
         # nothing may allocate under capture: the fallback queue of hexa fleets is reserved up front
         nat.check(self.ctx.lib.dsim_reserve(self.ctx.handle, self.ctx.stream_ptr(), self.state.n_pad))
         self._graph_made = True

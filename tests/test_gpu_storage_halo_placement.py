@@ -631,7 +631,9 @@ def test_graph_replay_of_a_downwash_fleet(gpu, world):
     for _ in range(15):
         A.step_fused(tgts[0])
     B.step_fused(tgts[1])
+    reuses = B.ctx.query(nat.QUERY_DW_REUSES)
     g = B.capture_fused(tgts[1], steps=4)
+    assert B._downwash.keep_lists == 0                          # (a captured sequence is fixed: its queries are made from scratch)
     assert (B._downwash._last is not None) and bool(B.ctx.lib.dsim_downwash_prebin_ok(n, B._downwash._last.nx, B._downwash._last.ny)) == (world == "dense")
     g.replay(); g.replay()                                      # 1 + 8
     B.step_fused(tgts[1])                                       # an ODD number of eager steps in between (the two count
@@ -640,6 +642,7 @@ def test_graph_replay_of_a_downwash_fleet(gpu, world):
     A.step_fused(tgts[0])
     torch.cuda.synchronize()
     assert A._env_steps == B._env_steps == 16
+    assert B.ctx.query(nat.QUERY_DW_REUSES) == reuses and (world != "dense" or A.ctx.query(nat.QUERY_DW_REUSES) > 10)
     sa, sb = A.state.fields(0, 26).cpu().numpy(), B.state.fields(0, 26).cpu().numpy()
     np.testing.assert_allclose(sb, sa, rtol=2e-5, atol=2e-6)
     assert B.ctx.query(nat.QUERY_WLS_FAILURES) == 0
