@@ -290,9 +290,12 @@ class CtrlAviary(PlacedFleetArrays, FleetObservation):
                 raise ValueError(downwash_exchange)
             # downwash_keep = K: one neighbour query in K makes per-cell candidate lists that the other K - 1 re-use on refreshed
             # positions (downwash.Downwash, dsim_downwash_args.keep: exact for any motion; single-rank fleets at a density that takes the
-            # banded query, otherwise ignored).  0 or 1: off.  None: the DSIM_DW_KEEP environment variable, else 32.
+            # banded query, otherwise ignored).  0 or 1: off.  None: the DSIM_DW_KEEP environment variable, else 32 for fleets of up to
+            # 131 072 drones and off beyond: a query from lists that the whole fleet has left is a brute-force one, quadratic in the
+            # fleet (7 ms at 65 536 drones), and although the lists pace their own BUILDs by what the device reports, the first few
+            # queries of a fleet that breaks into motion can be of that kind — tolerable on a shard, not on a million drones.
             if downwash_keep is None:
-                downwash_keep = int(os.environ.get("DSIM_DW_KEEP", "32"))
+                downwash_keep = int(os.environ.get("DSIM_DW_KEEP", "32" if self.NUM_DRONES <= (1 << 17) else "0"))
                 downwash_skin = float(os.environ.get("DSIM_DW_SKIN", downwash_skin))
             self._downwash = Downwash(self.ctx, self.state, self._type_id, dist, halo=halo, split=downwash_split,
                                       keep_lists=downwash_keep if halo is None else 0, keep_skin=downwash_skin)
