@@ -112,6 +112,7 @@ class DownwashArgs(ctypes.Structure):
         ("halo", ctypes.c_void_p),
         ("pairs_evaluated", ctypes.c_void_p),
         ("keep", ctypes.c_int32),
+        ("keep_age", ctypes.c_int32),
         ("keep_skin", ctypes.c_float),
         ("keep_ws", ctypes.c_void_p),
         ("keep_ws_len", ctypes.c_int64),

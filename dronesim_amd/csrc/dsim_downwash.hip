@@ -218,6 +218,7 @@ __global__ __launch_bounds__(TPB) void k_dw_query_cell(DwK a, BinK b, BinK cnd, 
   // 21.6 us on the idlest, 31.5 us on the busiest).  The INTERIOR cells take the first workgroup indices, the ring the last:
   // every CU gets its share of the full cells, and what starts last is what has nothing to do.  (Any order is correct.)
   const int c = dw_block_cell(b, ncells, (int)blockIdx.x);
+  if (KEEP && blockIdx.x == 0 && t < DW_DRIFT_WORDS) kp.drift[t] = t == 17 ? (long long)0xffffffff00000000LL : 0LL;   // (the moving skin starts over: u = 0, r = -1)
   if (accumulate && (int)blockIdx.x < ncells) {
     // halo pass: the cells that hold halo entries span [lo, hi] in each direction (kept by k_dw_bin_halo); a cell further
     // than the neighbourhood's reach from that range has nothing to add — most of a slab's cells: two scalar loads and out
@@ -692,6 +693,17 @@ __global__ __launch_bounds__(TPB, 7) void k_dw_query_kept(DwK a, BinK b, KeepK k
   const float bx0 = cx == 0 ? -__builtin_inff() : b.xmin + (float)cx * cs, bx1 = cx == b.nx - 1 ? __builtin_inff() : b.xmin + (float)(cx + 1) * cs;
   const float by0 = cy == 0 ? -__builtin_inff() : b.ymin + (float)cy * cs, by1 = cy == b.ny - 1 ? __builtin_inff() : b.ymin + (float)(cy + 1) * cs;
   const float RN2 = (DW_CUTOFF + kp.skin + 1e-3f) * (DW_CUTOFF + kp.skin + 1e-3f);
+  // (the skin moves with the fleet, dsim_kernels.h: a mover is binned and tested for reach where the lists would have it)
+  const float* __restrict__ const dh = reinterpret_cast<const float*>(kp.drift + 16);
+  const float ux = dh[0], uy = dh[1];
+  if (blockIdx.x == 0 && t == 0) {           // for the refresh that follows: its sums start from nothing, and where the drift will have the fleet
+    const int r1 = reinterpret_cast<const int*>(kp.drift + 16)[3] + 1;
+    const Drift3 un = drift_predict(kp.drift, r1);
+    float* pn = reinterpret_cast<float*>(kp.drift + 18 + 2 * (r1 & 1));
+    pn[0] = un.x; pn[1] = un.y; pn[2] = un.z;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) kp.drift[4 * (r1 & 3) + k] = 0;
+  }
   auto movers = [&](int pass) {                      // (wave 0)
     if (lane < DW_MOV_TILE) { rty[DW_CAP + lane] = -1; facc[DW_CAP + lane] = 0.0f; }
     int seen = 0, near_n = 0;                        // (uniform)
@@ -701,14 +713,14 @@ __global__ __launch_bounds__(TPB, 7) void k_dw_query_kept(DwK a, BinK b, KeepK k
       const bool valid = k0 + (int)lane < n_ovf;
       const long long i = (long long)__float_as_int(e.w) - a.local_offset;
       if (pass == 0) {
-        const float ox = fmaxf(fmaxf(bx0 - e.x, e.x - bx1), 0.0f), oy = fmaxf(fmaxf(by0 - e.y, e.y - by1), 0.0f);
+        const float ox = fmaxf(fmaxf(bx0 - (e.x - ux), (e.x - ux) - bx1), 0.0f), oy = fmaxf(fmaxf(by0 - (e.y - uy), (e.y - uy) - by1), 0.0f);
         const bool near = valid && ox * ox + oy * oy < RN2;
         const unsigned long long mn = __ballot(near);
         const int at = near_n + (int)__popcll(mn & ((1ULL << lane) - 1ULL));
         if (near && at < DW_MOV_TILE) { tpx[DW_MOV_AT + at] = e.x; tpy[DW_MOV_AT + at] = e.y; tpz[DW_MOV_AT + at] = e.z; }
         near_n += (int)__popcll(mn);
       }
-      const bool here = valid && i >= 0 && i < a.n && bin_cell(b, e.x, e.y) == c;
+      const bool here = valid && i >= 0 && i < a.n && bin_cell(b, e.x - ux, e.y - uy) == c;
       const unsigned long long mh = __ballot(here);
       const int ord = seen + (int)__popcll(mh & ((1ULL << lane) - 1ULL)) - pass * DW_MOV_TILE;
       if (here && ord >= 0 && ord < DW_MOV_TILE) {
@@ -1168,6 +1180,7 @@ static void keep_layout(const dsim_downwash_args* g, int64_t n_pad, KeepK* kp) {
   uintptr_t sp = ((uintptr_t)g->keep_ws + 15) & ~(uintptr_t)15;
   kp->pbuild = (float4*)sp;
   kp->lists = (int*)(kp->pbuild + n_pad);
+  kp->drift = (long long*)(kp->lists + (long long)g->nx * g->ny * DW_LSTRIDE);       // (8-byte aligned: DW_LSTRIDE is even)
   kp->skin = g->keep_skin;
   kp->counters = nullptr;
   kp->feedback = nullptr; kp->seq = 0;
@@ -1198,6 +1211,7 @@ void bin_next_prepare(dsim_ctx* ctx, int64_t n, const dsim_step_args* args, Step
     KeepK kp;
     keep_layout(g, a->n_pad, &kp);
     a->bin.pbuild = kp.pbuild; a->bin.skin2 = g->keep_skin * g->keep_skin;
+    a->bin.drift = kp.drift; a->bin.drift_r = g->keep_age > 0 ? g->keep_age - 1 : 0; a->bin.drift_mask = dw_drift_mask(n);
   }
 }
 
@@ -1333,6 +1347,10 @@ static int grid_build(dsim_ctx* ctx, hipStream_t st_, int64_t n, const dsim_view
         KeepK kp;
         keep_layout(g, state.n_pad, &kp);
         b.pbuild = kp.pbuild; b.skin2 = g->keep_skin * g->keep_skin;
+        b.drift = kp.drift; b.drift_r = g->keep_age > 0 ? g->keep_age - 1 : 0; b.drift_mask = dw_drift_mask(n);
+        // (this refresh's sums start from nothing, whatever a step that is not vouched for has left in their place)
+        hipError_t e = hipMemsetAsync(kp.drift + 4 * (b.drift_r & 3), 0, 4 * sizeof(long long), st_);
+        if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(k_dw_refresh, dim3(grid_for(n)), dim3(256), 0, st_, a, b);
       }
       a_ = a;
@@ -1375,7 +1393,7 @@ int64_t dsim_downwash_workspace(int64_t m, int32_t nx, int32_t ny) {
 
 int64_t dsim_downwash_keep_workspace(int64_t n_pad, int32_t nx, int32_t ny) {
   if (n_pad < 1 || nx < 1 || ny < 1) return -1;
-  return 4 + 4 * n_pad + (int64_t)nx * ny * DW_LSTRIDE;        // alignment slack | pbuild: float4 [n_pad] | the lists
+  return 4 + 4 * n_pad + (int64_t)nx * ny * DW_LSTRIDE + 2 * DW_DRIFT_WORDS;        // alignment slack | pbuild: float4 [n_pad] | the lists | the drift ring
 }
 
 int dsim_downwash_keep_stats(dsim_ctx* ctx, int64_t* outside_skin, int64_t* half_way, int64_t* of_query, int64_t* queries) {

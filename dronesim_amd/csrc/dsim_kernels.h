@@ -131,7 +131,39 @@ struct BinK {
   // they are in NOW.  null = the step bins.
   const float4* pbuild;     // [n_pad] (x, y, z when the lists were made, bucket slot as int bits)
   float skin2;              // skin^2
+  long long* drift;         // the skin moves with the fleet: DW_DRIFT below
+  int drift_r;              // which refresh since the lists were made this is (0: the first)
+  int drift_mask;           // the sample: drones whose index has none of these bits (dw_drift_mask)
 };
+// ---- a skin that moves with the fleet ---------------------------------------------------------------------------------
+// The lists are invariant under a common translation of the fleet: if every drone that stays in them is within the skin of
+// (where it was) + u, ANY u, two of them are within twice the skin of their old relative position — which is all the proof of
+// the lists' completeness uses.  A formation in flight therefore leaves no skin at all if u follows it.  u is the mean displacement
+// of a sample of the fleet (eight to sixteen drones, those inside the skin: integer atomics in 2^-16 m, deterministic — and few,
+// because atomics on one address queue up: every 64th drone of a 65 536-drone shard took the step kernel from 10 to 56 us), predicted one
+// refresh ahead from the last two (2 M[r-1] - M[r-2], M[-1] = 0: nobody has moved when the lists are made) by the query in
+// front of that refresh; the refresh that uses it writes down what it used, and the query that follows reads it there: movers are
+// binned and tested for reach at (position - u), because the cells' lists speak of where their drones WERE.  long longs: a ring of
+// four sums (x, y, z, count) | [16, 18) what the last refresh used (u as three floats, r) | [18, 22) the prediction for even / odd r.
+#define DW_DRIFT_WORDS 22
+#define DW_DRIFT_Q 65536.0f
+struct Drift3 { float x, y, z; };
+static inline int dw_drift_mask(long long n) {          // every 2^k-th drone, 8 .. 16 of them (at least every 64th)
+  long long stride = 64;
+  while (stride * 16 < n) stride <<= 1;
+  return (int)(stride - 1);
+}
+__device__ __forceinline__ Drift3 drift_predict(const long long* __restrict__ ring, int r) {
+  float m[2][3];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const long long* s = ring + 4 * ((r + 3 - k) & 3);          // M[r - 1 - k]
+    const long long cnt = r - 1 - k >= 0 ? s[3] : 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) m[k][c] = cnt > 0 ? (float)((double)s[c] / ((double)DW_DRIFT_Q * (double)cnt)) : 0.0f;
+  }
+  return Drift3{2.0f * m[0][0] - m[1][0], 2.0f * m[0][1] - m[1][1], 2.0f * m[0][2] - m[1][2]};
+}
 // ---- kept candidate lists ----------------------------------------------------------------------------
 // A fleet moves centimetres per Env.step: which candidates a cell's receivers have to look at, and in which height band each lies,
 // changes slowly.  A BUILD query (the banded cell-centred query, with its reach and band tests widened by twice the skin) writes, per
@@ -154,6 +186,7 @@ struct KeepK {
   int* lists;               // [ncells][DW_LSTRIDE]
   float4* pbuild;           // [n_pad] positions when the lists were made (NaN: never in a list), .w = the drone's bucket slot
   float skin;
+  long long* drift;               // [DW_DRIFT_WORDS] the moving skin's sums and what the last refresh used (BinK.drift)
   unsigned long long* counters;   // the ctx's diagnostics ([5]: DSIM_Q_DW_MOVERS)
   int* feedback;                  // nullable, host-mapped: [0] = the overflow length this REUSE query finds, [1] = seq (dsim_downwash_keep_stats)
   int seq;
@@ -161,9 +194,29 @@ struct KeepK {
 __device__ __forceinline__ void bin_refresh(const BinK& b, float x, float y, float z, long long world_index) {
   const long long i = world_index - b.local_offset;
   const float4 pb = b.pbuild[i];
-  const float dx = x - pb.x, dy = y - pb.y, dz = z - pb.z;
+  Drift3 u = Drift3{0.0f, 0.0f, 0.0f};
+  if (b.drift) {
+    const float* __restrict__ const pu = reinterpret_cast<const float*>(b.drift + 18 + 2 * (b.drift_r & 1));
+    u = Drift3{pu[0], pu[1], pu[2]};
+  }
+  const float ax = x - pb.x, ay = y - pb.y, az = z - pb.z;             // how far it has come since the lists were made
+  const float dx = ax - u.x, dy = ay - u.y, dz = az - u.z;             // ... and how far from where the fleet's drift would have it
   const float d2 = dx * dx + dy * dy + dz * dz;
   const bool stay = d2 <= b.skin2;                                     // (NaN anywhere: a mover)
+  if (b.drift) {
+    if (stay && (i & b.drift_mask) == 0) {                             // the sample the NEXT refreshes' drift is made of
+      long long* s = b.drift + 4 * (b.drift_r & 3);
+      atomicAdd((unsigned long long*)&s[0], (unsigned long long)(long long)__float2ll_rn(ax * DW_DRIFT_Q));
+      atomicAdd((unsigned long long*)&s[1], (unsigned long long)(long long)__float2ll_rn(ay * DW_DRIFT_Q));
+      atomicAdd((unsigned long long*)&s[2], (unsigned long long)(long long)__float2ll_rn(az * DW_DRIFT_Q));
+      atomicAdd((unsigned long long*)&s[3], 1ULL);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                         // what this refresh used: the query that follows reads it here
+      float* h = reinterpret_cast<float*>(b.drift + 16);
+      h[0] = u.x; h[1] = u.y; h[2] = u.z;
+      reinterpret_cast<int*>(b.drift + 16)[3] = b.drift_r;
+    }
+  }
   // how many are HALF WAY out: what a host that paces the BUILDs reads before a fleet on the march leaves the skin together
   // (dsim_downwash_keep_stats; one atomic per wave that has any)
   const unsigned long long half = __ballot(!(d2 <= 0.25f * b.skin2)), me = 1ULL << __lane_id();

@@ -522,6 +522,7 @@ class Downwash:
                                              self.force.data_ptr()))
         if a.keep_ws:
             self._keep_next(a)
+            a.keep_age = self._keep_age + 1 if a.keep == nat.DW_KEEP_REUSE else 0      # (which REUSE of these lists the next query is)
         self._last = a
         return self.force
 

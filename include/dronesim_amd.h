@@ -489,6 +489,11 @@ typedef struct dsim_downwash_args {
    * lists (none made yet, another grid or fleet size) is answered as a BUILD.  keep_ws: caller-owned,
    * dsim_downwash_keep_workspace(n_pad, nx, ny) int32 entries, owned by the library between a BUILD and the last REUSE. */
   int32_t  keep;            /* DSIM_DW_KEEP_* */
+  int32_t  keep_age;        /* REUSE: how many REUSE calls the lists have served, this one included (1, 2, ...; the dsim_step that is
+                               given this block as bin_next refreshes for that call).  The skin moves with the fleet — displacements are
+                               measured against the mean drift of a sample of it, predicted from the two refreshes before —, and the
+                               age says which of the ring of sums a refresh fills.  Performance only: a wrong age makes the prediction
+                               worse, never the result (the query reads the drift its refresh used from device memory).             */
   float    keep_skin;       /* metres, > 0 */
   int32_t* keep_ws;
   int64_t  keep_ws_len;

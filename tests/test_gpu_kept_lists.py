@@ -329,7 +329,7 @@ def test_the_library_answers_a_reuse_it_cannot_serve_as_a_build(gpu):
     ctx.close()
 
 
-def _march(gpu, keep):
+def _march(gpu, keep, shear):
     from dronesim_amd.envs import CtrlAviary, Physics
     from dronesim_amd.fleet import Targets
     nat = gpu[0]
@@ -339,9 +339,11 @@ def _march(gpu, keep):
     tid = (np.arange(n) % 2).astype(np.uint8)
     env = CtrlAviary(["robobee", "hexa_6DOF"], n, initial_xyzs=xyz, physics=Physics.PYB_DW, noise_seed=7, dict_io=False,
                      type_ids=tid, downwash_keep=keep)
-    vel = torch.zeros((3, n)); vel[0] = 4.0; vel[1] = -1.0                                 # the whole fleet on the march: 2 cm a step
-    env.state.set_fields(7, vel)
-    tg = Targets(env.ctx, n); tg.set(pos=f32(xyz + [3.0, -0.75, 0.0]).T, vel=np.tile(f32([[4.0], [-1.0], [0.0]]), (1, n)), yaw=0.0)
+    # the whole fleet on the march, 2 cm a step — as one formation, or (shear) every other drone the opposite way: no common drift
+    sign = np.where(np.arange(n) % 2 == 0, 1.0, -1.0) if shear else np.ones(n)
+    v = f32(np.stack([4.0 * sign, -1.0 * sign, np.zeros(n)]))
+    env.state.set_fields(7, torch.from_numpy(v).float())
+    tg = Targets(env.ctx, n); tg.set(pos=f32(xyz + 0.75 * v.T).T, vel=v, yaw=0.0)
     kinds = []
     for k in range(70):
         env.step_fused(tg)
@@ -352,12 +354,26 @@ def _march(gpu, keep):
     return r, stats, kinds
 
 
-def test_a_fleet_on_the_march_paces_its_own_builds(gpu):
-    """Every drone would leave the 0.1 m skin within six steps: the device's report of how many are HALF WAY out (host memory, nothing
-    synchronises; the host stays at most eight queries ahead of it) makes the host BUILD every few queries instead of the K = 32 it
-    was given — once the period is learnt nobody reaches the overflow list — and the flight is the flight with plain queries."""
-    ref, s0, _ = _march(gpu, 0)
-    got, s1, kinds = _march(gpu, 32)
+def test_a_fleet_on_the_march_keeps_its_lists(gpu):
+    """Env-level: the skin moves with the fleet (the drift of a sample of it, predicted a step ahead): 70 steps at 4 m/s — 1.2 m, twelve
+    skins — with the BUILDs the host was given (one query in 32) and next to nobody in the overflow list; the flight is the flight
+    with plain queries."""
+    ref, s0, _ = _march(gpu, 0, False)
+    got, s1, kinds = _march(gpu, 32, False)
+    assert s0 == (0, 0)
+    assert kinds.count(1) <= 3 and s1[0] >= 66, kinds
+    assert s1[1] / s1[0] < 16, s1
+    np.testing.assert_allclose(got[:, 0:3], ref[:, 0:3], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(got[:, 7:10], ref[:, 7:10], rtol=2e-4, atol=2e-4)
+
+
+def test_a_fleet_that_shears_paces_its_own_builds(gpu):
+    """Every other drone flies the opposite way: there is no common drift to follow, every drone would leave the 0.1 m skin within six
+    steps.  The device's report of how many are HALF WAY out (host memory, nothing synchronises; the host stays at most eight queries
+    ahead of it) makes the host BUILD every few queries instead of the K = 32 it was given — once the period is learnt nobody reaches
+    the overflow list — and the flight is the flight with plain queries."""
+    ref, s0, _ = _march(gpu, 0, True)
+    got, s1, kinds = _march(gpu, 32, True)
     assert s0 == (0, 0)
     builds = [i for i, k in enumerate(kinds) if k == 1]
     assert len(builds) >= 5 and max(j - i for i, j in zip(builds[:-1], builds[1:])) <= 20, kinds
@@ -365,3 +381,28 @@ def test_a_fleet_on_the_march_paces_its_own_builds(gpu):
     assert s1[1] <= 2 * 4096, s1                           # the overflow list held the fleet at most twice (the first time round, before the period was learnt)
     np.testing.assert_allclose(got[:, 0:3], ref[:, 0:3], rtol=0, atol=2e-4)
     np.testing.assert_allclose(got[:, 7:10], ref[:, 7:10], rtol=2e-4, atol=2e-4)
+
+
+def test_a_formation_in_flight_leaves_no_skin(gpu):
+    """The skin moves with the fleet: the whole fleet translating at 4 m/s (2 cm a step, the 0.1 m skin six steps wide), a thousand
+    drones of it loitering — the marchers stay in the lists for the whole K = 32, the loiterers drift out of the moving skin into the
+    overflow list, and the force is the brute-force one every step; then the formation stops, turns and flies on."""
+    n, side = 5200, 80.0
+    nat, ctx, st, dw, types, tid, rigid, rng = _setup(gpu, n, side, 47, keep=32, skin=0.1)
+    pos = f32(rigid[:, 0:3])
+    _check("kept lists formation: build", dw, st, types, tid, pos, n)
+    v = np.array([4.0, -1.0, 0.5]) / 240.0
+    lo = np.zeros(n, bool); lo[::50] = True                                              # 104 loiterers
+    for k in range(20):
+        if k == 12:
+            v = np.array([0.0, 0.0, 0.0])                                                 # the formation stops ...
+        if k == 15:
+            v = np.array([-3.0, 2.0, 0.0]) / 240.0                                        # ... and flies on elsewhere
+        pos = pos + np.where(lo[:, None], 0.0, v[None, :]) + rng.uniform(-0.002, 0.002, pos.shape)
+        _check(f"kept lists formation: step {k}", dw, st, types, tid, pos, n)
+    r, m = _reuses(nat, ctx)
+    assert r == 20                                                                        # no BUILD in between
+    # the formation has come 0.26 m and more: without the moving skin every one of its 5 096 drones would have been a mover from
+    # the seventh step on; with it only the loiterers (and the turns' overshoot) are
+    assert m < 20 * 400, m
+    ctx.close()
