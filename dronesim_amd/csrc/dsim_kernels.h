@@ -211,7 +211,7 @@ __device__ __forceinline__ void bin_refresh(const BinK& b, float x, float y, flo
       atomicAdd((unsigned long long*)&s[2], (unsigned long long)(long long)__float2ll_rn(az * DW_DRIFT_Q));
       atomicAdd((unsigned long long*)&s[3], 1ULL);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {                         // what this refresh used: the query that follows reads it here
+    if ((i & b.drift_mask) == 0 || (blockIdx.x == 0 && threadIdx.x == 0)) {   // what this refresh used: the query that follows reads it here (a few threads, the same words)
       float* h = reinterpret_cast<float*>(b.drift + 16);
       h[0] = u.x; h[1] = u.y; h[2] = u.z;
       reinterpret_cast<int*>(b.drift + 16)[3] = b.drift_r;
