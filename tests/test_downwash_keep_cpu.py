@@ -36,7 +36,7 @@ class _Lib:
 
     def dsim_downwash(self, handle, stream, n, view, ref, force):
         a = ref._obj
-        self.calls.append((a.keep, a.prebinned, round(a.keep_skin, 3), a.cell, bool(a.keep_ws)))
+        self.calls.append((a.keep, a.prebinned, round(a.keep_skin, 3), a.cell, bool(a.keep_ws), a.keep_age))
         return 0
 
 
@@ -76,6 +76,7 @@ def test_one_query_in_k_builds_and_the_step_in_between_is_told_what_comes_next()
     assert [c[0] for c in lib.calls] == [1, 2, 2, 2, 1, 2, 2, 2, 1, 2]                       # BUILD, then K - 1 REUSEs
     assert seen == [2, 2, 2, 1, 2, 2, 2, 1, 2, 2]                                            # the NEXT query's kind, known in time
     assert all(c[2] == 0.1 and c[4] for c in lib.calls)
+    assert [c[5] for c in lib.calls] == [0, 1, 2, 3, 0, 1, 2, 3, 0, 1]                       # which REUSE of its lists a query is (the moving skin's ring)
     assert abs(lib.calls[0][3] - 5.1) < 1e-6 and abs(lib.asked[3] - 5.1) < 1e-6              # cells of 5 m + the skin
     assert [c[1] for c in lib.calls] == [0] + [1] * 9                                        # the step vouched for every grid but the first
 
