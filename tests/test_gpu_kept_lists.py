@@ -406,3 +406,31 @@ def test_a_formation_in_flight_leaves_no_skin(gpu):
     # the seventh step on; with it only the loiterers (and the turns' overshoot) are
     assert m < 20 * 400, m
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_worlds_random_motions(gpu, seed):
+    """density 0.5 - 1.3 drones per m^2, skins of 0.05 - 0.3 m, a drifting, jittering fleet with stragglers, teleports and the odd NaN:
+    every query of three BUILD periods against the brute-force oracle"""
+    rng0 = np.random.default_rng(1000 + seed)
+    n = int(rng0.integers(3000, 9000))
+    side = float(np.sqrt(n / rng0.uniform(0.5, 1.3)))
+    skin = float(rng0.choice([0.05, 0.1, 0.3]))
+    nat, ctx, st, dw, types, tid, rigid, rng = _setup(gpu, n, side, 2000 + seed, keep=6, skin=skin, zmax=float(rng0.choice([4.0, 20.5])))
+    pos = f32(rigid[:, 0:3])
+    drift = rng0.uniform(-0.6, 0.6, 3) * skin
+    for k in range(17):
+        if k:
+            pos = pos + drift + rng.uniform(-0.25, 0.25, pos.shape) * skin
+            if k % 5 == 2:
+                drift = rng0.uniform(-0.6, 0.6, 3) * skin                                  # the formation turns
+            j = rng.integers(0, n, int(rng0.integers(0, 30)))
+            pos[j, 0:2] = rng.uniform(-5, side + 5, (len(j), 2))                          # teleports, some beyond the grid
+            if k == 7:
+                pos[int(rng0.integers(0, n))] = np.nan
+            if k == 9:
+                pos = np.where(np.isnan(pos), 1.0, pos)
+        _check(f"kept lists random[{seed}] query {k}", dw, st, types, tid, pos, n)
+        pos = f32(pos)
+    assert _reuses(nat, ctx)[0] >= 12 or dw._last.keep == nat.DW_KEEP_OFF                  # (a sparse draw takes the one-wave query: no lists)
+    ctx.close()
